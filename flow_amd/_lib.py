@@ -1,0 +1,125 @@
+"""ctypes binding of libflowsim.so (include/flowsim.h).
+
+The library is the product: if it is missing or cannot be loaded this module
+raises -- there is no Python / CPU fallback for the simulation path.
+"""
+import ctypes as C
+import os
+
+from .utils.exceptions import FatalFlowError
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libflowsim.so")
+
+FS_ABI_VERSION = 1
+FS_MAX_CTRL_PARAMS = 8
+
+# error codes
+FS_OK, FS_ERR_INVALID, FS_ERR_UNSUPPORTED, FS_ERR_HIP, FS_ERR_NOSPACE = 0, -1, -2, -3, -4
+# enum fs_precision
+FS_F32, FS_F64 = 0, 1
+# enum fs_controller
+(FS_CTRL_SIM, FS_CTRL_RL, FS_CTRL_IDM, FS_CTRL_CFM, FS_CTRL_BCM, FS_CTRL_LAC, FS_CTRL_OVM,
+ FS_CTRL_LINEAR_OVM, FS_CTRL_GIPPS, FS_CTRL_FOLLOWER_STOPPER, FS_CTRL_NONLOCAL_FOLLOWER_STOPPER) = range(11)
+# enum fs_failsafe
+FS_FAILSAFE_NONE, FS_FAILSAFE_INSTANTANEOUS, FS_FAILSAFE_SAFE_VELOCITY = range(3)
+# enum fs_env
+FS_ENV_ACCEL, FS_ENV_WAVE_ATTENUATION, FS_ENV_WAVE_ATTENUATION_PO = range(3)
+# enum fs_network / fs_integrator
+FS_NET_RING = 0
+FS_EULER, FS_BALLISTIC = 0, 1
+# enum fs_field
+(FS_FIELD_POS, FS_FIELD_VEL, FS_FIELD_HEADWAY, FS_FIELD_PREV_VEL, FS_FIELD_ACCEL, FS_FIELD_TIME,
+ FS_FIELD_RING_LENGTH, FS_FIELD_INIT_POS, FS_FIELD_INIT_VEL, FS_FIELD_CTRL_STATE) = range(10)
+
+EXPORTS = ["fs_create", "fs_destroy", "fs_last_error", "fs_abi_version", "fs_obs_dim", "fs_set_stream",
+           "fs_sync", "fs_reset", "fs_reset_dev", "fs_step", "fs_step_dev", "fs_rollout_dev",
+           "fs_get_state", "fs_set_state"]
+
+
+class fs_vehicle_spec(C.Structure):
+    _fields_ = [("controller", C.c_int32), ("fail_safe", C.c_int32), ("speed_mode", C.c_int32),
+                ("rl_index", C.c_int32), ("p", C.c_double * FS_MAX_CTRL_PARAMS), ("noise", C.c_double),
+                ("delay", C.c_double), ("max_accel", C.c_double), ("max_decel", C.c_double),
+                ("length", C.c_double), ("sumo_tau", C.c_double), ("sumo_min_gap", C.c_double),
+                ("sumo_max_speed", C.c_double), ("initial_speed", C.c_double)]
+
+
+class fs_config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("abi_version", C.c_uint32), ("precision", C.c_int32),
+                ("network", C.c_int32), ("env", C.c_int32), ("integrator", C.c_int32),
+                ("num_replicas", C.c_int32), ("num_vehicles", C.c_int32), ("num_rl", C.c_int32),
+                ("horizon", C.c_int32), ("warmup_steps", C.c_int32), ("sims_per_step", C.c_int32),
+                ("junction_mode", C.c_int32), ("clip_actions", C.c_int32), ("evaluate", C.c_int32),
+                ("device", C.c_int32), ("track_aux", C.c_int32), ("reserved0", C.c_int32),
+                ("seed", C.c_uint64), ("sim_step", C.c_double), ("slowdown_ramp", C.c_double),
+                ("junction_length", C.c_double), ("crash_gap", C.c_double), ("max_speed", C.c_double),
+                ("target_velocity", C.c_double), ("action_low", C.c_double), ("action_high", C.c_double),
+                ("po_max_length", C.c_double), ("vehicles", C.POINTER(fs_vehicle_spec)),
+                ("ring_length", C.POINTER(C.c_double)), ("init_pos", C.POINTER(C.c_double)),
+                ("init_vel", C.POINTER(C.c_double))]
+
+
+_lib = None
+
+
+def load():
+    """Load libflowsim.so once; raise if it is absent (the HIP path is the only path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FatalFlowError(
+            "libflowsim.so not found at %s: build it with `python -m flow_amd.build` "
+            "(hipcc, gfx950).  flow_amd has no CPU fallback." % LIB_PATH)
+    try:                       # share torch's HIP runtime (same SONAME) when torch is in the process
+        import torch  # noqa: F401
+    except Exception:          # pragma: no cover - torch is optional for the C ABI itself
+        pass
+    lib = C.CDLL(LIB_PATH)
+    h = C.c_void_p
+    f32p, u8p = C.c_void_p, C.c_void_p       # raw addresses: host numpy or device pointers
+    lib.fs_create.argtypes = [C.POINTER(fs_config), C.POINTER(h)]
+    lib.fs_create.restype = C.c_int
+    lib.fs_destroy.argtypes = [h]
+    lib.fs_destroy.restype = None
+    lib.fs_last_error.argtypes = []
+    lib.fs_last_error.restype = C.c_char_p
+    lib.fs_abi_version.argtypes = []
+    lib.fs_abi_version.restype = C.c_int
+    lib.fs_obs_dim.argtypes = [h]
+    lib.fs_obs_dim.restype = C.c_int
+    lib.fs_set_stream.argtypes = [h, C.c_void_p]
+    lib.fs_set_stream.restype = C.c_int
+    lib.fs_sync.argtypes = [h]
+    lib.fs_sync.restype = C.c_int
+    lib.fs_reset.argtypes = [h, u8p, f32p]
+    lib.fs_reset.restype = C.c_int
+    lib.fs_reset_dev.argtypes = [h, u8p, f32p]
+    lib.fs_reset_dev.restype = C.c_int
+    lib.fs_step.argtypes = [h, f32p, f32p, f32p, u8p]
+    lib.fs_step.restype = C.c_int
+    lib.fs_step_dev.argtypes = [h, f32p, f32p, f32p, u8p]
+    lib.fs_step_dev.restype = C.c_int
+    lib.fs_rollout_dev.argtypes = [h, C.c_int, f32p, C.c_size_t, f32p, f32p, u8p, C.c_int]
+    lib.fs_rollout_dev.restype = C.c_int
+    lib.fs_get_state.argtypes = [h, C.c_int, C.c_void_p, C.c_size_t]
+    lib.fs_get_state.restype = C.c_int
+    lib.fs_set_state.argtypes = [h, C.c_int, C.c_void_p, C.c_size_t]
+    lib.fs_set_state.restype = C.c_int
+    if lib.fs_abi_version() != FS_ABI_VERSION:
+        raise FatalFlowError("libflowsim.so ABI %d != binding ABI %d" % (lib.fs_abi_version(), FS_ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    """Map a C return code to the exception type the reference raises at that call point."""
+    if rc == FS_OK:
+        return
+    msg = load().fs_last_error().decode("utf-8", "replace")
+    if rc == FS_ERR_INVALID:
+        raise ValueError(msg)
+    if rc == FS_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise FatalFlowError(msg)          # FS_ERR_HIP, FS_ERR_NOSPACE (network/base.py:603-605)

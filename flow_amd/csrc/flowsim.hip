@@ -1,0 +1,498 @@
+// flowsim.hip -- C ABI (include/flowsim.h) over the gfx950 kernels in
+// flowsim_kernels.h.  Host code only allocates, uploads tables, picks the
+// kernel instantiation and enqueues launches; every number the environment
+// returns is computed on the GPU.  There is no CPU fallback: without a HIP
+// device fs_create fails with FS_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "flowsim.h"
+#include "flowsim_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return fail(FS_ERR_HIP, std::string(#expr) + " failed: " + hipGetErrorString(e_));   \
+  } while (0)
+
+struct SimBase {
+  virtual ~SimBase() {}
+  fs_config cfg{};
+  std::vector<fs_vehicle_spec> veh;
+  int obs_dim = 0;
+  int seg = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  // host-API staging buffers (device)
+  float* d_actions = nullptr;
+  float* d_obs = nullptr;
+  float* d_rew = nullptr;
+  uint8_t* d_done = nullptr;
+  uint8_t* d_mask = nullptr;
+  std::vector<void*> allocs;
+
+  virtual int launch_steps(int num_steps, const uint8_t* mask, const float* actions, size_t act_stride,
+                           float* obs, float* rew, uint8_t* done, int obs_every_step) = 0;
+  virtual int launch_reset(const uint8_t* mask) = 0;
+  virtual int get_state(int field, void* dst, size_t bytes) = 0;
+  virtual int set_state(int field, const void* src, size_t bytes) = 0;
+};
+
+template <typename T>
+struct Sim : SimBase {
+  fs::DevView<T> dv{};
+  std::vector<T> h_len;   // vehicle lengths (host copy, for FS_FIELD_HEADWAY)
+
+  template <typename U>
+  int dev_alloc(U** out, size_t count) {
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, (count ? count : 1) * sizeof(U)));
+    allocs.push_back(p);
+    *out = static_cast<U*>(p);
+    return FS_OK;
+  }
+
+  template <typename U>
+  int upload(const U** out, const std::vector<U>& host) {
+    U* p = nullptr;
+    int rc = dev_alloc(&p, host.size());
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(p, host.data(), host.size() * sizeof(U), hipMemcpyHostToDevice));
+    *out = p;
+    return FS_OK;
+  }
+
+  int init() {
+    const int R = cfg.num_replicas, N = cfg.num_vehicles;
+    const size_t RN = size_t(R) * N;
+    int rc;
+    if ((rc = dev_alloc(&dv.pos, RN))) return rc;
+    if ((rc = dev_alloc(&dv.vel, RN))) return rc;
+    if ((rc = dev_alloc(&dv.prev_vel, RN))) return rc;
+    if ((rc = dev_alloc(&dv.accel, RN))) return rc;
+    if ((rc = dev_alloc(&dv.ctrl_state, RN))) return rc;
+    if ((rc = dev_alloc(&dv.time, size_t(R)))) return rc;
+    if ((rc = dev_alloc(&dv.noise_ctr, size_t(R)))) return rc;
+    HIP_TRY(hipMemset(dv.noise_ctr, 0, size_t(R) * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(dv.time, 0, size_t(R) * sizeof(int32_t)));
+
+    std::vector<T> ipos(RN), ivel(RN), rlen(R);
+    for (size_t e = 0; e < RN; ++e) {
+      ipos[e] = T(cfg.init_pos[e]);
+      ivel[e] = cfg.init_vel ? T(cfg.init_vel[e]) : T(veh[e % N].initial_speed);
+    }
+    for (int r = 0; r < R; ++r) rlen[r] = T(cfg.ring_length[r]);
+    if ((rc = upload(&dv.init_pos, ipos))) return rc;
+    if ((rc = upload(&dv.init_vel, ivel))) return rc;
+    if ((rc = upload(&dv.ring_len, rlen))) return rc;
+
+    std::vector<int32_t> ctrl(N), fsafe(N), smode(N), rli(N);
+    std::vector<T> p(size_t(FS_MAX_CTRL_PARAMS) * N), noise(N), delay(N), maxa(N), maxd(N), len(N), stau(N),
+        sgap(N), smax(N);
+    int flags = 0;
+    bool all_idm = true;
+    for (int i = 0; i < N; ++i) {
+      const fs_vehicle_spec& v = veh[i];
+      ctrl[i] = v.controller;
+      fsafe[i] = v.fail_safe;
+      smode[i] = v.speed_mode;
+      rli[i] = v.rl_index;
+      for (int k = 0; k < FS_MAX_CTRL_PARAMS; ++k) p[size_t(k) * N + i] = T(v.p[k]);
+      noise[i] = T(v.noise);
+      delay[i] = T(v.delay);
+      maxa[i] = T(v.max_accel);
+      maxd[i] = T(v.max_decel);
+      len[i] = T(v.length);
+      stau[i] = T(v.sumo_tau);
+      sgap[i] = T(v.sumo_min_gap);
+      smax[i] = T(v.sumo_max_speed);
+      if (v.controller == FS_CTRL_BCM) flags |= fs::FLAG_NEED_FOLLOWER;
+      if (v.controller == FS_CTRL_NONLOCAL_FOLLOWER_STOPPER) flags |= fs::FLAG_NEED_MEAN;
+      if (v.controller == FS_CTRL_LAC) flags |= fs::FLAG_HAS_LAC;
+      if (v.noise > 0 && v.controller != FS_CTRL_SIM && v.controller != FS_CTRL_RL) flags |= fs::FLAG_HAS_NOISE;
+      if (v.fail_safe != FS_FAILSAFE_NONE) flags |= fs::FLAG_HAS_FAILSAFE;
+      if (v.controller == FS_CTRL_SIM || v.controller == FS_CTRL_RL || (v.speed_mode & 1) || cfg.junction_mode)
+        flags |= fs::FLAG_NEED_SUMO;
+      if (v.speed_mode & 6) flags |= fs::FLAG_NEED_SUMO;
+      if (v.controller != FS_CTRL_IDM) all_idm = false;
+    }
+    if (all_idm) flags |= fs::FLAG_ALL_IDM;
+    h_len = len;
+    if ((rc = upload(&dv.ctrl, ctrl))) return rc;
+    if ((rc = upload(&dv.failsafe, fsafe))) return rc;
+    if ((rc = upload(&dv.speed_mode, smode))) return rc;
+    if ((rc = upload(&dv.rl_index, rli))) return rc;
+    if ((rc = upload(&dv.p, p))) return rc;
+    if ((rc = upload(&dv.noise, noise))) return rc;
+    if ((rc = upload(&dv.delay, delay))) return rc;
+    if ((rc = upload(&dv.max_accel, maxa))) return rc;
+    if ((rc = upload(&dv.max_decel, maxd))) return rc;
+    if ((rc = upload(&dv.length, len))) return rc;
+    if ((rc = upload(&dv.sumo_tau, stau))) return rc;
+    if ((rc = upload(&dv.sumo_min_gap, sgap))) return rc;
+    if ((rc = upload(&dv.sumo_max_speed, smax))) return rc;
+
+    dv.R = R;
+    dv.N = N;
+    dv.num_rl = cfg.num_rl;
+    dv.env = cfg.env;
+    dv.integrator = cfg.integrator;
+    dv.sims_per_step = cfg.sims_per_step;
+    dv.junction_mode = cfg.junction_mode;
+    dv.clip_actions = cfg.clip_actions;
+    dv.evaluate = cfg.evaluate;
+    dv.track_aux = cfg.track_aux;
+    if (cfg.horizon < 0) {
+      dv.step_limit = INT_MAX;
+    } else {
+      long long lim = (long long)cfg.sims_per_step * ((long long)cfg.warmup_steps + cfg.horizon);
+      dv.step_limit = lim > INT_MAX ? INT_MAX : int(lim);
+    }
+    dv.flags = flags;
+    dv.seed_lo = uint32_t(cfg.seed & 0xFFFFFFFFull);
+    dv.seed_hi = uint32_t(cfg.seed >> 32);
+    dv.dt = T(cfg.sim_step);
+    dv.ramp = T(cfg.slowdown_ramp);
+    dv.jlen = T(cfg.junction_length);
+    dv.crash_gap = T(cfg.crash_gap);
+    dv.max_speed = T(cfg.max_speed);
+    dv.target_velocity = T(cfg.target_velocity);
+    {  // np.linalg.norm([target_velocity] * N) evaluated in double (rewards.py:50-51)
+      double ss = 0.0;
+      for (int i = 0; i < N; ++i) ss += cfg.target_velocity * cfg.target_velocity;
+      dv.max_cost = T(std::sqrt(ss));
+    }
+    dv.act_lo = T(cfg.action_low);
+    dv.act_hi = T(cfg.action_high);
+    dv.po_max_length = T(cfg.po_max_length);
+
+    // host-API staging
+    if ((rc = dev_alloc(&d_actions, size_t(R) * (cfg.num_rl > 0 ? cfg.num_rl : 1)))) return rc;
+    if ((rc = dev_alloc(&d_obs, size_t(R) * obs_dim))) return rc;
+    if ((rc = dev_alloc(&d_rew, size_t(R)))) return rc;
+    if ((rc = dev_alloc(&d_done, size_t(R)))) return rc;
+    if ((rc = dev_alloc(&d_mask, size_t(R)))) return rc;
+    return launch_reset(nullptr);
+  }
+
+  template <int SEG>
+  int launch_seg(int num_steps, const uint8_t* mask, const float* actions, size_t act_stride, float* obs,
+                 float* rew, uint8_t* done, int obs_every_step) {
+    constexpr int RPW = 64 / SEG;
+    const int blocks = (dv.R + RPW - 1) / RPW;
+    hipLaunchKernelGGL((fs::k_steps<T, SEG>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, mask, actions,
+                       act_stride, obs, rew, done, obs_every_step);
+    HIP_TRY(hipGetLastError());
+    return FS_OK;
+  }
+
+  int launch_steps(int num_steps, const uint8_t* mask, const float* actions, size_t act_stride, float* obs,
+                   float* rew, uint8_t* done, int obs_every_step) override {
+    switch (seg) {
+      case 8: return launch_seg<8>(num_steps, mask, actions, act_stride, obs, rew, done, obs_every_step);
+      case 16: return launch_seg<16>(num_steps, mask, actions, act_stride, obs, rew, done, obs_every_step);
+      case 32: return launch_seg<32>(num_steps, mask, actions, act_stride, obs, rew, done, obs_every_step);
+      default: return launch_seg<64>(num_steps, mask, actions, act_stride, obs, rew, done, obs_every_step);
+    }
+  }
+
+  int launch_reset(const uint8_t* mask) override {
+    const size_t n = size_t(dv.R) * dv.N;
+    int blocks = int((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL((fs::k_reset<T>), dim3(blocks), dim3(256), 0, stream, dv, mask);
+    HIP_TRY(hipGetLastError());
+    return FS_OK;
+  }
+
+  T* field_ptr(int field, size_t* count, bool* writable) {
+    const size_t RN = size_t(dv.R) * dv.N;
+    *writable = true;
+    switch (field) {
+      case FS_FIELD_POS: *count = RN; return dv.pos;
+      case FS_FIELD_VEL: *count = RN; return dv.vel;
+      case FS_FIELD_PREV_VEL: *count = RN; return dv.prev_vel;
+      case FS_FIELD_ACCEL: *count = RN; return dv.accel;
+      case FS_FIELD_CTRL_STATE: *count = RN; return dv.ctrl_state;
+      case FS_FIELD_RING_LENGTH: *count = size_t(dv.R); return const_cast<T*>(dv.ring_len);
+      case FS_FIELD_INIT_POS: *count = RN; return const_cast<T*>(dv.init_pos);
+      case FS_FIELD_INIT_VEL: *count = RN; return const_cast<T*>(dv.init_vel);
+      default: *count = 0; return nullptr;
+    }
+  }
+
+  int get_state(int field, void* dst, size_t bytes) override {
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (field == FS_FIELD_TIME) {
+      if (bytes != size_t(dv.R) * sizeof(int32_t)) return fail(FS_ERR_INVALID, "FS_FIELD_TIME: wrong byte count");
+      HIP_TRY(hipMemcpy(dst, dv.time, bytes, hipMemcpyDeviceToHost));
+      return FS_OK;
+    }
+    if (field == FS_FIELD_HEADWAY) {
+      // headway = (x_lead - x) mod L - len_lead, as the kernel computes it (vehicle/traci.py:219-250)
+      const int R = dv.R, N = dv.N;
+      const size_t RN = size_t(R) * N;
+      if (bytes != RN * sizeof(T)) return fail(FS_ERR_INVALID, "FS_FIELD_HEADWAY: wrong byte count");
+      std::vector<T> x(RN), rl(R);
+      HIP_TRY(hipMemcpy(x.data(), dv.pos, RN * sizeof(T), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(rl.data(), dv.ring_len, size_t(R) * sizeof(T), hipMemcpyDeviceToHost));
+      T* out = static_cast<T*>(dst);
+      for (int r = 0; r < R; ++r) {
+        const T L = rl[r] + T(4) * dv.jlen;
+        for (int i = 0; i < N; ++i) {
+          if (N == 1) { out[size_t(r) * N + i] = T(1000); continue; }
+          const int j = (i + 1 >= N) ? 0 : i + 1;
+          T d = x[size_t(r) * N + j] - x[size_t(r) * N + i];
+          if (d < T(0)) d = d + L;
+          out[size_t(r) * N + i] = d - h_len[j];
+        }
+      }
+      return FS_OK;
+    }
+    size_t count;
+    bool writable;
+    T* p = field_ptr(field, &count, &writable);
+    if (!p) return fail(FS_ERR_INVALID, "fs_get_state: unknown field");
+    if (bytes != count * sizeof(T)) return fail(FS_ERR_INVALID, "fs_get_state: wrong byte count");
+    HIP_TRY(hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost));
+    return FS_OK;
+  }
+
+  int set_state(int field, const void* src, size_t bytes) override {
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (field == FS_FIELD_TIME) {
+      if (bytes != size_t(dv.R) * sizeof(int32_t)) return fail(FS_ERR_INVALID, "FS_FIELD_TIME: wrong byte count");
+      HIP_TRY(hipMemcpy(dv.time, src, bytes, hipMemcpyHostToDevice));
+      return FS_OK;
+    }
+    if (field == FS_FIELD_HEADWAY) return fail(FS_ERR_INVALID, "FS_FIELD_HEADWAY is derived from positions");
+    size_t count;
+    bool writable;
+    T* p = field_ptr(field, &count, &writable);
+    if (!p) return fail(FS_ERR_INVALID, "fs_set_state: unknown field");
+    if (bytes != count * sizeof(T)) return fail(FS_ERR_INVALID, "fs_set_state: wrong byte count");
+    HIP_TRY(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+    return FS_OK;
+  }
+};
+
+int validate(const fs_config* c) {
+  if (!c) return fail(FS_ERR_INVALID, "fs_create: cfg is NULL");
+  if (c->struct_size != sizeof(fs_config))
+    return fail(FS_ERR_INVALID, "fs_create: struct_size mismatch (header/library out of sync)");
+  if (c->abi_version != FS_ABI_VERSION) return fail(FS_ERR_INVALID, "fs_create: abi_version mismatch");
+  if (c->precision != FS_F32 && c->precision != FS_F64) return fail(FS_ERR_INVALID, "fs_create: bad precision");
+  if (c->network != FS_NET_RING) return fail(FS_ERR_UNSUPPORTED, "fs_create: only FS_NET_RING is built");
+  if (c->env < FS_ENV_ACCEL || c->env > FS_ENV_WAVE_ATTENUATION_PO) return fail(FS_ERR_INVALID, "fs_create: bad env");
+  if (c->num_replicas < 1) return fail(FS_ERR_INVALID, "fs_create: num_replicas < 1");
+  if (c->num_vehicles < 1) return fail(FS_ERR_INVALID, "fs_create: num_vehicles < 1");
+  if (c->num_vehicles > 64)
+    return fail(FS_ERR_UNSUPPORTED, "fs_create: more than 64 vehicles per replica is not built yet");
+  if (c->num_rl < 0 || c->num_rl > c->num_vehicles) return fail(FS_ERR_INVALID, "fs_create: bad num_rl");
+  if (c->sims_per_step < 1) return fail(FS_ERR_INVALID, "fs_create: sims_per_step < 1");
+  if (c->warmup_steps < 0) return fail(FS_ERR_INVALID, "fs_create: warmup_steps < 0");
+  if (!(c->sim_step > 0)) return fail(FS_ERR_INVALID, "fs_create: sim_step <= 0");
+  if (!(c->slowdown_ramp > 0) || c->slowdown_ramp > 1) return fail(FS_ERR_INVALID, "fs_create: slowdown_ramp not in (0,1]");
+  if (c->junction_length < 0) return fail(FS_ERR_INVALID, "fs_create: junction_length < 0");
+  if (!c->vehicles || !c->ring_length || !c->init_pos) return fail(FS_ERR_INVALID, "fs_create: NULL table pointer");
+  int seen_rl = 0;
+  for (int i = 0; i < c->num_vehicles; ++i) {
+    const fs_vehicle_spec& v = c->vehicles[i];
+    if (v.controller < FS_CTRL_SIM || v.controller > FS_CTRL_NONLOCAL_FOLLOWER_STOPPER)
+      return fail(FS_ERR_INVALID, "fs_create: unknown controller id");
+    if (v.fail_safe < FS_FAILSAFE_NONE || v.fail_safe > FS_FAILSAFE_SAFE_VELOCITY)
+      return fail(FS_ERR_INVALID, "fs_create: unknown fail_safe id");
+    if (v.controller == FS_CTRL_RL) {
+      if (v.rl_index < 0 || v.rl_index >= c->num_rl) return fail(FS_ERR_INVALID, "fs_create: rl_index out of range");
+      ++seen_rl;
+    }
+    if (!(v.length > 0)) return fail(FS_ERR_INVALID, "fs_create: vehicle length <= 0");
+  }
+  if (seen_rl != c->num_rl) return fail(FS_ERR_INVALID, "fs_create: num_rl does not match the RL slots");
+  if (c->env == FS_ENV_WAVE_ATTENUATION_PO && c->num_rl < 1)
+    return fail(FS_ERR_INVALID, "fs_create: WaveAttenuationPOEnv needs an RL vehicle");
+  // placement sanity: every replica's vehicles must fit on its loop (network/base.py:603-605)
+  for (int r = 0; r < c->num_replicas; ++r) {
+    double need = 0;
+    for (int i = 0; i < c->num_vehicles; ++i) need += c->vehicles[i].length;
+    const double L = c->ring_length[r] + 4 * c->junction_length;
+    if (!(c->ring_length[r] > 0) || need > L) return fail(FS_ERR_NOSPACE, "fs_create: vehicles do not fit on the ring");
+    for (int i = 0; i < c->num_vehicles; ++i) {
+      const double x = c->init_pos[size_t(r) * c->num_vehicles + i];
+      if (!(x >= 0) || !(x < L)) return fail(FS_ERR_INVALID, "fs_create: init_pos outside [0, length)");
+    }
+  }
+  return FS_OK;
+}
+
+template <typename T>
+int create_typed(const fs_config* cfg, fs_handle* out) {
+  Sim<T>* s = new (std::nothrow) Sim<T>();
+  if (!s) return fail(FS_ERR_HIP, "fs_create: out of host memory");
+  s->cfg = *cfg;
+  s->veh.assign(cfg->vehicles, cfg->vehicles + cfg->num_vehicles);
+  s->obs_dim = (cfg->env == FS_ENV_WAVE_ATTENUATION_PO) ? 3 : 2 * cfg->num_vehicles;
+  int seg = 8;
+  while (seg < cfg->num_vehicles) seg <<= 1;
+  s->seg = seg;
+  hipError_t e = hipSetDevice(cfg->device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete s;
+    return fail(FS_ERR_HIP, std::string("fs_create: no usable HIP device: ") + hipGetErrorString(e));
+  }
+  s->stream = s->own_stream;
+  int rc = s->init();
+  if (rc == FS_OK) {
+    hipError_t e2 = hipStreamSynchronize(s->stream);
+    if (e2 != hipSuccess) rc = fail(FS_ERR_HIP, std::string("fs_create: ") + hipGetErrorString(e2));
+  }
+  if (rc != FS_OK) {
+    for (void* p : s->allocs) (void)hipFree(p);
+    (void)hipStreamDestroy(s->own_stream);
+    delete s;
+    return rc;
+  }
+  // the config's table pointers belong to the caller: do not keep them
+  s->cfg.vehicles = nullptr;
+  s->cfg.ring_length = nullptr;
+  s->cfg.init_pos = nullptr;
+  s->cfg.init_vel = nullptr;
+  *out = reinterpret_cast<fs_handle>(static_cast<SimBase*>(s));
+  return FS_OK;
+}
+
+inline SimBase* S(fs_handle h) { return reinterpret_cast<SimBase*>(h); }
+
+}  // namespace
+
+extern "C" {
+
+int fs_abi_version(void) { return FS_ABI_VERSION; }
+
+const char* fs_last_error(void) { return g_err.c_str(); }
+
+int fs_create(const fs_config* cfg, fs_handle* out) {
+  if (!out) return fail(FS_ERR_INVALID, "fs_create: out is NULL");
+  *out = nullptr;
+  int rc = validate(cfg);
+  if (rc) return rc;
+  return cfg->precision == FS_F64 ? create_typed<double>(cfg, out) : create_typed<float>(cfg, out);
+}
+
+void fs_destroy(fs_handle h) {
+  if (!h) return;
+  SimBase* s = S(h);
+  (void)hipSetDevice(s->cfg.device);
+  (void)hipStreamSynchronize(s->stream);
+  for (void* p : s->allocs) (void)hipFree(p);
+  (void)hipStreamDestroy(s->own_stream);
+  delete s;
+}
+
+int fs_obs_dim(fs_handle h) { return h ? S(h)->obs_dim : fail(FS_ERR_INVALID, "fs_obs_dim: NULL handle"); }
+
+int fs_set_stream(fs_handle h, void* hip_stream) {
+  if (!h) return fail(FS_ERR_INVALID, "fs_set_stream: NULL handle");
+  SimBase* s = S(h);
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  s->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : s->own_stream;
+  return FS_OK;
+}
+
+int fs_sync(fs_handle h) {
+  if (!h) return fail(FS_ERR_INVALID, "fs_sync: NULL handle");
+  HIP_TRY(hipStreamSynchronize(S(h)->stream));
+  return FS_OK;
+}
+
+int fs_reset_dev(fs_handle h, const uint8_t* mask_dev, float* obs_dev) {
+  if (!h) return fail(FS_ERR_INVALID, "fs_reset_dev: NULL handle");
+  SimBase* s = S(h);
+  int rc = s->launch_reset(mask_dev);
+  if (rc) return rc;
+  float* obs = obs_dev ? obs_dev : s->d_obs;
+  if (s->cfg.warmup_steps > 0)   // envs/base.py:554-555: warm-up steps with rl_actions=None
+    return s->launch_steps(s->cfg.warmup_steps, mask_dev, nullptr, 0, obs, s->d_rew, s->d_done, 0);
+  return s->launch_steps(0, mask_dev, nullptr, 0, obs, s->d_rew, s->d_done, 0);
+}
+
+int fs_reset(fs_handle h, const uint8_t* mask, float* obs_out) {
+  if (!h) return fail(FS_ERR_INVALID, "fs_reset: NULL handle");
+  SimBase* s = S(h);
+  const size_t R = size_t(s->cfg.num_replicas);
+  const uint8_t* dmask = nullptr;
+  if (mask) {
+    HIP_TRY(hipMemcpyAsync(s->d_mask, mask, R, hipMemcpyHostToDevice, s->stream));
+    dmask = s->d_mask;
+  }
+  int rc = fs_reset_dev(h, dmask, s->d_obs);
+  if (rc) return rc;
+  if (obs_out)
+    HIP_TRY(hipMemcpyAsync(obs_out, s->d_obs, R * s->obs_dim * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return FS_OK;
+}
+
+int fs_step_dev(fs_handle h, const float* actions_dev, float* obs_dev, float* rew_dev, uint8_t* done_dev) {
+  if (!h) return fail(FS_ERR_INVALID, "fs_step_dev: NULL handle");
+  if (!obs_dev || !rew_dev || !done_dev) return fail(FS_ERR_INVALID, "fs_step_dev: NULL output pointer");
+  return S(h)->launch_steps(1, nullptr, actions_dev, 0, obs_dev, rew_dev, done_dev, 0);
+}
+
+int fs_step(fs_handle h, const float* actions, float* obs, float* rew, uint8_t* done) {
+  if (!h) return fail(FS_ERR_INVALID, "fs_step: NULL handle");
+  if (!obs || !rew || !done) return fail(FS_ERR_INVALID, "fs_step: NULL output pointer");
+  SimBase* s = S(h);
+  const size_t R = size_t(s->cfg.num_replicas);
+  const float* dact = nullptr;
+  if (actions && s->cfg.num_rl > 0) {
+    HIP_TRY(hipMemcpyAsync(s->d_actions, actions, R * s->cfg.num_rl * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    dact = s->d_actions;
+  }
+  int rc = s->launch_steps(1, nullptr, dact, 0, s->d_obs, s->d_rew, s->d_done, 0);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(obs, s->d_obs, R * s->obs_dim * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(rew, s->d_rew, R * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(done, s->d_done, R, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return FS_OK;
+}
+
+int fs_rollout_dev(fs_handle h, int num_steps, const float* actions_dev, size_t action_stride_steps,
+                   float* obs_dev, float* rew_dev, uint8_t* done_dev, int obs_every_step) {
+  if (!h) return fail(FS_ERR_INVALID, "fs_rollout_dev: NULL handle");
+  if (num_steps < 1) return fail(FS_ERR_INVALID, "fs_rollout_dev: num_steps < 1");
+  if (!obs_dev || !rew_dev || !done_dev) return fail(FS_ERR_INVALID, "fs_rollout_dev: NULL output pointer");
+  return S(h)->launch_steps(num_steps, nullptr, actions_dev, action_stride_steps, obs_dev, rew_dev, done_dev,
+                            obs_every_step ? 1 : 0);
+}
+
+int fs_get_state(fs_handle h, int field, void* dst, size_t bytes) {
+  if (!h || !dst) return fail(FS_ERR_INVALID, "fs_get_state: NULL argument");
+  return S(h)->get_state(field, dst, bytes);
+}
+
+int fs_set_state(fs_handle h, int field, const void* src, size_t bytes) {
+  if (!h || !src) return fail(FS_ERR_INVALID, "fs_set_state: NULL argument");
+  return S(h)->set_state(field, src, bytes);
+}
+
+}  // extern "C"

@@ -1,0 +1,516 @@
+// flowsim_kernels.h -- device code of libflowsim: the fused batched step kernel
+// for closed single-lane routes (RingNetwork), written for gfx950 (CDNA4).
+//
+// Mapping (DESIGN.md "k_steps"): one 64-lane wavefront carries 64/SEG replicas,
+// SEG = smallest power of two >= N (vehicles per replica); lane = seg*SEG + i
+// holds vehicle i of its replica in registers for the whole launch.  The leader
+// of slot i on a closed single-lane loop is slot i+1 (cyclic), so the
+// leader/follower lookup is a fixed cross-lane rotation (ds_bpermute through the
+// LDS crossbar, no LDS allocation) and every per-replica reduction (reward norm,
+// crash/any flags) is an xor-butterfly inside the SEG-lane segment.
+//
+// Arithmetic contract: every floating-point expression below is evaluated in
+// T with the SAME operation order as oracle/controllers.py / oracle/refsim.py
+// (which restate the reference lines cited there); the library is built with
+// -ffp-contract=off so that a*b+c is never fused.  float is the bit-twin of the
+// float32 oracle; double restates the reference's Python-float arithmetic.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "flowsim.h"
+
+namespace fs {
+
+enum : int {
+  FLAG_NEED_FOLLOWER = 1,   // a BCM vehicle reads its follower (car_following_models.py:168-172)
+  FLAG_NEED_MEAN = 2,       // NonLocalFollowerStopper reads the replica mean speed
+  FLAG_HAS_NOISE = 4,       // some controller has noise > 0 (base_controller.py:109-110)
+  FLAG_HAS_LAC = 8,         // LAC controller state (car_following_models.py:243)
+  FLAG_NEED_SUMO = 16,      // some vehicle may be uncommanded or has speed_mode bit 0
+  FLAG_HAS_FAILSAFE = 32,
+  FLAG_ALL_IDM = 64,        // every slot is an IDM controller (fast path)
+};
+
+template <typename T>
+struct DevView {
+  // state, [R,N] unless noted
+  T* pos;
+  T* vel;
+  T* prev_vel;
+  T* accel;
+  T* ctrl_state;
+  int32_t* time;        // [R]
+  uint32_t* noise_ctr;  // [R]
+  const T* init_pos;
+  const T* init_vel;
+  const T* ring_len;    // [R]
+  // per-slot tables, [N]
+  const int32_t* ctrl;
+  const int32_t* failsafe;
+  const int32_t* speed_mode;
+  const int32_t* rl_index;
+  const T* p;           // [FS_MAX_CTRL_PARAMS][N]
+  const T* noise;
+  const T* delay;
+  const T* max_accel;
+  const T* max_decel;
+  const T* length;
+  const T* sumo_tau;
+  const T* sumo_min_gap;
+  const T* sumo_max_speed;
+  // scalars
+  int R, N, num_rl, env, integrator, sims_per_step, junction_mode, clip_actions, evaluate, track_aux;
+  int step_limit;       // sims_per_step*(warmup+horizon), INT_MAX for horizon=inf
+  int flags;
+  uint32_t seed_lo, seed_hi;
+  T dt, ramp, jlen, crash_gap, max_speed, target_velocity, max_cost, act_lo, act_hi, po_max_length;
+};
+
+// ---------------------------------------------------------------------------
+// small math helpers with a fixed operation order
+// ---------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T tmax(T a, T b) { return a > b ? a : b; }   // np.maximum (no NaN)
+template <typename T> __device__ __forceinline__ T tmin(T a, T b) { return a < b ? a : b; }   // np.minimum (no NaN)
+__device__ __forceinline__ float tsqrt(float x) { return __fsqrt_rn(x); }
+__device__ __forceinline__ double tsqrt(double x) { return __dsqrt_rn(x); }
+__device__ __forceinline__ float tfloor(float x) { return floorf(x); }
+__device__ __forceinline__ double tfloor(double x) { return floor(x); }
+__device__ __forceinline__ float tabs(float x) { return fabsf(x); }
+__device__ __forceinline__ double tabs(double x) { return fabs(x); }
+__device__ __forceinline__ float tcos(float x) { return cosf(x); }
+__device__ __forceinline__ double tcos(double x) { return cos(x); }
+__device__ __forceinline__ float tlog(float x) { return logf(x); }
+__device__ __forceinline__ double tlog(double x) { return log(x); }
+__device__ __forceinline__ float tpow(float x, float y) { return powf(x, y); }
+__device__ __forceinline__ double tpow(double x, double y) { return pow(x, y); }
+__device__ __forceinline__ float tfmin(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ double tfmin(double a, double b) { return fmin(a, b); }
+
+// oracle/controllers.py pow_delta
+template <typename T>
+__device__ __forceinline__ T pow_delta(T x, T d) {
+  if (d == T(4)) { T x2 = x * x; return x2 * x2; }
+  if (d == T(2)) return x * x;
+  if (d == T(1)) return x;
+  if (d == T(3)) return (x * x) * x;
+  if (d == T(8)) { T x2 = x * x; T x4 = x2 * x2; return x4 * x4; }
+  return tpow(x, d);
+}
+
+// cross-lane read (ds_bpermute_b32; two of them for double)
+template <typename T>
+__device__ __forceinline__ T lane_read(T v, int src_lane) { return __shfl(v, src_lane, 64); }
+
+// sum over the SEG-lane segment in the oracle's tree order (oracle/rewards.py tree_sum)
+template <int SEG, typename T>
+__device__ __forceinline__ T seg_sum(T v) {
+#pragma unroll
+  for (int off = 1; off < SEG; off <<= 1) v = v + __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <int SEG>
+__device__ __forceinline__ bool seg_any(bool pred, int seg) {
+  unsigned long long b = __ballot(pred);
+  if (SEG == 64) return b != 0ull;
+  unsigned long long m = ((1ull << (SEG & 63)) - 1ull) << (seg * (SEG & 63));
+  return (b & m) != 0ull;
+}
+
+// ---------------------------------------------------------------------------
+// Philox-4x32-10 + Box-Muller: oracle/refsim.py philox4x32_10 / gaussian_noise
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3,
+                                              uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ T gauss(uint32_t seed_lo, uint32_t seed_hi, uint32_t replica, uint32_t vehicle,
+                                   uint32_t step) {
+  uint32_t c0 = step, c1 = vehicle, c2 = replica, c3 = 0u;
+  philox4x32_10(c0, c1, c2, c3, seed_lo, seed_hi);
+  T u1 = T(double((c0 >> 8) + 1u) * (1.0 / 16777216.0));
+  T u2 = T(double(c1 >> 8) * (1.0 / 16777216.0));
+  return tsqrt(T(-2.0) * tlog(u1)) * tcos(T(6.283185307179586) * u2);
+}
+
+// ---------------------------------------------------------------------------
+// controllers (one lane = one vehicle); see oracle/controllers.py for citations
+// ---------------------------------------------------------------------------
+template <typename T>
+struct Slot {           // per-lane copy of the vehicle slot tables
+  int ctrl, failsafe, speed_mode, rl_index;
+  T p[FS_MAX_CTRL_PARAMS];
+  T noise, delay, max_accel, max_decel, length, sumo_tau, sumo_min_gap, sumo_max_speed;
+};
+
+template <typename T>
+__device__ __forceinline__ T ctrl_idm(T v, T vl, T h, bool has, const T* p) {
+  // p = {v0, T, a, b, delta, s0}; car_following_models.py:464-482
+  T hh = tabs(h) < T(1e-3) ? T(1e-3) : h;
+  T two_sqrt_ab = T(2) * tsqrt(p[2] * p[3]);
+  T dyn = v * p[1] + v * (v - vl) / two_sqrt_ab;
+  T s_star = has ? p[5] + tmax(T(0), dyn) : T(0);
+  T q = s_star / hh;
+  return p[2] * (T(1) - pow_delta(v / p[0], p[4]) - q * q);
+}
+
+template <typename T>
+__device__ __forceinline__ T ctrl_cfm(T v, T vl, T h, bool has, T max_accel, const T* p) {
+  // p = {k_d, k_v, k_c, d_des, v_des}; car_following_models.py:76-88
+  T acc = p[0] * (h - p[3]) + p[1] * (vl - v) + p[2] * (p[4] - v);
+  return has ? acc : max_accel;
+}
+
+template <typename T>
+__device__ __forceinline__ T ctrl_bcm(T v, T vl, T h, bool has, T vf, T hf, T max_accel, const T* p) {
+  // car_following_models.py:152-176
+  T acc = p[0] * (h - hf) + p[1] * ((vl - v) - (v - vf)) + p[2] * (p[4] - v);
+  return has ? acc : max_accel;
+}
+
+template <typename T>
+__device__ __forceinline__ T ctrl_lac(T v, T vl, T h, T len, T a_prev, T dt, const T* p) {
+  // p = {k_1, k_2, h, tau}; car_following_models.py:232-245
+  T ex = h - len - p[2] * v;
+  T ev = vl - v;
+  T u = p[0] * ex + p[1] * ev;
+  T a_dot = -(a_prev / p[3]) + (u / p[3]);
+  return a_dot * dt + a_prev;
+}
+
+template <typename T>
+__device__ __forceinline__ T ctrl_ovm(T v, T vl, T h, bool has, T max_accel, const T* p) {
+  // p = {alpha, beta, h_st, h_go, v_max}; car_following_models.py:308-328
+  T h_dot = vl - v;
+  T mid = p[4] / T(2) * (T(1) - tcos(T(3.141592653589793) * (h - p[2]) / (p[3] - p[2])));
+  T v_h = h <= p[2] ? T(0) : (h < p[3] ? mid : p[4]);
+  T acc = p[0] * (v_h - v) + p[1] * h_dot;
+  return has ? acc : max_accel;
+}
+
+template <typename T>
+__device__ __forceinline__ T ctrl_linear_ovm(T v, T h, const T* p) {
+  // p = {v_max, adaptation, h_st}; car_following_models.py:383-397
+  const T alpha = T(1.689);
+  T upper = p[2] + p[0] / alpha;
+  T v_h = h < p[2] ? T(0) : (h <= upper ? alpha * (h - p[2]) : p[0]);
+  return (v_h - v) / p[1];
+}
+
+template <typename T>
+__device__ __forceinline__ T ctrl_gipps(T v, T vl, T h, T dt, const T* p) {
+  // p = {v0, acc, b, b_l, s0, tau}; car_following_models.py:567-582
+  T r = v / p[0];
+  T v_acc = v + (T(2.5) * p[1] * p[5] * (T(1) - r) * tsqrt(T(0.025) + r));
+  T tb = p[5] * p[2];
+  T disc = (p[5] * p[5]) * (p[2] * p[2]) - (p[2] * ((T(2) * (h - p[4])) - (p[5] * v) - ((vl * vl) / p[3])));
+  T v_safe = tb + tsqrt(disc);
+  T v_next = tfmin(tfmin(v_acc, v_safe), p[0]);
+  return (v_next - v) / dt;
+}
+
+template <typename T>
+__device__ __forceinline__ T ctrl_follower_stopper(T v, T vl, T h, bool has, T dt, T v_des) {
+  // velocity_controllers.py:75-116
+  T dv_minus = tmin(vl - v, T(0));
+  T dv2 = dv_minus * dv_minus;
+  T dx_1 = T(4.5) + T(1.0 / (2 * 1.5)) * dv2;
+  T dx_2 = T(5.25) + T(1.0 / (2 * 1.0)) * dv2;
+  T dx_3 = T(6.0) + T(1.0 / (2 * 0.5)) * dv2;
+  T vv = tmin(tmax(vl, T(0)), v_des);
+  T c2 = vv * (h - dx_1) / (dx_2 - dx_1);
+  T c3 = vv + (v_des - v) * (h - dx_2) / (dx_3 - dx_2);
+  T v_cmd = h <= dx_1 ? T(0) : (h <= dx_2 ? c2 : (h <= dx_3 ? c3 : v_des));
+  v_cmd = has ? v_cmd : v_des;
+  return (v_cmd - v) / dt;
+}
+
+template <typename T>
+__device__ __forceinline__ T failsafe_instantaneous(T acc, T v, T h, bool has, T dt) {
+  // base_controller.py:120-169 (num_vehicles > 1 checked by the caller)
+  T next_vel = v + acc * dt;
+  T thresh = dt * next_vel + v * T(1e-3) + T(0.5) * v * dt;
+  bool stop = has && (next_vel > T(0)) && (h < thresh);
+  return stop ? -v / dt : acc;
+}
+
+template <typename T>
+__device__ __forceinline__ T failsafe_safe_velocity(T acc, T v, T vl, T h, T dt, T delay) {
+  // base_controller.py:171-236
+  T dv = vl - v;
+  T v_safe = T(2) * h / dt + dv - v * (T(2) * delay);
+  bool over = (v + acc * dt) > v_safe;
+  T clipped = v_safe > T(0) ? (v_safe - v) / dt : -v / dt;
+  return over ? clipped : acc;
+}
+
+template <typename T>
+__device__ __forceinline__ T sumo_idm_speed(T v, T vl, T h, bool has, T dt, const Slot<T>& s) {
+  // oracle/controllers.py sumo_idm_speed (SUMO-side, parity unpinned)
+  T gap = tmax(h, T(1e-3));
+  T two_sqrt = T(2) * tsqrt(s.max_accel * s.max_decel);
+  T ss = s.sumo_min_gap + tmax(T(0), v * s.sumo_tau + v * (v - vl) / two_sqrt);
+  T q = has ? ss / gap : T(0);
+  T r = v / s.sumo_max_speed;
+  T r2 = r * r;
+  T acc = s.max_accel * (T(1) - r2 * r2 - q * q);
+  return tmax(T(0), v + acc * dt);
+}
+
+// ---------------------------------------------------------------------------
+// the fused step kernel
+// ---------------------------------------------------------------------------
+template <typename T, int SEG>
+__global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const uint8_t* __restrict__ mask,
+                                              const float* __restrict__ actions, size_t act_stride,
+                                              float* __restrict__ obs, float* __restrict__ rew,
+                                              uint8_t* __restrict__ done, int obs_every_step) {
+  constexpr int RPW = 64 / SEG;
+  const int lane = threadIdx.x;
+  const int seg = lane / SEG;
+  const int i = lane % SEG;
+  const int r = blockIdx.x * RPW + seg;
+  const int N = s.N;
+  const bool rvalid = r < s.R;
+  const bool valid = rvalid && i < N;
+  const int rr = rvalid ? r : s.R - 1;
+  const int ii = i < N ? i : N - 1;
+  const size_t idx = size_t(rr) * N + ii;
+  const int segbase = seg * SEG;
+  const int lead_lane = segbase + (ii + 1 >= N ? 0 : ii + 1);
+  const int foll_lane = segbase + (ii == 0 ? N - 1 : ii - 1);
+  const bool has = N > 1;
+  const int flags = s.flags;
+
+  // per-lane slot parameters (registers for the whole launch)
+  Slot<T> sl;
+  sl.ctrl = s.ctrl[ii];
+  sl.failsafe = s.failsafe[ii];
+  sl.speed_mode = s.speed_mode[ii];
+  sl.rl_index = s.rl_index[ii];
+#pragma unroll
+  for (int k = 0; k < FS_MAX_CTRL_PARAMS; ++k) sl.p[k] = s.p[k * N + ii];
+  sl.noise = s.noise[ii];
+  sl.delay = s.delay[ii];
+  sl.max_accel = s.max_accel[ii];
+  sl.max_decel = s.max_decel[ii];
+  sl.length = s.length[ii];
+  sl.sumo_tau = s.sumo_tau[ii];
+  sl.sumo_min_gap = s.sumo_min_gap[ii];
+  sl.sumo_max_speed = s.sumo_max_speed[ii];
+  const T len_lead = lane_read(sl.length, lead_lane);
+
+  // per-replica scalars
+  const T base_len = s.ring_len[rr];
+  const T L = base_len + T(4) * s.jlen;          // network.length(): edges + 4 junctions
+  const T quarter = base_len / T(4);
+  const T qj = quarter + s.jlen;
+  const bool live_replica = rvalid && (mask == nullptr || mask[rr] != 0);
+  int tcount = s.time[rr];
+  uint32_t nctr = (flags & FLAG_HAS_NOISE) ? s.noise_ctr[rr] : 0u;
+
+  // state
+  T x = s.pos[idx];
+  T v = s.vel[idx];
+  T prev_v = v, last_acc = T(0);
+  T cst = (flags & FLAG_HAS_LAC) ? s.ctrl_state[idx] : T(0);
+  if (s.track_aux) { prev_v = s.prev_vel[idx]; last_acc = s.accel[idx]; }
+
+  // time-t neighbour snapshot (S1/S10)
+  T xl = lane_read(x, lead_lane);
+  T vl = lane_read(v, lead_lane);
+  T d = xl - x;
+  d = d < T(0) ? d + L : d;
+  T h = has ? d - len_lead : T(1000);
+
+  const T dt = s.dt;
+  const int obs_dim = (s.env == FS_ENV_WAVE_ATTENUATION_PO) ? 3 : 2 * N;
+
+  for (int step = 0; step < num_steps; ++step) {
+    // ---- RL action of this lane (envs/base.py:599-615) -------------------
+    const float* act = actions ? actions + size_t(step) * act_stride + size_t(rr) * s.num_rl : nullptr;
+    bool crashed = false;
+    for (int sub = 0; sub < s.sims_per_step; ++sub) {
+      const bool live = live_replica && !crashed;
+      // ---- controllers (S1: all read the snapshot) -----------------------
+      T vf = T(0), hf = T(0), mean_v = T(0);
+      if (flags & FLAG_NEED_FOLLOWER) { vf = lane_read(v, foll_lane); hf = lane_read(h, foll_lane); }
+      if (flags & FLAG_NEED_MEAN) mean_v = seg_sum<SEG>(valid ? v : T(0)) / T(N);
+      T acc = T(0);
+      bool commanded = false;
+      const int ct = sl.ctrl;
+      if (ct == FS_CTRL_RL) {
+        if (act != nullptr) {
+          T a = T(act[sl.rl_index < 0 ? 0 : sl.rl_index]);
+          if (s.clip_actions) a = tmin(tmax(a, s.act_lo), s.act_hi);
+          acc = a;
+          commanded = true;
+        }
+      } else if (ct != FS_CTRL_SIM) {
+        T a;
+        switch (ct) {
+          case FS_CTRL_IDM: a = ctrl_idm(v, vl, h, has, sl.p); break;
+          case FS_CTRL_CFM: a = ctrl_cfm(v, vl, h, has, sl.max_accel, sl.p); break;
+          case FS_CTRL_BCM: a = ctrl_bcm(v, vl, h, has, vf, hf, sl.max_accel, sl.p); break;
+          case FS_CTRL_LAC: a = ctrl_lac(v, vl, h, sl.length, cst, dt, sl.p); break;
+          case FS_CTRL_OVM: a = ctrl_ovm(v, vl, h, has, sl.max_accel, sl.p); break;
+          case FS_CTRL_LINEAR_OVM: a = ctrl_linear_ovm(v, h, sl.p); break;
+          case FS_CTRL_GIPPS: a = ctrl_gipps(v, vl, h, dt, sl.p); break;
+          case FS_CTRL_FOLLOWER_STOPPER: a = ctrl_follower_stopper(v, vl, h, has, dt, sl.p[0]); break;
+          default: a = ctrl_follower_stopper(v, vl, h, has, dt, mean_v); break;
+        }
+        commanded = true;
+        if (s.junction_mode) {                       // base_controller.py:98-99
+          T u = x - tfloor(x / qj) * qj;
+          commanded = !(u >= quarter);
+        }
+        if (ct == FS_CTRL_LAC && commanded && live) cst = a;
+        if (flags & FLAG_HAS_NOISE) {                // base_controller.py:109-110
+          if (sl.noise > T(0)) a = a + sl.noise * gauss<T>(s.seed_lo, s.seed_hi, uint32_t(rr), uint32_t(ii), nctr);
+        }
+        if (has) {                                   // base_controller.py:113-116, 141-142, 191-193
+          if (sl.failsafe == FS_FAILSAFE_INSTANTANEOUS) a = failsafe_instantaneous(a, v, h, has, dt);
+          else if (sl.failsafe == FS_FAILSAFE_SAFE_VELOCITY) a = failsafe_safe_velocity(a, v, vl, h, dt, sl.delay);
+        }
+        acc = a;
+      }
+      // ---- apply_acceleration + SUMO integration (S4-S9) ------------------
+      T next_vel = tmax(v + acc * dt, T(0));          // vehicle/traci.py:962
+      T vc = v + (next_vel - v) * s.ramp;             // slowDown(.., 1e-3)
+      T v_new = vc;
+      if (flags & FLAG_NEED_SUMO) {
+        T v_sumo = sumo_idm_speed(v, vl, h, has, dt, sl);
+        if (sl.speed_mode & 1) vc = tmin(vc, v_sumo);
+        if (sl.speed_mode & 2) vc = tmin(vc, v + sl.max_accel * dt);
+        if (sl.speed_mode & 4) vc = tmax(vc, v - sl.max_decel * dt);
+        v_new = commanded ? vc : v_sumo;
+      }
+      T x_new = (s.integrator == FS_BALLISTIC) ? x + (v + v_new) / T(2) * dt : x + v_new * dt;
+      x_new = x_new >= L ? x_new - L : x_new;
+      if (live) {
+        prev_v = v;
+        last_acc = acc;
+        x = x_new;
+        v = v_new;
+        tcount += 1;
+        nctr += 1u;
+      }
+      // ---- vehicle update: new neighbour snapshot (vehicle/traci.py:219-250)
+      xl = lane_read(x, lead_lane);
+      vl = lane_read(v, lead_lane);
+      d = xl - x;
+      d = d < T(0) ? d + L : d;
+      h = has ? d - len_lead : T(1000);
+      // ---- check_collision (S12) ----------------------------------------
+      const bool c = has && seg_any<SEG>(valid && (h < s.crash_gap), seg);
+      crashed = crashed || (c && live);
+    }
+
+    // ---- get_state / compute_reward / done (envs/base.py:387-412) ---------
+    const bool last = (step == num_steps - 1);
+    const size_t so = obs_every_step ? size_t(step) : 0;
+    if (obs_every_step || last) {
+      float* o = obs + (so * s.R + size_t(rr)) * obs_dim;
+      if (s.env == FS_ENV_WAVE_ATTENUATION_PO) {
+        // wave_attenuation.py:248-269; written by the RL vehicle's lane
+        if (valid && sl.ctrl == FS_CTRL_RL && sl.rl_index == 0) {
+          o[0] = float(v / T(15));
+          o[1] = float((vl - v) / T(15));
+          o[2] = float(d / s.po_max_length);
+        }
+      } else if (valid) {
+        o[ii] = float(v / s.max_speed);               // accel.py:118-119
+        o[N + ii] = float(x / L);                     // accel.py:120-121
+      }
+    }
+    // reward
+    T reward;
+    const bool bad = seg_any<SEG>(valid && (v < T(-100)), seg) || crashed;
+    if (s.env == FS_ENV_ACCEL) {
+      if (s.evaluate) {
+        reward = seg_sum<SEG>(valid ? v : T(0)) / T(N);                    // accel.py:111-112
+      } else {                                                            // rewards.py:6-59
+        T dv = valid ? v - s.target_velocity : T(0);
+        T cost = tsqrt(seg_sum<SEG>(dv * dv));
+        reward = tmax(s.max_cost - cost, T(0)) / (s.max_cost + T(1.1920928955078125e-07));
+        reward = bad ? T(0) : reward;
+      }
+    } else {                                                              // wave_attenuation.py:113-139
+      if (act == nullptr) {
+        reward = T(0);
+      } else {
+        T a = T(0);
+        if (ii < s.num_rl && i < N) {
+          a = T(act[ii]);
+          if (s.clip_actions) a = tmin(tmax(a, s.act_lo), s.act_hi);
+          a = tabs(a);
+        }
+        T mean_v = seg_sum<SEG>(valid ? v : T(0)) / T(N);
+        T mean_a = seg_sum<SEG>(a) / T(s.num_rl);
+        reward = T(4.0) * mean_v / T(20);
+        if (mean_a > T(0)) reward = reward + T(4) * (T(0) - mean_a);
+        reward = bad ? T(0) : reward;
+      }
+    }
+    if ((obs_every_step || last) && valid && ii == 0) {
+      rew[so * s.R + rr] = float(reward);
+      done[so * s.R + rr] = uint8_t((tcount >= s.step_limit) || crashed);  // envs/base.py:398-400
+    }
+  }
+
+  if (num_steps == 0) {   // observation of the current state only (Env.reset, envs/base.py:544-551)
+    float* o = obs + size_t(rr) * obs_dim;
+    if (s.env == FS_ENV_WAVE_ATTENUATION_PO) {
+      if (valid && sl.ctrl == FS_CTRL_RL && sl.rl_index == 0) {
+        o[0] = float(v / T(15));
+        o[1] = float((vl - v) / T(15));
+        o[2] = float(d / s.po_max_length);
+      }
+    } else if (valid) {
+      o[ii] = float(v / s.max_speed);
+      o[N + ii] = float(x / L);
+    }
+    return;
+  }
+
+  // ---- write the state back -------------------------------------------------
+  if (valid && live_replica) {
+    s.pos[idx] = x;
+    s.vel[idx] = v;
+    if (flags & FLAG_HAS_LAC) s.ctrl_state[idx] = cst;
+    if (s.track_aux) { s.prev_vel[idx] = prev_v; s.accel[idx] = last_acc; }
+    if (ii == 0) {
+      s.time[rr] = tcount;
+      if (flags & FLAG_HAS_NOISE) s.noise_ctr[rr] = nctr;
+    }
+  }
+}
+
+// Env.reset placement (envs/base.py:430, 494-518): selected replicas go back to
+// their initial state; vehicles are inserted without moving (S13).
+template <typename T>
+__global__ void k_reset(DevView<T> s, const uint8_t* __restrict__ mask) {
+  const size_t n = size_t(s.R) * s.N;
+  for (size_t e = size_t(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += size_t(gridDim.x) * blockDim.x) {
+    const int r = int(e / s.N);
+    if (mask != nullptr && mask[r] == 0) continue;
+    s.pos[e] = s.init_pos[e];
+    s.vel[e] = s.init_vel[e];
+    s.prev_vel[e] = s.init_vel[e];
+    s.accel[e] = T(0);
+    s.ctrl_state[e] = T(0);
+    if (e % s.N == 0) s.time[r] = 0;
+  }
+}
+
+}  // namespace fs

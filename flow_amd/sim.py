@@ -1,0 +1,190 @@
+"""FlowSim: the Python face of one libflowsim handle (one process, one GPU).
+
+Thin by design: it packs a plain ``spec`` dict into ``fs_config``, calls the
+C ABI (include/flowsim.h) and hands back numpy arrays (host API) or fills
+caller-owned torch-ROCm tensors (device API).  No simulation arithmetic lives
+here; without the HIP library or a GPU, construction raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+PRECISIONS = {"f32": L.FS_F32, "float32": L.FS_F32, "f64": L.FS_F64, "float64": L.FS_F64,
+              np.float32: L.FS_F32, np.float64: L.FS_F64}
+INTEGRATORS = {"euler": L.FS_EULER, "ballistic": L.FS_BALLISTIC}
+
+VEHICLE_DEFAULTS = dict(controller=L.FS_CTRL_SIM, fail_safe=L.FS_FAILSAFE_NONE, speed_mode=0, rl_index=-1,
+                        noise=0.0, delay=0.0, max_accel=2.6, max_decel=4.5, length=5.0, sumo_tau=1.0,
+                        sumo_min_gap=2.5, sumo_max_speed=30.0, initial_speed=0.0)
+
+
+def _ptr(a):
+    """Raw address of a numpy array / torch tensor / None."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return a.data_ptr()          # torch tensor
+
+
+class FlowSim:
+    """One batched simulator instance: R replicas x N vehicles on one GPU.
+
+    ``spec`` keys (see oracle/refsim.py RingOracle for the same dict):
+    num_replicas, num_vehicles, num_rl, vehicles (list of dicts), ring_length
+    [R], init_pos [R,N], init_vel [R,N] (optional), sim_step, slowdown_ramp,
+    integrator, junction_mode, junction_length, crash_gap, max_speed, env,
+    target_velocity, action_low, action_high, clip_actions, evaluate,
+    po_max_length, horizon, warmup_steps, sims_per_step, seed, track_aux.
+    """
+
+    def __init__(self, spec, precision="f32", device=0):
+        self.lib = L.load()
+        self.spec = spec
+        self.R = int(spec["num_replicas"])
+        self.N = int(spec["num_vehicles"])
+        self.num_rl = int(spec.get("num_rl", 0))
+        self.precision = PRECISIONS[precision]
+        self.real = np.float64 if self.precision == L.FS_F64 else np.float32
+        self.device = int(device)
+        self._h = C.c_void_p()
+
+        veh = (L.fs_vehicle_spec * self.N)()
+        if len(spec["vehicles"]) != self.N:
+            raise ValueError("spec['vehicles'] must have num_vehicles entries")
+        for i, vd in enumerate(spec["vehicles"]):
+            d = dict(VEHICLE_DEFAULTS)
+            d.update(vd)
+            v = veh[i]
+            for k in ("controller", "fail_safe", "speed_mode", "rl_index"):
+                setattr(v, k, int(d[k]))
+            p = list(d.get("p", [])) + [0.0] * L.FS_MAX_CTRL_PARAMS
+            for k in range(L.FS_MAX_CTRL_PARAMS):
+                v.p[k] = float(p[k])
+            for k in ("noise", "delay", "max_accel", "max_decel", "length", "sumo_tau", "sumo_min_gap",
+                      "sumo_max_speed", "initial_speed"):
+                setattr(v, k, float(d[k]))
+
+        dt = float(spec["sim_step"])
+        ring_length = np.ascontiguousarray(
+            np.broadcast_to(np.asarray(spec["ring_length"], dtype=np.float64), (self.R,)))
+        init_pos = np.ascontiguousarray(np.asarray(spec["init_pos"], dtype=np.float64).reshape(self.R, self.N))
+        init_vel = spec.get("init_vel")
+        if init_vel is not None:
+            init_vel = np.ascontiguousarray(np.asarray(init_vel, dtype=np.float64).reshape(self.R, self.N))
+        horizon = spec.get("horizon", float("inf"))
+        dp = C.POINTER(C.c_double)
+        cfg = L.fs_config(
+            struct_size=C.sizeof(L.fs_config), abi_version=L.FS_ABI_VERSION, precision=self.precision,
+            network=L.FS_NET_RING, env=int(spec.get("env", L.FS_ENV_ACCEL)),
+            integrator=INTEGRATORS[spec.get("integrator", "euler")],
+            num_replicas=self.R, num_vehicles=self.N, num_rl=self.num_rl,
+            horizon=-1 if horizon == float("inf") else int(horizon),
+            warmup_steps=int(spec.get("warmup_steps", 0)), sims_per_step=int(spec.get("sims_per_step", 1)),
+            junction_mode=int(spec.get("junction_mode", 0)), clip_actions=int(bool(spec.get("clip_actions", True))),
+            evaluate=int(bool(spec.get("evaluate", False))), device=self.device,
+            track_aux=int(bool(spec.get("track_aux", False))), reserved0=0,
+            seed=int(spec.get("seed", 0) or 0) & 0xFFFFFFFFFFFFFFFF,
+            sim_step=dt, slowdown_ramp=float(spec.get("slowdown_ramp", dt / (dt + 1e-3))),
+            junction_length=float(spec.get("junction_length", 0.1)), crash_gap=float(spec.get("crash_gap", 0.0)),
+            max_speed=float(spec["max_speed"]), target_velocity=float(spec.get("target_velocity", 0.0)),
+            action_low=float(spec.get("action_low", 0.0)), action_high=float(spec.get("action_high", 0.0)),
+            po_max_length=float(spec.get("po_max_length", 1.0)),
+            vehicles=veh, ring_length=ring_length.ctypes.data_as(dp), init_pos=init_pos.ctypes.data_as(dp),
+            init_vel=init_vel.ctypes.data_as(dp) if init_vel is not None else None)
+        L.check(self.lib.fs_create(C.byref(cfg), C.byref(self._h)))
+        self.obs_dim = self.lib.fs_obs_dim(self._h)
+
+    # ------------------------------------------------------------------ life cycle
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.fs_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        """Enqueue later launches on ``hip_stream`` (int address of a hipStream_t, e.g.
+        ``torch.cuda.current_stream().cuda_stream``); 0/None restores the handle's own stream."""
+        L.check(self.lib.fs_set_stream(self._h, C.c_void_p(int(hip_stream) if hip_stream else None)))
+
+    def sync(self):
+        L.check(self.lib.fs_sync(self._h))
+
+    # ------------------------------------------------------------------ host API (numpy in / out)
+    def reset(self, mask=None):
+        """Env.reset for the masked replicas (all if None); returns obs float32[R,obs_dim]."""
+        obs = np.empty((self.R, self.obs_dim), dtype=np.float32)
+        m = None if mask is None else np.ascontiguousarray(np.asarray(mask, dtype=np.uint8))
+        if m is not None and m.shape != (self.R,):
+            raise ValueError("mask must have shape [R]")
+        L.check(self.lib.fs_reset(self._h, _ptr(m), _ptr(obs)))
+        return obs
+
+    def step(self, actions=None):
+        """Env.step for all replicas; returns (obs [R,obs_dim] f32, reward [R] f32, done [R] bool)."""
+        a = None
+        if actions is not None and self.num_rl > 0:
+            a = np.ascontiguousarray(np.asarray(actions, dtype=np.float32).reshape(self.R, self.num_rl))
+        obs = np.empty((self.R, self.obs_dim), dtype=np.float32)
+        rew = np.empty(self.R, dtype=np.float32)
+        done = np.empty(self.R, dtype=np.uint8)
+        L.check(self.lib.fs_step(self._h, _ptr(a), _ptr(obs), _ptr(rew), _ptr(done)))
+        return obs, rew, done.astype(bool)
+
+    # ------------------------------------------------------------------ device API (torch-ROCm tensors)
+    def reset_dev(self, obs, mask=None):
+        L.check(self.lib.fs_reset_dev(self._h, _ptr(mask), _ptr(obs)))
+
+    def step_dev(self, obs, rew, done, actions=None):
+        L.check(self.lib.fs_step_dev(self._h, _ptr(actions), _ptr(obs), _ptr(rew), _ptr(done)))
+
+    def rollout_dev(self, num_steps, obs, rew, done, actions=None, action_stride_steps=None,
+                    obs_every_step=True):
+        """K env steps in one launch.  obs/rew/done are [K,R,...] when obs_every_step else [R,...]."""
+        if action_stride_steps is None:
+            action_stride_steps = self.R * self.num_rl if actions is not None and actions.dim() == 3 else 0
+        L.check(self.lib.fs_rollout_dev(self._h, int(num_steps), _ptr(actions), int(action_stride_steps),
+                                        _ptr(obs), _ptr(rew), _ptr(done), int(bool(obs_every_step))))
+
+    # ------------------------------------------------------------------ state access
+    def _field_shape(self, field):
+        if field in (L.FS_FIELD_TIME,):
+            return (self.R,), np.int32
+        if field == L.FS_FIELD_RING_LENGTH:
+            return (self.R,), self.real
+        return (self.R, self.N), self.real
+
+    def get_state(self, field):
+        shape, dt = self._field_shape(field)
+        out = np.empty(shape, dtype=dt)
+        L.check(self.lib.fs_get_state(self._h, int(field), _ptr(out), out.nbytes))
+        return out
+
+    def set_state(self, field, value):
+        shape, dt = self._field_shape(field)
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(value, dtype=dt), shape))
+        L.check(self.lib.fs_set_state(self._h, int(field), _ptr(a), a.nbytes))
+
+    # convenience
+    @property
+    def pos(self):
+        return self.get_state(L.FS_FIELD_POS)
+
+    @property
+    def vel(self):
+        return self.get_state(L.FS_FIELD_VEL)
+
+    @property
+    def headway(self):
+        return self.get_state(L.FS_FIELD_HEADWAY)
+
+    @property
+    def time_counter(self):
+        return self.get_state(L.FS_FIELD_TIME)

@@ -1,0 +1,206 @@
+/*
+ * flowsim.h -- C ABI of libflowsim.so, the MI355X-native batched traffic
+ * micro-simulation step loop.
+ *
+ * The reference (parthjaggi/flow) has no native boundary on this path: its
+ * "FFI" is the TraCI TCP protocol between flow.envs.Env and a SUMO subprocess.
+ * Each entry point below replaces the group of reference calls cited next to
+ * it (paths relative to the reference root).  Plain pointers and sizes only;
+ * no torch / numpy types.  All functions return FS_OK (0) or a negative
+ * FS_ERR_* code; fs_last_error() returns the message of the last failure on
+ * the calling thread.
+ *
+ * Threading: a handle is not thread-safe; use one handle per (process, GPU)
+ * (reference: one Env + one SUMO process per rollout worker,
+ * examples/train.py:149).  All device work of a handle is enqueued on one HIP
+ * stream (fs_set_stream) and is asynchronous with respect to the host unless
+ * the call copies results to host memory.
+ *
+ * Ownership: the library owns the simulator state in HBM; the caller owns
+ * every buffer it passes in.  "_dev" entry points take device pointers
+ * (hipMalloc / torch-ROCm storage); the others take host pointers and copy.
+ */
+#ifndef FLOWSIM_H
+#define FLOWSIM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FS_ABI_VERSION 1
+
+/* ---- error codes -------------------------------------------------------- */
+#define FS_OK 0
+#define FS_ERR_INVALID -1       /* bad argument / config (Python: ValueError / KeyError)   */
+#define FS_ERR_UNSUPPORTED -2   /* valid in the reference, not built yet (NotImplementedError) */
+#define FS_ERR_HIP -3           /* HIP runtime failure (FatalFlowError)                    */
+#define FS_ERR_NOSPACE -4       /* vehicles do not fit (network/base.py:603-605)            */
+
+/* ---- enums -------------------------------------------------------------- */
+enum fs_precision { FS_F32 = 0, FS_F64 = 1 };
+
+/* acceleration controllers, flow/controllers/__init__.py */
+enum fs_controller {
+  FS_CTRL_SIM = 0,              /* SimCarFollowingController: never commanded          car_following_models.py:485-497 */
+  FS_CTRL_RL = 1,               /* RLController: commanded by the action vector        rlcontroller.py:6-39 */
+  FS_CTRL_IDM = 2,              /* p = {v0, T, a, b, delta, s0}                         car_following_models.py:400-482 */
+  FS_CTRL_CFM = 3,              /* p = {k_d, k_v, k_c, d_des, v_des}                    :17-88 */
+  FS_CTRL_BCM = 4,              /* p = {k_d, k_v, k_c, d_des, v_des}                    :91-176 */
+  FS_CTRL_LAC = 5,              /* p = {k_1, k_2, h, tau}; stateful a                   :179-245 */
+  FS_CTRL_OVM = 6,              /* p = {alpha, beta, h_st, h_go, v_max}                 :248-328 */
+  FS_CTRL_LINEAR_OVM = 7,       /* p = {v_max, adaptation, h_st}                        :331-397 */
+  FS_CTRL_GIPPS = 8,            /* p = {v0, acc, b, b_l, s0, tau}                       :500-582 */
+  FS_CTRL_FOLLOWER_STOPPER = 9, /* p = {v_des}                                          velocity_controllers.py:7-116 */
+  FS_CTRL_NONLOCAL_FOLLOWER_STOPPER = 10 /* v_des = replica mean speed                  velocity_controllers.py:119-164 */
+};
+
+/* BaseController fail-safes, flow/controllers/base_controller.py:113-116 */
+enum fs_failsafe { FS_FAILSAFE_NONE = 0, FS_FAILSAFE_INSTANTANEOUS = 1, FS_FAILSAFE_SAFE_VELOCITY = 2 };
+
+/* environments (observation + reward heads) */
+enum fs_env {
+  FS_ENV_ACCEL = 0,                 /* AccelEnv                 flow/envs/ring/accel.py:25-183 */
+  FS_ENV_WAVE_ATTENUATION = 1,      /* WaveAttenuationEnv       flow/envs/ring/wave_attenuation.py:50-210 */
+  FS_ENV_WAVE_ATTENUATION_PO = 2    /* WaveAttenuationPOEnv     flow/envs/ring/wave_attenuation.py:213-276 */
+};
+
+enum fs_network { FS_NET_RING = 0 /* RingNetwork, flow/networks/ring.py */ };
+
+enum fs_integrator { FS_EULER = 0, FS_BALLISTIC = 1 /* SumoParams.use_ballistic, core/params.py:578-602 */ };
+
+/* fields of fs_get_state / fs_set_state (the read accessors of
+ * flow/core/kernel/vehicle/base.py:327-672 and the test back-doors of
+ * flow/core/kernel/vehicle/traci.py:411-425) */
+enum fs_field {
+  FS_FIELD_POS = 0,        /* real[R,N]  absolute position along the loop (get_x_by_id) */
+  FS_FIELD_VEL = 1,        /* real[R,N]  get_speed                                       */
+  FS_FIELD_HEADWAY = 2,    /* real[R,N]  get_headway (derived; read-only)                */
+  FS_FIELD_PREV_VEL = 3,   /* real[R,N]  get_previous_speed                              */
+  FS_FIELD_ACCEL = 4,      /* real[R,N]  last commanded acceleration (0 if uncommanded)  */
+  FS_FIELD_TIME = 5,       /* int32[R]   Env.time_counter                                */
+  FS_FIELD_RING_LENGTH = 6,/* real[R]    per-replica ring length (edges only)            */
+  FS_FIELD_INIT_POS = 7,   /* real[R,N]  Env.initial_state positions                     */
+  FS_FIELD_INIT_VEL = 8,   /* real[R,N]  Env.initial_state speeds                        */
+  FS_FIELD_CTRL_STATE = 9  /* real[R,N]  controller state (LAC: self.a)                  */
+};
+
+#define FS_MAX_CTRL_PARAMS 8
+
+/* One vehicle slot; identical for every replica (VehicleParams.add,
+ * flow/core/params.py:236-351, expanded per vehicle). */
+typedef struct fs_vehicle_spec {
+  int32_t controller;                 /* enum fs_controller */
+  int32_t fail_safe;                  /* enum fs_failsafe */
+  int32_t speed_mode;                 /* SUMO speed-mode bitmask, core/params.py:12-18 */
+  int32_t rl_index;                   /* column of the action vector, -1 if not RL */
+  double p[FS_MAX_CTRL_PARAMS];       /* controller parameters, see enum fs_controller */
+  double noise;                       /* sigma of the Gaussian acceleration noise */
+  double delay;                       /* delay used by the safe_velocity fail-safe */
+  double max_accel;                   /* SumoCarFollowingParams accel */
+  double max_decel;                   /* |SumoCarFollowingParams decel| */
+  double length;                      /* vehicle length [m] */
+  double sumo_tau;                    /* SumoCarFollowingParams tau */
+  double sumo_min_gap;                /* SumoCarFollowingParams min_gap */
+  double sumo_max_speed;              /* SumoCarFollowingParams max_speed */
+  double initial_speed;               /* VehicleParams.add(initial_speed=) */
+} fs_vehicle_spec;
+
+typedef struct fs_config {
+  uint32_t struct_size;               /* sizeof(fs_config), ABI check */
+  uint32_t abi_version;               /* FS_ABI_VERSION */
+  int32_t precision;                  /* enum fs_precision: arithmetic + state type */
+  int32_t network;                    /* enum fs_network */
+  int32_t env;                        /* enum fs_env */
+  int32_t integrator;                 /* enum fs_integrator */
+  int32_t num_replicas;               /* R */
+  int32_t num_vehicles;               /* N per replica (<= 64) */
+  int32_t num_rl;                     /* RL vehicles per replica */
+  int32_t horizon;                    /* EnvParams.horizon; <0 means inf */
+  int32_t warmup_steps;               /* EnvParams.warmup_steps */
+  int32_t sims_per_step;              /* EnvParams.sims_per_step */
+  int32_t junction_mode;              /* 1: no Flow command while on an internal edge (base_controller.py:98-99) */
+  int32_t clip_actions;               /* EnvParams.clip_actions */
+  int32_t evaluate;                   /* EnvParams.evaluate */
+  int32_t device;                     /* HIP device ordinal */
+  int32_t track_aux;                  /* 1: keep FS_FIELD_PREV_VEL / FS_FIELD_ACCEL up to date (get_previous_speed) */
+  int32_t reserved0;
+  uint64_t seed;                      /* SimParams.seed: key of the per-(replica,vehicle,step) noise stream */
+  double sim_step;                    /* SimParams.sim_step */
+  double slowdown_ramp;               /* v' = v + (next_vel - v)*ramp; dt/(dt+1e-3) models slowDown(.., 1e-3) */
+  double junction_length;             /* length of each internal edge */
+  double crash_gap;                   /* crash <=> some headway < crash_gap after the move */
+  double max_speed;                   /* k.network.max_speed() */
+  double target_velocity;             /* env_params.additional_params['target_velocity'] */
+  double action_low, action_high;     /* action_space bounds */
+  double po_max_length;               /* WaveAttenuationPOEnv max_length normaliser */
+  const fs_vehicle_spec* vehicles;    /* [N] */
+  const double* ring_length;          /* [R] length of each replica's ring (sum of its 4 edges) */
+  const double* init_pos;             /* [R,N] initial absolute positions */
+  const double* init_vel;             /* [R,N] initial speeds, or NULL -> vehicles[i].initial_speed */
+} fs_config;
+
+typedef struct fs_sim* fs_handle;
+
+/* ---- life cycle ----------------------------------------------------------
+ * fs_create replaces Env.__init__ -> Kernel / generate_network /
+ * start_simulation / setup_initial_state (flow/envs/base.py:102-229,
+ * 268-292; flow/core/kernel/simulation/traci.py:70-174).
+ * fs_destroy replaces Env.terminate (flow/envs/base.py:680-703). */
+int fs_create(const fs_config* cfg, fs_handle* out);
+void fs_destroy(fs_handle h);
+const char* fs_last_error(void);
+int fs_abi_version(void);
+
+/* observation width of the configured env (observation_space.shape[0]) */
+int fs_obs_dim(fs_handle h);
+
+/* Enqueue all later work of this handle on `hip_stream` (a hipStream_t);
+ * NULL restores the handle's own stream. */
+int fs_set_stream(fs_handle h, void* hip_stream);
+/* Block until the handle's stream is idle. */
+int fs_sync(fs_handle h);
+
+/* ---- reset ---------------------------------------------------------------
+ * Env.reset (flow/envs/base.py:414-560): re-place the vehicles of the
+ * replicas selected by mask (uint8[R], NULL = all) at their initial state,
+ * zero their time counters, then run warmup_steps steps with no RL action.
+ * obs_out (real32[R,obs_dim], may be NULL) receives the observation of every
+ * replica after the call. */
+int fs_reset(fs_handle h, const uint8_t* mask, float* obs_out);
+int fs_reset_dev(fs_handle h, const uint8_t* mask_dev, float* obs_dev);
+
+/* ---- step ----------------------------------------------------------------
+ * Env.step (flow/envs/base.py:294-412) for all R replicas: sims_per_step
+ * sub-steps of {controllers -> fail-safes -> apply_acceleration
+ * (vehicle/traci.py:952-963) -> simulation_step (simulation/traci.py:54-56)
+ * -> vehicle update (vehicle/traci.py:119-259) -> check_collision}, then
+ * get_state / compute_reward / done.
+ *   actions  real32[R,num_rl] or NULL (reference: rl_actions=None)
+ *   obs      real32[R,obs_dim]     rew  real32[R]     done  uint8[R]
+ * Observations are float32 as in the reference's Box(dtype=np.float32). */
+int fs_step(fs_handle h, const float* actions, float* obs, float* rew, uint8_t* done);
+int fs_step_dev(fs_handle h, const float* actions_dev, float* obs_dev, float* rew_dev, uint8_t* done_dev);
+
+/* K consecutive Env.step calls in one launch (state stays in registers).
+ *   actions_dev  real32[K,R,num_rl] (action_stride_steps = R*num_rl),
+ *                or one real32[R,num_rl] reused every step (stride 0), or NULL
+ *   obs_dev      real32[K,R,obs_dim] if obs_every_step, else real32[R,obs_dim] (last step)
+ *   rew_dev      real32[K,R] / real32[R]      done_dev uint8[K,R] / uint8[R]
+ * A replica that is done keeps stepping (the caller resets it, as
+ * Experiment.run / RLlib do after `done`, flow/core/experiment.py:144-161). */
+int fs_rollout_dev(fs_handle h, int num_steps, const float* actions_dev, size_t action_stride_steps,
+                   float* obs_dev, float* rew_dev, uint8_t* done_dev, int obs_every_step);
+
+/* ---- state access --------------------------------------------------------
+ * dst/src are host buffers of `bytes` bytes holding the field in the
+ * handle's precision (float or double) or int32 for FS_FIELD_TIME. */
+int fs_get_state(fs_handle h, int field, void* dst, size_t bytes);
+int fs_set_state(fs_handle h, int field, const void* src, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLOWSIM_H */

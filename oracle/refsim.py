@@ -1,0 +1,315 @@
+"""Oracle restatement of Env.step / Env.reset for closed single-lane routes.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Restates, batched over R independent replicas of N vehicles, the sequence the
+reference executes in ``flow/envs/base.py:294-412`` (step) and ``:414-560``
+(reset) for RingNetwork experiments, with the SUMO side of the step written
+out explicitly (S-list in DESIGN.md):
+
+  S1  all controllers read the time-t snapshot        envs/base.py:324-371
+  S4  next_vel = max(v + acc*dt, 0)                   vehicle/traci.py:962
+  S5  acc is None -> vehicle is not commanded         vehicle/traci.py:960
+  S6  slowDown(next_vel, 1e-3) ramp                   vehicle/traci.py:963  (SUMO side, unpinned < 1e-2)
+  S9  Euler x' = x + v'*dt  (ballistic optional)      simulation/traci.py:94-96
+  S10 headway = gap to the next vehicle along the loop minus its length
+                                                      vehicle/traci.py:219-250
+  S12 crash <=> some headway < crash_gap after the move (SUMO collision, unpinned)
+  S13 reset = placement, no movement, obs, then warm-up steps with no RL action
+
+dtype float64 restates the reference (Python floats); dtype float32 is the
+bit-twin of the HIP kernels (same operation order, no contraction).
+"""
+import numpy as np
+
+from . import controllers as C
+from . import rewards as Rw
+
+# controller ids -- must equal include/flowsim.h FS_CTRL_*
+CTRL_SIM, CTRL_RL, CTRL_IDM, CTRL_CFM, CTRL_BCM, CTRL_LAC, CTRL_OVM, CTRL_LINEAR_OVM, \
+    CTRL_GIPPS, CTRL_FOLLOWER_STOPPER, CTRL_NONLOCAL_FOLLOWER_STOPPER = range(11)
+FAILSAFE_NONE, FAILSAFE_INSTANTANEOUS, FAILSAFE_SAFE_VELOCITY = range(3)
+ENV_ACCEL, ENV_WAVE_ATTENUATION, ENV_WAVE_ATTENUATION_PO = range(3)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox-4x32-10 (Salmon et al., SC'11), vectorised; all args uint32 arrays."""
+    M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+    W0, W1 = np.uint32(0x9E3779B9), np.uint32(0xBB67AE85)
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint32) for c in (c0, c1, c2, c3))
+    k0 = np.asarray(k0, dtype=np.uint32)
+    k1 = np.asarray(k1, dtype=np.uint32)
+    for _ in range(10):
+        p0 = M0 * c0.astype(np.uint64)
+        p1 = M1 * c2.astype(np.uint64)
+        hi0, lo0 = (p0 >> np.uint64(32)).astype(np.uint32), p0.astype(np.uint32)
+        hi1, lo1 = (p1 >> np.uint64(32)).astype(np.uint32), p1.astype(np.uint32)
+        c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+        with np.errstate(over="ignore"):
+            k0 = k0 + W0
+            k1 = k1 + W1
+    return c0, c1, c2, c3
+
+
+def gaussian_noise(seed, replica, vehicle, step, dtype):
+    """N(0,1) per (replica, vehicle, step): Philox keyed by the 64-bit seed,
+    counter (step, vehicle, replica, 0); Box-Muller on the first two words.
+    Shared definition with the kernels (flowsim.hip: fs_gauss)."""
+    seed = int(seed)
+    k0 = np.uint32(seed & 0xFFFFFFFF)
+    k1 = np.uint32((seed >> 32) & 0xFFFFFFFF)
+    r0, r1, _, _ = philox4x32_10(step, vehicle, replica, np.zeros_like(replica), k0, k1)
+    # u1 in (0,1], u2 in [0,1)
+    u1 = ((r0 >> np.uint32(8)).astype(np.float64) + 1.0) * (1.0 / 16777216.0)
+    u2 = (r1 >> np.uint32(8)).astype(np.float64) * (1.0 / 16777216.0)
+    u1 = u1.astype(dtype)
+    u2 = u2.astype(dtype)
+    two_pi = np.asarray(6.283185307179586, dtype)
+    return np.sqrt(np.asarray(-2.0, dtype) * np.log(u1)) * np.cos(two_pi * u2)
+
+
+class RingOracle:
+    """Batched closed-loop (ring) oracle.  ``spec`` is a plain dict:
+
+    num_replicas R, num_vehicles N, sim_step, slowdown_ramp, integrator
+    ('euler'|'ballistic'), junction_mode (0|1), junction_length, crash_gap,
+    ring_length [R] (sum of the four edges), max_speed, env, target_velocity,
+    action_low/high, clip_actions, evaluate, po_max_length, horizon,
+    warmup_steps, sims_per_step, seed, init_pos [R,N], init_vel [R,N],
+    vehicles: list of N dicts {controller, p[8], fail_safe, noise, delay,
+    max_accel, max_decel, length, speed_mode, sumo_tau, sumo_min_gap,
+    sumo_max_speed, rl_index}.
+    """
+
+    def __init__(self, spec, dtype=np.float64):
+        self.spec = spec
+        self.dt_ = np.dtype(dtype)
+        T = self.dt_.type
+        self.R = int(spec["num_replicas"])
+        self.N = int(spec["num_vehicles"])
+        self.dt = float(spec["sim_step"])
+        self.ramp = T(spec.get("slowdown_ramp", self.dt / (self.dt + 1e-3)))
+        self.ballistic = spec.get("integrator", "euler") == "ballistic"
+        self.junction_mode = int(spec.get("junction_mode", 0))
+        self.jlen = float(spec.get("junction_length", 0.1))
+        self.crash_gap = T(spec.get("crash_gap", 0.0))
+        base = np.broadcast_to(np.asarray(spec["ring_length"], dtype=np.float64), (self.R,))
+        self.base_len = base.astype(self.dt_)                        # edges only
+        self.L = self.base_len + T(4) * T(self.jlen)                 # network.length(), in T like the kernel
+        self.veh = spec["vehicles"]
+        self.veh_len = np.array([v.get("length", 5.0) for v in self.veh], dtype=self.dt_)
+        self.rl_slots = [None] * int(spec.get("num_rl", 0))
+        for i, v in enumerate(self.veh):
+            if v["controller"] == CTRL_RL:
+                self.rl_slots[v["rl_index"]] = i
+        self.init_pos = np.asarray(spec["init_pos"], dtype=np.float64).astype(self.dt_).reshape(self.R, self.N)
+        iv = spec.get("init_vel")
+        if iv is None:
+            iv = np.broadcast_to(np.array([v.get("initial_speed", 0.0) for v in self.veh]),
+                                 (self.R, self.N))
+        self.init_vel = np.asarray(iv, dtype=np.float64).astype(self.dt_).reshape(self.R, self.N)
+        self.x = self.init_pos.copy()
+        self.v = self.init_vel.copy()
+        self.prev_v = self.v.copy()
+        self.lac_a = np.zeros((self.R, self.N), dtype=self.dt_)
+        self.time_counter = np.zeros(self.R, dtype=np.int64)
+        self.step_counter = np.zeros(self.R, dtype=np.int64)   # noise stream position
+        self.last_accel = np.zeros((self.R, self.N), dtype=self.dt_)
+        self.last_commanded = np.zeros((self.R, self.N), dtype=bool)
+
+    # ------------------------------------------------------------------ S10
+    def headways(self, x=None):
+        """h[r,i] = (x_lead - x_i) mod L - len_lead; leader = slot i+1 (cyclic)."""
+        x = self.x if x is None else x
+        T = self.dt_.type
+        if self.N == 1:
+            return np.full((self.R, 1), T(1000.0))                   # vehicle/traci.py:237
+        d = np.roll(x, -1, axis=1) - x
+        d = np.where(d < 0, d + self.L[:, None], d)
+        return d - np.roll(self.veh_len, -1)[None, :]
+
+    def in_junction(self, x):
+        """True where the front of the vehicle is on an internal edge
+        (networks/ring.py:211-214 tables; base_controller.py:98-99)."""
+        base = self.base_len if np.ndim(x) == 1 else self.base_len[:, None]
+        quarter = base / self.dt_.type(4)
+        q = quarter + self.dt_.type(self.jlen)
+        u = x - np.floor(x / q) * q
+        return u >= quarter
+
+    # ------------------------------------------------------------------ reset
+    def reset(self, mask=None):
+        m = np.ones(self.R, dtype=bool) if mask is None else np.asarray(mask, dtype=bool)
+        self.x[m] = self.init_pos[m]
+        self.v[m] = self.init_vel[m]
+        self.prev_v[m] = self.init_vel[m]
+        self.lac_a[m] = 0
+        self.time_counter[m] = 0
+        obs = self.get_state()
+        for _ in range(int(self.spec.get("warmup_steps", 0))):       # envs/base.py:554-555
+            obs, _, _ = self.step(None, _mask=m)
+        return obs
+
+    # ------------------------------------------------------------------ step
+    def _accelerations(self, actions, active):
+        """Returns (acc [R,N], commanded [R,N])."""
+        T = self.dt_.type
+        R, N = self.R, self.N
+        x, v = self.x, self.v
+        has_lead = np.full((R, N), N > 1)
+        h = self.headways()
+        v_lead = np.roll(v, -1, axis=1) if N > 1 else v
+        v_follow = np.roll(v, 1, axis=1)
+        h_follow = np.roll(h, 1, axis=1)
+        acc = np.zeros((R, N), dtype=self.dt_)
+        commanded = np.zeros((R, N), dtype=bool)
+        mean_speed = None
+        for i, vs in enumerate(self.veh):
+            ct = vs["controller"]
+            p = vs.get("p", [0] * 8)
+            sl = (slice(None), i)
+            a = None
+            if ct == CTRL_SIM:
+                continue
+            if ct == CTRL_RL:
+                if actions is None:
+                    continue
+                a = np.asarray(actions, dtype=self.dt_)[:, vs["rl_index"]]
+                if self.spec.get("clip_actions", True):              # envs/base.py:584-588
+                    a = np.clip(a, T(self.spec["action_low"]), T(self.spec["action_high"]))
+                acc[sl] = a
+                commanded[sl] = True
+                continue
+            args = (v[sl], v_lead[sl], h[sl], has_lead[sl])
+            if ct == CTRL_IDM:
+                a = C.idm(*args, v0=p[0], T=p[1], a=p[2], b=p[3], delta=p[4], s0=p[5])
+            elif ct == CTRL_CFM:
+                a = C.cfm(*args, vs["max_accel"], k_d=p[0], k_v=p[1], k_c=p[2], d_des=p[3], v_des=p[4])
+            elif ct == CTRL_BCM:
+                a = C.bcm(*args, v_follow[sl], h_follow[sl], vs["max_accel"],
+                          k_d=p[0], k_v=p[1], k_c=p[2], d_des=p[3], v_des=p[4])
+            elif ct == CTRL_LAC:
+                a = C.lac(v[sl], v_lead[sl], h[sl], self.veh_len[i], self.lac_a[sl], self.dt,
+                          k_1=p[0], k_2=p[1], h_gap=p[2], tau=p[3])
+            elif ct == CTRL_OVM:
+                a = C.ovm(*args, vs["max_accel"], alpha=p[0], beta=p[1], h_st=p[2], h_go=p[3], v_max=p[4])
+            elif ct == CTRL_LINEAR_OVM:
+                a = C.linear_ovm(v[sl], h[sl], v_max=p[0], adaptation=p[1], h_st=p[2])
+            elif ct == CTRL_GIPPS:
+                a = C.gipps(v[sl], v_lead[sl], h[sl], self.dt, v0=p[0], acc=p[1], b=p[2], b_l=p[3],
+                            s0=p[4], tau=p[5])
+            elif ct == CTRL_FOLLOWER_STOPPER:
+                a = C.follower_stopper(*args, self.dt, v_des=p[0])
+            elif ct == CTRL_NONLOCAL_FOLLOWER_STOPPER:
+                if mean_speed is None:
+                    mean_speed = Rw.tree_sum(v) / T(N)               # velocity_controllers.py:127
+                a = C.follower_stopper(*args, self.dt, v_des=mean_speed)
+            else:
+                raise ValueError("unknown controller %r" % ct)
+            cmd = np.ones(R, dtype=bool)
+            if self.junction_mode:                                   # base_controller.py:98-99
+                cmd = ~self.in_junction(x[sl])
+            if ct == CTRL_LAC:                                       # state only advances when get_accel ran
+                self.lac_a[sl] = np.where(cmd & active, a, self.lac_a[sl])
+            if vs.get("noise", 0) > 0:                               # base_controller.py:109-110
+                g = gaussian_noise(self.spec.get("seed", 0), np.arange(R, dtype=np.uint32),
+                                   np.full(R, i, dtype=np.uint32),
+                                   self.step_counter.astype(np.uint32), self.dt_)
+                a = a + T(vs["noise"]) * g
+            fs = vs.get("fail_safe", FAILSAFE_NONE)
+            if fs == FAILSAFE_INSTANTANEOUS:                         # base_controller.py:113-114
+                a = C.failsafe_instantaneous(a, v[sl], h[sl], has_lead[sl], self.dt, N)
+            elif fs == FAILSAFE_SAFE_VELOCITY:                       # base_controller.py:115-116
+                a = C.failsafe_safe_velocity(a, v[sl], v_lead[sl], h[sl], self.dt, vs.get("delay", 0), N)
+            acc[sl] = a
+            commanded[sl] = cmd
+        return acc, commanded, h, v_lead, has_lead
+
+    def _substep(self, actions, active):
+        T = self.dt_.type
+        dt = T(self.dt)
+        acc, commanded, h, v_lead, has_lead = self._accelerations(actions, active)
+        v = self.v
+        next_vel = np.maximum(v + acc * dt, T(0))                    # vehicle/traci.py:962
+        v_cmd = v + (next_vel - v) * self.ramp                       # S6
+        v_new = v.copy()
+        for i, vs in enumerate(self.veh):
+            sl = (slice(None), i)
+            v_sumo = C.sumo_idm_speed(v[sl], v_lead[sl], h[sl], has_lead[sl], self.dt,
+                                      accel=vs["max_accel"], decel=vs["max_decel"],
+                                      tau=vs.get("sumo_tau", 1.0), min_gap=vs.get("sumo_min_gap", 2.5),
+                                      max_speed=vs.get("sumo_max_speed", 30.0))
+            vc = v_cmd[sl]
+            mode = int(vs.get("speed_mode", 0))
+            if mode & 1:                                             # S8 bit0: regard safe speed
+                vc = np.minimum(vc, v_sumo)
+            if mode & 2:                                             # bit1: regard max accel
+                vc = np.minimum(vc, v[sl] + T(vs["max_accel"]) * dt)
+            if mode & 4:                                             # bit2: regard max decel
+                vc = np.maximum(vc, v[sl] - T(vs["max_decel"]) * dt)
+            v_new[sl] = np.where(commanded[sl], vc, v_sumo)
+        if self.ballistic:
+            x_new = self.x + (v + v_new) / T(2) * dt
+        else:
+            x_new = self.x + v_new * dt                              # S9
+        x_new = np.where(x_new >= self.L[:, None], x_new - self.L[:, None], x_new)
+        a2 = active[:, None]
+        self.prev_v = np.where(a2, v, self.prev_v)
+        self.x = np.where(a2, x_new, self.x)
+        self.v = np.where(a2, v_new, self.v)
+        self.last_accel = np.where(a2, acc, self.last_accel)
+        self.last_commanded = np.where(a2, commanded, self.last_commanded)
+        self.time_counter = self.time_counter + active
+        self.step_counter = self.step_counter + active
+        h_new = self.headways()
+        crash = np.any(h_new < self.crash_gap, axis=1) if self.N > 1 else np.zeros(self.R, bool)
+        return crash & active
+
+    def step(self, actions=None, _mask=None):
+        """Env.step for every replica (or those in ``_mask``): returns
+        (obs [R,obs_dim], reward [R], done [R])."""
+        active = np.ones(self.R, dtype=bool) if _mask is None else _mask.copy()
+        crashed = np.zeros(self.R, dtype=bool)
+        for _ in range(int(self.spec.get("sims_per_step", 1))):      # envs/base.py:324
+            c = self._substep(actions, active & ~crashed)
+            crashed |= c                                             # :381-382 break
+        obs = self.get_state()
+        horizon = self.spec.get("horizon", float("inf"))
+        limit = self.spec.get("sims_per_step", 1) * (self.spec.get("warmup_steps", 0) + horizon)
+        done = (self.time_counter >= limit) | crashed                # :398-400
+        reward = self.compute_reward(actions, crashed)
+        return obs, reward, done
+
+    # ------------------------------------------------------------------ env heads
+    def get_state(self):
+        T = self.dt_.type
+        env = self.spec.get("env", ENV_ACCEL)
+        if env in (ENV_ACCEL, ENV_WAVE_ATTENUATION):
+            # accel.py:116-123 / wave_attenuation.py:141-148
+            speed = self.v / T(self.spec["max_speed"])
+            pos = self.x / self.L[:, None]
+            return np.concatenate([speed, pos], axis=1)
+        if env == ENV_WAVE_ATTENUATION_PO:                           # wave_attenuation.py:248-269
+            i = self.rl_slots[0]
+            j = (i + 1) % self.N                                     # get_leader(rl_id) or rl_id
+            max_speed = T(15.)
+            max_length = T(self.spec["po_max_length"])
+            d = self.x[:, j] - self.x[:, i]
+            d = np.where(d < 0, d + self.L, d)                       # % network.length()
+            return np.stack([self.v[:, i] / max_speed,
+                             (self.v[:, j] - self.v[:, i]) / max_speed,
+                             d / max_length], axis=1)
+        raise ValueError(env)
+
+    def compute_reward(self, actions, fail):
+        env = self.spec.get("env", ENV_ACCEL)
+        T = self.dt_.type
+        if env == ENV_ACCEL:                                         # accel.py:109-114
+            if self.spec.get("evaluate", False):
+                return Rw.tree_sum(self.v) / T(self.N)
+            return Rw.desired_velocity(self.v, self.spec["target_velocity"], fail)
+        a = actions
+        if a is not None and self.spec.get("clip_actions", True):    # envs/base.py:406-408
+            a = np.clip(np.asarray(a, dtype=self.dt_), T(self.spec["action_low"]),
+                        T(self.spec["action_high"]))
+        return Rw.wave_attenuation_reward(self.v, a, fail)

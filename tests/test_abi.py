@@ -1,0 +1,85 @@
+"""CPU-side checks of the drop-in boundary: libflowsim.so loads, exports every symbol
+include/flowsim.h declares, and the ctypes mirror has the C layout (no compute calls)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "flowsim.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from flow_amd import build
+    build.build()
+    from flow_amd import _lib
+    return _lib.load()
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fs_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_entry_points():
+    from flow_amd import _lib
+    assert declared_symbols() == sorted(_lib.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol(lib):
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+    assert lib.fs_abi_version() == 1
+
+
+def test_ctypes_layout_matches_the_c_header(tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "flowsim.h"\n'
+                   'int main(void){printf("%zu %zu %zu %zu %zu\\n", sizeof(fs_config), sizeof(fs_vehicle_spec),'
+                   ' offsetof(fs_config, seed), offsetof(fs_config, vehicles), offsetof(fs_vehicle_spec, noise));'
+                   'return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    from flow_amd import _lib
+    assert int(out[0]) == ctypes.sizeof(_lib.fs_config)
+    assert int(out[1]) == ctypes.sizeof(_lib.fs_vehicle_spec)
+    assert int(out[2]) == _lib.fs_config.seed.offset
+    assert int(out[3]) == _lib.fs_config.vehicles.offset
+    assert int(out[4]) == _lib.fs_vehicle_spec.noise.offset
+
+
+def test_enums_agree_between_header_binding_and_oracle():
+    from flow_amd import _lib
+    from oracle import refsim as S
+    text = open(HEADER).read()
+
+    def enum_val(name):
+        m = re.search(r"\b%s\s*=\s*(-?\d+)" % name, text)
+        assert m, name
+        return int(m.group(1))
+    for n in ("SIM", "RL", "IDM", "CFM", "BCM", "LAC", "OVM", "LINEAR_OVM", "GIPPS", "FOLLOWER_STOPPER",
+              "NONLOCAL_FOLLOWER_STOPPER"):
+        assert enum_val("FS_CTRL_" + n) == getattr(_lib, "FS_CTRL_" + n) == getattr(S, "CTRL_" + n)
+    for n in ("ACCEL", "WAVE_ATTENUATION", "WAVE_ATTENUATION_PO"):
+        assert enum_val("FS_ENV_" + n) == getattr(_lib, "FS_ENV_" + n) == getattr(S, "ENV_" + n)
+    for n in ("NONE", "INSTANTANEOUS", "SAFE_VELOCITY"):
+        assert enum_val("FS_FAILSAFE_" + n) == getattr(_lib, "FS_FAILSAFE_" + n) == getattr(S, "FAILSAFE_" + n)
+
+
+def test_create_fails_loudly_without_a_gpu(lib):
+    """No CPU fallback: on a box without a HIP device fs_create must return an error."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import ring_spec
+    from flow_amd.sim import FlowSim
+    from flow_amd.utils.exceptions import FatalFlowError
+    with pytest.raises(FatalFlowError):
+        FlowSim(ring_spec(R=1, N=5, bunching=0), "f32")

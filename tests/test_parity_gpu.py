@@ -1,0 +1,269 @@
+"""GPU parity: the HIP path (through the C ABI, via flow_amd.sim.FlowSim) against
+the CPU oracle on the same seeded inputs.
+
+Bars (DESIGN.md "Parity"):
+  * float32 kernels vs the float32 oracle twin: bit-exact for controllers built
+    from + - * / sqrt (IDM, CFM, BCM, LAC, LinearOVM, Gipps, FollowerStopper,
+    fail-safes, integrator, observation, reward); 1e-5 where a libm function
+    (cos, log, pow) is involved (OVM, noise, non-integer IDM delta).
+  * float64 kernels vs the float64 oracle (the reference's arithmetic):
+    <= 1e-9 on positions / speeds over 1500 steps (north_star bar: 1e-4).
+"""
+import numpy as np
+import pytest
+
+from helpers import idm_vehicle, ring_spec
+from oracle import refsim as S
+
+pytestmark = pytest.mark.gpu
+
+
+def make(spec, precision):
+    from flow_amd.sim import FlowSim
+    return FlowSim(spec, precision=precision)
+
+
+def perturbed(spec, seed=0, sigma=0.5):
+    rng = np.random.default_rng(seed)
+    R, N = spec["num_replicas"], spec["num_vehicles"]
+    spec = dict(spec)
+    spec["init_pos"] = np.asarray(spec["init_pos"]) + np.abs(rng.normal(0, sigma, (R, N)))
+    return spec
+
+
+def run_pair(spec, precision, steps, actions=None, check_every=1, exact=True, atol=0.0):
+    dtype = np.float32 if precision == "f32" else np.float64
+    ora = S.RingOracle(spec, dtype)
+    sim = make(spec, precision)
+    o_ref = ora.reset()
+    o_gpu = sim.reset()
+    cmp = np.testing.assert_array_equal if exact else (lambda a, b: np.testing.assert_allclose(a, b, rtol=0, atol=atol))
+    cmp(o_gpu, o_ref.astype(np.float32))
+    for k in range(steps):
+        a = None if actions is None else actions[k]
+        o_ref, r_ref, d_ref = ora.step(a)
+        o_gpu, r_gpu, d_gpu = sim.step(a)
+        if k % check_every == 0 or k == steps - 1:
+            cmp(sim.pos, ora.x)
+            cmp(sim.vel, ora.v)
+            cmp(o_gpu, o_ref.astype(np.float32))
+            cmp(r_gpu, r_ref.astype(np.float32))
+            np.testing.assert_array_equal(d_gpu, d_ref)
+    np.testing.assert_array_equal(sim.time_counter, ora.time_counter)
+    sim.close()
+    return ora
+
+
+def test_c1_ring_f32_bit_exact_300_steps():
+    spec = ring_spec(R=1, N=22, junction_length=0.1, horizon=1500)
+    run_pair(spec, "f32", 300)
+
+
+def test_c2_shape_small_f32_bit_exact():
+    spec = perturbed(ring_spec(R=37, N=22, junction_length=0.1, horizon=200), seed=1)
+    run_pair(spec, "f32", 200, check_every=20)
+
+
+def test_c1_ring_f64_matches_reference_arithmetic_1500_steps():
+    spec = ring_spec(R=2, N=22, junction_length=0.1, horizon=1500)
+    ora = run_pair(spec, "f64", 1500, check_every=100, exact=False, atol=1e-9)
+    assert ora.v.max() > 1.0       # the ring actually developed traffic
+
+
+def test_f32_tracks_f64_reference_within_stated_budget():
+    # fp32 state cannot hold 1e-4 over 1500 steps of an unstable ring (DESIGN.md "Precision");
+    # the stated budget is 1e-4 for the first 200 steps and 1e-2 over the full horizon.
+    spec = ring_spec(R=4, N=22, junction_length=0.1, horizon=1500)
+    ora = S.RingOracle(spec, np.float64)
+    sim = make(spec, "f32")
+    ora.reset(), sim.reset()
+    for k in range(1500):
+        ora.step(None), sim.step(None)
+        if k == 199:
+            d = np.abs(sim.pos - ora.x)
+            assert np.minimum(d, 230.4 - d).max() < 1e-4
+            assert np.abs(sim.vel - ora.v).max() < 1e-4
+    d = np.abs(sim.pos - ora.x)
+    assert np.minimum(d, 230.4 - d).max() < 1e-2
+    assert np.abs(sim.vel - ora.v).max() < 1e-2
+    sim.close()
+
+
+@pytest.mark.parametrize("N", [1, 2, 5, 8, 9, 16, 17, 22, 33, 64])
+def test_ragged_vehicle_counts(N):
+    L = max(230.0, 8.0 * N)
+    spec = perturbed(ring_spec(R=5, N=N, length=L, bunching=0, junction_length=0.1, horizon=30), seed=N, sigma=0.2)
+    run_pair(spec, "f32", 40, check_every=5)
+
+
+def test_single_replica_and_odd_replica_counts():
+    for R in (1, 3, 63, 65):
+        spec = perturbed(ring_spec(R=R, N=14, length=150.0, bunching=0, horizon=20), seed=R, sigma=0.2)
+        run_pair(spec, "f32", 25, check_every=5)
+
+
+CTRL_CASES = {
+    "cfm": dict(controller=S.CTRL_CFM, p=[1, 1, 1, 1, 8, 0, 0, 0], max_accel=20, max_decel=5),
+    "bcm": dict(controller=S.CTRL_BCM, p=[1, 1, 1, 1, 8, 0, 0, 0], max_accel=15, max_decel=5),
+    "lac": dict(controller=S.CTRL_LAC, p=[0.3, 0.4, 1, 0.1, 0, 0, 0, 0]),
+    "linear_ovm": dict(controller=S.CTRL_LINEAR_OVM, p=[30, 0.65, 5, 0, 0, 0, 0, 0]),
+    "gipps": dict(controller=S.CTRL_GIPPS, p=[30, 1.5, -1, -1, 2, 1, 0, 0]),
+    "follower_stopper": dict(controller=S.CTRL_FOLLOWER_STOPPER, p=[7.5, 0, 0, 0, 0, 0, 0, 0],
+                             fail_safe=S.FAILSAFE_SAFE_VELOCITY, delay=1.0),
+    "nonlocal_follower_stopper": dict(controller=S.CTRL_NONLOCAL_FOLLOWER_STOPPER, p=[7.5, 0, 0, 0, 0, 0, 0, 0],
+                                      fail_safe=S.FAILSAFE_SAFE_VELOCITY, delay=1.0),
+    "idm_instantaneous": dict(fail_safe=S.FAILSAFE_INSTANTANEOUS),
+    "idm_safe_velocity": dict(fail_safe=S.FAILSAFE_SAFE_VELOCITY, delay=0.5),
+    "idm_delta2": dict(p=[30, 1, 1, 1.5, 2, 2, 0, 0]),
+}
+
+
+@pytest.mark.parametrize("name", list(CTRL_CASES))
+def test_controllers_f32_bit_exact(name):
+    N = 10
+    spec = perturbed(ring_spec(R=9, N=N, length=200.0, bunching=30, horizon=120), seed=5, sigma=0.3)
+    # half the ring runs the controller under test, the rest stays IDM (mixed waves diverge per lane)
+    spec["vehicles"] = [idm_vehicle(**CTRL_CASES[name]) if i % 2 == 0 else idm_vehicle() for i in range(N)]
+    spec["track_aux"] = True
+    run_pair(spec, "f32", 120, check_every=10)
+
+
+def test_ovm_within_libm_tolerance():
+    N = 10
+    spec = perturbed(ring_spec(R=6, N=N, length=200.0, bunching=30, horizon=100), seed=6, sigma=0.3)
+    spec["vehicles"] = [idm_vehicle(controller=S.CTRL_OVM, p=[1, 1, 2, 15, 30, 0, 0, 0], max_accel=15, max_decel=5,
+                                    fail_safe=S.FAILSAFE_SAFE_VELOCITY) for _ in range(N)]
+    run_pair(spec, "f32", 100, check_every=10, exact=False, atol=2e-4)
+    run_pair(spec, "f64", 100, check_every=10, exact=False, atol=1e-9)
+
+
+def test_noise_stream_matches_oracle_philox():
+    N = 8
+    spec = perturbed(ring_spec(R=16, N=N, length=150.0, bunching=0, horizon=50), seed=7, sigma=0.2)
+    spec["vehicles"] = [idm_vehicle(noise=0.2) for _ in range(N)]
+    spec["seed"] = 0x1234567890ABCDEF
+    run_pair(spec, "f64", 50, check_every=5, exact=False, atol=1e-9)
+    run_pair(spec, "f32", 50, check_every=5, exact=False, atol=5e-4)
+
+
+def test_rl_actions_clip_and_wave_attenuation_po():
+    N = 22
+    R = 12
+    spec = perturbed(ring_spec(R=R, N=N, length=260.0, bunching=50, junction_length=0.1, horizon=60,
+                               env=S.ENV_WAVE_ATTENUATION_PO, num_rl=1, action_low=-1.0, action_high=1.0,
+                               po_max_length=270.0, warmup_steps=15), seed=8)
+    veh = [idm_vehicle(sumo_min_gap=0.0) for _ in range(N - 1)]
+    veh.append(idm_vehicle(controller=S.CTRL_RL, rl_index=0))
+    spec["vehicles"] = veh
+    rng = np.random.default_rng(3)
+    actions = rng.uniform(-1.5, 1.5, (60, R, 1)).astype(np.float32)
+    run_pair(spec, "f32", 60, actions=actions, check_every=5)
+    spec["clip_actions"] = False
+    spec["env"] = S.ENV_WAVE_ATTENUATION
+    run_pair(spec, "f32", 30, actions=actions, check_every=5)
+
+
+def test_speed_mode_junction_mode_ballistic_sims_per_step():
+    N = 12
+    spec = perturbed(ring_spec(R=7, N=N, length=150.0, bunching=10, junction_length=0.1, horizon=40,
+                               junction_mode=1, integrator="ballistic", sims_per_step=3), seed=9, sigma=0.2)
+    spec["vehicles"] = [idm_vehicle(speed_mode=m) for m in (0, 1, 7, 25, 31, 0, 1, 7, 25, 31, 6, 2)]
+    run_pair(spec, "f32", 40, check_every=4)
+
+
+def test_crash_ends_episode_and_zeroes_reward():
+    N = 6
+    spec = ring_spec(R=4, N=N, length=60.0, bunching=0, horizon=500)
+    # a vehicle that never brakes (CFM with huge desired speed) rear-ends its leader
+    spec["vehicles"] = [idm_vehicle() for _ in range(N)]
+    spec["vehicles"][2] = idm_vehicle(controller=S.CTRL_CFM, p=[0, 0, 5, 0, 60, 0, 0, 0], max_accel=20)
+    ora = S.RingOracle(spec, np.float32)
+    sim = make(spec, "f32")
+    ora.reset(), sim.reset()
+    crashed = False
+    for _ in range(200):
+        o_ref, r_ref, d_ref = ora.step(None)
+        o_gpu, r_gpu, d_gpu = sim.step(None)
+        np.testing.assert_array_equal(d_gpu, d_ref)
+        np.testing.assert_array_equal(r_gpu, r_ref.astype(np.float32))
+        if d_ref.any():
+            crashed = True
+            assert (r_gpu[d_gpu] == 0).all()
+            break
+    assert crashed
+    sim.close()
+
+
+def test_masked_reset_and_warmup():
+    spec = perturbed(ring_spec(R=10, N=9, length=120.0, bunching=0, horizon=50, warmup_steps=6), seed=11, sigma=0.2)
+    ora = S.RingOracle(spec, np.float32)
+    sim = make(spec, "f32")
+    np.testing.assert_array_equal(sim.reset(), ora.reset().astype(np.float32))
+    for _ in range(7):
+        ora.step(None), sim.step(None)
+    mask = np.zeros(10, dtype=bool)
+    mask[[1, 4, 9]] = True
+    np.testing.assert_array_equal(sim.reset(mask), ora.reset(mask).astype(np.float32))
+    np.testing.assert_array_equal(sim.pos, ora.x)
+    np.testing.assert_array_equal(sim.time_counter, ora.time_counter)
+    for _ in range(5):
+        o_ref, r_ref, d_ref = ora.step(None)
+        o_gpu, r_gpu, d_gpu = sim.step(None)
+    np.testing.assert_array_equal(o_gpu, o_ref.astype(np.float32))
+    np.testing.assert_array_equal(sim.headway, ora.headways())
+    sim.close()
+
+
+def test_rollout_equals_repeated_steps_and_full_size_properties():
+    """C2 at full size (4096 x 22): K-step launch == K one-step launches bit for bit; ring invariants."""
+    import torch
+    R, N, K = 4096, 22, 64
+    spec = perturbed(ring_spec(R=R, N=N, junction_length=0.1, horizon=1500), seed=12)
+    a = make(spec, "f32")
+    b = make(spec, "f32")
+    a.reset(), b.reset()
+    dev = torch.device("cuda:0")
+    obs = torch.empty((K, R, 2 * N), dtype=torch.float32, device=dev)
+    rew = torch.empty((K, R), dtype=torch.float32, device=dev)
+    done = torch.empty((K, R), dtype=torch.uint8, device=dev)
+    a.rollout_dev(K, obs, rew, done, obs_every_step=True)
+    a.sync()
+    for k in range(K):
+        o, r, d = b.step(None)
+        if k in (0, K // 2, K - 1):
+            np.testing.assert_array_equal(obs[k].cpu().numpy(), o)
+            np.testing.assert_array_equal(rew[k].cpu().numpy(), r)
+    np.testing.assert_array_equal(a.pos, b.pos)
+    np.testing.assert_array_equal(a.vel, b.vel)
+    # size-independent properties: positions stay on the loop, gaps sum to L - N*len, order is kept
+    x, h = a.pos, a.headway
+    assert (x >= 0).all() and (x < 230.4).all()
+    np.testing.assert_allclose(h.sum(axis=1), 230.4 - 5.0 * N, atol=2e-3)
+    assert (h > 0).all()
+    # and a seeded sample of replicas against the oracle
+    idx = np.array([0, 1, 777, 2048, 4095])
+    sub = dict(spec)
+    sub["num_replicas"] = len(idx)
+    sub["init_pos"] = np.asarray(spec["init_pos"])[idx]
+    sub["ring_length"] = np.asarray(spec["ring_length"])[idx]
+    ora = S.RingOracle(sub, np.float32)
+    ora.reset()
+    for _ in range(K):
+        ora.step(None)
+    np.testing.assert_array_equal(a.pos[idx], ora.x)
+    np.testing.assert_array_equal(a.vel[idx], ora.v)
+    a.close(), b.close()
+
+
+def test_abi_rejects_bad_configs():
+    spec = ring_spec(R=2, N=5, bunching=0)
+    bad = dict(spec)
+    bad["vehicles"] = [idm_vehicle(controller=99) for _ in range(5)]
+    with pytest.raises(ValueError):
+        make(bad, "f32")
+    bad = ring_spec(R=2, N=5, bunching=0, length=20.0) if False else dict(spec)
+    bad["ring_length"] = np.full(2, 20.0)
+    bad["init_pos"] = np.tile(np.arange(5) * 3.0, (2, 1))
+    from flow_amd.utils.exceptions import FatalFlowError
+    with pytest.raises(FatalFlowError):
+        make(bad, "f32")
