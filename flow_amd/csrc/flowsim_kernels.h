@@ -72,8 +72,10 @@ struct DevView {
 // ---------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ T tmax(T a, T b) { return a > b ? a : b; }   // np.maximum (no NaN)
 template <typename T> __device__ __forceinline__ T tmin(T a, T b) { return a < b ? a : b; }   // np.minimum (no NaN)
-__device__ __forceinline__ float tsqrt(float x) { return __fsqrt_rn(x); }
-__device__ __forceinline__ double tsqrt(double x) { return __dsqrt_rn(x); }
+// __builtin_sqrt* is correctly rounded under hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt;
+// __fsqrt_rn is NOT (it maps to the native 1-ulp v_sqrt_f32 in this toolchain).
+__device__ __forceinline__ float tsqrt(float x) { return __builtin_sqrtf(x); }
+__device__ __forceinline__ double tsqrt(double x) { return __builtin_sqrt(x); }
 __device__ __forceinline__ float tfloor(float x) { return floorf(x); }
 __device__ __forceinline__ double tfloor(double x) { return floor(x); }
 __device__ __forceinline__ float tabs(float x) { return fabsf(x); }
