@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the batched ring step loop (BASELINE.json configs[1], "C2").
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one Env.step of ALL replicas on every rank (controllers -> fail-safes ->
+integration -> headways -> crash check -> observation + reward + done written to HBM).
+Workload per GPU (weak scaling): 4096 RingNetwork replicas x 22 IDM vehicles, fp32,
+sim_step 0.1, AccelEnv observation [4096, 44] written EVERY step, episodes of
+`horizon` = 1500 steps; each launch of the rollout kernel advances one fragment
+(<= 1500 steps) with the state in registers, and every replica is reset
+(Env.reset) when its episode ends.  Inputs are resident in HBM before the timed
+region.  For N > 1 each rank owns its own replicas (no data-path collective inside
+a step); the only exchange is one RCCL all-gather of the fragment's final
+observation/reward/done to the learner per fragment.
+
+Prints ONE JSON line (rank 0).  Extra keys: `roofline` (dominant kernel =
+k_steps, per-launch HIP-event timing), `cpu_baseline` (oracle C port on the host
+cores, bounded sample, rank 0, N=1 only), `step_api` (one launch per env step,
+the Gym-faithful call pattern), `f64` (same workload in float64).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+IDM_DEFAULT = [30, 1, 1, 1.5, 4, 2, 0, 0]      # flow/controllers/car_following_models.py:437-447
+
+
+def c2_spec(R, N=22, seed=0, horizon=1500):
+    """ring 230 m, 22 IDM vehicles, bunching 20, per-replica N(0, 0.5 m)
+    start perturbation so replicas do not share a trajectory."""
+    from flow_amd.networks.ring import ring_start_positions
+    x0 = ring_start_positions(N, length=230.0, bunching=20.0)
+    rng = np.random.default_rng(seed)
+    pos = x0[None, :] + np.abs(rng.normal(0.0, 0.5, (R, N)))
+    veh = dict(controller=2, p=IDM_DEFAULT, fail_safe=0, noise=0.0, delay=0.0, max_accel=2.6, max_decel=4.5,
+               length=5.0, speed_mode=0, sumo_tau=1.0, sumo_min_gap=2.5, sumo_max_speed=30.0, rl_index=-1)
+    return dict(num_replicas=R, num_vehicles=N, num_rl=0, sim_step=0.1, junction_length=0.1,
+                ring_length=np.full(R, 230.0), max_speed=30.0, env=0, target_velocity=10.0,
+                action_low=-3.0, action_high=3.0, horizon=horizon, warmup_steps=0, sims_per_step=1,
+                vehicles=[dict(veh) for _ in range(N)], init_pos=pos)
+
+
+class Runner:
+    """Drives one FlowSim handle in fragments of <= horizon steps with episode resets."""
+
+    def __init__(self, spec, precision, device, fragment):
+        import torch
+        from flow_amd.sim import FlowSim
+        self.torch = torch
+        self.sim = FlowSim(spec, precision=precision, device=device.index)
+        self.sim.set_stream(torch.cuda.current_stream(device).cuda_stream)
+        self.R, self.obs_dim = self.sim.R, self.sim.obs_dim
+        self.horizon = spec["horizon"]
+        self.fragment = min(fragment, self.horizon)
+        self.obs = torch.empty((self.fragment, self.R, self.obs_dim), dtype=torch.float32, device=device)
+        self.rew = torch.empty((self.fragment, self.R), dtype=torch.float32, device=device)
+        self.done = torch.empty((self.fragment, self.R), dtype=torch.uint8, device=device)
+        self.obs0 = torch.empty((self.R, self.obs_dim), dtype=torch.float32, device=device)
+        self.t_in_episode = 0
+        self.sim.reset_dev(self.obs0)
+        self.events = []
+
+    def run(self, steps, record=False, after_fragment=None):
+        torch = self.torch
+        left = steps
+        while left > 0:
+            k = min(self.fragment, left, self.horizon - self.t_in_episode)
+            if record:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            self.sim.rollout_dev(k, self.obs, self.rew, self.done, obs_every_step=True)
+            if record:
+                e1.record()
+                self.events.append((e0, e1, k))
+            if after_fragment is not None:
+                after_fragment(self.obs[k - 1], self.rew[k - 1], self.done[k - 1])
+            self.t_in_episode += k
+            left -= k
+            if self.t_in_episode >= self.horizon:          # every replica is done: Env.reset
+                self.sim.reset_dev(self.obs0)
+                self.t_in_episode = 0
+
+    def run_step_api(self, steps):
+        for _ in range(steps):
+            self.sim.step_dev(self.obs[0], self.rew[0], self.done[0])
+            self.t_in_episode += 1
+            if self.t_in_episode >= self.horizon:
+                self.sim.reset_dev(self.obs0)
+                self.t_in_episode = 0
+
+
+def cpu_baseline(spec_fn, seconds=12.0):
+    """Oracle C port (oracle/csim) on the host cores, bounded sample of the same workload."""
+    from oracle import cbuild
+    cores = len(os.sched_getaffinity(0))
+    R = 4096
+    spec = spec_fn(R)
+    sim = cbuild.CRingIDM(spec, np.float32, threads=cores)
+    sim.rollout(20, obs_every_step=True)               # warm-up
+    chunk, done_steps, t0 = 100, 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds and done_steps < 1500:
+        sim.rollout(chunk, obs_every_step=True)
+        done_steps += chunk
+    dt = time.perf_counter() - t0
+    return {"value": R * done_steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "oracle/csim C port (float32, OpenMP over replicas, obs written every step), "
+                      "%d replicas x 22 vehicles x %d steps in %.1f s" % (R, done_steps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30000)
+    ap.add_argument("--warmup", type=int, default=3000)
+    ap.add_argument("--replicas", type=int, default=4096, help="replicas per GPU")
+    ap.add_argument("--fragment", type=int, default=1500, help="env steps per rollout launch")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline / step_api / f64 legs")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the simulation path is HIP-only (no CPU fallback)")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+
+    R = args.replicas
+    spec = c2_spec(R, seed=1000 + rank)
+    runner = Runner(spec, args.precision, device, args.fragment)
+
+    gather = None
+    if world > 1:
+        from flow_amd.dist import ObservationGather
+        gather = ObservationGather(R, runner.obs_dim, world, device)
+
+    def after_fragment(o, r, d):
+        if gather is not None:
+            gather(o, r, d)
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    runner.run(args.warmup, after_fragment=after_fragment)
+    barrier()
+    t0 = time.perf_counter()
+    runner.run(args.steps, record=True, after_fragment=after_fragment)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel (k_steps), per launch, from HIP events on its stream
+    full = [(e0.elapsed_time(e1) * 1e-3, k) for e0, e1, k in runner.events if k == runner.fragment]
+    if not full:
+        full = [(e0.elapsed_time(e1) * 1e-3, k) for e0, e1, k in runner.events]
+    k_launch = full[0][1]
+    avg_launch_s = float(np.mean([t for t, _ in full]))
+    N = spec["num_vehicles"]
+    obs_b = runner.obs_dim * 4 + 4 + 1                    # obs + reward + done, per env-step
+    state_b = N * (4 + 4) * 2 + 4 * 2                     # pos+vel read and written once per launch, time counter
+    if args.precision == "f64":
+        state_b = N * (8 + 8) * 2 + 4 * 2
+    bytes_per_launch = R * (k_launch * obs_b + state_b)
+    achieved = bytes_per_launch / avg_launch_s / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if os.path.exists(tpath) and args.precision == "f32":
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("replicas") == R and tj.get("steps_per_launch") == k_launch:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "fs::k_steps<%s,32>" % ("float" if args.precision == "f32" else "double"),
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "bytes_per_launch": bytes_per_launch, "steps_per_launch": k_launch,
+                "avg_launch_ms": avg_launch_s * 1e3, "launches_timed": len(full),
+                "bytes_per_env_step": obs_b + state_b / k_launch,
+                "survey_533B_equiv_GBs": 533.0 * R * k_launch / avg_launch_s / 1e9}
+
+    out = {"metric": "env-steps/sec", "value": world * R * args.steps / elapsed, "unit": "env-steps/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+           "config": {"workload": "C2: RingNetwork 230 m, 22 IDM vehicles, %d replicas per GPU, AccelEnv obs "
+                                  "[R,44] + reward + done written every step, episodes of 1500 steps" % R,
+                      "replicas_per_gpu": R, "vehicles": N, "sim_step": 0.1, "horizon": 1500,
+                      "fragment_steps": runner.fragment,
+                      "parallelism": "replica-sharded x%d, obs all-gather per fragment" % world},
+           "roofline": roofline}
+
+    if world == 1 and rank == 0 and not args.no_extras:
+        # the Gym-faithful call pattern: one launch per env step (state round-trips through HBM)
+        n_api = 3000
+        runner.run_step_api(300)
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t1 = time.perf_counter()
+        e0.record()
+        runner.run_step_api(n_api)
+        e1.record()
+        torch.cuda.synchronize(device)
+        dt_api = time.perf_counter() - t1
+        per_step_b = 533.0 if args.precision == "f32" else 533.0 + 352.0
+        out["step_api"] = {"value": R * n_api / dt_api, "unit": "env-steps/s", "launches": n_api,
+                           "us_per_launch_wall": dt_api / n_api * 1e6,
+                           "us_per_launch_stream": e0.elapsed_time(e1) * 1e3 / n_api,
+                           "achieved_GBs": per_step_b * R * n_api / dt_api / 1e9,
+                           "note": "fs_step_dev: 1 launch per env step, 533 B/env-step algorithmic (SURVEY 8d)"}
+        # same workload in float64 (the reference's arithmetic type)
+        other = "f64" if args.precision == "f32" else "f32"
+        r2 = Runner(c2_spec(R, seed=1000), other, device, args.fragment)
+        r2.run(1500)
+        torch.cuda.synchronize(device)
+        t2 = time.perf_counter()
+        r2.run(6000)
+        torch.cuda.synchronize(device)
+        out[other] = {"value": R * 6000 / (time.perf_counter() - t2), "unit": "env-steps/s", "steps": 6000}
+        r2.sim.close()
+        out["cpu_baseline"] = cpu_baseline(lambda r: c2_spec(r, seed=1000))
+
+    runner.sim.close()
+    if world > 1:
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,224 @@
+"""k.network: static geometry queries and initial placement.
+
+Stands where flow/core/kernel/network/{base,traci}.py stood, without the
+netconvert subprocess: edge lengths come from the Network description, internal
+(junction) edge lengths from ``junction_length``.  Host Python, as in the
+reference -- placement runs once per construction, not on the step path.
+"""
+import logging
+import random
+
+import numpy as np
+
+from flow_amd.utils.exceptions import FatalFlowError
+
+VEHICLE_LENGTH = 5          # flow/core/kernel/network/base.py:10
+
+
+class NetworkKernel(object):
+    """Geometry of one network instance (flow/core/kernel/network/traci.py:90-228, 267-359)."""
+
+    def __init__(self, network, junction_length=0.1):
+        self.network = network
+        self.orig_name = network.orig_name
+        self.name = network.name
+        self.junction_length = junction_length
+        types = {t["id"]: t for t in (network.types or [])}
+        self._edges = {}
+        for e in network.edges:
+            t = types.get(e.get("type"), {})
+            self._edges[e["id"]] = {"length": float(e["length"]),
+                                    "lanes": int(e.get("numLanes", t.get("numLanes", 1))),
+                                    "speed": float(e.get("speed", t.get("speed", 30)))}
+        first = next(iter(self._edges.values()))
+        for eid, length in network.specify_internal_edges(junction_length):
+            self._edges[eid] = {"length": float(length), "lanes": first["lanes"], "speed": first["speed"]}
+        self._edge_list = [e for e in self._edges if e[0] != ':']
+        self._junction_list = [e for e in self._edges if e[0] == ':']
+        self.edgestarts = list(network.edge_starts) if network.edge_starts is not None else None
+        if self.edgestarts is None:                                  # traci.py:188-196
+            length, self.edgestarts = 0, []
+            for eid in sorted(self._edge_list):
+                self.edgestarts.append((eid, length))
+                length += self._edges[eid]['length']
+        self.internal_edgestarts = list(network.internal_edge_starts)
+        self.internal_edgestarts_dict = dict(self.internal_edgestarts)
+        self.total_edgestarts = sorted(self.edgestarts + self.internal_edgestarts, key=lambda t: t[1])
+        self.total_edgestarts_dict = dict(self.total_edgestarts)
+        self.rts = network.routes
+
+    # ---- static queries (traci.py:267-359)
+    def get_edge(self, x):
+        for (edge, start_pos) in reversed(self.total_edgestarts):
+            if x >= start_pos:
+                return edge, x - start_pos
+
+    def get_x(self, edge, position):
+        if len(edge) == 0:
+            return -1001
+        if edge[0] == ':':
+            try:
+                return self.internal_edgestarts_dict[edge] + position
+            except KeyError:
+                return self.total_edgestarts_dict.get(edge.rsplit('_', 1)[0], -1001)
+        return self.total_edgestarts_dict[edge] + position
+
+    def edge_length(self, edge_id):
+        try:
+            return self._edges[edge_id]['length']
+        except KeyError:
+            print('Error in edge length with key', edge_id)
+            return -1001
+
+    def length(self):
+        return sum(e['length'] for e in self._edges.values())
+
+    def non_internal_length(self):
+        return sum(self._edges[e]['length'] for e in self._edge_list)
+
+    def speed_limit(self, edge_id):
+        try:
+            return self._edges[edge_id]['speed']
+        except KeyError:
+            print('Error in speed limit with key', edge_id)
+            return -1001
+
+    def num_lanes(self, edge_id):
+        try:
+            return self._edges[edge_id]['lanes']
+        except KeyError:
+            print('Error in num lanes with key', edge_id)
+            return -1001
+
+    def max_speed(self):
+        return max(self.speed_limit(e) for e in self._edge_list)
+
+    def get_edge_list(self):
+        return self._edge_list
+
+    def get_junction_list(self):
+        return self._junction_list
+
+    def next_edge(self, edge, lane):
+        order = [t[0] for t in self.total_edgestarts if t[0] in self._edges]
+        if edge not in order:
+            return []
+        return [(order[(order.index(edge) + 1) % len(order)], lane)]
+
+    def prev_edge(self, edge, lane):
+        order = [t[0] for t in self.total_edgestarts if t[0] in self._edges]
+        if edge not in order:
+            return []
+        return [(order[(order.index(edge) - 1) % len(order)], lane)]
+
+    def update(self, reset):
+        pass
+
+    def close(self):
+        pass
+
+    # ---- initial placement (base.py:221-608)
+    def generate_starting_positions(self, initial_config, num_vehicles=None):
+        num_vehicles = num_vehicles or self.network.vehicles.num_vehicles
+        if initial_config.spacing == 'uniform':
+            return self.gen_even_start_pos(initial_config, num_vehicles)
+        if initial_config.spacing == 'random':
+            return self.gen_random_start_pos(initial_config, num_vehicles)
+        if initial_config.spacing == 'custom':
+            return self.network.gen_custom_start_pos(cls=self, net_params=self.network.net_params,
+                                                     initial_config=initial_config, num_vehicles=num_vehicles)
+        raise FatalFlowError('"spacing" argument in initial_config does not contain a valid option')
+
+    def _start_pos_util(self, initial_config, num_vehicles):
+        min_gap = max(0, initial_config.min_gap)
+        bunching = initial_config.bunching
+        if bunching < 0:
+            logging.warning('"bunching" cannot be negative; setting to 0')
+            bunching = 0
+        if initial_config.edges_distribution == 'all':
+            edges = self.get_edge_list()
+        else:
+            edges = list(initial_config.edges_distribution)
+        max_lane = max(self.num_lanes(e) for e in edges)
+        lanes_distribution = initial_config.lanes_distribution
+        if lanes_distribution > max_lane:
+            lanes_distribution = max_lane
+        elif lanes_distribution < 1:
+            logging.warning('"lanes_distribution" is too small; setting to 1')
+            lanes_distribution = 1
+        usable = [e for e in edges if self.edge_length(e) > min_gap + VEHICLE_LENGTH]
+        distribution_length = sum(self.edge_length(e) * min(self.num_lanes(e), lanes_distribution)
+                                  for e in usable)
+        available_length = distribution_length - lanes_distribution * bunching - \
+            num_vehicles * (min_gap + VEHICLE_LENGTH)
+        if available_length < 0:
+            raise FatalFlowError('There is not enough space to place all vehicles in the network.')
+        return min_gap, lanes_distribution, available_length, usable
+
+    def gen_even_start_pos(self, initial_config, num_vehicles):
+        if isinstance(initial_config.edges_distribution, dict):
+            raise NotImplementedError("edges_distribution as a dict is not built")
+        min_gap, lanes_distr, available_length, available_edges = \
+            self._start_pos_util(initial_config, num_vehicles)
+        if num_vehicles == 0:
+            return [], []
+        increment = available_length / num_vehicles
+        lanes = [self.num_lanes(e) for e in self.get_edge_list()]
+        uneven_lanes = any(lanes[0] != n for n in lanes[1:])
+        x, car_count = initial_config.x0, 0
+        startpositions, startlanes = [], []
+        ordered = [t[0] for t in self.total_edgestarts]
+        while car_count < num_vehicles:
+            pos = self.get_edge(x)
+            while pos[0] in self.internal_edgestarts_dict:           # never start inside a junction
+                nxt = self.total_edgestarts[(ordered.index(pos[0]) + 1) % len(ordered)]
+                x, pos = nxt[1], (nxt[0], 0)
+            while pos[0] not in available_edges:
+                x = (x + self.edge_length(pos[0])) % self.non_internal_length()
+                pos = self.get_edge(x)
+            if uneven_lanes and pos[1] < VEHICLE_LENGTH:
+                pos = (pos[0], VEHICLE_LENGTH)
+                x += VEHICLE_LENGTH
+                increment -= (VEHICLE_LENGTH * self.num_lanes(pos[0])) / (num_vehicles - car_count)
+            for lane in range(min([self.num_lanes(pos[0]), lanes_distr])):
+                car_count += 1
+                startpositions.append(pos)
+                startlanes.append(lane)
+                if car_count == num_vehicles:
+                    break
+            x = (x + increment + VEHICLE_LENGTH + min_gap) % self.non_internal_length()
+        if initial_config.perturbation > 0:
+            for i in range(num_vehicles):
+                perturb = np.random.normal(0, initial_config.perturbation)
+                edge, pos = startpositions[i]
+                startpositions[i] = (edge, max(0, min(self.edge_length(edge), pos + perturb)))
+        return startpositions, startlanes
+
+    def gen_random_start_pos(self, initial_config, num_vehicles):
+        if isinstance(initial_config.edges_distribution, dict):
+            raise NotImplementedError("edges_distribution as a dict is not built")
+        min_gap, lanes_distr, available_length, available_edges = \
+            self._start_pos_util(initial_config, num_vehicles)
+        efs = min_gap + VEHICLE_LENGTH
+        for edge in available_edges:
+            available_length -= efs * min([self.num_lanes(edge), lanes_distr])
+        init_absolute_pos = sorted(random.random() * available_length for _ in range(num_vehicles))
+        for i in range(num_vehicles):
+            init_absolute_pos[i] += (VEHICLE_LENGTH + min_gap) * i
+        decrement, edge_indx = 0, 0
+        startpositions, startlanes = [], []
+        for i in range(num_vehicles):
+            def locate():
+                edge_i = available_edges[edge_indx]
+                span = self.edge_length(edge_i) - efs
+                pos_i = (init_absolute_pos[i] - decrement) % span
+                lane_i = int(((init_absolute_pos[i] - decrement) - pos_i) / span)
+                return edge_i, pos_i + efs, lane_i
+            edge_i, pos_i, lane_i = locate()
+            while lane_i > min([self.num_lanes(edge_i), lanes_distr]) - 1:
+                decrement += min([self.num_lanes(edge_i), lanes_distr]) * (self.edge_length(edge_i) - efs)
+                edge_indx += 1
+                edge_i, pos_i, lane_i = locate()
+            startpositions.append((edge_i, pos_i))
+            startlanes.append(lane_i)
+        return startpositions, startlanes

@@ -1,0 +1,248 @@
+"""k.vehicle: per-replica read view over the simulator state in HBM, plus the command sink.
+
+Stands where flow/core/kernel/vehicle/{base,traci}.py stood.  The reference
+rebuilds a dict-of-dicts from TraCI subscriptions every step
+(vehicle/traci.py:119-259); here the state lives on the GPU as [R, N] arrays and
+this object copies what is asked for, lazily, once per step.
+"""
+import numpy as np
+
+from flow_amd import _lib as L
+from flow_amd.controllers import RLController, SimCarFollowingController, SimLaneChangeController
+
+
+class VehicleKernel(object):
+    """View of replica ``replica`` of a FlowSim."""
+
+    def __init__(self, master_kernel, sim_params):
+        self.master_kernel = master_kernel
+        self.sim_step = sim_params.sim_step
+        self.sim = None
+        self.replica = 0
+        self.__ids, self.__human_ids, self.__controlled_ids = [], [], []
+        self.__controlled_lc_ids, self.__rl_ids = [], []
+        self.__vehicles = {}
+        self.type_parameters, self.minGap = {}, {}
+        self.num_vehicles = 0
+        self.num_rl_vehicles = 0
+        self._slot = {}
+        self._cache = {}
+        self._pending = None          # RL accelerations buffered by apply_acceleration
+        self._observed = set()
+
+    # ---- construction (vehicle/traci.py:91-117, 261-372)
+    def initialize(self, vehicles):
+        self.type_parameters = vehicles.type_parameters
+        self.minGap = vehicles.minGap
+        self.__ids, self.__human_ids, self.__controlled_ids = [], [], []
+        self.__controlled_lc_ids, self.__rl_ids = [], []
+        self.__vehicles = {}
+        for typ in vehicles.initial:
+            for i in range(typ['num_vehicles']):
+                veh_id = '{}_{}'.format(typ['veh_id'], i)
+                tp = self.type_parameters[typ['veh_id']]
+                acc_cls, acc_kw = tp["acceleration_controller"]
+                lc_cls, lc_kw = tp["lane_change_controller"]
+                rt = tp["routing_controller"]
+                self.__vehicles[veh_id] = {
+                    "type": typ['veh_id'], "initial_speed": typ['initial_speed'],
+                    "acc_controller": acc_cls(veh_id, car_following_params=tp["car_following_params"],
+                                              **(acc_kw or {})),
+                    "lane_changer": lc_cls(veh_id=veh_id, **(lc_kw or {})),
+                    "router": rt[0](veh_id=veh_id, router_params=rt[1]) if rt is not None else None,
+                    "length": tp.get("length", 5.0)}
+                self._slot[veh_id] = len(self.__ids)
+                self.__ids.append(veh_id)
+                if acc_cls == RLController:
+                    self.__rl_ids.append(veh_id)
+                else:
+                    self.__human_ids.append(veh_id)
+                    if acc_cls != SimCarFollowingController:
+                        self.__controlled_ids.append(veh_id)
+                    if lc_cls != SimLaneChangeController:
+                        self.__controlled_lc_ids.append(veh_id)
+        self.__rl_ids.sort()                                         # vehicle/traci.py:259, 366
+        self.num_vehicles = len(self.__ids)
+        self.num_rl_vehicles = len(self.__rl_ids)
+
+    def attach(self, sim, replica=0):
+        self.sim, self.replica = sim, replica
+        self._cache = {}
+
+    def update(self, reset):
+        """Called after every simulation step: drop the host copies (vehicle/traci.py:119)."""
+        self._cache = {}
+        self._pending = None
+
+    def reset(self):
+        self._cache = {}
+
+    # ---- id lists (vehicle/base.py:327-380)
+    def get_ids(self):
+        return self.__ids
+
+    def get_human_ids(self):
+        return self.__human_ids
+
+    def get_controlled_ids(self):
+        return self.__controlled_ids
+
+    def get_controlled_lc_ids(self):
+        return self.__controlled_lc_ids
+
+    def get_rl_ids(self):
+        return self.__rl_ids
+
+    def get_arrived_ids(self):
+        return []
+
+    def get_departed_ids(self):
+        return []
+
+    def get_num_arrived(self):
+        return 0
+
+    def get_inflow_rate(self, time_span):
+        return 0
+
+    def get_outflow_rate(self, time_span):
+        return 0
+
+    def set_observed(self, veh_id):
+        self._observed.add(veh_id)
+
+    def remove_observed(self, veh_id):
+        self._observed.discard(veh_id)
+
+    def get_observed_ids(self):
+        return list(self._observed)
+
+    # ---- state reads
+    def _field(self, field):
+        if field not in self._cache:
+            self._cache[field] = self.sim.get_state(field)[self.replica]
+        return self._cache[field]
+
+    def _vec(self, veh_id, fn, error=-1001):
+        if isinstance(veh_id, (list, np.ndarray)):
+            return [self._vec(v, fn, error) for v in veh_id]
+        if veh_id not in self._slot:
+            return error
+        return fn(self._slot[veh_id])
+
+    def get_speed(self, veh_id, error=-1001):
+        return self._vec(veh_id, lambda i: float(self._field(L.FS_FIELD_VEL)[i]), error)
+
+    def get_default_speed(self, veh_id, error=-1001):
+        return self.get_speed(veh_id, error)
+
+    def get_previous_speed(self, veh_id, error=-1001):
+        return self._vec(veh_id, lambda i: float(self._field(L.FS_FIELD_PREV_VEL)[i]), error)
+
+    def get_accel(self, veh_id, error=None):
+        return self._vec(veh_id, lambda i: float(self._field(L.FS_FIELD_ACCEL)[i]), error)
+
+    def get_x_by_id(self, veh_id):
+        """Absolute position along the loop (vehicle/traci.py:1011-1017)."""
+        return self._vec(veh_id, lambda i: float(self._field(L.FS_FIELD_POS)[i]), 0.)
+
+    def _edge_pos(self, i):
+        return self.master_kernel.network.get_edge(float(self._field(L.FS_FIELD_POS)[i]))
+
+    def get_edge(self, veh_id, error=""):
+        return self._vec(veh_id, lambda i: self._edge_pos(i)[0], error)
+
+    def get_position(self, veh_id, error=-1001):
+        return self._vec(veh_id, lambda i: self._edge_pos(i)[1], error)
+
+    def get_lane(self, veh_id, error=-1001):
+        return self._vec(veh_id, lambda i: 0, error)
+
+    def get_headway(self, veh_id, error=-1001):
+        return self._vec(veh_id, lambda i: float(self._field(L.FS_FIELD_HEADWAY)[i]), error)
+
+    def get_leader(self, veh_id, error=""):
+        n = self.num_vehicles
+        return self._vec(veh_id, lambda i: self.__ids[(i + 1) % n] if n > 1 else None, error)
+
+    def get_follower(self, veh_id, error=""):
+        n = self.num_vehicles
+        return self._vec(veh_id, lambda i: self.__ids[(i - 1) % n] if n > 1 else None, error)
+
+    def get_length(self, veh_id, error=-1001):
+        return self._vec(veh_id, lambda i: self.__vehicles[self.__ids[i]]["length"], error)
+
+    def get_type(self, veh_id):
+        return self.__vehicles[veh_id]["type"]
+
+    def get_initial_speed(self, veh_id, error=-1001):
+        return self._vec(veh_id, lambda i: self.__vehicles[self.__ids[i]]["initial_speed"], error)
+
+    def get_acc_controller(self, veh_id, error=None):
+        return self._vec(veh_id, lambda i: self.__vehicles[self.__ids[i]]["acc_controller"], error)
+
+    def get_lane_changing_controller(self, veh_id, error=None):
+        return self._vec(veh_id, lambda i: self.__vehicles[self.__ids[i]]["lane_changer"], error)
+
+    def get_routing_controller(self, veh_id, error=None):
+        return self._vec(veh_id, lambda i: self.__vehicles[self.__ids[i]]["router"], error)
+
+    def get_ids_by_edge(self, edges):
+        if isinstance(edges, (list, np.ndarray)):
+            return sum([self.get_ids_by_edge(e) for e in edges], [])
+        return [v for v in self.__ids if self.get_edge(v) == edges]
+
+    def get_last_lc(self, veh_id, error=-1001):
+        return self._vec(veh_id, lambda i: -float("inf"), error)
+
+    def get_lane_leaders(self, veh_id, error=None):
+        return self._vec(veh_id, lambda i: [self.get_leader(self.__ids[i])], error)
+
+    def get_lane_followers(self, veh_id, error=None):
+        return self._vec(veh_id, lambda i: [self.get_follower(self.__ids[i])], error)
+
+    def get_lane_headways(self, veh_id, error=None):
+        return self._vec(veh_id, lambda i: [self.get_headway(self.__ids[i])], error)
+
+    def get_lane_tailways(self, veh_id, error=None):
+        return self._vec(veh_id, lambda i: [self.get_headway(self.get_follower(self.__ids[i]))]
+                         if self.num_vehicles > 1 else [1000], error)
+
+    # ---- commands
+    def apply_acceleration(self, veh_ids, acc):
+        """Buffer RL accelerations for the next simulation step (vehicle/traci.py:952-963).
+        Accelerations of non-RL vehicles come from their in-kernel controllers."""
+        if isinstance(veh_ids, str):
+            veh_ids, acc = [veh_ids], [acc]
+        if self._pending is None:
+            self._pending = {}
+        for vid, a in zip(veh_ids, acc):
+            if a is None or vid not in self._slot:
+                continue
+            if vid not in self.__rl_ids:
+                raise NotImplementedError(
+                    "apply_acceleration on a non-RL vehicle: its controller runs in the HIP kernel")
+            self._pending[vid] = float(a)
+
+    def apply_lane_change(self, veh_ids, direction):
+        """vehicle/traci.py:965-997: direction validation kept; single-lane networks clip to lane 0."""
+        if isinstance(veh_ids, str):
+            veh_ids, direction = [veh_ids], [direction]
+        if any(d not in [-1, 0, 1] for d in direction):
+            raise ValueError("Direction values for lane changes may only be: -1, 0, or 1.")
+
+    def choose_routes(self, veh_ids, route_choices):
+        pass
+
+    # ---- test back-doors (vehicle/traci.py:411-425)
+    def test_set_speed(self, veh_id, speed):
+        v = self.sim.get_state(L.FS_FIELD_VEL)
+        v[self.replica, self._slot[veh_id]] = speed
+        self.sim.set_state(L.FS_FIELD_VEL, v)
+        self._cache = {}
+
+    def test_set_position(self, veh_id, x):
+        p = self.sim.get_state(L.FS_FIELD_POS)
+        p[self.replica, self._slot[veh_id]] = x
+        self.sim.set_state(L.FS_FIELD_POS, p)
+        self._cache = {}

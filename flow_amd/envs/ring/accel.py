@@ -1,0 +1,74 @@
+"""AccelEnv (flow/envs/ring/accel.py:25-183): fully observed acceleration environment."""
+import numpy as np
+
+from flow_amd import _lib as L
+from flow_amd.envs.base import Env
+from flow_amd.utils.spaces import Box
+
+ADDITIONAL_ENV_PARAMS = {
+    # maximum acceleration for autonomous vehicles, in m/s^2
+    'max_accel': 3,
+    # maximum deceleration for autonomous vehicles, in m/s^2
+    'max_decel': 3,
+    # desired velocity for all vehicles in the network, in m/s
+    'target_velocity': 10,
+    # whether vehicles are sorted by position in the observation
+    'sort_vehicles': False
+}
+
+
+class AccelEnv(Env):
+    """States: [v_i / max_speed] ++ [x_i / length]; actions: accelerations of the RL vehicles;
+    reward: rewards.desired_velocity (mean speed when ``evaluate``); see accel.py:25-67."""
+
+    FS_ENV = L.FS_ENV_ACCEL
+
+    def __init__(self, env_params, sim_params, network, simulator='traci'):
+        for p in ADDITIONAL_ENV_PARAMS.keys():
+            if p not in env_params.additional_params:
+                raise KeyError('Environment parameter \'{}\' not supplied'.format(p))
+        if env_params.additional_params['sort_vehicles']:
+            raise NotImplementedError("AccelEnv(sort_vehicles=True) is not built (on a one-lane ring "
+                                      "the id order already is the ring order)")
+        self.prev_pos = dict()
+        self.absolute_position = dict()
+        super().__init__(env_params, sim_params, network, simulator)
+
+    @property
+    def action_space(self):
+        return Box(low=-abs(self.env_params.additional_params['max_decel']),
+                   high=self.env_params.additional_params['max_accel'],
+                   shape=(self.initial_vehicles.num_rl_vehicles, ), dtype=np.float32)
+
+    @property
+    def observation_space(self):
+        self.obs_var_labels = ['Velocity', 'Absolute_pos']
+        return Box(low=0, high=1, shape=(2 * self.initial_vehicles.num_vehicles, ), dtype=np.float32)
+
+    def _apply_rl_actions(self, rl_actions):
+        sorted_rl_ids = [veh_id for veh_id in self.sorted_ids if veh_id in self.k.vehicle.get_rl_ids()]
+        self.k.vehicle.apply_acceleration(sorted_rl_ids, rl_actions)
+
+    def compute_reward(self, rl_actions, **kwargs):
+        """Computed in the step kernel (rewards.desired_velocity / mean speed)."""
+        return self._last_reward
+
+    def get_state(self):
+        """Computed in the step kernel (accel.py:116-123)."""
+        return np.array(self._last_obs, dtype=np.float64)
+
+    def additional_command(self):
+        if self.k.vehicle.num_rl_vehicles > 0:
+            for veh_id in self.k.vehicle.get_human_ids():
+                self.k.vehicle.set_observed(veh_id)
+
+    @property
+    def sorted_ids(self):
+        return self.k.vehicle.get_ids()
+
+    def reset(self):
+        obs = super().reset()
+        for veh_id in self.k.vehicle.get_ids():
+            self.absolute_position[veh_id] = self.k.vehicle.get_x_by_id(veh_id)
+            self.prev_pos[veh_id] = self.k.vehicle.get_x_by_id(veh_id)
+        return obs

@@ -1,0 +1,128 @@
+"""VecFlowEnv: R replicas of one Flow environment stepped together on one GPU.
+
+The reference parallelises rollouts as one OS process + one SUMO process per
+environment (examples/train.py:149; SubprocVecEnv, examples/train.py:102-103).
+Here the R replicas are rows of [R, N] arrays in HBM advanced by one launch;
+observations, rewards and done flags stay on the device as torch tensors so a
+learner on the same GPU consumes them without a host copy.
+"""
+from copy import deepcopy
+
+import numpy as np
+
+from flow_amd import _lib as L
+
+
+class VecFlowEnv(object):
+    """Parameters: either ``flow_params`` (the reference's dict: env_name, network, env, sim, net,
+    veh, initial; flow/utils/registry.py:29-46) or the four objects ``env_class, env_params,
+    sim_params, network``.  ``device`` is the HIP ordinal of this process' GPU."""
+
+    def __init__(self, flow_params=None, num_replicas=4096, device=0, env_class=None, env_params=None,
+                 sim_params=None, network=None, seed=None):
+        import torch
+        self.torch = torch
+        if flow_params is not None:
+            from flow_amd.core.params import InitialConfig, TrafficLightParams
+            env_class = flow_params["env_name"]
+            env_params, sim_params = flow_params["env"], deepcopy(flow_params["sim"])
+            network = flow_params["network"](
+                name=flow_params["exp_tag"], vehicles=deepcopy(flow_params["veh"]), net_params=flow_params["net"],
+                initial_config=flow_params.get("initial", InitialConfig()),
+                traffic_lights=flow_params.get("tls", TrafficLightParams()))
+        if seed is not None:
+            sim_params = deepcopy(sim_params)
+            sim_params.seed = seed
+        self.num_envs = int(num_replicas)
+        self.device = torch.device("cuda", int(device))
+        env = env_class.__new__(env_class)
+        env.num_replicas = self.num_envs
+        env._device_index = int(device)
+        env.__init__(env_params, sim_params, network)
+        if env.FS_ENV is None:
+            env.terminate()
+            raise NotImplementedError("VecFlowEnv needs an env with an in-kernel observation/reward head")
+        self.env = env
+        self.sim = env.sim
+        self.k = env.k
+        self.observation_space = env.observation_space
+        self.action_space = env.action_space
+        self.obs_dim, self.num_rl = self.sim.obs_dim, self.sim.num_rl
+        R = self.num_envs
+        self._obs = torch.empty((R, self.obs_dim), dtype=torch.float32, device=self.device)
+        self._rew = torch.empty((R,), dtype=torch.float32, device=self.device)
+        self._done = torch.zeros((R,), dtype=torch.uint8, device=self.device)
+        self.use_current_stream()
+
+    def use_current_stream(self):
+        """Enqueue the simulator's launches on torch's current stream (ordering with learner kernels)."""
+        self.sim.set_stream(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check(self, t, shape, dtype):
+        if t is None:
+            return None
+        if t.device != self.device or t.dtype != dtype or tuple(t.shape) != tuple(shape) or not t.is_contiguous():
+            raise ValueError("expected a contiguous %s tensor of shape %s on %s" % (dtype, shape, self.device))
+        return t
+
+    def reset(self, mask=None):
+        """Reset all replicas (or those where ``mask`` [R] uint8/bool tensor is set); returns obs [R, obs_dim]."""
+        if mask is not None:
+            mask = self._check(mask.to(self.torch.uint8), (self.num_envs,), self.torch.uint8)
+        self.sim.reset_dev(self._obs, mask)
+        return self._obs
+
+    def reset_done(self):
+        """Reset exactly the replicas whose last ``done`` flag is set; no host synchronisation."""
+        self.sim.reset_dev(self._obs, self._done)
+        return self._obs
+
+    def step(self, actions=None):
+        """One Env.step of every replica.  ``actions``: float32 [R, num_rl] device tensor or None."""
+        a = self._check(actions, (self.num_envs, self.num_rl), self.torch.float32) if self.num_rl else None
+        self.sim.step_dev(self._obs, self._rew, self._done, a)
+        return self._obs, self._rew, self._done
+
+    def rollout(self, num_steps, actions=None, obs_every_step=True, out=None):
+        """``num_steps`` consecutive steps in one launch.  ``actions``: None, [R, num_rl] (held) or
+        [K, R, num_rl] (one per step).  Returns (obs, rew, done) with a leading K axis when
+        ``obs_every_step``."""
+        torch, R, K = self.torch, self.num_envs, int(num_steps)
+        if out is None:
+            lead = (K,) if obs_every_step else ()
+            out = (torch.empty(lead + (R, self.obs_dim), dtype=torch.float32, device=self.device),
+                   torch.empty(lead + (R,), dtype=torch.float32, device=self.device),
+                   torch.empty(lead + (R,), dtype=torch.uint8, device=self.device))
+        stride = 0
+        if actions is not None and self.num_rl:
+            if actions.dim() == 3:
+                self._check(actions, (K, R, self.num_rl), torch.float32)
+                stride = R * self.num_rl
+            else:
+                self._check(actions, (R, self.num_rl), torch.float32)
+        else:
+            actions = None
+        self.sim.rollout_dev(K, out[0], out[1], out[2], actions, stride, obs_every_step)
+        return out
+
+    # ---- host-side inspection
+    def get_state(self, field):
+        return self.sim.get_state(field)
+
+    @property
+    def positions(self):
+        return self.sim.get_state(L.FS_FIELD_POS)
+
+    @property
+    def speeds(self):
+        return self.sim.get_state(L.FS_FIELD_VEL)
+
+    def vehicle_view(self, replica):
+        """The k.vehicle accessor object looking at ``replica``."""
+        self.k.vehicle.attach(self.sim, int(replica))
+        return self.k.vehicle
+
+    def close(self):
+        self.env.terminate()
+
+    terminate = close

@@ -1,0 +1,5 @@
+"""Networks built for the GPU hot path (names as in flow/networks/__init__.py)."""
+from flow_amd.networks.base import Network
+from flow_amd.networks.ring import RingNetwork
+
+__all__ = ["Network", "RingNetwork"]

@@ -1,0 +1,67 @@
+"""Network descriptions (declarative part of flow/networks/base.py:306-410).
+
+A network class states its edges, routes and edge-start table; the reference
+then runs SUMO's ``netconvert`` to obtain the internal (junction) edges.  Here a
+network additionally states its internal edges itself (``specify_internal_edges``)
+because the GPU simulator has no netconvert step.
+"""
+import time
+
+from flow_amd.core.params import InitialConfig, TrafficLightParams
+
+
+class Network(object):
+    """Constructor contract of flow/networks/base.py:306-341 (detector_params optional:
+    the fork passes it from make_create_env, flow/utils/registry.py:94-101)."""
+
+    def __init__(self, name, vehicles, net_params, initial_config=InitialConfig(),
+                 traffic_lights=TrafficLightParams(), detector_params=None):
+        self.orig_name = name
+        self.name = name + time.strftime('_%Y%m%d-%H%M%S') + str(time.time())
+        self.vehicles = vehicles
+        self.net_params = net_params
+        self.initial_config = initial_config
+        self.traffic_lights = traffic_lights
+        self.detector_params = detector_params
+        if net_params.template is not None or net_params.osm_path is not None:
+            raise NotImplementedError("template / OSM networks are outside the GPU hot path")
+        self.routes = self.specify_routes(net_params)
+        self.nodes = self.specify_nodes(net_params)
+        self.edges = self.specify_edges(net_params)
+        self.types = self.specify_types(net_params)
+        self.connections = self.specify_connections(net_params)
+        self.edge_starts = self.specify_edge_starts()
+        self.internal_edge_starts = self.specify_internal_edge_starts()
+        self.intersection_edge_starts = []
+
+    def specify_nodes(self, net_params):
+        raise NotImplementedError
+
+    def specify_edges(self, net_params):
+        raise NotImplementedError
+
+    def specify_types(self, net_params):
+        return None
+
+    def specify_connections(self, net_params):
+        return None
+
+    def specify_routes(self, net_params):
+        return None
+
+    def specify_edge_starts(self):
+        return None
+
+    def specify_internal_edge_starts(self):
+        return []
+
+    def specify_internal_edges(self, junction_length):
+        """[(id, length)] of the internal edges netconvert would create."""
+        return []
+
+    @staticmethod
+    def gen_custom_start_pos(cls, net_params, initial_config, num_vehicles):
+        raise NotImplementedError
+
+    def __str__(self):
+        return 'Network ' + self.name + ' with ' + str(self.vehicles.num_vehicles) + ' vehicles.'

@@ -1,0 +1,88 @@
+"""Build and bind the oracle's C restatement (TEST INFRASTRUCTURE ONLY)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csim", "refsim.c")
+HDR = os.path.join(HERE, "csim", "refsim_body.h")
+LIB = os.path.join(HERE, "csim", "librefsim.so")
+
+
+def build(force=False):
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(SRC),
+                                                                         os.path.getmtime(HDR)):
+        return LIB
+    cmd = ["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-shared", "-fPIC",
+           "-o", LIB + ".tmp", SRC, "-lm"]
+    subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+    return _lib
+
+
+class CRingIDM:
+    """C twin of oracle.refsim.RingOracle for an all-IDM, AccelEnv ring spec."""
+
+    def __init__(self, spec, dtype=np.float32, threads=1):
+        self.lib = load()
+        self.dtype = np.dtype(dtype)
+        self.f64 = self.dtype == np.float64
+        T = self.dtype.type
+        self.R, self.N = int(spec["num_replicas"]), int(spec["num_vehicles"])
+        v0 = spec["vehicles"][0]
+        for v in spec["vehicles"]:
+            assert v["controller"] == 2 and list(v["p"]) == list(v0["p"]), "C twin covers all-IDM rings only"
+            assert v.get("fail_safe", 0) == 0 and v.get("noise", 0) == 0 and v.get("speed_mode", 0) == 0
+        assert spec.get("env", 0) == 0 and not spec.get("junction_mode", 0)
+        assert spec.get("sims_per_step", 1) == 1 and spec.get("integrator", "euler") == "euler"
+        self.p = np.array(v0["p"][:6], dtype=self.dtype)
+        self.veh_len = T(v0.get("length", 5.0))
+        self.dt = T(spec["sim_step"])
+        d = float(spec["sim_step"])
+        self.ramp = T(spec.get("slowdown_ramp", d / (d + 1e-3)))
+        self.jlen = T(spec.get("junction_length", 0.1))
+        self.ring_len = np.ascontiguousarray(
+            np.broadcast_to(np.asarray(spec["ring_length"], np.float64), (self.R,)).astype(self.dtype))
+        self.max_speed = T(spec["max_speed"])
+        self.target_v = T(spec["target_velocity"])
+        self.max_cost = T(np.linalg.norm(np.array([spec["target_velocity"]] * self.N, dtype=np.float64)))
+        self.crash_gap = T(spec.get("crash_gap", 0.0))
+        hz = spec.get("horizon", float("inf"))
+        self.step_limit = 2**31 - 1 if hz == float("inf") else int(spec.get("warmup_steps", 0) + hz)
+        self.init_pos = np.asarray(spec["init_pos"], np.float64).astype(self.dtype).reshape(self.R, self.N)
+        self.threads = int(threads)
+        self.reset()
+
+    def reset(self):
+        self.x = np.ascontiguousarray(self.init_pos.copy())
+        self.v = np.zeros((self.R, self.N), dtype=self.dtype)
+        self.tc = np.zeros(self.R, dtype=np.int32)
+
+    def rollout(self, steps, obs_every_step=False):
+        K = steps if obs_every_step else 1
+        obs = np.empty((K, self.R, 2 * self.N), np.float32)
+        rew = np.empty((K, self.R), np.float32)
+        done = np.empty((K, self.R), np.uint8)
+        fn = self.lib.refsim_ring_idm_f64_all if self.f64 else self.lib.refsim_ring_idm_f32_all
+        real = C.c_double if self.f64 else C.c_float
+        fn.restype = None
+        fn.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, real, real, real, C.c_void_p, real, real, real, real,
+                       real, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                       C.c_int, C.c_int]
+        fn(self.R, self.N, int(steps), self.ring_len.ctypes.data, self.jlen, self.dt, self.ramp, self.p.ctypes.data,
+           self.veh_len, self.max_speed, self.target_v, self.max_cost, self.crash_gap, self.step_limit,
+           self.x.ctypes.data, self.v.ctypes.data, self.tc.ctypes.data, obs.ctypes.data, rew.ctypes.data,
+           done.ctypes.data, int(obs_every_step), self.threads)
+        return obs, rew, done.astype(bool)

@@ -244,6 +244,37 @@ def gen_rewards(rng):
     return doc
 
 
+def gen_defaults():
+    """Default parameters of the reference's param / controller classes (for the host mirror)."""
+    import inspect
+    from flow.core import params as P
+    doc = {"SPEED_MODES": P.SPEED_MODES, "LC_MODES": P.LC_MODES,
+           "SumoCarFollowingParams": {"controller_params": P.SumoCarFollowingParams().controller_params,
+                                      "speed_mode": P.SumoCarFollowingParams().speed_mode},
+           "SumoLaneChangeParams": {"controller_params": P.SumoLaneChangeParams().controller_params,
+                                    "lane_change_mode": P.SumoLaneChangeParams().lane_change_mode}}
+
+    def sig(cls):
+        out = {}
+        for k, v in inspect.signature(cls.__init__).parameters.items():
+            if k in ("self", "kwargs") or v.default is inspect._empty:
+                continue
+            d = v.default
+            out[k] = d if isinstance(d, (int, float, str, bool, type(None))) else repr(d)
+        return out
+    for cls in (P.SumoParams, P.EnvParams, P.NetParams, P.InitialConfig, P.SimParams):
+        doc[cls.__name__] = sig(cls)
+    doc["controllers"] = {c.__name__: sig(c) for c in (
+        fc.IDMController, fc.CFMController, fc.BCMController, fc.LACController, fc.OVMController,
+        fc.LinearOVM, fc.GippsController, fc.FollowerStopper)}
+    v = P.VehicleParams()
+    v.add("human", acceleration_controller=(fc.IDMController, {}), num_vehicles=3)
+    v.add("rl", acceleration_controller=(fc.RLController, {}), num_vehicles=2)
+    doc["VehicleParams"] = {"ids": v.ids, "num_vehicles": v.num_vehicles, "num_rl_vehicles": v.num_rl_vehicles,
+                            "minGap": v.minGap, "types": [t["veh_id"] for t in v.types]}
+    return doc
+
+
 def copy_emission():
     src = os.path.join(REF, "tests/fast_tests/test_files/ring_230_emission.csv")
     keep = ["time", "id", "edge_id", "relative_position", "speed", "lane_number"]
@@ -258,7 +289,7 @@ def copy_emission():
 def main():
     rng = np.random.default_rng(20261003)
     for name, fn in (("controllers", gen_controllers), ("failsafes", gen_failsafes),
-                     ("rewards", gen_rewards)):
+                     ("rewards", gen_rewards), ("defaults", lambda r: gen_defaults())):
         with open(os.path.join(HERE, name + ".json"), "w") as f:
             json.dump(fn(rng), f, indent=1)
         print("wrote", name)

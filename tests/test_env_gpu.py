@@ -1,0 +1,218 @@
+"""GPU tests of the drop-in API: flow_amd.envs.* / make_create_env / VecFlowEnv driven the way
+the reference's own tests drive flow.envs (tests/fast_tests/test_environment_base_class.py,
+test_environments.py, test_experiment_base_class.py), with the oracle as the checker."""
+import random
+
+import numpy as np
+import pytest
+
+from helpers import ring_spec
+from oracle import refsim as S
+
+pytestmark = pytest.mark.gpu
+
+
+def ring_flow_params(n=22, length=230, horizon=1500, precision="f32", bunching=20, env_name=None, add_env=None,
+                     rl=0, warmup=0, **sim_kw):
+    from flow_amd.controllers import ContinuousRouter, IDMController, RLController
+    from flow_amd.core.params import (EnvParams, InitialConfig, NetParams, SumoCarFollowingParams, SumoParams,
+                                      VehicleParams)
+    from flow_amd.envs import AccelEnv
+    from flow_amd.envs.ring.accel import ADDITIONAL_ENV_PARAMS
+    from flow_amd.networks import RingNetwork
+    vehicles = VehicleParams()
+    vehicles.add(veh_id="idm", acceleration_controller=(IDMController, {}),
+                 routing_controller=(ContinuousRouter, {}),
+                 car_following_params=SumoCarFollowingParams(speed_mode="aggressive"), num_vehicles=n - rl)
+    if rl:
+        vehicles.add(veh_id="rl", acceleration_controller=(RLController, {}),
+                     routing_controller=(ContinuousRouter, {}),
+                     car_following_params=SumoCarFollowingParams(speed_mode="aggressive"), num_vehicles=rl)
+    return dict(
+        exp_tag="ring", env_name=env_name or AccelEnv, network=RingNetwork, simulator="traci",
+        sim=SumoParams(sim_step=0.1, render=False, precision=precision, **sim_kw),
+        env=EnvParams(horizon=horizon, warmup_steps=warmup, additional_params=add_env or dict(ADDITIONAL_ENV_PARAMS)),
+        net=NetParams(additional_params={"length": length, "lanes": 1, "speed_limit": 30, "resolution": 40}),
+        veh=vehicles, initial=InitialConfig(bunching=bunching))
+
+
+def test_c1_accel_env_trajectory_f64_within_1e4_of_reference_arithmetic():
+    """BASELINE configs[0]: 22-vehicle sugiyama ring, 1 env, 1500 steps; north_star bar 1e-4."""
+    from flow_amd.utils.registry import make_create_env
+    create_env, _ = make_create_env(ring_flow_params(precision="f64"))
+    env = create_env()
+    ora = S.RingOracle(ring_spec(R=1, N=22, junction_length=0.1, horizon=1500), np.float64)
+    obs = env.reset()
+    oref = ora.reset()
+    np.testing.assert_allclose(obs, oref[0], atol=1e-7)
+    ids = env.k.vehicle.get_ids()
+    for k in range(1500):
+        obs, rew, done, info = env.step(None)
+        oref, rref, dref = ora.step(None)
+        assert done == bool(dref[0]) == (k == 1499)
+        if k % 250 == 0 or k == 1499:
+            x = np.array(env.k.vehicle.get_x_by_id(ids))
+            v = np.array(env.k.vehicle.get_speed(ids))
+            assert np.abs(x - ora.x[0]).max() < 1e-4 and np.abs(v - ora.v[0]).max() < 1e-4
+            np.testing.assert_allclose(rew, rref[0], atol=1e-6)
+            np.testing.assert_allclose(np.array(env.k.vehicle.get_headway(ids)), ora.headways()[0], atol=1e-6)
+    assert obs.shape == (44,) and info == {}
+    assert np.mean(env.k.vehicle.get_speed(ids)) > 1.0
+    assert env.k.vehicle.get_edge(ids[0]) in ("bottom", "right", "top", "left", ":right_0", ":top_0", ":left_0",
+                                              ":bottom_0")
+    env.terminate()
+
+
+def test_apply_acceleration_semantics_one_decimal():
+    # reference tests/fast_tests/test_environment_base_class.py:146-188
+    from flow_amd.utils.registry import make_create_env
+    env = make_create_env(ring_flow_params(n=5, rl=5, bunching=0))[0]()
+    env.reset()
+    ids = env.k.vehicle.get_ids()
+    for vid, s in zip(ids, [1.0, 2.0, 0.05, 3.0, 0.0]):
+        env.k.vehicle.test_set_speed(vid, s)
+    v0 = np.array(env.k.vehicle.get_speed(ids))
+    acc = np.array([1.0, -1.0, -3.0, 0.5, 2.0])
+    env.step(acc)
+    v1 = np.array(env.k.vehicle.get_speed(ids))
+    np.testing.assert_array_almost_equal(v1, np.maximum(v0 + acc * 0.1, 0), decimal=1)
+    env.terminate()
+
+
+def test_rl_actions_speed_after_ten_steps():
+    # reference tests/fast_tests/test_experiment_base_class.py:84-111: a=1 for 10 steps -> speed ~ 1
+    from flow_amd.utils.registry import make_create_env
+    env = make_create_env(ring_flow_params(n=1, rl=1, bunching=0))[0]()
+    env.reset()
+    for _ in range(10):
+        obs, rew, done, _ = env.step([1.0])
+    np.testing.assert_almost_equal(env.k.vehicle.get_speed("rl_0"), 1.0, decimal=1)
+    env.terminate()
+
+
+def test_action_clipping_box():
+    # reference tests/fast_tests/test_environment_base_class.py:436-499
+    from flow_amd.utils.registry import make_create_env
+    env = make_create_env(ring_flow_params(n=4, rl=2, bunching=0))[0]()
+    np.testing.assert_array_equal(env.clip_actions(np.array([10.0, -7.0])), [3.0, -3.0])
+    assert env.clip_actions(None) is None
+    env.reset()
+    env.step(np.array([10.0, -7.0]))          # clipped to +-3 inside apply_rl_actions
+    np.testing.assert_allclose(env.k.vehicle.get_accel("rl_0"), 3.0)
+    env.terminate()
+
+
+def test_warmup_and_sims_per_step_and_horizon():
+    from flow_amd.utils.registry import make_create_env
+    fp = ring_flow_params(n=5, bunching=0, horizon=4, warmup=6)
+    fp["env"].sims_per_step = 3
+    env = make_create_env(fp)[0]()
+    env.reset()
+    assert env.time_counter == 18            # warm-up steps were taken (reference :260-277)
+    d = False
+    for k in range(4):
+        _, _, d, _ = env.step(None)
+        assert d == (k == 3)
+    assert env.time_counter == 30
+    env.terminate()
+
+
+def test_wave_attenuation_ring_length_sequence_and_po_obs():
+    # reference tests/fast_tests/test_environments.py:412-433: random.seed(9001) -> 230, 239, 256
+    from flow_amd.envs import WaveAttenuationPOEnv
+    from flow_amd.utils.registry import make_create_env
+    fp = ring_flow_params(n=22, rl=1, length=260, bunching=0, horizon=50, warmup=5, env_name=WaveAttenuationPOEnv,
+                          add_env={"max_accel": 1, "max_decel": 1, "ring_length": [220, 270]})
+    env = make_create_env(fp)[0]()
+    random.seed(9001)
+    seen = []
+    for _ in range(3):
+        obs = env.reset()
+        seen.append(env.net_params.additional_params["length"])
+        assert obs.shape == (3,)
+    assert seen == [230, 239, 256]
+    np.testing.assert_allclose(env.k.network.length(), 256.4)
+    obs, rew, done, _ = env.step([0.5])
+    rl, lead = "rl_0", env.k.vehicle.get_leader("rl_0")
+    exp = [env.k.vehicle.get_speed(rl) / 15., (env.k.vehicle.get_speed(lead) - env.k.vehicle.get_speed(rl)) / 15.,
+           ((env.k.vehicle.get_x_by_id(lead) - env.k.vehicle.get_x_by_id(rl)) % env.k.network.length()) / 270.]
+    np.testing.assert_allclose(obs, exp, atol=2e-6)
+    vel = np.array(env.k.vehicle.get_speed(env.k.vehicle.get_ids()))
+    np.testing.assert_allclose(rew, 4 * vel.mean() / 20 - 4 * 0.5, atol=1e-5)   # wave_attenuation.py:128-137
+    assert env.compute_reward(None) == 0
+    env.terminate()
+
+
+def test_vec_env_step_rollout_and_reset_done():
+    import torch
+    from flow_amd.envs import VecFlowEnv
+    R = 64
+    fp = ring_flow_params(n=22, horizon=20)
+    fp["initial"].perturbation = 0.3
+    np.random.seed(3)
+    vec = VecFlowEnv(fp, num_replicas=R)
+    spec = dict(vec.env._spec)
+    ora = S.RingOracle(spec, np.float32)
+    obs = vec.reset()
+    np.testing.assert_array_equal(obs.cpu().numpy(), ora.reset().astype(np.float32))
+    for _ in range(5):
+        o, r, d = vec.step()
+        oo, rr, dd = ora.step(None)
+    np.testing.assert_array_equal(o.cpu().numpy(), oo.astype(np.float32))
+    np.testing.assert_array_equal(r.cpu().numpy(), rr.astype(np.float32))
+    obs_k, rew_k, done_k = vec.rollout(15)
+    for k in range(15):
+        oo, rr, dd = ora.step(None)
+    np.testing.assert_array_equal(obs_k[-1].cpu().numpy(), oo.astype(np.float32))
+    assert bool(done_k[-1].all()) and not bool(done_k[-2].any())
+    # device-side masked reset: mark half the replicas done, reset exactly those
+    vec.step()
+    vec._done.zero_()
+    vec._done[::2] = 1
+    before = vec.positions.copy()
+    vec.reset_done()
+    torch.cuda.synchronize()
+    after = vec.positions
+    np.testing.assert_array_equal(after[1::2], before[1::2])
+    np.testing.assert_array_equal(after[::2], np.asarray(spec["init_pos"], dtype=np.float32)[::2])
+    tc = vec.get_state(5)
+    assert (tc[::2] == 0).all() and (tc[1::2] == 21).all()
+    view = vec.vehicle_view(3)
+    assert len(view.get_speed(view.get_ids())) == 22
+    vec.close()
+
+
+def test_custom_python_env_hooks_still_work():
+    """A user subclass with Python get_state / compute_reward (the reference's extension point)."""
+    from flow_amd.core import rewards
+    from flow_amd.envs import Env
+    from flow_amd.utils.registry import make_create_env
+    from flow_amd.utils.spaces import Box
+
+    class MyEnv(Env):
+        @property
+        def action_space(self):
+            return Box(low=-1, high=1, shape=(self.initial_vehicles.num_rl_vehicles,), dtype=np.float32)
+
+        @property
+        def observation_space(self):
+            return Box(low=0, high=100, shape=(self.initial_vehicles.num_vehicles,), dtype=np.float32)
+
+        def _apply_rl_actions(self, rl_actions):
+            self.k.vehicle.apply_acceleration(self.k.vehicle.get_rl_ids(), rl_actions)
+
+        def get_state(self):
+            return np.array(self.k.vehicle.get_headway(self.k.vehicle.get_ids()))
+
+        def compute_reward(self, rl_actions, **kwargs):
+            return rewards.average_velocity(self, fail=kwargs["fail"])
+
+    fp = ring_flow_params(n=6, rl=1, bunching=0, horizon=30, env_name=MyEnv)
+    env = make_create_env(fp)[0]()
+    obs = env.reset()
+    assert obs.shape == (6,) and np.all(obs > 0)
+    for _ in range(10):
+        obs, rew, done, _ = env.step([0.7])
+    np.testing.assert_allclose(rew, np.mean(env.k.vehicle.get_speed(env.k.vehicle.get_ids())))
+    np.testing.assert_allclose(obs.sum(), env.k.network.length() - 6 * 5, atol=1e-3)
+    env.terminate()

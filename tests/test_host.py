@@ -1,0 +1,234 @@
+"""CPU tests of the host-side mirror of the reference interface: parameter classes and their
+defaults (against defaults dumped from the imported reference), controller descriptors,
+network geometry / placement (against the oracle's literal restatement), spec resolution,
+and that constructing an environment without a GPU fails loudly."""
+import inspect
+import json
+import os
+
+import numpy as np
+import pytest
+
+from flow_amd import _lib as L
+from flow_amd import controllers as FC
+from flow_amd.core import params as P
+from flow_amd.core.kernel.network import NetworkKernel
+from flow_amd.networks import RingNetwork
+from flow_amd.networks.ring import ADDITIONAL_NET_PARAMS, ring_start_positions
+from oracle import network as ONet
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+DEF = json.load(open(os.path.join(GOLDEN, "defaults.json")))
+
+
+def sig(cls):
+    out = {}
+    for k, v in inspect.signature(cls.__init__).parameters.items():
+        if k in ("self", "kwargs") or v.default is inspect._empty:
+            continue
+        d = v.default
+        out[k] = d if isinstance(d, (int, float, str, bool, type(None))) else repr(d)
+    return out
+
+
+@pytest.mark.parametrize("name", ["SumoParams", "EnvParams", "NetParams", "InitialConfig", "SimParams"])
+def test_param_class_defaults_match_reference(name):
+    mine = sig(getattr(P, name))
+    for k, v in DEF[name].items():
+        assert k in mine, (name, k)
+        if not (isinstance(v, str) and v.startswith("<")):
+            assert mine[k] == v or (isinstance(v, float) and np.isinf(v) and np.isinf(mine[k])), (name, k)
+
+
+def test_mode_tables_and_sumo_param_dicts():
+    assert P.SPEED_MODES == DEF["SPEED_MODES"] and P.LC_MODES == DEF["LC_MODES"]
+    cf = P.SumoCarFollowingParams()
+    assert cf.controller_params == DEF["SumoCarFollowingParams"]["controller_params"]
+    assert cf.speed_mode == DEF["SumoCarFollowingParams"]["speed_mode"] == 25
+    assert P.SumoCarFollowingParams(speed_mode="aggressive").speed_mode == 0
+    lc = P.SumoLaneChangeParams()
+    assert lc.controller_params == DEF["SumoLaneChangeParams"]["controller_params"]
+    assert lc.lane_change_mode == 512
+
+
+@pytest.mark.parametrize("name", list(DEF["controllers"]))
+def test_controller_signatures_match_reference(name):
+    mine = sig(getattr(FC, name))
+    assert mine == DEF["controllers"][name]
+
+
+def test_vehicle_params_bookkeeping():
+    v = P.VehicleParams()
+    v.add("human", acceleration_controller=(FC.IDMController, {}), num_vehicles=3)
+    v.add("rl", acceleration_controller=(FC.RLController, {}), num_vehicles=2)
+    d = DEF["VehicleParams"]
+    assert v.ids == d["ids"] and v.num_vehicles == d["num_vehicles"]
+    assert v.num_rl_vehicles == d["num_rl_vehicles"] and v.minGap == d["minGap"]
+    assert v.get_type("rl_1") == "rl"
+
+
+def test_inflows_validation():
+    f = P.InFlows()
+    with pytest.raises(ValueError):
+        f.add("e", "human")
+    with pytest.raises(ValueError):
+        f.add("e", "human", vehs_per_hour=10, probability=0.2)
+    f.add("e", "human", vehs_per_hour=10)
+    assert f.get()[0]["vehsPerHour"] == 10
+
+
+def test_controller_descriptors_pack_parameters():
+    cf = P.SumoCarFollowingParams(accel=1.2, decel=-3.0)
+    c = FC.IDMController("v", car_following_params=cf, noise=0.2, fail_safe="safe_velocity", time_delay=0.3)
+    assert c.FS_ID == L.FS_CTRL_IDM and c.fs_params() == [30, 1, 1, 1.5, 4, 2]
+    assert (c.max_accel, c.max_deaccel, c.accel_noise, c.delay) == (1.2, 3.0, 0.2, 0.3)
+    f = FC.FollowerStopper("v", cf, v_des=7.5)
+    assert f.fail_safe == "safe_velocity" and f.delay == 1.0 and f.fs_params() == [7.5]
+    assert FC.RLController("v", cf).FS_ID == L.FS_CTRL_RL
+    assert FC.SimCarFollowingController("v", cf).FS_ID == L.FS_CTRL_SIM
+    with pytest.raises(ValueError):
+        FC.IDMController("v", car_following_params=cf, fail_safe="bogus")
+    with pytest.raises(NotImplementedError):
+        FC.PISaturation("v", cf)
+
+
+def make_ring(length=230, n=22, **ic):
+    v = P.VehicleParams()
+    v.add("idm", acceleration_controller=(FC.IDMController, {}), routing_controller=(FC.ContinuousRouter, {}),
+          num_vehicles=n)
+    add = dict(ADDITIONAL_NET_PARAMS)
+    add["length"] = length
+    return RingNetwork("ring", v, P.NetParams(additional_params=add), P.InitialConfig(**ic))
+
+
+def test_ring_network_requires_its_params():
+    with pytest.raises(KeyError):
+        RingNetwork("r", P.VehicleParams(), P.NetParams(additional_params={"length": 230}))
+
+
+@pytest.mark.parametrize("length,n,ic", [(230, 22, dict(bunching=20)), (1000, 15, dict(x0=5)),
+                                          (260, 22, dict(bunching=50, min_gap=0)), (100, 10, dict(min_gap=0.5))])
+def test_network_kernel_matches_oracle_geometry(length, n, ic):
+    net = make_ring(length, n, **ic)
+    k = NetworkKernel(net, junction_length=0.1)
+    o = ONet.ring_network(length, junction_length=0.1)
+    assert abs(k.length() - o.length()) < 1e-12 and k.non_internal_length() == o.non_internal_length()
+    assert k.max_speed() == 30 and k.edge_length("bottom") == length / 4
+    for x in np.linspace(0, length + 0.39, 57):
+        assert k.get_edge(x) == o.get_edge(x)
+    pos, lanes = k.generate_starting_positions(net.initial_config, n)
+    opos, olanes = o.gen_even_start_pos(n, **ic)
+    assert pos == opos and lanes == olanes
+    assert k.get_x("", 0) == -1001 and k.get_x(":top_0", 0.05) == o.get_x(":top_0", 0.05)
+    assert k.next_edge("bottom", 0) == [(":right_0", 0)] and k.prev_edge("bottom", 0) == [(":bottom_0", 0)]
+
+
+def test_not_enough_space_raises():
+    from flow_amd.utils.exceptions import FatalFlowError
+    net = make_ring(100, 30)
+    with pytest.raises(FatalFlowError):
+        NetworkKernel(net).generate_starting_positions(net.initial_config, 30)
+
+
+def test_ring_start_positions_c1():
+    x = ring_start_positions(22, length=230.0, bunching=20.0)
+    np.testing.assert_allclose(x, np.arange(22) * (100 / 22 + 5), atol=1e-9)
+
+
+class RecordingSim:
+    """Stands in for FlowSim on the CPU: records the spec the env resolved."""
+    last = None
+
+    def __init__(self, spec, precision="f32", device=0):
+        RecordingSim.last = (spec, precision)
+        self.R, self.N = spec["num_replicas"], spec["num_vehicles"]
+
+    def close(self):
+        pass
+
+
+def build_env(monkeypatch, env_cls, env_params, sim_params, network):
+    import flow_amd.envs.base as base
+    monkeypatch.setattr(base, "FlowSim", RecordingSim)
+    env = env_cls(env_params, sim_params, network)
+    return env, RecordingSim.last[0]
+
+
+def test_spec_resolution_c1(monkeypatch):
+    from flow_amd.envs import AccelEnv
+    from flow_amd.envs.ring.accel import ADDITIONAL_ENV_PARAMS
+    net = make_ring(230, 22, bunching=20)
+    env, spec = build_env(monkeypatch, AccelEnv, P.EnvParams(horizon=1500, additional_params=ADDITIONAL_ENV_PARAMS),
+                          P.SumoParams(sim_step=0.1, render=False), net)
+    assert spec["num_replicas"] == 1 and spec["num_vehicles"] == 22 and spec["num_rl"] == 0
+    assert spec["env"] == L.FS_ENV_ACCEL and spec["horizon"] == 1500 and spec["max_speed"] == 30
+    assert spec["target_velocity"] == 10 and abs(spec["slowdown_ramp"] - 0.1 / 0.101) < 1e-15
+    v = spec["vehicles"][0]
+    assert v["controller"] == L.FS_CTRL_IDM and v["p"] == [30, 1, 1, 1.5, 4, 2]
+    assert (v["max_accel"], v["max_decel"], v["speed_mode"], v["sumo_min_gap"]) == (2.6, 4.5, 25, 2.5)
+    np.testing.assert_allclose(spec["init_pos"][0], np.arange(22) * (100 / 22 + 5), atol=1e-9)
+    assert env.initial_state["idm_7"][1] == "right" and env.observation_space.shape == (44,)
+    assert env.action_space.shape == (0,) and env.initial_ids[0] == "idm_0"
+
+
+def test_spec_resolution_rl_ring(monkeypatch):
+    from flow_amd.envs import WaveAttenuationPOEnv
+    v = P.VehicleParams()
+    v.add("human", acceleration_controller=(FC.IDMController, {"noise": 0.2}),
+          car_following_params=P.SumoCarFollowingParams(min_gap=0), routing_controller=(FC.ContinuousRouter, {}),
+          num_vehicles=21)
+    v.add("rl", acceleration_controller=(FC.RLController, {}), routing_controller=(FC.ContinuousRouter, {}),
+          num_vehicles=1)
+    add = dict(ADDITIONAL_NET_PARAMS)
+    add["length"] = 260
+    net = RingNetwork("stabilizing_the_ring", v, P.NetParams(additional_params=add), P.InitialConfig())
+    ep = P.EnvParams(horizon=3000, warmup_steps=750, clip_actions=False,
+                     additional_params={"max_accel": 1, "max_decel": 1, "ring_length": [220, 270]})
+    env, spec = build_env(monkeypatch, WaveAttenuationPOEnv, ep, P.SumoParams(sim_step=0.1), net)
+    assert spec["env"] == L.FS_ENV_WAVE_ATTENUATION_PO and spec["num_rl"] == 1
+    assert spec["vehicles"][21]["controller"] == L.FS_CTRL_RL and spec["vehicles"][21]["rl_index"] == 0
+    assert spec["vehicles"][0]["noise"] == 0.2 and spec["vehicles"][0]["sumo_min_gap"] == 0
+    assert spec["po_max_length"] == 270 and spec["warmup_steps"] == 750 and spec["clip_actions"] is False
+    assert (spec["action_low"], spec["action_high"]) == (-1.0, 1.0)
+    assert env.observation_space.shape == (3,) and env.action_space.shape == (1,)
+    assert env.k.vehicle.get_rl_ids() == ["rl_0"] and env.k.vehicle.get_leader("rl_0") == "human_0"
+
+
+def test_missing_env_params_raise_keyerror(monkeypatch):
+    from flow_amd.envs import AccelEnv, WaveAttenuationEnv
+    net = make_ring()
+    with pytest.raises(KeyError):                  # reference tests/fast_tests/test_environments.py:1333-1375
+        build_env(monkeypatch, AccelEnv, P.EnvParams(additional_params={"max_accel": 1}), P.SumoParams(), net)
+    with pytest.raises(KeyError):
+        build_env(monkeypatch, WaveAttenuationEnv, P.EnvParams(additional_params={}), P.SumoParams(), net)
+
+
+def test_unsupported_features_raise_at_construction(monkeypatch):
+    from flow_amd.envs import AccelEnv
+    from flow_amd.envs.ring.accel import ADDITIONAL_ENV_PARAMS
+    add = dict(ADDITIONAL_NET_PARAMS)
+    add["lanes"] = 3
+    v = P.VehicleParams()
+    v.add("idm", acceleration_controller=(FC.IDMController, {}), num_vehicles=4)
+    net = RingNetwork("ring", v, P.NetParams(additional_params=add))
+    with pytest.raises(NotImplementedError):
+        build_env(monkeypatch, AccelEnv, P.EnvParams(additional_params=ADDITIONAL_ENV_PARAMS), P.SumoParams(), net)
+
+
+def test_env_construction_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from flow_amd.envs import AccelEnv
+    from flow_amd.envs.ring.accel import ADDITIONAL_ENV_PARAMS
+    from flow_amd.utils.exceptions import FatalFlowError
+    from flow_amd.utils.registry import make_create_env
+    v = P.VehicleParams()
+    v.add("idm", acceleration_controller=(FC.IDMController, {}), num_vehicles=5)
+    flow_params = dict(exp_tag="ring", env_name=AccelEnv, network=RingNetwork, simulator="traci",
+                       sim=P.SumoParams(), env=P.EnvParams(additional_params=ADDITIONAL_ENV_PARAMS),
+                       net=P.NetParams(additional_params=dict(ADDITIONAL_NET_PARAMS)), veh=v)
+    create_env, name = make_create_env(flow_params)
+    assert name.startswith("AccelEnv-v")
+    with pytest.raises(FatalFlowError):
+        create_env()
