@@ -98,10 +98,23 @@ class Runner:
                 self.t_in_episode = 0
 
 
+def host_cores():
+    """Cores this job may really use: affinity, capped by the cgroup CPU quota when there is one
+    and by the GPU box's per-GPU CPU share (16)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(spec_fn, seconds=12.0):
     """Oracle C port (oracle/csim) on the host cores, bounded sample of the same workload."""
     from oracle import cbuild
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     R = 4096
     spec = spec_fn(R)
     sim = cbuild.CRingIDM(spec, np.float32, threads=cores)
@@ -137,6 +150,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the simulation path is HIP-only (no CPU fallback)")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
+    # every launch of this process (simulator, events, collectives) goes to one explicit stream
+    torch.cuda.set_stream(torch.cuda.Stream(device))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)

@@ -33,7 +33,7 @@ FS_EULER, FS_BALLISTIC = 0, 1
  FS_FIELD_RING_LENGTH, FS_FIELD_INIT_POS, FS_FIELD_INIT_VEL, FS_FIELD_CTRL_STATE) = range(10)
 
 EXPORTS = ["fs_create", "fs_destroy", "fs_last_error", "fs_abi_version", "fs_obs_dim", "fs_set_stream",
-           "fs_sync", "fs_reset", "fs_reset_dev", "fs_step", "fs_step_dev", "fs_rollout_dev",
+           "fs_use_own_stream", "fs_sync", "fs_reset", "fs_reset_dev", "fs_step", "fs_step_dev", "fs_rollout_dev",
            "fs_get_state", "fs_set_state"]
 
 
@@ -91,6 +91,8 @@ def load():
     lib.fs_obs_dim.restype = C.c_int
     lib.fs_set_stream.argtypes = [h, C.c_void_p]
     lib.fs_set_stream.restype = C.c_int
+    lib.fs_use_own_stream.argtypes = [h]
+    lib.fs_use_own_stream.restype = C.c_int
     lib.fs_sync.argtypes = [h]
     lib.fs_sync.restype = C.c_int
     lib.fs_reset.argtypes = [h, u8p, f32p]

@@ -8,6 +8,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -47,6 +48,7 @@ struct SimBase {
   uint8_t* d_done = nullptr;
   uint8_t* d_mask = nullptr;
   std::vector<void*> allocs;
+  bool force_generic = false;   // FLOWSIM_FORCE_GENERIC=1: never take the specialised kernel (tests)
 
   virtual int launch_steps(int num_steps, const uint8_t* mask, const float* actions, size_t act_stride,
                            float* obs, float* rew, uint8_t* done, int obs_every_step) = 0;
@@ -192,13 +194,25 @@ struct Sim : SimBase {
     return launch_reset(nullptr);
   }
 
+  // the specialisation of k_steps for the headline configuration (see flowsim_kernels.h)
+  bool fast_ok(const uint8_t* mask, int num_steps) const {
+    const int f = dv.flags;
+    return (f & fs::FLAG_ALL_IDM) && !(f & (fs::FLAG_HAS_NOISE | fs::FLAG_HAS_FAILSAFE | fs::FLAG_NEED_SUMO)) &&
+           dv.env == FS_ENV_ACCEL && !dv.evaluate && dv.sims_per_step == 1 && dv.integrator == FS_EULER &&
+           !dv.junction_mode && !dv.track_aux && mask == nullptr && num_steps > 0 && !force_generic;
+  }
+
   template <int SEG>
   int launch_seg(int num_steps, const uint8_t* mask, const float* actions, size_t act_stride, float* obs,
                  float* rew, uint8_t* done, int obs_every_step) {
     constexpr int RPW = 64 / SEG;
     const int blocks = (dv.R + RPW - 1) / RPW;
-    hipLaunchKernelGGL((fs::k_steps<T, SEG>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, mask, actions,
-                       act_stride, obs, rew, done, obs_every_step);
+    if (fast_ok(mask, num_steps))
+      hipLaunchKernelGGL((fs::k_steps<T, SEG, 1>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, mask, actions,
+                         act_stride, obs, rew, done, obs_every_step);
+    else
+      hipLaunchKernelGGL((fs::k_steps<T, SEG, 0>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, mask, actions,
+                         act_stride, obs, rew, done, obs_every_step);
     HIP_TRY(hipGetLastError());
     return FS_OK;
   }
@@ -359,6 +373,10 @@ int create_typed(const fs_config* cfg, fs_handle* out) {
     return fail(FS_ERR_HIP, std::string("fs_create: no usable HIP device: ") + hipGetErrorString(e));
   }
   s->stream = s->own_stream;
+  {
+    const char* fg = std::getenv("FLOWSIM_FORCE_GENERIC");
+    s->force_generic = fg && fg[0] == '1';
+  }
   int rc = s->init();
   if (rc == FS_OK) {
     hipError_t e2 = hipStreamSynchronize(s->stream);
@@ -413,7 +431,15 @@ int fs_set_stream(fs_handle h, void* hip_stream) {
   if (!h) return fail(FS_ERR_INVALID, "fs_set_stream: NULL handle");
   SimBase* s = S(h);
   HIP_TRY(hipStreamSynchronize(s->stream));
-  s->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : s->own_stream;
+  s->stream = static_cast<hipStream_t>(hip_stream);
+  return FS_OK;
+}
+
+int fs_use_own_stream(fs_handle h) {
+  if (!h) return fail(FS_ERR_INVALID, "fs_use_own_stream: NULL handle");
+  SimBase* s = S(h);
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  s->stream = s->own_stream;
   return FS_OK;
 }
 

@@ -7,7 +7,8 @@
 // of slot i on a closed single-lane loop is slot i+1 (cyclic), so the
 // leader/follower lookup is a fixed cross-lane rotation (ds_bpermute through the
 // LDS crossbar, no LDS allocation) and every per-replica reduction (reward norm,
-// crash/any flags) is an xor-butterfly inside the SEG-lane segment.
+// crash/any flags) is an xor-butterfly inside the SEG-lane segment, built from DPP,
+// v_readlane and the gfx950 v_permlane16/32_swap instructions (VALU only).
 //
 // Arithmetic contract: every floating-point expression below is evaluated in
 // T with the SAME operation order as oracle/controllers.py / oracle/refsim.py
@@ -100,15 +101,106 @@ __device__ __forceinline__ T pow_delta(T x, T d) {
   return tpow(x, d);
 }
 
-// cross-lane read (ds_bpermute_b32; two of them for double)
-template <typename T>
-__device__ __forceinline__ T lane_read(T v, int src_lane) { return __shfl(v, src_lane, 64); }
+// ---------------------------------------------------------------------------
+// cross-lane primitives: DPP / v_readlane / v_permlane*_swap (VALU, no LDS-crossbar latency)
+// ---------------------------------------------------------------------------
+// DPP controls (GFX9 encoding): lanes with no source keep their own value.
+enum : int {
+  DPP_QUAD_XOR1 = 0xB1,     // quad_perm:[1,0,3,2]
+  DPP_QUAD_XOR2 = 0x4E,     // quad_perm:[2,3,0,1]
+  DPP_WAVE_SHL1 = 0x130,    // lane i <- lane i+1
+  DPP_WAVE_SHR1 = 0x138,    // lane i <- lane i-1
+  DPP_ROW_MIRROR = 0x140,   // lane i <- lane 15-i   (within a row of 16)
+  DPP_ROW_HALF_MIRROR = 0x141  // lane i <- lane 7-i (within a half row of 8)
+};
 
-// sum over the SEG-lane segment in the oracle's tree order (oracle/rewards.py tree_sum)
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) {
+  return __builtin_bit_cast(float, dpp_i<CTRL>(__builtin_bit_cast(int, v)));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp(double v) {
+  long long b = __builtin_bit_cast(long long, v);
+  int lo = dpp_i<CTRL>(int(b)), hi = dpp_i<CTRL>(int(b >> 32));
+  return __builtin_bit_cast(double, (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+__device__ __forceinline__ float read_lane(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ double read_lane(double v, int lane) {
+  long long b = __builtin_bit_cast(long long, v);
+  int lo = __builtin_amdgcn_readlane(int(b), lane), hi = __builtin_amdgcn_readlane(int(b >> 32), lane);
+  return __builtin_bit_cast(double, (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+// v + (value of the other 16-lane row of the pair): v_permlane16_swap_b32 (new on gfx950)
+__device__ __forceinline__ float add_swap16(float v) {
+  unsigned u = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+}
+__device__ __forceinline__ float add_swap32(float v) {
+  unsigned u = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+}
+__device__ __forceinline__ double add_swap16(double v) {
+  unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  unsigned lo = unsigned(b), hi = unsigned(b >> 32);
+  auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  double a = __builtin_bit_cast(double, ((unsigned long long)rh[0] << 32) | rl[0]);
+  double c = __builtin_bit_cast(double, ((unsigned long long)rh[1] << 32) | rl[1]);
+  return a + c;
+}
+__device__ __forceinline__ double add_swap32(double v) {
+  unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  unsigned lo = unsigned(b), hi = unsigned(b >> 32);
+  auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  double a = __builtin_bit_cast(double, ((unsigned long long)rh[0] << 32) | rl[0]);
+  double c = __builtin_bit_cast(double, ((unsigned long long)rh[1] << 32) | rl[1]);
+  return a + c;
+}
+
+// value held by the leader's lane (slot i+1, cyclic inside the SEG-lane segment): a one-lane
+// wave shift plus a v_readlane fix-up of the wrap lane (slot N-1 reads slot 0 of its segment)
+template <int SEG, typename T>
+__device__ __forceinline__ T lead_read(T v, int seg, bool wrap) {
+  T nxt = dpp<DPP_WAVE_SHL1>(v);
+  T first = v;
+#pragma unroll
+  for (int sg = 0; sg < 64 / SEG; ++sg) {
+    T f = read_lane(v, sg * SEG);
+    first = (seg == sg) ? f : first;
+  }
+  return wrap ? first : nxt;
+}
+// value held by the follower's lane (slot i-1, cyclic): slot 0 reads slot N-1 of its segment
+template <int SEG, typename T>
+__device__ __forceinline__ T foll_read(T v, int seg, bool wrap, int N) {
+  T prv = dpp<DPP_WAVE_SHR1>(v);
+  T last = v;
+#pragma unroll
+  for (int sg = 0; sg < 64 / SEG; ++sg) {
+    T f = read_lane(v, sg * SEG + N - 1);
+    last = (seg == sg) ? f : last;
+  }
+  return wrap ? last : prv;
+}
+
+// sum over the SEG-lane segment in the oracle's tree order (oracle/rewards.py tree_sum):
+// xor-1, xor-2 partners by quad_perm; once quads (then half rows, rows) are uniform the xor-4 /
+// xor-8 / xor-16 / xor-32 partner sums are reached by half-mirror / mirror / permlane swaps.
 template <int SEG, typename T>
 __device__ __forceinline__ T seg_sum(T v) {
-#pragma unroll
-  for (int off = 1; off < SEG; off <<= 1) v = v + __shfl_xor(v, off, 64);
+  v = v + dpp<DPP_QUAD_XOR1>(v);
+  v = v + dpp<DPP_QUAD_XOR2>(v);
+  v = v + dpp<DPP_ROW_HALF_MIRROR>(v);
+  if (SEG >= 16) v = v + dpp<DPP_ROW_MIRROR>(v);
+  if (SEG >= 32) v = add_swap16(v);
+  if (SEG >= 64) v = add_swap32(v);
   return v;
 }
 
@@ -272,7 +364,12 @@ __device__ __forceinline__ T sumo_idm_speed(T v, T vl, T h, bool has, T dt, cons
 // ---------------------------------------------------------------------------
 // the fused step kernel
 // ---------------------------------------------------------------------------
-template <typename T, int SEG>
+// FAST = 1 is the specialisation the host selects for the headline configuration: every
+// slot an IDMController without noise / fail-safe, speed_mode "aggressive", no junction
+// mode, sims_per_step 1, AccelEnv head with the desired_velocity reward, no reset mask,
+// no aux tracking.  It executes exactly the arithmetic of the generic path (same helper
+// functions, same order), with everything it cannot need compiled out.
+template <typename T, int SEG, int FAST>
 __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const uint8_t* __restrict__ mask,
                                               const float* __restrict__ actions, size_t act_stride,
                                               float* __restrict__ obs, float* __restrict__ rew,
@@ -288,9 +385,8 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
   const int rr = rvalid ? r : s.R - 1;
   const int ii = i < N ? i : N - 1;
   const size_t idx = size_t(rr) * N + ii;
-  const int segbase = seg * SEG;
-  const int lead_lane = segbase + (ii + 1 >= N ? 0 : ii + 1);
-  const int foll_lane = segbase + (ii == 0 ? N - 1 : ii - 1);
+  const bool wrap_lead = (i + 1 >= N);            // slot N-1 (and the idle lanes): leader is slot 0
+  const bool wrap_foll = (i == 0);
   const bool has = N > 1;
   const int flags = s.flags;
 
@@ -310,96 +406,114 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
   sl.sumo_tau = s.sumo_tau[ii];
   sl.sumo_min_gap = s.sumo_min_gap[ii];
   sl.sumo_max_speed = s.sumo_max_speed[ii];
-  const T len_lead = lane_read(sl.length, lead_lane);
+  const T len_lead = lead_read<SEG>(sl.length, seg, wrap_lead);
 
   // per-replica scalars
   const T base_len = s.ring_len[rr];
   const T L = base_len + T(4) * s.jlen;          // network.length(): edges + 4 junctions
   const T quarter = base_len / T(4);
   const T qj = quarter + s.jlen;
-  const bool live_replica = rvalid && (mask == nullptr || mask[rr] != 0);
+  const bool live_replica = rvalid && (FAST || mask == nullptr || mask[rr] != 0);
   int tcount = s.time[rr];
-  uint32_t nctr = (flags & FLAG_HAS_NOISE) ? s.noise_ctr[rr] : 0u;
+  uint32_t nctr = (!FAST && (flags & FLAG_HAS_NOISE)) ? s.noise_ctr[rr] : 0u;
 
   // state
   T x = s.pos[idx];
   T v = s.vel[idx];
   T prev_v = v, last_acc = T(0);
-  T cst = (flags & FLAG_HAS_LAC) ? s.ctrl_state[idx] : T(0);
-  if (s.track_aux) { prev_v = s.prev_vel[idx]; last_acc = s.accel[idx]; }
+  T cst = (!FAST && (flags & FLAG_HAS_LAC)) ? s.ctrl_state[idx] : T(0);
+  if (!FAST && s.track_aux) { prev_v = s.prev_vel[idx]; last_acc = s.accel[idx]; }
 
   // time-t neighbour snapshot (S1/S10)
-  T xl = lane_read(x, lead_lane);
-  T vl = lane_read(v, lead_lane);
+  T xl = lead_read<SEG>(x, seg, wrap_lead);
+  T vl = lead_read<SEG>(v, seg, wrap_lead);
   T d = xl - x;
   d = d < T(0) ? d + L : d;
   T h = has ? d - len_lead : T(1000);
 
   const T dt = s.dt;
-  const int obs_dim = (s.env == FS_ENV_WAVE_ATTENUATION_PO) ? 3 : 2 * N;
+  const int env = FAST ? int(FS_ENV_ACCEL) : s.env;
+  const int obs_dim = (env == FS_ENV_WAVE_ATTENUATION_PO) ? 3 : 2 * N;
+  const int sims_per_step = FAST ? 1 : s.sims_per_step;
+  const size_t step_rows = obs_every_step ? size_t(s.R) : 0;     // rows to advance per step
+  float* orow = obs + size_t(rr) * obs_dim;
+  float* rrow = rew + rr;
+  uint8_t* drow = done + rr;
 
   for (int step = 0; step < num_steps; ++step) {
     // ---- RL action of this lane (envs/base.py:599-615) -------------------
-    const float* act = actions ? actions + size_t(step) * act_stride + size_t(rr) * s.num_rl : nullptr;
+    const float* act = (!FAST && actions) ? actions + size_t(step) * act_stride + size_t(rr) * s.num_rl : nullptr;
     bool crashed = false;
-    for (int sub = 0; sub < s.sims_per_step; ++sub) {
+    for (int sub = 0; sub < sims_per_step; ++sub) {
       const bool live = live_replica && !crashed;
       // ---- controllers (S1: all read the snapshot) -----------------------
-      T vf = T(0), hf = T(0), mean_v = T(0);
-      if (flags & FLAG_NEED_FOLLOWER) { vf = lane_read(v, foll_lane); hf = lane_read(h, foll_lane); }
-      if (flags & FLAG_NEED_MEAN) mean_v = seg_sum<SEG>(valid ? v : T(0)) / T(N);
       T acc = T(0);
-      bool commanded = false;
-      const int ct = sl.ctrl;
-      if (ct == FS_CTRL_RL) {
-        if (act != nullptr) {
-          T a = T(act[sl.rl_index < 0 ? 0 : sl.rl_index]);
-          if (s.clip_actions) a = tmin(tmax(a, s.act_lo), s.act_hi);
-          acc = a;
+      bool commanded = true;
+      if (FAST) {
+        acc = ctrl_idm(v, vl, h, has, sl.p);
+      } else {
+        T vf = T(0), hf = T(0), mean_v = T(0);
+        if (flags & FLAG_NEED_FOLLOWER) {
+          vf = foll_read<SEG>(v, seg, wrap_foll, N);
+          hf = foll_read<SEG>(h, seg, wrap_foll, N);
+        }
+        if (flags & FLAG_NEED_MEAN) mean_v = seg_sum<SEG>(valid ? v : T(0)) / T(N);
+        commanded = false;
+        const int ct = sl.ctrl;
+        if (ct == FS_CTRL_RL) {
+          if (act != nullptr) {
+            T a = T(act[sl.rl_index < 0 ? 0 : sl.rl_index]);
+            if (s.clip_actions) a = tmin(tmax(a, s.act_lo), s.act_hi);
+            acc = a;
+            commanded = true;
+          }
+        } else if (ct != FS_CTRL_SIM) {
+          T a;
+          switch (ct) {
+            case FS_CTRL_IDM: a = ctrl_idm(v, vl, h, has, sl.p); break;
+            case FS_CTRL_CFM: a = ctrl_cfm(v, vl, h, has, sl.max_accel, sl.p); break;
+            case FS_CTRL_BCM: a = ctrl_bcm(v, vl, h, has, vf, hf, sl.max_accel, sl.p); break;
+            case FS_CTRL_LAC: a = ctrl_lac(v, vl, h, sl.length, cst, dt, sl.p); break;
+            case FS_CTRL_OVM: a = ctrl_ovm(v, vl, h, has, sl.max_accel, sl.p); break;
+            case FS_CTRL_LINEAR_OVM: a = ctrl_linear_ovm(v, h, sl.p); break;
+            case FS_CTRL_GIPPS: a = ctrl_gipps(v, vl, h, dt, sl.p); break;
+            case FS_CTRL_FOLLOWER_STOPPER: a = ctrl_follower_stopper(v, vl, h, has, dt, sl.p[0]); break;
+            default: a = ctrl_follower_stopper(v, vl, h, has, dt, mean_v); break;
+          }
           commanded = true;
+          if (s.junction_mode) {                       // base_controller.py:98-99
+            T u = x - tfloor(x / qj) * qj;
+            commanded = !(u >= quarter);
+          }
+          if (ct == FS_CTRL_LAC && commanded && live) cst = a;
+          if (flags & FLAG_HAS_NOISE) {                // base_controller.py:109-110
+            if (sl.noise > T(0)) a = a + sl.noise * gauss<T>(s.seed_lo, s.seed_hi, uint32_t(rr), uint32_t(ii), nctr);
+          }
+          if (has) {                                   // base_controller.py:113-116, 141-142, 191-193
+            if (sl.failsafe == FS_FAILSAFE_INSTANTANEOUS) a = failsafe_instantaneous(a, v, h, has, dt);
+            else if (sl.failsafe == FS_FAILSAFE_SAFE_VELOCITY) a = failsafe_safe_velocity(a, v, vl, h, dt, sl.delay);
+          }
+          acc = a;
         }
-      } else if (ct != FS_CTRL_SIM) {
-        T a;
-        switch (ct) {
-          case FS_CTRL_IDM: a = ctrl_idm(v, vl, h, has, sl.p); break;
-          case FS_CTRL_CFM: a = ctrl_cfm(v, vl, h, has, sl.max_accel, sl.p); break;
-          case FS_CTRL_BCM: a = ctrl_bcm(v, vl, h, has, vf, hf, sl.max_accel, sl.p); break;
-          case FS_CTRL_LAC: a = ctrl_lac(v, vl, h, sl.length, cst, dt, sl.p); break;
-          case FS_CTRL_OVM: a = ctrl_ovm(v, vl, h, has, sl.max_accel, sl.p); break;
-          case FS_CTRL_LINEAR_OVM: a = ctrl_linear_ovm(v, h, sl.p); break;
-          case FS_CTRL_GIPPS: a = ctrl_gipps(v, vl, h, dt, sl.p); break;
-          case FS_CTRL_FOLLOWER_STOPPER: a = ctrl_follower_stopper(v, vl, h, has, dt, sl.p[0]); break;
-          default: a = ctrl_follower_stopper(v, vl, h, has, dt, mean_v); break;
-        }
-        commanded = true;
-        if (s.junction_mode) {                       // base_controller.py:98-99
-          T u = x - tfloor(x / qj) * qj;
-          commanded = !(u >= quarter);
-        }
-        if (ct == FS_CTRL_LAC && commanded && live) cst = a;
-        if (flags & FLAG_HAS_NOISE) {                // base_controller.py:109-110
-          if (sl.noise > T(0)) a = a + sl.noise * gauss<T>(s.seed_lo, s.seed_hi, uint32_t(rr), uint32_t(ii), nctr);
-        }
-        if (has) {                                   // base_controller.py:113-116, 141-142, 191-193
-          if (sl.failsafe == FS_FAILSAFE_INSTANTANEOUS) a = failsafe_instantaneous(a, v, h, has, dt);
-          else if (sl.failsafe == FS_FAILSAFE_SAFE_VELOCITY) a = failsafe_safe_velocity(a, v, vl, h, dt, sl.delay);
-        }
-        acc = a;
       }
       // ---- apply_acceleration + SUMO integration (S4-S9) ------------------
       T next_vel = tmax(v + acc * dt, T(0));          // vehicle/traci.py:962
       T vc = v + (next_vel - v) * s.ramp;             // slowDown(.., 1e-3)
       T v_new = vc;
-      if (flags & FLAG_NEED_SUMO) {
+      if (!FAST && (flags & FLAG_NEED_SUMO)) {
         T v_sumo = sumo_idm_speed(v, vl, h, has, dt, sl);
         if (sl.speed_mode & 1) vc = tmin(vc, v_sumo);
         if (sl.speed_mode & 2) vc = tmin(vc, v + sl.max_accel * dt);
         if (sl.speed_mode & 4) vc = tmax(vc, v - sl.max_decel * dt);
         v_new = commanded ? vc : v_sumo;
       }
-      T x_new = (s.integrator == FS_BALLISTIC) ? x + (v + v_new) / T(2) * dt : x + v_new * dt;
+      T x_new = (!FAST && s.integrator == FS_BALLISTIC) ? x + (v + v_new) / T(2) * dt : x + v_new * dt;
       x_new = x_new >= L ? x_new - L : x_new;
-      if (live) {
+      if (FAST) {
+        x = x_new;
+        v = v_new;
+        tcount += 1;
+      } else if (live) {
         prev_v = v;
         last_acc = acc;
         x = x_new;
@@ -408,8 +522,8 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
         nctr += 1u;
       }
       // ---- vehicle update: new neighbour snapshot (vehicle/traci.py:219-250)
-      xl = lane_read(x, lead_lane);
-      vl = lane_read(v, lead_lane);
+      xl = lead_read<SEG>(x, seg, wrap_lead);
+      vl = lead_read<SEG>(v, seg, wrap_lead);
       d = xl - x;
       d = d < T(0) ? d + L : d;
       h = has ? d - len_lead : T(1000);
@@ -419,68 +533,68 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
     }
 
     // ---- get_state / compute_reward / done (envs/base.py:387-412) ---------
-    const bool last = (step == num_steps - 1);
-    const size_t so = obs_every_step ? size_t(step) : 0;
-    if (obs_every_step || last) {
-      float* o = obs + (so * s.R + size_t(rr)) * obs_dim;
-      if (s.env == FS_ENV_WAVE_ATTENUATION_PO) {
+    const bool emit = obs_every_step || (step == num_steps - 1);
+    if (emit) {
+      if (env == FS_ENV_WAVE_ATTENUATION_PO) {
         // wave_attenuation.py:248-269; written by the RL vehicle's lane
         if (valid && sl.ctrl == FS_CTRL_RL && sl.rl_index == 0) {
-          o[0] = float(v / T(15));
-          o[1] = float((vl - v) / T(15));
-          o[2] = float(d / s.po_max_length);
+          orow[0] = float(v / T(15));
+          orow[1] = float((vl - v) / T(15));
+          orow[2] = float(d / s.po_max_length);
         }
       } else if (valid) {
-        o[ii] = float(v / s.max_speed);               // accel.py:118-119
-        o[N + ii] = float(x / L);                     // accel.py:120-121
+        orow[ii] = float(v / s.max_speed);               // accel.py:118-119
+        orow[N + ii] = float(x / L);                     // accel.py:120-121
       }
-    }
-    // reward
-    T reward;
-    const bool bad = seg_any<SEG>(valid && (v < T(-100)), seg) || crashed;
-    if (s.env == FS_ENV_ACCEL) {
-      if (s.evaluate) {
-        reward = seg_sum<SEG>(valid ? v : T(0)) / T(N);                    // accel.py:111-112
-      } else {                                                            // rewards.py:6-59
-        T dv = valid ? v - s.target_velocity : T(0);
-        T cost = tsqrt(seg_sum<SEG>(dv * dv));
-        reward = tmax(s.max_cost - cost, T(0)) / (s.max_cost + T(1.1920928955078125e-07));
-        reward = bad ? T(0) : reward;
-      }
-    } else {                                                              // wave_attenuation.py:113-139
-      if (act == nullptr) {
-        reward = T(0);
-      } else {
-        T a = T(0);
-        if (ii < s.num_rl && i < N) {
-          a = T(act[ii]);
-          if (s.clip_actions) a = tmin(tmax(a, s.act_lo), s.act_hi);
-          a = tabs(a);
+      // reward
+      T reward;
+      const bool bad = seg_any<SEG>(valid && (v < T(-100)), seg) || crashed;
+      if (env == FS_ENV_ACCEL) {
+        if (!FAST && s.evaluate) {
+          reward = seg_sum<SEG>(valid ? v : T(0)) / T(N);                    // accel.py:111-112
+        } else {                                                            // rewards.py:6-59
+          T dv = valid ? v - s.target_velocity : T(0);
+          T cost = tsqrt(seg_sum<SEG>(dv * dv));
+          reward = tmax(s.max_cost - cost, T(0)) / (s.max_cost + T(1.1920928955078125e-07));
+          reward = bad ? T(0) : reward;
         }
-        T mean_v = seg_sum<SEG>(valid ? v : T(0)) / T(N);
-        T mean_a = seg_sum<SEG>(a) / T(s.num_rl);
-        reward = T(4.0) * mean_v / T(20);
-        if (mean_a > T(0)) reward = reward + T(4) * (T(0) - mean_a);
-        reward = bad ? T(0) : reward;
+      } else {                                                              // wave_attenuation.py:113-139
+        if (act == nullptr) {
+          reward = T(0);
+        } else {
+          T a = T(0);
+          if (ii < s.num_rl && i < N) {
+            a = T(act[ii]);
+            if (s.clip_actions) a = tmin(tmax(a, s.act_lo), s.act_hi);
+            a = tabs(a);
+          }
+          T mean_v = seg_sum<SEG>(valid ? v : T(0)) / T(N);
+          T mean_a = seg_sum<SEG>(a) / T(s.num_rl);
+          reward = T(4.0) * mean_v / T(20);
+          if (mean_a > T(0)) reward = reward + T(4) * (T(0) - mean_a);
+          reward = bad ? T(0) : reward;
+        }
       }
-    }
-    if ((obs_every_step || last) && valid && ii == 0) {
-      rew[so * s.R + rr] = float(reward);
-      done[so * s.R + rr] = uint8_t((tcount >= s.step_limit) || crashed);  // envs/base.py:398-400
+      if (valid && ii == 0) {
+        *rrow = float(reward);
+        *drow = uint8_t((tcount >= s.step_limit) || crashed);              // envs/base.py:398-400
+      }
+      orow += step_rows * obs_dim;
+      rrow += step_rows;
+      drow += step_rows;
     }
   }
 
   if (num_steps == 0) {   // observation of the current state only (Env.reset, envs/base.py:544-551)
-    float* o = obs + size_t(rr) * obs_dim;
-    if (s.env == FS_ENV_WAVE_ATTENUATION_PO) {
+    if (env == FS_ENV_WAVE_ATTENUATION_PO) {
       if (valid && sl.ctrl == FS_CTRL_RL && sl.rl_index == 0) {
-        o[0] = float(v / T(15));
-        o[1] = float((vl - v) / T(15));
-        o[2] = float(d / s.po_max_length);
+        orow[0] = float(v / T(15));
+        orow[1] = float((vl - v) / T(15));
+        orow[2] = float(d / s.po_max_length);
       }
     } else if (valid) {
-      o[ii] = float(v / s.max_speed);
-      o[N + ii] = float(x / L);
+      orow[ii] = float(v / s.max_speed);
+      orow[N + ii] = float(x / L);
     }
     return;
   }
@@ -489,11 +603,13 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
   if (valid && live_replica) {
     s.pos[idx] = x;
     s.vel[idx] = v;
-    if (flags & FLAG_HAS_LAC) s.ctrl_state[idx] = cst;
-    if (s.track_aux) { s.prev_vel[idx] = prev_v; s.accel[idx] = last_acc; }
+    if (!FAST) {
+      if (flags & FLAG_HAS_LAC) s.ctrl_state[idx] = cst;
+      if (s.track_aux) { s.prev_vel[idx] = prev_v; s.accel[idx] = last_acc; }
+    }
     if (ii == 0) {
       s.time[rr] = tcount;
-      if (flags & FLAG_HAS_NOISE) s.noise_ctr[rr] = nctr;
+      if (!FAST && (flags & FLAG_HAS_NOISE)) s.noise_ctr[rr] = nctr;
     }
   }
 }

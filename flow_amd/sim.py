@@ -111,8 +111,12 @@ class FlowSim:
 
     def set_stream(self, hip_stream):
         """Enqueue later launches on ``hip_stream`` (int address of a hipStream_t, e.g.
-        ``torch.cuda.current_stream().cuda_stream``); 0/None restores the handle's own stream."""
+        ``torch.cuda.current_stream().cuda_stream``; 0 is HIP's default stream)."""
         L.check(self.lib.fs_set_stream(self._h, C.c_void_p(int(hip_stream) if hip_stream else None)))
+
+    def use_own_stream(self):
+        """Go back to the non-blocking stream the handle created for itself."""
+        L.check(self.lib.fs_use_own_stream(self._h))
 
     def sync(self):
         L.check(self.lib.fs_sync(self._h))

@@ -157,9 +157,11 @@ int fs_abi_version(void);
 /* observation width of the configured env (observation_space.shape[0]) */
 int fs_obs_dim(fs_handle h);
 
-/* Enqueue all later work of this handle on `hip_stream` (a hipStream_t);
- * NULL restores the handle's own stream. */
+/* Enqueue all later work of this handle on `hip_stream` (a hipStream_t; NULL is
+ * HIP's default stream).  fs_use_own_stream goes back to the non-blocking stream
+ * the handle created for itself. */
 int fs_set_stream(fs_handle h, void* hip_stream);
+int fs_use_own_stream(fs_handle h);
 /* Block until the handle's stream is idle. */
 int fs_sync(fs_handle h);
 

@@ -255,6 +255,32 @@ def test_rollout_equals_repeated_steps_and_full_size_properties():
     a.close(), b.close()
 
 
+def test_specialised_kernel_equals_generic_kernel(monkeypatch):
+    """k_steps<T,SEG,FAST=1> (picked for all-IDM AccelEnv rings) must be bit-identical to the generic path."""
+    import torch
+    R, N, K = 512, 22, 200
+    spec = perturbed(ring_spec(R=R, N=N, junction_length=0.1, horizon=1500), seed=21)
+    outs = []
+    for force in ("1", "0"):
+        monkeypatch.setenv("FLOWSIM_FORCE_GENERIC", force)
+        for prec in ("f32", "f64"):
+            sim = make(spec, prec)
+            sim.reset()
+            dev = torch.device("cuda:0")
+            obs = torch.empty((K, R, 2 * N), dtype=torch.float32, device=dev)
+            rew = torch.empty((K, R), dtype=torch.float32, device=dev)
+            done = torch.empty((K, R), dtype=torch.uint8, device=dev)
+            sim.rollout_dev(K, obs, rew, done, obs_every_step=True)
+            sim.sync()
+            outs.append((prec, force, sim.pos, sim.vel, obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy(),
+                         sim.time_counter))
+            sim.close()
+    for a, b in ((outs[0], outs[2]), (outs[1], outs[3])):
+        assert a[0] == b[0] and a[1] != b[1]
+        for x, y in zip(a[2:], b[2:]):
+            np.testing.assert_array_equal(x, y)
+
+
 def test_abi_rejects_bad_configs():
     spec = ring_spec(R=2, N=5, bunching=0)
     bad = dict(spec)
