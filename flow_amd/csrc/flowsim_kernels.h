@@ -134,34 +134,46 @@ __device__ __forceinline__ double read_lane(double v, int lane) {
   int lo = __builtin_amdgcn_readlane(int(b), lane), hi = __builtin_amdgcn_readlane(int(b >> 32), lane);
   return __builtin_bit_cast(double, (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
 }
-// v + (value of the other 16-lane row of the pair): v_permlane16_swap_b32 (new on gfx950)
+// v + (value of the other 16-lane row of the pair): v_permlane16_swap_b32 (new on gfx950).
+// The two operands are made opaque copies first: given the SAME SSA value twice, hipcc 7.2 folds
+// the two results of the builtin into one register (it emitted v_add_f32 v,v,v after the swap).
+__device__ __forceinline__ void swap_rows16(unsigned& a, unsigned& b) {
+  asm volatile("" : "+v"(a), "+v"(b));
+  auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+}
+__device__ __forceinline__ void swap_rows32(unsigned& a, unsigned& b) {
+  asm volatile("" : "+v"(a), "+v"(b));
+  auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+}
 __device__ __forceinline__ float add_swap16(float v) {
-  unsigned u = __builtin_bit_cast(unsigned, v);
-  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+  unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+  swap_rows16(a, b);
+  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
 }
 __device__ __forceinline__ float add_swap32(float v) {
-  unsigned u = __builtin_bit_cast(unsigned, v);
-  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+  unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+  swap_rows32(a, b);
+  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
 }
 __device__ __forceinline__ double add_swap16(double v) {
-  unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-  unsigned lo = unsigned(b), hi = unsigned(b >> 32);
-  auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-  auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-  double a = __builtin_bit_cast(double, ((unsigned long long)rh[0] << 32) | rl[0]);
-  double c = __builtin_bit_cast(double, ((unsigned long long)rh[1] << 32) | rl[1]);
-  return a + c;
+  unsigned long long bits = __builtin_bit_cast(unsigned long long, v);
+  unsigned lo0 = unsigned(bits), hi0 = unsigned(bits >> 32), lo1 = lo0, hi1 = hi0;
+  swap_rows16(lo0, lo1);
+  swap_rows16(hi0, hi1);
+  return __builtin_bit_cast(double, ((unsigned long long)hi0 << 32) | lo0) +
+         __builtin_bit_cast(double, ((unsigned long long)hi1 << 32) | lo1);
 }
 __device__ __forceinline__ double add_swap32(double v) {
-  unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-  unsigned lo = unsigned(b), hi = unsigned(b >> 32);
-  auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-  auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-  double a = __builtin_bit_cast(double, ((unsigned long long)rh[0] << 32) | rl[0]);
-  double c = __builtin_bit_cast(double, ((unsigned long long)rh[1] << 32) | rl[1]);
-  return a + c;
+  unsigned long long bits = __builtin_bit_cast(unsigned long long, v);
+  unsigned lo0 = unsigned(bits), hi0 = unsigned(bits >> 32), lo1 = lo0, hi1 = hi0;
+  swap_rows32(lo0, lo1);
+  swap_rows32(hi0, hi1);
+  return __builtin_bit_cast(double, ((unsigned long long)hi0 << 32) | lo0) +
+         __builtin_bit_cast(double, ((unsigned long long)hi1 << 32) | lo1);
 }
 
 // value held by the leader's lane (slot i+1, cyclic inside the SEG-lane segment): a one-lane
