@@ -120,7 +120,9 @@ def cpu_baseline(spec_fn, seconds=12.0):
     sim = cbuild.CRingIDM(spec, np.float32, threads=cores)
     sim.rollout(20, obs_every_step=True)               # warm-up
     chunk, done_steps, t0 = 100, 0, time.perf_counter()
-    while time.perf_counter() - t0 < seconds and done_steps < 1500:
+    while time.perf_counter() - t0 < seconds:          # ~10-30 s of CPU work; episodes of 1500 steps
+        if done_steps % 1500 == 0:
+            sim.reset()
         sim.rollout(chunk, obs_every_step=True)
         done_steps += chunk
     dt = time.perf_counter() - t0
@@ -202,7 +204,7 @@ def main():
     bytes_per_launch = R * (k_launch * obs_b + state_b)
     achieved = bytes_per_launch / avg_launch_s / 1e9
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
     if os.path.exists(tpath) and args.precision == "f32":
         try:
             tj = json.load(open(tpath))
@@ -210,7 +212,8 @@ def main():
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "fs::k_steps<%s,32>" % ("float" if args.precision == "f32" else "double"),
+    roofline = {"bound": "hbm",
+                "kernel": "fs::k_rollout_idm<%s, 32, true>" % ("float" if args.precision == "f32" else "double"),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "bytes_per_launch": bytes_per_launch, "steps_per_launch": k_launch,
                 "avg_launch_ms": avg_launch_s * 1e3, "launches_timed": len(full),

@@ -47,6 +47,7 @@ struct SimBase {
   float* d_rew = nullptr;
   uint8_t* d_done = nullptr;
   uint8_t* d_mask = nullptr;
+  float* d_dump = nullptr;      // scratch words the idle lanes of k_rollout_idm store to
   std::vector<void*> allocs;
   bool force_generic = false;   // FLOWSIM_FORCE_GENERIC=1: never take the specialised kernel (tests)
 
@@ -136,6 +137,8 @@ struct Sim : SimBase {
       if (v.controller != FS_CTRL_IDM) all_idm = false;
     }
     if (all_idm) flags |= fs::FLAG_ALL_IDM;
+    delta4 = all_idm;
+    for (int i = 0; i < N; ++i) delta4 = delta4 && (veh[i].p[4] == 4.0);
     h_len = len;
     if ((rc = upload(&dv.ctrl, ctrl))) return rc;
     if ((rc = upload(&dv.failsafe, fsafe))) return rc;
@@ -191,10 +194,12 @@ struct Sim : SimBase {
     if ((rc = dev_alloc(&d_rew, size_t(R)))) return rc;
     if ((rc = dev_alloc(&d_done, size_t(R)))) return rc;
     if ((rc = dev_alloc(&d_mask, size_t(R)))) return rc;
+    if ((rc = dev_alloc(&d_dump, size_t(256)))) return rc;
     return launch_reset(nullptr);
   }
 
-  // the specialisation of k_steps for the headline configuration (see flowsim_kernels.h)
+  // the specialisations for the headline configuration (see flowsim_kernels.h)
+  bool delta4 = false;
   bool fast_ok(const uint8_t* mask, int num_steps) const {
     const int f = dv.flags;
     return (f & fs::FLAG_ALL_IDM) && !(f & (fs::FLAG_HAS_NOISE | fs::FLAG_HAS_FAILSAFE | fs::FLAG_NEED_SUMO)) &&
@@ -207,7 +212,14 @@ struct Sim : SimBase {
                  float* rew, uint8_t* done, int obs_every_step) {
     constexpr int RPW = 64 / SEG;
     const int blocks = (dv.R + RPW - 1) / RPW;
-    if (fast_ok(mask, num_steps))
+    if (fast_ok(mask, num_steps) && obs_every_step && dv.N > 1 && actions == nullptr) {
+      if (delta4)
+        hipLaunchKernelGGL((fs::k_rollout_idm<T, SEG, true>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, obs,
+                           rew, done, d_dump);
+      else
+        hipLaunchKernelGGL((fs::k_rollout_idm<T, SEG, false>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, obs,
+                           rew, done, d_dump);
+    } else if (fast_ok(mask, num_steps))
       hipLaunchKernelGGL((fs::k_steps<T, SEG, 1>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, mask, actions,
                          act_stride, obs, rew, done, obs_every_step);
     else

@@ -626,6 +626,110 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
   }
 }
 
+// ---------------------------------------------------------------------------
+// k_rollout_idm: the rollout kernel of the headline configuration
+// ---------------------------------------------------------------------------
+// Same arithmetic as k_steps (same helpers, same order), restricted to what the host checks
+// before choosing it (Sim::rollout_idm_ok): every slot an IDMController without noise or
+// fail-safe, speed_mode "aggressive", no junction mode, Euler, sims_per_step 1, N > 1, AccelEnv
+// head with the desired_velocity reward, observation written EVERY step.  Differences are
+// purely structural, to keep the step loop one straight-line block the scheduler can overlap:
+//   * idle lanes store to a scratch word instead of being masked off (no exec-mask regions);
+//   * the per-replica reward tail (sqrt, divide) is deferred: lane j of a segment keeps the
+//     reduced sum of squares of step j (mod SEG) and all SEG rewards are finished and
+//     stored together every SEG steps, one step per lane.
+template <typename T, int SEG, bool DELTA4>
+__global__ __launch_bounds__(64) void k_rollout_idm(DevView<T> s, int num_steps, float* __restrict__ obs,
+                                                    float* __restrict__ rew, uint8_t* __restrict__ done,
+                                                    float* __restrict__ dump) {
+  constexpr int RPW = 64 / SEG;
+  const int lane = threadIdx.x;
+  const int seg = lane / SEG;
+  const int i = lane % SEG;
+  const int r = blockIdx.x * RPW + seg;
+  const int N = s.N;
+  const bool rvalid = r < s.R;
+  const bool valid = rvalid && i < N;
+  const int rr = rvalid ? r : s.R - 1;
+  const int ii = i < N ? i : N - 1;
+  const size_t idx = size_t(rr) * N + ii;
+  const bool wrap_lead = (i + 1 >= N);
+
+  T p[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) p[k] = s.p[k * N + ii];
+  const T len_lead = lead_read<SEG>(s.length[ii], seg, wrap_lead);
+  const T base_len = s.ring_len[rr];
+  const T L = base_len + T(4) * s.jlen;
+  int tcount = s.time[rr];
+  T x = s.pos[idx];
+  T v = s.vel[idx];
+  T xl = lead_read<SEG>(x, seg, wrap_lead);
+  T vl = lead_read<SEG>(v, seg, wrap_lead);
+  T d = xl - x;
+  d = d < T(0) ? d + L : d;
+  T h = d - len_lead;
+
+  const T dt = s.dt, ramp = s.ramp;
+  const size_t row = size_t(2) * N;
+  float* po = valid ? obs + size_t(rr) * row + ii : dump;     // idle lanes write scratch
+  const size_t po_step = valid ? size_t(s.R) * row : 0;          // the scratch word does not move
+  T racc = T(0);
+  unsigned dacc = 0u;
+
+  for (int step = 0; step < num_steps; ++step) {
+    // IDMController.get_accel (ctrl_idm, car_following_models.py:464-482)
+    T hh = tabs(h) < T(1e-3) ? T(1e-3) : h;
+    T two_sqrt_ab = T(2) * tsqrt(p[2] * p[3]);
+    T dyn = v * p[1] + v * (v - vl) / two_sqrt_ab;
+    T s_star = p[5] + tmax(T(0), dyn);
+    T q = s_star / hh;
+    T ratio = v / p[0];
+    T pw;
+    if (DELTA4) { T r2 = ratio * ratio; pw = r2 * r2; } else { pw = pow_delta(ratio, p[4]); }
+    T acc = p[2] * (T(1) - pw - q * q);
+    // apply_acceleration + integration (S4-S9)
+    T next_vel = tmax(v + acc * dt, T(0));
+    v = v + (next_vel - v) * ramp;
+    T x_new = x + v * dt;
+    x = x_new >= L ? x_new - L : x_new;
+    tcount += 1;
+    // new neighbour snapshot (S10) and collision check (S12)
+    xl = lead_read<SEG>(x, seg, wrap_lead);
+    vl = lead_read<SEG>(v, seg, wrap_lead);
+    d = xl - x;
+    d = d < T(0) ? d + L : d;
+    h = d - len_lead;
+    const bool crashed = seg_any<SEG>(valid && (h < s.crash_gap), seg);
+    // AccelEnv.get_state (accel.py:116-123)
+    po[0] = float(v / s.max_speed);
+    po[N] = float(x / L);
+    po += po_step;
+    // rewards.desired_velocity, first half: the reduced sum of squares (rewards.py:53-54)
+    T dv = valid ? v - s.target_velocity : T(0);
+    T ssum = seg_sum<SEG>(dv * dv);
+    const bool bad = seg_any<SEG>(valid && (v < T(-100)), seg) || crashed;
+    const int slot = step & (SEG - 1);
+    racc = (i == slot) ? (bad ? T(-1) : ssum) : racc;
+    dacc = (i == slot) ? unsigned((tcount >= s.step_limit) || crashed) : dacc;
+    if (slot == SEG - 1 || step == num_steps - 1) {          // wave-uniform: finish SEG rewards at once
+      if (rvalid && i <= slot) {
+        T cost = tsqrt(racc < T(0) ? T(0) : racc);
+        T reward = tmax(s.max_cost - cost, T(0)) / (s.max_cost + T(1.1920928955078125e-07));   // rewards.py:59
+        reward = racc < T(0) ? T(0) : reward;                                                   // rewards.py:46
+        const size_t o = size_t(step - slot + i) * s.R + rr;
+        rew[o] = float(reward);
+        done[o] = uint8_t(dacc);                                                                // envs/base.py:398-400
+      }
+    }
+  }
+  if (valid) {
+    s.pos[idx] = x;
+    s.vel[idx] = v;
+    if (ii == 0) s.time[rr] = tcount;
+  }
+}
+
 // Env.reset placement (envs/base.py:430, 494-518): selected replicas go back to
 // their initial state; vehicles are inserted without moving (S13).
 template <typename T>
