@@ -64,7 +64,13 @@ class Env(_Base):
         self._last_obs = None
         self._last_reward = 0.0
         self._crash = False
+        self._recorder = None
+        self._sim_time = 0.0
         self.setup_initial_state()
+        if self.sim_params.emission_path is not None:
+            from flow_amd.core.util import TrajectoryRecorder, ensure_dir
+            ensure_dir(self.sim_params.emission_path)
+            self._recorder = TrajectoryRecorder(self)
         atexit.register(self.terminate)
 
     # ------------------------------------------------------------------ construction
@@ -126,6 +132,9 @@ class Env(_Base):
         self._crash = crash
         self.k.simulation.crashed = crash
         self._last_obs, self._last_reward = obs[0], float(rew[0])
+        if self._recorder is not None:
+            self._sim_time += n_sub * self.sim_step
+            self._recorder.record(self._sim_time)
         states = self.get_state()
         self.state = np.asarray(states).T
         next_observation = np.copy(states)
@@ -146,6 +155,10 @@ class Env(_Base):
         self.k.update(reset=True)
         self.time_counter = int(self.sim.time_counter[0])
         self._last_obs, self._last_reward, self._crash = obs[0], 0.0, False
+        if self._recorder is not None:
+            # SUMO inserts the vehicles during the reset step: first emission row is t = sim_step
+            self._sim_time = self.sim_step * (1 + self.time_counter)
+            self._recorder.record(self._sim_time)
         states = self.get_state()
         self.state = np.asarray(states).T
         return np.copy(states)
@@ -186,6 +199,17 @@ class Env(_Base):
         if getattr(self, "sim", None) is not None:
             self.sim.close()
             self.sim = None
+
+    def write_emission(self, path=None):
+        """Write the recorded trajectory as ``{network.name}-emission.csv`` under
+        ``sim_params.emission_path`` (the file Experiment.run(convert_to_csv=True) leaves behind,
+        flow/core/experiment.py:182-196)."""
+        if self._recorder is None:
+            return None
+        if path is None:
+            import os
+            path = os.path.join(self.sim_params.emission_path, "{0}-emission.csv".format(self.network.name))
+        return self._recorder.write(path)
 
     def render(self, reset=False, buffer_length=5):
         pass

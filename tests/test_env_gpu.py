@@ -220,3 +220,43 @@ def test_custom_python_env_hooks_still_work():
     np.testing.assert_allclose(rew, np.mean(env.k.vehicle.get_speed(env.k.vehicle.get_ids())))
     np.testing.assert_allclose(obs.sum(), env.k.network.length() - 6 * 5, atol=1e-3)
     env.terminate()
+
+
+def test_experiment_run_and_emission_csv(tmp_path):
+    """Experiment.run contract (reference tests/fast_tests/test_experiment_base_class.py:40-77, 120-185):
+    horizon honoured, runs deterministic, emission CSV with the reference's columns; and the first rows
+    reproduce the reference's SUMO fixture to its 2-decimal precision."""
+    import csv
+    import os
+    from flow_amd.core.experiment import Experiment
+    fp = ring_flow_params(n=22, horizon=12, emission_path=str(tmp_path), junction_length=0.0)
+    exp = Experiment(fp)
+    info = exp.run(2, convert_to_csv=True)
+    assert len(info["returns"]) == 2 and info["returns"][0] == info["returns"][1]
+    assert exp.env.time_counter == 12
+    path = info["emission_csv"]
+    assert os.path.basename(path).startswith("ring_") and path.endswith("-emission.csv")
+    rows = list(csv.DictReader(open(path)))
+    for col in ("time", "id", "edge_id", "relative_position", "speed", "lane_number", "x", "y"):
+        assert col in rows[0]
+    assert len(rows) == 2 * 13 * 22
+    golden = os.path.join(os.path.dirname(__file__), "golden", "ring_230_emission.csv")
+    ref = {(r["id"], round(float(r["time"]), 1)): r for r in csv.DictReader(open(golden))}
+    mine = {}
+    for r in rows:                       # first run only
+        key = (r["id"], round(float(r["time"]), 1))
+        mine.setdefault(key, r)
+    checked = 0
+    for (vid, t), r in ref.items():
+        if t > 0.5:
+            continue
+        m = mine[(vid, t)]
+        assert round(float(m["speed"]), 2) == float(r["speed"])
+        assert m["edge_id"] == r["edge_id"]
+        # the fixture predates the 0.1 m junction offsets of the edge-start table: compare loop coordinates
+        k = ["bottom", "right", "top", "left"].index(r["edge_id"])
+        mine_s = k * 57.6 + float(m["relative_position"])
+        ref_s = k * 57.5 + float(r["relative_position"])
+        assert abs(mine_s - ref_s) <= 0.0051
+        checked += 1
+    assert checked == 110
