@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "flowsim.h"
@@ -49,7 +50,8 @@ struct SimBase {
   uint8_t* d_mask = nullptr;
   float* d_dump = nullptr;      // scratch words the idle lanes of k_rollout_idm store to
   std::vector<void*> allocs;
-  bool force_generic = false;   // FLOWSIM_FORCE_GENERIC=1: never take the specialised kernel (tests)
+  bool force_generic = false;   // FLOWSIM_FORCE_GENERIC=1: never take the specialised kernels (tests)
+  bool no_fastdiv = false;      // FLOWSIM_NO_FASTDIV=1: keep the IEEE division sequence in k_rollout_idm
 
   virtual int launch_steps(int num_steps, const uint8_t* mask, const float* actions, size_t act_stride,
                            float* obs, float* rew, uint8_t* done, int obs_every_step) = 0;
@@ -198,6 +200,54 @@ struct Sim : SimBase {
     return launch_reset(nullptr);
   }
 
+  // ---- exact division by launch constants (flowsim_kernels.h div_const) --------------------
+  // The 3-operation reciprocal sequence is enabled only if, for every divisor the rollout kernel
+  // will use (v0 and 2*sqrt(a*b) of every slot, max_speed, the loop length of every replica), it
+  // reproduces x / c for ALL 2^23 float mantissas of x.  Checked lazily, once per handle state;
+  // set_state of the ring lengths invalidates it.  Only the float kernels use it.
+  int fastdiv_state = -1;       // -1 unknown, 0 no, 1 yes
+  static bool fastdiv_exact_for(float c) {
+    if (!(c > 0.0f) || !std::isfinite(c)) return false;
+    const float rc = 1.0f / c;
+    for (uint32_t m = 0; m < (1u << 23); ++m) {
+      const uint32_t bits = 0x3F800000u | m;
+      float x;
+      std::memcpy(&x, &bits, 4);
+      const float q0 = x * rc;
+      const float r = std::fmaf(-q0, c, x);
+      if (std::fmaf(r, rc, q0) != x / c) return false;
+    }
+    return true;
+  }
+  bool fastdiv_ok() {
+    if (!std::is_same<T, float>::value || force_generic || no_fastdiv) return false;
+    if (fastdiv_state >= 0) return fastdiv_state == 1;
+    fastdiv_state = 0;
+    std::vector<float> cs;
+    auto add = [&cs](float c) {
+      for (float e : cs)
+        if (e == c) return;
+      cs.push_back(c);
+    };
+    for (int i = 0; i < dv.N; ++i) {
+      add(float(veh[i].p[0]));
+      add(2.0f * std::sqrt(float(veh[i].p[2]) * float(veh[i].p[3])));
+    }
+    add(float(dv.max_speed));
+    std::vector<T> rl(size_t(dv.R));
+    if (hipMemcpy(rl.data(), dv.ring_len, rl.size() * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) return false;
+    for (T b : rl) {
+      const float L = float(b) + 4.0f * float(dv.jlen);
+      if (!(L >= 1.0f)) return false;        // keeps x = 0 or x >= ulp(L)/2 out of the tiny range
+      add(L);
+      if (cs.size() > 80) return false;      // too many distinct loop lengths to verify cheaply
+    }
+    for (float c : cs)
+      if (!fastdiv_exact_for(c)) return false;
+    fastdiv_state = 1;
+    return true;
+  }
+
   // the specialisations for the headline configuration (see flowsim_kernels.h)
   bool delta4 = false;
   bool fast_ok(const uint8_t* mask, int num_steps) const {
@@ -213,12 +263,16 @@ struct Sim : SimBase {
     constexpr int RPW = 64 / SEG;
     const int blocks = (dv.R + RPW - 1) / RPW;
     if (fast_ok(mask, num_steps) && obs_every_step && dv.N > 1 && actions == nullptr) {
-      if (delta4)
-        hipLaunchKernelGGL((fs::k_rollout_idm<T, SEG, true>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, obs,
-                           rew, done, d_dump);
+      const bool fd = fastdiv_ok();
+      if (delta4 && fd)
+        hipLaunchKernelGGL((fs::k_rollout_idm<T, SEG, true, true>), dim3(blocks), dim3(64), 0, stream, dv, num_steps,
+                           obs, rew, done, d_dump);
+      else if (delta4)
+        hipLaunchKernelGGL((fs::k_rollout_idm<T, SEG, true, false>), dim3(blocks), dim3(64), 0, stream, dv, num_steps,
+                           obs, rew, done, d_dump);
       else
-        hipLaunchKernelGGL((fs::k_rollout_idm<T, SEG, false>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, obs,
-                           rew, done, d_dump);
+        hipLaunchKernelGGL((fs::k_rollout_idm<T, SEG, false, false>), dim3(blocks), dim3(64), 0, stream, dv,
+                           num_steps, obs, rew, done, d_dump);
     } else if (fast_ok(mask, num_steps))
       hipLaunchKernelGGL((fs::k_steps<T, SEG, 1>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, mask, actions,
                          act_stride, obs, rew, done, obs_every_step);
@@ -315,6 +369,7 @@ struct Sim : SimBase {
     if (!p) return fail(FS_ERR_INVALID, "fs_set_state: unknown field");
     if (bytes != count * sizeof(T)) return fail(FS_ERR_INVALID, "fs_set_state: wrong byte count");
     HIP_TRY(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+    if (field == FS_FIELD_RING_LENGTH) fastdiv_state = -1;
     return FS_OK;
   }
 };
@@ -388,6 +443,8 @@ int create_typed(const fs_config* cfg, fs_handle* out) {
   {
     const char* fg = std::getenv("FLOWSIM_FORCE_GENERIC");
     s->force_generic = fg && fg[0] == '1';
+    const char* nf = std::getenv("FLOWSIM_NO_FASTDIV");
+    s->no_fastdiv = nf && nf[0] == '1';
   }
   int rc = s->init();
   if (rc == FS_OK) {

@@ -638,7 +638,25 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
 //   * the per-replica reward tail (sqrt, divide) is deferred: lane j of a segment keeps the
 //     reduced sum of squares of step j (mod SEG) and all SEG rewards are finished and
 //     stored together every SEG steps, one step per lane.
-template <typename T, int SEG, bool DELTA4>
+// x / c for a divisor c that is constant over the launch.  FASTDIV (float only) replaces the
+// IEEE division sequence by q0 = x*rc, r = fma(-q0, c, x), q = fma(r, rc, q0) with rc = RN(1/c).
+// The host enables it per handle only after checking, for EVERY float mantissa of x, that the
+// result equals x / c for each divisor used (Sim::verify_fastdiv, 2^23 cases per divisor): the
+// check is scale-invariant, so it covers every x whose remainder r stays a normal number; the
+// kernel routes dividends below 1e-15 (vehicles coming to rest) to the true division instead.
+template <bool FASTDIV>
+__device__ __forceinline__ float div_const(float x, float c, float rc) {
+  if (FASTDIV) {
+    float q0 = x * rc;
+    float r = __builtin_fmaf(-q0, c, x);
+    return __builtin_fmaf(r, rc, q0);
+  }
+  return x / c;
+}
+template <bool FASTDIV>
+__device__ __forceinline__ double div_const(double x, double c, double) { return x / c; }
+
+template <typename T, int SEG, bool DELTA4, bool FASTDIV>
 __global__ __launch_bounds__(64) void k_rollout_idm(DevView<T> s, int num_steps, float* __restrict__ obs,
                                                     float* __restrict__ rew, uint8_t* __restrict__ done,
                                                     float* __restrict__ dump) {
@@ -671,6 +689,8 @@ __global__ __launch_bounds__(64) void k_rollout_idm(DevView<T> s, int num_steps,
   T h = d - len_lead;
 
   const T dt = s.dt, ramp = s.ramp;
+  const T two_sqrt_ab = T(2) * tsqrt(p[2] * p[3]);
+  const T rc_v0 = T(1) / p[0], rc_ab = T(1) / two_sqrt_ab, rc_ms = T(1) / s.max_speed, rc_L = T(1) / L;
   const size_t row = size_t(2) * N;
   float* po = valid ? obs + size_t(rr) * row + ii : dump;     // idle lanes write scratch
   const size_t po_step = valid ? size_t(s.R) * row : 0;          // the scratch word does not move
@@ -680,11 +700,21 @@ __global__ __launch_bounds__(64) void k_rollout_idm(DevView<T> s, int num_steps,
   for (int step = 0; step < num_steps; ++step) {
     // IDMController.get_accel (ctrl_idm, car_following_models.py:464-482)
     T hh = tabs(h) < T(1e-3) ? T(1e-3) : h;
-    T two_sqrt_ab = T(2) * tsqrt(p[2] * p[3]);
-    T dyn = v * p[1] + v * (v - vl) / two_sqrt_ab;
+    T num = v * (v - vl);
+    T dq = div_const<FASTDIV>(num, two_sqrt_ab, rc_ab);
+    T ratio = div_const<FASTDIV>(v, p[0], rc_v0);
+    if (FASTDIV) {
+      // a speed in (0, 1e-15): its quotients leave the verified range -> true division (rare:
+      // only while a vehicle decays to rest); wave-uniform branch
+      const bool tiny = (v != T(0)) && (tabs(v) < T(1e-15));
+      if (__ballot(tiny) != 0ull) {
+        dq = tiny ? num / two_sqrt_ab : dq;
+        ratio = tiny ? v / p[0] : ratio;
+      }
+    }
+    T dyn = v * p[1] + dq;
     T s_star = p[5] + tmax(T(0), dyn);
     T q = s_star / hh;
-    T ratio = v / p[0];
     T pw;
     if (DELTA4) { T r2 = ratio * ratio; pw = r2 * r2; } else { pw = pow_delta(ratio, p[4]); }
     T acc = p[2] * (T(1) - pw - q * q);
@@ -702,8 +732,13 @@ __global__ __launch_bounds__(64) void k_rollout_idm(DevView<T> s, int num_steps,
     h = d - len_lead;
     const bool crashed = seg_any<SEG>(valid && (h < s.crash_gap), seg);
     // AccelEnv.get_state (accel.py:116-123)
-    po[0] = float(v / s.max_speed);
-    po[N] = float(x / L);
+    T ov = div_const<FASTDIV>(v, s.max_speed, rc_ms);
+    if (FASTDIV) {
+      const bool tiny = (v != T(0)) && (tabs(v) < T(1e-15));
+      if (__ballot(tiny) != 0ull) ov = tiny ? v / s.max_speed : ov;
+    }
+    po[0] = float(ov);
+    po[N] = float(div_const<FASTDIV>(x, L, rc_L));     // x is 0 or >= ulp(L)/2: never in the tiny range
     po += po_step;
     // rewards.desired_velocity, first half: the reduced sum of squares (rewards.py:53-54)
     T dv = valid ? v - s.target_velocity : T(0);

@@ -255,6 +255,40 @@ def test_rollout_equals_repeated_steps_and_full_size_properties():
     a.close(), b.close()
 
 
+def test_dense_ring_stop_and_go_through_denormal_speeds_bit_exact():
+    """Vehicles packed tighter than the IDM jam distance brake to a standstill: speeds decay through the
+    tiny / denormal range (v -> v/101 per step), the regime where the constant-divisor fast path must hand
+    over to the true division.  Step API (generic kernel) and rollout kernel, both against the oracle."""
+    import torch
+    R, N, K = 16, 22, 160
+    spec = perturbed(ring_spec(R=R, N=N, length=150.0, bunching=0, junction_length=0.1, horizon=400), seed=31,
+                     sigma=0.05)
+    rng = np.random.default_rng(5)
+    spec["init_vel"] = rng.uniform(0.0, 3.0, (R, N))
+    ora = run_pair(spec, "f32", K, check_every=8)
+    assert (ora.v == 0).any() and ((ora.v > 0) & (ora.v < 1e-30)).any() or (ora.v == 0).any()
+    sim = make(spec, "f32")
+    sim.reset()
+    dev = torch.device("cuda:0")
+    obs = torch.empty((K, R, 2 * N), dtype=torch.float32, device=dev)
+    rew = torch.empty((K, R), dtype=torch.float32, device=dev)
+    done = torch.empty((K, R), dtype=torch.uint8, device=dev)
+    sim.rollout_dev(K, obs, rew, done, obs_every_step=True)
+    sim.sync()
+    ref = S.RingOracle(spec, np.float32)
+    ref.reset()
+    seen_tiny = False
+    for k in range(K):
+        o, r, d = ref.step(None)
+        seen_tiny |= bool(((ref.v > 0) & (ref.v < 1e-15)).any())
+        np.testing.assert_array_equal(obs[k].cpu().numpy(), o.astype(np.float32))
+        np.testing.assert_array_equal(rew[k].cpu().numpy(), r.astype(np.float32))
+    assert seen_tiny, "the scenario must exercise the tiny-speed hand-over"
+    np.testing.assert_array_equal(sim.pos, ref.x)
+    np.testing.assert_array_equal(sim.vel, ref.v)
+    sim.close()
+
+
 def test_specialised_kernel_equals_generic_kernel(monkeypatch):
     """k_steps<T,SEG,FAST=1> (picked for all-IDM AccelEnv rings) must be bit-identical to the generic path."""
     import torch
@@ -263,6 +297,7 @@ def test_specialised_kernel_equals_generic_kernel(monkeypatch):
     outs = []
     for force in ("1", "0"):
         monkeypatch.setenv("FLOWSIM_FORCE_GENERIC", force)
+        monkeypatch.setenv("FLOWSIM_NO_FASTDIV", "0")
         for prec in ("f32", "f64"):
             sim = make(spec, prec)
             sim.reset()
