@@ -202,7 +202,7 @@ struct Sim : SimBase {
 
   // ---- exact division by launch constants (flowsim_kernels.h div_const) --------------------
   // The 3-operation reciprocal sequence is enabled only if, for every divisor the rollout kernel
-  // will use (v0 and 2*sqrt(a*b) of every slot, max_speed, the loop length of every replica), it
+  // will use (the loop length of every replica), it
   // reproduces x / c for ALL 2^23 float mantissas of x.  Checked lazily, once per handle state;
   // set_state of the ring lengths invalidates it.  Only the float kernels use it.
   int fastdiv_state = -1;       // -1 unknown, 0 no, 1 yes
@@ -229,11 +229,6 @@ struct Sim : SimBase {
         if (e == c) return;
       cs.push_back(c);
     };
-    for (int i = 0; i < dv.N; ++i) {
-      add(float(veh[i].p[0]));
-      add(2.0f * std::sqrt(float(veh[i].p[2]) * float(veh[i].p[3])));
-    }
-    add(float(dv.max_speed));
     std::vector<T> rl(size_t(dv.R));
     if (hipMemcpy(rl.data(), dv.ring_len, rl.size() * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) return false;
     for (T b : rl) {

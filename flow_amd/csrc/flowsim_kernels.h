@@ -104,7 +104,7 @@ __device__ __forceinline__ T pow_delta(T x, T d) {
 // ---------------------------------------------------------------------------
 // cross-lane primitives: DPP / v_readlane / v_permlane*_swap (VALU, no LDS-crossbar latency)
 // ---------------------------------------------------------------------------
-// DPP controls (GFX9 encoding): lanes with no source keep their own value.
+// DPP controls (GFX9 encoding).
 enum : int {
   DPP_QUAD_XOR1 = 0xB1,     // quad_perm:[1,0,3,2]
   DPP_QUAD_XOR2 = 0x4E,     // quad_perm:[2,3,0,1]
@@ -114,8 +114,11 @@ enum : int {
   DPP_ROW_HALF_MIRROR = 0x141  // lane i <- lane 7-i (within a half row of 8)
 };
 
+// bound_ctrl: a lane whose source does not exist reads 0 (only the last / first lane of the wave
+// under wave_shl / wave_shr, which callers patch); with old = 0 the compiler folds the move into
+// the consuming VALU instruction (v_add_f32_dpp), halving the cost of a reduction level.
 template <int CTRL>
-__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
 template <int CTRL>
 __device__ __forceinline__ float dpp(float v) {
   return __builtin_bit_cast(float, dpp_i<CTRL>(__builtin_bit_cast(int, v)));
@@ -641,9 +644,12 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
 // x / c for a divisor c that is constant over the launch.  FASTDIV (float only) replaces the
 // IEEE division sequence by q0 = x*rc, r = fma(-q0, c, x), q = fma(r, rc, q0) with rc = RN(1/c).
 // The host enables it per handle only after checking, for EVERY float mantissa of x, that the
-// result equals x / c for each divisor used (Sim::verify_fastdiv, 2^23 cases per divisor): the
-// check is scale-invariant, so it covers every x whose remainder r stays a normal number; the
-// kernel routes dividends below 1e-15 (vehicles coming to rest) to the true division instead.
+// result equals x / c for each divisor used (Sim::fastdiv_ok, 2^23 cases per divisor): the check
+// is scale-invariant, so it covers every x whose remainder r stays a normal number.  It is used
+// for the position quotient x / L only (x is 0 or >= ulp(L)/2).  Speeds decay through the
+// denormal range whenever a vehicle comes to rest, and guarding those dividends per step cost
+// more than the shorter sequence saved (measured: 6.81 vs 7.12 G env-steps/s), so every quotient
+// of a speed keeps the IEEE sequence.
 template <bool FASTDIV>
 __device__ __forceinline__ float div_const(float x, float c, float rc) {
   if (FASTDIV) {
@@ -690,7 +696,7 @@ __global__ __launch_bounds__(64) void k_rollout_idm(DevView<T> s, int num_steps,
 
   const T dt = s.dt, ramp = s.ramp;
   const T two_sqrt_ab = T(2) * tsqrt(p[2] * p[3]);
-  const T rc_v0 = T(1) / p[0], rc_ab = T(1) / two_sqrt_ab, rc_ms = T(1) / s.max_speed, rc_L = T(1) / L;
+  const T rc_L = T(1) / L;
   const size_t row = size_t(2) * N;
   float* po = valid ? obs + size_t(rr) * row + ii : dump;     // idle lanes write scratch
   const size_t po_step = valid ? size_t(s.R) * row : 0;          // the scratch word does not move
@@ -701,17 +707,8 @@ __global__ __launch_bounds__(64) void k_rollout_idm(DevView<T> s, int num_steps,
     // IDMController.get_accel (ctrl_idm, car_following_models.py:464-482)
     T hh = tabs(h) < T(1e-3) ? T(1e-3) : h;
     T num = v * (v - vl);
-    T dq = div_const<FASTDIV>(num, two_sqrt_ab, rc_ab);
-    T ratio = div_const<FASTDIV>(v, p[0], rc_v0);
-    if (FASTDIV) {
-      // a speed in (0, 1e-15): its quotients leave the verified range -> true division (rare:
-      // only while a vehicle decays to rest); wave-uniform branch
-      const bool tiny = (v != T(0)) && (tabs(v) < T(1e-15));
-      if (__ballot(tiny) != 0ull) {
-        dq = tiny ? num / two_sqrt_ab : dq;
-        ratio = tiny ? v / p[0] : ratio;
-      }
-    }
+    T dq = num / two_sqrt_ab;
+    T ratio = v / p[0];
     T dyn = v * p[1] + dq;
     T s_star = p[5] + tmax(T(0), dyn);
     T q = s_star / hh;
@@ -732,13 +729,10 @@ __global__ __launch_bounds__(64) void k_rollout_idm(DevView<T> s, int num_steps,
     h = d - len_lead;
     const bool crashed = seg_any<SEG>(valid && (h < s.crash_gap), seg);
     // AccelEnv.get_state (accel.py:116-123)
-    T ov = div_const<FASTDIV>(v, s.max_speed, rc_ms);
-    if (FASTDIV) {
-      const bool tiny = (v != T(0)) && (tabs(v) < T(1e-15));
-      if (__ballot(tiny) != 0ull) ov = tiny ? v / s.max_speed : ov;
-    }
-    po[0] = float(ov);
-    po[N] = float(div_const<FASTDIV>(x, L, rc_L));     // x is 0 or >= ulp(L)/2: never in the tiny range
+    po[0] = float(v / s.max_speed);
+    // speeds decay through the denormal range when a vehicle comes to rest, so only the position
+    // quotient takes the constant-divisor path: x is 0 or >= ulp(L)/2, never tiny
+    po[N] = float(div_const<FASTDIV>(x, L, rc_L));
     po += po_step;
     // rewards.desired_velocity, first half: the reduced sum of squares (rewards.py:53-54)
     T dv = valid ? v - s.target_velocity : T(0);
