@@ -11,7 +11,7 @@ from .utils.exceptions import FatalFlowError
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libflowsim.so")
 
-FS_ABI_VERSION = 1
+FS_ABI_VERSION = 2
 FS_MAX_CTRL_PARAMS = 8
 
 # error codes
@@ -24,15 +24,16 @@ FS_F32, FS_F64 = 0, 1
 # enum fs_failsafe
 FS_FAILSAFE_NONE, FS_FAILSAFE_INSTANTANEOUS, FS_FAILSAFE_SAFE_VELOCITY = range(3)
 # enum fs_env
-FS_ENV_ACCEL, FS_ENV_WAVE_ATTENUATION, FS_ENV_WAVE_ATTENUATION_PO = range(3)
+FS_ENV_ACCEL, FS_ENV_WAVE_ATTENUATION, FS_ENV_WAVE_ATTENUATION_PO, FS_ENV_LANE_CHANGE_ACCEL = range(4)
 # enum fs_network / fs_integrator
 FS_NET_RING = 0
 FS_EULER, FS_BALLISTIC = 0, 1
 # enum fs_field
 (FS_FIELD_POS, FS_FIELD_VEL, FS_FIELD_HEADWAY, FS_FIELD_PREV_VEL, FS_FIELD_ACCEL, FS_FIELD_TIME,
- FS_FIELD_RING_LENGTH, FS_FIELD_INIT_POS, FS_FIELD_INIT_VEL, FS_FIELD_CTRL_STATE) = range(10)
+ FS_FIELD_RING_LENGTH, FS_FIELD_INIT_POS, FS_FIELD_INIT_VEL, FS_FIELD_CTRL_STATE, FS_FIELD_LANE,
+ FS_FIELD_LAST_LC, FS_FIELD_LEADER, FS_FIELD_INIT_LANE) = range(14)
 
-EXPORTS = ["fs_create", "fs_destroy", "fs_last_error", "fs_abi_version", "fs_obs_dim", "fs_set_stream",
+EXPORTS = ["fs_create", "fs_destroy", "fs_last_error", "fs_abi_version", "fs_obs_dim", "fs_action_dim", "fs_set_stream",
            "fs_use_own_stream", "fs_sync", "fs_reset", "fs_reset_dev", "fs_step", "fs_step_dev", "fs_rollout_dev",
            "fs_get_state", "fs_set_state"]
 
@@ -51,13 +52,15 @@ class fs_config(C.Structure):
                 ("num_replicas", C.c_int32), ("num_vehicles", C.c_int32), ("num_rl", C.c_int32),
                 ("horizon", C.c_int32), ("warmup_steps", C.c_int32), ("sims_per_step", C.c_int32),
                 ("junction_mode", C.c_int32), ("clip_actions", C.c_int32), ("evaluate", C.c_int32),
-                ("device", C.c_int32), ("track_aux", C.c_int32), ("reserved0", C.c_int32),
+                ("device", C.c_int32), ("track_aux", C.c_int32), ("num_lanes", C.c_int32),
+                ("lane_change_mode", C.c_int32), ("last_lc_quirk", C.c_int32),
                 ("seed", C.c_uint64), ("sim_step", C.c_double), ("slowdown_ramp", C.c_double),
                 ("junction_length", C.c_double), ("crash_gap", C.c_double), ("max_speed", C.c_double),
                 ("target_velocity", C.c_double), ("action_low", C.c_double), ("action_high", C.c_double),
-                ("po_max_length", C.c_double), ("vehicles", C.POINTER(fs_vehicle_spec)),
+                ("po_max_length", C.c_double), ("lane_change_duration", C.c_double),
+                ("vehicles", C.POINTER(fs_vehicle_spec)),
                 ("ring_length", C.POINTER(C.c_double)), ("init_pos", C.POINTER(C.c_double)),
-                ("init_vel", C.POINTER(C.c_double))]
+                ("init_vel", C.POINTER(C.c_double)), ("init_lane", C.POINTER(C.c_int32))]
 
 
 _lib = None
@@ -89,6 +92,8 @@ def load():
     lib.fs_abi_version.restype = C.c_int
     lib.fs_obs_dim.argtypes = [h]
     lib.fs_obs_dim.restype = C.c_int
+    lib.fs_action_dim.argtypes = [h]
+    lib.fs_action_dim.restype = C.c_int
     lib.fs_set_stream.argtypes = [h, C.c_void_p]
     lib.fs_set_stream.restype = C.c_int
     lib.fs_use_own_stream.argtypes = [h]

@@ -39,6 +39,7 @@ struct SimBase {
   fs_config cfg{};
   std::vector<fs_vehicle_spec> veh;
   int obs_dim = 0;
+  int act_dim = 0;
   int seg = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
@@ -93,6 +94,14 @@ struct Sim : SimBase {
     if ((rc = dev_alloc(&dv.prev_vel, RN))) return rc;
     if ((rc = dev_alloc(&dv.accel, RN))) return rc;
     if ((rc = dev_alloc(&dv.ctrl_state, RN))) return rc;
+    if ((rc = dev_alloc(&dv.lane, RN))) return rc;
+    if ((rc = dev_alloc(&dv.last_lc, RN))) return rc;
+    {
+      std::vector<int32_t> il(RN, 0);
+      if (cfg.init_lane)
+        for (size_t e = 0; e < RN; ++e) il[e] = cfg.init_lane[e];
+      if ((rc = upload(&dv.init_lane, il))) return rc;
+    }
     if ((rc = dev_alloc(&dv.time, size_t(R)))) return rc;
     if ((rc = dev_alloc(&dv.noise_ctr, size_t(R)))) return rc;
     HIP_TRY(hipMemset(dv.noise_ctr, 0, size_t(R) * sizeof(uint32_t)));
@@ -166,6 +175,10 @@ struct Sim : SimBase {
     dv.clip_actions = cfg.clip_actions;
     dv.evaluate = cfg.evaluate;
     dv.track_aux = cfg.track_aux;
+    dv.num_lanes = cfg.num_lanes < 1 ? 1 : cfg.num_lanes;
+    dv.lane_change_mode = cfg.lane_change_mode;
+    dv.last_lc_quirk = cfg.last_lc_quirk;
+    dv.lc_duration = T(cfg.lane_change_duration);
     if (cfg.horizon < 0) {
       dv.step_limit = INT_MAX;
     } else {
@@ -191,7 +204,7 @@ struct Sim : SimBase {
     dv.po_max_length = T(cfg.po_max_length);
 
     // host-API staging
-    if ((rc = dev_alloc(&d_actions, size_t(R) * (cfg.num_rl > 0 ? cfg.num_rl : 1)))) return rc;
+    if ((rc = dev_alloc(&d_actions, size_t(R) * (act_dim > 0 ? act_dim : 1)))) return rc;
     if ((rc = dev_alloc(&d_obs, size_t(R) * obs_dim))) return rc;
     if ((rc = dev_alloc(&d_rew, size_t(R)))) return rc;
     if ((rc = dev_alloc(&d_done, size_t(R)))) return rc;
@@ -257,6 +270,12 @@ struct Sim : SimBase {
                  float* rew, uint8_t* done, int obs_every_step) {
     constexpr int RPW = 64 / SEG;
     const int blocks = (dv.R + RPW - 1) / RPW;
+    if (dv.num_lanes > 1) {
+      hipLaunchKernelGGL((fs::k_steps_ml<T, SEG>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, mask, actions,
+                         act_stride, obs, rew, done, obs_every_step);
+      HIP_TRY(hipGetLastError());
+      return FS_OK;
+    }
     if (fast_ok(mask, num_steps) && obs_every_step && dv.N > 1 && actions == nullptr) {
       const bool fd = fastdiv_ok();
       if (delta4 && fd)
@@ -320,23 +339,44 @@ struct Sim : SimBase {
       HIP_TRY(hipMemcpy(dst, dv.time, bytes, hipMemcpyDeviceToHost));
       return FS_OK;
     }
-    if (field == FS_FIELD_HEADWAY) {
-      // headway = (x_lead - x) mod L - len_lead, as the kernel computes it (vehicle/traci.py:219-250)
+    if (field == FS_FIELD_LANE || field == FS_FIELD_LAST_LC || field == FS_FIELD_INIT_LANE) {
+      const size_t RN = size_t(dv.R) * dv.N;
+      if (bytes != RN * sizeof(int32_t)) return fail(FS_ERR_INVALID, "fs_get_state: wrong byte count");
+      const int32_t* p = field == FS_FIELD_LANE ? dv.lane : (field == FS_FIELD_LAST_LC ? dv.last_lc : dv.init_lane);
+      HIP_TRY(hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost));
+      return FS_OK;
+    }
+    if (field == FS_FIELD_HEADWAY || field == FS_FIELD_LEADER) {
+      // the kernels' neighbour rule, evaluated on the host from the positions (and lanes):
+      // headway = (x_lead - x) mod L - len_lead (vehicle/traci.py:219-250); leader = own-lane nearest ahead
       const int R = dv.R, N = dv.N;
       const size_t RN = size_t(R) * N;
-      if (bytes != RN * sizeof(T)) return fail(FS_ERR_INVALID, "FS_FIELD_HEADWAY: wrong byte count");
+      const size_t want = RN * (field == FS_FIELD_HEADWAY ? sizeof(T) : sizeof(int32_t));
+      if (bytes != want) return fail(FS_ERR_INVALID, "fs_get_state: wrong byte count");
       std::vector<T> x(RN), rl(R);
+      std::vector<int32_t> ln(RN, 0);
       HIP_TRY(hipMemcpy(x.data(), dv.pos, RN * sizeof(T), hipMemcpyDeviceToHost));
       HIP_TRY(hipMemcpy(rl.data(), dv.ring_len, size_t(R) * sizeof(T), hipMemcpyDeviceToHost));
-      T* out = static_cast<T*>(dst);
+      if (dv.num_lanes > 1) HIP_TRY(hipMemcpy(ln.data(), dv.lane, RN * sizeof(int32_t), hipMemcpyDeviceToHost));
       for (int r = 0; r < R; ++r) {
         const T L = rl[r] + T(4) * dv.jlen;
         for (int i = 0; i < N; ++i) {
-          if (N == 1) { out[size_t(r) * N + i] = T(1000); continue; }
-          const int j = (i + 1 >= N) ? 0 : i + 1;
-          T d = x[size_t(r) * N + j] - x[size_t(r) * N + i];
-          if (d < T(0)) d = d + L;
-          out[size_t(r) * N + i] = d - h_len[j];
+          int lead = -1;
+          T best = T(0);
+          if (dv.num_lanes > 1) {
+            for (int j = 0; j < N; ++j) {
+              if (j == i || ln[size_t(r) * N + j] != ln[size_t(r) * N + i]) continue;
+              T d = x[size_t(r) * N + j] - x[size_t(r) * N + i];
+              if (d < T(0) || (d == T(0) && j < i)) d = d + L;
+              if (lead < 0 || d < best) { best = d; lead = j; }
+            }
+          } else if (N > 1) {
+            lead = (i + 1 >= N) ? 0 : i + 1;
+            best = x[size_t(r) * N + lead] - x[size_t(r) * N + i];
+            if (best < T(0)) best = best + L;
+          }
+          if (field == FS_FIELD_LEADER) static_cast<int32_t*>(dst)[size_t(r) * N + i] = lead;
+          else static_cast<T*>(dst)[size_t(r) * N + i] = lead < 0 ? T(1000) : best - h_len[lead];
         }
       }
       return FS_OK;
@@ -357,7 +397,15 @@ struct Sim : SimBase {
       HIP_TRY(hipMemcpy(dv.time, src, bytes, hipMemcpyHostToDevice));
       return FS_OK;
     }
-    if (field == FS_FIELD_HEADWAY) return fail(FS_ERR_INVALID, "FS_FIELD_HEADWAY is derived from positions");
+    if (field == FS_FIELD_HEADWAY || field == FS_FIELD_LEADER)
+      return fail(FS_ERR_INVALID, "headway / leader are derived from positions and lanes");
+    if (field == FS_FIELD_LANE || field == FS_FIELD_LAST_LC || field == FS_FIELD_INIT_LANE) {
+      const size_t RN = size_t(dv.R) * dv.N;
+      if (bytes != RN * sizeof(int32_t)) return fail(FS_ERR_INVALID, "fs_set_state: wrong byte count");
+      const int32_t* p = field == FS_FIELD_LANE ? dv.lane : (field == FS_FIELD_LAST_LC ? dv.last_lc : dv.init_lane);
+      HIP_TRY(hipMemcpy(const_cast<int32_t*>(p), src, bytes, hipMemcpyHostToDevice));
+      return FS_OK;
+    }
     size_t count;
     bool writable;
     T* p = field_ptr(field, &count, &writable);
@@ -376,7 +424,14 @@ int validate(const fs_config* c) {
   if (c->abi_version != FS_ABI_VERSION) return fail(FS_ERR_INVALID, "fs_create: abi_version mismatch");
   if (c->precision != FS_F32 && c->precision != FS_F64) return fail(FS_ERR_INVALID, "fs_create: bad precision");
   if (c->network != FS_NET_RING) return fail(FS_ERR_UNSUPPORTED, "fs_create: only FS_NET_RING is built");
-  if (c->env < FS_ENV_ACCEL || c->env > FS_ENV_WAVE_ATTENUATION_PO) return fail(FS_ERR_INVALID, "fs_create: bad env");
+  if (c->env < FS_ENV_ACCEL || c->env > FS_ENV_LANE_CHANGE_ACCEL) return fail(FS_ERR_INVALID, "fs_create: bad env");
+  if (c->num_lanes > 1 && c->env == FS_ENV_WAVE_ATTENUATION_PO)
+    return fail(FS_ERR_UNSUPPORTED, "fs_create: WaveAttenuationPOEnv on a multi-lane ring is not built");
+  if (c->num_lanes > 64) return fail(FS_ERR_INVALID, "fs_create: num_lanes > 64");
+  if (c->init_lane)
+    for (size_t e = 0; e < size_t(c->num_replicas > 0 ? c->num_replicas : 0) * (c->num_vehicles > 0 ? c->num_vehicles : 0); ++e)
+      if (c->init_lane[e] < 0 || c->init_lane[e] >= (c->num_lanes < 1 ? 1 : c->num_lanes))
+        return fail(FS_ERR_INVALID, "fs_create: init_lane out of range");
   if (c->num_replicas < 1) return fail(FS_ERR_INVALID, "fs_create: num_replicas < 1");
   if (c->num_vehicles < 1) return fail(FS_ERR_INVALID, "fs_create: num_vehicles < 1");
   if (c->num_vehicles > 64)
@@ -409,7 +464,8 @@ int validate(const fs_config* c) {
     double need = 0;
     for (int i = 0; i < c->num_vehicles; ++i) need += c->vehicles[i].length;
     const double L = c->ring_length[r] + 4 * c->junction_length;
-    if (!(c->ring_length[r] > 0) || need > L) return fail(FS_ERR_NOSPACE, "fs_create: vehicles do not fit on the ring");
+    if (!(c->ring_length[r] > 0) || need > L * (c->num_lanes < 1 ? 1 : c->num_lanes))
+      return fail(FS_ERR_NOSPACE, "fs_create: vehicles do not fit on the ring");
     for (int i = 0; i < c->num_vehicles; ++i) {
       const double x = c->init_pos[size_t(r) * c->num_vehicles + i];
       if (!(x >= 0) || !(x < L)) return fail(FS_ERR_INVALID, "fs_create: init_pos outside [0, length)");
@@ -424,7 +480,9 @@ int create_typed(const fs_config* cfg, fs_handle* out) {
   if (!s) return fail(FS_ERR_HIP, "fs_create: out of host memory");
   s->cfg = *cfg;
   s->veh.assign(cfg->vehicles, cfg->vehicles + cfg->num_vehicles);
-  s->obs_dim = (cfg->env == FS_ENV_WAVE_ATTENUATION_PO) ? 3 : 2 * cfg->num_vehicles;
+  s->obs_dim = (cfg->env == FS_ENV_WAVE_ATTENUATION_PO) ? 3
+               : (cfg->env == FS_ENV_LANE_CHANGE_ACCEL ? 3 : 2) * cfg->num_vehicles;
+  s->act_dim = cfg->num_rl * (cfg->env == FS_ENV_LANE_CHANGE_ACCEL ? 2 : 1);
   int seg = 8;
   while (seg < cfg->num_vehicles) seg <<= 1;
   s->seg = seg;
@@ -457,6 +515,7 @@ int create_typed(const fs_config* cfg, fs_handle* out) {
   s->cfg.ring_length = nullptr;
   s->cfg.init_pos = nullptr;
   s->cfg.init_vel = nullptr;
+  s->cfg.init_lane = nullptr;
   *out = reinterpret_cast<fs_handle>(static_cast<SimBase*>(s));
   return FS_OK;
 }
@@ -490,6 +549,8 @@ void fs_destroy(fs_handle h) {
 }
 
 int fs_obs_dim(fs_handle h) { return h ? S(h)->obs_dim : fail(FS_ERR_INVALID, "fs_obs_dim: NULL handle"); }
+
+int fs_action_dim(fs_handle h) { return h ? S(h)->act_dim : fail(FS_ERR_INVALID, "fs_action_dim: NULL handle"); }
 
 int fs_set_stream(fs_handle h, void* hip_stream) {
   if (!h) return fail(FS_ERR_INVALID, "fs_set_stream: NULL handle");
@@ -553,8 +614,8 @@ int fs_step(fs_handle h, const float* actions, float* obs, float* rew, uint8_t* 
   SimBase* s = S(h);
   const size_t R = size_t(s->cfg.num_replicas);
   const float* dact = nullptr;
-  if (actions && s->cfg.num_rl > 0) {
-    HIP_TRY(hipMemcpyAsync(s->d_actions, actions, R * s->cfg.num_rl * sizeof(float), hipMemcpyHostToDevice, s->stream));
+  if (actions && s->act_dim > 0) {
+    HIP_TRY(hipMemcpyAsync(s->d_actions, actions, R * s->act_dim * sizeof(float), hipMemcpyHostToDevice, s->stream));
     dact = s->d_actions;
   }
   int rc = s->launch_steps(1, nullptr, dact, 0, s->d_obs, s->d_rew, s->d_done, 0);

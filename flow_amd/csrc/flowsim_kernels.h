@@ -41,6 +41,9 @@ struct DevView {
   T* prev_vel;
   T* accel;
   T* ctrl_state;
+  int32_t* lane;        // [R,N]  (multi-lane only)
+  int32_t* last_lc;     // [R,N]  (multi-lane only)
+  const int32_t* init_lane;
   int32_t* time;        // [R]
   uint32_t* noise_ctr;  // [R]
   const T* init_pos;
@@ -62,10 +65,12 @@ struct DevView {
   const T* sumo_max_speed;
   // scalars
   int R, N, num_rl, env, integrator, sims_per_step, junction_mode, clip_actions, evaluate, track_aux;
+  int num_lanes, lane_change_mode, last_lc_quirk;
   int step_limit;       // sims_per_step*(warmup+horizon), INT_MAX for horizon=inf
   int flags;
   uint32_t seed_lo, seed_hi;
   T dt, ramp, jlen, crash_gap, max_speed, target_velocity, max_cost, act_lo, act_hi, po_max_length;
+  T lc_duration;
 };
 
 // ---------------------------------------------------------------------------
@@ -377,6 +382,56 @@ __device__ __forceinline__ T sumo_idm_speed(T v, T vl, T h, bool has, T dt, cons
 }
 
 // ---------------------------------------------------------------------------
+// BaseController.get_action for one vehicle (base_controller.py:70-118) + the RL command
+// (envs/base.py:599-615): shared by the single-lane and the multi-lane step kernels.
+// Returns the commanded acceleration; `commanded` = false means "no command this step" (S5).
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T control_accel(const DevView<T>& s, const Slot<T>& sl, int flags, T v, T vl, T h, bool has,
+                                           T vf, T hf, T mean_v, T x, T quarter, T qj, bool have_rl, T a_rl, bool live,
+                                           int rr, int ii, uint32_t nctr, T& cst, bool& commanded) {
+  T acc = T(0);
+  commanded = false;
+  const int ct = sl.ctrl;
+  if (ct == FS_CTRL_RL) {
+    if (have_rl) {
+      T a = a_rl;
+      if (s.clip_actions) a = tmin(tmax(a, s.act_lo), s.act_hi);
+      acc = a;
+      commanded = true;
+    }
+  } else if (ct != FS_CTRL_SIM) {
+    T a;
+    switch (ct) {
+      case FS_CTRL_IDM: a = ctrl_idm(v, vl, h, has, sl.p); break;
+      case FS_CTRL_CFM: a = ctrl_cfm(v, vl, h, has, sl.max_accel, sl.p); break;
+      case FS_CTRL_BCM: a = ctrl_bcm(v, vl, h, has, vf, hf, sl.max_accel, sl.p); break;
+      case FS_CTRL_LAC: a = ctrl_lac(v, vl, h, sl.length, cst, s.dt, sl.p); break;
+      case FS_CTRL_OVM: a = ctrl_ovm(v, vl, h, has, sl.max_accel, sl.p); break;
+      case FS_CTRL_LINEAR_OVM: a = ctrl_linear_ovm(v, h, sl.p); break;
+      case FS_CTRL_GIPPS: a = ctrl_gipps(v, vl, h, s.dt, sl.p); break;
+      case FS_CTRL_FOLLOWER_STOPPER: a = ctrl_follower_stopper(v, vl, h, has, s.dt, sl.p[0]); break;
+      default: a = ctrl_follower_stopper(v, vl, h, has, s.dt, mean_v); break;
+    }
+    commanded = true;
+    if (s.junction_mode) {                       // base_controller.py:98-99
+      T u = x - tfloor(x / qj) * qj;
+      commanded = !(u >= quarter);
+    }
+    if (ct == FS_CTRL_LAC && commanded && live) cst = a;
+    if (flags & FLAG_HAS_NOISE) {                // base_controller.py:109-110
+      if (sl.noise > T(0)) a = a + sl.noise * gauss<T>(s.seed_lo, s.seed_hi, uint32_t(rr), uint32_t(ii), nctr);
+    }
+    if (has) {                                   // base_controller.py:113-116, 141-142, 191-193
+      if (sl.failsafe == FS_FAILSAFE_INSTANTANEOUS) a = failsafe_instantaneous(a, v, h, has, s.dt);
+      else if (sl.failsafe == FS_FAILSAFE_SAFE_VELOCITY) a = failsafe_safe_velocity(a, v, vl, h, s.dt, sl.delay);
+    }
+    acc = a;
+  }
+  return acc;
+}
+
+// ---------------------------------------------------------------------------
 // the fused step kernel
 // ---------------------------------------------------------------------------
 // FAST = 1 is the specialisation the host selects for the headline configuration: every
@@ -473,43 +528,11 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
           hf = foll_read<SEG>(h, seg, wrap_foll, N);
         }
         if (flags & FLAG_NEED_MEAN) mean_v = seg_sum<SEG>(valid ? v : T(0)) / T(N);
-        commanded = false;
-        const int ct = sl.ctrl;
-        if (ct == FS_CTRL_RL) {
-          if (act != nullptr) {
-            T a = T(act[sl.rl_index < 0 ? 0 : sl.rl_index]);
-            if (s.clip_actions) a = tmin(tmax(a, s.act_lo), s.act_hi);
-            acc = a;
-            commanded = true;
-          }
-        } else if (ct != FS_CTRL_SIM) {
-          T a;
-          switch (ct) {
-            case FS_CTRL_IDM: a = ctrl_idm(v, vl, h, has, sl.p); break;
-            case FS_CTRL_CFM: a = ctrl_cfm(v, vl, h, has, sl.max_accel, sl.p); break;
-            case FS_CTRL_BCM: a = ctrl_bcm(v, vl, h, has, vf, hf, sl.max_accel, sl.p); break;
-            case FS_CTRL_LAC: a = ctrl_lac(v, vl, h, sl.length, cst, dt, sl.p); break;
-            case FS_CTRL_OVM: a = ctrl_ovm(v, vl, h, has, sl.max_accel, sl.p); break;
-            case FS_CTRL_LINEAR_OVM: a = ctrl_linear_ovm(v, h, sl.p); break;
-            case FS_CTRL_GIPPS: a = ctrl_gipps(v, vl, h, dt, sl.p); break;
-            case FS_CTRL_FOLLOWER_STOPPER: a = ctrl_follower_stopper(v, vl, h, has, dt, sl.p[0]); break;
-            default: a = ctrl_follower_stopper(v, vl, h, has, dt, mean_v); break;
-          }
-          commanded = true;
-          if (s.junction_mode) {                       // base_controller.py:98-99
-            T u = x - tfloor(x / qj) * qj;
-            commanded = !(u >= quarter);
-          }
-          if (ct == FS_CTRL_LAC && commanded && live) cst = a;
-          if (flags & FLAG_HAS_NOISE) {                // base_controller.py:109-110
-            if (sl.noise > T(0)) a = a + sl.noise * gauss<T>(s.seed_lo, s.seed_hi, uint32_t(rr), uint32_t(ii), nctr);
-          }
-          if (has) {                                   // base_controller.py:113-116, 141-142, 191-193
-            if (sl.failsafe == FS_FAILSAFE_INSTANTANEOUS) a = failsafe_instantaneous(a, v, h, has, dt);
-            else if (sl.failsafe == FS_FAILSAFE_SAFE_VELOCITY) a = failsafe_safe_velocity(a, v, vl, h, dt, sl.delay);
-          }
-          acc = a;
-        }
+        T a_rl = T(0);
+        const bool have_rl = (sl.ctrl == FS_CTRL_RL) && (act != nullptr);
+        if (have_rl) a_rl = T(act[sl.rl_index < 0 ? 0 : sl.rl_index]);
+        acc = control_accel(s, sl, flags, v, vl, h, has, vf, hf, mean_v, x, quarter, qj, have_rl, a_rl, live, rr, ii,
+                            nctr, cst, commanded);
       }
       // ---- apply_acceleration + SUMO integration (S4-S9) ------------------
       T next_vel = tmax(v + acc * dt, T(0));          // vehicle/traci.py:962
@@ -759,6 +782,291 @@ __global__ __launch_bounds__(64) void k_rollout_idm(DevView<T> s, int num_steps,
   }
 }
 
+// ---------------------------------------------------------------------------
+// k_steps_ml: multi-lane ring (RingNetwork lanes > 1; LaneChangeAccelEnv head)
+// ---------------------------------------------------------------------------
+// Same lane mapping as k_steps (lane = vehicle, segment = replica), but the leader of a vehicle
+// is no longer a fixed neighbour: it is the nearest vehicle ahead IN THE SAME LANE and changes
+// when a vehicle changes lane.  Every sub-step each lane scans the other N-1 slots of its
+// segment (cross-lane reads through the LDS crossbar, ds_bpermute) and keeps the smallest arc
+// distance -- oracle/refsim.py MultiLaneRingOracle.neighbours, ML2.  O(N) per vehicle instead
+// of a sort: N <= 64 and the scan is 2 bpermutes + ~8 VALU per candidate.
+template <typename T>
+__device__ __forceinline__ T bperm(T v, int src_lane) { return __shfl(v, src_lane, 64); }
+
+template <typename T, int SEG>
+__global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, const uint8_t* __restrict__ mask,
+                                                 const float* __restrict__ actions, size_t act_stride,
+                                                 float* __restrict__ obs, float* __restrict__ rew,
+                                                 uint8_t* __restrict__ done, int obs_every_step) {
+  constexpr int RPW = 64 / SEG;
+  const int lane_id = threadIdx.x;
+  const int seg = lane_id / SEG;
+  const int i = lane_id % SEG;
+  const int segbase = seg * SEG;
+  const int r = blockIdx.x * RPW + seg;
+  const int N = s.N;
+  const bool rvalid = r < s.R;
+  const bool valid = rvalid && i < N;
+  const int rr = rvalid ? r : s.R - 1;
+  const int ii = i < N ? i : N - 1;
+  const size_t idx = size_t(rr) * N + ii;
+  const int flags = s.flags;
+  const bool lc_env = (s.env == FS_ENV_LANE_CHANGE_ACCEL);
+  const int act_w = s.num_rl * (lc_env ? 2 : 1);
+
+  Slot<T> sl;
+  sl.ctrl = s.ctrl[ii];
+  sl.failsafe = s.failsafe[ii];
+  sl.speed_mode = s.speed_mode[ii];
+  sl.rl_index = s.rl_index[ii];
+#pragma unroll
+  for (int k = 0; k < FS_MAX_CTRL_PARAMS; ++k) sl.p[k] = s.p[k * N + ii];
+  sl.noise = s.noise[ii];
+  sl.delay = s.delay[ii];
+  sl.max_accel = s.max_accel[ii];
+  sl.max_decel = s.max_decel[ii];
+  sl.length = s.length[ii];
+  sl.sumo_tau = s.sumo_tau[ii];
+  sl.sumo_min_gap = s.sumo_min_gap[ii];
+  sl.sumo_max_speed = s.sumo_max_speed[ii];
+
+  const T base_len = s.ring_len[rr];
+  const T L = base_len + T(4) * s.jlen;
+  const T quarter = base_len / T(4);
+  const T qj = quarter + s.jlen;
+  const bool live_replica = rvalid && (mask == nullptr || mask[rr] != 0);
+  int tcount = s.time[rr];
+  uint32_t nctr = (flags & FLAG_HAS_NOISE) ? s.noise_ctr[rr] : 0u;
+
+  T x = s.pos[idx];
+  T v = s.vel[idx];
+  int ln = s.lane[idx];
+  int last_lc = s.last_lc[idx];
+  T prev_v = v, last_acc = T(0);
+  T cst = (flags & FLAG_HAS_LAC) ? s.ctrl_state[idx] : T(0);
+  if (s.track_aux) { prev_v = s.prev_vel[idx]; last_acc = s.accel[idx]; }
+
+  const T dt = s.dt;
+  const int obs_dim = lc_env ? 3 * N : ((s.env == FS_ENV_WAVE_ATTENUATION_PO) ? 3 : 2 * N);
+  const size_t step_rows = obs_every_step ? size_t(s.R) : 0;
+  float* orow = obs + size_t(rr) * obs_dim;
+  float* rrow = rew + rr;
+  uint8_t* drow = done + rr;
+
+  // own-lane neighbour scan (ML2): leader slot / arc / speed / length, follower slot
+  int lead = -1, foll = -1;
+  T dlead = T(0), vl = T(0), len_lead = T(0), h = T(1000), vf = T(0);
+  bool has = false;
+  auto scan = [&]() {
+    const T big = T(3.0e38);
+    T best = big, bestf = big;
+    lead = -1;
+    foll = -1;
+    for (int k = 1; k < N; ++k) {
+      int j = ii + k;
+      j = j >= N ? j - N : j;
+      const T xj = bperm(x, segbase + j);
+      const int lj = __shfl(ln, segbase + j, 64);
+      T dij = xj - x;                                   // arc from me to j
+      const bool wrapf = (dij < T(0)) || (dij == T(0) && j < ii);
+      dij = wrapf ? dij + L : dij;
+      T dji = x - xj;                                   // arc from j to me
+      const bool wrapb = (dji < T(0)) || (dji == T(0) && ii < j);
+      dji = wrapb ? dji + L : dji;
+      const bool same = (lj == ln);
+      // np.argmin takes the FIRST minimum in slot order: on a tie prefer the smaller slot index
+      if (same && (dij < best || (dij == best && j < lead))) { best = dij; lead = j; }
+      if (same && (dji < bestf || (dji == bestf && j < foll))) { bestf = dji; foll = j; }
+    }
+    has = lead >= 0;
+    const int lsrc = segbase + (has ? lead : ii);
+    dlead = best;
+    vl = bperm(v, lsrc);
+    len_lead = bperm(sl.length, lsrc);
+    h = has ? dlead - len_lead : T(1000);
+    if (!has) vl = T(-1001);                            // get_speed(None): the reference's error value
+  };
+  scan();
+
+  for (int step = 0; step < num_steps; ++step) {
+    const float* act = actions ? actions + size_t(step) * act_stride + size_t(rr) * act_w : nullptr;
+    bool crashed = false;
+    int lc_count_quirk = 0;
+    for (int sub = 0; sub < s.sims_per_step; ++sub) {
+      const bool live = live_replica && !crashed;
+      // ---- controllers on the snapshot (S1) -------------------------------
+      T hf = T(0), mean_v = T(0);
+      vf = T(0);
+      if (flags & FLAG_NEED_FOLLOWER) {
+        const int fsrc = segbase + (foll >= 0 ? foll : ii);
+        vf = bperm(v, fsrc);
+        hf = bperm(h, fsrc);
+      }
+      if (flags & FLAG_NEED_MEAN) mean_v = seg_sum<SEG>(valid ? v : T(0)) / T(N);
+      const bool have_rl = (sl.ctrl == FS_CTRL_RL) && (act != nullptr);
+      const int acol = (sl.rl_index < 0 ? 0 : sl.rl_index) * (lc_env ? 2 : 1);
+      T a_rl = have_rl ? T(act[acol]) : T(0);
+      bool commanded = false;
+      T acc = control_accel(s, sl, flags, v, vl, h, has, vf, hf, mean_v, x, quarter, qj, have_rl, a_rl, live, rr, ii,
+                            nctr, cst, commanded);
+      // ---- RL lane-change command (ML3) -----------------------------------
+      int new_ln = ln;
+      if (lc_env && have_rl) {
+        const T dirv = T(act[acol + 1]);
+        int direction = dirv > T(0.5) ? 1 : (dirv < T(-0.5) ? -1 : 0);
+        const T last = s.last_lc_quirk ? h : T(last_lc);
+        if (T(tcount + 1) <= s.lc_duration + last) direction = 0;      // lane_change_accel.py:143-147
+        int target = ln + direction;
+        target = target < 0 ? 0 : (target > s.num_lanes - 1 ? s.num_lanes - 1 : target);   // traci.py:982-984
+        new_ln = target;
+      }
+      if (lc_env) {
+        // refuse a change that would overlap a vehicle of the target lane (lane_change_mode != 0)
+        bool clash = false;
+        if (s.lane_change_mode != 0) {
+          for (int k = 1; k < N; ++k) {
+            int j = ii + k;
+            j = j >= N ? j - N : j;
+            const T xj = bperm(x, segbase + j);
+            const int lj = __shfl(ln, segbase + j, 64);
+            const T lenj = bperm(sl.length, segbase + j);
+            T dij = xj - x;
+            const bool wrapf = (dij < T(0)) || (dij == T(0) && j < ii);
+            dij = wrapf ? dij + L : dij;
+            const T dji = dij == T(0) ? T(0) : L - dij;
+            if (lj == new_ln && (dij < lenj || dji < sl.length)) clash = true;
+          }
+        }
+        if (clash || !live) new_ln = ln;
+      }
+      // ---- apply_acceleration + integration (S4-S9) -----------------------
+      T next_vel = tmax(v + acc * dt, T(0));
+      T vc = v + (next_vel - v) * s.ramp;
+      T v_new = vc;
+      if (flags & FLAG_NEED_SUMO) {
+        T v_sumo = sumo_idm_speed(v, vl, h, has, dt, sl);
+        if (sl.speed_mode & 1) vc = tmin(vc, v_sumo);
+        if (sl.speed_mode & 2) vc = tmin(vc, v + sl.max_accel * dt);
+        if (sl.speed_mode & 4) vc = tmax(vc, v - sl.max_decel * dt);
+        v_new = commanded ? vc : v_sumo;
+      }
+      T x_new = (s.integrator == FS_BALLISTIC) ? x + (v + v_new) / T(2) * dt : x + v_new * dt;
+      x_new = x_new >= L ? x_new - L : x_new;
+      if (live) {
+        prev_v = v;
+        last_acc = acc;
+        x = x_new;
+        v = v_new;
+        tcount += 1;
+        nctr += 1u;
+        if (new_ln != ln) { ln = new_ln; last_lc = tcount; }        // vehicle/traci.py:205-209
+      }
+      // ---- new neighbour snapshot + collision check ------------------------
+      scan();
+      const bool c = seg_any<SEG>(valid && has && (h < s.crash_gap), seg);
+      crashed = crashed || (c && live);
+    }
+
+    const bool emit = obs_every_step || (step == num_steps - 1);
+    if (emit) {
+      if (lc_env) {                                                  // lane_change_accel.py:100-117
+        if (valid) {
+          orow[ii] = float(v / s.max_speed);
+          orow[N + ii] = float(x / L);
+          orow[2 * N + ii] = float(T(ln) / T(s.num_lanes));
+        }
+      } else if (s.env == FS_ENV_WAVE_ATTENUATION_PO) {
+        if (valid && sl.ctrl == FS_CTRL_RL && sl.rl_index == 0) {
+          orow[0] = float(v / T(15));
+          orow[1] = float((vl - v) / T(15));
+          orow[2] = float((has ? dlead : T(0)) / s.po_max_length);
+        }
+      } else if (valid) {
+        orow[ii] = float(v / s.max_speed);
+        orow[N + ii] = float(x / L);
+      }
+      T reward;
+      const bool bad = seg_any<SEG>(valid && (v < T(-100)), seg) || crashed;
+      if (s.env == FS_ENV_ACCEL || lc_env) {
+        if (!lc_env && s.evaluate) {
+          reward = seg_sum<SEG>(valid ? v : T(0)) / T(N);
+        } else {
+          T dv = valid ? v - s.target_velocity : T(0);
+          T cost = tsqrt(seg_sum<SEG>(dv * dv));
+          reward = tmax(s.max_cost - cost, T(0)) / (s.max_cost + T(1.1920928955078125e-07));
+          reward = bad ? T(0) : reward;
+        }
+        if (lc_env) {                                                // lane_change_accel.py:92-96, in slot order
+          const T last = s.last_lc_quirk ? h : T(last_lc);
+          const bool hit = valid && sl.ctrl == FS_CTRL_RL && (last == T(tcount));
+          unsigned long long b = __ballot(hit);
+          if (SEG < 64) b = (b >> (seg * (SEG & 63))) & ((1ull << (SEG & 63)) - 1ull);
+          const int cnt = __popcll(b);
+          for (int k = 0; k < cnt; ++k) reward = reward - T(0.1);
+        }
+      } else {
+        if (act == nullptr) {
+          reward = T(0);
+        } else {
+          T a = T(0);
+          if (ii < s.num_rl && i < N) {
+            a = T(act[ii]);
+            if (s.clip_actions) a = tmin(tmax(a, s.act_lo), s.act_hi);
+            a = tabs(a);
+          }
+          T mean_v = seg_sum<SEG>(valid ? v : T(0)) / T(N);
+          T mean_a = seg_sum<SEG>(a) / T(s.num_rl);
+          reward = T(4.0) * mean_v / T(20);
+          if (mean_a > T(0)) reward = reward + T(4) * (T(0) - mean_a);
+          reward = bad ? T(0) : reward;
+        }
+      }
+      if (valid && ii == 0) {
+        *rrow = float(reward);
+        *drow = uint8_t((tcount >= s.step_limit) || crashed);
+      }
+      orow += step_rows * obs_dim;
+      rrow += step_rows;
+      drow += step_rows;
+    }
+    (void)lc_count_quirk;
+  }
+
+  if (num_steps == 0) {
+    if (lc_env) {
+      if (valid) {
+        orow[ii] = float(v / s.max_speed);
+        orow[N + ii] = float(x / L);
+        orow[2 * N + ii] = float(T(ln) / T(s.num_lanes));
+      }
+    } else if (s.env == FS_ENV_WAVE_ATTENUATION_PO) {
+      if (valid && sl.ctrl == FS_CTRL_RL && sl.rl_index == 0) {
+        orow[0] = float(v / T(15));
+        orow[1] = float((vl - v) / T(15));
+        orow[2] = float((has ? dlead : T(0)) / s.po_max_length);
+      }
+    } else if (valid) {
+      orow[ii] = float(v / s.max_speed);
+      orow[N + ii] = float(x / L);
+    }
+    return;
+  }
+
+  if (valid && live_replica) {
+    s.pos[idx] = x;
+    s.vel[idx] = v;
+    s.lane[idx] = ln;
+    s.last_lc[idx] = last_lc;
+    if (flags & FLAG_HAS_LAC) s.ctrl_state[idx] = cst;
+    if (s.track_aux) { s.prev_vel[idx] = prev_v; s.accel[idx] = last_acc; }
+    if (ii == 0) {
+      s.time[rr] = tcount;
+      if (flags & FLAG_HAS_NOISE) s.noise_ctr[rr] = nctr;
+    }
+  }
+}
+
 // Env.reset placement (envs/base.py:430, 494-518): selected replicas go back to
 // their initial state; vehicles are inserted without moving (S13).
 template <typename T>
@@ -772,6 +1080,10 @@ __global__ void k_reset(DevView<T> s, const uint8_t* __restrict__ mask) {
     s.prev_vel[e] = s.init_vel[e];
     s.accel[e] = T(0);
     s.ctrl_state[e] = T(0);
+    if (s.num_lanes > 1) {
+      s.lane[e] = s.init_lane[e];
+      s.last_lc[e] = -(1 << 30);
+    }
     if (e % s.N == 0) s.time[r] = 0;
   }
 }

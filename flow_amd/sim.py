@@ -37,7 +37,8 @@ class FlowSim:
     [R], init_pos [R,N], init_vel [R,N] (optional), sim_step, slowdown_ramp,
     integrator, junction_mode, junction_length, crash_gap, max_speed, env,
     target_velocity, action_low, action_high, clip_actions, evaluate,
-    po_max_length, horizon, warmup_steps, sims_per_step, seed, track_aux.
+    po_max_length, horizon, warmup_steps, sims_per_step, seed, track_aux, num_lanes, init_lane [R,N],
+    lane_change_duration, lane_change_mode, last_lc_quirk.
     """
 
     def __init__(self, spec, precision="f32", device=0):
@@ -74,6 +75,9 @@ class FlowSim:
         init_vel = spec.get("init_vel")
         if init_vel is not None:
             init_vel = np.ascontiguousarray(np.asarray(init_vel, dtype=np.float64).reshape(self.R, self.N))
+        init_lane = spec.get("init_lane")
+        if init_lane is not None:
+            init_lane = np.ascontiguousarray(np.asarray(init_lane, dtype=np.int32).reshape(self.R, self.N))
         horizon = spec.get("horizon", float("inf"))
         dp = C.POINTER(C.c_double)
         cfg = L.fs_config(
@@ -85,17 +89,22 @@ class FlowSim:
             warmup_steps=int(spec.get("warmup_steps", 0)), sims_per_step=int(spec.get("sims_per_step", 1)),
             junction_mode=int(spec.get("junction_mode", 0)), clip_actions=int(bool(spec.get("clip_actions", True))),
             evaluate=int(bool(spec.get("evaluate", False))), device=self.device,
-            track_aux=int(bool(spec.get("track_aux", False))), reserved0=0,
+            track_aux=int(bool(spec.get("track_aux", False))), num_lanes=int(spec.get("num_lanes", 1)),
+            lane_change_mode=int(spec.get("lane_change_mode", 512)),
+            last_lc_quirk=int(bool(spec.get("last_lc_quirk", True))),
             seed=int(spec.get("seed", 0) or 0) & 0xFFFFFFFFFFFFFFFF,
             sim_step=dt, slowdown_ramp=float(spec.get("slowdown_ramp", dt / (dt + 1e-3))),
             junction_length=float(spec.get("junction_length", 0.1)), crash_gap=float(spec.get("crash_gap", 0.0)),
             max_speed=float(spec["max_speed"]), target_velocity=float(spec.get("target_velocity", 0.0)),
             action_low=float(spec.get("action_low", 0.0)), action_high=float(spec.get("action_high", 0.0)),
             po_max_length=float(spec.get("po_max_length", 1.0)),
+            lane_change_duration=float(spec.get("lane_change_duration", 0.0)),
             vehicles=veh, ring_length=ring_length.ctypes.data_as(dp), init_pos=init_pos.ctypes.data_as(dp),
-            init_vel=init_vel.ctypes.data_as(dp) if init_vel is not None else None)
+            init_vel=init_vel.ctypes.data_as(dp) if init_vel is not None else None,
+            init_lane=init_lane.ctypes.data_as(C.POINTER(C.c_int32)) if init_lane is not None else None)
         L.check(self.lib.fs_create(C.byref(cfg), C.byref(self._h)))
         self.obs_dim = self.lib.fs_obs_dim(self._h)
+        self.act_dim = self.lib.fs_action_dim(self._h)
 
     # ------------------------------------------------------------------ life cycle
     def close(self):
@@ -134,8 +143,8 @@ class FlowSim:
     def step(self, actions=None):
         """Env.step for all replicas; returns (obs [R,obs_dim] f32, reward [R] f32, done [R] bool)."""
         a = None
-        if actions is not None and self.num_rl > 0:
-            a = np.ascontiguousarray(np.asarray(actions, dtype=np.float32).reshape(self.R, self.num_rl))
+        if actions is not None and self.act_dim > 0:
+            a = np.ascontiguousarray(np.asarray(actions, dtype=np.float32).reshape(self.R, self.act_dim))
         obs = np.empty((self.R, self.obs_dim), dtype=np.float32)
         rew = np.empty(self.R, dtype=np.float32)
         done = np.empty(self.R, dtype=np.uint8)
@@ -153,7 +162,7 @@ class FlowSim:
                     obs_every_step=True):
         """K env steps in one launch.  obs/rew/done are [K,R,...] when obs_every_step else [R,...]."""
         if action_stride_steps is None:
-            action_stride_steps = self.R * self.num_rl if actions is not None and actions.dim() == 3 else 0
+            action_stride_steps = self.R * self.act_dim if actions is not None and actions.dim() == 3 else 0
         L.check(self.lib.fs_rollout_dev(self._h, int(num_steps), _ptr(actions), int(action_stride_steps),
                                         _ptr(obs), _ptr(rew), _ptr(done), int(bool(obs_every_step))))
 
@@ -161,6 +170,8 @@ class FlowSim:
     def _field_shape(self, field):
         if field in (L.FS_FIELD_TIME,):
             return (self.R,), np.int32
+        if field in (L.FS_FIELD_LANE, L.FS_FIELD_LAST_LC, L.FS_FIELD_LEADER, L.FS_FIELD_INIT_LANE):
+            return (self.R, self.N), np.int32
         if field == L.FS_FIELD_RING_LENGTH:
             return (self.R,), self.real
         return (self.R, self.N), self.real

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FS_ABI_VERSION 1
+#define FS_ABI_VERSION 2
 
 /* ---- error codes -------------------------------------------------------- */
 #define FS_OK 0
@@ -64,10 +64,12 @@ enum fs_failsafe { FS_FAILSAFE_NONE = 0, FS_FAILSAFE_INSTANTANEOUS = 1, FS_FAILS
 enum fs_env {
   FS_ENV_ACCEL = 0,                 /* AccelEnv                 flow/envs/ring/accel.py:25-183 */
   FS_ENV_WAVE_ATTENUATION = 1,      /* WaveAttenuationEnv       flow/envs/ring/wave_attenuation.py:50-210 */
-  FS_ENV_WAVE_ATTENUATION_PO = 2    /* WaveAttenuationPOEnv     flow/envs/ring/wave_attenuation.py:213-276 */
+  FS_ENV_WAVE_ATTENUATION_PO = 2,   /* WaveAttenuationPOEnv     flow/envs/ring/wave_attenuation.py:213-276 */
+  FS_ENV_LANE_CHANGE_ACCEL = 3      /* LaneChangeAccelEnv       flow/envs/ring/lane_change_accel.py:28-154;
+                                       actions are [acc_0, dir_0, acc_1, dir_1, ...] (2 per RL vehicle) */
 };
 
-enum fs_network { FS_NET_RING = 0 /* RingNetwork, flow/networks/ring.py */ };
+enum fs_network { FS_NET_RING = 0 /* RingNetwork, flow/networks/ring.py (any number of lanes) */ };
 
 enum fs_integrator { FS_EULER = 0, FS_BALLISTIC = 1 /* SumoParams.use_ballistic, core/params.py:578-602 */ };
 
@@ -84,7 +86,11 @@ enum fs_field {
   FS_FIELD_RING_LENGTH = 6,/* real[R]    per-replica ring length (edges only)            */
   FS_FIELD_INIT_POS = 7,   /* real[R,N]  Env.initial_state positions                     */
   FS_FIELD_INIT_VEL = 8,   /* real[R,N]  Env.initial_state speeds                        */
-  FS_FIELD_CTRL_STATE = 9  /* real[R,N]  controller state (LAC: self.a)                  */
+  FS_FIELD_CTRL_STATE = 9, /* real[R,N]  controller state (LAC: self.a)                  */
+  FS_FIELD_LANE = 10,      /* int32[R,N] get_lane                                        */
+  FS_FIELD_LAST_LC = 11,   /* int32[R,N] time_counter of the last lane change (vehicle/traci.py:205-209) */
+  FS_FIELD_LEADER = 12,    /* int32[R,N] slot of the own-lane leader, -1 if none (get_leader; read-only) */
+  FS_FIELD_INIT_LANE = 13  /* int32[R,N] Env.initial_state lanes                          */
 };
 
 #define FS_MAX_CTRL_PARAMS 8
@@ -126,7 +132,10 @@ typedef struct fs_config {
   int32_t evaluate;                   /* EnvParams.evaluate */
   int32_t device;                     /* HIP device ordinal */
   int32_t track_aux;                  /* 1: keep FS_FIELD_PREV_VEL / FS_FIELD_ACCEL up to date (get_previous_speed) */
-  int32_t reserved0;
+  int32_t num_lanes;                  /* lanes of the ring (net_params 'lanes'); > 1 selects the multi-lane kernel */
+  int32_t lane_change_mode;           /* SumoLaneChangeParams.lane_change_mode: 0 = execute every commanded change,
+                                         otherwise refuse a change that would overlap a vehicle of the target lane */
+  int32_t last_lc_quirk;              /* 1: get_last_lc returns the headway, as this fork does (vehicle/traci.py:604-614) */
   uint64_t seed;                      /* SimParams.seed: key of the per-(replica,vehicle,step) noise stream */
   double sim_step;                    /* SimParams.sim_step */
   double slowdown_ramp;               /* v' = v + (next_vel - v)*ramp; dt/(dt+1e-3) models slowDown(.., 1e-3) */
@@ -136,10 +145,12 @@ typedef struct fs_config {
   double target_velocity;             /* env_params.additional_params['target_velocity'] */
   double action_low, action_high;     /* action_space bounds */
   double po_max_length;               /* WaveAttenuationPOEnv max_length normaliser */
+  double lane_change_duration;        /* env_params 'lane_change_duration' (lane_change_accel.py:143-147) */
   const fs_vehicle_spec* vehicles;    /* [N] */
   const double* ring_length;          /* [R] length of each replica's ring (sum of its 4 edges) */
   const double* init_pos;             /* [R,N] initial absolute positions */
   const double* init_vel;             /* [R,N] initial speeds, or NULL -> vehicles[i].initial_speed */
+  const int32_t* init_lane;           /* [R,N] initial lanes, or NULL -> lane 0 */
 } fs_config;
 
 typedef struct fs_sim* fs_handle;
@@ -154,8 +165,9 @@ void fs_destroy(fs_handle h);
 const char* fs_last_error(void);
 int fs_abi_version(void);
 
-/* observation width of the configured env (observation_space.shape[0]) */
+/* observation / action width of the configured env (observation_space.shape[0], action_space.shape[0]) */
 int fs_obs_dim(fs_handle h);
+int fs_action_dim(fs_handle h);
 
 /* Enqueue all later work of this handle on `hip_stream` (a hipStream_t; NULL is
  * HIP's default stream).  fs_use_own_stream goes back to the non-blocking stream
@@ -180,7 +192,8 @@ int fs_reset_dev(fs_handle h, const uint8_t* mask_dev, float* obs_dev);
  * (vehicle/traci.py:952-963) -> simulation_step (simulation/traci.py:54-56)
  * -> vehicle update (vehicle/traci.py:119-259) -> check_collision}, then
  * get_state / compute_reward / done.
- *   actions  real32[R,num_rl] or NULL (reference: rl_actions=None)
+ *   actions  real32[R,A] or NULL (reference: rl_actions=None); A = num_rl, or 2*num_rl for
+ *            FS_ENV_LANE_CHANGE_ACCEL (fs_action_dim)
  *   obs      real32[R,obs_dim]     rew  real32[R]     done  uint8[R]
  * Observations are float32 as in the reference's Box(dtype=np.float32). */
 int fs_step(fs_handle h, const float* actions, float* obs, float* rew, uint8_t* done);

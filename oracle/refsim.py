@@ -29,7 +29,7 @@ from . import rewards as Rw
 CTRL_SIM, CTRL_RL, CTRL_IDM, CTRL_CFM, CTRL_BCM, CTRL_LAC, CTRL_OVM, CTRL_LINEAR_OVM, \
     CTRL_GIPPS, CTRL_FOLLOWER_STOPPER, CTRL_NONLOCAL_FOLLOWER_STOPPER = range(11)
 FAILSAFE_NONE, FAILSAFE_INSTANTANEOUS, FAILSAFE_SAFE_VELOCITY = range(3)
-ENV_ACCEL, ENV_WAVE_ATTENUATION, ENV_WAVE_ATTENUATION_PO = range(3)
+ENV_ACCEL, ENV_WAVE_ATTENUATION, ENV_WAVE_ATTENUATION_PO, ENV_LANE_CHANGE_ACCEL = range(4)
 
 
 def philox4x32_10(c0, c1, c2, c3, k0, k1):
@@ -313,3 +313,235 @@ class RingOracle:
             a = np.clip(np.asarray(a, dtype=self.dt_), T(self.spec["action_low"]),
                         T(self.spec["action_high"]))
         return Rw.wave_attenuation_reward(self.v, a, fail)
+
+
+class MultiLaneRingOracle(RingOracle):
+    """Multi-lane ring (RingNetwork with lanes > 1, LaneChangeAccelEnv).
+
+    Restates, on top of RingOracle:
+
+      ML2  own-lane leader/follower search         flow/core/kernel/vehicle/traci.py:219-250 (SUMO getLeader)
+      ML3  RL lane-change command                  flow/envs/ring/lane_change_accel.py:132-154,
+                                                   flow/core/kernel/vehicle/traci.py:965-997
+      ML4  last_lc bookkeeping                     flow/core/kernel/vehicle/traci.py:205-209
+      ML6  LaneChangeAccelEnv state / reward       flow/envs/ring/lane_change_accel.py:100-130
+
+    Extra spec keys: num_lanes, init_lane [R,N], lane_change_duration (steps are compared with
+    time_counter exactly like the reference does), lane_change_mode (0: every commanded change is
+    executed; otherwise it is refused when it would overlap a vehicle of the target lane -- SUMO's
+    'no_lat_collide' check restated as a plain overlap test, UNPINNED), last_lc_quirk (True:
+    get_last_lc returns the headway as in this fork, vehicle/traci.py:604-614).
+    Actions for ENV_LANE_CHANGE_ACCEL are [acc_0, dir_0, acc_1, dir_1, ...] (lane_change_accel.py:134-135).
+    """
+
+    def __init__(self, spec, dtype=np.float64):
+        super().__init__(spec, dtype)
+        self.lanes = int(spec.get("num_lanes", 1))
+        il = spec.get("init_lane")
+        if il is None:
+            il = np.zeros((self.R, self.N), dtype=np.int32)
+        self.init_lane = np.asarray(il, dtype=np.int32).reshape(self.R, self.N)
+        self.lane = self.init_lane.copy()
+        self.last_lc = np.full((self.R, self.N), -(2 ** 30), dtype=np.int64)
+        self.lc_duration = self.dt_.type(spec.get("lane_change_duration", 0))
+        self.lc_mode = int(spec.get("lane_change_mode", 512))
+        self.quirk = bool(spec.get("last_lc_quirk", True))
+
+    # ---- ML2
+    def neighbours(self, x=None, lane=None):
+        """Own-lane leader / follower slot (-1 if none), headway, arc distances matrix d[r,i,j]."""
+        x = self.x if x is None else x
+        lane = self.lane if lane is None else lane
+        T = self.dt_.type
+        R, N = self.R, self.N
+        d = x[:, None, :] - x[:, :, None]                       # d[r,i,j] = x_j - x_i
+        jj = np.arange(N)
+        wrap = (d < 0) | ((d == 0) & (jj[None, None, :] < jj[None, :, None]))
+        d = np.where(wrap, d + self.L[:, None, None], d)
+        same = (lane[:, None, :] == lane[:, :, None]) & (jj[None, None, :] != jj[None, :, None])
+        big = T(3.0e38)
+        dl = np.where(same, d, big)
+        lead = np.argmin(dl, axis=2)
+        has = np.take_along_axis(dl, lead[:, :, None], 2)[:, :, 0] < big
+        dlead = np.take_along_axis(d, lead[:, :, None], 2)[:, :, 0]
+        h = np.where(has, dlead - self.veh_len[lead], T(1000.0))
+        # follower: the vehicle whose leader-distance to me is smallest = min over j of d[r,j,i]
+        dt_ = np.where(same, np.transpose(d, (0, 2, 1)), big)   # dt_[r,i,j] = d[r,j,i]
+        foll = np.argmin(dt_, axis=2)
+        lead = np.where(has, lead, -1)
+        foll = np.where(has, foll, -1)
+        return lead, foll, has, h, d
+
+    def headways(self, x=None):
+        return self.neighbours(x)[3]
+
+    def reset(self, mask=None):
+        m = np.ones(self.R, dtype=bool) if mask is None else np.asarray(mask, dtype=bool)
+        self.lane[m] = self.init_lane[m]
+        self.last_lc[m] = -(2 ** 30)
+        return super().reset(mask)
+
+    def _accelerations(self, actions, active):
+        """As RingOracle._accelerations with the dynamic own-lane neighbours."""
+        T = self.dt_.type
+        R, N = self.R, self.N
+        x, v = self.x, self.v
+        lead, foll, has_lead, h, _ = self.neighbours()
+        li = np.where(lead >= 0, lead, 0)
+        fi = np.where(foll >= 0, foll, 0)
+        # get_speed(None) is the error value -1001 (vehicle/traci.py get_speed default)
+        v_lead = np.where(lead >= 0, np.take_along_axis(v, li, 1), T(-1001))
+        v_follow = np.take_along_axis(v, fi, 1)
+        h_follow = np.take_along_axis(h, fi, 1)
+        acc = np.zeros((R, N), dtype=self.dt_)
+        commanded = np.zeros((R, N), dtype=bool)
+        mean_speed = None
+        per_rl = 2 if self.spec.get("env") == ENV_LANE_CHANGE_ACCEL else 1
+        for i, vs in enumerate(self.veh):
+            ct = vs["controller"]
+            p = vs.get("p", [0] * 8)
+            sl = (slice(None), i)
+            if ct == CTRL_SIM:
+                continue
+            if ct == CTRL_RL:
+                if actions is None:
+                    continue
+                a = np.asarray(actions, dtype=self.dt_)[:, per_rl * vs["rl_index"]]
+                if self.spec.get("clip_actions", True):
+                    a = np.clip(a, T(self.spec["action_low"]), T(self.spec["action_high"]))
+                acc[sl] = a
+                commanded[sl] = True
+                continue
+            args = (v[sl], v_lead[sl], h[sl], has_lead[sl])
+            if ct == CTRL_IDM:
+                a = C.idm(*args, v0=p[0], T=p[1], a=p[2], b=p[3], delta=p[4], s0=p[5])
+            elif ct == CTRL_CFM:
+                a = C.cfm(*args, vs["max_accel"], k_d=p[0], k_v=p[1], k_c=p[2], d_des=p[3], v_des=p[4])
+            elif ct == CTRL_BCM:
+                a = C.bcm(*args, v_follow[sl], h_follow[sl], vs["max_accel"],
+                          k_d=p[0], k_v=p[1], k_c=p[2], d_des=p[3], v_des=p[4])
+            elif ct == CTRL_LAC:
+                a = C.lac(v[sl], v_lead[sl], h[sl], self.veh_len[i], self.lac_a[sl], self.dt,
+                          k_1=p[0], k_2=p[1], h_gap=p[2], tau=p[3])
+            elif ct == CTRL_OVM:
+                a = C.ovm(*args, vs["max_accel"], alpha=p[0], beta=p[1], h_st=p[2], h_go=p[3], v_max=p[4])
+            elif ct == CTRL_LINEAR_OVM:
+                a = C.linear_ovm(v[sl], h[sl], v_max=p[0], adaptation=p[1], h_st=p[2])
+            elif ct == CTRL_GIPPS:
+                a = C.gipps(v[sl], v_lead[sl], h[sl], self.dt, v0=p[0], acc=p[1], b=p[2], b_l=p[3],
+                            s0=p[4], tau=p[5])
+            elif ct == CTRL_FOLLOWER_STOPPER:
+                a = C.follower_stopper(*args, self.dt, v_des=p[0])
+            elif ct == CTRL_NONLOCAL_FOLLOWER_STOPPER:
+                if mean_speed is None:
+                    mean_speed = Rw.tree_sum(v) / T(N)
+                a = C.follower_stopper(*args, self.dt, v_des=mean_speed)
+            else:
+                raise ValueError("unknown controller %r" % ct)
+            cmd = np.ones(R, dtype=bool)
+            if self.junction_mode:
+                cmd = ~self.in_junction(x[sl])
+            if ct == CTRL_LAC:
+                self.lac_a[sl] = np.where(cmd & active, a, self.lac_a[sl])
+            if vs.get("noise", 0) > 0:
+                g = gaussian_noise(self.spec.get("seed", 0), np.arange(R, dtype=np.uint32),
+                                   np.full(R, i, dtype=np.uint32),
+                                   self.step_counter.astype(np.uint32), self.dt_)
+                a = a + T(vs["noise"]) * g
+            fs = vs.get("fail_safe", FAILSAFE_NONE)
+            hl = has_lead[sl]
+            if fs == FAILSAFE_INSTANTANEOUS:
+                a = np.where(hl, C.failsafe_instantaneous(a, v[sl], h[sl], hl, self.dt, N), a)
+            elif fs == FAILSAFE_SAFE_VELOCITY:
+                a = np.where(hl, C.failsafe_safe_velocity(a, v[sl], v_lead[sl], h[sl], self.dt, vs.get("delay", 0), N), a)
+            acc[sl] = a
+            commanded[sl] = cmd
+        return acc, commanded, h, v_lead, has_lead
+
+    # ---- ML3: the lane the RL vehicles are in after this sub-step's commands
+    def _lane_changes(self, actions, active, h):
+        if actions is None or self.spec.get("env") != ENV_LANE_CHANGE_ACCEL:
+            return self.lane
+        T = self.dt_.type
+        acts = np.asarray(actions, dtype=self.dt_)
+        new_lane = self.lane.copy()
+        _, _, _, _, d = self.neighbours()
+        for i, vs in enumerate(self.veh):
+            if vs["controller"] != CTRL_RL:
+                continue
+            dirv = acts[:, 2 * vs["rl_index"] + 1]
+            direction = np.where(dirv > T(0.5), 1, np.where(dirv < T(-0.5), -1, 0))
+            last = h[:, i] if self.quirk else self.last_lc[:, i].astype(self.dt_)
+            blocked = (self.time_counter + 1).astype(self.dt_) <= self.lc_duration + last   # lane_change_accel.py:143-147
+            direction = np.where(blocked, 0, direction)
+            target = np.clip(self.lane[:, i] + direction, 0, self.lanes - 1)               # traci.py:982-984
+            want = (target != self.lane[:, i]) & active
+            if self.lc_mode != 0:
+                in_t = (self.lane == target[:, None])
+                in_t[:, i] = False
+                dik = d[:, i, :]                                     # arc from me to k
+                dki = np.where(dik == 0, T(0), self.L[:, None] - dik)
+                clash = in_t & ((dik < self.veh_len[None, :]) | (dki < self.veh_len[i]))
+                want = want & ~clash.any(axis=1)
+            new_lane[:, i] = np.where(want, target, self.lane[:, i])
+        return new_lane
+
+    def _substep(self, actions, active):
+        T = self.dt_.type
+        dt = T(self.dt)
+        acc, commanded, h, v_lead, has_lead = self._accelerations(actions, active)
+        new_lane = self._lane_changes(actions, active, h)
+        v = self.v
+        next_vel = np.maximum(v + acc * dt, T(0))
+        v_cmd = v + (next_vel - v) * self.ramp
+        v_new = v.copy()
+        for i, vs in enumerate(self.veh):
+            sl = (slice(None), i)
+            v_sumo = C.sumo_idm_speed(v[sl], v_lead[sl], h[sl], has_lead[sl], self.dt,
+                                      accel=vs["max_accel"], decel=vs["max_decel"],
+                                      tau=vs.get("sumo_tau", 1.0), min_gap=vs.get("sumo_min_gap", 2.5),
+                                      max_speed=vs.get("sumo_max_speed", 30.0))
+            vc = v_cmd[sl]
+            mode = int(vs.get("speed_mode", 0))
+            if mode & 1:
+                vc = np.minimum(vc, v_sumo)
+            if mode & 2:
+                vc = np.minimum(vc, v[sl] + T(vs["max_accel"]) * dt)
+            if mode & 4:
+                vc = np.maximum(vc, v[sl] - T(vs["max_decel"]) * dt)
+            v_new[sl] = np.where(commanded[sl], vc, v_sumo)
+        x_new = self.x + ((v + v_new) / T(2) * dt if self.ballistic else v_new * dt)
+        x_new = np.where(x_new >= self.L[:, None], x_new - self.L[:, None], x_new)
+        a2 = active[:, None]
+        changed = (new_lane != self.lane) & a2
+        self.prev_v = np.where(a2, v, self.prev_v)
+        self.x = np.where(a2, x_new, self.x)
+        self.v = np.where(a2, v_new, self.v)
+        self.lane = np.where(a2, new_lane, self.lane)
+        self.last_accel = np.where(a2, acc, self.last_accel)
+        self.time_counter = self.time_counter + active
+        self.step_counter = self.step_counter + active
+        self.last_lc = np.where(changed, self.time_counter[:, None], self.last_lc)          # traci.py:205-209
+        _, _, has_new, h_new, _ = self.neighbours()
+        crash = np.any(has_new & (h_new < self.crash_gap), axis=1)
+        return crash & active
+
+    def get_state(self):
+        if self.spec.get("env") != ENV_LANE_CHANGE_ACCEL:
+            return super().get_state()
+        T = self.dt_.type                                            # lane_change_accel.py:100-117
+        return np.concatenate([self.v / T(self.spec["max_speed"]), self.x / self.L[:, None],
+                               self.lane.astype(self.dt_) / T(self.lanes)], axis=1)
+
+    def compute_reward(self, actions, fail):
+        if self.spec.get("env") != ENV_LANE_CHANGE_ACCEL:
+            return super().compute_reward(actions, fail)
+        T = self.dt_.type                                            # lane_change_accel.py:86-98
+        reward = Rw.desired_velocity(self.v, self.spec["target_velocity"], fail)
+        h = self.headways()
+        for i, vs in enumerate(self.veh):
+            if vs["controller"] != CTRL_RL:
+                continue
+            last = h[:, i] if self.quirk else self.last_lc[:, i].astype(self.dt_)
+            reward = np.where(last == self.time_counter.astype(self.dt_), reward - T(0.1), reward)
+        return reward

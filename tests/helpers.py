@@ -33,3 +33,23 @@ def ring_spec(R=1, N=22, length=230.0, bunching=20.0, junction_length=0.0, horiz
     return spec
 
 
+
+
+def multilane_spec(R=4, N=21, lanes=3, length=230.0, horizon=100, n_rl=0, seed=0, junction_length=0.1, **kw):
+    """RingNetwork with ``lanes`` lanes: vehicles placed side by side as gen_even_start_pos does
+    (network/base.py:372-378), optionally with ``n_rl`` RL vehicles in the last slots."""
+    net = Net.ring_network(length, lanes=lanes, junction_length=junction_length)
+    pos, start_lanes = net.gen_even_start_pos(N)
+    x0 = np.array([net.get_x(e, p) for e, p in pos])
+    rng = np.random.default_rng(seed)
+    X = np.tile(x0, (R, 1)) + np.abs(rng.normal(0, 0.2, (R, N)))
+    veh = [idm_vehicle() for _ in range(N)]
+    for k in range(n_rl):
+        veh[N - n_rl + k] = idm_vehicle(controller=S.CTRL_RL, rl_index=k)
+    spec = dict(num_replicas=R, num_vehicles=N, num_rl=n_rl, sim_step=0.1, junction_length=junction_length,
+                ring_length=np.full(R, length), max_speed=30.0, env=S.ENV_LANE_CHANGE_ACCEL, target_velocity=10.0,
+                action_low=-3.0, action_high=3.0, horizon=horizon, warmup_steps=0, sims_per_step=1,
+                vehicles=veh, init_pos=X, num_lanes=lanes, init_lane=np.tile(np.array(start_lanes, dtype=np.int32), (R, 1)),
+                lane_change_duration=5, lane_change_mode=512, last_lc_quirk=True)
+    spec.update(kw)
+    return spec

@@ -34,7 +34,8 @@ def test_header_declares_the_expected_entry_points():
 def test_library_exports_every_declared_symbol(lib):
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.fs_abi_version() == 1
+    from flow_amd import _lib
+    assert lib.fs_abi_version() == _lib.FS_ABI_VERSION == 2
 
 
 def test_ctypes_layout_matches_the_c_header(tmp_path):
@@ -66,7 +67,7 @@ def test_enums_agree_between_header_binding_and_oracle():
     for n in ("SIM", "RL", "IDM", "CFM", "BCM", "LAC", "OVM", "LINEAR_OVM", "GIPPS", "FOLLOWER_STOPPER",
               "NONLOCAL_FOLLOWER_STOPPER"):
         assert enum_val("FS_CTRL_" + n) == getattr(_lib, "FS_CTRL_" + n) == getattr(S, "CTRL_" + n)
-    for n in ("ACCEL", "WAVE_ATTENUATION", "WAVE_ATTENUATION_PO"):
+    for n in ("ACCEL", "WAVE_ATTENUATION", "WAVE_ATTENUATION_PO", "LANE_CHANGE_ACCEL"):
         assert enum_val("FS_ENV_" + n) == getattr(_lib, "FS_ENV_" + n) == getattr(S, "ENV_" + n)
     for n in ("NONE", "INSTANTANEOUS", "SAFE_VELOCITY"):
         assert enum_val("FS_FAILSAFE_" + n) == getattr(_lib, "FS_FAILSAFE_" + n) == getattr(S, "FAILSAFE_" + n)

@@ -12,7 +12,7 @@ Bars (DESIGN.md "Parity"):
 import numpy as np
 import pytest
 
-from helpers import idm_vehicle, ring_spec
+from helpers import idm_vehicle, multilane_spec, ring_spec
 from oracle import refsim as S
 
 pytestmark = pytest.mark.gpu
@@ -314,6 +314,71 @@ def test_specialised_kernel_equals_generic_kernel(monkeypatch):
         assert a[0] == b[0] and a[1] != b[1]
         for x, y in zip(a[2:], b[2:]):
             np.testing.assert_array_equal(x, y)
+
+
+def run_pair_ml(spec, precision, steps, actions=None, exact=True, atol=0.0):
+    dtype = np.float32 if precision == "f32" else np.float64
+    ora = S.MultiLaneRingOracle(spec, dtype)
+    sim = make(spec, precision)
+    cmp = np.testing.assert_array_equal if exact else (lambda a, b: np.testing.assert_allclose(a, b, rtol=0, atol=atol))
+    cmp(sim.reset(), ora.reset().astype(np.float32))
+    from flow_amd import _lib as L
+    for k in range(steps):
+        a = None if actions is None else actions[k]
+        o_ref, r_ref, d_ref = ora.step(a)
+        o_gpu, r_gpu, d_gpu = sim.step(a)
+        cmp(sim.pos, ora.x)
+        cmp(sim.vel, ora.v)
+        np.testing.assert_array_equal(sim.get_state(L.FS_FIELD_LANE), ora.lane)
+        cmp(o_gpu, o_ref.astype(np.float32))
+        cmp(r_gpu, r_ref.astype(np.float32))
+        np.testing.assert_array_equal(d_gpu, d_ref)
+    lead = ora.neighbours()[0]
+    np.testing.assert_array_equal(sim.get_state(L.FS_FIELD_LEADER), lead)
+    cmp(sim.headway, ora.headways())
+    np.testing.assert_array_equal(sim.get_state(L.FS_FIELD_LAST_LC), ora.last_lc.astype(np.int32))
+    sim.close()
+    return ora
+
+
+def test_multilane_ring_own_lane_following_bit_exact():
+    """3-lane ring, 21 IDM vehicles side by side (the layout of reference test_vehicles.py:199-253): every
+    vehicle follows the nearest vehicle of ITS lane; no lane changes without commands (lane_change_mode 512)."""
+    spec = multilane_spec(R=5, N=21, lanes=3, horizon=150)
+    ora = run_pair_ml(spec, "f32", 150)
+    # lanes never change and the own-lane leader of slot i is slot i+3 (cyclic) throughout
+    assert (ora.lane == np.tile(np.arange(21) % 3, (5, 1))).all()
+    np.testing.assert_array_equal(ora.neighbours()[0], np.tile((np.arange(21) + 3) % 21, (5, 1)))
+    run_pair_ml(multilane_spec(R=3, N=21, lanes=3, horizon=60), "f64", 60, exact=False, atol=1e-9)
+
+
+def test_multilane_lane_change_commands_rate_limit_and_overlap_refusal():
+    """LaneChangeAccelEnv: actions [acc, dir] per RL vehicle; changes are clipped to the lane range, refused
+    while they would overlap a vehicle of the target lane, rate-limited as the fork does (get_last_lc returns
+    the headway), and the leader bookkeeping follows every executed change."""
+    R, N, K = 6, 14, 120
+    spec = multilane_spec(R=R, N=N, lanes=2, length=200.0, horizon=K, n_rl=2, seed=3, lane_change_duration=2)
+    rng = np.random.default_rng(11)
+    acts = np.zeros((K, R, 4), dtype=np.float32)
+    acts[:, :, 0::2] = rng.uniform(-1.0, 1.5, (K, R, 2))
+    acts[:, :, 1::2] = rng.integers(-1, 2, (K, R, 2))
+    ora = run_pair_ml(spec, "f32", K, actions=acts)
+    assert (ora.last_lc > 0).any(), "the scenario must execute lane changes"
+    # upstream semantics (true last-lane-change time) and 'aggressive' lane-change mode
+    spec2 = dict(spec, last_lc_quirk=False, lane_change_mode=0, lane_change_duration=7)
+    ora2 = run_pair_ml(spec2, "f32", K, actions=acts)
+    assert (ora2.last_lc > 0).any()
+
+
+def test_multilane_mixed_controllers_and_single_vehicle_lanes():
+    """A lane holding one vehicle has no leader (headway 1000, get_speed(None) = -1001 for LAC / Gipps)."""
+    R, N = 4, 7
+    spec = multilane_spec(R=R, N=N, lanes=3, length=120.0, horizon=40, env=S.ENV_ACCEL)
+    spec["init_lane"] = np.tile(np.array([0, 1, 0, 1, 0, 1, 2], dtype=np.int32), (R, 1))
+    spec["vehicles"][6] = idm_vehicle(controller=S.CTRL_CFM, p=[1, 1, 1, 1, 8, 0, 0, 0], max_accel=1.3)
+    spec["vehicles"][1] = idm_vehicle(controller=S.CTRL_BCM, p=[1, 1, 1, 1, 8, 0, 0, 0], max_accel=15)
+    spec["vehicles"][3] = idm_vehicle(fail_safe=S.FAILSAFE_SAFE_VELOCITY, delay=0.5)
+    run_pair_ml(spec, "f32", 40)
 
 
 def test_abi_rejects_bad_configs():
