@@ -28,6 +28,7 @@ class VehicleKernel(object):
         self._slot = {}
         self._cache = {}
         self._pending = None          # RL accelerations buffered by apply_acceleration
+        self._pending_lc = None       # RL lane-change directions buffered by apply_lane_change
         self._observed = set()
 
     # ---- construction (vehicle/traci.py:91-117, 261-372)
@@ -73,6 +74,7 @@ class VehicleKernel(object):
         """Called after every simulation step: drop the host copies (vehicle/traci.py:119)."""
         self._cache = {}
         self._pending = None
+        self._pending_lc = None
 
     def reset(self):
         self._cache = {}
@@ -155,7 +157,12 @@ class VehicleKernel(object):
     def get_position(self, veh_id, error=-1001):
         return self._vec(veh_id, lambda i: self._edge_pos(i)[1], error)
 
+    def _multilane(self):
+        return self.sim is not None and int(self.sim.spec.get("num_lanes", 1)) > 1
+
     def get_lane(self, veh_id, error=-1001):
+        if self._multilane():
+            return self._vec(veh_id, lambda i: int(self._field(L.FS_FIELD_LANE)[i]), error)
         return self._vec(veh_id, lambda i: 0, error)
 
     def get_headway(self, veh_id, error=-1001):
@@ -163,10 +170,24 @@ class VehicleKernel(object):
 
     def get_leader(self, veh_id, error=""):
         n = self.num_vehicles
+        if self._multilane():
+            def lead(i):
+                j = int(self._field(L.FS_FIELD_LEADER)[i])
+                return self.__ids[j] if j >= 0 else None
+            return self._vec(veh_id, lead, error)
         return self._vec(veh_id, lambda i: self.__ids[(i + 1) % n] if n > 1 else None, error)
 
     def get_follower(self, veh_id, error=""):
         n = self.num_vehicles
+        if self._multilane():
+            def foll(i):
+                lead = self._field(L.FS_FIELD_LEADER)
+                cand = [j for j in range(n) if int(lead[j]) == i]
+                if not cand:
+                    return None
+                hw = self._field(L.FS_FIELD_HEADWAY)
+                return self.__ids[min(cand, key=lambda j: hw[j])]      # vehicle/traci.py:243-250
+            return self._vec(veh_id, foll, error)
         return self._vec(veh_id, lambda i: self.__ids[(i - 1) % n] if n > 1 else None, error)
 
     def get_length(self, veh_id, error=-1001):
@@ -193,20 +214,60 @@ class VehicleKernel(object):
         return [v for v in self.__ids if self.get_edge(v) == edges]
 
     def get_last_lc(self, veh_id, error=-1001):
-        return self._vec(veh_id, lambda i: -float("inf"), error)
+        """This fork returns the HEADWAY here (vehicle/traci.py:604-614); kept unless the env was
+        built with LAST_LC_QUIRK = False, in which case it is the time of the last lane change."""
+        if isinstance(veh_id, (list, np.ndarray)):
+            return [self.get_headway(v, error) for v in veh_id]               # vehicle/traci.py:606-607
+        if veh_id not in self.__rl_ids:
+            return error
+        if self.sim is not None and not self.sim.spec.get("last_lc_quirk", True):
+            t = int(self._field(L.FS_FIELD_LAST_LC)[self._slot[veh_id]])
+            return -float("inf") if t < 0 else t
+        return self.get_headway(veh_id, error)
+
+    def _lane_neighbours(self, i):
+        """Per lane: (leader id, headway, follower id, tailway) as _multi_lane_headways computes them
+        (vehicle/traci.py:776-867): headway = pos_lead - pos - len(lead), tailway = pos - pos_follow -
+        len(self), defaults '' / 1000 when the lane holds no other vehicle."""
+        lanes = int(self.sim.spec.get("num_lanes", 1))
+        x = self._field(L.FS_FIELD_POS)
+        ln = self._field(L.FS_FIELD_LANE) if lanes > 1 else np.zeros(self.num_vehicles, dtype=np.int32)
+        Lloop = self.master_kernel.network.length()
+        out = []
+        for lane in range(lanes):
+            best_h, best_t, lead, foll = 1000, 1000, "", ""
+            dl, df = None, None
+            for j in range(self.num_vehicles):
+                if j == i or int(ln[j]) != lane:
+                    continue
+                ahead = (float(x[j]) - float(x[i])) % Lloop
+                behind = (float(x[i]) - float(x[j])) % Lloop
+                if dl is None or ahead < dl:
+                    dl, lead, best_h = ahead, self.__ids[j], ahead - self.__vehicles[self.__ids[j]]["length"]
+                if df is None or behind < df:
+                    df, foll, best_t = behind, self.__ids[j], behind - self.__vehicles[self.__ids[i]]["length"]
+            out.append((lead, best_h, foll, best_t))
+        return out
 
     def get_lane_leaders(self, veh_id, error=None):
-        return self._vec(veh_id, lambda i: [self.get_leader(self.__ids[i])], error)
-
-    def get_lane_followers(self, veh_id, error=None):
-        return self._vec(veh_id, lambda i: [self.get_follower(self.__ids[i])], error)
+        return self._vec(veh_id, lambda i: [t[0] for t in self._lane_neighbours(i)], error)
 
     def get_lane_headways(self, veh_id, error=None):
-        return self._vec(veh_id, lambda i: [self.get_headway(self.__ids[i])], error)
+        return self._vec(veh_id, lambda i: [t[1] for t in self._lane_neighbours(i)], error)
+
+    def get_lane_followers(self, veh_id, error=None):
+        return self._vec(veh_id, lambda i: [t[2] for t in self._lane_neighbours(i)], error)
 
     def get_lane_tailways(self, veh_id, error=None):
-        return self._vec(veh_id, lambda i: [self.get_headway(self.get_follower(self.__ids[i]))]
-                         if self.num_vehicles > 1 else [1000], error)
+        return self._vec(veh_id, lambda i: [t[3] for t in self._lane_neighbours(i)], error)
+
+    def get_lane_leaders_speed(self, veh_id, error=None):
+        return self._vec(veh_id, lambda i: [self.get_speed(t[0]) if t[0] else 0.0
+                                            for t in self._lane_neighbours(i)], error)
+
+    def get_lane_followers_speed(self, veh_id, error=None):
+        return self._vec(veh_id, lambda i: [self.get_speed(t[2]) if t[2] else 0.0
+                                            for t in self._lane_neighbours(i)], error)
 
     # ---- commands
     def apply_acceleration(self, veh_ids, acc):
@@ -230,6 +291,14 @@ class VehicleKernel(object):
             veh_ids, direction = [veh_ids], [direction]
         if any(d not in [-1, 0, 1] for d in direction):
             raise ValueError("Direction values for lane changes may only be: -1, 0, or 1.")
+        if self._pending_lc is None:
+            self._pending_lc = {}
+        for vid, d in zip(veh_ids, direction):
+            if d == 0 or vid not in self._slot:
+                continue
+            if vid not in self.__rl_ids:
+                raise NotImplementedError("lane changes of non-RL vehicles are decided in the HIP kernel")
+            self._pending_lc[vid] = int(d)
 
     def choose_routes(self, veh_ids, route_choices):
         pass

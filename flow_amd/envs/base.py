@@ -114,6 +114,12 @@ class Env(_Base):
         if not pend:
             return None
         order = self._rl_action_order()
+        if self.FS_ENV == L.FS_ENV_LANE_CHANGE_ACCEL:          # [acc_0, dir_0, acc_1, dir_1, ...]
+            lc = self.k.vehicle._pending_lc or {}
+            row = []
+            for v in order:
+                row += [pend.get(v, 0.0), float(lc.get(v, 0))]
+            return np.array([row], dtype=np.float32)
         return np.array([[pend.get(v, 0.0) for v in order]], dtype=np.float32)
 
     def step(self, rl_actions):
@@ -231,6 +237,6 @@ def redraw_ring(env, length, bunching=None, min_gap=None):
     env.initial_config = ic
     env.k.generate_network(env.network)
     N = env.k.vehicle.num_vehicles
-    X = initial_positions(env.k.network, ic, N, 1)
-    check_placement(X, np.array([s["length"] for s in env._spec["vehicles"]]), env.k.network.length())
+    X, lanes = initial_positions(env.k.network, ic, N, 1)
+    check_placement(X, np.array([s["length"] for s in env._spec["vehicles"]]), env.k.network.length(), lanes)
     return X

@@ -42,8 +42,6 @@ def initial_positions(network_kernel, initial_config, num_vehicles, num_replicas
         cfg = copy.copy(initial_config)
         cfg.perturbation = 0.0
     pos, lanes = network_kernel.generate_starting_positions(cfg, num_vehicles)
-    if any(lane != 0 for lane in lanes):
-        raise NotImplementedError("multi-lane placement is not built")
     x = np.array([network_kernel.get_x(e, p) for e, p in pos], dtype=np.float64)
     X = np.tile(x, (num_replicas, 1))
     if pert > 0:
@@ -53,13 +51,20 @@ def initial_positions(network_kernel, initial_config, num_vehicles, num_replicas
         rel = np.array([p for _, p in pos])
         rel = np.clip(rel[None, :] + rng.normal(0, pert, (num_replicas, num_vehicles)), 0, elen[None, :])
         X = start[None, :] + rel
-    return X
+    return X, np.tile(np.asarray(lanes, dtype=np.int32), (num_replicas, 1))
 
 
-def check_placement(X, lengths, loop_length):
+def check_placement(X, lengths, loop_length, lanes=None):
     """Slot order must be ring order with no overlap (the reference raises 'Not enough vehicles
-    have spawned' when SUMO refuses an overlapping insertion, envs/base.py:536-542)."""
-    if X.shape[1] > 1:
+    have spawned' when SUMO refuses an overlapping insertion, envs/base.py:536-542).  On a
+    multi-lane ring only overlaps inside a lane are rejected (the leader is searched per step)."""
+    if lanes is not None and lanes.max() > 0:
+        Lp = np.broadcast_to(np.asarray(loop_length, dtype=np.float64), (X.shape[0],))[:, None, None]
+        d = (X[:, None, :] - X[:, :, None]) % Lp                          # arc i -> j
+        same = (lanes[:, None, :] == lanes[:, :, None]) & ~np.eye(X.shape[1], dtype=bool)[None]
+        if (same & (d < lengths[None, None, :])).any():
+            raise FatalFlowError("initial placement overlaps inside a lane")
+    elif X.shape[1] > 1:
         gap = np.roll(X, -1, axis=1) - X
         gap[:, -1] += loop_length if np.ndim(loop_length) == 0 else np.asarray(loop_length)
         gap = gap - np.roll(lengths, -1)[None, :]
@@ -75,15 +80,18 @@ def build_spec(env, num_replicas, rng=None):
     sp, ep = env.sim_params, env.env_params
     if not isinstance(network, RingNetwork):
         raise NotImplementedError("network %s is not built in the HIP step loop yet" % type(network).__name__)
-    if network.net_params.additional_params["lanes"] != 1:
-        raise NotImplementedError("multi-lane rings are not built in the HIP step loop yet")
+    num_lanes = int(network.net_params.additional_params["lanes"])
     if len(network.net_params.inflows.get()) > 0:
         raise NotImplementedError("inflows are not built in the HIP step loop yet")
     R, N = int(num_replicas), veh_k.num_vehicles
     slots = vehicle_slots(veh_k, env._rl_action_order())
-    X = initial_positions(net_k, network.initial_config, N, R, rng)
+    X, lanes = initial_positions(net_k, network.initial_config, N, R, rng)
     lengths = np.array([s["length"] for s in slots])
-    check_placement(X, lengths, net_k.length())
+    check_placement(X, lengths, net_k.length(), lanes)
+    if num_lanes > 1 and env.FS_ENV == L.FS_ENV_WAVE_ATTENUATION_PO:
+        raise NotImplementedError("WaveAttenuationPOEnv on a multi-lane ring is not built")
+    lc_modes = {int(veh_k.type_parameters[veh_k.get_type(v)]["lane_change_params"].lane_change_mode)
+                for v in (veh_k.get_rl_ids() or veh_k.get_ids())}
     dt = sp.sim_step
     ramp = getattr(sp, "slowdown_ramp", None)
     space = env.action_space
@@ -95,9 +103,13 @@ def build_spec(env, num_replicas, rng=None):
         junction_mode=int(getattr(sp, "junction_mode", 0)), junction_length=float(net_k.junction_length),
         crash_gap=float(getattr(sp, "crash_gap", 0.0)), max_speed=float(net_k.max_speed()),
         env=env.FS_ENV, target_velocity=float(ep.additional_params.get("target_velocity", 0.0)),
-        action_low=float(np.min(space.low)) if N and veh_k.num_rl_vehicles else 0.0,
-        action_high=float(np.max(space.high)) if N and veh_k.num_rl_vehicles else 0.0,
+        action_low=float(space.low[0]) if N and veh_k.num_rl_vehicles else 0.0,      # acceleration bounds
+        action_high=float(space.high[0]) if N and veh_k.num_rl_vehicles else 0.0,
         clip_actions=bool(ep.clip_actions), evaluate=bool(ep.evaluate),
         po_max_length=float(env._po_max_length()), horizon=ep.horizon, warmup_steps=int(ep.warmup_steps),
-        sims_per_step=int(ep.sims_per_step), seed=int(sp.seed or 0), track_aux=True)
+        sims_per_step=int(ep.sims_per_step), seed=int(sp.seed or 0), track_aux=True,
+        num_lanes=num_lanes, init_lane=lanes,
+        lane_change_duration=float(ep.additional_params.get("lane_change_duration", 0)),
+        lane_change_mode=max(lc_modes) if lc_modes else 512,
+        last_lc_quirk=bool(getattr(env, "LAST_LC_QUIRK", True)))
     return spec

@@ -47,7 +47,7 @@ class VecFlowEnv(object):
         self.k = env.k
         self.observation_space = env.observation_space
         self.action_space = env.action_space
-        self.obs_dim, self.num_rl = self.sim.obs_dim, self.sim.num_rl
+        self.obs_dim, self.num_rl, self.act_dim = self.sim.obs_dim, self.sim.num_rl, self.sim.act_dim
         R = self.num_envs
         self._obs = torch.empty((R, self.obs_dim), dtype=torch.float32, device=self.device)
         self._rew = torch.empty((R,), dtype=torch.float32, device=self.device)
@@ -78,8 +78,8 @@ class VecFlowEnv(object):
         return self._obs
 
     def step(self, actions=None):
-        """One Env.step of every replica.  ``actions``: float32 [R, num_rl] device tensor or None."""
-        a = self._check(actions, (self.num_envs, self.num_rl), self.torch.float32) if self.num_rl else None
+        """One Env.step of every replica.  ``actions``: float32 [R, action_dim] device tensor or None."""
+        a = self._check(actions, (self.num_envs, self.act_dim), self.torch.float32) if self.act_dim else None
         self.sim.step_dev(self._obs, self._rew, self._done, a)
         return self._obs, self._rew, self._done
 
@@ -94,12 +94,12 @@ class VecFlowEnv(object):
                    torch.empty(lead + (R,), dtype=torch.float32, device=self.device),
                    torch.empty(lead + (R,), dtype=torch.uint8, device=self.device))
         stride = 0
-        if actions is not None and self.num_rl:
+        if actions is not None and self.act_dim:
             if actions.dim() == 3:
-                self._check(actions, (K, R, self.num_rl), torch.float32)
-                stride = R * self.num_rl
+                self._check(actions, (K, R, self.act_dim), torch.float32)
+                stride = R * self.act_dim
             else:
-                self._check(actions, (R, self.num_rl), torch.float32)
+                self._check(actions, (R, self.act_dim), torch.float32)
         else:
             actions = None
         self.sim.rollout_dev(K, out[0], out[1], out[2], actions, stride, obs_every_step)

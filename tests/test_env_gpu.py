@@ -260,3 +260,65 @@ def test_experiment_run_and_emission_csv(tmp_path):
         assert abs(mine_s - ref_s) <= 0.0051
         checked += 1
     assert checked == 110
+
+
+def lane_change_flow_params(n=21, rl=1, lanes=3, horizon=50, lc_mode="aggressive"):
+    from flow_amd.controllers import ContinuousRouter, IDMController, RLController
+    from flow_amd.core.params import (EnvParams, InitialConfig, NetParams, SumoCarFollowingParams,
+                                      SumoLaneChangeParams, SumoParams, VehicleParams)
+    from flow_amd.envs import LaneChangeAccelEnv
+    from flow_amd.envs.ring.lane_change_accel import ADDITIONAL_ENV_PARAMS
+    from flow_amd.networks import RingNetwork
+    vehicles = VehicleParams()
+    vehicles.add(veh_id="test", acceleration_controller=(IDMController, {}), routing_controller=(ContinuousRouter, {}),
+                 car_following_params=SumoCarFollowingParams(speed_mode="aggressive"), num_vehicles=n - rl)
+    if rl:
+        vehicles.add(veh_id="rl", acceleration_controller=(RLController, {}), routing_controller=(ContinuousRouter, {}),
+                     car_following_params=SumoCarFollowingParams(speed_mode="aggressive"),
+                     lane_change_params=SumoLaneChangeParams(lane_change_mode=lc_mode), num_vehicles=rl)
+    return dict(exp_tag="ring3", env_name=LaneChangeAccelEnv, network=RingNetwork, simulator="traci",
+                sim=SumoParams(sim_step=0.1, render=False),
+                env=EnvParams(horizon=horizon, additional_params=dict(ADDITIONAL_ENV_PARAMS)),
+                net=NetParams(additional_params={"length": 230, "lanes": lanes, "speed_limit": 30, "resolution": 40}),
+                veh=vehicles, initial=InitialConfig(lanes_distribution=float("inf")))
+
+
+def test_multilane_views_known_answers_of_reference_test_vehicles():
+    """reference tests/fast_tests/test_vehicles.py:199-253: 21 vehicles on a 3-lane ring; lane leaders and
+    lane headways of test_0 (the forward values do not cross a junction, so they do not depend on netconvert)."""
+    from flow_amd.utils.registry import make_create_env
+    env = make_create_env(lane_change_flow_params(n=21, rl=0))[0]()
+    env.reset()
+    k = env.k.vehicle
+    assert sorted(k.get_lane_leaders("test_0")) == ["test_1", "test_2", "test_3"]
+    np.testing.assert_allclose(sorted(k.get_lane_headways("test_0")), sorted([27.85714285714286, -5, -5]), atol=1e-5)
+    assert sorted(k.get_lane_followers("test_0")) == ["test_18", "test_19", "test_20"]
+    assert k.get_lane("test_4") == 1 and k.get_leader("test_0") == "test_3" and k.get_follower("test_3") == "test_0"
+    assert env.observation_space.shape == (63,)
+    env.terminate()
+
+
+def test_lane_change_accel_env_step_through_the_env_api():
+    from flow_amd.utils.registry import make_create_env
+    env = make_create_env(lane_change_flow_params(n=9, rl=1, lanes=3, horizon=200))[0]()
+    obs = env.reset()
+    assert obs.shape == (27,)
+    rl = "rl_0"
+    lane0 = env.k.vehicle.get_lane(rl)
+    assert lane0 == 2                                        # slot 8 of a side-by-side fill over 3 lanes
+    # the fork's rate limit reads the headway: with headway h, changes are refused until time_counter > 5 + h
+    h = env.k.vehicle.get_headway(rl)
+    for _ in range(3):
+        obs, rew, done, _ = env.step([0.5, -1])
+    assert env.k.vehicle.get_lane(rl) == lane0 and env.time_counter == 3 <= 5 + h
+    moved = None
+    for t in range(150):
+        obs, rew, done, _ = env.step([0.2, -1])
+        if env.k.vehicle.get_lane(rl) != lane0:
+            moved = env.time_counter
+            break
+    assert moved is not None and env.k.vehicle.get_lane(rl) == lane0 - 1
+    np.testing.assert_allclose(obs[18:], np.array(env.k.vehicle.get_lane(env.k.vehicle.get_ids())) / 3.0)
+    with pytest.raises(ValueError):
+        env.step([0.0, 0.4])                                 # vehicle/traci.py:973-975
+    env.terminate()

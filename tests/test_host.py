@@ -141,6 +141,7 @@ class RecordingSim:
 
     def __init__(self, spec, precision="f32", device=0):
         RecordingSim.last = (spec, precision)
+        self.spec = spec
         self.R, self.N = spec["num_replicas"], spec["num_vehicles"]
 
     def close(self):
@@ -206,13 +207,44 @@ def test_missing_env_params_raise_keyerror(monkeypatch):
 def test_unsupported_features_raise_at_construction(monkeypatch):
     from flow_amd.envs import AccelEnv
     from flow_amd.envs.ring.accel import ADDITIONAL_ENV_PARAMS
+    v = P.VehicleParams()
+    v.add("idm", acceleration_controller=(FC.IDMController, {}), num_vehicles=4)
+    net = RingNetwork("ring", v, P.NetParams(additional_params=dict(ADDITIONAL_NET_PARAMS)),
+                      P.InitialConfig(shuffle=True))
+    with pytest.raises(NotImplementedError):
+        build_env(monkeypatch, AccelEnv, P.EnvParams(additional_params=ADDITIONAL_ENV_PARAMS), P.SumoParams(), net)
+    inflow = P.InFlows()
+    inflow.add("bottom", "idm", vehs_per_hour=100)
+    net = RingNetwork("ring", v, P.NetParams(inflows=inflow, additional_params=dict(ADDITIONAL_NET_PARAMS)))
+    with pytest.raises(NotImplementedError):
+        build_env(monkeypatch, AccelEnv, P.EnvParams(additional_params=ADDITIONAL_ENV_PARAMS), P.SumoParams(), net)
+
+
+def test_spec_resolution_multilane_lane_change_env(monkeypatch):
+    """3-lane ring of reference tests/fast_tests/test_vehicles.py:199-253 (21 vehicles side by side) under
+    LaneChangeAccelEnv: lanes 0,1,2 repeat, action space of test_environments.py:84-100."""
+    from flow_amd.envs import LaneChangeAccelEnv
+    from flow_amd.envs.ring.lane_change_accel import ADDITIONAL_ENV_PARAMS
     add = dict(ADDITIONAL_NET_PARAMS)
     add["lanes"] = 3
     v = P.VehicleParams()
-    v.add("idm", acceleration_controller=(FC.IDMController, {}), num_vehicles=4)
-    net = RingNetwork("ring", v, P.NetParams(additional_params=add))
-    with pytest.raises(NotImplementedError):
-        build_env(monkeypatch, AccelEnv, P.EnvParams(additional_params=ADDITIONAL_ENV_PARAMS), P.SumoParams(), net)
+    v.add("test", acceleration_controller=(FC.IDMController, {}), num_vehicles=19)
+    v.add("rl", acceleration_controller=(FC.RLController, {}), num_vehicles=2,
+          lane_change_params=P.SumoLaneChangeParams(lane_change_mode="aggressive"))
+    net = RingNetwork("ring", v, P.NetParams(additional_params=add), P.InitialConfig(lanes_distribution=float("inf")))
+    env, spec = build_env(monkeypatch, LaneChangeAccelEnv, P.EnvParams(additional_params=ADDITIONAL_ENV_PARAMS),
+                          P.SumoParams(), net)
+    assert spec["num_lanes"] == 3 and spec["env"] == L.FS_ENV_LANE_CHANGE_ACCEL and spec["num_rl"] == 2
+    np.testing.assert_array_equal(spec["init_lane"][0], np.arange(21) % 3)
+    np.testing.assert_allclose(spec["init_pos"][0][:6], [0, 0, 0, 230 / 7, 230 / 7, 230 / 7])
+    assert spec["lane_change_duration"] == 5 and spec["lane_change_mode"] == 0 and spec["last_lc_quirk"] is True
+    assert (spec["action_low"], spec["action_high"]) == (-3.0, 3.0)
+    sp = env.action_space
+    np.testing.assert_array_equal(sp.low, [-3, -1, -3, -1])
+    np.testing.assert_array_equal(sp.high, [3, 1, 3, 1])
+    assert env.observation_space.shape == (63,)
+    with pytest.raises(ValueError):                       # vehicle/traci.py:973-975
+        env.k.vehicle.apply_lane_change(["rl_0"], [0.5])
 
 
 def test_env_construction_fails_loudly_without_gpu():
