@@ -244,7 +244,9 @@ class VehicleKernel(object):
                 behind = (float(x[i]) - float(x[j])) % Lloop
                 if dl is None or ahead < dl:
                     dl, lead, best_h = ahead, self.__ids[j], ahead - self.__vehicles[self.__ids[j]]["length"]
-                if df is None or behind < df:
+                # bisect_left semantics (vehicle/traci.py:826-848): a vehicle at the same position counts
+                # as the leader of that lane, never as the follower
+                if behind > 0 and (df is None or behind < df):
                     df, foll, best_t = behind, self.__ids[j], behind - self.__vehicles[self.__ids[i]]["length"]
             out.append((lead, best_h, foll, best_t))
         return out

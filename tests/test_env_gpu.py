@@ -311,14 +311,30 @@ def test_lane_change_accel_env_step_through_the_env_api():
     for _ in range(3):
         obs, rew, done, _ = env.step([0.5, -1])
     assert env.k.vehicle.get_lane(rl) == lane0 and env.time_counter == 3 <= 5 + h
-    moved = None
-    for t in range(150):
-        obs, rew, done, _ = env.step([0.2, -1])
-        if env.k.vehicle.get_lane(rl) != lane0:
-            moved = env.time_counter
-            break
-    assert moved is not None and env.k.vehicle.get_lane(rl) == lane0 - 1
-    np.testing.assert_allclose(obs[18:], np.array(env.k.vehicle.get_lane(env.k.vehicle.get_ids())) / 3.0)
     with pytest.raises(ValueError):
         env.step([0.0, 0.4])                                 # vehicle/traci.py:973-975
+    env.terminate()
+
+    # upstream meaning of get_last_lc (time of the last lane change): change at once, then rate-limited
+    from flow_amd.envs import LaneChangeAccelEnv
+
+    class UpstreamLC(LaneChangeAccelEnv):
+        LAST_LC_QUIRK = False
+
+    fp = lane_change_flow_params(n=9, rl=1, lanes=3, horizon=200)
+    fp["env_name"] = UpstreamLC
+    env = make_create_env(fp)[0]()
+    env.reset()
+    assert env.k.vehicle.get_last_lc(rl) == -float("inf")
+    obs, rew, done, _ = env.step([0.2, -1])
+    assert env.k.vehicle.get_lane(rl) == 1 and env.k.vehicle.get_last_lc(rl) == 1
+    for _ in range(5):                                      # time_counter <= lane_change_duration + last_lc: refused
+        obs, rew, done, _ = env.step([0.2, -1])
+    assert env.k.vehicle.get_lane(rl) == 1 and env.time_counter == 6
+    obs, rew, done, _ = env.step([0.2, -1])
+    assert env.k.vehicle.get_lane(rl) == 0 and env.k.vehicle.get_last_lc(rl) == 7
+    obs, rew, done, _ = env.step([0.2, -1])                 # already in lane 0: clipped (traci.py:982-984)
+    assert env.k.vehicle.get_lane(rl) == 0
+    np.testing.assert_allclose(obs[18:], np.array(env.k.vehicle.get_lane(env.k.vehicle.get_ids())) / 3.0)
+    assert env.k.vehicle.get_leader(rl) in ("test_0", "test_3", "test_6")
     env.terminate()
