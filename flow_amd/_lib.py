@@ -20,7 +20,8 @@ FS_OK, FS_ERR_INVALID, FS_ERR_UNSUPPORTED, FS_ERR_HIP, FS_ERR_NOSPACE = 0, -1, -
 FS_F32, FS_F64 = 0, 1
 # enum fs_controller
 (FS_CTRL_SIM, FS_CTRL_RL, FS_CTRL_IDM, FS_CTRL_CFM, FS_CTRL_BCM, FS_CTRL_LAC, FS_CTRL_OVM,
- FS_CTRL_LINEAR_OVM, FS_CTRL_GIPPS, FS_CTRL_FOLLOWER_STOPPER, FS_CTRL_NONLOCAL_FOLLOWER_STOPPER) = range(11)
+ FS_CTRL_LINEAR_OVM, FS_CTRL_GIPPS, FS_CTRL_FOLLOWER_STOPPER, FS_CTRL_NONLOCAL_FOLLOWER_STOPPER,
+ FS_CTRL_PISATURATION) = range(12)
 # enum fs_failsafe
 FS_FAILSAFE_NONE, FS_FAILSAFE_INSTANTANEOUS, FS_FAILSAFE_SAFE_VELOCITY = range(3)
 # enum fs_env

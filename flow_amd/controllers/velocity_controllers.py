@@ -26,7 +26,11 @@ class NonLocalFollowerStopper(FollowerStopper):
 
 
 class PISaturation(BaseController):
-    """velocity_controllers.py:167-240.  Needs a 38 s speed history per vehicle; not built yet."""
+    """velocity_controllers.py:167-240: PI controller with saturation; the kernel keeps the last
+    int(38 / sim_step) - 1 speeds of the vehicle in HBM and the previous command as controller state."""
+    FS_ID = L.FS_CTRL_PISATURATION
 
     def __init__(self, veh_id, car_following_params):
-        raise NotImplementedError("PISaturation is not built in the HIP step kernel yet")
+        BaseController.__init__(self, veh_id, car_following_params, delay=1.0)
+        self.max_accel = car_following_params.controller_params['accel']
+        self.gamma, self.g_l, self.g_u, self.v_catch = 2, 7, 30, 1

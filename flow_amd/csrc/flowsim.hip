@@ -117,7 +117,8 @@ struct Sim : SimBase {
     if ((rc = upload(&dv.init_vel, ivel))) return rc;
     if ((rc = upload(&dv.ring_len, rlen))) return rc;
 
-    std::vector<int32_t> ctrl(N), fsafe(N), smode(N), rli(N);
+    std::vector<int32_t> ctrl(N), fsafe(N), smode(N), rli(N), pisi(N, -1);
+    int n_pis = 0;
     std::vector<T> p(size_t(FS_MAX_CTRL_PARAMS) * N), noise(N), delay(N), maxa(N), maxd(N), len(N), stau(N),
         sgap(N), smax(N);
     int flags = 0;
@@ -140,6 +141,10 @@ struct Sim : SimBase {
       if (v.controller == FS_CTRL_BCM) flags |= fs::FLAG_NEED_FOLLOWER;
       if (v.controller == FS_CTRL_NONLOCAL_FOLLOWER_STOPPER) flags |= fs::FLAG_NEED_MEAN;
       if (v.controller == FS_CTRL_LAC) flags |= fs::FLAG_HAS_LAC;
+      if (v.controller == FS_CTRL_PISATURATION) {
+        flags |= fs::FLAG_HAS_LAC;
+        pisi[i] = n_pis++;
+      }
       if (v.noise > 0 && v.controller != FS_CTRL_SIM && v.controller != FS_CTRL_RL) flags |= fs::FLAG_HAS_NOISE;
       if (v.fail_safe != FS_FAILSAFE_NONE) flags |= fs::FLAG_HAS_FAILSAFE;
       if (v.controller == FS_CTRL_SIM || v.controller == FS_CTRL_RL || (v.speed_mode & 1) || cfg.junction_mode)
@@ -155,6 +160,13 @@ struct Sim : SimBase {
     if ((rc = upload(&dv.failsafe, fsafe))) return rc;
     if ((rc = upload(&dv.speed_mode, smode))) return rc;
     if ((rc = upload(&dv.rl_index, rli))) return rc;
+    if ((rc = upload(&dv.pis_index, pisi))) return rc;
+    dv.n_pis = n_pis;
+    dv.pis_H = int(38.0 / cfg.sim_step) - 1;          // velocity_controllers.py:221
+    if (dv.pis_H < 1) dv.pis_H = 1;
+    if ((rc = dev_alloc(&dv.pis_hist, size_t(R) * (n_pis ? n_pis : 1) * (n_pis ? dv.pis_H : 1)))) return rc;
+    if ((rc = dev_alloc(&dv.pis_n, size_t(R) * (n_pis ? n_pis : 1)))) return rc;
+    HIP_TRY(hipMemset(dv.pis_n, 0, size_t(R) * (n_pis ? n_pis : 1) * sizeof(int32_t)));
     if ((rc = upload(&dv.p, p))) return rc;
     if ((rc = upload(&dv.noise, noise))) return rc;
     if ((rc = upload(&dv.delay, delay))) return rc;
@@ -446,7 +458,7 @@ int validate(const fs_config* c) {
   int seen_rl = 0;
   for (int i = 0; i < c->num_vehicles; ++i) {
     const fs_vehicle_spec& v = c->vehicles[i];
-    if (v.controller < FS_CTRL_SIM || v.controller > FS_CTRL_NONLOCAL_FOLLOWER_STOPPER)
+    if (v.controller < FS_CTRL_SIM || v.controller > FS_CTRL_PISATURATION)
       return fail(FS_ERR_INVALID, "fs_create: unknown controller id");
     if (v.fail_safe < FS_FAILSAFE_NONE || v.fail_safe > FS_FAILSAFE_SAFE_VELOCITY)
       return fail(FS_ERR_INVALID, "fs_create: unknown fail_safe id");

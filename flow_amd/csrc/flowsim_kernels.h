@@ -27,7 +27,7 @@ enum : int {
   FLAG_NEED_FOLLOWER = 1,   // a BCM vehicle reads its follower (car_following_models.py:168-172)
   FLAG_NEED_MEAN = 2,       // NonLocalFollowerStopper reads the replica mean speed
   FLAG_HAS_NOISE = 4,       // some controller has noise > 0 (base_controller.py:109-110)
-  FLAG_HAS_LAC = 8,         // LAC controller state (car_following_models.py:243)
+  FLAG_HAS_LAC = 8,         // per-vehicle controller state: LAC a (car_following_models.py:243), PISaturation v_cmd
   FLAG_NEED_SUMO = 16,      // some vehicle may be uncommanded or has speed_mode bit 0
   FLAG_HAS_FAILSAFE = 32,
   FLAG_ALL_IDM = 64,        // every slot is an IDM controller (fast path)
@@ -44,6 +44,9 @@ struct DevView {
   int32_t* lane;        // [R,N]  (multi-lane only)
   int32_t* last_lc;     // [R,N]  (multi-lane only)
   const int32_t* init_lane;
+  T* pis_hist;          // [R, n_pis, pis_H] PISaturation speed history (ring buffers)
+  int32_t* pis_n;       // [R, n_pis] speeds appended so far
+  const int32_t* pis_index;   // [N] index among the PISaturation slots, -1 otherwise
   int32_t* time;        // [R]
   uint32_t* noise_ctr;  // [R]
   const T* init_pos;
@@ -65,7 +68,7 @@ struct DevView {
   const T* sumo_max_speed;
   // scalars
   int R, N, num_rl, env, integrator, sims_per_step, junction_mode, clip_actions, evaluate, track_aux;
-  int num_lanes, lane_change_mode, last_lc_quirk;
+  int num_lanes, lane_change_mode, last_lc_quirk, n_pis, pis_H;
   int step_limit;       // sims_per_step*(warmup+horizon), INT_MAX for horizon=inf
   int flags;
   uint32_t seed_lo, seed_hi;
@@ -262,7 +265,7 @@ __device__ __forceinline__ T gauss(uint32_t seed_lo, uint32_t seed_hi, uint32_t 
 // ---------------------------------------------------------------------------
 template <typename T>
 struct Slot {           // per-lane copy of the vehicle slot tables
-  int ctrl, failsafe, speed_mode, rl_index;
+  int ctrl, failsafe, speed_mode, rl_index, pis_index;
   T p[FS_MAX_CTRL_PARAMS];
   T noise, delay, max_accel, max_decel, length, sumo_tau, sumo_min_gap, sumo_max_speed;
 };
@@ -349,6 +352,38 @@ __device__ __forceinline__ T ctrl_follower_stopper(T v, T vl, T h, bool has, T d
   return (v_cmd - v) / dt;
 }
 
+// PISaturation.get_accel (velocity_controllers.py:208-240); oracle/refsim.py pisaturation_step.
+// hist: this vehicle's ring buffer of the last H speeds, n: appends so far, v_cmd: previous command.
+template <typename T>
+__device__ __forceinline__ T ctrl_pisaturation(T v, T vl, T h, T dt, T max_accel, T* hist, int32_t* n_ptr, int H,
+                                               bool update, T& v_cmd) {
+  const T dv = vl - v;
+  const T dx_s = tmax(T(2) * dv, T(4));
+  const int n = *n_ptr;
+  const int pos = n % H;                           // append here (the oldest speed is overwritten once full)
+  const int n_new = n + 1;
+  const int cnt = n_new < H ? n_new : H;
+  const int start = n_new > H ? n_new % H : 0;
+  T total = T(0);
+  for (int k = 0; k < cnt; ++k) {                  // oldest -> newest
+    int idx = start + k;
+    idx = idx >= H ? idx - H : idx;
+    total = total + (idx == pos ? v : hist[idx]);
+  }
+  if (update) {                                    // only the vehicle's own lane, only when the step is committed
+    hist[pos] = v;
+    *n_ptr = n_new;
+  }
+  const T v_des = total / T(cnt);
+  const T v_target = v_des + T(1) * tmin(tmax((h - T(7)) / (T(30) - T(7)), T(0)), T(1));
+  const T alpha = tmin(tmax((h - dx_s) / T(2), T(0)), T(1));
+  const T beta = T(1) - T(0.5) * alpha;
+  const T new_cmd = beta * (alpha * v_target + (T(1) - alpha) * vl) + (T(1) - beta) * v_cmd;
+  const T accel = tmin((new_cmd - v) / dt, max_accel);
+  if (update) v_cmd = new_cmd;
+  return accel;
+}
+
 template <typename T>
 __device__ __forceinline__ T failsafe_instantaneous(T acc, T v, T h, bool has, T dt) {
   // base_controller.py:120-169 (num_vehicles > 1 checked by the caller)
@@ -402,7 +437,18 @@ __device__ __forceinline__ T control_accel(const DevView<T>& s, const Slot<T>& s
     }
   } else if (ct != FS_CTRL_SIM) {
     T a;
+    bool on_edge = true;
+    if (s.junction_mode) {                       // base_controller.py:98-99
+      T u = x - tfloor(x / qj) * qj;
+      on_edge = !(u >= quarter);
+    }
     switch (ct) {
+      case FS_CTRL_PISATURATION: {
+        const size_t slot = size_t(rr) * s.n_pis + (sl.pis_index < 0 ? 0 : sl.pis_index);
+        a = ctrl_pisaturation(v, vl, h, s.dt, sl.max_accel, s.pis_hist + slot * s.pis_H, s.pis_n + slot, s.pis_H,
+                              on_edge && live, cst);
+        break;
+      }
       case FS_CTRL_IDM: a = ctrl_idm(v, vl, h, has, sl.p); break;
       case FS_CTRL_CFM: a = ctrl_cfm(v, vl, h, has, sl.max_accel, sl.p); break;
       case FS_CTRL_BCM: a = ctrl_bcm(v, vl, h, has, vf, hf, sl.max_accel, sl.p); break;
@@ -413,11 +459,7 @@ __device__ __forceinline__ T control_accel(const DevView<T>& s, const Slot<T>& s
       case FS_CTRL_FOLLOWER_STOPPER: a = ctrl_follower_stopper(v, vl, h, has, s.dt, sl.p[0]); break;
       default: a = ctrl_follower_stopper(v, vl, h, has, s.dt, mean_v); break;
     }
-    commanded = true;
-    if (s.junction_mode) {                       // base_controller.py:98-99
-      T u = x - tfloor(x / qj) * qj;
-      commanded = !(u >= quarter);
-    }
+    commanded = on_edge;
     if (ct == FS_CTRL_LAC && commanded && live) cst = a;
     if (flags & FLAG_HAS_NOISE) {                // base_controller.py:109-110
       if (sl.noise > T(0)) a = a + sl.noise * gauss<T>(s.seed_lo, s.seed_hi, uint32_t(rr), uint32_t(ii), nctr);
@@ -466,6 +508,7 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
   sl.failsafe = s.failsafe[ii];
   sl.speed_mode = s.speed_mode[ii];
   sl.rl_index = s.rl_index[ii];
+  sl.pis_index = s.pis_index[ii];
 #pragma unroll
   for (int k = 0; k < FS_MAX_CTRL_PARAMS; ++k) sl.p[k] = s.p[k * N + ii];
   sl.noise = s.noise[ii];
@@ -531,8 +574,8 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
         T a_rl = T(0);
         const bool have_rl = (sl.ctrl == FS_CTRL_RL) && (act != nullptr);
         if (have_rl) a_rl = T(act[sl.rl_index < 0 ? 0 : sl.rl_index]);
-        acc = control_accel(s, sl, flags, v, vl, h, has, vf, hf, mean_v, x, quarter, qj, have_rl, a_rl, live, rr, ii,
-                            nctr, cst, commanded);
+        acc = control_accel(s, sl, flags, v, vl, h, has, vf, hf, mean_v, x, quarter, qj, have_rl, a_rl,
+                            live && i < N, rr, ii, nctr, cst, commanded);
       }
       // ---- apply_acceleration + SUMO integration (S4-S9) ------------------
       T next_vel = tmax(v + acc * dt, T(0));          // vehicle/traci.py:962
@@ -820,6 +863,7 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
   sl.failsafe = s.failsafe[ii];
   sl.speed_mode = s.speed_mode[ii];
   sl.rl_index = s.rl_index[ii];
+  sl.pis_index = s.pis_index[ii];
 #pragma unroll
   for (int k = 0; k < FS_MAX_CTRL_PARAMS; ++k) sl.p[k] = s.p[k * N + ii];
   sl.noise = s.noise[ii];
@@ -908,8 +952,8 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
       const int acol = (sl.rl_index < 0 ? 0 : sl.rl_index) * (lc_env ? 2 : 1);
       T a_rl = have_rl ? T(act[acol]) : T(0);
       bool commanded = false;
-      T acc = control_accel(s, sl, flags, v, vl, h, has, vf, hf, mean_v, x, quarter, qj, have_rl, a_rl, live, rr, ii,
-                            nctr, cst, commanded);
+      T acc = control_accel(s, sl, flags, v, vl, h, has, vf, hf, mean_v, x, quarter, qj, have_rl, a_rl,
+                            live && i < N, rr, ii, nctr, cst, commanded);
       // ---- RL lane-change command (ML3) -----------------------------------
       int new_ln = ln;
       if (lc_env && have_rl) {
@@ -1084,6 +1128,7 @@ __global__ void k_reset(DevView<T> s, const uint8_t* __restrict__ mask) {
       s.lane[e] = s.init_lane[e];
       s.last_lc[e] = -(1 << 30);
     }
+    if (s.n_pis > 0 && s.pis_index[e % s.N] >= 0) s.pis_n[size_t(r) * s.n_pis + s.pis_index[e % s.N]] = 0;
     if (e % s.N == 0) s.time[r] = 0;
   }
 }

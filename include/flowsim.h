@@ -54,7 +54,8 @@ enum fs_controller {
   FS_CTRL_LINEAR_OVM = 7,       /* p = {v_max, adaptation, h_st}                        :331-397 */
   FS_CTRL_GIPPS = 8,            /* p = {v0, acc, b, b_l, s0, tau}                       :500-582 */
   FS_CTRL_FOLLOWER_STOPPER = 9, /* p = {v_des}                                          velocity_controllers.py:7-116 */
-  FS_CTRL_NONLOCAL_FOLLOWER_STOPPER = 10 /* v_des = replica mean speed                  velocity_controllers.py:119-164 */
+  FS_CTRL_NONLOCAL_FOLLOWER_STOPPER = 10, /* v_des = replica mean speed                 velocity_controllers.py:119-164 */
+  FS_CTRL_PISATURATION = 11     /* no parameters; keeps int(38/sim_step)-1 past speeds  velocity_controllers.py:167-240 */
 };
 
 /* BaseController fail-safes, flow/controllers/base_controller.py:113-116 */

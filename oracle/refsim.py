@@ -27,7 +27,7 @@ from . import rewards as Rw
 
 # controller ids -- must equal include/flowsim.h FS_CTRL_*
 CTRL_SIM, CTRL_RL, CTRL_IDM, CTRL_CFM, CTRL_BCM, CTRL_LAC, CTRL_OVM, CTRL_LINEAR_OVM, \
-    CTRL_GIPPS, CTRL_FOLLOWER_STOPPER, CTRL_NONLOCAL_FOLLOWER_STOPPER = range(11)
+    CTRL_GIPPS, CTRL_FOLLOWER_STOPPER, CTRL_NONLOCAL_FOLLOWER_STOPPER, CTRL_PISATURATION = range(12)
 FAILSAFE_NONE, FAILSAFE_INSTANTANEOUS, FAILSAFE_SAFE_VELOCITY = range(3)
 ENV_ACCEL, ENV_WAVE_ATTENUATION, ENV_WAVE_ATTENUATION_PO, ENV_LANE_CHANGE_ACCEL = range(4)
 
@@ -66,6 +66,40 @@ def gaussian_noise(seed, replica, vehicle, step, dtype):
     u2 = u2.astype(dtype)
     two_pi = np.asarray(6.283185307179586, dtype)
     return np.sqrt(np.asarray(-2.0, dtype) * np.log(u1)) * np.cos(two_pi * u2)
+
+
+def pisaturation_step(hist, n, v_cmd, v, v_lead, h, dt, max_accel, do_update, dtype):
+    """PISaturation.get_accel (velocity_controllers.py:208-240) for one slot over R replicas.
+
+    ``hist`` [R,H] ring buffer (slot k holds the k-th appended speed modulo H), ``n`` [R] count of
+    appends, ``v_cmd`` [R] previous command.  Returns (accel, new_v_cmd); mutates hist/n where
+    ``do_update``.  v_des is the mean of the kept speeds summed OLDEST -> NEWEST in the working
+    dtype (the reference's np.mean sums pairwise: equal to rounding)."""
+    T = np.dtype(dtype).type
+    R, H = hist.shape
+    dv = v_lead - v
+    dx_s = np.maximum(T(2) * dv, T(4))                                   # :216
+    hist_new = hist.copy()
+    rows = np.arange(R)
+    hist_new[rows, n % H] = v                                            # :219 (append; oldest overwritten = :221-222)
+    n_new = n + 1
+    cnt = np.minimum(n_new, H)
+    start = np.where(n_new > H, n_new % H, 0)
+    total = np.zeros(R, dtype=dtype)
+    for k in range(H):
+        idx = (start + k) % H
+        total = np.where(k < cnt, total + hist_new[rows, idx], total)
+    v_des = total / cnt.astype(dtype)                                    # :225
+    g_l, g_u, gamma, v_catch = T(7), T(30), T(2), T(1)
+    v_target = v_des + v_catch * np.minimum(np.maximum((h - g_l) / (g_u - g_l), T(0)), T(1))   # :226-227
+    alpha = np.minimum(np.maximum((h - dx_s) / gamma, T(0)), T(1))       # :230
+    beta = T(1) - T(0.5) * alpha                                         # :231
+    new_cmd = beta * (alpha * v_target + (T(1) - alpha) * v_lead) + (T(1) - beta) * v_cmd    # :234-235
+    accel = np.minimum((new_cmd - v) / T(dt), T(max_accel))              # :238-240
+    upd = np.asarray(do_update, dtype=bool)
+    hist[upd] = hist_new[upd]
+    n[upd] = n_new[upd]
+    return accel, np.where(upd, new_cmd, v_cmd)
 
 
 class RingOracle:
@@ -111,7 +145,12 @@ class RingOracle:
         self.x = self.init_pos.copy()
         self.v = self.init_vel.copy()
         self.prev_v = self.v.copy()
-        self.lac_a = np.zeros((self.R, self.N), dtype=self.dt_)
+        self.lac_a = np.zeros((self.R, self.N), dtype=self.dt_)     # controller state: LAC a / PISaturation v_cmd
+        # PISaturation speed history (velocity_controllers.py:193, 218-222): the last int(38/dt)-1 speeds
+        self.pis_H = max(int(38 / self.dt) - 1, 1)
+        self.pis_hist = np.zeros((self.R, self.N, self.pis_H), dtype=self.dt_) \
+            if any(v["controller"] == CTRL_PISATURATION for v in self.veh) else None
+        self.pis_n = np.zeros((self.R, self.N), dtype=np.int64)      # number of speeds ever appended
         self.time_counter = np.zeros(self.R, dtype=np.int64)
         self.step_counter = np.zeros(self.R, dtype=np.int64)   # noise stream position
         self.last_accel = np.zeros((self.R, self.N), dtype=self.dt_)
@@ -144,6 +183,7 @@ class RingOracle:
         self.v[m] = self.init_vel[m]
         self.prev_v[m] = self.init_vel[m]
         self.lac_a[m] = 0
+        self.pis_n[m] = 0
         self.time_counter[m] = 0
         obs = self.get_state()
         for _ in range(int(self.spec.get("warmup_steps", 0))):       # envs/base.py:554-555
@@ -204,6 +244,11 @@ class RingOracle:
                 if mean_speed is None:
                     mean_speed = Rw.tree_sum(v) / T(N)               # velocity_controllers.py:127
                 a = C.follower_stopper(*args, self.dt, v_des=mean_speed)
+            elif ct == CTRL_PISATURATION:
+                pre_cmd = ~self.in_junction(x[sl]) if self.junction_mode else np.ones(R, dtype=bool)
+                a, self.lac_a[sl] = pisaturation_step(self.pis_hist[:, i, :], self.pis_n[:, i], self.lac_a[sl], v[sl],
+                                                      v_lead[sl], h[sl], self.dt, vs["max_accel"], pre_cmd & active,
+                                                      self.dt_)
             else:
                 raise ValueError("unknown controller %r" % ct)
             cmd = np.ones(R, dtype=bool)
@@ -436,6 +481,11 @@ class MultiLaneRingOracle(RingOracle):
                 if mean_speed is None:
                     mean_speed = Rw.tree_sum(v) / T(N)
                 a = C.follower_stopper(*args, self.dt, v_des=mean_speed)
+            elif ct == CTRL_PISATURATION:
+                pre_cmd = ~self.in_junction(x[sl]) if self.junction_mode else np.ones(R, dtype=bool)
+                a, self.lac_a[sl] = pisaturation_step(self.pis_hist[:, i, :], self.pis_n[:, i], self.lac_a[sl], v[sl],
+                                                      v_lead[sl], h[sl], self.dt, vs["max_accel"], pre_cmd & active,
+                                                      self.dt_)
             else:
                 raise ValueError("unknown controller %r" % ct)
             cmd = np.ones(R, dtype=bool)

@@ -65,7 +65,7 @@ def test_enums_agree_between_header_binding_and_oracle():
         assert m, name
         return int(m.group(1))
     for n in ("SIM", "RL", "IDM", "CFM", "BCM", "LAC", "OVM", "LINEAR_OVM", "GIPPS", "FOLLOWER_STOPPER",
-              "NONLOCAL_FOLLOWER_STOPPER"):
+              "NONLOCAL_FOLLOWER_STOPPER", "PISATURATION"):
         assert enum_val("FS_CTRL_" + n) == getattr(_lib, "FS_CTRL_" + n) == getattr(S, "CTRL_" + n)
     for n in ("ACCEL", "WAVE_ATTENUATION", "WAVE_ATTENUATION_PO", "LANE_CHANGE_ACCEL"):
         assert enum_val("FS_ENV_" + n) == getattr(_lib, "FS_ENV_" + n) == getattr(S, "ENV_" + n)

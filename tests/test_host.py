@@ -88,8 +88,8 @@ def test_controller_descriptors_pack_parameters():
     assert FC.SimCarFollowingController("v", cf).FS_ID == L.FS_CTRL_SIM
     with pytest.raises(ValueError):
         FC.IDMController("v", car_following_params=cf, fail_safe="bogus")
-    with pytest.raises(NotImplementedError):
-        FC.PISaturation("v", cf)
+    pis = FC.PISaturation("v", cf)
+    assert pis.FS_ID == L.FS_CTRL_PISATURATION and pis.delay == 1.0 and pis.fail_safe is None
 
 
 def make_ring(length=230, n=22, **ic):

@@ -115,6 +115,7 @@ CTRL_CASES = {
     "idm_instantaneous": dict(fail_safe=S.FAILSAFE_INSTANTANEOUS),
     "idm_safe_velocity": dict(fail_safe=S.FAILSAFE_SAFE_VELOCITY, delay=0.5),
     "idm_delta2": dict(p=[30, 1, 1, 1.5, 2, 2, 0, 0]),
+    "pisaturation": dict(controller=S.CTRL_PISATURATION, p=[0] * 8, max_accel=20, max_decel=5, delay=1.0),
 }
 
 
@@ -126,6 +127,29 @@ def test_controllers_f32_bit_exact(name):
     spec["vehicles"] = [idm_vehicle(**CTRL_CASES[name]) if i % 2 == 0 else idm_vehicle() for i in range(N)]
     spec["track_aux"] = True
     run_pair(spec, "f32", 120, check_every=10)
+
+
+def test_pisaturation_history_wraps_its_ring_buffer():
+    """sim_step 1.0 -> the controller keeps int(38/1)-1 = 37 speeds: 60 steps overwrite the buffer."""
+    N = 6
+    spec = perturbed(ring_spec(R=5, N=N, length=120.0, bunching=10, horizon=80, sim_step=1.0), seed=15, sigma=0.3)
+    spec["vehicles"] = [idm_vehicle() for _ in range(N)]
+    spec["vehicles"][2] = idm_vehicle(controller=S.CTRL_PISATURATION, p=[0] * 8, max_accel=2.6, delay=1.0)
+    spec["junction_mode"] = 1
+    run_pair(spec, "f32", 60, check_every=6)
+    mask_spec = dict(spec, warmup_steps=3)
+    ora = S.RingOracle(mask_spec, np.float32)
+    sim = make(mask_spec, "f32")
+    ora.reset(), sim.reset()
+    for _ in range(5):
+        ora.step(None), sim.step(None)
+    m = np.array([1, 0, 1, 0, 0], dtype=bool)
+    np.testing.assert_array_equal(sim.reset(m), ora.reset(m).astype(np.float32))
+    for _ in range(45):
+        o_ref, r_ref, _ = ora.step(None)
+        o_gpu, r_gpu, _ = sim.step(None)
+    np.testing.assert_array_equal(o_gpu, o_ref.astype(np.float32))
+    sim.close()
 
 
 def test_ovm_within_libm_tolerance():
