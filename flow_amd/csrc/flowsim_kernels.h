@@ -227,6 +227,28 @@ __device__ __forceinline__ T seg_sum(T v) {
   return v;
 }
 
+// bitwise OR over the SEG-lane segment (same butterfly as seg_sum)
+__device__ __forceinline__ unsigned or_swap16(unsigned v) {
+  unsigned a = v, b = v;
+  swap_rows16(a, b);
+  return a | b;
+}
+__device__ __forceinline__ unsigned or_swap32(unsigned v) {
+  unsigned a = v, b = v;
+  swap_rows32(a, b);
+  return a | b;
+}
+template <int SEG>
+__device__ __forceinline__ unsigned seg_or(unsigned v) {
+  v |= unsigned(dpp_i<DPP_QUAD_XOR1>(int(v)));
+  v |= unsigned(dpp_i<DPP_QUAD_XOR2>(int(v)));
+  v |= unsigned(dpp_i<DPP_ROW_HALF_MIRROR>(int(v)));
+  if (SEG >= 16) v |= unsigned(dpp_i<DPP_ROW_MIRROR>(int(v)));
+  if (SEG >= 32) v = or_swap16(v);
+  if (SEG >= 64) v = or_swap32(v);
+  return v;
+}
+
 template <int SEG>
 __device__ __forceinline__ bool seg_any(bool pred, int seg) {
   unsigned long long b = __ballot(pred);
@@ -705,8 +727,9 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
 // purely structural, to keep the step loop one straight-line block the scheduler can overlap:
 //   * idle lanes store to a scratch word instead of being masked off (no exec-mask regions);
 //   * the per-replica reward tail (sqrt, divide) is deferred: lane j of a segment keeps the
-//     reduced sum of squares of step j (mod SEG) and all SEG rewards are finished and
-//     stored together every SEG steps, one step per lane.
+//     reduced sum of squares of step j (mod PERIOD = min(SEG, 32)); PERIOD rewards are finished
+//     and stored together, one step per lane; the collision / bad-speed facts of those steps
+//     travel as per-lane bit masks and are OR-reduced once per flush.
 // x / c for a divisor c that is constant over the launch.  FASTDIV (float only) replaces the
 // IEEE division sequence by q0 = x*rc, r = fma(-q0, c, x), q = fma(r, rc, q0) with rc = RN(1/c).
 // The host enables it per handle only after checking, for EVERY float mantissa of x, that the
@@ -766,8 +789,9 @@ __global__ __launch_bounds__(64) void k_rollout_idm(DevView<T> s, int num_steps,
   const size_t row = size_t(2) * N;
   float* po = valid ? obs + size_t(rr) * row + ii : dump;     // idle lanes write scratch
   const size_t po_step = valid ? size_t(s.R) * row : 0;          // the scratch word does not move
+  constexpr int PERIOD = SEG < 32 ? SEG : 32;     // steps whose reward tail is finished together
   T racc = T(0);
-  unsigned dacc = 0u;
+  unsigned crash_bits = 0u, bad_bits = 0u;
 
   for (int step = 0; step < num_steps; ++step) {
     // IDMController.get_accel (ctrl_idm, car_following_models.py:464-482)
@@ -793,7 +817,13 @@ __global__ __launch_bounds__(64) void k_rollout_idm(DevView<T> s, int num_steps,
     d = xl - x;
     d = d < T(0) ? d + L : d;
     h = d - len_lead;
-    const bool crashed = seg_any<SEG>(valid && (h < s.crash_gap), seg);
+    // collision (S12) and the v < -100 guard (rewards.py:46) are per-lane facts of this step: each lane
+    // records them in bit `slot` of a mask and the per-replica "any" is taken for all SEG steps at once
+    // at the flush (an OR-butterfly over the segment), instead of two ballots per step
+    const int slot = step & (PERIOD - 1);
+    const unsigned bit = 1u << slot;
+    crash_bits |= (valid && (h < s.crash_gap)) ? bit : 0u;
+    bad_bits |= (valid && (v < T(-100))) ? bit : 0u;
     // AccelEnv.get_state (accel.py:116-123)
     po[0] = float(v / s.max_speed);
     // speeds decay through the denormal range when a vehicle comes to rest, so only the position
@@ -803,18 +833,22 @@ __global__ __launch_bounds__(64) void k_rollout_idm(DevView<T> s, int num_steps,
     // rewards.desired_velocity, first half: the reduced sum of squares (rewards.py:53-54)
     T dv = valid ? v - s.target_velocity : T(0);
     T ssum = seg_sum<SEG>(dv * dv);
-    const bool bad = seg_any<SEG>(valid && (v < T(-100)), seg) || crashed;
-    const int slot = step & (SEG - 1);
-    racc = (i == slot) ? (bad ? T(-1) : ssum) : racc;
-    dacc = (i == slot) ? unsigned((tcount >= s.step_limit) || crashed) : dacc;
-    if (slot == SEG - 1 || step == num_steps - 1) {          // wave-uniform: finish SEG rewards at once
+    racc = (i == slot) ? ssum : racc;
+    if (slot == PERIOD - 1 || step == num_steps - 1) {       // wave-uniform: finish PERIOD rewards at once
+      const unsigned crash_any = seg_or<SEG>(crash_bits);
+      const unsigned bad_any = seg_or<SEG>(bad_bits) | crash_any;
+      crash_bits = 0u;
+      bad_bits = 0u;
       if (rvalid && i <= slot) {
-        T cost = tsqrt(racc < T(0) ? T(0) : racc);
+        const bool my_bad = (bad_any >> i) & 1u;
+        const bool my_crash = (crash_any >> i) & 1u;
+        const int t_i = tcount - (slot - i);                 // time counter after the step this lane finishes
+        T cost = tsqrt(racc);
         T reward = tmax(s.max_cost - cost, T(0)) / (s.max_cost + T(1.1920928955078125e-07));   // rewards.py:59
-        reward = racc < T(0) ? T(0) : reward;                                                   // rewards.py:46
+        reward = my_bad ? T(0) : reward;                                                        // rewards.py:46
         const size_t o = size_t(step - slot + i) * s.R + rr;
         rew[o] = float(reward);
-        done[o] = uint8_t(dacc);                                                                // envs/base.py:398-400
+        done[o] = uint8_t((t_i >= s.step_limit) || my_crash);                                   // envs/base.py:398-400
       }
     }
   }
@@ -936,7 +970,6 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
   for (int step = 0; step < num_steps; ++step) {
     const float* act = actions ? actions + size_t(step) * act_stride + size_t(rr) * act_w : nullptr;
     bool crashed = false;
-    int lc_count_quirk = 0;
     for (int sub = 0; sub < s.sims_per_step; ++sub) {
       const bool live = live_replica && !crashed;
       // ---- controllers on the snapshot (S1) -------------------------------
@@ -1074,7 +1107,6 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
       rrow += step_rows;
       drow += step_rows;
     }
-    (void)lc_count_quirk;
   }
 
   if (num_steps == 0) {

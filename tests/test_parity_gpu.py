@@ -313,6 +313,41 @@ def test_dense_ring_stop_and_go_through_denormal_speeds_bit_exact():
     sim.close()
 
 
+@pytest.mark.parametrize("N,K", [(5, 19), (14, 50), (22, 77), (40, 70), (64, 45)])
+def test_rollout_kernel_all_segment_widths_vs_oracle(N, K):
+    """k_rollout_idm for every segment width (8..64 lanes), launch lengths that are not multiples of the
+    flush period, and a replica that crashes mid-launch (reward 0, done flag) -- against the oracle."""
+    import torch
+    R = 9
+    L = max(120.0, 7.5 * N)
+    spec = perturbed(ring_spec(R=R, N=N, length=L, bunching=0, junction_length=0.1, horizon=K - 7), seed=40 + N, sigma=0.2)
+    spec["crash_gap"] = 1.95            # IDM closes to s0 = 2 m: some replicas "crash" under this rule
+    rng = np.random.default_rng(N)
+    spec["init_vel"] = rng.uniform(0.0, 6.0, (R, N))
+    sim = make(spec, "f32")
+    sim.reset()
+    dev = torch.device("cuda:0")
+    obs = torch.empty((K, R, 2 * N), dtype=torch.float32, device=dev)
+    rew = torch.empty((K, R), dtype=torch.float32, device=dev)
+    done = torch.empty((K, R), dtype=torch.uint8, device=dev)
+    sim.rollout_dev(K, obs, rew, done, obs_every_step=True)
+    sim.sync()
+    ora = S.RingOracle(spec, np.float32)
+    ora.reset()
+    any_crash = False
+    for k in range(K):
+        o, r, d = ora.step(None)
+        np.testing.assert_array_equal(obs[k].cpu().numpy(), o.astype(np.float32))
+        np.testing.assert_array_equal(rew[k].cpu().numpy(), r.astype(np.float32))
+        np.testing.assert_array_equal(done[k].cpu().numpy().astype(bool), d)
+        any_crash |= bool((d & (ora.time_counter < K - 7)).any())
+    np.testing.assert_array_equal(sim.pos, ora.x)
+    np.testing.assert_array_equal(sim.time_counter, ora.time_counter)
+    if N >= 22:
+        assert any_crash, "the scenario must exercise the crash flag path"
+    sim.close()
+
+
 def test_specialised_kernel_equals_generic_kernel(monkeypatch):
     """k_steps<T,SEG,FAST=1> (picked for all-IDM AccelEnv rings) must be bit-identical to the generic path."""
     import torch
