@@ -142,6 +142,12 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline / step_api / f64 legs")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON); native libraries print banners there (RCCL's
+    # version block), so file descriptor 1 points at stderr until the result is written
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -154,8 +160,12 @@ def main():
     torch.cuda.set_device(device)
     # every launch of this process (simulator, events, collectives) goes to one explicit stream
     torch.cuda.set_stream(torch.cuda.Stream(device))
-    if world > 1:
+    # BENCH_FORCE_DIST=1 takes the N > 1 code path (RCCL init, per-fragment all-gather, MAX over ranks)
+    # even with one rank, so the distributed plumbing can be exercised on a one-GPU box
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
@@ -165,7 +175,7 @@ def main():
     runner = Runner(spec, args.precision, device, args.fragment)
 
     gather = None
-    if world > 1:
+    if use_dist:
         from flow_amd.dist import ObservationGather
         gather = ObservationGather(R, runner.obs_dim, world, device)
 
@@ -175,7 +185,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -185,7 +195,7 @@ def main():
     runner.run(args.steps, record=True, after_fragment=after_fragment)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -262,10 +272,11 @@ def main():
         out["cpu_baseline"] = cpu_baseline(lambda r: c2_spec(r, seed=1000))
 
     runner.sim.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":
