@@ -11,7 +11,7 @@ from .utils.exceptions import FatalFlowError
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libflowsim.so")
 
-FS_ABI_VERSION = 2
+FS_ABI_VERSION = 3
 FS_MAX_CTRL_PARAMS = 8
 
 # error codes
@@ -27,7 +27,8 @@ FS_FAILSAFE_NONE, FS_FAILSAFE_INSTANTANEOUS, FS_FAILSAFE_SAFE_VELOCITY = range(3
 # enum fs_env
 FS_ENV_ACCEL, FS_ENV_WAVE_ATTENUATION, FS_ENV_WAVE_ATTENUATION_PO, FS_ENV_LANE_CHANGE_ACCEL = range(4)
 # enum fs_network / fs_integrator
-FS_NET_RING = 0
+FS_NET_RING, FS_NET_FIGURE_EIGHT = 0, 1
+FS_MAX_SEGMENTS = 16
 FS_EULER, FS_BALLISTIC = 0, 1
 # enum fs_field
 (FS_FIELD_POS, FS_FIELD_VEL, FS_FIELD_HEADWAY, FS_FIELD_PREV_VEL, FS_FIELD_ACCEL, FS_FIELD_TIME,
@@ -47,6 +48,17 @@ class fs_vehicle_spec(C.Structure):
                 ("sumo_max_speed", C.c_double), ("initial_speed", C.c_double)]
 
 
+class fs_segment(C.Structure):
+    _fields_ = [("start", C.c_double), ("flow_start", C.c_double), ("flow_slope", C.c_double),
+                ("internal", C.c_int32), ("reserved", C.c_int32)]
+
+
+class fs_junction(C.Structure):
+    _fields_ = [("enabled", C.c_int32), ("reserved", C.c_int32), ("a_in", C.c_double), ("a_out", C.c_double),
+                ("b_in", C.c_double), ("b_out", C.c_double), ("lookahead", C.c_double), ("time_gap", C.c_double),
+                ("za_lo", C.c_double), ("za_hi", C.c_double), ("zb_lo", C.c_double), ("zb_hi", C.c_double)]
+
+
 class fs_config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("abi_version", C.c_uint32), ("precision", C.c_int32),
                 ("network", C.c_int32), ("env", C.c_int32), ("integrator", C.c_int32),
@@ -61,7 +73,9 @@ class fs_config(C.Structure):
                 ("po_max_length", C.c_double), ("lane_change_duration", C.c_double),
                 ("vehicles", C.POINTER(fs_vehicle_spec)),
                 ("ring_length", C.POINTER(C.c_double)), ("init_pos", C.POINTER(C.c_double)),
-                ("init_vel", C.POINTER(C.c_double)), ("init_lane", C.POINTER(C.c_int32))]
+                ("init_vel", C.POINTER(C.c_double)), ("init_lane", C.POINTER(C.c_int32)),
+                ("segments", C.POINTER(fs_segment)), ("num_segments", C.c_int32), ("reserved2", C.c_int32),
+                ("junction", fs_junction)]
 
 
 _lib = None

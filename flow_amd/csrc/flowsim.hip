@@ -38,6 +38,7 @@ struct SimBase {
   virtual ~SimBase() {}
   fs_config cfg{};
   std::vector<fs_vehicle_spec> veh;
+  std::vector<fs_segment> segs;
   int obs_dim = 0;
   int act_dim = 0;
   int seg = 0;
@@ -191,6 +192,26 @@ struct Sim : SimBase {
     dv.lane_change_mode = cfg.lane_change_mode;
     dv.last_lc_quirk = cfg.last_lc_quirk;
     dv.lc_duration = T(cfg.lane_change_duration);
+    dv.nseg = cfg.num_segments;
+    dv.seg_internal = 0u;
+    for (int k = 0; k < FS_MAX_SEGMENTS; ++k) {
+      const bool in = k < cfg.num_segments;
+      dv.seg_start[k] = in ? T(segs[k].start) : T(0);
+      dv.seg_flow_start[k] = in ? T(segs[k].flow_start) : T(0);
+      dv.seg_flow_slope[k] = in ? T(segs[k].flow_slope) : T(0);
+      if (in && segs[k].internal) dv.seg_internal |= (1u << k);
+    }
+    dv.junction_on = cfg.junction.enabled;
+    dv.ja_in = T(cfg.junction.a_in);
+    dv.ja_out = T(cfg.junction.a_out);
+    dv.jb_in = T(cfg.junction.b_in);
+    dv.jb_out = T(cfg.junction.b_out);
+    dv.j_lookahead = T(cfg.junction.lookahead);
+    dv.j_time_gap = T(cfg.junction.time_gap);
+    dv.za_lo = T(cfg.junction.za_lo);
+    dv.za_hi = T(cfg.junction.za_hi);
+    dv.zb_lo = T(cfg.junction.zb_lo);
+    dv.zb_hi = T(cfg.junction.zb_hi);
     if (cfg.horizon < 0) {
       dv.step_limit = INT_MAX;
     } else {
@@ -274,7 +295,8 @@ struct Sim : SimBase {
     const int f = dv.flags;
     return (f & fs::FLAG_ALL_IDM) && !(f & (fs::FLAG_HAS_NOISE | fs::FLAG_HAS_FAILSAFE | fs::FLAG_NEED_SUMO)) &&
            dv.env == FS_ENV_ACCEL && !dv.evaluate && dv.sims_per_step == 1 && dv.integrator == FS_EULER &&
-           !dv.junction_mode && !dv.track_aux && mask == nullptr && num_steps > 0 && !force_generic;
+           !dv.junction_mode && !dv.track_aux && mask == nullptr && num_steps > 0 && !force_generic &&
+           dv.nseg == 0 && !dv.junction_on;
   }
 
   template <int SEG>
@@ -435,7 +457,19 @@ int validate(const fs_config* c) {
     return fail(FS_ERR_INVALID, "fs_create: struct_size mismatch (header/library out of sync)");
   if (c->abi_version != FS_ABI_VERSION) return fail(FS_ERR_INVALID, "fs_create: abi_version mismatch");
   if (c->precision != FS_F32 && c->precision != FS_F64) return fail(FS_ERR_INVALID, "fs_create: bad precision");
-  if (c->network != FS_NET_RING) return fail(FS_ERR_UNSUPPORTED, "fs_create: only FS_NET_RING is built");
+  if (c->network != FS_NET_RING && c->network != FS_NET_FIGURE_EIGHT)
+    return fail(FS_ERR_UNSUPPORTED, "fs_create: network not built");
+  if (c->network == FS_NET_RING && (c->num_segments != 0 || c->junction.enabled))
+    return fail(FS_ERR_INVALID, "fs_create: a ring takes no segment table / junction");
+  if (c->network == FS_NET_FIGURE_EIGHT) {
+    if (c->num_segments < 1 || c->num_segments > FS_MAX_SEGMENTS || !c->segments)
+      return fail(FS_ERR_INVALID, "fs_create: figure eight needs 1..FS_MAX_SEGMENTS segments");
+    if (c->num_lanes > 1) return fail(FS_ERR_UNSUPPORTED, "fs_create: multi-lane figure eight is not built");
+    if (c->segments[0].start != 0.0) return fail(FS_ERR_INVALID, "fs_create: segment 0 must start at 0");
+    for (int k = 1; k < c->num_segments; ++k)
+      if (!(c->segments[k].start > c->segments[k - 1].start))
+        return fail(FS_ERR_INVALID, "fs_create: segment starts must increase");
+  }
   if (c->env < FS_ENV_ACCEL || c->env > FS_ENV_LANE_CHANGE_ACCEL) return fail(FS_ERR_INVALID, "fs_create: bad env");
   if (c->num_lanes > 1 && c->env == FS_ENV_WAVE_ATTENUATION_PO)
     return fail(FS_ERR_UNSUPPORTED, "fs_create: WaveAttenuationPOEnv on a multi-lane ring is not built");
@@ -492,6 +526,7 @@ int create_typed(const fs_config* cfg, fs_handle* out) {
   if (!s) return fail(FS_ERR_HIP, "fs_create: out of host memory");
   s->cfg = *cfg;
   s->veh.assign(cfg->vehicles, cfg->vehicles + cfg->num_vehicles);
+  if (cfg->num_segments > 0) s->segs.assign(cfg->segments, cfg->segments + cfg->num_segments);
   s->obs_dim = (cfg->env == FS_ENV_WAVE_ATTENUATION_PO) ? 3
                : (cfg->env == FS_ENV_LANE_CHANGE_ACCEL ? 3 : 2) * cfg->num_vehicles;
   s->act_dim = cfg->num_rl * (cfg->env == FS_ENV_LANE_CHANGE_ACCEL ? 2 : 1);
@@ -528,6 +563,7 @@ int create_typed(const fs_config* cfg, fs_handle* out) {
   s->cfg.init_pos = nullptr;
   s->cfg.init_vel = nullptr;
   s->cfg.init_lane = nullptr;
+  s->cfg.segments = nullptr;
   *out = reinterpret_cast<fs_handle>(static_cast<SimBase*>(s));
   return FS_OK;
 }

@@ -74,6 +74,11 @@ struct DevView {
   uint32_t seed_lo, seed_hi;
   T dt, ramp, jlen, crash_gap, max_speed, target_velocity, max_cost, act_lo, act_hi, po_max_length;
   T lc_duration;
+  // non-ring closed loops (figure eight): edge table in route order + the crossing model (S-J)
+  int nseg, junction_on;
+  unsigned seg_internal;                 // bit k: segment k is a junction-internal edge
+  T seg_start[FS_MAX_SEGMENTS], seg_flow_start[FS_MAX_SEGMENTS], seg_flow_slope[FS_MAX_SEGMENTS];
+  T ja_in, ja_out, jb_in, jb_out, j_lookahead, j_time_gap, za_lo, za_hi, zb_lo, zb_hi;
 };
 
 // ---------------------------------------------------------------------------
@@ -438,6 +443,23 @@ __device__ __forceinline__ T sumo_idm_speed(T v, T vl, T h, bool has, T dt, cons
   return tmax(T(0), v + acc * dt);
 }
 
+// segment of loop coordinate x (the last one whose start is <= x): is it internal, and Flow's table
+// coordinate of x (oracle/refsim.py _segment_lookup)
+template <typename T>
+__device__ __forceinline__ void segment_lookup(const DevView<T>& s, T x, bool& internal, T& flow_x) {
+  int k = 0;
+  for (int q = 1; q < s.nseg; ++q) k = (x >= s.seg_start[q]) ? q : k;
+  T st = s.seg_start[0], fs0 = s.seg_flow_start[0], sl = s.seg_flow_slope[0];
+  for (int q = 1; q < s.nseg; ++q) {
+    const bool hit = (q == k);
+    st = hit ? s.seg_start[q] : st;
+    fs0 = hit ? s.seg_flow_start[q] : fs0;
+    sl = hit ? s.seg_flow_slope[q] : sl;
+  }
+  internal = (s.seg_internal >> k) & 1u;
+  flow_x = fs0 + sl * (x - st);
+}
+
 // ---------------------------------------------------------------------------
 // BaseController.get_action for one vehicle (base_controller.py:70-118) + the RL command
 // (envs/base.py:599-615): shared by the single-lane and the multi-lane step kernels.
@@ -461,8 +483,15 @@ __device__ __forceinline__ T control_accel(const DevView<T>& s, const Slot<T>& s
     T a;
     bool on_edge = true;
     if (s.junction_mode) {                       // base_controller.py:98-99
-      T u = x - tfloor(x / qj) * qj;
-      on_edge = !(u >= quarter);
+      if (s.nseg > 0) {
+        bool internal;
+        T fx;
+        segment_lookup(s, x, internal, fx);
+        on_edge = !internal;
+      } else {
+        T u = x - tfloor(x / qj) * qj;
+        on_edge = !(u >= quarter);
+      }
     }
     switch (ct) {
       case FS_CTRL_PISATURATION: {
@@ -610,6 +639,18 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
         if (sl.speed_mode & 4) vc = tmax(vc, v - sl.max_decel * dt);
         v_new = commanded ? vc : v_sumo;
       }
+      if (!FAST && s.junction_on) {                   // S-J: right of way at the crossing
+        // stream a blocks the box while one of its vehicles is inside, has not cleared it with its tail,
+        // or reaches it within time_gap; stream a yields only to a vehicle of stream b inside the box
+        const bool major_busy = seg_any<SEG>(valid && (x >= s.ja_in - s.j_time_gap * v) && (x < s.ja_out + sl.length), seg);
+        const bool minor_in_box = seg_any<SEG>(valid && (x >= s.jb_in) && (x < s.jb_out + sl.length), seg);
+        T cap = T(3.0e38);
+        if ((x >= s.jb_in - s.j_lookahead) && (x < s.jb_in) && major_busy)
+          cap = tmin(cap, sumo_idm_speed(v, T(0), s.jb_in - x, true, dt, sl));
+        if ((x >= s.ja_in - s.j_lookahead) && (x < s.ja_in) && minor_in_box)
+          cap = tmin(cap, sumo_idm_speed(v, T(0), s.ja_in - x, true, dt, sl));
+        if ((sl.speed_mode & 1) || !commanded) v_new = tmin(v_new, cap);
+      }
       T x_new = (!FAST && s.integrator == FS_BALLISTIC) ? x + (v + v_new) / T(2) * dt : x + v_new * dt;
       x_new = x_new >= L ? x_new - L : x_new;
       if (FAST) {
@@ -631,7 +672,10 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
       d = d < T(0) ? d + L : d;
       h = has ? d - len_lead : T(1000);
       // ---- check_collision (S12) ----------------------------------------
-      const bool c = has && seg_any<SEG>(valid && (h < s.crash_gap), seg);
+      bool c = has && seg_any<SEG>(valid && (h < s.crash_gap), seg);
+      if (!FAST && s.junction_on)                     // S-J: both streams on the crossing point at once
+        c = c || (seg_any<SEG>(valid && (x >= s.za_lo) && (x < s.za_hi), seg) &&
+                  seg_any<SEG>(valid && (x >= s.zb_lo) && (x < s.zb_hi), seg));
       crashed = crashed || (c && live);
     }
 
@@ -646,8 +690,13 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
           orow[2] = float(d / s.po_max_length);
         }
       } else if (valid) {
+        T xo = x;
+        if (!FAST && s.nseg > 0) {
+          bool internal;
+          segment_lookup(s, x, internal, xo);
+        }
         orow[ii] = float(v / s.max_speed);               // accel.py:118-119
-        orow[N + ii] = float(x / L);                     // accel.py:120-121
+        orow[N + ii] = float(xo / L);                    // accel.py:120-121
       }
       // reward
       T reward;
@@ -696,8 +745,13 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
         orow[2] = float(d / s.po_max_length);
       }
     } else if (valid) {
+      T xo = x;
+      if (!FAST && s.nseg > 0) {
+        bool internal;
+        segment_lookup(s, x, internal, xo);
+      }
       orow[ii] = float(v / s.max_speed);
-      orow[N + ii] = float(x / L);
+      orow[N + ii] = float(xo / L);
     }
     return;
   }

@@ -38,7 +38,8 @@ class FlowSim:
     integrator, junction_mode, junction_length, crash_gap, max_speed, env,
     target_velocity, action_low, action_high, clip_actions, evaluate,
     po_max_length, horizon, warmup_steps, sims_per_step, seed, track_aux, num_lanes, init_lane [R,N],
-    lane_change_duration, lane_change_mode, last_lc_quirk.
+    lane_change_duration, lane_change_mode, last_lc_quirk, segments [(start, internal, flow_start,
+    flow_slope)], junction {a_in, a_out, b_in, b_out, lookahead, time_gap, za_lo, za_hi, zb_lo, zb_hi}.
     """
 
     def __init__(self, spec, precision="f32", device=0):
@@ -78,11 +79,24 @@ class FlowSim:
         init_lane = spec.get("init_lane")
         if init_lane is not None:
             init_lane = np.ascontiguousarray(np.asarray(init_lane, dtype=np.int32).reshape(self.R, self.N))
+        segs = spec.get("segments")
+        seg_arr = None
+        if segs:
+            seg_arr = (L.fs_segment * len(segs))()
+            for k, (st, inter, fs0, slope) in enumerate(segs):
+                seg_arr[k].start, seg_arr[k].internal = float(st), int(bool(inter))
+                seg_arr[k].flow_start, seg_arr[k].flow_slope = float(fs0), float(slope)
+        junc = L.fs_junction()
+        J = spec.get("junction")
+        if J:
+            junc.enabled = 1
+            for k in ("a_in", "a_out", "b_in", "b_out", "lookahead", "time_gap", "za_lo", "za_hi", "zb_lo", "zb_hi"):
+                setattr(junc, k, float(J[k]))
         horizon = spec.get("horizon", float("inf"))
         dp = C.POINTER(C.c_double)
         cfg = L.fs_config(
             struct_size=C.sizeof(L.fs_config), abi_version=L.FS_ABI_VERSION, precision=self.precision,
-            network=L.FS_NET_RING, env=int(spec.get("env", L.FS_ENV_ACCEL)),
+            network=L.FS_NET_FIGURE_EIGHT if segs else L.FS_NET_RING, env=int(spec.get("env", L.FS_ENV_ACCEL)),
             integrator=INTEGRATORS[spec.get("integrator", "euler")],
             num_replicas=self.R, num_vehicles=self.N, num_rl=self.num_rl,
             horizon=-1 if horizon == float("inf") else int(horizon),
@@ -101,7 +115,8 @@ class FlowSim:
             lane_change_duration=float(spec.get("lane_change_duration", 0.0)),
             vehicles=veh, ring_length=ring_length.ctypes.data_as(dp), init_pos=init_pos.ctypes.data_as(dp),
             init_vel=init_vel.ctypes.data_as(dp) if init_vel is not None else None,
-            init_lane=init_lane.ctypes.data_as(C.POINTER(C.c_int32)) if init_lane is not None else None)
+            init_lane=init_lane.ctypes.data_as(C.POINTER(C.c_int32)) if init_lane is not None else None,
+            segments=seg_arr, num_segments=len(segs) if segs else 0, reserved2=0, junction=junc)
         L.check(self.lib.fs_create(C.byref(cfg), C.byref(self._h)))
         self.obs_dim = self.lib.fs_obs_dim(self._h)
         self.act_dim = self.lib.fs_action_dim(self._h)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FS_ABI_VERSION 2
+#define FS_ABI_VERSION 3
 
 /* ---- error codes -------------------------------------------------------- */
 #define FS_OK 0
@@ -70,7 +70,11 @@ enum fs_env {
                                        actions are [acc_0, dir_0, acc_1, dir_1, ...] (2 per RL vehicle) */
 };
 
-enum fs_network { FS_NET_RING = 0 /* RingNetwork, flow/networks/ring.py (any number of lanes) */ };
+enum fs_network {
+  FS_NET_RING = 0,          /* RingNetwork, flow/networks/ring.py (any number of lanes) */
+  FS_NET_FIGURE_EIGHT = 1   /* FigureEightNetwork, flow/networks/figure_eight.py: a closed one-lane loop that
+                               crosses itself; described by fs_config.segments + fs_config.junction */
+};
 
 enum fs_integrator { FS_EULER = 0, FS_BALLISTIC = 1 /* SumoParams.use_ballistic, core/params.py:578-602 */ };
 
@@ -95,6 +99,32 @@ enum fs_field {
 };
 
 #define FS_MAX_CTRL_PARAMS 8
+#define FS_MAX_SEGMENTS 16
+
+/* One edge of a closed loop in route order (non-ring networks).  `start` is the loop coordinate of the
+ * edge's first metre; Flow's own coordinate of a point `x` on it (get_x_by_id, vehicle/traci.py:1011-1017
+ * with the network's edge-start table) is flow_start + flow_slope * (x - start); internal edges without
+ * a table entry have slope 0 (network/traci.py:280-287). */
+typedef struct fs_segment {
+  double start;
+  double flow_start;
+  double flow_slope;
+  int32_t internal;                   /* 1: junction-internal edge (':...'): no Flow command with junction_mode */
+  int32_t reserved;
+} fs_segment;
+
+/* The self-crossing of the figure eight (SUMO's junction logic restated, unpinned).
+ * Stream a (bottom->top, priority 78) crosses stream b (right->left, priority 46),
+ * flow/networks/figure_eight.py:126-154. */
+typedef struct fs_junction {
+  int32_t enabled;
+  int32_t reserved;
+  double a_in, a_out;                 /* loop coordinates of the internal edge of stream a */
+  double b_in, b_out;                 /* ... of stream b */
+  double lookahead;                   /* a vehicle this close to its entry line may have to yield */
+  double time_gap;                    /* stream a blocks the box when it reaches a_in within time_gap */
+  double za_lo, za_hi, zb_lo, zb_hi;  /* front positions at which a body covers the crossing point */
+} fs_junction;
 
 /* One vehicle slot; identical for every replica (VehicleParams.add,
  * flow/core/params.py:236-351, expanded per vehicle). */
@@ -152,6 +182,10 @@ typedef struct fs_config {
   const double* init_pos;             /* [R,N] initial absolute positions */
   const double* init_vel;             /* [R,N] initial speeds, or NULL -> vehicles[i].initial_speed */
   const int32_t* init_lane;           /* [R,N] initial lanes, or NULL -> lane 0 */
+  const fs_segment* segments;         /* [num_segments] edge table of a non-ring loop, or NULL */
+  int32_t num_segments;               /* 0 for FS_NET_RING */
+  int32_t reserved2;
+  fs_junction junction;               /* crossing model, enabled only for FS_NET_FIGURE_EIGHT */
 } fs_config;
 
 typedef struct fs_sim* fs_handle;

@@ -132,6 +132,10 @@ class RingOracle:
         self.L = self.base_len + T(4) * T(self.jlen)                 # network.length(), in T like the kernel
         self.veh = spec["vehicles"]
         self.veh_len = np.array([v.get("length", 5.0) for v in self.veh], dtype=self.dt_)
+        # closed loops other than the plain ring (figure eight): an ordered segment table
+        # [(phys_start, internal, flow_start, flow_slope)] + the crossing model
+        self.segments = spec.get("segments")
+        self.junction = spec.get("junction")
         self.rl_slots = [None] * int(spec.get("num_rl", 0))
         for i, v in enumerate(self.veh):
             if v["controller"] == CTRL_RL:
@@ -170,11 +174,73 @@ class RingOracle:
     def in_junction(self, x):
         """True where the front of the vehicle is on an internal edge
         (networks/ring.py:211-214 tables; base_controller.py:98-99)."""
+        if self.segments is not None:
+            return self._segment_lookup(x)[0]
         base = self.base_len if np.ndim(x) == 1 else self.base_len[:, None]
         quarter = base / self.dt_.type(4)
         q = quarter + self.dt_.type(self.jlen)
         u = x - np.floor(x / q) * q
         return u >= quarter
+
+    def _segment_lookup(self, x):
+        """(internal?, table coordinate) of loop coordinate x: the segment is the last one whose start
+        is <= x; table coordinate = flow_start + flow_slope * (x - start)  (get_x_by_id,
+        vehicle/traci.py:1011-1017 with the network's edge-start table)."""
+        T = self.dt_.type
+        internal = np.zeros(np.shape(x), dtype=bool)
+        start = np.zeros(np.shape(x), dtype=self.dt_)
+        fstart = np.zeros(np.shape(x), dtype=self.dt_)
+        slope = np.zeros(np.shape(x), dtype=self.dt_)
+        for (st, inter, fs, sl) in self.segments:
+            hit = x >= T(st)
+            internal = np.where(hit, bool(inter), internal)
+            start = np.where(hit, T(st), start)
+            fstart = np.where(hit, T(fs), fstart)
+            slope = np.where(hit, T(sl), slope)
+        return internal, fstart + slope * (x - start)
+
+    def obs_position(self, x):
+        return x if self.segments is None else self._segment_lookup(x)[1]
+
+    def _yield_speed_cap(self, v):
+        """S-J: speed a yielding vehicle may not exceed (SUMO's right-of-way restated): a vehicle on the
+        approach of its stream stops at the box entry like behind a standing leader while the other
+        stream blocks the box; inf elsewhere.  Returns [R,N]."""
+        T = self.dt_.type
+        J = self.junction
+        x = self.x
+        inf = np.full(x.shape, T(3.0e38))
+        if J is None:
+            return inf
+        a_in, a_out, b_in, b_out = T(J["a_in"]), T(J["a_out"]), T(J["b_in"]), T(J["b_out"])
+        D, Tg = T(J["lookahead"]), T(J["time_gap"])
+        ln = self.veh_len[None, :]
+        # the major stream (a) blocks the box while a vehicle is inside it, has not cleared it with its
+        # tail, or reaches it within time_gap at its current speed
+        major_busy = np.any((x >= a_in - Tg * v) & (x < a_out + ln), axis=1)[:, None]
+        minor_in_box = np.any((x >= b_in) & (x < b_out + ln), axis=1)[:, None]
+        cap = inf
+        for (entry, blocked) in ((b_in, major_busy), (a_in, minor_in_box)):
+            approaching = (x >= entry - D) & (x < entry) & blocked
+            gap = entry - x
+            stop = np.stack([C.sumo_idm_speed(v[:, i], np.zeros(self.R, self.dt_), gap[:, i], np.ones(self.R, bool),
+                                              self.dt, accel=vs["max_accel"], decel=vs["max_decel"],
+                                              tau=vs.get("sumo_tau", 1.0), min_gap=vs.get("sumo_min_gap", 2.5),
+                                              max_speed=vs.get("sumo_max_speed", 30.0))
+                             for i, vs in enumerate(self.veh)], axis=1)
+            cap = np.where(approaching, np.minimum(cap, stop), cap)
+        return cap
+
+    def _crossing_crash(self):
+        """S-J: both streams inside the conflict zone of the crossing at once = collision."""
+        J = self.junction
+        if J is None:
+            return np.zeros(self.R, dtype=bool)
+        T = self.dt_.type
+        x = self.x
+        in_a = np.any((x >= T(J["za_lo"])) & (x < T(J["za_hi"])), axis=1)
+        in_b = np.any((x >= T(J["zb_lo"])) & (x < T(J["zb_hi"])), axis=1)
+        return in_a & in_b
 
     # ------------------------------------------------------------------ reset
     def reset(self, mask=None):
@@ -293,6 +359,12 @@ class RingOracle:
             if mode & 4:                                             # bit2: regard max decel
                 vc = np.maximum(vc, v[sl] - T(vs["max_decel"]) * dt)
             v_new[sl] = np.where(commanded[sl], vc, v_sumo)
+        if self.junction is not None:                                # S-J right of way at the crossing
+            cap = self._yield_speed_cap(v)
+            for i, vs in enumerate(self.veh):
+                obeys = (int(vs.get("speed_mode", 0)) & 1) != 0
+                sl = (slice(None), i)
+                v_new[sl] = np.where(obeys | ~commanded[sl], np.minimum(v_new[sl], cap[sl]), v_new[sl])
         if self.ballistic:
             x_new = self.x + (v + v_new) / T(2) * dt
         else:
@@ -308,6 +380,7 @@ class RingOracle:
         self.step_counter = self.step_counter + active
         h_new = self.headways()
         crash = np.any(h_new < self.crash_gap, axis=1) if self.N > 1 else np.zeros(self.R, bool)
+        crash = crash | self._crossing_crash()
         return crash & active
 
     def step(self, actions=None, _mask=None):
@@ -332,7 +405,7 @@ class RingOracle:
         if env in (ENV_ACCEL, ENV_WAVE_ATTENUATION):
             # accel.py:116-123 / wave_attenuation.py:141-148
             speed = self.v / T(self.spec["max_speed"])
-            pos = self.x / self.L[:, None]
+            pos = self.obs_position(self.x) / self.L[:, None]
             return np.concatenate([speed, pos], axis=1)
         if env == ENV_WAVE_ATTENUATION_PO:                           # wave_attenuation.py:248-269
             i = self.rl_slots[0]

@@ -35,14 +35,15 @@ def test_library_exports_every_declared_symbol(lib):
     for name in declared_symbols():
         assert hasattr(lib, name), name
     from flow_amd import _lib
-    assert lib.fs_abi_version() == _lib.FS_ABI_VERSION == 2
+    assert lib.fs_abi_version() == _lib.FS_ABI_VERSION == 3
 
 
 def test_ctypes_layout_matches_the_c_header(tmp_path):
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "flowsim.h"\n'
-                   'int main(void){printf("%zu %zu %zu %zu %zu\\n", sizeof(fs_config), sizeof(fs_vehicle_spec),'
-                   ' offsetof(fs_config, seed), offsetof(fs_config, vehicles), offsetof(fs_vehicle_spec, noise));'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(fs_config), sizeof(fs_vehicle_spec),'
+                   ' offsetof(fs_config, seed), offsetof(fs_config, vehicles), offsetof(fs_vehicle_spec, noise),'
+                   ' offsetof(fs_config, junction), sizeof(fs_segment));'
                    'return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
@@ -53,6 +54,7 @@ def test_ctypes_layout_matches_the_c_header(tmp_path):
     assert int(out[2]) == _lib.fs_config.seed.offset
     assert int(out[3]) == _lib.fs_config.vehicles.offset
     assert int(out[4]) == _lib.fs_vehicle_spec.noise.offset
+    assert int(out[5]) == _lib.fs_config.junction.offset and int(out[6]) == ctypes.sizeof(_lib.fs_segment)
 
 
 def test_enums_agree_between_header_binding_and_oracle():

@@ -12,7 +12,7 @@ Bars (DESIGN.md "Parity"):
 import numpy as np
 import pytest
 
-from helpers import idm_vehicle, multilane_spec, ring_spec
+from helpers import figure_eight_spec, idm_vehicle, multilane_spec, ring_spec
 from oracle import refsim as S
 
 pytestmark = pytest.mark.gpu
@@ -438,6 +438,42 @@ def test_multilane_mixed_controllers_and_single_vehicle_lanes():
     spec["vehicles"][1] = idm_vehicle(controller=S.CTRL_BCM, p=[1, 1, 1, 1, 8, 0, 0, 0], max_accel=15)
     spec["vehicles"][3] = idm_vehicle(fail_safe=S.FAILSAFE_SAFE_VELOCITY, delay=0.5)
     run_pair_ml(spec, "f32", 40)
+
+
+def test_figure_eight_crossing_yield_and_table_coordinates_bit_exact():
+    """FigureEightNetwork (BASELINE configs[2] geometry): 14 IDM vehicles with speed_mode obey_safe_speed,
+    no Flow command on internal edges (junction_mode), right of way at the crossing (S-J), observation in
+    Flow's edge-start-table coordinates.  400 steps bit-exact in f32, 1e-9 in f64."""
+    spec = figure_eight_spec(R=7, N=14, horizon=500, seed=2)
+    ora = run_pair(spec, "f32", 400, check_every=20)
+    assert ora.v.max() > 3.0 and (ora.headways() > 0).all()
+    run_pair(figure_eight_spec(R=3, N=14, horizon=300, seed=3), "f64", 300, check_every=25, exact=False, atol=1e-9)
+
+
+def test_figure_eight_with_rl_vehicle_noise_and_crossing_crash():
+    """C3: 13 noisy IDM + 1 RL vehicle; an RL vehicle in 'aggressive' speed mode ignores the right of way,
+    so with hostile actions the crossing rule must flag a crash (done, reward 0) exactly as the oracle does."""
+    R, N, K = 8, 14, 260
+    spec = figure_eight_spec(R=R, N=N, horizon=K, seed=5, num_rl=1)
+    veh = [idm_vehicle(speed_mode=1, max_decel=1.5, noise=0.2) for _ in range(N - 1)]
+    veh.append(idm_vehicle(controller=S.CTRL_RL, rl_index=0, speed_mode=0))
+    spec["vehicles"] = veh
+    spec["seed"] = 77
+    rng = np.random.default_rng(9)
+    actions = rng.uniform(0.5, 3.0, (K, R, 1)).astype(np.float32)
+    ora = S.RingOracle(spec, np.float64)
+    sim = make(spec, "f64")
+    np.testing.assert_allclose(sim.reset(), ora.reset().astype(np.float32), atol=1e-6)
+    crashed = np.zeros(R, dtype=bool)
+    for k in range(K):
+        o_ref, r_ref, d_ref = ora.step(actions[k])
+        o_gpu, r_gpu, d_gpu = sim.step(actions[k])
+        np.testing.assert_array_equal(d_gpu, d_ref)
+        np.testing.assert_allclose(sim.pos, ora.x, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(r_gpu, r_ref.astype(np.float32), atol=1e-6)
+        crashed |= d_ref & (ora.time_counter < K)
+    assert crashed.any(), "hostile RL actions must produce a crash somewhere"
+    sim.close()
 
 
 def test_abi_rejects_bad_configs():
