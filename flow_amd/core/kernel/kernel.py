@@ -17,7 +17,8 @@ class Kernel(object):
         self.detector = None
 
     def generate_network(self, network):
-        self.network = NetworkKernel(network, junction_length=getattr(self.sim_params, "junction_length", 0.1))
+        self.network = NetworkKernel(network, junction_length=getattr(self.sim_params, "junction_length", 0.1),
+                                     center_length=getattr(self.sim_params, "center_length", None))
         return self.network
 
     def pass_api(self, kernel_api):

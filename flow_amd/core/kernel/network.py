@@ -18,7 +18,7 @@ VEHICLE_LENGTH = 5          # flow/core/kernel/network/base.py:10
 class NetworkKernel(object):
     """Geometry of one network instance (flow/core/kernel/network/traci.py:90-228, 267-359)."""
 
-    def __init__(self, network, junction_length=0.1):
+    def __init__(self, network, junction_length=0.1, center_length=None):
         self.network = network
         self.orig_name = network.orig_name
         self.name = network.name
@@ -31,7 +31,7 @@ class NetworkKernel(object):
                                     "lanes": int(e.get("numLanes", t.get("numLanes", 1))),
                                     "speed": float(e.get("speed", t.get("speed", 30)))}
         first = next(iter(self._edges.values()))
-        for eid, length in network.specify_internal_edges(junction_length):
+        for eid, length in network.specify_internal_edges(junction_length, center_length):
             self._edges[eid] = {"length": float(length), "lanes": first["lanes"], "speed": first["speed"]}
         self._edge_list = [e for e in self._edges if e[0] != ':']
         self._junction_list = [e for e in self._edges if e[0] == ':']
@@ -46,6 +46,54 @@ class NetworkKernel(object):
         self.total_edgestarts = sorted(self.edgestarts + self.internal_edgestarts, key=lambda t: t[1])
         self.total_edgestarts_dict = dict(self.total_edgestarts)
         self.rts = network.routes
+        # loop coordinate (what the simulator integrates) when it is not the table coordinate
+        order = network.specify_loop_order()
+        self.loop_starts = None
+        if order is not None:
+            self.loop_starts, s0 = [], 0.0
+            for eid in order:
+                self.loop_starts.append((eid, s0))
+                s0 += self._edges[eid]['length']
+
+    def locate(self, s):
+        """(edge, position on it) of loop coordinate ``s``."""
+        if self.loop_starts is None:
+            return self.get_edge(s)
+        for (edge, start) in reversed(self.loop_starts):
+            if s >= start:
+                return edge, s - start
+
+    def loop_coordinate(self, edge, position):
+        if self.loop_starts is None:
+            return self.get_x(edge, position)
+        return dict(self.loop_starts)[edge] + position
+
+    def loop_segments(self):
+        """[(start, internal, flow_start, flow_slope)] for fs_config.segments (None for a plain ring)."""
+        if self.loop_starts is None:
+            return None
+        segs = []
+        for edge, start in self.loop_starts:
+            if edge[0] == ':' and edge not in self.internal_edgestarts_dict:
+                segs.append((start, True, float(self.get_x(edge, 0.0)), 0.0))        # traci.py:283-287
+            else:
+                segs.append((start, edge[0] == ':', float(self.get_x(edge, 0.0)), 1.0))
+        return segs
+
+    def crossing_model(self, vehicle_length=5.0, half_width=0.9, time_gap=3.0):
+        """fs_config.junction of a self-crossing loop, None otherwise."""
+        cr = self.network.specify_crossing()
+        if cr is None or self.loop_starts is None:
+            return None
+        starts = dict(self.loop_starts)
+        a, b = cr
+        a_in, b_in = starts[a], starts[b]
+        ca, cb = self._edges[a]['length'], self._edges[b]['length']
+        approach = [e for e, _ in self.loop_starts]
+        look = self._edges[approach[approach.index(b) - 1]]['length']
+        return dict(a_in=a_in, a_out=a_in + ca, b_in=b_in, b_out=b_in + cb, lookahead=look, time_gap=time_gap,
+                    za_lo=a_in + ca / 2 - half_width, za_hi=a_in + ca / 2 + vehicle_length + half_width,
+                    zb_lo=b_in + cb / 2 - half_width, zb_hi=b_in + cb / 2 + vehicle_length + half_width)
 
     # ---- static queries (traci.py:267-359)
     def get_edge(self, x):

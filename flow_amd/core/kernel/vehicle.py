@@ -145,11 +145,15 @@ class VehicleKernel(object):
         return self._vec(veh_id, lambda i: float(self._field(L.FS_FIELD_ACCEL)[i]), error)
 
     def get_x_by_id(self, veh_id):
-        """Absolute position along the loop (vehicle/traci.py:1011-1017)."""
-        return self._vec(veh_id, lambda i: float(self._field(L.FS_FIELD_POS)[i]), 0.)
+        """Flow's absolute position: edge start of the network's table + position on the edge
+        (vehicle/traci.py:1011-1017)."""
+        net = self.master_kernel.network
+        if net.loop_starts is None:
+            return self._vec(veh_id, lambda i: float(self._field(L.FS_FIELD_POS)[i]), 0.)
+        return self._vec(veh_id, lambda i: float(net.get_x(*self._edge_pos(i))), 0.)
 
     def _edge_pos(self, i):
-        return self.master_kernel.network.get_edge(float(self._field(L.FS_FIELD_POS)[i]))
+        return self.master_kernel.network.locate(float(self._field(L.FS_FIELD_POS)[i]))
 
     def get_edge(self, veh_id, error=""):
         return self._vec(veh_id, lambda i: self._edge_pos(i)[0], error)

@@ -165,7 +165,11 @@ class SumoParams(SimParams):
     """flow/core/params.py:510-617.  Extra, GPU-simulator-only keywords (all optional):
 
     slowdown_ramp   None -> dt/(dt+1e-3): the ramp of TraCI slowDown(v, 1e-3); 1.0 = exact
-    junction_mode   1 -> vehicles on internal edges get no Flow command (base_controller.py:98-99)
+    junction_mode   1 -> vehicles on internal edges get no Flow command (base_controller.py:98-99);
+                    None -> 0 on a ring (0.1 m junctions, treated as seamless), 1 on a figure eight
+    center_length   length of the ':center_*' internal edges of a figure eight (None -> 9.4, the
+                    netconvert value in the reference's fixture)
+    crossing_time_gap  right-of-way model of the figure-eight crossing
     junction_length length of each internal edge (netconvert output in the reference)
     crash_gap       a replica crashes when a bumper gap falls below this after a move
     precision       'f32' | 'f64' arithmetic and state type of the kernels
@@ -175,8 +179,8 @@ class SumoParams(SimParams):
                  render=False, save_render=False, sight_radius=25, show_radius=False, pxpm=2,
                  force_color_update=False, overtake_right=False, seed=None, restart_instance=False,
                  print_warnings=True, start_at_load=True, teleport_time=-1, num_clients=1, color_by_speed=False,
-                 use_ballistic=False, slowdown_ramp=None, junction_mode=0, junction_length=0.1, crash_gap=0.0,
-                 precision="f32"):
+                 use_ballistic=False, slowdown_ramp=None, junction_mode=None, junction_length=0.1, crash_gap=0.0,
+                 precision="f32", center_length=None, crossing_time_gap=3.0):
         super(SumoParams, self).__init__(sim_step, render, restart_instance, emission_path, save_render,
                                          sight_radius, show_radius, pxpm, force_color_update)
         self.port = port
@@ -195,6 +199,8 @@ class SumoParams(SimParams):
         self.junction_length = junction_length
         self.crash_gap = crash_gap
         self.precision = precision
+        self.center_length = center_length
+        self.crossing_time_gap = crossing_time_gap
 
 
 class EnvParams:

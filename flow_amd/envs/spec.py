@@ -4,6 +4,7 @@ import numpy as np
 
 from flow_amd import _lib as L
 from flow_amd.controllers import RLController
+from flow_amd.networks.figure_eight import FigureEightNetwork
 from flow_amd.networks.ring import RingNetwork
 from flow_amd.utils.exceptions import FatalFlowError
 
@@ -42,11 +43,11 @@ def initial_positions(network_kernel, initial_config, num_vehicles, num_replicas
         cfg = copy.copy(initial_config)
         cfg.perturbation = 0.0
     pos, lanes = network_kernel.generate_starting_positions(cfg, num_vehicles)
-    x = np.array([network_kernel.get_x(e, p) for e, p in pos], dtype=np.float64)
+    x = np.array([network_kernel.loop_coordinate(e, p) for e, p in pos], dtype=np.float64)
     X = np.tile(x, (num_replicas, 1))
     if pert > 0:
         rng = rng or np.random
-        start = np.array([network_kernel.get_x(e, 0) for e, _ in pos])
+        start = np.array([network_kernel.loop_coordinate(e, 0) for e, _ in pos])
         elen = np.array([network_kernel.edge_length(e) for e, _ in pos])
         rel = np.array([p for _, p in pos])
         rel = np.clip(rel[None, :] + rng.normal(0, pert, (num_replicas, num_vehicles)), 0, elen[None, :])
@@ -78,9 +79,12 @@ def build_spec(env, num_replicas, rng=None):
     """The spec of ``env`` (a flow_amd Env under construction) replicated ``num_replicas`` times."""
     network, net_k, veh_k = env.network, env.k.network, env.k.vehicle
     sp, ep = env.sim_params, env.env_params
-    if not isinstance(network, RingNetwork):
+    if not isinstance(network, (RingNetwork, FigureEightNetwork)):
         raise NotImplementedError("network %s is not built in the HIP step loop yet" % type(network).__name__)
     num_lanes = int(network.net_params.additional_params["lanes"])
+    fig8 = isinstance(network, FigureEightNetwork)
+    if fig8 and num_lanes != 1:
+        raise NotImplementedError("multi-lane figure eight is not built in the HIP step loop yet")
     if len(network.net_params.inflows.get()) > 0:
         raise NotImplementedError("inflows are not built in the HIP step loop yet")
     R, N = int(num_replicas), veh_k.num_vehicles
@@ -97,10 +101,14 @@ def build_spec(env, num_replicas, rng=None):
     space = env.action_space
     spec = dict(
         num_replicas=R, num_vehicles=N, num_rl=veh_k.num_rl_vehicles, vehicles=slots,
-        ring_length=np.full(R, float(network.net_params.additional_params["length"])), init_pos=X,
+        ring_length=np.full(R, float(network.net_params.additional_params["length"]) if not fig8
+                            else net_k.length() - 4 * float(net_k.junction_length)), init_pos=X,
+        segments=net_k.loop_segments(),
+        junction=net_k.crossing_model(time_gap=float(getattr(sp, "crossing_time_gap", 3.0))),
         sim_step=dt, slowdown_ramp=dt / (dt + 1e-3) if ramp is None else float(ramp),
         integrator="ballistic" if getattr(sp, "use_ballistic", False) else "euler",
-        junction_mode=int(getattr(sp, "junction_mode", 0)), junction_length=float(net_k.junction_length),
+        junction_mode=int(fig8 if getattr(sp, "junction_mode", None) is None else sp.junction_mode),
+        junction_length=float(net_k.junction_length),
         crash_gap=float(getattr(sp, "crash_gap", 0.0)), max_speed=float(net_k.max_speed()),
         env=env.FS_ENV, target_velocity=float(ep.additional_params.get("target_velocity", 0.0)),
         action_low=float(space.low[0]) if N and veh_k.num_rl_vehicles else 0.0,      # acceleration bounds

@@ -1,5 +1,6 @@
 """Networks built for the GPU hot path (names as in flow/networks/__init__.py)."""
 from flow_amd.networks.base import Network
 from flow_amd.networks.ring import RingNetwork
+from flow_amd.networks.figure_eight import FigureEightNetwork
 
-__all__ = ["Network", "RingNetwork"]
+__all__ = ["Network", "RingNetwork", "FigureEightNetwork"]

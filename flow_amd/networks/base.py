@@ -55,9 +55,17 @@ class Network(object):
     def specify_internal_edge_starts(self):
         return []
 
-    def specify_internal_edges(self, junction_length):
+    def specify_internal_edges(self, junction_length, center_length=None):
         """[(id, length)] of the internal edges netconvert would create."""
         return []
+
+    def specify_loop_order(self):
+        """Closed-route networks whose loop coordinate differs from Flow's edge-start table list their
+        edges (internal ones included) in driving order; None = the table is the loop coordinate."""
+        return None
+
+    def specify_crossing(self):
+        return None
 
     @staticmethod
     def gen_custom_start_pos(cls, net_params, initial_config, num_vehicles):

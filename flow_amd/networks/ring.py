@@ -68,7 +68,7 @@ class RingNetwork(Network):
                 (":left_0", 0.75 * ring_length + 2 * junction_length),
                 (":bottom_0", ring_length + 3 * junction_length)]
 
-    def specify_internal_edges(self, junction_length):
+    def specify_internal_edges(self, junction_length, center_length=None):
         return [(":right_0", junction_length), (":top_0", junction_length), (":left_0", junction_length),
                 (":bottom_0", junction_length)]
 

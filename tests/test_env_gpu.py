@@ -338,3 +338,48 @@ def test_lane_change_accel_env_step_through_the_env_api():
     np.testing.assert_allclose(obs[18:], np.array(env.k.vehicle.get_lane(env.k.vehicle.get_ids())) / 3.0)
     assert env.k.vehicle.get_leader(rl) in ("test_0", "test_3", "test_6")
     env.terminate()
+
+
+def test_figure_eight_accel_env_runs_a_full_episode_and_matches_the_oracle():
+    """examples/exp_configs/non_rl/figure_eight.py: 14 IDM vehicles, obey_safe_speed, AccelEnv, horizon 1500.
+    The episode must complete without a crossing collision (vehicles queue at the crossing), observations stay in
+    the Box, and the first 400 steps agree with the oracle on the same spec (f64, 1e-9)."""
+    from flow_amd.controllers import ContinuousRouter, IDMController, StaticLaneChanger
+    from flow_amd.core.params import EnvParams, NetParams, SumoCarFollowingParams, SumoParams, VehicleParams
+    from flow_amd.envs import AccelEnv
+    from flow_amd.envs.ring.accel import ADDITIONAL_ENV_PARAMS
+    from flow_amd.networks import FigureEightNetwork
+    from flow_amd.networks.figure_eight import ADDITIONAL_NET_PARAMS
+    from flow_amd.utils.registry import make_create_env
+    vehicles = VehicleParams()
+    vehicles.add(veh_id="idm", acceleration_controller=(IDMController, {}),
+                 lane_change_controller=(StaticLaneChanger, {}), routing_controller=(ContinuousRouter, {}),
+                 car_following_params=SumoCarFollowingParams(speed_mode="obey_safe_speed", decel=1.5),
+                 initial_speed=0, num_vehicles=14)
+    fp = dict(exp_tag="figure8", env_name=AccelEnv, network=FigureEightNetwork, simulator="traci",
+              sim=SumoParams(render=False, precision="f64"),
+              env=EnvParams(horizon=1500, additional_params=dict(ADDITIONAL_ENV_PARAMS)),
+              net=NetParams(additional_params=dict(ADDITIONAL_NET_PARAMS)), veh=vehicles)
+    env = make_create_env(fp)[0]()
+    ora = S.RingOracle(dict(env._spec), np.float64)
+    obs = env.reset()
+    ora.reset()
+    ids = env.k.vehicle.get_ids()
+    edges_seen = set()
+    for k in range(1500):
+        obs, rew, done, _ = env.step(None)
+        assert done == (k == 1499), "no crossing collision before the horizon"
+        if k < 400:
+            o_ref, r_ref, _ = ora.step(None)
+            if k % 50 == 0:
+                np.testing.assert_allclose(obs, o_ref[0], atol=1e-6)
+                np.testing.assert_allclose(rew, r_ref[0], atol=1e-6)
+        if k % 25 == 0:
+            edges_seen.update(env.k.vehicle.get_edge(ids))
+    assert obs.shape == (28,) and (obs >= 0).all() and (obs <= 1).all()
+    assert {"bottom", "top", "upper_ring", "right", "left", "lower_ring"} <= edges_seen
+    assert np.mean(env.k.vehicle.get_speed(ids)) > 2.0
+    x = env.k.vehicle.get_x_by_id(ids[0])
+    e, p = env.k.vehicle.get_edge(ids[0]), env.k.vehicle.get_position(ids[0])
+    assert abs(env.k.network.get_x(e, p) - x) < 1e-9
+    env.terminate()

@@ -264,3 +264,41 @@ def test_env_construction_fails_loudly_without_gpu():
     assert name.startswith("AccelEnv-v")
     with pytest.raises(FatalFlowError):
         create_env()
+
+
+def test_figure_eight_geometry_known_answers_and_spec(monkeypatch):
+    """reference tests/fast_tests/test_scenario_base_class.py:51-94 (get_x / get_edge on the figure eight),
+    :656-693 (':center_*' length 9.40) and the netconvert lengths of tests/fast_tests/test_files/fig8_test.net.xml
+    (total 421.94 m, non-internal 402.74 m)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from helpers import figure_eight_tables
+    from flow_amd.envs import AccelEnv
+    from flow_amd.envs.ring.accel import ADDITIONAL_ENV_PARAMS
+    from flow_amd.networks import FigureEightNetwork
+    from flow_amd.networks.figure_eight import ADDITIONAL_NET_PARAMS as FIG8
+    v = P.VehicleParams()
+    v.add("idm", acceleration_controller=(FC.IDMController, {}), routing_controller=(FC.ContinuousRouter, {}),
+          car_following_params=P.SumoCarFollowingParams(speed_mode="obey_safe_speed", decel=1.5), num_vehicles=14)
+    net = FigureEightNetwork("figure8", v, P.NetParams(additional_params=dict(FIG8)))
+    k = NetworkKernel(net)
+    assert k.get_edge(5) == ("bottom", 4.72) and abs(k.get_x("bottom", 4.72) - 5) < 1e-12
+    assert k.get_edge(0.1) == (":bottom", 0.1) and k.get_x(":bottom", 0.1) == 0.1
+    np.testing.assert_allclose(k.edge_length(":center_0"), 9.40)
+    np.testing.assert_allclose(k.edge_length("upper_ring"), 141.37, atol=5e-3)
+    np.testing.assert_allclose(k.length(), 421.94, atol=5e-3)
+    np.testing.assert_allclose(k.non_internal_length(), 402.74, atol=5e-3)
+    assert k.locate(31.0) == (":center_1", 1.0) and k.locate(0.0) == ("bottom", 0.0)
+    with pytest.raises(KeyError):
+        FigureEightNetwork("f", v, P.NetParams(additional_params={"radius_ring": 30}))
+    env, spec = build_env(monkeypatch, AccelEnv, P.EnvParams(horizon=1500, additional_params=ADDITIONAL_ENV_PARAMS),
+                          P.SumoParams(), net)
+    segs, junction, total, starts, onet = figure_eight_tables()
+    np.testing.assert_allclose(np.array(spec["segments"], dtype=float), np.array(segs, dtype=float), atol=1e-12)
+    for key, val in junction.items():
+        np.testing.assert_allclose(spec["junction"][key], val, atol=1e-12)
+    np.testing.assert_allclose(spec["ring_length"][0] + 0.4, total)
+    assert spec["junction_mode"] == 1 and spec["vehicles"][0]["speed_mode"] == 1 and spec["vehicles"][0]["max_decel"] == 1.5
+    pos, _ = onet.gen_even_start_pos(14)
+    np.testing.assert_allclose(spec["init_pos"][0], [starts[e] + p for e, p in pos], atol=1e-12)
+    assert env.observation_space.shape == (28,)
