@@ -1,7 +1,6 @@
 """Experiment: the non-RL rollout runner of flow/core/experiment.py:13-198 on the GPU step loop."""
 import datetime
 import logging
-import os
 import time
 
 import numpy as np

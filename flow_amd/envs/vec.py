@@ -8,8 +8,6 @@ learner on the same GPU consumes them without a host copy.
 """
 from copy import deepcopy
 
-import numpy as np
-
 from flow_amd import _lib as L
 
 
