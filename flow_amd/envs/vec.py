@@ -50,6 +50,11 @@ class VecFlowEnv(object):
         self._obs = torch.empty((R, self.obs_dim), dtype=torch.float32, device=self.device)
         self._rew = torch.empty((R,), dtype=torch.float32, device=self.device)
         self._done = torch.zeros((R,), dtype=torch.uint8, device=self.device)
+        import numpy as np
+        self._resample = env.env_params.additional_params.get('ring_length', None) is not None \
+            and env.FS_ENV in (L.FS_ENV_WAVE_ATTENUATION, L.FS_ENV_WAVE_ATTENUATION_PO)
+        self._rng = np.random.default_rng(sim_params.seed)
+        self._placement_cache = {}
         self.use_current_stream()
 
     def use_current_stream(self):
@@ -63,15 +68,54 @@ class VecFlowEnv(object):
             raise ValueError("expected a contiguous %s tensor of shape %s on %s" % (dtype, shape, self.device))
         return t
 
+    def _resample_ring_lengths(self, mask_host):
+        """WaveAttenuationEnv.reset (flow/envs/ring/wave_attenuation.py:157-210) for the replicas being reset:
+        each draws its own ring length in ``ring_length`` and is re-placed with InitialConfig(bunching=50,
+        min_gap=0).  Host-side (placement runs once per distinct length), then uploaded."""
+        import numpy as np
+        from flow_amd.core.kernel.network import NetworkKernel
+        from flow_amd.core.params import InitialConfig, NetParams
+        from flow_amd.envs.spec import check_placement, initial_positions
+        lo, hi = self.env.env_params.additional_params['ring_length']
+        idx = np.flatnonzero(mask_host)
+        if idx.size == 0:
+            return
+        lengths = self.sim.get_state(L.FS_FIELD_RING_LENGTH).astype(np.float64)
+        init = self.sim.get_state(L.FS_FIELD_INIT_POS).astype(np.float64)
+        draw = self._rng.integers(lo, hi + 1, idx.size)            # random.randint(lo, hi) per replica
+        veh_len = np.array([v["length"] for v in self.env._spec["vehicles"]])
+        ic = InitialConfig(bunching=50, min_gap=0)
+        for length in np.unique(draw):
+            if length not in self._placement_cache:
+                add = dict(self.env.net_params.additional_params)
+                add["length"] = int(length)
+                net = self.env.network.__class__(self.env.network.orig_name, self.env.network.vehicles,
+                                                 NetParams(additional_params=add), ic)
+                nk = NetworkKernel(net, junction_length=self.k.network.junction_length)
+                X, lanes = initial_positions(nk, ic, self.sim.N, 1)
+                check_placement(X, veh_len, nk.length(), lanes)
+                self._placement_cache[length] = X[0]
+            sel = idx[draw == length]
+            lengths[sel] = float(length)
+            init[sel] = self._placement_cache[length][None, :]
+        self.sim.set_state(L.FS_FIELD_RING_LENGTH, lengths)
+        self.sim.set_state(L.FS_FIELD_INIT_POS, init)
+
     def reset(self, mask=None):
         """Reset all replicas (or those where ``mask`` [R] uint8/bool tensor is set); returns obs [R, obs_dim]."""
         if mask is not None:
             mask = self._check(mask.to(self.torch.uint8), (self.num_envs,), self.torch.uint8)
+        if self._resample:
+            import numpy as np
+            self._resample_ring_lengths(np.ones(self.num_envs, bool) if mask is None else mask.cpu().numpy() != 0)
         self.sim.reset_dev(self._obs, mask)
         return self._obs
 
     def reset_done(self):
-        """Reset exactly the replicas whose last ``done`` flag is set; no host synchronisation."""
+        """Reset exactly the replicas whose last ``done`` flag is set.  No host synchronisation, unless the
+        environment redraws its network per episode (WaveAttenuationEnv with ``ring_length``)."""
+        if self._resample:
+            self._resample_ring_lengths(self._done.cpu().numpy() != 0)
         self.sim.reset_dev(self._obs, self._done)
         return self._obs
 
