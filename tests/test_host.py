@@ -302,3 +302,31 @@ def test_figure_eight_geometry_known_answers_and_spec(monkeypatch):
     pos, _ = onet.gen_even_start_pos(14)
     np.testing.assert_allclose(spec["init_pos"][0], [starts[e] + p for e, p in pos], atol=1e-12)
     assert env.observation_space.shape == (28,)
+
+
+def test_flow_params_json_round_trip_and_reference_file(monkeypatch):
+    """flow/utils/rllib.py FlowParamsEncoder / get_flow_params: (a) the reference's own stored file
+    tests/fast_tests/test_files/ring_230.json (committed as tests/golden/ring_230_flow_params.json) loads into
+    flow_amd objects and resolves to a spec; (b) encode -> decode round trip."""
+    import json as _json
+    from flow_amd.utils.rllib import FlowParamsEncoder, get_flow_params
+    fp = get_flow_params(os.path.join(GOLDEN, "ring_230_flow_params.json"))
+    from flow_amd.envs import WaveAttenuationPOEnv
+    assert fp["env_name"] is WaveAttenuationPOEnv and fp["network"] is RingNetwork
+    assert fp["veh"].num_vehicles == 22 and fp["veh"].num_rl_vehicles == 1
+    assert fp["env"].warmup_steps == 750 and fp["env"].horizon == 3000 and fp["sim"].sim_step == 0.1
+    assert fp["veh"].type_parameters["human"]["acceleration_controller"][0] is FC.IDMController
+    assert fp["veh"].type_parameters["human"]["acceleration_controller"][1] == {"noise": 0.2}
+    assert fp["veh"].type_parameters["human"]["car_following_params"].speed_mode == 25
+    assert fp["initial"].lanes_distribution == float("inf")
+    net = fp["network"](name=fp["exp_tag"], vehicles=fp["veh"], net_params=fp["net"], initial_config=fp["initial"])
+    env, spec = build_env(monkeypatch, fp["env_name"], fp["env"], fp["sim"], net)
+    assert spec["num_vehicles"] == 22 and spec["env"] == L.FS_ENV_WAVE_ATTENUATION_PO and spec["warmup_steps"] == 750
+    assert spec["vehicles"][0]["noise"] == 0.2 and spec["vehicles"][21]["controller"] == L.FS_CTRL_RL
+
+    text = _json.dumps(fp, cls=FlowParamsEncoder, sort_keys=True)
+    again = get_flow_params({"env_config": {"flow_params": text}})
+    assert again["env_name"] is WaveAttenuationPOEnv and again["network"] is RingNetwork
+    assert again["veh"].ids == fp["veh"].ids and again["env"].additional_params == fp["env"].additional_params
+    assert again["net"].additional_params == fp["net"].additional_params
+    assert again["veh"].type_parameters["rl"]["acceleration_controller"][0] is FC.RLController
