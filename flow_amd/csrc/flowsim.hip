@@ -54,6 +54,7 @@ struct SimBase {
   std::vector<void*> allocs;
   bool force_generic = false;   // FLOWSIM_FORCE_GENERIC=1: never take the specialised kernels (tests)
   bool no_fastdiv = false;      // FLOWSIM_NO_FASTDIV=1: keep the IEEE division sequence in k_rollout_idm
+  int rollout_block = 512;      // threads per block of k_rollout_idm (FLOWSIM_ROLLOUT_BLOCK overrides; sweep: DESIGN.md)
 
   virtual int launch_steps(int num_steps, const uint8_t* mask, const float* actions, size_t act_stride,
                            float* obs, float* rew, uint8_t* done, int obs_every_step) = 0;
@@ -312,15 +313,18 @@ struct Sim : SimBase {
     }
     if (fast_ok(mask, num_steps) && obs_every_step && dv.N > 1 && actions == nullptr) {
       const bool fd = fastdiv_ok();
+      const int waves = blocks;                                   // one wave per 64/SEG replicas
+      const int wpb = rollout_block / 64;                         // waves per block
+      const dim3 grid((waves + wpb - 1) / wpb), block(rollout_block);
       if (delta4 && fd)
-        hipLaunchKernelGGL((fs::k_rollout_idm<T, SEG, true, true>), dim3(blocks), dim3(64), 0, stream, dv, num_steps,
-                           obs, rew, done, d_dump);
+        hipLaunchKernelGGL((fs::k_rollout_idm<T, SEG, true, true>), grid, block, 0, stream, dv, num_steps, obs, rew,
+                           done, d_dump);
       else if (delta4)
-        hipLaunchKernelGGL((fs::k_rollout_idm<T, SEG, true, false>), dim3(blocks), dim3(64), 0, stream, dv, num_steps,
-                           obs, rew, done, d_dump);
+        hipLaunchKernelGGL((fs::k_rollout_idm<T, SEG, true, false>), grid, block, 0, stream, dv, num_steps, obs, rew,
+                           done, d_dump);
       else
-        hipLaunchKernelGGL((fs::k_rollout_idm<T, SEG, false, false>), dim3(blocks), dim3(64), 0, stream, dv,
-                           num_steps, obs, rew, done, d_dump);
+        hipLaunchKernelGGL((fs::k_rollout_idm<T, SEG, false, false>), grid, block, 0, stream, dv, num_steps, obs, rew,
+                           done, d_dump);
     } else if (fast_ok(mask, num_steps))
       hipLaunchKernelGGL((fs::k_steps<T, SEG, 1>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, mask, actions,
                          act_stride, obs, rew, done, obs_every_step);
@@ -545,6 +549,11 @@ int create_typed(const fs_config* cfg, fs_handle* out) {
     s->force_generic = fg && fg[0] == '1';
     const char* nf = std::getenv("FLOWSIM_NO_FASTDIV");
     s->no_fastdiv = nf && nf[0] == '1';
+    const char* rb = std::getenv("FLOWSIM_ROLLOUT_BLOCK");
+    if (rb) {
+      const int v = std::atoi(rb);
+      if (v >= 64 && v <= 1024 && v % 64 == 0) s->rollout_block = v;
+    }
   }
   int rc = s->init();
   if (rc == FS_OK) {
