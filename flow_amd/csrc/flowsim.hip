@@ -494,6 +494,7 @@ int validate(const fs_config* c) {
   if (c->junction_length < 0) return fail(FS_ERR_INVALID, "fs_create: junction_length < 0");
   if (!c->vehicles || !c->ring_length || !c->init_pos) return fail(FS_ERR_INVALID, "fs_create: NULL table pointer");
   int seen_rl = 0;
+  unsigned long long rl_mask = 0ull;       // num_vehicles <= 64
   for (int i = 0; i < c->num_vehicles; ++i) {
     const fs_vehicle_spec& v = c->vehicles[i];
     if (v.controller < FS_CTRL_SIM || v.controller > FS_CTRL_PISATURATION)
@@ -502,6 +503,8 @@ int validate(const fs_config* c) {
       return fail(FS_ERR_INVALID, "fs_create: unknown fail_safe id");
     if (v.controller == FS_CTRL_RL) {
       if (v.rl_index < 0 || v.rl_index >= c->num_rl) return fail(FS_ERR_INVALID, "fs_create: rl_index out of range");
+      if (rl_mask & (1ull << v.rl_index)) return fail(FS_ERR_INVALID, "fs_create: rl_index used twice");
+      rl_mask |= 1ull << v.rl_index;
       ++seen_rl;
     }
     if (!(v.length > 0)) return fail(FS_ERR_INVALID, "fs_create: vehicle length <= 0");

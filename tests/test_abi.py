@@ -86,3 +86,45 @@ def test_create_fails_loudly_without_a_gpu(lib):
     from flow_amd.utils.exceptions import FatalFlowError
     with pytest.raises(FatalFlowError):
         FlowSim(ring_spec(R=1, N=5, bunching=0), "f32")
+
+
+def test_config_validation_needs_no_gpu(lib):
+    """fs_create validates the whole config before it touches the device: the reference's error types come
+    back through the binding (ValueError / NotImplementedError / FatalFlowError) with a message."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import idm_vehicle, ring_spec
+    from flow_amd.sim import FlowSim
+    from flow_amd.utils.exceptions import FatalFlowError
+
+    def spec(**kw):
+        s = ring_spec(R=2, N=5, bunching=0)
+        s.update(kw)
+        return s
+    with pytest.raises(ValueError, match="unknown controller"):
+        FlowSim(spec(vehicles=[idm_vehicle(controller=99)] * 5), "f32")
+    with pytest.raises(ValueError, match="rl_index"):
+        FlowSim(spec(vehicles=[idm_vehicle(controller=1, rl_index=3)] * 5, num_rl=5), "f32")      # used twice
+    with pytest.raises(ValueError, match="rl_index out of range"):
+        FlowSim(spec(vehicles=[idm_vehicle()] * 4 + [idm_vehicle(controller=1, rl_index=4)], num_rl=1), "f32")
+    with pytest.raises(ValueError, match="num_rl"):
+        FlowSim(spec(num_rl=2), "f32")
+    with pytest.raises(ValueError, match="sim_step"):
+        FlowSim(spec(sim_step=0.0), "f32")
+    with pytest.raises(ValueError, match="slowdown_ramp"):
+        FlowSim(spec(slowdown_ramp=1.5), "f32")
+    with pytest.raises(ValueError, match="init_pos"):
+        FlowSim(spec(init_pos=np.full((2, 5), 500.0)), "f32")
+    with pytest.raises(FatalFlowError, match="do not fit"):              # network/base.py:603-605
+        FlowSim(spec(ring_length=np.full(2, 20.0), init_pos=np.tile(np.arange(5) * 3.0, (2, 1))), "f32")
+    big = ring_spec(R=1, N=65, length=800.0, bunching=0)
+    with pytest.raises(NotImplementedError, match="64 vehicles"):
+        FlowSim(big, "f32")
+    with pytest.raises(NotImplementedError, match="multi-lane"):
+        FlowSim(spec(num_lanes=2, env=2, num_rl=1,
+                     vehicles=[idm_vehicle()] * 4 + [idm_vehicle(controller=1, rl_index=0)]), "f32")
+    with pytest.raises(ValueError, match="init_lane"):
+        FlowSim(spec(num_lanes=2, init_lane=np.full((2, 5), 7)), "f32")
+    with pytest.raises(ValueError, match="segment table"):
+        FlowSim(dict(spec(), junction=dict(a_in=1, a_out=2, b_in=3, b_out=4, lookahead=1, time_gap=1, za_lo=0,
+                                           za_hi=1, zb_lo=0, zb_hi=1)), "f32")
