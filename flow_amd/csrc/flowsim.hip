@@ -10,6 +10,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <type_traits>
@@ -249,12 +251,28 @@ struct Sim : SimBase {
 
   // ---- exact division by launch constants (flowsim_kernels.h div_const) --------------------
   // The 3-operation reciprocal sequence is enabled only if, for every divisor the rollout kernel
-  // will use (the loop length of every replica), it
+  // will use (v0 and 2*sqrt(a*b) of every slot, the loop length of every replica), it
   // reproduces x / c for ALL 2^23 float mantissas of x.  Checked lazily, once per handle state;
   // set_state of the ring lengths invalidates it.  Only the float kernels use it.
   int fastdiv_state = -1;       // -1 unknown, 0 no, 1 yes
   static bool fastdiv_exact_for(float c) {
     if (!(c > 0.0f) || !std::isfinite(c)) return false;
+    // process-wide memo: the answer depends on the divisor only
+    static std::mutex mu;
+    static std::map<uint32_t, bool> memo;
+    uint32_t key;
+    std::memcpy(&key, &c, 4);
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      auto it = memo.find(key);
+      if (it != memo.end()) return it->second;
+    }
+    const bool ok = fastdiv_exact_uncached(c);
+    std::lock_guard<std::mutex> lock(mu);
+    memo[key] = ok;
+    return ok;
+  }
+  static bool fastdiv_exact_uncached(float c) {
     const float rc = 1.0f / c;
     for (uint32_t m = 0; m < (1u << 23); ++m) {
       const uint32_t bits = 0x3F800000u | m;
@@ -276,6 +294,11 @@ struct Sim : SimBase {
         if (e == c) return;
       cs.push_back(c);
     };
+    for (int i = 0; i < dv.N; ++i) {            // per-slot IDM divisors and the s0 >= 1e-3 premise
+      add(float(veh[i].p[0]));
+      add(2.0f * std::sqrt(float(veh[i].p[2]) * float(veh[i].p[3])));
+      if (!(float(veh[i].p[5]) >= 1e-3f) || !(float(veh[i].p[5]) <= 1e6f)) return false;
+    }
     std::vector<T> rl(size_t(dv.R));
     if (hipMemcpy(rl.data(), dv.ring_len, rl.size() * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) return false;
     for (T b : rl) {

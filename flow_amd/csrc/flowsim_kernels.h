@@ -788,11 +788,17 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
 // IEEE division sequence by q0 = x*rc, r = fma(-q0, c, x), q = fma(r, rc, q0) with rc = RN(1/c).
 // The host enables it per handle only after checking, for EVERY float mantissa of x, that the
 // result equals x / c for each divisor used (Sim::fastdiv_ok, 2^23 cases per divisor): the check
-// is scale-invariant, so it covers every x whose remainder r stays a normal number.  It is used
-// for the position quotient x / L only (x is 0 or >= ulp(L)/2).  Speeds decay through the
-// denormal range whenever a vehicle comes to rest, and guarding those dividends per step cost
-// more than the shorter sequence saved (measured: 6.81 vs 7.12 G env-steps/s), so every quotient
-// of a speed keeps the IEEE sequence.
+// is scale-invariant, so it covers every x whose remainder r stays a normal number (|x| >= 2^-70).
+// Where it is used, and why smaller dividends cannot change a result there:
+//   x / L        the observation: x is 0 or >= ulp(L)/2, never tiny.
+//   v / v0       feeds pw = (v/v0)^4 only: for v < 2^-70 both the exact and the approximate ratio
+//                give pw = 0 (underflow), so 1 - pw - q*q is identical.
+//   num / 2sqrt(ab)  feeds dyn = v*T + dq: |num| < 2^-70 makes |dq| < 2^-70; then either v*T >= 2^-40
+//                and dq is below half an ulp of it (dyn = v*T either way), or dyn < 2^-39 and
+//                s* = s0 + max(0, dyn) = s0 exactly because s0 >= 1e-3 (host-checked).
+// The speed observation v / max_speed is an OUTPUT and speeds decay through the denormal range
+// whenever a vehicle comes to rest (39 % of wave-steps on C2 hold one below 2^-90), so it keeps the
+// IEEE sequence; guarding it per step cost more than it saved (measured 6.81 vs 7.12 G env-steps/s).
 template <bool FASTDIV>
 __device__ __forceinline__ float div_const(float x, float c, float rc) {
   if (FASTDIV) {
@@ -804,6 +810,24 @@ __device__ __forceinline__ float div_const(float x, float c, float rc) {
 }
 template <bool FASTDIV>
 __device__ __forceinline__ double div_const(double x, double c, double) { return x / c; }
+
+// n / d for operands that need none of the IEEE sequence's scaling or special-case fix-up
+// (both finite, non-zero, |value| within [2^-60, 2^60]): the same refinement hipcc emits for `/`
+// -- v_rcp_f32, one Newton step on the reciprocal, quotient, two residual corrections -- without
+// v_div_scale (x2), v_div_fmas' post-scale and v_div_fixup.  With unscaled operands those four are
+// the identity, so the result is bit-identical to n / d.  Used for s* / h only: s* >= s0 >= 1e-3
+// (host-checked) and 1e-3 <= |h| <= loop length.
+__device__ __forceinline__ float div_core(float n, float d) {
+  const float y0 = __builtin_amdgcn_rcpf(d);
+  const float e = __builtin_fmaf(-d, y0, 1.0f);
+  const float y = __builtin_fmaf(e, y0, y0);
+  const float q0 = n * y;
+  const float r0 = __builtin_fmaf(-d, q0, n);
+  const float q1 = __builtin_fmaf(r0, y, q0);
+  const float r1 = __builtin_fmaf(-d, q1, n);
+  return __builtin_fmaf(r1, y, q1);
+}
+__device__ __forceinline__ double div_core(double n, double d) { return n / d; }
 
 template <typename T, int SEG, bool DELTA4, bool FASTDIV>
 __global__ __launch_bounds__(1024) void k_rollout_idm(DevView<T> s, int num_steps, float* __restrict__ obs,
@@ -845,7 +869,7 @@ __global__ __launch_bounds__(1024) void k_rollout_idm(DevView<T> s, int num_step
 
   const T dt = s.dt, ramp = s.ramp;
   const T two_sqrt_ab = T(2) * tsqrt(p[2] * p[3]);
-  const T rc_L = T(1) / L;
+  const T rc_L = T(1) / L, rc_v0 = T(1) / p[0], rc_ab = T(1) / two_sqrt_ab;
   const size_t row = size_t(2) * N;
   float* po = valid ? obs + size_t(rr) * row + ii : dump;     // idle lanes write scratch
   const size_t po_step = valid ? size_t(s.R) * row : 0;          // the scratch word does not move
@@ -857,11 +881,11 @@ __global__ __launch_bounds__(1024) void k_rollout_idm(DevView<T> s, int num_step
     // IDMController.get_accel (ctrl_idm, car_following_models.py:464-482)
     T hh = tabs(h) < T(1e-3) ? T(1e-3) : h;
     T num = v * (v - vl);
-    T dq = num / two_sqrt_ab;
-    T ratio = v / p[0];
+    T dq = div_const<FASTDIV>(num, two_sqrt_ab, rc_ab);
+    T ratio = div_const<FASTDIV>(v, p[0], rc_v0);
     T dyn = v * p[1] + dq;
     T s_star = p[5] + tmax(T(0), dyn);
-    T q = s_star / hh;
+    T q = FASTDIV ? div_core(s_star, hh) : s_star / hh;
     T pw;
     if (DELTA4) { T r2 = ratio * ratio; pw = r2 * r2; } else { pw = pow_delta(ratio, p[4]); }
     T acc = p[2] * (T(1) - pw - q * q);
@@ -885,9 +909,7 @@ __global__ __launch_bounds__(1024) void k_rollout_idm(DevView<T> s, int num_step
     crash_bits |= (valid && (h < s.crash_gap)) ? bit : 0u;
     bad_bits |= (valid && (v < T(-100))) ? bit : 0u;
     // AccelEnv.get_state (accel.py:116-123)
-    po[0] = float(v / s.max_speed);
-    // speeds decay through the denormal range when a vehicle comes to rest, so only the position
-    // quotient takes the constant-divisor path: x is 0 or >= ulp(L)/2, never tiny
+    po[0] = float(v / s.max_speed);                      // an output: IEEE division (see div_const)
     po[N] = float(div_const<FASTDIV>(x, L, rc_L));
     po += po_step;
     // rewards.desired_velocity, first half: the reduced sum of squares (rewards.py:53-54)
