@@ -269,7 +269,8 @@ def main():
         except Exception:
             traffic = None
     roofline = {"bound": "hbm",
-                "kernel": "fs::k_rollout_idm<%s, 32, true>" % ("float" if args.precision == "f32" else "double"),
+                "kernel": "fs::k_rollout_idm<%s, 32, true, %s>" % (("float", "true") if args.precision == "f32"
+                                                                   else ("double", "false")),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "bytes_per_launch": bytes_per_launch, "steps_per_launch": k_launch,
                 "avg_launch_ms": avg_launch_s * 1e3, "launches_timed": len(full),
