@@ -476,6 +476,139 @@ def test_figure_eight_with_rl_vehicle_noise_and_crossing_crash():
     sim.close()
 
 
+EXACT_CONTROLLERS = [
+    lambda rng: idm_vehicle(p=[float(rng.uniform(15, 35)), float(rng.uniform(0.5, 1.5)), float(rng.uniform(0.8, 2.0)),
+                               float(rng.uniform(1.0, 2.5)), float(rng.choice([1, 2, 3, 4, 8])),
+                               float(rng.uniform(1.0, 3.0)), 0, 0]),
+    lambda rng: idm_vehicle(controller=S.CTRL_CFM, p=[1, 1, float(rng.uniform(0.5, 1.5)), 1, 8, 0, 0, 0], max_accel=3.0),
+    lambda rng: idm_vehicle(controller=S.CTRL_BCM, p=[0.5, 1, 1, 1, float(rng.uniform(5, 10)), 0, 0, 0], max_accel=2.0),
+    lambda rng: idm_vehicle(controller=S.CTRL_LAC, p=[0.3, 0.4, 1, float(rng.uniform(0.1, 0.5)), 0, 0, 0, 0]),
+    lambda rng: idm_vehicle(controller=S.CTRL_LINEAR_OVM, p=[30, 0.65, float(rng.uniform(3, 6)), 0, 0, 0, 0, 0]),
+    lambda rng: idm_vehicle(controller=S.CTRL_GIPPS, p=[30, 1.5, -1, -1, 2, 1, 0, 0]),
+    lambda rng: idm_vehicle(controller=S.CTRL_FOLLOWER_STOPPER, p=[float(rng.uniform(5, 12)), 0, 0, 0, 0, 0, 0, 0],
+                            fail_safe=S.FAILSAFE_SAFE_VELOCITY, delay=1.0),
+    lambda rng: idm_vehicle(controller=S.CTRL_NONLOCAL_FOLLOWER_STOPPER, p=[7.5, 0, 0, 0, 0, 0, 0, 0],
+                            fail_safe=S.FAILSAFE_SAFE_VELOCITY, delay=1.0),
+    lambda rng: idm_vehicle(controller=S.CTRL_PISATURATION, p=[0] * 8, max_accel=2.6, delay=1.0),
+    lambda rng: idm_vehicle(controller=S.CTRL_SIM),
+]
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_random_single_lane_configs_bit_exact(seed):
+    """Seeded random configurations: vehicle count, replica count, per-replica ring lengths, controller mix,
+    fail-safes, speed modes, junction mode, integrator, sims_per_step, warm-up, RL actions, masked resets --
+    float32 HIP path vs float32 oracle, every field bit for bit."""
+    rng = np.random.default_rng(1000 + seed)
+    N = int(rng.integers(1, 65))
+    R = int(rng.integers(1, 41))
+    base = float(max(60.0, N * rng.uniform(7.5, 12.0)))
+    lengths = np.round(base + rng.uniform(0, 40, R))
+    jl = float(rng.choice([0.0, 0.1, 0.25]))
+    n_rl = int(rng.integers(0, min(N, 3) + 1))
+    veh = []
+    for i in range(N):
+        v = EXACT_CONTROLLERS[int(rng.integers(0, len(EXACT_CONTROLLERS)))](rng)
+        if v["controller"] not in (S.CTRL_FOLLOWER_STOPPER, S.CTRL_NONLOCAL_FOLLOWER_STOPPER):
+            v["fail_safe"] = int(rng.choice([0, 0, 1, 2]))
+            v["delay"] = float(rng.choice([0.0, 0.5]))
+        v["speed_mode"] = int(rng.choice([0, 0, 1, 6, 7, 25, 31]))
+        v["length"] = float(rng.choice([5.0, 5.0, 4.0]))
+        veh.append(v)
+    for k in range(n_rl):
+        veh[int(N - 1 - k)] = idm_vehicle(controller=S.CTRL_RL, rl_index=k, speed_mode=int(rng.choice([0, 1])))
+    frac = np.sort(rng.uniform(0, 1, N))
+    spacing = (lengths[:, None] + 4 * jl - 6.0 * N)            # free room per replica
+    X = np.cumsum(np.full((R, N), 6.0), axis=1) - 6.0 + frac[None, :] * np.maximum(spacing, 0.0) * 0.999
+    env = int(rng.choice([S.ENV_ACCEL, S.ENV_ACCEL, S.ENV_WAVE_ATTENUATION] + ([S.ENV_WAVE_ATTENUATION_PO] if n_rl else [])))
+    if env != S.ENV_ACCEL and n_rl == 0:
+        env = S.ENV_ACCEL
+    spec = dict(num_replicas=R, num_vehicles=N, num_rl=n_rl, sim_step=float(rng.choice([0.1, 0.2, 0.5])),
+                junction_length=jl, ring_length=lengths, max_speed=30.0, env=env,
+                target_velocity=float(rng.choice([8, 10, 20])), action_low=-float(rng.uniform(0.5, 3)),
+                action_high=float(rng.uniform(0.5, 3)), horizon=int(rng.integers(5, 40)),
+                warmup_steps=int(rng.integers(0, 4)), sims_per_step=int(rng.integers(1, 4)), vehicles=veh,
+                init_pos=X, init_vel=rng.uniform(0, 4, (R, N)), junction_mode=int(rng.integers(0, 2)),
+                integrator=str(rng.choice(["euler", "ballistic"])), clip_actions=bool(rng.integers(0, 2)),
+                evaluate=bool(rng.integers(0, 2)), po_max_length=float(lengths.max()), track_aux=bool(rng.integers(0, 2)),
+                crash_gap=float(rng.choice([0.0, 0.5])), slowdown_ramp=float(rng.choice([1.0, 0.1 / 0.101])))
+    steps = 30
+    actions = rng.uniform(-4, 4, (steps, R, max(n_rl, 1))).astype(np.float32)[:, :, :n_rl] if n_rl else None
+    ora = S.RingOracle(spec, np.float32)
+    sim = make(spec, "f32")
+    np.testing.assert_array_equal(sim.reset(), ora.reset().astype(np.float32))
+    for k in range(steps):
+        a = None if actions is None or k % 7 == 3 else actions[k]
+        o_ref, r_ref, d_ref = ora.step(a)
+        o_gpu, r_gpu, d_gpu = sim.step(a)
+        np.testing.assert_array_equal(sim.pos, ora.x)
+        np.testing.assert_array_equal(sim.vel, ora.v)
+        np.testing.assert_array_equal(o_gpu, o_ref.astype(np.float32))
+        np.testing.assert_array_equal(r_gpu, r_ref.astype(np.float32))
+        np.testing.assert_array_equal(d_gpu, d_ref)
+        if k == 12:
+            m = rng.integers(0, 2, R).astype(bool)
+            np.testing.assert_array_equal(sim.reset(m), ora.reset(m).astype(np.float32))
+    np.testing.assert_array_equal(sim.time_counter, ora.time_counter)
+    np.testing.assert_array_equal(sim.headway, ora.headways())
+    sim.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_random_multilane_configs_bit_exact(seed):
+    """Seeded random multi-lane rings: lanes, vehicles per lane, controller mix, RL lane-change tapes with
+    non-integer directions, both get_last_lc meanings, both lane-change modes."""
+    rng = np.random.default_rng(5000 + seed)
+    lanes = int(rng.integers(2, 5))
+    N = int(rng.integers(lanes, 41))
+    R = int(rng.integers(1, 17))
+    n_rl = int(rng.integers(1, min(N, 4) + 1))
+    length = float(max(80.0, (N / lanes) * rng.uniform(9.0, 14.0)))
+    per_lane = -(-N // lanes)
+    slot_x = (np.arange(N) // lanes) * (length / per_lane) + rng.uniform(0, 0.5, N)
+    X = np.tile(slot_x, (R, 1)) + rng.uniform(0, 0.3, (R, N))
+    lane0 = np.tile((np.arange(N) % lanes).astype(np.int32), (R, 1))
+    veh = [EXACT_CONTROLLERS[int(rng.integers(0, 7))](rng) for _ in range(N)]
+    for v in veh:
+        v["speed_mode"] = int(rng.choice([0, 0, 1, 7]))
+    rl_slots = rng.choice(N, n_rl, replace=False)
+    for k, i in enumerate(sorted(rl_slots)):
+        veh[int(i)] = idm_vehicle(controller=S.CTRL_RL, rl_index=k)
+    env = int(rng.choice([S.ENV_LANE_CHANGE_ACCEL, S.ENV_LANE_CHANGE_ACCEL, S.ENV_ACCEL]))
+    spec = dict(num_replicas=R, num_vehicles=N, num_rl=n_rl, sim_step=0.1, junction_length=0.1,
+                ring_length=np.full(R, length), max_speed=30.0, env=env, target_velocity=10.0,
+                action_low=-2.0, action_high=2.0, horizon=int(rng.integers(10, 60)), warmup_steps=int(rng.integers(0, 3)),
+                sims_per_step=int(rng.integers(1, 3)), vehicles=veh, init_pos=X, init_vel=rng.uniform(0, 5, (R, N)),
+                num_lanes=lanes, init_lane=lane0, lane_change_duration=float(rng.choice([0, 2, 5])),
+                lane_change_mode=int(rng.choice([0, 512])), last_lc_quirk=bool(rng.integers(0, 2)),
+                junction_mode=int(rng.integers(0, 2)), crash_gap=float(rng.choice([0.0, 0.3])))
+    steps = 40
+    width = n_rl * (2 if env == S.ENV_LANE_CHANGE_ACCEL else 1)
+    actions = rng.uniform(-2.5, 2.5, (steps, R, width)).astype(np.float32)
+    if env == S.ENV_LANE_CHANGE_ACCEL:
+        actions[:, :, 1::2] = rng.choice([-1.0, 0.0, 1.0, 0.4, -0.7], (steps, R, n_rl))
+    from flow_amd import _lib as L
+    ora = S.MultiLaneRingOracle(spec, np.float32)
+    sim = make(spec, "f32")
+    np.testing.assert_array_equal(sim.reset(), ora.reset().astype(np.float32))
+    for k in range(steps):
+        a = None if k % 9 == 4 else actions[k]
+        o_ref, r_ref, d_ref = ora.step(a)
+        o_gpu, r_gpu, d_gpu = sim.step(a)
+        np.testing.assert_array_equal(sim.pos, ora.x)
+        np.testing.assert_array_equal(sim.vel, ora.v)
+        np.testing.assert_array_equal(sim.get_state(L.FS_FIELD_LANE), ora.lane)
+        np.testing.assert_array_equal(o_gpu, o_ref.astype(np.float32))
+        np.testing.assert_array_equal(r_gpu, r_ref.astype(np.float32))
+        np.testing.assert_array_equal(d_gpu, d_ref)
+        if k == 15:
+            m = rng.integers(0, 2, R).astype(bool)
+            np.testing.assert_array_equal(sim.reset(m), ora.reset(m).astype(np.float32))
+    np.testing.assert_array_equal(sim.get_state(L.FS_FIELD_LEADER), ora.neighbours()[0])
+    np.testing.assert_array_equal(sim.get_state(L.FS_FIELD_LAST_LC), ora.last_lc.astype(np.int32))
+    sim.close()
+
+
 def test_abi_rejects_bad_configs():
     spec = ring_spec(R=2, N=5, bunching=0)
     bad = dict(spec)
