@@ -111,13 +111,15 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def c3_leg(device, R=4096, steps=3000):
+def c3_leg(device, R=4096, steps=3000, po=False):
     """BASELINE configs[2] (informational, not the headline): FigureEightNetwork, 13 noisy IDM + 1 RL vehicle,
-    AccelEnv observation (28), random RL actions from a pre-generated tape, generic k_steps kernel."""
+    random RL actions from a pre-generated tape, generic k_steps kernel.  ``po=False``: AccelEnv observation (28),
+    the pairing the reference itself uses (singleagent_figure_eight.py:44); ``po=True``: the 3-value
+    WaveAttenuationPOEnv observation BASELINE.json names."""
     import torch
     from flow_amd.controllers import ContinuousRouter, IDMController, RLController
     from flow_amd.core.params import EnvParams, NetParams, SumoCarFollowingParams, SumoParams, VehicleParams
-    from flow_amd.envs import AccelEnv, VecFlowEnv
+    from flow_amd.envs import AccelEnv, VecFlowEnv, WaveAttenuationPOEnv
     from flow_amd.networks import FigureEightNetwork
     from flow_amd.networks.figure_eight import ADDITIONAL_NET_PARAMS
     veh = VehicleParams()
@@ -126,10 +128,11 @@ def c3_leg(device, R=4096, steps=3000):
             car_following_params=SumoCarFollowingParams(speed_mode="obey_safe_speed", decel=1.5), num_vehicles=13)
     veh.add(veh_id="rl", acceleration_controller=(RLController, {}), routing_controller=(ContinuousRouter, {}),
             car_following_params=SumoCarFollowingParams(speed_mode="obey_safe_speed", decel=1.5), num_vehicles=1)
-    fp = dict(exp_tag="figure_eight", env_name=AccelEnv, network=FigureEightNetwork, simulator="traci",
-              sim=SumoParams(sim_step=0.1, render=False, seed=7),
-              env=EnvParams(horizon=1500, additional_params={"target_velocity": 20, "max_accel": 3, "max_decel": 3,
-                                                             "sort_vehicles": False}),
+    add = {"max_accel": 3, "max_decel": 3, "ring_length": None} if po else \
+        {"target_velocity": 20, "max_accel": 3, "max_decel": 3, "sort_vehicles": False}
+    fp = dict(exp_tag="figure_eight", env_name=WaveAttenuationPOEnv if po else AccelEnv, network=FigureEightNetwork,
+              simulator="traci", sim=SumoParams(sim_step=0.1, render=False, seed=7),
+              env=EnvParams(horizon=1500, additional_params=add),
               net=NetParams(additional_params=dict(ADDITIONAL_NET_PARAMS)), veh=veh)
     vec = VecFlowEnv(fp, num_replicas=R, device=device.index)
     K = 1500
@@ -152,9 +155,9 @@ def c3_leg(device, R=4096, steps=3000):
     crashed = float((out[2][:-1].max(dim=0).values > 0).float().mean().item())
     vec.close()
     return {"value": R * done_steps / dt, "unit": "env-steps/s", "steps": done_steps, "replicas": R,
-            "obs_dim": 28, "replicas_crashed_before_horizon": crashed,
-            "workload": "C3: FigureEightNetwork r=30, 13 IDM (noise 0.2, obey_safe_speed) + 1 RL, AccelEnv, "
-                        "random actions; generic kernel"}
+            "obs_dim": 3 if po else 28, "replicas_crashed_before_horizon": crashed,
+            "workload": "C3: FigureEightNetwork r=30, 13 IDM (noise 0.2, obey_safe_speed) + 1 RL, %s, "
+                        "random actions; generic kernel" % ("WaveAttenuationPOEnv" if po else "AccelEnv")}
 
 
 def cpu_baseline(spec_fn, seconds=12.0):
@@ -317,6 +320,7 @@ def main():
         out[other] = {"value": R * 6000 / (time.perf_counter() - t2), "unit": "env-steps/s", "steps": 6000}
         r2.sim.close()
         out["c3_figure_eight"] = c3_leg(device)
+        out["c3_figure_eight_po"] = c3_leg(device, po=True)
         out["cpu_baseline"] = cpu_baseline(lambda r: c2_spec(r, seed=1000))
 
     runner.sim.close()
