@@ -330,3 +330,35 @@ def test_flow_params_json_round_trip_and_reference_file(monkeypatch):
     assert again["veh"].ids == fp["veh"].ids and again["env"].additional_params == fp["env"].additional_params
     assert again["net"].additional_params == fp["net"].additional_params
     assert again["veh"].type_parameters["rl"]["acceleration_controller"][0] is FC.RLController
+
+
+def test_package_alias_lets_reference_style_imports_resolve(monkeypatch):
+    """after ``flow_amd.install_as_flow()`` the import lines of a reference experiment file
+    (examples/exp_configs/non_rl/ring.py:6-10, examples/exp_configs/rl/singleagent/singleagent_ring.py:6-10,
+    examples/simulate.py:9) resolve to this package."""
+    import importlib
+    import sys
+    import flow_amd
+    for name in [m for m in sys.modules if m == "flow" or m.startswith("flow.")]:
+        monkeypatch.delitem(sys.modules, name)
+    monkeypatch.setattr(sys, "meta_path", list(sys.meta_path))
+    flow_amd.install_as_flow()
+    ns = {}
+    exec("from flow.controllers import IDMController, ContinuousRouter, RLController\n"
+         "from flow.core.params import SumoParams, EnvParams, InitialConfig, NetParams\n"
+         "from flow.core.params import VehicleParams, SumoCarFollowingParams\n"
+         "from flow.envs.ring.accel import AccelEnv, ADDITIONAL_ENV_PARAMS\n"
+         "from flow.envs import WaveAttenuationPOEnv\n"
+         "from flow.networks.ring import RingNetwork, ADDITIONAL_NET_PARAMS\n"
+         "from flow.networks import FigureEightNetwork\n"
+         "from flow.core.experiment import Experiment\n"
+         "from flow.utils.registry import make_create_env\n"
+         "from flow.utils.rllib import FlowParamsEncoder, get_flow_params\n"
+         "from flow.core import rewards\n", ns)
+    assert ns["IDMController"] is FC.IDMController and ns["RingNetwork"] is RingNetwork
+    assert ns["ADDITIONAL_ENV_PARAMS"]["target_velocity"] == 10 and ns["ADDITIONAL_NET_PARAMS"]["length"] == 230
+    assert importlib.import_module("flow.envs").AccelEnv is ns["AccelEnv"]
+    import flow_amd.envs
+    assert ns["AccelEnv"] is flow_amd.envs.AccelEnv and ns["Experiment"].__module__ == "flow_amd.core.experiment"
+    for name in [m for m in list(sys.modules) if m == "flow" or m.startswith("flow.")]:
+        monkeypatch.delitem(sys.modules, name, raising=False)
