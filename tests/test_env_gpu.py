@@ -1,6 +1,7 @@
 """GPU tests of the drop-in API: flow_amd.envs.* / make_create_env / VecFlowEnv driven the way
 the reference's own tests drive flow.envs (tests/fast_tests/test_environment_base_class.py,
 test_environments.py, test_experiment_base_class.py), with the oracle as the checker."""
+import os
 import random
 
 import numpy as np
@@ -458,3 +459,20 @@ def test_figure_eight_wave_attenuation_po_env_vectorised():
     np.testing.assert_allclose(r_k[-1].cpu().numpy(), r_ref.astype(np.float32), atol=1e-5)
     np.testing.assert_array_equal(d_k[-1].cpu().numpy().astype(bool), d_ref)
     vec.close()
+
+
+def test_examples_simulate_script_runs_reference_style_configs(tmp_path):
+    """examples/simulate.py ring / figure_eight: experiment files written with ``from flow...`` imports run through
+    flow_amd.install_as_flow() and Experiment.run, and the ring run leaves an emission CSV behind."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "simulate.py"), "ring", "--gen_emission"],
+                         cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "steps/second" in out.stdout and "Round 0, return" in out.stdout
+    files = os.listdir(os.path.join(str(tmp_path), "data"))
+    assert len(files) == 1 and files[0].endswith("-emission.csv")
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "simulate.py"), "figure_eight"],
+                         cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
