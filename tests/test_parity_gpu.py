@@ -554,6 +554,51 @@ def test_fuzz_random_single_lane_configs_bit_exact(seed):
     sim.close()
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_rollout_kernel_heterogeneous_idm_bit_exact(seed):
+    """k_rollout_idm with a different IDM parameter set in every slot (several v0 / a / b / delta / s0 / T:
+    each divisor is verified on the host before the reciprocal path is used), per-replica ring lengths, random
+    initial speeds including vehicles at rest, against the oracle over a launch that is not a multiple of 32."""
+    import torch
+    rng = np.random.default_rng(9000 + seed)
+    N = int(rng.integers(2, 41))
+    R = int(rng.integers(1, 30))
+    K = int(rng.integers(20, 90))
+    lengths = np.round(max(80.0, N * 9.0) + rng.uniform(0, 30, R))
+    veh = []
+    for i in range(N):
+        veh.append(idm_vehicle(p=[float(rng.choice([20, 25, 30, 33.3])), float(rng.uniform(0.6, 1.4)),
+                                  float(rng.choice([0.8, 1.0, 1.3])), float(rng.choice([1.5, 2.0])),
+                                  float(rng.choice([4, 4, 4, 2])) if seed % 2 else 4.0, float(rng.choice([1.5, 2.0, 2.5])),
+                                  0, 0], length=float(rng.choice([5.0, 4.5]))))
+    frac = np.sort(rng.uniform(0, 1, N))
+    room = lengths[:, None] + 0.4 - 6.0 * N
+    X = np.cumsum(np.full((R, N), 6.0), axis=1) - 6.0 + frac[None, :] * room * 0.999
+    V = rng.uniform(0, 6, (R, N)) * (rng.uniform(0, 1, (R, N)) > 0.3)
+    spec = dict(num_replicas=R, num_vehicles=N, num_rl=0, sim_step=0.1, junction_length=0.1, ring_length=lengths,
+                max_speed=30.0, env=S.ENV_ACCEL, target_velocity=float(rng.choice([5, 10])), action_low=-1.0,
+                action_high=1.0, horizon=K - 3, warmup_steps=0, sims_per_step=1, vehicles=veh, init_pos=X, init_vel=V,
+                crash_gap=float(rng.choice([0.0, 1.0])))
+    sim = make(spec, "f32")
+    sim.reset()
+    dev = torch.device("cuda:0")
+    obs = torch.empty((K, R, 2 * N), dtype=torch.float32, device=dev)
+    rew = torch.empty((K, R), dtype=torch.float32, device=dev)
+    done = torch.empty((K, R), dtype=torch.uint8, device=dev)
+    sim.rollout_dev(K, obs, rew, done, obs_every_step=True)
+    sim.sync()
+    ora = S.RingOracle(spec, np.float32)
+    ora.reset()
+    for k in range(K):
+        o, r, d = ora.step(None)
+        np.testing.assert_array_equal(obs[k].cpu().numpy(), o.astype(np.float32))
+        np.testing.assert_array_equal(rew[k].cpu().numpy(), r.astype(np.float32))
+        np.testing.assert_array_equal(done[k].cpu().numpy().astype(bool), d)
+    np.testing.assert_array_equal(sim.pos, ora.x)
+    np.testing.assert_array_equal(sim.vel, ora.v)
+    sim.close()
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_fuzz_random_multilane_configs_bit_exact(seed):
     """Seeded random multi-lane rings: lanes, vehicles per lane, controller mix, RL lane-change tapes with
