@@ -230,7 +230,7 @@ def main():
 
     def after_fragment(o, r, d):
         if gather is not None:
-            gather(o, r, d)
+            gather.launch(o, r, d)       # overlaps the next fragment; the learner reads gather.result() one fragment late
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -239,9 +239,13 @@ def main():
         torch.cuda.synchronize(device)
 
     runner.run(args.warmup, after_fragment=after_fragment)
+    if gather is not None:
+        gather.wait()
     barrier()
     t0 = time.perf_counter()
     runner.run(args.steps, record=True, after_fragment=after_fragment)
+    if gather is not None:
+        gather.wait()
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:

@@ -29,10 +29,27 @@ class ObservationGather(object):
         self.recv = torch.empty((self.W * self.R, self.D + 2), dtype=torch.float32, device=device)
 
     def __call__(self, obs, rew, done):
+        """Blocking gather: pack, all-gather, return the unpacked global batch."""
+        self.launch(obs, rew, done)
+        return self.result()
+
+    def launch(self, obs, rew, done):
+        """Pack and start the all-gather without waiting for it (the simulator's next fragment overlaps the
+        collective); the previous gather, if any, is completed first because it owns ``send`` / ``recv``."""
+        self.wait()
         self.send[:, :self.D].copy_(obs)
         self.send[:, self.D].copy_(rew)
         self.send[:, self.D + 1].copy_(done)
-        dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+        self._work = dist.all_gather_into_tensor(self.recv, self.send, group=self.group, async_op=True)
+
+    def wait(self):
+        work = getattr(self, "_work", None)
+        if work is not None:
+            work.wait()
+            self._work = None
+
+    def result(self):
+        self.wait()
         return self.unpack()
 
     def unpack(self):
