@@ -604,9 +604,29 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
   float* rrow = rew + rr;
   uint8_t* drow = done + rr;
 
+  // RL actions are read one step ahead (a dependent HBM load at the top of every step would be fully exposed:
+  // a replica-wave has at most a few companions on its SIMD): a_own = this lane's command, a_red = the action
+  // of column `ii` (what the WaveAttenuation reward averages)
+  const bool use_act = !FAST && actions != nullptr;
+  const bool rl_lane = sl.ctrl == FS_CTRL_RL;
+  const int own_col = sl.rl_index < 0 ? 0 : sl.rl_index;
+  const bool red_lane = ii < s.num_rl && i < N;
+  float a_own_next = 0.0f, a_red_next = 0.0f;
+  if (use_act && num_steps > 0) {
+    const float* a0 = actions + size_t(rr) * s.num_rl;
+    if (rl_lane) a_own_next = a0[own_col];
+    if (red_lane) a_red_next = a0[ii];
+  }
+
   for (int step = 0; step < num_steps; ++step) {
     // ---- RL action of this lane (envs/base.py:599-615) -------------------
-    const float* act = (!FAST && actions) ? actions + size_t(step) * act_stride + size_t(rr) * s.num_rl : nullptr;
+    const float* act = use_act ? actions + size_t(step) * act_stride + size_t(rr) * s.num_rl : nullptr;
+    const float a_own = a_own_next, a_red = a_red_next;
+    if (use_act && step + 1 < num_steps) {
+      const float* an = actions + size_t(step + 1) * act_stride + size_t(rr) * s.num_rl;
+      if (rl_lane) a_own_next = an[own_col];
+      if (red_lane) a_red_next = an[ii];
+    }
     bool crashed = false;
     for (int sub = 0; sub < sims_per_step; ++sub) {
       const bool live = live_replica && !crashed;
@@ -622,9 +642,8 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
           hf = foll_read<SEG>(h, seg, wrap_foll, N);
         }
         if (flags & FLAG_NEED_MEAN) mean_v = seg_sum<SEG>(valid ? v : T(0)) / T(N);
-        T a_rl = T(0);
-        const bool have_rl = (sl.ctrl == FS_CTRL_RL) && (act != nullptr);
-        if (have_rl) a_rl = T(act[sl.rl_index < 0 ? 0 : sl.rl_index]);
+        const bool have_rl = rl_lane && (act != nullptr);
+        const T a_rl = have_rl ? T(a_own) : T(0);
         acc = control_accel(s, sl, flags, v, vl, h, has, vf, hf, mean_v, x, quarter, qj, have_rl, a_rl,
                             live && i < N, rr, ii, nctr, cst, commanded);
       }
@@ -715,8 +734,8 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
           reward = T(0);
         } else {
           T a = T(0);
-          if (ii < s.num_rl && i < N) {
-            a = T(act[ii]);
+          if (red_lane) {
+            a = T(a_red);
             if (s.clip_actions) a = tmin(tmax(a, s.act_lo), s.act_hi);
             a = tabs(a);
           }
