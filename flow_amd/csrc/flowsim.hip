@@ -68,7 +68,8 @@ struct SimBase {
 template <typename T>
 struct Sim : SimBase {
   fs::DevView<T> dv{};
-  std::vector<T> h_len;   // vehicle lengths (host copy, for FS_FIELD_HEADWAY)
+  std::vector<T> h_len;        // vehicle lengths (host copy, for FS_FIELD_HEADWAY)
+  std::vector<T> h_ring_len;   // ring lengths (host copy, for the divisor verification)
 
   template <typename U>
   int dev_alloc(U** out, size_t count) {
@@ -120,6 +121,7 @@ struct Sim : SimBase {
     if ((rc = upload(&dv.init_pos, ipos))) return rc;
     if ((rc = upload(&dv.init_vel, ivel))) return rc;
     if ((rc = upload(&dv.ring_len, rlen))) return rc;
+    h_ring_len = rlen;
 
     std::vector<int32_t> ctrl(N), fsafe(N), smode(N), rli(N), pisi(N, -1);
     int n_pis = 0;
@@ -299,9 +301,7 @@ struct Sim : SimBase {
       add(2.0f * std::sqrt(float(veh[i].p[2]) * float(veh[i].p[3])));
       if (!(float(veh[i].p[5]) >= 1e-3f) || !(float(veh[i].p[5]) <= 1e6f)) return false;
     }
-    std::vector<T> rl(size_t(dv.R));
-    if (hipMemcpy(rl.data(), dv.ring_len, rl.size() * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) return false;
-    for (T b : rl) {
+    for (T b : h_ring_len) {                    // host copy: no HIP call on the launch path
       const float L = float(b) + 4.0f * float(dv.jlen);
       if (!(L >= 1.0f)) return false;        // keeps x = 0 or x >= ulp(L)/2 out of the tiny range
       add(L);
@@ -473,7 +473,10 @@ struct Sim : SimBase {
     if (!p) return fail(FS_ERR_INVALID, "fs_set_state: unknown field");
     if (bytes != count * sizeof(T)) return fail(FS_ERR_INVALID, "fs_set_state: wrong byte count");
     HIP_TRY(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
-    if (field == FS_FIELD_RING_LENGTH) fastdiv_state = -1;
+    if (field == FS_FIELD_RING_LENGTH) {
+      h_ring_len.assign(static_cast<const T*>(src), static_cast<const T*>(src) + count);
+      fastdiv_state = -1;
+    }
     return FS_OK;
   }
 };
