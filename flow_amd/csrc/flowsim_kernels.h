@@ -853,10 +853,10 @@ __global__ __launch_bounds__(1024) void k_rollout_idm(DevView<T> s, int num_step
                                                       float* __restrict__ rew, uint8_t* __restrict__ done,
                                                       float* __restrict__ dump) {
   // Waves are independent (no LDS, no barrier); the block size only decides how many of them share a
-  // CU.  Measured at R = 4096 (2048 waves, 1500 steps): 64 threads 0.768 ms, 256: 0.751, 512: 0.745,
-  // 768: 0.943, 1024: 1.170 -- packing 4 waves per SIMD onto half the CUs is SLOWER, i.e. the loop is
-  // bound by VALU issue (~3.8 cycles per instruction of this mix: IEEE division sequences, v_rcp,
-  // DPP), not by exposed latency; 512 keeps every CU busy with 2 waves per SIMD (Sim::rollout_block).
+  // CU.  Measured at R = 4096 (2048 waves, 1500 steps): 64 threads 0.657 ms, 256: 0.626, 512: 0.621,
+  // 768: 0.737, 1024: 0.909 -- packing 4 waves per SIMD onto half the CUs is SLOWER, i.e. the loop is
+  // bound by VALU issue (~4 cycles per instruction of this mix), not by exposed latency; 512 keeps every
+  // CU busy with 2 waves per SIMD (Sim::rollout_block, profiles/r01_sweep_block.log).
   constexpr int RPW = 64 / SEG;
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
