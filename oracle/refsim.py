@@ -101,6 +101,83 @@ def pisaturation_step(hist, n, v_cmd, v, v_lead, h, dt, max_accel, do_update, dt
     n[upd] = n_new[upd]
     return accel, np.where(upd, new_cmd, v_cmd)
 
+def controller_dispatch(o, v, v_lead, h, has_lead, v_follow, h_follow, rl_value, rl_commanded, on_edge, active,
+                        mean_speed, noise_slot=None):
+    """BaseController.get_action for every slot (base_controller.py:70-118) plus the RL command
+    (envs/base.py:599-615), shared by every oracle class.
+
+    All array arguments are [R,N] except ``active`` [R] and ``mean_speed`` (a callable returning the
+    [R] mean speed NonLocalFollowerStopper reads, velocity_controllers.py:127).  ``rl_value`` /
+    ``rl_commanded``: the (unclipped) action and whether an action exists for the slot this sub-step;
+    ``on_edge`` is False while the vehicle is on an internal edge and junction_mode is on
+    (base_controller.py:98-99).  Returns (acc [R,N], commanded [R,N]); advances the LAC / PISaturation
+    state of ``o`` for active replicas."""
+    T = o.dt_.type
+    R, N = v.shape
+    acc = np.zeros((R, N), dtype=o.dt_)
+    commanded = np.zeros((R, N), dtype=bool)
+    ms = None
+    for i, vs in enumerate(o.veh):
+        ct = vs["controller"]
+        p = vs.get("p", [0] * 8)
+        sl = (slice(None), i)
+        if ct == CTRL_SIM:
+            continue
+        if ct == CTRL_RL:
+            a = rl_value[sl].astype(o.dt_)
+            if o.spec.get("clip_actions", True):                  # envs/base.py:584-588
+                a = np.clip(a, T(o.spec["action_low"]), T(o.spec["action_high"]))
+            acc[sl] = np.where(rl_commanded[sl], a, T(0))
+            commanded[sl] = rl_commanded[sl]
+            continue
+        args = (v[sl], v_lead[sl], h[sl], has_lead[sl])
+        cmd = on_edge[sl]
+        if ct == CTRL_IDM:
+            a = C.idm(*args, v0=p[0], T=p[1], a=p[2], b=p[3], delta=p[4], s0=p[5])
+        elif ct == CTRL_CFM:
+            a = C.cfm(*args, vs["max_accel"], k_d=p[0], k_v=p[1], k_c=p[2], d_des=p[3], v_des=p[4])
+        elif ct == CTRL_BCM:
+            a = C.bcm(*args, v_follow[sl], h_follow[sl], vs["max_accel"],
+                      k_d=p[0], k_v=p[1], k_c=p[2], d_des=p[3], v_des=p[4])
+        elif ct == CTRL_LAC:
+            a = C.lac(v[sl], v_lead[sl], h[sl], o.veh_len[i], o.lac_a[sl], o.dt,
+                      k_1=p[0], k_2=p[1], h_gap=p[2], tau=p[3])
+        elif ct == CTRL_OVM:
+            a = C.ovm(*args, vs["max_accel"], alpha=p[0], beta=p[1], h_st=p[2], h_go=p[3], v_max=p[4])
+        elif ct == CTRL_LINEAR_OVM:
+            a = C.linear_ovm(v[sl], h[sl], v_max=p[0], adaptation=p[1], h_st=p[2])
+        elif ct == CTRL_GIPPS:
+            a = C.gipps(v[sl], v_lead[sl], h[sl], o.dt, v0=p[0], acc=p[1], b=p[2], b_l=p[3],
+                        s0=p[4], tau=p[5])
+        elif ct == CTRL_FOLLOWER_STOPPER:
+            a = C.follower_stopper(*args, o.dt, v_des=p[0])
+        elif ct == CTRL_NONLOCAL_FOLLOWER_STOPPER:
+            if ms is None:
+                ms = mean_speed()
+            a = C.follower_stopper(*args, o.dt, v_des=ms)
+        elif ct == CTRL_PISATURATION:
+            a, o.lac_a[sl] = pisaturation_step(o.pis_hist[:, i, :], o.pis_n[:, i], o.lac_a[sl], v[sl],
+                                               v_lead[sl], h[sl], o.dt, vs["max_accel"], cmd & active, o.dt_)
+        else:
+            raise ValueError("unknown controller %r" % ct)
+        if ct == CTRL_LAC:                                        # state only advances when get_accel ran
+            o.lac_a[sl] = np.where(cmd & active, a, o.lac_a[sl])
+        if vs.get("noise", 0) > 0:                                # base_controller.py:109-110
+            slot = np.full(R, i, dtype=np.uint32) if noise_slot is None else noise_slot[sl].astype(np.uint32)
+            g = gaussian_noise(o.spec.get("seed", 0), np.arange(R, dtype=np.uint32), slot,
+                               o.step_counter.astype(np.uint32), o.dt_)
+            a = a + T(vs["noise"]) * g
+        fs = vs.get("fail_safe", FAILSAFE_NONE)
+        hl = has_lead[sl]
+        nveh = 2 if N > 1 else 1                                  # the fail-safes only ask "is N == 1"
+        if fs == FAILSAFE_INSTANTANEOUS:                          # base_controller.py:113-114
+            a = np.where(hl, C.failsafe_instantaneous(a, v[sl], h[sl], hl, o.dt, nveh), a)
+        elif fs == FAILSAFE_SAFE_VELOCITY:                        # base_controller.py:115-116
+            a = np.where(hl, C.failsafe_safe_velocity(a, v[sl], v_lead[sl], h[sl], o.dt, vs.get("delay", 0), nveh), a)
+        acc[sl] = a
+        commanded[sl] = cmd
+    return acc, commanded
+
 
 class RingOracle:
     """Batched closed-loop (ring) oracle.  ``spec`` is a plain dict:
@@ -257,83 +334,36 @@ class RingOracle:
         return obs
 
     # ------------------------------------------------------------------ step
+    def _rl_inputs(self, actions, per_rl=1):
+        """(rl_value [R,N], rl_commanded [R,N]) of the static slot -> action-column mapping."""
+        rl_value = np.zeros((self.R, self.N), dtype=self.dt_)
+        rl_cmd = np.zeros((self.R, self.N), dtype=bool)
+        if actions is not None:
+            acts = np.asarray(actions, dtype=self.dt_)
+            for i, vs in enumerate(self.veh):
+                if vs["controller"] == CTRL_RL:
+                    rl_value[:, i] = acts[:, per_rl * vs["rl_index"]]
+                    rl_cmd[:, i] = True
+        return rl_value, rl_cmd
+
+    def _on_edge(self):
+        if not self.junction_mode:
+            return np.ones((self.R, self.N), dtype=bool)
+        return ~self.in_junction(self.x)
+
     def _accelerations(self, actions, active):
-        """Returns (acc [R,N], commanded [R,N])."""
+        """Returns (acc [R,N], commanded [R,N], h, v_lead, has_lead)."""
         T = self.dt_.type
         R, N = self.R, self.N
-        x, v = self.x, self.v
+        v = self.v
         has_lead = np.full((R, N), N > 1)
         h = self.headways()
         v_lead = np.roll(v, -1, axis=1) if N > 1 else v
         v_follow = np.roll(v, 1, axis=1)
         h_follow = np.roll(h, 1, axis=1)
-        acc = np.zeros((R, N), dtype=self.dt_)
-        commanded = np.zeros((R, N), dtype=bool)
-        mean_speed = None
-        for i, vs in enumerate(self.veh):
-            ct = vs["controller"]
-            p = vs.get("p", [0] * 8)
-            sl = (slice(None), i)
-            a = None
-            if ct == CTRL_SIM:
-                continue
-            if ct == CTRL_RL:
-                if actions is None:
-                    continue
-                a = np.asarray(actions, dtype=self.dt_)[:, vs["rl_index"]]
-                if self.spec.get("clip_actions", True):              # envs/base.py:584-588
-                    a = np.clip(a, T(self.spec["action_low"]), T(self.spec["action_high"]))
-                acc[sl] = a
-                commanded[sl] = True
-                continue
-            args = (v[sl], v_lead[sl], h[sl], has_lead[sl])
-            if ct == CTRL_IDM:
-                a = C.idm(*args, v0=p[0], T=p[1], a=p[2], b=p[3], delta=p[4], s0=p[5])
-            elif ct == CTRL_CFM:
-                a = C.cfm(*args, vs["max_accel"], k_d=p[0], k_v=p[1], k_c=p[2], d_des=p[3], v_des=p[4])
-            elif ct == CTRL_BCM:
-                a = C.bcm(*args, v_follow[sl], h_follow[sl], vs["max_accel"],
-                          k_d=p[0], k_v=p[1], k_c=p[2], d_des=p[3], v_des=p[4])
-            elif ct == CTRL_LAC:
-                a = C.lac(v[sl], v_lead[sl], h[sl], self.veh_len[i], self.lac_a[sl], self.dt,
-                          k_1=p[0], k_2=p[1], h_gap=p[2], tau=p[3])
-            elif ct == CTRL_OVM:
-                a = C.ovm(*args, vs["max_accel"], alpha=p[0], beta=p[1], h_st=p[2], h_go=p[3], v_max=p[4])
-            elif ct == CTRL_LINEAR_OVM:
-                a = C.linear_ovm(v[sl], h[sl], v_max=p[0], adaptation=p[1], h_st=p[2])
-            elif ct == CTRL_GIPPS:
-                a = C.gipps(v[sl], v_lead[sl], h[sl], self.dt, v0=p[0], acc=p[1], b=p[2], b_l=p[3],
-                            s0=p[4], tau=p[5])
-            elif ct == CTRL_FOLLOWER_STOPPER:
-                a = C.follower_stopper(*args, self.dt, v_des=p[0])
-            elif ct == CTRL_NONLOCAL_FOLLOWER_STOPPER:
-                if mean_speed is None:
-                    mean_speed = Rw.tree_sum(v) / T(N)               # velocity_controllers.py:127
-                a = C.follower_stopper(*args, self.dt, v_des=mean_speed)
-            elif ct == CTRL_PISATURATION:
-                pre_cmd = ~self.in_junction(x[sl]) if self.junction_mode else np.ones(R, dtype=bool)
-                a, self.lac_a[sl] = pisaturation_step(self.pis_hist[:, i, :], self.pis_n[:, i], self.lac_a[sl], v[sl],
-                                                      v_lead[sl], h[sl], self.dt, vs["max_accel"], pre_cmd & active,
-                                                      self.dt_)
-            else:
-                raise ValueError("unknown controller %r" % ct)
-            cmd = np.ones(R, dtype=bool)
-            if self.junction_mode:                                   # base_controller.py:98-99
-                cmd = ~self.in_junction(x[sl])
-            if ct == CTRL_LAC:                                       # state only advances when get_accel ran
-                self.lac_a[sl] = np.where(cmd & active, a, self.lac_a[sl])
-            if vs.get("noise", 0) > 0:                               # base_controller.py:109-110
-                g = gaussian_noise(self.spec.get("seed", 0), np.arange(R, dtype=np.uint32),
-                                   np.full(R, i, dtype=np.uint32),
-                                   self.step_counter.astype(np.uint32), self.dt_)
-                a = a + T(vs["noise"]) * g
-            fs = vs.get("fail_safe", FAILSAFE_NONE)
-            if fs == FAILSAFE_INSTANTANEOUS:                         # base_controller.py:113-114
-                a = C.failsafe_instantaneous(a, v[sl], h[sl], has_lead[sl], self.dt, N)
-            elif fs == FAILSAFE_SAFE_VELOCITY:                       # base_controller.py:115-116
-                a = C.failsafe_safe_velocity(a, v[sl], v_lead[sl], h[sl], self.dt, vs.get("delay", 0), N)
-            acc[sl] = a
-            commanded[sl] = cmd
+        rl_value, rl_cmd = self._rl_inputs(actions)
+        acc, commanded = controller_dispatch(self, v, v_lead, h, has_lead, v_follow, h_follow, rl_value, rl_cmd,
+                                             self._on_edge(), active, lambda: Rw.tree_sum(v) / T(N))
         return acc, commanded, h, v_lead, has_lead
 
     def _substep(self, actions, active):
@@ -502,8 +532,7 @@ class MultiLaneRingOracle(RingOracle):
     def _accelerations(self, actions, active):
         """As RingOracle._accelerations with the dynamic own-lane neighbours."""
         T = self.dt_.type
-        R, N = self.R, self.N
-        x, v = self.x, self.v
+        v = self.v
         lead, foll, has_lead, h, _ = self.neighbours()
         li = np.where(lead >= 0, lead, 0)
         fi = np.where(foll >= 0, foll, 0)
@@ -511,74 +540,10 @@ class MultiLaneRingOracle(RingOracle):
         v_lead = np.where(lead >= 0, np.take_along_axis(v, li, 1), T(-1001))
         v_follow = np.take_along_axis(v, fi, 1)
         h_follow = np.take_along_axis(h, fi, 1)
-        acc = np.zeros((R, N), dtype=self.dt_)
-        commanded = np.zeros((R, N), dtype=bool)
-        mean_speed = None
         per_rl = 2 if self.spec.get("env") == ENV_LANE_CHANGE_ACCEL else 1
-        for i, vs in enumerate(self.veh):
-            ct = vs["controller"]
-            p = vs.get("p", [0] * 8)
-            sl = (slice(None), i)
-            if ct == CTRL_SIM:
-                continue
-            if ct == CTRL_RL:
-                if actions is None:
-                    continue
-                a = np.asarray(actions, dtype=self.dt_)[:, per_rl * vs["rl_index"]]
-                if self.spec.get("clip_actions", True):
-                    a = np.clip(a, T(self.spec["action_low"]), T(self.spec["action_high"]))
-                acc[sl] = a
-                commanded[sl] = True
-                continue
-            args = (v[sl], v_lead[sl], h[sl], has_lead[sl])
-            if ct == CTRL_IDM:
-                a = C.idm(*args, v0=p[0], T=p[1], a=p[2], b=p[3], delta=p[4], s0=p[5])
-            elif ct == CTRL_CFM:
-                a = C.cfm(*args, vs["max_accel"], k_d=p[0], k_v=p[1], k_c=p[2], d_des=p[3], v_des=p[4])
-            elif ct == CTRL_BCM:
-                a = C.bcm(*args, v_follow[sl], h_follow[sl], vs["max_accel"],
-                          k_d=p[0], k_v=p[1], k_c=p[2], d_des=p[3], v_des=p[4])
-            elif ct == CTRL_LAC:
-                a = C.lac(v[sl], v_lead[sl], h[sl], self.veh_len[i], self.lac_a[sl], self.dt,
-                          k_1=p[0], k_2=p[1], h_gap=p[2], tau=p[3])
-            elif ct == CTRL_OVM:
-                a = C.ovm(*args, vs["max_accel"], alpha=p[0], beta=p[1], h_st=p[2], h_go=p[3], v_max=p[4])
-            elif ct == CTRL_LINEAR_OVM:
-                a = C.linear_ovm(v[sl], h[sl], v_max=p[0], adaptation=p[1], h_st=p[2])
-            elif ct == CTRL_GIPPS:
-                a = C.gipps(v[sl], v_lead[sl], h[sl], self.dt, v0=p[0], acc=p[1], b=p[2], b_l=p[3],
-                            s0=p[4], tau=p[5])
-            elif ct == CTRL_FOLLOWER_STOPPER:
-                a = C.follower_stopper(*args, self.dt, v_des=p[0])
-            elif ct == CTRL_NONLOCAL_FOLLOWER_STOPPER:
-                if mean_speed is None:
-                    mean_speed = Rw.tree_sum(v) / T(N)
-                a = C.follower_stopper(*args, self.dt, v_des=mean_speed)
-            elif ct == CTRL_PISATURATION:
-                pre_cmd = ~self.in_junction(x[sl]) if self.junction_mode else np.ones(R, dtype=bool)
-                a, self.lac_a[sl] = pisaturation_step(self.pis_hist[:, i, :], self.pis_n[:, i], self.lac_a[sl], v[sl],
-                                                      v_lead[sl], h[sl], self.dt, vs["max_accel"], pre_cmd & active,
-                                                      self.dt_)
-            else:
-                raise ValueError("unknown controller %r" % ct)
-            cmd = np.ones(R, dtype=bool)
-            if self.junction_mode:
-                cmd = ~self.in_junction(x[sl])
-            if ct == CTRL_LAC:
-                self.lac_a[sl] = np.where(cmd & active, a, self.lac_a[sl])
-            if vs.get("noise", 0) > 0:
-                g = gaussian_noise(self.spec.get("seed", 0), np.arange(R, dtype=np.uint32),
-                                   np.full(R, i, dtype=np.uint32),
-                                   self.step_counter.astype(np.uint32), self.dt_)
-                a = a + T(vs["noise"]) * g
-            fs = vs.get("fail_safe", FAILSAFE_NONE)
-            hl = has_lead[sl]
-            if fs == FAILSAFE_INSTANTANEOUS:
-                a = np.where(hl, C.failsafe_instantaneous(a, v[sl], h[sl], hl, self.dt, N), a)
-            elif fs == FAILSAFE_SAFE_VELOCITY:
-                a = np.where(hl, C.failsafe_safe_velocity(a, v[sl], v_lead[sl], h[sl], self.dt, vs.get("delay", 0), N), a)
-            acc[sl] = a
-            commanded[sl] = cmd
+        rl_value, rl_cmd = self._rl_inputs(actions, per_rl)
+        acc, commanded = controller_dispatch(self, v, v_lead, h, has_lead, v_follow, h_follow, rl_value, rl_cmd,
+                                             self._on_edge(), active, lambda: Rw.tree_sum(v) / T(self.N))
         return acc, commanded, h, v_lead, has_lead
 
     # ---- ML3: the lane the RL vehicles are in after this sub-step's commands
