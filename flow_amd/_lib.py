@@ -11,7 +11,7 @@ from .utils.exceptions import FatalFlowError
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libflowsim.so")
 
-FS_ABI_VERSION = 3
+FS_ABI_VERSION = 4
 FS_MAX_CTRL_PARAMS = 8
 
 # error codes
@@ -25,15 +25,18 @@ FS_F32, FS_F64 = 0, 1
 # enum fs_failsafe
 FS_FAILSAFE_NONE, FS_FAILSAFE_INSTANTANEOUS, FS_FAILSAFE_SAFE_VELOCITY = range(3)
 # enum fs_env
-FS_ENV_ACCEL, FS_ENV_WAVE_ATTENUATION, FS_ENV_WAVE_ATTENUATION_PO, FS_ENV_LANE_CHANGE_ACCEL = range(4)
+(FS_ENV_ACCEL, FS_ENV_WAVE_ATTENUATION, FS_ENV_WAVE_ATTENUATION_PO, FS_ENV_LANE_CHANGE_ACCEL, FS_ENV_MERGE_PO,
+ FS_ENV_MERGE_MA) = range(6)
 # enum fs_network / fs_integrator
-FS_NET_RING, FS_NET_FIGURE_EIGHT = 0, 1
+FS_NET_RING, FS_NET_FIGURE_EIGHT, FS_NET_MERGE = 0, 1, 2
 FS_MAX_SEGMENTS = 16
+FS_MAX_INFLOWS = 8
 FS_EULER, FS_BALLISTIC = 0, 1
 # enum fs_field
 (FS_FIELD_POS, FS_FIELD_VEL, FS_FIELD_HEADWAY, FS_FIELD_PREV_VEL, FS_FIELD_ACCEL, FS_FIELD_TIME,
  FS_FIELD_RING_LENGTH, FS_FIELD_INIT_POS, FS_FIELD_INIT_VEL, FS_FIELD_CTRL_STATE, FS_FIELD_LANE,
- FS_FIELD_LAST_LC, FS_FIELD_LEADER, FS_FIELD_INIT_LANE) = range(14)
+ FS_FIELD_LAST_LC, FS_FIELD_LEADER, FS_FIELD_INIT_LANE, FS_FIELD_ROUTE, FS_FIELD_SEQ, FS_FIELD_ORIGIN,
+ FS_FIELD_FOLLOWER, FS_FIELD_CTL_SEQ, FS_FIELD_COUNTERS, FS_FIELD_ARRIVED_RL) = range(21)
 
 EXPORTS = ["fs_create", "fs_destroy", "fs_last_error", "fs_abi_version", "fs_obs_dim", "fs_action_dim", "fs_set_stream",
            "fs_use_own_stream", "fs_sync", "fs_reset", "fs_reset_dev", "fs_step", "fs_step_dev", "fs_rollout_dev",
@@ -42,7 +45,8 @@ EXPORTS = ["fs_create", "fs_destroy", "fs_last_error", "fs_abi_version", "fs_obs
 
 class fs_vehicle_spec(C.Structure):
     _fields_ = [("controller", C.c_int32), ("fail_safe", C.c_int32), ("speed_mode", C.c_int32),
-                ("rl_index", C.c_int32), ("p", C.c_double * FS_MAX_CTRL_PARAMS), ("noise", C.c_double),
+                ("rl_index", C.c_int32), ("type", C.c_int32), ("reserved", C.c_int32),
+                ("p", C.c_double * FS_MAX_CTRL_PARAMS), ("noise", C.c_double),
                 ("delay", C.c_double), ("max_accel", C.c_double), ("max_decel", C.c_double),
                 ("length", C.c_double), ("sumo_tau", C.c_double), ("sumo_min_gap", C.c_double),
                 ("sumo_max_speed", C.c_double), ("initial_speed", C.c_double)]
@@ -50,7 +54,13 @@ class fs_vehicle_spec(C.Structure):
 
 class fs_segment(C.Structure):
     _fields_ = [("start", C.c_double), ("flow_start", C.c_double), ("flow_slope", C.c_double),
-                ("internal", C.c_int32), ("reserved", C.c_int32)]
+                ("internal", C.c_int32), ("route", C.c_int32)]
+
+
+class fs_inflow(C.Structure):
+    _fields_ = [("type", C.c_int32), ("route", C.c_int32), ("number", C.c_int32), ("reserved", C.c_int32),
+                ("period", C.c_double), ("begin", C.c_double), ("end", C.c_double), ("depart_speed", C.c_double),
+                ("depart_pos", C.c_double)]
 
 
 class fs_junction(C.Structure):
@@ -74,8 +84,12 @@ class fs_config(C.Structure):
                 ("vehicles", C.POINTER(fs_vehicle_spec)),
                 ("ring_length", C.POINTER(C.c_double)), ("init_pos", C.POINTER(C.c_double)),
                 ("init_vel", C.POINTER(C.c_double)), ("init_lane", C.POINTER(C.c_int32)),
-                ("segments", C.POINTER(fs_segment)), ("num_segments", C.c_int32), ("reserved2", C.c_int32),
-                ("junction", fs_junction)]
+                ("segments", C.POINTER(fs_segment)), ("num_segments", C.c_int32), ("num_inflows", C.c_int32),
+                ("junction", fs_junction),
+                ("inflows", C.POINTER(fs_inflow)), ("init_alive", C.POINTER(C.c_uint8)),
+                ("route_start", C.c_double * 2), ("merge_x", C.c_double), ("box_in", C.c_double),
+                ("end_x", C.c_double), ("net_length", C.c_double), ("ma_apply_actions", C.c_int32),
+                ("reserved3", C.c_int32)]
 
 
 _lib = None

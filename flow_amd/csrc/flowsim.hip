@@ -19,6 +19,7 @@
 
 #include "flowsim.h"
 #include "flowsim_kernels.h"
+#include "flowsim_open.h"
 
 namespace {
 
@@ -41,6 +42,8 @@ struct SimBase {
   fs_config cfg{};
   std::vector<fs_vehicle_spec> veh;
   std::vector<fs_segment> segs;
+  std::vector<fs_inflow> inflows;
+  std::vector<uint8_t> init_alive;
   int obs_dim = 0;
   int act_dim = 0;
   int seg = 0;
@@ -54,6 +57,7 @@ struct SimBase {
   uint8_t* d_mask = nullptr;
   float* d_dump = nullptr;      // scratch words the idle lanes of k_rollout_idm store to
   std::vector<void*> allocs;
+  int after_reset = 0;          // open networks: the next zero-step launch follows a reset (update(reset=True))
   bool force_generic = false;   // FLOWSIM_FORCE_GENERIC=1: never take the specialised kernels (tests)
   bool no_fastdiv = false;      // FLOWSIM_NO_FASTDIV=1: keep the IEEE division sequence in k_rollout_idm
   int rollout_block = 512;      // threads per block of k_rollout_idm (FLOWSIM_ROLLOUT_BLOCK overrides; sweep: DESIGN.md)
@@ -68,6 +72,8 @@ struct SimBase {
 template <typename T>
 struct Sim : SimBase {
   fs::DevView<T> dv{};
+  fs::OpenView<T> ov{};        // open networks (FS_NET_MERGE) only
+  bool open_net = false;
   std::vector<T> h_len;        // vehicle lengths (host copy, for FS_FIELD_HEADWAY)
   std::vector<T> h_ring_len;   // ring lengths (host copy, for the divisor verification)
 
@@ -117,7 +123,7 @@ struct Sim : SimBase {
       ipos[e] = T(cfg.init_pos[e]);
       ivel[e] = cfg.init_vel ? T(cfg.init_vel[e]) : T(veh[e % N].initial_speed);
     }
-    for (int r = 0; r < R; ++r) rlen[r] = T(cfg.ring_length[r]);
+    for (int r = 0; r < R; ++r) rlen[r] = cfg.ring_length ? T(cfg.ring_length[r]) : T(0);
     if ((rc = upload(&dv.init_pos, ipos))) return rc;
     if ((rc = upload(&dv.init_vel, ivel))) return rc;
     if ((rc = upload(&dv.ring_len, rlen))) return rc;
@@ -241,6 +247,9 @@ struct Sim : SimBase {
     dv.act_hi = T(cfg.action_high);
     dv.po_max_length = T(cfg.po_max_length);
 
+    open_net = (cfg.network == FS_NET_MERGE);
+    if (open_net && (rc = init_open())) return rc;
+
     // host-API staging
     if ((rc = dev_alloc(&d_actions, size_t(R) * (act_dim > 0 ? act_dim : 1)))) return rc;
     if ((rc = dev_alloc(&d_obs, size_t(R) * obs_dim))) return rc;
@@ -249,6 +258,77 @@ struct Sim : SimBase {
     if ((rc = dev_alloc(&d_mask, size_t(R)))) return rc;
     if ((rc = dev_alloc(&d_dump, size_t(256)))) return rc;
     return launch_reset(nullptr);
+  }
+
+  // ---- open networks: per-slot bookkeeping arrays, route tables, inflow table ------------------
+  int init_open() {
+    const int R = cfg.num_replicas, N = cfg.num_vehicles;
+    const size_t RN = size_t(R) * N;
+    int rc;
+    if ((rc = dev_alloc(&ov.seq, RN))) return rc;
+    if ((rc = dev_alloc(&ov.origin, RN))) return rc;
+    if ((rc = dev_alloc(&ov.foll, RN))) return rc;
+    if ((rc = dev_alloc(&ov.ctl_seq, RN))) return rc;
+    if ((rc = dev_alloc(&ov.lead, RN))) return rc;
+    if ((rc = dev_alloc(&ov.arrived_rl, RN))) return rc;
+    if ((rc = dev_alloc(&ov.foll_h, RN))) return rc;
+    if ((rc = dev_alloc(&ov.headway, RN))) return rc;
+    if ((rc = dev_alloc(&ov.counters, size_t(R) * 8))) return rc;
+    if ((rc = dev_alloc(&ov.emitted, size_t(R) * FS_MAX_INFLOWS))) return rc;
+    if ((rc = upload(&ov.init_alive, init_alive))) return rc;
+    std::vector<int32_t> st(N);
+    int n_rl_slots = 0;
+    for (int i = 0; i < N; ++i) {
+      st[i] = veh[i].type;
+      if (veh[i].controller == FS_CTRL_RL) ++n_rl_slots;
+    }
+    if ((rc = upload(&ov.slot_type, st))) return rc;
+    std::vector<T> mc(size_t(N) + 1);
+    for (int n = 0; n <= N; ++n) {               // np.linalg.norm([target] * n) in double (rewards.py:50-51)
+      double ss = 0.0;
+      for (int i = 0; i < n; ++i) ss += cfg.target_velocity * cfg.target_velocity;
+      mc[n] = T(std::sqrt(ss));
+    }
+    if ((rc = upload(&ov.max_cost, mc))) return rc;
+    ov.n_inflows = cfg.num_inflows;
+    ov.ma_apply_actions = cfg.ma_apply_actions;
+    ov.n_rl_slots = n_rl_slots;
+    for (int f = 0; f < FS_MAX_INFLOWS; ++f) {
+      const bool in = f < cfg.num_inflows;
+      ov.fl_type[f] = in ? inflows[f].type : 0;
+      ov.fl_route[f] = in ? inflows[f].route : 0;
+      ov.fl_number[f] = in ? inflows[f].number : 0;
+      ov.fl_period[f] = in ? inflows[f].period : 1.0;
+      ov.fl_begin[f] = in ? inflows[f].begin : 0.0;
+      ov.fl_end[f] = in ? inflows[f].end : 0.0;
+      ov.fl_speed[f] = in ? T(inflows[f].depart_speed) : T(0);
+      ov.fl_pos[f] = in ? T(inflows[f].depart_pos) : T(0);
+      ov.fl_first_slot[f] = 0;
+      if (in)
+        for (int i = N - 1; i >= 0; --i)
+          if (veh[i].type == inflows[f].type) ov.fl_first_slot[f] = i;
+    }
+    ov.dt_d = cfg.sim_step;
+    for (int r = 0; r < 2; ++r) {
+      ov.nseg[r] = 0;
+      ov.seg_internal[r] = 0u;
+      for (int k = 0; k < FS_MAX_SEGMENTS; ++k)
+        ov.seg_start[r][k] = ov.seg_flow_start[r][k] = ov.seg_flow_slope[r][k] = T(0);
+      ov.route_start[r] = T(cfg.route_start[r]);
+    }
+    for (const fs_segment& sg : segs) {
+      const int r = sg.route, k = ov.nseg[r]++;
+      ov.seg_start[r][k] = T(sg.start);
+      ov.seg_flow_start[r][k] = T(sg.flow_start);
+      ov.seg_flow_slope[r][k] = T(sg.flow_slope);
+      if (sg.internal) ov.seg_internal[r] |= (1u << k);
+    }
+    ov.merge_x = T(cfg.merge_x);
+    ov.box_in = T(cfg.box_in);
+    ov.end_x = T(cfg.end_x);
+    ov.net_length = T(cfg.net_length);
+    dv.nseg = 0;                                   // the closed-loop segment table is not used
+    return FS_OK;
   }
 
   // ---- exact division by launch constants (flowsim_kernels.h div_const) --------------------
@@ -328,6 +408,12 @@ struct Sim : SimBase {
                  float* rew, uint8_t* done, int obs_every_step) {
     constexpr int RPW = 64 / SEG;
     const int blocks = (dv.R + RPW - 1) / RPW;
+    if (open_net) {
+      hipLaunchKernelGGL((fs::k_steps_open<T, SEG>), dim3(blocks), dim3(64), 0, stream, dv, ov, num_steps, mask,
+                         actions, act_stride, obs, rew, done, obs_every_step, after_reset);
+      HIP_TRY(hipGetLastError());
+      return FS_OK;
+    }
     if (dv.num_lanes > 1) {
       hipLaunchKernelGGL((fs::k_steps_ml<T, SEG>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, mask, actions,
                          act_stride, obs, rew, done, obs_every_step);
@@ -369,6 +455,11 @@ struct Sim : SimBase {
   }
 
   int launch_reset(const uint8_t* mask) override {
+    if (open_net) {
+      hipLaunchKernelGGL((fs::k_reset_open<T>), dim3((dv.R + 63) / 64), dim3(64), 0, stream, dv, ov, mask);
+      HIP_TRY(hipGetLastError());
+      return FS_OK;
+    }
     const size_t n = size_t(dv.R) * dv.N;
     int blocks = int((n + 255) / 256);
     if (blocks > 2048) blocks = 2048;
@@ -405,6 +496,34 @@ struct Sim : SimBase {
       if (bytes != RN * sizeof(int32_t)) return fail(FS_ERR_INVALID, "fs_get_state: wrong byte count");
       const int32_t* p = field == FS_FIELD_LANE ? dv.lane : (field == FS_FIELD_LAST_LC ? dv.last_lc : dv.init_lane);
       HIP_TRY(hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost));
+      return FS_OK;
+    }
+    if (field >= FS_FIELD_ROUTE && field <= FS_FIELD_ARRIVED_RL) {
+      if (!open_net) return fail(FS_ERR_INVALID, "fs_get_state: field exists for open networks only");
+      const size_t RN = size_t(dv.R) * dv.N;
+      const int32_t* p = nullptr;
+      size_t count = RN;
+      switch (field) {
+        case FS_FIELD_ROUTE: p = dv.lane; break;
+        case FS_FIELD_SEQ: p = ov.seq; break;
+        case FS_FIELD_ORIGIN: p = ov.origin; break;
+        case FS_FIELD_FOLLOWER: p = ov.foll; break;
+        case FS_FIELD_CTL_SEQ: p = ov.ctl_seq; break;
+        case FS_FIELD_COUNTERS: p = ov.counters; count = size_t(dv.R) * 8; break;
+        default: p = ov.arrived_rl; break;
+      }
+      if (bytes != count * sizeof(int32_t)) return fail(FS_ERR_INVALID, "fs_get_state: wrong byte count");
+      HIP_TRY(hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost));
+      return FS_OK;
+    }
+    if (open_net && (field == FS_FIELD_HEADWAY || field == FS_FIELD_LEADER)) {
+      // open networks keep the snapshot of the last update on the device (vehicle/traci.py:219-250)
+      const size_t RN = size_t(dv.R) * dv.N;
+      const size_t want = RN * (field == FS_FIELD_HEADWAY ? sizeof(T) : sizeof(int32_t));
+      if (bytes != want) return fail(FS_ERR_INVALID, "fs_get_state: wrong byte count");
+      HIP_TRY(hipMemcpy(dst, field == FS_FIELD_HEADWAY ? static_cast<const void*>(ov.headway)
+                                                        : static_cast<const void*>(ov.lead),
+                        bytes, hipMemcpyDeviceToHost));
       return FS_OK;
     }
     if (field == FS_FIELD_HEADWAY || field == FS_FIELD_LEADER) {
@@ -460,11 +579,15 @@ struct Sim : SimBase {
     }
     if (field == FS_FIELD_HEADWAY || field == FS_FIELD_LEADER)
       return fail(FS_ERR_INVALID, "headway / leader are derived from positions and lanes");
+    if (field >= FS_FIELD_SEQ && field <= FS_FIELD_ARRIVED_RL)
+      return fail(FS_ERR_INVALID, "fs_set_state: read-only field");
+    if (field == FS_FIELD_ROUTE) field = FS_FIELD_LANE;
     if (field == FS_FIELD_LANE || field == FS_FIELD_LAST_LC || field == FS_FIELD_INIT_LANE) {
       const size_t RN = size_t(dv.R) * dv.N;
       if (bytes != RN * sizeof(int32_t)) return fail(FS_ERR_INVALID, "fs_set_state: wrong byte count");
       const int32_t* p = field == FS_FIELD_LANE ? dv.lane : (field == FS_FIELD_LAST_LC ? dv.last_lc : dv.init_lane);
       HIP_TRY(hipMemcpy(const_cast<int32_t*>(p), src, bytes, hipMemcpyHostToDevice));
+      if (open_net && field == FS_FIELD_LANE) return launch_steps(0, nullptr, nullptr, 0, d_obs, d_rew, d_done, 0);
       return FS_OK;
     }
     size_t count;
@@ -473,6 +596,8 @@ struct Sim : SimBase {
     if (!p) return fail(FS_ERR_INVALID, "fs_set_state: unknown field");
     if (bytes != count * sizeof(T)) return fail(FS_ERR_INVALID, "fs_set_state: wrong byte count");
     HIP_TRY(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+    if (open_net && (field == FS_FIELD_POS || field == FS_FIELD_VEL))   // refresh the leader / headway snapshot
+      return launch_steps(0, nullptr, nullptr, 0, d_obs, d_rew, d_done, 0);
     if (field == FS_FIELD_RING_LENGTH) {
       h_ring_len.assign(static_cast<const T*>(src), static_cast<const T*>(src) + count);
       fastdiv_state = -1;
@@ -487,8 +612,42 @@ int validate(const fs_config* c) {
     return fail(FS_ERR_INVALID, "fs_create: struct_size mismatch (header/library out of sync)");
   if (c->abi_version != FS_ABI_VERSION) return fail(FS_ERR_INVALID, "fs_create: abi_version mismatch");
   if (c->precision != FS_F32 && c->precision != FS_F64) return fail(FS_ERR_INVALID, "fs_create: bad precision");
-  if (c->network != FS_NET_RING && c->network != FS_NET_FIGURE_EIGHT)
+  if (c->network != FS_NET_RING && c->network != FS_NET_FIGURE_EIGHT && c->network != FS_NET_MERGE)
     return fail(FS_ERR_UNSUPPORTED, "fs_create: network not built");
+  const bool open_net = c->network == FS_NET_MERGE;
+  const bool merge_env = c->env == FS_ENV_MERGE_PO || c->env == FS_ENV_MERGE_MA;
+  if (open_net != merge_env)
+    return fail(FS_ERR_INVALID, "fs_create: the merge envs and FS_NET_MERGE go together");
+  if (open_net) {
+    if (c->num_lanes > 1) return fail(FS_ERR_UNSUPPORTED, "fs_create: multi-lane merge is not built");
+    if (c->num_segments < 2 || c->num_segments > 2 * FS_MAX_SEGMENTS || !c->segments)
+      return fail(FS_ERR_INVALID, "fs_create: FS_NET_MERGE needs the segment tables of both routes");
+    int per_route[2] = {0, 0};
+    for (int k = 0; k < c->num_segments; ++k) {
+      const fs_segment& sg = c->segments[k];
+      if (sg.route < 0 || sg.route > 1) return fail(FS_ERR_INVALID, "fs_create: segment route must be 0 or 1");
+      if (k > 0 && sg.route < c->segments[k - 1].route)
+        return fail(FS_ERR_INVALID, "fs_create: segment rows must be grouped by route");
+      if (k > 0 && sg.route == c->segments[k - 1].route && !(sg.start > c->segments[k - 1].start))
+        return fail(FS_ERR_INVALID, "fs_create: segment starts must increase");
+      if (++per_route[sg.route] > FS_MAX_SEGMENTS) return fail(FS_ERR_INVALID, "fs_create: too many segments");
+    }
+    if (!per_route[0] || !per_route[1]) return fail(FS_ERR_INVALID, "fs_create: a route has no segment");
+    if (c->num_inflows < 0 || c->num_inflows > FS_MAX_INFLOWS || (c->num_inflows > 0 && !c->inflows))
+      return fail(FS_ERR_INVALID, "fs_create: bad inflow table");
+    for (int f = 0; f < c->num_inflows; ++f) {
+      const fs_inflow& fl = c->inflows[f];
+      if (fl.route < 0 || fl.route > 1) return fail(FS_ERR_INVALID, "fs_create: inflow route must be 0 or 1");
+      if (!(fl.period > 0)) return fail(FS_ERR_INVALID, "fs_create: inflow period <= 0");
+      if (!(fl.depart_speed >= 0) || !(fl.depart_pos >= 0)) return fail(FS_ERR_INVALID, "fs_create: bad inflow departure");
+      bool type_ok = false;
+      for (int i = 0; i < c->num_vehicles; ++i) type_ok = type_ok || c->vehicles[i].type == fl.type;
+      if (!type_ok) return fail(FS_ERR_INVALID, "fs_create: inflow of a vehicle type that has no slot");
+    }
+    if (!c->init_alive || !c->init_lane) return fail(FS_ERR_INVALID, "fs_create: FS_NET_MERGE needs init_alive and init_lane (routes)");
+    if (!(c->box_in < c->merge_x) || !(c->merge_x < c->end_x) || !(c->net_length > 0))
+      return fail(FS_ERR_INVALID, "fs_create: need box_in < merge_x < end_x and net_length > 0");
+  }
   if (c->network == FS_NET_RING && (c->num_segments != 0 || c->junction.enabled))
     return fail(FS_ERR_INVALID, "fs_create: a ring takes no segment table / junction");
   if (c->network == FS_NET_FIGURE_EIGHT) {
@@ -500,11 +659,11 @@ int validate(const fs_config* c) {
       if (!(c->segments[k].start > c->segments[k - 1].start))
         return fail(FS_ERR_INVALID, "fs_create: segment starts must increase");
   }
-  if (c->env < FS_ENV_ACCEL || c->env > FS_ENV_LANE_CHANGE_ACCEL) return fail(FS_ERR_INVALID, "fs_create: bad env");
+  if (c->env < FS_ENV_ACCEL || c->env > FS_ENV_MERGE_MA) return fail(FS_ERR_INVALID, "fs_create: bad env");
   if (c->num_lanes > 1 && c->env == FS_ENV_WAVE_ATTENUATION_PO)
     return fail(FS_ERR_UNSUPPORTED, "fs_create: WaveAttenuationPOEnv on a multi-lane ring is not built");
   if (c->num_lanes > 64) return fail(FS_ERR_INVALID, "fs_create: num_lanes > 64");
-  if (c->init_lane)
+  if (c->init_lane && !open_net)
     for (size_t e = 0; e < size_t(c->num_replicas > 0 ? c->num_replicas : 0) * (c->num_vehicles > 0 ? c->num_vehicles : 0); ++e)
       if (c->init_lane[e] < 0 || c->init_lane[e] >= (c->num_lanes < 1 ? 1 : c->num_lanes))
         return fail(FS_ERR_INVALID, "fs_create: init_lane out of range");
@@ -518,7 +677,8 @@ int validate(const fs_config* c) {
   if (!(c->sim_step > 0)) return fail(FS_ERR_INVALID, "fs_create: sim_step <= 0");
   if (!(c->slowdown_ramp > 0) || c->slowdown_ramp > 1) return fail(FS_ERR_INVALID, "fs_create: slowdown_ramp not in (0,1]");
   if (c->junction_length < 0) return fail(FS_ERR_INVALID, "fs_create: junction_length < 0");
-  if (!c->vehicles || !c->ring_length || !c->init_pos) return fail(FS_ERR_INVALID, "fs_create: NULL table pointer");
+  if (!c->vehicles || (!c->ring_length && !open_net) || !c->init_pos)
+    return fail(FS_ERR_INVALID, "fs_create: NULL table pointer");
   int seen_rl = 0;
   unsigned long long rl_mask = 0ull;       // num_vehicles <= 64
   for (int i = 0; i < c->num_vehicles; ++i) {
@@ -527,7 +687,11 @@ int validate(const fs_config* c) {
       return fail(FS_ERR_INVALID, "fs_create: unknown controller id");
     if (v.fail_safe < FS_FAILSAFE_NONE || v.fail_safe > FS_FAILSAFE_SAFE_VELOCITY)
       return fail(FS_ERR_INVALID, "fs_create: unknown fail_safe id");
-    if (v.controller == FS_CTRL_RL) {
+    if (open_net && v.controller == FS_CTRL_PISATURATION)
+      return fail(FS_ERR_UNSUPPORTED, "fs_create: PISaturation on an open network is not built");
+    if (v.controller == FS_CTRL_RL && c->env == FS_ENV_MERGE_PO) {
+      ++seen_rl;                        // the action column is the place in rl_veh, not rl_index
+    } else if (v.controller == FS_CTRL_RL) {
       if (v.rl_index < 0 || v.rl_index >= c->num_rl) return fail(FS_ERR_INVALID, "fs_create: rl_index out of range");
       if (rl_mask & (1ull << v.rl_index)) return fail(FS_ERR_INVALID, "fs_create: rl_index used twice");
       rl_mask |= 1ull << v.rl_index;
@@ -535,7 +699,19 @@ int validate(const fs_config* c) {
     }
     if (!(v.length > 0)) return fail(FS_ERR_INVALID, "fs_create: vehicle length <= 0");
   }
-  if (seen_rl != c->num_rl) return fail(FS_ERR_INVALID, "fs_create: num_rl does not match the RL slots");
+  if (seen_rl != c->num_rl && c->env != FS_ENV_MERGE_PO)
+    return fail(FS_ERR_INVALID, "fs_create: num_rl does not match the RL slots");
+  if (open_net) {
+    // placement sanity of the initial vehicles: inside their route, alive flags consistent
+    for (size_t e = 0; e < size_t(c->num_replicas) * c->num_vehicles; ++e) {
+      if (!c->init_alive[e]) continue;
+      const int rt = c->init_lane[e];
+      if (rt < 0 || rt > 1) return fail(FS_ERR_INVALID, "fs_create: initial route must be 0 or 1");
+      const double x = c->init_pos[e];
+      if (!(x >= c->route_start[rt]) || !(x < c->end_x)) return fail(FS_ERR_INVALID, "fs_create: init_pos outside the route");
+    }
+    return FS_OK;
+  }
   if (c->env == FS_ENV_WAVE_ATTENUATION_PO && c->num_rl < 1)
     return fail(FS_ERR_INVALID, "fs_create: WaveAttenuationPOEnv needs an RL vehicle");
   // placement sanity: every replica's vehicles must fit on its loop (network/base.py:603-605)
@@ -560,8 +736,15 @@ int create_typed(const fs_config* cfg, fs_handle* out) {
   s->cfg = *cfg;
   s->veh.assign(cfg->vehicles, cfg->vehicles + cfg->num_vehicles);
   if (cfg->num_segments > 0) s->segs.assign(cfg->segments, cfg->segments + cfg->num_segments);
+  if (cfg->network == FS_NET_MERGE) {
+    if (cfg->num_inflows > 0) s->inflows.assign(cfg->inflows, cfg->inflows + cfg->num_inflows);
+    s->init_alive.assign(cfg->init_alive, cfg->init_alive + size_t(cfg->num_replicas) * cfg->num_vehicles);
+  }
   s->obs_dim = (cfg->env == FS_ENV_WAVE_ATTENUATION_PO) ? 3
-               : (cfg->env == FS_ENV_LANE_CHANGE_ACCEL ? 3 : 2) * cfg->num_vehicles;
+               : (cfg->env == FS_ENV_MERGE_PO || cfg->env == FS_ENV_MERGE_MA)
+                     ? 5 * cfg->num_rl
+                     : (cfg->env == FS_ENV_LANE_CHANGE_ACCEL ? 3 : 2) * cfg->num_vehicles;
+  if (s->obs_dim < 1) s->obs_dim = 1;      // an env without RL places still gets a (dummy) buffer
   s->act_dim = cfg->num_rl * (cfg->env == FS_ENV_LANE_CHANGE_ACCEL ? 2 : 1);
   int seg = 8;
   while (seg < cfg->num_vehicles) seg <<= 1;
@@ -602,6 +785,8 @@ int create_typed(const fs_config* cfg, fs_handle* out) {
   s->cfg.init_vel = nullptr;
   s->cfg.init_lane = nullptr;
   s->cfg.segments = nullptr;
+  s->cfg.inflows = nullptr;
+  s->cfg.init_alive = nullptr;
   *out = reinterpret_cast<fs_handle>(static_cast<SimBase*>(s));
   return FS_OK;
 }
@@ -666,6 +851,15 @@ int fs_reset_dev(fs_handle h, const uint8_t* mask_dev, float* obs_dev) {
   int rc = s->launch_reset(mask_dev);
   if (rc) return rc;
   float* obs = obs_dev ? obs_dev : s->d_obs;
+  if (s->cfg.network == FS_NET_MERGE) {   // update(reset=True) of the fresh placement, before any warm-up step
+    s->after_reset = 1;
+    rc = s->launch_steps(0, mask_dev, nullptr, 0, obs, s->d_rew, s->d_done, 0);
+    s->after_reset = 0;
+    if (rc) return rc;
+    if (s->cfg.warmup_steps > 0)
+      return s->launch_steps(s->cfg.warmup_steps, mask_dev, nullptr, 0, obs, s->d_rew, s->d_done, 0);
+    return FS_OK;
+  }
   if (s->cfg.warmup_steps > 0)   // envs/base.py:554-555: warm-up steps with rl_actions=None
     return s->launch_steps(s->cfg.warmup_steps, mask_dev, nullptr, 0, obs, s->d_rew, s->d_done, 0);
   return s->launch_steps(0, mask_dev, nullptr, 0, obs, s->d_rew, s->d_done, 0);

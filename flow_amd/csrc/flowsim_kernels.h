@@ -466,9 +466,9 @@ __device__ __forceinline__ void segment_lookup(const DevView<T>& s, T x, bool& i
 // Returns the commanded acceleration; `commanded` = false means "no command this step" (S5).
 // ---------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ T control_accel(const DevView<T>& s, const Slot<T>& sl, int flags, T v, T vl, T h, bool has,
-                                           T vf, T hf, T mean_v, T x, T quarter, T qj, bool have_rl, T a_rl, bool live,
-                                           int rr, int ii, uint32_t nctr, T& cst, bool& commanded) {
+__device__ __forceinline__ T control_accel_on(const DevView<T>& s, const Slot<T>& sl, int flags, T v, T vl, T h, bool has,
+                                              T vf, T hf, T mean_v, bool on_edge, bool have_rl, T a_rl, bool live,
+                                              int rr, int ii, uint32_t nctr, T& cst, bool& commanded) {
   T acc = T(0);
   commanded = false;
   const int ct = sl.ctrl;
@@ -481,18 +481,6 @@ __device__ __forceinline__ T control_accel(const DevView<T>& s, const Slot<T>& s
     }
   } else if (ct != FS_CTRL_SIM) {
     T a;
-    bool on_edge = true;
-    if (s.junction_mode) {                       // base_controller.py:98-99
-      if (s.nseg > 0) {
-        bool internal;
-        T fx;
-        segment_lookup(s, x, internal, fx);
-        on_edge = !internal;
-      } else {
-        T u = x - tfloor(x / qj) * qj;
-        on_edge = !(u >= quarter);
-      }
-    }
     switch (ct) {
       case FS_CTRL_PISATURATION: {
         const size_t slot = size_t(rr) * s.n_pis + (sl.pis_index < 0 ? 0 : sl.pis_index);
@@ -522,6 +510,27 @@ __device__ __forceinline__ T control_accel(const DevView<T>& s, const Slot<T>& s
     acc = a;
   }
   return acc;
+}
+
+// closed loops: "on an edge" (base_controller.py:98-99) from the loop coordinate
+template <typename T>
+__device__ __forceinline__ T control_accel(const DevView<T>& s, const Slot<T>& sl, int flags, T v, T vl, T h, bool has,
+                                           T vf, T hf, T mean_v, T x, T quarter, T qj, bool have_rl, T a_rl, bool live,
+                                           int rr, int ii, uint32_t nctr, T& cst, bool& commanded) {
+  bool on_edge = true;
+  if (s.junction_mode && sl.ctrl != FS_CTRL_RL && sl.ctrl != FS_CTRL_SIM) {
+    if (s.nseg > 0) {
+      bool internal;
+      T fx;
+      segment_lookup(s, x, internal, fx);
+      on_edge = !internal;
+    } else {
+      T u = x - tfloor(x / qj) * qj;
+      on_edge = !(u >= quarter);
+    }
+  }
+  return control_accel_on(s, sl, flags, v, vl, h, has, vf, hf, mean_v, on_edge, have_rl, a_rl, live, rr, ii, nctr, cst,
+                          commanded);
 }
 
 // ---------------------------------------------------------------------------

@@ -1,0 +1,566 @@
+// flowsim_open.h -- gfx950 step kernel for OPEN networks (FS_NET_MERGE): vehicles enter through inflows,
+// leave at the end of their route, two routes converge at a priority junction.
+//
+// Reference behaviour restated (rule numbers = oracle/opennet.py, which is the bit-twin of this file):
+//   O1  TraCIVehicle.update bookkeeping + sticky follower      flow/core/kernel/vehicle/traci.py:119-259
+//   O2  MergePOEnv rl_veh / rl_queue, get_state, reward        flow/envs/merge.py:109-221
+//   O3  MultiAgentMergePOEnv                                   flow/envs/multiagent/merge.py:86-171
+//   O4  rewards.desired_velocity over the vehicles present     flow/core/rewards.py:6-59
+//   O5  get_x_by_id through the edge-start table               flow/core/kernel/network/traci.py:273-289
+//   M1-M7 the SUMO side (slots, inflow schedule, insertion, arrival, leader, right of way, movement)
+//
+// Lane mapping as in the closed-loop kernels: one 64-lane wave carries 64/SEG replicas, lane seg*SEG + i holds
+// SLOT i of its replica in registers (a slot is free when its route is -1).  Neighbours change with every
+// insertion / arrival / merge, so each sub-step every lane scans the other slots of its segment through the
+// LDS crossbar (ds_bpermute), as k_steps_ml does; per-replica bookkeeping (inflow clocks, id counters, the
+// rl_veh list) is computed redundantly by every lane of the segment from ballots.  All cross-lane reads are
+// executed by the whole wave (loop bounds are launch constants), never under segment-divergent control flow.
+#pragma once
+
+namespace fs {
+
+template <typename T>
+struct OpenView {
+  int32_t* seq;          // [R,N] place in the id list
+  int32_t* origin;       // [R,N]
+  int32_t* foll;         // [R,N] sticky follower slot
+  int32_t* ctl_seq;      // [R,N] >= 0: in rl_veh
+  int32_t* lead;         // [R,N] leader slot of the last update (get_leader)
+  int32_t* arrived_rl;   // [R,N]
+  T* foll_h;             // [R,N] "follower_headway"
+  T* headway;            // [R,N] get_headway
+  int32_t* counters;     // [R,8]
+  int32_t* emitted;      // [R,FS_MAX_INFLOWS]
+  const uint8_t* init_alive;   // [R,N]
+  const int32_t* slot_type;    // [N]
+  const T* max_cost;           // [N+1] norm([target]*n)
+  int n_inflows, ma_apply_actions, n_rl_slots;
+  int fl_type[FS_MAX_INFLOWS], fl_route[FS_MAX_INFLOWS], fl_number[FS_MAX_INFLOWS], fl_first_slot[FS_MAX_INFLOWS];
+  double fl_period[FS_MAX_INFLOWS], fl_begin[FS_MAX_INFLOWS], fl_end[FS_MAX_INFLOWS];
+  T fl_speed[FS_MAX_INFLOWS], fl_pos[FS_MAX_INFLOWS];
+  double dt_d;
+  int nseg[2];
+  unsigned seg_internal[2];
+  T seg_start[2][FS_MAX_SEGMENTS], seg_flow_start[2][FS_MAX_SEGMENTS], seg_flow_slope[2][FS_MAX_SEGMENTS];
+  T route_start[2];
+  T merge_x, box_in, end_x, net_length;
+};
+
+enum { CNT_SIM_STEPS = 0, CNT_SEQ = 1, CNT_CTL = 2, CNT_ARRIVED = 3, CNT_DEPARTED = 4, CNT_TOTAL_ARRIVED = 5,
+       CNT_TOTAL_DEPARTED = 6 };
+
+template <int SEG>
+__device__ __forceinline__ unsigned long long seg_ballot(bool pred, int seg) {
+  unsigned long long b = __ballot(pred);
+  if (SEG == 64) return b;
+  return (b >> (seg * (SEG & 63))) & ((1ull << (SEG & 63)) - 1ull);
+}
+
+template <int SEG, typename T>
+__device__ __forceinline__ T seg_min(T v) {
+#pragma unroll
+  for (int off = 1; off < SEG; off <<= 1) {
+    const T w = __shfl_xor(v, off, 64);
+    v = w < v ? w : v;
+  }
+  return v;
+}
+
+// (internal?, Flow table coordinate) of coordinate x on route r (O5); both tables are walked with uniform
+// loops and the lane keeps the one of its route
+template <typename T>
+__device__ __forceinline__ void route_lookup(const OpenView<T>& o, T x, int route, bool& internal, T& flow_x) {
+  internal = false;
+  flow_x = T(0);
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    int k = 0;
+    T st = o.seg_start[r][0], fs0 = o.seg_flow_start[r][0], sl = o.seg_flow_slope[r][0];
+    for (int q = 1; q < o.nseg[r]; ++q) {
+      const bool hit = x >= o.seg_start[r][q];
+      k = hit ? q : k;
+      st = hit ? o.seg_start[r][q] : st;
+      fs0 = hit ? o.seg_flow_start[r][q] : fs0;
+      sl = hit ? o.seg_flow_slope[r][q] : sl;
+    }
+    if (route == r) {
+      internal = (o.seg_internal[r] >> k) & 1u;
+      flow_x = fs0 + sl * (x - st);
+    }
+  }
+}
+
+template <typename T, int SEG>
+__global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, int num_steps,
+                                                   const uint8_t* __restrict__ mask,
+                                                   const float* __restrict__ actions, size_t act_stride,
+                                                   float* __restrict__ obs, float* __restrict__ rew,
+                                                   uint8_t* __restrict__ done, int obs_every_step,
+                                                   int after_reset) {
+  constexpr int RPW = 64 / SEG;
+  const T BIGV = T(3.0e38);
+  const int lane_id = threadIdx.x;
+  const int seg = lane_id / SEG;
+  const int i = lane_id % SEG;
+  const int segbase = seg * SEG;
+  const int r = blockIdx.x * RPW + seg;
+  const int N = s.N;
+  const bool rvalid = r < s.R;
+  const bool slot_ok = i < N;
+  const bool valid = rvalid && slot_ok;
+  const int rr = rvalid ? r : s.R - 1;
+  const int ii = slot_ok ? i : N - 1;
+  const size_t idx = size_t(rr) * N + ii;
+  const int flags = s.flags;
+  const int env = s.env;
+  const bool po_env = (env == FS_ENV_MERGE_PO);
+
+  Slot<T> sl;
+  sl.ctrl = s.ctrl[ii];
+  sl.failsafe = s.failsafe[ii];
+  sl.speed_mode = s.speed_mode[ii];
+  sl.rl_index = s.rl_index[ii];
+  sl.pis_index = -1;
+#pragma unroll
+  for (int k = 0; k < FS_MAX_CTRL_PARAMS; ++k) sl.p[k] = s.p[k * N + ii];
+  sl.noise = s.noise[ii];
+  sl.delay = s.delay[ii];
+  sl.max_accel = s.max_accel[ii];
+  sl.max_decel = s.max_decel[ii];
+  sl.length = s.length[ii];
+  sl.sumo_tau = s.sumo_tau[ii];
+  sl.sumo_min_gap = s.sumo_min_gap[ii];
+  sl.sumo_max_speed = s.sumo_max_speed[ii];
+  const int my_type = o.slot_type[ii];
+  const bool is_rl = sl.ctrl == FS_CTRL_RL;
+
+  const bool live_replica = rvalid && (mask == nullptr || mask[rr] != 0);
+  int tcount = s.time[rr];
+  uint32_t nctr = s.noise_ctr[rr];
+  int32_t* cnt = o.counters + size_t(rr) * 8;
+  int sim_steps = cnt[CNT_SIM_STEPS], seq_ctr = cnt[CNT_SEQ], ctl_ctr = cnt[CNT_CTL];
+  int n_arr = cnt[CNT_ARRIVED], n_dep = cnt[CNT_DEPARTED], tot_arr = cnt[CNT_TOTAL_ARRIVED],
+      tot_dep = cnt[CNT_TOTAL_DEPARTED];
+  int emitted[FS_MAX_INFLOWS];
+#pragma unroll
+  for (int f = 0; f < FS_MAX_INFLOWS; ++f) emitted[f] = o.emitted[size_t(rr) * FS_MAX_INFLOWS + f];
+
+  T x = s.pos[idx];
+  T v = s.vel[idx];
+  int route = slot_ok ? s.lane[idx] : -1;
+  int seq = o.seq[idx];
+  int origin = o.origin[idx];
+  int foll = o.foll[idx];
+  T foll_h = o.foll_h[idx];
+  int ctl_seq = slot_ok ? o.ctl_seq[idx] : -1;
+  int arrived_rl = o.arrived_rl[idx];
+  T prev_v = s.prev_vel[idx], last_acc = s.accel[idx];
+  T cst = s.ctrl_state[idx];
+  bool just_arrived = false;
+
+  const T dt = s.dt;
+  const int num_rl = s.num_rl;
+  const int obs_dim = 5 * num_rl;
+  const size_t step_rows = obs_every_step ? size_t(s.R) : 0;
+  float* orow = obs + size_t(rr) * obs_dim;
+  float* rrow = rew + rr;
+  uint8_t* drow = done + rr;
+
+  // ---- M5: leader = nearest vehicle ahead on the own route -------------------------------------------
+  int lead = -1;
+  T vl = T(-1001), h = T(1000);
+  bool has = false;
+  auto scan = [&]() {
+    const bool alive = route >= 0;
+    T best = BIGV;
+    lead = -1;
+    for (int k = 1; k < N; ++k) {
+      int j = ii + k;
+      j = j >= N ? j - N : j;
+      const T xj = bperm(x, segbase + j);
+      const int rj = __shfl(route, segbase + j, 64);
+      const T d = xj - x;
+      const bool ahead = (d > T(0)) || (d == T(0) && j < ii);
+      const bool cand = ahead && alive && rj >= 0 && (rj == route || xj >= o.merge_x);
+      if (cand && (d < best || (d == best && j < lead))) { best = d; lead = j; }
+    }
+    has = lead >= 0;
+    const int lsrc = segbase + (has ? lead : ii);
+    const T vsrc = bperm(v, lsrc);
+    const T len_lead = bperm(sl.length, lsrc);
+    vl = has ? vsrc : T(-1001);                         // get_speed(None): the accessor's error value
+    h = has ? best - len_lead : T(1000);                // vehicle/traci.py:237
+  };
+  // ---- O1: the sticky follower entry of THIS vehicle after an update ---------------------------------
+  auto follower_update = [&](bool live) {
+    const bool alive = route >= 0;
+    const bool no_lead = alive && !has;
+    const T start_h = no_lead ? T(1000) : foll_h;
+    const int start_f = no_lead ? -1 : foll;
+    T bestf = BIGV;
+    int bseq = 0x7fffffff, bj = -1;
+    for (int k = 1; k < N; ++k) {
+      int j = ii + k;
+      j = j >= N ? j - N : j;
+      const int lj = __shfl(lead, segbase + j, 64);
+      const T hj = bperm(h, segbase + j);
+      const int sj = __shfl(seq, segbase + j, 64);
+      const bool elig = (lj == ii) && slot_ok && (has || sj > seq);
+      if (elig && (hj < bestf || (hj == bestf && sj < bseq))) { bestf = hj; bseq = sj; bj = j; }
+    }
+    const bool better = (bestf < start_h) && (bestf < BIGV);
+    if (alive && live) {
+      foll = better ? bj : start_f;
+      foll_h = better ? bestf : start_h;
+    }
+  };
+  // place of this slot in rl_veh (-1 if not in it): rank by order of joining, ghosts included (O2)
+  auto ctl_rank = [&]() -> int {
+    unsigned long long b = seg_ballot<SEG>(ctl_seq >= 0, seg);
+    int rank = 0;
+    for (int t = 0; t < num_rl; ++t) {
+      const bool bit = b != 0ull;
+      const int j = bit ? __ffsll((long long)b) - 1 : 0;
+      b &= b - 1ull;
+      const int cj = __shfl(ctl_seq, segbase + j, 64);
+      if (bit && cj < ctl_seq) rank += 1;
+    }
+    return ctl_seq >= 0 ? rank : -1;
+  };
+  // the five features of the vehicle in this slot (merge.py:128-156)
+  auto five = [&](T* f5) {
+    const bool alive = route >= 0;
+    bool internal;
+    T fx;
+    route_lookup(o, x, route, internal, fx);
+    const int ld = alive ? lead : -1;
+    const int fo = alive ? foll : -1;
+    const int lsrc = segbase + (ld >= 0 ? ld : ii), fsrc = segbase + (fo >= 0 ? fo : ii);
+    const T v_l = bperm(v, lsrc), fx_l = bperm(fx, lsrc), v_f = bperm(v, fsrc), h_f = bperm(h, fsrc);
+    const T this_speed = alive ? v : T(-1001);
+    const T lead_speed = ld >= 0 ? v_l : s.max_speed;
+    const T lead_head = ld >= 0 ? fx_l - fx - sl.length : o.net_length;
+    const T follow_speed = fo >= 0 ? v_f : T(0);
+    const T follow_head = fo >= 0 ? h_f : o.net_length;
+    f5[0] = this_speed / s.max_speed;
+    f5[1] = (lead_speed - this_speed) / s.max_speed;
+    f5[2] = lead_head / o.net_length;
+    f5[3] = (this_speed - follow_speed) / s.max_speed;
+    f5[4] = follow_head / o.net_length;
+  };
+  auto write_obs = [&](int rank) {
+    T f5[5];
+    five(f5);
+    if (po_env) {
+      const int n_ctl = __popcll(seg_ballot<SEG>(ctl_seq >= 0, seg));
+      if (valid && rank >= 0 && rank < num_rl) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) orow[5 * rank + q] = float(f5[q]);
+      }
+      if (rvalid && i < num_rl && i >= n_ctl) {          // unfilled entries stay 0 (merge.py:126)
+#pragma unroll
+        for (int q = 0; q < 5; ++q) orow[5 * i + q] = 0.0f;
+      }
+    } else if (valid && is_rl) {
+      const bool alive = route >= 0;
+#pragma unroll
+      for (int q = 0; q < 5; ++q) orow[5 * sl.rl_index + q] = alive ? float(f5[q]) : 0.0f;
+    }
+  };
+  auto store_snapshot = [&]() {
+    if (valid && live_replica) {
+      o.lead[idx] = lead;
+      o.headway[idx] = h;
+    }
+  };
+
+  scan();
+
+  if (num_steps == 0) {
+    // after_reset: update(reset=True) registers the followers of the initial placement (vehicle/traci.py:219-250)
+    if (after_reset) {
+      follower_update(live_replica);
+      if (valid && live_replica) {
+        o.foll[idx] = foll;
+        o.foll_h[idx] = foll_h;
+      }
+    }
+    write_obs(po_env ? ctl_rank() : -1);
+    store_snapshot();
+    return;
+  }
+
+  for (int step = 0; step < num_steps; ++step) {
+    const float* act = actions ? actions + size_t(step) * act_stride + size_t(rr) * num_rl : nullptr;
+    bool crashed = false;
+    for (int sub = 0; sub < s.sims_per_step; ++sub) {
+      const bool live = live_replica && !crashed;
+      const bool alive = route >= 0;
+      // ---- controllers on the snapshot (S1) ------------------------------------------------------------
+      T vf = T(0), hf = T(0), mean_v = T(0);
+      if (flags & FLAG_NEED_FOLLOWER) {
+        const int fsrc = segbase + (foll >= 0 ? foll : 0);
+        vf = bperm(v, fsrc);
+        hf = bperm(h, fsrc);
+      }
+      if (flags & FLAG_NEED_MEAN) {
+        const int n_alive = __popcll(seg_ballot<SEG>(alive, seg));
+        mean_v = seg_sum<SEG>(alive ? v : T(0)) / T(n_alive > 0 ? n_alive : 1);
+      }
+      bool internal;
+      T fx_unused;
+      route_lookup(o, x, route, internal, fx_unused);
+      const bool on_edge = s.junction_mode ? !internal : true;
+      // RL command (envs/base.py:355 runs before additional_command: the rl_veh list of the last sub-step)
+      bool have_rl = false;
+      T a_rl = T(0);
+      if (po_env) {
+        const int rank = ctl_rank();
+        have_rl = (act != nullptr) && is_rl && alive && rank >= 0 && rank < num_rl;
+        if (have_rl) a_rl = T(act[rank]);
+      } else if (o.ma_apply_actions && act != nullptr && is_rl && alive) {
+        const float a = act[sl.rl_index];
+        have_rl = !(a != a);                             // NaN: no action for this vehicle this step
+        a_rl = have_rl ? T(a) : T(0);
+      }
+      bool commanded = false;
+      T acc = control_accel_on(s, sl, flags, v, vl, h, has, vf, hf, mean_v, on_edge, have_rl, a_rl, live && slot_ok,
+                               rr, ii, nctr, cst, commanded);
+      // ---- MergePOEnv.additional_command (merge.py:189-221) --------------------------------------------
+      if (po_env) {
+        const bool alive_rl = alive && is_rl;
+        if (live && !alive_rl) ctl_seq = -1;
+        const int n_ctl = __popcll(seg_ballot<SEG>(ctl_seq >= 0, seg));
+        const int free_places = num_rl - n_ctl > 0 ? num_rl - n_ctl : 0;
+        const bool queued = alive_rl && ctl_seq < 0;
+        unsigned long long qb = seg_ballot<SEG>(queued, seg);
+        int qrank = 0;
+        for (int t = 0; t < o.n_rl_slots; ++t) {
+          const bool bit = qb != 0ull;
+          const int j = bit ? __ffsll((long long)qb) - 1 : 0;
+          qb &= qb - 1ull;
+          const int sj = __shfl(seq, segbase + j, 64);
+          if (bit && sj < seq) qrank += 1;
+        }
+        const bool take = queued && (qrank < free_places) && live;
+        const int n_take = __popcll(seg_ballot<SEG>(take, seg));
+        if (take) ctl_seq = ctl_ctr + qrank;
+        ctl_ctr += n_take;
+      }
+      // ---- M7: apply_acceleration + SUMO integration ---------------------------------------------------
+      T next_vel = tmax(v + acc * dt, T(0));
+      T vc = v + (next_vel - v) * s.ramp;
+      T v_sumo = sumo_idm_speed(v, vl, h, has, dt, sl);
+      if (sl.speed_mode & 1) vc = tmin(vc, v_sumo);
+      if (sl.speed_mode & 2) vc = tmin(vc, v + sl.max_accel * dt);
+      if (sl.speed_mode & 4) vc = tmax(vc, v - sl.max_decel * dt);
+      T v_new = commanded ? vc : v_sumo;
+      if (s.junction_on) {                               // M6: right of way at the merge
+        const bool in_reach = alive && (x < o.merge_x);
+        const bool major_busy = seg_any<SEG>(in_reach && route == 0 && (x >= o.box_in - s.j_time_gap * v), seg);
+        const bool minor_in_box = seg_any<SEG>(in_reach && route == 1 && (x >= o.box_in), seg);
+        const bool approaching = alive && (x >= o.box_in - s.j_lookahead) && (x < o.box_in);
+        const bool yields = approaching && ((route == 1 && major_busy) || (route == 0 && minor_in_box));
+        const T stop = sumo_idm_speed(v, T(0), o.box_in - x, true, dt, sl);
+        const T cap = yields ? stop : BIGV;
+        if ((sl.speed_mode & 1) || !commanded) v_new = tmin(v_new, cap);
+      }
+      T x_new = (s.integrator == FS_BALLISTIC) ? x + (v + v_new) / T(2) * dt : x + v_new * dt;
+      const bool mv = live && alive;
+      if (mv) {
+        prev_v = v;
+        last_acc = acc;
+        x = x_new;
+        v = v_new;
+      }
+      if (live) {
+        tcount += 1;
+        nctr += 1u;
+        sim_steps += 1;
+      }
+      // ---- M4: arrivals -------------------------------------------------------------------------------
+      const bool arrived = mv && (x >= o.end_x);
+      if (live) arrived_rl = (arrived && is_rl) ? 1 : 0;
+      if (arrived) route = -1;
+      just_arrived = arrived;
+      {
+        const int na = __popcll(seg_ballot<SEG>(arrived, seg));
+        if (live) { n_arr = na; n_dep = 0; }
+        tot_arr += na;
+      }
+      // ---- M2 / M3: insertions in InFlows order -------------------------------------------------------
+#pragma unroll
+      for (int f = 0; f < FS_MAX_INFLOWS; ++f) {
+        if (f < o.n_inflows) {
+          const int k = emitted[f];
+          const double due_t = o.fl_begin[f] + double(k) * o.fl_period[f];
+          const double now = double(sim_steps - 1) * o.dt_d;
+          const bool due = (due_t <= now) && (due_t <= o.fl_end[f]) && (o.fl_number[f] < 0 || k < o.fl_number[f]);
+          const int typ = o.fl_type[f], route_f = o.fl_route[f];
+          const bool alive_now = route >= 0;
+          const bool free_slot = !alive_now && slot_ok && (my_type == typ) && !just_arrived;
+          const unsigned long long fb = seg_ballot<SEG>(free_slot, seg);
+          const int slot = fb ? __ffsll((long long)fb) - 1 : 0;
+          const T x_dep = (route_f == 0 ? o.route_start[0] : o.route_start[1]) + o.fl_pos[f];
+          const T v_dep = o.fl_speed[f];
+          const bool cand = alive_now && (route == route_f || x >= o.merge_x);
+          const T xm = seg_min<SEG>(cand ? x : BIGV);
+          const unsigned long long cb = seg_ballot<SEG>(cand && x == xm, seg);
+          const bool has_lead = cb != 0ull;
+          const int j = has_lead ? __ffsll((long long)cb) - 1 : 0;
+          const T back_j = bperm(x - sl.length, segbase + j);
+          const T v_lead = bperm(v, segbase + j);
+          const T gap = back_j - x_dep;
+          const int fs0 = o.fl_first_slot[f];
+          const T two_sqrt = T(2) * tsqrt(s.max_accel[fs0] * s.max_decel[fs0]);
+          const T need = s.sumo_min_gap[fs0] +
+                         tmax(T(0), v_dep * s.sumo_tau[fs0] + v_dep * (v_dep - v_lead) / two_sqrt);
+          const bool ok = live && due && (fb != 0ull) && (!has_lead || gap >= need);
+          if (ok && slot_ok && ii == slot) {
+            x = x_dep;
+            v = v_dep;
+            prev_v = T(0);                               // previous_speeds.get(veh_id, 0)
+            cst = T(0);
+            last_acc = T(0);
+            route = route_f;
+            seq = seq_ctr;
+            origin = f * (1 << 20) + k;
+            foll = -1;
+            foll_h = BIGV;
+            ctl_seq = -1;
+          }
+          if (ok) {
+            seq_ctr += 1;
+            emitted[f] = k + 1;
+            n_dep += 1;
+            tot_dep += 1;
+          }
+        }
+      }
+      // ---- O1: new neighbour snapshot, sticky followers, collision check --------------------------------
+      scan();
+      follower_update(live);
+      bool c = seg_any<SEG>((route >= 0) && has && (h < s.crash_gap), seg);
+      if (s.junction_on) {
+        const bool inside = (route >= 0) && (x >= o.box_in) && (x < o.merge_x);
+        c = c || (seg_any<SEG>(inside && route == 0, seg) && seg_any<SEG>(inside && route == 1, seg));
+      }
+      if (env == FS_ENV_MERGE_MA) c = false;             // multiagent/base.py:188-190: crash = 0
+      crashed = crashed || (c && live);
+    }
+
+    // ---- get_state / compute_reward / done ---------------------------------------------------------------
+    const bool emit = obs_every_step || (step == num_steps - 1);
+    if (emit) {
+      const int rank = po_env ? ctl_rank() : -1;
+      write_obs(rank);
+      const bool alive = route >= 0;
+      const int n_alive = __popcll(seg_ballot<SEG>(alive, seg));
+      T reward;
+      if (s.evaluate) {                                  // merge.py:161-162
+        const T sum_v = seg_sum<SEG>(alive ? v : T(0));
+        reward = n_alive > 0 ? sum_v / T(n_alive) : T(0);
+      } else {
+        const T max_cost = o.max_cost[n_alive];          // O4
+        const T dv = alive ? v - s.target_velocity : T(0);
+        const T cost = tsqrt(seg_sum<SEG>(dv * dv));
+        T cost1 = tmax(max_cost - cost, T(0)) / (max_cost + T(1.1920928955078125e-07));
+        const bool bad = seg_any<SEG>(alive && (v < T(-100)), seg) || n_alive == 0;
+        cost1 = bad ? T(0) : cost1;
+        // small time headways (merge.py:172-180), summed in rl_veh order (MergePO) / slot order (multi-agent)
+        const bool use = alive && is_rl && has && (v > T(0)) && (po_env ? rank >= 0 : true);
+        const T t_headway = tmax(h / (use ? v : T(1)), T(0));
+        const T term = tmin((t_headway - T(1)) / T(1), T(0));
+        T cost2 = T(0);
+        unsigned long long ub = seg_ballot<SEG>(use, seg);
+        const int lim = po_env ? num_rl : o.n_rl_slots;
+        for (int t = 0; t < lim; ++t) {
+          const unsigned long long b = po_env ? seg_ballot<SEG>(use && rank == t, seg) : ub;
+          const bool bit = b != 0ull;
+          const int j = bit ? __ffsll((long long)b) - 1 : 0;
+          ub &= ub - 1ull;
+          const T tj = bperm(term, segbase + j);
+          if (bit) cost2 = cost2 + tj;
+        }
+        reward = tmax(cost1 + T(0.1) * cost2, T(0));
+        reward = crashed ? T(0) : reward;
+      }
+      if (valid && ii == 0) {
+        *rrow = float(reward);
+        *drow = uint8_t((tcount >= s.step_limit) || crashed);
+      }
+      orow += step_rows * obs_dim;
+      rrow += step_rows;
+      drow += step_rows;
+    }
+  }
+
+  if (valid && live_replica) {
+    s.pos[idx] = x;
+    s.vel[idx] = v;
+    s.lane[idx] = route;
+    s.prev_vel[idx] = prev_v;
+    s.accel[idx] = last_acc;
+    s.ctrl_state[idx] = cst;
+    o.seq[idx] = seq;
+    o.origin[idx] = origin;
+    o.foll[idx] = foll;
+    o.foll_h[idx] = foll_h;
+    o.ctl_seq[idx] = ctl_seq;
+    o.arrived_rl[idx] = arrived_rl;
+    o.lead[idx] = lead;
+    o.headway[idx] = h;
+    if (ii == 0) {
+      s.time[rr] = tcount;
+      s.noise_ctr[rr] = nctr;
+      cnt[CNT_SIM_STEPS] = sim_steps;
+      cnt[CNT_SEQ] = seq_ctr;
+      cnt[CNT_CTL] = ctl_ctr;
+      cnt[CNT_ARRIVED] = n_arr;
+      cnt[CNT_DEPARTED] = n_dep;
+      cnt[CNT_TOTAL_ARRIVED] = tot_arr;
+      cnt[CNT_TOTAL_DEPARTED] = tot_dep;
+#pragma unroll
+      for (int f = 0; f < FS_MAX_INFLOWS; ++f) o.emitted[size_t(rr) * FS_MAX_INFLOWS + f] = emitted[f];
+    }
+  }
+}
+
+// Env.reset of an open network: the initial vehicles back in their slots, every other slot free, clocks and
+// id counters restarted (restart_instance: SUMO starts again at time 0, envs/base.py:430-470); S13: one step
+// has run when reset returns.
+template <typename T>
+__global__ void k_reset_open(DevView<T> s, OpenView<T> o, const uint8_t* __restrict__ mask) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= s.R) return;
+  if (mask != nullptr && mask[r] == 0) return;
+  const int N = s.N;
+  int ids = 0;
+  for (int i = 0; i < N; ++i) {
+    const size_t e = size_t(r) * N + i;
+    const bool a = o.init_alive[e] != 0;
+    s.pos[e] = s.init_pos[e];
+    s.vel[e] = s.init_vel[e];
+    s.prev_vel[e] = s.init_vel[e];
+    s.accel[e] = T(0);
+    s.ctrl_state[e] = T(0);
+    s.lane[e] = a ? s.init_lane[e] : -1;
+    o.seq[e] = a ? ids : 0;
+    o.origin[e] = a ? -1 - i : -1;
+    o.foll[e] = -1;
+    o.foll_h[e] = T(3.0e38);
+    o.ctl_seq[e] = -1;
+    o.arrived_rl[e] = 0;
+    o.lead[e] = -1;
+    o.headway[e] = T(1000);
+    ids += a ? 1 : 0;
+  }
+  int32_t* cnt = o.counters + size_t(r) * 8;
+  cnt[CNT_SIM_STEPS] = 1;
+  cnt[CNT_SEQ] = ids;
+  for (int q = 2; q < 8; ++q) cnt[q] = 0;
+  for (int f = 0; f < FS_MAX_INFLOWS; ++f) o.emitted[size_t(r) * FS_MAX_INFLOWS + f] = 0;
+  s.time[r] = 0;
+}
+
+}  // namespace fs

@@ -62,6 +62,7 @@ class FlowSim:
             v = veh[i]
             for k in ("controller", "fail_safe", "speed_mode", "rl_index"):
                 setattr(v, k, int(d[k]))
+            v.type = int(d.get("type", 0))
             p = list(d.get("p", [])) + [0.0] * L.FS_MAX_CTRL_PARAMS
             for k in range(L.FS_MAX_CTRL_PARAMS):
                 v.p[k] = float(p[k])
@@ -70,8 +71,11 @@ class FlowSim:
                 setattr(v, k, float(d[k]))
 
         dt = float(spec["sim_step"])
-        ring_length = np.ascontiguousarray(
-            np.broadcast_to(np.asarray(spec["ring_length"], dtype=np.float64), (self.R,)))
+        self.open_net = spec.get("network") == "merge"
+        ring_length = None
+        if not self.open_net:
+            ring_length = np.ascontiguousarray(
+                np.broadcast_to(np.asarray(spec["ring_length"], dtype=np.float64), (self.R,)))
         init_pos = np.ascontiguousarray(np.asarray(spec["init_pos"], dtype=np.float64).reshape(self.R, self.N))
         init_vel = spec.get("init_vel")
         if init_vel is not None:
@@ -80,23 +84,50 @@ class FlowSim:
         if init_lane is not None:
             init_lane = np.ascontiguousarray(np.asarray(init_lane, dtype=np.int32).reshape(self.R, self.N))
         segs = spec.get("segments")
+        if self.open_net:                                  # one table per route, rows tagged with the route
+            segs = [row + (r,) for r, rt in enumerate(spec["routes"]) for row in map(tuple, rt["segments"])]
         seg_arr = None
         if segs:
             seg_arr = (L.fs_segment * len(segs))()
-            for k, (st, inter, fs0, slope) in enumerate(segs):
+            for k, row in enumerate(segs):
+                st, inter, fs0, slope = row[:4]
                 seg_arr[k].start, seg_arr[k].internal = float(st), int(bool(inter))
                 seg_arr[k].flow_start, seg_arr[k].flow_slope = float(fs0), float(slope)
+                seg_arr[k].route = int(row[4]) if len(row) > 4 else 0
         junc = L.fs_junction()
         J = spec.get("junction")
-        if J:
+        if J and self.open_net:
+            junc.enabled = int(J.get("enabled", 1))
+            junc.lookahead, junc.time_gap = float(J["lookahead"]), float(J["time_gap"])
+        elif J:
             junc.enabled = 1
             for k in ("a_in", "a_out", "b_in", "b_out", "lookahead", "time_gap", "za_lo", "za_hi", "zb_lo", "zb_hi"):
                 setattr(junc, k, float(J[k]))
+        inflow_arr, init_alive, n_inflows = None, None, 0
+        if self.open_net:
+            fl = spec.get("inflows", [])
+            n_inflows = len(fl)
+            if n_inflows > L.FS_MAX_INFLOWS:
+                raise NotImplementedError("more than %d inflows is not built" % L.FS_MAX_INFLOWS)
+            inflow_arr = (L.fs_inflow * max(n_inflows, 1))()
+            for k, f in enumerate(fl):
+                a = inflow_arr[k]
+                a.type, a.route = int(f["type"]), int(f["route"])
+                num = f.get("number", -1)
+                a.number = -1 if num is None else int(num)
+                a.period, a.begin, a.end = float(f["period"]), float(f.get("begin", 1.0)), float(f.get("end", 86400.0))
+                a.depart_speed, a.depart_pos = float(f["depart_speed"]), float(f["depart_pos"])
+            init_alive = np.ascontiguousarray(np.asarray(spec["init_alive"], dtype=np.uint8).reshape(self.R, self.N))
+            if init_vel is None:
+                init_vel = np.zeros((self.R, self.N))
+            if init_lane is None:
+                init_lane = np.ascontiguousarray(np.asarray(spec["init_route"], dtype=np.int32).reshape(self.R, self.N))
         horizon = spec.get("horizon", float("inf"))
         dp = C.POINTER(C.c_double)
         cfg = L.fs_config(
             struct_size=C.sizeof(L.fs_config), abi_version=L.FS_ABI_VERSION, precision=self.precision,
-            network=L.FS_NET_FIGURE_EIGHT if segs else L.FS_NET_RING, env=int(spec.get("env", L.FS_ENV_ACCEL)),
+            network=L.FS_NET_MERGE if self.open_net else (L.FS_NET_FIGURE_EIGHT if segs else L.FS_NET_RING),
+            env=int(spec.get("env", L.FS_ENV_ACCEL)),
             integrator=INTEGRATORS[spec.get("integrator", "euler")],
             num_replicas=self.R, num_vehicles=self.N, num_rl=self.num_rl,
             horizon=-1 if horizon == float("inf") else int(horizon),
@@ -113,10 +144,18 @@ class FlowSim:
             action_low=float(spec.get("action_low", 0.0)), action_high=float(spec.get("action_high", 0.0)),
             po_max_length=float(spec.get("po_max_length", 1.0)),
             lane_change_duration=float(spec.get("lane_change_duration", 0.0)),
-            vehicles=veh, ring_length=ring_length.ctypes.data_as(dp), init_pos=init_pos.ctypes.data_as(dp),
+            vehicles=veh, ring_length=ring_length.ctypes.data_as(dp) if ring_length is not None else None,
+            init_pos=init_pos.ctypes.data_as(dp),
             init_vel=init_vel.ctypes.data_as(dp) if init_vel is not None else None,
             init_lane=init_lane.ctypes.data_as(C.POINTER(C.c_int32)) if init_lane is not None else None,
-            segments=seg_arr, num_segments=len(segs) if segs else 0, reserved2=0, junction=junc)
+            segments=seg_arr, num_segments=len(segs) if segs else 0, num_inflows=n_inflows, junction=junc,
+            inflows=inflow_arr, init_alive=init_alive.ctypes.data_as(C.POINTER(C.c_uint8)) if init_alive is not None else None,
+            merge_x=float(spec.get("merge_x", 0.0)), box_in=float(spec.get("box_in", 0.0)),
+            end_x=float(spec.get("end_x", 0.0)), net_length=float(spec.get("net_length", 0.0)),
+            ma_apply_actions=int(bool(spec.get("ma_apply_actions", False))), reserved3=0)
+        if self.open_net:
+            cfg.route_start[0] = float(spec["routes"][0]["start"])
+            cfg.route_start[1] = float(spec["routes"][1]["start"])
         L.check(self.lib.fs_create(C.byref(cfg), C.byref(self._h)))
         self.obs_dim = self.lib.fs_obs_dim(self._h)
         self.act_dim = self.lib.fs_action_dim(self._h)
@@ -185,8 +224,11 @@ class FlowSim:
     def _field_shape(self, field):
         if field in (L.FS_FIELD_TIME,):
             return (self.R,), np.int32
-        if field in (L.FS_FIELD_LANE, L.FS_FIELD_LAST_LC, L.FS_FIELD_LEADER, L.FS_FIELD_INIT_LANE):
+        if field in (L.FS_FIELD_LANE, L.FS_FIELD_LAST_LC, L.FS_FIELD_LEADER, L.FS_FIELD_INIT_LANE, L.FS_FIELD_ROUTE,
+                     L.FS_FIELD_SEQ, L.FS_FIELD_ORIGIN, L.FS_FIELD_FOLLOWER, L.FS_FIELD_CTL_SEQ, L.FS_FIELD_ARRIVED_RL):
             return (self.R, self.N), np.int32
+        if field == L.FS_FIELD_COUNTERS:
+            return (self.R, 8), np.int32
         if field == L.FS_FIELD_RING_LENGTH:
             return (self.R,), self.real
         return (self.R, self.N), self.real

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FS_ABI_VERSION 3
+#define FS_ABI_VERSION 4
 
 /* ---- error codes -------------------------------------------------------- */
 #define FS_OK 0
@@ -66,14 +66,21 @@ enum fs_env {
   FS_ENV_ACCEL = 0,                 /* AccelEnv                 flow/envs/ring/accel.py:25-183 */
   FS_ENV_WAVE_ATTENUATION = 1,      /* WaveAttenuationEnv       flow/envs/ring/wave_attenuation.py:50-210 */
   FS_ENV_WAVE_ATTENUATION_PO = 2,   /* WaveAttenuationPOEnv     flow/envs/ring/wave_attenuation.py:213-276 */
-  FS_ENV_LANE_CHANGE_ACCEL = 3      /* LaneChangeAccelEnv       flow/envs/ring/lane_change_accel.py:28-154;
+  FS_ENV_LANE_CHANGE_ACCEL = 3,     /* LaneChangeAccelEnv       flow/envs/ring/lane_change_accel.py:28-154;
                                        actions are [acc_0, dir_0, acc_1, dir_1, ...] (2 per RL vehicle) */
+  FS_ENV_MERGE_PO = 4,              /* MergePOEnv               flow/envs/merge.py:28-231: num_rl controlled vehicles
+                                       (rl_queue / rl_veh slotting), obs 5*num_rl, action column = place in rl_veh */
+  FS_ENV_MERGE_MA = 5               /* MultiAgentMergePOEnv     flow/envs/multiagent/merge.py:19-190: one 5-vector and
+                                       one action column per RL slot (column = rl_index), shared reward, no crash */
 };
 
 enum fs_network {
   FS_NET_RING = 0,          /* RingNetwork, flow/networks/ring.py (any number of lanes) */
-  FS_NET_FIGURE_EIGHT = 1   /* FigureEightNetwork, flow/networks/figure_eight.py: a closed one-lane loop that
+  FS_NET_FIGURE_EIGHT = 1,  /* FigureEightNetwork, flow/networks/figure_eight.py: a closed one-lane loop that
                                crosses itself; described by fs_config.segments + fs_config.junction */
+  FS_NET_MERGE = 2          /* MergeNetwork, flow/networks/merge.py: an OPEN one-lane network, two routes (0 = highway,
+                               1 = on-ramp) converging at a priority junction; vehicles enter through fs_config.inflows
+                               and leave at end_x.  num_vehicles is the slot CAPACITY of a replica. */
 };
 
 enum fs_integrator { FS_EULER = 0, FS_BALLISTIC = 1 /* SumoParams.use_ballistic, core/params.py:578-602 */ };
@@ -95,11 +102,22 @@ enum fs_field {
   FS_FIELD_LANE = 10,      /* int32[R,N] get_lane                                        */
   FS_FIELD_LAST_LC = 11,   /* int32[R,N] time_counter of the last lane change (vehicle/traci.py:205-209) */
   FS_FIELD_LEADER = 12,    /* int32[R,N] slot of the own-lane leader, -1 if none (get_leader; read-only) */
-  FS_FIELD_INIT_LANE = 13  /* int32[R,N] Env.initial_state lanes                          */
+  FS_FIELD_INIT_LANE = 13, /* int32[R,N] Env.initial_state lanes (open networks: routes)  */
+  /* open networks only (read-only except ROUTE) */
+  FS_FIELD_ROUTE = 14,     /* int32[R,N] route of the vehicle in the slot, -1 = free slot (alias of LANE) */
+  FS_FIELD_SEQ = 15,       /* int32[R,N] place in the id list = departure order (vehicle/traci.py:279-280)  */
+  FS_FIELD_ORIGIN = 16,    /* int32[R,N] inflow * 2^20 + running number ("flow_<f>.<k>"), or -1-i for initial vehicle i */
+  FS_FIELD_FOLLOWER = 17,  /* int32[R,N] get_follower: the sticky follower of vehicle/traci.py:243-250, -1 if none */
+  FS_FIELD_CTL_SEQ = 18,   /* int32[R,N] >= 0: the vehicle is in MergePOEnv.rl_veh, value = order of joining */
+  FS_FIELD_COUNTERS = 19,  /* int32[R,8] {steps since simulator start, vehicles ever departed (id counter), rl_veh
+                              join counter, arrived last sub-step, departed last sub-step, arrived total,
+                              departed total, 0}  (get_num_arrived / get_outflow_rate inputs, vehicle/traci.py:493-533) */
+  FS_FIELD_ARRIVED_RL = 20 /* int32[R,N] 1: the RL vehicle of this slot arrived in the last sub-step (get_arrived_rl_ids) */
 };
 
 #define FS_MAX_CTRL_PARAMS 8
 #define FS_MAX_SEGMENTS 16
+#define FS_MAX_INFLOWS 8
 
 /* One edge of a closed loop in route order (non-ring networks).  `start` is the loop coordinate of the
  * edge's first metre; Flow's own coordinate of a point `x` on it (get_x_by_id, vehicle/traci.py:1011-1017
@@ -110,8 +128,21 @@ typedef struct fs_segment {
   double flow_start;
   double flow_slope;
   int32_t internal;                   /* 1: junction-internal edge (':...'): no Flow command with junction_mode */
-  int32_t reserved;
+  int32_t route;                      /* FS_NET_MERGE: the route this row belongs to (rows of a route are contiguous,
+                                         starts increasing); 0 otherwise */
 } fs_segment;
+
+/* One InFlows.add entry (flow/core/params.py:1080-1213) of an open network. */
+typedef struct fs_inflow {
+  int32_t type;                       /* vehicle type = fs_vehicle_spec.type of the slots it may occupy */
+  int32_t route;                      /* route of its edge (0 highway, 1 on-ramp) */
+  int32_t number;                     /* total vehicles to create, < 0 = unlimited */
+  int32_t reserved;
+  double period;                      /* seconds between vehicles: 3600 / vehs_per_hour, or `period` */
+  double begin, end;                  /* first departure time / end of the departure interval [s] */
+  double depart_speed;                /* departSpeed [m/s] */
+  double depart_pos;                  /* front position on the first edge at insertion (SUMO "base": the vehicle length) */
+} fs_inflow;
 
 /* The self-crossing of the figure eight (SUMO's junction logic restated, unpinned).
  * Stream a (bottom->top, priority 78) crosses stream b (right->left, priority 46),
@@ -133,6 +164,8 @@ typedef struct fs_vehicle_spec {
   int32_t fail_safe;                  /* enum fs_failsafe */
   int32_t speed_mode;                 /* SUMO speed-mode bitmask, core/params.py:12-18 */
   int32_t rl_index;                   /* column of the action vector, -1 if not RL */
+  int32_t type;                       /* open networks: index of the vehicle type (VehicleParams.add order) */
+  int32_t reserved;
   double p[FS_MAX_CTRL_PARAMS];       /* controller parameters, see enum fs_controller */
   double noise;                       /* sigma of the Gaussian acceleration noise */
   double delay;                       /* delay used by the safe_velocity fail-safe */
@@ -153,8 +186,8 @@ typedef struct fs_config {
   int32_t env;                        /* enum fs_env */
   int32_t integrator;                 /* enum fs_integrator */
   int32_t num_replicas;               /* R */
-  int32_t num_vehicles;               /* N per replica (<= 64) */
-  int32_t num_rl;                     /* RL vehicles per replica */
+  int32_t num_vehicles;               /* N per replica (<= 64); open networks: slot capacity */
+  int32_t num_rl;                     /* RL vehicles per replica; FS_ENV_MERGE_PO: env_params 'num_rl' */
   int32_t horizon;                    /* EnvParams.horizon; <0 means inf */
   int32_t warmup_steps;               /* EnvParams.warmup_steps */
   int32_t sims_per_step;              /* EnvParams.sims_per_step */
@@ -184,8 +217,21 @@ typedef struct fs_config {
   const int32_t* init_lane;           /* [R,N] initial lanes, or NULL -> lane 0 */
   const fs_segment* segments;         /* [num_segments] edge table of a non-ring loop, or NULL */
   int32_t num_segments;               /* 0 for FS_NET_RING */
-  int32_t reserved2;
-  fs_junction junction;               /* crossing model, enabled only for FS_NET_FIGURE_EIGHT */
+  int32_t num_inflows;                /* FS_NET_MERGE: entries of `inflows` (<= FS_MAX_INFLOWS) */
+  fs_junction junction;               /* crossing model (figure eight) / merge right of way: for FS_NET_MERGE only
+                                         enabled, lookahead and time_gap are read (the box is [box_in, merge_x)) */
+  /* ---- open networks (FS_NET_MERGE); ignored otherwise ---- */
+  const fs_inflow* inflows;           /* [num_inflows] in InFlows.add order */
+  const uint8_t* init_alive;          /* [R,N] 1: the slot holds an initial vehicle (init_pos / init_vel / init_lane =
+                                         its coordinate, speed and ROUTE) */
+  double route_start[2];              /* coordinate of the first metre of route 0 / 1 */
+  double merge_x;                     /* coordinate where the two routes join (start of edge 'center') */
+  double box_in;                      /* coordinate of the junction entry lines (merge_x - internal length) */
+  double end_x;                       /* vehicles whose front reaches end_x have arrived */
+  double net_length;                  /* k.network.length(): the normaliser of MergePOEnv.get_state */
+  int32_t ma_apply_actions;           /* FS_ENV_MERGE_MA: 0 = actions are never applied, as this fork ships
+                                         (multiagent/merge.py:92-96); 1 = column rl_index commands the slot, NaN = none */
+  int32_t reserved3;
 } fs_config;
 
 typedef struct fs_sim* fs_handle;

@@ -1,0 +1,519 @@
+"""Oracle restatement of Env.step / Env.reset for OPEN networks (MergeNetwork): vehicles enter through
+inflows, leave at the end of their route, and two routes converge at a priority junction.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Flow-side rules restated here (pinned by the reference's source text; the reference has no numeric
+known-answer test for them beyond the space / parameter checks of
+tests/fast_tests/test_environments.py:616-700, 1140-1225, which tests/test_host.py repeats):
+
+  O1  vehicle bookkeeping of TraCIVehicle.update            flow/core/kernel/vehicle/traci.py:119-259
+      (arrived vehicles removed, departed vehicles appended to the id list, previous speed of a new
+      vehicle is 0, no-leader => headway 1e3 / leader None, and the STICKY follower rule of :243-250:
+      a leader's "follower_headway" is only ever lowered, and a vehicle without a leader has its own
+      follower entry cleared when it is visited in id order)
+  O2  MergePOEnv: rl_queue / rl_veh slotting, 5 features per controlled vehicle, reward
+                                                              flow/envs/merge.py:109-221
+      - actions are applied with the rl_veh list of the PREVIOUS additional_command (envs/base.py:355-357
+        runs apply_rl_actions before additional_command), column = position in rl_veh;
+      - a controlled vehicle that arrived stays in rl_veh for the get_state of that step: its five
+        features are built from the accessors' error values (get_speed -> -1001, leader/follower "")
+  O3  MultiAgentMergePOEnv: one 5-vector per RL vehicle in the network, shared reward, no crash
+      (this fork forces crash = 0, flow/envs/multiagent/base.py:188-190); as shipped its
+      _apply_rl_actions never applies an action (flow/envs/multiagent/merge.py:92-96 iterates
+      enumerate(...)): spec['ma_apply_actions'] = False reproduces that
+  O4  rewards.desired_velocity over the vehicles currently in the network   flow/core/rewards.py:6-59
+  O5  get_x_by_id = edge-start table + position, internal edges resolve to their table entry without
+      the position (network/traci.py:273-289)
+
+SUMO-side rules (third-party code, absent; stated here, PARITY UNPINNED -- DESIGN.md M-list):
+
+  M1  slots: capacity N, partitioned by vehicle type; an inflow takes the lowest free slot of its type
+      (a slot freed by an arrival is free from the next step on; with no free slot the vehicle waits)
+  M2  inflow schedule: the k-th vehicle of a flow is due at begin + k * 3600/vehsPerHour; a vehicle is
+      inserted at the end of the first integration step whose START time (n * sim_step, n = steps since
+      the simulator started) is >= its due time
+  M3  insertion: front at departPos = vehicle length ("base"), speed departSpeed; refused (retried next
+      step) while the gap to the nearest vehicle ahead on the route is below the SUMO-IDM desired gap
+      minGap + max(0, v*tau + v*(v - v_lead) / (2*sqrt(accel*decel))); one vehicle per flow and step
+  M4  arrival: a vehicle whose front reaches the end of the last edge is removed in that step
+  M5  leader = nearest vehicle ahead on the own route (a vehicle on the other branch upstream of the
+      merge point is not a leader); headway = x_lead - len_lead - x
+  M6  right of way at the merge (S-J form): the minor route stops at the junction entry while a major
+      vehicle is inside the junction or reaches its entry within time_gap; a major vehicle stops at the
+      entry while a minor vehicle is inside; both routes inside at once = collision
+  M7  movement = S4-S9 of the ring oracle (slowDown ramp, speed-mode clamps, SUMO-IDM when uncommanded)
+
+dtype float64 restates the reference's arithmetic type; dtype float32 is the bit-twin of the HIP kernel
+`k_steps_open` (same operation order).
+"""
+import numpy as np
+
+from . import controllers as C
+from . import rewards as Rw
+from .refsim import CTRL_RL, controller_dispatch
+
+ENV_MERGE_PO, ENV_MERGE_MA = 4, 5          # include/flowsim.h FS_ENV_MERGE_PO / FS_ENV_MERGE_MA
+NO_LEADER_HEADWAY = 1000.0                 # vehicle/traci.py:237
+ERR = -1001.0                              # default `error` of the vehicle accessors
+BIG = 3.0e38
+
+
+class MergeOracle:
+    """Batched open-network oracle.  ``spec`` keys (plain Python / numpy):
+
+    num_replicas R; num_vehicles N (slot capacity); vehicles [N] slot dicts as in RingOracle plus
+    'type' (index of the vehicle type); routes: [{'start': x, 'segments': [(start, internal,
+    flow_start, flow_slope), ...]}] for route 0 (major) and 1 (minor); merge_x, box_in, end_x;
+    junction: {'enabled', 'lookahead', 'time_gap'}; inflows: [{'type', 'route', 'period', 'begin',
+    'end', 'number', 'depart_speed', 'depart_pos'}]; init_alive / init_pos / init_vel / init_route [R,N];
+    net_length, max_speed, env, num_rl, target_velocity, action_low/high, clip_actions, evaluate,
+    horizon, warmup_steps, sims_per_step, sim_step, slowdown_ramp, integrator, junction_mode,
+    crash_gap, seed, ma_apply_actions.
+    """
+
+    def __init__(self, spec, dtype=np.float64):
+        self.spec = spec
+        self.dt_ = np.dtype(dtype)
+        T = self.dt_.type
+        self.R, self.N = int(spec["num_replicas"]), int(spec["num_vehicles"])
+        R, N = self.R, self.N
+        self.dt = float(spec["sim_step"])
+        self.ramp = T(spec.get("slowdown_ramp", self.dt / (self.dt + 1e-3)))
+        self.ballistic = spec.get("integrator", "euler") == "ballistic"
+        self.junction_mode = int(spec.get("junction_mode", 1))
+        self.crash_gap = T(spec.get("crash_gap", 0.0))
+        self.veh = spec["vehicles"]
+        self.veh_len = np.array([v.get("length", 5.0) for v in self.veh], dtype=self.dt_)
+        self.slot_type = np.array([v["type"] for v in self.veh], dtype=np.int64)
+        self.is_rl = np.array([v["controller"] == CTRL_RL for v in self.veh])
+        self.routes = spec["routes"]
+        self.merge_x, self.box_in, self.end_x = T(spec["merge_x"]), T(spec["box_in"]), T(spec["end_x"])
+        self.junction = spec.get("junction") or {"enabled": 0}
+        self.inflows = spec.get("inflows", [])
+        self.env = int(spec.get("env", ENV_MERGE_PO))
+        self.num_rl = int(spec.get("num_rl", 0))
+        self.net_length = T(spec["net_length"])
+        self.max_speed = T(spec["max_speed"])
+        # norm([target] * n) for n = 0..N, evaluated like the reference (float64 numpy) -- rewards.py:50-51
+        tv = float(spec.get("target_velocity", 0.0))
+        self.max_cost = np.array([np.linalg.norm(np.array([tv] * n, dtype=np.float64)) for n in range(N + 1)]
+                                 ).astype(self.dt_)
+        self.init_alive = np.asarray(spec["init_alive"], dtype=bool).reshape(R, N)
+        self.init_pos = np.asarray(spec["init_pos"], dtype=np.float64).astype(self.dt_).reshape(R, N)
+        self.init_vel = np.asarray(spec["init_vel"], dtype=np.float64).astype(self.dt_).reshape(R, N)
+        self.init_route = np.asarray(spec["init_route"], dtype=np.int64).reshape(R, N)
+        z = lambda dt=self.dt_: np.zeros((R, N), dtype=dt)                                 # noqa: E731
+        self.x, self.v, self.prev_v, self.lac_a, self.last_accel = z(), z(), z(), z(), z()
+        self.route = np.full((R, N), -1, dtype=np.int64)           # -1: free slot
+        self.seq = z(np.int64)                                      # position in the id list (departure order)
+        self.origin = np.full((R, N), -1, dtype=np.int64)          # flow * 2^20 + k, or -1-i for initial vehicle i
+        self.foll = np.full((R, N), -1, dtype=np.int64)            # sticky follower slot (O1)
+        self.foll_h = np.full((R, N), T(BIG), dtype=self.dt_)      # its recorded headway ("follower_headway")
+        self.ctl_seq = np.full((R, N), -1, dtype=np.int64)         # >= 0: in rl_veh, order of joining (O2)
+        self.lead = np.full((R, N), -1, dtype=np.int64)
+        self.h = np.full((R, N), T(NO_LEADER_HEADWAY), dtype=self.dt_)
+        self.pis_H = max(int(38 / self.dt) - 1, 1)
+        self.pis_hist = None
+        self.pis_n = z(np.int64)
+        self.time_counter = np.zeros(R, dtype=np.int64)
+        self.step_counter = np.zeros(R, dtype=np.int64)            # noise stream position
+        self.sim_steps = np.zeros(R, dtype=np.int64)               # integration steps since the simulator started
+        self.seq_ctr = np.zeros(R, dtype=np.int64)
+        self.ctl_ctr = np.zeros(R, dtype=np.int64)
+        self.emitted = np.zeros((R, max(len(self.inflows), 1)), dtype=np.int64)
+        self.num_arrived = np.zeros(R, dtype=np.int64)             # of the last sub-step (get_num_arrived)
+        self.num_departed = np.zeros(R, dtype=np.int64)
+        self.total_arrived = np.zeros(R, dtype=np.int64)
+        self.total_departed = np.zeros(R, dtype=np.int64)
+        self.arrived_rl = np.zeros((R, N), dtype=bool)             # RL slots that arrived in the last sub-step
+        self._just_arrived = np.zeros((R, N), dtype=bool)
+
+    # ------------------------------------------------------------------ geometry
+    @property
+    def alive(self):
+        return self.route >= 0
+
+    def _segment_lookup(self, x, route):
+        """(internal?, Flow table coordinate) of coordinate x on ``route`` (O5)."""
+        T = self.dt_.type
+        internal = np.zeros(x.shape, dtype=bool)
+        flow_x = np.zeros(x.shape, dtype=self.dt_)
+        for r, rt in enumerate(self.routes):
+            inter = np.zeros(x.shape, dtype=bool)
+            start = np.zeros(x.shape, dtype=self.dt_)
+            fstart = np.zeros(x.shape, dtype=self.dt_)
+            slope = np.zeros(x.shape, dtype=self.dt_)
+            for (st, it, fs, sl) in rt["segments"]:
+                hit = x >= T(st)
+                inter = np.where(hit, bool(it), inter)
+                start = np.where(hit, T(st), start)
+                fstart = np.where(hit, T(fs), fstart)
+                slope = np.where(hit, T(sl), slope)
+            sel = route == r
+            internal = np.where(sel, inter, internal)
+            flow_x = np.where(sel, fstart + slope * (x - start), flow_x)
+        return internal, flow_x
+
+    def flow_x(self):
+        return self._segment_lookup(self.x, self.route)[1]
+
+    # ------------------------------------------------------------------ O1 / M5: neighbour snapshot
+    def _update_neighbours(self, active):
+        """Leader / headway of every vehicle (M5) and the sticky follower bookkeeping (O1) after a move."""
+        T = self.dt_.type
+        R, N = self.R, self.N
+        x, alive, route = self.x, self.alive, self.route
+        jj = np.arange(N)
+        d = x[:, None, :] - x[:, :, None]                                  # d[r,i,j] = x_j - x_i
+        ahead = (d > 0) | ((d == 0) & (jj[None, None, :] < jj[None, :, None]))
+        shared = x >= self.merge_x
+        cand = ahead & alive[:, None, :] & alive[:, :, None] & (jj[None, None, :] != jj[None, :, None]) & \
+            ((route[:, None, :] == route[:, :, None]) | shared[:, None, :])
+        dl = np.where(cand, d, T(BIG))
+        lead = np.argmin(dl, axis=2)                                       # first minimum = lowest slot on a tie
+        has = np.take_along_axis(dl, lead[:, :, None], 2)[:, :, 0] < T(BIG)
+        dlead = np.take_along_axis(d, lead[:, :, None], 2)[:, :, 0]
+        h = np.where(has, dlead - self.veh_len[lead], T(NO_LEADER_HEADWAY))
+        lead = np.where(has, lead, -1)
+        a2 = active[:, None]
+        self.lead = np.where(a2, lead, self.lead)
+        self.h = np.where(a2, h, self.h)
+        # ---- sticky follower (vehicle/traci.py:232-250), visited in id-list (seq) order
+        # a vehicle WITHOUT a leader clears its own entry when visited: only followers later in the id
+        # list can re-register in this update, starting from follower_headway = 1e3
+        no_lead = alive & ~has
+        start_h = np.where(no_lead, T(NO_LEADER_HEADWAY), self.foll_h)
+        start_f = np.where(no_lead, -1, self.foll)
+        # candidate followers j of X: leader(j) == X, and (X has a leader or seq_j > seq_X)
+        is_foll = (lead[:, None, :] == jj[None, :, None]) & alive[:, None, :] & has[:, None, :]   # [r,X,j]
+        later = self.seq[:, None, :] > self.seq[:, :, None]
+        elig = is_foll & (has[:, :, None] | later)
+        hj = np.where(elig, h[:, None, :], T(BIG))
+        # the smallest headway wins; on a tie the first in the id list (it is visited first and '<' is strict)
+        best = hj.min(axis=2)
+        tie = np.where(hj == best[:, :, None], self.seq[:, None, :], np.iinfo(np.int64).max)
+        bj = np.argmin(tie, axis=2)
+        better = (best < start_h) & (best < T(BIG))
+        new_f = np.where(better, bj, start_f)
+        new_h = np.where(better, best, start_h)
+        upd = a2 & alive
+        self.foll = np.where(upd, new_f, self.foll)
+        self.foll_h = np.where(upd, new_h, self.foll_h)
+        return has
+
+    # ------------------------------------------------------------------ M6
+    def _yield_speed_cap(self, v):
+        T = self.dt_.type
+        J = self.junction
+        cap = np.full(self.x.shape, T(BIG))
+        if not J.get("enabled", 0):
+            return cap
+        x, alive, route = self.x, self.alive, self.route
+        D, Tg = T(J["lookahead"]), T(J["time_gap"])
+        in_reach = alive & (x < self.merge_x)
+        major_busy = np.any(in_reach & (route == 0) & (x >= self.box_in - Tg * v), axis=1)[:, None]
+        minor_in_box = np.any(in_reach & (route == 1) & (x >= self.box_in), axis=1)[:, None]
+        gap = self.box_in - x
+        stop = np.stack([C.sumo_idm_speed(v[:, i], np.zeros(self.R, self.dt_), gap[:, i], np.ones(self.R, bool),
+                                          self.dt, accel=vs["max_accel"], decel=vs["max_decel"],
+                                          tau=vs.get("sumo_tau", 1.0), min_gap=vs.get("sumo_min_gap", 2.5),
+                                          max_speed=vs.get("sumo_max_speed", 30.0))
+                         for i, vs in enumerate(self.veh)], axis=1)
+        approaching = alive & (x >= self.box_in - D) & (x < self.box_in)
+        yields = approaching & (((route == 1) & major_busy) | ((route == 0) & minor_in_box))
+        return np.where(yields, stop, cap)
+
+    def _box_crash(self):
+        if not self.junction.get("enabled", 0):
+            return np.zeros(self.R, dtype=bool)
+        inside = self.alive & (self.x >= self.box_in) & (self.x < self.merge_x)
+        return np.any(inside & (self.route == 0), axis=1) & np.any(inside & (self.route == 1), axis=1)
+
+    # ------------------------------------------------------------------ O2: who is commanded by which column
+    def _ctl_rank(self):
+        """Position of each slot in rl_veh (-1 if not in it): rank by order of joining."""
+        c = self.ctl_seq
+        inl = c >= 0
+        rank = (inl[:, None, :] & (c[:, None, :] < c[:, :, None])).sum(axis=2)
+        return np.where(inl, rank, -1)
+
+    def _rl_inputs(self, actions):
+        R, N = self.R, self.N
+        rl_value = np.zeros((R, N), dtype=self.dt_)
+        rl_cmd = np.zeros((R, N), dtype=bool)
+        if actions is None:
+            return rl_value, rl_cmd
+        acts = np.asarray(actions, dtype=self.dt_)
+        if self.env == ENV_MERGE_PO:                                      # merge.py:109-115
+            rank = self._ctl_rank()
+            ok = (rank >= 0) & self.alive & self.is_rl[None, :]
+            rl_value = np.where(ok, np.take_along_axis(acts, np.clip(rank, 0, acts.shape[1] - 1), 1), rl_value)
+            rl_cmd = ok
+        elif self.spec.get("ma_apply_actions", False):                    # the evident intent of multiagent/merge.py:92-96
+            for i, vs in enumerate(self.veh):
+                if vs["controller"] == CTRL_RL:
+                    a = acts[:, vs["rl_index"]]
+                    rl_cmd[:, i] = self.alive[:, i] & ~np.isnan(a)       # NaN: no action for this vehicle
+                    rl_value[:, i] = np.where(rl_cmd[:, i], a, 0)
+        return rl_value, rl_cmd
+
+    def _additional_command(self, active):
+        """MergePOEnv.additional_command (merge.py:189-221) on the vehicles known before this sub-step moves."""
+        if self.env != ENV_MERGE_PO:
+            return
+        alive_rl = self.alive & self.is_rl[None, :]
+        a2 = active[:, None]
+        # vehicles that left are dropped from rl_veh (and from the queue, which is implicit here)
+        self.ctl_seq = np.where(a2 & ~alive_rl, -1, self.ctl_seq)
+        n_ctl = (self.ctl_seq >= 0).sum(axis=1)
+        free = np.maximum(self.num_rl - n_ctl, 0)
+        queued = alive_rl & (self.ctl_seq < 0)
+        # queue order = order of entering the network (rl_ids is scanned every step; vehicles of one step
+        # enter the queue in sorted-id order, here: departure order)
+        qrank = (queued[:, None, :] & (self.seq[:, None, :] < self.seq[:, :, None])).sum(axis=2)
+        take = queued & (qrank < free[:, None]) & a2
+        self.ctl_seq = np.where(take, self.ctl_ctr[:, None] + qrank, self.ctl_seq)
+        self.ctl_ctr = self.ctl_ctr + take.sum(axis=1)
+
+    # ------------------------------------------------------------------ reset
+    def reset(self, mask=None):
+        T = self.dt_.type
+        m = np.ones(self.R, dtype=bool) if mask is None else np.asarray(mask, dtype=bool)
+        m2 = m[:, None]
+        N = self.N
+        self.x = np.where(m2, self.init_pos, self.x)
+        self.v = np.where(m2, self.init_vel, self.v)
+        self.prev_v = np.where(m2, self.init_vel, self.prev_v)
+        self.route = np.where(m2, np.where(self.init_alive, self.init_route, -1), self.route)
+        ids = np.cumsum(self.init_alive, axis=1) - 1                       # id-list order = slot order at reset
+        self.seq = np.where(m2, np.where(self.init_alive, ids, 0), self.seq)
+        self.origin = np.where(m2, np.where(self.init_alive, -1 - np.arange(N)[None, :], -1), self.origin)
+        self.seq_ctr = np.where(m, self.init_alive.sum(axis=1), self.seq_ctr)
+        self.foll = np.where(m2, -1, self.foll)
+        self.foll_h = np.where(m2, T(BIG), self.foll_h)
+        self.ctl_seq = np.where(m2, -1, self.ctl_seq)
+        self.ctl_ctr = np.where(m, 0, self.ctl_ctr)
+        self.lac_a = np.where(m2, T(0), self.lac_a)
+        self.last_accel = np.where(m2, T(0), self.last_accel)
+        self.emitted = np.where(m2[:, :1], 0, self.emitted)
+        self.time_counter = np.where(m, 0, self.time_counter)
+        self.sim_steps = np.where(m, 1, self.sim_steps)                    # S13: one step ran during the reset
+        for a in (self.num_arrived, self.num_departed, self.total_arrived, self.total_departed):
+            a[m] = 0
+        self.arrived_rl = np.where(m2, False, self.arrived_rl)
+        self._update_neighbours(m)
+        obs = self.get_state()
+        for _ in range(int(self.spec.get("warmup_steps", 0))):
+            obs, _, _ = self.step(None, _mask=m)
+        return obs
+
+    # ------------------------------------------------------------------ step
+    def _insert(self, active):
+        """M2 / M3, flows in InFlows order."""
+        T = self.dt_.type
+        R, N = self.R, self.N
+        rows = np.arange(R)
+        self.num_departed = np.where(active, 0, self.num_departed)
+        now = (self.sim_steps - 1).astype(np.float64) * self.dt           # start time of the step that just ran
+        for f, fl in enumerate(self.inflows):
+            k = self.emitted[:, f]
+            due_t = float(fl["begin"]) + k.astype(np.float64) * float(fl["period"])
+            due = (due_t <= now) & (due_t <= float(fl.get("end", 86400.0)))
+            if fl.get("number", -1) is not None and fl.get("number", -1) >= 0:
+                due &= k < int(fl["number"])
+            typ, route = int(fl["type"]), int(fl["route"])
+            free = (~self.alive) & (self.slot_type[None, :] == typ) & ~self._just_arrived
+            slot = np.argmax(free, axis=1)                                 # lowest free slot of the type
+            has_slot = free.any(axis=1)
+            vs = self.veh[int(np.flatnonzero(self.slot_type == typ)[0])]
+            x_dep = T(self.routes[route]["start"]) + T(fl["depart_pos"])
+            v_dep = T(fl["depart_speed"])
+            cand = self.alive & ((self.route == route) | (self.x >= self.merge_x))
+            back = np.where(cand, self.x - self.veh_len[None, :], T(BIG))
+            j = np.argmin(np.where(cand, self.x, T(BIG)), axis=1)         # nearest vehicle ahead = smallest x
+            has_lead = cand.any(axis=1)
+            gap = back[rows, j] - x_dep
+            v_lead = self.v[rows, j]
+            two_sqrt = T(2) * np.sqrt(T(vs["max_accel"]) * T(vs["max_decel"]))
+            need = T(vs.get("sumo_min_gap", 2.5)) + np.maximum(
+                T(0), v_dep * T(vs.get("sumo_tau", 1.0)) + v_dep * (v_dep - v_lead) / two_sqrt)
+            ok = active & due & has_slot & (~has_lead | (gap >= need))
+            r_ok = rows[ok]
+            s_ok = slot[ok]
+            self.x[r_ok, s_ok] = x_dep
+            self.v[r_ok, s_ok] = v_dep
+            self.prev_v[r_ok, s_ok] = T(0)                                 # previous_speeds.get(veh_id, 0)
+            self.lac_a[r_ok, s_ok] = T(0)
+            self.last_accel[r_ok, s_ok] = T(0)
+            self.route[r_ok, s_ok] = route
+            self.seq[r_ok, s_ok] = self.seq_ctr[ok]
+            self.origin[r_ok, s_ok] = f * (1 << 20) + k[ok]
+            self.foll[r_ok, s_ok] = -1
+            self.foll_h[r_ok, s_ok] = T(BIG)
+            self.ctl_seq[r_ok, s_ok] = -1
+            self.pis_n[r_ok, s_ok] = 0
+            self.seq_ctr = self.seq_ctr + ok
+            self.emitted[:, f] = k + ok
+            self.num_departed = self.num_departed + ok
+            self.total_departed = self.total_departed + ok
+
+    def _substep(self, actions, active):
+        T = self.dt_.type
+        dt = T(self.dt)
+        R, N = self.R, self.N
+        alive = self.alive
+        v, x = self.v, self.x
+        lead, h = self.lead, self.h
+        has_lead = lead >= 0
+        li = np.where(has_lead, lead, 0)
+        v_lead = np.where(has_lead, np.take_along_axis(v, li, 1), T(ERR))
+        fi = np.where(self.foll >= 0, self.foll, 0)
+        v_follow = np.take_along_axis(v, fi, 1)
+        h_follow = np.take_along_axis(h, fi, 1)
+        internal, _ = self._segment_lookup(x, self.route)
+        on_edge = ~internal if self.junction_mode else np.ones((R, N), dtype=bool)
+        rl_value, rl_cmd = self._rl_inputs(actions)                       # envs/base.py:355 (before additional_command)
+        n_alive = alive.sum(axis=1)
+        acc, commanded = controller_dispatch(
+            self, v, v_lead, h, has_lead, v_follow, h_follow, rl_value, rl_cmd, on_edge, active,
+            lambda: Rw.tree_sum(np.where(alive, v, T(0))) / np.maximum(n_alive, 1).astype(self.dt_))
+        self._additional_command(active)                                   # envs/base.py:357
+        # ---- M7 movement
+        next_vel = np.maximum(v + acc * dt, T(0))
+        v_cmd = v + (next_vel - v) * self.ramp
+        v_new = v.copy()
+        for i, vs in enumerate(self.veh):
+            sl = (slice(None), i)
+            v_sumo = C.sumo_idm_speed(v[sl], v_lead[sl], h[sl], has_lead[sl], self.dt,
+                                      accel=vs["max_accel"], decel=vs["max_decel"],
+                                      tau=vs.get("sumo_tau", 1.0), min_gap=vs.get("sumo_min_gap", 2.5),
+                                      max_speed=vs.get("sumo_max_speed", 30.0))
+            vc = v_cmd[sl]
+            mode = int(vs.get("speed_mode", 0))
+            if mode & 1:
+                vc = np.minimum(vc, v_sumo)
+            if mode & 2:
+                vc = np.minimum(vc, v[sl] + T(vs["max_accel"]) * dt)
+            if mode & 4:
+                vc = np.maximum(vc, v[sl] - T(vs["max_decel"]) * dt)
+            v_new[sl] = np.where(commanded[sl], vc, v_sumo)
+        cap = self._yield_speed_cap(v)
+        obeys = np.array([(int(vs.get("speed_mode", 0)) & 1) != 0 for vs in self.veh])[None, :]
+        v_new = np.where(obeys | ~commanded, np.minimum(v_new, cap), v_new)
+        x_new = x + ((v + v_new) / T(2) * dt if self.ballistic else v_new * dt)
+        mv = active[:, None] & alive
+        self.prev_v = np.where(mv, v, self.prev_v)
+        self.x = np.where(mv, x_new, x)
+        self.v = np.where(mv, v_new, v)
+        self.last_accel = np.where(mv, acc, self.last_accel)
+        self.time_counter = self.time_counter + active
+        self.step_counter = self.step_counter + active
+        self.sim_steps = self.sim_steps + active
+        # ---- M4 arrivals
+        arrived = mv & (self.x >= self.end_x)
+        self.arrived_rl = np.where(active[:, None], arrived & self.is_rl[None, :], self.arrived_rl)
+        self._just_arrived = arrived
+        self.route = np.where(arrived, -1, self.route)
+        self.num_arrived = np.where(active, arrived.sum(axis=1), self.num_arrived)
+        self.total_arrived = self.total_arrived + arrived.sum(axis=1)
+        # ---- M2 / M3 insertions, then the new snapshot (O1)
+        self._insert(active)
+        has_new = self._update_neighbours(active)
+        crash = np.any(self.alive & has_new & (self.h < self.crash_gap), axis=1) | self._box_crash()
+        return crash & active
+
+    def step(self, actions=None, _mask=None):
+        active = np.ones(self.R, dtype=bool) if _mask is None else _mask.copy()
+        crashed = np.zeros(self.R, dtype=bool)
+        for _ in range(int(self.spec.get("sims_per_step", 1))):
+            c = self._substep(actions, active & ~crashed)
+            if self.env == ENV_MERGE_MA:                                   # multiagent/base.py:188-190: crash = 0
+                c = np.zeros_like(c)
+            crashed |= c
+        obs = self.get_state()
+        horizon = self.spec.get("horizon", float("inf"))
+        limit = self.spec.get("sims_per_step", 1) * (self.spec.get("warmup_steps", 0) + horizon)
+        done = (self.time_counter >= limit) | crashed
+        reward = self.compute_reward(actions, crashed)
+        return obs, reward, done
+
+    # ------------------------------------------------------------------ env heads
+    def _five(self, i):
+        """The five features of the vehicle in slot i ([R,5]) -- merge.py:128-156 / multiagent/merge.py:108-140."""
+        T = self.dt_.type
+        R = self.R
+        rows = np.arange(R)
+        fx = self.flow_x()
+        alive = self.alive[:, i]
+        this_speed = np.where(alive, self.v[:, i], T(ERR))
+        lead = np.where(alive, self.lead[:, i], -1)
+        foll = np.where(alive, self.foll[:, i], -1)
+        li, fi = np.where(lead >= 0, lead, 0), np.where(foll >= 0, foll, 0)
+        lead_speed = np.where(lead >= 0, self.v[rows, li], self.max_speed)
+        lead_head = np.where(lead >= 0, fx[rows, li] - fx[:, i] - self.veh_len[i], self.net_length)
+        follow_speed = np.where(foll >= 0, self.v[rows, fi], T(0))
+        follow_head = np.where(foll >= 0, self.h[rows, fi], self.net_length)
+        return np.stack([this_speed / self.max_speed, (lead_speed - this_speed) / self.max_speed,
+                         lead_head / self.net_length, (this_speed - follow_speed) / self.max_speed,
+                         follow_head / self.net_length], axis=1)
+
+    def get_state(self):
+        T = self.dt_.type
+        R, N = self.R, self.N
+        if self.env == ENV_MERGE_PO:
+            obs = np.zeros((R, 5 * self.num_rl), dtype=self.dt_)
+            rank = self._ctl_rank()
+            for i in range(N):
+                if not self.is_rl[i]:
+                    continue
+                five = self._five(i)
+                for k in range(self.num_rl):
+                    sel = rank[:, i] == k
+                    obs[sel, 5 * k:5 * k + 5] = five[sel]
+            return obs
+        rl_slots = [i for i in range(N) if self.is_rl[i]]
+        obs = np.zeros((R, 5 * len(rl_slots)), dtype=self.dt_)
+        for i in rl_slots:                                                 # column block = vehicles[i]['rl_index']
+            c = self.veh[i]["rl_index"]
+            five = self._five(i)
+            obs[:, 5 * c:5 * c + 5] = np.where(self.alive[:, i, None], five, T(0))
+        return obs
+
+    def compute_reward(self, actions, fail):
+        T = self.dt_.type
+        alive = self.alive
+        n = alive.sum(axis=1)
+        if self.spec.get("evaluate", False):                               # merge.py:161-162
+            return np.where(n > 0, Rw.tree_sum(np.where(alive, self.v, T(0))) / np.maximum(n, 1).astype(self.dt_), T(0))
+        # O4: desired_velocity over the vehicles in the network
+        max_cost = self.max_cost[n]
+        d = np.where(alive, self.v - T(self.spec["target_velocity"]), T(0))
+        cost = np.sqrt(Rw.tree_sum(d * d))
+        cost1 = np.maximum(max_cost - cost, T(0)) / (max_cost + T(Rw.EPS_F32))
+        bad = np.any(alive & (self.v < T(-100)), axis=1) | (n == 0)
+        cost1 = np.where(bad, T(0), cost1)
+        # small time headways of the controlled (MergePO) / all (multi-agent) RL vehicles, in rl_veh / slot order
+        cost2 = np.zeros(self.R, dtype=self.dt_)
+        if self.env == ENV_MERGE_PO:
+            rank = self._ctl_rank()
+            order = [(k, None) for k in range(self.num_rl)]
+        else:
+            rank = None
+            order = [(None, i) for i in range(self.N) if self.is_rl[i]]
+        for k, i in order:
+            if k is not None:
+                sel = (rank == k) & alive                                   # a ghost has no leader: skipped
+                idx = np.argmax(sel, axis=1)
+                has_v = sel.any(axis=1)
+            else:
+                idx = np.full(self.R, i)
+                has_v = alive[:, i]
+            rows = np.arange(self.R)
+            vv, hh, ld = self.v[rows, idx], self.h[rows, idx], self.lead[rows, idx]
+            use = has_v & (ld >= 0) & (vv > T(0))
+            t_headway = np.maximum(hh / np.where(use, vv, T(1)), T(0))
+            term = np.minimum((t_headway - T(1)) / T(1), T(0))
+            cost2 = np.where(use, cost2 + term, cost2)
+        reward = np.maximum(T(1.0) * cost1 + T(0.1) * cost2, T(0))
+        return np.where(np.asarray(fail), T(0), reward)

@@ -106,3 +106,58 @@ def figure_eight_spec(R=4, N=14, radius=30.0, horizon=200, seed=0, junction_leng
                 sims_per_step=1, vehicles=veh, init_pos=X, junction_mode=1, segments=segs, junction=junction)
     spec.update(kw)
     return spec
+
+
+def merge_tables(pre=200.0, merge=100.0, post=100.0, junction_length=0.1, center_length=22.5, inflow_len=100.0):
+    """Route tables of MergeNetwork written out literally (independent of flow_amd.networks.merge so the
+    host mirror can be checked against it).  Both routes share one coordinate with the merge point (start
+    of edge 'center') at merge_x; Flow's edge-start table is flow/networks/merge.py:198-216; internal edges
+    resolve to their table entry without the position (network/traci.py:280-287, slope 0)."""
+    j, J = junction_length, center_length
+    up0 = inflow_len + j + pre + J                  # length of the highway route upstream of the merge point
+    up1 = inflow_len + j + merge + J
+    merge_x = max(up0, up1)
+    s0, s1 = merge_x - up0, merge_x - up1
+    c_start = inflow_len + pre + 22.6               # ("center", INFLOW_EDGE_LEN + premerge + 22.6)
+    r0 = [(s0, 0, 0.0, 1.0), (s0 + inflow_len, 1, inflow_len, 0.0), (s0 + inflow_len + j, 0, inflow_len + 0.1, 1.0),
+          (s0 + inflow_len + j + pre, 1, inflow_len + pre + 0.1, 0.0), (merge_x, 0, c_start, 1.0)]
+    im = inflow_len + pre + post + 22.6             # ("inflow_merge", ...)
+    r1 = [(s1, 0, im, 1.0), (s1 + inflow_len, 1, 2 * inflow_len + pre + post + 22.6, 0.0),
+          (s1 + inflow_len + j, 0, 2 * inflow_len + pre + post + 22.7, 1.0),
+          (s1 + inflow_len + j + merge, 1, inflow_len + pre + 0.1, 0.0), (merge_x, 0, c_start, 1.0)]
+    net_length = 2 * inflow_len + pre + merge + post + 2 * j + 2 * J
+    return dict(routes=[dict(start=s0, segments=r0), dict(start=s1, segments=r1)], merge_x=merge_x,
+                box_in=merge_x - J, end_x=merge_x + post, net_length=net_length)
+
+
+def merge_spec(R=4, cap_human=12, cap_rl=4, num_rl=2, pre=200.0, merge=100.0, post=100.0, horizon=200, seed=0,
+               q_highway=1800.0, q_rl=200.0, q_merge=300.0, n_init=3, env=None, time_gap=1.0, **kw):
+    """MergeNetwork + MergePOEnv-like spec: IDM humans (noise 0.2, obey_safe_speed) and RL vehicles entering
+    through three inflows as in examples/exp_configs/rl/multiagent/multiagent_merge.py:46-83."""
+    from oracle import opennet as O
+    tb = merge_tables(pre, merge, post)
+    N = cap_human + cap_rl
+    veh = [idm_vehicle(noise=0.2, speed_mode=1, type=0) for _ in range(cap_human)] + \
+          [idm_vehicle(controller=S.CTRL_RL, rl_index=k, speed_mode=1, type=1) for k in range(cap_rl)]
+    rng = np.random.default_rng(seed)
+    alive = np.zeros((R, N), dtype=bool)
+    alive[:, :n_init] = True
+    s0 = tb["routes"][0]["start"]
+    # initial humans spread over the highway edges, slot 0 furthest downstream (placement is host work)
+    base = s0 + 100.1 + pre - 30.0 - 40.0 * np.arange(n_init)
+    X = np.zeros((R, N))
+    X[:, :n_init] = base[None, :] + rng.uniform(0, 5.0, (R, n_init))
+    spec = dict(num_replicas=R, num_vehicles=N, num_rl=num_rl, sim_step=0.2, max_speed=30.0,
+                env=O.ENV_MERGE_PO if env is None else env, target_velocity=20.0, action_low=-1.5, action_high=1.5,
+                horizon=horizon, warmup_steps=0, sims_per_step=1, vehicles=veh, seed=seed,
+                junction=dict(enabled=1, lookahead=merge, time_gap=time_gap), junction_mode=1,
+                inflows=[dict(type=0, route=0, period=3600.0 / q_highway, begin=1.0, end=86400.0, number=-1,
+                              depart_speed=10.0, depart_pos=5.0),
+                         dict(type=1, route=0, period=3600.0 / q_rl, begin=1.0, end=86400.0, number=-1,
+                              depart_speed=10.0, depart_pos=5.0),
+                         dict(type=0, route=1, period=3600.0 / q_merge, begin=1.0, end=86400.0, number=-1,
+                              depart_speed=7.5, depart_pos=5.0)],
+                init_alive=alive, init_pos=X, init_vel=np.zeros((R, N)), init_route=np.zeros((R, N), dtype=np.int32),
+                network="merge", **tb)
+    spec.update(kw)
+    return spec

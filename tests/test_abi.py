@@ -35,15 +35,16 @@ def test_library_exports_every_declared_symbol(lib):
     for name in declared_symbols():
         assert hasattr(lib, name), name
     from flow_amd import _lib
-    assert lib.fs_abi_version() == _lib.FS_ABI_VERSION == 3
+    assert lib.fs_abi_version() == _lib.FS_ABI_VERSION == 4
 
 
 def test_ctypes_layout_matches_the_c_header(tmp_path):
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "flowsim.h"\n'
-                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(fs_config), sizeof(fs_vehicle_spec),'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(fs_config), sizeof(fs_vehicle_spec),'
                    ' offsetof(fs_config, seed), offsetof(fs_config, vehicles), offsetof(fs_vehicle_spec, noise),'
-                   ' offsetof(fs_config, junction), sizeof(fs_segment));'
+                   ' offsetof(fs_config, junction), sizeof(fs_segment), sizeof(fs_inflow), offsetof(fs_config, inflows),'
+                   ' offsetof(fs_config, route_start), offsetof(fs_config, ma_apply_actions));'
                    'return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
@@ -55,6 +56,8 @@ def test_ctypes_layout_matches_the_c_header(tmp_path):
     assert int(out[3]) == _lib.fs_config.vehicles.offset
     assert int(out[4]) == _lib.fs_vehicle_spec.noise.offset
     assert int(out[5]) == _lib.fs_config.junction.offset and int(out[6]) == ctypes.sizeof(_lib.fs_segment)
+    assert int(out[7]) == ctypes.sizeof(_lib.fs_inflow) and int(out[8]) == _lib.fs_config.inflows.offset
+    assert int(out[9]) == _lib.fs_config.route_start.offset and int(out[10]) == _lib.fs_config.ma_apply_actions.offset
 
 
 def test_enums_agree_between_header_binding_and_oracle():

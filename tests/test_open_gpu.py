@@ -1,0 +1,194 @@
+"""GPU parity of the open-network path (FS_NET_MERGE, `k_steps_open`) against oracle/opennet.py on the
+same seeded inputs, through the C ABI.
+
+Bars: float32 kernel vs the float32 oracle twin -- bit-exact on every state field, observation, reward
+and done flag for noise-free configurations (the only libm call on this path is the Gaussian noise);
+float64 kernel vs the float64 oracle (the reference's arithmetic type) -- 1e-9.
+"""
+import numpy as np
+import pytest
+
+from helpers import idm_vehicle, merge_spec
+from oracle import opennet as O
+from oracle import refsim as S
+
+pytestmark = pytest.mark.gpu
+
+
+def make(spec, precision):
+    from flow_amd.sim import FlowSim
+    return FlowSim(spec, precision=precision)
+
+
+def quiet(spec):
+    """The same spec with the acceleration noise switched off (bit-exact comparisons)."""
+    spec = dict(spec)
+    spec["vehicles"] = [dict(v, noise=0.0) for v in spec["vehicles"]]
+    return spec
+
+
+def compare_state(sim, ora, exact=True, atol=0.0):
+    from flow_amd import _lib as L
+    alive = ora.alive
+    route = sim.get_state(L.FS_FIELD_ROUTE)
+    np.testing.assert_array_equal(route, ora.route)
+    cmp = (lambda a, b: np.testing.assert_array_equal(a[alive], b[alive])) if exact else \
+        (lambda a, b: np.testing.assert_allclose(a[alive], b[alive], rtol=0, atol=atol))
+    cmp(sim.pos, ora.x)
+    cmp(sim.vel, ora.v)
+    cmp(sim.get_state(L.FS_FIELD_PREV_VEL), ora.prev_v)
+    cmp(sim.headway, ora.h)
+    for field, ref in ((L.FS_FIELD_SEQ, ora.seq), (L.FS_FIELD_ORIGIN, ora.origin), (L.FS_FIELD_LEADER, ora.lead),
+                       (L.FS_FIELD_FOLLOWER, ora.foll)):
+        got = sim.get_state(field)
+        np.testing.assert_array_equal(got[alive], ref[alive])
+    np.testing.assert_array_equal(sim.get_state(L.FS_FIELD_CTL_SEQ), ora.ctl_seq)
+    np.testing.assert_array_equal(sim.get_state(L.FS_FIELD_ARRIVED_RL), ora.arrived_rl.astype(np.int32))
+    cnt = sim.get_state(L.FS_FIELD_COUNTERS)
+    np.testing.assert_array_equal(cnt[:, 0], ora.sim_steps)
+    np.testing.assert_array_equal(cnt[:, 1], ora.seq_ctr)
+    np.testing.assert_array_equal(cnt[:, 2], ora.ctl_ctr)
+    np.testing.assert_array_equal(cnt[:, 3], ora.num_arrived)
+    np.testing.assert_array_equal(cnt[:, 4], ora.num_departed)
+    np.testing.assert_array_equal(cnt[:, 5], ora.total_arrived)
+    np.testing.assert_array_equal(cnt[:, 6], ora.total_departed)
+
+
+def run_pair(spec, precision, steps, action_fn=None, check_every=10, exact=True, atol=0.0):
+    dtype = np.float32 if precision == "f32" else np.float64
+    ora = O.MergeOracle(spec, dtype)
+    sim = make(spec, precision)
+    cmp = np.testing.assert_array_equal if exact else (lambda a, b: np.testing.assert_allclose(a, b, rtol=0, atol=atol))
+    cmp(sim.reset(), ora.reset().astype(np.float32))
+    compare_state(sim, ora, exact, atol)
+    for k in range(steps):
+        a = None if action_fn is None else action_fn(k)
+        o_ref, r_ref, d_ref = ora.step(a)
+        o_gpu, r_gpu, d_gpu = sim.step(a)
+        cmp(o_gpu, o_ref.astype(np.float32))
+        cmp(r_gpu, r_ref.astype(np.float32))
+        np.testing.assert_array_equal(d_gpu, d_ref)
+        if k % check_every == 0 or k == steps - 1:
+            compare_state(sim, ora, exact, atol)
+    np.testing.assert_array_equal(sim.time_counter, ora.time_counter)
+    sim.close()
+    return ora
+
+
+def uniform_actions(spec, seed, lo=-1.0, hi=1.5):
+    rng = np.random.default_rng(seed)
+    R, A = spec["num_replicas"], spec["num_rl"]
+    return lambda k: rng.uniform(lo, hi, (R, A)).astype(np.float32)
+
+
+def test_merge_po_f32_bit_exact_with_inflows_arrivals_and_rl_queue():
+    spec = quiet(merge_spec(R=5, cap_human=26, cap_rl=5, num_rl=2, horizon=500, seed=3))
+    ora = run_pair(spec, "f32", 500, uniform_actions(spec, 7, 0.0, 1.5))
+    # the run exercised the whole life cycle
+    assert ora.total_departed.min() > 20 and ora.total_arrived.min() > 5
+    assert (ora.ctl_ctr > 2).all()                      # RL vehicles joined and left rl_veh
+
+
+def test_merge_po_f32_small_capacity_several_replicas_per_wave():
+    """cap 8 -> SEG 8, eight replicas per wave; the slot pools overflow (vehicles wait outside)."""
+    spec = quiet(merge_spec(R=19, cap_human=6, cap_rl=2, num_rl=1, horizon=300, seed=5, pre=120.0, q_highway=1500.0))
+    run_pair(spec, "f32", 300, uniform_actions(spec, 11))
+
+
+def test_merge_po_f32_sims_per_step_and_warmup():
+    spec = quiet(merge_spec(R=4, cap_human=12, cap_rl=4, num_rl=3, horizon=60, seed=9, sims_per_step=5,
+                            warmup_steps=7))
+    run_pair(spec, "f32", 60, uniform_actions(spec, 2, 0.2, 1.5), check_every=5)
+
+
+def test_merge_po_no_actions_means_sumo_drives_the_rl_vehicles():
+    spec = quiet(merge_spec(R=3, cap_human=12, cap_rl=4, num_rl=2, horizon=200, seed=1))
+    run_pair(spec, "f32", 200, None)
+
+
+def test_merge_po_f64_matches_reference_arithmetic():
+    spec = quiet(merge_spec(R=3, cap_human=20, cap_rl=4, num_rl=2, horizon=400, seed=4))
+    run_pair(spec, "f64", 400, uniform_actions(spec, 5, 0.0, 1.5), check_every=25, exact=False, atol=1e-9)
+
+
+def test_merge_po_noise_short_horizon_tolerance():
+    """With the Gaussian acceleration noise (libm log / cos on both sides) the float32 paths agree to 1e-4
+    over a horizon short enough that no discrete event (insertion, yield) flips."""
+    spec = merge_spec(R=4, cap_human=12, cap_rl=4, num_rl=2, horizon=40, seed=8)
+    run_pair(spec, "f32", 40, uniform_actions(spec, 3, 0.0, 1.0), exact=False, atol=1e-4)
+
+
+def test_merge_multiagent_as_shipped_and_with_actions_applied():
+    for apply in (False, True):
+        spec = quiet(merge_spec(R=4, cap_human=14, cap_rl=4, num_rl=4, horizon=300, seed=6, env=O.ENV_MERGE_MA,
+                                ma_apply_actions=apply))
+        rng = np.random.default_rng(13)
+
+        def acts(k, rng=rng):
+            a = rng.uniform(0.0, 1.5, (4, 4)).astype(np.float32)
+            a[rng.random((4, 4)) < 0.2] = np.nan          # "the vehicle just entered": no action
+            return a
+        run_pair(spec, "f32", 300, acts)
+
+
+def test_merge_other_controllers_and_failsafes():
+    spec = quiet(merge_spec(R=3, cap_human=12, cap_rl=3, num_rl=2, horizon=250, seed=12))
+    veh = spec["vehicles"]
+    for i in range(12):
+        kind = i % 4
+        if kind == 1:
+            veh[i] = idm_vehicle(controller=S.CTRL_FOLLOWER_STOPPER, p=[12.0] + [0] * 7, speed_mode=1, type=0)
+        elif kind == 2:
+            veh[i] = idm_vehicle(controller=S.CTRL_GIPPS, p=[30, 1.5, -1, -1, 2, 1, 0, 0], speed_mode=1, type=0,
+                                 fail_safe=S.FAILSAFE_SAFE_VELOCITY)
+        elif kind == 3:
+            veh[i] = idm_vehicle(controller=S.CTRL_SIM, type=0)
+    run_pair(spec, "f32", 250, uniform_actions(spec, 21, 0.0, 1.5))
+
+
+def test_merge_masked_reset_restarts_only_the_selected_replicas():
+    spec = quiet(merge_spec(R=6, cap_human=12, cap_rl=3, num_rl=2, horizon=100, seed=2))
+    ora = O.MergeOracle(spec, np.float32)
+    sim = make(spec, "f32")
+    np.testing.assert_array_equal(sim.reset(), ora.reset().astype(np.float32))
+    acts = uniform_actions(spec, 4, 0.0, 1.5)
+    for k in range(80):
+        a = acts(k)
+        ora.step(a), sim.step(a)
+    mask = np.array([1, 0, 0, 1, 0, 1], dtype=bool)
+    np.testing.assert_array_equal(sim.reset(mask), ora.reset(mask).astype(np.float32))
+    compare_state(sim, ora)
+    for k in range(60):
+        a = acts(k)
+        o_ref, r_ref, d_ref = ora.step(a)
+        o_gpu, r_gpu, d_gpu = sim.step(a)
+        np.testing.assert_array_equal(o_gpu, o_ref.astype(np.float32))
+        np.testing.assert_array_equal(r_gpu, r_ref.astype(np.float32))
+        np.testing.assert_array_equal(d_gpu, d_ref)
+    compare_state(sim, ora)
+    sim.close()
+
+
+def test_merge_rollout_equals_stepping():
+    """K steps in one launch == K single-step launches (same kernel, state kept in registers)."""
+    import torch
+    spec = quiet(merge_spec(R=8, cap_human=20, cap_rl=4, num_rl=2, horizon=200, seed=14))
+    K, R = 120, 8
+    rng = np.random.default_rng(3)
+    acts = rng.uniform(0.0, 1.5, (K, R, 2)).astype(np.float32)
+    a = make(spec, "f32")
+    b = make(spec, "f32")
+    a.reset(), b.reset()
+    dev = torch.device("cuda:0")
+    obs = torch.empty((K, R, a.obs_dim), dtype=torch.float32, device=dev)
+    rew = torch.empty((K, R), dtype=torch.float32, device=dev)
+    done = torch.empty((K, R), dtype=torch.uint8, device=dev)
+    a.rollout_dev(K, obs, rew, done, actions=torch.from_numpy(acts).to(dev))
+    a.sync()
+    for k in range(K):
+        o, r, d = b.step(acts[k])
+        np.testing.assert_array_equal(obs[k].cpu().numpy(), o)
+        np.testing.assert_array_equal(rew[k].cpu().numpy(), r)
+        np.testing.assert_array_equal(done[k].cpu().numpy().astype(bool), d)
+    np.testing.assert_array_equal(a.pos, b.pos)
+    a.close(), b.close()
