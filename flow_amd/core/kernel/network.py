@@ -55,6 +55,53 @@ class NetworkKernel(object):
                 self.loop_starts.append((eid, s0))
                 s0 += self._edges[eid]['length']
 
+    # ---- open networks (MergeNetwork): two routes sharing one coordinate, merge point at merge_x
+    def open_tables(self):
+        """Route tables of an open network for the simulator (None for closed networks): both routes are
+        laid on one coordinate so that their common last edges coincide; ``segments`` rows are
+        (start, internal, flow_start, flow_slope) with Flow's table coordinate of a point = flow_start +
+        flow_slope * (x - start) (get_x; internal edges without a table entry have slope 0)."""
+        paths = self.network.specify_open_routes()
+        if paths is None:
+            return None
+        a, b = paths
+        n_common = 0
+        while n_common < min(len(a), len(b)) and a[-1 - n_common] == b[-1 - n_common]:
+            n_common += 1
+        up = [sum(self._edges[e]['length'] for e in p[:len(p) - n_common]) for p in paths]
+        merge_x = max(up)
+        routes, self._open_starts = [], []
+        for p, u in zip(paths, up):
+            x, segs, starts = merge_x - u, [], []
+            for e in p:
+                if e[0] == ':' and e not in self.internal_edgestarts_dict:
+                    segs.append((x, True, float(self.get_x(e, 0.0)), 0.0))            # traci.py:283-287
+                else:
+                    segs.append((x, e[0] == ':', float(self.get_x(e, 0.0)), 1.0))
+                starts.append((e, x))
+                x += self._edges[e]['length']
+            routes.append(dict(start=merge_x - u, segments=segs))
+            self._open_starts.append(starts)
+        last_internal = paths[0][len(paths[0]) - n_common - 1]
+        box_in = merge_x - self._edges[last_internal]['length'] if last_internal[0] == ':' else merge_x
+        end_x = merge_x + sum(self._edges[e]['length'] for e in a[len(a) - n_common:])
+        return dict(routes=routes, merge_x=merge_x, box_in=box_in, end_x=end_x, net_length=self.length())
+
+    def open_locate(self, route, x):
+        """(edge, position on it) of coordinate ``x`` on ``route`` of an open network."""
+        for (edge, start) in reversed(self._open_starts[route]):
+            if x >= start:
+                return edge, x - start
+        return self._open_starts[route][0][0], 0.0
+
+    def open_coordinate(self, edge, position):
+        """(route, x) of a point on ``edge`` (an edge both routes share belongs to route 0)."""
+        for r, starts in enumerate(self._open_starts):
+            for e, start in starts:
+                if e == edge:
+                    return r, start + position
+        raise KeyError(edge)
+
     def locate(self, s):
         """(edge, position on it) of loop coordinate ``s``."""
         if self.loop_starts is None:

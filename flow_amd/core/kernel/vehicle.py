@@ -30,6 +30,11 @@ class VehicleKernel(object):
         self._pending = None          # RL accelerations buffered by apply_acceleration
         self._pending_lc = None       # RL lane-change directions buffered by apply_lane_change
         self._observed = set()
+        # open networks: the vehicles in the network change every step (vehicle/traci.py:145-216)
+        self._open = False
+        self._slot_id = {}
+        self._num_departed, self._num_arrived = [], []
+        self._departed_ids, self._arrived_ids, self._arrived_rl_ids = [], [], []
 
     # ---- construction (vehicle/traci.py:91-117, 261-372)
     def initialize(self, vehicles):
@@ -69,12 +74,87 @@ class VehicleKernel(object):
     def attach(self, sim, replica=0):
         self.sim, self.replica = sim, replica
         self._cache = {}
+        self._open = bool(getattr(sim, "open_net", False))
+        if self._open:
+            self._init_id_of_slot = {i: v for v, i in sim.spec["init_slot"].items()}
+            self._refresh_open(reset=True)
 
     def update(self, reset):
         """Called after every simulation step: drop the host copies (vehicle/traci.py:119)."""
         self._cache = {}
         self._pending = None
         self._pending_lc = None
+        if self._open:
+            self._refresh_open(reset)
+
+    def _sid(self, i):
+        """id of the vehicle in slot i."""
+        return self._slot_id[i] if self._open else self.__ids[i]
+
+    def _new_vehicle(self, veh_id, type_name):
+        tp = self.type_parameters[type_name]
+        acc_cls, acc_kw = tp["acceleration_controller"]
+        lc_cls, lc_kw = tp["lane_change_controller"]
+        rt = tp["routing_controller"]
+        return {"type": type_name, "initial_speed": tp.get("initial_speed", 0),
+                "acc_controller": acc_cls(veh_id, car_following_params=tp["car_following_params"], **(acc_kw or {})),
+                "lane_changer": lc_cls(veh_id=veh_id, **(lc_kw or {})),
+                "router": rt[0](veh_id=veh_id, router_params=rt[1]) if rt is not None else None,
+                "length": tp.get("length", 5.0)}
+
+    def _refresh_open(self, reset):
+        """Rebuild the id lists from the slot state on the device (TraCIVehicle.update, vehicle/traci.py:145-216):
+        ids in departure order, arrived vehicles dropped, departed ones appended; SUMO names the k-th vehicle
+        of InFlows entry "flow_f" as "flow_f.k"."""
+        spec = self.sim.spec
+        route = self._field(L.FS_FIELD_ROUTE)
+        seq = self._field(L.FS_FIELD_SEQ)
+        origin = self._field(L.FS_FIELD_ORIGIN)
+        names, base, caps = spec["slot_types"], spec["slot_base"], spec["slot_caps"]
+        slots = sorted((int(seq[i]), i) for i in range(len(route)) if route[i] >= 0)
+        old_ids, old_rl = list(self.__ids), list(self.__rl_ids)
+        ids, slot_of, id_of = [], {}, {}
+        for _, i in slots:
+            o = int(origin[i])
+            veh_id = self._init_id_of_slot[i] if o < 0 else "%s.%d" % (spec["inflows"][o >> 20]["name"], o & 0xFFFFF)
+            ids.append(veh_id)
+            slot_of[veh_id], id_of[i] = i, veh_id
+        vehicles = {}
+        for veh_id in ids:
+            if veh_id in self.__vehicles:
+                vehicles[veh_id] = self.__vehicles[veh_id]
+            else:
+                i = slot_of[veh_id]
+                tname = next(n for n in names if base[n] <= i < base[n] + caps[n])
+                vehicles[veh_id] = self._new_vehicle(veh_id, tname)
+        self.__vehicles = vehicles
+        self.__ids, self._slot, self._slot_id = ids, slot_of, id_of
+        self.__rl_ids, self.__human_ids, self.__controlled_ids, self.__controlled_lc_ids = [], [], [], []
+        for veh_id in ids:
+            tp = self.type_parameters[vehicles[veh_id]["type"]]
+            if tp["acceleration_controller"][0] == RLController:
+                self.__rl_ids.append(veh_id)
+            else:
+                self.__human_ids.append(veh_id)
+                if tp["acceleration_controller"][0] != SimCarFollowingController:
+                    self.__controlled_ids.append(veh_id)
+                if tp["lane_change_controller"][0] != SimLaneChangeController:
+                    self.__controlled_lc_ids.append(veh_id)
+        self.__rl_ids.sort()                                         # vehicle/traci.py:259
+        self.num_vehicles, self.num_rl_vehicles = len(ids), len(self.__rl_ids)
+        if reset:                                                    # vehicle/traci.py:184-195
+            for h in (self._num_departed, self._num_arrived, self._departed_ids, self._arrived_ids,
+                      self._arrived_rl_ids):
+                del h[:]
+            return
+        now = set(ids)
+        departed = [v for v in ids if v not in set(old_ids)]
+        arrived = [v for v in old_ids if v not in now]
+        self._num_departed.append(len(departed))
+        self._num_arrived.append(len(arrived))
+        self._departed_ids.append(departed)
+        self._arrived_ids.append(arrived)
+        self._arrived_rl_ids.append([v for v in arrived if v in old_rl])
 
     def reset(self):
         self._cache = {}
@@ -95,20 +175,32 @@ class VehicleKernel(object):
     def get_rl_ids(self):
         return self.__rl_ids
 
+    # vehicle/traci.py:493-533; one history entry per Env.step here (the reference appends one per sub-step)
     def get_arrived_ids(self):
-        return []
+        return self._arrived_ids[-1] if self._arrived_ids else 0
+
+    def get_arrived_rl_ids(self):
+        return self._arrived_rl_ids[-1] if self._arrived_rl_ids else 0
 
     def get_departed_ids(self):
-        return []
+        return self._departed_ids[-1] if self._departed_ids else 0
 
     def get_num_arrived(self):
-        return 0
+        return self._num_arrived[-1] if self._num_arrived else 0
+
+    def _rate(self, hist, time_span):
+        if len(hist) == 0:
+            return 0
+        n_sub = int(self.sim.spec.get("sims_per_step", 1)) if self.sim is not None else 1
+        steps = max(int(time_span / (self.sim_step * n_sub)), 1)
+        window = hist[-steps:]
+        return 3600 * sum(window) / (len(window) * n_sub * self.sim_step)
 
     def get_inflow_rate(self, time_span):
-        return 0
+        return self._rate(self._num_departed, time_span)
 
     def get_outflow_rate(self, time_span):
-        return 0
+        return self._rate(self._num_arrived, time_span)
 
     def set_observed(self, veh_id):
         self._observed.add(veh_id)
@@ -148,12 +240,24 @@ class VehicleKernel(object):
         """Flow's absolute position: edge start of the network's table + position on the edge
         (vehicle/traci.py:1011-1017)."""
         net = self.master_kernel.network
-        if net.loop_starts is None:
+        if net.loop_starts is None and not self._open:
             return self._vec(veh_id, lambda i: float(self._field(L.FS_FIELD_POS)[i]), 0.)
         return self._vec(veh_id, lambda i: float(net.get_x(*self._edge_pos(i))), 0.)
 
     def _edge_pos(self, i):
+        if self._open:
+            return self.master_kernel.network.open_locate(int(self._field(L.FS_FIELD_ROUTE)[i]),
+                                                          float(self._field(L.FS_FIELD_POS)[i]))
         return self.master_kernel.network.locate(float(self._field(L.FS_FIELD_POS)[i]))
+
+    def get_route(self, veh_id, error=None):
+        """Edges of the vehicle's route (vehicle/traci.py:571-578)."""
+        err = list() if error is None else error
+        if not self._open:
+            return self._vec(veh_id, lambda i: self.master_kernel.network.rts.get(self._edge_pos(i)[0], err), err)
+        paths = self.master_kernel.network.network.specify_open_routes()
+        return self._vec(veh_id, lambda i: [e for e in paths[int(self._field(L.FS_FIELD_ROUTE)[i])] if e[0] != ':'],
+                         err)
 
     def get_edge(self, veh_id, error=""):
         return self._vec(veh_id, lambda i: self._edge_pos(i)[0], error)
@@ -174,15 +278,20 @@ class VehicleKernel(object):
 
     def get_leader(self, veh_id, error=""):
         n = self.num_vehicles
-        if self._multilane():
+        if self._multilane() or self._open:
             def lead(i):
                 j = int(self._field(L.FS_FIELD_LEADER)[i])
-                return self.__ids[j] if j >= 0 else None
+                return self._sid(j) if j >= 0 else None
             return self._vec(veh_id, lead, error)
         return self._vec(veh_id, lambda i: self.__ids[(i + 1) % n] if n > 1 else None, error)
 
     def get_follower(self, veh_id, error=""):
         n = self.num_vehicles
+        if self._open:                                   # the sticky entry of vehicle/traci.py:243-250
+            def foll(i):
+                j = int(self._field(L.FS_FIELD_FOLLOWER)[i])
+                return self._sid(j) if j >= 0 else None
+            return self._vec(veh_id, foll, error)
         if self._multilane():
             def foll(i):
                 lead = self._field(L.FS_FIELD_LEADER)
@@ -195,22 +304,22 @@ class VehicleKernel(object):
         return self._vec(veh_id, lambda i: self.__ids[(i - 1) % n] if n > 1 else None, error)
 
     def get_length(self, veh_id, error=-1001):
-        return self._vec(veh_id, lambda i: self.__vehicles[self.__ids[i]]["length"], error)
+        return self._vec(veh_id, lambda i: self.__vehicles[self._sid(i)]["length"], error)
 
     def get_type(self, veh_id):
         return self.__vehicles[veh_id]["type"]
 
     def get_initial_speed(self, veh_id, error=-1001):
-        return self._vec(veh_id, lambda i: self.__vehicles[self.__ids[i]]["initial_speed"], error)
+        return self._vec(veh_id, lambda i: self.__vehicles[self._sid(i)]["initial_speed"], error)
 
     def get_acc_controller(self, veh_id, error=None):
-        return self._vec(veh_id, lambda i: self.__vehicles[self.__ids[i]]["acc_controller"], error)
+        return self._vec(veh_id, lambda i: self.__vehicles[self._sid(i)]["acc_controller"], error)
 
     def get_lane_changing_controller(self, veh_id, error=None):
-        return self._vec(veh_id, lambda i: self.__vehicles[self.__ids[i]]["lane_changer"], error)
+        return self._vec(veh_id, lambda i: self.__vehicles[self._sid(i)]["lane_changer"], error)
 
     def get_routing_controller(self, veh_id, error=None):
-        return self._vec(veh_id, lambda i: self.__vehicles[self.__ids[i]]["router"], error)
+        return self._vec(veh_id, lambda i: self.__vehicles[self._sid(i)]["router"], error)
 
     def get_ids_by_edge(self, edges):
         if isinstance(edges, (list, np.ndarray)):

@@ -169,7 +169,11 @@ class SumoParams(SimParams):
                     None -> 0 on a ring (0.1 m junctions, treated as seamless), 1 on a figure eight
     center_length   length of the ':center_*' internal edges of a figure eight (None -> 9.4, the
                     netconvert value in the reference's fixture)
-    crossing_time_gap  right-of-way model of the figure-eight crossing
+    crossing_time_gap  right-of-way model of the figure-eight crossing / the merge junction:
+                    None -> 3.0 s on a figure eight, 1.0 s on a merge
+    max_vehicles    open networks: vehicle slots per replica (<= 64), shared out over the vehicle types
+    slot_capacity   open networks: {vehicle type: slots}, overrides the default share-out
+    merge_right_of_way  open networks: False switches the junction priority model off
     junction_length length of each internal edge (netconvert output in the reference)
     crash_gap       a replica crashes when a bumper gap falls below this after a move
     precision       'f32' | 'f64' arithmetic and state type of the kernels
@@ -180,7 +184,8 @@ class SumoParams(SimParams):
                  force_color_update=False, overtake_right=False, seed=None, restart_instance=False,
                  print_warnings=True, start_at_load=True, teleport_time=-1, num_clients=1, color_by_speed=False,
                  use_ballistic=False, slowdown_ramp=None, junction_mode=None, junction_length=0.1, crash_gap=0.0,
-                 precision="f32", center_length=None, crossing_time_gap=3.0):
+                 precision="f32", center_length=None, crossing_time_gap=None, max_vehicles=64, slot_capacity=None,
+                 merge_right_of_way=True):
         super(SumoParams, self).__init__(sim_step, render, restart_instance, emission_path, save_render,
                                          sight_radius, show_radius, pxpm, force_color_update)
         self.port = port
@@ -201,6 +206,9 @@ class SumoParams(SimParams):
         self.precision = precision
         self.center_length = center_length
         self.crossing_time_gap = crossing_time_gap
+        self.max_vehicles = max_vehicles
+        self.slot_capacity = slot_capacity
+        self.merge_right_of_way = merge_right_of_way
 
 
 class EnvParams:
@@ -220,30 +228,42 @@ class EnvParams:
 
 
 class InFlows:
-    """flow/core/params.py:1070-1220.  Open-network inflows are not on the built hot path
-    yet; ``add`` validates and stores so configs load, simulators reject non-empty inflows."""
+    """flow/core/params.py:1070-1220: ``add`` validates and stores; the open-network simulator reads
+    ``vehsPerHour`` / ``period``, ``departSpeed``, ``begin``, ``end``, ``number``."""
 
     def __init__(self):
         self.__flows = []
 
     def add(self, edge, veh_type, vehs_per_hour=None, probability=None, period=None, depart_lane="first",
             depart_speed=0, name="flow", begin=1, end=86400, number=None, **kwargs):
-        given = [x is not None for x in (vehs_per_hour, probability, period)]
-        if sum(given) != 1:                                         # params.py:1188-1200
-            raise ValueError("exactly one of vehs_per_hour, probability, period must be given")
-        if probability is not None and not (0 <= probability <= 1):
-            raise ValueError("Inflow.probability should be between 0 and 1")
+        if "vehsPerHour" in kwargs:                                  # deprecated spellings, params.py:1167-1178
+            vehs_per_hour = kwargs.pop("vehsPerHour")
+        if "departLane" in kwargs:
+            depart_lane = kwargs.pop("departLane")
+        if "departSpeed" in kwargs:
+            depart_speed = kwargs.pop("departSpeed")
         new = {"name": "%s_%d" % (name, len(self.__flows)), "vtype": veh_type, "edge": edge,
                "departLane": depart_lane, "departSpeed": depart_speed, "begin": begin, "end": end}
         new.update(kwargs)
+        given = [x is not None for x in (vehs_per_hour, probability, period)]
+        if sum(given) != 1:                                         # params.py:1188-1194
+            raise ValueError("Exactly one among the three parameters 'vehs_per_hour', 'probability' and "
+                             "'period' must be specified in InFlows.add. {} were specified.".format(sum(given)))
+        if probability is not None and not (0 <= probability <= 1):
+            raise ValueError("Inflow.add called with parameter 'probability' set to {}, but probability should "
+                             "be between 0 and 1.".format(probability))
+        if begin is not None and begin < 1:                          # params.py:1198-1200
+            raise ValueError("Inflow.add called with parameter 'begin' set to {}, but begin should be greater "
+                             "or equal than 1 second.".format(begin))
+        if number is not None:
+            del new["end"]
+            new["number"] = number
         if vehs_per_hour is not None:
             new["vehsPerHour"] = vehs_per_hour
         if probability is not None:
             new["probability"] = probability
         if period is not None:
             new["period"] = period
-        if number is not None:
-            new["number"] = number
         self.__flows.append(new)
 
     def sort(self, key):

@@ -97,7 +97,11 @@ class Env(_Base):
         self.k.vehicle.attach(self.sim, 0)
         x0 = spec["init_pos"][0]
         for i, veh_id in enumerate(self.initial_ids):
-            edge, pos = self.k.network.get_edge(float(x0[i]))
+            if spec.get("network") == "merge":
+                slot = spec["init_slot"][veh_id]
+                edge, pos = self.k.network.open_locate(int(spec["init_route"][0][slot]), float(x0[slot]))
+            else:
+                edge, pos = self.k.network.get_edge(float(x0[i]))
             self.initial_state[veh_id] = (self.k.vehicle.get_type(veh_id), edge, 0, pos,
                                           self.k.vehicle.get_initial_speed(veh_id))
 

@@ -1,0 +1,117 @@
+"""MergePOEnv (flow/envs/merge.py): partially observable open-merge environment.
+
+The rl_queue / rl_veh slotting, the 5 features per controlled vehicle and the reward are computed inside
+the HIP step kernel (head FS_ENV_MERGE_PO, flow_amd/csrc/flowsim_open.h); ``rl_veh`` / ``rl_queue`` /
+``leader`` / ``follower`` are host mirrors of that state, kept for code that reads them."""
+import collections
+
+import numpy as np
+
+from flow_amd import _lib as L
+from flow_amd.envs.base import Env
+from flow_amd.utils.spaces import Box
+
+ADDITIONAL_ENV_PARAMS = {
+    # maximum acceleration for autonomous vehicles, in m/s^2
+    "max_accel": 3,
+    # maximum deceleration for autonomous vehicles, in m/s^2
+    "max_decel": 3,
+    # desired velocity for all vehicles in the network, in m/s
+    "target_velocity": 25,
+    # maximum number of controllable vehicles in the network
+    "num_rl": 5,
+}
+
+
+class MergePOEnv(Env):
+    """flow/envs/merge.py:28-231.
+
+    States: for each of the ``num_rl`` controlled vehicles [v/v_max, (v_lead - v)/v_max, gap_lead/L,
+    (v - v_follow)/v_max, gap_follow/L]; zeros for unused places.  Actions: one bounded acceleration per
+    place in ``rl_veh``.  Reward: desired-velocity term minus a small-time-headway penalty.  A rollout ends
+    at the horizon or on a collision.
+
+    Not reproduced (documented in DESIGN.md): rl_veh surviving ``reset`` (the reference never clears it), and
+    the skipped element when two consecutive entries of rl_veh leave in the same sub-step (merge.py:206-208
+    removes from the list it iterates)."""
+
+    FS_ENV = L.FS_ENV_MERGE_PO
+
+    def __init__(self, env_params, sim_params, network=None, simulator='traci', scenario=None):
+        for p in ADDITIONAL_ENV_PARAMS.keys():
+            if p not in env_params.additional_params:
+                raise KeyError('Environment parameter "{}" not supplied'.format(p))
+        self.num_rl = env_params.additional_params["num_rl"]
+        self.rl_queue = collections.deque()
+        self.rl_veh = []
+        self.leader = []
+        self.follower = []
+        self._po_actions = None
+        self._ghost_ids = {}
+        super().__init__(env_params, sim_params, network, simulator, scenario)
+
+    @property
+    def action_space(self):
+        return Box(low=-abs(self.env_params.additional_params["max_decel"]),
+                   high=self.env_params.additional_params["max_accel"], shape=(self.num_rl,), dtype=np.float32)
+
+    @property
+    def observation_space(self):
+        return Box(low=0, high=1, shape=(5 * self.num_rl,), dtype=np.float32)
+
+    # ---- actions: the vector goes to the device as it is; column i commands rl_veh[i] (merge.py:109-115)
+    def _apply_rl_actions(self, rl_actions):
+        self._po_actions = np.asarray(rl_actions, dtype=np.float32).reshape(1, self.num_rl)
+
+    def _action_vector(self):
+        a, self._po_actions = self._po_actions, None
+        return a
+
+    # ---- host mirrors of the device lists
+    def _sync_lists(self):
+        veh = self.k.vehicle
+        ctl = veh._field(L.FS_FIELD_CTL_SEQ)
+        route = veh._field(L.FS_FIELD_ROUTE)
+        seq = veh._field(L.FS_FIELD_SEQ)
+        in_list = sorted((int(ctl[i]), i) for i in range(len(ctl)) if ctl[i] >= 0)
+        ids = []
+        for _, i in in_list:
+            vid = veh._slot_id.get(i) if route[i] >= 0 else self._ghost_ids.get(i)
+            if vid is not None:
+                ids.append(vid)
+                self._ghost_ids[i] = vid                   # still listed for one get_state after it arrived
+        self.rl_veh = ids
+        rl_ids = set(veh.get_rl_ids())
+        queued = sorted((int(seq[i]), veh._slot_id[i]) for i in range(len(ctl))
+                        if route[i] >= 0 and ctl[i] < 0 and veh._slot_id.get(i) in rl_ids)
+        self.rl_queue = collections.deque(v for _, v in queued)
+
+    def get_state(self, rl_id=None, **kwargs):
+        """merge.py:117-158; the numbers come from the kernel, the observed-vehicle lists are rebuilt here."""
+        self._sync_lists()
+        self.leader, self.follower = [], []
+        for rl in self.rl_veh:
+            lead, foll = self.k.vehicle.get_leader(rl), self.k.vehicle.get_follower(rl)
+            if lead not in ["", None]:
+                self.leader.append(lead)
+            if foll not in ["", None]:
+                self.follower.append(foll)
+        return np.asarray(self._last_obs, dtype=np.float32).copy()
+
+    def compute_reward(self, rl_actions, **kwargs):
+        """merge.py:160-187 (evaluated in the kernel, including the ``evaluate`` and ``fail`` cases)."""
+        if kwargs.get("fail") and not self.env_params.evaluate:
+            return 0
+        return self._last_reward
+
+    def additional_command(self):
+        """merge.py:189-221: the queue bookkeeping runs in the kernel every sub-step; here the observed
+        vehicles are marked."""
+        for veh_id in self.leader + self.follower:
+            self.k.vehicle.set_observed(veh_id)
+
+    def reset(self):
+        self.leader = []
+        self.follower = []
+        self._ghost_ids = {}
+        return super().reset()

@@ -1,0 +1,5 @@
+"""Multi-agent environments on the GPU hot path (names as in flow/envs/multiagent/__init__.py)."""
+from flow_amd.envs.multiagent.base import MultiEnv
+from flow_amd.envs.multiagent.merge import MultiAgentMergePOEnv
+
+__all__ = ["MultiEnv", "MultiAgentMergePOEnv"]

@@ -75,10 +75,161 @@ def check_placement(X, lengths, loop_length, lanes=None):
         raise FatalFlowError("initial position outside the network")
 
 
+def type_slot(veh_k, type_name, type_index, rl_index):
+    """fs_vehicle_spec dict of a slot that holds vehicles of ``type_name`` (open networks: slots are
+    partitioned by vehicle type, every vehicle of a type has the controller of VehicleParams.add)."""
+    tp = veh_k.type_parameters[type_name]
+    acc_cls, acc_kw = tp["acceleration_controller"]
+    ctrl = acc_cls("slot", car_following_params=tp["car_following_params"], **(acc_kw or {}))
+    if ctrl.FS_ID is None:
+        raise NotImplementedError("controller %s is not built" % type(ctrl).__name__)
+    cf = ctrl.car_following_params
+    is_rl = isinstance(ctrl, RLController)
+    return dict(controller=ctrl.FS_ID, p=[float(x) for x in ctrl.fs_params()],
+                fail_safe={None: 0, 'instantaneous': 1, 'safe_velocity': 2}[ctrl.fail_safe],
+                noise=float(ctrl.accel_noise), delay=float(ctrl.delay), max_accel=float(ctrl.max_accel),
+                max_decel=float(ctrl.max_deaccel), length=float(tp.get("length", 5.0)),
+                speed_mode=int(cf.speed_mode), sumo_tau=float(cf.controller_params["tau"]),
+                sumo_min_gap=float(cf.controller_params["minGap"]),
+                sumo_max_speed=float(cf.controller_params["maxSpeed"]),
+                initial_speed=float(tp.get("initial_speed", 0.0)), type=type_index,
+                rl_index=rl_index if is_rl else -1), is_rl
+
+
+def slot_capacities(vehicles, inflows, total, given=None):
+    """Slots per vehicle type (M1).  ``given`` ({type: slots}) wins; otherwise every type gets its initial
+    vehicles plus a share of the remaining slots proportional to its inflow rate (vehicles / hour)."""
+    names = [t["veh_id"] for t in vehicles.initial]
+    init = {t["veh_id"]: int(t["num_vehicles"]) for t in vehicles.initial}
+    if given:
+        caps = [int(given.get(n, init[n])) for n in names]
+    else:
+        rate = {n: 0.0 for n in names}
+        for f in inflows:
+            rate[f["vtype"]] += float(f["vehsPerHour"]) if "vehsPerHour" in f else 3600.0 / float(f["period"])
+        spare = total - sum(init.values())
+        if spare < 0:
+            raise FatalFlowError("more initial vehicles than vehicle slots (max_vehicles)")
+        tot_rate = sum(rate.values())
+        caps = [init[n] + (int(spare * rate[n] / tot_rate) if tot_rate > 0 else 0) for n in names]
+        left = total - sum(caps)                           # rounding leftovers go to the busiest type
+        if tot_rate > 0 and left > 0:
+            caps[max(range(len(names)), key=lambda i: rate[names[i]])] += left
+    for n, c in zip(names, caps):
+        if c < init[n]:
+            raise FatalFlowError("slot_capacity[%r] is below its initial vehicles" % n)
+    return names, caps
+
+
+def build_open_spec(env, num_replicas, rng=None):
+    """The spec of an open-network env (MergeNetwork): slot pools, route tables, inflow table."""
+    network, net_k, veh_k = env.network, env.k.network, env.k.vehicle
+    sp, ep = env.sim_params, env.env_params
+    ap = network.net_params.additional_params
+    if int(ap.get("merge_lanes", 1)) != 1 or int(ap.get("highway_lanes", 1)) != 1:
+        raise NotImplementedError("multi-lane merge networks are not built in the HIP step loop yet")
+    tables = net_k.open_tables()
+    R = int(num_replicas)
+    flows = network.net_params.inflows.get()
+    total = int(getattr(sp, "max_vehicles", None) or 64)
+    names, caps = slot_capacities(network.vehicles, flows, total, getattr(sp, "slot_capacity", None))
+    if env.FS_ENV == L.FS_ENV_MERGE_PO and sum(caps) < int(ep.additional_params["num_rl"]):
+        # the observation has num_rl places even if fewer vehicles can ever exist: pad with empty slots
+        rl_types = [i for i, n in enumerate(names)
+                    if veh_k.type_parameters[n]["acceleration_controller"][0] == RLController]
+        caps[rl_types[0] if rl_types else 0] += int(ep.additional_params["num_rl"]) - sum(caps)
+    N = sum(caps)
+    if N < 1 or N > 64:
+        raise NotImplementedError("open networks hold 1..64 vehicle slots per replica (got %d)" % N)
+    slots, base, n_rl_slots = [], {}, 0
+    for t, (name, cap) in enumerate(zip(names, caps)):
+        base[name] = len(slots)
+        for _ in range(cap):
+            d, is_rl = type_slot(veh_k, name, t, n_rl_slots)
+            n_rl_slots += 1 if is_rl else 0
+            slots.append(d)
+    # initial vehicles: ids in VehicleParams order, the k-th vehicle of a type sits in the k-th slot of its pool
+    ids = veh_k.get_ids()
+    pos, _ = net_k.generate_starting_positions(network.initial_config, len(ids)) if ids else ([], [])
+    alive = np.zeros((R, N), dtype=bool)
+    X = np.zeros((R, N))
+    V = np.zeros((R, N))
+    route = np.zeros((R, N), dtype=np.int32)
+    seen, init_slot = {}, {}
+    for veh_id, (edge, p) in zip(ids, pos):
+        name = veh_k.get_type(veh_id)
+        k = seen.get(name, 0)
+        seen[name] = k + 1
+        i = base[name] + k
+        init_slot[veh_id] = i
+        r, x = net_k.open_coordinate(edge, p)
+        alive[:, i], X[:, i], route[:, i] = True, x, r
+        V[:, i] = float(veh_k.get_initial_speed(veh_id))
+    pert = network.initial_config.perturbation
+    if pert > 0 and ids:                                   # network/base.py:384-389, drawn per replica
+        rng = rng or np.random
+        for veh_id, (edge, p) in zip(ids, pos):
+            i = init_slot[veh_id]
+            r, x0 = net_k.open_coordinate(edge, 0.0)
+            rel = np.clip(p + rng.normal(0, pert, R), 0, net_k.edge_length(edge))
+            X[:, i] = x0 + rel
+    first_edges = [p[0] for p in network.specify_open_routes()]
+    inflows = []
+    for f in flows:
+        if f["edge"] not in first_edges:
+            raise NotImplementedError("inflow on edge %r: only the first edge of a route is built" % f["edge"])
+        if "probability" in f:
+            raise NotImplementedError("probabilistic inflows are not built (vehs_per_hour / period are)")
+        ds = f.get("departSpeed", 0)
+        if isinstance(ds, str):
+            if ds not in ("speedLimit", "max"):
+                raise NotImplementedError("departSpeed=%r is not built" % ds)
+            ds = net_k.speed_limit(f["edge"])
+        period = 3600.0 / float(f["vehsPerHour"]) if "vehsPerHour" in f else float(f["period"])
+        tname = f["vtype"]
+        inflows.append(dict(type=names.index(tname), route=first_edges.index(f["edge"]), period=period,
+                            begin=float(f.get("begin", 1)), end=float(f.get("end", 86400)),
+                            number=int(f["number"]) if "number" in f else -1, depart_speed=float(ds),
+                            depart_pos=float(veh_k.type_parameters[tname].get("length", 5.0)), name=f["name"]))
+    dt = sp.sim_step
+    ramp = getattr(sp, "slowdown_ramp", None)
+    space = env.action_space
+    num_rl = int(ep.additional_params["num_rl"]) if env.FS_ENV == L.FS_ENV_MERGE_PO else n_rl_slots
+    if env.FS_ENV == L.FS_ENV_MERGE_PO and num_rl > N:
+        raise FatalFlowError("num_rl exceeds the vehicle slots of a replica")
+    jm = getattr(sp, "junction_mode", None)
+    tg = getattr(sp, "crossing_time_gap", None)
+    merge_len = float(ap["merge_length"])
+    spec = dict(
+        network="merge", num_replicas=R, num_vehicles=N, num_rl=num_rl, vehicles=slots,
+        init_alive=alive, init_pos=X, init_vel=V, init_route=route, inflows=inflows,
+        junction=dict(enabled=int(getattr(sp, "merge_right_of_way", True)), lookahead=merge_len,
+                      time_gap=1.0 if tg is None else float(tg)),
+        sim_step=dt, slowdown_ramp=dt / (dt + 1e-3) if ramp is None else float(ramp),
+        integrator="ballistic" if getattr(sp, "use_ballistic", False) else "euler",
+        junction_mode=int(1 if jm is None else jm), junction_length=float(net_k.junction_length),
+        crash_gap=float(getattr(sp, "crash_gap", 0.0)), max_speed=float(net_k.max_speed()),
+        env=env.FS_ENV, target_velocity=float(ep.additional_params.get("target_velocity", 0.0)),
+        action_low=float(np.min(space.low)), action_high=float(np.max(space.high)),
+        # MultiEnv.clip_actions returns the dict unclipped in this fork (multiagent/base.py:366-391)
+        clip_actions=bool(ep.clip_actions) and env.FS_ENV != L.FS_ENV_MERGE_MA, evaluate=bool(ep.evaluate),
+        horizon=ep.horizon, warmup_steps=int(ep.warmup_steps), sims_per_step=int(ep.sims_per_step),
+        seed=int(sp.seed or 0), track_aux=True, ma_apply_actions=not bool(getattr(env, "APPLY_ENUMERATE_QUIRK", True)),
+        slot_types=names, slot_base=base, slot_caps=dict(zip(names, caps)), init_slot=init_slot, **tables)
+    return spec
+
+
 def build_spec(env, num_replicas, rng=None):
     """The spec of ``env`` (a flow_amd Env under construction) replicated ``num_replicas`` times."""
     network, net_k, veh_k = env.network, env.k.network, env.k.vehicle
     sp, ep = env.sim_params, env.env_params
+    if network.specify_open_routes() is not None:
+        if env.FS_ENV not in (L.FS_ENV_MERGE_PO, L.FS_ENV_MERGE_MA):
+            raise NotImplementedError("%s on an open network is not built (MergePOEnv / MultiAgentMergePOEnv are)"
+                                      % type(env).__name__)
+        return build_open_spec(env, num_replicas, rng)
+    if env.FS_ENV in (L.FS_ENV_MERGE_PO, L.FS_ENV_MERGE_MA):
+        raise NotImplementedError("the merge environments need an open network (MergeNetwork)")
     if not isinstance(network, (RingNetwork, FigureEightNetwork)):
         raise NotImplementedError("network %s is not built in the HIP step loop yet" % type(network).__name__)
     num_lanes = int(network.net_params.additional_params["lanes"])
@@ -104,7 +255,7 @@ def build_spec(env, num_replicas, rng=None):
         ring_length=np.full(R, float(network.net_params.additional_params["length"]) if not fig8
                             else net_k.length() - 4 * float(net_k.junction_length)), init_pos=X,
         segments=net_k.loop_segments(),
-        junction=net_k.crossing_model(time_gap=float(getattr(sp, "crossing_time_gap", 3.0))),
+        junction=net_k.crossing_model(time_gap=float(getattr(sp, "crossing_time_gap", None) or 3.0)),
         sim_step=dt, slowdown_ramp=dt / (dt + 1e-3) if ramp is None else float(ramp),
         integrator="ballistic" if getattr(sp, "use_ballistic", False) else "euler",
         junction_mode=int(fig8 if getattr(sp, "junction_mode", None) is None else sp.junction_mode),

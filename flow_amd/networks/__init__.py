@@ -2,5 +2,6 @@
 from flow_amd.networks.base import Network
 from flow_amd.networks.ring import RingNetwork
 from flow_amd.networks.figure_eight import FigureEightNetwork
+from flow_amd.networks.merge import MergeNetwork
 
-__all__ = ["Network", "RingNetwork", "FigureEightNetwork"]
+__all__ = ["Network", "RingNetwork", "FigureEightNetwork", "MergeNetwork"]

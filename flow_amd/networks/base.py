@@ -67,6 +67,11 @@ class Network(object):
     def specify_crossing(self):
         return None
 
+    def specify_open_routes(self):
+        """Open networks list their driving paths (internal edges included, major route first, common
+        last edges); None = a closed network."""
+        return None
+
     @staticmethod
     def gen_custom_start_pos(cls, net_params, initial_config, num_vehicles):
         raise NotImplementedError

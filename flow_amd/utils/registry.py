@@ -14,7 +14,8 @@ def make_create_env(params, version=0, render=None):
     exp_tag = params["exp_tag"]
     if isinstance(params["env_name"], str):
         import flow_amd.envs as envs
-        env_class = getattr(envs, params["env_name"])
+        import flow_amd.envs.multiagent as ma_envs
+        env_class = getattr(envs, params["env_name"], None) or getattr(ma_envs, params["env_name"])
     else:
         env_class = params["env_name"]
     base_env_name = env_class.__name__
