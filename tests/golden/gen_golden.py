@@ -275,6 +275,14 @@ def gen_defaults():
     return doc
 
 
+def copy_flow_params():
+    """The stored flow_params files the reference's own tests hold (data, not code):
+    tests/fast_tests/test_files/ring_230.json and merge.json."""
+    import shutil
+    for src, dst in (("ring_230.json", "ring_230_flow_params.json"), ("merge.json", "merge_flow_params.json")):
+        shutil.copyfile(os.path.join(REF, "tests/fast_tests/test_files", src), os.path.join(HERE, dst))
+
+
 def copy_emission():
     src = os.path.join(REF, "tests/fast_tests/test_files/ring_230_emission.csv")
     keep = ["time", "id", "edge_id", "relative_position", "speed", "lane_number"]
@@ -295,6 +303,8 @@ def main():
         print("wrote", name)
     copy_emission()
     print("wrote ring_230_emission.csv")
+    copy_flow_params()
+    print("wrote ring_230_flow_params.json, merge_flow_params.json")
 
 
 if __name__ == "__main__":

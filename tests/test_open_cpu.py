@@ -1,0 +1,312 @@
+"""CPU tests of the open-network row: the merge oracle (oracle/opennet.py) against hand-checkable facts,
+the host mirror (MergeNetwork, InFlows, slot pools, MergePOEnv spec) and the C-ABI validation of open
+configurations.  No GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import idm_vehicle, merge_spec, merge_tables
+from oracle import opennet as O
+from oracle import refsim as S
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def quiet(spec):
+    spec = dict(spec)
+    spec["vehicles"] = [dict(v, noise=0.0) for v in spec["vehicles"]]
+    return spec
+
+
+# ------------------------------------------------------------------ oracle
+def test_vehicle_count_is_conserved_and_nobody_overlaps():
+    spec = quiet(merge_spec(R=4, cap_human=28, cap_rl=4, num_rl=2, horizon=600, seed=2))
+    o = O.MergeOracle(spec, np.float64)
+    o.reset()
+    n0 = o.alive.sum(axis=1)
+    rng = np.random.default_rng(0)
+    for k in range(600):
+        _, _, done = o.step(rng.uniform(0.3, 1.5, (4, 2)))
+        assert not done.any() or k == 599                                  # no collision with right of way on
+        np.testing.assert_array_equal(o.total_departed - o.total_arrived, o.alive.sum(axis=1) - n0)
+        h = np.where(o.alive & (o.lead >= 0), o.h, 1.0)
+        assert (h > 0).all()
+        x = np.where(o.alive, o.x, o.merge_x)
+        start = np.where(o.route == 1, spec["routes"][1]["start"], spec["routes"][0]["start"])
+        assert (x >= start - 1e-9).all() and (x < o.end_x).all()
+    assert o.total_arrived.min() > 10
+    # ids: departure numbers are unique among the vehicles in the network
+    for r in range(4):
+        seqs = o.seq[r][o.alive[r]]
+        assert len(set(seqs.tolist())) == len(seqs)
+
+
+def test_inflow_schedule_on_an_empty_road():
+    """M2: the k-th vehicle of a flow is due at begin + k * period; it appears after the first step whose start
+    time n * dt is >= that (n counts integration steps, the reset's own step included)."""
+    spec = quiet(merge_spec(R=1, cap_human=20, cap_rl=2, num_rl=1, n_init=0, q_highway=360.0, q_rl=1e-3,
+                            q_merge=1e-3, horizon=1000))
+    o = O.MergeOracle(spec, np.float64)
+    o.reset()
+    seen = []
+    for n in range(1, 400):                     # env step n runs integration step n (start time n * 0.2)
+        o.step(None)
+        seen.append(int(o.total_departed[0]))
+    period, dt = 10.0, 0.2
+    for n in range(1, 400):
+        due = int(np.floor((n * dt - 1.0) / period + 1e-9)) + 1 if n >= 5 else 0
+        # the two 1e-3 veh/h flows emit their first vehicle at t = 1 too: the on-ramp one at once (step 5), the
+        # highway one after the first human has cleared the SUMO-IDM desired gap 2.5 + 10 * 1 m (M3) -- step 13
+        assert seen[n - 1] == due + (1 if n >= 5 else 0) + (1 if n >= 13 else 0), (n, seen[n - 1], due)
+
+
+def test_insertion_waits_for_a_safe_gap_and_for_a_free_slot():
+    spec = quiet(merge_spec(R=1, cap_human=3, cap_rl=1, num_rl=1, n_init=0, q_highway=3600.0, q_rl=1e-3,
+                            q_merge=1e-3, horizon=1000))
+    o = O.MergeOracle(spec, np.float64)
+    o.reset()
+    for _ in range(200):
+        o.step(None)
+        gaps = o.h[0][o.alive[0] & (o.lead[0] >= 0)]
+        assert (gaps > 2.0).all()
+    # 3 human slots: never more than 3 humans in the network although one is due every second
+    assert o.alive[0, :3].sum() <= 3 and o.total_departed[0] < 200 * 0.2 + 2
+    assert o.emitted[0, 0] == o.total_departed[0] - o.emitted[0, 1] - o.emitted[0, 2]
+
+
+def test_rl_queue_is_first_in_first_out_and_the_ghost_row():
+    spec = quiet(merge_spec(R=1, cap_human=10, cap_rl=4, num_rl=1, n_init=0, q_highway=600.0, q_rl=900.0,
+                            q_merge=1e-3, horizon=2000, pre=60.0, post=60.0))
+    o = O.MergeOracle(spec, np.float64)
+    o.reset()
+    controlled, ghosts = [], 0
+    for k in range(900):
+        obs, _, _ = o.step(np.full((1, 1), 0.8))
+        ctl = np.flatnonzero(o.ctl_seq[0] >= 0)
+        assert len(ctl) <= 1
+        if len(ctl):
+            i = int(ctl[0])
+            key = int(o.origin[0, i]) if o.alive[0, i] else controlled[-1]
+            if not controlled or controlled[-1] != key:
+                controlled.append(key)
+            if not o.alive[0, i]:                                          # arrived this step: error values
+                ghosts += 1
+                np.testing.assert_allclose(obs[0], [-1001 / 30, (30 + 1001) / 30, 1.0, -1001 / 30, 1.0])
+        else:
+            np.testing.assert_array_equal(obs[0], np.zeros(5))             # unused places stay 0
+    ks = [c & 0xFFFFF for c in controlled]
+    assert len(ks) >= 3 and ks == sorted(ks) and ghosts >= 2               # served in order of entering
+
+
+def test_actions_reach_the_vehicle_at_its_place_in_rl_veh():
+    spec = quiet(merge_spec(R=1, cap_human=6, cap_rl=4, num_rl=2, n_init=0, q_highway=1e-3, q_rl=1200.0,
+                            q_merge=1e-3, horizon=500))
+    o = O.MergeOracle(spec, np.float64)
+    o.reset()
+    for k in range(60):
+        o.step(np.array([[1.0, -1.0]]))
+    rank = o._ctl_rank()[0]
+    first, second = int(np.flatnonzero(rank == 0)[0]), int(np.flatnonzero(rank == 1)[0])
+    assert o.seq[0, first] < o.seq[0, second]
+    assert o.last_accel[0, first] == 1.0 and o.last_accel[0, second] == -1.0
+
+
+def test_sticky_follower_rule():
+    """vehicle/traci.py:243-250: 'follower_headway' is only ever lowered; a vehicle without a leader is reset."""
+    tb = merge_tables()
+    veh = [idm_vehicle(type=0) for _ in range(4)]
+    base = dict(num_replicas=1, num_vehicles=4, num_rl=0, sim_step=0.2, max_speed=30.0, env=O.ENV_MERGE_MA,
+                vehicles=veh, inflows=[], junction=dict(enabled=0, lookahead=100.0, time_gap=1.0),
+                init_alive=np.ones((1, 4), bool), init_vel=np.zeros((1, 4)), init_route=np.zeros((1, 4), int),
+                init_pos=np.array([[300.0, 280.0, 200.0, 100.0]]), target_velocity=10.0, action_low=-1, action_high=1, **tb)
+    o = O.MergeOracle(base, np.float64)
+    o.reset()
+    np.testing.assert_array_equal(o.lead[0], [-1, 0, 1, 2])
+    np.testing.assert_array_equal(o.foll[0], [1, 2, 3, -1])
+    assert o.foll_h[0, 1] == 280.0 - 5 - 200.0
+    # vehicle 2 falls back: its headway to 1 grows, the recorded minimum stays
+    o.x[0, 2] = 150.0
+    o._update_neighbours(np.ones(1, bool))
+    assert o.foll[0, 1] == 2 and o.foll_h[0, 1] == 75.0 and o.h[0, 2] == 125.0
+    # a merge-branch vehicle becomes another follower of 1 with a larger gap than the recorded one: not registered
+    o.route[0, 3], o.x[0, 3] = 1, 190.0
+    o._update_neighbours(np.ones(1, bool))
+    assert o.lead[0, 3] == -1                       # vehicle 1 is still upstream of the merge point: not its leader
+    o.x[0, 0], o.x[0, 1] = 400.0, 330.0             # 1 moves onto the shared edge: leader of both 2 and 3
+    o._update_neighbours(np.ones(1, bool))
+    assert o.lead[0, 2] == 1 and o.lead[0, 3] == 1 and o.foll[0, 1] == 2 and o.foll_h[0, 1] == 75.0
+    # the front vehicle has no leader: its entry restarts from 1000 each update
+    assert o.foll[0, 0] == 1 and o.foll_h[0, 0] == 400.0 - 5 - 330.0
+
+
+def test_minor_route_yields_and_no_box_conflict():
+    spec = quiet(merge_spec(R=2, cap_human=28, cap_rl=2, num_rl=1, q_highway=1700.0, q_rl=1e-3, q_merge=600.0,
+                            horizon=700, seed=3))
+    o = O.MergeOracle(spec, np.float64)
+    o.reset()
+    waited = False
+    for k in range(700):
+        _, _, done = o.step(None)
+        inside = o.alive & (o.x >= o.box_in) & (o.x < o.merge_x)
+        assert not ((inside & (o.route == 0)).any(axis=1) & (inside & (o.route == 1)).any(axis=1)).any()
+        near = o.alive & (o.route == 1) & (o.x > o.box_in - 8.0) & (o.x < o.box_in) & (o.v < 0.2)
+        waited |= bool(near.any())
+        assert not done.any() or k == 699
+    assert waited and (o.total_arrived > 30).all()
+
+
+def test_float32_twin_tracks_float64_over_a_short_horizon():
+    spec = quiet(merge_spec(R=2, cap_human=12, cap_rl=2, num_rl=1, horizon=100, seed=5))
+    a, b = O.MergeOracle(spec, np.float32), O.MergeOracle(spec, np.float64)
+    a.reset(), b.reset()
+    for k in range(60):
+        act = np.full((2, 1), 0.5)
+        a.step(act), b.step(act)
+    np.testing.assert_array_equal(a.route, b.route)
+    np.testing.assert_allclose(a.x[a.alive], b.x[b.alive], atol=5e-3)
+
+
+# ------------------------------------------------------------------ host mirror
+def merge_network(pre=500, n_human=5, n_rl=0, flows=True):
+    from flow_amd.controllers import IDMController, RLController
+    from flow_amd.core import params as P
+    from flow_amd.networks.merge import ADDITIONAL_NET_PARAMS, MergeNetwork
+    add = ADDITIONAL_NET_PARAMS.copy()
+    add["pre_merge_length"] = pre
+    v = P.VehicleParams()
+    v.add("human", acceleration_controller=(IDMController, {"noise": 0.2}),
+          car_following_params=P.SumoCarFollowingParams(speed_mode="obey_safe_speed"), num_vehicles=n_human)
+    v.add("rl", acceleration_controller=(RLController, {}),
+          car_following_params=P.SumoCarFollowingParams(speed_mode="obey_safe_speed"), num_vehicles=n_rl)
+    inflow = P.InFlows()
+    if flows:
+        inflow.add(veh_type="human", edge="inflow_highway", vehs_per_hour=1800, departLane="free", departSpeed=10)
+        inflow.add(veh_type="rl", edge="inflow_highway", vehs_per_hour=200, departLane="free", departSpeed=10)
+        inflow.add(veh_type="human", edge="inflow_merge", vehs_per_hour=100, departLane="free", departSpeed=7.5)
+    return MergeNetwork("merge", v, P.NetParams(inflows=inflow, additional_params=add))
+
+
+def test_merge_network_tables_equal_the_literal_ones():
+    from flow_amd.core.kernel.network import NetworkKernel
+    from flow_amd.networks.merge import MergeNetwork
+    with pytest.raises(KeyError):
+        from flow_amd.core import params as P
+        MergeNetwork("m", P.VehicleParams(), P.NetParams(additional_params={"merge_length": 100}))
+    for pre in (200, 500):
+        k = NetworkKernel(merge_network(pre), junction_length=0.1)
+        t, ref = k.open_tables(), merge_tables(pre=float(pre))
+        for key in ("merge_x", "box_in", "end_x", "net_length"):
+            assert abs(t[key] - ref[key]) < 1e-9
+        for r in range(2):
+            np.testing.assert_allclose(np.array(t["routes"][r]["segments"], float),
+                                       np.array(ref["routes"][r]["segments"], float), atol=1e-9)
+        assert k.length() == 100 + pre + 100 + 100 + 100 + 0.2 + 45.0 and k.max_speed() == 30
+        assert k.get_x(":center_0", 3.0) == 100 + pre + 0.1 == k.get_x(":center_1", 7.0)     # traci.py:283-287
+        assert k.open_locate(0, t["merge_x"] + 1.0) == ("center", 1.0)
+        assert k.open_coordinate("bottom", 10.0) == (1, t["routes"][1]["start"] + 100.1 + 10.0)
+
+
+def test_inflows_accept_the_deprecated_spellings_and_validate():
+    from flow_amd.core.params import InFlows
+    f = InFlows()
+    f.add(veh_type="human", edge="e", vehsPerHour=1200, departLane="free", departSpeed=10)      # params.py:1167-1178
+    assert f.get()[0] == {"name": "flow_0", "vtype": "human", "edge": "e", "departLane": "free", "departSpeed": 10,
+                          "begin": 1, "end": 86400, "vehsPerHour": 1200}
+    f.add(veh_type="human", edge="e", period=3, number=7)
+    assert f.get()[1]["name"] == "flow_1" and f.get()[1]["number"] == 7 and "end" not in f.get()[1]
+    for bad in (dict(), dict(vehs_per_hour=1, period=2), dict(probability=1.5), dict(vehs_per_hour=1, begin=0)):
+        with pytest.raises(ValueError):                                                             # :1188-1200
+            InFlows().add(veh_type="human", edge="e", **bad)
+
+
+def test_slot_capacities():
+    from flow_amd.envs.spec import slot_capacities
+    from flow_amd.utils.exceptions import FatalFlowError
+    net = merge_network()
+    flows = net.net_params.inflows.get()
+    names, caps = slot_capacities(net.vehicles, flows, 64)
+    assert names == ["human", "rl"] and sum(caps) == 64 and caps[1] == int(59 * 200 / 2100) and caps[0] >= 5
+    assert slot_capacities(net.vehicles, flows, 64, {"human": 40, "rl": 9})[1] == [40, 9]
+    assert slot_capacities(net.vehicles, [], 64)[1] == [5, 0]
+    with pytest.raises(FatalFlowError):
+        slot_capacities(net.vehicles, flows, 3)
+    with pytest.raises(FatalFlowError):
+        slot_capacities(net.vehicles, flows, 64, {"human": 2, "rl": 9})
+
+
+def test_reference_merge_fixture_resolves_to_an_open_spec(monkeypatch):
+    """tests/fast_tests/test_files/merge.json (committed as tests/golden/merge_flow_params.json): the stored
+    flow_params of the merge_0 benchmark load into flow_amd objects and resolve to a simulator spec."""
+    from test_host import build_env
+    from flow_amd import _lib as L
+    from flow_amd.envs import MergePOEnv
+    from flow_amd.networks import MergeNetwork
+    from flow_amd.utils.rllib import get_flow_params
+    fp = get_flow_params(os.path.join(GOLDEN, "merge_flow_params.json"))
+    assert fp["env_name"] is MergePOEnv and fp["network"] is MergeNetwork
+    assert [f["vehsPerHour"] for f in fp["net"].inflows.get()] == [1800.0, 200.0, 100]
+    net = fp["network"](name=fp["exp_tag"], vehicles=fp["veh"], net_params=fp["net"], initial_config=fp["initial"])
+    env, spec = build_env(monkeypatch, fp["env_name"], fp["env"], fp["sim"], net)
+    assert spec["network"] == "merge" and spec["env"] == L.FS_ENV_MERGE_PO and spec["num_rl"] == 5
+    assert spec["num_vehicles"] == 64 and spec["sims_per_step"] == 2 and spec["sim_step"] == 0.2
+    assert [f["period"] for f in spec["inflows"]] == [2.0, 18.0, 36.0]
+    assert [(f["type"], f["route"], f["depart_speed"]) for f in spec["inflows"]] == [(0, 0, 10.0), (1, 0, 10.0), (0, 1, 7.5)]
+    assert spec["init_alive"][0].sum() == 5 and spec["vehicles"][0]["controller"] == L.FS_CTRL_SIM
+    assert spec["vehicles"][-1]["controller"] == L.FS_CTRL_RL and spec["vehicles"][0]["max_accel"] == 1.0
+    tb = merge_tables(pre=500.0)
+    assert abs(spec["merge_x"] - tb["merge_x"]) < 1e-9 and abs(spec["net_length"] - tb["net_length"]) < 1e-9
+    assert env.observation_space.shape == (25,) and env.action_space.shape == (5,)
+    # the five initial humans: spread evenly over all edges like gen_even_start_pos does (network/base.py:263-391)
+    assert [env.initial_state["human_%d" % i][1] for i in range(5)] == \
+        ["inflow_highway", "left", "left", "left", "center"]
+    assert abs(env.initial_state["human_1"][3] - 79.9) < 1e-9 and abs(env.initial_state["human_4"][3] - 97.4) < 1e-9
+    # the oracle accepts the very same dict
+    o = O.MergeOracle(spec, np.float64)
+    o.reset()
+    for _ in range(50):
+        o.step(None)
+    assert o.total_departed[0] > 5
+
+
+def test_merge_envs_require_their_additional_params():
+    """test_environments.py:646-660, 1171-1183 (test_additional_params)."""
+    from flow_amd.core.params import EnvParams, SumoParams
+    from flow_amd.envs import MergePOEnv
+    from flow_amd.envs.multiagent import MultiAgentMergePOEnv
+    net = merge_network()
+    full = {"max_accel": 1, "max_decel": 1, "target_velocity": 25, "num_rl": 5}
+    for key in full:
+        with pytest.raises(KeyError):
+            MergePOEnv(EnvParams(additional_params={k: v for k, v in full.items() if k != key}), SumoParams(), net)
+    for key in ("max_accel", "max_decel", "target_velocity"):
+        with pytest.raises(KeyError):
+            MultiAgentMergePOEnv(EnvParams(additional_params={k: v for k, v in full.items() if k != key}),
+                                 SumoParams(), net)
+
+
+def test_open_config_validation_needs_no_gpu():
+    from flow_amd import build
+    build.build()
+    from flow_amd.sim import FlowSim
+
+    def spec(**kw):
+        s = merge_spec(R=2, cap_human=6, cap_rl=2, num_rl=1)
+        s.update(kw)
+        return s
+    with pytest.raises(ValueError, match="vehicle type that has no slot"):
+        FlowSim(spec(inflows=[dict(type=7, route=0, period=2.0, depart_speed=1.0, depart_pos=5.0)]), "f32")
+    with pytest.raises(ValueError, match="inflow route"):
+        FlowSim(spec(inflows=[dict(type=0, route=3, period=2.0, depart_speed=1.0, depart_pos=5.0)]), "f32")
+    with pytest.raises(ValueError, match="period"):
+        FlowSim(spec(inflows=[dict(type=0, route=0, period=0.0, depart_speed=1.0, depart_pos=5.0)]), "f32")
+    with pytest.raises(ValueError, match="box_in < merge_x"):
+        FlowSim(spec(box_in=400.0), "f32")
+    with pytest.raises(ValueError, match="go together"):
+        FlowSim(spec(env=S.ENV_ACCEL), "f32")
+    with pytest.raises(ValueError, match="init_pos outside the route"):
+        FlowSim(spec(init_pos=np.full((2, 8), 9999.0)), "f32")
+    with pytest.raises(NotImplementedError, match="PISaturation"):
+        s = spec()
+        s["vehicles"] = [idm_vehicle(controller=S.CTRL_PISATURATION, type=0)] + s["vehicles"][1:]
+        FlowSim(s, "f32")
