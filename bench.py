@@ -16,7 +16,7 @@ observation/reward/done to the learner per fragment.
 
 Prints ONE JSON line (rank 0).  Extra keys: `roofline` (dominant kernel =
 k_steps, per-launch HIP-event timing), `cpu_baseline` (oracle C port on the host
-cores, bounded sample, rank 0, N=1 only), `step_api` (one launch per env step,
+cores, bounded sample, rank 0, N=1 only), `c5_merge` (open-network kernel, informational), `step_api` (one launch per env step,
 the Gym-faithful call pattern), `f64` (same workload in float64).
 """
 import argparse
@@ -158,6 +158,62 @@ def c3_leg(device, R=4096, steps=3000, po=False):
             "obs_dim": 3 if po else 28, "replicas_crashed_before_horizon": crashed,
             "workload": "C3: FigureEightNetwork r=30, 13 IDM (noise 0.2, obey_safe_speed) + 1 RL, %s, "
                         "random actions; generic kernel" % ("WaveAttenuationPOEnv" if po else "AccelEnv")}
+
+
+def c5_leg(device, R=1024, env_steps=600):
+    """BASELINE configs[4] (informational, not the headline): MergeNetwork pre_merge 500 m, 5 initial humans +
+    inflows 1800 / 200 (RL) / 100 veh/h, sim_step 0.2, sims_per_step 5, horizon 600, MultiAgentMergePOEnv head
+    (examples/exp_configs/rl/multiagent/multiagent_merge.py); 1024 replicas per GPU = 8192 over 8 GPUs; the
+    open-network kernel k_steps_open, 64 vehicle slots per replica.  fp32 state (BASELINE names fp16 state /
+    fp32 integrator: the state arrays here are fp32, nothing is stored in fp16)."""
+    import torch
+    from flow_amd import _lib as L
+    from flow_amd.controllers import IDMController, RLController
+    from flow_amd.core.params import (EnvParams, InFlows, NetParams, SumoCarFollowingParams, SumoParams,
+                                      VehicleParams)
+    from flow_amd.envs import VecFlowEnv
+    from flow_amd.envs.multiagent import MultiAgentMergePOEnv
+    from flow_amd.networks import MergeNetwork
+    from flow_amd.networks.merge import ADDITIONAL_NET_PARAMS
+    add = dict(ADDITIONAL_NET_PARAMS)
+    add["pre_merge_length"] = 500
+    veh = VehicleParams()
+    veh.add(veh_id="human", acceleration_controller=(IDMController, {"noise": 0.2}),
+            car_following_params=SumoCarFollowingParams(speed_mode="obey_safe_speed"), num_vehicles=5)
+    veh.add(veh_id="rl", acceleration_controller=(RLController, {}),
+            car_following_params=SumoCarFollowingParams(speed_mode="obey_safe_speed"), num_vehicles=0)
+    inflow = InFlows()
+    inflow.add(veh_type="human", edge="inflow_highway", vehs_per_hour=1800, depart_lane="free", depart_speed=10)
+    inflow.add(veh_type="rl", edge="inflow_highway", vehs_per_hour=200, depart_lane="free", depart_speed=10)
+    inflow.add(veh_type="human", edge="inflow_merge", vehs_per_hour=100, depart_lane="free", depart_speed=7.5)
+    fp = dict(exp_tag="multiagent_merge", env_name=MultiAgentMergePOEnv, network=MergeNetwork, simulator="traci",
+              sim=SumoParams(sim_step=0.2, render=False, restart_instance=True, seed=11),
+              env=EnvParams(horizon=600, sims_per_step=5, warmup_steps=0,
+                            additional_params={"max_accel": 1.5, "max_decel": 1.5, "target_velocity": 20}),
+              net=NetParams(inflows=inflow, additional_params=add), veh=veh)
+    vec = VecFlowEnv(fp, num_replicas=R, device=device.index)
+    K = env_steps
+    out = (torch.empty((K, R, vec.obs_dim), dtype=torch.float32, device=device),
+           torch.empty((K, R), dtype=torch.float32, device=device),
+           torch.empty((K, R), dtype=torch.uint8, device=device))
+    vec.reset()
+    vec.sim.rollout_dev(60, out[0][:60], out[1][:60], out[2][:60])       # warm-up launch
+    vec.reset()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    vec.sim.rollout_dev(K, *out)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    cnt = vec.sim.get_state(L.FS_FIELD_COUNTERS)
+    route = vec.sim.get_state(L.FS_FIELD_ROUTE)
+    res = {"value": R * K * 5 / dt, "unit": "env-steps/s (simulation sub-steps)", "env_steps": K, "sims_per_step": 5,
+           "replicas": R, "gym_steps_per_s": R * K / dt, "obs_dim": vec.obs_dim,
+           "vehicles_in_network_mean": float((route >= 0).sum(axis=1).mean()),
+           "departed_mean": float(cnt[:, 6].mean()), "arrived_mean": float(cnt[:, 5].mean()),
+           "workload": "C5: MergeNetwork pre_merge 500 m, inflows 1800 + 200 RL + 100 veh/h, 64 slots, "
+                       "MultiAgentMergePOEnv head, sim_step 0.2 x 5 sub-steps, one 600-step episode; k_steps_open"}
+    vec.close()
+    return res
 
 
 def cpu_baseline(spec_fn, seconds=12.0):
@@ -325,6 +381,7 @@ def main():
         r2.sim.close()
         out["c3_figure_eight"] = c3_leg(device)
         out["c3_figure_eight_po"] = c3_leg(device, po=True)
+        out["c5_merge"] = c5_leg(device)
         out["cpu_baseline"] = cpu_baseline(lambda r: c2_spec(r, seed=1000))
 
     runner.sim.close()

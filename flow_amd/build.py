@@ -6,7 +6,8 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 SRC = os.path.join(PKG, "csrc", "flowsim.hip")
-DEPS = [SRC, os.path.join(PKG, "csrc", "flowsim_kernels.h"), os.path.join(ROOT, "include", "flowsim.h")]
+DEPS = [SRC, os.path.join(PKG, "csrc", "flowsim_kernels.h"), os.path.join(PKG, "csrc", "flowsim_open.h"),
+        os.path.join(ROOT, "include", "flowsim.h")]
 LIB = os.path.join(PKG, "libflowsim.so")
 
 # -ffp-contract=off: the kernels are the float32 bit-twin of the oracle only if a*b+c is never fused

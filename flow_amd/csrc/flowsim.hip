@@ -283,46 +283,50 @@ struct Sim : SimBase {
       if (veh[i].controller == FS_CTRL_RL) ++n_rl_slots;
     }
     if ((rc = upload(&ov.slot_type, st))) return rc;
-    std::vector<T> mc(size_t(N) + 1);
-    for (int n = 0; n <= N; ++n) {               // np.linalg.norm([target] * n) in double (rewards.py:50-51)
+    std::vector<T> tab(size_t(fs::TAB_ROWS) * 64, T(0));
+    for (int n = 0; n <= 64; ++n) {               // np.linalg.norm([target] * n) in double (rewards.py:50-51)
       double ss = 0.0;
       for (int i = 0; i < n; ++i) ss += cfg.target_velocity * cfg.target_velocity;
-      mc[n] = T(std::sqrt(ss));
+      if (n < 64) tab[size_t(fs::TAB_MAX_COST) * 64 + n] = T(std::sqrt(ss));
+      else ov.max_cost_full = T(std::sqrt(ss));
     }
-    if ((rc = upload(&ov.max_cost, mc))) return rc;
     ov.n_inflows = cfg.num_inflows;
     ov.ma_apply_actions = cfg.ma_apply_actions;
     ov.n_rl_slots = n_rl_slots;
-    for (int f = 0; f < FS_MAX_INFLOWS; ++f) {
-      const bool in = f < cfg.num_inflows;
-      ov.fl_type[f] = in ? inflows[f].type : 0;
-      ov.fl_route[f] = in ? inflows[f].route : 0;
-      ov.fl_number[f] = in ? inflows[f].number : 0;
-      ov.fl_period[f] = in ? inflows[f].period : 1.0;
-      ov.fl_begin[f] = in ? inflows[f].begin : 0.0;
-      ov.fl_end[f] = in ? inflows[f].end : 0.0;
-      ov.fl_speed[f] = in ? T(inflows[f].depart_speed) : T(0);
-      ov.fl_pos[f] = in ? T(inflows[f].depart_pos) : T(0);
-      ov.fl_first_slot[f] = 0;
-      if (in)
-        for (int i = N - 1; i >= 0; --i)
-          if (veh[i].type == inflows[f].type) ov.fl_first_slot[f] = i;
+    std::vector<double> ftd(3 * 64, 0.0);
+    std::vector<int32_t> fti(3 * 64, 0);
+    for (int f = 0; f < cfg.num_inflows; ++f) {
+      ftd[f] = inflows[f].period;
+      ftd[64 + f] = inflows[f].begin;
+      ftd[128 + f] = inflows[f].end;
+      fti[f] = inflows[f].type;
+      fti[64 + f] = inflows[f].route;
+      fti[128 + f] = inflows[f].number;
+      int first = 0;                               // the type's parameters: those of its first slot
+      for (int i = N - 1; i >= 0; --i)
+        if (veh[i].type == inflows[f].type) first = i;
+      // same operations, in T, as oracle/opennet.py _insert
+      tab[size_t(fs::TAB_FL_XDEP) * 64 + f] = T(cfg.route_start[inflows[f].route]) + T(inflows[f].depart_pos);
+      tab[size_t(fs::TAB_FL_VDEP) * 64 + f] = T(inflows[f].depart_speed);
+      tab[size_t(fs::TAB_FL_MINGAP) * 64 + f] = T(veh[first].sumo_min_gap);
+      tab[size_t(fs::TAB_FL_TAU) * 64 + f] = T(veh[first].sumo_tau);
+      tab[size_t(fs::TAB_FL_TWOSQRT) * 64 + f] = T(2) * std::sqrt(T(veh[first].max_accel) * T(veh[first].max_decel));
     }
     ov.dt_d = cfg.sim_step;
     for (int r = 0; r < 2; ++r) {
       ov.nseg[r] = 0;
       ov.seg_internal[r] = 0u;
-      for (int k = 0; k < FS_MAX_SEGMENTS; ++k)
-        ov.seg_start[r][k] = ov.seg_flow_start[r][k] = ov.seg_flow_slope[r][k] = T(0);
-      ov.route_start[r] = T(cfg.route_start[r]);
     }
     for (const fs_segment& sg : segs) {
       const int r = sg.route, k = ov.nseg[r]++;
-      ov.seg_start[r][k] = T(sg.start);
-      ov.seg_flow_start[r][k] = T(sg.flow_start);
-      ov.seg_flow_slope[r][k] = T(sg.flow_slope);
+      tab[size_t(fs::TAB_SEG_START) * 64 + r * 16 + k] = T(sg.start);
+      tab[size_t(fs::TAB_SEG_FLOW) * 64 + r * 16 + k] = T(sg.flow_start);
+      tab[size_t(fs::TAB_SEG_SLOPE) * 64 + r * 16 + k] = T(sg.flow_slope);
       if (sg.internal) ov.seg_internal[r] |= (1u << k);
     }
+    if ((rc = upload(&ov.lane_tab, tab))) return rc;
+    if ((rc = upload(&ov.flow_tab_d, ftd))) return rc;
+    if ((rc = upload(&ov.flow_tab_i, fti))) return rc;
     ov.merge_x = T(cfg.merge_x);
     ov.box_in = T(cfg.box_in);
     ov.end_x = T(cfg.end_x);

@@ -33,17 +33,30 @@ struct OpenView {
   int32_t* emitted;      // [R,FS_MAX_INFLOWS]
   const uint8_t* init_alive;   // [R,N]
   const int32_t* slot_type;    // [N]
-  const T* max_cost;           // [N+1] norm([target]*n)
+  // Launch constants the step loop reads are kept one-per-lane in a few VGPRs and fetched with v_readlane, so the
+  // loop body makes no memory access for them: lane_tab[row][lane], rows = enum below (host: Sim::init_open)
+  const T* lane_tab;
+  const double* flow_tab_d;    // [3][64] lane f: period, begin, end of inflow f (the schedule is evaluated in double)
+  const int32_t* flow_tab_i;   // [3][64] lane f: vehicle type, route, number (-1 = unlimited)
   int n_inflows, ma_apply_actions, n_rl_slots;
-  int fl_type[FS_MAX_INFLOWS], fl_route[FS_MAX_INFLOWS], fl_number[FS_MAX_INFLOWS], fl_first_slot[FS_MAX_INFLOWS];
-  double fl_period[FS_MAX_INFLOWS], fl_begin[FS_MAX_INFLOWS], fl_end[FS_MAX_INFLOWS];
-  T fl_speed[FS_MAX_INFLOWS], fl_pos[FS_MAX_INFLOWS];
   double dt_d;
   int nseg[2];
   unsigned seg_internal[2];
-  T seg_start[2][FS_MAX_SEGMENTS], seg_flow_start[2][FS_MAX_SEGMENTS], seg_flow_slope[2][FS_MAX_SEGMENTS];
-  T route_start[2];
+  T max_cost_full;             // norm([target] * 64): the one entry that does not fit the 64-lane row
   T merge_x, box_in, end_x, net_length;
+};
+
+enum {
+  TAB_SEG_START = 0,    // lane r*16 + q: start of segment q of route r
+  TAB_SEG_FLOW = 1,     // ... its Flow table coordinate
+  TAB_SEG_SLOPE = 2,    // ... 1 or 0
+  TAB_FL_XDEP = 3,      // lane f: insertion coordinate of inflow f (route start + departPos)
+  TAB_FL_VDEP = 4,      // ... departSpeed
+  TAB_FL_MINGAP = 5,    // ... minGap / tau / 2*sqrt(accel*decel) of its vehicle type (M3)
+  TAB_FL_TAU = 6,
+  TAB_FL_TWOSQRT = 7,
+  TAB_MAX_COST = 8,     // lane n: norm([target] * n), n < 64
+  TAB_ROWS = 9
 };
 
 enum { CNT_SIM_STEPS = 0, CNT_SEQ = 1, CNT_CTL = 2, CNT_ARRIVED = 3, CNT_DEPARTED = 4, CNT_TOTAL_ARRIVED = 5,
@@ -56,32 +69,95 @@ __device__ __forceinline__ unsigned long long seg_ballot(bool pred, int seg) {
   return (b >> (seg * (SEG & 63))) & ((1ull << (SEG & 63)) - 1ull);
 }
 
+// minimum over the SEG-lane segment: the butterfly of seg_sum with min instead of +
+__device__ __forceinline__ float min_swap16(float v) {
+  unsigned a = __float_as_uint(v), b = a;
+  swap_rows16(a, b);
+  const float fa = __uint_as_float(a), fb = __uint_as_float(b);
+  return fb < fa ? fb : fa;
+}
+__device__ __forceinline__ float min_swap32(float v) {
+  unsigned a = __float_as_uint(v), b = a;
+  swap_rows32(a, b);
+  const float fa = __uint_as_float(a), fb = __uint_as_float(b);
+  return fb < fa ? fb : fa;
+}
+__device__ __forceinline__ double min_swap16(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  unsigned lo0 = unsigned(u), lo1 = lo0, hi0 = unsigned(u >> 32), hi1 = hi0;
+  swap_rows16(lo0, lo1);
+  swap_rows16(hi0, hi1);
+  const double a = __builtin_bit_cast(double, ((unsigned long long)hi0 << 32) | lo0);
+  const double b = __builtin_bit_cast(double, ((unsigned long long)hi1 << 32) | lo1);
+  return b < a ? b : a;
+}
+__device__ __forceinline__ double min_swap32(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  unsigned lo0 = unsigned(u), lo1 = lo0, hi0 = unsigned(u >> 32), hi1 = hi0;
+  swap_rows32(lo0, lo1);
+  swap_rows32(hi0, hi1);
+  const double a = __builtin_bit_cast(double, ((unsigned long long)hi0 << 32) | lo0);
+  const double b = __builtin_bit_cast(double, ((unsigned long long)hi1 << 32) | lo1);
+  return b < a ? b : a;
+}
 template <int SEG, typename T>
 __device__ __forceinline__ T seg_min(T v) {
-#pragma unroll
-  for (int off = 1; off < SEG; off <<= 1) {
-    const T w = __shfl_xor(v, off, 64);
+  T w = dpp<DPP_QUAD_XOR1>(v);
+  v = w < v ? w : v;
+  w = dpp<DPP_QUAD_XOR2>(v);
+  v = w < v ? w : v;
+  w = dpp<DPP_ROW_HALF_MIRROR>(v);
+  v = w < v ? w : v;
+  if (SEG >= 16) {
+    w = dpp<DPP_ROW_MIRROR>(v);
     v = w < v ? w : v;
   }
+  if (SEG >= 32) v = min_swap16(v);
+  if (SEG >= 64) v = min_swap32(v);
   return v;
 }
 
-// (internal?, Flow table coordinate) of coordinate x on route r (O5); both tables are walked with uniform
-// loops and the lane keeps the one of its route
+// value that slot j (wave-uniform) of MY segment holds: v_readlane broadcasts through an SGPR, no LDS round trip
+__device__ __forceinline__ int read_lane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+template <int SEG>
+__device__ __forceinline__ int seg_read_i(int v, int j, int seg) {
+  int out = read_lane_i(v, j);
+#pragma unroll
+  for (int sg = 1; sg < 64 / SEG; ++sg) {
+    const int f = read_lane_i(v, sg * SEG + j);
+    out = (seg == sg) ? f : out;
+  }
+  return out;
+}
+template <int SEG, typename T>
+__device__ __forceinline__ T seg_read(T v, int j, int seg) {
+  T out = read_lane(v, j);
+#pragma unroll
+  for (int sg = 1; sg < 64 / SEG; ++sg) {
+    const T f = read_lane(v, sg * SEG + j);
+    out = (seg == sg) ? f : out;
+  }
+  return out;
+}
+
+// (internal?, Flow table coordinate) of coordinate x on route r (O5).  tab_* are the lane-indexed segment rows; both
+// routes are walked with wave-uniform loops and the lane keeps the result of its own route.
 template <typename T>
-__device__ __forceinline__ void route_lookup(const OpenView<T>& o, T x, int route, bool& internal, T& flow_x) {
+__device__ __forceinline__ void route_lookup(const OpenView<T>& o, T tab_start, T tab_flow, T tab_slope, T x, int route,
+                                             bool& internal, T& flow_x) {
   internal = false;
   flow_x = T(0);
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     int k = 0;
-    T st = o.seg_start[r][0], fs0 = o.seg_flow_start[r][0], sl = o.seg_flow_slope[r][0];
+    T st = read_lane(tab_start, r * 16), fs0 = read_lane(tab_flow, r * 16), sl = read_lane(tab_slope, r * 16);
     for (int q = 1; q < o.nseg[r]; ++q) {
-      const bool hit = x >= o.seg_start[r][q];
+      const T sq = read_lane(tab_start, r * 16 + q);
+      const bool hit = x >= sq;
       k = hit ? q : k;
-      st = hit ? o.seg_start[r][q] : st;
-      fs0 = hit ? o.seg_flow_start[r][q] : fs0;
-      sl = hit ? o.seg_flow_slope[r][q] : sl;
+      st = hit ? sq : st;
+      fs0 = hit ? read_lane(tab_flow, r * 16 + q) : fs0;
+      sl = hit ? read_lane(tab_slope, r * 16 + q) : sl;
     }
     if (route == r) {
       internal = (o.seg_internal[r] >> k) & 1u;
@@ -133,6 +209,15 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
   sl.sumo_max_speed = s.sumo_max_speed[ii];
   const int my_type = o.slot_type[ii];
   const bool is_rl = sl.ctrl == FS_CTRL_RL;
+  const T tab_start = o.lane_tab[TAB_SEG_START * 64 + lane_id], tab_flow = o.lane_tab[TAB_SEG_FLOW * 64 + lane_id],
+          tab_slope = o.lane_tab[TAB_SEG_SLOPE * 64 + lane_id], tab_xdep = o.lane_tab[TAB_FL_XDEP * 64 + lane_id],
+          tab_vdep = o.lane_tab[TAB_FL_VDEP * 64 + lane_id], tab_mingap = o.lane_tab[TAB_FL_MINGAP * 64 + lane_id],
+          tab_tau = o.lane_tab[TAB_FL_TAU * 64 + lane_id], tab_twosqrt = o.lane_tab[TAB_FL_TWOSQRT * 64 + lane_id],
+          tab_maxcost = o.lane_tab[TAB_MAX_COST * 64 + lane_id];
+  const double ft_period = o.flow_tab_d[lane_id], ft_begin = o.flow_tab_d[64 + lane_id],
+               ft_end = o.flow_tab_d[128 + lane_id];
+  const int ft_type = o.flow_tab_i[lane_id], ft_route = o.flow_tab_i[64 + lane_id],
+            ft_number = o.flow_tab_i[128 + lane_id];
 
   const bool live_replica = rvalid && (mask == nullptr || mask[rr] != 0);
   int tcount = s.time[rr];
@@ -141,9 +226,8 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
   int sim_steps = cnt[CNT_SIM_STEPS], seq_ctr = cnt[CNT_SEQ], ctl_ctr = cnt[CNT_CTL];
   int n_arr = cnt[CNT_ARRIVED], n_dep = cnt[CNT_DEPARTED], tot_arr = cnt[CNT_TOTAL_ARRIVED],
       tot_dep = cnt[CNT_TOTAL_DEPARTED];
-  int emitted[FS_MAX_INFLOWS];
-#pragma unroll
-  for (int f = 0; f < FS_MAX_INFLOWS; ++f) emitted[f] = o.emitted[size_t(rr) * FS_MAX_INFLOWS + f];
+  // vehicles emitted so far by inflow f of this replica: held by lane f of the replica's segment (SEG >= 8)
+  int emit_l = (i < FS_MAX_INFLOWS) ? o.emitted[size_t(rr) * FS_MAX_INFLOWS + i] : 0;
 
   T x = s.pos[idx];
   T v = s.vel[idx];
@@ -166,6 +250,14 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
   float* rrow = rew + rr;
   uint8_t* drow = done + rr;
 
+  // slots j that hold a vehicle in at least one replica of this wave, as a wave-uniform SEG-bit mask
+  auto occupied_slots = [&]() -> unsigned long long {
+    unsigned long long u = __ballot(route >= 0);
+    if (SEG < 64) u |= u >> 32;
+    if (SEG < 32) u |= u >> 16;
+    if (SEG < 16) u |= u >> 8;
+    return SEG == 64 ? u : (u & ((1ull << (SEG & 63)) - 1ull));
+  };
   // ---- M5: leader = nearest vehicle ahead on the own route -------------------------------------------
   int lead = -1;
   T vl = T(-1001), h = T(1000);
@@ -174,15 +266,16 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
     const bool alive = route >= 0;
     T best = BIGV;
     lead = -1;
-    for (int k = 1; k < N; ++k) {
-      int j = ii + k;
-      j = j >= N ? j - N : j;
-      const T xj = bperm(x, segbase + j);
-      const int rj = __shfl(route, segbase + j, 64);
+    // only slots that hold a vehicle in some replica of this wave (wave-uniform mask), ascending: on a tie the
+    // lowest slot stays
+    for (unsigned long long u = occupied_slots(); u; u &= u - 1ull) {
+      const int j = __ffsll((long long)u) - 1;
+      const T xj = seg_read<SEG>(x, j, seg);
+      const int rj = seg_read_i<SEG>(route, j, seg);
       const T d = xj - x;
       const bool ahead = (d > T(0)) || (d == T(0) && j < ii);
-      const bool cand = ahead && alive && rj >= 0 && (rj == route || xj >= o.merge_x);
-      if (cand && (d < best || (d == best && j < lead))) { best = d; lead = j; }
+      const bool cand = (j != ii) && ahead && alive && rj >= 0 && (rj == route || xj >= o.merge_x);
+      if (cand && d < best) { best = d; lead = j; }
     }
     has = lead >= 0;
     const int lsrc = segbase + (has ? lead : ii);
@@ -199,12 +292,11 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
     const int start_f = no_lead ? -1 : foll;
     T bestf = BIGV;
     int bseq = 0x7fffffff, bj = -1;
-    for (int k = 1; k < N; ++k) {
-      int j = ii + k;
-      j = j >= N ? j - N : j;
-      const int lj = __shfl(lead, segbase + j, 64);
-      const T hj = bperm(h, segbase + j);
-      const int sj = __shfl(seq, segbase + j, 64);
+    for (unsigned long long u = occupied_slots(); u; u &= u - 1ull) {
+      const int j = __ffsll((long long)u) - 1;
+      const int lj = seg_read_i<SEG>(lead, j, seg);
+      const T hj = seg_read<SEG>(h, j, seg);
+      const int sj = seg_read_i<SEG>(seq, j, seg);
       const bool elig = (lj == ii) && slot_ok && (has || sj > seq);
       if (elig && (hj < bestf || (hj == bestf && sj < bseq))) { bestf = hj; bseq = sj; bj = j; }
     }
@@ -232,7 +324,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
     const bool alive = route >= 0;
     bool internal;
     T fx;
-    route_lookup(o, x, route, internal, fx);
+    route_lookup(o, tab_start, tab_flow, tab_slope, x, route, internal, fx);
     const int ld = alive ? lead : -1;
     const int fo = alive ? foll : -1;
     const int lsrc = segbase + (ld >= 0 ? ld : ii), fsrc = segbase + (fo >= 0 ? fo : ii);
@@ -309,7 +401,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       }
       bool internal;
       T fx_unused;
-      route_lookup(o, x, route, internal, fx_unused);
+      route_lookup(o, tab_start, tab_flow, tab_slope, x, route, internal, fx_unused);
       const bool on_edge = s.junction_mode ? !internal : true;
       // RL command (envs/base.py:355 runs before additional_command: the rl_veh list of the last sub-step)
       bool have_rl = false;
@@ -389,52 +481,51 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         tot_arr += na;
       }
       // ---- M2 / M3: insertions in InFlows order -------------------------------------------------------
-#pragma unroll
-      for (int f = 0; f < FS_MAX_INFLOWS; ++f) {
-        if (f < o.n_inflows) {
-          const int k = emitted[f];
-          const double due_t = o.fl_begin[f] + double(k) * o.fl_period[f];
-          const double now = double(sim_steps - 1) * o.dt_d;
-          const bool due = (due_t <= now) && (due_t <= o.fl_end[f]) && (o.fl_number[f] < 0 || k < o.fl_number[f]);
-          const int typ = o.fl_type[f], route_f = o.fl_route[f];
-          const bool alive_now = route >= 0;
-          const bool free_slot = !alive_now && slot_ok && (my_type == typ) && !just_arrived;
-          const unsigned long long fb = seg_ballot<SEG>(free_slot, seg);
-          const int slot = fb ? __ffsll((long long)fb) - 1 : 0;
-          const T x_dep = (route_f == 0 ? o.route_start[0] : o.route_start[1]) + o.fl_pos[f];
-          const T v_dep = o.fl_speed[f];
-          const bool cand = alive_now && (route == route_f || x >= o.merge_x);
-          const T xm = seg_min<SEG>(cand ? x : BIGV);
-          const unsigned long long cb = seg_ballot<SEG>(cand && x == xm, seg);
-          const bool has_lead = cb != 0ull;
-          const int j = has_lead ? __ffsll((long long)cb) - 1 : 0;
-          const T back_j = bperm(x - sl.length, segbase + j);
-          const T v_lead = bperm(v, segbase + j);
-          const T gap = back_j - x_dep;
-          const int fs0 = o.fl_first_slot[f];
-          const T two_sqrt = T(2) * tsqrt(s.max_accel[fs0] * s.max_decel[fs0]);
-          const T need = s.sumo_min_gap[fs0] +
-                         tmax(T(0), v_dep * s.sumo_tau[fs0] + v_dep * (v_dep - v_lead) / two_sqrt);
-          const bool ok = live && due && (fb != 0ull) && (!has_lead || gap >= need);
-          if (ok && slot_ok && ii == slot) {
-            x = x_dep;
-            v = v_dep;
-            prev_v = T(0);                               // previous_speeds.get(veh_id, 0)
-            cst = T(0);
-            last_acc = T(0);
-            route = route_f;
-            seq = seq_ctr;
-            origin = f * (1 << 20) + k;
-            foll = -1;
-            foll_h = BIGV;
-            ctl_seq = -1;
-          }
-          if (ok) {
-            seq_ctr += 1;
-            emitted[f] = k + 1;
-            n_dep += 1;
-            tot_dep += 1;
-          }
+      // (a rolled loop over the inflows; every per-flow constant comes out of a lane table, so the loop keeps no
+      // scalar registers alive across the step loop)
+      const double now = double(sim_steps - 1) * o.dt_d;
+      for (int f = 0; f < o.n_inflows; ++f) {
+        const int k = seg_read_i<SEG>(emit_l, f, seg);
+        const double due_t = read_lane(ft_begin, f) + double(k) * read_lane(ft_period, f);
+        const int number = read_lane_i(ft_number, f);
+        const bool due = (due_t <= now) && (due_t <= read_lane(ft_end, f)) && (number < 0 || k < number);
+        const int typ = read_lane_i(ft_type, f), route_f = read_lane_i(ft_route, f);
+        const bool alive_now = route >= 0;
+        const bool free_slot = !alive_now && slot_ok && (my_type == typ) && !just_arrived;
+        const unsigned long long fb = seg_ballot<SEG>(free_slot, seg);
+        const int slot = fb ? __ffsll((long long)fb) - 1 : 0;
+        const T x_dep = read_lane(tab_xdep, f);
+        const T v_dep = read_lane(tab_vdep, f);
+        const bool cand = alive_now && (route == route_f || x >= o.merge_x);
+        const T xm = seg_min<SEG>(cand ? x : BIGV);
+        const unsigned long long cb = seg_ballot<SEG>(cand && x == xm, seg);
+        const bool has_lead = cb != 0ull;
+        const int j = has_lead ? __ffsll((long long)cb) - 1 : 0;
+        const T back_j = bperm(x - sl.length, segbase + j);
+        const T v_lead = bperm(v, segbase + j);
+        const T gap = back_j - x_dep;
+        const T two_sqrt = read_lane(tab_twosqrt, f);
+        const T need = read_lane(tab_mingap, f) +
+                       tmax(T(0), v_dep * read_lane(tab_tau, f) + v_dep * (v_dep - v_lead) / two_sqrt);
+        const bool ok = live && due && (fb != 0ull) && (!has_lead || gap >= need);
+        if (ok && slot_ok && ii == slot) {
+          x = x_dep;
+          v = v_dep;
+          prev_v = T(0);                                 // previous_speeds.get(veh_id, 0)
+          cst = T(0);
+          last_acc = T(0);
+          route = route_f;
+          seq = seq_ctr;
+          origin = f * (1 << 20) + k;
+          foll = -1;
+          foll_h = BIGV;
+          ctl_seq = -1;
+        }
+        if (ok) {
+          seq_ctr += 1;
+          if (i == f) emit_l = k + 1;
+          n_dep += 1;
+          tot_dep += 1;
         }
       }
       // ---- O1: new neighbour snapshot, sticky followers, collision check --------------------------------
@@ -461,7 +552,9 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         const T sum_v = seg_sum<SEG>(alive ? v : T(0));
         reward = n_alive > 0 ? sum_v / T(n_alive) : T(0);
       } else {
-        const T max_cost = o.max_cost[n_alive];          // O4
+        // O4; n_alive differs between the replicas of a wave: a gather (ds_bpermute), not a v_readlane
+        const T mc_lane = bperm(tab_maxcost, n_alive & 63);
+        const T max_cost = n_alive < 64 ? mc_lane : o.max_cost_full;
         const T dv = alive ? v - s.target_velocity : T(0);
         const T cost = tsqrt(seg_sum<SEG>(dv * dv));
         T cost1 = tmax(max_cost - cost, T(0)) / (max_cost + T(1.1920928955078125e-07));
@@ -520,10 +613,9 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       cnt[CNT_DEPARTED] = n_dep;
       cnt[CNT_TOTAL_ARRIVED] = tot_arr;
       cnt[CNT_TOTAL_DEPARTED] = tot_dep;
-#pragma unroll
-      for (int f = 0; f < FS_MAX_INFLOWS; ++f) o.emitted[size_t(rr) * FS_MAX_INFLOWS + f] = emitted[f];
     }
   }
+  if (rvalid && live_replica && i < FS_MAX_INFLOWS) o.emitted[size_t(rr) * FS_MAX_INFLOWS + i] = emit_l;
 }
 
 // Env.reset of an open network: the initial vehicles back in their slots, every other slot free, clocks and
