@@ -460,7 +460,10 @@ struct Sim : SimBase {
 
   int launch_reset(const uint8_t* mask) override {
     if (open_net) {
-      hipLaunchKernelGGL((fs::k_reset_open<T>), dim3((dv.R + 63) / 64), dim3(64), 0, stream, dv, ov, mask);
+      const size_t n_open = size_t(dv.R) * dv.N;
+      int blocks_open = int((n_open + 255) / 256);
+      if (blocks_open > 2048) blocks_open = 2048;
+      hipLaunchKernelGGL((fs::k_reset_open<T>), dim3(blocks_open), dim3(256), 0, stream, dv, ov, mask);
       HIP_TRY(hipGetLastError());
       return FS_OK;
     }

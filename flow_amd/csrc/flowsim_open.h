@@ -258,47 +258,73 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
     if (SEG < 16) u |= u >> 8;
     return SEG == 64 ? u : (u & ((1ull << (SEG & 63)) - 1ull));
   };
-  // ---- M5: leader = nearest vehicle ahead on the own route -------------------------------------------
+  // ---- M5 + O1: neighbours through the ORDER of the vehicles ------------------------------------------------
+  // Every sub-step each lane needs its leader (nearest vehicle ahead on its route) and, for the sticky follower
+  // rule, the vehicles whose leader it is.  Instead of comparing all pairs, the lanes are ranked once by position
+  // (one v_readlane + compare + add-with-carry per occupied slot); everything else is O(1) per lane on 64-bit
+  // masks laid out in that order:
+  //   rank       place of the vehicle in the order "x ascending, equal x: higher slot first"; free slots rank last
+  //   sorted_slot  lane segbase+p holds the slot whose rank is p (one ds_permute push; the ranks of a segment are a
+  //              permutation of 0..SEG-1)
+  //   B0, B1     bit p: the vehicle of rank p is on route 0 / 1;   SH  bit p: it is past the merge point
+  // leader(i)   = lowest set bit above rank_i of (B_route(i) | SH)
+  // followers(X) = for each route, the highest set bit of B_r below rank_X, if that vehicle's leader is X
   int lead = -1;
   T vl = T(-1001), h = T(1000);
   bool has = false;
-  auto scan = [&]() {
+  auto or64 = [&](unsigned long long m) -> unsigned long long {
+    const unsigned lo = seg_or<SEG>(unsigned(m));
+    const unsigned hi = SEG == 64 ? seg_or<SEG>(unsigned(m >> 32)) : 0u;
+    return ((unsigned long long)hi << 32) | lo;
+  };
+  auto neighbours = [&](bool live, bool follow) {
     const bool alive = route >= 0;
-    T best = BIGV;
-    lead = -1;
-    // only slots that hold a vehicle in some replica of this wave (wave-uniform mask), ascending: on a tie the
-    // lowest slot stays
+    const T xr = alive ? x : BIGV;
+    int rank = 0;
     for (unsigned long long u = occupied_slots(); u; u &= u - 1ull) {
       const int j = __ffsll((long long)u) - 1;
-      const T xj = seg_read<SEG>(x, j, seg);
-      const int rj = seg_read_i<SEG>(route, j, seg);
-      const T d = xj - x;
-      const bool ahead = (d > T(0)) || (d == T(0) && j < ii);
-      const bool cand = (j != ii) && ahead && alive && rj >= 0 && (rj == route || xj >= o.merge_x);
-      if (cand && d < best) { best = d; lead = j; }
+      const T xj = seg_read<SEG>(xr, j, seg);
+      rank += ((xj < xr) || (xj == xr && j > ii)) ? 1 : 0;
     }
-    has = lead >= 0;
-    const int lsrc = segbase + (has ? lead : ii);
-    const T vsrc = bperm(v, lsrc);
+    const unsigned long long segmask = SEG == 64 ? ~0ull : ((1ull << (SEG & 63)) - 1ull);
+    const unsigned long long am = seg_ballot<SEG>(alive, seg);
+    if (!alive) rank = __popcll(am) + __popcll(~am & segmask & ((1ull << i) - 1ull));
+    const int sorted_slot = __builtin_amdgcn_ds_permute((segbase + rank) << 2, i);
+    const unsigned long long bit = 1ull << rank;
+    const unsigned long long B0 = or64(alive && route == 0 ? bit : 0ull);
+    const unsigned long long B1 = or64(alive && route == 1 ? bit : 0ull);
+    const unsigned long long SH = or64(alive && x >= o.merge_x ? bit : 0ull);
+    const unsigned long long above = rank >= 63 ? 0ull : (~0ull << (rank + 1));
+    const unsigned long long m = alive ? (((route == 0 ? B0 : B1) | SH) & above) : 0ull;
+    has = m != 0ull;
+    const int lead_pos = has ? __ffsll((long long)m) - 1 : 0;
+    const int lslot = __shfl(sorted_slot, segbase + lead_pos, 64);
+    lead = has ? lslot : -1;
+    const int lsrc = segbase + (has ? lslot : ii);
+    const T x_l = bperm(x, lsrc);
+    const T v_l = bperm(v, lsrc);
     const T len_lead = bperm(sl.length, lsrc);
-    vl = has ? vsrc : T(-1001);                         // get_speed(None): the accessor's error value
-    h = has ? best - len_lead : T(1000);                // vehicle/traci.py:237
-  };
-  // ---- O1: the sticky follower entry of THIS vehicle after an update ---------------------------------
-  auto follower_update = [&](bool live) {
-    const bool alive = route >= 0;
+    vl = has ? v_l : T(-1001);                          // get_speed(None): the accessor's error value
+    h = has ? (x_l - x) - len_lead : T(1000);           // vehicle/traci.py:237
+    if (!follow) return;
+    // ---- O1: the sticky follower entry of THIS vehicle (vehicle/traci.py:232-250) ----------------------
     const bool no_lead = alive && !has;
     const T start_h = no_lead ? T(1000) : foll_h;
     const int start_f = no_lead ? -1 : foll;
+    const unsigned long long below = bit - 1ull;
     T bestf = BIGV;
     int bseq = 0x7fffffff, bj = -1;
-    for (unsigned long long u = occupied_slots(); u; u &= u - 1ull) {
-      const int j = __ffsll((long long)u) - 1;
-      const int lj = seg_read_i<SEG>(lead, j, seg);
-      const T hj = seg_read<SEG>(h, j, seg);
-      const int sj = seg_read_i<SEG>(seq, j, seg);
-      const bool elig = (lj == ii) && slot_ok && (has || sj > seq);
-      if (elig && (hj < bestf || (hj == bestf && sj < bseq))) { bestf = hj; bseq = sj; bj = j; }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const unsigned long long mb = (r == 0 ? B0 : B1) & below;
+      const bool has_c = alive && mb != 0ull;
+      const int q = has_c ? 63 - __clzll((long long)mb) : 0;
+      const int cslot = __shfl(sorted_slot, segbase + q, 64);
+      const int c_lead = __shfl(lead, segbase + cslot, 64);
+      const T c_h = bperm(h, segbase + cslot);
+      const int c_seq = __shfl(seq, segbase + cslot, 64);
+      const bool elig = has_c && (c_lead == ii) && (has || c_seq > seq);
+      if (elig && (c_h < bestf || (c_h == bestf && c_seq < bseq))) { bestf = c_h; bseq = c_seq; bj = cslot; }
     }
     const bool better = (bestf < start_h) && (bestf < BIGV);
     if (alive && live) {
@@ -366,12 +392,12 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
     }
   };
 
-  scan();
+  neighbours(false, false);
 
   if (num_steps == 0) {
     // after_reset: update(reset=True) registers the followers of the initial placement (vehicle/traci.py:219-250)
     if (after_reset) {
-      follower_update(live_replica);
+      neighbours(live_replica, true);
       if (valid && live_replica) {
         o.foll[idx] = foll;
         o.foll_h[idx] = foll_h;
@@ -489,6 +515,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         const double due_t = read_lane(ft_begin, f) + double(k) * read_lane(ft_period, f);
         const int number = read_lane_i(ft_number, f);
         const bool due = (due_t <= now) && (due_t <= read_lane(ft_end, f)) && (number < 0 || k < number);
+        if (__ballot(due && live) == 0ull) continue;     // wave-uniform: this inflow is due in no replica of the wave
         const int typ = read_lane_i(ft_type, f), route_f = read_lane_i(ft_route, f);
         const bool alive_now = route >= 0;
         const bool free_slot = !alive_now && slot_ok && (my_type == typ) && !just_arrived;
@@ -529,8 +556,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         }
       }
       // ---- O1: new neighbour snapshot, sticky followers, collision check --------------------------------
-      scan();
-      follower_update(live);
+      neighbours(live, true);
       bool c = seg_any<SEG>((route >= 0) && has && (h < s.crash_gap), seg);
       if (s.junction_on) {
         const bool inside = (route >= 0) && (x >= o.box_in) && (x < o.merge_x);
@@ -623,14 +649,15 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
 // has run when reset returns.
 template <typename T>
 __global__ void k_reset_open(DevView<T> s, OpenView<T> o, const uint8_t* __restrict__ mask) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= s.R) return;
-  if (mask != nullptr && mask[r] == 0) return;
   const int N = s.N;
-  int ids = 0;
-  for (int i = 0; i < N; ++i) {
-    const size_t e = size_t(r) * N + i;
-    const bool a = o.init_alive[e] != 0;
+  const size_t n = size_t(s.R) * N;
+  for (size_t e = size_t(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += size_t(gridDim.x) * blockDim.x) {
+    const int r = int(e / N), i = int(e % N);
+    if (mask != nullptr && mask[r] == 0) continue;
+    const uint8_t* al = o.init_alive + size_t(r) * N;
+    const bool a = al[i] != 0;
+    int ids = 0;                                   // id-list place = number of initial vehicles in lower slots
+    for (int j = 0; j < i; ++j) ids += al[j] ? 1 : 0;
     s.pos[e] = s.init_pos[e];
     s.vel[e] = s.init_vel[e];
     s.prev_vel[e] = s.init_vel[e];
@@ -645,14 +672,24 @@ __global__ void k_reset_open(DevView<T> s, OpenView<T> o, const uint8_t* __restr
     o.arrived_rl[e] = 0;
     o.lead[e] = -1;
     o.headway[e] = T(1000);
-    ids += a ? 1 : 0;
+    if (i < FS_MAX_INFLOWS) o.emitted[size_t(r) * FS_MAX_INFLOWS + i] = 0;
+    if (i == 0) {
+      int total = 0;
+      for (int j = 0; j < N; ++j) total += al[j] ? 1 : 0;
+      int32_t* cnt = o.counters + size_t(r) * 8;
+      cnt[CNT_SIM_STEPS] = 1;
+      cnt[CNT_SEQ] = total;
+      for (int q = 2; q < 8; ++q) cnt[q] = 0;
+      s.time[r] = 0;
+    }
   }
-  int32_t* cnt = o.counters + size_t(r) * 8;
-  cnt[CNT_SIM_STEPS] = 1;
-  cnt[CNT_SEQ] = ids;
-  for (int q = 2; q < 8; ++q) cnt[q] = 0;
-  for (int f = 0; f < FS_MAX_INFLOWS; ++f) o.emitted[size_t(r) * FS_MAX_INFLOWS + f] = 0;
-  s.time[r] = 0;
+  // replicas with fewer than FS_MAX_INFLOWS slots: the remaining inflow counters
+  if (N < FS_MAX_INFLOWS)
+    for (size_t e = size_t(blockIdx.x) * blockDim.x + threadIdx.x; e < size_t(s.R) * FS_MAX_INFLOWS;
+         e += size_t(gridDim.x) * blockDim.x) {
+      const int r = int(e / FS_MAX_INFLOWS);
+      if (mask == nullptr || mask[r] != 0) o.emitted[e] = 0;
+    }
 }
 
 }  // namespace fs

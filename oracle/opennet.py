@@ -38,7 +38,8 @@ SUMO-side rules (third-party code, absent; stated here, PARITY UNPINNED -- DESIG
       minGap + max(0, v*tau + v*(v - v_lead) / (2*sqrt(accel*decel))); one vehicle per flow and step
   M4  arrival: a vehicle whose front reaches the end of the last edge is removed in that step
   M5  leader = nearest vehicle ahead on the own route (a vehicle on the other branch upstream of the
-      merge point is not a leader); headway = x_lead - len_lead - x
+      merge point is not a leader); headway = (x_lead - x) - len_lead; vehicles are totally ordered by
+      (x ascending, equal x: higher slot first)
   M6  right of way at the merge (S-J form): the minor route stops at the junction entry while a major
       vehicle is inside the junction or reaches its entry within time_gap; a major vehicle stops at the
       entry while a minor vehicle is inside; both routes inside at once = collision
@@ -170,9 +171,11 @@ class MergeOracle:
         shared = x >= self.merge_x
         cand = ahead & alive[:, None, :] & alive[:, :, None] & (jj[None, None, :] != jj[None, :, None]) & \
             ((route[:, None, :] == route[:, :, None]) | shared[:, None, :])
-        dl = np.where(cand, d, T(BIG))
-        lead = np.argmin(dl, axis=2)                                       # first minimum = lowest slot on a tie
-        has = np.take_along_axis(dl, lead[:, :, None], 2)[:, :, 0] < T(BIG)
+        # the nearest candidate = the smallest x_j; vehicles are ordered by (x ascending, equal x: higher slot
+        # first), so among candidates at one position the highest slot is the nearest
+        xl = np.where(cand, x[:, None, :], T(BIG))
+        lead = (N - 1) - np.argmin(xl[:, :, ::-1], axis=2)
+        has = np.take_along_axis(xl, lead[:, :, None], 2)[:, :, 0] < T(BIG)
         dlead = np.take_along_axis(d, lead[:, :, None], 2)[:, :, 0]
         h = np.where(has, dlead - self.veh_len[lead], T(NO_LEADER_HEADWAY))
         lead = np.where(has, lead, -1)

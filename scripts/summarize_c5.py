@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 CSVs written by scripts/profile_c5.sh into profiles/<tag>_c5_*:
+
+    python scripts/summarize_c5.py gpurun_out/prof_c5_r01 r01
+
+<tag>_c5_kernel_stats.csv (the --kernel-trace --stats table), <tag>_c5_pmc_summary.json (SQ counters of the longest
+k_steps_open launch, per wave and per simulation sub-step) and <tag>_c5_bench.json (the leg's JSON)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(root, "profiles")
+
+
+def newest(pattern):
+    return sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)[-1]
+
+
+shutil.copy(newest("trace/*/*_kernel_stats.csv"), os.path.join(out, "%s_c5_kernel_stats.csv" % tag))
+bench = json.loads(open(os.path.join(src, "bench_trace.json")).read().strip().splitlines()[-1])
+json.dump(bench, open(os.path.join(out, "%s_c5_bench.json" % tag), "w"), indent=1)
+waves = bench["replicas"]                      # 64 slots per replica: one wave each
+substeps = bench["env_steps"] * bench["sims_per_step"]
+counters = {}
+for d in ("pmc_sq", "pmc_sq2"):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(newest(d + "/*/*_counter_collection.csv"))):
+        if "k_steps_open" in r["Kernel_Name"]:
+            agg[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+    for name, by_dispatch in agg.items():
+        total = max(by_dispatch.values())      # the timed 600-step launch
+        counters[name] = {"per_launch": total, "per_wave_per_substep": total / waves / substeps}
+rows = list(csv.DictReader(open(newest("trace/*/*_kernel_stats.csv"))))
+k = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+json.dump({"kernel": k["Name"], "waves": waves, "substeps_per_launch": substeps,
+           "longest_launch_ns_kernel_trace": float(k["MaxNs"]), "counters": counters,
+           "note": "SQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count in units of 4 clock cycles"},
+          open(os.path.join(out, "%s_c5_pmc_summary.json" % tag), "w"), indent=1)
+print(json.dumps(counters, indent=1))
