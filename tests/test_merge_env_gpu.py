@@ -177,3 +177,32 @@ def test_vec_env_runs_the_c5_merge_configuration():
     cnt = vec.sim.get_state(L.FS_FIELD_COUNTERS)
     assert (cnt[:, 0] == 1 + 5 * K).all() and (cnt[:, 6] > 20).all()
     assert torch.isfinite(o).all() and (r >= 0).all()
+
+
+def test_simulate_script_runs_the_merge_experiment_and_writes_the_emission_file(tmp_path):
+    """examples/simulate.py merge (the reference's examples/exp_configs/non_rl/merge.py experiment, 3600 steps of
+    5 sub-steps): runs through install_as_flow() + Experiment.run and leaves a trajectory CSV whose vehicle ids and
+    edges are those SUMO would report."""
+    import csv
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "simulate.py"), "merge", "--gen_emission"],
+                         cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "steps/second" in out.stdout and "Round 0, return" in out.stdout
+    files = os.listdir(os.path.join(str(tmp_path), "data"))
+    assert len(files) == 1 and files[0].endswith("-emission.csv")
+    rows = list(csv.DictReader(open(os.path.join(str(tmp_path), "data", files[0]))))
+    ids = {r["id"] for r in rows}
+    edges = {r["edge_id"] for r in rows}
+    assert {"human_0", "flow_0.0", "flow_1.0"} <= ids and len(ids) > 1500        # ~2100 veh/h for one hour
+    assert {"inflow_highway", "left", "center", "inflow_merge", "bottom"} <= edges
+    last = {}
+    for r in rows:                                   # every vehicle only ever moves forward along its route
+        key = r["id"]
+        x = float(r["x"]) if "x" in r and r["x"] not in ("", None) else None
+        t = float(r["time"])
+        assert key not in last or t >= last[key]
+        last[key] = t
