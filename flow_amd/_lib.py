@@ -11,7 +11,7 @@ from .utils.exceptions import FatalFlowError
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libflowsim.so")
 
-FS_ABI_VERSION = 4
+FS_ABI_VERSION = 5
 FS_MAX_CTRL_PARAMS = 8
 
 # error codes
@@ -26,9 +26,9 @@ FS_F32, FS_F64 = 0, 1
 FS_FAILSAFE_NONE, FS_FAILSAFE_INSTANTANEOUS, FS_FAILSAFE_SAFE_VELOCITY = range(3)
 # enum fs_env
 (FS_ENV_ACCEL, FS_ENV_WAVE_ATTENUATION, FS_ENV_WAVE_ATTENUATION_PO, FS_ENV_LANE_CHANGE_ACCEL, FS_ENV_MERGE_PO,
- FS_ENV_MERGE_MA) = range(6)
+ FS_ENV_MERGE_MA, FS_ENV_BOTTLENECK_DV, FS_ENV_BOTTLENECK) = range(8)
 # enum fs_network / fs_integrator
-FS_NET_RING, FS_NET_FIGURE_EIGHT, FS_NET_MERGE = 0, 1, 2
+FS_NET_RING, FS_NET_FIGURE_EIGHT, FS_NET_MERGE, FS_NET_BOTTLENECK = 0, 1, 2, 3
 FS_MAX_SEGMENTS = 16
 FS_MAX_INFLOWS = 8
 FS_EULER, FS_BALLISTIC = 0, 1
@@ -36,7 +36,7 @@ FS_EULER, FS_BALLISTIC = 0, 1
 (FS_FIELD_POS, FS_FIELD_VEL, FS_FIELD_HEADWAY, FS_FIELD_PREV_VEL, FS_FIELD_ACCEL, FS_FIELD_TIME,
  FS_FIELD_RING_LENGTH, FS_FIELD_INIT_POS, FS_FIELD_INIT_VEL, FS_FIELD_CTRL_STATE, FS_FIELD_LANE,
  FS_FIELD_LAST_LC, FS_FIELD_LEADER, FS_FIELD_INIT_LANE, FS_FIELD_ROUTE, FS_FIELD_SEQ, FS_FIELD_ORIGIN,
- FS_FIELD_FOLLOWER, FS_FIELD_CTL_SEQ, FS_FIELD_COUNTERS, FS_FIELD_ARRIVED_RL) = range(21)
+ FS_FIELD_FOLLOWER, FS_FIELD_CTL_SEQ, FS_FIELD_COUNTERS, FS_FIELD_ARRIVED_RL, FS_FIELD_MAX_SPEED) = range(22)
 
 EXPORTS = ["fs_create", "fs_destroy", "fs_last_error", "fs_abi_version", "fs_obs_dim", "fs_action_dim", "fs_set_stream",
            "fs_use_own_stream", "fs_sync", "fs_reset", "fs_reset_dev", "fs_step", "fs_step_dev", "fs_rollout_dev",
@@ -61,6 +61,11 @@ class fs_inflow(C.Structure):
     _fields_ = [("type", C.c_int32), ("route", C.c_int32), ("number", C.c_int32), ("reserved", C.c_int32),
                 ("period", C.c_double), ("begin", C.c_double), ("end", C.c_double), ("depart_speed", C.c_double),
                 ("depart_pos", C.c_double)]
+
+
+class fs_cell(C.Structure):
+    _fields_ = [("edge_start", C.c_double), ("lo", C.c_double), ("hi", C.c_double), ("lane", C.c_int32),
+                ("last_segment", C.c_int32)]
 
 
 class fs_junction(C.Structure):
@@ -89,7 +94,10 @@ class fs_config(C.Structure):
                 ("inflows", C.POINTER(fs_inflow)), ("init_alive", C.POINTER(C.c_uint8)),
                 ("route_start", C.c_double * 2), ("merge_x", C.c_double), ("box_in", C.c_double),
                 ("end_x", C.c_double), ("net_length", C.c_double), ("ma_apply_actions", C.c_int32),
-                ("reserved3", C.c_int32)]
+                ("num_obs_cells", C.c_int32), ("merge1_x", C.c_double), ("merge2_x", C.c_double),
+                ("zipper_distance", C.c_double), ("speed_limit", C.c_double), ("outflow_norm", C.c_double),
+                ("obs_cells", C.POINTER(fs_cell)), ("act_cells", C.POINTER(fs_cell)),
+                ("obs_outflow_window", C.c_int32), ("reward_outflow_window", C.c_int32)]
 
 
 _lib = None

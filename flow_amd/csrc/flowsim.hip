@@ -43,6 +43,7 @@ struct SimBase {
   std::vector<fs_vehicle_spec> veh;
   std::vector<fs_segment> segs;
   std::vector<fs_inflow> inflows;
+  std::vector<fs_cell> obs_cells, act_cells;
   std::vector<uint8_t> init_alive;
   int obs_dim = 0;
   int act_dim = 0;
@@ -247,7 +248,7 @@ struct Sim : SimBase {
     dv.act_hi = T(cfg.action_high);
     dv.po_max_length = T(cfg.po_max_length);
 
-    open_net = (cfg.network == FS_NET_MERGE);
+    open_net = (cfg.network == FS_NET_MERGE || cfg.network == FS_NET_BOTTLENECK);
     if (open_net && (rc = init_open())) return rc;
 
     // host-API staging
@@ -273,6 +274,8 @@ struct Sim : SimBase {
     if ((rc = dev_alloc(&ov.arrived_rl, RN))) return rc;
     if ((rc = dev_alloc(&ov.foll_h, RN))) return rc;
     if ((rc = dev_alloc(&ov.headway, RN))) return rc;
+    if ((rc = dev_alloc(&ov.vmax, RN))) return rc;
+    if ((rc = dev_alloc(&ov.arr_hist, size_t(R) * 20))) return rc;
     if ((rc = dev_alloc(&ov.counters, size_t(R) * 8))) return rc;
     if ((rc = dev_alloc(&ov.emitted, size_t(R) * FS_MAX_INFLOWS))) return rc;
     if ((rc = upload(&ov.init_alive, init_alive))) return rc;
@@ -327,6 +330,35 @@ struct Sim : SimBase {
     if ((rc = upload(&ov.lane_tab, tab))) return rc;
     if ((rc = upload(&ov.flow_tab_d, ftd))) return rc;
     if ((rc = upload(&ov.flow_tab_i, fti))) return rc;
+    {   // lane drops + bottleneck heads
+      const bool bn = cfg.network == FS_NET_BOTTLENECK;
+      ov.m1 = T(bn ? cfg.merge1_x : cfg.merge_x);
+      ov.m2 = T(bn ? cfg.merge2_x : cfg.merge_x);
+      ov.zip_d = T(bn ? cfg.zipper_distance : 0.0);
+      ov.speed_limit = cfg.speed_limit > 0 ? T(cfg.speed_limit) : T(3.0e38);
+      ov.n_obs_cells = int(obs_cells.size());
+      ov.n_act_cells = int(act_cells.size());
+      ov.obs_window = cfg.obs_outflow_window;
+      ov.rew_window = cfg.reward_outflow_window;
+      ov.out_norm = T(cfg.outflow_norm > 0 ? cfg.outflow_norm : 2000.0);
+      ov.obs_dim = obs_dim;
+      std::vector<T> ct(6 * 64, T(0));
+      std::vector<int32_t> cti(2 * 64, 0);
+      for (size_t c = 0; c < obs_cells.size(); ++c) {
+        ct[fs::CELL_OBS_START * 64 + c] = T(obs_cells[c].edge_start);
+        ct[fs::CELL_OBS_LO * 64 + c] = T(obs_cells[c].lo);
+        ct[fs::CELL_OBS_HI * 64 + c] = T(obs_cells[c].hi);
+        cti[c] = obs_cells[c].lane | (obs_cells[c].last_segment ? 256 : 0);
+      }
+      for (size_t c = 0; c < act_cells.size(); ++c) {
+        ct[fs::CELL_ACT_START * 64 + c] = T(act_cells[c].edge_start);
+        ct[fs::CELL_ACT_LO * 64 + c] = T(act_cells[c].lo);
+        ct[fs::CELL_ACT_HI * 64 + c] = T(act_cells[c].hi);
+        cti[64 + c] = act_cells[c].lane;
+      }
+      if ((rc = upload(&ov.cell_tab, ct))) return rc;
+      if ((rc = upload(&ov.cell_tab_i, cti))) return rc;
+    }
     ov.merge_x = T(cfg.merge_x);
     ov.box_in = T(cfg.box_in);
     ov.end_x = T(cfg.end_x);
@@ -413,8 +445,12 @@ struct Sim : SimBase {
     constexpr int RPW = 64 / SEG;
     const int blocks = (dv.R + RPW - 1) / RPW;
     if (open_net) {
-      hipLaunchKernelGGL((fs::k_steps_open<T, SEG>), dim3(blocks), dim3(64), 0, stream, dv, ov, num_steps, mask,
-                         actions, act_stride, obs, rew, done, obs_every_step, after_reset);
+      if (cfg.network == FS_NET_BOTTLENECK)
+        hipLaunchKernelGGL((fs::k_steps_open<T, SEG, 4>), dim3(blocks), dim3(64), 0, stream, dv, ov, num_steps, mask,
+                           actions, act_stride, obs, rew, done, obs_every_step, after_reset);
+      else
+        hipLaunchKernelGGL((fs::k_steps_open<T, SEG, 2>), dim3(blocks), dim3(64), 0, stream, dv, ov, num_steps, mask,
+                           actions, act_stride, obs, rew, done, obs_every_step, after_reset);
       HIP_TRY(hipGetLastError());
       return FS_OK;
     }
@@ -484,6 +520,7 @@ struct Sim : SimBase {
       case FS_FIELD_PREV_VEL: *count = RN; return dv.prev_vel;
       case FS_FIELD_ACCEL: *count = RN; return dv.accel;
       case FS_FIELD_CTRL_STATE: *count = RN; return dv.ctrl_state;
+      case FS_FIELD_MAX_SPEED: *count = open_net ? RN : 0; return open_net ? ov.vmax : nullptr;
       case FS_FIELD_RING_LENGTH: *count = size_t(dv.R); return const_cast<T*>(dv.ring_len);
       case FS_FIELD_INIT_POS: *count = RN; return const_cast<T*>(dv.init_pos);
       case FS_FIELD_INIT_VEL: *count = RN; return const_cast<T*>(dv.init_vel);
@@ -588,6 +625,8 @@ struct Sim : SimBase {
       return fail(FS_ERR_INVALID, "headway / leader are derived from positions and lanes");
     if (field >= FS_FIELD_SEQ && field <= FS_FIELD_ARRIVED_RL)
       return fail(FS_ERR_INVALID, "fs_set_state: read-only field");
+    if (field == FS_FIELD_MAX_SPEED && !open_net)
+      return fail(FS_ERR_INVALID, "fs_set_state: FS_FIELD_MAX_SPEED exists for open networks only");
     if (field == FS_FIELD_ROUTE) field = FS_FIELD_LANE;
     if (field == FS_FIELD_LANE || field == FS_FIELD_LAST_LC || field == FS_FIELD_INIT_LANE) {
       const size_t RN = size_t(dv.R) * dv.N;
@@ -619,12 +658,32 @@ int validate(const fs_config* c) {
     return fail(FS_ERR_INVALID, "fs_create: struct_size mismatch (header/library out of sync)");
   if (c->abi_version != FS_ABI_VERSION) return fail(FS_ERR_INVALID, "fs_create: abi_version mismatch");
   if (c->precision != FS_F32 && c->precision != FS_F64) return fail(FS_ERR_INVALID, "fs_create: bad precision");
-  if (c->network != FS_NET_RING && c->network != FS_NET_FIGURE_EIGHT && c->network != FS_NET_MERGE)
+  if (c->network < FS_NET_RING || c->network > FS_NET_BOTTLENECK)
     return fail(FS_ERR_UNSUPPORTED, "fs_create: network not built");
-  const bool open_net = c->network == FS_NET_MERGE;
+  const bool open_net = c->network == FS_NET_MERGE || c->network == FS_NET_BOTTLENECK;
   const bool merge_env = c->env == FS_ENV_MERGE_PO || c->env == FS_ENV_MERGE_MA;
-  if (open_net != merge_env)
+  const bool bn_env = c->env == FS_ENV_BOTTLENECK_DV || c->env == FS_ENV_BOTTLENECK;
+  if ((c->network == FS_NET_MERGE) != merge_env)
     return fail(FS_ERR_INVALID, "fs_create: the merge envs and FS_NET_MERGE go together");
+  if ((c->network == FS_NET_BOTTLENECK) != bn_env)
+    return fail(FS_ERR_INVALID, "fs_create: the bottleneck envs and FS_NET_BOTTLENECK go together");
+  if (c->network == FS_NET_BOTTLENECK) {
+    if (c->num_vehicles <= 32)
+      return fail(FS_ERR_UNSUPPORTED, "fs_create: the bottleneck heads need more than 32 vehicle slots per replica");
+    if (!(c->merge1_x <= c->merge2_x) || !(c->merge2_x < c->end_x) || !(c->zipper_distance >= 0))
+      return fail(FS_ERR_INVALID, "fs_create: need merge1_x <= merge2_x < end_x and zipper_distance >= 0");
+    if (c->junction.enabled) return fail(FS_ERR_INVALID, "fs_create: the priority-junction model is for FS_NET_MERGE");
+    if (c->obs_outflow_window < 1 || c->obs_outflow_window > 20 || c->reward_outflow_window < 1 ||
+        c->reward_outflow_window > 20)
+      return fail(FS_ERR_INVALID, "fs_create: outflow windows must be 1..20 sub-steps");
+    if (c->evaluate) return fail(FS_ERR_UNSUPPORTED, "fs_create: evaluate mode of the bottleneck envs is not built");
+    if (c->env == FS_ENV_BOTTLENECK_DV) {
+      if (c->num_obs_cells < 1 || c->num_obs_cells > 64 || !c->obs_cells)
+        return fail(FS_ERR_INVALID, "fs_create: 1..64 observation cells");
+      if (c->num_rl < 0 || c->num_rl > 64 || (c->num_rl > 0 && !c->act_cells))
+        return fail(FS_ERR_INVALID, "fs_create: 0..64 action cells");
+    }
+  }
   if (open_net) {
     if (c->num_lanes > 1) return fail(FS_ERR_UNSUPPORTED, "fs_create: multi-lane merge is not built");
     if (c->num_segments < 2 || c->num_segments > 2 * FS_MAX_SEGMENTS || !c->segments)
@@ -632,19 +691,22 @@ int validate(const fs_config* c) {
     int per_route[2] = {0, 0};
     for (int k = 0; k < c->num_segments; ++k) {
       const fs_segment& sg = c->segments[k];
-      if (sg.route < 0 || sg.route > 1) return fail(FS_ERR_INVALID, "fs_create: segment route must be 0 or 1");
+      if (sg.route < 0 || sg.route > (c->network == FS_NET_MERGE ? 1 : 0))
+        return fail(FS_ERR_INVALID, "fs_create: segment route out of range");
       if (k > 0 && sg.route < c->segments[k - 1].route)
         return fail(FS_ERR_INVALID, "fs_create: segment rows must be grouped by route");
       if (k > 0 && sg.route == c->segments[k - 1].route && !(sg.start > c->segments[k - 1].start))
         return fail(FS_ERR_INVALID, "fs_create: segment starts must increase");
       if (++per_route[sg.route] > FS_MAX_SEGMENTS) return fail(FS_ERR_INVALID, "fs_create: too many segments");
     }
-    if (!per_route[0] || !per_route[1]) return fail(FS_ERR_INVALID, "fs_create: a route has no segment");
+    if (!per_route[0] || (c->network == FS_NET_MERGE && !per_route[1]))
+      return fail(FS_ERR_INVALID, "fs_create: a route has no segment");
     if (c->num_inflows < 0 || c->num_inflows > FS_MAX_INFLOWS || (c->num_inflows > 0 && !c->inflows))
       return fail(FS_ERR_INVALID, "fs_create: bad inflow table");
     for (int f = 0; f < c->num_inflows; ++f) {
       const fs_inflow& fl = c->inflows[f];
-      if (fl.route < 0 || fl.route > 1) return fail(FS_ERR_INVALID, "fs_create: inflow route must be 0 or 1");
+      if (c->network == FS_NET_MERGE ? (fl.route < 0 || fl.route > 1) : (fl.route < -1 || fl.route > 3))
+        return fail(FS_ERR_INVALID, "fs_create: inflow route out of range");
       if (!(fl.period > 0)) return fail(FS_ERR_INVALID, "fs_create: inflow period <= 0");
       if (!(fl.depart_speed >= 0) || !(fl.depart_pos >= 0)) return fail(FS_ERR_INVALID, "fs_create: bad inflow departure");
       bool type_ok = false;
@@ -666,7 +728,7 @@ int validate(const fs_config* c) {
       if (!(c->segments[k].start > c->segments[k - 1].start))
         return fail(FS_ERR_INVALID, "fs_create: segment starts must increase");
   }
-  if (c->env < FS_ENV_ACCEL || c->env > FS_ENV_MERGE_MA) return fail(FS_ERR_INVALID, "fs_create: bad env");
+  if (c->env < FS_ENV_ACCEL || c->env > FS_ENV_BOTTLENECK) return fail(FS_ERR_INVALID, "fs_create: bad env");
   if (c->num_lanes > 1 && c->env == FS_ENV_WAVE_ATTENUATION_PO)
     return fail(FS_ERR_UNSUPPORTED, "fs_create: WaveAttenuationPOEnv on a multi-lane ring is not built");
   if (c->num_lanes > 64) return fail(FS_ERR_INVALID, "fs_create: num_lanes > 64");
@@ -678,7 +740,8 @@ int validate(const fs_config* c) {
   if (c->num_vehicles < 1) return fail(FS_ERR_INVALID, "fs_create: num_vehicles < 1");
   if (c->num_vehicles > 64)
     return fail(FS_ERR_UNSUPPORTED, "fs_create: more than 64 vehicles per replica is not built yet");
-  if (c->num_rl < 0 || c->num_rl > c->num_vehicles) return fail(FS_ERR_INVALID, "fs_create: bad num_rl");
+  if (c->num_rl < 0 || (c->num_rl > c->num_vehicles && c->env != FS_ENV_BOTTLENECK_DV))
+    return fail(FS_ERR_INVALID, "fs_create: bad num_rl");
   if (c->sims_per_step < 1) return fail(FS_ERR_INVALID, "fs_create: sims_per_step < 1");
   if (c->warmup_steps < 0) return fail(FS_ERR_INVALID, "fs_create: warmup_steps < 0");
   if (!(c->sim_step > 0)) return fail(FS_ERR_INVALID, "fs_create: sim_step <= 0");
@@ -696,7 +759,7 @@ int validate(const fs_config* c) {
       return fail(FS_ERR_INVALID, "fs_create: unknown fail_safe id");
     if (open_net && v.controller == FS_CTRL_PISATURATION)
       return fail(FS_ERR_UNSUPPORTED, "fs_create: PISaturation on an open network is not built");
-    if (v.controller == FS_CTRL_RL && c->env == FS_ENV_MERGE_PO) {
+    if (v.controller == FS_CTRL_RL && (c->env == FS_ENV_MERGE_PO || bn_env)) {
       ++seen_rl;                        // the action column is the place in rl_veh, not rl_index
     } else if (v.controller == FS_CTRL_RL) {
       if (v.rl_index < 0 || v.rl_index >= c->num_rl) return fail(FS_ERR_INVALID, "fs_create: rl_index out of range");
@@ -706,16 +769,18 @@ int validate(const fs_config* c) {
     }
     if (!(v.length > 0)) return fail(FS_ERR_INVALID, "fs_create: vehicle length <= 0");
   }
-  if (seen_rl != c->num_rl && c->env != FS_ENV_MERGE_PO)
+  if (seen_rl != c->num_rl && c->env != FS_ENV_MERGE_PO && !bn_env)
     return fail(FS_ERR_INVALID, "fs_create: num_rl does not match the RL slots");
   if (open_net) {
     // placement sanity of the initial vehicles: inside their route, alive flags consistent
     for (size_t e = 0; e < size_t(c->num_replicas) * c->num_vehicles; ++e) {
       if (!c->init_alive[e]) continue;
       const int rt = c->init_lane[e];
-      if (rt < 0 || rt > 1) return fail(FS_ERR_INVALID, "fs_create: initial route must be 0 or 1");
+      if (rt < 0 || rt > (c->network == FS_NET_MERGE ? 1 : 3))
+        return fail(FS_ERR_INVALID, "fs_create: initial route out of range");
       const double x = c->init_pos[e];
-      if (!(x >= c->route_start[rt]) || !(x < c->end_x)) return fail(FS_ERR_INVALID, "fs_create: init_pos outside the route");
+      if (!(x >= c->route_start[c->network == FS_NET_MERGE ? rt : 0]) || !(x < c->end_x))
+        return fail(FS_ERR_INVALID, "fs_create: init_pos outside the route");
     }
     return FS_OK;
   }
@@ -743,11 +808,17 @@ int create_typed(const fs_config* cfg, fs_handle* out) {
   s->cfg = *cfg;
   s->veh.assign(cfg->vehicles, cfg->vehicles + cfg->num_vehicles);
   if (cfg->num_segments > 0) s->segs.assign(cfg->segments, cfg->segments + cfg->num_segments);
-  if (cfg->network == FS_NET_MERGE) {
+  if (cfg->network == FS_NET_MERGE || cfg->network == FS_NET_BOTTLENECK) {
     if (cfg->num_inflows > 0) s->inflows.assign(cfg->inflows, cfg->inflows + cfg->num_inflows);
     s->init_alive.assign(cfg->init_alive, cfg->init_alive + size_t(cfg->num_replicas) * cfg->num_vehicles);
+    if (cfg->env == FS_ENV_BOTTLENECK_DV) {
+      s->obs_cells.assign(cfg->obs_cells, cfg->obs_cells + cfg->num_obs_cells);
+      if (cfg->num_rl > 0) s->act_cells.assign(cfg->act_cells, cfg->act_cells + cfg->num_rl);
+    }
   }
   s->obs_dim = (cfg->env == FS_ENV_WAVE_ATTENUATION_PO) ? 3
+               : (cfg->env == FS_ENV_BOTTLENECK_DV) ? 4 * cfg->num_obs_cells + 1
+               : (cfg->env == FS_ENV_BOTTLENECK) ? 1
                : (cfg->env == FS_ENV_MERGE_PO || cfg->env == FS_ENV_MERGE_MA)
                      ? 5 * cfg->num_rl
                      : (cfg->env == FS_ENV_LANE_CHANGE_ACCEL ? 3 : 2) * cfg->num_vehicles;
@@ -794,6 +865,8 @@ int create_typed(const fs_config* cfg, fs_handle* out) {
   s->cfg.segments = nullptr;
   s->cfg.inflows = nullptr;
   s->cfg.init_alive = nullptr;
+  s->cfg.obs_cells = nullptr;
+  s->cfg.act_cells = nullptr;
   *out = reinterpret_cast<fs_handle>(static_cast<SimBase*>(s));
   return FS_OK;
 }
@@ -858,7 +931,7 @@ int fs_reset_dev(fs_handle h, const uint8_t* mask_dev, float* obs_dev) {
   int rc = s->launch_reset(mask_dev);
   if (rc) return rc;
   float* obs = obs_dev ? obs_dev : s->d_obs;
-  if (s->cfg.network == FS_NET_MERGE) {   // update(reset=True) of the fresh placement, before any warm-up step
+  if (s->cfg.network == FS_NET_MERGE || s->cfg.network == FS_NET_BOTTLENECK) {   // update(reset=True) first
     s->after_reset = 1;
     rc = s->launch_steps(0, mask_dev, nullptr, 0, obs, s->d_rew, s->d_done, 0);
     s->after_reset = 0;

@@ -29,6 +29,8 @@ struct OpenView {
   int32_t* arrived_rl;   // [R,N]
   T* foll_h;             // [R,N] "follower_headway"
   T* headway;            // [R,N] get_headway
+  T* vmax;               // [R,N] per-vehicle maxSpeed of the SUMO car-following model (M10, setMaxSpeed)
+  int32_t* arr_hist;     // [R,20] arrivals of the last 20 sub-steps (ring buffer indexed by sub-step % 20)
   int32_t* counters;     // [R,8]
   int32_t* emitted;      // [R,FS_MAX_INFLOWS]
   const uint8_t* init_alive;   // [R,N]
@@ -44,6 +46,13 @@ struct OpenView {
   unsigned seg_internal[2];
   T max_cost_full;             // norm([target] * 64): the one entry that does not fit the 64-lane row
   T merge_x, box_in, end_x, net_length;
+  // lane drops (M8-M10): lanes 2q, 2q+1 join at m1, the resulting lanes at m2 (two paths: m1 == m2 == merge_x)
+  T m1, m2, zip_d, speed_limit;
+  // bottleneck heads (O6 / O7)
+  const T* cell_tab;           // [6][64] lane c: edge start / lo / hi of observation cell c, of action cell c
+  const int32_t* cell_tab_i;   // [2][64] lane c: lane | is_last_segment << 8 of observation cell c, lane of action cell c
+  int n_obs_cells, n_act_cells, obs_window, rew_window, obs_dim;
+  T out_norm;                  // 2000 * scaling
 };
 
 enum {
@@ -58,6 +67,7 @@ enum {
   TAB_MAX_COST = 8,     // lane n: norm([target] * n), n < 64
   TAB_ROWS = 9
 };
+enum { CELL_OBS_START = 0, CELL_OBS_LO = 1, CELL_OBS_HI = 2, CELL_ACT_START = 3, CELL_ACT_LO = 4, CELL_ACT_HI = 5 };
 
 enum { CNT_SIM_STEPS = 0, CNT_SEQ = 1, CNT_CTL = 2, CNT_ARRIVED = 3, CNT_DEPARTED = 4, CNT_TOTAL_ARRIVED = 5,
        CNT_TOTAL_DEPARTED = 6 };
@@ -142,13 +152,13 @@ __device__ __forceinline__ T seg_read(T v, int j, int seg) {
 
 // (internal?, Flow table coordinate) of coordinate x on route r (O5).  tab_* are the lane-indexed segment rows; both
 // routes are walked with wave-uniform loops and the lane keeps the result of its own route.
-template <typename T>
+template <int NR, typename T>
 __device__ __forceinline__ void route_lookup(const OpenView<T>& o, T tab_start, T tab_flow, T tab_slope, T x, int route,
                                              bool& internal, T& flow_x) {
   internal = false;
   flow_x = T(0);
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
+  for (int r = 0; r < NR; ++r) {
     int k = 0;
     T st = read_lane(tab_start, r * 16), fs0 = read_lane(tab_flow, r * 16), sl = read_lane(tab_slope, r * 16);
     for (int q = 1; q < o.nseg[r]; ++q) {
@@ -159,14 +169,16 @@ __device__ __forceinline__ void route_lookup(const OpenView<T>& o, T tab_start, 
       fs0 = hit ? read_lane(tab_flow, r * 16 + q) : fs0;
       sl = hit ? read_lane(tab_slope, r * 16 + q) : sl;
     }
-    if (route == r) {
+    if (NR == 1 || route == r) {
       internal = (o.seg_internal[r] >> k) & 1u;
       flow_x = fs0 + sl * (x - st);
     }
   }
 }
 
-template <typename T, int SEG>
+// P = number of paths (entry lanes): 2 = MergeNetwork (each path has its own segment table), 4 = BottleneckNetwork
+// (one table; lanes 2q / 2q+1 join at m1, the two resulting lanes at m2)
+template <typename T, int SEG, int P>
 __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, int num_steps,
                                                    const uint8_t* __restrict__ mask,
                                                    const float* __restrict__ actions, size_t act_stride,
@@ -174,6 +186,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
                                                    uint8_t* __restrict__ done, int obs_every_step,
                                                    int after_reset) {
   constexpr int RPW = 64 / SEG;
+  constexpr int NR = (P == 2) ? 2 : 1;            // segment tables
   const T BIGV = T(3.0e38);
   const int lane_id = threadIdx.x;
   const int seg = lane_id / SEG;
@@ -190,6 +203,8 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
   const int flags = s.flags;
   const int env = s.env;
   const bool po_env = (env == FS_ENV_MERGE_PO);
+  const bool bn_env = (SEG == 64) && (env == FS_ENV_BOTTLENECK_DV || env == FS_ENV_BOTTLENECK);
+  const bool dv_env = (SEG == 64) && (env == FS_ENV_BOTTLENECK_DV);
 
   Slot<T> sl;
   sl.ctrl = s.ctrl[ii];
@@ -218,6 +233,18 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
                ft_end = o.flow_tab_d[128 + lane_id];
   const int ft_type = o.flow_tab_i[lane_id], ft_route = o.flow_tab_i[64 + lane_id],
             ft_number = o.flow_tab_i[128 + lane_id];
+  T co_start = T(0), co_lo = T(0), co_hi = T(0), ca_start = T(0), ca_lo = T(0), ca_hi = T(0);
+  int co_lane = 0, ca_lane = 0;
+  if (bn_env) {
+    co_start = o.cell_tab[CELL_OBS_START * 64 + lane_id];
+    co_lo = o.cell_tab[CELL_OBS_LO * 64 + lane_id];
+    co_hi = o.cell_tab[CELL_OBS_HI * 64 + lane_id];
+    ca_start = o.cell_tab[CELL_ACT_START * 64 + lane_id];
+    ca_lo = o.cell_tab[CELL_ACT_LO * 64 + lane_id];
+    ca_hi = o.cell_tab[CELL_ACT_HI * 64 + lane_id];
+    co_lane = o.cell_tab_i[lane_id];
+    ca_lane = o.cell_tab_i[64 + lane_id];
+  }
 
   const bool live_replica = rvalid && (mask == nullptr || mask[rr] != 0);
   int tcount = s.time[rr];
@@ -240,11 +267,14 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
   int arrived_rl = o.arrived_rl[idx];
   T prev_v = s.prev_vel[idx], last_acc = s.accel[idx];
   T cst = s.ctrl_state[idx];
+  T vmax = o.vmax[idx];
+  int hist_l = (bn_env && i < 20) ? o.arr_hist[size_t(rr) * 20 + i] : 0;     // arrivals of sub-step % 20 == lane
   bool just_arrived = false;
+  auto shift_of = [&](T xx) -> int { return (xx >= o.m1 ? 1 : 0) + (xx >= o.m2 ? 1 : 0); };
 
   const T dt = s.dt;
   const int num_rl = s.num_rl;
-  const int obs_dim = 5 * num_rl;
+  const int obs_dim = o.obs_dim;
   const size_t step_rows = obs_every_step ? size_t(s.R) : 0;
   float* orow = obs + size_t(rr) * obs_dim;
   float* rrow = rew + rr;
@@ -271,7 +301,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
   // followers(X) = for each route, the highest set bit of B_r below rank_X, if that vehicle's leader is X
   int lead = -1;
   T vl = T(-1001), h = T(1000);
-  bool has = false;
+  bool has = false, lead_same_lane = false;
   auto or64 = [&](unsigned long long m) -> unsigned long long {
     const unsigned lo = seg_or<SEG>(unsigned(m));
     const unsigned hi = SEG == 64 ? seg_or<SEG>(unsigned(m >> 32)) : 0u;
@@ -291,11 +321,25 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
     if (!alive) rank = __popcll(am) + __popcll(~am & segmask & ((1ull << i) - 1ull));
     const int sorted_slot = __builtin_amdgcn_ds_permute((segbase + rank) << 2, i);
     const unsigned long long bit = 1ull << rank;
-    const unsigned long long B0 = or64(alive && route == 0 ? bit : 0ull);
-    const unsigned long long B1 = or64(alive && route == 1 ? bit : 0ull);
-    const unsigned long long SH = or64(alive && x >= o.merge_x ? bit : 0ull);
+    unsigned long long B[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) B[q] = or64(alive && route == q ? bit : 0ull);
+    const unsigned long long R1 = or64(alive && x >= o.m1 ? bit : 0ull);
+    const unsigned long long R2 = (P == 2) ? R1 : or64(alive && x >= o.m2 ? bit : 0ull);
+    unsigned long long ALL = 0ull, own = 0ull;
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+      ALL |= B[q];
+      own = (route == q) ? B[q] : own;
+    }
+    const unsigned long long pair = (P == 2) ? ALL : (route < 2 ? (B[0] | B[1 % P]) : (B[2 % P] | B[3 % P]));
+    // M5 / M8: a vehicle of region g (number of joins upstream of IT) is on my lane if our paths agree after
+    // max(g, la) joins, la = joins upstream of the point zipper_distance ahead of me
+    const int la = shift_of(x + o.zip_d);
+    const unsigned long long cl0 = la == 0 ? own : (la == 1 ? pair : ALL);
+    const unsigned long long cl1 = la <= 1 ? pair : ALL;
     const unsigned long long above = rank >= 63 ? 0ull : (~0ull << (rank + 1));
-    const unsigned long long m = alive ? (((route == 0 ? B0 : B1) | SH) & above) : 0ull;
+    const unsigned long long m = alive ? (((~R1 & cl0) | (R1 & ~R2 & cl1) | (R2 & ALL)) & above) : 0ull;
     has = m != 0ull;
     const int lead_pos = has ? __ffsll((long long)m) - 1 : 0;
     const int lslot = __shfl(sorted_slot, segbase + lead_pos, 64);
@@ -306,6 +350,13 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
     const T len_lead = bperm(sl.length, lsrc);
     vl = has ? v_l : T(-1001);                          // get_speed(None): the accessor's error value
     h = has ? (x_l - x) - len_lead : T(1000);           // vehicle/traci.py:237
+    if (P > 2) {                                        // M8: does the leader share my PHYSICAL lane (collision check)
+      const int p_l = __shfl(route, lsrc, 64);
+      const int sh_l = shift_of(x_l);
+      lead_same_lane = has && ((route >> sh_l) == (p_l >> sh_l));
+    } else {
+      lead_same_lane = has;
+    }
     if (!follow) return;
     // ---- O1: the sticky follower entry of THIS vehicle (vehicle/traci.py:232-250) ----------------------
     const bool no_lead = alive && !has;
@@ -315,8 +366,8 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
     T bestf = BIGV;
     int bseq = 0x7fffffff, bj = -1;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const unsigned long long mb = (r == 0 ? B0 : B1) & below;
+    for (int r = 0; r < P; ++r) {
+      const unsigned long long mb = B[r] & below;
       const bool has_c = alive && mb != 0ull;
       const int q = has_c ? 63 - __clzll((long long)mb) : 0;
       const int cslot = __shfl(sorted_slot, segbase + q, 64);
@@ -350,7 +401,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
     const bool alive = route >= 0;
     bool internal;
     T fx;
-    route_lookup(o, tab_start, tab_flow, tab_slope, x, route, internal, fx);
+    route_lookup<NR>(o, tab_start, tab_flow, tab_slope, x, route, internal, fx);
     const int ld = alive ? lead : -1;
     const int fo = alive ? foll : -1;
     const int lsrc = segbase + (ld >= 0 ? ld : ii), fsrc = segbase + (fo >= 0 ? fo : ii);
@@ -366,7 +417,61 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
     f5[3] = (this_speed - follow_speed) / s.max_speed;
     f5[4] = follow_head / o.net_length;
   };
+  // get_outflow_rate over the last `window` sub-steps (vehicle/traci.py:500-505); the history is one count per lane
+  auto outflow = [&](int window) -> T {
+    const int n = tcount < window ? tcount : window;
+    const int ago = (((tcount - 1 - i) % 20) + 20) % 20;
+    const T mine = (i < 20 && ago < n) ? T(hist_l) : T(0);
+    const T total = seg_sum<SEG>(mine);                   // small integers: exact in any order
+    const T rate = (T(3600) * total) / (T(n > 0 ? n : 1) * dt);
+    return n > 0 ? rate : T(0);
+  };
   auto write_obs = [&](int rank) {
+    if (bn_env) {
+      if (env == FS_ENV_BOTTLENECK) {                    // bottleneck.py:481-483
+        if (valid && ii == 0) orow[0] = 1.0f;
+        return;
+      }
+      // ---- O6 get_state (bottleneck.py:868-924): which observation cell am I in ...
+      const bool alive = route >= 0;
+      bool internal;
+      T fx;
+      route_lookup<NR>(o, tab_start, tab_flow, tab_slope, x, route, internal, fx);
+      const int my_lane = (route < 0 ? 0 : route) >> shift_of(x);
+      int ocell = -1;
+      for (int c = 0; c < o.n_obs_cells; ++c) {
+        const T pos = x - read_lane(co_start, c);
+        const int cl = read_lane_i(co_lane, c);
+        bool inside = (pos > read_lane(co_lo, c)) && (pos <= read_lane(co_hi, c));
+        if (cl >> 8) inside = inside || (pos == T(0));   // np.searchsorted(..) - 1 == -1: the edge's last segment
+        if (alive && !internal && inside && my_lane == (cl & 0xff) && ocell < 0) ocell = c;
+      }
+      // ... then lane c gathers cell c, vehicles in slot order
+      int cnt_h = 0, cnt_r = 0;
+      T sp_h = T(0), sp_r = T(0);
+      for (unsigned long long u = occupied_slots(); u; u &= u - 1ull) {
+        const int j = __ffsll((long long)u) - 1;
+        const int cj = read_lane_i(ocell, j);
+        const T vj = read_lane(v, j);
+        const bool rj = read_lane_i(is_rl ? 1 : 0, j) != 0;
+        const bool mine = cj == lane_id;
+        if (mine && rj) { cnt_r += 1; sp_r = sp_r + vj; }
+        if (mine && !rj) { cnt_h += 1; sp_h = sp_h + vj; }
+      }
+      const int C = o.n_obs_cells;
+      const T nh = T(cnt_h) / T(20), nr = T(cnt_r) / T(20);          // NUM_VEHICLE_NORM
+      const T mean_h = (cnt_h > 0 ? sp_h / (nh * T(20)) : T(0)) / T(50);
+      const T mean_r = (cnt_r > 0 ? sp_r / (nr * T(20)) : T(0)) / T(50);
+      const T of = outflow(o.obs_window) / T(2000.0);
+      if (rvalid && lane_id < C) {
+        orow[lane_id] = float(nh);
+        orow[C + lane_id] = float(nr);
+        orow[2 * C + lane_id] = float(mean_h);
+        orow[3 * C + lane_id] = float(mean_r);
+      }
+      if (rvalid && lane_id == 0) orow[4 * C] = float(of);
+      return;
+    }
     T f5[5];
     five(f5);
     if (po_env) {
@@ -427,7 +532,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       }
       bool internal;
       T fx_unused;
-      route_lookup(o, tab_start, tab_flow, tab_slope, x, route, internal, fx_unused);
+      route_lookup<NR>(o, tab_start, tab_flow, tab_slope, x, route, internal, fx_unused);
       const bool on_edge = s.junction_mode ? !internal : true;
       // RL command (envs/base.py:355 runs before additional_command: the rl_veh list of the last sub-step)
       bool have_rl = false;
@@ -444,6 +549,21 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       bool commanded = false;
       T acc = control_accel_on(s, sl, flags, v, vl, h, has, vf, hf, mean_v, on_edge, have_rl, a_rl, live && slot_ok,
                                rr, ii, nctr, cst, commanded);
+      // ---- O6: BottleneckDesiredVelocityEnv._apply_rl_actions (bottleneck.py:926-969) -------------------
+      if (dv_env && act != nullptr) {
+        const int my_lane = (route < 0 ? 0 : route) >> shift_of(x);
+        int acell = -1;
+        for (int c = 0; c < o.n_act_cells; ++c) {
+          const T pos = x - read_lane(ca_start, c);
+          const bool inside = (pos > read_lane(ca_lo, c)) && (pos <= read_lane(ca_hi, c));
+          if (alive && !internal && inside && my_lane == read_lane_i(ca_lane, c) && acell < 0) acell = c;
+        }
+        T a = acell >= 0 ? T(act[acell]) : T(0);
+        if (s.clip_actions) a = tmin(tmax(a, s.act_lo), s.act_hi);
+        T nxt = tmin(tmax(vmax + a, T(0.01)), T(23.0));
+        nxt = acell >= 0 ? nxt : T(23.0);
+        if (live && alive && is_rl) vmax = nxt;
+      }
       // ---- MergePOEnv.additional_command (merge.py:189-221) --------------------------------------------
       if (po_env) {
         const bool alive_rl = alive && is_rl;
@@ -468,7 +588,9 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       // ---- M7: apply_acceleration + SUMO integration ---------------------------------------------------
       T next_vel = tmax(v + acc * dt, T(0));
       T vc = v + (next_vel - v) * s.ramp;
-      T v_sumo = sumo_idm_speed(v, vl, h, has, dt, sl);
+      Slot<T> sm = sl;
+      sm.sumo_max_speed = tmin(vmax, o.speed_limit);     // M10
+      T v_sumo = sumo_idm_speed(v, vl, h, has, dt, sm);
       if (sl.speed_mode & 1) vc = tmin(vc, v_sumo);
       if (sl.speed_mode & 2) vc = tmin(vc, v + sl.max_accel * dt);
       if (sl.speed_mode & 4) vc = tmax(vc, v - sl.max_decel * dt);
@@ -479,7 +601,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         const bool minor_in_box = seg_any<SEG>(in_reach && route == 1 && (x >= o.box_in), seg);
         const bool approaching = alive && (x >= o.box_in - s.j_lookahead) && (x < o.box_in);
         const bool yields = approaching && ((route == 1 && major_busy) || (route == 0 && minor_in_box));
-        const T stop = sumo_idm_speed(v, T(0), o.box_in - x, true, dt, sl);
+        const T stop = sumo_idm_speed(v, T(0), o.box_in - x, true, dt, sm);
         const T cap = yields ? stop : BIGV;
         if ((sl.speed_mode & 1) || !commanded) v_new = tmin(v_new, cap);
       }
@@ -505,6 +627,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         const int na = __popcll(seg_ballot<SEG>(arrived, seg));
         if (live) { n_arr = na; n_dep = 0; }
         tot_arr += na;
+        if (bn_env && live && i == (tcount - 1) % 20) hist_l = na;
       }
       // ---- M2 / M3: insertions in InFlows order -------------------------------------------------------
       // (a rolled loop over the inflows; every per-flow constant comes out of a lane table, so the loop keeps no
@@ -516,14 +639,21 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         const int number = read_lane_i(ft_number, f);
         const bool due = (due_t <= now) && (due_t <= read_lane(ft_end, f)) && (number < 0 || k < number);
         if (__ballot(due && live) == 0ull) continue;     // wave-uniform: this inflow is due in no replica of the wave
-        const int typ = read_lane_i(ft_type, f), route_f = read_lane_i(ft_route, f);
+        const int typ = read_lane_i(ft_type, f);
+        int route_f = read_lane_i(ft_route, f);
+        if (route_f < 0) {                               // M9: departLane = "random"
+          uint32_t c0 = uint32_t(k), c1 = uint32_t(1000 + f), c2 = uint32_t(rr), c3 = 1u;
+          philox4x32_10(c0, c1, c2, c3, s.seed_lo, s.seed_hi);
+          route_f = int((uint64_t(c0 >> 8) * uint64_t(P)) >> 24);
+        }
         const bool alive_now = route >= 0;
         const bool free_slot = !alive_now && slot_ok && (my_type == typ) && !just_arrived;
         const unsigned long long fb = seg_ballot<SEG>(free_slot, seg);
         const int slot = fb ? __ffsll((long long)fb) - 1 : 0;
         const T x_dep = read_lane(tab_xdep, f);
         const T v_dep = read_lane(tab_vdep, f);
-        const bool cand = alive_now && (route == route_f || x >= o.merge_x);
+        const int sj = tmax(shift_of(x), shift_of(x_dep + o.zip_d));
+        const bool cand = alive_now && ((route >> sj) == (route_f >> sj));
         const T xm = seg_min<SEG>(cand ? x : BIGV);
         const unsigned long long cb = seg_ballot<SEG>(cand && x == xm, seg);
         const bool has_lead = cb != 0ull;
@@ -542,6 +672,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
           cst = T(0);
           last_acc = T(0);
           route = route_f;
+          vmax = sl.sumo_max_speed;
           seq = seq_ctr;
           origin = f * (1 << 20) + k;
           foll = -1;
@@ -557,7 +688,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       }
       // ---- O1: new neighbour snapshot, sticky followers, collision check --------------------------------
       neighbours(live, true);
-      bool c = seg_any<SEG>((route >= 0) && has && (h < s.crash_gap), seg);
+      bool c = seg_any<SEG>((route >= 0) && has && lead_same_lane && (h < s.crash_gap), seg);
       if (s.junction_on) {
         const bool inside = (route >= 0) && (x >= o.box_in) && (x < o.merge_x);
         c = c || (seg_any<SEG>(inside && route == 0, seg) && seg_any<SEG>(inside && route == 1, seg));
@@ -574,7 +705,9 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       const bool alive = route >= 0;
       const int n_alive = __popcll(seg_ballot<SEG>(alive, seg));
       T reward;
-      if (s.evaluate) {                                  // merge.py:161-162
+      if (bn_env) {                                      // bottleneck.py:474-478, 971-981
+        reward = outflow(o.rew_window) / o.out_norm;
+      } else if (s.evaluate) {                           // merge.py:161-162
         const T sum_v = seg_sum<SEG>(alive ? v : T(0));
         reward = n_alive > 0 ? sum_v / T(n_alive) : T(0);
       } else {
@@ -627,6 +760,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
     o.foll_h[idx] = foll_h;
     o.ctl_seq[idx] = ctl_seq;
     o.arrived_rl[idx] = arrived_rl;
+    o.vmax[idx] = vmax;
     o.lead[idx] = lead;
     o.headway[idx] = h;
     if (ii == 0) {
@@ -642,6 +776,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
     }
   }
   if (rvalid && live_replica && i < FS_MAX_INFLOWS) o.emitted[size_t(rr) * FS_MAX_INFLOWS + i] = emit_l;
+  if (bn_env && rvalid && live_replica && i < 20) o.arr_hist[size_t(rr) * 20 + i] = hist_l;
 }
 
 // Env.reset of an open network: the initial vehicles back in their slots, every other slot free, clocks and
@@ -670,6 +805,7 @@ __global__ void k_reset_open(DevView<T> s, OpenView<T> o, const uint8_t* __restr
     o.foll_h[e] = T(3.0e38);
     o.ctl_seq[e] = -1;
     o.arrived_rl[e] = 0;
+    o.vmax[e] = s.sumo_max_speed[i];
     o.lead[e] = -1;
     o.headway[e] = T(1000);
     if (i < FS_MAX_INFLOWS) o.emitted[size_t(r) * FS_MAX_INFLOWS + i] = 0;
@@ -680,6 +816,7 @@ __global__ void k_reset_open(DevView<T> s, OpenView<T> o, const uint8_t* __restr
       cnt[CNT_SIM_STEPS] = 1;
       cnt[CNT_SEQ] = total;
       for (int q = 2; q < 8; ++q) cnt[q] = 0;
+      for (int q = 0; q < 20; ++q) o.arr_hist[size_t(r) * 20 + q] = 0;
       s.time[r] = 0;
     }
   }

@@ -171,7 +171,9 @@ def build_open_spec(env, num_replicas, rng=None):
         for veh_id, (edge, p) in zip(ids, pos):
             i = init_slot[veh_id]
             r, x0 = net_k.open_coordinate(edge, 0.0)
-            rel = np.clip(p + rng.normal(0, pert, R), 0, net_k.edge_length(edge))
+            # base.py:386-389 clamps to [0, edge length]; a vehicle exactly at the end of the last edge would already
+            # have arrived, so the upper clamp stays 1 cm inside the edge
+            rel = np.clip(p + rng.normal(0, pert, R), 0, net_k.edge_length(edge) - 0.01)
             X[:, i] = x0 + rel
     first_edges = [p[0] for p in network.specify_open_routes()]
     inflows = []

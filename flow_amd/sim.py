@@ -71,7 +71,8 @@ class FlowSim:
                 setattr(v, k, float(d[k]))
 
         dt = float(spec["sim_step"])
-        self.open_net = spec.get("network") == "merge"
+        self.open_net = spec.get("network") in ("merge", "bottleneck")
+        self.bottleneck = spec.get("network") == "bottleneck"
         ring_length = None
         if not self.open_net:
             ring_length = np.ascontiguousarray(
@@ -122,11 +123,21 @@ class FlowSim:
                 init_vel = np.zeros((self.R, self.N))
             if init_lane is None:
                 init_lane = np.ascontiguousarray(np.asarray(spec["init_route"], dtype=np.int32).reshape(self.R, self.N))
+        def cells(rows):
+            if not rows:
+                return None
+            arr = (L.fs_cell * len(rows))()
+            for k, (start, lo, hi, lane, last) in enumerate(rows):
+                arr[k].edge_start, arr[k].lo, arr[k].hi = float(start), float(lo), float(hi)
+                arr[k].lane, arr[k].last_segment = int(lane), int(bool(last))
+            return arr
+        obs_cells, act_cells = cells(spec.get("obs_cells")), cells(spec.get("action_cells"))
         horizon = spec.get("horizon", float("inf"))
         dp = C.POINTER(C.c_double)
         cfg = L.fs_config(
             struct_size=C.sizeof(L.fs_config), abi_version=L.FS_ABI_VERSION, precision=self.precision,
-            network=L.FS_NET_MERGE if self.open_net else (L.FS_NET_FIGURE_EIGHT if segs else L.FS_NET_RING),
+            network=(L.FS_NET_BOTTLENECK if self.bottleneck else L.FS_NET_MERGE) if self.open_net
+            else (L.FS_NET_FIGURE_EIGHT if segs else L.FS_NET_RING),
             env=int(spec.get("env", L.FS_ENV_ACCEL)),
             integrator=INTEGRATORS[spec.get("integrator", "euler")],
             num_replicas=self.R, num_vehicles=self.N, num_rl=self.num_rl,
@@ -152,10 +163,17 @@ class FlowSim:
             inflows=inflow_arr, init_alive=init_alive.ctypes.data_as(C.POINTER(C.c_uint8)) if init_alive is not None else None,
             merge_x=float(spec.get("merge_x", 0.0)), box_in=float(spec.get("box_in", 0.0)),
             end_x=float(spec.get("end_x", 0.0)), net_length=float(spec.get("net_length", 0.0)),
-            ma_apply_actions=int(bool(spec.get("ma_apply_actions", False))), reserved3=0)
+            ma_apply_actions=int(bool(spec.get("ma_apply_actions", False))),
+            num_obs_cells=len(obs_cells) if obs_cells is not None else 0,
+            merge1_x=float(spec.get("merge1_x", spec.get("merge_x", 0.0))),
+            merge2_x=float(spec.get("merge2_x", spec.get("merge_x", 0.0))),
+            zipper_distance=float(spec.get("zipper_distance", 0.0)), speed_limit=float(spec.get("speed_limit", 0.0)),
+            outflow_norm=2000.0 * float(spec.get("scaling", 1)), obs_cells=obs_cells, act_cells=act_cells,
+            obs_outflow_window=int(spec.get("obs_outflow_window", 20)),
+            reward_outflow_window=int(spec.get("reward_outflow_window", 10)))
         if self.open_net:
             cfg.route_start[0] = float(spec["routes"][0]["start"])
-            cfg.route_start[1] = float(spec["routes"][1]["start"])
+            cfg.route_start[1] = float(spec["routes"][min(1, len(spec["routes"]) - 1)]["start"])
         L.check(self.lib.fs_create(C.byref(cfg), C.byref(self._h)))
         self.obs_dim = self.lib.fs_obs_dim(self._h)
         self.act_dim = self.lib.fs_action_dim(self._h)
@@ -229,6 +247,8 @@ class FlowSim:
             return (self.R, self.N), np.int32
         if field == L.FS_FIELD_COUNTERS:
             return (self.R, 8), np.int32
+        if field == L.FS_FIELD_MAX_SPEED:
+            return (self.R, self.N), self.real
         if field == L.FS_FIELD_RING_LENGTH:
             return (self.R,), self.real
         return (self.R, self.N), self.real

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FS_ABI_VERSION 4
+#define FS_ABI_VERSION 5
 
 /* ---- error codes -------------------------------------------------------- */
 #define FS_OK 0
@@ -70,17 +70,24 @@ enum fs_env {
                                        actions are [acc_0, dir_0, acc_1, dir_1, ...] (2 per RL vehicle) */
   FS_ENV_MERGE_PO = 4,              /* MergePOEnv               flow/envs/merge.py:28-231: num_rl controlled vehicles
                                        (rl_queue / rl_veh slotting), obs 5*num_rl, action column = place in rl_veh */
-  FS_ENV_MERGE_MA = 5               /* MultiAgentMergePOEnv     flow/envs/multiagent/merge.py:19-190: one 5-vector and
+  FS_ENV_MERGE_MA = 5,              /* MultiAgentMergePOEnv     flow/envs/multiagent/merge.py:19-190: one 5-vector and
                                        one action column per RL slot (column = rl_index), shared reward, no crash */
+  FS_ENV_BOTTLENECK_DV = 6,         /* BottleneckDesiredVelocityEnv  flow/envs/bottleneck.py:760-1085: 4 values per
+                                       observed lane-segment + outflow; one action per controlled lane-segment (num_rl =
+                                       num_act_cells) shifting the maxSpeed of the RL vehicles inside it */
+  FS_ENV_BOTTLENECK = 7             /* BottleneckEnv            flow/envs/bottleneck.py:83-483: observation [1], outflow reward */
 };
 
 enum fs_network {
   FS_NET_RING = 0,          /* RingNetwork, flow/networks/ring.py (any number of lanes) */
   FS_NET_FIGURE_EIGHT = 1,  /* FigureEightNetwork, flow/networks/figure_eight.py: a closed one-lane loop that
                                crosses itself; described by fs_config.segments + fs_config.junction */
-  FS_NET_MERGE = 2          /* MergeNetwork, flow/networks/merge.py: an OPEN one-lane network, two routes (0 = highway,
+  FS_NET_MERGE = 2,         /* MergeNetwork, flow/networks/merge.py: an OPEN one-lane network, two routes (0 = highway,
                                1 = on-ramp) converging at a priority junction; vehicles enter through fs_config.inflows
                                and leave at end_x.  num_vehicles is the slot CAPACITY of a replica. */
+  FS_NET_BOTTLENECK = 3     /* BottleneckNetwork, flow/networks/bottleneck.py (scaling 1): an OPEN network of four entry
+                               lanes that join pairwise at two zipper junctions (4 -> 2 -> 1); nobody changes lane
+                               (lane_change_mode 0), a vehicle's "route" is its entry lane 0..3 */
 };
 
 enum fs_integrator { FS_EULER = 0, FS_BALLISTIC = 1 /* SumoParams.use_ballistic, core/params.py:578-602 */ };
@@ -112,7 +119,8 @@ enum fs_field {
   FS_FIELD_COUNTERS = 19,  /* int32[R,8] {steps since simulator start, vehicles ever departed (id counter), rl_veh
                               join counter, arrived last sub-step, departed last sub-step, arrived total,
                               departed total, 0}  (get_num_arrived / get_outflow_rate inputs, vehicle/traci.py:493-533) */
-  FS_FIELD_ARRIVED_RL = 20 /* int32[R,N] 1: the RL vehicle of this slot arrived in the last sub-step (get_arrived_rl_ids) */
+  FS_FIELD_ARRIVED_RL = 20,/* int32[R,N] 1: the RL vehicle of this slot arrived in the last sub-step (get_arrived_rl_ids) */
+  FS_FIELD_MAX_SPEED = 21  /* real[R,N]  get_max_speed / set_max_speed: maxSpeed of the SUMO car-following model */
 };
 
 #define FS_MAX_CTRL_PARAMS 8
@@ -129,13 +137,14 @@ typedef struct fs_segment {
   double flow_slope;
   int32_t internal;                   /* 1: junction-internal edge (':...'): no Flow command with junction_mode */
   int32_t route;                      /* FS_NET_MERGE: the route this row belongs to (rows of a route are contiguous,
-                                         starts increasing); 0 otherwise */
+                                         starts increasing); 0 otherwise (FS_NET_BOTTLENECK: one table for all lanes) */
 } fs_segment;
 
 /* One InFlows.add entry (flow/core/params.py:1080-1213) of an open network. */
 typedef struct fs_inflow {
   int32_t type;                       /* vehicle type = fs_vehicle_spec.type of the slots it may occupy */
-  int32_t route;                      /* route of its edge (0 highway, 1 on-ramp) */
+  int32_t route;                      /* route of its edge (0 highway, 1 on-ramp); FS_NET_BOTTLENECK: entry lane, or -1 for
+                                         departLane = "random" (drawn per vehicle from the Philox stream) */
   int32_t number;                     /* total vehicles to create, < 0 = unlimited */
   int32_t reserved;
   double period;                      /* seconds between vehicles: 3600 / vehs_per_hour, or `period` */
@@ -156,6 +165,15 @@ typedef struct fs_junction {
   double time_gap;                    /* stream a blocks the box when it reaches a_in within time_gap */
   double za_lo, za_hi, zb_lo, zb_hi;  /* front positions at which a body covers the crossing point */
 } fs_junction;
+
+/* One lane-segment of the bottleneck environments (bottleneck.py:796-812): the vehicles on `lane` whose position
+ * on the edge lies in (lo, hi]  (np.searchsorted(slices, pos) - 1). */
+typedef struct fs_cell {
+  double edge_start;                  /* coordinate of the first metre of the edge */
+  double lo, hi;                      /* segment boundaries, relative to the edge start */
+  int32_t lane;                       /* lane index on that edge */
+  int32_t last_segment;               /* 1: last segment of its edge (takes a vehicle standing exactly at pos 0) */
+} fs_cell;
 
 /* One vehicle slot; identical for every replica (VehicleParams.add,
  * flow/core/params.py:236-351, expanded per vehicle). */
@@ -231,7 +249,16 @@ typedef struct fs_config {
   double net_length;                  /* k.network.length(): the normaliser of MergePOEnv.get_state */
   int32_t ma_apply_actions;           /* FS_ENV_MERGE_MA: 0 = actions are never applied, as this fork ships
                                          (multiagent/merge.py:92-96); 1 = column rl_index commands the slot, NaN = none */
-  int32_t reserved3;
+  int32_t num_obs_cells;              /* FS_ENV_BOTTLENECK_DV: observed lane-segments (<= 64), obs_dim = 4 * cells + 1 */
+  /* ---- FS_NET_BOTTLENECK ---- */
+  double merge1_x, merge2_x;          /* coordinates where lanes (2q, 2q+1) join / where the two resulting lanes join */
+  double zipper_distance;             /* a vehicle this close to a join follows the nearest vehicle of either joining lane */
+  double speed_limit;                 /* edge speed limit: desired speed = min(vehicle maxSpeed, speed_limit); 0 = none */
+  double outflow_norm;                /* 2000 * scaling: normaliser of the outflow reward */
+  const fs_cell* obs_cells;           /* [num_obs_cells] in observation order (edge, segment, lane) */
+  const fs_cell* act_cells;           /* [num_rl] controlled lane-segments, action column order */
+  int32_t obs_outflow_window;         /* int(20 * sim_step / sim_step): sub-steps of the observed outflow */
+  int32_t reward_outflow_window;      /* int(10 * sim_step / sim_step) */
 } fs_config;
 
 typedef struct fs_sim* fs_handle;

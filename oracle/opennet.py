@@ -45,6 +45,25 @@ SUMO-side rules (third-party code, absent; stated here, PARITY UNPINNED -- DESIG
       entry while a minor vehicle is inside; both routes inside at once = collision
   M7  movement = S4-S9 of the ring oracle (slowDown ramp, speed-mode clamps, SUMO-IDM when uncommanded)
 
+Lane-drop networks (BottleneckNetwork, flow/networks/bottleneck.py: 4 lanes -> 2 -> 1 at two zipper junctions,
+with lane_change_mode = 0 nobody changes lane, examples/exp_configs/rl/singleagent/singleagent_bottleneck.py:33-53)
+are the same thing with more paths: a vehicle keeps the PATH it entered on (its entry lane p); lanes 2q and
+2q+1 join at merge1_x, the two resulting lanes join at merge2_x, so the physical lane of path p at coordinate x is
+p >> shift(x), shift(x) = (x >= merge1_x) + (x >= merge2_x).  MergeNetwork is the case of two paths with
+merge1_x = merge2_x.  Additional rules:
+
+  M8  zipper junction: within zipper_distance of a merge point a vehicle already treats the lane it is about to
+      join as its own (it follows the nearest vehicle ahead on either joining lane); a collision needs the two
+      vehicles to be on one physical lane
+  M9  departLane = "random": the entry lane of vehicle k of inflow f is floor(u * lanes), u from Philox keyed by
+      (seed; k, f, replica); drawn once, the insertion is retried until it fits (M3)
+  M10 the desired speed of the SUMO car-following model is min(vehicle maxSpeed, edge speed limit); maxSpeed is
+      per vehicle and changed by BottleneckDesiredVelocityEnv (setMaxSpeed)
+  O6  BottleneckDesiredVelocityEnv (flow/envs/bottleneck.py:866-986): per (edge, segment, lane) vehicle counts
+      and mean speeds of human / RL vehicles, outflow; actions shift the maxSpeed of the RL vehicles in the
+      controlled lane-segments, clip(maxSpeed + a, 0.01, 23); reward = outflow of the last 10 steps / (2000 * scaling)
+  O7  BottleneckEnv (:234-268, 474-483): observation [1], the same outflow reward
+
 dtype float64 restates the reference's arithmetic type; dtype float32 is the bit-twin of the HIP kernel
 `k_steps_open` (same operation order).
 """
@@ -52,9 +71,9 @@ import numpy as np
 
 from . import controllers as C
 from . import rewards as Rw
-from .refsim import CTRL_RL, controller_dispatch
+from .refsim import CTRL_RL, controller_dispatch, philox4x32_10
 
-ENV_MERGE_PO, ENV_MERGE_MA = 4, 5          # include/flowsim.h FS_ENV_MERGE_PO / FS_ENV_MERGE_MA
+ENV_MERGE_PO, ENV_MERGE_MA, ENV_BOTTLENECK_DV, ENV_BOTTLENECK = 4, 5, 6, 7     # include/flowsim.h FS_ENV_*
 NO_LEADER_HEADWAY = 1000.0                 # vehicle/traci.py:237
 ERR = -1001.0                              # default `error` of the vehicle accessors
 BIG = 3.0e38
@@ -90,6 +109,13 @@ class MergeOracle:
         self.is_rl = np.array([v["controller"] == CTRL_RL for v in self.veh])
         self.routes = spec["routes"]
         self.merge_x, self.box_in, self.end_x = T(spec["merge_x"]), T(spec["box_in"]), T(spec["end_x"])
+        self.P = int(spec.get("num_paths", 2))
+        self.m1 = T(spec.get("merge1_x", spec["merge_x"]))
+        self.m2 = T(spec.get("merge2_x", spec["merge_x"]))
+        self.zip_d = T(spec.get("zipper_distance", 0.0))
+        self.speed_limit = T(spec.get("speed_limit", BIG))
+        self.cells = spec.get("obs_cells")                  # O6: [(x_lo, x_hi, lane)] in observation order
+        self.ctl_cells = spec.get("action_cells")           # O6: [(x_lo, x_hi, lane)] per action column
         self.junction = spec.get("junction") or {"enabled": 0}
         self.inflows = spec.get("inflows", [])
         self.env = int(spec.get("env", ENV_MERGE_PO))
@@ -106,7 +132,9 @@ class MergeOracle:
         self.init_route = np.asarray(spec["init_route"], dtype=np.int64).reshape(R, N)
         z = lambda dt=self.dt_: np.zeros((R, N), dtype=dt)                                 # noqa: E731
         self.x, self.v, self.prev_v, self.lac_a, self.last_accel = z(), z(), z(), z(), z()
-        self.route = np.full((R, N), -1, dtype=np.int64)           # -1: free slot
+        self.vmax = np.tile(np.array([v.get("sumo_max_speed", 30.0) for v in self.veh], dtype=self.dt_), (R, 1))
+        self.arr_hist = np.zeros((R, 20), dtype=np.int64)          # arrivals of the last 20 sub-steps (ring buffer)
+        self.route = np.full((R, N), -1, dtype=np.int64)           # -1: free slot; else the path (entry lane)
         self.seq = z(np.int64)                                      # position in the id list (departure order)
         self.origin = np.full((R, N), -1, dtype=np.int64)          # flow * 2^20 + k, or -1-i for initial vehicle i
         self.foll = np.full((R, N), -1, dtype=np.int64)            # sticky follower slot (O1)
@@ -140,7 +168,8 @@ class MergeOracle:
         T = self.dt_.type
         internal = np.zeros(x.shape, dtype=bool)
         flow_x = np.zeros(x.shape, dtype=self.dt_)
-        for r, rt in enumerate(self.routes):
+        for r in range(self.P):
+            rt = self.routes[min(r, len(self.routes) - 1)]
             inter = np.zeros(x.shape, dtype=bool)
             start = np.zeros(x.shape, dtype=self.dt_)
             fstart = np.zeros(x.shape, dtype=self.dt_)
@@ -159,6 +188,10 @@ class MergeOracle:
     def flow_x(self):
         return self._segment_lookup(self.x, self.route)[1]
 
+    def shift(self, x):
+        """Number of lane joins upstream of coordinate x."""
+        return (x >= self.m1).astype(np.int64) + (x >= self.m2).astype(np.int64)
+
     # ------------------------------------------------------------------ O1 / M5: neighbour snapshot
     def _update_neighbours(self, active):
         """Leader / headway of every vehicle (M5) and the sticky follower bookkeeping (O1) after a move."""
@@ -168,9 +201,11 @@ class MergeOracle:
         jj = np.arange(N)
         d = x[:, None, :] - x[:, :, None]                                  # d[r,i,j] = x_j - x_i
         ahead = (d > 0) | ((d == 0) & (jj[None, None, :] < jj[None, :, None]))
-        shared = x >= self.merge_x
-        cand = ahead & alive[:, None, :] & alive[:, :, None] & (jj[None, None, :] != jj[None, :, None]) & \
-            ((route[:, None, :] == route[:, :, None]) | shared[:, None, :])
+        # M5 / M8: j is on my lane if our paths agree after the joins upstream of max(x_j, x_i + zipper_distance)
+        sh = self.shift(np.maximum(x[:, None, :], (x + self.zip_d)[:, :, None]))
+        rr_ = np.maximum(route, 0)
+        same_lane = (rr_[:, None, :] >> sh) == (rr_[:, :, None] >> sh)
+        cand = ahead & alive[:, None, :] & alive[:, :, None] & (jj[None, None, :] != jj[None, :, None]) & same_lane
         # the nearest candidate = the smallest x_j; vehicles are ordered by (x ascending, equal x: higher slot
         # first), so among candidates at one position the highest slot is the nearest
         xl = np.where(cand, x[:, None, :], T(BIG))
@@ -180,6 +215,10 @@ class MergeOracle:
         h = np.where(has, dlead - self.veh_len[lead], T(NO_LEADER_HEADWAY))
         lead = np.where(has, lead, -1)
         a2 = active[:, None]
+        # M8: the leader shares my physical lane (collision check) if our paths agree at ITS position
+        li_ = np.where(has, lead, 0)
+        shl = self.shift(np.take_along_axis(x, li_, 1))
+        self.lead_same_lane = has & ((rr_ >> shl) == (np.take_along_axis(rr_, li_, 1) >> shl))
         self.lead = np.where(a2, lead, self.lead)
         self.h = np.where(a2, h, self.h)
         # ---- sticky follower (vehicle/traci.py:232-250), visited in id-list (seq) order
@@ -221,7 +260,7 @@ class MergeOracle:
         stop = np.stack([C.sumo_idm_speed(v[:, i], np.zeros(self.R, self.dt_), gap[:, i], np.ones(self.R, bool),
                                           self.dt, accel=vs["max_accel"], decel=vs["max_decel"],
                                           tau=vs.get("sumo_tau", 1.0), min_gap=vs.get("sumo_min_gap", 2.5),
-                                          max_speed=vs.get("sumo_max_speed", 30.0))
+                                          max_speed=np.minimum(self.vmax[:, i], self.speed_limit))
                          for i, vs in enumerate(self.veh)], axis=1)
         approaching = alive & (x >= self.box_in - D) & (x < self.box_in)
         yields = approaching & (((route == 1) & major_busy) | ((route == 0) & minor_in_box))
@@ -279,6 +318,49 @@ class MergeOracle:
         self.ctl_seq = np.where(take, self.ctl_ctr[:, None] + qrank, self.ctl_seq)
         self.ctl_ctr = self.ctl_ctr + take.sum(axis=1)
 
+    # ------------------------------------------------------------------ O6: desired-velocity actions
+    def _cell_of(self, cells, last_of_edge=None):
+        """[R,N] index of the (x_lo, x_hi, lane, edge_start) cell each vehicle is in, -1 if none: position on the
+        edge in (lo, hi] as np.searchsorted(..) - 1 gives it (bottleneck.py:903-904, 948); a vehicle exactly at
+        the start of an edge falls into bucket -1 = the LAST segment of that edge (numpy negative index)."""
+        T = self.dt_.type
+        lane = np.maximum(self.route, 0) >> self.shift(self.x)
+        internal, _ = self._segment_lookup(self.x, self.route)
+        out = np.full(self.x.shape, -1, dtype=np.int64)
+        for c, (start, lo, hi, ln, is_last) in enumerate(cells):
+            pos = self.x - T(start)
+            inside = (pos > T(lo)) & (pos <= T(hi))
+            if last_of_edge and is_last:
+                inside = inside | (pos == T(0))
+            hit = self.alive & ~internal & inside & (lane == ln) & (out < 0)
+            out = np.where(hit, c, out)
+        return out
+
+    def _desired_velocity_actions(self, actions, active):
+        if self.env != ENV_BOTTLENECK_DV or actions is None:
+            return
+        T = self.dt_.type
+        acts = np.asarray(actions, dtype=self.dt_)
+        if self.spec.get("clip_actions", True):
+            acts = np.clip(acts, T(self.spec["action_low"]), T(self.spec["action_high"]))
+        cell = self._cell_of(self.ctl_cells)
+        a = np.take_along_axis(acts, np.maximum(cell, 0), 1)
+        nxt = np.minimum(np.maximum(self.vmax + a, T(0.01)), T(23.0))       # bottleneck.py:964-965
+        nxt = np.where(cell >= 0, nxt, T(23.0))                             # :969
+        upd = active[:, None] & self.alive & self.is_rl[None, :]
+        self.vmax = np.where(upd, nxt, self.vmax)
+
+    def _outflow(self, window):
+        """get_outflow_rate over the last ``window`` sub-steps (vehicle/traci.py:500-505), [R]."""
+        T = self.dt_.type
+        n = np.minimum(self.time_counter, window)
+        total = np.zeros(self.R, dtype=np.int64)
+        for k in range(window):
+            idx = (self.time_counter - 1 - k) % 20
+            total += np.where(k < n, self.arr_hist[np.arange(self.R), idx], 0)
+        rate = (T(3600) * total.astype(self.dt_)) / (np.maximum(n, 1).astype(self.dt_) * T(self.dt))
+        return np.where(n > 0, rate, T(0))
+
     # ------------------------------------------------------------------ reset
     def reset(self, mask=None):
         T = self.dt_.type
@@ -300,6 +382,10 @@ class MergeOracle:
         self.lac_a = np.where(m2, T(0), self.lac_a)
         self.last_accel = np.where(m2, T(0), self.last_accel)
         self.emitted = np.where(m2[:, :1], 0, self.emitted)
+        self.vmax = np.where(m2, np.array([v.get("sumo_max_speed", 30.0) for v in self.veh], dtype=self.dt_)[None, :],
+                             self.vmax)
+        self.arr_hist = np.where(m2[:, :1], 0, self.arr_hist)
+        self._just_arrived = np.where(m2, False, self._just_arrived)
         self.time_counter = np.where(m, 0, self.time_counter)
         self.sim_steps = np.where(m, 1, self.sim_steps)                    # S13: one step ran during the reset
         for a in (self.num_arrived, self.num_departed, self.total_arrived, self.total_departed):
@@ -325,14 +411,25 @@ class MergeOracle:
             due = (due_t <= now) & (due_t <= float(fl.get("end", 86400.0)))
             if fl.get("number", -1) is not None and fl.get("number", -1) >= 0:
                 due &= k < int(fl["number"])
-            typ, route = int(fl["type"]), int(fl["route"])
+            typ = int(fl["type"])
+            if int(fl["route"]) < 0:                                      # M9: departLane = "random"
+                r0, _, _, _ = philox4x32_10(k.astype(np.uint32), np.full(R, 1000 + f, dtype=np.uint32),
+                                            np.arange(R, dtype=np.uint32), np.ones(R, dtype=np.uint32),
+                                            np.uint32(int(self.spec.get("seed", 0)) & 0xFFFFFFFF),
+                                            np.uint32((int(self.spec.get("seed", 0)) >> 32) & 0xFFFFFFFF))
+                route = (((r0 >> np.uint32(8)).astype(np.int64) * self.P) >> 24)
+            else:
+                route = np.full(R, int(fl["route"]), dtype=np.int64)
             free = (~self.alive) & (self.slot_type[None, :] == typ) & ~self._just_arrived
             slot = np.argmax(free, axis=1)                                 # lowest free slot of the type
             has_slot = free.any(axis=1)
             vs = self.veh[int(np.flatnonzero(self.slot_type == typ)[0])]
-            x_dep = T(self.routes[route]["start"]) + T(fl["depart_pos"])
+            starts = np.array([self.routes[min(q, len(self.routes) - 1)]["start"] for q in range(self.P)],
+                              dtype=self.dt_)
+            x_dep = starts[route] + T(fl["depart_pos"])
             v_dep = T(fl["depart_speed"])
-            cand = self.alive & ((self.route == route) | (self.x >= self.merge_x))
+            sh = self.shift(np.maximum(self.x, (x_dep + self.zip_d)[:, None]))
+            cand = self.alive & ((np.maximum(self.route, 0) >> sh) == (route[:, None] >> sh))
             back = np.where(cand, self.x - self.veh_len[None, :], T(BIG))
             j = np.argmin(np.where(cand, self.x, T(BIG)), axis=1)         # nearest vehicle ahead = smallest x
             has_lead = cand.any(axis=1)
@@ -344,12 +441,13 @@ class MergeOracle:
             ok = active & due & has_slot & (~has_lead | (gap >= need))
             r_ok = rows[ok]
             s_ok = slot[ok]
-            self.x[r_ok, s_ok] = x_dep
+            self.x[r_ok, s_ok] = x_dep[ok]
             self.v[r_ok, s_ok] = v_dep
             self.prev_v[r_ok, s_ok] = T(0)                                 # previous_speeds.get(veh_id, 0)
             self.lac_a[r_ok, s_ok] = T(0)
             self.last_accel[r_ok, s_ok] = T(0)
-            self.route[r_ok, s_ok] = route
+            self.route[r_ok, s_ok] = route[ok]
+            self.vmax[r_ok, s_ok] = T(vs.get("sumo_max_speed", 30.0))
             self.seq[r_ok, s_ok] = self.seq_ctr[ok]
             self.origin[r_ok, s_ok] = f * (1 << 20) + k[ok]
             self.foll[r_ok, s_ok] = -1
@@ -381,6 +479,7 @@ class MergeOracle:
         acc, commanded = controller_dispatch(
             self, v, v_lead, h, has_lead, v_follow, h_follow, rl_value, rl_cmd, on_edge, active,
             lambda: Rw.tree_sum(np.where(alive, v, T(0))) / np.maximum(n_alive, 1).astype(self.dt_))
+        self._desired_velocity_actions(actions, active)                   # O6, envs/base.py:355
         self._additional_command(active)                                   # envs/base.py:357
         # ---- M7 movement
         next_vel = np.maximum(v + acc * dt, T(0))
@@ -391,7 +490,7 @@ class MergeOracle:
             v_sumo = C.sumo_idm_speed(v[sl], v_lead[sl], h[sl], has_lead[sl], self.dt,
                                       accel=vs["max_accel"], decel=vs["max_decel"],
                                       tau=vs.get("sumo_tau", 1.0), min_gap=vs.get("sumo_min_gap", 2.5),
-                                      max_speed=vs.get("sumo_max_speed", 30.0))
+                                      max_speed=np.minimum(self.vmax[:, i], self.speed_limit))     # M10
             vc = v_cmd[sl]
             mode = int(vs.get("speed_mode", 0))
             if mode & 1:
@@ -419,11 +518,14 @@ class MergeOracle:
         self._just_arrived = arrived
         self.route = np.where(arrived, -1, self.route)
         self.num_arrived = np.where(active, arrived.sum(axis=1), self.num_arrived)
+        slot_t = (self.time_counter - 1) % 20                              # this sub-step's place in the ring buffer
+        rows_ = np.arange(self.R)
+        self.arr_hist[rows_[active], slot_t[active]] = arrived.sum(axis=1)[active]
         self.total_arrived = self.total_arrived + arrived.sum(axis=1)
         # ---- M2 / M3 insertions, then the new snapshot (O1)
         self._insert(active)
         has_new = self._update_neighbours(active)
-        crash = np.any(self.alive & has_new & (self.h < self.crash_gap), axis=1) | self._box_crash()
+        crash = np.any(self.alive & has_new & self.lead_same_lane & (self.h < self.crash_gap), axis=1) | self._box_crash()
         return crash & active
 
     def step(self, actions=None, _mask=None):
@@ -464,6 +566,26 @@ class MergeOracle:
     def get_state(self):
         T = self.dt_.type
         R, N = self.R, self.N
+        if self.env == ENV_BOTTLENECK:                                     # bottleneck.py:481-483
+            return np.ones((R, 1), dtype=self.dt_)
+        if self.env == ENV_BOTTLENECK_DV:                                  # bottleneck.py:868-924
+            cell = self._cell_of(self.cells, last_of_edge=True)
+            C = len(self.cells)
+            cnt_h, cnt_r = np.zeros((R, C), self.dt_), np.zeros((R, C), self.dt_)
+            sp_h, sp_r = np.zeros((R, C), self.dt_), np.zeros((R, C), self.dt_)
+            for c in range(C):
+                mh = (cell == c) & ~self.is_rl[None, :]
+                mr = (cell == c) & self.is_rl[None, :]
+                cnt_h[:, c], cnt_r[:, c] = mh.sum(axis=1), mr.sum(axis=1)
+                for i in range(N):                                         # speeds added up in slot order
+                    sp_h[:, c] = np.where(mh[:, i], sp_h[:, c] + self.v[:, i], sp_h[:, c])
+                    sp_r[:, c] = np.where(mr[:, i], sp_r[:, c] + self.v[:, i], sp_r[:, c])
+            nh, nr = cnt_h / T(20), cnt_r / T(20)                          # NUM_VEHICLE_NORM
+            un_h, un_r = nh * T(20), nr * T(20)
+            mean_h = np.where(cnt_h > 0, sp_h / np.where(cnt_h > 0, un_h, T(1)), T(0)) / T(50)
+            mean_r = np.where(cnt_r > 0, sp_r / np.where(cnt_r > 0, un_r, T(1)), T(0)) / T(50)
+            outflow = self._outflow(int(self.spec["obs_outflow_window"])) / T(2000.0)
+            return np.concatenate([nh, nr, mean_h, mean_r, outflow[:, None]], axis=1)
         if self.env == ENV_MERGE_PO:
             obs = np.zeros((R, 5 * self.num_rl), dtype=self.dt_)
             rank = self._ctl_rank()
@@ -485,6 +607,8 @@ class MergeOracle:
 
     def compute_reward(self, actions, fail):
         T = self.dt_.type
+        if self.env in (ENV_BOTTLENECK, ENV_BOTTLENECK_DV):                # bottleneck.py:474-478, 971-981
+            return self._outflow(int(self.spec["reward_outflow_window"])) / T(2000.0 * self.spec.get("scaling", 1))
         alive = self.alive
         n = alive.sum(axis=1)
         if self.spec.get("evaluate", False):                               # merge.py:161-162

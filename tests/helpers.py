@@ -161,3 +161,74 @@ def merge_spec(R=4, cap_human=12, cap_rl=4, num_rl=2, pre=200.0, merge=100.0, po
                 network="merge", **tb)
     spec.update(kw)
     return spec
+
+
+def bottleneck_tables(junction_length=0.1, zipper_length=20.0, scaling=1):
+    """BottleneckNetwork (flow/networks/bottleneck.py:111-165, scaling 1) on one coordinate: edges 1-5 of
+    100 / 310 / 140 / 280 / 155 m with 4 / 4 / 4 / 2 / 1 lanes, short internal edges at nodes 2 and 3, zipper
+    junctions of ``zipper_length`` at nodes 4 and 5.  Flow's edge-start table is ("1",0),("2",100),("3",405),
+    ("4",425),("5",580) (:232-234); internal edges have no table entry (slope 0, value -1001 does not matter: the
+    bottleneck envs only use edge-relative positions)."""
+    j, z = junction_length, zipper_length
+    e = [100.0, 310.0, 140.0, 280.0, 155.0]
+    s1 = 0.0
+    s2 = s1 + e[0] + j
+    s3 = s2 + e[1] + j
+    s4 = s3 + e[2] + z
+    s5 = s4 + e[3] + z
+    end = s5 + e[4]
+    segs = [(s1, 0, 0.0, 1.0), (s1 + e[0], 1, -1001.0, 0.0), (s2, 0, 100.0, 1.0), (s2 + e[1], 1, -1001.0, 0.0),
+            (s3, 0, 405.0, 1.0), (s3 + e[2], 1, -1001.0, 0.0), (s4, 0, 425.0, 1.0), (s4 + e[3], 1, -1001.0, 0.0),
+            (s5, 0, 580.0, 1.0)]
+    starts = dict(zip("12345", [s1, s2, s3, s4, s5]))
+    lanes = dict(zip("12345", [4, 4, 4, 2, 1]))
+    lengths = dict(zip("12345", e))
+    return dict(routes=[dict(start=0.0, segments=segs)], num_paths=4, merge1_x=s4, merge2_x=s5, merge_x=s5,
+                box_in=s5 - z, end_x=end, net_length=sum(e) + 2 * j + 2 * z * 3, edge_start=starts, edge_lanes=lanes,
+                edge_length=lengths)
+
+
+def segment_cells(tb, segments):
+    """[(edge_start_x, lo, hi, lane, is_last_segment)] in the order the bottleneck envs walk them: edge, segment,
+    lane (np.linspace(0, edge_length, n + 1) boundaries, bottleneck.py:796-812)."""
+    cells = []
+    for edge, n in segments:
+        bounds = np.linspace(0, tb["edge_length"][edge], n + 1)
+        for k in range(n):
+            for lane in range(tb["edge_lanes"][edge]):
+                cells.append((tb["edge_start"][edge], float(bounds[k]), float(bounds[k + 1]), lane, k == n - 1))
+    return cells
+
+
+def bottleneck_spec(R=4, cap_human=40, cap_rl=8, horizon=300, seed=0, q=2300.0, av_frac=0.1, env=None,
+                    zipper_distance=50.0, warmup_steps=0, **kw):
+    """singleagent_bottleneck.py: humans and RL vehicles all driven by the SUMO car-following model, inflow on
+    edge 1 with departLane='random', BottleneckDesiredVelocityEnv head (141 observations, 20 actions)."""
+    from oracle import opennet as O
+    tb = bottleneck_tables()
+    N = cap_human + cap_rl
+    veh = [idm_vehicle(controller=S.CTRL_SIM, speed_mode=31, type=0) for _ in range(cap_human)] + \
+          [idm_vehicle(controller=S.CTRL_RL, rl_index=k, speed_mode=9, type=1) for k in range(cap_rl)]
+    rng = np.random.default_rng(seed)
+    alive = np.zeros((R, N), dtype=bool)
+    X = np.zeros((R, N))
+    route = np.zeros((R, N), dtype=np.int32)
+    # one human and one RL vehicle to start with, on edges 2.. (InitialConfig edges_distribution)
+    alive[:, 0], X[:, 0], route[:, 0] = True, 300.0 + rng.uniform(0, 10, R), 1
+    alive[:, cap_human], X[:, cap_human], route[:, cap_human] = True, 600.0 + rng.uniform(0, 10, R), 2
+    obs_cells = segment_cells(tb, [("1", 1), ("2", 3), ("3", 3), ("4", 3), ("5", 1)])
+    act_cells = segment_cells(tb, [("2", 2), ("3", 2), ("4", 2)])
+    spec = dict(network="bottleneck", num_replicas=R, num_vehicles=N, num_rl=len(act_cells), sim_step=0.5, max_speed=23.0,
+                env=O.ENV_BOTTLENECK_DV if env is None else env, target_velocity=40.0, action_low=-1.5, action_high=1.5,
+                horizon=horizon, warmup_steps=warmup_steps, sims_per_step=1, vehicles=veh, seed=seed,
+                junction=dict(enabled=0, lookahead=0.0, time_gap=1.0), junction_mode=1, speed_limit=23.0,
+                zipper_distance=zipper_distance, scaling=1, obs_cells=obs_cells, action_cells=act_cells,
+                obs_outflow_window=20, reward_outflow_window=10,
+                inflows=[dict(type=0, route=-1, period=3600.0 / (q * (1 - av_frac)), begin=1.0, end=86400.0, number=-1,
+                              depart_speed=10.0, depart_pos=5.0),
+                         dict(type=1, route=-1, period=3600.0 / (q * av_frac), begin=1.0, end=86400.0, number=-1,
+                              depart_speed=10.0, depart_pos=5.0)],
+                init_alive=alive, init_pos=X, init_vel=np.zeros((R, N)), init_route=route,
+                **{k: v for k, v in tb.items() if k not in ("edge_start", "edge_lanes", "edge_length")})
+    spec.update(kw)
+    return spec

@@ -192,3 +192,79 @@ def test_merge_rollout_equals_stepping():
         np.testing.assert_array_equal(done[k].cpu().numpy().astype(bool), d)
     np.testing.assert_array_equal(a.pos, b.pos)
     a.close(), b.close()
+
+
+# ------------------------------------------------------------------ lane drops (BottleneckNetwork)
+def bottleneck_actions(spec, seed, lo=-1.0, hi=1.0):
+    rng = np.random.default_rng(seed)
+    R, A = spec["num_replicas"], spec["num_rl"]
+    return lambda k: rng.uniform(lo, hi, (R, A)).astype(np.float32)
+
+
+def compare_vmax(sim, ora):
+    from flow_amd import _lib as L
+    got = sim.get_state(L.FS_FIELD_MAX_SPEED)
+    np.testing.assert_array_equal(got[ora.alive], ora.vmax[ora.alive])
+
+
+def test_bottleneck_desired_velocity_f32_bit_exact():
+    from helpers import bottleneck_spec
+    spec = bottleneck_spec(R=5, cap_human=48, cap_rl=8, horizon=500, seed=3)
+    ora = run_pair(spec, "f32", 500, bottleneck_actions(spec, 5))
+    assert ora.total_arrived.min() > 50 and (ora.alive.sum(axis=1) > 25).all()
+    assert (ora.vmax[:, 48:][ora.alive[:, 48:]] < 23.0).any()          # the actions moved some maxSpeed
+
+
+def test_bottleneck_state_fields_and_warmup():
+    from helpers import bottleneck_spec
+    spec = bottleneck_spec(R=3, cap_human=40, cap_rl=6, horizon=120, seed=7, warmup_steps=40)
+    dtype = np.float32
+    ora = O.MergeOracle(spec, dtype)
+    sim = make(spec, "f32")
+    np.testing.assert_array_equal(sim.reset(), ora.reset().astype(np.float32))
+    acts = bottleneck_actions(spec, 2)
+    for k in range(120):
+        a = acts(k)
+        o_ref, r_ref, d_ref = ora.step(a)
+        o_gpu, r_gpu, d_gpu = sim.step(a)
+        np.testing.assert_array_equal(o_gpu, o_ref.astype(np.float32))
+        np.testing.assert_array_equal(r_gpu, r_ref.astype(np.float32))
+        np.testing.assert_array_equal(d_gpu, d_ref)
+        if k % 20 == 0:
+            compare_state(sim, ora)
+            compare_vmax(sim, ora)
+    assert d_ref.all()
+    sim.close()
+
+
+def test_bottleneck_base_env_and_no_actions():
+    from helpers import bottleneck_spec
+    spec = bottleneck_spec(R=3, cap_human=44, cap_rl=4, horizon=200, seed=9, env=O.ENV_BOTTLENECK, num_rl=0,
+                           action_cells=[])
+    ora = run_pair(spec, "f32", 200, None)
+    assert ora.total_arrived.min() > 10
+
+
+def test_bottleneck_f64_matches_reference_arithmetic():
+    from helpers import bottleneck_spec
+    spec = bottleneck_spec(R=2, cap_human=44, cap_rl=6, horizon=300, seed=4)
+    run_pair(spec, "f64", 300, bottleneck_actions(spec, 8), check_every=25, exact=False, atol=1e-9)
+
+
+def test_bottleneck_without_zipper_lookahead_crashes_at_the_joins():
+    """zipper_distance = 0: vehicles only see the other lane once they are on it -- side-by-side arrivals at a join
+    are collisions (the crash rule needs one physical lane), and the run stays bit-identical to the oracle."""
+    from helpers import bottleneck_spec
+    spec = bottleneck_spec(R=4, cap_human=48, cap_rl=4, horizon=400, seed=11, zipper_distance=0.0)
+    ora = O.MergeOracle(spec, np.float32)
+    sim = make(spec, "f32")
+    np.testing.assert_array_equal(sim.reset(), ora.reset().astype(np.float32))
+    crashed = np.zeros(4, dtype=bool)
+    for k in range(400):
+        o_ref, r_ref, d_ref = ora.step(None)
+        o_gpu, r_gpu, d_gpu = sim.step(None)
+        np.testing.assert_array_equal(o_gpu, o_ref.astype(np.float32))
+        np.testing.assert_array_equal(d_gpu, d_ref)
+        crashed |= d_ref & (ora.time_counter < 400)
+    assert crashed.any()
+    sim.close()
