@@ -64,6 +64,8 @@ class NetworkKernel(object):
         paths = self.network.specify_open_routes()
         if paths is None:
             return None
+        if len(paths) == 1:
+            return self._lane_drop_tables(paths[0])
         a, b = paths
         n_common = 0
         while n_common < min(len(a), len(b)) and a[-1 - n_common] == b[-1 - n_common]:
@@ -87,12 +89,40 @@ class NetworkKernel(object):
         end_x = merge_x + sum(self._edges[e]['length'] for e in a[len(a) - n_common:])
         return dict(routes=routes, merge_x=merge_x, box_in=box_in, end_x=end_x, net_length=self.length())
 
+    def _lane_drop_tables(self, path):
+        """Lane-drop network (BottleneckNetwork): every lane drives the same edges; lanes 2q / 2q+1 join at the
+        start of the edges ``specify_lane_joins`` names."""
+        x, segs, starts = 0.0, [], []
+        for e in path:
+            if e[0] == ':':
+                segs.append((x, True, float(self.get_x(e, 0.0)), 0.0))
+            else:
+                segs.append((x, False, float(self.get_x(e, 0.0)), 1.0))
+            starts.append((e, x))
+            x += self._edges[e]['length']
+        self._open_starts = [starts]
+        joins = self.network.specify_lane_joins()
+        sd = dict(starts)
+        last_internal = path[path.index(joins[1]) - 1]
+        return dict(routes=[dict(start=0.0, segments=segs)], num_paths=self._edges[path[0]]['lanes'],
+                    merge1_x=sd[joins[0]], merge2_x=sd[joins[1]], merge_x=sd[joins[1]],
+                    box_in=sd[joins[1]] - self._edges[last_internal]['length'], end_x=x, net_length=self.length())
+
+    def open_lane(self, route, x):
+        """Lane index on its current edge of a vehicle that entered on lane ``route`` (lane-drop networks)."""
+        t = getattr(self, "_lane_joins_x", None)
+        if t is None:
+            sd = dict(self._open_starts[0])
+            t = self._lane_joins_x = [sd[e] for e in (self.network.specify_lane_joins() or [])]
+        return int(route) >> sum(1 for m in t if x >= m)
+
     def open_locate(self, route, x):
         """(edge, position on it) of coordinate ``x`` on ``route`` of an open network."""
-        for (edge, start) in reversed(self._open_starts[route]):
+        starts = self._open_starts[route if len(self._open_starts) > 1 else 0]
+        for (edge, start) in reversed(starts):
             if x >= start:
                 return edge, x - start
-        return self._open_starts[route][0][0], 0.0
+        return starts[0][0], 0.0
 
     def open_coordinate(self, edge, position):
         """(route, x) of a point on ``edge`` (an edge both routes share belongs to route 0)."""

@@ -40,6 +40,7 @@ class VehicleKernel(object):
     def initialize(self, vehicles):
         self.type_parameters = vehicles.type_parameters
         self.minGap = vehicles.minGap
+        self._open, self._slot_id, self._slot, self.sim = False, {}, {}, None    # until attach()
         self.__ids, self.__human_ids, self.__controlled_ids = [], [], []
         self.__controlled_lc_ids, self.__rl_ids = [], []
         self.__vehicles = {}
@@ -269,6 +270,10 @@ class VehicleKernel(object):
         return self.sim is not None and int(self.sim.spec.get("num_lanes", 1)) > 1
 
     def get_lane(self, veh_id, error=-1001):
+        if self._open and self.sim.spec.get("network") == "bottleneck":      # lane on the current edge
+            net = self.master_kernel.network
+            return self._vec(veh_id, lambda i: net.open_lane(int(self._field(L.FS_FIELD_ROUTE)[i]),
+                                                             float(self._field(L.FS_FIELD_POS)[i])), error)
         if self._multilane():
             return self._vec(veh_id, lambda i: int(self._field(L.FS_FIELD_LANE)[i]), error)
         return self._vec(veh_id, lambda i: 0, error)
@@ -302,6 +307,21 @@ class VehicleKernel(object):
                 return self.__ids[min(cand, key=lambda j: hw[j])]      # vehicle/traci.py:243-250
             return self._vec(veh_id, foll, error)
         return self._vec(veh_id, lambda i: self.__ids[(i - 1) % n] if n > 1 else None, error)
+
+    def get_max_speed(self, veh_id, error=-1001):
+        """maxSpeed of the SUMO car-following model of the vehicle (vehicle/traci.py get_max_speed)."""
+        if not self._open:
+            return self._vec(veh_id, lambda i: float(self.sim.spec["vehicles"][i].get("sumo_max_speed", 30.0)), error)
+        return self._vec(veh_id, lambda i: float(self._field(L.FS_FIELD_MAX_SPEED)[i]), error)
+
+    def set_max_speed(self, veh_id, max_speed):
+        """vehicle/traci.py set_max_speed (setMaxSpeed): open networks only -- closed loops keep it per type."""
+        if not self._open:
+            raise NotImplementedError("set_max_speed is built for open networks")
+        m = self.sim.get_state(L.FS_FIELD_MAX_SPEED)
+        m[self.replica, self._slot[veh_id]] = max_speed
+        self.sim.set_state(L.FS_FIELD_MAX_SPEED, m)
+        self._cache.pop(L.FS_FIELD_MAX_SPEED, None)
 
     def get_length(self, veh_id, error=-1001):
         return self._vec(veh_id, lambda i: self.__vehicles[self._sid(i)]["length"], error)

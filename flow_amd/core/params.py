@@ -174,6 +174,8 @@ class SumoParams(SimParams):
     max_vehicles    open networks: vehicle slots per replica (<= 64), shared out over the vehicle types
     slot_capacity   open networks: {vehicle type: slots}, overrides the default share-out
     merge_right_of_way  open networks: False switches the junction priority model off
+    zipper_distance lane-drop networks: distance before a zipper junction from which a vehicle follows the nearest
+                    vehicle of either joining lane
     junction_length length of each internal edge (netconvert output in the reference)
     crash_gap       a replica crashes when a bumper gap falls below this after a move
     precision       'f32' | 'f64' arithmetic and state type of the kernels
@@ -185,7 +187,7 @@ class SumoParams(SimParams):
                  print_warnings=True, start_at_load=True, teleport_time=-1, num_clients=1, color_by_speed=False,
                  use_ballistic=False, slowdown_ramp=None, junction_mode=None, junction_length=0.1, crash_gap=0.0,
                  precision="f32", center_length=None, crossing_time_gap=None, max_vehicles=64, slot_capacity=None,
-                 merge_right_of_way=True):
+                 merge_right_of_way=True, zipper_distance=50.0):
         super(SumoParams, self).__init__(sim_step, render, restart_instance, emission_path, save_render,
                                          sight_radius, show_radius, pxpm, force_color_update)
         self.port = port
@@ -209,6 +211,7 @@ class SumoParams(SimParams):
         self.max_vehicles = max_vehicles
         self.slot_capacity = slot_capacity
         self.merge_right_of_way = merge_right_of_way
+        self.zipper_distance = zipper_distance
 
 
 class EnvParams:

@@ -70,7 +70,7 @@ enum {
 enum { CELL_OBS_START = 0, CELL_OBS_LO = 1, CELL_OBS_HI = 2, CELL_ACT_START = 3, CELL_ACT_LO = 4, CELL_ACT_HI = 5 };
 
 enum { CNT_SIM_STEPS = 0, CNT_SEQ = 1, CNT_CTL = 2, CNT_ARRIVED = 3, CNT_DEPARTED = 4, CNT_TOTAL_ARRIVED = 5,
-       CNT_TOTAL_DEPARTED = 6 };
+       CNT_TOTAL_DEPARTED = 6, CNT_TOTAL_DROPPED = 7 };
 
 template <int SEG>
 __device__ __forceinline__ unsigned long long seg_ballot(bool pred, int seg) {
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
   int32_t* cnt = o.counters + size_t(rr) * 8;
   int sim_steps = cnt[CNT_SIM_STEPS], seq_ctr = cnt[CNT_SEQ], ctl_ctr = cnt[CNT_CTL];
   int n_arr = cnt[CNT_ARRIVED], n_dep = cnt[CNT_DEPARTED], tot_arr = cnt[CNT_TOTAL_ARRIVED],
-      tot_dep = cnt[CNT_TOTAL_DEPARTED];
+      tot_dep = cnt[CNT_TOTAL_DEPARTED], tot_drop = cnt[CNT_TOTAL_DROPPED];
   // vehicles emitted so far by inflow f of this replica: held by lane f of the replica's segment (SEG >= 8)
   int emit_l = (i < FS_MAX_INFLOWS) ? o.emitted[size_t(rr) * FS_MAX_INFLOWS + i] : 0;
 
@@ -641,7 +641,8 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         if (__ballot(due && live) == 0ull) continue;     // wave-uniform: this inflow is due in no replica of the wave
         const int typ = read_lane_i(ft_type, f);
         int route_f = read_lane_i(ft_route, f);
-        if (route_f < 0) {                               // M9: departLane = "random"
+        const bool random_lane = route_f < 0;
+        if (random_lane) {                               // M9: departLane = "random"
           uint32_t c0 = uint32_t(k), c1 = uint32_t(1000 + f), c2 = uint32_t(rr), c3 = 1u;
           philox4x32_10(c0, c1, c2, c3, s.seed_lo, s.seed_hi);
           route_f = int((uint64_t(c0 >> 8) * uint64_t(P)) >> 24);
@@ -681,10 +682,13 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         }
         if (ok) {
           seq_ctr += 1;
-          if (i == f) emit_l = k + 1;
           n_dep += 1;
           tot_dep += 1;
         }
+        // M9: a random-lane vehicle that does not fit when it is due is dropped, not retried
+        const bool consumed = ok || (random_lane && live && due);
+        if (consumed && i == f) emit_l = k + 1;
+        if (consumed && !ok) tot_drop += 1;
       }
       // ---- O1: new neighbour snapshot, sticky followers, collision check --------------------------------
       neighbours(live, true);
@@ -773,6 +777,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       cnt[CNT_DEPARTED] = n_dep;
       cnt[CNT_TOTAL_ARRIVED] = tot_arr;
       cnt[CNT_TOTAL_DEPARTED] = tot_dep;
+      cnt[CNT_TOTAL_DROPPED] = tot_drop;
     }
   }
   if (rvalid && live_replica && i < FS_MAX_INFLOWS) o.emitted[size_t(rr) * FS_MAX_INFLOWS + i] = emit_l;

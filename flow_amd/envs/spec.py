@@ -126,8 +126,11 @@ def build_open_spec(env, num_replicas, rng=None):
     network, net_k, veh_k = env.network, env.k.network, env.k.vehicle
     sp, ep = env.sim_params, env.env_params
     ap = network.net_params.additional_params
+    lane_drop = network.specify_lane_joins() is not None          # BottleneckNetwork
     if int(ap.get("merge_lanes", 1)) != 1 or int(ap.get("highway_lanes", 1)) != 1:
         raise NotImplementedError("multi-lane merge networks are not built in the HIP step loop yet")
+    if lane_drop and int(ap.get("scaling", 1)) != 1:
+        raise NotImplementedError("BottleneckNetwork with scaling > 1 is not built (4 -> 2 -> 1 lanes only)")
     tables = net_k.open_tables()
     R = int(num_replicas)
     flows = network.net_params.inflows.get()
@@ -138,6 +141,9 @@ def build_open_spec(env, num_replicas, rng=None):
         rl_types = [i for i, n in enumerate(names)
                     if veh_k.type_parameters[n]["acceleration_controller"][0] == RLController]
         caps[rl_types[0] if rl_types else 0] += int(ep.additional_params["num_rl"]) - sum(caps)
+    if lane_drop and sum(caps) < total:
+        # the bottleneck heads use one lane per lane-segment and need the full wave: spare slots stay empty
+        caps[max(range(len(caps)), key=lambda i: caps[i])] += total - sum(caps)
     N = sum(caps)
     if N < 1 or N > 64:
         raise NotImplementedError("open networks hold 1..64 vehicle slots per replica (got %d)" % N)
@@ -150,19 +156,25 @@ def build_open_spec(env, num_replicas, rng=None):
             slots.append(d)
     # initial vehicles: ids in VehicleParams order, the k-th vehicle of a type sits in the k-th slot of its pool
     ids = veh_k.get_ids()
-    pos, _ = net_k.generate_starting_positions(network.initial_config, len(ids)) if ids else ([], [])
+    pos, start_lanes = net_k.generate_starting_positions(network.initial_config, len(ids)) if ids else ([], [])
     alive = np.zeros((R, N), dtype=bool)
     X = np.zeros((R, N))
     V = np.zeros((R, N))
     route = np.zeros((R, N), dtype=np.int32)
     seen, init_slot = {}, {}
-    for veh_id, (edge, p) in zip(ids, pos):
+    for n_v, (veh_id, (edge, p)) in enumerate(zip(ids, pos)):
         name = veh_k.get_type(veh_id)
         k = seen.get(name, 0)
         seen[name] = k + 1
         i = base[name] + k
         init_slot[veh_id] = i
+        # Flow's edge-start table of the bottleneck does not match its edge lengths (bottleneck.py:232-234 vs
+        # :116-165), so gen_even_start_pos can return a position past the end of an edge: kept inside the edge
+        p = min(p, net_k.edge_length(edge) - 0.01)
         r, x = net_k.open_coordinate(edge, p)
+        if lane_drop:       # the path is the entry lane: lane l of an edge after j joins continues entry lane l << j
+            joins = sum(1 for m in (tables["merge1_x"], tables["merge2_x"]) if x >= m)
+            r = int(start_lanes[n_v]) << joins
         alive[:, i], X[:, i], route[:, i] = True, x, r
         V[:, i] = float(veh_k.get_initial_speed(veh_id))
     pert = network.initial_config.perturbation
@@ -176,6 +188,7 @@ def build_open_spec(env, num_replicas, rng=None):
             rel = np.clip(p + rng.normal(0, pert, R), 0, net_k.edge_length(edge) - 0.01)
             X[:, i] = x0 + rel
     first_edges = [p[0] for p in network.specify_open_routes()]
+    dt_ = sp.sim_step
     inflows = []
     for f in flows:
         if f["edge"] not in first_edges:
@@ -189,7 +202,19 @@ def build_open_spec(env, num_replicas, rng=None):
             ds = net_k.speed_limit(f["edge"])
         period = 3600.0 / float(f["vehsPerHour"]) if "vehsPerHour" in f else float(f["period"])
         tname = f["vtype"]
-        inflows.append(dict(type=names.index(tname), route=first_edges.index(f["edge"]), period=period,
+        flow_route = first_edges.index(f["edge"])
+        if lane_drop:                                      # the "route" of a lane-drop network is the entry lane
+            dl = f.get("departLane", "first")
+            if dl == "random":
+                flow_route = -1
+            elif dl == "first":
+                flow_route = 0
+            elif isinstance(dl, int) and 0 <= dl < tables["num_paths"]:
+                flow_route = int(dl)
+            else:
+                raise NotImplementedError("departLane=%r on a multi-lane edge is not built ('random', 'first' or a "
+                                          "lane index are)" % (dl,))
+        inflows.append(dict(type=names.index(tname), route=flow_route, period=period,
                             begin=float(f.get("begin", 1)), end=float(f.get("end", 86400)),
                             number=int(f["number"]) if "number" in f else -1, depart_speed=float(ds),
                             depart_pos=float(veh_k.type_parameters[tname].get("length", 5.0)), name=f["name"]))
@@ -199,14 +224,23 @@ def build_open_spec(env, num_replicas, rng=None):
     num_rl = int(ep.additional_params["num_rl"]) if env.FS_ENV == L.FS_ENV_MERGE_PO else n_rl_slots
     if env.FS_ENV == L.FS_ENV_MERGE_PO and num_rl > N:
         raise FatalFlowError("num_rl exceeds the vehicle slots of a replica")
+    extra = {}
+    if lane_drop:
+        obs_cells, act_cells = env._fs_cells(tables)
+        num_rl = len(act_cells)
+        extra = dict(obs_cells=obs_cells, action_cells=act_cells, scaling=int(ap.get("scaling", 1)),
+                     zipper_distance=float(getattr(sp, "zipper_distance", 50.0)),
+                     obs_outflow_window=max(1, min(20, int(20 * dt_ / dt_))),        # get_outflow_rate(20 * sim_step)
+                     reward_outflow_window=max(1, min(20, int(10 * dt_ / dt_))))     # get_outflow_rate(10 * sim_step)
     jm = getattr(sp, "junction_mode", None)
     tg = getattr(sp, "crossing_time_gap", None)
-    merge_len = float(ap["merge_length"])
+    merge_len = float(ap.get("merge_length", 0.0))
     spec = dict(
-        network="merge", num_replicas=R, num_vehicles=N, num_rl=num_rl, vehicles=slots,
+        network="bottleneck" if lane_drop else "merge", num_replicas=R, num_vehicles=N, num_rl=num_rl, vehicles=slots,
         init_alive=alive, init_pos=X, init_vel=V, init_route=route, inflows=inflows,
-        junction=dict(enabled=int(getattr(sp, "merge_right_of_way", True)), lookahead=merge_len,
-                      time_gap=1.0 if tg is None else float(tg)),
+        junction=dict(enabled=int(getattr(sp, "merge_right_of_way", True)) if not lane_drop else 0,
+                      lookahead=merge_len, time_gap=1.0 if tg is None else float(tg)),
+        speed_limit=float(net_k.speed_limit(first_edges[0])),
         sim_step=dt, slowdown_ramp=dt / (dt + 1e-3) if ramp is None else float(ramp),
         integrator="ballistic" if getattr(sp, "use_ballistic", False) else "euler",
         junction_mode=int(1 if jm is None else jm), junction_length=float(net_k.junction_length),
@@ -218,6 +252,7 @@ def build_open_spec(env, num_replicas, rng=None):
         horizon=ep.horizon, warmup_steps=int(ep.warmup_steps), sims_per_step=int(ep.sims_per_step),
         seed=int(sp.seed or 0), track_aux=True, ma_apply_actions=not bool(getattr(env, "APPLY_ENUMERATE_QUIRK", True)),
         slot_types=names, slot_base=base, slot_caps=dict(zip(names, caps)), init_slot=init_slot, **tables)
+    spec.update(extra)
     return spec
 
 
@@ -226,12 +261,13 @@ def build_spec(env, num_replicas, rng=None):
     network, net_k, veh_k = env.network, env.k.network, env.k.vehicle
     sp, ep = env.sim_params, env.env_params
     if network.specify_open_routes() is not None:
-        if env.FS_ENV not in (L.FS_ENV_MERGE_PO, L.FS_ENV_MERGE_MA):
-            raise NotImplementedError("%s on an open network is not built (MergePOEnv / MultiAgentMergePOEnv are)"
-                                      % type(env).__name__)
+        lane_drop = network.specify_lane_joins() is not None
+        ok = (L.FS_ENV_BOTTLENECK_DV, L.FS_ENV_BOTTLENECK) if lane_drop else (L.FS_ENV_MERGE_PO, L.FS_ENV_MERGE_MA)
+        if env.FS_ENV not in ok:
+            raise NotImplementedError("%s on %s is not built" % (type(env).__name__, type(network).__name__))
         return build_open_spec(env, num_replicas, rng)
-    if env.FS_ENV in (L.FS_ENV_MERGE_PO, L.FS_ENV_MERGE_MA):
-        raise NotImplementedError("the merge environments need an open network (MergeNetwork)")
+    if env.FS_ENV in (L.FS_ENV_MERGE_PO, L.FS_ENV_MERGE_MA, L.FS_ENV_BOTTLENECK_DV, L.FS_ENV_BOTTLENECK):
+        raise NotImplementedError("%s needs its open network (MergeNetwork / BottleneckNetwork)" % type(env).__name__)
     if not isinstance(network, (RingNetwork, FigureEightNetwork)):
         raise NotImplementedError("network %s is not built in the HIP step loop yet" % type(network).__name__)
     num_lanes = int(network.net_params.additional_params["lanes"])

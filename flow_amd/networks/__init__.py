@@ -3,5 +3,6 @@ from flow_amd.networks.base import Network
 from flow_amd.networks.ring import RingNetwork
 from flow_amd.networks.figure_eight import FigureEightNetwork
 from flow_amd.networks.merge import MergeNetwork
+from flow_amd.networks.bottleneck import BottleneckNetwork
 
-__all__ = ["Network", "RingNetwork", "FigureEightNetwork", "MergeNetwork"]
+__all__ = ["Network", "RingNetwork", "FigureEightNetwork", "MergeNetwork", "BottleneckNetwork"]

@@ -67,6 +67,10 @@ class Network(object):
     def specify_crossing(self):
         return None
 
+    def specify_lane_joins(self):
+        """Lane-drop networks: the edges at whose start the lanes have joined pairwise; None otherwise."""
+        return None
+
     def specify_open_routes(self):
         """Open networks list their driving paths (internal edges included, major route first, common
         last edges); None = a closed network."""

@@ -118,7 +118,8 @@ enum fs_field {
   FS_FIELD_CTL_SEQ = 18,   /* int32[R,N] >= 0: the vehicle is in MergePOEnv.rl_veh, value = order of joining */
   FS_FIELD_COUNTERS = 19,  /* int32[R,8] {steps since simulator start, vehicles ever departed (id counter), rl_veh
                               join counter, arrived last sub-step, departed last sub-step, arrived total,
-                              departed total, 0}  (get_num_arrived / get_outflow_rate inputs, vehicle/traci.py:493-533) */
+                              departed total, random-lane vehicles dropped at insertion}  (get_num_arrived /
+                              get_outflow_rate inputs, vehicle/traci.py:493-533) */
   FS_FIELD_ARRIVED_RL = 20,/* int32[R,N] 1: the RL vehicle of this slot arrived in the last sub-step (get_arrived_rl_ids) */
   FS_FIELD_MAX_SPEED = 21  /* real[R,N]  get_max_speed / set_max_speed: maxSpeed of the SUMO car-following model */
 };

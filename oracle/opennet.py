@@ -56,7 +56,8 @@ merge1_x = merge2_x.  Additional rules:
       join as its own (it follows the nearest vehicle ahead on either joining lane); a collision needs the two
       vehicles to be on one physical lane
   M9  departLane = "random": the entry lane of vehicle k of inflow f is floor(u * lanes), u from Philox keyed by
-      (seed; k, f, replica); drawn once, the insertion is retried until it fits (M3)
+      (seed; k, f, replica); "the vehicle insertion is not retried if it could not be inserted"
+      (flow/core/params.py:1118-1119 quoting SUMO): a vehicle that does not fit when it is due is dropped
   M10 the desired speed of the SUMO car-following model is min(vehicle maxSpeed, edge speed limit); maxSpeed is
       per vehicle and changed by BottleneckDesiredVelocityEnv (setMaxSpeed)
   O6  BottleneckDesiredVelocityEnv (flow/envs/bottleneck.py:866-986): per (edge, segment, lane) vehicle counts
@@ -155,6 +156,7 @@ class MergeOracle:
         self.num_departed = np.zeros(R, dtype=np.int64)
         self.total_arrived = np.zeros(R, dtype=np.int64)
         self.total_departed = np.zeros(R, dtype=np.int64)
+        self.total_dropped = np.zeros(R, dtype=np.int64)          # vehicles of random-lane inflows that did not fit
         self.arrived_rl = np.zeros((R, N), dtype=bool)             # RL slots that arrived in the last sub-step
         self._just_arrived = np.zeros((R, N), dtype=bool)
 
@@ -388,7 +390,7 @@ class MergeOracle:
         self._just_arrived = np.where(m2, False, self._just_arrived)
         self.time_counter = np.where(m, 0, self.time_counter)
         self.sim_steps = np.where(m, 1, self.sim_steps)                    # S13: one step ran during the reset
-        for a in (self.num_arrived, self.num_departed, self.total_arrived, self.total_departed):
+        for a in (self.num_arrived, self.num_departed, self.total_arrived, self.total_departed, self.total_dropped):
             a[m] = 0
         self.arrived_rl = np.where(m2, False, self.arrived_rl)
         self._update_neighbours(m)
@@ -455,7 +457,10 @@ class MergeOracle:
             self.ctl_seq[r_ok, s_ok] = -1
             self.pis_n[r_ok, s_ok] = 0
             self.seq_ctr = self.seq_ctr + ok
-            self.emitted[:, f] = k + ok
+            # M9: with departLane = "random" SUMO does not retry a vehicle it could not insert: it is dropped
+            consumed = (active & due) if int(fl["route"]) < 0 else ok
+            self.total_dropped = self.total_dropped + (consumed & ~ok)
+            self.emitted[:, f] = k + consumed
             self.num_departed = self.num_departed + ok
             self.total_departed = self.total_departed + ok
 

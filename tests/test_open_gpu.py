@@ -52,6 +52,7 @@ def compare_state(sim, ora, exact=True, atol=0.0):
     np.testing.assert_array_equal(cnt[:, 4], ora.num_departed)
     np.testing.assert_array_equal(cnt[:, 5], ora.total_arrived)
     np.testing.assert_array_equal(cnt[:, 6], ora.total_departed)
+    np.testing.assert_array_equal(cnt[:, 7], ora.total_dropped)
 
 
 def run_pair(spec, precision, steps, action_fn=None, check_every=10, exact=True, atol=0.0):
