@@ -16,7 +16,7 @@ observation/reward/done to the learner per fragment.
 
 Prints ONE JSON line (rank 0).  Extra keys: `roofline` (dominant kernel =
 k_steps, per-launch HIP-event timing), `cpu_baseline` (oracle C port on the host
-cores, bounded sample, rank 0, N=1 only), `c5_merge` (open-network kernel, informational), `step_api` (one launch per env step,
+cores, bounded sample, rank 0, N=1 only), `c4_bottleneck` / `c5_merge` (open-network kernel, informational), `step_api` (one launch per env step,
 the Gym-faithful call pattern), `f64` (same workload in float64).
 """
 import argparse
@@ -216,6 +216,70 @@ def c5_leg(device, R=1024, env_steps=600):
     return res
 
 
+def c4_leg(device, R=128, env_steps=1000):
+    """BASELINE configs[3] (informational, not the headline): BottleneckNetwork scaling 1 (4 -> 2 -> 1 lanes at two
+    zipper junctions), inflow 2300 veh/h (10 % RL) with random entry lanes, all vehicles on the SUMO car-following
+    model, BottleneckDesiredVelocityEnv head (141 observations, 20 actions), sim_step 0.5, warm-up 40 + horizon 1000
+    (examples/exp_configs/rl/singleagent/singleagent_bottleneck.py); 128 replicas per GPU = 1024 over 8 GPUs."""
+    import torch
+    from flow_amd import _lib as L
+    from flow_amd.controllers import ContinuousRouter, RLController, SimLaneChangeController
+    from flow_amd.core.params import (EnvParams, InFlows, InitialConfig, NetParams, SumoCarFollowingParams,
+                                      SumoLaneChangeParams, SumoParams, VehicleParams)
+    from flow_amd.envs import BottleneckDesiredVelocityEnv, VecFlowEnv
+    from flow_amd.networks import BottleneckNetwork
+    veh = VehicleParams()
+    veh.add(veh_id="human", lane_change_controller=(SimLaneChangeController, {}),
+            routing_controller=(ContinuousRouter, {}),
+            car_following_params=SumoCarFollowingParams(speed_mode="all_checks"),
+            lane_change_params=SumoLaneChangeParams(lane_change_mode=0), num_vehicles=1)
+    veh.add(veh_id="followerstopper", acceleration_controller=(RLController, {}),
+            lane_change_controller=(SimLaneChangeController, {}), routing_controller=(ContinuousRouter, {}),
+            car_following_params=SumoCarFollowingParams(speed_mode=9),
+            lane_change_params=SumoLaneChangeParams(lane_change_mode=0), num_vehicles=1)
+    add = {"target_velocity": 40, "disable_tb": True, "disable_ramp_metering": True,
+           "controlled_segments": [("1", 1, False), ("2", 2, True), ("3", 2, True), ("4", 2, True), ("5", 1, False)],
+           "symmetric": False, "observed_segments": [("1", 1), ("2", 3), ("3", 3), ("4", 3), ("5", 1)],
+           "reset_inflow": False, "lane_change_duration": 5, "max_accel": 3, "max_decel": 3,
+           "inflow_range": [1000, 2000]}
+    inflow = InFlows()
+    inflow.add(veh_type="human", edge="1", vehs_per_hour=2300 * 0.9, depart_lane="random", depart_speed=10)
+    inflow.add(veh_type="followerstopper", edge="1", vehs_per_hour=2300 * 0.1, depart_lane="random", depart_speed=10)
+    fp = dict(exp_tag="DesiredVelocity", env_name=BottleneckDesiredVelocityEnv, network=BottleneckNetwork,
+              simulator="traci", sim=SumoParams(sim_step=0.5, render=False, restart_instance=True, seed=5),
+              env=EnvParams(warmup_steps=40, sims_per_step=1, horizon=1000, additional_params=add),
+              net=NetParams(inflows=inflow, additional_params={"scaling": 1, "speed_limit": 23}), veh=veh,
+              initial=InitialConfig(spacing="uniform", min_gap=5, lanes_distribution=float("inf"),
+                                    edges_distribution=["2", "3", "4", "5"]))
+    vec = VecFlowEnv(fp, num_replicas=R, device=device.index)
+    K = env_steps
+    gen = torch.Generator(device=device).manual_seed(3)
+    tape = (torch.rand((K, R, vec.act_dim), device=device, generator=gen) * 2 - 1) * 1.5
+    out = (torch.empty((K, R, vec.obs_dim), dtype=torch.float32, device=device),
+           torch.empty((K, R), dtype=torch.float32, device=device),
+           torch.empty((K, R), dtype=torch.uint8, device=device))
+    vec.reset()
+    vec.sim.rollout_dev(50, out[0][:50], out[1][:50], out[2][:50], actions=tape[:50])       # warm-up launch
+    vec.reset()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    vec.sim.rollout_dev(K, *out, actions=tape)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    cnt = vec.sim.get_state(L.FS_FIELD_COUNTERS)
+    route = vec.sim.get_state(L.FS_FIELD_ROUTE)
+    res = {"value": R * K / dt, "unit": "env-steps/s", "env_steps": K, "replicas": R, "obs_dim": vec.obs_dim,
+           "act_dim": vec.act_dim, "vehicles_in_network_mean": float((route >= 0).sum(axis=1).mean()),
+           "departed_mean": float(cnt[:, 6].mean()), "arrived_mean": float(cnt[:, 5].mean()),
+           "dropped_at_insertion_mean": float(cnt[:, 7].mean()),
+           "outflow_veh_per_hour_mean": float(out[1][-200:].mean().item() * 2000.0),
+           "workload": "C4: BottleneckNetwork 4->2->1 lanes, inflow 2300 veh/h (10 % RL, random lanes), 64 slots, "
+                       "BottleneckDesiredVelocityEnv head (141 obs / 20 actions), sim_step 0.5, one 1000-step episode "
+                       "after 40 warm-up steps, random actions; k_steps_open<.,64,4>"}
+    vec.close()
+    return res
+
+
 def cpu_baseline(spec_fn, seconds=12.0):
     """Oracle C port (oracle/csim) on the host cores, bounded sample of the same workload."""
     from oracle import cbuild
@@ -381,6 +445,7 @@ def main():
         r2.sim.close()
         out["c3_figure_eight"] = c3_leg(device)
         out["c3_figure_eight_po"] = c3_leg(device, po=True)
+        out["c4_bottleneck"] = c4_leg(device)
         out["c5_merge"] = c5_leg(device)
         out["cpu_baseline"] = cpu_baseline(lambda r: c2_spec(r, seed=1000))
 

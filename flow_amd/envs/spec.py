@@ -131,6 +131,13 @@ def build_open_spec(env, num_replicas, rng=None):
         raise NotImplementedError("multi-lane merge networks are not built in the HIP step loop yet")
     if lane_drop and int(ap.get("scaling", 1)) != 1:
         raise NotImplementedError("BottleneckNetwork with scaling > 1 is not built (4 -> 2 -> 1 lanes only)")
+    if lane_drop:
+        for name, tp in veh_k.type_parameters.items():
+            mode = int(tp["lane_change_params"].lane_change_mode)
+            if mode & 0b01010101:      # SUMO laneChangeMode: strategic / cooperative / speed-gain / keep-right changes
+                raise NotImplementedError(
+                    "vehicle type %r has lane_change_mode=%d: SUMO's own lane changing (LC2013) is not built on the "
+                    "lane-drop network; the shipped bottleneck experiments run with lane_change_mode=0" % (name, mode))
     tables = net_k.open_tables()
     R = int(num_replicas)
     flows = network.net_params.inflows.get()

@@ -1,4 +1,7 @@
-"""The C5 merge leg of bench.py on its own (for profiling k_steps_open): prints one JSON object."""
+"""The C5 merge / C4 bottleneck leg of bench.py on its own (for profiling k_steps_open): prints one JSON object.
+
+    python scripts/bench_c5.py [replicas] [c5|c4]
+"""
 import json
 import os
 import sys
@@ -9,4 +12,6 @@ if __name__ == "__main__":
     import torch
     import bench
     R = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-    print(json.dumps(bench.c5_leg(torch.device("cuda", 0), R=R)))
+    leg = sys.argv[2] if len(sys.argv) > 2 else "c5"
+    fn = bench.c4_leg if leg == "c4" else bench.c5_leg
+    print(json.dumps(fn(torch.device("cuda", 0), R=R)))

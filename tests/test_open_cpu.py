@@ -310,3 +310,159 @@ def test_open_config_validation_needs_no_gpu():
         s = spec()
         s["vehicles"] = [idm_vehicle(controller=S.CTRL_PISATURATION, type=0)] + s["vehicles"][1:]
         FlowSim(s, "f32")
+
+
+# ------------------------------------------------------------------ lane drops (BottleneckNetwork)
+def test_bottleneck_oracle_facts():
+    from helpers import bottleneck_spec
+    spec = bottleneck_spec(R=3, horizon=500, seed=1)
+    o = O.MergeOracle(spec, np.float64)
+    o.reset()
+    paths = {}
+    rng = np.random.default_rng(0)
+    lanes_seen = set()
+    for k in range(500):
+        obs, rew, done = o.step(rng.uniform(-1.0, 1.0, (3, 20)))
+        assert not done.any() or k == 499                      # the zipper look-ahead keeps the joins collision-free
+        # nobody ever changes path (lane_change_mode = 0); a path is an entry lane 0..3
+        for r in range(3):
+            for i in np.flatnonzero(o.alive[r]):
+                key = (r, int(o.seq[r, i]))
+                assert paths.setdefault(key, int(o.route[r, i])) == int(o.route[r, i])
+                lanes_seen.add(int(o.route[r, i]))
+        # maxSpeed of RL vehicles stays inside the env's clip, humans keep the type value
+        vm = o.vmax[:, 40:][o.alive[:, 40:]]              # 30 = the type value of a vehicle no action has reached yet
+        assert (((vm <= 23.0) & (vm >= 0.01)) | (vm == 30.0)).all()
+        assert (o.vmax[:, :40] == 30.0).all()
+        # nobody drives faster than the edge limit allows (+ one step of acceleration tolerance)
+        assert (o.v[o.alive] <= 23.0 + 1e-9).all()
+        # observation: counts are multiples of 1/20, outflow consistent with the arrival history
+        C = 35
+        cnt = obs[:, :2 * C] * 20
+        np.testing.assert_allclose(cnt, np.round(cnt), atol=1e-9)
+        on_edges = np.array([(o.alive[r] & ~o._segment_lookup(o.x, o.route)[0][r]).sum() for r in range(3)])
+        np.testing.assert_array_equal(np.round(cnt).sum(axis=1).astype(int), on_edges)
+    assert lanes_seen == {0, 1, 2, 3} and o.total_arrived.min() > 60
+    # reward = arrivals of the last 10 steps as a rate / 2000; observed outflow = last 20 steps
+    last10 = np.array([o.arr_hist[r][[(o.time_counter[r] - 1 - k) % 20 for k in range(10)]].sum() for r in range(3)])
+    np.testing.assert_allclose(rew, 3600 * last10 / (10 * 0.5) / 2000.0)
+
+
+def test_bottleneck_cell_lookup_by_hand():
+    from helpers import bottleneck_spec, bottleneck_tables
+    tb = bottleneck_tables()
+    spec = bottleneck_spec(R=1, horizon=10)
+    o = O.MergeOracle(spec, np.float64)
+    o.reset()
+    o.route[:] = -1
+    # edge 2 starts at 100.1 (3 observed segments of 103.33 m, 2 controlled ones of 155 m), edge 4 at 570.2 (2 lanes)
+    for slot, (x, path) in enumerate([(100.1 + 10.0, 3), (100.1 + 200.0, 1), (570.2 + 279.0, 2), (100.05, 0),
+                                      (100.1, 2)]):
+        o.route[0, slot], o.x[0, slot] = path, x
+    cells = o._cell_of(o.cells, last_of_edge=True)[0]
+    names = [("1", 0)] * 0
+    idx = {}
+    c = 0
+    for edge, n in [("1", 1), ("2", 3), ("3", 3), ("4", 3), ("5", 1)]:
+        lanes = {"1": 4, "2": 4, "3": 4, "4": 2, "5": 1}[edge]
+        for k in range(n):
+            for lane in range(lanes):
+                idx[(edge, k, lane)] = c
+                c += 1
+    assert cells[0] == idx[("2", 0, 3)] and cells[1] == idx[("2", 1, 1)]
+    assert cells[2] == idx[("4", 2, 1)]                       # path 2 drives lane 1 after the first join
+    assert cells[3] == -1                                     # on the internal edge ':2_0': not observed
+    assert cells[4] == idx[("2", 2, 2)]                       # exactly at the edge start: bucket -1 = last segment
+    act = o._cell_of(o.ctl_cells)[0]
+    assert act[0] == 0 * 4 + 3 and act[1] == 1 * 4 + 1 and act[2] == 16 + 1 * 2 + 1 and act[3] == -1 and act[4] == -1
+
+
+def test_zipper_lookahead_orders_the_joining_lanes():
+    """M8: inside zipper_distance of a join a vehicle follows the nearest vehicle of either joining lane."""
+    from helpers import bottleneck_spec
+    spec = bottleneck_spec(R=1, horizon=10, zipper_distance=50.0)
+    o = O.MergeOracle(spec, np.float64)
+    o.reset()
+    o.route[:] = -1
+    m1 = float(o.m1)
+    for slot, (x, path) in enumerate([(m1 - 20.0, 0), (m1 - 8.0, 1), (m1 - 70.0, 1), (m1 - 60.0, 2), (m1 + 30.0, 3)]):
+        o.route[0, slot], o.x[0, slot] = path, x
+    o._update_neighbours(np.ones(1, bool))
+    assert o.lead[0, 0] == 1                    # lane 0 inside the zone: the lane-1 vehicle ahead is its leader
+    assert not o.lead_same_lane[0, 0]           # ... but they are not on one physical lane yet: no collision test
+    assert o.lead[0, 2] == 1 and o.lead_same_lane[0, 2]      # outside the zone: own lane only
+    assert o.lead[0, 3] == 4 and o.lead[0, 1] == -1          # path 2 joins path 3's lane; path 1's lane is free ahead
+
+
+def test_bottleneck_network_tables_and_spec(monkeypatch):
+    from helpers import bottleneck_tables
+    from test_host import build_env
+    from flow_amd import _lib as L
+    from flow_amd.core.kernel.network import NetworkKernel
+    from flow_amd.core import params as P
+    from flow_amd.envs import BottleneckDesiredVelocityEnv
+    from flow_amd.networks import BottleneckNetwork
+    from flow_amd.controllers import RLController, SimLaneChangeController, ContinuousRouter
+    with pytest.raises(KeyError):
+        BottleneckNetwork("b", P.VehicleParams(), P.NetParams(additional_params={"scaling": 1}))
+    v = P.VehicleParams()
+    v.add(veh_id="human", lane_change_controller=(SimLaneChangeController, {}), routing_controller=(ContinuousRouter, {}),
+          car_following_params=P.SumoCarFollowingParams(speed_mode="all_checks"),
+          lane_change_params=P.SumoLaneChangeParams(lane_change_mode=0), num_vehicles=1)
+    v.add(veh_id="followerstopper", acceleration_controller=(RLController, {}),
+          car_following_params=P.SumoCarFollowingParams(speed_mode=9),
+          lane_change_params=P.SumoLaneChangeParams(lane_change_mode=0), num_vehicles=1)
+    inflow = P.InFlows()
+    inflow.add(veh_type="human", edge="1", vehs_per_hour=2070, departLane="random", departSpeed=10)
+    inflow.add(veh_type="followerstopper", edge="1", vehs_per_hour=230, departLane="random", departSpeed=10)
+    net = BottleneckNetwork("b", v, P.NetParams(inflows=inflow, additional_params={"scaling": 1, "speed_limit": 23}),
+                            P.InitialConfig(spacing="uniform", min_gap=5, lanes_distribution=float("inf"),
+                                            edges_distribution=["2", "3", "4", "5"]))
+    k = NetworkKernel(net, junction_length=0.1)
+    t, ref = k.open_tables(), bottleneck_tables()
+    for key in ("merge1_x", "merge2_x", "end_x", "net_length", "num_paths", "box_in"):
+        assert abs(t[key] - ref[key]) < 1e-9, key
+    np.testing.assert_allclose(np.array(t["routes"][0]["segments"], float),
+                               np.array(ref["routes"][0]["segments"], float), atol=1e-9)
+    assert net.get_bottleneck_lanes(3) == [1, 0] and k.num_lanes("4") == 2 and k.max_speed() == 23
+    add = {"target_velocity": 40, "disable_tb": True, "disable_ramp_metering": True,
+           "controlled_segments": [("1", 1, False), ("2", 2, True), ("3", 2, True), ("4", 2, True), ("5", 1, False)],
+           "symmetric": False, "observed_segments": [("1", 1), ("2", 3), ("3", 3), ("4", 3), ("5", 1)],
+           "reset_inflow": False, "lane_change_duration": 5, "max_accel": 3, "max_decel": 3, "inflow_range": [1000, 2000]}
+    env, spec = build_env(monkeypatch, BottleneckDesiredVelocityEnv,
+                          P.EnvParams(warmup_steps=40, horizon=1000, additional_params=add),
+                          P.SumoParams(sim_step=0.5, restart_instance=True), net)
+    assert spec["network"] == "bottleneck" and spec["env"] == L.FS_ENV_BOTTLENECK_DV and spec["num_paths"] == 4
+    assert spec["num_vehicles"] == 64 and spec["num_rl"] == 20 and len(spec["obs_cells"]) == 35
+    assert spec["obs_outflow_window"] == 20 and spec["reward_outflow_window"] == 10 and spec["speed_limit"] == 23
+    assert spec["junction"]["enabled"] == 0 and spec["zipper_distance"] == 50.0
+    assert env.observation_space.shape == (141,) and env.action_space.shape == (20,)
+    assert env.action_index == {"2": [0], "3": [8], "4": [16]}
+    from helpers import segment_cells
+    assert spec["obs_cells"] == segment_cells(ref, [("1", 1), ("2", 3), ("3", 3), ("4", 3), ("5", 1)])
+    assert spec["action_cells"] == segment_cells(ref, [("2", 2), ("3", 2), ("4", 2)])
+    # SUMO's own lane changing is not modelled: such configurations are refused, not silently altered
+    v2 = P.VehicleParams()
+    v2.add(veh_id="human", lane_change_params=P.SumoLaneChangeParams(lane_change_mode=1621), num_vehicles=1)
+    v2.add(veh_id="followerstopper", acceleration_controller=(RLController, {}), num_vehicles=1)
+    net2 = BottleneckNetwork("b", v2, P.NetParams(inflows=inflow, additional_params={"scaling": 1, "speed_limit": 23}))
+    with pytest.raises(NotImplementedError, match="lane_change_mode"):
+        build_env(monkeypatch, BottleneckDesiredVelocityEnv, P.EnvParams(additional_params=add), P.SumoParams(), net2)
+    with pytest.raises(NotImplementedError, match="scaling"):
+        net3 = BottleneckNetwork("b", v, P.NetParams(inflows=inflow, additional_params={"scaling": 2, "speed_limit": 23}))
+        build_env(monkeypatch, BottleneckDesiredVelocityEnv, P.EnvParams(additional_params=add), P.SumoParams(), net3)
+
+
+def test_bottleneck_config_validation_needs_no_gpu():
+    from flow_amd import build
+    build.build()
+    from helpers import bottleneck_spec
+    from flow_amd.sim import FlowSim
+    with pytest.raises(NotImplementedError, match="more than 32 vehicle slots"):
+        FlowSim(bottleneck_spec(R=1, cap_human=20, cap_rl=4), "f32")
+    with pytest.raises(ValueError, match="go together"):
+        FlowSim(bottleneck_spec(R=1, env=O.ENV_MERGE_PO), "f32")
+    with pytest.raises(ValueError, match="outflow windows"):
+        FlowSim(bottleneck_spec(R=1, obs_outflow_window=30), "f32")
+    with pytest.raises(ValueError, match="merge1_x <= merge2_x"):
+        FlowSim(bottleneck_spec(R=1, merge1_x=900.0), "f32")
