@@ -341,6 +341,7 @@ def main():
 
     R = args.replicas
     spec = c2_spec(R, seed=1000 + rank)
+    spec["replica_offset"] = rank * R          # global replica ids (noise streams do not depend on the sharding)
     runner = Runner(spec, args.precision, device, args.fragment)
 
     gather = None

@@ -97,7 +97,8 @@ class fs_config(C.Structure):
                 ("num_obs_cells", C.c_int32), ("merge1_x", C.c_double), ("merge2_x", C.c_double),
                 ("zipper_distance", C.c_double), ("speed_limit", C.c_double), ("outflow_norm", C.c_double),
                 ("obs_cells", C.POINTER(fs_cell)), ("act_cells", C.POINTER(fs_cell)),
-                ("obs_outflow_window", C.c_int32), ("reward_outflow_window", C.c_int32)]
+                ("obs_outflow_window", C.c_int32), ("reward_outflow_window", C.c_int32),
+                ("replica_offset", C.c_int64)]
 
 
 _lib = None

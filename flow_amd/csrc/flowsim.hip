@@ -233,6 +233,7 @@ struct Sim : SimBase {
     dv.flags = flags;
     dv.seed_lo = uint32_t(cfg.seed & 0xFFFFFFFFull);
     dv.seed_hi = uint32_t(cfg.seed >> 32);
+    dv.rep0 = uint32_t(cfg.replica_offset);
     dv.dt = T(cfg.sim_step);
     dv.ramp = T(cfg.slowdown_ramp);
     dv.jlen = T(cfg.junction_length);
@@ -737,6 +738,7 @@ int validate(const fs_config* c) {
       if (c->init_lane[e] < 0 || c->init_lane[e] >= (c->num_lanes < 1 ? 1 : c->num_lanes))
         return fail(FS_ERR_INVALID, "fs_create: init_lane out of range");
   if (c->num_replicas < 1) return fail(FS_ERR_INVALID, "fs_create: num_replicas < 1");
+  if (c->replica_offset < 0) return fail(FS_ERR_INVALID, "fs_create: replica_offset < 0");
   if (c->num_vehicles < 1) return fail(FS_ERR_INVALID, "fs_create: num_vehicles < 1");
   if (c->num_vehicles > 64)
     return fail(FS_ERR_UNSUPPORTED, "fs_create: more than 64 vehicles per replica is not built yet");

@@ -72,6 +72,7 @@ struct DevView {
   int step_limit;       // sims_per_step*(warmup+horizon), INT_MAX for horizon=inf
   int flags;
   uint32_t seed_lo, seed_hi;
+  uint32_t rep0;        // global index of this handle's replica 0: noise streams are keyed by GLOBAL replica ids
   T dt, ramp, jlen, crash_gap, max_speed, target_velocity, max_cost, act_lo, act_hi, po_max_length;
   T lc_duration;
   // non-ring closed loops (figure eight): edge table in route order + the crossing model (S-J)
@@ -501,7 +502,7 @@ __device__ __forceinline__ T control_accel_on(const DevView<T>& s, const Slot<T>
     commanded = on_edge;
     if (ct == FS_CTRL_LAC && commanded && live) cst = a;
     if (flags & FLAG_HAS_NOISE) {                // base_controller.py:109-110
-      if (sl.noise > T(0)) a = a + sl.noise * gauss<T>(s.seed_lo, s.seed_hi, uint32_t(rr), uint32_t(ii), nctr);
+      if (sl.noise > T(0)) a = a + sl.noise * gauss<T>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(ii), nctr);
     }
     if (has) {                                   // base_controller.py:113-116, 141-142, 191-193
       if (sl.failsafe == FS_FAILSAFE_INSTANTANEOUS) a = failsafe_instantaneous(a, v, h, has, s.dt);

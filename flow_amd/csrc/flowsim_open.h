@@ -643,7 +643,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         int route_f = read_lane_i(ft_route, f);
         const bool random_lane = route_f < 0;
         if (random_lane) {                               // M9: departLane = "random"
-          uint32_t c0 = uint32_t(k), c1 = uint32_t(1000 + f), c2 = uint32_t(rr), c3 = 1u;
+          uint32_t c0 = uint32_t(k), c1 = uint32_t(1000 + f), c2 = s.rep0 + uint32_t(rr), c3 = 1u;
           philox4x32_10(c0, c1, c2, c3, s.seed_lo, s.seed_hi);
           route_f = int((uint64_t(c0 >> 8) * uint64_t(P)) >> 24);
         }

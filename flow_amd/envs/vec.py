@@ -14,10 +14,11 @@ from flow_amd import _lib as L
 class VecFlowEnv(object):
     """Parameters: either ``flow_params`` (the reference's dict: env_name, network, env, sim, net,
     veh, initial; flow/utils/registry.py:29-46) or the four objects ``env_class, env_params,
-    sim_params, network``.  ``device`` is the HIP ordinal of this process' GPU."""
+    sim_params, network``.  ``device`` is the HIP ordinal of this process' GPU; ``replica_offset`` the global index
+    of this process' first replica when a job is sharded over GPUs (noise streams follow global replica ids)."""
 
     def __init__(self, flow_params=None, num_replicas=4096, device=0, env_class=None, env_params=None,
-                 sim_params=None, network=None, seed=None):
+                 sim_params=None, network=None, seed=None, replica_offset=0):
         import torch
         self.torch = torch
         if flow_params is not None:
@@ -36,6 +37,7 @@ class VecFlowEnv(object):
         env = env_class.__new__(env_class)
         env.num_replicas = self.num_envs
         env._device_index = int(device)
+        env._replica_offset = int(replica_offset)     # global index of replica 0 (flow_amd.dist.shard_range)
         env.__init__(env_params, sim_params, network)
         if env.FS_ENV is None:
             env.terminate()

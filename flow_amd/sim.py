@@ -170,7 +170,8 @@ class FlowSim:
             zipper_distance=float(spec.get("zipper_distance", 0.0)), speed_limit=float(spec.get("speed_limit", 0.0)),
             outflow_norm=2000.0 * float(spec.get("scaling", 1)), obs_cells=obs_cells, act_cells=act_cells,
             obs_outflow_window=int(spec.get("obs_outflow_window", 20)),
-            reward_outflow_window=int(spec.get("reward_outflow_window", 10)))
+            reward_outflow_window=int(spec.get("reward_outflow_window", 10)),
+            replica_offset=int(spec.get("replica_offset", 0)))
         if self.open_net:
             cfg.route_start[0] = float(spec["routes"][0]["start"])
             cfg.route_start[1] = float(spec["routes"][min(1, len(spec["routes"]) - 1)]["start"])

@@ -260,6 +260,11 @@ typedef struct fs_config {
   const fs_cell* act_cells;           /* [num_rl] controlled lane-segments, action column order */
   int32_t obs_outflow_window;         /* int(20 * sim_step / sim_step): sub-steps of the observed outflow */
   int32_t reward_outflow_window;      /* int(10 * sim_step / sim_step) */
+  /* ---- sharding ---- */
+  int64_t replica_offset;             /* global index of this handle's replica 0 (one handle per GPU holds a contiguous
+                                         block of the job's replicas): the Philox streams (acceleration noise, random
+                                         entry lanes) are keyed by offset + local index, so a replica's trajectory does
+                                         not depend on how the job is sharded */
 } fs_config;
 
 typedef struct fs_sim* fs_handle;

@@ -416,7 +416,8 @@ class MergeOracle:
             typ = int(fl["type"])
             if int(fl["route"]) < 0:                                      # M9: departLane = "random"
                 r0, _, _, _ = philox4x32_10(k.astype(np.uint32), np.full(R, 1000 + f, dtype=np.uint32),
-                                            np.arange(R, dtype=np.uint32), np.ones(R, dtype=np.uint32),
+                                            (np.arange(R) + int(self.spec.get("replica_offset", 0))).astype(np.uint32),
+                                            np.ones(R, dtype=np.uint32),
                                             np.uint32(int(self.spec.get("seed", 0)) & 0xFFFFFFFF),
                                             np.uint32((int(self.spec.get("seed", 0)) >> 32) & 0xFFFFFFFF))
                 route = (((r0 >> np.uint32(8)).astype(np.int64) * self.P) >> 24)

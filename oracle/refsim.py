@@ -164,7 +164,8 @@ def controller_dispatch(o, v, v_lead, h, has_lead, v_follow, h_follow, rl_value,
             o.lac_a[sl] = np.where(cmd & active, a, o.lac_a[sl])
         if vs.get("noise", 0) > 0:                                # base_controller.py:109-110
             slot = np.full(R, i, dtype=np.uint32) if noise_slot is None else noise_slot[sl].astype(np.uint32)
-            g = gaussian_noise(o.spec.get("seed", 0), np.arange(R, dtype=np.uint32), slot,
+            g = gaussian_noise(o.spec.get("seed", 0),
+                               (np.arange(R) + int(o.spec.get("replica_offset", 0))).astype(np.uint32), slot,
                                o.step_counter.astype(np.uint32), o.dt_)
             a = a + T(vs["noise"]) * g
         fs = vs.get("fail_safe", FAILSAFE_NONE)

@@ -269,3 +269,30 @@ def test_bottleneck_without_zipper_lookahead_crashes_at_the_joins():
         crashed |= d_ref & (ora.time_counter < 400)
     assert crashed.any()
     sim.close()
+
+
+def test_sharded_open_network_handles_reproduce_the_unsharded_run():
+    """Random entry lanes (M9) are drawn from the GLOBAL replica id: shards [0, 3) + [3, 8) == one handle of 8."""
+    from helpers import bottleneck_spec
+    spec = bottleneck_spec(R=8, cap_human=44, cap_rl=6, horizon=150, seed=21)
+    whole = make(spec, "f32")
+    parts = []
+    for lo, hi in ((0, 3), (3, 8)):
+        sub = dict(spec, num_replicas=hi - lo, replica_offset=lo)
+        for key in ("init_alive", "init_pos", "init_vel", "init_route"):
+            sub[key] = np.asarray(spec[key])[lo:hi]
+        parts.append(make(sub, "f32"))
+    whole.reset()
+    [p.reset() for p in parts]
+    acts = bottleneck_actions(spec, 6)
+    for k in range(150):
+        a = acts(k)
+        o_w, r_w, d_w = whole.step(a)
+        outs = [p.step(a[lo:hi]) for p, (lo, hi) in zip(parts, ((0, 3), (3, 8)))]
+        np.testing.assert_array_equal(o_w, np.concatenate([o[0] for o in outs]))
+        np.testing.assert_array_equal(r_w, np.concatenate([o[1] for o in outs]))
+    from flow_amd import _lib as L
+    np.testing.assert_array_equal(whole.get_state(L.FS_FIELD_ROUTE),
+                                  np.concatenate([p.get_state(L.FS_FIELD_ROUTE) for p in parts]))
+    for s in [whole] + parts:
+        s.close()

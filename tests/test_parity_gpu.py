@@ -666,3 +666,40 @@ def test_abi_rejects_bad_configs():
     from flow_amd.utils.exceptions import FatalFlowError
     with pytest.raises(FatalFlowError):
         make(bad, "f32")
+
+
+def test_sharded_handles_reproduce_the_unsharded_run_bit_for_bit():
+    """a replica's trajectory does not depend on how the job is sharded -- two handles holding replicas
+    [0, 5) and [5, 12) (replica_offset 5) of a noisy configuration equal one handle holding all twelve."""
+    spec = perturbed(ring_spec(R=12, N=14, junction_length=0.1, horizon=120), seed=3)
+    spec["vehicles"] = [idm_vehicle(noise=0.3) for _ in range(14)]
+    spec["seed"] = 77
+    whole = make(spec, "f32")
+    parts = []
+    for lo, hi in ((0, 5), (5, 12)):
+        sub = dict(spec, num_replicas=hi - lo, init_pos=np.asarray(spec["init_pos"])[lo:hi],
+                   ring_length=np.asarray(spec["ring_length"])[lo:hi], replica_offset=lo)
+        parts.append(make(sub, "f32"))
+    whole.reset()
+    [p.reset() for p in parts]
+    for _ in range(120):
+        o_w, r_w, d_w = whole.step(None)
+        outs = [p.step(None) for p in parts]
+    np.testing.assert_array_equal(o_w, np.concatenate([o[0] for o in outs]))
+    np.testing.assert_array_equal(r_w, np.concatenate([o[1] for o in outs]))
+    np.testing.assert_array_equal(whole.vel, np.concatenate([p.vel for p in parts]))
+    assert not np.array_equal(parts[0].vel[:5], parts[1].vel[:5])       # and the shards are not copies of each other
+    # the float32 oracle with the same offset follows the noisy shard to libm tolerance
+    ora = S.RingOracle(dict(spec, num_replicas=7, init_pos=np.asarray(spec["init_pos"])[5:12],
+                            ring_length=np.asarray(spec["ring_length"])[5:12], replica_offset=5), np.float32)
+    ora.reset()
+    for _ in range(20):
+        ora.step(None)
+    again = make(dict(spec, num_replicas=7, init_pos=np.asarray(spec["init_pos"])[5:12],
+                      ring_length=np.asarray(spec["ring_length"])[5:12], replica_offset=5), "f32")
+    again.reset()
+    for _ in range(20):
+        again.step(None)
+    np.testing.assert_allclose(again.vel, ora.v, rtol=0, atol=1e-4)
+    for s in [whole, again] + parts:
+        s.close()
