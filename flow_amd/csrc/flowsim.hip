@@ -345,18 +345,28 @@ struct Sim : SimBase {
       ov.obs_dim = obs_dim;
       std::vector<T> ct(6 * 64, T(0));
       std::vector<int32_t> cti(2 * 64, 0);
-      for (size_t c = 0; c < obs_cells.size(); ++c) {
-        ct[fs::CELL_OBS_START * 64 + c] = T(obs_cells[c].edge_start);
-        ct[fs::CELL_OBS_LO * 64 + c] = T(obs_cells[c].lo);
-        ct[fs::CELL_OBS_HI * 64 + c] = T(obs_cells[c].hi);
-        cti[c] = obs_cells[c].lane | (obs_cells[c].last_segment ? 256 : 0);
-      }
-      for (size_t c = 0; c < act_cells.size(); ++c) {
-        ct[fs::CELL_ACT_START * 64 + c] = T(act_cells[c].edge_start);
-        ct[fs::CELL_ACT_LO * 64 + c] = T(act_cells[c].lo);
-        ct[fs::CELL_ACT_HI * 64 + c] = T(act_cells[c].hi);
-        cti[64 + c] = act_cells[c].lane;
-      }
+      // consecutive cells that differ only in the lane (lane l, l+1, ...) form one group
+      auto group = [&](const std::vector<fs_cell>& cells, int row_start, int row_lo, int row_hi, int row_i) {
+        int g = 0;
+        for (size_t c = 0; c < cells.size();) {
+          size_t e = c + 1;
+          while (e < cells.size() && cells[e].edge_start == cells[c].edge_start && cells[e].lo == cells[c].lo &&
+                 cells[e].hi == cells[c].hi && cells[e].last_segment == cells[c].last_segment &&
+                 cells[e].lane == cells[c].lane + int(e - c))
+            ++e;
+          ct[size_t(row_start) * 64 + g] = T(cells[c].edge_start);
+          ct[size_t(row_lo) * 64 + g] = T(cells[c].lo);
+          ct[size_t(row_hi) * 64 + g] = T(cells[c].hi);
+          cti[size_t(row_i) * 64 + g] = int(c) | (int(e - c) << 8) | (cells[c].lane << 16) |
+                                         ((cells[c].last_segment ? 1 : 0) << 24);
+          ++g;
+          c = e;
+        }
+        return g;
+      };
+      ov.n_obs_groups = group(obs_cells, fs::CELL_OBS_START, fs::CELL_OBS_LO, fs::CELL_OBS_HI, 0);
+      ov.n_act_groups = group(act_cells, fs::CELL_ACT_START, fs::CELL_ACT_LO, fs::CELL_ACT_HI, 1);
+      ov.track_followers = cfg.track_followers;
       if ((rc = upload(&ov.cell_tab, ct))) return rc;
       if ((rc = upload(&ov.cell_tab_i, cti))) return rc;
     }
@@ -666,6 +676,8 @@ int validate(const fs_config* c) {
   const bool bn_env = c->env == FS_ENV_BOTTLENECK_DV || c->env == FS_ENV_BOTTLENECK;
   if ((c->network == FS_NET_MERGE) != merge_env)
     return fail(FS_ERR_INVALID, "fs_create: the merge envs and FS_NET_MERGE go together");
+  if (c->network == FS_NET_MERGE && !c->track_followers)
+    return fail(FS_ERR_INVALID, "fs_create: the merge observations need track_followers = 1");
   if ((c->network == FS_NET_BOTTLENECK) != bn_env)
     return fail(FS_ERR_INVALID, "fs_create: the bottleneck envs and FS_NET_BOTTLENECK go together");
   if (c->network == FS_NET_BOTTLENECK) {
@@ -681,6 +693,11 @@ int validate(const fs_config* c) {
     if (c->env == FS_ENV_BOTTLENECK_DV) {
       if (c->num_obs_cells < 1 || c->num_obs_cells > 64 || !c->obs_cells)
         return fail(FS_ERR_INVALID, "fs_create: 1..64 observation cells");
+      for (int k = 0; k < c->num_obs_cells; ++k)
+        if (c->obs_cells[k].lane < 0 || c->obs_cells[k].lane > 63) return fail(FS_ERR_INVALID, "fs_create: cell lane");
+      for (int k = 0; k < c->num_rl; ++k)
+        if (c->act_cells && (c->act_cells[k].lane < 0 || c->act_cells[k].lane > 63))
+          return fail(FS_ERR_INVALID, "fs_create: cell lane");
       if (c->num_rl < 0 || c->num_rl > 64 || (c->num_rl > 0 && !c->act_cells))
         return fail(FS_ERR_INVALID, "fs_create: 0..64 action cells");
     }

@@ -49,9 +49,10 @@ struct OpenView {
   // lane drops (M8-M10): lanes 2q, 2q+1 join at m1, the resulting lanes at m2 (two paths: m1 == m2 == merge_x)
   T m1, m2, zip_d, speed_limit;
   // bottleneck heads (O6 / O7)
-  const T* cell_tab;           // [6][64] lane c: edge start / lo / hi of observation cell c, of action cell c
-  const int32_t* cell_tab_i;   // [2][64] lane c: lane | is_last_segment << 8 of observation cell c, lane of action cell c
-  int n_obs_cells, n_act_cells, obs_window, rew_window, obs_dim;
+  // lane-segments are stored as GROUPS of cells that differ only in the lane: lane g of the tables holds group g
+  const T* cell_tab;           // [6][64] edge start / lo / hi of observation group g, of action group g
+  const int32_t* cell_tab_i;   // [2][64] first cell | lanes << 8 | first lane << 16 | is_last_segment << 24 (obs / action)
+  int n_obs_cells, n_act_cells, n_obs_groups, n_act_groups, obs_window, rew_window, obs_dim, track_followers;
   T out_norm;                  // 2000 * scaling
 };
 
@@ -202,9 +203,12 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
   const size_t idx = size_t(rr) * N + ii;
   const int flags = s.flags;
   const int env = s.env;
-  const bool po_env = (env == FS_ENV_MERGE_PO);
-  const bool bn_env = (SEG == 64) && (env == FS_ENV_BOTTLENECK_DV || env == FS_ENV_BOTTLENECK);
-  const bool dv_env = (SEG == 64) && (env == FS_ENV_BOTTLENECK_DV);
+  // the env families are tied to the network (validated by fs_create): P == 2 merge heads, P == 4 bottleneck heads;
+  // making that a compile-time fact keeps each instantiation free of the other family's code and registers
+  const bool po_env = (P == 2) && (env == FS_ENV_MERGE_PO);
+  const bool bn_env = (P == 4) && (SEG == 64) && (env == FS_ENV_BOTTLENECK_DV || env == FS_ENV_BOTTLENECK);
+  const bool dv_env = (P == 4) && (SEG == 64) && (env == FS_ENV_BOTTLENECK_DV);
+  const bool track_foll = (P == 2) ? true : (o.track_followers != 0);
 
   Slot<T> sl;
   sl.ctrl = s.ctrl[ii];
@@ -296,17 +300,13 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
   //   rank       place of the vehicle in the order "x ascending, equal x: higher slot first"; free slots rank last
   //   sorted_slot  lane segbase+p holds the slot whose rank is p (one ds_permute push; the ranks of a segment are a
   //              permutation of 0..SEG-1)
-  //   B0, B1     bit p: the vehicle of rank p is on route 0 / 1;   SH  bit p: it is past the merge point
+  //   B[q], R1, R2  bit p: the vehicle of rank p is on path q / has passed the first / the second join (ballots over
+  //              the (path, joins) key pushed to the rank's lane the same way)
   // leader(i)   = lowest set bit above rank_i of (B_route(i) | SH)
   // followers(X) = for each route, the highest set bit of B_r below rank_X, if that vehicle's leader is X
   int lead = -1;
   T vl = T(-1001), h = T(1000);
   bool has = false, lead_same_lane = false;
-  auto or64 = [&](unsigned long long m) -> unsigned long long {
-    const unsigned lo = seg_or<SEG>(unsigned(m));
-    const unsigned hi = SEG == 64 ? seg_or<SEG>(unsigned(m >> 32)) : 0u;
-    return ((unsigned long long)hi << 32) | lo;
-  };
   auto neighbours = [&](bool live, bool follow) {
     const bool alive = route >= 0;
     const T xr = alive ? x : BIGV;
@@ -320,12 +320,17 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
     const unsigned long long am = seg_ballot<SEG>(alive, seg);
     if (!alive) rank = __popcll(am) + __popcll(~am & segmask & ((1ull << i) - 1ull));
     const int sorted_slot = __builtin_amdgcn_ds_permute((segbase + rank) << 2, i);
+    // the same push for (path, joins upstream of the vehicle): once the lanes hold these in rank order the
+    // per-path / per-region masks are plain ballots
+    const int my_key = alive ? (route | (shift_of(x) << 8)) : 0xffff;
+    const int skey = __builtin_amdgcn_ds_permute((segbase + rank) << 2, my_key);
+    const bool s_alive = skey != 0xffff;
     const unsigned long long bit = 1ull << rank;
     unsigned long long B[P];
 #pragma unroll
-    for (int q = 0; q < P; ++q) B[q] = or64(alive && route == q ? bit : 0ull);
-    const unsigned long long R1 = or64(alive && x >= o.m1 ? bit : 0ull);
-    const unsigned long long R2 = (P == 2) ? R1 : or64(alive && x >= o.m2 ? bit : 0ull);
+    for (int q = 0; q < P; ++q) B[q] = seg_ballot<SEG>(s_alive && (skey & 0xff) == q, seg);
+    const unsigned long long R1 = seg_ballot<SEG>(s_alive && (skey >> 8) >= 1, seg);
+    const unsigned long long R2 = (P == 2) ? R1 : seg_ballot<SEG>(s_alive && (skey >> 8) >= 2, seg);
     unsigned long long ALL = 0ull, own = 0ull;
 #pragma unroll
     for (int q = 0; q < P; ++q) {
@@ -439,24 +444,35 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       route_lookup<NR>(o, tab_start, tab_flow, tab_slope, x, route, internal, fx);
       const int my_lane = (route < 0 ? 0 : route) >> shift_of(x);
       int ocell = -1;
-      for (int c = 0; c < o.n_obs_cells; ++c) {
-        const T pos = x - read_lane(co_start, c);
-        const int cl = read_lane_i(co_lane, c);
-        bool inside = (pos > read_lane(co_lo, c)) && (pos <= read_lane(co_hi, c));
-        if (cl >> 8) inside = inside || (pos == T(0));   // np.searchsorted(..) - 1 == -1: the edge's last segment
-        if (alive && !internal && inside && my_lane == (cl & 0xff) && ocell < 0) ocell = c;
+      for (int g = 0; g < o.n_obs_groups; ++g) {
+        const T pos = x - read_lane(co_start, g);
+        const int meta = read_lane_i(co_lane, g);
+        bool inside = (pos > read_lane(co_lo, g)) && (pos <= read_lane(co_hi, g));
+        if (meta >> 24) inside = inside || (pos == T(0));   // np.searchsorted(..) - 1 == -1: the edge's last segment
+        const int rel = my_lane - ((meta >> 16) & 0xff);
+        if (alive && !internal && inside && rel >= 0 && rel < ((meta >> 8) & 0xff) && ocell < 0)
+          ocell = (meta & 0xff) + rel;
       }
-      // ... then lane c gathers cell c, vehicles in slot order
-      int cnt_h = 0, cnt_r = 0;
+      // ... then lane c collects cell c: who is in it (one ballot per cell and class), then their speeds in slot order
+      unsigned long long mh = 0ull, mr = 0ull;
+      for (int c = 0; c < o.n_obs_cells; ++c) {
+        const unsigned long long bh = __ballot(ocell == c && !is_rl);
+        const unsigned long long br = __ballot(ocell == c && is_rl);
+        if (lane_id == c) { mh = bh; mr = br; }
+      }
+      const int cnt_h = __popcll(mh), cnt_r = __popcll(mr);
       T sp_h = T(0), sp_r = T(0);
-      for (unsigned long long u = occupied_slots(); u; u &= u - 1ull) {
-        const int j = __ffsll((long long)u) - 1;
-        const int cj = read_lane_i(ocell, j);
-        const T vj = read_lane(v, j);
-        const bool rj = read_lane_i(is_rl ? 1 : 0, j) != 0;
-        const bool mine = cj == lane_id;
-        if (mine && rj) { cnt_r += 1; sp_r = sp_r + vj; }
-        if (mine && !rj) { cnt_h += 1; sp_h = sp_h + vj; }
+      while (__ballot(mh != 0ull) != 0ull) {
+        const int j = mh ? __ffsll((long long)mh) - 1 : 0;
+        const T vj = bperm(v, j);
+        if (mh) sp_h = sp_h + vj;
+        mh &= mh - 1ull;
+      }
+      while (__ballot(mr != 0ull) != 0ull) {
+        const int j = mr ? __ffsll((long long)mr) - 1 : 0;
+        const T vj = bperm(v, j);
+        if (mr) sp_r = sp_r + vj;
+        mr &= mr - 1ull;
       }
       const int C = o.n_obs_cells;
       const T nh = T(cnt_h) / T(20), nr = T(cnt_r) / T(20);          // NUM_VEHICLE_NORM
@@ -502,7 +518,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
   if (num_steps == 0) {
     // after_reset: update(reset=True) registers the followers of the initial placement (vehicle/traci.py:219-250)
     if (after_reset) {
-      neighbours(live_replica, true);
+      neighbours(live_replica, track_foll);
       if (valid && live_replica) {
         o.foll[idx] = foll;
         o.foll_h[idx] = foll_h;
@@ -553,10 +569,13 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       if (dv_env && act != nullptr) {
         const int my_lane = (route < 0 ? 0 : route) >> shift_of(x);
         int acell = -1;
-        for (int c = 0; c < o.n_act_cells; ++c) {
-          const T pos = x - read_lane(ca_start, c);
-          const bool inside = (pos > read_lane(ca_lo, c)) && (pos <= read_lane(ca_hi, c));
-          if (alive && !internal && inside && my_lane == read_lane_i(ca_lane, c) && acell < 0) acell = c;
+        for (int g = 0; g < o.n_act_groups; ++g) {
+          const T pos = x - read_lane(ca_start, g);
+          const bool inside = (pos > read_lane(ca_lo, g)) && (pos <= read_lane(ca_hi, g));
+          const int meta = read_lane_i(ca_lane, g);
+          const int rel = my_lane - ((meta >> 16) & 0xff);
+          if (alive && !internal && inside && rel >= 0 && rel < ((meta >> 8) & 0xff) && acell < 0)
+            acell = (meta & 0xff) + rel;
         }
         T a = acell >= 0 ? T(act[acell]) : T(0);
         if (s.clip_actions) a = tmin(tmax(a, s.act_lo), s.act_hi);
@@ -691,7 +710,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         if (consumed && !ok) tot_drop += 1;
       }
       // ---- O1: new neighbour snapshot, sticky followers, collision check --------------------------------
-      neighbours(live, true);
+      neighbours(live, track_foll);
       bool c = seg_any<SEG>((route >= 0) && has && lead_same_lane && (h < s.crash_gap), seg);
       if (s.junction_on) {
         const bool inside = (route >= 0) && (x >= o.box_in) && (x < o.merge_x);

@@ -236,6 +236,8 @@ def build_open_spec(env, num_replicas, rng=None):
         obs_cells, act_cells = env._fs_cells(tables)
         num_rl = len(act_cells)
         extra = dict(obs_cells=obs_cells, action_cells=act_cells, scaling=int(ap.get("scaling", 1)),
+                     track_followers=False,                          # no bottleneck env reads get_follower
+
                      zipper_distance=float(getattr(sp, "zipper_distance", 50.0)),
                      obs_outflow_window=max(1, min(20, int(20 * dt_ / dt_))),        # get_outflow_rate(20 * sim_step)
                      reward_outflow_window=max(1, min(20, int(10 * dt_ / dt_))))     # get_outflow_rate(10 * sim_step)

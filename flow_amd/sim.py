@@ -171,6 +171,7 @@ class FlowSim:
             outflow_norm=2000.0 * float(spec.get("scaling", 1)), obs_cells=obs_cells, act_cells=act_cells,
             obs_outflow_window=int(spec.get("obs_outflow_window", 20)),
             reward_outflow_window=int(spec.get("reward_outflow_window", 10)),
+            track_followers=int(bool(spec.get("track_followers", True))), reserved4=0,
             replica_offset=int(spec.get("replica_offset", 0)))
         if self.open_net:
             cfg.route_start[0] = float(spec["routes"][0]["start"])

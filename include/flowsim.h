@@ -260,6 +260,9 @@ typedef struct fs_config {
   const fs_cell* act_cells;           /* [num_rl] controlled lane-segments, action column order */
   int32_t obs_outflow_window;         /* int(20 * sim_step / sim_step): sub-steps of the observed outflow */
   int32_t reward_outflow_window;      /* int(10 * sim_step / sim_step) */
+  int32_t track_followers;            /* open networks: 1 = keep the sticky follower entries (FS_FIELD_FOLLOWER, used by the
+                                         merge observations and BCM); 0 = skip them (the bottleneck envs never read them) */
+  int32_t reserved4;
   /* ---- sharding ---- */
   int64_t replica_offset;             /* global index of this handle's replica 0 (one handle per GPU holds a contiguous
                                          block of the job's replicas): the Philox streams (acceleration noise, random

@@ -241,7 +241,7 @@ class MergeOracle:
         better = (best < start_h) & (best < T(BIG))
         new_f = np.where(better, bj, start_f)
         new_h = np.where(better, best, start_h)
-        upd = a2 & alive
+        upd = a2 & alive & bool(self.spec.get("track_followers", True))
         self.foll = np.where(upd, new_f, self.foll)
         self.foll_h = np.where(upd, new_h, self.foll_h)
         return has

@@ -223,7 +223,7 @@ def bottleneck_spec(R=4, cap_human=40, cap_rl=8, horizon=300, seed=0, q=2300.0, 
                 horizon=horizon, warmup_steps=warmup_steps, sims_per_step=1, vehicles=veh, seed=seed,
                 junction=dict(enabled=0, lookahead=0.0, time_gap=1.0), junction_mode=1, speed_limit=23.0,
                 zipper_distance=zipper_distance, scaling=1, obs_cells=obs_cells, action_cells=act_cells,
-                obs_outflow_window=20, reward_outflow_window=10,
+                obs_outflow_window=20, reward_outflow_window=10, track_followers=False,
                 inflows=[dict(type=0, route=-1, period=3600.0 / (q * (1 - av_frac)), begin=1.0, end=86400.0, number=-1,
                               depart_speed=10.0, depart_pos=5.0),
                          dict(type=1, route=-1, period=3600.0 / (q * av_frac), begin=1.0, end=86400.0, number=-1,
