@@ -418,7 +418,7 @@ class VehicleKernel(object):
             if vid not in self.__rl_ids:
                 raise NotImplementedError(
                     "apply_acceleration on a non-RL vehicle: its controller runs in the HIP kernel")
-            self._pending[vid] = float(a)
+            self._pending[vid] = float(np.asarray(a, dtype=np.float64).reshape(-1)[0])
 
     def apply_lane_change(self, veh_ids, direction):
         """vehicle/traci.py:965-997: direction validation kept; single-lane networks clip to lane 0."""

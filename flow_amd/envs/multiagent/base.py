@@ -34,6 +34,7 @@ class MultiEnv(_MA, Env):
         self.k.update(reset=False)
         self.time_counter = int(self.sim.time_counter[0])
         self._last_obs, self._last_reward = obs[0], float(rew[0])
+        self.k.simulation.crashed = False
         crash = 0                                                    # multiagent/base.py:188-190
         states = self.get_state()
         arrived = self.k.vehicle.get_arrived_ids() or []
@@ -73,5 +74,3 @@ class MultiEnv(_MA, Env):
             return
         self._apply_rl_actions(self.clip_actions(rl_actions))
 
-    def _action_vector(self):
-        return None

@@ -39,7 +39,7 @@ class VecFlowEnv(object):
         env._device_index = int(device)
         env._replica_offset = int(replica_offset)     # global index of replica 0 (flow_amd.dist.shard_range)
         env.__init__(env_params, sim_params, network)
-        if env.FS_ENV is None:
+        if env.FS_ENV is None or getattr(env, "HOST_HEADS", False):
             env.terminate()
             raise NotImplementedError("VecFlowEnv needs an env with an in-kernel observation/reward head")
         self.env = env
