@@ -71,6 +71,14 @@ class VehicleKernel(object):
         self.__rl_ids.sort()                                         # vehicle/traci.py:259, 366
         self.num_vehicles = len(self.__ids)
         self.num_rl_vehicles = len(self.__rl_ids)
+        self._order = list(self.__ids)                               # id of the vehicle in slot i (ring order)
+
+    def set_slot_order(self, order):
+        """InitialConfig.shuffle (envs/base.py:268-292): the start positions were handed out in shuffled id order,
+        so slot i (i-th position along the loop) holds ``order[i]``; get_ids() keeps its order."""
+        assert sorted(order) == sorted(self.__ids)
+        self._order = list(order)
+        self._slot = {v: i for i, v in enumerate(order)}
 
     def attach(self, sim, replica=0):
         self.sim, self.replica = sim, replica
@@ -90,7 +98,7 @@ class VehicleKernel(object):
 
     def _sid(self, i):
         """id of the vehicle in slot i."""
-        return self._slot_id[i] if self._open else self.__ids[i]
+        return self._slot_id[i] if self._open else self._order[i]
 
     def _new_vehicle(self, veh_id, type_name):
         tp = self.type_parameters[type_name]
@@ -288,7 +296,7 @@ class VehicleKernel(object):
                 j = int(self._field(L.FS_FIELD_LEADER)[i])
                 return self._sid(j) if j >= 0 else None
             return self._vec(veh_id, lead, error)
-        return self._vec(veh_id, lambda i: self.__ids[(i + 1) % n] if n > 1 else None, error)
+        return self._vec(veh_id, lambda i: self._order[(i + 1) % n] if n > 1 else None, error)
 
     def get_follower(self, veh_id, error=""):
         n = self.num_vehicles
@@ -304,9 +312,9 @@ class VehicleKernel(object):
                 if not cand:
                     return None
                 hw = self._field(L.FS_FIELD_HEADWAY)
-                return self.__ids[min(cand, key=lambda j: hw[j])]      # vehicle/traci.py:243-250
+                return self._order[min(cand, key=lambda j: hw[j])]     # vehicle/traci.py:243-250
             return self._vec(veh_id, foll, error)
-        return self._vec(veh_id, lambda i: self.__ids[(i - 1) % n] if n > 1 else None, error)
+        return self._vec(veh_id, lambda i: self._order[(i - 1) % n] if n > 1 else None, error)
 
     def get_max_speed(self, veh_id, error=-1001):
         """maxSpeed of the SUMO car-following model of the vehicle (vehicle/traci.py get_max_speed)."""
@@ -376,11 +384,11 @@ class VehicleKernel(object):
                 ahead = (float(x[j]) - float(x[i])) % Lloop
                 behind = (float(x[i]) - float(x[j])) % Lloop
                 if dl is None or ahead < dl:
-                    dl, lead, best_h = ahead, self.__ids[j], ahead - self.__vehicles[self.__ids[j]]["length"]
+                    dl, lead, best_h = ahead, self._order[j], ahead - self.__vehicles[self._order[j]]["length"]
                 # bisect_left semantics (vehicle/traci.py:826-848): a vehicle at the same position counts
                 # as the leader of that lane, never as the follower
                 if behind > 0 and (df is None or behind < df):
-                    df, foll, best_t = behind, self.__ids[j], behind - self.__vehicles[self.__ids[i]]["length"]
+                    df, foll, best_t = behind, self._order[j], behind - self.__vehicles[self._order[i]]["length"]
             out.append((lead, best_h, foll, best_t))
         return out
 

@@ -44,6 +44,7 @@ struct SimBase {
   std::vector<fs_segment> segs;
   std::vector<fs_inflow> inflows;
   std::vector<fs_cell> obs_cells, act_cells;
+  std::vector<int32_t> obs_perm;
   std::vector<uint8_t> init_alive;
   int obs_dim = 0;
   int act_dim = 0;
@@ -115,6 +116,12 @@ struct Sim : SimBase {
       if ((rc = upload(&dv.init_lane, il))) return rc;
     }
     if ((rc = dev_alloc(&dv.time, size_t(R)))) return rc;
+    if ((rc = dev_alloc(&dv.sort_key, RN))) return rc;
+    dv.sort_vehicles = cfg.sort_vehicles;
+    dv.obs_perm = nullptr;
+    if (!obs_perm.empty()) {
+      if ((rc = upload(&dv.obs_perm, obs_perm))) return rc;
+    }
     if ((rc = dev_alloc(&dv.noise_ctr, size_t(R)))) return rc;
     HIP_TRY(hipMemset(dv.noise_ctr, 0, size_t(R) * sizeof(uint32_t)));
     HIP_TRY(hipMemset(dv.time, 0, size_t(R) * sizeof(int32_t)));
@@ -447,7 +454,7 @@ struct Sim : SimBase {
     return (f & fs::FLAG_ALL_IDM) && !(f & (fs::FLAG_HAS_NOISE | fs::FLAG_HAS_FAILSAFE | fs::FLAG_NEED_SUMO)) &&
            dv.env == FS_ENV_ACCEL && !dv.evaluate && dv.sims_per_step == 1 && dv.integrator == FS_EULER &&
            !dv.junction_mode && !dv.track_aux && mask == nullptr && num_steps > 0 && !force_generic &&
-           dv.nseg == 0 && !dv.junction_on;
+           dv.nseg == 0 && !dv.junction_on && !dv.sort_vehicles && dv.obs_perm == nullptr;
   }
 
   template <int SEG>
@@ -756,6 +763,21 @@ int validate(const fs_config* c) {
         return fail(FS_ERR_INVALID, "fs_create: init_lane out of range");
   if (c->num_replicas < 1) return fail(FS_ERR_INVALID, "fs_create: num_replicas < 1");
   if (c->replica_offset < 0) return fail(FS_ERR_INVALID, "fs_create: replica_offset < 0");
+  if (c->sort_vehicles || c->obs_perm) {
+    if (c->env != FS_ENV_ACCEL && c->sort_vehicles)
+      return fail(FS_ERR_INVALID, "fs_create: sort_vehicles belongs to AccelEnv");
+    if (c->num_lanes > 1 || c->network == FS_NET_MERGE || c->network == FS_NET_BOTTLENECK)
+      return fail(FS_ERR_UNSUPPORTED, "fs_create: sort_vehicles / shuffled ids are built for single-lane closed loops");
+    if (c->obs_perm) {
+      unsigned long long seen = 0ull;
+      for (int i = 0; i < c->num_vehicles && i < 64; ++i) {
+        const int q = c->obs_perm[i];
+        if (q < 0 || q >= c->num_vehicles || (seen >> q) & 1ull)
+          return fail(FS_ERR_INVALID, "fs_create: obs_perm is not a permutation");
+        seen |= 1ull << q;
+      }
+    }
+  }
   if (c->num_vehicles < 1) return fail(FS_ERR_INVALID, "fs_create: num_vehicles < 1");
   if (c->num_vehicles > 64)
     return fail(FS_ERR_UNSUPPORTED, "fs_create: more than 64 vehicles per replica is not built yet");
@@ -827,6 +849,7 @@ int create_typed(const fs_config* cfg, fs_handle* out) {
   s->cfg = *cfg;
   s->veh.assign(cfg->vehicles, cfg->vehicles + cfg->num_vehicles);
   if (cfg->num_segments > 0) s->segs.assign(cfg->segments, cfg->segments + cfg->num_segments);
+  if (cfg->obs_perm) s->obs_perm.assign(cfg->obs_perm, cfg->obs_perm + cfg->num_vehicles);
   if (cfg->network == FS_NET_MERGE || cfg->network == FS_NET_BOTTLENECK) {
     if (cfg->num_inflows > 0) s->inflows.assign(cfg->inflows, cfg->inflows + cfg->num_inflows);
     s->init_alive.assign(cfg->init_alive, cfg->init_alive + size_t(cfg->num_replicas) * cfg->num_vehicles);
@@ -885,6 +908,7 @@ int create_typed(const fs_config* cfg, fs_handle* out) {
   s->cfg.inflows = nullptr;
   s->cfg.init_alive = nullptr;
   s->cfg.obs_cells = nullptr;
+  s->cfg.obs_perm = nullptr;
   s->cfg.act_cells = nullptr;
   *out = reinterpret_cast<fs_handle>(static_cast<SimBase*>(s));
   return FS_OK;

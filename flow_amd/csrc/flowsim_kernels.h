@@ -48,6 +48,8 @@ struct DevView {
   int32_t* pis_n;       // [R, n_pis] speeds appended so far
   const int32_t* pis_index;   // [N] index among the PISaturation slots, -1 otherwise
   int32_t* time;        // [R]
+  T* sort_key;          // [R,N] AccelEnv.absolute_position of the last additional_command (sort_vehicles only)
+  const int32_t* obs_perm;   // [N] place of the slot's vehicle in get_ids() (InitialConfig.shuffle), or NULL = identity
   uint32_t* noise_ctr;  // [R]
   const T* init_pos;
   const T* init_vel;
@@ -68,7 +70,7 @@ struct DevView {
   const T* sumo_max_speed;
   // scalars
   int R, N, num_rl, env, integrator, sims_per_step, junction_mode, clip_actions, evaluate, track_aux;
-  int num_lanes, lane_change_mode, last_lc_quirk, n_pis, pis_H;
+  int num_lanes, lane_change_mode, last_lc_quirk, n_pis, pis_H, sort_vehicles;
   int step_limit;       // sims_per_step*(warmup+horizon), INT_MAX for horizon=inf
   int flags;
   uint32_t seed_lo, seed_hi;
@@ -151,6 +153,29 @@ __device__ __forceinline__ double read_lane(double v, int lane) {
   int lo = __builtin_amdgcn_readlane(int(b), lane), hi = __builtin_amdgcn_readlane(int(b >> 32), lane);
   return __builtin_bit_cast(double, (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
 }
+// value that slot j (wave-uniform) of MY segment holds: v_readlane broadcasts through an SGPR, no LDS round trip
+__device__ __forceinline__ int read_lane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+template <int SEG>
+__device__ __forceinline__ int seg_read_i(int v, int j, int seg) {
+  int out = read_lane_i(v, j);
+#pragma unroll
+  for (int sg = 1; sg < 64 / SEG; ++sg) {
+    const int f = read_lane_i(v, sg * SEG + j);
+    out = (seg == sg) ? f : out;
+  }
+  return out;
+}
+template <int SEG, typename T>
+__device__ __forceinline__ T seg_read(T v, int j, int seg) {
+  T out = read_lane(v, j);
+#pragma unroll
+  for (int sg = 1; sg < 64 / SEG; ++sg) {
+    const T f = read_lane(v, sg * SEG + j);
+    out = (seg == sg) ? f : out;
+  }
+  return out;
+}
+
 // v + (value of the other 16-lane row of the pair): v_permlane16_swap_b32 (new on gfx950).
 // The two operands are made opaque copies first: given the SAME SSA value twice, hipcc 7.2 folds
 // the two results of the builtin into one register (it emitted v_add_f32 v,v,v after the swap).
@@ -605,6 +630,25 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
   d = d < T(0) ? d + L : d;
   T h = has ? d - len_lead : T(1000);
 
+  // observation / action ORDER (accel.py:101-123, 150-169): get_ids() order = obs_perm (identity unless the start
+  // positions were shuffled); with sort_vehicles the vehicles are ordered by the absolute position recorded at the
+  // last additional_command (= the position before the last move), ties in id order (sorted() is stable)
+  const bool sorted = !FAST && s.sort_vehicles != 0;
+  const int perm_i = (!FAST && s.obs_perm != nullptr) ? s.obs_perm[ii] : ii;
+  T xs = sorted ? s.sort_key[idx] : T(0);
+  auto order_rank = [&](bool rl_only) -> int {
+    int rk = 0;
+    const int me_rl = (sl.ctrl == FS_CTRL_RL) ? 1 : 0;
+    for (int j = 0; j < N; ++j) {
+      const T xj = seg_read<SEG>(xs, j, seg);
+      const int pj = seg_read_i<SEG>(perm_i, j, seg);
+      const int rlj = seg_read_i<SEG>(me_rl, j, seg);
+      const bool before = (xj < xs) || (xj == xs && pj < perm_i);
+      if (before && (!rl_only || rlj != 0)) rk += 1;
+    }
+    return rk;
+  };
+
   const T dt = s.dt;
   const int env = FAST ? int(FS_ENV_ACCEL) : s.env;
   const int obs_dim = (env == FS_ENV_WAVE_ATTENUATION_PO) ? 3 : 2 * N;
@@ -653,9 +697,21 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
         }
         if (flags & FLAG_NEED_MEAN) mean_v = seg_sum<SEG>(valid ? v : T(0)) / T(N);
         const bool have_rl = rl_lane && (act != nullptr);
-        const T a_rl = have_rl ? T(a_own) : T(0);
+        T a_rl = have_rl ? T(a_own) : T(0);
+        if (sorted && act != nullptr) {                  // accel.py:103-107: the k-th RL vehicle in sorted order
+          const int col = order_rank(true);
+          if (have_rl) a_rl = T(act[col]);
+        }
         acc = control_accel(s, sl, flags, v, vl, h, has, vf, hf, mean_v, x, quarter, qj, have_rl, a_rl,
                             live && i < N, rr, ii, nctr, cst, commanded);
+        if (sorted && live) {                            // accel.py:150-169 additional_command: position before the move
+          T xa = x;
+          if (s.nseg > 0) {
+            bool internal;
+            segment_lookup(s, x, internal, xa);
+          }
+          xs = xa;
+        }
       }
       // ---- apply_acceleration + SUMO integration (S4-S9) ------------------
       T next_vel = tmax(v + acc * dt, T(0));          // vehicle/traci.py:962
@@ -711,6 +767,7 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
     // ---- get_state / compute_reward / done (envs/base.py:387-412) ---------
     const bool emit = obs_every_step || (step == num_steps - 1);
     if (emit) {
+      const int oi = FAST ? ii : (sorted ? order_rank(false) : perm_i);
       if (env == FS_ENV_WAVE_ATTENUATION_PO) {
         // wave_attenuation.py:248-269; written by the RL vehicle's lane
         if (valid && sl.ctrl == FS_CTRL_RL && sl.rl_index == 0) {
@@ -724,8 +781,8 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
           bool internal;
           segment_lookup(s, x, internal, xo);
         }
-        orow[ii] = float(v / s.max_speed);               // accel.py:118-119
-        orow[N + ii] = float(xo / L);                    // accel.py:120-121
+        orow[oi] = float(v / s.max_speed);               // accel.py:118-119
+        orow[N + oi] = float(xo / L);                    // accel.py:120-121
       }
       // reward
       T reward;
@@ -767,6 +824,7 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
   }
 
   if (num_steps == 0) {   // observation of the current state only (Env.reset, envs/base.py:544-551)
+    const int oi = FAST ? ii : (sorted ? order_rank(false) : perm_i);
     if (env == FS_ENV_WAVE_ATTENUATION_PO) {
       if (valid && sl.ctrl == FS_CTRL_RL && sl.rl_index == 0) {
         orow[0] = float(v / T(15));
@@ -779,8 +837,8 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
         bool internal;
         segment_lookup(s, x, internal, xo);
       }
-      orow[ii] = float(v / s.max_speed);
-      orow[N + ii] = float(xo / L);
+      orow[oi] = float(v / s.max_speed);
+      orow[N + oi] = float(xo / L);
     }
     return;
   }
@@ -789,6 +847,7 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
   if (valid && live_replica) {
     s.pos[idx] = x;
     s.vel[idx] = v;
+    if (sorted) s.sort_key[idx] = xs;
     if (!FAST) {
       if (flags & FLAG_HAS_LAC) s.ctrl_state[idx] = cst;
       if (s.track_aux) { s.prev_vel[idx] = prev_v; s.accel[idx] = last_acc; }
@@ -1267,6 +1326,14 @@ __global__ void k_reset(DevView<T> s, const uint8_t* __restrict__ mask) {
     s.prev_vel[e] = s.init_vel[e];
     s.accel[e] = T(0);
     s.ctrl_state[e] = T(0);
+    if (s.sort_vehicles) {                         // accel.py:171-183: absolute_position = get_x_by_id at reset
+      T xa = s.init_pos[e];
+      if (s.nseg > 0) {
+        bool internal;
+        segment_lookup(s, s.init_pos[e], internal, xa);
+      }
+      s.sort_key[e] = xa;
+    }
     if (s.num_lanes > 1) {
       s.lane[e] = s.init_lane[e];
       s.last_lc[e] = -(1 << 30);

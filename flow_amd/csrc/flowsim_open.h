@@ -128,29 +128,6 @@ __device__ __forceinline__ T seg_min(T v) {
   return v;
 }
 
-// value that slot j (wave-uniform) of MY segment holds: v_readlane broadcasts through an SGPR, no LDS round trip
-__device__ __forceinline__ int read_lane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-template <int SEG>
-__device__ __forceinline__ int seg_read_i(int v, int j, int seg) {
-  int out = read_lane_i(v, j);
-#pragma unroll
-  for (int sg = 1; sg < 64 / SEG; ++sg) {
-    const int f = read_lane_i(v, sg * SEG + j);
-    out = (seg == sg) ? f : out;
-  }
-  return out;
-}
-template <int SEG, typename T>
-__device__ __forceinline__ T seg_read(T v, int j, int seg) {
-  T out = read_lane(v, j);
-#pragma unroll
-  for (int sg = 1; sg < 64 / SEG; ++sg) {
-    const T f = read_lane(v, sg * SEG + j);
-    out = (seg == sg) ? f : out;
-  }
-  return out;
-}
-
 // (internal?, Flow table coordinate) of coordinate x on route r (O5).  tab_* are the lane-indexed segment rows; both
 // routes are walked with wave-uniform loops and the lane keeps the result of its own route.
 template <int NR, typename T>

@@ -89,6 +89,8 @@ class Env(_Base):
         """envs/base.py:268-292: compute the start placement and (re)create the simulator."""
         if self.sim is not None:
             self.sim.close()
+        if self.initial_config.shuffle:                 # envs/base.py:276-277
+            random.shuffle(self.initial_ids)
         spec = build_spec(self, self.num_replicas)
         if self.FS_ENV is None:
             spec["env"] = L.FS_ENV_ACCEL
@@ -97,7 +99,7 @@ class Env(_Base):
         self.k.vehicle.attach(self.sim, 0)
         x0 = spec["init_pos"][0]
         for i, veh_id in enumerate(self.initial_ids):
-            if spec.get("network") == "merge":
+            if spec.get("network") in ("merge", "bottleneck"):
                 slot = spec["init_slot"][veh_id]
                 edge, pos = self.k.network.open_locate(int(spec["init_route"][0][slot]), float(x0[slot]))
             else:
@@ -161,6 +163,8 @@ class Env(_Base):
         if self.sim_params.restart_instance or self.step_counter > 2e6:
             self.step_counter = 0
             self.sim_params.seed = random.randint(0, int(1e5))
+        elif self.initial_config.shuffle:               # envs/base.py:445-446: new placement, hence a new simulator
+            self.setup_initial_state()
         obs = self.sim.reset()
         self.k.update(reset=True)
         self.time_counter = int(self.sim.time_counter[0])

@@ -27,9 +27,7 @@ class AccelEnv(Env):
         for p in ADDITIONAL_ENV_PARAMS.keys():
             if p not in env_params.additional_params:
                 raise KeyError('Environment parameter \'{}\' not supplied'.format(p))
-        if env_params.additional_params['sort_vehicles']:
-            raise NotImplementedError("AccelEnv(sort_vehicles=True) is not built (on a one-lane ring "
-                                      "the id order already is the ring order)")
+        self._sorted_actions = None
         self.prev_pos = dict()
         self.absolute_position = dict()
         super().__init__(env_params, sim_params, network, simulator)
@@ -48,6 +46,15 @@ class AccelEnv(Env):
     def _apply_rl_actions(self, rl_actions):
         sorted_rl_ids = [veh_id for veh_id in self.sorted_ids if veh_id in self.k.vehicle.get_rl_ids()]
         self.k.vehicle.apply_acceleration(sorted_rl_ids, rl_actions)
+        if self.env_params.additional_params['sort_vehicles']:
+            # column k commands the k-th RL vehicle in sorted order: the kernel resolves that order itself
+            self._sorted_actions = np.asarray(rl_actions, dtype=np.float32).reshape(1, -1)
+
+    def _action_vector(self):
+        if self.env_params.additional_params['sort_vehicles']:
+            a, self._sorted_actions = self._sorted_actions, None
+            return a
+        return super()._action_vector()
 
     def compute_reward(self, rl_actions, **kwargs):
         """Computed in the step kernel (rewards.desired_velocity / mean speed)."""
@@ -58,12 +65,29 @@ class AccelEnv(Env):
         return np.array(self._last_obs, dtype=np.float64)
 
     def additional_command(self):
+        """accel.py:150-169: observed vehicles, and the running absolute position behind ``sorted_ids``."""
         if self.k.vehicle.num_rl_vehicles > 0:
             for veh_id in self.k.vehicle.get_human_ids():
                 self.k.vehicle.set_observed(veh_id)
+        if self.env_params.additional_params['sort_vehicles']:
+            for veh_id in self.k.vehicle.get_ids():
+                this_pos = self.k.vehicle.get_x_by_id(veh_id)
+                if this_pos == -1001:
+                    self.absolute_position[veh_id] = -1001
+                else:
+                    change = this_pos - self.prev_pos.get(veh_id, this_pos)
+                    self.absolute_position[veh_id] = \
+                        (self.absolute_position.get(veh_id, this_pos) + change) % self.k.network.length()
+                    self.prev_pos[veh_id] = this_pos
+
+    def _get_abs_position(self, veh_id):
+        return self.absolute_position.get(veh_id, -1001)
 
     @property
     def sorted_ids(self):
+        """accel.py:134-148."""
+        if self.env_params.additional_params['sort_vehicles']:
+            return sorted(self.k.vehicle.get_ids(), key=self._get_abs_position)
         return self.k.vehicle.get_ids()
 
     def reset(self):

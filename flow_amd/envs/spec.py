@@ -12,7 +12,7 @@ from flow_amd.utils.exceptions import FatalFlowError
 def vehicle_slots(vehicle_kernel, rl_order):
     """One fs_vehicle_spec dict per vehicle, in id (insertion) order (vehicle/traci.py:109-117)."""
     slots = []
-    for veh_id in vehicle_kernel.get_ids():
+    for veh_id in getattr(vehicle_kernel, "_order", None) or vehicle_kernel.get_ids():
         ctrl = vehicle_kernel.get_acc_controller(veh_id)
         if ctrl.FS_ID is None:
             raise NotImplementedError("controller %s is not built" % type(ctrl).__name__)
@@ -34,8 +34,6 @@ def initial_positions(network_kernel, initial_config, num_vehicles, num_replicas
     """[R,N] absolute start positions (+ [N] lanes).  The even/random placement of
     network/base.py:221-608 is computed once; a positive ``perturbation`` is drawn per
     replica (base.py:384-389), clamped to the vehicle's edge like the reference."""
-    if initial_config.shuffle:
-        raise NotImplementedError("InitialConfig(shuffle=True) is not built (slot order = ring order)")
     pert = initial_config.perturbation
     cfg = initial_config
     if pert > 0:                                  # draw the perturbation here, vectorised over replicas
@@ -287,6 +285,16 @@ def build_spec(env, num_replicas, rng=None):
     if len(network.net_params.inflows.get()) > 0:
         raise NotImplementedError("inflows are not built in the HIP step loop yet")
     R, N = int(num_replicas), veh_k.num_vehicles
+    obs_perm = None
+    if network.initial_config.shuffle:                     # envs/base.py:268-292: positions go to shuffled ids
+        if num_lanes > 1:
+            raise NotImplementedError("InitialConfig(shuffle=True) on a multi-lane ring is not built")
+        veh_k.set_slot_order(env.initial_ids)
+        ids = veh_k.get_ids()
+        obs_perm = np.array([ids.index(v) for v in env.initial_ids], dtype=np.int32)
+    sort_vehicles = bool(ep.additional_params.get("sort_vehicles", False))
+    if sort_vehicles and env.FS_ENV != L.FS_ENV_ACCEL:
+        raise NotImplementedError("sort_vehicles is built for AccelEnv on single-lane closed loops")
     slots = vehicle_slots(veh_k, env._rl_action_order())
     X, lanes = initial_positions(net_k, network.initial_config, N, R, rng)
     lengths = np.array([s["length"] for s in slots])
@@ -319,5 +327,7 @@ def build_spec(env, num_replicas, rng=None):
         num_lanes=num_lanes, init_lane=lanes,
         lane_change_duration=float(ep.additional_params.get("lane_change_duration", 0)),
         lane_change_mode=max(lc_modes) if lc_modes else 512,
-        last_lc_quirk=bool(getattr(env, "LAST_LC_QUIRK", True)))
+        last_lc_quirk=bool(getattr(env, "LAST_LC_QUIRK", True)), sort_vehicles=sort_vehicles)
+    if obs_perm is not None:
+        spec["obs_perm"] = obs_perm
     return spec

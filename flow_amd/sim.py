@@ -132,6 +132,9 @@ class FlowSim:
                 arr[k].lane, arr[k].last_segment = int(lane), int(bool(last))
             return arr
         obs_cells, act_cells = cells(spec.get("obs_cells")), cells(spec.get("action_cells"))
+        obs_perm = spec.get("obs_perm")
+        if obs_perm is not None:
+            obs_perm = np.ascontiguousarray(np.asarray(obs_perm, dtype=np.int32).reshape(self.N))
         horizon = spec.get("horizon", float("inf"))
         dp = C.POINTER(C.c_double)
         cfg = L.fs_config(
@@ -172,6 +175,8 @@ class FlowSim:
             obs_outflow_window=int(spec.get("obs_outflow_window", 20)),
             reward_outflow_window=int(spec.get("reward_outflow_window", 10)),
             track_followers=int(bool(spec.get("track_followers", True))), reserved4=0,
+            sort_vehicles=int(bool(spec.get("sort_vehicles", False))), reserved5=0,
+            obs_perm=obs_perm.ctypes.data_as(C.POINTER(C.c_int32)) if obs_perm is not None else None,
             replica_offset=int(spec.get("replica_offset", 0)))
         if self.open_net:
             cfg.route_start[0] = float(spec["routes"][0]["start"])

@@ -263,6 +263,12 @@ typedef struct fs_config {
   int32_t track_followers;            /* open networks: 1 = keep the sticky follower entries (FS_FIELD_FOLLOWER, used by the
                                          merge observations and BCM); 0 = skip them (the bottleneck envs never read them) */
   int32_t reserved4;
+  /* ---- observation order of AccelEnv-style heads on single-lane closed loops ---- */
+  int32_t sort_vehicles;              /* env_params 'sort_vehicles' (accel.py:101-169): observation entries and RL action
+                                         columns follow the absolute position recorded at the last additional_command */
+  int32_t reserved5;
+  const int32_t* obs_perm;            /* [N] place of slot i's vehicle in get_ids() when InitialConfig.shuffle assigned the
+                                         start positions in shuffled id order (envs/base.py:268-292); NULL = identity */
   /* ---- sharding ---- */
   int64_t replica_offset;             /* global index of this handle's replica 0 (one handle per GPU holds a contiguous
                                          block of the job's replicas): the Philox streams (acceleration noise, random

@@ -237,6 +237,11 @@ class RingOracle:
         self.step_counter = np.zeros(self.R, dtype=np.int64)   # noise stream position
         self.last_accel = np.zeros((self.R, self.N), dtype=self.dt_)
         self.last_commanded = np.zeros((self.R, self.N), dtype=bool)
+        # observation / action order (accel.py:101-123, 150-169; envs/base.py:268-292)
+        self.sort_vehicles = bool(spec.get("sort_vehicles", False))
+        perm = spec.get("obs_perm")
+        self.obs_perm = np.arange(self.N) if perm is None else np.asarray(perm, dtype=np.int64)
+        self.x_sort = self.obs_position(self.x).copy()               # AccelEnv.absolute_position
 
     # ------------------------------------------------------------------ S10
     def headways(self, x=None):
@@ -329,21 +334,38 @@ class RingOracle:
         self.lac_a[m] = 0
         self.pis_n[m] = 0
         self.time_counter[m] = 0
+        self.x_sort[m] = self.obs_position(self.x)[m]
         obs = self.get_state()
         for _ in range(int(self.spec.get("warmup_steps", 0))):       # envs/base.py:554-555
             obs, _, _ = self.step(None, _mask=m)
         return obs
 
     # ------------------------------------------------------------------ step
+    def _order_rank(self, rl_only=False):
+        """[R,N] place of every vehicle in sorted(get_ids(), key=absolute_position) -- stable, so ties keep the
+        id order (obs_perm); with ``rl_only`` the place among the RL vehicles (accel.py:103-107)."""
+        key, perm = self.x_sort, self.obs_perm
+        before = (key[:, None, :] < key[:, :, None]) | \
+            ((key[:, None, :] == key[:, :, None]) & (perm[None, None, :] < perm[None, :, None]))
+        if rl_only:
+            is_rl = np.array([v["controller"] == CTRL_RL for v in self.veh])
+            before = before & is_rl[None, None, :]
+        return before.sum(axis=2)
+
     def _rl_inputs(self, actions, per_rl=1):
-        """(rl_value [R,N], rl_commanded [R,N]) of the static slot -> action-column mapping."""
+        """(rl_value [R,N], rl_commanded [R,N]): the slot -> action-column mapping (static rl_index, or the place
+        among the RL vehicles in sorted order when sort_vehicles)."""
         rl_value = np.zeros((self.R, self.N), dtype=self.dt_)
         rl_cmd = np.zeros((self.R, self.N), dtype=bool)
         if actions is not None:
             acts = np.asarray(actions, dtype=self.dt_)
+            col = self._order_rank(rl_only=True) if self.sort_vehicles else None
             for i, vs in enumerate(self.veh):
                 if vs["controller"] == CTRL_RL:
-                    rl_value[:, i] = acts[:, per_rl * vs["rl_index"]]
+                    if col is None:
+                        rl_value[:, i] = acts[:, per_rl * vs["rl_index"]]
+                    else:
+                        rl_value[:, i] = np.take_along_axis(acts, col[:, i:i + 1], 1)[:, 0]
                     rl_cmd[:, i] = True
         return rl_value, rl_cmd
 
@@ -371,6 +393,8 @@ class RingOracle:
         T = self.dt_.type
         dt = T(self.dt)
         acc, commanded, h, v_lead, has_lead = self._accelerations(actions, active)
+        if self.sort_vehicles:                                       # accel.py:150-169: additional_command
+            self.x_sort = np.where(active[:, None], self.obs_position(self.x), self.x_sort)
         v = self.v
         next_vel = np.maximum(v + acc * dt, T(0))                    # vehicle/traci.py:962
         v_cmd = v + (next_vel - v) * self.ramp                       # S6
@@ -437,7 +461,14 @@ class RingOracle:
             # accel.py:116-123 / wave_attenuation.py:141-148
             speed = self.v / T(self.spec["max_speed"])
             pos = self.obs_position(self.x) / self.L[:, None]
-            return np.concatenate([speed, pos], axis=1)
+            if self.sort_vehicles and env == ENV_ACCEL:
+                place = self._order_rank()
+            else:
+                place = np.broadcast_to(self.obs_perm[None, :], speed.shape)
+            out_s, out_p = np.empty_like(speed), np.empty_like(pos)
+            np.put_along_axis(out_s, place, speed, 1)
+            np.put_along_axis(out_p, place, pos, 1)
+            return np.concatenate([out_s, out_p], axis=1)
         if env == ENV_WAVE_ATTENUATION_PO:                           # wave_attenuation.py:248-269
             i = self.rl_slots[0]
             j = (i + 1) % self.N                                     # get_leader(rl_id) or rl_id

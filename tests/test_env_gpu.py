@@ -476,3 +476,64 @@ def test_examples_simulate_script_runs_reference_style_configs(tmp_path):
     out = subprocess.run([sys.executable, os.path.join(root, "examples", "simulate.py"), "figure_eight"],
                          cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
+
+
+def test_reference_sorting_tests_with_shuffled_start_positions():
+    """tests/fast_tests/test_environments.py:281-330 (test_sorting / test_no_sorting): with InitialConfig.shuffle the
+    ids are not in ring order; sort_vehicles=True makes sorted_ids ascending in absolute_position, False leaves
+    get_ids() untouched.  Plus: the sorted observation equals the oracle's, RL actions reach the vehicles in sorted
+    order, and a shuffle reset draws a new placement."""
+    import random
+    from flow_amd.controllers import ContinuousRouter, IDMController, RLController
+    from flow_amd.core.params import EnvParams, InitialConfig, NetParams, SumoParams, VehicleParams
+    from flow_amd.envs import AccelEnv
+    from flow_amd.networks.ring import ADDITIONAL_NET_PARAMS, RingNetwork
+    from oracle import refsim as S
+
+    def network():
+        v = VehicleParams()
+        v.add("rl", acceleration_controller=(RLController, {}), routing_controller=(ContinuousRouter, {}),
+              num_vehicles=2)
+        v.add("human", acceleration_controller=(IDMController, {}), routing_controller=(ContinuousRouter, {}),
+              num_vehicles=8)
+        return RingNetwork("ring", v, NetParams(additional_params=dict(ADDITIONAL_NET_PARAMS)),
+                           InitialConfig(shuffle=True))
+
+    add = {"max_accel": 3, "max_decel": 3, "target_velocity": 10, "sort_vehicles": True}
+    random.seed(11)
+    env = AccelEnv(sim_params=SumoParams(sim_step=0.1), network=network(),
+                   env_params=EnvParams(horizon=200, additional_params=add))
+    env.reset()
+    env.additional_command()
+    sorted_ids = env.sorted_ids
+    positions = [env.absolute_position[veh_id] for veh_id in sorted_ids]
+    assert all(positions[i] <= positions[i + 1] for i in range(len(positions) - 1))
+    assert sorted_ids != env.k.vehicle.get_ids()                       # the shuffle really moved somebody
+    first = dict(env.initial_state)
+    ora = S.RingOracle(env._spec, np.float32)
+    ora.reset()
+    rng = np.random.default_rng(0)
+    for k in range(200):
+        a = rng.uniform(-1, 1, 2).astype(np.float32)
+        obs, rew, done, _ = env.step(a)
+        o_ref, r_ref, d_ref = ora.step(a[None, :])
+        np.testing.assert_array_equal(obs.astype(np.float32), o_ref[0].astype(np.float32))
+        # the host's sorted_ids (running absolute_position) is the order the kernel used for this observation
+        x_by_id = {v: env.k.vehicle.get_x_by_id(v) / env.k.network.length() for v in env.sorted_ids}
+        np.testing.assert_allclose(obs[10:], [x_by_id[v] for v in env.sorted_ids], atol=1e-6)
+    env.reset()                                                        # shuffle: a new placement every reset
+    assert dict(env.initial_state) != first
+    env.terminate()
+
+    add["sort_vehicles"] = False
+    env = AccelEnv(sim_params=SumoParams(sim_step=0.1), network=network(),
+                   env_params=EnvParams(horizon=50, additional_params=add))
+    env.reset()
+    env.additional_command()
+    assert list(env.sorted_ids) == env.k.vehicle.get_ids()
+    obs, _, _, _ = env.step(np.array([0.5, -0.5]))
+    # observation in get_ids() order although the ring order is shuffled
+    np.testing.assert_allclose(obs[10:], [env.k.vehicle.get_x_by_id(v) / env.k.network.length()
+                                          for v in env.k.vehicle.get_ids()], atol=1e-6)
+    assert env.k.vehicle.get_accel("rl_0") == pytest.approx(0.5) and env.k.vehicle.get_accel("rl_1") == pytest.approx(-0.5)
+    env.terminate()

@@ -211,8 +211,26 @@ def test_unsupported_features_raise_at_construction(monkeypatch):
     v.add("idm", acceleration_controller=(FC.IDMController, {}), num_vehicles=4)
     net = RingNetwork("ring", v, P.NetParams(additional_params=dict(ADDITIONAL_NET_PARAMS)),
                       P.InitialConfig(shuffle=True))
+    # InitialConfig(shuffle=True) (envs/base.py:268-292): the start positions go to the ids in shuffled order; the
+    # simulator keeps its slots in ring order and is told where each slot's vehicle sits in get_ids()
+    import random
+    random.seed(3)
+    env, spec = build_env(monkeypatch, AccelEnv, P.EnvParams(additional_params=dict(ADDITIONAL_ENV_PARAMS,
+                                                                                     sort_vehicles=True)),
+                          P.SumoParams(), net)
+    assert sorted(spec["obs_perm"].tolist()) == [0, 1, 2, 3] and spec["sort_vehicles"] is True
+    assert [env.k.vehicle.get_ids()[q] for q in spec["obs_perm"]] == env.initial_ids
+    assert env.k.vehicle.get_ids() == ["idm_0", "idm_1", "idm_2", "idm_3"]
+    # slots are in ring order: the start positions along the loop ascend with the slot
+    xs = [spec["init_pos"][0][env.k.vehicle._slot[v]] for v in env.k.vehicle._order]
+    assert xs == sorted(xs)
+    add3 = dict(ADDITIONAL_NET_PARAMS)
+    add3["lanes"] = 3
+    net3 = RingNetwork("ring", v, P.NetParams(additional_params=add3), P.InitialConfig(shuffle=True))
+    from flow_amd.envs import LaneChangeAccelEnv
+    from flow_amd.envs.ring.lane_change_accel import ADDITIONAL_ENV_PARAMS as LC_PARAMS
     with pytest.raises(NotImplementedError):
-        build_env(monkeypatch, AccelEnv, P.EnvParams(additional_params=ADDITIONAL_ENV_PARAMS), P.SumoParams(), net)
+        build_env(monkeypatch, LaneChangeAccelEnv, P.EnvParams(additional_params=LC_PARAMS), P.SumoParams(), net3)
     inflow = P.InFlows()
     inflow.add("bottom", "idm", vehs_per_hour=100)
     net = RingNetwork("ring", v, P.NetParams(inflows=inflow, additional_params=dict(ADDITIONAL_NET_PARAMS)))

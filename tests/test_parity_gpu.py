@@ -703,3 +703,33 @@ def test_sharded_handles_reproduce_the_unsharded_run_bit_for_bit():
     np.testing.assert_allclose(again.vel, ora.v, rtol=0, atol=1e-4)
     for s in [whole, again] + parts:
         s.close()
+
+
+def test_sort_vehicles_and_shuffled_ids_bit_exact():
+    """accel.py:101-169 + envs/base.py:268-292: observation entries and RL action columns follow the absolute position
+    recorded at the last additional_command (sort_vehicles), or the shuffled id order (obs_perm)."""
+    rng = np.random.default_rng(5)
+    N = 12
+    veh = [idm_vehicle() for _ in range(N)]
+    for k, i in enumerate((2, 7, 9)):
+        veh[i] = idm_vehicle(controller=S.CTRL_RL, rl_index=k)
+    base = perturbed(ring_spec(R=9, N=N, length=150.0, bunching=10.0, junction_length=0.1, horizon=400, num_rl=3,
+                               vehicles=veh, action_low=-1.0, action_high=1.0), seed=2)
+    base["init_vel"] = np.full((9, N), 6.0)                       # fast enough to lap the 150 m ring in 400 steps
+    perm = rng.permutation(N)
+    for extra in (dict(sort_vehicles=True), dict(obs_perm=perm), dict(sort_vehicles=True, obs_perm=perm)):
+        spec = dict(base, **extra)
+        acts = rng.uniform(-1, 1, (400, 9, 3)).astype(np.float32)
+        ora = run_pair(spec, "f32", 400, acts, check_every=50)
+        if extra.get("sort_vehicles"):
+            pos = ora.get_state()[:, N:]
+            # sorted by the position of the previous additional_command: ascending except where somebody just wrapped
+            assert (np.diff(pos, axis=1) < 0).sum(axis=1).max() <= 2
+            assert (ora.x.min(axis=1) < 10).any() and ora.time_counter[0] == 400
+    # figure eight: the key is Flow's table coordinate (get_x_by_id), which is not monotone in the loop coordinate
+    spec8 = figure_eight_spec(R=6, N=14, horizon=300, seed=4)
+    spec8["vehicles"] = [dict(v, noise=0.0) for v in spec8["vehicles"]]
+    spec8["sort_vehicles"] = True
+    n_rl = spec8["num_rl"]
+    acts = rng.uniform(-1, 1, (300, 6, max(n_rl, 1))).astype(np.float32)
+    run_pair(spec8, "f32", 300, acts if n_rl else None, check_every=50)
