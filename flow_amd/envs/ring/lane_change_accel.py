@@ -57,3 +57,65 @@ class LaneChangeAccelEnv(AccelEnv):
         self.k.vehicle.apply_acceleration(sorted_rl_ids, acc=acceleration)
         self.k.vehicle.apply_lane_change(sorted_rl_ids, direction=[int(d) if float(d).is_integer() else d
                                                                    for d in direction])
+
+
+class LaneChangeAccelPOEnv(LaneChangeAccelEnv):
+    """POMDP version (flow/envs/ring/lane_change_accel.py:163-262): for every RL vehicle the headway, tailway, leader
+    speed and follower speed in EVERY lane, then the RL vehicles' own speeds.  The observation is assembled on the
+    host from the device state through ``k.vehicle.get_lane_*`` (the per-lane lists of vehicle/traci.py:699-950),
+    statement by statement as the reference does it -- including that the headways and tailways go into the vector in
+    metres (the reference normalises a list it has already copied from), the trailing ego speed in m/s, and that its
+    ``return`` sits INSIDE the loop over the RL vehicles (:262): only the first RL vehicle's block is filled and one
+    ego speed appended (``RETURN_IN_LOOP_QUIRK``; False = all RL vehicles, the evident intent)."""
+
+    HOST_HEADS = True
+    RETURN_IN_LOOP_QUIRK = True
+
+    def __init__(self, env_params, sim_params, network, simulator='traci'):
+        super().__init__(env_params, sim_params, network, simulator)
+        self.num_lanes = max(self.k.network.num_lanes(edge) for edge in self.k.network.get_edge_list())
+        self.visible = []
+
+    @property
+    def observation_space(self):
+        n_rl = self.initial_vehicles.num_rl_vehicles
+        return Box(low=0, high=1, shape=(4 * n_rl * self.num_lanes + n_rl, ), dtype=np.float32)
+
+    def get_state(self):
+        veh = self.k.vehicle
+        obs = [0 for _ in range(4 * veh.num_rl_vehicles * self.num_lanes)]
+        self.visible = []
+        for i, rl_id in enumerate(veh.get_rl_ids()):
+            max_length = self.k.network.length()
+            max_speed = self.k.network.max_speed()
+            headway = [1] * self.num_lanes
+            tailway = [1] * self.num_lanes
+            vel_in_front = [0] * self.num_lanes
+            vel_behind = [0] * self.num_lanes
+            lane_leaders = veh.get_lane_leaders(rl_id)
+            lane_followers = veh.get_lane_followers(rl_id)
+            lane_headways = veh.get_lane_headways(rl_id)
+            lane_tailways = veh.get_lane_tailways(rl_id)
+            headway[0:len(lane_headways)] = lane_headways
+            tailway[0:len(lane_tailways)] = lane_tailways
+            for j, lane_leader in enumerate(lane_leaders):
+                if lane_leader != '':
+                    lane_headways[j] /= max_length
+                    vel_in_front[j] = veh.get_speed(lane_leader) / max_speed
+                    self.visible.extend([lane_leader])
+            for j, lane_follower in enumerate(lane_followers):
+                if lane_follower != '':
+                    lane_headways[j] /= max_length
+                    vel_behind[j] = veh.get_speed(lane_follower) / max_speed
+                    self.visible.extend([lane_follower])
+            obs[4 * self.num_lanes * i:4 * self.num_lanes * (i + 1)] = \
+                np.concatenate((headway, tailway, vel_in_front, vel_behind))
+            obs.append(veh.get_speed(rl_id))
+            if self.RETURN_IN_LOOP_QUIRK:
+                return np.array(obs)
+        return np.array(obs) if not self.RETURN_IN_LOOP_QUIRK else None
+
+    def additional_command(self):
+        """lane_change_accel.py:257-262."""
+        for veh_id in self.visible:
+            self.k.vehicle.set_observed(veh_id)

@@ -537,3 +537,61 @@ def test_reference_sorting_tests_with_shuffled_start_positions():
                                           for v in env.k.vehicle.get_ids()], atol=1e-6)
     assert env.k.vehicle.get_accel("rl_0") == pytest.approx(0.5) and env.k.vehicle.get_accel("rl_1") == pytest.approx(-0.5)
     env.terminate()
+
+
+def test_lane_change_accel_po_env_reference_tests_and_observation():
+    """tests/fast_tests/test_environments.py:117-198 (TestLaneChangeAccelPOEnv: 1 RL + 1 human on a one-lane ring:
+    observation size 5, action size 2, observed ['human_0']) and the per-lane lists on a 3-lane ring."""
+    from flow_amd.controllers import ContinuousRouter, IDMController, RLController
+    from flow_amd.core.params import EnvParams, InitialConfig, NetParams, SumoParams, VehicleParams
+    from flow_amd.envs import LaneChangeAccelPOEnv
+    from flow_amd.networks.ring import ADDITIONAL_NET_PARAMS, RingNetwork
+    add = {"max_accel": 3, "max_decel": 3, "target_velocity": 10, "lane_change_duration": 5, "sort_vehicles": False}
+    v = VehicleParams()
+    v.add("rl", acceleration_controller=(RLController, {}), num_vehicles=1)
+    v.add("human", acceleration_controller=(IDMController, {}), num_vehicles=1)
+    net = RingNetwork("test_merge", v, NetParams(additional_params=dict(ADDITIONAL_NET_PARAMS)))
+    env = LaneChangeAccelPOEnv(sim_params=SumoParams(), network=net, env_params=EnvParams(additional_params=add))
+    assert env.observation_space.shape == (5,) and env.action_space.shape == (2,)
+    assert list(env.action_space.low) == [-3, -1] and list(env.action_space.high) == [3, 1]
+    env.reset()
+    obs, _, _, _ = env.step(None)
+    env.additional_command()
+    assert env.k.vehicle.get_observed_ids() == ["human_0"]
+    x_rl, x_h = env.k.vehicle.get_x_by_id("rl_0"), env.k.vehicle.get_x_by_id("human_0")
+    L_ = env.k.network.length()
+    # [headway, tailway, leader speed / v_max, follower speed / v_max, ego speed]; head/tailway in METRES (see class doc)
+    np.testing.assert_allclose(obs, [(x_h - x_rl) % L_ - 5, (x_rl - x_h) % L_ - 5, env.k.vehicle.get_speed("human_0") / 30,
+                                     env.k.vehicle.get_speed("human_0") / 30, env.k.vehicle.get_speed("rl_0")], atol=1e-5)
+    env.terminate()
+
+    lanes3 = dict(ADDITIONAL_NET_PARAMS)
+    lanes3["lanes"] = 3
+    v = VehicleParams()
+    v.add("human", acceleration_controller=(IDMController, {}), routing_controller=(ContinuousRouter, {}),
+          num_vehicles=19)
+    v.add("rl", acceleration_controller=(RLController, {}), routing_controller=(ContinuousRouter, {}), num_vehicles=2)
+    net = RingNetwork("ring3", v, NetParams(additional_params=lanes3), InitialConfig(lanes_distribution=float("inf")))
+    env = LaneChangeAccelPOEnv(sim_params=SumoParams(sim_step=0.1), network=net,
+                               env_params=EnvParams(horizon=50, additional_params=add))
+    assert env.observation_space.shape == (4 * 2 * 3 + 2,)
+    env.reset()
+    for k in range(30):
+        obs, rew, done, _ = env.step(np.array([0.5, 1 if k == 5 else 0, -0.5, 0]))
+    assert obs.shape == (4 * 2 * 3 + 1,)                 # the reference returns inside its loop over the RL vehicles
+    veh = env.k.vehicle
+    rl = veh.get_rl_ids()[0]
+    np.testing.assert_allclose(obs[0:3], veh.get_lane_headways(rl))
+    np.testing.assert_allclose(obs[3:6], veh.get_lane_tailways(rl))
+    np.testing.assert_allclose(obs[6:9], [s / 30 for s in veh.get_lane_leaders_speed(rl)])
+    np.testing.assert_allclose(obs[9:12], [s / 30 for s in veh.get_lane_followers_speed(rl)])
+    assert (obs[12:24] == 0).all() and obs[24] == veh.get_speed(rl)
+
+    class AllRl(LaneChangeAccelPOEnv):
+        RETURN_IN_LOOP_QUIRK = False
+    env.terminate()
+    env = AllRl(sim_params=SumoParams(sim_step=0.1), network=net, env_params=EnvParams(horizon=50, additional_params=add))
+    env.reset()
+    obs, _, _, _ = env.step(None)
+    assert obs.shape == (26,) and obs[24] == env.k.vehicle.get_speed("rl_0") and obs[25] == env.k.vehicle.get_speed("rl_1")
+    env.terminate()
