@@ -18,7 +18,7 @@ flow_amd.install_as_flow()
 
 def parse_args(args):
     parser = argparse.ArgumentParser(description="Run a non-RL experiment from exp_configs/non_rl.")
-    parser.add_argument('exp_config', type=str, help='name of a module in exp_configs/non_rl (ring, figure_eight, merge)')
+    parser.add_argument('exp_config', type=str, help='name of a module in exp_configs/non_rl (ring, figure_eight, merge, bottleneck)')
     parser.add_argument('--num_runs', type=int, default=1)
     parser.add_argument('--gen_emission', action='store_true', help='write the trajectory CSV under ./data')
     return parser.parse_known_args(args)[0]

@@ -45,7 +45,7 @@ EXPORTS = ["fs_create", "fs_destroy", "fs_last_error", "fs_abi_version", "fs_obs
 
 class fs_vehicle_spec(C.Structure):
     _fields_ = [("controller", C.c_int32), ("fail_safe", C.c_int32), ("speed_mode", C.c_int32),
-                ("rl_index", C.c_int32), ("type", C.c_int32), ("reserved", C.c_int32),
+                ("rl_index", C.c_int32), ("type", C.c_int32), ("lane_change_mode", C.c_int32),
                 ("p", C.c_double * FS_MAX_CTRL_PARAMS), ("noise", C.c_double),
                 ("delay", C.c_double), ("max_accel", C.c_double), ("max_decel", C.c_double),
                 ("length", C.c_double), ("sumo_tau", C.c_double), ("sumo_min_gap", C.c_double),
@@ -98,7 +98,9 @@ class fs_config(C.Structure):
                 ("zipper_distance", C.c_double), ("speed_limit", C.c_double), ("outflow_norm", C.c_double),
                 ("obs_cells", C.POINTER(fs_cell)), ("act_cells", C.POINTER(fs_cell)),
                 ("obs_outflow_window", C.c_int32), ("reward_outflow_window", C.c_int32),
-                ("track_followers", C.c_int32), ("reserved4", C.c_int32), ("sort_vehicles", C.c_int32),
+                ("track_followers", C.c_int32), ("reserved4", C.c_int32),
+                ("lane_change_cooldown_steps", C.c_int32), ("reserved6", C.c_int32), ("lane_change_min_gain", C.c_double),
+                ("sort_vehicles", C.c_int32),
                 ("reserved5", C.c_int32), ("obs_perm", C.POINTER(C.c_int32)), ("replica_offset", C.c_int64)]
 
 

@@ -176,6 +176,9 @@ class SumoParams(SimParams):
     merge_right_of_way  open networks: False switches the junction priority model off
     zipper_distance lane-drop networks: distance before a zipper junction from which a vehicle follows the nearest
                     vehicle of either joining lane
+    lane_change_cooldown / lane_change_min_gain  lane-drop networks: seconds a vehicle keeps its lane after a change /
+                    leader-gap gain [m] a change must bring, for vehicle types whose lane_change_mode lets SUMO change
+                    lanes (the simplified model M11, NOT LC2013)
     junction_length length of each internal edge (netconvert output in the reference)
     crash_gap       a replica crashes when a bumper gap falls below this after a move
     precision       'f32' | 'f64' arithmetic and state type of the kernels
@@ -187,7 +190,7 @@ class SumoParams(SimParams):
                  print_warnings=True, start_at_load=True, teleport_time=-1, num_clients=1, color_by_speed=False,
                  use_ballistic=False, slowdown_ramp=None, junction_mode=None, junction_length=0.1, crash_gap=0.0,
                  precision="f32", center_length=None, crossing_time_gap=None, max_vehicles=64, slot_capacity=None,
-                 merge_right_of_way=True, zipper_distance=50.0):
+                 merge_right_of_way=True, zipper_distance=50.0, lane_change_cooldown=5.0, lane_change_min_gain=10.0):
         super(SumoParams, self).__init__(sim_step, render, restart_instance, emission_path, save_render,
                                          sight_radius, show_radius, pxpm, force_color_update)
         self.port = port
@@ -212,6 +215,8 @@ class SumoParams(SimParams):
         self.slot_capacity = slot_capacity
         self.merge_right_of_way = merge_right_of_way
         self.zipper_distance = zipper_distance
+        self.lane_change_cooldown = lane_change_cooldown
+        self.lane_change_min_gain = lane_change_min_gain
 
 
 class EnvParams:

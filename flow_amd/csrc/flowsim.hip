@@ -374,6 +374,16 @@ struct Sim : SimBase {
       ov.n_obs_groups = group(obs_cells, fs::CELL_OBS_START, fs::CELL_OBS_LO, fs::CELL_OBS_HI, 0);
       ov.n_act_groups = group(act_cells, fs::CELL_ACT_START, fs::CELL_ACT_LO, fs::CELL_ACT_HI, 1);
       ov.track_followers = cfg.track_followers;
+      std::vector<int32_t> lca(N, 0);
+      int any_lc = 0;
+      for (int i = 0; i < N; ++i) {
+        lca[i] = (veh[i].lane_change_mode & 0x55) != 0;
+        any_lc |= lca[i];
+      }
+      if ((rc = upload(&ov.lc_auto, lca))) return rc;
+      ov.lc_enabled = bn && any_lc;
+      ov.lc_cooldown = cfg.lane_change_cooldown_steps;
+      ov.lc_min_gain = T(cfg.lane_change_min_gain);
       if ((rc = upload(&ov.cell_tab, ct))) return rc;
       if ((rc = upload(&ov.cell_tab_i, cti))) return rc;
     }

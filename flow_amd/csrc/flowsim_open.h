@@ -53,6 +53,10 @@ struct OpenView {
   const T* cell_tab;           // [6][64] edge start / lo / hi of observation group g, of action group g
   const int32_t* cell_tab_i;   // [2][64] first cell | lanes << 8 | first lane << 16 | is_last_segment << 24 (obs / action)
   int n_obs_cells, n_act_cells, n_obs_groups, n_act_groups, obs_window, rew_window, obs_dim, track_followers;
+  // M11 simplified lane changing
+  const int32_t* lc_auto;      // [N] 1: the slot's vehicle type changes lane on its own
+  int lc_enabled, lc_cooldown;
+  T lc_min_gain;
   T out_norm;                  // 2000 * scaling
 };
 
@@ -127,6 +131,9 @@ __device__ __forceinline__ T seg_min(T v) {
   if (SEG >= 64) v = min_swap32(v);
   return v;
 }
+
+template <int SEG, typename T>
+__device__ __forceinline__ T seg_max(T v) { return -seg_min<SEG>(-v); }
 
 // (internal?, Flow table coordinate) of coordinate x on route r (O5).  tab_* are the lane-indexed segment rows; both
 // routes are walked with wave-uniform loops and the lane keeps the result of its own route.
@@ -249,6 +256,11 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
   T prev_v = s.prev_vel[idx], last_acc = s.accel[idx];
   T cst = s.ctrl_state[idx];
   T vmax = o.vmax[idx];
+  const bool lc_on = (P > 2) && (o.lc_enabled != 0);
+  const bool my_lc_auto = lc_on && (o.lc_auto[ii] != 0);
+  int last_lc = lc_on ? s.last_lc[idx] : 0;
+  int lc_want = -1;                 // path wanted after the next move (M11); recomputed with every neighbour update
+  T lc_gain = T(0);
   int hist_l = (bn_env && i < 20) ? o.arr_hist[size_t(rr) * 20 + i] : 0;     // arrivals of sub-step % 20 == lane
   bool just_arrived = false;
   auto shift_of = [&](T xx) -> int { return (xx >= o.m1 ? 1 : 0) + (xx >= o.m2 ? 1 : 0); };
@@ -338,6 +350,55 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       lead_same_lane = has && ((route >> sh_l) == (p_l >> sh_l));
     } else {
       lead_same_lane = has;
+    }
+    if (lc_on) {
+      // ---- M11: which adjacent lane (if any) this vehicle would like to continue on after the next move ----------
+      bool internal;
+      T fx;
+      route_lookup<NR>(o, tab_start, tab_flow, tab_slope, x, route, internal, fx);
+      const int g = shift_of(x);
+      const int my_path = route < 0 ? 0 : route;
+      const int lane = my_path >> g, n_lanes = P >> g;
+      const bool ok0 = alive && my_lc_auto && !internal && g < 2 && la == g && n_lanes > 1 &&
+                       (tcount - last_lc >= o.lc_cooldown);
+      const unsigned long long below = bit - 1ull;
+      const T two_sqrt = T(2) * tsqrt(sl.max_accel * sl.max_decel);
+      T best_gain = -BIGV;
+      int best_path = -1;
+#pragma unroll
+      for (int dl = -1; dl <= 1; dl += 2) {               // right first, so that left wins a tie
+        const int tl = lane + dl;
+        const bool valid_t = ok0 && tl >= 0 && tl < n_lanes;
+        const int p2 = valid_t ? (tl << g) : 0;
+        unsigned long long own2 = 0ull;
+#pragma unroll
+        for (int q = 0; q < P; ++q) own2 = (p2 == q) ? B[q] : own2;
+        const unsigned long long pair2 = p2 < 2 ? (B[0] | B[1 % P]) : (B[2 % P] | B[3 % P]);
+        const unsigned long long c0 = la == 0 ? own2 : (la == 1 ? pair2 : ALL);
+        const unsigned long long c1 = la <= 1 ? pair2 : ALL;
+        const unsigned long long ml = valid_t ? (((~R1 & c0) | (R1 & ~R2 & c1) | (R2 & ALL)) & above) : 0ull;
+        // the lanes that feed the target lane at my position: path q with q >> g == tl
+        const unsigned long long feed = g == 0 ? own2 : pair2;
+        const unsigned long long mf = valid_t ? (feed & below) : 0ull;
+        const bool has_l = ml != 0ull, has_f = mf != 0ull;
+        const int lpos = has_l ? __ffsll((long long)ml) - 1 : 0;
+        const int fpos = has_f ? 63 - __clzll((long long)mf) : 0;
+        const int ls = __shfl(sorted_slot, segbase + lpos, 64), fs_ = __shfl(sorted_slot, segbase + fpos, 64);
+        const T xl2 = bperm(x, segbase + ls), vl2 = bperm(v, segbase + ls), ll2 = bperm(sl.length, segbase + ls);
+        const T xf2 = bperm(x, segbase + fs_), vf2 = bperm(v, segbase + fs_);
+        const T gap_l = has_l ? (xl2 - x) - ll2 : T(1000.0);
+        const T gap_f = has_f ? (x - xf2) - sl.length : T(1000.0);
+        const T v_l = has_l ? vl2 : T(0), v_f = has_f ? vf2 : T(0);
+        const T need_l = sl.sumo_min_gap + tmax(T(0), v * sl.sumo_tau + v * (v - v_l) / two_sqrt);
+        const T need_f = sl.sumo_min_gap + tmax(T(0), v_f * sl.sumo_tau + v_f * (v_f - v) / two_sqrt);
+        const bool safe = (!has_l || gap_l >= need_l) && (!has_f || gap_f >= need_f);
+        const T gain = gap_l - h;
+        const bool take = valid_t && safe && (gain >= o.lc_min_gain) && (gain >= best_gain);
+        best_gain = take ? gain : best_gain;
+        best_path = take ? p2 : best_path;
+      }
+      lc_want = best_path;
+      lc_gain = best_path >= 0 ? best_gain : T(0);
     }
     if (!follow) return;
     // ---- O1: the sticky follower entry of THIS vehicle (vehicle/traci.py:232-250) ----------------------
@@ -601,6 +662,17 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         const T cap = yields ? stop : BIGV;
         if ((sl.speed_mode & 1) || !commanded) v_new = tmin(v_new, cap);
       }
+      if (lc_on) {                                       // M11: the one lane change of this step, with the move
+        const bool want = lc_want >= 0 && alive && live;
+        const T gsel = want ? lc_gain : -BIGV;
+        const T gmax = seg_max<SEG>(gsel);
+        const unsigned long long wb = seg_ballot<SEG>(want && gsel == gmax, seg);
+        const int win = wb ? __ffsll((long long)wb) - 1 : -1;
+        if (slot_ok && ii == win) {
+          route = lc_want;
+          last_lc = tcount + 1;
+        }
+      }
       T x_new = (s.integrator == FS_BALLISTIC) ? x + (v + v_new) / T(2) * dt : x + v_new * dt;
       const bool mv = live && alive;
       if (mv) {
@@ -669,6 +741,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
           cst = T(0);
           last_acc = T(0);
           route = route_f;
+          last_lc = -(1 << 30);
           vmax = sl.sumo_max_speed;
           seq = seq_ctr;
           origin = f * (1 << 20) + k;
@@ -761,6 +834,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
     o.ctl_seq[idx] = ctl_seq;
     o.arrived_rl[idx] = arrived_rl;
     o.vmax[idx] = vmax;
+    if (lc_on) s.last_lc[idx] = last_lc;
     o.lead[idx] = lead;
     o.headway[idx] = h;
     if (ii == 0) {
@@ -807,6 +881,7 @@ __global__ void k_reset_open(DevView<T> s, OpenView<T> o, const uint8_t* __restr
     o.ctl_seq[e] = -1;
     o.arrived_rl[e] = 0;
     o.vmax[e] = s.sumo_max_speed[i];
+    s.last_lc[e] = -(1 << 30);
     o.lead[e] = -1;
     o.headway[e] = T(1000);
     if (i < FS_MAX_INFLOWS) o.emitted[size_t(r) * FS_MAX_INFLOWS + i] = 0;

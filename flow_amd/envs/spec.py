@@ -91,6 +91,7 @@ def type_slot(veh_k, type_name, type_index, rl_index):
                 sumo_min_gap=float(cf.controller_params["minGap"]),
                 sumo_max_speed=float(cf.controller_params["maxSpeed"]),
                 initial_speed=float(tp.get("initial_speed", 0.0)), type=type_index,
+                lane_change_mode=int(tp["lane_change_params"].lane_change_mode),
                 rl_index=rl_index if is_rl else -1), is_rl
 
 
@@ -129,13 +130,6 @@ def build_open_spec(env, num_replicas, rng=None):
         raise NotImplementedError("multi-lane merge networks are not built in the HIP step loop yet")
     if lane_drop and int(ap.get("scaling", 1)) != 1:
         raise NotImplementedError("BottleneckNetwork with scaling > 1 is not built (4 -> 2 -> 1 lanes only)")
-    if lane_drop:
-        for name, tp in veh_k.type_parameters.items():
-            mode = int(tp["lane_change_params"].lane_change_mode)
-            if mode & 0b01010101:      # SUMO laneChangeMode: strategic / cooperative / speed-gain / keep-right changes
-                raise NotImplementedError(
-                    "vehicle type %r has lane_change_mode=%d: SUMO's own lane changing (LC2013) is not built on the "
-                    "lane-drop network; the shipped bottleneck experiments run with lane_change_mode=0" % (name, mode))
     tables = net_k.open_tables()
     R = int(num_replicas)
     flows = network.net_params.inflows.get()
@@ -235,6 +229,9 @@ def build_open_spec(env, num_replicas, rng=None):
         num_rl = len(act_cells)
         extra = dict(obs_cells=obs_cells, action_cells=act_cells, scaling=int(ap.get("scaling", 1)),
                      track_followers=False,                          # no bottleneck env reads get_follower
+                     # M11 (simplified lane changing for types whose lane_change_mode lets SUMO change lanes)
+                     lane_change_cooldown_steps=max(1, int(round(float(getattr(sp, "lane_change_cooldown", 5.0)) / dt_))),
+                     lane_change_min_gain=float(getattr(sp, "lane_change_min_gain", 10.0)),
 
                      zipper_distance=float(getattr(sp, "zipper_distance", 50.0)),
                      obs_outflow_window=max(1, min(20, int(20 * dt_ / dt_))),        # get_outflow_rate(20 * sim_step)

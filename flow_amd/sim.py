@@ -63,6 +63,7 @@ class FlowSim:
             for k in ("controller", "fail_safe", "speed_mode", "rl_index"):
                 setattr(v, k, int(d[k]))
             v.type = int(d.get("type", 0))
+            v.lane_change_mode = int(d.get("lane_change_mode", 0))
             p = list(d.get("p", [])) + [0.0] * L.FS_MAX_CTRL_PARAMS
             for k in range(L.FS_MAX_CTRL_PARAMS):
                 v.p[k] = float(p[k])
@@ -175,6 +176,8 @@ class FlowSim:
             obs_outflow_window=int(spec.get("obs_outflow_window", 20)),
             reward_outflow_window=int(spec.get("reward_outflow_window", 10)),
             track_followers=int(bool(spec.get("track_followers", True))), reserved4=0,
+            lane_change_cooldown_steps=int(spec.get("lane_change_cooldown_steps", 10)), reserved6=0,
+            lane_change_min_gain=float(spec.get("lane_change_min_gain", 10.0)),
             sort_vehicles=int(bool(spec.get("sort_vehicles", False))), reserved5=0,
             obs_perm=obs_perm.ctypes.data_as(C.POINTER(C.c_int32)) if obs_perm is not None else None,
             replica_offset=int(spec.get("replica_offset", 0)))

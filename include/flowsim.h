@@ -184,7 +184,9 @@ typedef struct fs_vehicle_spec {
   int32_t speed_mode;                 /* SUMO speed-mode bitmask, core/params.py:12-18 */
   int32_t rl_index;                   /* column of the action vector, -1 if not RL */
   int32_t type;                       /* open networks: index of the vehicle type (VehicleParams.add order) */
-  int32_t reserved;
+  int32_t lane_change_mode;           /* SumoLaneChangeParams.lane_change_mode of the type; FS_NET_BOTTLENECK: a strategic /
+                                         cooperative / speed-gain / keep-right bit (mode & 0x55) switches the simplified
+                                         lane-change model on for this vehicle */
   double p[FS_MAX_CTRL_PARAMS];       /* controller parameters, see enum fs_controller */
   double noise;                       /* sigma of the Gaussian acceleration noise */
   double delay;                       /* delay used by the safe_velocity fail-safe */
@@ -263,6 +265,10 @@ typedef struct fs_config {
   int32_t track_followers;            /* open networks: 1 = keep the sticky follower entries (FS_FIELD_FOLLOWER, used by the
                                          merge observations and BCM); 0 = skip them (the bottleneck envs never read them) */
   int32_t reserved4;
+  /* ---- simplified lane changing on FS_NET_BOTTLENECK ---- */
+  int32_t lane_change_cooldown_steps; /* sub-steps a vehicle keeps its lane after a change */
+  int32_t reserved6;
+  double lane_change_min_gain;        /* leader-gap gain [m] a lane change must bring */
   /* ---- observation order of AccelEnv-style heads on single-lane closed loops ---- */
   int32_t sort_vehicles;              /* env_params 'sort_vehicles' (accel.py:101-169): observation entries and RL action
                                          columns follow the absolute position recorded at the last additional_command */

@@ -60,6 +60,13 @@ merge1_x = merge2_x.  Additional rules:
       (flow/core/params.py:1118-1119 quoting SUMO): a vehicle that does not fit when it is due is dropped
   M10 the desired speed of the SUMO car-following model is min(vehicle maxSpeed, edge speed limit); maxSpeed is
       per vehicle and changed by BottleneckDesiredVelocityEnv (setMaxSpeed)
+  M11 simplified lane changing (NOT SUMO's LC2013; for vehicle types whose lane_change_mode has a strategic /
+      cooperative / speed-gain / keep-right bit): on a multi-lane stretch, outside the zipper zones and internal edges
+      and after a cool-down, a vehicle wants the adjacent lane (left preferred on a tie) whose leader gap exceeds its
+      current headway by lane_change_min_gain, if the gaps to the new leader and to the new follower are at least the
+      SUMO-IDM desired gaps; decided on the snapshot of the last update, ONE change per replica and step (largest
+      gain, lowest slot on a tie), executed with the move; the vehicle continues as the lowest entry lane of its
+      new physical lane
   O6  BottleneckDesiredVelocityEnv (flow/envs/bottleneck.py:866-986): per (edge, segment, lane) vehicle counts
       and mean speeds of human / RL vehicles, outflow; actions shift the maxSpeed of the RL vehicles in the
       controlled lane-segments, clip(maxSpeed + a, 0.01, 23); reward = outflow of the last 10 steps / (2000 * scaling)
@@ -115,6 +122,10 @@ class MergeOracle:
         self.m2 = T(spec.get("merge2_x", spec["merge_x"]))
         self.zip_d = T(spec.get("zipper_distance", 0.0))
         self.speed_limit = T(spec.get("speed_limit", BIG))
+        self.lc_auto = np.array([(int(v.get("lane_change_mode", 0)) & 0b01010101) != 0 for v in self.veh])
+        self.lc_enabled = bool(self.lc_auto.any()) and self.P > 2
+        self.lc_cooldown = int(spec.get("lane_change_cooldown_steps", 10))
+        self.lc_min_gain = T(spec.get("lane_change_min_gain", 10.0))
         self.cells = spec.get("obs_cells")                  # O6: [(x_lo, x_hi, lane)] in observation order
         self.ctl_cells = spec.get("action_cells")           # O6: [(x_lo, x_hi, lane)] per action column
         self.junction = spec.get("junction") or {"enabled": 0}
@@ -135,6 +146,9 @@ class MergeOracle:
         self.x, self.v, self.prev_v, self.lac_a, self.last_accel = z(), z(), z(), z(), z()
         self.vmax = np.tile(np.array([v.get("sumo_max_speed", 30.0) for v in self.veh], dtype=self.dt_), (R, 1))
         self.arr_hist = np.zeros((R, 20), dtype=np.int64)          # arrivals of the last 20 sub-steps (ring buffer)
+        self.last_lc = np.full((R, N), -(1 << 30), dtype=np.int64)  # time_counter of the last lane change (M11)
+        self.lc_want = np.full((R, N), -1, dtype=np.int64)         # path wanted after the next move, -1 = stay
+        self.lc_gain = np.zeros((R, N), dtype=self.dt_)
         self.route = np.full((R, N), -1, dtype=np.int64)           # -1: free slot; else the path (entry lane)
         self.seq = z(np.int64)                                      # position in the id list (departure order)
         self.origin = np.full((R, N), -1, dtype=np.int64)          # flow * 2^20 + k, or -1-i for initial vehicle i
@@ -244,7 +258,74 @@ class MergeOracle:
         upd = a2 & alive & bool(self.spec.get("track_followers", True))
         self.foll = np.where(upd, new_f, self.foll)
         self.foll_h = np.where(upd, new_h, self.foll_h)
+        if self.lc_enabled:
+            self._lane_change_wishes(active, d, ahead, h, has)
         return has
+
+    def _lane_change_wishes(self, active, d, ahead, h, has):
+        """M11: the path every vehicle would like to continue on after the next move (-1: stay)."""
+        T = self.dt_.type
+        R, N = self.R, self.N
+        x, v, alive, route = self.x, self.v, self.alive, np.maximum(self.route, 0)
+        jj = np.arange(N)
+        g = self.shift(x)                                                  # joins upstream of me
+        la = self.shift(x + self.zip_d)
+        internal, _ = self._segment_lookup(x, self.route)
+        lane = route >> g
+        n_lanes = self.P >> g
+        ok0 = alive & self.lc_auto[None, :] & ~internal & (g < 2) & (la == g) & (n_lanes > 1) & \
+            ((self.time_counter[:, None] - self.last_lc) >= self.lc_cooldown)
+        pair_ok = alive[:, None, :] & alive[:, :, None] & (jj[None, None, :] != jj[None, :, None])
+        behind = pair_ok & ~ahead
+        best_gain = np.full((R, N), T(-BIG))
+        best_path = np.full((R, N), -1, dtype=np.int64)
+        vs_p = {k: np.array([vv.get(k, dflt) for vv in self.veh], dtype=self.dt_)
+                for k, dflt in (("sumo_min_gap", 2.5), ("sumo_tau", 1.0), ("max_accel", 2.6), ("max_decel", 4.5))}
+        two_sqrt = T(2) * np.sqrt(vs_p["max_accel"] * vs_p["max_decel"])
+
+        def need(a, b):
+            return vs_p["sumo_min_gap"][None, :] + np.maximum(T(0), a * vs_p["sumo_tau"][None, :] +
+                                                               a * (a - b) / two_sqrt[None, :])
+        for dlane in (-1, 1):                                              # right first, so that left wins a tie
+            tl = lane + dlane
+            valid = ok0 & (tl >= 0) & (tl < n_lanes)
+            p2 = np.where(valid, tl << g, 0)                               # lowest entry lane of the target lane
+            # leader on the target lane: as M5 / M8 with my path replaced by p2
+            sh = np.maximum(self.shift(x)[:, None, :], la[:, :, None])
+            cand = pair_ok & ahead & ((p2[:, :, None] >> sh) == (route[:, None, :] >> sh))
+            xl = np.where(cand, x[:, None, :], T(BIG))
+            li = (N - 1) - np.argmin(xl[:, :, ::-1], axis=2)
+            has_l = np.take_along_axis(xl, li[:, :, None], 2)[:, :, 0] < T(BIG)
+            gap_l = np.where(has_l, np.take_along_axis(d, li[:, :, None], 2)[:, :, 0] - self.veh_len[li], T(1000.0))
+            v_l = np.where(has_l, np.take_along_axis(v, li, 1), T(0))
+            # follower on the target lane: the nearest vehicle behind whose path leads onto that lane at my position
+            fc = behind & ((route[:, None, :] >> g[:, :, None]) == tl[:, :, None])
+            xf = np.where(fc, x[:, None, :], T(-BIG))
+            fi = np.argmax(xf, axis=2)                                     # largest x; lowest slot on a tie = nearest
+            has_f = np.take_along_axis(xf, fi[:, :, None], 2)[:, :, 0] > T(-BIG)
+            gap_f = np.where(has_f, (x - np.take_along_axis(x, fi, 1)) - self.veh_len[None, :], T(1000.0))
+            v_f = np.where(has_f, np.take_along_axis(v, fi, 1), T(0))
+            safe = (~has_l | (gap_l >= need(v, v_l))) & (~has_f | (gap_f >= need(v_f, v)))
+            gain = gap_l - h
+            want = valid & safe & (gain >= self.lc_min_gain)
+            take = want & (gain >= best_gain)
+            best_gain = np.where(take, gain, best_gain)
+            best_path = np.where(take, p2, best_path)
+        a2 = active[:, None]
+        self.lc_want = np.where(a2, best_path, self.lc_want)
+        self.lc_gain = np.where(a2, np.where(best_path >= 0, best_gain, T(0)), self.lc_gain)
+
+    def _apply_lane_change(self, active):
+        """M11: the one lane change of this step (largest gain, lowest slot on a tie); returns nothing, edits route."""
+        T = self.dt_.type
+        want = (self.lc_want >= 0) & self.alive & active[:, None]
+        gain = np.where(want, self.lc_gain, T(-BIG))
+        win = np.argmax(gain, axis=1)                                      # first maximum = lowest slot
+        rows = np.arange(self.R)
+        ok = want[rows, win]
+        self.route[rows[ok], win[ok]] = self.lc_want[rows[ok], win[ok]]
+        self.last_lc[rows[ok], win[ok]] = self.time_counter[ok] + 1
+        self.num_lane_changes = getattr(self, "num_lane_changes", np.zeros(self.R, dtype=np.int64)) + ok
 
     # ------------------------------------------------------------------ M6
     def _yield_speed_cap(self, v):
@@ -387,6 +468,8 @@ class MergeOracle:
         self.vmax = np.where(m2, np.array([v.get("sumo_max_speed", 30.0) for v in self.veh], dtype=self.dt_)[None, :],
                              self.vmax)
         self.arr_hist = np.where(m2[:, :1], 0, self.arr_hist)
+        self.last_lc = np.where(m2, -(1 << 30), self.last_lc)
+        self.lc_want = np.where(m2, -1, self.lc_want)
         self._just_arrived = np.where(m2, False, self._just_arrived)
         self.time_counter = np.where(m, 0, self.time_counter)
         self.sim_steps = np.where(m, 1, self.sim_steps)                    # S13: one step ran during the reset
@@ -451,6 +534,8 @@ class MergeOracle:
             self.last_accel[r_ok, s_ok] = T(0)
             self.route[r_ok, s_ok] = route[ok]
             self.vmax[r_ok, s_ok] = T(vs.get("sumo_max_speed", 30.0))
+            self.last_lc[r_ok, s_ok] = -(1 << 30)
+            self.lc_want[r_ok, s_ok] = -1
             self.seq[r_ok, s_ok] = self.seq_ctr[ok]
             self.origin[r_ok, s_ok] = f * (1 << 20) + k[ok]
             self.foll[r_ok, s_ok] = -1
@@ -509,6 +594,8 @@ class MergeOracle:
         cap = self._yield_speed_cap(v)
         obeys = np.array([(int(vs.get("speed_mode", 0)) & 1) != 0 for vs in self.veh])[None, :]
         v_new = np.where(obeys | ~commanded, np.minimum(v_new, cap), v_new)
+        if self.lc_enabled:
+            self._apply_lane_change(active)                                # M11, with this step's move
         x_new = x + ((v + v_new) / T(2) * dt if self.ballistic else v_new * dt)
         mv = active[:, None] & alive
         self.prev_v = np.where(mv, v, self.prev_v)

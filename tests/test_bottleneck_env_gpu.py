@@ -151,3 +151,20 @@ def test_vec_env_runs_the_c4_configuration():
     cnt = vec.sim.get_state(L.FS_FIELD_COUNTERS)
     assert (cnt[:, 0] == 1 + 40 + K).all() and (cnt[:, 6] > 50).all()
     assert torch.isfinite(o).all() and float(r.max()) > 0.3 and (o[-1, :, -1] > 0).any()
+
+
+def test_simulate_script_runs_the_bottleneck_experiment(tmp_path):
+    """examples/simulate.py bottleneck (the reference's examples/exp_configs/non_rl/bottleneck.py: BottleneckEnv, random
+    initial placement, lane_change_mode 1621 -> the simplified lane-change model): runs through install_as_flow() +
+    Experiment.run and reports an outflow."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "simulate.py"), "bottleneck"],
+                         cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "steps/second" in out.stdout and "Round 0, return" in out.stdout
+    m = re.search(r"Average, std outflows: ([0-9.]+)", out.stdout)
+    assert m and 800 < float(m.group(1)) < 2400, out.stdout[-800:]

@@ -296,3 +296,19 @@ def test_sharded_open_network_handles_reproduce_the_unsharded_run():
                                   np.concatenate([p.get_state(L.FS_FIELD_ROUTE) for p in parts]))
     for s in [whole] + parts:
         s.close()
+
+
+def test_bottleneck_simplified_lane_changing_f32_bit_exact():
+    """M11 on: the humans' lane_change_mode lets SUMO change lanes -> the simplified model runs in the kernel."""
+    from flow_amd import _lib as L
+    from helpers import bottleneck_spec
+    spec = bottleneck_spec(R=5, cap_human=48, cap_rl=8, horizon=400, seed=13, lane_change_cooldown_steps=8,
+                           lane_change_min_gain=8.0)
+    for v in spec["vehicles"][:48]:
+        v["lane_change_mode"] = 1621
+    ora = run_pair(spec, "f32", 400, bottleneck_actions(spec, 4))
+    assert (ora.num_lane_changes > 40).all()
+    spec64 = dict(spec, num_replicas=2)
+    for key in ("init_alive", "init_pos", "init_vel", "init_route"):
+        spec64[key] = np.asarray(spec[key])[:2]
+    run_pair(spec64, "f64", 200, bottleneck_actions(spec64, 4), check_every=25, exact=False, atol=1e-9)
