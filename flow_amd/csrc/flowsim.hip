@@ -132,6 +132,8 @@ struct Sim : SimBase {
       ivel[e] = cfg.init_vel ? T(cfg.init_vel[e]) : T(veh[e % N].initial_speed);
     }
     for (int r = 0; r < R; ++r) rlen[r] = cfg.ring_length ? T(cfg.ring_length[r]) : T(0);
+    for (T vv : ivel) init_vel_negative = init_vel_negative || !(vv >= T(-100));
+    neg_speed_possible = init_vel_negative;
     if ((rc = upload(&dv.init_pos, ipos))) return rc;
     if ((rc = upload(&dv.init_vel, ivel))) return rc;
     if ((rc = upload(&dv.ring_len, rlen))) return rc;
@@ -400,6 +402,10 @@ struct Sim : SimBase {
   // will use (v0 and 2*sqrt(a*b) of every slot, the loop length of every replica), it
   // reproduces x / c for ALL 2^23 float mantissas of x.  Checked lazily, once per handle state;
   // set_state of the ring lengths invalidates it.  Only the float kernels use it.
+  // rewards.py:46 ("any speed < -100 -> reward 0") can only fire on speeds put there from outside (see
+  // k_rollout_idm): true while the initial speeds or an upload since the last full reset held such a value
+  bool neg_speed_possible = false;
+  bool init_vel_negative = false;
   int fastdiv_state = -1;       // -1 unknown, 0 no, 1 yes
   static bool fastdiv_exact_for(float c) {
     if (!(c > 0.0f) || !std::isfinite(c)) return false;
@@ -493,15 +499,14 @@ struct Sim : SimBase {
       const int waves = blocks;                                   // one wave per 64/SEG replicas
       const int wpb = rollout_block / 64;                         // waves per block
       const dim3 grid((waves + wpb - 1) / wpb), block(rollout_block);
-      if (delta4 && fd)
-        hipLaunchKernelGGL((fs::k_rollout_idm<T, SEG, true, true>), grid, block, 0, stream, dv, num_steps, obs, rew,
-                           done, d_dump);
-      else if (delta4)
-        hipLaunchKernelGGL((fs::k_rollout_idm<T, SEG, true, false>), grid, block, 0, stream, dv, num_steps, obs, rew,
-                           done, d_dump);
-      else
-        hipLaunchKernelGGL((fs::k_rollout_idm<T, SEG, false, false>), grid, block, 0, stream, dv, num_steps, obs, rew,
-                           done, d_dump);
+      const bool bc = neg_speed_possible;
+#define FS_ROLLOUT(D4, FD, BC)                                                                               \
+  hipLaunchKernelGGL((fs::k_rollout_idm<T, SEG, D4, FD, BC>), grid, block, 0, stream, dv, num_steps, obs, rew, \
+                     done, d_dump)
+      if (delta4 && fd) { if (bc) FS_ROLLOUT(true, true, true); else FS_ROLLOUT(true, true, false); }
+      else if (delta4) { if (bc) FS_ROLLOUT(true, false, true); else FS_ROLLOUT(true, false, false); }
+      else { if (bc) FS_ROLLOUT(false, false, true); else FS_ROLLOUT(false, false, false); }
+#undef FS_ROLLOUT
     } else if (fast_ok(mask, num_steps))
       hipLaunchKernelGGL((fs::k_steps<T, SEG, 1>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, mask, actions,
                          act_stride, obs, rew, done, obs_every_step);
@@ -523,6 +528,7 @@ struct Sim : SimBase {
   }
 
   int launch_reset(const uint8_t* mask) override {
+    if (mask == nullptr) neg_speed_possible = init_vel_negative;     // every replica back at its initial speeds
     if (open_net) {
       const size_t n_open = size_t(dv.R) * dv.N;
       int blocks_open = int((n_open + 255) / 256);
@@ -670,6 +676,13 @@ struct Sim : SimBase {
     if (!p) return fail(FS_ERR_INVALID, "fs_set_state: unknown field");
     if (bytes != count * sizeof(T)) return fail(FS_ERR_INVALID, "fs_set_state: wrong byte count");
     HIP_TRY(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+    if (field == FS_FIELD_VEL || field == FS_FIELD_INIT_VEL) {
+      bool neg = false;
+      const T* vals = static_cast<const T*>(src);
+      for (size_t e = 0; e < count; ++e) neg = neg || !(vals[e] >= T(-100));
+      if (field == FS_FIELD_INIT_VEL) init_vel_negative = neg;
+      neg_speed_possible = neg_speed_possible || neg;
+    }
     if (open_net && (field == FS_FIELD_POS || field == FS_FIELD_VEL))   // refresh the leader / headway snapshot
       return launch_steps(0, nullptr, nullptr, 0, d_obs, d_rew, d_done, 0);
     if (field == FS_FIELD_RING_LENGTH) {

@@ -127,7 +127,9 @@ enum : int {
   DPP_WAVE_SHL1 = 0x130,    // lane i <- lane i+1
   DPP_WAVE_SHR1 = 0x138,    // lane i <- lane i-1
   DPP_ROW_MIRROR = 0x140,   // lane i <- lane 15-i   (within a row of 16)
-  DPP_ROW_HALF_MIRROR = 0x141  // lane i <- lane 7-i (within a half row of 8)
+  DPP_ROW_HALF_MIRROR = 0x141, // lane i <- lane 7-i (within a half row of 8)
+  DPP_ROW_SHL1 = 0x101, DPP_ROW_SHL2 = 0x102, DPP_ROW_SHL4 = 0x104, DPP_ROW_SHL8 = 0x108,   // lane i <- lane i+n (row of 16)
+  DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118    // lane i <- lane i-n
 };
 
 // bound_ctrl: a lane whose source does not exist reads 0 (only the last / first lane of the wave
@@ -254,6 +256,68 @@ __device__ __forceinline__ T seg_sum(T v) {
   v = v + dpp<DPP_ROW_HALF_MIRROR>(v);
   if (SEG >= 16) v = v + dpp<DPP_ROW_MIRROR>(v);
   if (SEG >= 32) v = add_swap16(v);
+  if (SEG >= 64) v = add_swap32(v);
+  return v;
+}
+
+
+// ---------------------------------------------------------------------------
+// Transposed reduction: K = 2^k vectors (one value per lane each) are summed over the lanes of a segment
+// TOGETHER -- after level b every lane keeps only the vectors whose index has bit b equal to its own lane bit b,
+// so the register count halves per level and lane i ends up with the complete sum of vector i.  Each level
+// adds the xor-2^b partner, i.e. exactly the tree of seg_sum / oracle tree_sum (a + b is commutative), in
+// ~3 VALU per surviving vector instead of one full butterfly per vector.
+//   lanes with bit b = 0 need lo_own + lo_partner(l + 2^b), lanes with bit b = 1 need hi_own + hi_partner(l - 2^b):
+//   both sums are formed with a row shift (the out-of-row reads are never selected) and picked per lane;
+//   the xor-16 / xor-32 levels use v_permlane{16,32}_swap(lo, hi), whose two results add up to exactly that.
+// ---------------------------------------------------------------------------
+template <int SHL, int SHR, typename T>
+__device__ __forceinline__ T tr_combine(T lo, T hi, bool upper) {
+  const T t = lo + dpp<SHL>(lo);
+  const T u = hi + dpp<SHR>(hi);
+  return upper ? u : t;
+}
+__device__ __forceinline__ float tr_combine16(float lo, float hi) {
+  unsigned a = __builtin_bit_cast(unsigned, lo), b = __builtin_bit_cast(unsigned, hi);
+  swap_rows16(a, b);
+  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ double tr_combine16(double lo, double hi) {
+  const unsigned long long bl = __builtin_bit_cast(unsigned long long, lo), bh = __builtin_bit_cast(unsigned long long, hi);
+  unsigned l0 = unsigned(bl), l1 = unsigned(bl >> 32), h0 = unsigned(bh), h1 = unsigned(bh >> 32);
+  swap_rows16(l0, h0);
+  swap_rows16(l1, h1);
+  return __builtin_bit_cast(double, ((unsigned long long)l1 << 32) | l0) +
+         __builtin_bit_cast(double, ((unsigned long long)h1 << 32) | h0);
+}
+// K vectors in a[0..K-1] -> the sum of vector (lane % K) over the SEG-lane segment, in every lane
+template <int SEG, int K, typename T>
+__device__ __forceinline__ T transposed_sum(T* a, int lane) {
+  static_assert(K <= 32 && K <= SEG, "at most min(SEG, 32) vectors");
+  if (K >= 2) {
+#pragma unroll
+    for (int k = 0; k < K / 2; ++k) a[k] = tr_combine<DPP_ROW_SHL1, DPP_ROW_SHR1>(a[2 * k], a[2 * k + 1], (lane & 1) != 0);
+  }
+  if (K >= 4) {
+#pragma unroll
+    for (int k = 0; k < K / 4; ++k) a[k] = tr_combine<DPP_ROW_SHL2, DPP_ROW_SHR2>(a[2 * k], a[2 * k + 1], (lane & 2) != 0);
+  }
+  if (K >= 8) {
+#pragma unroll
+    for (int k = 0; k < K / 8; ++k) a[k] = tr_combine<DPP_ROW_SHL4, DPP_ROW_SHR4>(a[2 * k], a[2 * k + 1], (lane & 4) != 0);
+  }
+  if (K >= 16) {
+#pragma unroll
+    for (int k = 0; k < K / 16; ++k) a[k] = tr_combine<DPP_ROW_SHL8, DPP_ROW_SHR8>(a[2 * k], a[2 * k + 1], (lane & 8) != 0);
+  }
+  if (K >= 32) a[0] = tr_combine16(a[0], a[1]);
+  T v = a[0];
+  // lanes of the segment that hold the same vector index still have to be added up (SEG > K)
+  if (K < 2 && SEG >= 2) v = v + dpp<DPP_QUAD_XOR1>(v);
+  if (K < 4 && SEG >= 4) v = v + dpp<DPP_QUAD_XOR2>(v);
+  if (K < 8 && SEG >= 8) v = v + dpp<DPP_ROW_HALF_MIRROR>(v);
+  if (K < 16 && SEG >= 16) v = v + dpp<DPP_ROW_MIRROR>(v);
+  if (K < 32 && SEG >= 32) v = add_swap16(v);
   if (SEG >= 64) v = add_swap32(v);
   return v;
 }
@@ -869,9 +933,14 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
 // purely structural, to keep the step loop one straight-line block the scheduler can overlap:
 //   * idle lanes store to a scratch word instead of being masked off (no exec-mask regions);
 //   * the per-replica reward tail (sqrt, divide) is deferred: lane j of a segment keeps the
-//     reduced sum of squares of step j (mod PERIOD = min(SEG, 32)); PERIOD rewards are finished
-//     and stored together, one step per lane; the collision / bad-speed facts of those steps
-//     travel as per-lane bit masks and are OR-reduced once per flush.
+//     reduced sum of squares of step j of a block of PERIOD = min(SEG, 32) steps: the PERIOD per-lane terms
+//     are summed over the lanes TOGETHER (transposed_sum, ~3 VALU per step instead of a full butterfly each),
+//     and the PERIOD rewards are finished and stored at once, one step per lane; the collision / bad-speed
+//     facts of those steps travel as per-lane bit masks and are OR-reduced once per flush.
+//   * BADCHK = false drops the "any speed < -100" test of rewards.py:46: with next_vel = max(.., 0) and a ramp in
+//     (0, 1] a speed >= -100 can never fall below -100 again, so the test can only fire on speeds that were put
+//     there from outside; the host selects BADCHK = true whenever the initial speeds or an fs_set_state upload
+//     since the last full reset contained a value < -100 (Sim::neg_speed_possible).
 // x / c for a divisor c that is constant over the launch.  FASTDIV (float only) replaces the
 // IEEE division sequence by q0 = x*rc, r = fma(-q0, c, x), q = fma(r, rc, q0) with rc = RN(1/c).
 // The host enables it per handle only after checking, for EVERY float mantissa of x, that the
@@ -917,7 +986,7 @@ __device__ __forceinline__ float div_core(float n, float d) {
 }
 __device__ __forceinline__ double div_core(double n, double d) { return n / d; }
 
-template <typename T, int SEG, bool DELTA4, bool FASTDIV>
+template <typename T, int SEG, bool DELTA4, bool FASTDIV, bool BADCHK>
 __global__ __launch_bounds__(1024) void k_rollout_idm(DevView<T> s, int num_steps, float* __restrict__ obs,
                                                       float* __restrict__ rew, uint8_t* __restrict__ done,
                                                       float* __restrict__ dump) {
@@ -962,64 +1031,72 @@ __global__ __launch_bounds__(1024) void k_rollout_idm(DevView<T> s, int num_step
   float* po = valid ? obs + size_t(rr) * row + ii : dump;     // idle lanes write scratch
   const size_t po_step = valid ? size_t(s.R) * row : 0;          // the scratch word does not move
   constexpr int PERIOD = SEG < 32 ? SEG : 32;     // steps whose reward tail is finished together
-  T racc = T(0);
   unsigned crash_bits = 0u, bad_bits = 0u;
 
-  for (int step = 0; step < num_steps; ++step) {
-    // IDMController.get_accel (ctrl_idm, car_following_models.py:464-482)
-    T hh = tabs(h) < T(1e-3) ? T(1e-3) : h;
-    T num = v * (v - vl);
-    T dq = div_const<FASTDIV>(num, two_sqrt_ab, rc_ab);
-    T ratio = div_const<FASTDIV>(v, p[0], rc_v0);
-    T dyn = v * p[1] + dq;
-    T s_star = p[5] + tmax(T(0), dyn);
-    T q = FASTDIV ? div_core(s_star, hh) : s_star / hh;
-    T pw;
-    if (DELTA4) { T r2 = ratio * ratio; pw = r2 * r2; } else { pw = pow_delta(ratio, p[4]); }
-    T acc = p[2] * (T(1) - pw - q * q);
-    // apply_acceleration + integration (S4-S9)
-    T next_vel = tmax(v + acc * dt, T(0));
-    v = v + (next_vel - v) * ramp;
-    T x_new = x + v * dt;
-    x = x_new >= L ? x_new - L : x_new;
-    tcount += 1;
-    // new neighbour snapshot (S10) and collision check (S12)
-    xl = lead_read<SEG>(x, seg, wrap_lead);
-    vl = lead_read<SEG>(v, seg, wrap_lead);
-    d = xl - x;
-    d = d < T(0) ? d + L : d;
-    h = d - len_lead;
-    // collision (S12) and the v < -100 guard (rewards.py:46) are per-lane facts of this step: each lane
-    // records them in bit `slot` of a mask and the per-replica "any" is taken for all SEG steps at once
-    // at the flush (an OR-butterfly over the segment), instead of two ballots per step
-    const int slot = step & (PERIOD - 1);
-    const unsigned bit = 1u << slot;
-    crash_bits |= (valid && (h < s.crash_gap)) ? bit : 0u;
-    bad_bits |= (valid && (v < T(-100))) ? bit : 0u;
-    // AccelEnv.get_state (accel.py:116-123)
-    po[0] = float(v / s.max_speed);                      // an output: IEEE division (see div_const)
-    po[N] = float(div_const<FASTDIV>(x, L, rc_L));
-    po += po_step;
-    // rewards.desired_velocity, first half: the reduced sum of squares (rewards.py:53-54)
-    T dv = valid ? v - s.target_velocity : T(0);
-    T ssum = seg_sum<SEG>(dv * dv);
-    racc = (i == slot) ? ssum : racc;
-    if (slot == PERIOD - 1 || step == num_steps - 1) {       // wave-uniform: finish PERIOD rewards at once
-      const unsigned crash_any = seg_or<SEG>(crash_bits);
-      const unsigned bad_any = seg_or<SEG>(bad_bits) | crash_any;
-      crash_bits = 0u;
-      bad_bits = 0u;
-      if (rvalid && i <= slot) {
-        const bool my_bad = (bad_any >> i) & 1u;
-        const bool my_crash = (crash_any >> i) & 1u;
-        const int t_i = tcount - (slot - i);                 // time counter after the step this lane finishes
-        T cost = tsqrt(racc);
-        T reward = tmax(s.max_cost - cost, T(0)) / (s.max_cost + T(1.1920928955078125e-07));   // rewards.py:59
-        reward = my_bad ? T(0) : reward;                                                        // rewards.py:46
-        const size_t o = size_t(step - slot + i) * s.R + rr;
-        rew[o] = float(reward);
-        done[o] = uint8_t((t_i >= s.step_limit) || my_crash);                                   // envs/base.py:398-400
+  // PERIOD steps at a time: each keeps its per-lane (v - v_target)^2 in a register; the PERIOD vectors are then
+  // summed over the lanes together (transposed_sum) and lane j finishes the reward of step j
+  for (int base = 0; base < num_steps; base += PERIOD) {
+    T sq[PERIOD];
+#pragma unroll
+    for (int slot = 0; slot < PERIOD; ++slot) {
+      sq[slot] = T(0);
+      if (base + slot < num_steps) {                       // wave-uniform
+        // IDMController.get_accel (ctrl_idm, car_following_models.py:464-482)
+        T hh = tabs(h) < T(1e-3) ? T(1e-3) : h;
+        T num = v * (v - vl);
+        T dq = div_const<FASTDIV>(num, two_sqrt_ab, rc_ab);
+        T ratio = div_const<FASTDIV>(v, p[0], rc_v0);
+        T dyn = v * p[1] + dq;
+        T s_star = p[5] + tmax(T(0), dyn);
+        T q = FASTDIV ? div_core(s_star, hh) : s_star / hh;
+        T pw;
+        if (DELTA4) { T r2 = ratio * ratio; pw = r2 * r2; } else { pw = pow_delta(ratio, p[4]); }
+        T acc = p[2] * (T(1) - pw - q * q);
+        // apply_acceleration + integration (S4-S9)
+        T next_vel = tmax(v + acc * dt, T(0));
+        v = v + (next_vel - v) * ramp;
+        T x_new = x + v * dt;
+        x = x_new >= L ? x_new - L : x_new;
+        tcount += 1;
+        // new neighbour snapshot (S10) and collision check (S12)
+        xl = lead_read<SEG>(x, seg, wrap_lead);
+        vl = lead_read<SEG>(v, seg, wrap_lead);
+        d = xl - x;
+        d = d < T(0) ? d + L : d;
+        h = d - len_lead;
+        // collision (S12) and the v < -100 guard (rewards.py:46) are per-lane facts of this step: each lane
+        // records them in bit `slot` of a mask and the per-replica "any" is taken for all PERIOD steps at once
+        // at the flush (an OR-butterfly over the segment), instead of two ballots per step.  (Collecting the
+        // ballots as scalar masks instead was measured slower: 10.24 vs 10.45 G env-steps/s.)
+        const unsigned bit = 1u << slot;
+        crash_bits |= (valid && (h < s.crash_gap)) ? bit : 0u;
+        if (BADCHK) bad_bits |= (valid && (v < T(-100))) ? bit : 0u;
+        // AccelEnv.get_state (accel.py:116-123)
+        po[0] = float(v / s.max_speed);                    // an output: IEEE division (see div_const)
+        po[N] = float(div_const<FASTDIV>(x, L, rc_L));
+        po += po_step;
+        // rewards.desired_velocity, first half: this lane's term of the sum of squares (rewards.py:53-54)
+        T dv = valid ? v - s.target_velocity : T(0);
+        sq[slot] = dv * dv;
       }
+    }
+    const T racc = transposed_sum<SEG, PERIOD>(sq, lane);
+    const int last = (num_steps - base < PERIOD ? num_steps - base : PERIOD) - 1;   // last step of this block
+    const unsigned crash_any = seg_or<SEG>(crash_bits);
+    const unsigned bad_any = (BADCHK ? seg_or<SEG>(bad_bits) : 0u) | crash_any;
+    crash_bits = 0u;
+    bad_bits = 0u;
+    const int j = i & (PERIOD - 1);                         // the step of the block this lane finishes
+    if (rvalid && i < PERIOD && j <= last) {
+      const bool my_bad = (bad_any >> j) & 1u;
+      const bool my_crash = (crash_any >> j) & 1u;
+      const int t_i = tcount - (last - j);                 // time counter after that step
+      T cost = tsqrt(racc);
+      T reward = tmax(s.max_cost - cost, T(0)) / (s.max_cost + T(1.1920928955078125e-07));   // rewards.py:59
+      reward = my_bad ? T(0) : reward;                                                        // rewards.py:46
+      const size_t o = size_t(base + j) * s.R + rr;
+      rew[o] = float(reward);
+      done[o] = uint8_t((t_i >= s.step_limit) || my_crash);                                   // envs/base.py:398-400
     }
   }
   if (valid) {

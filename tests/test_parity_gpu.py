@@ -733,3 +733,39 @@ def test_sort_vehicles_and_shuffled_ids_bit_exact():
     n_rl = spec8["num_rl"]
     acts = rng.uniform(-1, 1, (300, 6, max(n_rl, 1))).astype(np.float32)
     run_pair(spec8, "f32", 300, acts if n_rl else None, check_every=50)
+
+
+def test_rollout_kernel_keeps_the_bad_speed_rule_when_speeds_come_from_outside(monkeypatch):
+    """rewards.py:46: any speed < -100 -> reward 0.  The rollout kernel drops that compare unless such a speed was
+    uploaded (initial speeds / fs_set_state) since the last full reset: both cases must equal the generic kernel."""
+    import torch
+    from flow_amd import _lib as L
+    R, N, K = 64, 22, 40
+    spec = perturbed(ring_spec(R=R, N=N, junction_length=0.1, horizon=1500), seed=5)
+    outs = {}
+    for force in ("0", "1"):
+        monkeypatch.setenv("FLOWSIM_FORCE_GENERIC", force)
+        sim = make(spec, "f32")
+        sim.reset()
+        dev = torch.device("cuda:0")
+        bufs = (torch.empty((K, R, 2 * N), dtype=torch.float32, device=dev),
+                torch.empty((K, R), dtype=torch.float32, device=dev), torch.empty((K, R), dtype=torch.uint8, device=dev))
+        sim.rollout_dev(K, *bufs)                                       # plain state: nothing below -100
+        sim.sync()
+        first = bufs[1].cpu().numpy().copy()
+        v = sim.vel
+        v[::2, 3] = -30000.0                                            # -> -297 after one step (ramp 0.99), then -2.9
+        sim.set_state(L.FS_FIELD_VEL, v)
+        sim.rollout_dev(K, *bufs)
+        sim.sync()
+        second = bufs[1].cpu().numpy().copy()
+        sim.reset()                                                     # full reset: back to the unchecked variant
+        sim.rollout_dev(K, *bufs)
+        sim.sync()
+        outs[force] = (first, second, bufs[1].cpu().numpy().copy(), sim.vel)
+        sim.close()
+    for a, b in zip(outs["0"], outs["1"]):
+        np.testing.assert_array_equal(a, b)
+    second = outs["0"][1]
+    assert (second[0, ::2] == 0).all() and (second[0, 1::2] > 0).all() and (outs["0"][0] > 0).all()
+    np.testing.assert_array_equal(outs["0"][0], outs["0"][2])
