@@ -494,7 +494,8 @@ struct Sim : SimBase {
       HIP_TRY(hipGetLastError());
       return FS_OK;
     }
-    if (fast_ok(mask, num_steps) && obs_every_step && dv.N > 1 && actions == nullptr) {
+    if (fast_ok(mask, num_steps) && obs_every_step && dv.N > 1 && actions == nullptr &&
+        size_t(dv.R) * 2 * dv.N * sizeof(float) < (size_t(1) << 32)) {   // 32-bit byte offsets inside one step's block
       const bool fd = fastdiv_ok();
       const int waves = blocks;                                   // one wave per 64/SEG replicas
       const int wpb = rollout_block / 64;                         // waves per block

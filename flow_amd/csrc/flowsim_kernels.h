@@ -1027,9 +1027,18 @@ __global__ __launch_bounds__(1024) void k_rollout_idm(DevView<T> s, int num_step
   const T dt = s.dt, ramp = s.ramp;
   const T two_sqrt_ab = T(2) * tsqrt(p[2] * p[3]);
   const T rc_L = T(1) / L, rc_v0 = T(1) / p[0], rc_ab = T(1) / two_sqrt_ab;
-  const size_t row = size_t(2) * N;
-  float* po = valid ? obs + size_t(rr) * row + ii : dump;     // idle lanes write scratch
-  const size_t po_step = valid ? size_t(s.R) * row : 0;          // the scratch word does not move
+  // Observation stores: one wave-uniform base pointer that advances by a whole [R, 2N] block per step (scalar
+  // add) plus a 32-bit per-lane byte offset: one v_lshl_add_u64 per store instead of carrying a 64-bit pointer per
+  // lane.  (Forcing the SGPR-base `global_store_dword voff, vdata, saddr` form with a one-instruction asm was
+  // measured slower, 11.38 vs 11.49 G env-steps/s: the volatile asm pins the scheduler.)  Idle lanes (i >= N, or a replica index past R) are exact clones of slot N-1 /
+  // replica R-1 (same state, same leader, same parameters: see ii / rr / wrap_lead above), so they store the SAME
+  // values to the SAME addresses as the lane they shadow instead of being masked off.
+  const unsigned row = 2u * unsigned(N);
+  const unsigned off_b = (unsigned(rr) * row + unsigned(ii)) * 4u;      // BYTE offsets: the host guarantees < 2^32
+  const unsigned off_b2 = off_b + unsigned(N) * 4u;
+  char* ob = reinterpret_cast<char*>(obs);
+  const size_t ob_step = size_t(s.R) * row * sizeof(float);
+  (void)dump;
   constexpr int PERIOD = SEG < 32 ? SEG : 32;     // steps whose reward tail is finished together
   unsigned crash_bits = 0u, bad_bits = 0u;
 
@@ -1047,7 +1056,9 @@ __global__ __launch_bounds__(1024) void k_rollout_idm(DevView<T> s, int num_step
         T dq = div_const<FASTDIV>(num, two_sqrt_ab, rc_ab);
         T ratio = div_const<FASTDIV>(v, p[0], rc_v0);
         T dyn = v * p[1] + dq;
-        T s_star = p[5] + tmax(T(0), dyn);
+        // max(0, dyn) written so that it compiles to one v_max_f32 (operand order only matters for a NaN dyn,
+        // which no finite state produces; k_steps keeps np.maximum's NaN propagation)
+        T s_star = p[5] + tmax(dyn, T(0));
         T q = FASTDIV ? div_core(s_star, hh) : s_star / hh;
         T pw;
         if (DELTA4) { T r2 = ratio * ratio; pw = r2 * r2; } else { pw = pow_delta(ratio, p[4]); }
@@ -1068,13 +1079,14 @@ __global__ __launch_bounds__(1024) void k_rollout_idm(DevView<T> s, int num_step
         // records them in bit `slot` of a mask and the per-replica "any" is taken for all PERIOD steps at once
         // at the flush (an OR-butterfly over the segment), instead of two ballots per step.  (Collecting the
         // ballots as scalar masks instead was measured slower: 10.24 vs 10.45 G env-steps/s.)
+        // (idle lanes are clones of a valid lane: their flags repeat that lane's and need no masking)
         const unsigned bit = 1u << slot;
-        crash_bits |= (valid && (h < s.crash_gap)) ? bit : 0u;
-        if (BADCHK) bad_bits |= (valid && (v < T(-100))) ? bit : 0u;
+        crash_bits |= (h < s.crash_gap) ? bit : 0u;
+        if (BADCHK) bad_bits |= (v < T(-100)) ? bit : 0u;
         // AccelEnv.get_state (accel.py:116-123)
-        po[0] = float(v / s.max_speed);                    // an output: IEEE division (see div_const)
-        po[N] = float(div_const<FASTDIV>(x, L, rc_L));
-        po += po_step;
+        *reinterpret_cast<float*>(ob + off_b) = float(v / s.max_speed);   // an output: IEEE division (see div_const)
+        *reinterpret_cast<float*>(ob + off_b2) = float(div_const<FASTDIV>(x, L, rc_L));
+        ob += ob_step;
         // rewards.desired_velocity, first half: this lane's term of the sum of squares (rewards.py:53-54)
         T dv = valid ? v - s.target_velocity : T(0);
         sq[slot] = dv * dv;
