@@ -131,3 +131,14 @@ def test_config_validation_needs_no_gpu(lib):
     with pytest.raises(ValueError, match="segment table"):
         FlowSim(dict(spec(), junction=dict(a_in=1, a_out=2, b_in=3, b_out=4, lookahead=1, time_gap=1, za_lo=0,
                                            za_hi=1, zb_lo=0, zb_hi=1)), "f32")
+
+
+def test_integration_doc_binding_lists_the_current_fields():
+    """INTEGRATION.md shows the ctypes stub a maintainer of the reference would add: its field lists must be the
+    binding's (they are regenerated from flow_amd/_lib.py whenever the ABI changes)."""
+    from flow_amd import _lib
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for cls in (_lib.fs_vehicle_spec, _lib.fs_segment, _lib.fs_inflow, _lib.fs_cell, _lib.fs_junction, _lib.fs_config):
+        m = re.search(r"class %s\(C\.Structure\):\n(.*?)\]\n" % cls.__name__, text, flags=re.S)
+        assert m, cls.__name__
+        assert re.findall(r'\("([a-z_0-9]+)",', m.group(1)) == [n for n, _ in cls._fields_], cls.__name__
