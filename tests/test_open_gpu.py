@@ -312,3 +312,65 @@ def test_bottleneck_simplified_lane_changing_f32_bit_exact():
     for key in ("init_alive", "init_pos", "init_vel", "init_route"):
         spec64[key] = np.asarray(spec[key])[:2]
     run_pair(spec64, "f64", 200, bottleneck_actions(spec64, 4), check_every=25, exact=False, atol=1e-9)
+
+
+def random_open_spec(seed):
+    """A random open-network configuration: merge (two paths) or lane drop (four), random geometry knobs, inflow
+    rates, slot pools, controllers, horizons -- everything the kernel has a branch for."""
+    from helpers import bottleneck_spec
+    rng = np.random.default_rng(1000 + seed)
+    R = int(rng.integers(1, 9))
+    if seed % 3 != 2:                                                   # ---- merge
+        cap_rl = int(rng.integers(1, 6))
+        cap_h = int(rng.choice([6, 11, 14, 27, 40])) if cap_rl + 40 <= 64 else 12
+        ma = bool(rng.integers(0, 2))
+        num_rl = cap_rl if ma else int(rng.integers(1, cap_rl + 1))
+        spec = quiet(merge_spec(R=R, cap_human=cap_h, cap_rl=cap_rl, num_rl=num_rl, pre=float(rng.choice([80, 200, 500])),
+                                merge=float(rng.choice([60, 100])), post=float(rng.choice([50, 100])),
+                                horizon=int(rng.integers(40, 200)), seed=seed,
+                                q_highway=float(rng.choice([600, 1500, 2400])), q_rl=float(rng.choice([150, 400, 900])),
+                                q_merge=float(rng.choice([100, 400, 900])), n_init=int(rng.integers(0, 4)),
+                                env=O.ENV_MERGE_MA if ma else None, time_gap=float(rng.choice([0.5, 1.0, 3.0])),
+                                sims_per_step=int(rng.choice([1, 1, 2, 5])), warmup_steps=int(rng.choice([0, 0, 6])),
+                                ma_apply_actions=bool(rng.integers(0, 2)), crash_gap=float(rng.choice([0.0, 0.5])),
+                                slowdown_ramp=float(rng.choice([1.0, 0.2 / 0.201]))))
+        spec["junction"]["enabled"] = int(rng.integers(0, 2))
+        veh = spec["vehicles"]
+        for i in range(cap_h):
+            kind = int(rng.integers(0, 6))
+            if kind == 1:
+                veh[i] = idm_vehicle(controller=S.CTRL_SIM, speed_mode=int(rng.choice([0, 1, 7, 25, 31])), type=0)
+            elif kind == 2:
+                veh[i] = idm_vehicle(controller=S.CTRL_FOLLOWER_STOPPER, p=[float(rng.uniform(5, 20))] + [0] * 7,
+                                     speed_mode=1, type=0)
+            elif kind == 3:
+                veh[i] = idm_vehicle(controller=S.CTRL_CFM, p=[1, 1, 1, 1, 8, 0, 0, 0], speed_mode=1, type=0,
+                                     fail_safe=S.FAILSAFE_INSTANTANEOUS)
+            else:
+                veh[i] = idm_vehicle(p=[float(rng.uniform(15, 30)), 1, float(rng.uniform(0.8, 2)), 1.5, 4, 2, 0, 0],
+                                     speed_mode=int(rng.choice([0, 1, 3])), type=0)
+        A = spec["num_rl"]
+        acts = (lambda k, r=np.random.default_rng(seed): r.uniform(-1.0, 1.5, (R, A)).astype(np.float32))
+        return spec, acts
+    cap_rl = int(rng.integers(2, 9))
+    spec = bottleneck_spec(R=R, cap_human=int(rng.integers(33, 57 - cap_rl)), cap_rl=cap_rl,
+                           horizon=int(rng.integers(60, 220)), seed=seed, q=float(rng.choice([1200, 2300, 3600])),
+                           av_frac=float(rng.choice([0.1, 0.3])), zipper_distance=float(rng.choice([0.0, 20.0, 50.0, 120.0])),
+                           warmup_steps=int(rng.choice([0, 0, 20])), lane_change_cooldown_steps=int(rng.choice([2, 8, 20])),
+                           lane_change_min_gain=float(rng.choice([3.0, 10.0])), crash_gap=float(rng.choice([0.0, 1.0])))
+    if rng.integers(0, 2):
+        for v in spec["vehicles"][:int(spec["num_vehicles"]) - cap_rl]:
+            v["lane_change_mode"] = 1621
+    if rng.integers(0, 3) == 0:
+        for v in spec["vehicles"][int(spec["num_vehicles"]) - cap_rl:]:
+            v["lane_change_mode"] = 597
+    A = spec["num_rl"]
+    acts = (lambda k, r=np.random.default_rng(seed): r.uniform(-1.5, 1.5, (R, A)).astype(np.float32))
+    return spec, acts
+
+
+@pytest.mark.parametrize("seed", list(range(18)))
+def test_fuzz_random_open_network_configs_bit_exact(seed):
+    spec, acts = random_open_spec(seed)
+    steps = int(spec["horizon"])
+    run_pair(spec, "f32", steps, acts if seed % 5 else None, check_every=max(1, steps // 4))
