@@ -275,6 +275,53 @@ def gen_defaults():
     return doc
 
 
+def gen_inflows():
+    """InFlows.add as the reference stores it (flow/core/params.py:1080-1213), for the calls the merge and bottleneck
+    experiments make (deprecated spellings included), its error cases, and the vehicle-type dicts of those
+    experiments -- the inputs of the open-network spec builder."""
+    import warnings
+    from flow.core import params as P
+    warnings.simplefilter("ignore")
+    calls = [
+        dict(veh_type="human", edge="inflow_highway", vehs_per_hour=1800, departLane="free", departSpeed=10),
+        dict(veh_type="rl", edge="inflow_highway", vehs_per_hour=200, depart_lane="free", depart_speed=10),
+        dict(veh_type="human", edge="inflow_merge", vehsPerHour=100, departLane="free", departSpeed=7.5),
+        dict(veh_type="human", edge="1", vehs_per_hour=2070.0, departLane="random", departSpeed=10),
+        dict(veh_type="human", edge="1", period=3, number=7, begin=5),
+        dict(veh_type="human", edge="1", probability=0.25, name="prob"),
+    ]
+    inflow = P.InFlows()
+    for c in calls:
+        inflow.add(**dict(c))
+    errors = []
+    for bad in (dict(), dict(vehs_per_hour=1, period=2), dict(probability=1.5), dict(vehs_per_hour=1, begin=0),
+                dict(probability=-0.1)):
+        try:
+            P.InFlows().add(veh_type="human", edge="e", **bad)
+            errors.append({"args": bad, "error": None})
+        except Exception as e:                                        # noqa: BLE001
+            errors.append({"args": bad, "error": type(e).__name__})
+    v = P.VehicleParams()
+    v.add(veh_id="human", lane_change_controller=(fc.SimLaneChangeController, {}),
+          routing_controller=(fc.ContinuousRouter, {}),
+          car_following_params=P.SumoCarFollowingParams(speed_mode="all_checks"),
+          lane_change_params=P.SumoLaneChangeParams(lane_change_mode=0), num_vehicles=1)
+    v.add(veh_id="followerstopper", acceleration_controller=(fc.RLController, {}),
+          car_following_params=P.SumoCarFollowingParams(speed_mode=9),
+          lane_change_params=P.SumoLaneChangeParams(lane_change_mode=1621), num_vehicles=1)
+    types = {}
+    for name, tp in v.type_parameters.items():
+        types[name] = {"acceleration_controller": tp["acceleration_controller"][0].__name__,
+                       "lane_change_controller": tp["lane_change_controller"][0].__name__,
+                       "speed_mode": tp["car_following_params"].speed_mode,
+                       "controller_params": tp["car_following_params"].controller_params,
+                       "lane_change_mode": tp["lane_change_params"].lane_change_mode,
+                       "initial_speed": tp["initial_speed"]}
+    return {"calls": calls, "flows": inflow.get(), "errors": errors, "vehicle_types": types,
+            "initial": [{k: (t[k] if not isinstance(t[k], tuple) else t[k][0].__name__)
+                         for k in ("veh_id", "num_vehicles", "initial_speed")} for t in v.initial]}
+
+
 def copy_flow_params():
     """The stored flow_params files the reference's own tests hold (data, not code):
     tests/fast_tests/test_files/ring_230.json and merge.json."""
@@ -297,7 +344,8 @@ def copy_emission():
 def main():
     rng = np.random.default_rng(20261003)
     for name, fn in (("controllers", gen_controllers), ("failsafes", gen_failsafes),
-                     ("rewards", gen_rewards), ("defaults", lambda r: gen_defaults())):
+                     ("rewards", gen_rewards), ("defaults", lambda r: gen_defaults()),
+                     ("inflows", lambda r: gen_inflows())):
         with open(os.path.join(HERE, name + ".json"), "w") as f:
             json.dump(fn(rng), f, indent=1)
         print("wrote", name)

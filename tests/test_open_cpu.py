@@ -504,3 +504,40 @@ def test_simplified_lane_changing_facts():
     # cool-down: no vehicle has two changes closer than 10 steps -- checked through last_lc bookkeeping above; the lanes
     # ahead of the first join are used evenly enough that nobody is starved
     assert o.total_arrived.min() > 40
+
+
+def test_inflows_and_vehicle_types_match_the_reference_golden():
+    """tests/golden/inflows.json: what the reference's own InFlows.add / VehicleParams.add produce (generated by
+    importing flow.core.params, gen_golden.py: gen_inflows) for the calls of the merge / bottleneck experiments."""
+    import json
+    from flow_amd.controllers import ContinuousRouter, RLController, SimLaneChangeController
+    from flow_amd.core import params as P
+    gold = json.load(open(os.path.join(GOLDEN, "inflows.json")))
+    inflow = P.InFlows()
+    for c in gold["calls"]:
+        inflow.add(**dict(c))
+    assert inflow.get() == gold["flows"]
+    for case in gold["errors"]:
+        if case["error"] is None:
+            P.InFlows().add(veh_type="human", edge="e", **case["args"])
+        else:
+            with pytest.raises(ValueError):
+                P.InFlows().add(veh_type="human", edge="e", **case["args"])
+            assert case["error"] == "ValueError"
+    v = P.VehicleParams()
+    v.add(veh_id="human", lane_change_controller=(SimLaneChangeController, {}), routing_controller=(ContinuousRouter, {}),
+          car_following_params=P.SumoCarFollowingParams(speed_mode="all_checks"),
+          lane_change_params=P.SumoLaneChangeParams(lane_change_mode=0), num_vehicles=1)
+    v.add(veh_id="followerstopper", acceleration_controller=(RLController, {}),
+          car_following_params=P.SumoCarFollowingParams(speed_mode=9),
+          lane_change_params=P.SumoLaneChangeParams(lane_change_mode=1621), num_vehicles=1)
+    for name, want in gold["vehicle_types"].items():
+        tp = v.type_parameters[name]
+        assert tp["acceleration_controller"][0].__name__ == want["acceleration_controller"]
+        assert tp["lane_change_controller"][0].__name__ == want["lane_change_controller"]
+        assert tp["car_following_params"].speed_mode == want["speed_mode"]
+        assert tp["car_following_params"].controller_params == want["controller_params"]
+        assert tp["lane_change_params"].lane_change_mode == want["lane_change_mode"]
+        assert tp["initial_speed"] == want["initial_speed"]
+    assert [(t["veh_id"], t["num_vehicles"], t["initial_speed"]) for t in v.initial] == \
+        [(t["veh_id"], t["num_vehicles"], t["initial_speed"]) for t in gold["initial"]]
