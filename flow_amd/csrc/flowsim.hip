@@ -144,7 +144,7 @@ struct Sim : SimBase {
     std::vector<T> p(size_t(FS_MAX_CTRL_PARAMS) * N), noise(N), delay(N), maxa(N), maxd(N), len(N), stau(N),
         sgap(N), smax(N);
     int flags = 0;
-    bool all_idm = true;
+    bool all_idm = true, idm_set = true;
     for (int i = 0; i < N; ++i) {
       const fs_vehicle_spec& v = veh[i];
       ctrl[i] = v.controller;
@@ -173,8 +173,10 @@ struct Sim : SimBase {
         flags |= fs::FLAG_NEED_SUMO;
       if (v.speed_mode & 6) flags |= fs::FLAG_NEED_SUMO;
       if (v.controller != FS_CTRL_IDM) all_idm = false;
+      if (v.controller != FS_CTRL_IDM && v.controller != FS_CTRL_RL && v.controller != FS_CTRL_SIM) idm_set = false;
     }
     if (all_idm) flags |= fs::FLAG_ALL_IDM;
+    if (idm_set) flags |= fs::FLAG_IDM_SET;
     delta4 = all_idm;
     for (int i = 0; i < N; ++i) delta4 = delta4 && (veh[i].p[4] == 4.0);
     h_len = len;
@@ -511,8 +513,11 @@ struct Sim : SimBase {
     } else if (fast_ok(mask, num_steps))
       hipLaunchKernelGGL((fs::k_steps<T, SEG, 1>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, mask, actions,
                          act_stride, obs, rew, done, obs_every_step);
+    else if ((dv.flags & fs::FLAG_IDM_SET) && !force_generic)
+      hipLaunchKernelGGL((fs::k_steps<T, SEG, 0, 1>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, mask, actions,
+                         act_stride, obs, rew, done, obs_every_step);
     else
-      hipLaunchKernelGGL((fs::k_steps<T, SEG, 0>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, mask, actions,
+      hipLaunchKernelGGL((fs::k_steps<T, SEG, 0, 0>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, mask, actions,
                          act_stride, obs, rew, done, obs_every_step);
     HIP_TRY(hipGetLastError());
     return FS_OK;

@@ -31,6 +31,7 @@ enum : int {
   FLAG_NEED_SUMO = 16,      // some vehicle may be uncommanded or has speed_mode bit 0
   FLAG_HAS_FAILSAFE = 32,
   FLAG_ALL_IDM = 64,        // every slot is an IDM controller (fast path)
+  FLAG_IDM_SET = 128,       // every slot is an IDMController, an RLController or a SimCarFollowingController
 };
 
 template <typename T>
@@ -533,10 +534,39 @@ __device__ __forceinline__ T sumo_idm_speed(T v, T vl, T h, bool has, T dt, cons
   return tmax(T(0), v + acc * dt);
 }
 
+// The closed-network segment table (<= FS_MAX_SEGMENTS rows) lives in three VGPRs, lane q holding row
+// q, loaded once per launch: a lookup inside the step loop is then v_readlane compares plus three
+// ds_bpermute gathers, with no trip to the kernarg segment (a lane-varying index into the by-value
+// DevView arrays compiles to global loads, whose latency one wave per SIMD cannot hide).
+template <typename T>
+struct SegTab { T start, flow_start, flow_slope; };
+
+template <typename T>
+__device__ __forceinline__ SegTab<T> load_segtab(const DevView<T>& s, int lane) {
+  const int q = lane & (FS_MAX_SEGMENTS - 1);
+  SegTab<T> t;
+  t.start = s.seg_start[q];
+  t.flow_start = s.seg_flow_start[q];
+  t.flow_slope = s.seg_flow_slope[q];
+  return t;
+}
+
 // segment of loop coordinate x (the last one whose start is <= x): is it internal, and Flow's table
 // coordinate of x (oracle/refsim.py _segment_lookup)
 template <typename T>
-__device__ __forceinline__ void segment_lookup(const DevView<T>& s, T x, bool& internal, T& flow_x) {
+// MUST be called with all 64 lanes active (ds_bpermute reads 0 from a disabled lane).
+__device__ __forceinline__ void segment_lookup(const DevView<T>& s, const SegTab<T>& tab, T x, bool& internal,
+                                               T& flow_x) {
+  int k = 0;
+  for (int q = 1; q < s.nseg; ++q) k = (x >= read_lane(tab.start, q)) ? q : k;
+  const T st = __shfl(tab.start, k, 64), fs0 = __shfl(tab.flow_start, k, 64), sl = __shfl(tab.flow_slope, k, 64);
+  internal = (s.seg_internal >> k) & 1u;
+  flow_x = fs0 + sl * (x - st);
+}
+
+// the same lookup straight from the by-value tables, for code that runs once per launch or reset
+template <typename T>
+__device__ __forceinline__ void segment_lookup_args(const DevView<T>& s, T x, bool& internal, T& flow_x) {
   int k = 0;
   for (int q = 1; q < s.nseg; ++q) k = (x >= s.seg_start[q]) ? q : k;
   T st = s.seg_start[0], fs0 = s.seg_flow_start[0], sl = s.seg_flow_slope[0];
@@ -555,7 +585,8 @@ __device__ __forceinline__ void segment_lookup(const DevView<T>& s, T x, bool& i
 // (envs/base.py:599-615): shared by the single-lane and the multi-lane step kernels.
 // Returns the commanded acceleration; `commanded` = false means "no command this step" (S5).
 // ---------------------------------------------------------------------------
-template <typename T>
+// CSET = 1: the host guarantees every slot is IDM / RL / Sim (FLAG_IDM_SET), so the controller switch collapses.
+template <typename T, int CSET = 0>
 __device__ __forceinline__ T control_accel_on(const DevView<T>& s, const Slot<T>& sl, int flags, T v, T vl, T h, bool has,
                                               T vf, T hf, T mean_v, bool on_edge, bool have_rl, T a_rl, bool live,
                                               int rr, int ii, uint32_t nctr, T& cst, bool& commanded) {
@@ -571,7 +602,8 @@ __device__ __forceinline__ T control_accel_on(const DevView<T>& s, const Slot<T>
     }
   } else if (ct != FS_CTRL_SIM) {
     T a;
-    switch (ct) {
+    if (CSET == 1) a = ctrl_idm(v, vl, h, has, sl.p);
+    else switch (ct) {
       case FS_CTRL_PISATURATION: {
         const size_t slot = size_t(rr) * s.n_pis + (sl.pis_index < 0 ? 0 : sl.pis_index);
         a = ctrl_pisaturation(v, vl, h, s.dt, sl.max_accel, s.pis_hist + slot * s.pis_H, s.pis_n + slot, s.pis_H,
@@ -589,7 +621,7 @@ __device__ __forceinline__ T control_accel_on(const DevView<T>& s, const Slot<T>
       default: a = ctrl_follower_stopper(v, vl, h, has, s.dt, mean_v); break;
     }
     commanded = on_edge;
-    if (ct == FS_CTRL_LAC && commanded && live) cst = a;
+    if (CSET == 0 && ct == FS_CTRL_LAC && commanded && live) cst = a;
     if (flags & FLAG_HAS_NOISE) {                // base_controller.py:109-110
       if (sl.noise > T(0)) a = a + sl.noise * gauss<T>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(ii), nctr);
     }
@@ -602,25 +634,25 @@ __device__ __forceinline__ T control_accel_on(const DevView<T>& s, const Slot<T>
   return acc;
 }
 
-// closed loops: "on an edge" (base_controller.py:98-99) from the loop coordinate
-template <typename T>
-__device__ __forceinline__ T control_accel(const DevView<T>& s, const Slot<T>& sl, int flags, T v, T vl, T h, bool has,
-                                           T vf, T hf, T mean_v, T x, T quarter, T qj, bool have_rl, T a_rl, bool live,
-                                           int rr, int ii, uint32_t nctr, T& cst, bool& commanded) {
+// closed loops: "on an edge" (base_controller.py:98-99) from the loop coordinate; `internal` / `flow_x` are the
+// segment lookup of x, made by every lane before the lane-divergent controller code
+template <typename T, int CSET = 0>
+__device__ __forceinline__ T control_accel(const DevView<T>& s, const SegTab<T>& tab, const Slot<T>& sl, int flags, T v,
+                                           T vl, T h, bool has, T vf, T hf, T mean_v, T x, T quarter, T qj, bool have_rl,
+                                           T a_rl, bool live, int rr, int ii, uint32_t nctr, T& cst, bool& commanded,
+                                           T& flow_x) {
   bool on_edge = true;
-  if (s.junction_mode && sl.ctrl != FS_CTRL_RL && sl.ctrl != FS_CTRL_SIM) {
-    if (s.nseg > 0) {
-      bool internal;
-      T fx;
-      segment_lookup(s, x, internal, fx);
-      on_edge = !internal;
-    } else {
-      T u = x - tfloor(x / qj) * qj;
-      on_edge = !(u >= quarter);
-    }
+  flow_x = x;
+  if (s.nseg > 0) {
+    bool internal;
+    segment_lookup(s, tab, x, internal, flow_x);
+    if (s.junction_mode && sl.ctrl != FS_CTRL_RL && sl.ctrl != FS_CTRL_SIM) on_edge = !internal;
+  } else if (s.junction_mode && sl.ctrl != FS_CTRL_RL && sl.ctrl != FS_CTRL_SIM) {
+    T u = x - tfloor(x / qj) * qj;
+    on_edge = !(u >= quarter);
   }
-  return control_accel_on(s, sl, flags, v, vl, h, has, vf, hf, mean_v, on_edge, have_rl, a_rl, live, rr, ii, nctr, cst,
-                          commanded);
+  return control_accel_on<T, CSET>(s, sl, flags, v, vl, h, has, vf, hf, mean_v, on_edge, have_rl, a_rl, live, rr, ii,
+                                   nctr, cst, commanded);
 }
 
 // ---------------------------------------------------------------------------
@@ -631,7 +663,9 @@ __device__ __forceinline__ T control_accel(const DevView<T>& s, const Slot<T>& s
 // mode, sims_per_step 1, AccelEnv head with the desired_velocity reward, no reset mask,
 // no aux tracking.  It executes exactly the arithmetic of the generic path (same helper
 // functions, same order), with everything it cannot need compiled out.
-template <typename T, int SEG, int FAST>
+// CSET = 1 (generic path only) compiles the controller switch down to IDM / RL / Sim slots, the common
+// "IDM humans + RL vehicles" population of the reference's experiments: every other feature stays.
+template <typename T, int SEG, int FAST, int CSET = 0>
 __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const uint8_t* __restrict__ mask,
                                               const float* __restrict__ actions, size_t act_stride,
                                               float* __restrict__ obs, float* __restrict__ rew,
@@ -650,7 +684,7 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
   const bool wrap_lead = (i + 1 >= N);            // slot N-1 (and the idle lanes): leader is slot 0
   const bool wrap_foll = (i == 0);
   const bool has = N > 1;
-  const int flags = s.flags;
+  const int flags = CSET == 1 ? (s.flags & ~(FLAG_NEED_FOLLOWER | FLAG_NEED_MEAN | FLAG_HAS_LAC)) : s.flags;
 
   // per-lane slot parameters (registers for the whole launch)
   Slot<T> sl;
@@ -670,6 +704,7 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
   sl.sumo_min_gap = s.sumo_min_gap[ii];
   sl.sumo_max_speed = s.sumo_max_speed[ii];
   const T len_lead = lead_read<SEG>(sl.length, seg, wrap_lead);
+  const SegTab<T> segtab = (!FAST && s.nseg > 0) ? load_segtab(s, lane) : SegTab<T>{T(0), T(0), T(0)};
 
   // per-replica scalars
   const T base_len = s.ring_len[rr];
@@ -766,16 +801,10 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
           const int col = order_rank(true);
           if (have_rl) a_rl = T(act[col]);
         }
-        acc = control_accel(s, sl, flags, v, vl, h, has, vf, hf, mean_v, x, quarter, qj, have_rl, a_rl,
-                            live && i < N, rr, ii, nctr, cst, commanded);
-        if (sorted && live) {                            // accel.py:150-169 additional_command: position before the move
-          T xa = x;
-          if (s.nseg > 0) {
-            bool internal;
-            segment_lookup(s, x, internal, xa);
-          }
-          xs = xa;
-        }
+        T xa;
+        acc = control_accel<T, CSET>(s, segtab, sl, flags, v, vl, h, has, vf, hf, mean_v, x, quarter, qj, have_rl,
+                                     a_rl, live && i < N, rr, ii, nctr, cst, commanded, xa);
+        if (sorted && live) xs = xa;                     // accel.py:150-169 additional_command: position before the move
       }
       // ---- apply_acceleration + SUMO integration (S4-S9) ------------------
       T next_vel = tmax(v + acc * dt, T(0));          // vehicle/traci.py:962
@@ -832,6 +861,11 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
     const bool emit = obs_every_step || (step == num_steps - 1);
     if (emit) {
       const int oi = FAST ? ii : (sorted ? order_rank(false) : perm_i);
+      T xo = x;
+      if (!FAST && s.nseg > 0 && env != FS_ENV_WAVE_ATTENUATION_PO) {   // every lane looks up, then `valid` ones store
+        bool internal;
+        segment_lookup(s, segtab, x, internal, xo);
+      }
       if (env == FS_ENV_WAVE_ATTENUATION_PO) {
         // wave_attenuation.py:248-269; written by the RL vehicle's lane
         if (valid && sl.ctrl == FS_CTRL_RL && sl.rl_index == 0) {
@@ -840,11 +874,6 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
           orow[2] = float(d / s.po_max_length);
         }
       } else if (valid) {
-        T xo = x;
-        if (!FAST && s.nseg > 0) {
-          bool internal;
-          segment_lookup(s, x, internal, xo);
-        }
         orow[oi] = float(v / s.max_speed);               // accel.py:118-119
         orow[N + oi] = float(xo / L);                    // accel.py:120-121
       }
@@ -889,6 +918,11 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
 
   if (num_steps == 0) {   // observation of the current state only (Env.reset, envs/base.py:544-551)
     const int oi = FAST ? ii : (sorted ? order_rank(false) : perm_i);
+    T xo = x;
+    if (!FAST && s.nseg > 0) {
+      bool internal;
+      segment_lookup(s, segtab, x, internal, xo);
+    }
     if (env == FS_ENV_WAVE_ATTENUATION_PO) {
       if (valid && sl.ctrl == FS_CTRL_RL && sl.rl_index == 0) {
         orow[0] = float(v / T(15));
@@ -896,11 +930,6 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
         orow[2] = float(d / s.po_max_length);
       }
     } else if (valid) {
-      T xo = x;
-      if (!FAST && s.nseg > 0) {
-        bool internal;
-        segment_lookup(s, x, internal, xo);
-      }
       orow[oi] = float(v / s.max_speed);
       orow[N + oi] = float(xo / L);
     }
@@ -1167,6 +1196,7 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
   sl.sumo_tau = s.sumo_tau[ii];
   sl.sumo_min_gap = s.sumo_min_gap[ii];
   sl.sumo_max_speed = s.sumo_max_speed[ii];
+  const SegTab<T> segtab = s.nseg > 0 ? load_segtab(s, threadIdx.x) : SegTab<T>{T(0), T(0), T(0)};
 
   const T base_len = s.ring_len[rr];
   const T L = base_len + T(4) * s.jlen;
@@ -1244,8 +1274,9 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
       const int acol = (sl.rl_index < 0 ? 0 : sl.rl_index) * (lc_env ? 2 : 1);
       T a_rl = have_rl ? T(act[acol]) : T(0);
       bool commanded = false;
-      T acc = control_accel(s, sl, flags, v, vl, h, has, vf, hf, mean_v, x, quarter, qj, have_rl, a_rl,
-                            live && i < N, rr, ii, nctr, cst, commanded);
+      T xa_unused;
+      T acc = control_accel(s, segtab, sl, flags, v, vl, h, has, vf, hf, mean_v, x, quarter, qj, have_rl, a_rl,
+                            live && i < N, rr, ii, nctr, cst, commanded, xa_unused);
       // ---- RL lane-change command (ML3) -----------------------------------
       int new_ln = ln;
       if (lc_env && have_rl) {
@@ -1419,7 +1450,7 @@ __global__ void k_reset(DevView<T> s, const uint8_t* __restrict__ mask) {
       T xa = s.init_pos[e];
       if (s.nseg > 0) {
         bool internal;
-        segment_lookup(s, s.init_pos[e], internal, xa);
+        segment_lookup_args(s, s.init_pos[e], internal, xa);
       }
       s.sort_key[e] = xa;
     }
