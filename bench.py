@@ -216,7 +216,7 @@ def c5_leg(device, R=1024, env_steps=600):
     return res
 
 
-def c4_leg(device, R=128, env_steps=1000):
+def c4_leg(device, R=128, env_steps=1000, slots=256):
     """BASELINE configs[3] (informational, not the headline): BottleneckNetwork scaling 1 (4 -> 2 -> 1 lanes at two
     zipper junctions), inflow 2300 veh/h (10 % RL) with random entry lanes, all vehicles on the SUMO car-following
     model, BottleneckDesiredVelocityEnv head (141 observations, 20 actions), sim_step 0.5, warm-up 40 + horizon 1000
@@ -246,7 +246,8 @@ def c4_leg(device, R=128, env_steps=1000):
     inflow.add(veh_type="human", edge="1", vehs_per_hour=2300 * 0.9, depart_lane="random", depart_speed=10)
     inflow.add(veh_type="followerstopper", edge="1", vehs_per_hour=2300 * 0.1, depart_lane="random", depart_speed=10)
     fp = dict(exp_tag="DesiredVelocity", env_name=BottleneckDesiredVelocityEnv, network=BottleneckNetwork,
-              simulator="traci", sim=SumoParams(sim_step=0.5, render=False, restart_instance=True, seed=5),
+              simulator="traci", sim=SumoParams(sim_step=0.5, render=False, restart_instance=True, seed=5,
+                                                max_vehicles=slots),
               env=EnvParams(warmup_steps=40, sims_per_step=1, horizon=1000, additional_params=add),
               net=NetParams(inflows=inflow, additional_params={"scaling": 1, "speed_limit": 23}), veh=veh,
               initial=InitialConfig(spacing="uniform", min_gap=5, lanes_distribution=float("inf"),
@@ -273,9 +274,12 @@ def c4_leg(device, R=128, env_steps=1000):
            "departed_mean": float(cnt[:, 6].mean()), "arrived_mean": float(cnt[:, 5].mean()),
            "dropped_at_insertion_mean": float(cnt[:, 7].mean()),
            "outflow_veh_per_hour_mean": float(out[1][-200:].mean().item() * 2000.0),
-           "workload": "C4: BottleneckNetwork 4->2->1 lanes, inflow 2300 veh/h (10 % RL, random lanes), 64 slots, "
+           "slots": slots,
+           "workload": "C4: BottleneckNetwork 4->2->1 lanes, inflow 2300 veh/h (10 %% RL, random lanes), %d slots, "
                        "BottleneckDesiredVelocityEnv head (141 obs / 20 actions), sim_step 0.5, one 1000-step episode "
-                       "after 40 warm-up steps, random actions; k_steps_open<.,64,4>"}
+                       "after 40 warm-up steps, random actions; %s" %
+                       (slots, "k_steps_wide<., %d> (one workgroup per replica)" % ((slots + 63) // 64 if slots > 128 else 2)
+                        if slots > 64 else "k_steps_open<.,64,4>")}
     vec.close()
     return res
 

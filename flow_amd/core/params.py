@@ -171,7 +171,7 @@ class SumoParams(SimParams):
                     netconvert value in the reference's fixture)
     crossing_time_gap  right-of-way model of the figure-eight crossing / the merge junction:
                     None -> 3.0 s on a figure eight, 1.0 s on a merge
-    max_vehicles    open networks: vehicle slots per replica (<= 64), shared out over the vehicle types
+    max_vehicles    open networks: vehicle slots per replica (<= 64; <= 256 on BottleneckNetwork), shared out over the vehicle types
     slot_capacity   open networks: {vehicle type: slots}, overrides the default share-out
     merge_right_of_way  open networks: False switches the junction priority model off
     zipper_distance lane-drop networks: distance before a zipper junction from which a vehicle follows the nearest

@@ -20,6 +20,7 @@
 #include "flowsim.h"
 #include "flowsim_kernels.h"
 #include "flowsim_open.h"
+#include "flowsim_wide.h"
 
 namespace {
 
@@ -475,6 +476,16 @@ struct Sim : SimBase {
            dv.nseg == 0 && !dv.junction_on && !dv.sort_vehicles && dv.obs_perm == nullptr;
   }
 
+  // more than 64 slots per replica (lane-drop network): one workgroup of W waves per replica
+  template <int W>
+  int launch_wide(int num_steps, const uint8_t* mask, const float* actions, size_t act_stride, float* obs,
+                  float* rew, uint8_t* done, int obs_every_step) {
+    hipLaunchKernelGGL((fs::k_steps_wide<T, W>), dim3(dv.R), dim3(64 * W), 0, stream, dv, ov, num_steps, mask,
+                       actions, act_stride, obs, rew, done, obs_every_step, after_reset);
+    HIP_TRY(hipGetLastError());
+    return FS_OK;
+  }
+
   template <int SEG>
   int launch_seg(int num_steps, const uint8_t* mask, const float* actions, size_t act_stride, float* obs,
                  float* rew, uint8_t* done, int obs_every_step) {
@@ -529,6 +540,8 @@ struct Sim : SimBase {
       case 8: return launch_seg<8>(num_steps, mask, actions, act_stride, obs, rew, done, obs_every_step);
       case 16: return launch_seg<16>(num_steps, mask, actions, act_stride, obs, rew, done, obs_every_step);
       case 32: return launch_seg<32>(num_steps, mask, actions, act_stride, obs, rew, done, obs_every_step);
+      case 128: return launch_wide<2>(num_steps, mask, actions, act_stride, obs, rew, done, obs_every_step);
+      case 256: return launch_wide<4>(num_steps, mask, actions, act_stride, obs, rew, done, obs_every_step);
       default: return launch_seg<64>(num_steps, mask, actions, act_stride, obs, rew, done, obs_every_step);
     }
   }
@@ -808,8 +821,10 @@ int validate(const fs_config* c) {
     }
   }
   if (c->num_vehicles < 1) return fail(FS_ERR_INVALID, "fs_create: num_vehicles < 1");
-  if (c->num_vehicles > 64)
-    return fail(FS_ERR_UNSUPPORTED, "fs_create: more than 64 vehicles per replica is not built yet");
+  if (c->num_vehicles > 64 && c->network != FS_NET_BOTTLENECK)
+    return fail(FS_ERR_UNSUPPORTED, "fs_create: more than 64 vehicles per replica is built for FS_NET_BOTTLENECK only");
+  if (c->num_vehicles > FS_MAX_SLOTS_WIDE)
+    return fail(FS_ERR_UNSUPPORTED, "fs_create: more than 256 vehicle slots per replica is not built");
   if (c->num_rl < 0 || (c->num_rl > c->num_vehicles && c->env != FS_ENV_BOTTLENECK_DV))
     return fail(FS_ERR_INVALID, "fs_create: bad num_rl");
   if (c->sims_per_step < 1) return fail(FS_ERR_INVALID, "fs_create: sims_per_step < 1");
@@ -896,7 +911,7 @@ int create_typed(const fs_config* cfg, fs_handle* out) {
   if (s->obs_dim < 1) s->obs_dim = 1;      // an env without RL places still gets a (dummy) buffer
   s->act_dim = cfg->num_rl * (cfg->env == FS_ENV_LANE_CHANGE_ACCEL ? 2 : 1);
   int seg = 8;
-  while (seg < cfg->num_vehicles) seg <<= 1;
+  while (seg < cfg->num_vehicles) seg <<= 1;       // 128 / 256: one workgroup of 2 / 4 waves per replica (k_steps_wide)
   s->seg = seg;
   hipError_t e = hipSetDevice(cfg->device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking);

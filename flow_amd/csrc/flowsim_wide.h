@@ -1,0 +1,692 @@
+// flowsim_wide.h -- the open-network step kernel for replicas with MORE THAN 64 vehicle slots (lane-drop
+// BottleneckNetwork: at C4's demand the queue upstream of the drops holds ~200 vehicles).
+//
+// Same rules, in the same order of floating-point operations, as k_steps_open<T, 64, 4> (flowsim_open.h; rule
+// numbers = oracle/opennet.py).  What changes is the mapping: one replica = one WORKGROUP of W waves, thread t
+// holds slot t in registers, and everything the 64-slot kernel did through the wave (ballots, ds_bpermute,
+// DPP reductions) goes through LDS instead:
+//   * per-slot values other threads gather (x, v, length, route, leader, headway, seq) are mirrored in LDS arrays;
+//   * a mask over slots / ranks is W 64-bit words, one ballot per wave, published to LDS and read back by everyone;
+//   * a reduction is one per-wave partial (DPP / ballot inside the wave) + a combine over the W partials, in the
+//     order of the xor-butterfly's next levels ((w0 + w1) + (w2 + w3)) so that oracle/rewards.py tree_sum holds.
+// A value is published before a __syncthreads() and consumed after it; scratch words alternate between two
+// buffers so that a fast wave's next publication never lands on words a slow wave is still reading.  Control flow
+// around every barrier is block-uniform: a block holds ONE replica, so `live`, `due`, `crashed` are uniform.
+#pragma once
+
+namespace fs {
+
+template <typename T, int W>
+struct WideLds {
+  static constexpr int NS = 64 * W;
+  T x[NS];                      // position of the vehicle in slot j; BIGV when the slot is free
+  T v[NS];
+  T h[NS];                      // headway of the last neighbour update
+  T len[NS];                    // launch constant
+  int route[NS];
+  int lead[NS];
+  int seq[NS];
+  int sorted_slot[NS];          // [rank] -> slot
+  int skey[NS];                 // [rank] -> path | joins << 8, 0xffff for a free slot
+  unsigned long long rmask[6][W];        // masks over RANKS: path 0..3, passed the first / the second join
+  unsigned long long words[2][2][W];
+  T red_t[2][4][W];
+  int red_i[2][4][W];
+  unsigned long long cell[2][64][W];     // observation cells: [human | rl][cell][wave] = members in that wave
+  // launch constants (flowsim_open.h keeps them in lane-indexed VGPRs and reads them with v_readlane; here they
+  // are read from LDS with a uniform address, which holds under any EXEC mask and costs no registers)
+  T tab[TAB_ROWS][64];
+  T ctab[6][64];
+  double ftd[3][FS_MAX_INFLOWS];
+  int fti[3][FS_MAX_INFLOWS];
+  int ctab_i[2][64];
+  int emitted[FS_MAX_INFLOWS];           // vehicles emitted so far by inflow f
+  int hist[20];                          // arrivals of sub-step % 20
+};
+
+// (internal?, Flow table coordinate) of coordinate x on the single route of the lane-drop network (O5)
+template <typename T, int W>
+__device__ __forceinline__ void route_lookup_lds(const OpenView<T>& o, const WideLds<T, W>& L, T x, bool& internal,
+                                                 T& flow_x) {
+  int k = 0;
+  T st = L.tab[TAB_SEG_START][0], fs0 = L.tab[TAB_SEG_FLOW][0], sl = L.tab[TAB_SEG_SLOPE][0];
+  for (int q = 1; q < o.nseg[0]; ++q) {
+    const T sq = L.tab[TAB_SEG_START][q];
+    const bool hit = x >= sq;
+    k = hit ? q : k;
+    st = hit ? sq : st;
+    fs0 = hit ? L.tab[TAB_SEG_FLOW][q] : fs0;
+    sl = hit ? L.tab[TAB_SEG_SLOPE][q] : sl;
+  }
+  internal = (o.seg_internal[0] >> k) & 1u;
+  flow_x = fs0 + sl * (x - st);
+}
+
+__device__ __forceinline__ int first_bit(unsigned long long m) { return __ffsll((long long)m) - 1; }
+__device__ __forceinline__ int last_bit(unsigned long long m) { return 63 - __clzll((long long)m); }
+
+template <typename T, int W>
+__global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T> o, int num_steps,
+                                                       const uint8_t* __restrict__ mask,
+                                                       const float* __restrict__ actions, size_t act_stride,
+                                                       float* __restrict__ obs, float* __restrict__ rew,
+                                                       uint8_t* __restrict__ done, int obs_every_step,
+                                                       int after_reset) {
+  constexpr int P = 4;
+  constexpr int NS = 64 * W;
+  using ull = unsigned long long;
+  __shared__ WideLds<T, W> L;
+  const T BIGV = T(3.0e38);
+  const int tid = threadIdx.x;
+  const int w = tid >> 6;                 // wave of the block
+  const int l = tid & 63;                 // lane of the wave
+  const int rr = blockIdx.x;              // one replica per block
+  const int N = s.N;
+  const bool slot_ok = tid < N;
+  const int ii = slot_ok ? tid : N - 1;
+  const size_t idx = size_t(rr) * N + ii;
+  const int flags = s.flags;
+  const int env = s.env;
+  const bool dv_env = env == FS_ENV_BOTTLENECK_DV;
+  const bool track_foll = o.track_followers != 0;
+
+  Slot<T> sl;
+  sl.ctrl = s.ctrl[ii];
+  sl.failsafe = s.failsafe[ii];
+  sl.speed_mode = s.speed_mode[ii];
+  sl.rl_index = s.rl_index[ii];
+  sl.pis_index = -1;
+#pragma unroll
+  for (int k = 0; k < FS_MAX_CTRL_PARAMS; ++k) sl.p[k] = s.p[k * N + ii];
+  sl.noise = s.noise[ii];
+  sl.delay = s.delay[ii];
+  sl.max_accel = s.max_accel[ii];
+  sl.max_decel = s.max_decel[ii];
+  sl.length = s.length[ii];
+  sl.sumo_tau = s.sumo_tau[ii];
+  sl.sumo_min_gap = s.sumo_min_gap[ii];
+  sl.sumo_max_speed = s.sumo_max_speed[ii];
+  const int my_type = o.slot_type[ii];
+  const bool is_rl = sl.ctrl == FS_CTRL_RL;
+  if (tid < 64) {
+#pragma unroll
+    for (int row = 0; row < TAB_ROWS; ++row) L.tab[row][tid] = o.lane_tab[row * 64 + tid];
+    if (dv_env) {
+#pragma unroll
+      for (int row = 0; row < 6; ++row) L.ctab[row][tid] = o.cell_tab[row * 64 + tid];
+      L.ctab_i[0][tid] = o.cell_tab_i[tid];
+      L.ctab_i[1][tid] = o.cell_tab_i[64 + tid];
+    }
+    if (tid < FS_MAX_INFLOWS) {
+#pragma unroll
+      for (int row = 0; row < 3; ++row) {
+        L.ftd[row][tid] = o.flow_tab_d[row * 64 + tid];
+        L.fti[row][tid] = o.flow_tab_i[row * 64 + tid];
+      }
+      L.emitted[tid] = o.emitted[size_t(rr) * FS_MAX_INFLOWS + tid];
+    }
+    if (tid < 20) L.hist[tid] = o.arr_hist[size_t(rr) * 20 + tid];
+  }
+
+  const bool live_replica = mask == nullptr || mask[rr] != 0;
+  int tcount = s.time[rr];
+  uint32_t nctr = s.noise_ctr[rr];
+  int32_t* cnt = o.counters + size_t(rr) * 8;
+  int sim_steps = cnt[CNT_SIM_STEPS], seq_ctr = cnt[CNT_SEQ];
+  const int ctl_ctr = cnt[CNT_CTL];
+  int n_arr = cnt[CNT_ARRIVED], n_dep = cnt[CNT_DEPARTED], tot_arr = cnt[CNT_TOTAL_ARRIVED],
+      tot_dep = cnt[CNT_TOTAL_DEPARTED], tot_drop = cnt[CNT_TOTAL_DROPPED];
+
+  T x = s.pos[idx];
+  T v = s.vel[idx];
+  int route = slot_ok ? s.lane[idx] : -1;
+  int seq = o.seq[idx];
+  int origin = o.origin[idx];
+  int foll = o.foll[idx];
+  T foll_h = o.foll_h[idx];
+  int arrived_rl = o.arrived_rl[idx];
+  T prev_v = s.prev_vel[idx], last_acc = s.accel[idx];
+  T cst = s.ctrl_state[idx];
+  T vmax = o.vmax[idx];
+  const bool lc_on = o.lc_enabled != 0;
+  const bool my_lc_auto = lc_on && (o.lc_auto[ii] != 0);
+  int last_lc = lc_on ? s.last_lc[idx] : 0;
+  int lc_want = -1;
+  T lc_gain = T(0);
+  bool just_arrived = false;
+  auto shift_of = [&](T xx) -> int { return (xx >= o.m1 ? 1 : 0) + (xx >= o.m2 ? 1 : 0); };
+
+  const T dt = s.dt;
+  const int obs_dim = o.obs_dim;
+  const size_t step_rows = obs_every_step ? size_t(s.R) : 0;
+  float* orow = obs + size_t(rr) * obs_dim;
+  float* rrow = rew + rr;
+  uint8_t* drow = done + rr;
+
+  L.len[tid] = sl.length;
+  int phase = 0;                           // scratch buffer of the next publication (block-uniform)
+
+  // ---- M5 + O1: neighbours through the ORDER of the vehicles (see k_steps_open) ----------------------------
+  int lead = -1;
+  T vl = T(-1001), h = T(1000);
+  bool has = false, lead_same_lane = false;
+  // `crash_out`: does any vehicle of the replica sit closer than crash_gap behind its leader on its own lane
+  auto neighbours = [&](bool live, bool follow, bool& crash_out) {
+    const bool alive = route >= 0;
+    const T xr = alive ? x : BIGV;
+    L.x[tid] = xr;
+    L.v[tid] = v;
+    L.route[tid] = route;
+    __syncthreads();
+    // rank: x ascending, equal x: higher slot first; free slots after the vehicles (any fixed order)
+    int rank = 0;
+#pragma unroll 8
+    for (int j = 0; j < NS; ++j) {
+      const T xj = L.x[j];
+      rank += ((xj < xr) || (xj == xr && j > tid)) ? 1 : 0;
+    }
+    L.sorted_slot[rank] = tid;
+    const int my_key = alive ? (route | (shift_of(x) << 8)) : 0xffff;
+    L.skey[rank] = my_key;
+    __syncthreads();
+    const int skey = L.skey[tid];          // the key of the vehicle whose rank is my thread index
+    const bool s_alive = skey != 0xffff;
+    {
+      ull bw[P + 2];
+#pragma unroll
+      for (int q = 0; q < P; ++q) bw[q] = __ballot(s_alive && (skey & 0xff) == q);
+      bw[P] = __ballot(s_alive && (skey >> 8) >= 1);
+      bw[P + 1] = __ballot(s_alive && (skey >> 8) >= 2);
+      if (l == 0) {
+#pragma unroll
+        for (int q = 0; q < P + 2; ++q) L.rmask[q][w] = bw[q];
+      }
+    }
+    __syncthreads();
+    // the masks stay in LDS (written again two barriers into the next call) and are fetched word by word
+    auto Bw = [&](int q, int ww) -> ull { return L.rmask[q][ww]; };
+    auto ALLw = [&](int ww) -> ull { return L.rmask[0][ww] | L.rmask[1][ww] | L.rmask[2][ww] | L.rmask[3][ww]; };
+    auto pathw = [&](int p, int ww) -> ull { return L.rmask[p & 3][ww]; };                  // lanes of path p
+    auto pairw = [&](int p, int ww) -> ull { return L.rmask[p & 2][ww] | L.rmask[(p & 2) | 1][ww]; };
+    // vehicles on "my lane" of those ahead, word ww: see k_steps_open (M5 / M8)
+    auto cand_w = [&](int p, int la_, int ww) -> ull {
+      const ull R1 = L.rmask[P][ww], R2 = L.rmask[P + 1][ww], ALL = ALLw(ww);
+      const ull pr = pairw(p, ww);
+      const ull c0 = la_ == 0 ? pathw(p, ww) : (la_ == 1 ? pr : ALL);
+      const ull c1 = la_ <= 1 ? pr : ALL;
+      return (~R1 & c0) | (R1 & ~R2 & c1) | (R2 & ALL);
+    };
+    const int rw = rank >> 6, rb = rank & 63;
+    auto above_w = [&](int ww) -> ull { return ww < rw ? 0ull : (ww > rw ? ~0ull : (rb == 63 ? 0ull : (~0ull << (rb + 1)))); };
+    auto below_w = [&](int ww) -> ull { return ww < rw ? ~0ull : (ww > rw ? 0ull : ((1ull << rb) - 1ull)); };
+    const int la = shift_of(x + o.zip_d);
+    const int my_path = route < 0 ? 0 : route;
+    int lead_pos = -1;
+#pragma unroll
+    for (int ww = 0; ww < W; ++ww) {
+      const ull m = alive ? (cand_w(my_path, la, ww) & above_w(ww)) : 0ull;
+      if (lead_pos < 0 && m != 0ull) lead_pos = ww * 64 + first_bit(m);
+    }
+    has = lead_pos >= 0;
+    const int lslot = L.sorted_slot[has ? lead_pos : 0];
+    lead = has ? lslot : -1;
+    const int lsrc = has ? lslot : ii;
+    const T x_l = L.x[lsrc];
+    const T v_l = L.v[lsrc];
+    const T len_lead = L.len[lsrc];
+    vl = has ? v_l : T(-1001);
+    h = has ? (x_l - x) - len_lead : T(1000);
+    {
+      const int p_l = L.route[lsrc];
+      const int sh_l = shift_of(x_l);
+      lead_same_lane = has && ((route >> sh_l) == (p_l >> sh_l));
+    }
+    if (lc_on) {
+      // ---- M11: which adjacent lane (if any) this vehicle would like to continue on after the next move ----------
+      bool internal;
+      T fx;
+      route_lookup_lds<T, W>(o, L, x, internal, fx);
+      const int g = shift_of(x);
+      const int lane = my_path >> g, n_lanes = P >> g;
+      const bool ok0 = alive && my_lc_auto && !internal && g < 2 && la == g && n_lanes > 1 &&
+                       (tcount - last_lc >= o.lc_cooldown);
+      const T two_sqrt = T(2) * tsqrt(sl.max_accel * sl.max_decel);
+      T best_gain = -BIGV;
+      int best_path = -1;
+#pragma unroll
+      for (int dl = -1; dl <= 1; dl += 2) {               // right first, so that left wins a tie
+        const int tl = lane + dl;
+        const bool valid_t = ok0 && tl >= 0 && tl < n_lanes;
+        const int p2 = valid_t ? (tl << g) : 0;
+        int lpos = -1, fpos = -1;
+#pragma unroll
+        for (int ww = 0; ww < W; ++ww) {
+          const ull ml = valid_t ? (cand_w(p2, la, ww) & above_w(ww)) : 0ull;
+          const ull feed = g == 0 ? pathw(p2, ww) : pairw(p2, ww);   // the lanes that feed the target lane at my position
+          const ull mf = valid_t ? (feed & below_w(ww)) : 0ull;
+          if (lpos < 0 && ml != 0ull) lpos = ww * 64 + first_bit(ml);
+          if (mf != 0ull) fpos = ww * 64 + last_bit(mf);  // words ascend: the last hit is the highest rank
+        }
+        const bool has_l = lpos >= 0, has_f = fpos >= 0;
+        const int ls = L.sorted_slot[has_l ? lpos : 0], fs_ = L.sorted_slot[has_f ? fpos : 0];
+        const T xl2 = L.x[ls], vl2 = L.v[ls], ll2 = L.len[ls];
+        const T xf2 = L.x[fs_], vf2 = L.v[fs_];
+        const T gap_l = has_l ? (xl2 - x) - ll2 : T(1000.0);
+        const T gap_f = has_f ? (x - xf2) - sl.length : T(1000.0);
+        const T v_l2 = has_l ? vl2 : T(0), v_f = has_f ? vf2 : T(0);
+        const T need_l = sl.sumo_min_gap + tmax(T(0), v * sl.sumo_tau + v * (v - v_l2) / two_sqrt);
+        const T need_f = sl.sumo_min_gap + tmax(T(0), v_f * sl.sumo_tau + v_f * (v_f - v) / two_sqrt);
+        const bool safe = (!has_l || gap_l >= need_l) && (!has_f || gap_f >= need_f);
+        const T gain = gap_l - h;
+        const bool take = valid_t && safe && (gain >= o.lc_min_gain) && (gain >= best_gain);
+        best_gain = take ? gain : best_gain;
+        best_path = take ? p2 : best_path;
+      }
+      lc_want = best_path;
+      lc_gain = best_path >= 0 ? best_gain : T(0);
+    }
+    // publish what the follower rule and the crash check read of OTHER slots
+    L.lead[tid] = lead;
+    L.h[tid] = h;
+    L.seq[tid] = seq;
+    const int b1 = phase & 1;
+    phase += 1;
+    {
+      const ull cw = __ballot(alive && has && lead_same_lane && (h < s.crash_gap));
+      if (l == 0) L.words[b1][0][w] = cw;
+    }
+    __syncthreads();
+    ull call = 0ull;
+#pragma unroll
+    for (int ww = 0; ww < W; ++ww) call |= L.words[b1][0][ww];
+    crash_out = call != 0ull;
+    if (!follow) return;
+    // ---- O1: the sticky follower entry of THIS vehicle (vehicle/traci.py:232-250) ----------------------
+    const bool no_lead = alive && !has;
+    const T start_h = no_lead ? T(1000) : foll_h;
+    const int start_f = no_lead ? -1 : foll;
+    T bestf = BIGV;
+    int bseq = 0x7fffffff, bj = -1;
+#pragma unroll
+    for (int r = 0; r < P; ++r) {
+      int q = -1;
+#pragma unroll
+      for (int ww = 0; ww < W; ++ww) {
+        const ull mb = Bw(r, ww) & below_w(ww);
+        if (mb != 0ull) q = ww * 64 + last_bit(mb);
+      }
+      const bool has_c = alive && q >= 0;
+      const int cslot = L.sorted_slot[has_c ? q : 0];
+      const int c_lead = L.lead[cslot];
+      const T c_h = L.h[cslot];
+      const int c_seq = L.seq[cslot];
+      const bool elig = has_c && (c_lead == ii) && (has || c_seq > seq);
+      if (elig && (c_h < bestf || (c_h == bestf && c_seq < bseq))) { bestf = c_h; bseq = c_seq; bj = cslot; }
+    }
+    const bool better = (bestf < start_h) && (bestf < BIGV);
+    if (alive && live) {
+      foll = better ? bj : start_f;
+      foll_h = better ? bestf : start_h;
+    }
+  };
+  // get_outflow_rate over the last `window` sub-steps (vehicle/traci.py:500-505): inside each wave, on its copy
+  auto outflow = [&](int window) -> T {
+    const int n = tcount < window ? tcount : window;
+    int total_i = 0;
+    for (int q = 0; q < 20; ++q) {
+      const int ago = (((tcount - 1 - q) % 20) + 20) % 20;
+      total_i += (ago < n) ? L.hist[q] : 0;
+    }
+    const T total = T(total_i);                           // small integers: the float sum of k_steps_open is exact
+    const T rate = (T(3600) * total) / (T(n > 0 ? n : 1) * dt);
+    return n > 0 ? rate : T(0);
+  };
+  auto write_obs = [&]() {
+    if (env == FS_ENV_BOTTLENECK) {                      // bottleneck.py:481-483
+      if (tid == 0) orow[0] = 1.0f;
+      return;
+    }
+    // ---- O6 get_state (bottleneck.py:868-924): which observation cell am I in ...
+    const bool alive = route >= 0;
+    bool internal;
+    T fx;
+    route_lookup_lds<T, W>(o, L, x, internal, fx);
+    const int my_lane = (route < 0 ? 0 : route) >> shift_of(x);
+    int ocell = -1;
+    for (int g = 0; g < o.n_obs_groups; ++g) {
+      const T pos = x - L.ctab[CELL_OBS_START][g];
+      const int meta = L.ctab_i[0][g];
+      bool inside = (pos > L.ctab[CELL_OBS_LO][g]) && (pos <= L.ctab[CELL_OBS_HI][g]);
+      if (meta >> 24) inside = inside || (pos == T(0));   // np.searchsorted(..) - 1 == -1: the edge's last segment
+      const int rel = my_lane - ((meta >> 16) & 0xff);
+      if (alive && !internal && inside && rel >= 0 && rel < ((meta >> 8) & 0xff) && ocell < 0)
+        ocell = (meta & 0xff) + rel;
+    }
+    // ... then thread c collects cell c: who is in it (one ballot per wave, cell and class), their speeds in slot order
+    const int C = o.n_obs_cells;
+    __syncthreads();
+    for (int c = 0; c < C; ++c) {
+      const ull bh = __ballot(ocell == c && !is_rl);
+      const ull br = __ballot(ocell == c && is_rl);
+      L.cell[0][c][w] = bh;
+      L.cell[1][c][w] = br;
+    }
+    __syncthreads();
+    if (tid < C) {
+      int cnt_h = 0, cnt_r = 0;
+      T sp_h = T(0), sp_r = T(0);
+#pragma unroll
+      for (int ww = 0; ww < W; ++ww) {
+        ull mh = L.cell[0][tid][ww], mr = L.cell[1][tid][ww];
+        cnt_h += __popcll(mh);
+        cnt_r += __popcll(mr);
+        while (mh != 0ull) {
+          sp_h = sp_h + L.v[ww * 64 + first_bit(mh)];
+          mh &= mh - 1ull;
+        }
+        while (mr != 0ull) {
+          sp_r = sp_r + L.v[ww * 64 + first_bit(mr)];
+          mr &= mr - 1ull;
+        }
+      }
+      const T nh = T(cnt_h) / T(20), nr = T(cnt_r) / T(20);          // NUM_VEHICLE_NORM
+      const T mean_h = (cnt_h > 0 ? sp_h / (nh * T(20)) : T(0)) / T(50);
+      const T mean_r = (cnt_r > 0 ? sp_r / (nr * T(20)) : T(0)) / T(50);
+      orow[tid] = float(nh);
+      orow[C + tid] = float(nr);
+      orow[2 * C + tid] = float(mean_h);
+      orow[3 * C + tid] = float(mean_r);
+    }
+    const T of = outflow(o.obs_window) / T(2000.0);
+    if (tid == 0) orow[4 * C] = float(of);
+    // (the next write of the cell words is a whole sub-step, i.e. several barriers, away)
+  };
+  auto store_snapshot = [&]() {
+    if (slot_ok && live_replica) {
+      o.lead[idx] = lead;
+      o.headway[idx] = h;
+    }
+  };
+
+  bool crash_now = false;
+  neighbours(false, false, crash_now);
+
+  if (num_steps == 0) {
+    if (after_reset) {
+      neighbours(live_replica, track_foll, crash_now);
+      if (slot_ok && live_replica) {
+        o.foll[idx] = foll;
+        o.foll_h[idx] = foll_h;
+      }
+    }
+    write_obs();
+    store_snapshot();
+    return;
+  }
+
+  for (int step = 0; step < num_steps; ++step) {
+    const float* act = actions ? actions + size_t(step) * act_stride + size_t(rr) * s.num_rl : nullptr;
+    bool crashed = false;
+    for (int sub = 0; sub < s.sims_per_step; ++sub) {
+      const bool live = live_replica && !crashed;
+      const bool alive = route >= 0;
+      // ---- controllers on the snapshot (S1) ------------------------------------------------------------
+      T vf = T(0), hf = T(0), mean_v = T(0);
+      if (flags & FLAG_NEED_FOLLOWER) {
+        const int fsrc = foll >= 0 ? foll : 0;
+        vf = L.v[fsrc];
+        hf = L.h[fsrc];
+      }
+      if (flags & FLAG_NEED_MEAN) {
+        const int bm = phase & 1;
+        phase += 1;
+        const int na_w = __popcll(__ballot(alive));
+        const T sv_w = seg_sum<64>(alive ? v : T(0));
+        if (l == 0) {
+          L.red_i[bm][0][w] = na_w;
+          L.red_t[bm][0][w] = sv_w;
+        }
+        __syncthreads();
+        int n_alive = 0;
+        T part[W];
+#pragma unroll
+        for (int ww = 0; ww < W; ++ww) {
+          n_alive += L.red_i[bm][0][ww];
+          part[ww] = L.red_t[bm][0][ww];
+        }
+        T tot = part[0];
+        if (W == 2) tot = part[0] + part[1];
+        if (W == 4) tot = (part[0] + part[1]) + (part[2 % W] + part[3 % W]);
+        mean_v = tot / T(n_alive > 0 ? n_alive : 1);
+      }
+      bool internal;
+      T fx_unused;
+      route_lookup_lds<T, W>(o, L, x, internal, fx_unused);
+      const bool on_edge = s.junction_mode ? !internal : true;
+      bool commanded = false;
+      T acc = control_accel_on(s, sl, flags, v, vl, h, has, vf, hf, mean_v, on_edge, false, T(0), live && slot_ok,
+                               rr, ii, nctr, cst, commanded);
+      // ---- O6: BottleneckDesiredVelocityEnv._apply_rl_actions (bottleneck.py:926-969) -------------------
+      if (dv_env && act != nullptr) {
+        const int my_lane = (route < 0 ? 0 : route) >> shift_of(x);
+        int acell = -1;
+        for (int g = 0; g < o.n_act_groups; ++g) {
+          const T pos = x - L.ctab[CELL_ACT_START][g];
+          const bool inside = (pos > L.ctab[CELL_ACT_LO][g]) && (pos <= L.ctab[CELL_ACT_HI][g]);
+          const int meta = L.ctab_i[1][g];
+          const int rel = my_lane - ((meta >> 16) & 0xff);
+          if (alive && !internal && inside && rel >= 0 && rel < ((meta >> 8) & 0xff) && acell < 0)
+            acell = (meta & 0xff) + rel;
+        }
+        T a = acell >= 0 ? T(act[acell]) : T(0);
+        if (s.clip_actions) a = tmin(tmax(a, s.act_lo), s.act_hi);
+        T nxt = tmin(tmax(vmax + a, T(0.01)), T(23.0));
+        nxt = acell >= 0 ? nxt : T(23.0);
+        if (live && alive && is_rl) vmax = nxt;
+      }
+      // ---- M7: apply_acceleration + SUMO integration ---------------------------------------------------
+      T next_vel = tmax(v + acc * dt, T(0));
+      T vc = v + (next_vel - v) * s.ramp;
+      Slot<T> sm = sl;
+      sm.sumo_max_speed = tmin(vmax, o.speed_limit);     // M10
+      T v_sumo = sumo_idm_speed(v, vl, h, has, dt, sm);
+      if (sl.speed_mode & 1) vc = tmin(vc, v_sumo);
+      if (sl.speed_mode & 2) vc = tmin(vc, v + sl.max_accel * dt);
+      if (sl.speed_mode & 4) vc = tmax(vc, v - sl.max_decel * dt);
+      T v_new = commanded ? vc : v_sumo;
+      T x_new = (s.integrator == FS_BALLISTIC) ? x + (v + v_new) / T(2) * dt : x + v_new * dt;
+      const bool mv = live && alive;
+      const bool arrived = mv && (x_new >= o.end_x);
+      // ---- one publication for M11's arbitration (largest gain, lowest slot on a tie) and the arrival count ----
+      {
+        const int bq = phase & 1;
+        phase += 1;
+        const bool want = lc_on && lc_want >= 0 && alive && live;
+        const T gsel = want ? lc_gain : -BIGV;
+        const T gmax_w = seg_max<64>(gsel);
+        const ull wb = __ballot(want && gsel == gmax_w);
+        const int na_w = __popcll(__ballot(arrived));
+        if (l == 0) {
+          L.red_t[bq][0][w] = gmax_w;
+          L.red_i[bq][0][w] = wb ? w * 64 + first_bit(wb) : -1;
+          L.red_i[bq][1][w] = na_w;
+        }
+        __syncthreads();
+        int win = -1, na = 0;
+        T gbest = -BIGV;
+#pragma unroll
+        for (int ww = 0; ww < W; ++ww) {
+          const int cw = L.red_i[bq][0][ww];
+          const T gw = L.red_t[bq][0][ww];
+          if (cw >= 0 && (win < 0 || gw > gbest)) {        // waves ascend: the first one wins a tie
+            win = cw;
+            gbest = gw;
+          }
+          na += L.red_i[bq][1][ww];
+        }
+        if (lc_on && slot_ok && ii == win) {
+          route = lc_want;
+          last_lc = tcount + 1;
+        }
+        if (mv) {
+          prev_v = v;
+          last_acc = acc;
+          x = x_new;
+          v = v_new;
+        }
+        if (live) {
+          tcount += 1;
+          nctr += 1u;
+          sim_steps += 1;
+        }
+        // ---- M4: arrivals -----------------------------------------------------------------------------
+        if (live) arrived_rl = (arrived && is_rl) ? 1 : 0;
+        if (arrived) route = -1;
+        just_arrived = arrived;
+        if (live) { n_arr = na; n_dep = 0; }
+        tot_arr += na;
+        if (live && tid == 0) L.hist[(tcount - 1) % 20] = na;   // read after the next barriers (outflow)
+      }
+      // ---- M2 / M3: insertions in InFlows order -------------------------------------------------------
+      const double now = double(sim_steps - 1) * o.dt_d;
+      for (int f = 0; f < o.n_inflows; ++f) {
+        const int k = L.emitted[f];
+        const double due_t = L.ftd[1][f] + double(k) * L.ftd[0][f];
+        const int number = L.fti[2][f];
+        const bool due = (due_t <= now) && (due_t <= L.ftd[2][f]) && (number < 0 || k < number);
+        if (!(due && live)) continue;                    // block-uniform
+        const int typ = L.fti[0][f];
+        int route_f = L.fti[1][f];
+        const bool random_lane = route_f < 0;
+        if (random_lane) {                               // M9: departLane = "random"
+          uint32_t c0 = uint32_t(k), c1 = uint32_t(1000 + f), c2 = s.rep0 + uint32_t(rr), c3 = 1u;
+          philox4x32_10(c0, c1, c2, c3, s.seed_lo, s.seed_hi);
+          route_f = int((uint64_t(c0 >> 8) * uint64_t(P)) >> 24);
+        }
+        const bool alive_now = route >= 0;
+        const bool free_slot = !alive_now && slot_ok && (my_type == typ) && !just_arrived;
+        const T x_dep = L.tab[TAB_FL_XDEP][f];
+        const T v_dep = L.tab[TAB_FL_VDEP][f];
+        const int sj = tmax(shift_of(x), shift_of(x_dep + o.zip_d));
+        const bool cand = alive_now && ((route >> sj) == (route_f >> sj));
+        // per wave: its free slots, its rearmost candidate leader (lowest slot on equal x) and that one's back / speed
+        const int bi = phase & 1;
+        phase += 1;
+        {
+          const ull fbw = __ballot(free_slot);
+          const T xm_w = seg_min<64>(cand ? x : BIGV);
+          const ull cbw = __ballot(cand && x == xm_w);
+          const int jl = cbw ? first_bit(cbw) : 0;
+          const T back_w = bperm(x - sl.length, jl);
+          const T vlead_w = bperm(v, jl);
+          if (l == 0) {
+            L.words[bi][0][w] = fbw;
+            L.red_i[bi][0][w] = cbw ? 1 : 0;
+            L.red_t[bi][0][w] = xm_w;
+            L.red_t[bi][1][w] = back_w;
+            L.red_t[bi][2][w] = vlead_w;
+          }
+        }
+        __syncthreads();
+        int slot = -1;
+        bool has_lead = false;
+        T xm = BIGV, back_j = T(0), v_lead = T(0);
+#pragma unroll
+        for (int ww = 0; ww < W; ++ww) {
+          const ull fbw = L.words[bi][0][ww];
+          if (slot < 0 && fbw != 0ull) slot = ww * 64 + first_bit(fbw);
+          const bool hw = L.red_i[bi][0][ww] != 0;
+          const T xw = L.red_t[bi][0][ww];
+          if (hw && (!has_lead || xw < xm)) {              // strictly smaller: the lower wave keeps a tie
+            has_lead = true;
+            xm = xw;
+            back_j = L.red_t[bi][1][ww];
+            v_lead = L.red_t[bi][2][ww];
+          }
+        }
+        const T gap = back_j - x_dep;
+        const T two_sqrt = L.tab[TAB_FL_TWOSQRT][f];
+        const T need = L.tab[TAB_FL_MINGAP][f] +
+                       tmax(T(0), v_dep * L.tab[TAB_FL_TAU][f] + v_dep * (v_dep - v_lead) / two_sqrt);
+        const bool ok = (slot >= 0) && (!has_lead || gap >= need);
+        if (ok && slot_ok && ii == slot) {
+          x = x_dep;
+          v = v_dep;
+          prev_v = T(0);                                 // previous_speeds.get(veh_id, 0)
+          cst = T(0);
+          last_acc = T(0);
+          route = route_f;
+          last_lc = -(1 << 30);
+          vmax = sl.sumo_max_speed;
+          seq = seq_ctr;
+          origin = f * (1 << 20) + k;
+          foll = -1;
+          foll_h = BIGV;
+        }
+        if (ok) {
+          seq_ctr += 1;
+          n_dep += 1;
+          tot_dep += 1;
+        }
+        // M9: a random-lane vehicle that does not fit when it is due is dropped, not retried
+        const bool consumed = ok || random_lane;
+        if (consumed && tid == 0) L.emitted[f] = k + 1;    // every thread read k before this iteration's barrier
+        if (consumed && !ok) tot_drop += 1;
+      }
+      // ---- O1: new neighbour snapshot, sticky followers, collision check --------------------------------
+      bool c = false;
+      neighbours(live, track_foll, c);
+      crashed = crashed || (c && live);
+    }
+
+    // ---- get_state / compute_reward / done ---------------------------------------------------------------
+    const bool emit = obs_every_step || (step == num_steps - 1);
+    if (emit) {
+      write_obs();
+      const T reward = outflow(o.rew_window) / o.out_norm;       // bottleneck.py:474-478, 971-981
+      if (tid == 0) {
+        *rrow = float(reward);
+        *drow = uint8_t((tcount >= s.step_limit) || crashed);
+      }
+      orow += step_rows * obs_dim;
+      rrow += step_rows;
+      drow += step_rows;
+    }
+  }
+
+  if (slot_ok && live_replica) {
+    s.pos[idx] = x;
+    s.vel[idx] = v;
+    s.lane[idx] = route;
+    s.prev_vel[idx] = prev_v;
+    s.accel[idx] = last_acc;
+    s.ctrl_state[idx] = cst;
+    o.seq[idx] = seq;
+    o.origin[idx] = origin;
+    o.foll[idx] = foll;
+    o.foll_h[idx] = foll_h;
+    o.ctl_seq[idx] = -1;
+    o.arrived_rl[idx] = arrived_rl;
+    o.vmax[idx] = vmax;
+    if (lc_on) s.last_lc[idx] = last_lc;
+    o.lead[idx] = lead;
+    o.headway[idx] = h;
+    if (tid == 0) {
+      s.time[rr] = tcount;
+      s.noise_ctr[rr] = nctr;
+      cnt[CNT_SIM_STEPS] = sim_steps;
+      cnt[CNT_SEQ] = seq_ctr;
+      cnt[CNT_CTL] = ctl_ctr;
+      cnt[CNT_ARRIVED] = n_arr;
+      cnt[CNT_DEPARTED] = n_dep;
+      cnt[CNT_TOTAL_ARRIVED] = tot_arr;
+      cnt[CNT_TOTAL_DEPARTED] = tot_dep;
+      cnt[CNT_TOTAL_DROPPED] = tot_drop;
+    }
+  }
+  __syncthreads();
+  if (live_replica && tid < FS_MAX_INFLOWS) o.emitted[size_t(rr) * FS_MAX_INFLOWS + tid] = L.emitted[tid];
+  if (live_replica && tid < 20) o.arr_hist[size_t(rr) * 20 + tid] = L.hist[tid];
+}
+
+}  // namespace fs

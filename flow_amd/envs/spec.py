@@ -144,8 +144,9 @@ def build_open_spec(env, num_replicas, rng=None):
         # the bottleneck heads use one lane per lane-segment and need the full wave: spare slots stay empty
         caps[max(range(len(caps)), key=lambda i: caps[i])] += total - sum(caps)
     N = sum(caps)
-    if N < 1 or N > 64:
-        raise NotImplementedError("open networks hold 1..64 vehicle slots per replica (got %d)" % N)
+    n_max = 256 if lane_drop else 64       # FS_MAX_SLOTS_WIDE: k_steps_wide runs a replica on up to four waves
+    if N < 1 or N > n_max:
+        raise NotImplementedError("this network holds 1..%d vehicle slots per replica (got %d)" % (n_max, N))
     slots, base, n_rl_slots = [], {}, 0
     for t, (name, cap) in enumerate(zip(names, caps)):
         base[name] = len(slots)

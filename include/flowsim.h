@@ -127,6 +127,7 @@ enum fs_field {
 #define FS_MAX_CTRL_PARAMS 8
 #define FS_MAX_SEGMENTS 16
 #define FS_MAX_INFLOWS 8
+#define FS_MAX_SLOTS_WIDE 256   /* vehicle slots per replica on FS_NET_BOTTLENECK (64 everywhere else) */
 
 /* One edge of a closed loop in route order (non-ring networks).  `start` is the loop coordinate of the
  * edge's first metre; Flow's own coordinate of a point `x` on it (get_x_by_id, vehicle/traci.py:1011-1017
@@ -207,7 +208,7 @@ typedef struct fs_config {
   int32_t env;                        /* enum fs_env */
   int32_t integrator;                 /* enum fs_integrator */
   int32_t num_replicas;               /* R */
-  int32_t num_vehicles;               /* N per replica (<= 64); open networks: slot capacity */
+  int32_t num_vehicles;               /* N per replica (<= 64; FS_NET_BOTTLENECK: <= FS_MAX_SLOTS_WIDE); open networks: slot capacity */
   int32_t num_rl;                     /* RL vehicles per replica; FS_ENV_MERGE_PO: env_params 'num_rl' */
   int32_t horizon;                    /* EnvParams.horizon; <0 means inf */
   int32_t warmup_steps;               /* EnvParams.warmup_steps */

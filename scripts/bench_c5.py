@@ -1,6 +1,6 @@
 """The C5 merge / C4 bottleneck leg of bench.py on its own (for profiling k_steps_open): prints one JSON object.
 
-    python scripts/bench_c5.py [replicas] [c5|c4]
+    python scripts/bench_c5.py [replicas] [c5|c4] [slots (c4 only, default 256)]
 """
 import json
 import os
@@ -13,5 +13,8 @@ if __name__ == "__main__":
     import bench
     R = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     leg = sys.argv[2] if len(sys.argv) > 2 else "c5"
-    fn = bench.c4_leg if leg == "c4" else bench.c5_leg
-    print(json.dumps(fn(torch.device("cuda", 0), R=R)))
+    if leg == "c4":
+        slots = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+        print(json.dumps(bench.c4_leg(torch.device("cuda", 0), R=R, slots=slots)))
+    else:
+        print(json.dumps(bench.c5_leg(torch.device("cuda", 0), R=R)))

@@ -114,6 +114,35 @@ def test_desired_velocity_env_equals_oracle_on_the_c4_configuration():
     env.terminate()
 
 
+def test_desired_velocity_env_with_200_vehicle_slots_holds_the_whole_queue():
+    """SumoParams(max_vehicles=200): the replica runs on k_steps_wide (one workgroup of four waves); the queue upstream
+    of the lane drops outgrows 64 vehicles and nothing is dropped for lack of a slot."""
+    from flow_amd import _lib as L
+    env = make_env(c4_flow_params(horizon=700, max_vehicles=200))
+    spec = env._spec
+    assert spec["num_vehicles"] == 200 and spec["num_rl"] == 20
+    ora = O.MergeOracle(spec, np.float32)
+    obs = env.reset()
+    np.testing.assert_array_equal(obs, ora.reset()[0].astype(np.float32))
+    rng = np.random.default_rng(1)
+    for k in range(700):
+        a = rng.uniform(-1.5, 1.5, 20).astype(np.float32)
+        obs, rew, done, _ = env.step(a)
+        o_ref, r_ref, d_ref = ora.step(a[None, :])
+        np.testing.assert_array_equal(obs, o_ref[0].astype(np.float32))
+        assert rew == np.float32(r_ref[0]) and done == bool(d_ref[0])
+    veh = env.k.vehicle
+    ids = veh.get_ids()
+    assert len(ids) == int(ora.alive[0].sum()) > 64
+    assert len(set(ids)) == len(ids) and all(veh.get_edge(v) for v in ids)
+    h = np.array([veh.get_headway(v) for v in ids])          # (a zipper partner on the other lane may overlap)
+    alive = ora.alive[0]
+    np.testing.assert_array_equal(np.sort(h.astype(np.float32)), np.sort(ora.h[0][alive].astype(np.float32)))
+    assert len(veh.get_rl_ids()) >= 5
+    assert int(env.sim.get_state(L.FS_FIELD_COUNTERS)[0, 6]) == int(ora.total_departed[0])
+    env.terminate()
+
+
 def test_reset_inflow_draws_a_new_rate_like_the_reference():
     """test_environments.py:886-947: np.random.seed(123) -> the constructor's toll_wait_time draws, then reset()
     draws uniform(1000, 2000) = 1719.47 veh/h.  The reference then measures ~1353.6 veh/h entering (SUMO drops the

@@ -469,6 +469,32 @@ def test_bottleneck_config_validation_needs_no_gpu():
         FlowSim(bottleneck_spec(R=1, obs_outflow_window=30), "f32")
     with pytest.raises(ValueError, match="merge1_x <= merge2_x"):
         FlowSim(bottleneck_spec(R=1, merge1_x=900.0), "f32")
+    with pytest.raises(NotImplementedError, match="256 vehicle slots"):      # k_steps_wide: at most four waves per replica
+        FlowSim(bottleneck_spec(R=1, cap_human=250, cap_rl=7), "f32")
+    with pytest.raises(NotImplementedError, match="FS_NET_BOTTLENECK only"):
+        FlowSim(merge_spec(R=1, cap_human=60, cap_rl=6, num_rl=2), "f32")
+
+
+def test_wide_oracle_runs_beyond_64_slots_and_the_queue_outgrows_one_wave():
+    """The oracle has no slot limit of its own: C4's demand on 200 slots keeps more than 64 vehicles in the network
+    (what the 64-slot kernel had to drop at insertion), conserves vehicles and never overlaps two on one lane."""
+    from helpers import bottleneck_spec
+    spec = bottleneck_spec(R=2, cap_human=180, cap_rl=20, horizon=700, seed=2)
+    ora = O.MergeOracle(spec, np.float32)
+    ora.reset()
+    rng = np.random.default_rng(0)
+    peak = 0
+    for k in range(700):
+        ora.step(rng.uniform(-1, 1, (2, spec["num_rl"])).astype(np.float32))
+        peak = max(peak, int(ora.alive.sum(axis=1).max()))
+        np.testing.assert_array_equal(ora.alive.sum(axis=1) + ora.total_arrived, 2 + ora.total_departed)
+    assert peak > 64
+    spec64 = bottleneck_spec(R=2, cap_human=56, cap_rl=8, horizon=700, seed=2)
+    o64 = O.MergeOracle(spec64, np.float32)
+    o64.reset()
+    for k in range(700):
+        o64.step(None)
+    assert (o64.total_dropped > ora.total_dropped).all()             # the 64-slot pool drops what does not fit
 
 
 def test_simplified_lane_changing_facts():

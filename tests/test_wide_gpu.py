@@ -1,0 +1,154 @@
+"""GPU parity of `k_steps_wide` (flowsim_wide.h): BottleneckNetwork replicas with MORE than 64 vehicle slots, one
+workgroup of 2 / 4 waves per replica, against oracle/opennet.py through the C ABI.
+
+Same bars as test_open_gpu.py: float32 kernel vs the float32 oracle twin bit-exact on every state field,
+observation, reward and done flag; float64 kernel vs the float64 oracle within 1e-9.
+"""
+import numpy as np
+import pytest
+
+from oracle import opennet as O
+from test_open_gpu import bottleneck_actions, compare_state, compare_vmax, make, run_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def test_wide_desired_velocity_f32_bit_exact_192_slots():
+    """C4's demand: the queue upstream of the lane drops outgrows one wave (more than 64 vehicles in the network)."""
+    from helpers import bottleneck_spec
+    spec = bottleneck_spec(R=3, cap_human=170, cap_rl=22, horizon=700, seed=3)
+    ora = run_pair(spec, "f32", 700, bottleneck_actions(spec, 5), check_every=50)
+    assert (ora.alive.sum(axis=1) > 64).all()                          # really beyond the 64-slot kernel
+    assert ora.total_arrived.min() > 100
+
+
+def test_wide_two_waves_and_a_full_block():
+    from helpers import bottleneck_spec
+    for cap_h, cap_rl in ((90, 10), (116, 12)):                        # 100 slots (two waves, 28 idle lanes) / 128
+        spec = bottleneck_spec(R=2, cap_human=cap_h, cap_rl=cap_rl, horizon=400, seed=cap_h)
+        ora = run_pair(spec, "f32", 400, bottleneck_actions(spec, 1), check_every=40)
+        assert (ora.alive.sum(axis=1) > 64).any()
+
+
+def test_wide_state_fields_warmup_and_max_speed():
+    from helpers import bottleneck_spec
+    spec = bottleneck_spec(R=2, cap_human=120, cap_rl=30, horizon=200, seed=7, warmup_steps=60)
+    ora = O.MergeOracle(spec, np.float32)
+    sim = make(spec, "f32")
+    np.testing.assert_array_equal(sim.reset(), ora.reset().astype(np.float32))
+    compare_state(sim, ora)
+    acts = bottleneck_actions(spec, 2)
+    for k in range(200):
+        a = acts(k)
+        o_ref, r_ref, d_ref = ora.step(a)
+        o_gpu, r_gpu, d_gpu = sim.step(a)
+        np.testing.assert_array_equal(o_gpu, o_ref.astype(np.float32))
+        np.testing.assert_array_equal(r_gpu, r_ref.astype(np.float32))
+        np.testing.assert_array_equal(d_gpu, d_ref)
+        if k % 25 == 0:
+            compare_state(sim, ora)
+            compare_vmax(sim, ora)
+    assert d_ref.all()
+    sim.close()
+
+
+def test_wide_base_env_no_actions_256_slots():
+    from helpers import bottleneck_spec
+    spec = bottleneck_spec(R=2, cap_human=236, cap_rl=20, horizon=500, seed=9, env=O.ENV_BOTTLENECK, num_rl=0,
+                           action_cells=[], q=3600.0)
+    ora = run_pair(spec, "f32", 500, None, check_every=50)
+    assert ora.total_arrived.min() > 50
+
+
+def test_wide_f64_matches_reference_arithmetic():
+    from helpers import bottleneck_spec
+    spec = bottleneck_spec(R=2, cap_human=130, cap_rl=14, horizon=400, seed=4)
+    run_pair(spec, "f64", 400, bottleneck_actions(spec, 8), check_every=50, exact=False, atol=1e-9)
+
+
+def test_wide_simplified_lane_changing_and_followers():
+    """M11 and the sticky-follower bookkeeping (O1) across waves."""
+    from helpers import bottleneck_spec
+    spec = bottleneck_spec(R=3, cap_human=150, cap_rl=20, horizon=500, seed=13, lane_change_cooldown_steps=8,
+                           lane_change_min_gain=8.0, track_followers=True)
+    for v in spec["vehicles"][:150]:
+        v["lane_change_mode"] = 1621
+    ora = run_pair(spec, "f32", 500, bottleneck_actions(spec, 4), check_every=50)
+    assert (ora.num_lane_changes > 40).all()
+
+
+def test_wide_without_zipper_lookahead_crashes_at_the_joins():
+    from helpers import bottleneck_spec
+    spec = bottleneck_spec(R=3, cap_human=100, cap_rl=8, horizon=400, seed=11, zipper_distance=0.0)
+    ora = O.MergeOracle(spec, np.float32)
+    sim = make(spec, "f32")
+    np.testing.assert_array_equal(sim.reset(), ora.reset().astype(np.float32))
+    crashed = np.zeros(3, dtype=bool)
+    for k in range(400):
+        o_ref, r_ref, d_ref = ora.step(None)
+        o_gpu, r_gpu, d_gpu = sim.step(None)
+        np.testing.assert_array_equal(o_gpu, o_ref.astype(np.float32))
+        np.testing.assert_array_equal(d_gpu, d_ref)
+        crashed |= d_ref & (ora.time_counter < 400)
+    assert crashed.any()
+    sim.close()
+
+
+def test_wide_masked_reset_and_rollout_equal_stepping():
+    import torch
+    from helpers import bottleneck_spec
+    spec = bottleneck_spec(R=4, cap_human=100, cap_rl=12, horizon=200, seed=5)
+    K, R, A = 80, 4, spec["num_rl"]
+    acts = np.random.default_rng(3).uniform(-1.0, 1.0, (K, R, A)).astype(np.float32)
+    a, b = make(spec, "f32"), make(spec, "f32")
+    a.reset(), b.reset()
+    dev = torch.device("cuda:0")
+    obs = torch.empty((K, R, a.obs_dim), dtype=torch.float32, device=dev)
+    rew = torch.empty((K, R), dtype=torch.float32, device=dev)
+    done = torch.empty((K, R), dtype=torch.uint8, device=dev)
+    a.rollout_dev(K, obs, rew, done, actions=torch.from_numpy(acts).to(dev))
+    a.sync()
+    for k in range(K):
+        o, r, d = b.step(acts[k])
+        np.testing.assert_array_equal(obs[k].cpu().numpy(), o)
+        np.testing.assert_array_equal(rew[k].cpu().numpy(), r)
+        np.testing.assert_array_equal(done[k].cpu().numpy().astype(bool), d)
+    np.testing.assert_array_equal(a.pos, b.pos)
+    a.close()
+    # masked reset against the oracle: replicas 0 and 3 restart, 1 and 2 keep going
+    ora = O.MergeOracle(spec, np.float32)
+    ora.reset()
+    for k in range(K):
+        ora.step(acts[k])
+    mask = np.array([1, 0, 0, 1], dtype=bool)
+    np.testing.assert_array_equal(b.reset(mask), ora.reset(mask).astype(np.float32))
+    compare_state(b, ora)
+    for k in range(40):
+        o_ref, r_ref, d_ref = ora.step(acts[k])
+        o_gpu, r_gpu, d_gpu = b.step(acts[k])
+        np.testing.assert_array_equal(o_gpu, o_ref.astype(np.float32))
+        np.testing.assert_array_equal(r_gpu, r_ref.astype(np.float32))
+        np.testing.assert_array_equal(d_gpu, d_ref)
+    compare_state(b, ora)
+    b.close()
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_wide_fuzz_random_lane_drop_configs_bit_exact(seed):
+    from helpers import bottleneck_spec
+    rng = np.random.default_rng(7000 + seed)
+    R = int(rng.integers(1, 5))
+    cap_rl = int(rng.integers(2, 30))
+    N = int(rng.integers(65, 257))
+    spec = bottleneck_spec(R=R, cap_human=N - cap_rl, cap_rl=cap_rl, horizon=int(rng.integers(150, 420)), seed=seed,
+                           q=float(rng.choice([2300, 3600, 5000])), av_frac=float(rng.choice([0.1, 0.3])),
+                           zipper_distance=float(rng.choice([0.0, 20.0, 50.0, 120.0])),
+                           warmup_steps=int(rng.choice([0, 0, 20])), lane_change_cooldown_steps=int(rng.choice([2, 8, 20])),
+                           lane_change_min_gain=float(rng.choice([3.0, 10.0])), crash_gap=float(rng.choice([0.0, 1.0])),
+                           track_followers=bool(rng.integers(0, 2)), sims_per_step=int(rng.choice([1, 1, 2])))
+    if rng.integers(0, 2):
+        for v in spec["vehicles"][:N - cap_rl]:
+            v["lane_change_mode"] = 1621
+    A = spec["num_rl"]
+    acts = (lambda k, r=np.random.default_rng(seed): r.uniform(-1.5, 1.5, (R, A)).astype(np.float32))
+    run_pair(spec, "f32", int(spec["horizon"]), acts, check_every=30)
