@@ -135,24 +135,96 @@ __device__ __forceinline__ T seg_min(T v) {
 template <int SEG, typename T>
 __device__ __forceinline__ T seg_max(T v) { return -seg_min<SEG>(-v); }
 
-// (internal?, Flow table coordinate) of coordinate x on route r (O5).  tab_* are the lane-indexed segment rows; both
-// routes are walked with wave-uniform loops and the lane keeps the result of its own route.
-template <int NR, typename T>
-__device__ __forceinline__ void route_lookup(const OpenView<T>& o, T tab_start, T tab_flow, T tab_slope, T x, int route,
-                                             bool& internal, T& flow_x) {
+// ---- launch constants of the step loop ---------------------------------------------------------------------
+// float32 instantiations keep them ONE PER LANE in VGPRs and fetch entry j with v_readlane (no memory access in
+// the loop).  float64 instantiations run out of architectural VGPRs: hipcc parks such rows in AGPRs and brings
+// them back with v_accvgpr_read under the CURRENT exec mask right before the v_readlane, which returns stale
+// data for rows held by lanes that are inactive at that point (found by the f64 parity test of k_steps_wide).
+// They therefore read the same tables from LDS with a uniform address, valid under any exec mask.
+template <typename T>
+struct OpenTabsLds {
+  T tab[TAB_ROWS][64];
+  T ctab[6][64];
+  double ftd[3][64];
+  int fti[3][64];
+  int ctab_i[2][64];
+};
+
+template <typename T, bool IN_LDS>
+struct OpenTabs;
+
+template <typename T>
+struct OpenTabs<T, false> {
+  T tab[TAB_ROWS], ctab[6];
+  double ftd[3];
+  int fti[3], ctab_i[2];
+  __device__ __forceinline__ void load(const OpenView<T>& o, int lane, bool cells, OpenTabsLds<T>*) {
+#pragma unroll
+    for (int r = 0; r < TAB_ROWS; ++r) tab[r] = o.lane_tab[r * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      ftd[r] = o.flow_tab_d[r * 64 + lane];
+      fti[r] = o.flow_tab_i[r * 64 + lane];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) ctab[r] = cells ? o.cell_tab[r * 64 + lane] : T(0);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) ctab_i[r] = cells ? o.cell_tab_i[r * 64 + lane] : 0;
+  }
+  template <int ROW> __device__ __forceinline__ T t(int j) const { return read_lane(tab[ROW], j); }
+  template <int ROW> __device__ __forceinline__ T c(int j) const { return read_lane(ctab[ROW], j); }
+  template <int ROW> __device__ __forceinline__ int ci(int j) const { return read_lane_i(ctab_i[ROW], j); }
+  template <int ROW> __device__ __forceinline__ double fd(int j) const { return read_lane(ftd[ROW], j); }
+  template <int ROW> __device__ __forceinline__ int fi(int j) const { return read_lane_i(fti[ROW], j); }
+  // entry j with a lane-varying j (whole wave active)
+  template <int ROW> __device__ __forceinline__ T t_gather(int j) const { return __shfl(tab[ROW], j, 64); }
+};
+
+template <typename T>
+struct OpenTabs<T, true> {
+  const OpenTabsLds<T>* L;
+  __device__ __forceinline__ void load(const OpenView<T>& o, int lane, bool cells, OpenTabsLds<T>* lds) {
+#pragma unroll
+    for (int r = 0; r < TAB_ROWS; ++r) lds->tab[r][lane] = o.lane_tab[r * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      lds->ftd[r][lane] = o.flow_tab_d[r * 64 + lane];
+      lds->fti[r][lane] = o.flow_tab_i[r * 64 + lane];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) lds->ctab[r][lane] = cells ? o.cell_tab[r * 64 + lane] : T(0);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) lds->ctab_i[r][lane] = cells ? o.cell_tab_i[r * 64 + lane] : 0;
+    L = lds;
+    __syncthreads();
+  }
+  template <int ROW> __device__ __forceinline__ T t(int j) const { return L->tab[ROW][j]; }
+  template <int ROW> __device__ __forceinline__ T c(int j) const { return L->ctab[ROW][j]; }
+  template <int ROW> __device__ __forceinline__ int ci(int j) const { return L->ctab_i[ROW][j]; }
+  template <int ROW> __device__ __forceinline__ double fd(int j) const { return L->ftd[ROW][j]; }
+  template <int ROW> __device__ __forceinline__ int fi(int j) const { return L->fti[ROW][j]; }
+  template <int ROW> __device__ __forceinline__ T t_gather(int j) const { return L->tab[ROW][j]; }
+};
+
+// (internal?, Flow table coordinate) of coordinate x on route r (O5): both routes are walked with wave-uniform
+// loops and the lane keeps the result of its own route.
+template <int NR, typename T, typename TABS>
+__device__ __forceinline__ void route_lookup(const OpenView<T>& o, const TABS& tb, T x, int route, bool& internal,
+                                             T& flow_x) {
   internal = false;
   flow_x = T(0);
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     int k = 0;
-    T st = read_lane(tab_start, r * 16), fs0 = read_lane(tab_flow, r * 16), sl = read_lane(tab_slope, r * 16);
+    T st = tb.template t<TAB_SEG_START>(r * 16), fs0 = tb.template t<TAB_SEG_FLOW>(r * 16),
+      sl = tb.template t<TAB_SEG_SLOPE>(r * 16);
     for (int q = 1; q < o.nseg[r]; ++q) {
-      const T sq = read_lane(tab_start, r * 16 + q);
+      const T sq = tb.template t<TAB_SEG_START>(r * 16 + q);
       const bool hit = x >= sq;
       k = hit ? q : k;
       st = hit ? sq : st;
-      fs0 = hit ? read_lane(tab_flow, r * 16 + q) : fs0;
-      sl = hit ? read_lane(tab_slope, r * 16 + q) : sl;
+      fs0 = hit ? tb.template t<TAB_SEG_FLOW>(r * 16 + q) : fs0;
+      sl = hit ? tb.template t<TAB_SEG_SLOPE>(r * 16 + q) : sl;
     }
     if (NR == 1 || route == r) {
       internal = (o.seg_internal[r] >> k) & 1u;
@@ -212,27 +284,10 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
   sl.sumo_max_speed = s.sumo_max_speed[ii];
   const int my_type = o.slot_type[ii];
   const bool is_rl = sl.ctrl == FS_CTRL_RL;
-  const T tab_start = o.lane_tab[TAB_SEG_START * 64 + lane_id], tab_flow = o.lane_tab[TAB_SEG_FLOW * 64 + lane_id],
-          tab_slope = o.lane_tab[TAB_SEG_SLOPE * 64 + lane_id], tab_xdep = o.lane_tab[TAB_FL_XDEP * 64 + lane_id],
-          tab_vdep = o.lane_tab[TAB_FL_VDEP * 64 + lane_id], tab_mingap = o.lane_tab[TAB_FL_MINGAP * 64 + lane_id],
-          tab_tau = o.lane_tab[TAB_FL_TAU * 64 + lane_id], tab_twosqrt = o.lane_tab[TAB_FL_TWOSQRT * 64 + lane_id],
-          tab_maxcost = o.lane_tab[TAB_MAX_COST * 64 + lane_id];
-  const double ft_period = o.flow_tab_d[lane_id], ft_begin = o.flow_tab_d[64 + lane_id],
-               ft_end = o.flow_tab_d[128 + lane_id];
-  const int ft_type = o.flow_tab_i[lane_id], ft_route = o.flow_tab_i[64 + lane_id],
-            ft_number = o.flow_tab_i[128 + lane_id];
-  T co_start = T(0), co_lo = T(0), co_hi = T(0), ca_start = T(0), ca_lo = T(0), ca_hi = T(0);
-  int co_lane = 0, ca_lane = 0;
-  if (bn_env) {
-    co_start = o.cell_tab[CELL_OBS_START * 64 + lane_id];
-    co_lo = o.cell_tab[CELL_OBS_LO * 64 + lane_id];
-    co_hi = o.cell_tab[CELL_OBS_HI * 64 + lane_id];
-    ca_start = o.cell_tab[CELL_ACT_START * 64 + lane_id];
-    ca_lo = o.cell_tab[CELL_ACT_LO * 64 + lane_id];
-    ca_hi = o.cell_tab[CELL_ACT_HI * 64 + lane_id];
-    co_lane = o.cell_tab_i[lane_id];
-    ca_lane = o.cell_tab_i[64 + lane_id];
-  }
+  constexpr bool TABS_IN_LDS = sizeof(T) == 8;
+  __shared__ typename std::conditional<TABS_IN_LDS, OpenTabsLds<T>, int>::type tabs_mem;
+  OpenTabs<T, TABS_IN_LDS> tb;
+  tb.load(o, lane_id, bn_env, reinterpret_cast<OpenTabsLds<T>*>(&tabs_mem));
 
   const bool live_replica = rvalid && (mask == nullptr || mask[rr] != 0);
   int tcount = s.time[rr];
@@ -355,7 +410,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       // ---- M11: which adjacent lane (if any) this vehicle would like to continue on after the next move ----------
       bool internal;
       T fx;
-      route_lookup<NR>(o, tab_start, tab_flow, tab_slope, x, route, internal, fx);
+      route_lookup<NR>(o, tb, x, route, internal, fx);
       const int g = shift_of(x);
       const int my_path = route < 0 ? 0 : route;
       const int lane = my_path >> g, n_lanes = P >> g;
@@ -444,7 +499,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
     const bool alive = route >= 0;
     bool internal;
     T fx;
-    route_lookup<NR>(o, tab_start, tab_flow, tab_slope, x, route, internal, fx);
+    route_lookup<NR>(o, tb, x, route, internal, fx);
     const int ld = alive ? lead : -1;
     const int fo = alive ? foll : -1;
     const int lsrc = segbase + (ld >= 0 ? ld : ii), fsrc = segbase + (fo >= 0 ? fo : ii);
@@ -479,13 +534,13 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       const bool alive = route >= 0;
       bool internal;
       T fx;
-      route_lookup<NR>(o, tab_start, tab_flow, tab_slope, x, route, internal, fx);
+      route_lookup<NR>(o, tb, x, route, internal, fx);
       const int my_lane = (route < 0 ? 0 : route) >> shift_of(x);
       int ocell = -1;
       for (int g = 0; g < o.n_obs_groups; ++g) {
-        const T pos = x - read_lane(co_start, g);
-        const int meta = read_lane_i(co_lane, g);
-        bool inside = (pos > read_lane(co_lo, g)) && (pos <= read_lane(co_hi, g));
+        const T pos = x - tb.template c<CELL_OBS_START>(g);
+        const int meta = tb.template ci<0>(g);
+        bool inside = (pos > tb.template c<CELL_OBS_LO>(g)) && (pos <= tb.template c<CELL_OBS_HI>(g));
         if (meta >> 24) inside = inside || (pos == T(0));   // np.searchsorted(..) - 1 == -1: the edge's last segment
         const int rel = my_lane - ((meta >> 16) & 0xff);
         if (alive && !internal && inside && rel >= 0 && rel < ((meta >> 8) & 0xff) && ocell < 0)
@@ -586,7 +641,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       }
       bool internal;
       T fx_unused;
-      route_lookup<NR>(o, tab_start, tab_flow, tab_slope, x, route, internal, fx_unused);
+      route_lookup<NR>(o, tb, x, route, internal, fx_unused);
       const bool on_edge = s.junction_mode ? !internal : true;
       // RL command (envs/base.py:355 runs before additional_command: the rl_veh list of the last sub-step)
       bool have_rl = false;
@@ -608,9 +663,9 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         const int my_lane = (route < 0 ? 0 : route) >> shift_of(x);
         int acell = -1;
         for (int g = 0; g < o.n_act_groups; ++g) {
-          const T pos = x - read_lane(ca_start, g);
-          const bool inside = (pos > read_lane(ca_lo, g)) && (pos <= read_lane(ca_hi, g));
-          const int meta = read_lane_i(ca_lane, g);
+          const T pos = x - tb.template c<CELL_ACT_START>(g);
+          const bool inside = (pos > tb.template c<CELL_ACT_LO>(g)) && (pos <= tb.template c<CELL_ACT_HI>(g));
+          const int meta = tb.template ci<1>(g);
           const int rel = my_lane - ((meta >> 16) & 0xff);
           if (alive && !internal && inside && rel >= 0 && rel < ((meta >> 8) & 0xff) && acell < 0)
             acell = (meta & 0xff) + rel;
@@ -703,12 +758,12 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       const double now = double(sim_steps - 1) * o.dt_d;
       for (int f = 0; f < o.n_inflows; ++f) {
         const int k = seg_read_i<SEG>(emit_l, f, seg);
-        const double due_t = read_lane(ft_begin, f) + double(k) * read_lane(ft_period, f);
-        const int number = read_lane_i(ft_number, f);
-        const bool due = (due_t <= now) && (due_t <= read_lane(ft_end, f)) && (number < 0 || k < number);
+        const double due_t = tb.template fd<1>(f) + double(k) * tb.template fd<0>(f);
+        const int number = tb.template fi<2>(f);
+        const bool due = (due_t <= now) && (due_t <= tb.template fd<2>(f)) && (number < 0 || k < number);
         if (__ballot(due && live) == 0ull) continue;     // wave-uniform: this inflow is due in no replica of the wave
-        const int typ = read_lane_i(ft_type, f);
-        int route_f = read_lane_i(ft_route, f);
+        const int typ = tb.template fi<0>(f);
+        int route_f = tb.template fi<1>(f);
         const bool random_lane = route_f < 0;
         if (random_lane) {                               // M9: departLane = "random"
           uint32_t c0 = uint32_t(k), c1 = uint32_t(1000 + f), c2 = s.rep0 + uint32_t(rr), c3 = 1u;
@@ -719,8 +774,8 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         const bool free_slot = !alive_now && slot_ok && (my_type == typ) && !just_arrived;
         const unsigned long long fb = seg_ballot<SEG>(free_slot, seg);
         const int slot = fb ? __ffsll((long long)fb) - 1 : 0;
-        const T x_dep = read_lane(tab_xdep, f);
-        const T v_dep = read_lane(tab_vdep, f);
+        const T x_dep = tb.template t<TAB_FL_XDEP>(f);
+        const T v_dep = tb.template t<TAB_FL_VDEP>(f);
         const int sj = tmax(shift_of(x), shift_of(x_dep + o.zip_d));
         const bool cand = alive_now && ((route >> sj) == (route_f >> sj));
         const T xm = seg_min<SEG>(cand ? x : BIGV);
@@ -730,9 +785,9 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         const T back_j = bperm(x - sl.length, segbase + j);
         const T v_lead = bperm(v, segbase + j);
         const T gap = back_j - x_dep;
-        const T two_sqrt = read_lane(tab_twosqrt, f);
-        const T need = read_lane(tab_mingap, f) +
-                       tmax(T(0), v_dep * read_lane(tab_tau, f) + v_dep * (v_dep - v_lead) / two_sqrt);
+        const T two_sqrt = tb.template t<TAB_FL_TWOSQRT>(f);
+        const T need = tb.template t<TAB_FL_MINGAP>(f) +
+                       tmax(T(0), v_dep * tb.template t<TAB_FL_TAU>(f) + v_dep * (v_dep - v_lead) / two_sqrt);
         const bool ok = live && due && (fb != 0ull) && (!has_lead || gap >= need);
         if (ok && slot_ok && ii == slot) {
           x = x_dep;
@@ -785,7 +840,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         reward = n_alive > 0 ? sum_v / T(n_alive) : T(0);
       } else {
         // O4; n_alive differs between the replicas of a wave: a gather (ds_bpermute), not a v_readlane
-        const T mc_lane = bperm(tab_maxcost, n_alive & 63);
+        const T mc_lane = tb.template t_gather<TAB_MAX_COST>(n_alive & 63);
         const T max_cost = n_alive < 64 ? mc_lane : o.max_cost_full;
         const T dv = alive ? v - s.target_velocity : T(0);
         const T cost = tsqrt(seg_sum<SEG>(dv * dv));
