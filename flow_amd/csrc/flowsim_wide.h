@@ -28,6 +28,7 @@ struct WideLds {
   int seq[NS];
   int sorted_slot[NS];          // [rank] -> slot
   int skey[NS];                 // [rank] -> path | joins << 8, 0xffff for a free slot
+  unsigned long long okey[sizeof(T) == 4 ? NS : 1];   // float32: the 64-bit ordering key of slot j
   unsigned long long rmask[6][W];        // masks over RANKS: path 0..3, passed the first / the second join
   unsigned long long words[2][2][W];
   T red_t[2][4][W];
@@ -177,13 +178,26 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
     L.x[tid] = xr;
     L.v[tid] = v;
     L.route[tid] = route;
-    __syncthreads();
     // rank: x ascending, equal x: higher slot first; free slots after the vehicles (any fixed order)
     int rank = 0;
+    if (sizeof(T) == 4) {
+      // float32: the order is that of ONE unsigned 64-bit key, (order-preserving image of x) : (NS-1-slot), so a
+      // pair costs a v_cmp_lt_u64 and an add-with-carry instead of two float compares and three mask operations
+      // (x + 0 turns a -0.0 into +0.0, whose integer images would otherwise differ)
+      const uint32_t xb = __float_as_uint(float(xr) + 0.0f);
+      const uint32_t ord = (xb & 0x80000000u) ? ~xb : (xb | 0x80000000u);
+      const ull key = (ull(ord) << 32) | ull(uint32_t(NS - 1 - tid));
+      L.okey[tid] = key;
+      __syncthreads();
 #pragma unroll 8
-    for (int j = 0; j < NS; ++j) {
-      const T xj = L.x[j];
-      rank += ((xj < xr) || (xj == xr && j > tid)) ? 1 : 0;
+      for (int j = 0; j < NS; ++j) rank += (L.okey[j] < key) ? 1 : 0;
+    } else {
+      __syncthreads();
+#pragma unroll 8
+      for (int j = 0; j < NS; ++j) {
+        const T xj = L.x[j];
+        rank += ((xj < xr) || (xj == xr && j > tid)) ? 1 : 0;
+      }
     }
     L.sorted_slot[rank] = tid;
     const int my_key = alive ? (route | (shift_of(x) << 8)) : 0xffff;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn the rocprofv3 CSVs written by scripts/profile_c5.sh into profiles/<tag>_c5_*:
 
-    python scripts/summarize_c5.py gpurun_out/prof_c5_r01 r01
+    python scripts/summarize_c5.py gpurun_out/prof_c5_r01 r01 [c5|c4]
 
 <tag>_c5_kernel_stats.csv (the --kernel-trace --stats table), <tag>_c5_pmc_summary.json (SQ counters of the longest
 k_steps_open launch, per wave and per simulation sub-step) and <tag>_c5_bench.json (the leg's JSON)."""
@@ -14,6 +14,7 @@ import shutil
 import sys
 
 src, tag = sys.argv[1], sys.argv[2]
+leg = sys.argv[3] if len(sys.argv) > 3 else "c5"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 
@@ -22,16 +23,18 @@ def newest(pattern):
     return sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)[-1]
 
 
-shutil.copy(newest("trace/*/*_kernel_stats.csv"), os.path.join(out, "%s_c5_kernel_stats.csv" % tag))
+shutil.copy(newest("trace/*/*_kernel_stats.csv"), os.path.join(out, "%s_%s_kernel_stats.csv" % (tag, leg)))
 bench = json.loads(open(os.path.join(src, "bench_trace.json")).read().strip().splitlines()[-1])
-json.dump(bench, open(os.path.join(out, "%s_c5_bench.json" % tag), "w"), indent=1)
-waves = bench["replicas"]                      # 64 slots per replica: one wave each
-substeps = bench["env_steps"] * bench["sims_per_step"]
+json.dump(bench, open(os.path.join(out, "%s_%s_bench.json" % (tag, leg)), "w"), indent=1)
+slots = bench.get("slots", 64)                 # 64 slots per replica: one wave each; k_steps_wide: 2 or 4 waves
+waves = bench["replicas"] * (1 if slots <= 64 else (2 if slots <= 128 else 4))
+substeps = bench["env_steps"] * bench.get("sims_per_step", 1)
+pattern = "k_steps_wide" if slots > 64 else "k_steps_open"
 counters = {}
 for d in ("pmc_sq", "pmc_sq2"):
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(newest(d + "/*/*_counter_collection.csv"))):
-        if "k_steps_open" in r["Kernel_Name"]:
+        if pattern in r["Kernel_Name"]:
             agg[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
     for name, by_dispatch in agg.items():
         total = max(by_dispatch.values())      # the timed 600-step launch
@@ -41,5 +44,5 @@ k = max(rows, key=lambda r: float(r["TotalDurationNs"]))
 json.dump({"kernel": k["Name"], "waves": waves, "substeps_per_launch": substeps,
            "longest_launch_ns_kernel_trace": float(k["MaxNs"]), "counters": counters,
            "note": "SQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count in units of 4 clock cycles"},
-          open(os.path.join(out, "%s_c5_pmc_summary.json" % tag), "w"), indent=1)
+          open(os.path.join(out, "%s_%s_pmc_summary.json" % (tag, leg)), "w"), indent=1)
 print(json.dumps(counters, indent=1))
