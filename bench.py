@@ -154,7 +154,7 @@ def c3_leg(device, R=4096, steps=3000, po=False):
     dt = time.perf_counter() - t0
     crashed = float((out[2][:-1].max(dim=0).values > 0).float().mean().item())
     vec.close()
-    return {"value": R * done_steps / dt, "unit": "env-steps/s", "steps": done_steps, "replicas": R,
+    return {"value": R * done_steps / dt, "unit": "env-steps/s", "steps": done_steps, "steps_per_launch": K, "replicas": R,
             "obs_dim": 3 if po else 28, "replicas_crashed_before_horizon": crashed,
             "workload": "C3: FigureEightNetwork r=30, 13 IDM (noise 0.2, obey_safe_speed) + 1 RL, %s, "
                         "random actions; generic kernel" % ("WaveAttenuationPOEnv" if po else "AccelEnv")}

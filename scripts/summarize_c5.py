@@ -28,8 +28,11 @@ bench = json.loads(open(os.path.join(src, "bench_trace.json")).read().strip().sp
 json.dump(bench, open(os.path.join(out, "%s_%s_bench.json" % (tag, leg)), "w"), indent=1)
 slots = bench.get("slots", 64)                 # 64 slots per replica: one wave each; k_steps_wide: 2 or 4 waves
 waves = bench["replicas"] * (1 if slots <= 64 else (2 if slots <= 128 else 4))
-substeps = bench["env_steps"] * bench.get("sims_per_step", 1)
+substeps = bench.get("env_steps", bench.get("steps", 0)) * bench.get("sims_per_step", 1)
 pattern = "k_steps_wide" if slots > 64 else "k_steps_open"
+if leg == "c3":                                # 14 vehicles -> 16 lanes per replica, 4 replicas per wave
+    waves, pattern = bench["replicas"] // 4, "fs::k_steps<"
+    substeps = bench.get("steps_per_launch", 1500)
 counters = {}
 for d in ("pmc_sq", "pmc_sq2"):
     agg = collections.defaultdict(lambda: collections.defaultdict(float))

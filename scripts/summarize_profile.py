@@ -20,7 +20,12 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+def newest(*parts):
+    """gpurun merges every call's files into the same directory: take the latest pass"""
+    return sorted(glob.glob(os.path.join(src, *parts)), key=os.path.getmtime)[-1]
+
+
+stats = newest("trace", "*", "*_kernel_stats.csv")
 shutil.copy(stats, os.path.join(out, "%s_kernel_stats.csv" % tag))
 rows = list(csv.DictReader(open(stats)))
 dom = max(rows, key=lambda r: float(r["TotalDurationNs"]))
@@ -31,7 +36,7 @@ json.dump(bench, open(os.path.join(out, "%s_bench_under_profiler.json" % tag), "
 
 
 def per_launch(pass_dir):
-    f = glob.glob(os.path.join(src, pass_dir, "*", "*_counter_collection.csv"))[0]
+    f = newest(pass_dir, "*", "*_counter_collection.csv")
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Kernel_Name"] == kernel:
