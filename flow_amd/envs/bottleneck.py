@@ -4,8 +4,9 @@ Built: ``BottleneckEnv`` (the base: observation [1], outflow reward) and ``Bottl
 speed limits per lane-segment for the RL vehicles) with the toll booth and the ramp meter switched OFF, as every
 shipped bottleneck experiment runs them (examples/exp_configs/rl/singleagent/singleagent_bottleneck.py:24-25).
 Observation, maxSpeed updates and reward are computed in the HIP step kernel (heads FS_ENV_BOTTLENECK /
-FS_ENV_BOTTLENECK_DV).  Not built: the toll-booth / ALINEA ramp-meter logic (traffic lights), ``BottleneckAccelEnv``
-(per-vehicle lane changes) and the ``evaluate`` reward; they raise NotImplementedError at construction."""
+FS_ENV_BOTTLENECK_DV).  ``BottleneckAccelEnv`` is built for networks without RL vehicles (what the reference's own
+test exercises).  Not built: the toll-booth / ALINEA ramp-meter logic (traffic lights), ``BottleneckAccelEnv`` with RL
+vehicles (per-vehicle lane changes) and the ``evaluate`` reward; they raise NotImplementedError at construction."""
 from copy import deepcopy
 
 import numpy as np
@@ -132,13 +133,69 @@ class BottleneckEnv(Env):
 
 
 class BottleneckAccelEnv(BottleneckEnv):
-    """flow/envs/bottleneck.py:486-757 -- per-vehicle accelerations and lane changes: not built."""
+    """flow/envs/bottleneck.py:486-757.
+
+    Built for the case the reference itself tests (tests/fast_tests/test_environments.py:813-878): NO RL vehicles in
+    the network.  The observation is then the per-edge block only (mean speed / max speed and vehicles per metre for
+    every edge of ``get_edge_list()``, the rendering-only "fake_edge" included: 12 numbers), the action space is empty,
+    and the reward is ``rewards.desired_velocity`` (the forward-progress and lane-change terms are sums over the RL
+    vehicles).  Both are assembled on the host from the device state (``HOST_HEADS``), statement by statement as the
+    reference does.  With RL vehicles the env needs per-vehicle lane-change commands on the lane-drop network and the
+    re-insertion of exited RL vehicles (:733-757): not built, raises at construction."""
+
+    HOST_HEADS = True
 
     def __init__(self, env_params, sim_params, network=None, simulator='traci', scenario=None):
-        for p in list(ADDITIONAL_ENV_PARAMS.keys()) + list(ADDITIONAL_RL_ENV_PARAMS.keys()):
+        for p in ADDITIONAL_RL_ENV_PARAMS.keys():
             if p not in env_params.additional_params:
                 raise KeyError('Environment parameter "{}" not supplied'.format(p))
-        raise NotImplementedError("BottleneckAccelEnv needs lane changes on the lane-drop network: not built")
+        net = network if network is not None else scenario
+        if net.vehicles.num_rl_vehicles > 0:
+            raise NotImplementedError("BottleneckAccelEnv with RL vehicles needs per-vehicle lane-change commands and "
+                                      "re-insertion on the lane-drop network: not built")
+        self.num_rl = 0                              # the spaces are read while the simulator is being set up
+        super().__init__(env_params, sim_params, network, simulator, scenario)
+        self.add_rl_if_exit = env_params.get_additional_param("add_rl_if_exit")
+        self.num_rl = deepcopy(self.initial_vehicles.num_rl_vehicles)
+        self.rl_id_list = deepcopy(self.initial_vehicles.get_rl_ids())
+        self.max_speed = self.k.network.max_speed()
+
+    @property
+    def observation_space(self):
+        num_edges = len(self.k.network.get_edge_list())
+        num_obs = 2 * num_edges + 4 * MAX_LANES * self.scaling * self.num_rl + 4 * self.num_rl
+        return Box(low=0, high=1, shape=(num_obs, ), dtype=np.float32)
+
+    @property
+    def action_space(self):
+        max_decel = self.env_params.additional_params["max_decel"]
+        max_accel = self.env_params.additional_params["max_accel"]
+        lb = [-abs(max_decel), -1] * self.num_rl
+        ub = [max_accel, 1] * self.num_rl
+        return Box(np.array(lb, dtype=np.float32), np.array(ub, dtype=np.float32), dtype=np.float32)
+
+    def get_state(self):
+        """:539-640 with an empty RL list: rl_obs and relative_obs are empty, the per-edge block remains."""
+        veh = self.k.vehicle
+        edge_obs = []
+        for edge in self.k.network.get_edge_list():
+            veh_ids = veh.get_ids_by_edge(edge)
+            if len(veh_ids) > 0:
+                avg_speed = (sum(veh.get_speed(veh_ids)) / len(veh_ids)) / self.max_speed
+                density = len(veh_ids) / self.k.network.edge_length(edge)
+                edge_obs += [avg_speed, density]
+            else:
+                edge_obs += [0, 0]
+        return np.asarray(edge_obs, dtype=np.float64)
+
+    def compute_reward(self, rl_actions, **kwargs):
+        """:642-649; no RL vehicles: the lane-change penalty and the forward-progress term are empty sums."""
+        from flow_amd.core import rewards
+        return rewards.desired_velocity(self) + rewards.rl_forward_progress(self, gain=0.1) - \
+            rewards.boolean_action_penalty(np.zeros(0), gain=1.0)
+
+    def _apply_rl_actions(self, actions):
+        return None
 
 
 class BottleneckDesiredVelocityEnv(BottleneckEnv):

@@ -251,7 +251,8 @@ def build_open_spec(env, num_replicas, rng=None):
         junction_mode=int(1 if jm is None else jm), junction_length=float(net_k.junction_length),
         crash_gap=float(getattr(sp, "crash_gap", 0.0)), max_speed=float(net_k.max_speed()),
         env=env.FS_ENV, target_velocity=float(ep.additional_params.get("target_velocity", 0.0)),
-        action_low=float(np.min(space.low)), action_high=float(np.max(space.high)),
+        action_low=float(np.min(space.low)) if space.low.size else 0.0,          # an env without RL vehicles has an
+        action_high=float(np.max(space.high)) if space.high.size else 0.0,      # empty action space
         # MultiEnv.clip_actions returns the dict unclipped in this fork (multiagent/base.py:366-391)
         clip_actions=bool(ep.clip_actions) and env.FS_ENV != L.FS_ENV_MERGE_MA, evaluate=bool(ep.evaluate),
         horizon=ep.horizon, warmup_steps=int(ep.warmup_steps), sims_per_step=int(ep.sims_per_step),

@@ -41,7 +41,11 @@ class BottleneckNetwork(Network):
         assert isinstance(scaling, int), "Scaling must be an int"
         edges = [{"id": e, "from": e, "to": str(int(e) + 1), "length": ln, "spreadType": "center",
                   "numLanes": lanes * scaling, "speed": speed} for e, ln, lanes in EDGES]
-        return edges            # the reference's extra "fake_edge" is a rendering aid only (:155-163)
+        # the reference's extra edge, a rendering aid off the road (:165-174): nothing drives on it, but it is part of
+        # get_edge_list() and so of BottleneckAccelEnv's observation and of the network length
+        edges.append({"id": "fake_edge", "from": "fake1", "to": "fake2", "length": 1, "spreadType": "center",
+                      "numLanes": scaling, "speed": speed})
+        return edges
 
     def specify_connections(self, net_params):
         scaling = net_params.additional_params.get("scaling", 1)

@@ -184,8 +184,8 @@ def bottleneck_tables(junction_length=0.1, zipper_length=20.0, scaling=1):
     lanes = dict(zip("12345", [4, 4, 4, 2, 1]))
     lengths = dict(zip("12345", e))
     return dict(routes=[dict(start=0.0, segments=segs)], num_paths=4, merge1_x=s4, merge2_x=s5, merge_x=s5,
-                box_in=s5 - z, end_x=end, net_length=sum(e) + 2 * j + 2 * z, edge_start=starts, edge_lanes=lanes,
-                edge_length=lengths)
+                box_in=s5 - z, end_x=end, net_length=sum(e) + 2 * j + 2 * z + 1.0,   # + the 1 m rendering-only fake_edge
+                edge_start=starts, edge_lanes=lanes, edge_length=lengths)
 
 
 def segment_cells(tb, segments):

@@ -74,10 +74,55 @@ def test_reference_bottleneck_env_tests():
     assert sum(len(lane) for lane in env.edge_dict["1"]) + sum(len(lane) for lane in env.edge_dict["2"]) >= 8
     env.terminate()
     with pytest.raises(NotImplementedError):
-        BottleneckAccelEnv(EnvParams(additional_params=dict(full, target_velocity=30, add_rl_if_exit=True)),
-                           sim_params, net)
-    with pytest.raises(NotImplementedError):
         BottleneckEnv(EnvParams(additional_params=dict(full, disable_tb=False)), sim_params, net)
+
+
+def test_reference_bottleneck_accel_env_tests():
+    """test_environments.py:813-878: ten humans, no RL vehicle: required params, observation space of 12 in [0, 1]
+    (two numbers for each of the six edges, the rendering-only fake_edge included), an empty action space; the
+    observation and the reward are the reference's formulas over the device state."""
+    from flow_amd.core.params import EnvParams, NetParams, SumoParams, VehicleParams
+    from flow_amd.controllers import RLController
+    from flow_amd.envs import BottleneckAccelEnv
+    from flow_amd.networks import BottleneckNetwork
+    vehicles = VehicleParams()
+    vehicles.add(veh_id="human", num_vehicles=10)
+    full = {"max_accel": 3, "max_decel": 3, "lane_change_duration": 5, "disable_tb": True,
+            "disable_ramp_metering": True, "target_velocity": 30, "add_rl_if_exit": True}
+    net = BottleneckNetwork(name="bay_bridge_toll", vehicles=vehicles,
+                            net_params=NetParams(additional_params={"scaling": 1, "speed_limit": 23}))
+    sim_params = SumoParams(sim_step=0.5, restart_instance=True)
+    for key in full:
+        with pytest.raises(KeyError):
+            BottleneckAccelEnv(EnvParams(additional_params={k: v for k, v in full.items() if k != key}), sim_params, net)
+    env = BottleneckAccelEnv(EnvParams(additional_params=full), sim_params, net)
+    obs = env.reset()
+    space = env.observation_space
+    assert space.shape == (12,) and (space.low == 0).all() and (space.high == 1).all()
+    assert env.action_space.shape == (0,)
+    assert env.k.network.get_edge_list() == ["1", "2", "3", "4", "5", "fake_edge"]
+    assert obs.shape == (12,) and (obs[-2:] == 0).all()
+    for _ in range(40):
+        obs, rew, done, _ = env.step(None)
+    veh = env.k.vehicle
+    ids = veh.get_ids()
+    speeds = np.array(veh.get_speed(ids))
+    for k, edge in enumerate(["1", "2", "3", "4", "5"]):
+        on = [v for v in ids if veh.get_edge(v) == edge]
+        want = [np.mean(veh.get_speed(on)) / 23.0, len(on) / env.k.network.edge_length(edge)] if on else [0, 0]
+        np.testing.assert_allclose(obs[2 * k:2 * k + 2], want, rtol=1e-6)
+    cost = np.linalg.norm(speeds - 30.0)
+    mx = np.linalg.norm(np.full(len(ids), 30.0))
+    np.testing.assert_allclose(rew, max(mx - cost, 0) / (mx + np.finfo(np.float32).eps), rtol=1e-6)
+    assert 0 < rew < 1 and not done
+    env.terminate()
+    rl = VehicleParams()
+    rl.add(veh_id="human", num_vehicles=5)
+    rl.add(veh_id="rl", acceleration_controller=(RLController, {}), num_vehicles=2)
+    net_rl = BottleneckNetwork(name="bay_bridge_toll", vehicles=rl,
+                               net_params=NetParams(additional_params={"scaling": 1, "speed_limit": 23}))
+    with pytest.raises(NotImplementedError, match="RL vehicles"):
+        BottleneckAccelEnv(EnvParams(additional_params=full), sim_params, net_rl)
 
 
 def test_desired_velocity_env_equals_oracle_on_the_c4_configuration():
