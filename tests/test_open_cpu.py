@@ -476,24 +476,21 @@ def test_bottleneck_config_validation_needs_no_gpu():
 
 
 def test_wide_oracle_runs_beyond_64_slots_and_the_queue_outgrows_one_wave():
-    """The oracle has no slot limit of its own: C4's demand on 200 slots keeps more than 64 vehicles in the network
-    (what the 64-slot kernel had to drop at insertion), conserves vehicles and never overlaps two on one lane."""
+    """The oracle has no slot limit of its own: a heavy demand on 200 slots keeps more than 64 vehicles in the network
+    (what the 64-slot kernel has to drop at insertion), conserves vehicles, and drops fewer than a 64-slot pool."""
     from helpers import bottleneck_spec
-    spec = bottleneck_spec(R=2, cap_human=180, cap_rl=20, horizon=700, seed=2)
-    ora = O.MergeOracle(spec, np.float32)
-    ora.reset()
+    spec = bottleneck_spec(R=1, cap_human=180, cap_rl=20, horizon=400, seed=2, q=3600.0)
+    spec64 = bottleneck_spec(R=1, cap_human=56, cap_rl=8, horizon=400, seed=2, q=3600.0)
+    ora, o64 = O.MergeOracle(spec, np.float32), O.MergeOracle(spec64, np.float32)
+    ora.reset(), o64.reset()
     rng = np.random.default_rng(0)
-    peak = 0
-    for k in range(700):
-        ora.step(rng.uniform(-1, 1, (2, spec["num_rl"])).astype(np.float32))
-        peak = max(peak, int(ora.alive.sum(axis=1).max()))
-        np.testing.assert_array_equal(ora.alive.sum(axis=1) + ora.total_arrived, 2 + ora.total_departed)
-    assert peak > 64
-    spec64 = bottleneck_spec(R=2, cap_human=56, cap_rl=8, horizon=700, seed=2)
-    o64 = O.MergeOracle(spec64, np.float32)
-    o64.reset()
-    for k in range(700):
+    steps = 0
+    while steps < 400 and not (ora.alive.sum() > 80):
+        ora.step(rng.uniform(-1, 1, (1, spec["num_rl"])).astype(np.float32))
         o64.step(None)
+        steps += 1
+        np.testing.assert_array_equal(ora.alive.sum(axis=1) + ora.total_arrived, 2 + ora.total_departed)
+    assert ora.alive.sum() > 80 and o64.alive.sum() <= 64
     assert (o64.total_dropped > ora.total_dropped).all()             # the 64-slot pool drops what does not fit
 
 
