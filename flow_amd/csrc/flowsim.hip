@@ -480,8 +480,13 @@ struct Sim : SimBase {
   template <int W>
   int launch_wide(int num_steps, const uint8_t* mask, const float* actions, size_t act_stride, float* obs,
                   float* rew, uint8_t* done, int obs_every_step) {
-    hipLaunchKernelGGL((fs::k_steps_wide<T, W>), dim3(dv.R), dim3(64 * W), 0, stream, dv, ov, num_steps, mask,
-                       actions, act_stride, obs, rew, done, obs_every_step, after_reset);
+    if (std::is_same<T, float>::value && (dv.flags & fs::FLAG_IDM_SET) && !force_generic)
+      hipLaunchKernelGGL((fs::k_steps_wide<T, W, (std::is_same<T, float>::value ? 1 : 0)>), dim3(dv.R), dim3(64 * W), 0,
+                         stream, dv, ov, num_steps, mask, actions, act_stride, obs, rew, done, obs_every_step,
+                         after_reset);
+    else
+      hipLaunchKernelGGL((fs::k_steps_wide<T, W, 0>), dim3(dv.R), dim3(64 * W), 0, stream, dv, ov, num_steps, mask,
+                         actions, act_stride, obs, rew, done, obs_every_step, after_reset);
     HIP_TRY(hipGetLastError());
     return FS_OK;
   }
@@ -492,12 +497,17 @@ struct Sim : SimBase {
     constexpr int RPW = 64 / SEG;
     const int blocks = (dv.R + RPW - 1) / RPW;
     if (open_net) {
-      if (cfg.network == FS_NET_BOTTLENECK)
-        hipLaunchKernelGGL((fs::k_steps_open<T, SEG, 4>), dim3(blocks), dim3(64), 0, stream, dv, ov, num_steps, mask,
-                           actions, act_stride, obs, rew, done, obs_every_step, after_reset);
-      else
-        hipLaunchKernelGGL((fs::k_steps_open<T, SEG, 2>), dim3(blocks), dim3(64), 0, stream, dv, ov, num_steps, mask,
-                           actions, act_stride, obs, rew, done, obs_every_step, after_reset);
+      // the float32 instantiations exist twice: CSET = 1 for populations of IDM / RL / Sim slots only
+      const bool cset = std::is_same<T, float>::value && (dv.flags & fs::FLAG_IDM_SET) && !force_generic;
+#define FS_OPEN(P_, C_)                                                                                          \
+  hipLaunchKernelGGL((fs::k_steps_open<T, SEG, P_, C_>), dim3(blocks), dim3(64), 0, stream, dv, ov, num_steps, mask, \
+                     actions, act_stride, obs, rew, done, obs_every_step, after_reset)
+      if (cfg.network == FS_NET_BOTTLENECK) {
+        if (cset) FS_OPEN(4, (std::is_same<T, float>::value ? 1 : 0)); else FS_OPEN(4, 0);
+      } else {
+        if (cset) FS_OPEN(2, (std::is_same<T, float>::value ? 1 : 0)); else FS_OPEN(2, 0);
+      }
+#undef FS_OPEN
       HIP_TRY(hipGetLastError());
       return FS_OK;
     }

@@ -235,7 +235,8 @@ __device__ __forceinline__ void route_lookup(const OpenView<T>& o, const TABS& t
 
 // P = number of paths (entry lanes): 2 = MergeNetwork (each path has its own segment table), 4 = BottleneckNetwork
 // (one table; lanes 2q / 2q+1 join at m1, the two resulting lanes at m2)
-template <typename T, int SEG, int P>
+// CSET = 1: every slot is an IDM / RL / Sim-car-following controller (FLAG_IDM_SET), see control_accel_on
+template <typename T, int SEG, int P, int CSET = 0>
 __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, int num_steps,
                                                    const uint8_t* __restrict__ mask,
                                                    const float* __restrict__ actions, size_t act_stride,
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
   const int rr = rvalid ? r : s.R - 1;
   const int ii = slot_ok ? i : N - 1;
   const size_t idx = size_t(rr) * N + ii;
-  const int flags = s.flags;
+  const int flags = CSET == 1 ? (s.flags & ~(FLAG_NEED_FOLLOWER | FLAG_NEED_MEAN | FLAG_HAS_LAC)) : s.flags;
   const int env = s.env;
   // the env families are tied to the network (validated by fs_create): P == 2 merge heads, P == 4 bottleneck heads;
   // making that a compile-time fact keeps each instantiation free of the other family's code and registers
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         a_rl = have_rl ? T(a) : T(0);
       }
       bool commanded = false;
-      T acc = control_accel_on(s, sl, flags, v, vl, h, has, vf, hf, mean_v, on_edge, have_rl, a_rl, live && slot_ok,
+      T acc = control_accel_on<T, CSET>(s, sl, flags, v, vl, h, has, vf, hf, mean_v, on_edge, have_rl, a_rl, live && slot_ok,
                                rr, ii, nctr, cst, commanded);
       // ---- O6: BottleneckDesiredVelocityEnv._apply_rl_actions (bottleneck.py:926-969) -------------------
       if (dv_env && act != nullptr) {

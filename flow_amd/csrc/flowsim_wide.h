@@ -66,7 +66,7 @@ __device__ __forceinline__ void route_lookup_lds(const OpenView<T>& o, const Wid
 __device__ __forceinline__ int first_bit(unsigned long long m) { return __ffsll((long long)m) - 1; }
 __device__ __forceinline__ int last_bit(unsigned long long m) { return 63 - __clzll((long long)m); }
 
-template <typename T, int W>
+template <typename T, int W, int CSET = 0>
 __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T> o, int num_steps,
                                                        const uint8_t* __restrict__ mask,
                                                        const float* __restrict__ actions, size_t act_stride,
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
   const bool slot_ok = tid < N;
   const int ii = slot_ok ? tid : N - 1;
   const size_t idx = size_t(rr) * N + ii;
-  const int flags = s.flags;
+  const int flags = CSET == 1 ? (s.flags & ~(FLAG_NEED_FOLLOWER | FLAG_NEED_MEAN | FLAG_HAS_LAC)) : s.flags;
   const int env = s.env;
   const bool dv_env = env == FS_ENV_BOTTLENECK_DV;
   const bool track_foll = o.track_followers != 0;
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
       route_lookup_lds<T, W>(o, L, x, internal, fx_unused);
       const bool on_edge = s.junction_mode ? !internal : true;
       bool commanded = false;
-      T acc = control_accel_on(s, sl, flags, v, vl, h, has, vf, hf, mean_v, on_edge, false, T(0), live && slot_ok,
+      T acc = control_accel_on<T, CSET>(s, sl, flags, v, vl, h, has, vf, hf, mean_v, on_edge, false, T(0), live && slot_ok,
                                rr, ii, nctr, cst, commanded);
       // ---- O6: BottleneckDesiredVelocityEnv._apply_rl_actions (bottleneck.py:926-969) -------------------
       if (dv_env && act != nullptr) {

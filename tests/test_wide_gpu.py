@@ -152,3 +152,35 @@ def test_wide_fuzz_random_lane_drop_configs_bit_exact(seed):
     A = spec["num_rl"]
     acts = (lambda k, r=np.random.default_rng(seed): r.uniform(-1.5, 1.5, (R, A)).astype(np.float32))
     run_pair(spec, "f32", int(spec["horizon"]), acts, check_every=30)
+
+
+def test_wide_other_controllers_and_generic_instantiation(monkeypatch):
+    """k_steps_wide exists twice in float32: CSET = 1 for IDM / RL / Sim populations (every case above) and the generic
+    one.  A mixed population (CFM with the instantaneous fail-safe, FollowerStopper, IDM) takes the generic kernel; the
+    Sim / RL population forced onto the generic kernel (FLOWSIM_FORCE_GENERIC) gives the same bits as on CSET = 1."""
+    from helpers import bottleneck_spec, idm_vehicle
+    from oracle import refsim as S
+    spec = bottleneck_spec(R=2, cap_human=110, cap_rl=12, horizon=300, seed=17)
+    veh = spec["vehicles"]
+    for i in range(110):
+        if i % 3 == 0:
+            veh[i] = idm_vehicle(controller=S.CTRL_CFM, p=[1, 1, 1, 1, 8, 0, 0, 0], speed_mode=1, type=0,
+                                 fail_safe=S.FAILSAFE_INSTANTANEOUS)
+        elif i % 3 == 1:
+            veh[i] = idm_vehicle(controller=S.CTRL_FOLLOWER_STOPPER, p=[12.0] + [0] * 7, speed_mode=1, type=0)
+        else:
+            veh[i] = idm_vehicle(p=[20.0, 1, 1.2, 1.5, 4, 2, 0, 0], speed_mode=1, type=0, noise=0.0)
+    run_pair(spec, "f32", 300, bottleneck_actions(spec, 2), check_every=30)
+    plain = bottleneck_spec(R=2, cap_human=110, cap_rl=12, horizon=200, seed=18)
+    outs = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("FLOWSIM_FORCE_GENERIC", force)
+        sim = make(plain, "f32")
+        sim.reset()
+        acts = bottleneck_actions(plain, 6)
+        for k in range(200):
+            o, r, d = sim.step(acts(k))
+        outs.append((o, r, sim.pos.copy(), sim.vel.copy()))
+        sim.close()
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(a, b)
