@@ -1,0 +1,57 @@
+"""Code-generation guards (no GPU needed: hipcc cross-compiles gfx950 here).
+
+The float32 step kernels keep launch constants one per lane in VGPRs and read them with v_readlane.  That idiom is
+only sound while those VGPRs are never parked in AGPRs: hipcc re-materialises an AGPR-held value with v_accvgpr_read
+under the CURRENT exec mask right before the v_readlane, so rows held by lanes that are inactive at that point would
+read stale data (found in the float64 wide kernel; the float64 open-network kernels read their
+tables from LDS for that reason).  This test pins the premise: every float32 instantiation of the step kernels uses
+zero AGPRs and spills nothing to scratch memory."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def device_asm(tmp_path_factory):
+    from flow_amd import build
+    hipcc = build.find_hipcc()
+    if hipcc is None:
+        pytest.skip("hipcc not found")
+    out = tmp_path_factory.mktemp("asm") / "flowsim.s"
+    flags = [f for f in build.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    cmd = [hipcc] + flags + ["-S", "--cuda-device-only", "-I" + os.path.join(ROOT, "include"),
+                             "-I" + os.path.join(ROOT, "flow_amd", "csrc"), "-o", str(out), build.SRC]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    return out.read_text()
+
+
+def kernel_resources(asm):
+    """{mangled kernel name: {num_vgpr, num_agpr, private_seg_size}} from the .set directives of the device asm."""
+    table = {}
+    for name, key, val in re.findall(r"\.set (_ZN2fs\w+)\.(num_vgpr|num_agpr|private_seg_size), (\d+)", asm):
+        table.setdefault(name, {})[key] = int(val)
+    return table
+
+
+def test_float32_step_kernels_use_no_agprs(device_asm):
+    table = kernel_resources(device_asm)
+    step_kernels = {n: r for n, r in table.items()
+                    if re.match(r"_ZN2fs\d+(k_steps|k_steps_ml|k_steps_open|k_steps_wide|k_rollout_idm)I", n)}
+    f32 = {n: r for n, r in step_kernels.items() if re.match(r"_ZN2fs\d+k_\w+?If", n)}
+    f64 = {n: r for n, r in step_kernels.items() if re.match(r"_ZN2fs\d+k_\w+?Id", n)}
+    assert len(f32) >= 20 and len(f64) >= 10, (len(f32), len(f64))
+    # (a few bytes of scratch are fine: the large-argument path of libm's cosf keeps a small array there)
+    bad = {n: r for n, r in f32.items() if r.get("num_agpr", 0) != 0 or r.get("private_seg_size", 0) > 64}
+    assert not bad, bad
+    # the headline kernel must leave room for 2+ waves per SIMD (512 VGPRs per SIMD lane)
+    rollout = [r for n, r in f32.items() if "k_rollout_idm" in n]
+    assert rollout and max(r["num_vgpr"] for r in rollout) <= 128
+    # the float64 kernels that still spill to AGPRs must be the ones whose tables live in LDS (open / wide) or that
+    # hold no lane tables beyond the three segment rows (k_steps): nothing else may appear here unnoticed
+    spilling = sorted({re.match(r"_ZN2fs\d+(k_[a-z_]+?)I", n).group(1) for n, r in f64.items() if r.get("num_agpr", 0)})
+    assert set(spilling) <= {"k_steps", "k_steps_open", "k_steps_wide"}, spilling
