@@ -41,6 +41,7 @@ class VehicleKernel(object):
         self.type_parameters = vehicles.type_parameters
         self.minGap = vehicles.minGap
         self._open, self._slot_id, self._slot, self.sim = False, {}, {}, None    # until attach()
+        self._ring_n = None
         self.__ids, self.__human_ids, self.__controlled_ids = [], [], []
         self.__controlled_lc_ids, self.__rl_ids = [], []
         self.__vehicles = {}
@@ -83,6 +84,8 @@ class VehicleKernel(object):
     def attach(self, sim, replica=0):
         self.sim, self.replica = sim, replica
         self._cache = {}
+        # MultiRingNetwork: ring r = replica r; vehicle g = r * N + i is slot i of replica r (ids in ring order)
+        self._ring_n = int(sim.spec["num_vehicles"]) if sim.spec.get("rings") else None
         self._open = bool(getattr(sim, "open_net", False))
         if self._open:
             self._init_id_of_slot = {i: v for v, i in sim.spec["init_slot"].items()}
@@ -223,8 +226,15 @@ class VehicleKernel(object):
     # ---- state reads
     def _field(self, field):
         if field not in self._cache:
-            self._cache[field] = self.sim.get_state(field)[self.replica]
+            a = self.sim.get_state(field)
+            self._cache[field] = a.reshape(-1) if self._ring_n else a[self.replica]
         return self._cache[field]
+
+    def _ring_neighbour(self, i, step):
+        """Slot ``step`` places ahead of slot i on i's own ring (closed single-lane loops keep their order)."""
+        n = self._ring_n or self.num_vehicles
+        base = (i // n) * n
+        return base + (i - base + step) % n
 
     def _vec(self, veh_id, fn, error=-1001):
         if isinstance(veh_id, (list, np.ndarray)):
@@ -249,11 +259,13 @@ class VehicleKernel(object):
         """Flow's absolute position: edge start of the network's table + position on the edge
         (vehicle/traci.py:1011-1017)."""
         net = self.master_kernel.network
-        if net.loop_starts is None and not self._open:
+        if net.loop_starts is None and not self._open and not self._ring_n:
             return self._vec(veh_id, lambda i: float(self._field(L.FS_FIELD_POS)[i]), 0.)
         return self._vec(veh_id, lambda i: float(net.get_x(*self._edge_pos(i))), 0.)
 
     def _edge_pos(self, i):
+        if self._ring_n:
+            return self.master_kernel.network.locate_ring(i // self._ring_n, float(self._field(L.FS_FIELD_POS)[i]))
         if self._open:
             return self.master_kernel.network.open_locate(int(self._field(L.FS_FIELD_ROUTE)[i]),
                                                           float(self._field(L.FS_FIELD_POS)[i]))
@@ -296,7 +308,7 @@ class VehicleKernel(object):
                 j = int(self._field(L.FS_FIELD_LEADER)[i])
                 return self._sid(j) if j >= 0 else None
             return self._vec(veh_id, lead, error)
-        return self._vec(veh_id, lambda i: self._order[(i + 1) % n] if n > 1 else None, error)
+        return self._vec(veh_id, lambda i: self._order[self._ring_neighbour(i, 1)] if n > 1 else None, error)
 
     def get_follower(self, veh_id, error=""):
         n = self.num_vehicles
@@ -314,7 +326,7 @@ class VehicleKernel(object):
                 hw = self._field(L.FS_FIELD_HEADWAY)
                 return self._order[min(cand, key=lambda j: hw[j])]     # vehicle/traci.py:243-250
             return self._vec(veh_id, foll, error)
-        return self._vec(veh_id, lambda i: self._order[(i - 1) % n] if n > 1 else None, error)
+        return self._vec(veh_id, lambda i: self._order[self._ring_neighbour(i, -1)] if n > 1 else None, error)
 
     def get_max_speed(self, veh_id, error=-1001):
         """maxSpeed of the SUMO car-following model of the vehicle (vehicle/traci.py get_max_speed)."""
@@ -352,7 +364,12 @@ class VehicleKernel(object):
     def get_ids_by_edge(self, edges):
         if isinstance(edges, (list, np.ndarray)):
             return sum([self.get_ids_by_edge(e) for e in edges], [])
-        return [v for v in self.__ids if self.get_edge(v) == edges]
+        if "by_edge" not in self._cache:                 # one pass per simulation step
+            table = {}
+            for v in self.__ids:
+                table.setdefault(self.get_edge(v), []).append(v)
+            self._cache["by_edge"] = table
+        return list(self._cache["by_edge"].get(edges, []))
 
     def get_last_lc(self, veh_id, error=-1001):
         """This fork returns the HEADWAY here (vehicle/traci.py:604-614); kept unless the env was
@@ -447,14 +464,18 @@ class VehicleKernel(object):
         pass
 
     # ---- test back-doors (vehicle/traci.py:411-425)
+    def _rs(self, veh_id):
+        i = self._slot[veh_id]
+        return (i // self._ring_n, i % self._ring_n) if self._ring_n else (self.replica, i)
+
     def test_set_speed(self, veh_id, speed):
         v = self.sim.get_state(L.FS_FIELD_VEL)
-        v[self.replica, self._slot[veh_id]] = speed
+        v[self._rs(veh_id)] = speed
         self.sim.set_state(L.FS_FIELD_VEL, v)
         self._cache = {}
 
     def test_set_position(self, veh_id, x):
         p = self.sim.get_state(L.FS_FIELD_POS)
-        p[self.replica, self._slot[veh_id]] = x
+        p[self._rs(veh_id)] = x
         self.sim.set_state(L.FS_FIELD_POS, p)
         self._cache = {}

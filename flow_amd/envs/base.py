@@ -99,7 +99,10 @@ class Env(_Base):
         self.k.vehicle.attach(self.sim, 0)
         x0 = spec["init_pos"][0]
         for i, veh_id in enumerate(self.initial_ids):
-            if spec.get("network") in ("merge", "bottleneck"):
+            if spec.get("rings"):                     # MultiRingNetwork: vehicle i is slot i % n of ring i // n
+                r, k = divmod(i, int(spec["num_vehicles"]))
+                edge, pos = self.k.network.locate_ring(r, float(spec["init_pos"][r][k]))
+            elif spec.get("network") in ("merge", "bottleneck"):
                 slot = spec["init_slot"][veh_id]
                 edge, pos = self.k.network.open_locate(int(spec["init_route"][0][slot]), float(x0[slot]))
             else:

@@ -2,7 +2,7 @@
 from flow_amd.envs.multiagent.base import MultiEnv
 from flow_amd.envs.multiagent.merge import MultiAgentMergePOEnv
 from flow_amd.envs.multiagent.ring.accel import AdversarialAccelEnv, MultiAgentAccelPOEnv
-from flow_amd.envs.multiagent.ring.wave_attenuation import MultiAgentWaveAttenuationPOEnv
+from flow_amd.envs.multiagent.ring.wave_attenuation import MultiAgentWaveAttenuationPOEnv, MultiWaveAttenuationPOEnv
 
 __all__ = ["MultiEnv", "MultiAgentMergePOEnv", "AdversarialAccelEnv", "MultiAgentAccelPOEnv",
-           "MultiAgentWaveAttenuationPOEnv"]
+           "MultiAgentWaveAttenuationPOEnv", "MultiWaveAttenuationPOEnv"]

@@ -108,3 +108,120 @@ def test_adversarial_accel_env():
     np.testing.assert_allclose(obs["av"][0::2], ora.v[0] / 30, rtol=0, atol=1e-6)
     np.testing.assert_allclose(obs["av"][1::2], ora.x[0] / env.k.network.length(), rtol=0, atol=1e-6)
     env.terminate()
+
+
+def lord_of_the_rings(num_rings=3, noise=0.0, horizon=120, warmup=20):
+    """examples/exp_configs/rl/multiagent/lord_of_the_rings.py:30-104 (NUM_RINGS rings of 21 IDM + 1 RL vehicle)."""
+    from flow_amd.controllers import ContinuousRouter, IDMController, RLController
+    from flow_amd.core.params import EnvParams, InitialConfig, NetParams, SumoParams, VehicleParams
+    from flow_amd.envs.multiagent import MultiWaveAttenuationPOEnv
+    from flow_amd.networks import MultiRingNetwork
+    vehicles = VehicleParams()
+    for i in range(num_rings):
+        vehicles.add(veh_id='human_{}'.format(i), acceleration_controller=(IDMController, {'noise': noise}),
+                     routing_controller=(ContinuousRouter, {}), num_vehicles=21)
+        vehicles.add(veh_id='rl_{}'.format(i), acceleration_controller=(RLController, {}),
+                     routing_controller=(ContinuousRouter, {}), num_vehicles=1)
+    return dict(exp_tag='lord_of_numrings{}'.format(num_rings), env_name=MultiWaveAttenuationPOEnv,
+                network=MultiRingNetwork, simulator='traci', sim=SumoParams(sim_step=0.1, render=False),
+                env=EnvParams(horizon=horizon, warmup_steps=warmup,
+                              additional_params={'max_accel': 1, 'max_decel': 1, 'ring_length': [230, 230],
+                                                 'target_velocity': 4}),
+                net=NetParams(additional_params={'length': 230, 'lanes': 1, 'speed_limit': 30, 'resolution': 40,
+                                                 'num_rings': num_rings}),
+                veh=vehicles, initial=InitialConfig(bunching=20.0, spacing='custom'))
+
+
+def test_multi_wave_attenuation_po_env_on_the_lord_of_the_rings_network():
+    """multiagent/ring/wave_attenuation.py:34-127 on MultiRingNetwork: ring r runs as replica r of the ring kernel; the
+    per-agent observation and reward are the reference's formulas over that state, checked against the oracle."""
+    from flow_amd.utils.registry import make_create_env
+    K = 3
+    env = make_create_env(lord_of_the_rings(K))[0]()
+    assert env.observation_space.shape == (3,) and env.action_space.shape == (1,)
+    spec = env._spec
+    assert spec["num_replicas"] == K and spec["num_vehicles"] == 22 and spec["num_rl"] == 1
+    # custom placement (multi_ring.py:98-150): every ring starts at its own x = 0; the spacing comes from the total length
+    inc = (K * 230 - 20 - 5 * 22 * K) / (22 * K) + 5
+    np.testing.assert_allclose(spec["init_pos"][1][:3], [0, inc, 2 * inc], atol=1e-9)
+    net = env.k.network
+    assert net.get_edge_list()[:5] == ["bottom_0", "right_0", "top_0", "left_0", "bottom_1"]
+    assert net.get_x("right_2", 1.5) == 2 * 230 + 57.5 + 1.5
+    ora = S.RingOracle(spec, np.float64)
+    obs = env.reset()
+    ora.reset()
+    rl_ids = ["rl_{}_0".format(r) for r in range(K)]
+    assert sorted(obs) == rl_ids and env.k.vehicle.get_rl_ids() == rl_ids
+    veh = env.k.vehicle
+    assert veh.get_leader("rl_1_0") == "human_1_0" and veh.get_follower("human_2_0") == "rl_2_0"
+    assert veh.get_edge("human_1_0") == "bottom_1" and veh.get_edge("rl_2_0").endswith("_2")
+    rng = np.random.default_rng(0)
+    for k in range(120):
+        acts = {rl: np.array([rng.uniform(-1, 1)]) for rl in rl_ids}
+        obs, rew, done, _ = env.step(acts)
+        ora.step(np.array([[float(acts[rl][0])] for rl in rl_ids]))
+        h = ora.headways()
+        for r, rl in enumerate(rl_ids):
+            x, v = ora.x[r], ora.v[r]
+            want = [v[21] / 15, (v[0] - v[21]) / 15, h[r][21] / 230]
+            np.testing.assert_allclose(obs[rl], want, rtol=0, atol=2e-5)
+            # reward: the vehicles of ring r that are on one of its four edges (not inside a 0.1 m junction)
+            quarter = 57.5 + 0.1
+            on_edge = (x % quarter) < 57.5
+            vel = v[on_edge]
+            mx = np.linalg.norm(np.full(len(vel), 4.0))
+            np.testing.assert_allclose(rew[rl], max(mx - np.linalg.norm(vel - 4.0), 0) / mx, rtol=0, atol=2e-5)
+        assert done["__all__"] == (k == 119) and not any(done[rl] for rl in rl_ids)
+    env.additional_command()
+    assert set(veh.get_observed_ids()) >= {"human_0_0", "human_1_0", "human_2_0"}
+    assert len(veh.get_ids_by_edge(env.gen_edges("1"))) in (21, 22)
+    env.terminate()
+
+
+def test_multi_ring_requires_equal_rings_and_the_net_params():
+    from flow_amd.controllers import IDMController, RLController
+    from flow_amd.core.params import EnvParams, NetParams, SumoParams, VehicleParams
+    from flow_amd.envs.multiagent import MultiWaveAttenuationPOEnv
+    from flow_amd.networks import MultiRingNetwork
+    from flow_amd.networks.multi_ring import ADDITIONAL_NET_PARAMS
+    v = VehicleParams()
+    v.add("human", acceleration_controller=(IDMController, {}), num_vehicles=5)
+    for key in ADDITIONAL_NET_PARAMS:
+        with pytest.raises(KeyError):
+            MultiRingNetwork("m", v, NetParams(additional_params={k: x for k, x in ADDITIONAL_NET_PARAMS.items() if k != key}))
+    uneven = VehicleParams()
+    uneven.add("human_0", acceleration_controller=(IDMController, {}), num_vehicles=4)
+    uneven.add("rl_0", acceleration_controller=(RLController, {}), num_vehicles=1)
+    uneven.add("rl_1", acceleration_controller=(RLController, {}), num_vehicles=1)
+    uneven.add("human_1", acceleration_controller=(IDMController, {}), num_vehicles=4)
+    add = dict(ADDITIONAL_NET_PARAMS, num_rings=2)
+    env_params = EnvParams(additional_params={'max_accel': 1, 'max_decel': 1, 'ring_length': [230, 230],
+                                              'target_velocity': 4})
+    with pytest.raises(NotImplementedError, match="same vehicle types in the same order"):
+        MultiWaveAttenuationPOEnv(env_params, SumoParams(), MultiRingNetwork("m", uneven, NetParams(additional_params=add)))
+
+
+def test_lord_of_the_rings_example_file_runs_with_seven_rings():
+    import importlib
+    import os
+    import sys
+    import flow_amd
+    flow_amd.install_as_flow()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "examples"))
+    try:
+        mod = importlib.import_module("exp_configs.rl.lord_of_the_rings")
+    finally:
+        sys.path.pop(0)
+    from flow_amd.utils.registry import make_create_env
+    params = dict(mod.flow_params)
+    params["env"].warmup_steps = 30
+    env = make_create_env(params)[0]()
+    obs = env.reset()
+    assert len(obs) == 7 and env._spec["num_replicas"] == 7
+    for _ in range(20):
+        obs, rew, done, _ = env.step({rl: np.array([0.3]) for rl in obs})
+    assert len(rew) == 7 and all(0 <= r <= 1 for r in rew.values()) and not done["__all__"]
+    speeds = env.k.vehicle.get_speed(env.k.vehicle.get_ids())
+    assert len(speeds) == 154 and min(speeds) >= 0
+    env.terminate()
