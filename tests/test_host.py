@@ -407,6 +407,14 @@ def test_deprecated_module_paths_still_resolve_and_warn():
                      (BottleneckScenario, BottleneckNetwork)):
         assert issubclass(old, new) and old is not new
     assert issubclass(RingScenario, Scenario.__mro__[1])
+    from flow.envs.multiagent import AdversarialAccelEnv, MultiEnv, MultiWaveAttenuationPOEnv
+    from flow.multiagent_envs import AdversarialAccelEnv as OldAdv, MultiEnv as OldMulti
+    from flow.multiagent_envs.loop.wave_attenuation import MultiWaveAttenuationPOEnv as OldMW
+    from flow.networks import MultiRingNetwork
+    from flow.scenarios import MultiLoopScenario, MultiRingScenario
+    for old, new in ((OldAdv, AdversarialAccelEnv), (OldMulti, MultiEnv), (OldMW, MultiWaveAttenuationPOEnv),
+                     (MultiRingScenario, MultiRingNetwork), (MultiLoopScenario, MultiRingNetwork)):
+        assert issubclass(old, new) and old is not new
     vehicles = VehicleParams()
     vehicles.add("human", num_vehicles=3)
     with warnings.catch_warnings(record=True) as caught:
