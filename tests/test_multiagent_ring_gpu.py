@@ -225,3 +225,64 @@ def test_lord_of_the_rings_example_file_runs_with_seven_rings():
     speeds = env.k.vehicle.get_speed(env.k.vehicle.get_ids())
     assert len(speeds) == 154 and min(speeds) >= 0
     env.terminate()
+
+
+def fig8_vehicles(groups, noise=0.0):
+    """[(n_human, n_rl)] -> VehicleParams in the layout of examples/exp_configs/rl/multiagent/*figure_eight.py."""
+    from flow_amd.controllers import ContinuousRouter, IDMController, RLController
+    from flow_amd.core.params import SumoCarFollowingParams, VehicleParams
+    v = VehicleParams()
+    for i, (n_h, n_rl) in enumerate(groups):
+        tag = "_{}".format(i) if len(groups) > 1 else ""
+        v.add(veh_id="human" + tag, acceleration_controller=(IDMController, {"noise": noise}),
+              routing_controller=(ContinuousRouter, {}),
+              car_following_params=SumoCarFollowingParams(speed_mode="obey_safe_speed", decel=1.5), num_vehicles=n_h)
+        v.add(veh_id="rl" + tag, acceleration_controller=(RLController, {}), routing_controller=(ContinuousRouter, {}),
+              car_following_params=SumoCarFollowingParams(speed_mode="obey_safe_speed", accel=3, decel=3),
+              num_vehicles=n_rl)
+    return v
+
+
+def test_multiagent_envs_on_the_figure_eight_examples():
+    """multiagent_figure_eight.py (MultiAgentAccelPOEnv, 2 x (6 humans + 1 RL)) and adversarial_figure_eight.py
+    (AdversarialAccelEnv, 13 humans + 1 RL) on FigureEightNetwork: trajectories against the oracle, observation
+    formulas over that state."""
+    from flow_amd.core.params import EnvParams, InitialConfig, NetParams, SumoParams
+    from flow_amd.envs.multiagent import AdversarialAccelEnv, MultiAgentAccelPOEnv
+    from flow_amd.networks import FigureEightNetwork
+    from flow_amd.networks.figure_eight import ADDITIONAL_NET_PARAMS
+    add = {"target_velocity": 20, "max_accel": 3, "max_decel": 3, "sort_vehicles": False}
+    net = FigureEightNetwork("fig8", fig8_vehicles([(6, 1), (6, 1)]), NetParams(additional_params=dict(ADDITIONAL_NET_PARAMS)),
+                             InitialConfig())
+    env = MultiAgentAccelPOEnv(EnvParams(horizon=150, additional_params=add), SumoParams(sim_step=0.1), net)
+    ora = S.RingOracle(env._spec, np.float64)
+    obs = env.reset()
+    ora.reset()
+    assert sorted(obs) == ["rl_0_0", "rl_1_0"] and env.observation_space.shape == (6,)
+    rng = np.random.default_rng(3)
+    for k in range(150):
+        acts = {rl: np.array([rng.uniform(-3, 3)]) for rl in obs}
+        obs, rew, done, _ = env.step(acts)
+        ora.step(np.array([[float(acts["rl_0_0"][0]), float(acts["rl_1_0"][0])]]))
+    ids = env.k.vehicle.get_ids()
+    np.testing.assert_allclose(env.k.vehicle.get_speed(ids), ora.v[0], rtol=0, atol=2e-4)
+    for rl, i in (("rl_0_0", 6), ("rl_1_0", 13)):
+        assert abs(obs[rl][1] - ora.v[0][i] / env.k.network.max_speed()) < 2e-5
+    assert set(rew) == {"rl_0_0", "rl_1_0"} and done["__all__"]
+    env.terminate()
+
+    net = FigureEightNetwork("fig8", fig8_vehicles([(13, 1)]), NetParams(additional_params=dict(ADDITIONAL_NET_PARAMS)),
+                             InitialConfig())
+    env = AdversarialAccelEnv(EnvParams(horizon=100, additional_params=dict(add, perturb_weight=0.03)),
+                              SumoParams(sim_step=0.1), net)
+    ora = S.RingOracle(env._spec, np.float64)
+    obs = env.reset()
+    ora.reset()
+    assert sorted(obs) == ["adversary", "av"] and obs["av"].shape == (28,)
+    for k in range(100):
+        av, adv = rng.uniform(-3, 3, 1), rng.uniform(-3, 3, 1)
+        obs, rew, done, _ = env.step({"av": av, "adversary": adv})
+        ora.step(np.array([np.float32(av + 0.03 * adv)]))
+    np.testing.assert_allclose(obs["av"][0::2], ora.v[0] / env.k.network.max_speed(), rtol=0, atol=2e-5)
+    assert rew["av"] == -rew["adversary"] and 0 < rew["av"] < 1
+    env.terminate()
