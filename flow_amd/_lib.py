@@ -98,7 +98,7 @@ class fs_config(C.Structure):
                 ("zipper_distance", C.c_double), ("speed_limit", C.c_double), ("outflow_norm", C.c_double),
                 ("obs_cells", C.POINTER(fs_cell)), ("act_cells", C.POINTER(fs_cell)),
                 ("obs_outflow_window", C.c_int32), ("reward_outflow_window", C.c_int32),
-                ("track_followers", C.c_int32), ("reserved4", C.c_int32),
+                ("track_followers", C.c_int32), ("num_paths", C.c_int32),
                 ("lane_change_cooldown_steps", C.c_int32), ("reserved6", C.c_int32), ("lane_change_min_gain", C.c_double),
                 ("sort_vehicles", C.c_int32),
                 ("reserved5", C.c_int32), ("obs_perm", C.POINTER(C.c_int32)), ("replica_offset", C.c_int64)]

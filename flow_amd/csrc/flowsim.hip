@@ -480,13 +480,15 @@ struct Sim : SimBase {
   template <int W>
   int launch_wide(int num_steps, const uint8_t* mask, const float* actions, size_t act_stride, float* obs,
                   float* rew, uint8_t* done, int obs_every_step) {
-    if (std::is_same<T, float>::value && (dv.flags & fs::FLAG_IDM_SET) && !force_generic)
-      hipLaunchKernelGGL((fs::k_steps_wide<T, W, (std::is_same<T, float>::value ? 1 : 0)>), dim3(dv.R), dim3(64 * W), 0,
-                         stream, dv, ov, num_steps, mask, actions, act_stride, obs, rew, done, obs_every_step,
-                         after_reset);
-    else
-      hipLaunchKernelGGL((fs::k_steps_wide<T, W, 0>), dim3(dv.R), dim3(64 * W), 0, stream, dv, ov, num_steps, mask,
-                         actions, act_stride, obs, rew, done, obs_every_step, after_reset);
+    // float32 exists twice (CSET = 1: IDM / RL / Sim slots only); num_paths = 8 is the scaling-2 network
+    constexpr int C1 = std::is_same<T, float>::value ? 1 : 0;
+    const bool cset = C1 == 1 && (dv.flags & fs::FLAG_IDM_SET) && !force_generic;
+#define FS_WIDE(P_, C_)                                                                                          \
+  hipLaunchKernelGGL((fs::k_steps_wide<T, W, C_, P_>), dim3(dv.R), dim3(64 * W), 0, stream, dv, ov, num_steps, mask, \
+                     actions, act_stride, obs, rew, done, obs_every_step, after_reset)
+    if (cfg.num_paths == 8) { if (cset) FS_WIDE(8, C1); else FS_WIDE(8, 0); }
+    else { if (cset) FS_WIDE(4, C1); else FS_WIDE(4, 0); }
+#undef FS_WIDE
     HIP_TRY(hipGetLastError());
     return FS_OK;
   }
@@ -749,9 +751,15 @@ int validate(const fs_config* c) {
         c->reward_outflow_window > 20)
       return fail(FS_ERR_INVALID, "fs_create: outflow windows must be 1..20 sub-steps");
     if (c->evaluate) return fail(FS_ERR_UNSUPPORTED, "fs_create: evaluate mode of the bottleneck envs is not built");
+    if (c->num_paths != 0 && c->num_paths != 4 && c->num_paths != 8)
+      return fail(FS_ERR_UNSUPPORTED, "fs_create: num_paths (4 * scaling) must be 4 or 8");
+    if (c->num_paths == 8 && c->num_vehicles <= 64)
+      return fail(FS_ERR_UNSUPPORTED, "fs_create: num_paths = 8 (scaling 2) is built in the workgroup-per-replica kernel: "
+                                      "more than 64 vehicle slots per replica");
     if (c->env == FS_ENV_BOTTLENECK_DV) {
-      if (c->num_obs_cells < 1 || c->num_obs_cells > 64 || !c->obs_cells)
-        return fail(FS_ERR_INVALID, "fs_create: 1..64 observation cells");
+      const int max_cells = c->num_vehicles > 64 ? 128 : 64;
+      if (c->num_obs_cells < 1 || c->num_obs_cells > max_cells || !c->obs_cells)
+        return fail(FS_ERR_INVALID, "fs_create: 1..64 observation cells (1..128 with more than 64 vehicle slots)");
       for (int k = 0; k < c->num_obs_cells; ++k)
         if (c->obs_cells[k].lane < 0 || c->obs_cells[k].lane > 63) return fail(FS_ERR_INVALID, "fs_create: cell lane");
       for (int k = 0; k < c->num_rl; ++k)
@@ -782,7 +790,8 @@ int validate(const fs_config* c) {
       return fail(FS_ERR_INVALID, "fs_create: bad inflow table");
     for (int f = 0; f < c->num_inflows; ++f) {
       const fs_inflow& fl = c->inflows[f];
-      if (c->network == FS_NET_MERGE ? (fl.route < 0 || fl.route > 1) : (fl.route < -1 || fl.route > 3))
+      if (c->network == FS_NET_MERGE ? (fl.route < 0 || fl.route > 1)
+                                     : (fl.route < -1 || fl.route > (c->num_paths == 8 ? 7 : 3)))
         return fail(FS_ERR_INVALID, "fs_create: inflow route out of range");
       if (!(fl.period > 0)) return fail(FS_ERR_INVALID, "fs_create: inflow period <= 0");
       if (!(fl.depart_speed >= 0) || !(fl.depart_pos >= 0)) return fail(FS_ERR_INVALID, "fs_create: bad inflow departure");
@@ -871,7 +880,7 @@ int validate(const fs_config* c) {
     for (size_t e = 0; e < size_t(c->num_replicas) * c->num_vehicles; ++e) {
       if (!c->init_alive[e]) continue;
       const int rt = c->init_lane[e];
-      if (rt < 0 || rt > (c->network == FS_NET_MERGE ? 1 : 3))
+      if (rt < 0 || rt > (c->network == FS_NET_MERGE ? 1 : (c->num_paths == 8 ? 7 : 3)))
         return fail(FS_ERR_INVALID, "fs_create: initial route out of range");
       const double x = c->init_pos[e];
       if (!(x >= c->route_start[c->network == FS_NET_MERGE ? rt : 0]) || !(x < c->end_x))

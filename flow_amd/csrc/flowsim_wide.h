@@ -29,11 +29,11 @@ struct WideLds {
   int sorted_slot[NS];          // [rank] -> slot
   int skey[NS];                 // [rank] -> path | joins << 8, 0xffff for a free slot
   unsigned long long okey[sizeof(T) == 4 ? NS : 1];   // float32: the 64-bit ordering key of slot j
-  unsigned long long rmask[6][W];        // masks over RANKS: path 0..3, passed the first / the second join
+  unsigned long long rmask[10][W];       // masks over RANKS: path 0..P-1 (P <= 8), then passed the first / the second join
   unsigned long long words[2][2][W];
   T red_t[2][4][W];
   int red_i[2][4][W];
-  unsigned long long cell[2][64][W];     // observation cells: [human | rl][cell][wave] = members in that wave
+  unsigned long long cell[2][128][W];    // observation cells: [human | rl][cell][wave] = members in that wave
   // launch constants (flowsim_open.h keeps them in lane-indexed VGPRs and reads them with v_readlane; here they
   // are read from LDS with a uniform address, which holds under any EXEC mask and costs no registers)
   T tab[TAB_ROWS][64];
@@ -66,14 +66,14 @@ __device__ __forceinline__ void route_lookup_lds(const OpenView<T>& o, const Wid
 __device__ __forceinline__ int first_bit(unsigned long long m) { return __ffsll((long long)m) - 1; }
 __device__ __forceinline__ int last_bit(unsigned long long m) { return 63 - __clzll((long long)m); }
 
-template <typename T, int W, int CSET = 0>
+// P = entry lanes of the lane-drop network: 4 (4 -> 2 -> 1 lanes) or 8 (scaling 2: 8 -> 4 -> 2)
+template <typename T, int W, int CSET = 0, int P = 4>
 __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T> o, int num_steps,
                                                        const uint8_t* __restrict__ mask,
                                                        const float* __restrict__ actions, size_t act_stride,
                                                        float* __restrict__ obs, float* __restrict__ rew,
                                                        uint8_t* __restrict__ done, int obs_every_step,
                                                        int after_reset) {
-  constexpr int P = 4;
   constexpr int NS = 64 * W;
   using ull = unsigned long long;
   __shared__ WideLds<T, W> L;
@@ -219,16 +219,21 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
     __syncthreads();
     // the masks stay in LDS (written again two barriers into the next call) and are fetched word by word
     auto Bw = [&](int q, int ww) -> ull { return L.rmask[q][ww]; };
-    auto ALLw = [&](int ww) -> ull { return L.rmask[0][ww] | L.rmask[1][ww] | L.rmask[2][ww] | L.rmask[3][ww]; };
-    auto pathw = [&](int p, int ww) -> ull { return L.rmask[p & 3][ww]; };                  // lanes of path p
-    auto pairw = [&](int p, int ww) -> ull { return L.rmask[p & 2][ww] | L.rmask[(p & 2) | 1][ww]; };
-    // vehicles on "my lane" of those ahead, word ww: see k_steps_open (M5 / M8)
+    // lanes of path p / of the pair p joins first / of the four paths that share p's lane after both joins
+    auto pathw = [&](int p, int ww) -> ull { return L.rmask[p & (P - 1)][ww]; };
+    auto pairw = [&](int p, int ww) -> ull { return L.rmask[p & (P - 2)][ww] | L.rmask[(p & (P - 2)) | 1][ww]; };
+    auto quadw = [&](int p, int ww) -> ull {
+      const int q0 = p & (P - 4);
+      return L.rmask[q0][ww] | L.rmask[q0 + 1][ww] | L.rmask[q0 + 2][ww] | L.rmask[q0 + 3][ww];
+    };
+    // vehicles on "my lane" of those ahead, word ww: see k_steps_open (M5 / M8); a vehicle that has passed j joins
+    // shares my lane if our paths agree after max(j, la) joins
     auto cand_w = [&](int p, int la_, int ww) -> ull {
-      const ull R1 = L.rmask[P][ww], R2 = L.rmask[P + 1][ww], ALL = ALLw(ww);
+      const ull R1 = L.rmask[P][ww], R2 = L.rmask[P + 1][ww], G2 = quadw(p, ww);
       const ull pr = pairw(p, ww);
-      const ull c0 = la_ == 0 ? pathw(p, ww) : (la_ == 1 ? pr : ALL);
-      const ull c1 = la_ <= 1 ? pr : ALL;
-      return (~R1 & c0) | (R1 & ~R2 & c1) | (R2 & ALL);
+      const ull c0 = la_ == 0 ? pathw(p, ww) : (la_ == 1 ? pr : G2);
+      const ull c1 = la_ <= 1 ? pr : G2;
+      return (~R1 & c0) | (R1 & ~R2 & c1) | (R2 & G2);
     };
     const int rw = rank >> 6, rb = rank & 63;
     auto above_w = [&](int ww) -> ull { return ww < rw ? 0ull : (ww > rw ? ~0ull : (rb == 63 ? 0ull : (~0ull << (rb + 1)))); };
@@ -378,12 +383,13 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
     }
     // ... then thread c collects cell c: who is in it (one ballot per wave, cell and class), their speeds in slot order
     const int C = o.n_obs_cells;
-    __syncthreads();
     for (int c = 0; c < C; ++c) {
       const ull bh = __ballot(ocell == c && !is_rl);
       const ull br = __ballot(ocell == c && is_rl);
-      L.cell[0][c][w] = bh;
-      L.cell[1][c][w] = br;
+      if (l == 0) {
+        L.cell[0][c][w] = bh;
+        L.cell[1][c][w] = br;
+      }
     }
     __syncthreads();
     if (tid < C) {

@@ -255,8 +255,8 @@ class BottleneckDesiredVelocityEnv(BottleneckEnv):
                                       "pairs them with EDGE_LIST by position)")
         obs = cells(self.obs_segments)
         act = cells([(e, n) for e, n, c in self.segments if c])
-        if len(obs) > 64 or len(act) > 64:
-            raise NotImplementedError("more than 64 observed / controlled lane-segments is not built")
+        if len(obs) > 128 or len(act) > 64:
+            raise NotImplementedError("more than 128 observed / 64 controlled lane-segments is not built")
         return obs, act
 
     @property

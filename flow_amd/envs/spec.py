@@ -129,8 +129,8 @@ def build_open_spec(env, num_replicas, rng=None):
     lane_drop = network.specify_lane_joins() is not None          # BottleneckNetwork
     if int(ap.get("merge_lanes", 1)) != 1 or int(ap.get("highway_lanes", 1)) != 1:
         raise NotImplementedError("multi-lane merge networks are not built in the HIP step loop yet")
-    if lane_drop and int(ap.get("scaling", 1)) != 1:
-        raise NotImplementedError("BottleneckNetwork with scaling > 1 is not built (4 -> 2 -> 1 lanes only)")
+    if lane_drop and int(ap.get("scaling", 1)) not in (1, 2):
+        raise NotImplementedError("BottleneckNetwork is built for scaling 1 (4 -> 2 -> 1 lanes) and 2 (8 -> 4 -> 2)")
     tables = net_k.open_tables()
     R = int(num_replicas)
     flows = network.net_params.inflows.get()
@@ -148,6 +148,9 @@ def build_open_spec(env, num_replicas, rng=None):
     n_max = 256 if lane_drop else 64       # FS_MAX_SLOTS_WIDE: k_steps_wide runs a replica on up to four waves
     if N < 1 or N > n_max:
         raise NotImplementedError("this network holds 1..%d vehicle slots per replica (got %d)" % (n_max, N))
+    if lane_drop and int(ap.get("scaling", 1)) == 2 and N <= 64:
+        raise NotImplementedError("BottleneckNetwork with scaling 2 runs on the workgroup-per-replica kernel: set "
+                                  "SumoParams(max_vehicles=...) above 64 (its demand needs that many slots anyway)")
     slots, base, n_rl_slots = [], {}, 0
     for t, (name, cap) in enumerate(zip(names, caps)):
         base[name] = len(slots)

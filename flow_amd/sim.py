@@ -175,7 +175,8 @@ class FlowSim:
             outflow_norm=2000.0 * float(spec.get("scaling", 1)), obs_cells=obs_cells, act_cells=act_cells,
             obs_outflow_window=int(spec.get("obs_outflow_window", 20)),
             reward_outflow_window=int(spec.get("reward_outflow_window", 10)),
-            track_followers=int(bool(spec.get("track_followers", True))), reserved4=0,
+            track_followers=int(bool(spec.get("track_followers", True))),
+            num_paths=int(spec.get("num_paths", 0)) if spec.get("network") == "bottleneck" else 0,
             lane_change_cooldown_steps=int(spec.get("lane_change_cooldown_steps", 10)), reserved6=0,
             lane_change_min_gain=float(spec.get("lane_change_min_gain", 10.0)),
             sort_vehicles=int(bool(spec.get("sort_vehicles", False))), reserved5=0,

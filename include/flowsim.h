@@ -85,9 +85,10 @@ enum fs_network {
   FS_NET_MERGE = 2,         /* MergeNetwork, flow/networks/merge.py: an OPEN one-lane network, two routes (0 = highway,
                                1 = on-ramp) converging at a priority junction; vehicles enter through fs_config.inflows
                                and leave at end_x.  num_vehicles is the slot CAPACITY of a replica. */
-  FS_NET_BOTTLENECK = 3     /* BottleneckNetwork, flow/networks/bottleneck.py (scaling 1): an OPEN network of four entry
-                               lanes that join pairwise at two zipper junctions (4 -> 2 -> 1); nobody changes lane
-                               (lane_change_mode 0), a vehicle's "route" is its entry lane 0..3 */
+  FS_NET_BOTTLENECK = 3     /* BottleneckNetwork, flow/networks/bottleneck.py (scaling 1 or 2): an OPEN network of
+                               num_paths = 4 * scaling entry lanes that join pairwise at two zipper junctions
+                               (4 -> 2 -> 1, or 8 -> 4 -> 2); a vehicle's "route" is the entry lane it continues,
+                               0..num_paths-1 (the simplified lane changing of M11 moves it to a neighbouring one) */
 };
 
 enum fs_integrator { FS_EULER = 0, FS_BALLISTIC = 1 /* SumoParams.use_ballistic, core/params.py:578-602 */ };
@@ -253,7 +254,8 @@ typedef struct fs_config {
   double net_length;                  /* k.network.length(): the normaliser of MergePOEnv.get_state */
   int32_t ma_apply_actions;           /* FS_ENV_MERGE_MA: 0 = actions are never applied, as this fork ships
                                          (multiagent/merge.py:92-96); 1 = column rl_index commands the slot, NaN = none */
-  int32_t num_obs_cells;              /* FS_ENV_BOTTLENECK_DV: observed lane-segments (<= 64), obs_dim = 4 * cells + 1 */
+  int32_t num_obs_cells;              /* FS_ENV_BOTTLENECK_DV: observed lane-segments (<= 64; <= 128 with num_vehicles > 64),
+                                         obs_dim = 4 * cells + 1 */
   /* ---- FS_NET_BOTTLENECK ---- */
   double merge1_x, merge2_x;          /* coordinates where lanes (2q, 2q+1) join / where the two resulting lanes join */
   double zipper_distance;             /* a vehicle this close to a join follows the nearest vehicle of either joining lane */
@@ -265,7 +267,8 @@ typedef struct fs_config {
   int32_t reward_outflow_window;      /* int(10 * sim_step / sim_step) */
   int32_t track_followers;            /* open networks: 1 = keep the sticky follower entries (FS_FIELD_FOLLOWER, used by the
                                          merge observations and BCM); 0 = skip them (the bottleneck envs never read them) */
-  int32_t reserved4;
+  int32_t num_paths;                  /* FS_NET_BOTTLENECK: entry lanes = 4 * scaling: 4 (0 = 4) or 8 (8 -> 4 -> 2 lanes;
+                                         needs num_vehicles > 64, i.e. the workgroup-per-replica kernel) */
   /* ---- simplified lane changing on FS_NET_BOTTLENECK ---- */
   int32_t lane_change_cooldown_steps; /* sub-steps a vehicle keeps its lane after a change */
   int32_t reserved6;

@@ -181,9 +181,9 @@ def bottleneck_tables(junction_length=0.1, zipper_length=20.0, scaling=1):
             (s3, 0, 405.0, 1.0), (s3 + e[2], 1, -1001.0, 0.0), (s4, 0, 425.0, 1.0), (s4 + e[3], 1, -1001.0, 0.0),
             (s5, 0, 580.0, 1.0)]
     starts = dict(zip("12345", [s1, s2, s3, s4, s5]))
-    lanes = dict(zip("12345", [4, 4, 4, 2, 1]))
+    lanes = dict(zip("12345", [4 * scaling, 4 * scaling, 4 * scaling, 2 * scaling, scaling]))
     lengths = dict(zip("12345", e))
-    return dict(routes=[dict(start=0.0, segments=segs)], num_paths=4, merge1_x=s4, merge2_x=s5, merge_x=s5,
+    return dict(routes=[dict(start=0.0, segments=segs)], num_paths=4 * scaling, merge1_x=s4, merge2_x=s5, merge_x=s5,
                 box_in=s5 - z, end_x=end, net_length=sum(e) + 2 * j + 2 * z + 1.0,   # + the 1 m rendering-only fake_edge
                 edge_start=starts, edge_lanes=lanes, edge_length=lengths)
 
@@ -201,11 +201,11 @@ def segment_cells(tb, segments):
 
 
 def bottleneck_spec(R=4, cap_human=40, cap_rl=8, horizon=300, seed=0, q=2300.0, av_frac=0.1, env=None,
-                    zipper_distance=50.0, warmup_steps=0, **kw):
+                    zipper_distance=50.0, warmup_steps=0, scaling=1, **kw):
     """singleagent_bottleneck.py: humans and RL vehicles all driven by the SUMO car-following model, inflow on
     edge 1 with departLane='random', BottleneckDesiredVelocityEnv head (141 observations, 20 actions)."""
     from oracle import opennet as O
-    tb = bottleneck_tables()
+    tb = bottleneck_tables(scaling=scaling)
     N = cap_human + cap_rl
     veh = [idm_vehicle(controller=S.CTRL_SIM, speed_mode=31, type=0) for _ in range(cap_human)] + \
           [idm_vehicle(controller=S.CTRL_RL, rl_index=k, speed_mode=9, type=1) for k in range(cap_rl)]
@@ -222,7 +222,7 @@ def bottleneck_spec(R=4, cap_human=40, cap_rl=8, horizon=300, seed=0, q=2300.0, 
                 env=O.ENV_BOTTLENECK_DV if env is None else env, target_velocity=40.0, action_low=-1.5, action_high=1.5,
                 horizon=horizon, warmup_steps=warmup_steps, sims_per_step=1, vehicles=veh, seed=seed,
                 junction=dict(enabled=0, lookahead=0.0, time_gap=1.0), junction_mode=1, speed_limit=23.0,
-                zipper_distance=zipper_distance, scaling=1, obs_cells=obs_cells, action_cells=act_cells,
+                zipper_distance=zipper_distance, scaling=scaling, obs_cells=obs_cells, action_cells=act_cells,
                 obs_outflow_window=20, reward_outflow_window=10, track_followers=False,
                 inflows=[dict(type=0, route=-1, period=3600.0 / (q * (1 - av_frac)), begin=1.0, end=86400.0, number=-1,
                               depart_speed=10.0, depart_pos=5.0),

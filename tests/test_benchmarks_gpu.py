@@ -1,7 +1,7 @@
 """The reference's benchmark configurations that fall on the built path (flow/benchmarks/{figureeight0-2, merge0-2,
-bottleneck0-1}.py; their flow_params restated here from those files): each is constructed through make_create_env,
+bottleneck0-2}.py; their flow_params restated here from those files): each is constructed through make_create_env,
 stepped with random actions and compared with the oracle run on the env's own spec.  bottleneck2 (scaling = 2:
-8 -> 4 -> 2 lanes) is not built and must say so at construction."""
+8 -> 4 -> 2 lanes) needs more than 64 vehicle slots per replica (SumoParams(max_vehicles=...))."""
 import numpy as np
 import pytest
 
@@ -169,6 +169,27 @@ def test_bottleneck_benchmarks(k, slots):
     env.terminate()
 
 
-def test_bottleneck2_scaling_two_is_refused_at_construction():
-    with pytest.raises(NotImplementedError, match="scaling"):
-        make_env(bottleneck_benchmark(2))
+def test_bottleneck2_benchmark_scaling_two():
+    with pytest.raises(NotImplementedError, match="above 64"):
+        make_env(bottleneck_benchmark(2))                                  # the default pool of 64 slots
+    env = make_env(bottleneck_benchmark(2, max_vehicles=256))
+    assert env.observation_space.shape == (4 * 70 + 1,) and env.action_space.shape == (40,)
+    assert env._spec["num_paths"] == 8 and env._spec["scaling"] == 2
+    ora = O.MergeOracle(env._spec, np.float32)
+    np.testing.assert_array_equal(env.reset(), ora.reset()[0].astype(np.float32))
+    rng = np.random.default_rng(22)
+    for _ in range(400):
+        a = rng.uniform(-1.5, 1.5, 40).astype(np.float32)
+        obs, rew, done, _ = env.step(a)
+        o_ref, r_ref, d_ref = ora.step(a[None, :])
+        np.testing.assert_array_equal(obs, o_ref[0].astype(np.float32))
+        assert rew == np.float32(r_ref[0]) and done == bool(d_ref[0])
+    veh = env.k.vehicle
+    ids = veh.get_ids()
+    assert len(ids) == int(ora.alive[0].sum()) > 60
+    lanes = {e: set() for e in "12345"}
+    for v in ids:
+        if veh.get_edge(v) in lanes:
+            lanes[veh.get_edge(v)].add(veh.get_lane(v))
+    assert max(lanes["2"]) >= 6 and max(lanes["4"]) <= 3 and max(lanes["5"] | {0}) <= 1
+    env.terminate()

@@ -473,6 +473,32 @@ def test_bottleneck_config_validation_needs_no_gpu():
         FlowSim(bottleneck_spec(R=1, cap_human=250, cap_rl=7), "f32")
     with pytest.raises(NotImplementedError, match="FS_NET_BOTTLENECK only"):
         FlowSim(merge_spec(R=1, cap_human=60, cap_rl=6, num_rl=2), "f32")
+    with pytest.raises(NotImplementedError, match="more than 64 vehicle slots"):    # scaling 2: the wide kernel only
+        FlowSim(bottleneck_spec(R=1, cap_human=50, cap_rl=10, scaling=2), "f32")
+    with pytest.raises(NotImplementedError, match="must be 4 or 8"):
+        FlowSim(bottleneck_spec(R=1, cap_human=100, cap_rl=10, num_paths=12), "f32")
+
+
+def test_scaling_two_oracle_facts():
+    """BottleneckNetwork scaling 2: eight entry lanes join to four, then to two; lane = path >> joins passed."""
+    from helpers import bottleneck_spec
+    spec = bottleneck_spec(R=1, cap_human=120, cap_rl=20, horizon=250, seed=3, q=4000.0, scaling=2)
+    assert spec["num_paths"] == 8 and len(spec["obs_cells"]) == 70 and len(spec["action_cells"]) == 40
+    ora = O.MergeOracle(spec, np.float32)
+    ora.reset()
+    for k in range(250):
+        obs, rew, done = ora.step(None)
+        np.testing.assert_array_equal(ora.alive.sum(axis=1) + ora.total_arrived, 2 + ora.total_departed)
+    a = ora.alive[0]
+    x, p = ora.x[0][a], ora.route[0][a]
+    assert set(p) == set(range(8)) and obs.shape == (1, 281)
+    lane = p >> ((x >= spec["merge1_x"]).astype(int) + (x >= spec["merge2_x"]).astype(int))
+    assert lane[x >= spec["merge2_x"]].max() <= 1 and lane[(x >= spec["merge1_x"]) & (x < spec["merge2_x"])].max() <= 3
+    # nobody overlaps its leader on its own physical lane
+    for i in np.nonzero(a)[0]:
+        j = ora.lead[0][i]
+        if j >= 0 and ora.lead_same_lane[0][i]:
+            assert ora.x[0][j] - ora.x[0][i] - 5.0 > -1e-3
 
 
 def test_wide_oracle_runs_beyond_64_slots_and_the_queue_outgrows_one_wave():
