@@ -178,7 +178,7 @@ def test_bottleneck2_benchmark_scaling_two():
     ora = O.MergeOracle(env._spec, np.float32)
     np.testing.assert_array_equal(env.reset(), ora.reset()[0].astype(np.float32))
     rng = np.random.default_rng(22)
-    for _ in range(400):
+    for _ in range(250):
         a = rng.uniform(-1.5, 1.5, 40).astype(np.float32)
         obs, rew, done, _ = env.step(a)
         o_ref, r_ref, d_ref = ora.step(a[None, :])

@@ -191,20 +191,20 @@ def test_wide_scaling_two_eight_entry_lanes():
     lane-segments, twice the demand; num_paths = 8 in the workgroup-per-replica kernel."""
     from flow_amd import _lib as L
     from helpers import bottleneck_spec
-    spec = bottleneck_spec(R=2, cap_human=200, cap_rl=40, horizon=500, seed=6, q=4000.0, scaling=2)
+    spec = bottleneck_spec(R=1, cap_human=200, cap_rl=40, horizon=400, seed=6, q=4000.0, scaling=2)
     assert spec["num_paths"] == 8 and len(spec["obs_cells"]) == 70 and spec["num_rl"] == 40
-    ora = run_pair(spec, "f32", 500, bottleneck_actions(spec, 3), check_every=50)
+    ora = run_pair(spec, "f32", 400, bottleneck_actions(spec, 3), check_every=50)
     alive = ora.alive[0]
     assert set(ora.route[0][alive]) == set(range(8))                       # every entry lane is in use
     assert set((ora.route[0][alive & (ora.x[0] > spec["merge2_x"])] >> 2)) == {0, 1}    # two lanes leave the network
-    assert ora.total_arrived.min() > 150
+    assert ora.total_arrived.min() > 100
     # with the simplified lane changing, in float64 and on two waves
     spec = bottleneck_spec(R=2, cap_human=100, cap_rl=20, horizon=300, seed=8, q=4000.0, scaling=2,
                            lane_change_cooldown_steps=8, lane_change_min_gain=8.0)
     for v in spec["vehicles"][:100]:
         v["lane_change_mode"] = 1621
-    ora = run_pair(spec, "f32", 300, bottleneck_actions(spec, 5), check_every=50)
+    ora = run_pair(spec, "f32", 250, bottleneck_actions(spec, 5), check_every=50)
     assert (ora.num_lane_changes > 20).all()
-    run_pair(spec, "f64", 200, bottleneck_actions(spec, 5), check_every=50, exact=False, atol=1e-9)
+    run_pair(spec, "f64", 120, bottleneck_actions(spec, 5), check_every=40, exact=False, atol=1e-9)
     with pytest.raises(NotImplementedError, match="more than 64 vehicle slots"):
         make(bottleneck_spec(R=1, cap_human=50, cap_rl=10, scaling=2), "f32")
