@@ -825,10 +825,12 @@ int validate(const fs_config* c) {
   if (c->num_replicas < 1) return fail(FS_ERR_INVALID, "fs_create: num_replicas < 1");
   if (c->replica_offset < 0) return fail(FS_ERR_INVALID, "fs_create: replica_offset < 0");
   if (c->sort_vehicles || c->obs_perm) {
-    if (c->env != FS_ENV_ACCEL && c->sort_vehicles)
-      return fail(FS_ERR_INVALID, "fs_create: sort_vehicles belongs to AccelEnv");
-    if (c->num_lanes > 1 || c->network == FS_NET_MERGE || c->network == FS_NET_BOTTLENECK)
-      return fail(FS_ERR_UNSUPPORTED, "fs_create: sort_vehicles / shuffled ids are built for single-lane closed loops");
+    if (c->env != FS_ENV_ACCEL && c->env != FS_ENV_LANE_CHANGE_ACCEL && c->sort_vehicles)
+      return fail(FS_ERR_INVALID, "fs_create: sort_vehicles belongs to AccelEnv / LaneChangeAccelEnv");
+    if (c->network == FS_NET_MERGE || c->network == FS_NET_BOTTLENECK || (c->num_lanes > 1 && c->obs_perm) ||
+        (c->num_lanes > 1 && c->env != FS_ENV_LANE_CHANGE_ACCEL))
+      return fail(FS_ERR_UNSUPPORTED, "fs_create: sort_vehicles is built for closed loops (single-lane AccelEnv, "
+                                      "LaneChangeAccelEnv); shuffled ids for single-lane closed loops");
     if (c->obs_perm) {
       unsigned long long seen = 0ull;
       for (int i = 0; i < c->num_vehicles && i < 64; ++i) {

@@ -1213,6 +1213,21 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
   T prev_v = v, last_acc = T(0);
   T cst = (flags & FLAG_HAS_LAC) ? s.ctrl_state[idx] : T(0);
   if (s.track_aux) { prev_v = s.prev_vel[idx]; last_acc = s.accel[idx]; }
+  // sort_vehicles (LaneChangeAccelEnv, lane_change_accel.py:100-139 through AccelEnv.sorted_ids): as in k_steps the
+  // vehicles are ordered by the position recorded at the last additional_command, ties in id order
+  const bool sorted = s.sort_vehicles != 0;
+  T xs = sorted ? s.sort_key[idx] : T(0);
+  auto order_rank = [&](bool rl_only) -> int {
+    int rk = 0;
+    const int me_rl = (sl.ctrl == FS_CTRL_RL) ? 1 : 0;
+    for (int j = 0; j < N; ++j) {
+      const T xj = seg_read<SEG>(xs, j, seg);
+      const int rlj = seg_read_i<SEG>(me_rl, j, seg);
+      const bool before = (xj < xs) || (xj == xs && j < ii);
+      if (before && (!rl_only || rlj != 0)) rk += 1;
+    }
+    return rk;
+  };
 
   const T dt = s.dt;
   const int obs_dim = lc_env ? 3 * N : ((s.env == FS_ENV_WAVE_ATTENUATION_PO) ? 3 : 2 * N);
@@ -1271,12 +1286,15 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
       }
       if (flags & FLAG_NEED_MEAN) mean_v = seg_sum<SEG>(valid ? v : T(0)) / T(N);
       const bool have_rl = (sl.ctrl == FS_CTRL_RL) && (act != nullptr);
-      const int acol = (sl.rl_index < 0 ? 0 : sl.rl_index) * (lc_env ? 2 : 1);
+      // sort_vehicles (lane_change_accel.py:137-139): the k-th RL vehicle in sorted order takes action pair k
+      const int rl_place = (sorted && act != nullptr) ? order_rank(true) : (sl.rl_index < 0 ? 0 : sl.rl_index);
+      const int acol = rl_place * (lc_env ? 2 : 1);
       T a_rl = have_rl ? T(act[acol]) : T(0);
       bool commanded = false;
       T xa_unused;
       T acc = control_accel(s, segtab, sl, flags, v, vl, h, has, vf, hf, mean_v, x, quarter, qj, have_rl, a_rl,
                             live && i < N, rr, ii, nctr, cst, commanded, xa_unused);
+      if (sorted && live) xs = x;                    // accel.py:150-169 additional_command: the position before the move
       // ---- RL lane-change command (ML3) -----------------------------------
       int new_ln = ln;
       if (lc_env && have_rl) {
@@ -1337,11 +1355,12 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
 
     const bool emit = obs_every_step || (step == num_steps - 1);
     if (emit) {
+      const int oi = sorted ? order_rank(false) : ii;
       if (lc_env) {                                                  // lane_change_accel.py:100-117
         if (valid) {
-          orow[ii] = float(v / s.max_speed);
-          orow[N + ii] = float(x / L);
-          orow[2 * N + ii] = float(T(ln) / T(s.num_lanes));
+          orow[oi] = float(v / s.max_speed);
+          orow[N + oi] = float(x / L);
+          orow[2 * N + oi] = float(T(ln) / T(s.num_lanes));
         }
       } else if (s.env == FS_ENV_WAVE_ATTENUATION_PO) {
         if (valid && sl.ctrl == FS_CTRL_RL && sl.rl_index == 0) {
@@ -1400,11 +1419,12 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
   }
 
   if (num_steps == 0) {
+    const int oi = sorted ? order_rank(false) : ii;
     if (lc_env) {
       if (valid) {
-        orow[ii] = float(v / s.max_speed);
-        orow[N + ii] = float(x / L);
-        orow[2 * N + ii] = float(T(ln) / T(s.num_lanes));
+        orow[oi] = float(v / s.max_speed);
+        orow[N + oi] = float(x / L);
+        orow[2 * N + oi] = float(T(ln) / T(s.num_lanes));
       }
     } else if (s.env == FS_ENV_WAVE_ATTENUATION_PO) {
       if (valid && sl.ctrl == FS_CTRL_RL && sl.rl_index == 0) {
@@ -1424,6 +1444,7 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
     s.vel[idx] = v;
     s.lane[idx] = ln;
     s.last_lc[idx] = last_lc;
+    if (sorted) s.sort_key[idx] = xs;
     if (flags & FLAG_HAS_LAC) s.ctrl_state[idx] = cst;
     if (s.track_aux) { s.prev_vel[idx] = prev_v; s.accel[idx] = last_acc; }
     if (ii == 0) {

@@ -57,6 +57,9 @@ class LaneChangeAccelEnv(AccelEnv):
         self.k.vehicle.apply_acceleration(sorted_rl_ids, acc=acceleration)
         self.k.vehicle.apply_lane_change(sorted_rl_ids, direction=[int(d) if float(d).is_integer() else d
                                                                    for d in direction])
+        if self.env_params.additional_params['sort_vehicles']:
+            # pair k commands the k-th RL vehicle in sorted order: the kernel resolves that order itself
+            self._sorted_actions = actions.astype(np.float32).reshape(1, -1)
 
 
 class LaneChangeAccelPOEnv(LaneChangeAccelEnv):

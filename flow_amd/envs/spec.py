@@ -351,8 +351,10 @@ def build_spec(env, num_replicas, rng=None):
         ids = veh_k.get_ids()
         obs_perm = np.array([ids.index(v) for v in env.initial_ids], dtype=np.int32)
     sort_vehicles = bool(ep.additional_params.get("sort_vehicles", False))
-    if sort_vehicles and env.FS_ENV != L.FS_ENV_ACCEL:
-        raise NotImplementedError("sort_vehicles is built for AccelEnv on single-lane closed loops")
+    if sort_vehicles and not (env.FS_ENV == L.FS_ENV_ACCEL or
+                              (env.FS_ENV == L.FS_ENV_LANE_CHANGE_ACCEL and num_lanes > 1 and obs_perm is None)):
+        raise NotImplementedError("sort_vehicles is built for AccelEnv on single-lane closed loops and for "
+                                  "LaneChangeAccelEnv on multi-lane rings")
     slots = vehicle_slots(veh_k, env._rl_action_order())
     X, lanes = initial_positions(net_k, network.initial_config, N, R, rng)
     lengths = np.array([s["length"] for s in slots])

@@ -365,7 +365,7 @@ class RingOracle:
                     if col is None:
                         rl_value[:, i] = acts[:, per_rl * vs["rl_index"]]
                     else:
-                        rl_value[:, i] = np.take_along_axis(acts, col[:, i:i + 1], 1)[:, 0]
+                        rl_value[:, i] = np.take_along_axis(acts, per_rl * col[:, i:i + 1], 1)[:, 0]
                     rl_cmd[:, i] = True
         return rl_value, rl_cmd
 
@@ -586,10 +586,12 @@ class MultiLaneRingOracle(RingOracle):
         acts = np.asarray(actions, dtype=self.dt_)
         new_lane = self.lane.copy()
         _, _, _, _, d = self.neighbours()
+        col = self._order_rank(rl_only=True) if self.sort_vehicles else None    # lane_change_accel.py:137-139
         for i, vs in enumerate(self.veh):
             if vs["controller"] != CTRL_RL:
                 continue
-            dirv = acts[:, 2 * vs["rl_index"] + 1]
+            dirv = acts[:, 2 * vs["rl_index"] + 1] if col is None else \
+                np.take_along_axis(acts, 2 * col[:, i:i + 1] + 1, 1)[:, 0]
             direction = np.where(dirv > T(0.5), 1, np.where(dirv < T(-0.5), -1, 0))
             last = h[:, i] if self.quirk else self.last_lc[:, i].astype(self.dt_)
             blocked = (self.time_counter + 1).astype(self.dt_) <= self.lc_duration + last   # lane_change_accel.py:143-147
@@ -611,6 +613,8 @@ class MultiLaneRingOracle(RingOracle):
         dt = T(self.dt)
         acc, commanded, h, v_lead, has_lead = self._accelerations(actions, active)
         new_lane = self._lane_changes(actions, active, h)
+        if self.sort_vehicles:                                       # accel.py:150-169: additional_command
+            self.x_sort = np.where(active[:, None], self.obs_position(self.x), self.x_sort)
         v = self.v
         next_vel = np.maximum(v + acc * dt, T(0))
         v_cmd = v + (next_vel - v) * self.ramp
@@ -650,8 +654,14 @@ class MultiLaneRingOracle(RingOracle):
         if self.spec.get("env") != ENV_LANE_CHANGE_ACCEL:
             return super().get_state()
         T = self.dt_.type                                            # lane_change_accel.py:100-117
-        return np.concatenate([self.v / T(self.spec["max_speed"]), self.x / self.L[:, None],
-                               self.lane.astype(self.dt_) / T(self.lanes)], axis=1)
+        cols = [self.v / T(self.spec["max_speed"]), self.x / self.L[:, None], self.lane.astype(self.dt_) / T(self.lanes)]
+        if self.sort_vehicles:                                       # ... for veh_id in self.sorted_ids
+            place = self._order_rank()
+            out = [np.empty_like(c) for c in cols]
+            for o, c in zip(out, cols):
+                np.put_along_axis(o, place, c, 1)
+            cols = out
+        return np.concatenate(cols, axis=1)
 
     def compute_reward(self, actions, fail):
         if self.spec.get("env") != ENV_LANE_CHANGE_ACCEL:

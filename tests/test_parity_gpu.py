@@ -769,3 +769,25 @@ def test_rollout_kernel_keeps_the_bad_speed_rule_when_speeds_come_from_outside(m
     second = outs["0"][1]
     assert (second[0, ::2] == 0).all() and (second[0, 1::2] > 0).all() and (outs["0"][0] > 0).all()
     np.testing.assert_array_equal(outs["0"][0], outs["0"][2])
+
+
+def test_multilane_sort_vehicles_lane_change_env_bit_exact():
+    """LaneChangeAccelEnv(sort_vehicles=True) on a multi-lane ring (lane_change_accel.py:100-154 through
+    AccelEnv.sorted_ids): observation entries and the [acc, dir] action PAIRS follow the absolute position recorded at
+    the last additional_command; vehicles overtake each other across lanes, so the order really changes."""
+    R, N, K = 5, 14, 160
+    spec = multilane_spec(R=R, N=N, lanes=2, length=200.0, horizon=K, n_rl=3, seed=5, lane_change_duration=2,
+                          sort_vehicles=True)
+    rng = np.random.default_rng(12)
+    acts = np.zeros((K, R, 6), dtype=np.float32)
+    acts[:, :, 0::2] = rng.uniform(-1.0, 1.5, (K, R, 3))
+    acts[:, :, 1::2] = rng.integers(-1, 2, (K, R, 3))
+    ora = run_pair_ml(spec, "f32", K, actions=acts)
+    assert (ora.last_lc > 0).any()
+    rank = ora._order_rank()
+    assert (rank != np.arange(N)[None, :]).any(), "the sorted order must differ from the id order at the end"
+    plain = run_pair_ml(dict(spec, sort_vehicles=False), "f32", K, actions=acts)
+    assert not np.array_equal(plain.x, ora.x)                      # the action pairs reached other vehicles
+    run_pair_ml(dict(spec, num_replicas=2, init_pos=spec["init_pos"][:2], init_lane=spec["init_lane"][:2],
+                     ring_length=spec["ring_length"][:2]), "f64", 80,
+                actions=acts[:80, :2], exact=False, atol=1e-9)
