@@ -296,9 +296,27 @@ class NetworkKernel(object):
             raise FatalFlowError('There is not enough space to place all vehicles in the network.')
         return min_gap, lanes_distribution, available_length, usable
 
+    def _per_edge_start_pos(self, generator, initial_config, num_vehicles):
+        """edges_distribution = {edge: number of vehicles} (network/base.py:285-308, 410-433): every edge is filled on
+        its own, in the order of the dict, the vehicles taking the positions in id order.  (The reference leaves
+        ``initial_config.edges_distribution`` set to the last edge afterwards; the config is not modified here.)"""
+        import copy
+        dist = initial_config.edges_distribution
+        total = sum(dist[k] for k in dist)
+        assert num_vehicles == total, \
+            'Number of vehicles in edges_distribution and the Vehicles class do not match: {}, {}'.format(num_vehicles, total)
+        startpositions, startlanes = [], []
+        for key in dist:
+            cfg = copy.copy(initial_config)
+            cfg.edges_distribution = [key]
+            pos, lane = generator(cfg, dist[key])
+            startpositions.extend(pos)
+            startlanes.extend(lane)
+        return startpositions, startlanes
+
     def gen_even_start_pos(self, initial_config, num_vehicles):
         if isinstance(initial_config.edges_distribution, dict):
-            raise NotImplementedError("edges_distribution as a dict is not built")
+            return self._per_edge_start_pos(self.gen_even_start_pos, initial_config, num_vehicles)
         min_gap, lanes_distr, available_length, available_edges = \
             self._start_pos_util(initial_config, num_vehicles)
         if num_vehicles == 0:
@@ -337,7 +355,7 @@ class NetworkKernel(object):
 
     def gen_random_start_pos(self, initial_config, num_vehicles):
         if isinstance(initial_config.edges_distribution, dict):
-            raise NotImplementedError("edges_distribution as a dict is not built")
+            return self._per_edge_start_pos(self.gen_random_start_pos, initial_config, num_vehicles)
         min_gap, lanes_distr, available_length, available_edges = \
             self._start_pos_util(initial_config, num_vehicles)
         efs = min_gap + VEHICLE_LENGTH

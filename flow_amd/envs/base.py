@@ -98,11 +98,13 @@ class Env(_Base):
         self.sim = FlowSim(spec, precision=self._precision(), device=getattr(self, "_device_index", 0))
         self.k.vehicle.attach(self.sim, 0)
         x0 = spec["init_pos"][0]
-        for i, veh_id in enumerate(self.initial_ids):
+        open_net = spec.get("network") in ("merge", "bottleneck")
+        # closed loops: slot i of the simulator holds k.vehicle._order[i] (id order unless shuffled / re-ordered)
+        for i, veh_id in enumerate(self.initial_ids if open_net else self.k.vehicle._order):
             if spec.get("rings"):                     # MultiRingNetwork: vehicle i is slot i % n of ring i // n
                 r, k = divmod(i, int(spec["num_vehicles"]))
                 edge, pos = self.k.network.locate_ring(r, float(spec["init_pos"][r][k]))
-            elif spec.get("network") in ("merge", "bottleneck"):
+            elif open_net:
                 slot = spec["init_slot"][veh_id]
                 edge, pos = self.k.network.open_locate(int(spec["init_route"][0][slot]), float(x0[slot]))
             else:

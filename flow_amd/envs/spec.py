@@ -355,8 +355,17 @@ def build_spec(env, num_replicas, rng=None):
                               (env.FS_ENV == L.FS_ENV_LANE_CHANGE_ACCEL and num_lanes > 1 and obs_perm is None)):
         raise NotImplementedError("sort_vehicles is built for AccelEnv on single-lane closed loops and for "
                                   "LaneChangeAccelEnv on multi-lane rings")
-    slots = vehicle_slots(veh_k, env._rl_action_order())
     X, lanes = initial_positions(net_k, network.initial_config, N, R, rng)
+    if num_lanes == 1 and obs_perm is None and N > 1 and np.any(np.diff(X[0]) < 0):
+        # the placement is not in driving order (edges_distribution as a dict fills edge after edge in the order of
+        # the dict, network/base.py:285-308): the simulator keeps its slots in ring order, so the vehicles are handed
+        # to the slots by position and the id order travels as the observation permutation (as for shuffle)
+        order = np.argsort(X[0], kind="stable")
+        ids = veh_k.get_ids()
+        veh_k.set_slot_order([ids[j] for j in order])
+        obs_perm = order.astype(np.int32)
+        X = X[:, order]
+    slots = vehicle_slots(veh_k, env._rl_action_order())
     lengths = np.array([s["length"] for s in slots])
     check_placement(X, lengths, net_k.length(), lanes)
     if num_lanes > 1 and env.FS_ENV == L.FS_ENV_WAVE_ATTENUATION_PO:

@@ -630,3 +630,43 @@ def test_lane_change_accel_env_sort_vehicles_through_the_env_api():
             reordered = True
     assert changed and reordered
     env.terminate()
+
+
+def test_edges_distribution_as_a_dict_reference_test():
+    """tests/fast_tests/test_scenario_base_class.py:389-409: {edge: number of vehicles}; a count that does not match
+    the vehicles raises AssertionError; the edges are filled in the order of the dict (here not the driving order:
+    the simulator's slots are handed out by position and the id order travels as the observation permutation)."""
+    from flow_amd.controllers import ContinuousRouter, IDMController
+    from flow_amd.core.params import EnvParams, InitialConfig, NetParams, SumoParams, VehicleParams
+    from flow_amd.envs import AccelEnv
+    from flow_amd.envs.ring.accel import ADDITIONAL_ENV_PARAMS
+    from flow_amd.networks import RingNetwork
+
+    def make(edges, lanes=1):
+        vehicles = VehicleParams()
+        vehicles.add(veh_id="test", acceleration_controller=(IDMController, {}),
+                     routing_controller=(ContinuousRouter, {}), num_vehicles=15)
+        net = RingNetwork("ring", vehicles, NetParams(additional_params={"length": 230, "lanes": lanes,
+                                                                         "speed_limit": 30, "resolution": 40}),
+                          InitialConfig(edges_distribution=edges))
+        return AccelEnv(EnvParams(additional_params=dict(ADDITIONAL_ENV_PARAMS)), SumoParams(sim_step=0.1), net)
+
+    with pytest.raises(AssertionError):
+        make({"top": 2, "bottom": 1})
+    edges = {"top": 5, "bottom": 6, "left": 4}
+    for lanes in (1, 4):
+        env = make(edges, lanes)
+        env.reset()
+        veh = env.k.vehicle
+        for edge in edges:
+            assert len(veh.get_ids_by_edge(edge)) == edges[edge]
+        assert [veh.get_edge(v) for v in veh.get_ids()] == ["top"] * 5 + ["bottom"] * 6 + ["left"] * 4
+        if lanes == 1:
+            assert veh.get_leader("test_4") == "test_11" and veh.get_leader("test_14") == "test_5"
+            obs = env.reset()                                   # observation in id order: speeds, then positions
+            x = np.array([veh.get_x_by_id(v) for v in veh.get_ids()])
+            np.testing.assert_allclose(obs[15:], x / env.k.network.length(), atol=1e-6)
+        for _ in range(20):
+            obs, rew, done, _ = env.step(None)
+        assert np.isfinite(obs).all() and min(veh.get_headway(veh.get_ids())) > 0
+        env.terminate()
