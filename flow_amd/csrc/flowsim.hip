@@ -827,10 +827,10 @@ int validate(const fs_config* c) {
   if (c->sort_vehicles || c->obs_perm) {
     if (c->env != FS_ENV_ACCEL && c->env != FS_ENV_LANE_CHANGE_ACCEL && c->sort_vehicles)
       return fail(FS_ERR_INVALID, "fs_create: sort_vehicles belongs to AccelEnv / LaneChangeAccelEnv");
-    if (c->network == FS_NET_MERGE || c->network == FS_NET_BOTTLENECK || (c->num_lanes > 1 && c->obs_perm) ||
-        (c->num_lanes > 1 && c->env != FS_ENV_LANE_CHANGE_ACCEL))
-      return fail(FS_ERR_UNSUPPORTED, "fs_create: sort_vehicles is built for closed loops (single-lane AccelEnv, "
-                                      "LaneChangeAccelEnv); shuffled ids for single-lane closed loops");
+    if (c->network == FS_NET_MERGE || c->network == FS_NET_BOTTLENECK ||
+        (c->num_lanes > 1 && c->sort_vehicles && c->env != FS_ENV_LANE_CHANGE_ACCEL))
+      return fail(FS_ERR_UNSUPPORTED, "fs_create: sort_vehicles / shuffled ids are built for closed loops "
+                                      "(sort_vehicles on multi-lane rings: LaneChangeAccelEnv)");
     if (c->obs_perm) {
       unsigned long long seen = 0ull;
       for (int i = 0; i < c->num_vehicles && i < 64; ++i) {

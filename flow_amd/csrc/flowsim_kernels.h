@@ -1215,15 +1215,18 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
   if (s.track_aux) { prev_v = s.prev_vel[idx]; last_acc = s.accel[idx]; }
   // sort_vehicles (LaneChangeAccelEnv, lane_change_accel.py:100-139 through AccelEnv.sorted_ids): as in k_steps the
   // vehicles are ordered by the position recorded at the last additional_command, ties in id order
+  // get_ids() order = obs_perm (identity unless InitialConfig.shuffle handed the start places to shuffled ids)
   const bool sorted = s.sort_vehicles != 0;
+  const int perm_i = s.obs_perm != nullptr ? s.obs_perm[ii] : ii;
   T xs = sorted ? s.sort_key[idx] : T(0);
   auto order_rank = [&](bool rl_only) -> int {
     int rk = 0;
     const int me_rl = (sl.ctrl == FS_CTRL_RL) ? 1 : 0;
     for (int j = 0; j < N; ++j) {
       const T xj = seg_read<SEG>(xs, j, seg);
+      const int pj = seg_read_i<SEG>(perm_i, j, seg);
       const int rlj = seg_read_i<SEG>(me_rl, j, seg);
-      const bool before = (xj < xs) || (xj == xs && j < ii);
+      const bool before = (xj < xs) || (xj == xs && pj < perm_i);
       if (before && (!rl_only || rlj != 0)) rk += 1;
     }
     return rk;
@@ -1355,7 +1358,7 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
 
     const bool emit = obs_every_step || (step == num_steps - 1);
     if (emit) {
-      const int oi = sorted ? order_rank(false) : ii;
+      const int oi = sorted ? order_rank(false) : perm_i;
       if (lc_env) {                                                  // lane_change_accel.py:100-117
         if (valid) {
           orow[oi] = float(v / s.max_speed);
@@ -1369,8 +1372,8 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
           orow[2] = float((has ? dlead : T(0)) / s.po_max_length);
         }
       } else if (valid) {
-        orow[ii] = float(v / s.max_speed);
-        orow[N + ii] = float(x / L);
+        orow[oi] = float(v / s.max_speed);
+        orow[N + oi] = float(x / L);
       }
       T reward;
       const bool bad = seg_any<SEG>(valid && (v < T(-100)), seg) || crashed;
@@ -1419,7 +1422,7 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
   }
 
   if (num_steps == 0) {
-    const int oi = sorted ? order_rank(false) : ii;
+    const int oi = sorted ? order_rank(false) : perm_i;
     if (lc_env) {
       if (valid) {
         orow[oi] = float(v / s.max_speed);
@@ -1433,8 +1436,8 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
         orow[2] = float((has ? dlead : T(0)) / s.po_max_length);
       }
     } else if (valid) {
-      orow[ii] = float(v / s.max_speed);
-      orow[N + ii] = float(x / L);
+      orow[oi] = float(v / s.max_speed);
+      orow[N + oi] = float(x / L);
     }
     return;
   }

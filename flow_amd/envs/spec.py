@@ -345,14 +345,12 @@ def build_spec(env, num_replicas, rng=None):
     R, N = int(num_replicas), veh_k.num_vehicles
     obs_perm = None
     if network.initial_config.shuffle:                     # envs/base.py:268-292: positions go to shuffled ids
-        if num_lanes > 1:
-            raise NotImplementedError("InitialConfig(shuffle=True) on a multi-lane ring is not built")
         veh_k.set_slot_order(env.initial_ids)
         ids = veh_k.get_ids()
         obs_perm = np.array([ids.index(v) for v in env.initial_ids], dtype=np.int32)
     sort_vehicles = bool(ep.additional_params.get("sort_vehicles", False))
     if sort_vehicles and not (env.FS_ENV == L.FS_ENV_ACCEL or
-                              (env.FS_ENV == L.FS_ENV_LANE_CHANGE_ACCEL and num_lanes > 1 and obs_perm is None)):
+                              (env.FS_ENV == L.FS_ENV_LANE_CHANGE_ACCEL and num_lanes > 1)):
         raise NotImplementedError("sort_vehicles is built for AccelEnv on single-lane closed loops and for "
                                   "LaneChangeAccelEnv on multi-lane rings")
     X, lanes = initial_positions(net_k, network.initial_config, N, R, rng)

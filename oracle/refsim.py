@@ -655,13 +655,12 @@ class MultiLaneRingOracle(RingOracle):
             return super().get_state()
         T = self.dt_.type                                            # lane_change_accel.py:100-117
         cols = [self.v / T(self.spec["max_speed"]), self.x / self.L[:, None], self.lane.astype(self.dt_) / T(self.lanes)]
-        if self.sort_vehicles:                                       # ... for veh_id in self.sorted_ids
-            place = self._order_rank()
-            out = [np.empty_like(c) for c in cols]
-            for o, c in zip(out, cols):
-                np.put_along_axis(o, place, c, 1)
-            cols = out
-        return np.concatenate(cols, axis=1)
+        # ... for veh_id in self.sorted_ids (get_ids() order = obs_perm unless sort_vehicles)
+        place = self._order_rank() if self.sort_vehicles else np.broadcast_to(self.obs_perm[None, :], cols[0].shape)
+        out = [np.empty_like(c) for c in cols]
+        for o, c in zip(out, cols):
+            np.put_along_axis(o, place, c, 1)
+        return np.concatenate(out, axis=1)
 
     def compute_reward(self, actions, fail):
         if self.spec.get("env") != ENV_LANE_CHANGE_ACCEL:

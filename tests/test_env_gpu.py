@@ -670,3 +670,30 @@ def test_edges_distribution_as_a_dict_reference_test():
             obs, rew, done, _ = env.step(None)
         assert np.isfinite(obs).all() and min(veh.get_headway(veh.get_ids())) > 0
         env.terminate()
+
+
+def test_shuffle_on_a_multi_lane_ring():
+    """InitialConfig(shuffle=True) with lanes > 1 (envs/base.py:268-292): ids keep their order in get_ids() and in the
+    observation, the places (position, lane) are handed out in shuffled order, and a reset re-shuffles."""
+    import random
+    from flow_amd.utils.registry import make_create_env
+    fp = lane_change_flow_params(n=12, rl=2, lanes=3, horizon=60)
+    fp["initial"].shuffle = True
+    random.seed(5)
+    env = make_create_env(fp)[0]()
+    obs = env.reset()
+    veh = env.k.vehicle
+    ids = veh.get_ids()
+    assert ids == ["test_%d" % i for i in range(10)] + ["rl_0", "rl_1"]
+    x = np.array([veh.get_x_by_id(v) for v in ids])
+    assert (np.diff(x) < 0).any()                              # not in driving order any more
+    np.testing.assert_allclose(obs[12:24], x / env.k.network.length(), atol=1e-6)
+    np.testing.assert_allclose(obs[24:], np.array(veh.get_lane(ids)) / 3.0, atol=1e-6)
+    first = x.copy()
+    for _ in range(10):
+        obs, rew, done, _ = env.step([0.3, 0, -0.2, 0])
+    np.testing.assert_allclose(obs[:12], np.array(veh.get_speed(ids)) / 30.0, atol=1e-6)
+    env.reset()
+    again = np.array([veh.get_x_by_id(v) for v in veh.get_ids()])
+    assert sorted(np.round(again, 6)) == sorted(np.round(first, 6)) and not np.allclose(again, first)
+    env.terminate()

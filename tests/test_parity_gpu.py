@@ -791,3 +791,20 @@ def test_multilane_sort_vehicles_lane_change_env_bit_exact():
     run_pair_ml(dict(spec, num_replicas=2, init_pos=spec["init_pos"][:2], init_lane=spec["init_lane"][:2],
                      ring_length=spec["ring_length"][:2]), "f64", 80,
                 actions=acts[:80, :2], exact=False, atol=1e-9)
+
+
+def test_multilane_shuffled_ids_with_and_without_sorting():
+    """InitialConfig(shuffle=True) on a multi-lane ring: the start places go to the ids in shuffled order, the
+    observation stays in get_ids() order (obs_perm); with sort_vehicles the id order only breaks ties."""
+    R, N, K = 4, 12, 100
+    rng = np.random.default_rng(21)
+    perm = rng.permutation(N).astype(np.int32)
+    for sort in (False, True):
+        spec = multilane_spec(R=R, N=N, lanes=3, length=180.0, horizon=K, n_rl=2, seed=9, lane_change_duration=2,
+                              obs_perm=perm, sort_vehicles=sort)
+        acts = np.zeros((K, R, 4), dtype=np.float32)
+        acts[:, :, 0::2] = rng.uniform(-1.0, 1.5, (K, R, 2))
+        acts[:, :, 1::2] = rng.integers(-1, 2, (K, R, 2))
+        run_pair_ml(spec, "f32", K, actions=acts)
+    plain = multilane_spec(R=R, N=N, lanes=3, length=180.0, horizon=40, env=S.ENV_ACCEL, obs_perm=perm)
+    run_pair_ml(plain, "f32", 40)
