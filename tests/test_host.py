@@ -229,8 +229,11 @@ def test_unsupported_features_raise_at_construction(monkeypatch):
     net3 = RingNetwork("ring", v, P.NetParams(additional_params=add3), P.InitialConfig(shuffle=True))
     from flow_amd.envs import LaneChangeAccelEnv
     from flow_amd.envs.ring.lane_change_accel import ADDITIONAL_ENV_PARAMS as LC_PARAMS
-    with pytest.raises(NotImplementedError):
-        build_env(monkeypatch, LaneChangeAccelEnv, P.EnvParams(additional_params=LC_PARAMS), P.SumoParams(), net3)
+    # shuffle on a multi-lane ring: same permutation mechanism, the places are (position, lane) pairs
+    env3, spec3 = build_env(monkeypatch, LaneChangeAccelEnv, P.EnvParams(additional_params=LC_PARAMS), P.SumoParams(),
+                            net3)
+    assert sorted(spec3["obs_perm"].tolist()) == [0, 1, 2, 3] and spec3["num_lanes"] == 3
+    assert [env3.k.vehicle.get_ids()[q] for q in spec3["obs_perm"]] == env3.initial_ids
     inflow = P.InFlows()
     inflow.add("bottom", "idm", vehs_per_hour=100)
     net = RingNetwork("ring", v, P.NetParams(inflows=inflow, additional_params=dict(ADDITIONAL_NET_PARAMS)))
