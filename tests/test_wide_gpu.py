@@ -208,3 +208,70 @@ def test_wide_scaling_two_eight_entry_lanes():
     run_pair(spec, "f64", 120, bottleneck_actions(spec, 5), check_every=40, exact=False, atol=1e-9)
     with pytest.raises(NotImplementedError, match="more than 64 vehicle slots"):
         make(bottleneck_spec(R=1, cap_human=50, cap_rl=10, scaling=2), "f32")
+
+
+def test_full_size_properties_of_the_c4_and_c5_configurations():
+    """BASELINE configs[3] / [4] at their per-GPU sizes (128 lane-drop replicas x 256 slots on k_steps_wide, 1024 merge
+    replicas x 64 slots on k_steps_open), too large for the oracle: size-independent properties instead --
+    a K-step launch equals K one-step launches bit for bit, vehicles are conserved (in network + arrived = initial +
+    departed), nobody overlaps its leader on its own lane, two shards of 64 reproduce the handle of 128."""
+    import torch
+    from flow_amd import _lib as L
+    from helpers import bottleneck_spec, merge_spec
+    dev = torch.device("cuda:0")
+
+    def rollout(sim, K, acts):
+        obs = torch.empty((K, sim.R, sim.obs_dim), dtype=torch.float32, device=dev)
+        rew = torch.empty((K, sim.R), dtype=torch.float32, device=dev)
+        done = torch.empty((K, sim.R), dtype=torch.uint8, device=dev)
+        sim.rollout_dev(K, obs, rew, done, actions=acts)
+        sim.sync()
+        return obs, rew, done
+
+    def conserved(sim, n_init):
+        cnt = sim.get_state(L.FS_FIELD_COUNTERS)
+        route = sim.get_state(L.FS_FIELD_ROUTE)
+        np.testing.assert_array_equal((route >= 0).sum(axis=1) + cnt[:, 5], n_init + cnt[:, 6])
+        lead = sim.get_state(L.FS_FIELD_LEADER)
+        h = sim.headway
+        alive = route >= 0
+        assert (lead[alive] < sim.N).all() and np.isfinite(h[alive]).all()
+        return cnt
+
+    K = 120
+    for name, spec, n_init in (("c4", bottleneck_spec(R=128, cap_human=230, cap_rl=26, horizon=1000, seed=31), 2),
+                               ("c5", merge_spec(R=1024, cap_human=56, cap_rl=8, num_rl=8, horizon=600, seed=32,
+                                                 env=O.ENV_MERGE_MA), None)):
+        if name == "c5":
+            spec["vehicles"] = [dict(v, noise=0.0) for v in spec["vehicles"]]
+            n_init = np.asarray(spec["init_alive"]).sum(axis=1)
+        a, b = make(spec, "f32"), make(spec, "f32")
+        a.reset(), b.reset()
+        gen = torch.Generator(device=dev).manual_seed(5)
+        acts = (torch.rand((K, a.R, max(a.act_dim, 1)), device=dev, generator=gen) * 2 - 1)[:, :, :a.act_dim].contiguous()
+        obs, rew, done = rollout(a, K, acts if a.act_dim else None)
+        for k in range(K):
+            o = torch.empty((a.R, a.obs_dim), dtype=torch.float32, device=dev)
+            r = torch.empty((a.R,), dtype=torch.float32, device=dev)
+            d = torch.empty((a.R,), dtype=torch.uint8, device=dev)
+            b.step_dev(o, r, d, actions=acts[k] if a.act_dim else None)
+            if k % 40 == 39 or k == K - 1:
+                b.sync()
+                assert torch.equal(o, obs[k]) and torch.equal(r, rew[k]) and torch.equal(d, done[k])
+        np.testing.assert_array_equal(a.pos, b.pos)
+        cnt = conserved(a, n_init)
+        assert (cnt[:, 6] > 10).all()                          # the inflows were at work
+        if name == "c4":
+            halves = []
+            for lo, hi in ((0, 64), (64, 128)):
+                sub = dict(spec, num_replicas=hi - lo, replica_offset=lo)
+                for key in ("init_alive", "init_pos", "init_vel", "init_route"):
+                    sub[key] = np.asarray(spec[key])[lo:hi]
+                s = make(sub, "f32")
+                s.reset()
+                o2, r2, d2 = rollout(s, K, acts[:, lo:hi].contiguous())
+                assert torch.equal(o2, obs[:, lo:hi]) and torch.equal(r2, rew[:, lo:hi])
+                halves.append(s.get_state(L.FS_FIELD_ROUTE))
+                s.close()
+            np.testing.assert_array_equal(np.concatenate(halves), a.get_state(L.FS_FIELD_ROUTE))
+        a.close(), b.close()
