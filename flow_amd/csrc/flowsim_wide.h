@@ -28,40 +28,20 @@ struct WideLds {
   int seq[NS];
   int sorted_slot[NS];          // [rank] -> slot
   int skey[NS];                 // [rank] -> path | joins << 8, 0xffff for a free slot
-  unsigned long long okey[sizeof(T) == 4 ? NS : 1];   // float32: the 64-bit ordering key of slot j
+  unsigned long long okey[sizeof(T) == 4 ? NS : 1];   // float32: the 64-bit ordering keys of the vehicles, compacted
+  T cx[sizeof(T) == 4 ? 1 : NS];                      // float64: their positions ...
+  int cslot[sizeof(T) == 4 ? 1 : NS];                 // ... and slots, compacted
   unsigned long long rmask[10][W];       // masks over RANKS: path 0..P-1 (P <= 8), then passed the first / the second join
   unsigned long long words[2][2][W];
   T red_t[2][4][W];
   int red_i[2][4][W];
   unsigned long long cell[2][128][W];    // observation cells: [human | rl][cell][wave] = members in that wave
-  // launch constants (flowsim_open.h keeps them in lane-indexed VGPRs and reads them with v_readlane; here they
-  // are read from LDS with a uniform address, which holds under any EXEC mask and costs no registers)
-  T tab[TAB_ROWS][64];
-  T ctab[6][64];
-  double ftd[3][FS_MAX_INFLOWS];
-  int fti[3][FS_MAX_INFLOWS];
-  int ctab_i[2][64];
+  // launch constants: float32 keeps them one per lane in VGPRs (one copy per wave) and reads them with v_readlane,
+  // float64 reads this LDS copy with uniform addresses -- OpenTabs<T, IN_LDS> of flowsim_open.h, and why
+  OpenTabsLds<T> tabs;
   int emitted[FS_MAX_INFLOWS];           // vehicles emitted so far by inflow f
   int hist[20];                          // arrivals of sub-step % 20
 };
-
-// (internal?, Flow table coordinate) of coordinate x on the single route of the lane-drop network (O5)
-template <typename T, int W>
-__device__ __forceinline__ void route_lookup_lds(const OpenView<T>& o, const WideLds<T, W>& L, T x, bool& internal,
-                                                 T& flow_x) {
-  int k = 0;
-  T st = L.tab[TAB_SEG_START][0], fs0 = L.tab[TAB_SEG_FLOW][0], sl = L.tab[TAB_SEG_SLOPE][0];
-  for (int q = 1; q < o.nseg[0]; ++q) {
-    const T sq = L.tab[TAB_SEG_START][q];
-    const bool hit = x >= sq;
-    k = hit ? q : k;
-    st = hit ? sq : st;
-    fs0 = hit ? L.tab[TAB_SEG_FLOW][q] : fs0;
-    sl = hit ? L.tab[TAB_SEG_SLOPE][q] : sl;
-  }
-  internal = (o.seg_internal[0] >> k) & 1u;
-  flow_x = fs0 + sl * (x - st);
-}
 
 __device__ __forceinline__ int first_bit(unsigned long long m) { return __ffsll((long long)m) - 1; }
 __device__ __forceinline__ int last_bit(unsigned long long m) { return 63 - __clzll((long long)m); }
@@ -109,25 +89,11 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
   sl.sumo_max_speed = s.sumo_max_speed[ii];
   const int my_type = o.slot_type[ii];
   const bool is_rl = sl.ctrl == FS_CTRL_RL;
-  if (tid < 64) {
-#pragma unroll
-    for (int row = 0; row < TAB_ROWS; ++row) L.tab[row][tid] = o.lane_tab[row * 64 + tid];
-    if (dv_env) {
-#pragma unroll
-      for (int row = 0; row < 6; ++row) L.ctab[row][tid] = o.cell_tab[row * 64 + tid];
-      L.ctab_i[0][tid] = o.cell_tab_i[tid];
-      L.ctab_i[1][tid] = o.cell_tab_i[64 + tid];
-    }
-    if (tid < FS_MAX_INFLOWS) {
-#pragma unroll
-      for (int row = 0; row < 3; ++row) {
-        L.ftd[row][tid] = o.flow_tab_d[row * 64 + tid];
-        L.fti[row][tid] = o.flow_tab_i[row * 64 + tid];
-      }
-      L.emitted[tid] = o.emitted[size_t(rr) * FS_MAX_INFLOWS + tid];
-    }
-    if (tid < 20) L.hist[tid] = o.arr_hist[size_t(rr) * 20 + tid];
-  }
+  constexpr bool TABS_IN_LDS = sizeof(T) == 8;
+  OpenTabs<T, TABS_IN_LDS> tb;
+  tb.load(o, l, dv_env, &L.tabs);              // float32: every wave keeps its own lane-indexed copy
+  if (tid < FS_MAX_INFLOWS) L.emitted[tid] = o.emitted[size_t(rr) * FS_MAX_INFLOWS + tid];
+  if (tid < 20) L.hist[tid] = o.arr_hist[size_t(rr) * 20 + tid];
 
   const bool live_replica = mask == nullptr || mask[rr] != 0;
   int tcount = s.time[rr];
@@ -165,6 +131,7 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
   uint8_t* drow = done + rr;
 
   L.len[tid] = sl.length;
+  for (int k = tid; k < 2 * 128 * W; k += NS) (&L.cell[0][0][0])[k] = 0ull;
   int phase = 0;                           // scratch buffer of the next publication (block-uniform)
 
   // ---- M5 + O1: neighbours through the ORDER of the vehicles (see k_steps_open) ----------------------------
@@ -178,7 +145,22 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
     L.x[tid] = xr;
     L.v[tid] = v;
     L.route[tid] = route;
-    // rank: x ascending, equal x: higher slot first; free slots after the vehicles (any fixed order)
+    // rank: x ascending, equal x: higher slot first; free slots after the vehicles (any fixed order).  Only the
+    // vehicles are compared: their keys are first compacted (ballot prefix inside the wave + the wave totals), so the
+    // count runs over n_alive entries instead of all NS slots; a free slot ranks n_alive + (free slots below it).
+    const ull am = __ballot(alive);
+    const int bA = phase & 1;
+    phase += 1;
+    if (l == 0) L.red_i[bA][0][w] = __popcll(am);
+    __syncthreads();
+    int base = 0, n_alive = 0;
+#pragma unroll
+    for (int ww = 0; ww < W; ++ww) {
+      const int cw = L.red_i[bA][0][ww];
+      base += ww < w ? cw : 0;
+      n_alive += cw;
+    }
+    const int place = base + __popcll(am & ((1ull << l) - 1ull));    // vehicles in lower slots
     int rank = 0;
     if (sizeof(T) == 4) {
       // float32: the order is that of ONE unsigned 64-bit key, (order-preserving image of x) : (NS-1-slot), so a
@@ -187,18 +169,23 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
       const uint32_t xb = __float_as_uint(float(xr) + 0.0f);
       const uint32_t ord = (xb & 0x80000000u) ? ~xb : (xb | 0x80000000u);
       const ull key = (ull(ord) << 32) | ull(uint32_t(NS - 1 - tid));
-      L.okey[tid] = key;
+      if (alive) L.okey[place] = key;
       __syncthreads();
 #pragma unroll 8
-      for (int j = 0; j < NS; ++j) rank += (L.okey[j] < key) ? 1 : 0;
+      for (int j = 0; j < n_alive; ++j) rank += (L.okey[j] < key) ? 1 : 0;
     } else {
+      if (alive) {
+        L.cx[place] = xr;
+        L.cslot[place] = tid;
+      }
       __syncthreads();
 #pragma unroll 8
-      for (int j = 0; j < NS; ++j) {
-        const T xj = L.x[j];
-        rank += ((xj < xr) || (xj == xr && j > tid)) ? 1 : 0;
+      for (int j = 0; j < n_alive; ++j) {
+        const T xj = L.cx[j];
+        rank += ((xj < xr) || (xj == xr && L.cslot[j] > tid)) ? 1 : 0;
       }
     }
+    if (!alive) rank = n_alive + (tid - place);
     L.sorted_slot[rank] = tid;
     const int my_key = alive ? (route | (shift_of(x) << 8)) : 0xffff;
     L.skey[rank] = my_key;
@@ -264,7 +251,7 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
       // ---- M11: which adjacent lane (if any) this vehicle would like to continue on after the next move ----------
       bool internal;
       T fx;
-      route_lookup_lds<T, W>(o, L, x, internal, fx);
+      route_lookup<1>(o, tb, x, route, internal, fx);
       const int g = shift_of(x);
       const int lane = my_path >> g, n_lanes = P >> g;
       const bool ok0 = alive && my_lc_auto && !internal && g < 2 && la == g && n_lanes > 1 &&
@@ -351,9 +338,11 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
   // get_outflow_rate over the last `window` sub-steps (vehicle/traci.py:500-505): inside each wave, on its copy
   auto outflow = [&](int window) -> T {
     const int n = tcount < window ? tcount : window;
+    const int newest = (((tcount - 1) % 20) + 20) % 20;  // entry of the last sub-step; entry q is (newest - q) mod 20 old
     int total_i = 0;
     for (int q = 0; q < 20; ++q) {
-      const int ago = (((tcount - 1 - q) % 20) + 20) % 20;
+      int ago = newest - q;
+      ago += ago < 0 ? 20 : 0;
       total_i += (ago < n) ? L.hist[q] : 0;
     }
     const T total = T(total_i);                           // small integers: the float sum of k_steps_open is exact
@@ -369,35 +358,33 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
     const bool alive = route >= 0;
     bool internal;
     T fx;
-    route_lookup_lds<T, W>(o, L, x, internal, fx);
+    route_lookup<1>(o, tb, x, route, internal, fx);
     const int my_lane = (route < 0 ? 0 : route) >> shift_of(x);
     int ocell = -1;
     for (int g = 0; g < o.n_obs_groups; ++g) {
-      const T pos = x - L.ctab[CELL_OBS_START][g];
-      const int meta = L.ctab_i[0][g];
-      bool inside = (pos > L.ctab[CELL_OBS_LO][g]) && (pos <= L.ctab[CELL_OBS_HI][g]);
+      const T pos = x - tb.template c<CELL_OBS_START>(g);
+      const int meta = tb.template ci<0>(g);
+      bool inside = (pos > tb.template c<CELL_OBS_LO>(g)) && (pos <= tb.template c<CELL_OBS_HI>(g));
       if (meta >> 24) inside = inside || (pos == T(0));   // np.searchsorted(..) - 1 == -1: the edge's last segment
       const int rel = my_lane - ((meta >> 16) & 0xff);
       if (alive && !internal && inside && rel >= 0 && rel < ((meta >> 8) & 0xff) && ocell < 0)
         ocell = (meta & 0xff) + rel;
     }
-    // ... then thread c collects cell c: who is in it (one ballot per wave, cell and class), their speeds in slot order
+    // ... then every vehicle enters itself in its cell's membership words (one LDS atomic per vehicle instead of two
+    // ballots per cell; the words were cleared by their owner after the previous observation)
     const int C = o.n_obs_cells;
-    for (int c = 0; c < C; ++c) {
-      const ull bh = __ballot(ocell == c && !is_rl);
-      const ull br = __ballot(ocell == c && is_rl);
-      if (l == 0) {
-        L.cell[0][c][w] = bh;
-        L.cell[1][c][w] = br;
-      }
-    }
+    if (ocell >= 0) atomicOr(&L.cell[is_rl ? 1 : 0][ocell][w], 1ull << l);
     __syncthreads();
-    if (tid < C) {
+    // cell c is collected by lane c / W of wave c % W: the sequential gathers of the W waves run side by side
+    const int my_cell = l * W + w;
+    if (my_cell < C) {
       int cnt_h = 0, cnt_r = 0;
       T sp_h = T(0), sp_r = T(0);
 #pragma unroll
       for (int ww = 0; ww < W; ++ww) {
-        ull mh = L.cell[0][tid][ww], mr = L.cell[1][tid][ww];
+        ull mh = L.cell[0][my_cell][ww], mr = L.cell[1][my_cell][ww];
+        L.cell[0][my_cell][ww] = 0ull;                  // (the next entries come several barriers later)
+        L.cell[1][my_cell][ww] = 0ull;
         cnt_h += __popcll(mh);
         cnt_r += __popcll(mr);
         while (mh != 0ull) {
@@ -412,10 +399,10 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
       const T nh = T(cnt_h) / T(20), nr = T(cnt_r) / T(20);          // NUM_VEHICLE_NORM
       const T mean_h = (cnt_h > 0 ? sp_h / (nh * T(20)) : T(0)) / T(50);
       const T mean_r = (cnt_r > 0 ? sp_r / (nr * T(20)) : T(0)) / T(50);
-      orow[tid] = float(nh);
-      orow[C + tid] = float(nr);
-      orow[2 * C + tid] = float(mean_h);
-      orow[3 * C + tid] = float(mean_r);
+      orow[my_cell] = float(nh);
+      orow[C + my_cell] = float(nr);
+      orow[2 * C + my_cell] = float(mean_h);
+      orow[3 * C + my_cell] = float(mean_r);
     }
     const T of = outflow(o.obs_window) / T(2000.0);
     if (tid == 0) orow[4 * C] = float(of);
@@ -481,7 +468,7 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
       }
       bool internal;
       T fx_unused;
-      route_lookup_lds<T, W>(o, L, x, internal, fx_unused);
+      route_lookup<1>(o, tb, x, route, internal, fx_unused);
       const bool on_edge = s.junction_mode ? !internal : true;
       bool commanded = false;
       T acc = control_accel_on<T, CSET>(s, sl, flags, v, vl, h, has, vf, hf, mean_v, on_edge, false, T(0), live && slot_ok,
@@ -491,9 +478,9 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
         const int my_lane = (route < 0 ? 0 : route) >> shift_of(x);
         int acell = -1;
         for (int g = 0; g < o.n_act_groups; ++g) {
-          const T pos = x - L.ctab[CELL_ACT_START][g];
-          const bool inside = (pos > L.ctab[CELL_ACT_LO][g]) && (pos <= L.ctab[CELL_ACT_HI][g]);
-          const int meta = L.ctab_i[1][g];
+          const T pos = x - tb.template c<CELL_ACT_START>(g);
+          const bool inside = (pos > tb.template c<CELL_ACT_LO>(g)) && (pos <= tb.template c<CELL_ACT_HI>(g));
+          const int meta = tb.template ci<1>(g);
           const int rel = my_lane - ((meta >> 16) & 0xff);
           if (alive && !internal && inside && rel >= 0 && rel < ((meta >> 8) & 0xff) && acell < 0)
             acell = (meta & 0xff) + rel;
@@ -571,12 +558,12 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
       const double now = double(sim_steps - 1) * o.dt_d;
       for (int f = 0; f < o.n_inflows; ++f) {
         const int k = L.emitted[f];
-        const double due_t = L.ftd[1][f] + double(k) * L.ftd[0][f];
-        const int number = L.fti[2][f];
-        const bool due = (due_t <= now) && (due_t <= L.ftd[2][f]) && (number < 0 || k < number);
+        const double due_t = tb.template fd<1>(f) + double(k) * tb.template fd<0>(f);
+        const int number = tb.template fi<2>(f);
+        const bool due = (due_t <= now) && (due_t <= tb.template fd<2>(f)) && (number < 0 || k < number);
         if (!(due && live)) continue;                    // block-uniform
-        const int typ = L.fti[0][f];
-        int route_f = L.fti[1][f];
+        const int typ = tb.template fi<0>(f);
+        int route_f = tb.template fi<1>(f);
         const bool random_lane = route_f < 0;
         if (random_lane) {                               // M9: departLane = "random"
           uint32_t c0 = uint32_t(k), c1 = uint32_t(1000 + f), c2 = s.rep0 + uint32_t(rr), c3 = 1u;
@@ -585,8 +572,8 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
         }
         const bool alive_now = route >= 0;
         const bool free_slot = !alive_now && slot_ok && (my_type == typ) && !just_arrived;
-        const T x_dep = L.tab[TAB_FL_XDEP][f];
-        const T v_dep = L.tab[TAB_FL_VDEP][f];
+        const T x_dep = tb.template t<TAB_FL_XDEP>(f);
+        const T v_dep = tb.template t<TAB_FL_VDEP>(f);
         const int sj = tmax(shift_of(x), shift_of(x_dep + o.zip_d));
         const bool cand = alive_now && ((route >> sj) == (route_f >> sj));
         // per wave: its free slots, its rearmost candidate leader (lowest slot on equal x) and that one's back / speed
@@ -625,9 +612,9 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
           }
         }
         const T gap = back_j - x_dep;
-        const T two_sqrt = L.tab[TAB_FL_TWOSQRT][f];
-        const T need = L.tab[TAB_FL_MINGAP][f] +
-                       tmax(T(0), v_dep * L.tab[TAB_FL_TAU][f] + v_dep * (v_dep - v_lead) / two_sqrt);
+        const T two_sqrt = tb.template t<TAB_FL_TWOSQRT>(f);
+        const T need = tb.template t<TAB_FL_MINGAP>(f) +
+                       tmax(T(0), v_dep * tb.template t<TAB_FL_TAU>(f) + v_dep * (v_dep - v_lead) / two_sqrt);
         const bool ok = (slot >= 0) && (!has_lead || gap >= need);
         if (ok && slot_ok && ii == slot) {
           x = x_dep;
