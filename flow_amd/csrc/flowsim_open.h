@@ -299,6 +299,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       tot_dep = cnt[CNT_TOTAL_DEPARTED], tot_drop = cnt[CNT_TOTAL_DROPPED];
   // vehicles emitted so far by inflow f of this replica: held by lane f of the replica's segment (SEG >= 8)
   int emit_l = (i < FS_MAX_INFLOWS) ? o.emitted[size_t(rr) * FS_MAX_INFLOWS + i] : 0;
+  double next_due = -1.0e300;                                   // unknown yet: the first sub-step evaluates the schedule
 
   T x = s.pos[idx];
   T v = s.vel[idx];
@@ -364,12 +365,19 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       const uint32_t xb = __float_as_uint(float(xr) + 0.0f);
       const uint32_t ord = (xb & 0x80000000u) ? ~xb : (xb | 0x80000000u);
       const unsigned long long key = ((unsigned long long)ord << 32) | (unsigned long long)uint32_t(SEG - 1 - ii);
-      for (unsigned long long u = occupied_slots(); u; u &= u - 1ull) {
-        const int j = __ffsll((long long)u) - 1;
-        const uint32_t oj = uint32_t(seg_read_i<SEG>(int(ord), j, seg));
-        const unsigned long long kj = ((unsigned long long)oj << 32) | (unsigned long long)uint32_t(SEG - 1 - j);
-        rank += (kj < key) ? 1 : 0;
+      // four slots per iteration (independent compares); a free slot's key is the largest and never counts
+      const unsigned long long occ = occupied_slots();
+      int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+      for (int q = 0; q < SEG; q += 4) {
+        if (((occ >> q) & 0xFull) == 0ull) continue;
+        const uint32_t o0 = uint32_t(seg_read_i<SEG>(int(ord), q, seg)), o1 = uint32_t(seg_read_i<SEG>(int(ord), q + 1, seg)),
+                       o2 = uint32_t(seg_read_i<SEG>(int(ord), q + 2, seg)), o3 = uint32_t(seg_read_i<SEG>(int(ord), q + 3, seg));
+        r0 += ((((unsigned long long)o0 << 32) | (unsigned long long)uint32_t(SEG - 1 - q)) < key) ? 1 : 0;
+        r1 += ((((unsigned long long)o1 << 32) | (unsigned long long)uint32_t(SEG - 2 - q)) < key) ? 1 : 0;
+        r2 += ((((unsigned long long)o2 << 32) | (unsigned long long)uint32_t(SEG - 3 - q)) < key) ? 1 : 0;
+        r3 += ((((unsigned long long)o3 << 32) | (unsigned long long)uint32_t(SEG - 4 - q)) < key) ? 1 : 0;
       }
+      rank = (r0 + r1) + (r2 + r3);
     } else {
       for (unsigned long long u = occupied_slots(); u; u &= u - 1ull) {
         const int j = __ffsll((long long)u) - 1;
@@ -773,9 +781,14 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       // (a rolled loop over the inflows; every per-flow constant comes out of a lane table, so the loop keeps no
       // scalar registers alive across the step loop)
       const double now = double(sim_steps - 1) * o.dt_d;
-      for (int f = 0; f < o.n_inflows; ++f) {
+      // `next_due` = earliest scheduled time of the replica's next vehicles (their count / end limits aside): while
+      // it lies ahead in every replica of the wave the whole loop is skipped -- most sub-steps
+      const bool any_due = __ballot(live && (next_due <= now)) != 0ull;
+      double nd = 1.0e300;
+      for (int f = 0; any_due && f < o.n_inflows; ++f) {
         const int k = seg_read_i<SEG>(emit_l, f, seg);
         const double due_t = tb.template fd<1>(f) + double(k) * tb.template fd<0>(f);
+        nd = (due_t < nd) ? due_t : nd;
         const int number = tb.template fi<2>(f);
         const bool due = (due_t <= now) && (due_t <= tb.template fd<2>(f)) && (number < 0 || k < number);
         if (__ballot(due && live) == 0ull) continue;     // wave-uniform: this inflow is due in no replica of the wave
@@ -830,7 +843,9 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         const bool consumed = ok || (random_lane && live && due);
         if (consumed && i == f) emit_l = k + 1;
         if (consumed && !ok) tot_drop += 1;
+        if (consumed) nd = 0.0;                            // its next vehicle: re-evaluated in the next sub-step
       }
+      if (any_due) next_due = nd;
       // ---- O1: new neighbour snapshot, sticky followers, collision check --------------------------------
       neighbours(live, track_foll);
       bool c = seg_any<SEG>((route >= 0) && has && lead_same_lane && (h < s.crash_gap), seg);
