@@ -356,7 +356,7 @@ struct Sim : SimBase {
       ov.out_norm = T(cfg.outflow_norm > 0 ? cfg.outflow_norm : 2000.0);
       ov.obs_dim = obs_dim;
       std::vector<T> ct(6 * 64, T(0));
-      std::vector<int32_t> cti(2 * 64, 0);
+      std::vector<int32_t> cti(3 * 64, 0);
       // consecutive cells that differ only in the lane (lane l, l+1, ...) form one group
       auto group = [&](const std::vector<fs_cell>& cells, int row_start, int row_lo, int row_hi, int row_i) {
         int g = 0;
@@ -378,6 +378,25 @@ struct Sim : SimBase {
       };
       ov.n_obs_groups = group(obs_cells, fs::CELL_OBS_START, fs::CELL_OBS_LO, fs::CELL_OBS_HI, 0);
       ov.n_act_groups = group(act_cells, fs::CELL_ACT_START, fs::CELL_ACT_LO, fs::CELL_ACT_HI, 1);
+      // row 2: the groups that lie on route segment k (an edge and its groups share the start coordinate), so that a
+      // vehicle only tries the lane-segments of its own edge
+      ov.obs_span = ov.act_span = 0;
+      auto ranges = [&](int n_groups, int row_start, int shift) {
+        int span = 0;
+        for (size_t k = 0; k < segs.size() && k < 64; ++k) {
+          int first = -1, cnt = 0;
+          for (int g = 0; g < n_groups; ++g)
+            if (double(ct[size_t(row_start) * 64 + g]) == double(T(segs[k].start)) && !segs[k].internal) {
+              if (first < 0) first = g;
+              ++cnt;
+            }
+          if (first >= 0) cti[size_t(2) * 64 + k] |= (first | (cnt << 8)) << shift;
+          span = cnt > span ? cnt : span;
+        }
+        return span;
+      };
+      ov.obs_span = ranges(ov.n_obs_groups, fs::CELL_OBS_START, 0);
+      ov.act_span = ranges(ov.n_act_groups, fs::CELL_ACT_START, 16);
       ov.track_followers = cfg.track_followers;
       std::vector<int32_t> lca(N, 0);
       int any_lc = 0;

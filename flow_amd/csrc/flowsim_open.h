@@ -51,8 +51,11 @@ struct OpenView {
   // bottleneck heads (O6 / O7)
   // lane-segments are stored as GROUPS of cells that differ only in the lane: lane g of the tables holds group g
   const T* cell_tab;           // [6][64] edge start / lo / hi of observation group g, of action group g
-  const int32_t* cell_tab_i;   // [2][64] first cell | lanes << 8 | first lane << 16 | is_last_segment << 24 (obs / action)
+  const int32_t* cell_tab_i;   // [3][64] rows 0 / 1: first cell | lanes << 8 | first lane << 16 | is_last_segment << 24 of
+                               // observation / action group g; row 2, lane k: the groups on route segment k,
+                               // obs first | obs count << 8 | action first << 16 | action count << 24
   int n_obs_cells, n_act_cells, n_obs_groups, n_act_groups, obs_window, rew_window, obs_dim, track_followers;
+  int obs_span, act_span;      // most groups any one segment (edge) holds
   // M11 simplified lane changing
   const int32_t* lc_auto;      // [N] 1: the slot's vehicle type changes lane on its own
   int lc_enabled, lc_cooldown;
@@ -147,7 +150,7 @@ struct OpenTabsLds {
   T ctab[6][64];
   double ftd[3][64];
   int fti[3][64];
-  int ctab_i[2][64];
+  int ctab_i[3][64];
 };
 
 template <typename T, bool IN_LDS>
@@ -157,7 +160,7 @@ template <typename T>
 struct OpenTabs<T, false> {
   T tab[TAB_ROWS], ctab[6];
   double ftd[3];
-  int fti[3], ctab_i[2];
+  int fti[3], ctab_i[3];
   __device__ __forceinline__ void load(const OpenView<T>& o, int lane, bool cells, OpenTabsLds<T>*) {
 #pragma unroll
     for (int r = 0; r < TAB_ROWS; ++r) tab[r] = o.lane_tab[r * 64 + lane];
@@ -169,7 +172,7 @@ struct OpenTabs<T, false> {
 #pragma unroll
     for (int r = 0; r < 6; ++r) ctab[r] = cells ? o.cell_tab[r * 64 + lane] : T(0);
 #pragma unroll
-    for (int r = 0; r < 2; ++r) ctab_i[r] = cells ? o.cell_tab_i[r * 64 + lane] : 0;
+    for (int r = 0; r < 3; ++r) ctab_i[r] = cells ? o.cell_tab_i[r * 64 + lane] : 0;
   }
   template <int ROW> __device__ __forceinline__ T t(int j) const { return read_lane(tab[ROW], j); }
   template <int ROW> __device__ __forceinline__ T c(int j) const { return read_lane(ctab[ROW], j); }
@@ -178,6 +181,8 @@ struct OpenTabs<T, false> {
   template <int ROW> __device__ __forceinline__ int fi(int j) const { return read_lane_i(fti[ROW], j); }
   // entry j with a lane-varying j (whole wave active)
   template <int ROW> __device__ __forceinline__ T t_gather(int j) const { return __shfl(tab[ROW], j, 64); }
+  template <int ROW> __device__ __forceinline__ T c_gather(int j) const { return __shfl(ctab[ROW], j, 64); }
+  template <int ROW> __device__ __forceinline__ int ci_gather(int j) const { return __shfl(ctab_i[ROW], j, 64); }
 };
 
 template <typename T>
@@ -194,7 +199,7 @@ struct OpenTabs<T, true> {
 #pragma unroll
     for (int r = 0; r < 6; ++r) lds->ctab[r][lane] = cells ? o.cell_tab[r * 64 + lane] : T(0);
 #pragma unroll
-    for (int r = 0; r < 2; ++r) lds->ctab_i[r][lane] = cells ? o.cell_tab_i[r * 64 + lane] : 0;
+    for (int r = 0; r < 3; ++r) lds->ctab_i[r][lane] = cells ? o.cell_tab_i[r * 64 + lane] : 0;
     L = lds;
     __syncthreads();
   }
@@ -204,15 +209,18 @@ struct OpenTabs<T, true> {
   template <int ROW> __device__ __forceinline__ double fd(int j) const { return L->ftd[ROW][j]; }
   template <int ROW> __device__ __forceinline__ int fi(int j) const { return L->fti[ROW][j]; }
   template <int ROW> __device__ __forceinline__ T t_gather(int j) const { return L->tab[ROW][j]; }
+  template <int ROW> __device__ __forceinline__ T c_gather(int j) const { return L->ctab[ROW][j]; }
+  template <int ROW> __device__ __forceinline__ int ci_gather(int j) const { return L->ctab_i[ROW][j]; }
 };
 
 // (internal?, Flow table coordinate) of coordinate x on route r (O5): both routes are walked with wave-uniform
 // loops and the lane keeps the result of its own route.
 template <int NR, typename T, typename TABS>
 __device__ __forceinline__ void route_lookup(const OpenView<T>& o, const TABS& tb, T x, int route, bool& internal,
-                                             T& flow_x) {
+                                             T& flow_x, int& seg_k) {
   internal = false;
   flow_x = T(0);
+  seg_k = 0;
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     int k = 0;
@@ -229,8 +237,37 @@ __device__ __forceinline__ void route_lookup(const OpenView<T>& o, const TABS& t
     if (NR == 1 || route == r) {
       internal = (o.seg_internal[r] >> k) & 1u;
       flow_x = fs0 + sl * (x - st);
+      seg_k = k;
     }
   }
+}
+template <int NR, typename T, typename TABS>
+__device__ __forceinline__ void route_lookup(const OpenView<T>& o, const TABS& tb, T x, int route, bool& internal,
+                                             T& flow_x) {
+  int k_unused;
+  route_lookup<NR>(o, tb, x, route, internal, flow_x, k_unused);
+}
+
+// O6: the lane-segment ("cell") of a vehicle at coordinate x on route segment seg_k, lane my_lane; -1 = none.  KIND 0:
+// observation cells, 1: action cells.  Only the groups of the vehicle's own edge are tried (row 2 of the integer
+// table says which), gathered with a lane-varying index: call with the whole wave active.
+template <int KIND, typename T, typename TABS>
+__device__ __forceinline__ int cell_of(const TABS& tb, int span, T x, int seg_k, int my_lane, bool eligible) {
+  const int range = tb.template ci_gather<2>(seg_k);
+  const int g0 = (range >> (KIND * 16)) & 0xff, cnt = (range >> (KIND * 16 + 8)) & 0xff;
+  int cell = -1;
+  for (int r = 0; r < span; ++r) {
+    const int g = g0 + (r < cnt ? r : 0);
+    const T pos = x - tb.template c_gather<KIND * 3 + 0>(g);
+    const T lo = tb.template c_gather<KIND * 3 + 1>(g), hi = tb.template c_gather<KIND * 3 + 2>(g);
+    const int meta = tb.template ci_gather<KIND>(g);
+    bool inside = (pos > lo) & (pos <= hi);
+    if (KIND == 0) inside = inside | (((meta >> 24) != 0) & (pos == T(0)));   // searchsorted(..) - 1 == -1: last segment
+    const int rel = my_lane - ((meta >> 16) & 0xff);
+    const bool hit = eligible & (r < cnt) & inside & (rel >= 0) & (rel < ((meta >> 8) & 0xff)) & (cell < 0);
+    cell = hit ? (meta & 0xff) + rel : cell;
+  }
+  return cell;
 }
 
 // P = number of paths (entry lanes): 2 = MergeNetwork (each path has its own segment table), 4 = BottleneckNetwork
@@ -559,18 +596,10 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       const bool alive = route >= 0;
       bool internal;
       T fx;
-      route_lookup<NR>(o, tb, x, route, internal, fx);
+      int seg_k;
+      route_lookup<NR>(o, tb, x, route, internal, fx, seg_k);
       const int my_lane = (route < 0 ? 0 : route) >> shift_of(x);
-      int ocell = -1;
-      for (int g = 0; g < o.n_obs_groups; ++g) {
-        const T pos = x - tb.template c<CELL_OBS_START>(g);
-        const int meta = tb.template ci<0>(g);
-        bool inside = (pos > tb.template c<CELL_OBS_LO>(g)) && (pos <= tb.template c<CELL_OBS_HI>(g));
-        if (meta >> 24) inside = inside || (pos == T(0));   // np.searchsorted(..) - 1 == -1: the edge's last segment
-        const int rel = my_lane - ((meta >> 16) & 0xff);
-        if (alive && !internal && inside && rel >= 0 && rel < ((meta >> 8) & 0xff) && ocell < 0)
-          ocell = (meta & 0xff) + rel;
-      }
+      const int ocell = cell_of<0>(tb, o.obs_span, x, seg_k, my_lane, alive && !internal);
       // ... then lane c collects cell c: who is in it (one ballot per cell and class), then their speeds in slot order
       unsigned long long mh = 0ull, mr = 0ull;
       for (int c = 0; c < o.n_obs_cells; ++c) {
@@ -666,7 +695,8 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       }
       bool internal;
       T fx_unused;
-      route_lookup<NR>(o, tb, x, route, internal, fx_unused);
+      int seg_k;
+      route_lookup<NR>(o, tb, x, route, internal, fx_unused, seg_k);
       const bool on_edge = s.junction_mode ? !internal : true;
       // RL command (envs/base.py:355 runs before additional_command: the rl_veh list of the last sub-step)
       bool have_rl = false;
@@ -686,15 +716,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       // ---- O6: BottleneckDesiredVelocityEnv._apply_rl_actions (bottleneck.py:926-969) -------------------
       if (dv_env && act != nullptr) {
         const int my_lane = (route < 0 ? 0 : route) >> shift_of(x);
-        int acell = -1;
-        for (int g = 0; g < o.n_act_groups; ++g) {
-          const T pos = x - tb.template c<CELL_ACT_START>(g);
-          const bool inside = (pos > tb.template c<CELL_ACT_LO>(g)) && (pos <= tb.template c<CELL_ACT_HI>(g));
-          const int meta = tb.template ci<1>(g);
-          const int rel = my_lane - ((meta >> 16) & 0xff);
-          if (alive && !internal && inside && rel >= 0 && rel < ((meta >> 8) & 0xff) && acell < 0)
-            acell = (meta & 0xff) + rel;
-        }
+        const int acell = cell_of<1>(tb, o.act_span, x, seg_k, my_lane, alive && !internal);
         T a = acell >= 0 ? T(act[acell]) : T(0);
         if (s.clip_actions) a = tmin(tmax(a, s.act_lo), s.act_hi);
         T nxt = tmin(tmax(vmax + a, T(0.01)), T(23.0));

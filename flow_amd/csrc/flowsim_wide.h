@@ -358,18 +358,10 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
     const bool alive = route >= 0;
     bool internal;
     T fx;
-    route_lookup<1>(o, tb, x, route, internal, fx);
+    int seg_k;
+    route_lookup<1>(o, tb, x, route, internal, fx, seg_k);
     const int my_lane = (route < 0 ? 0 : route) >> shift_of(x);
-    int ocell = -1;
-    for (int g = 0; g < o.n_obs_groups; ++g) {
-      const T pos = x - tb.template c<CELL_OBS_START>(g);
-      const int meta = tb.template ci<0>(g);
-      bool inside = (pos > tb.template c<CELL_OBS_LO>(g)) && (pos <= tb.template c<CELL_OBS_HI>(g));
-      if (meta >> 24) inside = inside || (pos == T(0));   // np.searchsorted(..) - 1 == -1: the edge's last segment
-      const int rel = my_lane - ((meta >> 16) & 0xff);
-      if (alive && !internal && inside && rel >= 0 && rel < ((meta >> 8) & 0xff) && ocell < 0)
-        ocell = (meta & 0xff) + rel;
-    }
+    const int ocell = cell_of<0>(tb, o.obs_span, x, seg_k, my_lane, alive && !internal);
     // ... then every vehicle enters itself in its cell's membership words (one LDS atomic per vehicle instead of two
     // ballots per cell; the words were cleared by their owner after the previous observation)
     const int C = o.n_obs_cells;
@@ -468,7 +460,8 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
       }
       bool internal;
       T fx_unused;
-      route_lookup<1>(o, tb, x, route, internal, fx_unused);
+      int seg_k;
+      route_lookup<1>(o, tb, x, route, internal, fx_unused, seg_k);
       const bool on_edge = s.junction_mode ? !internal : true;
       bool commanded = false;
       T acc = control_accel_on<T, CSET>(s, sl, flags, v, vl, h, has, vf, hf, mean_v, on_edge, false, T(0), live && slot_ok,
@@ -476,15 +469,7 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
       // ---- O6: BottleneckDesiredVelocityEnv._apply_rl_actions (bottleneck.py:926-969) -------------------
       if (dv_env && act != nullptr) {
         const int my_lane = (route < 0 ? 0 : route) >> shift_of(x);
-        int acell = -1;
-        for (int g = 0; g < o.n_act_groups; ++g) {
-          const T pos = x - tb.template c<CELL_ACT_START>(g);
-          const bool inside = (pos > tb.template c<CELL_ACT_LO>(g)) && (pos <= tb.template c<CELL_ACT_HI>(g));
-          const int meta = tb.template ci<1>(g);
-          const int rel = my_lane - ((meta >> 16) & 0xff);
-          if (alive && !internal && inside && rel >= 0 && rel < ((meta >> 8) & 0xff) && acell < 0)
-            acell = (meta & 0xff) + rel;
-        }
+        const int acell = cell_of<1>(tb, o.act_span, x, seg_k, my_lane, alive && !internal);
         T a = acell >= 0 ? T(act[acell]) : T(0);
         if (s.clip_actions) a = tmin(tmax(a, s.act_lo), s.act_hi);
         T nxt = tmin(tmax(vmax + a, T(0.01)), T(23.0));
