@@ -524,7 +524,12 @@ struct Sim : SimBase {
   hipLaunchKernelGGL((fs::k_steps_open<T, SEG, P_, C_>), dim3(blocks), dim3(64), 0, stream, dv, ov, num_steps, mask, \
                      actions, act_stride, obs, rew, done, obs_every_step, after_reset)
       if (cfg.network == FS_NET_BOTTLENECK) {
-        if (cset) FS_OPEN(4, (std::is_same<T, float>::value ? 1 : 0)); else FS_OPEN(4, 0);
+        // the lane-drop heads need more than 32 slots (fs_create checks it): only the 64-lane segment is built
+        if constexpr (SEG == 64) {
+          if (cset) FS_OPEN(4, (std::is_same<T, float>::value ? 1 : 0)); else FS_OPEN(4, 0);
+        } else {
+          return fail(FS_ERR_UNSUPPORTED, "fs_step: FS_NET_BOTTLENECK runs on 64-lane segments only");
+        }
       } else {
         if (cset) FS_OPEN(2, (std::is_same<T, float>::value ? 1 : 0)); else FS_OPEN(2, 0);
       }

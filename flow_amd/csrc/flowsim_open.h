@@ -139,11 +139,14 @@ template <int SEG, typename T>
 __device__ __forceinline__ T seg_max(T v) { return -seg_min<SEG>(-v); }
 
 // ---- launch constants of the step loop ---------------------------------------------------------------------
-// float32 instantiations keep them ONE PER LANE in VGPRs and fetch entry j with v_readlane (no memory access in
-// the loop).  float64 instantiations run out of architectural VGPRs: hipcc parks such rows in AGPRs and brings
-// them back with v_accvgpr_read under the CURRENT exec mask right before the v_readlane, which returns stale
-// data for rows held by lanes that are inactive at that point (found by the f64 parity test of k_steps_wide).
-// They therefore read the same tables from LDS with a uniform address, valid under any exec mask.
+// Two homes for the tables, chosen by OpenTabs<T, IN_LDS>:
+//   IN_LDS = false  one entry per lane in VGPRs, entry j fetched with v_readlane (no memory access in the loop);
+//   IN_LDS = true   an LDS copy read with a uniform (or, for the gathers, lane-varying) address.
+// The kernels use the LDS home.  The VGPR home is only sound while the table registers are never parked in AGPRs:
+// hipcc brings an AGPR-held row back with v_accvgpr_read under the CURRENT exec mask right before the v_readlane,
+// which then returns stale data for rows held by lanes that are inactive at that point (found by the f64 parity
+// test of k_steps_wide).  The float64 kernels always spill; the float32 ones sit at 190-256 VGPRs, one edit away
+// from it, and measured no faster with the VGPR home (C5 237 M, C4 15.5 M either way) -- so LDS for all of them.
 template <typename T>
 struct OpenTabsLds {
   T tab[TAB_ROWS][64];
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
   sl.sumo_max_speed = s.sumo_max_speed[ii];
   const int my_type = o.slot_type[ii];
   const bool is_rl = sl.ctrl == FS_CTRL_RL;
-  constexpr bool TABS_IN_LDS = sizeof(T) == 8;
+  constexpr bool TABS_IN_LDS = true;               // see OpenTabs above
   __shared__ typename std::conditional<TABS_IN_LDS, OpenTabsLds<T>, int>::type tabs_mem;
   OpenTabs<T, TABS_IN_LDS> tb;
   tb.load(o, lane_id, bn_env, reinterpret_cast<OpenTabsLds<T>*>(&tabs_mem));

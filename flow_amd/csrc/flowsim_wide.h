@@ -36,8 +36,7 @@ struct WideLds {
   T red_t[2][4][W];
   int red_i[2][4][W];
   unsigned long long cell[2][128][W];    // observation cells: [human | rl][cell][wave] = members in that wave
-  // launch constants: float32 keeps them one per lane in VGPRs (one copy per wave) and reads them with v_readlane,
-  // float64 reads this LDS copy with uniform addresses -- OpenTabs<T, IN_LDS> of flowsim_open.h, and why
+  // launch constants, read with uniform / gathered addresses -- OpenTabs<T, IN_LDS> of flowsim_open.h, and why
   OpenTabsLds<T> tabs;
   int emitted[FS_MAX_INFLOWS];           // vehicles emitted so far by inflow f
   int hist[20];                          // arrivals of sub-step % 20
@@ -89,9 +88,9 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
   sl.sumo_max_speed = s.sumo_max_speed[ii];
   const int my_type = o.slot_type[ii];
   const bool is_rl = sl.ctrl == FS_CTRL_RL;
-  constexpr bool TABS_IN_LDS = sizeof(T) == 8;
+  constexpr bool TABS_IN_LDS = true;
   OpenTabs<T, TABS_IN_LDS> tb;
-  tb.load(o, l, dv_env, &L.tabs);              // float32: every wave keeps its own lane-indexed copy
+  tb.load(o, l, dv_env, &L.tabs);
   if (tid < FS_MAX_INFLOWS) L.emitted[tid] = o.emitted[size_t(rr) * FS_MAX_INFLOWS + tid];
   if (tid < 20) L.hist[tid] = o.arr_hist[size_t(rr) * 20 + tid];
 

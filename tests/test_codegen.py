@@ -1,11 +1,12 @@
 """Code-generation guards (no GPU needed: hipcc cross-compiles gfx950 here).
 
-The float32 step kernels keep launch constants one per lane in VGPRs and read them with v_readlane.  That idiom is
-only sound while those VGPRs are never parked in AGPRs: hipcc re-materialises an AGPR-held value with v_accvgpr_read
-under the CURRENT exec mask right before the v_readlane, so rows held by lanes that are inactive at that point would
-read stale data (found in the float64 wide kernel; the float64 open-network kernels read their
-tables from LDS for that reason).  This test pins the premise: every float32 instantiation of the step kernels uses
-zero AGPRs and spills nothing to scratch memory."""
+The step kernels read per-replica values other lanes hold with v_readlane (segment tables of the closed loops,
+ordering keys, inflow counters).  That idiom is only sound while those VGPRs are never parked in AGPRs: hipcc
+re-materialises an AGPR-held value with v_accvgpr_read under the CURRENT exec mask right before the v_readlane, so
+rows held by lanes that are inactive at that point would read stale data (found in the float64 wide kernel, DESIGN.md
+section 4; the open-network kernels read their launch tables from LDS for that reason).  This test pins the premise:
+every float32 instantiation of the step kernels uses zero AGPRs and spills nothing to scratch memory -- it caught
+k_steps_open<float, 32, .> growing past 256 VGPRs once."""
 import os
 import re
 import subprocess
