@@ -396,7 +396,7 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
       orow[3 * C + my_cell] = float(mean_r);
     }
     const T of = outflow(o.obs_window) / T(2000.0);
-    if (tid == 0) orow[4 * C] = float(of);
+    if (tid == 64) orow[4 * C] = float(of);            // (each single-lane store costs its wave ~0.5 us: one per wave)
     // (the next write of the cell words is a whole sub-step, i.e. several barriers, away)
   };
   auto store_snapshot = [&]() {
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
     if (emit) {
       write_obs();
       const T reward = outflow(o.rew_window) / o.out_norm;       // bottleneck.py:474-478, 971-981
-      if (tid == 0) {
+      if (tid == 64 * (W - 1)) {
         *rrow = float(reward);
         *drow = uint8_t((tcount >= s.step_limit) || crashed);
       }
