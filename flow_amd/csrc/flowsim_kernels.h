@@ -580,6 +580,43 @@ __device__ __forceinline__ void segment_lookup_args(const DevView<T>& s, T x, bo
   flow_x = fs0 + sl * (x - st);
 }
 
+// The segment a vehicle is on, FOLLOWED from step to step instead of searched: vehicles only move forward, so after a
+// move the cached segment is still right unless x has passed the next start (advance) or wrapped around the loop
+// (restart from segment 0).  A step then costs two compares and a ballot; the table rows of the current segment are
+// re-gathered (ds_bpermute, whole wave) only when some lane changes segment.  One lookup per move serves both the
+// observation of this step and the "on an edge" test of the next one (same x).  On C3 the two searches per step
+// (an 11-iteration v_readlane loop each, ~135 cycles per iteration at one wave per SIMD) were 38 % of the step.
+template <typename T>
+struct SegCursor {
+  int k;
+  T st, fs0, sl, next;
+
+  __device__ __forceinline__ void refresh(const SegTab<T>& tab, int nseg) {        // all 64 lanes active
+    st = __shfl(tab.start, k, 64);
+    fs0 = __shfl(tab.flow_start, k, 64);
+    sl = __shfl(tab.flow_slope, k, 64);
+    const T nx = __shfl(tab.start, k + 1 < nseg ? k + 1 : k, 64);
+    next = (k + 1 < nseg) ? nx : T(3.0e38);
+  }
+  __device__ __forceinline__ void init(const DevView<T>& s, const SegTab<T>& tab, T x) {
+    k = 0;
+    for (int q = 1; q < s.nseg; ++q) k = (x >= read_lane(tab.start, q)) ? q : k;
+    refresh(tab, s.nseg);
+  }
+  __device__ __forceinline__ void follow(const DevView<T>& s, const SegTab<T>& tab, T x) {   // all 64 lanes active
+    if (__ballot(x < st) != 0ull) {
+      k = (x < st) ? 0 : k;
+      refresh(tab, s.nseg);
+    }
+    while (__ballot(x >= next) != 0ull) {
+      k += (x >= next) ? 1 : 0;
+      refresh(tab, s.nseg);
+    }
+  }
+  __device__ __forceinline__ bool internal(const DevView<T>& s) const { return (s.seg_internal >> k) & 1u; }
+  __device__ __forceinline__ T flow_x(T x) const { return fs0 + sl * (x - st); }
+};
+
 // ---------------------------------------------------------------------------
 // BaseController.get_action for one vehicle (base_controller.py:70-118) + the RL command
 // (envs/base.py:599-615): shared by the single-lane and the multi-lane step kernels.
@@ -705,6 +742,8 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
   sl.sumo_max_speed = s.sumo_max_speed[ii];
   const T len_lead = lead_read<SEG>(sl.length, seg, wrap_lead);
   const SegTab<T> segtab = (!FAST && s.nseg > 0) ? load_segtab(s, lane) : SegTab<T>{T(0), T(0), T(0)};
+  const bool use_seg = !FAST && s.nseg > 0;            // figure eight: Flow's table coordinate / internal edges
+  SegCursor<T> cur = {0, T(0), T(0), T(1), T(3.0e38)};
 
   // per-replica scalars
   const T base_len = s.ring_len[rr];
@@ -718,6 +757,7 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
   // state
   T x = s.pos[idx];
   T v = s.vel[idx];
+  if (use_seg) cur.init(s, segtab, x);
   T prev_v = v, last_acc = T(0);
   T cst = (!FAST && (flags & FLAG_HAS_LAC)) ? s.ctrl_state[idx] : T(0);
   if (!FAST && s.track_aux) { prev_v = s.prev_vel[idx]; last_acc = s.accel[idx]; }
@@ -801,9 +841,19 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
           const int col = order_rank(true);
           if (have_rl) a_rl = T(act[col]);
         }
-        T xa;
-        acc = control_accel<T, CSET>(s, segtab, sl, flags, v, vl, h, has, vf, hf, mean_v, x, quarter, qj, have_rl,
-                                     a_rl, live && i < N, rr, ii, nctr, cst, commanded, xa);
+        // "on an edge" (base_controller.py:98-99) and Flow's coordinate of x, from the segment cursor
+        bool on_edge = true;
+        T xa = x;
+        const bool gated = s.junction_mode && sl.ctrl != FS_CTRL_RL && sl.ctrl != FS_CTRL_SIM;
+        if (use_seg) {
+          xa = cur.flow_x(x);
+          if (gated) on_edge = !cur.internal(s);
+        } else if (gated) {
+          T u = x - tfloor(x / qj) * qj;
+          on_edge = !(u >= quarter);
+        }
+        acc = control_accel_on<T, CSET>(s, sl, flags, v, vl, h, has, vf, hf, mean_v, on_edge, have_rl, a_rl,
+                                        live && i < N, rr, ii, nctr, cst, commanded);
         if (sorted && live) xs = xa;                     // accel.py:150-169 additional_command: position before the move
       }
       // ---- apply_acceleration + SUMO integration (S4-S9) ------------------
@@ -843,6 +893,7 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
         tcount += 1;
         nctr += 1u;
       }
+      if (use_seg) cur.follow(s, segtab, x);
       // ---- vehicle update: new neighbour snapshot (vehicle/traci.py:219-250)
       xl = lead_read<SEG>(x, seg, wrap_lead);
       vl = lead_read<SEG>(v, seg, wrap_lead);
@@ -861,11 +912,7 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
     const bool emit = obs_every_step || (step == num_steps - 1);
     if (emit) {
       const int oi = FAST ? ii : (sorted ? order_rank(false) : perm_i);
-      T xo = x;
-      if (!FAST && s.nseg > 0 && env != FS_ENV_WAVE_ATTENUATION_PO) {   // every lane looks up, then `valid` ones store
-        bool internal;
-        segment_lookup(s, segtab, x, internal, xo);
-      }
+      const T xo = use_seg ? cur.flow_x(x) : x;
       if (env == FS_ENV_WAVE_ATTENUATION_PO) {
         // wave_attenuation.py:248-269; written by the RL vehicle's lane
         if (valid && sl.ctrl == FS_CTRL_RL && sl.rl_index == 0) {
@@ -918,11 +965,7 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
 
   if (num_steps == 0) {   // observation of the current state only (Env.reset, envs/base.py:544-551)
     const int oi = FAST ? ii : (sorted ? order_rank(false) : perm_i);
-    T xo = x;
-    if (!FAST && s.nseg > 0) {
-      bool internal;
-      segment_lookup(s, segtab, x, internal, xo);
-    }
+    const T xo = use_seg ? cur.flow_x(x) : x;
     if (env == FS_ENV_WAVE_ATTENUATION_PO) {
       if (valid && sl.ctrl == FS_CTRL_RL && sl.rl_index == 0) {
         orow[0] = float(v / T(15));
