@@ -251,6 +251,40 @@ __device__ __forceinline__ void route_lookup(const OpenView<T>& o, const TABS& t
   route_lookup<NR>(o, tb, x, route, internal, flow_x, k_unused);
 }
 
+// The route segment of a vehicle, FOLLOWED from sub-step to sub-step (vehicles only move forward) instead of searched
+// by every reader: after a move the cached segment holds unless x has passed the next start; a vehicle inserted into
+// the slot starts again from its route's first segment.  The table row of the current segment is cached in registers
+// and re-read from the LDS tables (plain loads with a per-lane index: fine under any exec mask) only on a change.
+template <typename T, typename TABS>
+struct RouteCursor {
+  int k;
+  T st, fs0, sl, next;
+  __device__ __forceinline__ void refresh(const OpenView<T>& o, const TABS& tb, int r) {
+    st = tb.template t_gather<TAB_SEG_START>(r * 16 + k);
+    fs0 = tb.template t_gather<TAB_SEG_FLOW>(r * 16 + k);
+    sl = tb.template t_gather<TAB_SEG_SLOPE>(r * 16 + k);
+    const bool more = k + 1 < o.nseg[r];
+    const T nx = tb.template t_gather<TAB_SEG_START>(r * 16 + (more ? k + 1 : k));
+    next = more ? nx : T(3.0e38);
+  }
+  __device__ __forceinline__ void restart(const OpenView<T>& o, const TABS& tb, int r, T x) {
+    k = 0;
+    refresh(o, tb, r);
+    while (x >= next) {
+      k += 1;
+      refresh(o, tb, r);
+    }
+  }
+  __device__ __forceinline__ void follow(const OpenView<T>& o, const TABS& tb, int r, T x) {
+    while (x >= next) {
+      k += 1;
+      refresh(o, tb, r);
+    }
+  }
+  __device__ __forceinline__ bool internal(const OpenView<T>& o, int r) const { return (o.seg_internal[r] >> k) & 1u; }
+  __device__ __forceinline__ T flow_x(T x) const { return fs0 + sl * (x - st); }
+};
+
 // O6: the lane-segment ("cell") of a vehicle at coordinate x on route segment seg_k, lane my_lane; -1 = none.  KIND 0:
 // observation cells, 1: action cells.  Only the groups of the vehicle's own edge are tried (row 2 of the integer
 // table says which), gathered with a lane-varying index: call with the whole wave active.
@@ -329,6 +363,8 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
   __shared__ typename std::conditional<TABS_IN_LDS, OpenTabsLds<T>, int>::type tabs_mem;
   OpenTabs<T, TABS_IN_LDS> tb;
   tb.load(o, lane_id, bn_env, reinterpret_cast<OpenTabsLds<T>*>(&tabs_mem));
+  static_assert(TABS_IN_LDS, "RouteCursor reads the tables with per-lane indices under divergent control flow");
+  RouteCursor<T, OpenTabs<T, TABS_IN_LDS>> cur;
 
   const bool live_replica = rvalid && (mask == nullptr || mask[rr] != 0);
   int tcount = s.time[rr];
@@ -353,6 +389,8 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
   T prev_v = s.prev_vel[idx], last_acc = s.accel[idx];
   T cst = s.ctrl_state[idx];
   T vmax = o.vmax[idx];
+  const auto seg_route = [&]() -> int { return (NR == 1 || route < 0) ? 0 : route; };   // segment table of my route
+  cur.restart(o, tb, seg_route(), x);
   const bool lc_on = (P > 2) && (o.lc_enabled != 0);
   const bool my_lc_auto = lc_on && (o.lc_auto[ii] != 0);
   int last_lc = lc_on ? s.last_lc[idx] : 0;
@@ -473,9 +511,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
     }
     if (lc_on) {
       // ---- M11: which adjacent lane (if any) this vehicle would like to continue on after the next move ----------
-      bool internal;
-      T fx;
-      route_lookup<NR>(o, tb, x, route, internal, fx);
+      const bool internal = cur.internal(o, seg_route());
       const int g = shift_of(x);
       const int my_path = route < 0 ? 0 : route;
       const int lane = my_path >> g, n_lanes = P >> g;
@@ -562,9 +598,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
   // the five features of the vehicle in this slot (merge.py:128-156)
   auto five = [&](T* f5) {
     const bool alive = route >= 0;
-    bool internal;
-    T fx;
-    route_lookup<NR>(o, tb, x, route, internal, fx);
+    const T fx = cur.flow_x(x);
     const int ld = alive ? lead : -1;
     const int fo = alive ? foll : -1;
     const int lsrc = segbase + (ld >= 0 ? ld : ii), fsrc = segbase + (fo >= 0 ? fo : ii);
@@ -597,10 +631,8 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       }
       // ---- O6 get_state (bottleneck.py:868-924): which observation cell am I in ...
       const bool alive = route >= 0;
-      bool internal;
-      T fx;
-      int seg_k;
-      route_lookup<NR>(o, tb, x, route, internal, fx, seg_k);
+      const bool internal = cur.internal(o, seg_route());
+      const int seg_k = cur.k;
       const int my_lane = (route < 0 ? 0 : route) >> shift_of(x);
       const int ocell = cell_of<0>(tb, o.obs_span, x, seg_k, my_lane, alive && !internal);
       // ... then lane c collects cell c: who is in it (one ballot per cell and class), then their speeds in slot order
@@ -696,10 +728,8 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         const int n_alive = __popcll(seg_ballot<SEG>(alive, seg));
         mean_v = seg_sum<SEG>(alive ? v : T(0)) / T(n_alive > 0 ? n_alive : 1);
       }
-      bool internal;
-      T fx_unused;
-      int seg_k;
-      route_lookup<NR>(o, tb, x, route, internal, fx_unused, seg_k);
+      const bool internal = cur.internal(o, seg_route());
+      const int seg_k = cur.k;
       const bool on_edge = s.junction_mode ? !internal : true;
       // RL command (envs/base.py:355 runs before additional_command: the rl_veh list of the last sub-step)
       bool have_rl = false;
@@ -786,6 +816,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         x = x_new;
         v = v_new;
       }
+      if (mv) cur.follow(o, tb, seg_route(), x);
       if (live) {
         tcount += 1;
         nctr += 1u;
@@ -858,6 +889,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
           foll = -1;
           foll_h = BIGV;
           ctl_seq = -1;
+          cur.restart(o, tb, seg_route(), x);
         }
         if (ok) {
           seq_ctr += 1;

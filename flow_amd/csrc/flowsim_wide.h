@@ -91,6 +91,8 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
   constexpr bool TABS_IN_LDS = true;
   OpenTabs<T, TABS_IN_LDS> tb;
   tb.load(o, l, dv_env, &L.tabs);
+  static_assert(TABS_IN_LDS, "RouteCursor reads the tables with per-lane indices under divergent control flow");
+  RouteCursor<T, OpenTabs<T, TABS_IN_LDS>> cur;
   if (tid < FS_MAX_INFLOWS) L.emitted[tid] = o.emitted[size_t(rr) * FS_MAX_INFLOWS + tid];
   if (tid < 20) L.hist[tid] = o.arr_hist[size_t(rr) * 20 + tid];
 
@@ -114,6 +116,7 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
   T prev_v = s.prev_vel[idx], last_acc = s.accel[idx];
   T cst = s.ctrl_state[idx];
   T vmax = o.vmax[idx];
+  cur.restart(o, tb, 0, x);                     // one segment table: every lane drives the same edges
   const bool lc_on = o.lc_enabled != 0;
   const bool my_lc_auto = lc_on && (o.lc_auto[ii] != 0);
   int last_lc = lc_on ? s.last_lc[idx] : 0;
@@ -248,9 +251,7 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
     }
     if (lc_on) {
       // ---- M11: which adjacent lane (if any) this vehicle would like to continue on after the next move ----------
-      bool internal;
-      T fx;
-      route_lookup<1>(o, tb, x, route, internal, fx);
+      const bool internal = cur.internal(o, 0);
       const int g = shift_of(x);
       const int lane = my_path >> g, n_lanes = P >> g;
       const bool ok0 = alive && my_lc_auto && !internal && g < 2 && la == g && n_lanes > 1 &&
@@ -355,10 +356,8 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
     }
     // ---- O6 get_state (bottleneck.py:868-924): which observation cell am I in ...
     const bool alive = route >= 0;
-    bool internal;
-    T fx;
-    int seg_k;
-    route_lookup<1>(o, tb, x, route, internal, fx, seg_k);
+    const bool internal = cur.internal(o, 0);
+    const int seg_k = cur.k;
     const int my_lane = (route < 0 ? 0 : route) >> shift_of(x);
     const int ocell = cell_of<0>(tb, o.obs_span, x, seg_k, my_lane, alive && !internal);
     // ... then every vehicle enters itself in its cell's membership words (one LDS atomic per vehicle instead of two
@@ -457,10 +456,8 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
         if (W == 4) tot = (part[0] + part[1]) + (part[2 % W] + part[3 % W]);
         mean_v = tot / T(n_alive > 0 ? n_alive : 1);
       }
-      bool internal;
-      T fx_unused;
-      int seg_k;
-      route_lookup<1>(o, tb, x, route, internal, fx_unused, seg_k);
+      const bool internal = cur.internal(o, 0);
+      const int seg_k = cur.k;
       const bool on_edge = s.junction_mode ? !internal : true;
       bool commanded = false;
       T acc = control_accel_on<T, CSET>(s, sl, flags, v, vl, h, has, vf, hf, mean_v, on_edge, false, T(0), live && slot_ok,
@@ -525,6 +522,7 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
           x = x_new;
           v = v_new;
         }
+        if (mv) cur.follow(o, tb, 0, x);
         if (live) {
           tcount += 1;
           nctr += 1u;
@@ -613,6 +611,7 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
           origin = f * (1 << 20) + k;
           foll = -1;
           foll_h = BIGV;
+          cur.restart(o, tb, 0, x);
         }
         if (ok) {
           seq_ctr += 1;
