@@ -434,43 +434,56 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
   auto neighbours = [&](bool live, bool follow) {
     const bool alive = route >= 0;
     const T xr = alive ? x : BIGV;
-    int rank = 0;
+    const unsigned long long segmask = SEG == 64 ? ~0ull : ((1ull << (SEG & 63)) - 1ull);
+    const unsigned long long am = seg_ballot<SEG>(alive, seg);
+    const int dead_rank = __popcll(am) + __popcll(~am & segmask & ((1ull << i) - 1ull));
+    const int my_key = alive ? (route | (shift_of(x) << 8)) : 0xffff;
+    int rank = 0, sorted_slot, skey;
     if (sizeof(T) == 4) {
-      // float32: one unsigned 64-bit key per slot, (order-preserving image of x) : (SEG-1-slot), so a pair is a
-      // v_readlane, a v_cmp_lt_u64 against the uniform key of slot j and an add-with-carry.  Written with || the
-      // two-compare form compiled to two nested exec-mask branches per iteration (125 cycles each: 35 % of C5).
-      // (x + 0 turns a -0.0 into +0.0, whose integer images would otherwise differ)
+      // float32: the order "x ascending, equal x: higher slot first" is that of the unsigned 64-bit key
+      // (order-preserving image of x) : (SEG-1-slot).  Two vehicles with the SAME x are rare (two inflows releasing
+      // at one coordinate in one sub-step), so the count runs on the 32-bit images alone -- v_readlane, v_cmp_lt_u32,
+      // add-with-carry per slot, four slots per iteration; a free slot's image is the largest and never counts --
+      // and is checked: tied vehicles get the same count, their pushes collide, and a rank lane stays unmarked.
+      // Only then the exact 64-bit count runs.  (Written with || the two-compare form had compiled to two nested
+      // exec-mask branches per slot, 125 cycles each: 35 % of C5.  x + 0 turns a -0.0 into +0.0, whose integer
+      // images would otherwise differ.)
       const uint32_t xb = __float_as_uint(float(xr) + 0.0f);
       const uint32_t ord = (xb & 0x80000000u) ? ~xb : (xb | 0x80000000u);
-      const unsigned long long key = ((unsigned long long)ord << 32) | (unsigned long long)uint32_t(SEG - 1 - ii);
-      // four slots per iteration (independent compares); a free slot's key is the largest and never counts
       const unsigned long long occ = occupied_slots();
       int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
       for (int q = 0; q < SEG; q += 4) {
         if (((occ >> q) & 0xFull) == 0ull) continue;
-        const uint32_t o0 = uint32_t(seg_read_i<SEG>(int(ord), q, seg)), o1 = uint32_t(seg_read_i<SEG>(int(ord), q + 1, seg)),
-                       o2 = uint32_t(seg_read_i<SEG>(int(ord), q + 2, seg)), o3 = uint32_t(seg_read_i<SEG>(int(ord), q + 3, seg));
-        r0 += ((((unsigned long long)o0 << 32) | (unsigned long long)uint32_t(SEG - 1 - q)) < key) ? 1 : 0;
-        r1 += ((((unsigned long long)o1 << 32) | (unsigned long long)uint32_t(SEG - 2 - q)) < key) ? 1 : 0;
-        r2 += ((((unsigned long long)o2 << 32) | (unsigned long long)uint32_t(SEG - 3 - q)) < key) ? 1 : 0;
-        r3 += ((((unsigned long long)o3 << 32) | (unsigned long long)uint32_t(SEG - 4 - q)) < key) ? 1 : 0;
+        r0 += (uint32_t(seg_read_i<SEG>(int(ord), q, seg)) < ord) ? 1 : 0;
+        r1 += (uint32_t(seg_read_i<SEG>(int(ord), q + 1, seg)) < ord) ? 1 : 0;
+        r2 += (uint32_t(seg_read_i<SEG>(int(ord), q + 2, seg)) < ord) ? 1 : 0;
+        r3 += (uint32_t(seg_read_i<SEG>(int(ord), q + 3, seg)) < ord) ? 1 : 0;
       }
-      rank = (r0 + r1) + (r2 + r3);
+      rank = alive ? (r0 + r1) + (r2 + r3) : dead_rank;
+      const int marked = __builtin_amdgcn_ds_permute((segbase + rank) << 2, 1);
+      if (__ballot(marked == 0) != 0ull) {                      // some rank lane got no vehicle: a tie somewhere
+        const unsigned long long key = ((unsigned long long)ord << 32) | (unsigned long long)uint32_t(SEG - 1 - ii);
+        int rk = 0;
+        for (unsigned long long u = occ; u; u &= u - 1ull) {
+          const int j = __ffsll((long long)u) - 1;
+          const unsigned long long kj = ((unsigned long long)uint32_t(seg_read_i<SEG>(int(ord), j, seg)) << 32) |
+                                        (unsigned long long)uint32_t(SEG - 1 - j);
+          rk += (kj < key) ? 1 : 0;
+        }
+        rank = alive ? rk : dead_rank;
+      }
     } else {
       for (unsigned long long u = occupied_slots(); u; u &= u - 1ull) {
         const int j = __ffsll((long long)u) - 1;
         const T xj = seg_read<SEG>(xr, j, seg);
         rank += (int(xj < xr) | (int(xj == xr) & int(j > ii)));     // bitwise: no short-circuit branches
       }
+      rank = alive ? rank : dead_rank;
     }
-    const unsigned long long segmask = SEG == 64 ? ~0ull : ((1ull << (SEG & 63)) - 1ull);
-    const unsigned long long am = seg_ballot<SEG>(alive, seg);
-    if (!alive) rank = __popcll(am) + __popcll(~am & segmask & ((1ull << i) - 1ull));
-    const int sorted_slot = __builtin_amdgcn_ds_permute((segbase + rank) << 2, i);
+    sorted_slot = __builtin_amdgcn_ds_permute((segbase + rank) << 2, i);
     // the same push for (path, joins upstream of the vehicle): once the lanes hold these in rank order the
     // per-path / per-region masks are plain ballots
-    const int my_key = alive ? (route | (shift_of(x) << 8)) : 0xffff;
-    const int skey = __builtin_amdgcn_ds_permute((segbase + rank) << 2, my_key);
+    skey = __builtin_amdgcn_ds_permute((segbase + rank) << 2, my_key);
     const bool s_alive = skey != 0xffff;
     const unsigned long long bit = 1ull << rank;
     unsigned long long B[P];

@@ -374,3 +374,37 @@ def test_fuzz_random_open_network_configs_bit_exact(seed):
     spec, acts = random_open_spec(seed)
     steps = int(spec["horizon"])
     run_pair(spec, "f32", steps, acts if seed % 5 else None, check_every=max(1, steps // 4))
+
+
+def test_equal_positions_take_the_exact_ranking_path():
+    """Vehicles at exactly the same coordinate (two initial ones side by side; two inflows with the same schedule
+    releasing at one coordinate in the same sub-step): the fast 32-bit ranking sees a tie and hands over to the
+    64-bit one -- order 'higher slot first', as the oracle sorts."""
+    from helpers import bottleneck_spec
+    spec = bottleneck_spec(R=3, cap_human=40, cap_rl=8, horizon=160, seed=2)
+    X = np.asarray(spec["init_pos"]).copy()
+    X[:, 40] = X[:, 0]                                      # the RL vehicle starts level with the human, other lane
+    spec["init_pos"] = X
+    for f in spec["inflows"]:                               # same clock for both inflows: they release together
+        f["period"], f["begin"] = 1.5, 1.0
+    probe = O.MergeOracle(spec, np.float32)                 # the scenario really produces equal coordinates
+    probe.reset()
+    acts = bottleneck_actions(spec, 3)
+    tie_steps = 0
+    for k in range(160):
+        probe.step(acts(k))
+        tie_steps += sum(len(np.unique(probe.x[r][probe.alive[r]])) < probe.alive[r].sum() for r in range(3))
+    assert tie_steps > 20
+    ora = run_pair(spec, "f32", 160, bottleneck_actions(spec, 3), check_every=5)
+    assert ora.total_departed.min() > 40
+    mspec = quiet(merge_spec(R=3, cap_human=20, cap_rl=6, num_rl=3, horizon=120, seed=5))
+    mspec["init_pos"] = np.asarray(mspec["init_pos"]).copy()
+    alive0 = np.nonzero(np.asarray(mspec["init_alive"])[0])[0]
+    if len(alive0) >= 2:                                    # two initial vehicles on the two routes at one coordinate
+        mspec["init_pos"][:, alive0[1]] = mspec["init_pos"][:, alive0[0]]
+    for f in mspec["inflows"]:
+        f["period"], f["begin"] = 4.0, 1.0
+    try:
+        run_pair(mspec, "f32", 120, uniform_actions(mspec, 2, 0.0, 1.0), check_every=5)
+    except ValueError as e:                                 # the placement check may refuse overlapping same-route starts
+        assert "init" in str(e)
