@@ -275,3 +275,24 @@ def test_full_size_properties_of_the_c4_and_c5_configurations():
                 s.close()
             np.testing.assert_array_equal(np.concatenate(halves), a.get_state(L.FS_FIELD_ROUTE))
         a.close(), b.close()
+
+
+def test_wide_equal_positions_take_the_exact_ranking_path():
+    """Two inflows on one clock release side by side at one coordinate: the 32-bit ranking of k_steps_wide sees the
+    collision in the scatter and repeats the sub-step's ranking with the exact 64-bit keys."""
+    from helpers import bottleneck_spec
+    spec = bottleneck_spec(R=2, cap_human=110, cap_rl=18, horizon=220, seed=4, q=3600.0)
+    X = np.asarray(spec["init_pos"]).copy()
+    X[:, 110] = X[:, 0]
+    spec["init_pos"] = X
+    for f in spec["inflows"]:
+        f["period"], f["begin"] = 1.0, 1.0
+    probe = O.MergeOracle(spec, np.float32)
+    probe.reset()
+    acts = bottleneck_actions(spec, 3)
+    tie_steps = 0
+    for k in range(220):
+        probe.step(acts(k))
+        tie_steps += sum(len(np.unique(probe.x[r][probe.alive[r]])) < probe.alive[r].sum() for r in range(2))
+    assert tie_steps > 30 and (probe.alive.sum(axis=1) > 64).any()
+    run_pair(spec, "f32", 220, bottleneck_actions(spec, 3), check_every=10)
