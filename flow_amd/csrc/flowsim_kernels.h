@@ -1291,21 +1291,24 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
     T best = big, bestf = big;
     lead = -1;
     foll = -1;
-    for (int k = 1; k < N; ++k) {
-      int j = ii + k;
-      j = j >= N ? j - N : j;
-      const T xj = bperm(x, segbase + j);
-      const int lj = __shfl(ln, segbase + j, 64);
+    // slot j is the same for every lane of the wave: x_j / lane_j come by v_readlane (no LDS round trip per
+    // candidate), and the tests are bitwise so that they stay selects instead of nested exec-mask branches
+    for (int j = 0; j < N; ++j) {
+      const T xj = seg_read<SEG>(x, j, seg);
+      const int lj = seg_read_i<SEG>(ln, j, seg);
       T dij = xj - x;                                   // arc from me to j
-      const bool wrapf = (dij < T(0)) || (dij == T(0) && j < ii);
+      const bool wrapf = (dij < T(0)) | ((dij == T(0)) & (j < ii));
       dij = wrapf ? dij + L : dij;
       T dji = x - xj;                                   // arc from j to me
-      const bool wrapb = (dji < T(0)) || (dji == T(0) && ii < j);
+      const bool wrapb = (dji < T(0)) | ((dji == T(0)) & (ii < j));
       dji = wrapb ? dji + L : dji;
-      const bool same = (lj == ln);
-      // np.argmin takes the FIRST minimum in slot order: on a tie prefer the smaller slot index
-      if (same && (dij < best || (dij == best && j < lead))) { best = dij; lead = j; }
-      if (same && (dji < bestf || (dji == bestf && j < foll))) { bestf = dji; foll = j; }
+      const bool same = (lj == ln) & (j != ii);
+      // np.argmin takes the FIRST minimum in slot order; j ascends, so a strict < keeps the smaller slot on a tie
+      const bool tl = same & (dij < best), tf = same & (dji < bestf);
+      best = tl ? dij : best;
+      lead = tl ? j : lead;
+      bestf = tf ? dji : bestf;
+      foll = tf ? j : foll;
     }
     has = lead >= 0;
     const int lsrc = segbase + (has ? lead : ii);
@@ -1356,17 +1359,15 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
         // refuse a change that would overlap a vehicle of the target lane (lane_change_mode != 0)
         bool clash = false;
         if (s.lane_change_mode != 0) {
-          for (int k = 1; k < N; ++k) {
-            int j = ii + k;
-            j = j >= N ? j - N : j;
-            const T xj = bperm(x, segbase + j);
-            const int lj = __shfl(ln, segbase + j, 64);
-            const T lenj = bperm(sl.length, segbase + j);
+          for (int j = 0; j < N; ++j) {
+            const T xj = seg_read<SEG>(x, j, seg);
+            const int lj = seg_read_i<SEG>(ln, j, seg);
+            const T lenj = seg_read<SEG>(sl.length, j, seg);
             T dij = xj - x;
-            const bool wrapf = (dij < T(0)) || (dij == T(0) && j < ii);
+            const bool wrapf = (dij < T(0)) | ((dij == T(0)) & (j < ii));
             dij = wrapf ? dij + L : dij;
             const T dji = dij == T(0) ? T(0) : L - dij;
-            if (lj == new_ln && (dij < lenj || dji < sl.length)) clash = true;
+            clash = clash | ((j != ii) & (lj == new_ln) & ((dij < lenj) | (dji < sl.length)));
           }
         }
         if (clash || !live) new_ln = ln;
