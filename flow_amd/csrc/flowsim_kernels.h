@@ -1358,7 +1358,8 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
       if (lc_env) {
         // refuse a change that would overlap a vehicle of the target lane (lane_change_mode != 0)
         bool clash = false;
-        if (s.lane_change_mode != 0) {
+        // (only a vehicle that is about to change lane can clash: skipped when no lane of the wave is)
+        if (s.lane_change_mode != 0 && __ballot(new_ln != ln) != 0ull) {
           for (int j = 0; j < N; ++j) {
             const T xj = seg_read<SEG>(x, j, seg);
             const int lj = seg_read_i<SEG>(ln, j, seg);
