@@ -311,7 +311,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3000)
     ap.add_argument("--replicas", type=int, default=4096, help="replicas per GPU")
     ap.add_argument("--fragment", type=int, default=1500, help="env steps per rollout launch")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--precision", default="f32", choices=["f32", "f64", "mixed"])
     ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline / step_api / f64 legs")
     args = ap.parse_args()
 
@@ -387,7 +387,7 @@ def main():
     N = spec["num_vehicles"]
     obs_b = runner.obs_dim * 4 + 4 + 1                    # obs + reward + done, per env-step
     state_b = N * (4 + 4) * 2 + 4 * 2                     # pos+vel read and written once per launch, time counter
-    if args.precision == "f64":
+    if args.precision != "f32":
         state_b = N * (8 + 8) * 2 + 4 * 2
     bytes_per_launch = R * (k_launch * obs_b + state_b)
     achieved = bytes_per_launch / avg_launch_s / 1e9

@@ -20,6 +20,7 @@
 #include "flowsim.h"
 #include "flowsim_kernels.h"
 #include "flowsim_open.h"
+#include "flowsim_pair.h"
 #include "flowsim_wide.h"
 
 namespace {
@@ -64,6 +65,9 @@ struct SimBase {
   bool force_generic = false;   // FLOWSIM_FORCE_GENERIC=1: never take the specialised kernels (tests)
   bool no_fastdiv = false;      // FLOWSIM_NO_FASTDIV=1: keep the IEEE division sequence in k_rollout_idm
   int rollout_block = 512;      // threads per block of k_rollout_idm (FLOWSIM_ROLLOUT_BLOCK overrides; sweep: DESIGN.md)
+  bool mixed = false;           // FS_MIXED: float64 state, float32 controller arithmetic (k_rollout_pair<double>)
+  bool no_pair = false;         // FLOWSIM_NO_PAIR=1: keep k_rollout_idm (one vehicle per lane) for the float rollout
+  int pair_block = 256;         // threads per block of k_rollout_pair (FLOWSIM_PAIR_BLOCK overrides)
 
   virtual int launch_steps(int num_steps, const uint8_t* mask, const float* actions, size_t act_stride,
                            float* obs, float* rew, uint8_t* done, int obs_every_step) = 0;
@@ -459,7 +463,7 @@ struct Sim : SimBase {
     return true;
   }
   bool fastdiv_ok() {
-    if (!std::is_same<T, float>::value || force_generic || no_fastdiv) return false;
+    if ((!std::is_same<T, float>::value && !mixed) || force_generic || no_fastdiv) return false;
     if (fastdiv_state >= 0) return fastdiv_state == 1;
     fastdiv_state = 0;
     std::vector<float> cs;
@@ -543,7 +547,33 @@ struct Sim : SimBase {
       HIP_TRY(hipGetLastError());
       return FS_OK;
     }
-    if (fast_ok(mask, num_steps) && obs_every_step && dv.N > 1 && actions == nullptr &&
+    // two vehicles per lane (flowsim_pair.h): even N; the only stepping kernel of a FS_MIXED handle
+    constexpr int ROW = SEG >= 16 ? SEG / 2 : 8;
+    const bool pair_ok = fast_ok(mask, num_steps) && (obs_every_step || num_steps == 1) && dv.N >= 2 &&
+                         (dv.N % 2) == 0 && actions == nullptr && !no_pair &&
+                         size_t(dv.R) * 2 * dv.N * sizeof(float) * 16 < (size_t(1) << 32);   // 32-bit offsets in a block
+    if (mixed && num_steps == 0) {                       // observation of the current state (Env.reset)
+      const int n = dv.R * dv.N;
+      hipLaunchKernelGGL((fs::k_obs_mixed), dim3((n + 255) / 256), dim3(256), 0, stream, dv, obs);
+      HIP_TRY(hipGetLastError());
+      return FS_OK;
+    }
+    if (mixed && !pair_ok)
+      return fail(FS_ERR_UNSUPPORTED, "FS_MIXED is built for the all-IDM ring rollout (observation every step or "
+                                      "single steps, no reset mask during stepping)");
+    if (pair_ok && (mixed || std::is_same<T, float>::value)) {
+      const bool fd = fastdiv_ok();
+      const int waves = (dv.R + (64 / ROW) - 1) / (64 / ROW);
+      const int wpb = pair_block / 64;
+      const dim3 grid((waves + wpb - 1) / wpb), block(pair_block);
+      const bool bc = neg_speed_possible;
+#define FS_PAIR(D4, FD, BC)                                                                                   \
+  hipLaunchKernelGGL((fs::k_rollout_pair<T, ROW, D4, FD, BC>), grid, block, 0, stream, dv, num_steps, obs, rew, done)
+      if (delta4 && fd) { if (bc) FS_PAIR(true, true, true); else FS_PAIR(true, true, false); }
+      else if (delta4) { if (bc) FS_PAIR(true, false, true); else FS_PAIR(true, false, false); }
+      else { if (bc) FS_PAIR(false, false, true); else FS_PAIR(false, false, false); }
+#undef FS_PAIR
+    } else if (fast_ok(mask, num_steps) && obs_every_step && dv.N > 1 && actions == nullptr &&
         size_t(dv.R) * 2 * dv.N * sizeof(float) < (size_t(1) << 32)) {   // 32-bit byte offsets inside one step's block
       const bool fd = fastdiv_ok();
       const int waves = blocks;                                   // one wave per 64/SEG replicas
@@ -753,7 +783,21 @@ int validate(const fs_config* c) {
   if (c->struct_size != sizeof(fs_config))
     return fail(FS_ERR_INVALID, "fs_create: struct_size mismatch (header/library out of sync)");
   if (c->abi_version != FS_ABI_VERSION) return fail(FS_ERR_INVALID, "fs_create: abi_version mismatch");
-  if (c->precision != FS_F32 && c->precision != FS_F64) return fail(FS_ERR_INVALID, "fs_create: bad precision");
+  if (c->precision != FS_F32 && c->precision != FS_F64 && c->precision != FS_MIXED)
+    return fail(FS_ERR_INVALID, "fs_create: bad precision");
+  if (c->precision == FS_MIXED) {
+    bool ok = c->network == FS_NET_RING && c->num_lanes <= 1 && c->env == FS_ENV_ACCEL && !c->evaluate &&
+              c->sims_per_step == 1 && c->integrator == FS_EULER && !c->junction_mode && !c->track_aux &&
+              !c->sort_vehicles && !c->obs_perm && c->warmup_steps == 0 && c->num_vehicles >= 2 &&
+              c->num_vehicles <= 64 && (c->num_vehicles % 2) == 0 && c->vehicles;
+    for (int i = 0; ok && i < c->num_vehicles; ++i) {
+      const fs_vehicle_spec& v = c->vehicles[i];
+      ok = v.controller == FS_CTRL_IDM && !(v.noise > 0) && v.fail_safe == FS_FAILSAFE_NONE && v.speed_mode == 0;
+    }
+    if (!ok)
+      return fail(FS_ERR_UNSUPPORTED, "fs_create: FS_MIXED is built for the rollout path of single-lane rings with an "
+                                      "even number of plain IDM vehicles (speed mode 0, AccelEnv, no warm-up)");
+  }
   if (c->network < FS_NET_RING || c->network > FS_NET_BOTTLENECK)
     return fail(FS_ERR_UNSUPPORTED, "fs_create: network not built");
   const bool open_net = c->network == FS_NET_MERGE || c->network == FS_NET_BOTTLENECK;
@@ -936,6 +980,7 @@ int create_typed(const fs_config* cfg, fs_handle* out) {
   Sim<T>* s = new (std::nothrow) Sim<T>();
   if (!s) return fail(FS_ERR_HIP, "fs_create: out of host memory");
   s->cfg = *cfg;
+  s->mixed = cfg->precision == FS_MIXED;
   s->veh.assign(cfg->vehicles, cfg->vehicles + cfg->num_vehicles);
   if (cfg->num_segments > 0) s->segs.assign(cfg->segments, cfg->segments + cfg->num_segments);
   if (cfg->obs_perm) s->obs_perm.assign(cfg->obs_perm, cfg->obs_perm + cfg->num_vehicles);
@@ -970,6 +1015,13 @@ int create_typed(const fs_config* cfg, fs_handle* out) {
     s->force_generic = fg && fg[0] == '1';
     const char* nf = std::getenv("FLOWSIM_NO_FASTDIV");
     s->no_fastdiv = nf && nf[0] == '1';
+    const char* np = std::getenv("FLOWSIM_NO_PAIR");
+    s->no_pair = np && np[0] == '1';
+    const char* pb = std::getenv("FLOWSIM_PAIR_BLOCK");
+    if (pb) {
+      const int v = std::atoi(pb);
+      if (v >= 64 && v <= 256 && v % 64 == 0) s->pair_block = v;
+    }
     const char* rb = std::getenv("FLOWSIM_ROLLOUT_BLOCK");
     if (rb) {
       const int v = std::atoi(rb);
@@ -1018,7 +1070,7 @@ int fs_create(const fs_config* cfg, fs_handle* out) {
   *out = nullptr;
   int rc = validate(cfg);
   if (rc) return rc;
-  return cfg->precision == FS_F64 ? create_typed<double>(cfg, out) : create_typed<float>(cfg, out);
+  return cfg->precision == FS_F32 ? create_typed<float>(cfg, out) : create_typed<double>(cfg, out);
 }
 
 void fs_destroy(fs_handle h) {

@@ -1,0 +1,670 @@
+// flowsim_pair.h -- k_rollout_pair: the rollout kernel of the headline configuration, TWO vehicles per lane.
+//
+// Same configuration class as k_rollout_idm (every slot a plain IDMController, speed mode "aggressive", Euler,
+// sims_per_step 1, AccelEnv head, observation every step) for an EVEN number of vehicles.  What changes is the
+// mapping, chosen from the issue costs measured on gfx950 (scripts/ubench, profiles/r02_valu_issue_ubench.txt):
+// a wave that is alone on its SIMD issues ONE instruction per ~4.4 cycles whatever the instruction is, and at
+// BASELINE's 4096 replicas there is about one wave per SIMD -- so the lever is work per instruction:
+//   * lane k of a ROW-lane row holds vehicles 2k (A) and 2k+1 (B) of one replica; the mul / add / fma chains of
+//     the two run as ONE packed instruction (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 on a register pair);
+//   * the leader of A is B of the same lane (no cross-lane read); the leader of B is A of the next lane: one
+//     row shift (DPP row_shl:1) plus the wrap lane's broadcast of lane 0 (DPP row_newbcast) per quantity;
+//   * the first level of the reward tree (oracle/rewards.py tree_sum pairs (2k, 2k+1)) is an in-lane add;
+//   * a lane stores its two speeds and its two positions as one dwordx2 each, through a buffer descriptor whose
+//     scalar offset selects the step (no per-step address arithmetic in VALU or SALU).
+// Arithmetic per vehicle is the operation sequence of k_rollout_idm / oracle/refsim.py (float: bit-twin of the
+// float32 oracle), with one exception that is value-preserving: the speed observation v / max_speed is evaluated
+// through float64 (cvt, mul by RN(1/c), two fma, cvt) -- correctly rounded for EVERY float v including the
+// denormal range (exhaustively checked for the divisors of tests/test_oracle_c.py::test_div_via_f64), which
+// replaces the ten-instruction IEEE sequence.
+//
+// MIXED (state type double): positions and speeds are kept and integrated in float64, the controller (the IDM
+// acceleration) runs in float32 on their rounded images -- "fp32 physics on f64 accumulators".  This is the
+// precision that meets BASELINE's 1e-4 trajectory bar at fp32 cost: float32 state drifts ~5e-3 m from the
+// reference's float64 arithmetic over 1500 steps of the (string-unstable) sugiyama ring, the mixed form 4e-5 m
+// (oracle/csim refsim_ring_idm_mixed is its bit-twin; tests/test_pair_gpu.py).
+#pragma once
+#include "flowsim_kernels.h"
+
+namespace fs {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef unsigned u2v __attribute__((__vector_size__(8)));
+
+enum : int { DPP_ROW_NEWBCAST0 = 0x150, DPP_ROW_NEWBCAST8 = 0x158 };
+
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat(float a) { return f2{a, a}; }
+
+// packed float32 arithmetic of the C++ step (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32)
+__device__ __forceinline__ f2 pk_mul(f2 a, f2 b) { return a * b; }
+__device__ __forceinline__ f2 pk_add(f2 a, f2 b) { return a + b; }
+__device__ __forceinline__ f2 pk_sub(f2 a, f2 b) { return a - b; }
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return fma2(a, b, c); }
+__device__ __forceinline__ f2 pk_fnma(f2 a, f2 b, f2 c) { return fma2(-a, b, c); }
+// x >= 0 ? x : y for y >= 0 (and x never -0): negative floats compare above every non-negative one as unsigned
+// integers, so this is one v_min_u32 on the bit patterns when additionally x <= y whenever x >= 0
+__device__ __forceinline__ float nonneg_else(float x, float y) {
+  const unsigned a = __builtin_bit_cast(unsigned, x), b = __builtin_bit_cast(unsigned, y);
+  return __builtin_bit_cast(float, a < b ? a : b);
+}
+
+// value of slot A of the NEXT lane of the row (lane 0's for the last occupied lane and its idle clones)
+template <int ROW>
+__device__ __forceinline__ float next_a(float v, bool last, int lane) {
+  if (ROW == 16) {
+    const float t = dpp<DPP_ROW_SHL1>(v), w = dpp<DPP_ROW_NEWBCAST0>(v);
+    return last ? w : t;
+  } else if (ROW == 8) {
+    const float t = dpp<DPP_ROW_SHL1>(v), w0 = dpp<DPP_ROW_NEWBCAST0>(v), w8 = dpp<DPP_ROW_NEWBCAST8>(v);
+    return last ? ((lane & 8) ? w8 : w0) : t;
+  } else if (ROW == 32) {
+    const float t = dpp<DPP_WAVE_SHL1>(v), w0 = read_lane(v, 0), w1 = read_lane(v, 32);
+    return last ? ((lane & 32) ? w1 : w0) : t;
+  } else {
+    const float t = dpp<DPP_WAVE_SHL1>(v), w = read_lane(v, 0);
+    return last ? w : t;
+  }
+}
+template <int ROW>
+__device__ __forceinline__ double next_a(double v, bool last, int lane) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const float lo = next_a<ROW>(__builtin_bit_cast(float, unsigned(b)), last, lane);
+  const float hi = next_a<ROW>(__builtin_bit_cast(float, unsigned(b >> 32)), last, lane);
+  return __builtin_bit_cast(double, ((unsigned long long)__builtin_bit_cast(unsigned, hi) << 32) |
+                                        __builtin_bit_cast(unsigned, lo));
+}
+
+// x / c, correctly rounded to float for every float x (any sign, zero, denormal) and every normal float c:
+// q = RN64(x * RN64(1/c)) is within 2^-52 of the quotient, one fma pair makes it the correctly rounded float64
+// quotient up to 1 ulp64 and EXACT whenever the quotient is representable (the only way to sit on a float32
+// rounding boundary, ties of the denormal range included); otherwise the quotient of two 24-bit numbers stays
+// >= 2^-47 (relative) away from every boundary, so the second rounding cannot differ from a single one.
+__device__ __forceinline__ float div_via_f64(float x, double c, double rc) {
+  const double xd = double(x);
+  double q = xd * rc;
+  const double r = __builtin_fma(-q, c, xd);
+  q = __builtin_fma(r, rc, q);
+  return float(q);
+}
+
+template <bool FASTDIV>
+__device__ __forceinline__ f2 div_const2(f2 x, f2 c, f2 rc) {
+  if (FASTDIV) {
+    const f2 q0 = pk_mul(x, rc);
+    const f2 r = pk_fnma(q0, c, x);
+    return pk_fma(r, rc, q0);
+  }
+  return f2{x.x / c.x, x.y / c.y};
+}
+// div_core (flowsim_kernels.h) on a pair: two v_rcp_f32, the refinement packed
+__device__ __forceinline__ f2 div_core2(f2 n, f2 d, f2 one) {
+  const f2 y0 = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  const f2 e = pk_fnma(d, y0, one);
+  const f2 y = pk_fma(e, y0, y0);
+  const f2 q0 = pk_mul(n, y);
+  const f2 r0 = pk_fnma(d, q0, n);
+  const f2 q1 = pk_fma(r0, y, q0);
+  const f2 r1 = pk_fnma(d, q1, n);
+  return pk_fma(r1, y, q1);
+}
+
+// IDMController.get_accel for the two vehicles of a lane (ctrl_idm's operation order; car_following_models.py:464-482)
+template <bool DELTA4, bool FASTDIV>
+__device__ __forceinline__ f2 idm_pair(f2 v, f2 vl, f2 h, const f2* p, f2 two_sqrt_ab, f2 rc_ab, f2 rc_v0, f2 one) {
+  f2 hh;
+  hh.x = tabs(h.x) < 1e-3f ? 1e-3f : h.x;
+  hh.y = tabs(h.y) < 1e-3f ? 1e-3f : h.y;
+  const f2 num = pk_mul(v, pk_sub(v, vl));
+  const f2 dq = div_const2<FASTDIV>(num, two_sqrt_ab, rc_ab);
+  const f2 ratio = div_const2<FASTDIV>(v, p[0], rc_v0);
+  const f2 dyn = pk_add(pk_mul(v, p[1]), dq);
+  f2 s_star;
+  s_star.x = tmax(dyn.x, 0.0f);
+  s_star.y = tmax(dyn.y, 0.0f);
+  s_star = pk_add(p[5], s_star);
+  const f2 q = FASTDIV ? div_core2(s_star, hh, one) : f2{s_star.x / hh.x, s_star.y / hh.y};
+  f2 pw;
+  if (DELTA4) {
+    const f2 r2 = pk_mul(ratio, ratio);
+    pw = pk_mul(r2, r2);
+  } else {
+    pw = f2{pow_delta(ratio.x, p[4].x), pow_delta(ratio.y, p[4].y)};
+  }
+  return pk_mul(p[2], pk_sub(pk_sub(one, pw), pk_mul(q, q)));
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// One step of the float32 twin written out instruction by instruction (ROW = 16, delta = 4, exact reciprocal
+// divisions, no v < -100 check): the hot instantiation.  Why not leave it to hipcc: (1) its hazard recogniser
+// puts an `s_nop 0` between EVERY packed instruction and a consumer that follows directly (its "dst_sel
+// forwarding" rule reads VOP3P's op_sel_hi bit of src0 as a destination select; packed f32 writes whole
+// registers) -- 26 per step in the C++ form of this loop, and a wave that is alone on its SIMD pays a full
+// issue slot (~4.4 cycles, scripts/ubench) for each; wrapping the packed operations one per asm statement makes
+// it worse (every asm result is treated as such a hazard); (2) the leader differences fold their row shift into
+// the subtraction (v_sub_f32_dpp) and the wrap-around selects are integer minima, which it does not find.
+// The sequence is ctrl_idm / k_rollout_idm's operation order per vehicle; hazards kept by construction:
+//   v_cmp -> v_cndmask on that SGPR pair: >= 2 instructions between;  v_rcp_f32 -> first use: >= 4;
+//   VALU write -> DPP read of the register (v', x'): >= 8.
+// Register map (pinned so that the halves of a pair can be named): V v[112:113], X v[114:115], H v[116:117],
+// DVL (= v - v_leader) v[118:119], HH v[120:121], Y v[122:123], A v[124:125], B v[126:127], OV v[128:129],
+// C v[130:131], D v[132:133], E v[134:135], F v[136:137].
+struct PairConsts {
+  f2 p0, p1, p2, p5, rc_v0, tsab, rc_ab, one, dt2, ramp2, L2, rc_L2, len_lead, gap2, vmask, tvm;
+  float c1e3;
+  double ms64, rc_ms64;
+  unsigned long long last_mask;
+};
+// part A: controller, integration, position observation (stored by the caller between the two parts: the two
+// stores of a step reach the CU's memory pipeline half a step apart)
+__device__ __forceinline__ void pair_step_asm_a(f2& V, f2& X, f2& H, f2& DVL, f2& OX, const PairConsts& c) {
+  unsigned long long sa, sb;
+  asm volatile(
+      // ---- IDMController.get_accel
+      "v_cmp_nlt_f32_e64 %[sa], |v116|, %[c1e3]\n"
+      "v_cmp_nlt_f32_e64 %[sb], |v117|, %[c1e3]\n"
+      "v_pk_mul_f32 v[124:125], v[112:113], v[118:119]\n"                                   // num = v (v - vl)
+      "v_pk_mul_f32 v[126:127], v[124:125], %[rcab]\n"
+      "v_pk_fma_f32 v[130:131], v[126:127], %[tsab], v[124:125] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+      "v_pk_fma_f32 v[126:127], v[130:131], %[rcab], v[126:127]\n"                          // B = num / 2sqrt(ab)
+      "v_cndmask_b32_e64 v120, %[c1e3], v116, %[sa]\n"                                      // hh
+      "v_cndmask_b32_e64 v121, %[c1e3], v117, %[sb]\n"
+      "v_pk_mul_f32 v[124:125], v[112:113], %[rcv0]\n"
+      "v_rcp_f32_e32 v122, v120\n"
+      "v_rcp_f32_e32 v123, v121\n"
+      "v_pk_fma_f32 v[130:131], v[124:125], %[p0], v[112:113] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+      "v_pk_fma_f32 v[124:125], v[130:131], %[rcv0], v[124:125]\n"                          // A = v / v0
+      "v_pk_mul_f32 v[130:131], v[112:113], %[p1]\n"
+      "v_pk_add_f32 v[130:131], v[130:131], v[126:127]\n"                                   // C = dyn
+      "v_pk_fma_f32 v[126:127], v[120:121], v[122:123], %[one] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"   // e
+      "v_max_f32_e32 v130, 0, v130\n"
+      "v_max_f32_e32 v131, 0, v131\n"
+      "v_pk_fma_f32 v[122:123], v[126:127], v[122:123], v[122:123]\n"                       // Y = refined 1/hh
+      "v_pk_add_f32 v[130:131], %[p5], v[130:131]\n"                                        // C = s*
+      "v_pk_mul_f32 v[124:125], v[124:125], v[124:125]\n"
+      "v_pk_mul_f32 v[126:127], v[130:131], v[122:123]\n"                                   // q0
+      "v_pk_mul_f32 v[124:125], v[124:125], v[124:125]\n"                                   // A = (v/v0)^4
+      "v_pk_fma_f32 v[132:133], v[120:121], v[126:127], v[130:131] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+      "v_pk_add_f32 v[124:125], %[one], v[124:125] neg_lo:[0,1] neg_hi:[0,1]\n"             // A = 1 - pw
+      "v_pk_fma_f32 v[126:127], v[132:133], v[122:123], v[126:127]\n"                       // q1
+      "v_pk_fma_f32 v[132:133], v[120:121], v[126:127], v[130:131] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+      "v_pk_fma_f32 v[126:127], v[132:133], v[122:123], v[126:127]\n"                       // B = s* / hh
+      "v_pk_mul_f32 v[126:127], v[126:127], v[126:127]\n"
+      "v_pk_add_f32 v[124:125], v[124:125], v[126:127] neg_lo:[0,1] neg_hi:[0,1]\n"
+      "v_pk_mul_f32 v[124:125], %[p2], v[124:125]\n"                                        // A = acc
+      // ---- apply_acceleration + integration (S4-S9)
+      "v_pk_mul_f32 v[124:125], v[124:125], %[dt2]\n"
+      "v_pk_add_f32 v[124:125], v[112:113], v[124:125]\n"
+      "v_max_f32_e32 v124, 0, v124\n"
+      "v_max_f32_e32 v125, 0, v125\n"                                                       // next_vel
+      "v_pk_add_f32 v[124:125], v[124:125], v[112:113] neg_lo:[0,1] neg_hi:[0,1]\n"
+      "v_pk_mul_f32 v[124:125], v[124:125], %[ramp2]\n"
+      "v_pk_add_f32 v[112:113], v[112:113], v[124:125]\n"                                   // V = v'
+      "v_pk_mul_f32 v[124:125], v[112:113], %[dt2]\n"
+      "v_pk_add_f32 v[124:125], v[114:115], v[124:125]\n"                                   // x_new
+      "v_pk_add_f32 v[126:127], v[124:125], %[L2] neg_lo:[0,1] neg_hi:[0,1]\n"              // x_new - L
+      "v_min_u32_e32 v114, v126, v124\n"                                                    // X = x'
+      "v_min_u32_e32 v115, v127, v125\n"
+      // ---- observation x'/L
+      "v_pk_mul_f32 v[124:125], v[114:115], %[rcL2]\n"
+      "v_pk_fma_f32 v[126:127], v[124:125], %[L2], v[114:115] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+      "v_pk_fma_f32 %[ox], v[126:127], %[rcL2], v[124:125]\n"
+      : "+{v[112:113]}"(V), "+{v[114:115]}"(X), "+{v[116:117]}"(H), "+{v[118:119]}"(DVL), [ox] "=&v"(OX),
+        [sa] "=&s"(sa), [sb] "=&s"(sb)
+      : [c1e3] "v"(c.c1e3), [rcab] "v"(c.rc_ab), [tsab] "v"(c.tsab), [rcv0] "v"(c.rc_v0), [p0] "v"(c.p0),
+        [p1] "v"(c.p1), [p2] "v"(c.p2), [p5] "v"(c.p5), [one] "v"(c.one), [dt2] "v"(c.dt2), [ramp2] "v"(c.ramp2),
+        [L2] "v"(c.L2), [rcL2] "v"(c.rc_L2)
+      : "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v130", "v131", "v132", "v133");
+}
+// part B: new neighbour snapshot, collision bit, reward term, speed observation
+__device__ __forceinline__ void pair_step_asm_b(f2& V, f2& X, f2& H, f2& DVL, f2& OV, unsigned& crash_bits, float& sq,
+                                                const PairConsts& c) {
+  asm volatile(
+      // ---- new snapshot (S10): v - v_leader and the gaps, leader of B = A of the next lane (lane 0 for the last)
+      "v_sub_f32_e32 v118, v112, v113\n"
+      "v_sub_f32_e32 v132, v115, v114\n"
+      "v_subrev_f32_dpp v119, v112, v113 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_subrev_f32_dpp v134, v112, v113 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+      "v_sub_f32_dpp v133, v114, v115 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_sub_f32_dpp v135, v114, v115 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+      "v_cndmask_b32_e64 v119, v119, v134, %[last]\n"
+      "v_cndmask_b32_e64 v133, v133, v135, %[last]\n"
+      "v_pk_add_f32 v[126:127], v[132:133], %[L2]\n"                                        // d + L
+      "v_min_u32_e32 v132, v132, v126\n"
+      "v_min_u32_e32 v133, v133, v127\n"
+      "v_pk_add_f32 v[116:117], v[132:133], %[lenlead] neg_lo:[0,1] neg_hi:[0,1]\n"         // H = new headways
+      // ---- collision (S12): sign of min(h - crash_gap)
+      "v_pk_add_f32 v[126:127], v[116:117], %[gap2] neg_lo:[0,1] neg_hi:[0,1]\n"
+      "v_min_f32_e32 v126, v126, v127\n"
+      "v_alignbit_b32 %[cb], %[cb], v126, 31\n"
+      // ---- reward term (v - target)^2 of both vehicles, added
+      "v_pk_fma_f32 v[124:125], v[112:113], %[vmask], %[tvm]\n"
+      "v_pk_mul_f32 v[124:125], v[124:125], v[124:125]\n"
+      "v_add_f32_e32 %[sq], v124, v125\n"
+      // ---- observation v'/max_speed through float64 (div_via_f64)
+      "v_cvt_f64_f32_e32 v[130:131], v112\n"
+      "v_cvt_f64_f32_e32 v[132:133], v113\n"
+      "v_mul_f64 v[134:135], v[130:131], %[rcms]\n"
+      "v_mul_f64 v[136:137], v[132:133], %[rcms]\n"
+      "v_fma_f64 v[130:131], -v[134:135], %[ms], v[130:131]\n"
+      "v_fma_f64 v[132:133], -v[136:137], %[ms], v[132:133]\n"
+      "v_fma_f64 v[134:135], v[130:131], %[rcms], v[134:135]\n"
+      "v_fma_f64 v[136:137], v[132:133], %[rcms], v[136:137]\n"
+      "v_cvt_f32_f64_e32 v128, v[134:135]\n"
+      "v_cvt_f32_f64_e32 v129, v[136:137]\n"
+      : "+{v[112:113]}"(V), "+{v[114:115]}"(X), "+{v[116:117]}"(H), "+{v[118:119]}"(DVL), "={v[128:129]}"(OV),
+        [cb] "+v"(crash_bits), [sq] "=&v"(sq)
+      : [L2] "v"(c.L2), [lenlead] "v"(c.len_lead), [gap2] "v"(c.gap2), [vmask] "v"(c.vmask), [tvm] "v"(c.tvm),
+        [ms] "v"(c.ms64), [rcms] "v"(c.rc_ms64), [last] "s"(c.last_mask)
+      : "v124", "v125", "v126", "v127", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137");
+}
+
+// The FS_MIXED step (state float64, controller float32), same construction.  Register map: V32 (float images of
+// the speeds) v[112:113], XA v[114:115], XB v[116:117] (positions, float64), VA v[118:119], VB v[138:139] (speeds,
+// float64), H v[140:141], DVL v[142:143], HH v[120:121], Y v[122:123], A v[124:125], B v[126:127], OV v[128:129],
+// C v[130:131], D v[132:133], E v[134:135], F v[136:137], OXr v[144:145].
+struct MixedConsts {
+  f2 p0, p1, p2, p5, rc_v0, tsab, rc_ab, one, gap2, vmask, tvm;
+  float c1e3;
+  double dt, ramp, L, rc_L, rc_ms, len_b, len_next, zero;
+  unsigned long long last_mask;
+};
+__device__ __forceinline__ void mixed_step_asm_a(f2& V32, double& XA, double& XB, double& VA, double& VB, f2& H, f2& DVL,
+                                                 f2& OV, const MixedConsts& c) {
+  unsigned long long sa, sb;
+  asm volatile(
+      // ---- IDMController.get_accel in float32 on the rounded speeds / headways (as pair_step_asm)
+      "v_cmp_nlt_f32_e64 %[sa], |v140|, %[c1e3]\n"
+      "v_cmp_nlt_f32_e64 %[sb], |v141|, %[c1e3]\n"
+      "v_pk_mul_f32 v[124:125], v[112:113], v[142:143]\n"
+      "v_pk_mul_f32 v[126:127], v[124:125], %[rcab]\n"
+      "v_pk_fma_f32 v[130:131], v[126:127], %[tsab], v[124:125] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+      "v_pk_fma_f32 v[126:127], v[130:131], %[rcab], v[126:127]\n"
+      "v_cndmask_b32_e64 v120, %[c1e3], v140, %[sa]\n"
+      "v_cndmask_b32_e64 v121, %[c1e3], v141, %[sb]\n"
+      "v_pk_mul_f32 v[124:125], v[112:113], %[rcv0]\n"
+      "v_rcp_f32_e32 v122, v120\n"
+      "v_rcp_f32_e32 v123, v121\n"
+      "v_pk_fma_f32 v[130:131], v[124:125], %[p0], v[112:113] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+      "v_pk_fma_f32 v[124:125], v[130:131], %[rcv0], v[124:125]\n"
+      "v_pk_mul_f32 v[130:131], v[112:113], %[p1]\n"
+      "v_pk_add_f32 v[130:131], v[130:131], v[126:127]\n"
+      "v_pk_fma_f32 v[126:127], v[120:121], v[122:123], %[one] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+      "v_max_f32_e32 v130, 0, v130\n"
+      "v_max_f32_e32 v131, 0, v131\n"
+      "v_pk_fma_f32 v[122:123], v[126:127], v[122:123], v[122:123]\n"
+      "v_pk_add_f32 v[130:131], %[p5], v[130:131]\n"
+      "v_pk_mul_f32 v[124:125], v[124:125], v[124:125]\n"
+      "v_pk_mul_f32 v[126:127], v[130:131], v[122:123]\n"
+      "v_pk_mul_f32 v[124:125], v[124:125], v[124:125]\n"
+      "v_pk_fma_f32 v[132:133], v[120:121], v[126:127], v[130:131] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+      "v_pk_add_f32 v[124:125], %[one], v[124:125] neg_lo:[0,1] neg_hi:[0,1]\n"
+      "v_pk_fma_f32 v[126:127], v[132:133], v[122:123], v[126:127]\n"
+      "v_pk_fma_f32 v[132:133], v[120:121], v[126:127], v[130:131] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+      "v_pk_fma_f32 v[126:127], v[132:133], v[122:123], v[126:127]\n"
+      "v_pk_mul_f32 v[126:127], v[126:127], v[126:127]\n"
+      "v_pk_add_f32 v[124:125], v[124:125], v[126:127] neg_lo:[0,1] neg_hi:[0,1]\n"
+      "v_pk_mul_f32 v[124:125], %[p2], v[124:125]\n"                                        // A = acc (float32)
+      // ---- apply_acceleration + integration (S4-S9) in float64
+      "v_cvt_f64_f32_e32 v[130:131], v124\n"
+      "v_cvt_f64_f32_e32 v[132:133], v125\n"
+      "v_mul_f64 v[130:131], v[130:131], %[dt]\n"
+      "v_mul_f64 v[132:133], v[132:133], %[dt]\n"
+      "v_add_f64 v[130:131], v[118:119], v[130:131]\n"
+      "v_add_f64 v[132:133], v[138:139], v[132:133]\n"
+      "v_max_f64 v[130:131], v[130:131], %[zero]\n"                                        // next_vel
+      "v_max_f64 v[132:133], v[132:133], %[zero]\n"
+      "v_add_f64 v[130:131], v[130:131], -v[118:119]\n"
+      "v_add_f64 v[132:133], v[132:133], -v[138:139]\n"
+      "v_mul_f64 v[130:131], v[130:131], %[ramp]\n"
+      "v_mul_f64 v[132:133], v[132:133], %[ramp]\n"
+      "v_add_f64 v[118:119], v[118:119], v[130:131]\n"                                      // VA = v'
+      "v_add_f64 v[138:139], v[138:139], v[132:133]\n"                                      // VB
+      "v_mul_f64 v[130:131], v[118:119], %[dt]\n"
+      "v_mul_f64 v[132:133], v[138:139], %[dt]\n"
+      "v_add_f64 v[130:131], v[114:115], v[130:131]\n"                                      // x_new
+      "v_add_f64 v[132:133], v[116:117], v[132:133]\n"
+      "v_add_f64 v[134:135], v[130:131], -%[L]\n"                                           // x_new - L
+      "v_add_f64 v[136:137], v[132:133], -%[L]\n"
+      "v_cvt_f32_f64_e32 v112, v[118:119]\n"                                                // V32 = float images
+      "v_cvt_f32_f64_e32 v113, v[138:139]\n"
+      "v_cmp_gt_i32_e64 %[sa], 0, v135\n"                                                   // x_new - L < 0 (sign)
+      "v_cmp_gt_i32_e64 %[sb], 0, v137\n"
+      "v_mul_f64 v[120:121], v[118:119], %[rcms]\n"                                         // observation v' / max_speed
+      "v_mul_f64 v[122:123], v[138:139], %[rcms]\n"
+      "v_cndmask_b32_e64 v114, v134, v130, %[sa]\n"                                         // XA = x'
+      "v_cndmask_b32_e64 v115, v135, v131, %[sa]\n"
+      "v_cndmask_b32_e64 v116, v136, v132, %[sb]\n"                                         // XB
+      "v_cndmask_b32_e64 v117, v137, v133, %[sb]\n"
+      "v_cvt_f32_f64_e32 v128, v[120:121]\n"
+      "v_cvt_f32_f64_e32 v129, v[122:123]\n"
+      : "+{v[112:113]}"(V32), "+{v[114:115]}"(XA), "+{v[116:117]}"(XB), "+{v[118:119]}"(VA), "+{v[138:139]}"(VB),
+        "+{v[140:141]}"(H), "+{v[142:143]}"(DVL), "={v[128:129]}"(OV), [sa] "=&s"(sa), [sb] "=&s"(sb)
+      : [c1e3] "v"(c.c1e3), [rcab] "v"(c.rc_ab), [tsab] "v"(c.tsab), [rcv0] "v"(c.rc_v0), [p0] "v"(c.p0),
+        [p1] "v"(c.p1), [p2] "v"(c.p2), [p5] "v"(c.p5), [one] "v"(c.one), [dt] "v"(c.dt), [ramp] "v"(c.ramp),
+        [L] "v"(c.L), [rcms] "v"(c.rc_ms), [zero] "v"(c.zero)
+      : "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v130", "v131", "v132", "v133", "v134",
+        "v135", "v136", "v137");
+}
+__device__ __forceinline__ void mixed_step_asm_b(f2& V32, double& XA, double& XB, f2& H, f2& DVL, f2& OX,
+                                                 unsigned& crash_bits, float& sq, const MixedConsts& c) {
+  unsigned long long sa, sb;
+  asm volatile(
+      // ---- new snapshot: v - v_leader (float32 images), gaps in float64
+      "v_sub_f32_e32 v142, v112, v113\n"
+      "v_subrev_f32_dpp v143, v112, v113 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_subrev_f32_dpp v124, v112, v113 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+      "v_mov_b32_dpp v130, v114 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"        // position of the next lane's A
+      "v_mov_b32_dpp v131, v115 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_mov_b32_dpp v132, v114 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+      "v_mov_b32_dpp v133, v115 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+      "v_cndmask_b32_e64 v143, v143, v124, %[last]\n"
+      "v_cndmask_b32_e64 v130, v130, v132, %[last]\n"
+      "v_cndmask_b32_e64 v131, v131, v133, %[last]\n"
+      "v_mul_f64 v[120:121], v[114:115], %[rcL]\n"                                          // observation x' / L
+      "v_mul_f64 v[122:123], v[116:117], %[rcL]\n"
+      "v_add_f64 v[134:135], v[116:117], -v[114:115]\n"                                     // dA = xB - xA
+      "v_add_f64 v[136:137], v[130:131], -v[116:117]\n"                                     // dB = x_next - xB
+      "v_cvt_f32_f64_e32 v144, v[120:121]\n"
+      "v_cvt_f32_f64_e32 v145, v[122:123]\n"
+      "v_add_f64 v[130:131], v[134:135], %[L]\n"
+      "v_add_f64 v[132:133], v[136:137], %[L]\n"
+      "v_cmp_gt_i32_e64 %[sa], 0, v135\n"                                                   // d < 0 (d is never -0)
+      "v_cmp_gt_i32_e64 %[sb], 0, v137\n"
+      "v_pk_fma_f32 v[124:125], v[112:113], %[vmask], %[tvm]\n"                             // reward term
+      "v_pk_mul_f32 v[124:125], v[124:125], v[124:125]\n"
+      "v_cndmask_b32_e64 v134, v134, v130, %[sa]\n"
+      "v_cndmask_b32_e64 v135, v135, v131, %[sa]\n"
+      "v_cndmask_b32_e64 v136, v136, v132, %[sb]\n"
+      "v_cndmask_b32_e64 v137, v137, v133, %[sb]\n"
+      "v_add_f32_e32 %[sq], v124, v125\n"
+      "v_add_f64 v[134:135], v[134:135], -%[lenb]\n"
+      "v_add_f64 v[136:137], v[136:137], -%[lennext]\n"
+      "v_cvt_f32_f64_e32 v140, v[134:135]\n"                                                // H = new headways (float32)
+      "v_cvt_f32_f64_e32 v141, v[136:137]\n"
+      // ---- collision (S12)
+      "v_pk_add_f32 v[126:127], v[140:141], %[gap2] neg_lo:[0,1] neg_hi:[0,1]\n"
+      "v_min_f32_e32 v126, v126, v127\n"
+      "v_alignbit_b32 %[cb], %[cb], v126, 31\n"
+      : "+{v[112:113]}"(V32), "+{v[114:115]}"(XA), "+{v[116:117]}"(XB), "+{v[140:141]}"(H), "+{v[142:143]}"(DVL),
+        "={v[144:145]}"(OX), [cb] "+v"(crash_bits), [sq] "=&v"(sq), [sa] "=&s"(sa), [sb] "=&s"(sb)
+      : [L] "v"(c.L), [rcL] "v"(c.rc_L), [gap2] "v"(c.gap2), [vmask] "v"(c.vmask), [tvm] "v"(c.tvm),
+        [lenb] "v"(c.len_b), [lennext] "v"(c.len_next), [last] "s"(c.last_mask)
+      : "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v130", "v131", "v132", "v133", "v134",
+        "v135", "v136", "v137");
+}
+
+// T = float: the float32 bit-twin.  T = double: MIXED (see the header).  ROW = lanes per replica (N <= 2 ROW).
+template <typename T, int ROW, bool DELTA4, bool FASTDIV, bool BADCHK>
+__global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_steps, float* __restrict__ obs,
+                                                      float* __restrict__ rew, uint8_t* __restrict__ done) {
+  constexpr bool MIXED = sizeof(T) == 8;
+  constexpr bool ASM = ROW == 16 && DELTA4 && FASTDIV && !BADCHK;     // pair_step_asm / mixed_step_asm
+  constexpr int RPW = 64 / ROW;
+  constexpr int PERIOD = ROW < 16 ? ROW : 16;       // steps whose reward tail is finished together
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int row = lane / ROW;
+  const int k = lane % ROW;
+  const int r = wave * RPW + row;
+  const int N = s.N;
+  const int LP = N >> 1;                            // occupied lanes of a row (N is even: host-checked)
+  const bool rvalid = r < s.R;
+  const bool valid = rvalid && k < LP;
+  // idle lanes (k >= LP, or a replica index past R) are exact clones of lane LP-1 / replica R-1: same state, same
+  // leader, same parameters -- they compute and store the SAME values to the SAME addresses, never masked off
+  const int rr = rvalid ? r : s.R - 1;
+  const int kk = k < LP ? k : LP - 1;
+  const bool last = (kk == LP - 1);                 // B's leader is slot 0 (lane 0 of the row)
+  const int iA = 2 * kk, iB = iA + 1;
+  const size_t idx = size_t(rr) * N + iA;
+
+  f2 p[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) p[q] = f2{float(s.p[q * N + iA]), float(s.p[q * N + iB])};
+  const T lenB = s.length[iB];
+  const T len_nextA = next_a<ROW>(T(s.length[iA]), last, lane);
+  const T base_len = s.ring_len[rr];
+  const T L = base_len + T(4) * s.jlen;
+  int tcount = s.time[rr];
+
+  const float dt = float(s.dt), ramp = float(s.ramp);
+  const f2 two_sqrt_ab = {2.0f * tsqrt(p[2].x * p[3].x), 2.0f * tsqrt(p[2].y * p[3].y)};
+  const f2 rc_v0 = {1.0f / p[0].x, 1.0f / p[0].y}, rc_ab = {1.0f / two_sqrt_ab.x, 1.0f / two_sqrt_ab.y};
+  const float Lf = float(L);
+  const f2 L2 = splat(Lf), rc_L2 = splat(1.0f / Lf), one = splat(1.0f), dt2 = splat(dt), ramp2 = splat(ramp);
+  const f2 gap2 = splat(float(s.crash_gap)), m100 = splat(-100.0f);
+  // reward terms of idle lanes are zero: (v - target)^2 is formed as fma(v, m, -target m) with m = 1 (valid: the
+  // product v * 1 is exact, so the fma rounds v - target once, as the subtraction does) or m = 0
+  const f2 vmask = splat(valid ? 1.0f : 0.0f), tvm = splat(valid ? -float(s.target_velocity) : 0.0f);
+  const double ms64 = double(s.max_speed), rc_ms64 = 1.0 / ms64;
+  const double L64 = double(L), rc_L64 = 1.0 / L64, dt64 = double(s.dt), ramp64 = double(s.ramp);
+
+  // state: float pairs (twin) or two doubles + their float images (mixed)
+  f2 x, v;                       // float32 images (twin: THE state)
+  double xdA = 0, xdB = 0, vdA = 0, vdB = 0;
+  if (MIXED) {
+    xdA = double(s.pos[idx]); xdB = double(s.pos[idx + 1]);
+    vdA = double(s.vel[idx]); vdB = double(s.vel[idx + 1]);
+    v = f2{float(vdA), float(vdB)};
+    x = f2{0.0f, 0.0f};
+  } else {
+    x = f2{float(s.pos[idx]), float(s.pos[idx + 1])};
+    v = f2{float(s.vel[idx]), float(s.vel[idx + 1])};
+  }
+  const f2 len_lead = {float(lenB), float(len_nextA)};
+
+  // headways of the current snapshot (S10)
+  auto headway = [&]() -> f2 {
+    if (MIXED) {
+      const double xn = next_a<ROW>(xdA, last, lane);
+      double dA = xdB - xdA, dB = xn - xdB;
+      dA = dA < 0.0 ? dA + L64 : dA;
+      dB = dB < 0.0 ? dB + L64 : dB;
+      return f2{float(dA - double(lenB)), float(dB - double(len_nextA))};
+    } else {
+      const f2 xl = {x.y, next_a<ROW>(x.x, last, lane)};
+      f2 d = pk_sub(xl, x);
+      const f2 dw = pk_add(d, L2);                 // d < 0 ? d + L : d  (d in (-L, L), never -0; d + L > d)
+      d.x = nonneg_else(d.x, dw.x);
+      d.y = nonneg_else(d.y, dw.y);
+      return pk_sub(d, len_lead);
+    }
+  };
+  f2 h = headway();
+  f2 vl = {v.y, next_a<ROW>(v.x, last, lane)};
+  f2 dvl = v - vl;                                          // ASM path carries v - v_leader instead of v_leader
+  PairConsts pc;
+  pc.p0 = p[0]; pc.p1 = p[1]; pc.p2 = p[2]; pc.p5 = p[5]; pc.rc_v0 = rc_v0; pc.tsab = two_sqrt_ab; pc.rc_ab = rc_ab;
+  pc.one = one; pc.dt2 = dt2; pc.ramp2 = ramp2; pc.L2 = L2; pc.rc_L2 = rc_L2; pc.len_lead = len_lead;
+  pc.gap2 = gap2; pc.vmask = vmask; pc.tvm = tvm; pc.c1e3 = 1e-3f; pc.ms64 = ms64; pc.rc_ms64 = rc_ms64;
+  pc.last_mask = __ballot(last);
+  MixedConsts mc;
+  mc.p0 = p[0]; mc.p1 = p[1]; mc.p2 = p[2]; mc.p5 = p[5]; mc.rc_v0 = rc_v0; mc.tsab = two_sqrt_ab; mc.rc_ab = rc_ab;
+  mc.one = one; mc.gap2 = gap2; mc.vmask = vmask; mc.tvm = tvm; mc.c1e3 = 1e-3f; mc.dt = dt64; mc.ramp = ramp64;
+  mc.L = L64; mc.rc_L = rc_L64; mc.rc_ms = rc_ms64; mc.len_b = double(lenB); mc.len_next = double(len_nextA);
+  mc.zero = 0.0; mc.last_mask = pc.last_mask;
+
+  // observation stores: buffer descriptor over the PERIOD-step block being written + per-lane byte offsets; the
+  // scalar offset of an unrolled step is a launch constant (slot * bytes per step)
+  const unsigned rowb = 2u * unsigned(N) * 4u;                              // bytes of one replica's observation
+#ifdef FS_DIAG_OOB
+  const unsigned off_v = valid ? unsigned(rr) * rowb + unsigned(iA) * 4u : 0xFFFFFF00u;
+  const unsigned off_x = valid ? off_v + unsigned(N) * 4u : 0xFFFFFF00u;
+#else
+  const unsigned off_v = unsigned(rr) * rowb + unsigned(iA) * 4u;           // BYTE offsets: host guarantees < 2^32
+  const unsigned off_x = off_v + unsigned(N) * 4u;
+#endif
+  const size_t step_bytes = size_t(s.R) * rowb;
+  const unsigned step_b32 = unsigned(step_bytes);                           // PERIOD * step_bytes < 2^32 (host)
+  char* ob = reinterpret_cast<char*>(obs);
+  unsigned crash_bits = 0u, bad_bits = 0u;
+
+  auto one_step = [&](int slot, __amdgpu_buffer_rsrc_t rs, float& sq_out) {
+    if constexpr (ASM) {
+      f2 ov, ox;
+      const unsigned so = unsigned(slot) * step_b32;
+      if constexpr (MIXED) {
+        mixed_step_asm_a(v, xdA, xdB, vdA, vdB, h, dvl, ov, mc);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, ov), rs, off_v, so, 0);
+        mixed_step_asm_b(v, xdA, xdB, h, dvl, ox, crash_bits, sq_out, mc);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, ox), rs, off_x, so, 0);
+      } else {
+#if defined(FS_DIAG_X4)       // timing experiment: ONE 16-byte store per lane and step (wrong layout)
+        pair_step_asm_a(v, x, h, dvl, ox, pc);
+        pair_step_asm_b(v, x, h, dvl, ov, crash_bits, sq_out, pc);
+        typedef unsigned u4v_ __attribute__((__vector_size__(16)));
+        const u4v_ d4 = {__builtin_bit_cast(unsigned, ov.x), __builtin_bit_cast(unsigned, ov.y),
+                         __builtin_bit_cast(unsigned, ox.x), __builtin_bit_cast(unsigned, ox.y)};
+        __builtin_amdgcn_raw_buffer_store_b128(d4, rs, unsigned(wave) * 1024u + unsigned(lane) * 16u, so, 0);
+#elif defined(FS_DIAG_NOSTORE)
+        pair_step_asm_a(v, x, h, dvl, ox, pc);
+        pair_step_asm_b(v, x, h, dvl, ov, crash_bits, sq_out, pc);
+        asm volatile("" :: "v"(ov), "v"(ox), "s"(so));
+#else
+        pair_step_asm_a(v, x, h, dvl, ox, pc);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, ox), rs, off_x, so, 0);
+        pair_step_asm_b(v, x, h, dvl, ov, crash_bits, sq_out, pc);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, ov), rs, off_v, so, 0);
+#endif
+      }
+      return;
+    }
+    // IDMController.get_accel on the snapshot
+    const f2 acc = idm_pair<DELTA4, FASTDIV>(v, vl, h, p, two_sqrt_ab, rc_ab, rc_v0, one);
+    f2 ox;
+    if (MIXED) {
+      // apply_acceleration + integration (S4-S9) in float64 on the float32 acceleration
+      const double aA = double(acc.x), aB = double(acc.y);
+      const double nA = tmax(vdA + aA * dt64, 0.0), nB = tmax(vdB + aB * dt64, 0.0);
+      vdA = vdA + (nA - vdA) * ramp64;
+      vdB = vdB + (nB - vdB) * ramp64;
+      const double xA = xdA + vdA * dt64, xB = xdB + vdB * dt64;
+      xdA = xA >= L64 ? xA - L64 : xA;
+      xdB = xB >= L64 ? xB - L64 : xB;
+      v = f2{float(vdA), float(vdB)};
+      ox = f2{float(xdA * rc_L64), float(xdB * rc_L64)};
+    } else {
+      f2 nv = pk_add(v, pk_mul(acc, dt2));
+      nv.x = tmax(nv.x, 0.0f);
+      nv.y = tmax(nv.y, 0.0f);
+      v = pk_add(v, pk_mul(pk_sub(nv, v), ramp2));
+      const f2 xn = pk_add(x, pk_mul(v, dt2));
+      const f2 xw = pk_sub(xn, L2);                  // x_new >= L ? x_new - L : x_new  (0 <= x_new - L < x_new)
+      x.x = nonneg_else(xw.x, xn.x);
+      x.y = nonneg_else(xw.y, xn.y);
+      ox = div_const2<FASTDIV>(x, L2, rc_L2);
+    }
+    // new neighbour snapshot (S10)
+    h = headway();
+    vl = f2{v.y, next_a<ROW>(v.x, last, lane)};
+    // collision (S12): sign of h - crash_gap (h < gap  <=>  the difference is negative: no -0 from a non-zero
+    // difference, denormals are kept); bit (PERIOD-1-slot) of crash_bits after the block
+    // (the smaller of the two differences carries the sign: written as bits(a) | bits(b), hipcc 7.2 drops the
+    // second operand -- "or of two bitcast vector elements, only bit 31 demanded" is miscompiled, found by
+    // tests/test_pair_gpu.py::test_pair_f32_per_slot_parameters_lengths_and_crashes)
+    const f2 hc = pk_sub(h, gap2);
+    crash_bits = __builtin_amdgcn_alignbit(crash_bits, __builtin_bit_cast(unsigned, __builtin_fminf(hc.x, hc.y)), 31);
+    if (BADCHK) {
+      const f2 vb = pk_sub(v, m100);
+      bad_bits = __builtin_amdgcn_alignbit(bad_bits, __builtin_bit_cast(unsigned, __builtin_fminf(vb.x, vb.y)), 31);
+    }
+    // AccelEnv.get_state (accel.py:116-123)
+    f2 ov;
+    if (MIXED) ov = f2{float(vdA * rc_ms64), float(vdB * rc_ms64)};
+    else ov = f2{div_via_f64(v.x, ms64, rc_ms64), div_via_f64(v.y, ms64, rc_ms64)};
+    const unsigned so = unsigned(slot) * step_b32;
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, ov), rs, off_v, so, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, ox), rs, off_x, so, 0);
+    // rewards.desired_velocity, first half: the lane's two terms, added (first level of the tree)
+    const f2 dv = pk_fma(v, vmask, tvm);
+    const f2 sq = pk_mul(dv, dv);
+    sq_out = sq.x + sq.y;
+  };
+
+#ifdef FS_DIAG_STAGGER
+  // timing experiment: the waves of a workgroup start FS_DIAG_STAGGER x 64 cycles apart
+  for (int w = 0; w < int(threadIdx.x >> 6); ++w) __builtin_amdgcn_s_sleep(FS_DIAG_STAGGER);
+#endif
+#ifdef FS_DIAG_STAGGER_CU
+  for (int w = 0; w < int(blockIdx.x % FS_DIAG_STAGGER_MOD); ++w) __builtin_amdgcn_s_sleep(FS_DIAG_STAGGER_CU);
+#endif
+  // full blocks of PERIOD steps: straight-line code, rewards finished PERIOD at a time
+  int base = 0;
+  for (; base + PERIOD <= num_steps; base += PERIOD) {
+    float sq[PERIOD];
+    const size_t remain = size_t(num_steps - base) * step_bytes;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        ob, 0, remain > 0xFFFFFFFFull ? 0xFFFFFFFFu : unsigned(remain), 0x00020000);
+#pragma unroll
+    for (int slot = 0; slot < PERIOD; ++slot) one_step(slot, rs, sq[slot]);
+    ob += size_t(PERIOD) * step_bytes;
+    tcount += PERIOD;
+    const float racc = transposed_sum<ROW, PERIOD>(sq, lane);
+    const unsigned crash_any = seg_or<ROW>(crash_bits);
+    const unsigned bad_any = (BADCHK ? seg_or<ROW>(bad_bits) : 0u) | crash_any;    // v + 100 < 0  <=>  sign set
+    crash_bits = 0u;
+    bad_bits = 0u;
+    if (rvalid && k < PERIOD) {                            // lane k finishes step k of the block
+      const bool my_crash = (crash_any >> (PERIOD - 1 - k)) & 1u;
+      const bool my_bad = (bad_any >> (PERIOD - 1 - k)) & 1u;
+      const int t_k = tcount - (PERIOD - 1 - k);           // time counter after that step
+      const float cost = tsqrt(racc);
+      const float max_cost = float(s.max_cost);
+      float reward = tmax(max_cost - cost, 0.0f) / (max_cost + 1.1920928955078125e-07f);   // rewards.py:59
+      reward = my_bad ? 0.0f : reward;                                                     // rewards.py:46
+      const size_t o = size_t(base + k) * s.R + rr;
+      rew[o] = reward;
+      done[o] = uint8_t((t_k >= s.step_limit) || my_crash);                                // envs/base.py:398-400
+    }
+  }
+  // the remaining num_steps % PERIOD steps one at a time (same tree: seg_sum is transposed_sum's order)
+#pragma unroll 1
+  for (; base < num_steps; ++base) {
+    float sq1;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ob, 0, unsigned(step_bytes), 0x00020000);
+    one_step(0, rs, sq1);
+    ob += step_bytes;
+    tcount += 1;
+    const float racc = seg_sum<ROW>(sq1);
+    const bool my_crash = (seg_or<ROW>(crash_bits) & 1u) != 0u;
+    const bool my_bad = (BADCHK && (seg_or<ROW>(bad_bits) & 1u) != 0u) || my_crash;
+    crash_bits = 0u;
+    bad_bits = 0u;
+    if (rvalid && k == 0) {
+      const float cost = tsqrt(racc);
+      const float max_cost = float(s.max_cost);
+      float reward = tmax(max_cost - cost, 0.0f) / (max_cost + 1.1920928955078125e-07f);
+      reward = my_bad ? 0.0f : reward;
+      const size_t o = size_t(base) * s.R + rr;
+      rew[o] = reward;
+      done[o] = uint8_t((tcount >= s.step_limit) || my_crash);
+    }
+  }
+  if (valid) {
+    if (MIXED) {
+      s.pos[idx] = T(xdA); s.pos[idx + 1] = T(xdB);
+      s.vel[idx] = T(vdA); s.vel[idx + 1] = T(vdB);
+    } else {
+      s.pos[idx] = T(x.x); s.pos[idx + 1] = T(x.y);
+      s.vel[idx] = T(v.x); s.vel[idx + 1] = T(v.y);
+    }
+    if (kk == 0) s.time[rr] = tcount;
+  }
+}
+
+// observation of the current state of a FS_MIXED handle (Env.reset): the mixed head's own form (reciprocal
+// multiplication in float64, then the rounding to float32)
+__global__ void k_obs_mixed(DevView<double> s, float* __restrict__ obs) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= s.R * s.N) return;
+  const int r = e / s.N, i = e % s.N;
+  const double L = s.ring_len[r] + 4.0 * s.jlen;
+  float* o = obs + size_t(r) * 2 * s.N;
+  o[i] = float(s.vel[e] * (1.0 / double(s.max_speed)));
+  o[s.N + i] = float(s.pos[e] * (1.0 / L));
+}
+__global__ void k_obs_mixed(DevView<float>, float*) {}   // never launched: keeps launch_seg<float> well-formed
+
+}  // namespace fs

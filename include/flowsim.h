@@ -40,7 +40,12 @@ extern "C" {
 #define FS_ERR_NOSPACE -4       /* vehicles do not fit (network/base.py:603-605)            */
 
 /* ---- enums -------------------------------------------------------------- */
-enum fs_precision { FS_F32 = 0, FS_F64 = 1 };
+/* FS_F32 / FS_F64: arithmetic and state in that type (FS_F64 = the reference's Python-float arithmetic).
+ * FS_MIXED: positions and speeds kept and integrated in float64, the acceleration controller evaluated in
+ * float32 on their rounded images -- within 1e-4 of the float64 trajectories over a 1500-step episode at
+ * float32 cost.  Built for the rollout path of all-IDM single-lane rings (AccelEnv head); state fields are
+ * float64 as for FS_F64. */
+enum fs_precision { FS_F32 = 0, FS_F64 = 1, FS_MIXED = 2 };
 
 /* acceleration controllers, flow/controllers/__init__.py */
 enum fs_controller {

@@ -86,3 +86,66 @@ class CRingIDM:
            self.x.ctypes.data, self.v.ctypes.data, self.tc.ctypes.data, obs.ctypes.data, rew.ctypes.data,
            done.ctypes.data, int(obs_every_step), self.threads)
         return obs, rew, done.astype(bool)
+
+
+class CRingIDMMixed:
+    """C twin of the FS_MIXED rollout (flow_amd/csrc/flowsim_pair.h, state float64 / controller float32):
+    refsim_ring_idm_mixed in csim/refsim.c.  Per-slot IDM parameters and vehicle lengths."""
+
+    def __init__(self, spec, threads=1):
+        self.lib = load()
+        self.R, self.N = int(spec["num_replicas"]), int(spec["num_vehicles"])
+        for v in spec["vehicles"]:
+            assert v["controller"] == 2 and v.get("fail_safe", 0) == 0 and v.get("noise", 0) == 0
+            assert v.get("speed_mode", 0) == 0
+        assert spec.get("env", 0) == 0 and not spec.get("junction_mode", 0)
+        assert spec.get("sims_per_step", 1) == 1 and spec.get("integrator", "euler") == "euler"
+        self.p = np.ascontiguousarray(np.array([list(v["p"][:6]) for v in spec["vehicles"]], np.float64).T)  # [6,N]
+        self.veh_len = np.ascontiguousarray(np.array([v.get("length", 5.0) for v in spec["vehicles"]], np.float64))
+        self.dt = float(spec["sim_step"])
+        self.ramp = float(spec.get("slowdown_ramp", self.dt / (self.dt + 1e-3)))
+        self.jlen = float(spec.get("junction_length", 0.1))
+        self.ring_len = np.ascontiguousarray(
+            np.broadcast_to(np.asarray(spec["ring_length"], np.float64), (self.R,)).copy())
+        self.max_speed = float(spec["max_speed"])
+        self.target_v = float(spec["target_velocity"])
+        self.max_cost = float(np.linalg.norm(np.array([spec["target_velocity"]] * self.N, dtype=np.float64)))
+        self.crash_gap = float(spec.get("crash_gap", 0.0))
+        hz = spec.get("horizon", float("inf"))
+        self.step_limit = 2**31 - 1 if hz == float("inf") else int(spec.get("warmup_steps", 0) + hz)
+        self.init_pos = np.asarray(spec["init_pos"], np.float64).reshape(self.R, self.N)
+        iv = spec.get("init_vel")
+        self.init_vel = np.zeros((self.R, self.N)) if iv is None else np.asarray(iv, np.float64).reshape(self.R, self.N)
+        self.threads = int(threads)
+        self.reset()
+
+    def reset(self):
+        self.x = np.ascontiguousarray(self.init_pos.copy())
+        self.v = np.ascontiguousarray(self.init_vel.copy())
+        self.tc = np.zeros(self.R, dtype=np.int32)
+
+    def rollout(self, steps, obs_every_step=False):
+        K = steps if obs_every_step else 1
+        obs = np.empty((K, self.R, 2 * self.N), np.float32)
+        rew = np.empty((K, self.R), np.float32)
+        done = np.empty((K, self.R), np.uint8)
+        fn = self.lib.refsim_ring_idm_mixed_all
+        d = C.c_double
+        fn.restype = None
+        fn.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, d, d, d, C.c_void_p, C.c_void_p, d, d, d, d, C.c_int,
+                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        fn(self.R, self.N, int(steps), self.ring_len.ctypes.data, self.jlen, self.dt, self.ramp, self.p.ctypes.data,
+           self.veh_len.ctypes.data, self.max_speed, self.target_v, self.max_cost, self.crash_gap, self.step_limit,
+           self.x.ctypes.data, self.v.ctypes.data, self.tc.ctypes.data, obs.ctypes.data, rew.ctypes.data,
+           done.ctypes.data, int(obs_every_step), self.threads)
+        return obs, rew, done.astype(bool)
+
+
+def div_via_f64_mismatches(c, bits_lo, bits_hi, threads=8):
+    """Number of float32 x with bit pattern in [bits_lo, bits_hi) for which the kernel's float64 route to
+    x / c (flowsim_pair.h div_via_f64) differs from the IEEE float32 quotient."""
+    lib = load()
+    fn = lib.refsim_div_via_f64_mismatches
+    fn.restype = C.c_longlong
+    fn.argtypes = [C.c_float, C.c_uint32, C.c_uint32, C.c_int]
+    return int(fn(float(c), int(bits_lo), int(bits_hi), int(threads)))

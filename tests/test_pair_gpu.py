@@ -1,0 +1,308 @@
+"""GPU parity of the two-vehicles-per-lane rollout kernel (flow_amd/csrc/flowsim_pair.h) and of the launch
+bench.py times: 4096 replicas x 22 vehicles x 1500 steps in ONE launch.
+
+  * float32: bit-exact against the float32 oracle (numpy RingOracle for per-slot parameters, the C twin
+    oracle/csim for the large cases) and against the one-vehicle-per-lane kernel k_rollout_idm;
+  * FS_MIXED (float64 state, float32 controller): bit-exact against its C twin refsim_ring_idm_mixed, and
+    within 1e-4 m / 1e-4 m/s of the float64 oracle (the reference's arithmetic) after 1500 steps -- the
+    north-star trajectory bar -- on C1 and on the C2 launch;
+  * float64: <= 1e-9 of the float64 oracle on the same launch.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import idm_vehicle, ring_spec
+from oracle import cbuild
+from oracle import refsim as S
+
+pytestmark = pytest.mark.gpu
+
+
+def perturbed(spec, seed=0, sigma=0.5):
+    rng = np.random.default_rng(seed)
+    R, N = spec["num_replicas"], spec["num_vehicles"]
+    spec = dict(spec)
+    spec["init_pos"] = np.asarray(spec["init_pos"]) + np.abs(rng.normal(0, sigma, (R, N)))
+    return spec
+
+
+def gpu_rollout(spec, precision, K, env=None):
+    """One fs_rollout_dev launch of K steps, observation every step; returns host copies + the handle."""
+    import torch
+    from flow_amd.sim import FlowSim
+    old = {}
+    for k, v in (env or {}).items():
+        old[k] = os.environ.get(k)
+        os.environ[k] = v
+    try:
+        sim = FlowSim(spec, precision=precision)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    dev = torch.device("cuda", 0)
+    R = sim.R
+    obs = torch.full((K, R, sim.obs_dim), float("nan"), dtype=torch.float32, device=dev)
+    rew = torch.full((K, R), float("nan"), dtype=torch.float32, device=dev)
+    done = torch.full((K, R), 7, dtype=torch.uint8, device=dev)
+    sim.reset()
+    torch.cuda.synchronize()          # the fills above run on torch's stream, the simulator on its own
+    sim.rollout_dev(K, obs, rew, done, obs_every_step=True)
+    sim.sync()
+    return sim, obs, rew, done
+
+
+def ring_distance(a, b, L):
+    d = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))
+    return np.minimum(d, L - d)
+
+
+EVEN_N = [2, 4, 6, 8, 10, 14, 16, 18, 22, 30, 32, 34, 48, 62, 64]
+
+
+@pytest.mark.parametrize("N", EVEN_N)
+def test_pair_f32_bit_exact_vs_numpy_oracle_ragged_sizes(N):
+    # every row width (8 / 16 / 32 / 64 lanes per replica), odd replica counts, K not a multiple of the block
+    L = max(230.0, 9.0 * N)
+    R = 7 if N > 32 else 13
+    K = 37
+    spec = perturbed(ring_spec(R=R, N=N, length=L, bunching=0, junction_length=0.1, horizon=30), seed=N, sigma=0.2)
+    sim, obs, rew, done = gpu_rollout(spec, "f32", K)
+    ora = S.RingOracle(spec, np.float32)
+    ora.reset()
+    for k in range(K):
+        o, r, d = ora.step(None)
+        np.testing.assert_array_equal(obs[k].cpu().numpy(), o.astype(np.float32), err_msg="obs step %d" % k)
+        np.testing.assert_array_equal(rew[k].cpu().numpy(), r.astype(np.float32), err_msg="rew step %d" % k)
+        np.testing.assert_array_equal(done[k].cpu().numpy().astype(bool), d, err_msg="done step %d" % k)
+    np.testing.assert_array_equal(sim.pos, ora.x)
+    np.testing.assert_array_equal(sim.vel, ora.v)
+    np.testing.assert_array_equal(sim.time_counter, ora.time_counter)
+    sim.close()
+
+
+def test_pair_f32_per_slot_parameters_lengths_and_crashes():
+    # different IDM parameters and lengths per slot (pairs see two parameter sets), a dense ring that crashes
+    N, R, K = 22, 9, 120
+    rng = np.random.default_rng(5)
+    veh = []
+    for i in range(N):
+        veh.append(idm_vehicle(p=[float(rng.uniform(20, 35)), float(rng.uniform(0.8, 1.4)), float(rng.uniform(0.8, 2.0)),
+                                  float(rng.uniform(1.0, 2.5)), 4, float(rng.uniform(1.0, 3.0)), 0, 0],
+                               length=float(rng.choice([4.0, 5.0, 6.5]))))
+    spec = perturbed(ring_spec(R=R, N=N, length=160.0, bunching=0, junction_length=0.1, horizon=100,
+                               vehicles=veh), seed=3, sigma=0.3)
+    init_vel = rng.uniform(0, 12, (R, N))
+    spec["init_vel"] = init_vel
+    sim, obs, rew, done = gpu_rollout(spec, "f32", K)
+    ora = S.RingOracle(spec, np.float32)
+    ora.reset()
+    crashed = False
+    for k in range(K):
+        o, r, d = ora.step(None)
+        crashed = crashed or bool(d[:].any() and k < 99)
+        np.testing.assert_array_equal(obs[k].cpu().numpy(), o.astype(np.float32))
+        np.testing.assert_array_equal(rew[k].cpu().numpy(), r.astype(np.float32))
+        np.testing.assert_array_equal(done[k].cpu().numpy().astype(bool), d)
+    assert crashed, "the case is meant to contain collisions"
+    np.testing.assert_array_equal(sim.pos, ora.x)
+    np.testing.assert_array_equal(sim.vel, ora.v)
+    sim.close()
+
+
+def test_pair_kernel_equals_one_vehicle_per_lane_kernel():
+    spec = perturbed(ring_spec(R=70, N=22, junction_length=0.1, horizon=1500), seed=2)
+    K = 200
+    a, oa, ra, da = gpu_rollout(spec, "f32", K)
+    b, ob, rb, db = gpu_rollout(spec, "f32", K, env={"FLOWSIM_NO_PAIR": "1"})
+    assert (oa == ob).all() and (ra == rb).all() and (da == db).all()
+    np.testing.assert_array_equal(a.pos, b.pos)
+    np.testing.assert_array_equal(a.vel, b.vel)
+    a.close(), b.close()
+
+
+def test_pair_non_delta4_and_generic_division():
+    # delta != 4 takes pow_delta, FLOWSIM_NO_FASTDIV keeps the IEEE divisions
+    veh = [idm_vehicle(p=[30, 1, 1, 1.5, 2, 2, 0, 0]) for _ in range(22)]
+    spec = perturbed(ring_spec(R=11, N=22, junction_length=0.1, horizon=100, vehicles=veh), seed=4)
+    for env in ({}, {"FLOWSIM_NO_FASTDIV": "1"}):
+        sim, obs, rew, done = gpu_rollout(spec, "f32", 50, env=env)
+        ora = S.RingOracle(spec, np.float32)
+        ora.reset()
+        for k in range(50):
+            o, r, d = ora.step(None)
+        np.testing.assert_array_equal(obs[49].cpu().numpy(), o.astype(np.float32))
+        np.testing.assert_array_equal(rew[49].cpu().numpy(), r.astype(np.float32))
+        np.testing.assert_array_equal(sim.pos, ora.x)
+        sim.close()
+
+
+def test_pair_negative_speed_upload_zeroes_the_reward():
+    # rewards.py:46 -- a speed < -100 can only come from outside: fs_set_state switches the check on
+    from flow_amd import _lib as L
+    import torch
+    from flow_amd.sim import FlowSim
+    spec = perturbed(ring_spec(R=6, N=22, junction_length=0.1, horizon=100), seed=6)
+    sim = FlowSim(spec, "f32")
+    ora = S.RingOracle(spec, np.float32)
+    sim.reset(), ora.reset()
+    v = np.zeros((6, 22), np.float32)
+    v[2, 5] = -150.0
+    sim.set_state(L.FS_FIELD_VEL, v)
+    ora.v[...] = v
+    dev = torch.device("cuda", 0)
+    obs = torch.empty((3, 6, 44), dtype=torch.float32, device=dev)
+    rew = torch.empty((3, 6), dtype=torch.float32, device=dev)
+    done = torch.empty((3, 6), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    sim.rollout_dev(3, obs, rew, done)
+    sim.sync()
+    for k in range(3):
+        o, r, d = ora.step(None)
+        np.testing.assert_array_equal(rew[k].cpu().numpy(), r.astype(np.float32))
+        np.testing.assert_array_equal(obs[k].cpu().numpy(), o.astype(np.float32))
+    sim.close()
+
+
+# ---------------------------------------------------------------------------------------------- FS_MIXED
+@pytest.mark.parametrize("N,R,K", [(22, 19, 100), (2, 5, 40), (8, 9, 33), (32, 6, 50), (40, 5, 48), (64, 3, 35)])
+def test_mixed_bit_exact_vs_its_c_twin(N, R, K):
+    L = max(230.0, 9.0 * N)
+    spec = perturbed(ring_spec(R=R, N=N, length=L, bunching=0 if N != 22 else 20, junction_length=0.1,
+                               horizon=80), seed=N, sigma=0.2)
+    sim, obs, rew, done = gpu_rollout(spec, "mixed", K)
+    twin = cbuild.CRingIDMMixed(spec)
+    o, r, d = twin.rollout(K, obs_every_step=True)
+    np.testing.assert_array_equal(obs.cpu().numpy(), o)
+    np.testing.assert_array_equal(rew.cpu().numpy(), r)
+    np.testing.assert_array_equal(done.cpu().numpy().astype(bool), d)
+    assert sim.pos.dtype == np.float64
+    np.testing.assert_array_equal(sim.pos, twin.x)
+    np.testing.assert_array_equal(sim.vel, twin.v)
+    np.testing.assert_array_equal(sim.time_counter, twin.tc)
+    sim.close()
+
+
+def test_mixed_single_steps_and_reset_observation():
+    from flow_amd.sim import FlowSim
+    spec = perturbed(ring_spec(R=5, N=22, junction_length=0.1, horizon=50), seed=8)
+    sim = FlowSim(spec, "mixed")
+    twin = cbuild.CRingIDMMixed(spec)
+    o0 = sim.reset()
+    L = 230.4
+    np.testing.assert_array_equal(o0[:, 22:], (twin.x * (1.0 / L)).astype(np.float32))
+    np.testing.assert_array_equal(o0[:, :22], np.zeros((5, 22), np.float32))
+    for k in range(30):
+        o, r, d = sim.step(None)
+        to, tr, td = twin.rollout(1, obs_every_step=True)
+        np.testing.assert_array_equal(o, to[0])
+        np.testing.assert_array_equal(r, tr[0])
+        np.testing.assert_array_equal(d, td[0])
+    sim.close()
+
+
+def test_mixed_refuses_what_it_is_not_built_for():
+    from flow_amd.sim import FlowSim
+    spec = ring_spec(R=2, N=21, junction_length=0.1)
+    with pytest.raises(NotImplementedError):
+        FlowSim(spec, "mixed")                                   # odd vehicle count
+    veh = [idm_vehicle(noise=0.1) for _ in range(22)]
+    with pytest.raises(NotImplementedError):
+        FlowSim(ring_spec(R=2, N=22, vehicles=veh), "mixed")     # noise
+
+
+def test_c1_mixed_within_1e4_of_reference_arithmetic_1500_steps():
+    # BASELINE configs[0]: the 22-vehicle sugiyama ring, one env, 1500 steps; float64 oracle = the reference's arithmetic
+    spec = ring_spec(R=1, N=22, junction_length=0.1, horizon=1500)
+    sim, obs, rew, done = gpu_rollout(spec, "mixed", 1500)
+    ref = cbuild.CRingIDM(spec, np.float64)
+    o, r, d = ref.rollout(1500, obs_every_step=True)
+    assert ring_distance(sim.pos, ref.x, 230.4).max() < 1e-4
+    assert np.abs(sim.vel - ref.v).max() < 1e-4
+    assert np.abs(obs.cpu().numpy() - o).max() < 1e-6            # normalised observations
+    assert np.abs(rew.cpu().numpy() - r).max() < 1e-5
+    np.testing.assert_array_equal(done.cpu().numpy().astype(bool), d)
+    assert ref.v.max() > 1.0
+    sim.close()
+
+
+# ------------------------------------------------------------------- the launch bench.py times (C2, full size)
+SAMPLED = [0, 1, 15, 16, 17, 31, 100, 500, 777, 1000, 1234, 1498, 1499]
+
+
+def c2_spec(R=4096):
+    from bench import c2_spec as bench_spec
+    return bench_spec(R, seed=1000)
+
+
+def stepwise_samples(ora, K, sampled):
+    """Advance a C oracle to every sampled step (obs of the LAST step of each chunk)."""
+    out, t = {}, 0
+    for k in sampled:
+        o, r, d = ora.rollout(k + 1 - t, obs_every_step=False)
+        out[k] = (o[0].copy(), r[0].copy(), d[0].copy())
+        t = k + 1
+    if t < K:
+        ora.rollout(K - t, obs_every_step=False)
+    return out
+
+
+def test_c2_full_launch_f32_bit_exact_all_replicas():
+    spec = c2_spec()
+    K = 1500
+    sim, obs, rew, done = gpu_rollout(spec, "f32", K)
+    ora = cbuild.CRingIDM(spec, np.float32, threads=8)
+    smp = stepwise_samples(ora, K, SAMPLED)
+    for k in SAMPLED:
+        o, r, d = smp[k]
+        np.testing.assert_array_equal(obs[k].cpu().numpy(), o, err_msg="obs step %d" % k)
+        np.testing.assert_array_equal(rew[k].cpu().numpy(), r, err_msg="rew step %d" % k)
+        np.testing.assert_array_equal(done[k].cpu().numpy().astype(bool), d, err_msg="done step %d" % k)
+    np.testing.assert_array_equal(sim.pos, ora.x)
+    np.testing.assert_array_equal(sim.vel, ora.v)
+    np.testing.assert_array_equal(sim.time_counter, ora.tc)
+    assert done[K - 1].all() and not done[K - 2].any()            # horizon reached, nobody crashed
+    assert not bool(obs.isnan().any()) and not bool(rew.isnan().any()) and int(done.max()) == 1
+    sim.close()
+
+
+def test_c2_full_launch_mixed_bit_exact_and_within_1e4_of_f64():
+    spec = c2_spec()
+    K = 1500
+    sim, obs, rew, done = gpu_rollout(spec, "mixed", K)
+    twin = cbuild.CRingIDMMixed(spec, threads=8)
+    smp = stepwise_samples(twin, K, SAMPLED)
+    for k in SAMPLED:
+        o, r, d = smp[k]
+        np.testing.assert_array_equal(obs[k].cpu().numpy(), o, err_msg="obs step %d" % k)
+        np.testing.assert_array_equal(rew[k].cpu().numpy(), r, err_msg="rew step %d" % k)
+        np.testing.assert_array_equal(done[k].cpu().numpy().astype(bool), d, err_msg="done step %d" % k)
+    np.testing.assert_array_equal(sim.pos, twin.x)
+    np.testing.assert_array_equal(sim.vel, twin.v)
+    ref = cbuild.CRingIDM(spec, np.float64, threads=8)
+    ref.rollout(K)
+    dx = ring_distance(sim.pos, ref.x, 230.4).max()
+    dv = np.abs(sim.vel - ref.v).max()
+    assert dx < 1e-4 and dv < 1e-4, (dx, dv)                      # north-star trajectory bar
+    assert not bool(obs.isnan().any())
+    sim.close()
+
+
+def test_c2_full_launch_f64_within_1e9():
+    spec = c2_spec()
+    K = 1500
+    sim, obs, rew, done = gpu_rollout(spec, "f64", K)
+    ref = cbuild.CRingIDM(spec, np.float64, threads=8)
+    smp = stepwise_samples(ref, K, SAMPLED)
+    for k in SAMPLED:
+        o, r, d = smp[k]
+        np.testing.assert_allclose(obs[k].cpu().numpy(), o, rtol=0, atol=1e-7)
+        np.testing.assert_allclose(rew[k].cpu().numpy(), r, rtol=0, atol=1e-6)
+        np.testing.assert_array_equal(done[k].cpu().numpy().astype(bool), d)
+    assert ring_distance(sim.pos, ref.x, 230.4).max() < 1e-9
+    assert np.abs(sim.vel - ref.v).max() < 1e-9
+    sim.close()
