@@ -14,10 +14,13 @@ region.  For N > 1 each rank owns its own replicas (no data-path collective insi
 a step); the only exchange is one RCCL all-gather of the fragment's final
 observation/reward/done to the learner per fragment.
 
-Prints ONE JSON line (rank 0).  Extra keys: `roofline` (dominant kernel =
-k_steps, per-launch HIP-event timing), `cpu_baseline` (oracle C port on the host
-cores, bounded sample, rank 0, N=1 only), `c4_bottleneck` / `c5_merge` (open-network kernel, informational), `step_api` (one launch per env step,
-the Gym-faithful call pattern), `f64` (same workload in float64).
+Prints ONE JSON line (rank 0).  `value` / `ms_per_step` describe exactly the --steps given.  Whatever --steps is,
+`roofline` (dominant kernel, per-launch HIP events) and `parity` (deviation of the reported dtype from the float64
+oracle after a 1500-step episode) come from >= 5 full 1500-step launches made in the same process.  Extra keys at
+N = 1: `rollout_1500` (the same for mixed / f32 / f64), `cpu_baseline` (oracle C port on the host cores, bounded
+sample), `step_api` (one launch per env step), `ring_default_speed_mode` (the reference's ring experiment with its
+default speed mode: generic kernel), `c3_*` / `c4_bottleneck` / `c5_merge` (the other BASELINE configs, informational).
+`--gpus N` without a launcher starts its N ranks itself.
 """
 import argparse
 import json
@@ -304,6 +307,152 @@ def cpu_baseline(spec_fn, seconds=12.0):
                       "%d replicas x 22 vehicles x %d steps in %.1f s" % (R, done_steps, dt)}
 
 
+def ring_defaults_leg(device, R=4096, K=1500):
+    """The reference's own 22-IDM ring experiment AS SHIPPED (examples/exp_configs/non_rl/ring.py:13-61: the
+    SumoCarFollowingParams default speed_mode 'right_of_way' = 25, whose bit 0 makes SUMO's safe-speed rule cap
+    every command) through VecFlowEnv: this configuration cannot take the specialised rollout kernels (they are
+    for speed_mode 'aggressive', which the headline states in `config`) and runs the generic k_steps kernel."""
+    import torch
+    from flow_amd.controllers import ContinuousRouter, IDMController
+    from flow_amd.core.params import EnvParams, InitialConfig, NetParams, SumoParams, VehicleParams
+    from flow_amd.envs import AccelEnv, VecFlowEnv
+    from flow_amd.networks import RingNetwork
+    from flow_amd.networks.ring import ADDITIONAL_NET_PARAMS
+    veh = VehicleParams()
+    veh.add(veh_id="idm", acceleration_controller=(IDMController, {}), routing_controller=(ContinuousRouter, {}),
+            num_vehicles=22)
+    fp = dict(exp_tag="ring", env_name=AccelEnv, network=RingNetwork, simulator="traci",
+              sim=SumoParams(render=False, sim_step=0.1),
+              env=EnvParams(horizon=1500, additional_params={"max_accel": 3, "max_decel": 3, "target_velocity": 10,
+                                                             "sort_vehicles": False}),
+              net=NetParams(additional_params=dict(ADDITIONAL_NET_PARAMS)), veh=veh,
+              initial=InitialConfig(bunching=20))
+    vec = VecFlowEnv(fp, num_replicas=R, device=device.index)
+    out = (torch.empty((K, R, vec.obs_dim), dtype=torch.float32, device=device),
+           torch.empty((K, R), dtype=torch.float32, device=device),
+           torch.empty((K, R), dtype=torch.uint8, device=device))
+    vec.reset()
+    vec.rollout(K, None, out=out)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    n = 0
+    for _ in range(2):
+        vec.reset()
+        vec.rollout(K, None, out=out)
+        n += K
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    vec.close()
+    return {"value": R * n / dt, "unit": "env-steps/s", "steps": n, "replicas": R,
+            "workload": "examples/exp_configs/non_rl/ring.py through VecFlowEnv: 22 IDM, speed_mode 'right_of_way' "
+                        "(the SumoCarFollowingParams default); generic kernel k_steps<float,32,0,1>"}
+
+
+KERNEL_NAMES = {"f32": "fs::k_rollout_pair<float, 16, true, true, false>",
+                "mixed": "fs::k_rollout_pair<double, 16, true, true, false>",
+                "f64": "fs::k_rollout_idm<double, 32, true, false, false>"}
+
+
+def launch_bytes(R, N, K, precision):
+    """Algorithmic HBM bytes of ONE K-step rollout launch: observation [K,R,2N] f32 + reward f32 + done u8 written
+    every step; state (pos, vel) read and written once, time counter once."""
+    obs_b = 2 * N * 4 + 4 + 1
+    st = 4 if precision == "f32" else 8
+    state_b = N * (st + st) * 2 + 4 * 2
+    return R * (K * obs_b + state_b), obs_b + state_b / float(K)
+
+
+def pmc_traffic(precision, R, K):
+    """HBM bytes per launch from the committed PMC summary of THIS kernel (profiles/r02_*), or None."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_summary_%s.json" % precision)
+    try:
+        tj = json.load(open(path))
+        if tj.get("replicas") == R and tj.get("steps_per_launch") == K and tj.get("kernel", "").startswith(
+                KERNEL_NAMES[precision].split("<")[0]):
+            return tj.get("hbm_bytes_per_launch"), os.path.basename(path)
+    except Exception:
+        pass
+    return None, None
+
+
+def rollout_1500_leg(device, precision, R, launches=6, check_parity=True):
+    """>= 5 full 1500-step fragments of C2 in one process, per-launch HIP events on the kernel's
+    stream, roofline of that kernel, and the deviation of the final state from the float64 oracle (oracle/csim,
+    the reference's arithmetic) after one 1500-step episode: the parity figure of this dtype."""
+    import torch
+    from flow_amd.sim import FlowSim
+    K, N = 1500, 22
+    spec = c2_spec(R, seed=1000)
+    sim = FlowSim(spec, precision=precision, device=device.index)
+    sim.set_stream(torch.cuda.current_stream(device).cuda_stream)
+    obs = torch.empty((K, R, 2 * N), dtype=torch.float32, device=device)
+    rew = torch.empty((K, R), dtype=torch.float32, device=device)
+    done = torch.empty((K, R), dtype=torch.uint8, device=device)
+    obs0 = torch.empty((R, 2 * N), dtype=torch.float32, device=device)
+    sim.reset_dev(obs0)
+    sim.rollout_dev(K, obs, rew, done)
+    torch.cuda.synchronize(device)
+    parity = None
+    if check_parity:
+        from oracle import cbuild
+        ref = cbuild.CRingIDM(spec, np.float64, threads=host_cores())
+        ref.rollout(K)
+        L = 230.4
+        dx = np.abs(sim.pos.astype(np.float64) - ref.x)
+        dx = float(np.minimum(dx, L - dx).max())
+        dv = float(np.abs(sim.vel.astype(np.float64) - ref.v).max())
+        parity = {"max_abs_dx_m": dx, "max_abs_dv_mps": dv, "steps": K, "replicas": R,
+                  "against": "oracle/csim float64 (the reference's arithmetic type), all replicas, step 1500",
+                  "within_1e-4": bool(dx < 1e-4 and dv < 1e-4)}
+    events = []
+    t0 = time.perf_counter()
+    for _ in range(launches):
+        sim.reset_dev(obs0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        sim.rollout_dev(K, obs, rew, done)
+        e1.record()
+        events.append((e0, e1))
+    torch.cuda.synchronize(device)
+    wall = time.perf_counter() - t0
+    ms = [a.elapsed_time(b) for a, b in events]
+    avg_s = float(np.mean(ms)) * 1e-3
+    nbytes, per_step = launch_bytes(R, N, K, precision)
+    traffic, src = pmc_traffic(precision, R, K)
+    sim.close()
+    return {"value": R * K / avg_s, "unit": "env-steps/s (kernel time of a 1500-step launch)",
+            "value_wall": R * K * launches / wall, "dtype": precision, "launches_timed": launches,
+            "avg_launch_ms": avg_s * 1e3, "min_launch_ms": float(min(ms)), "max_launch_ms": float(max(ms)),
+            "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[precision], "achieved": nbytes / avg_s / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / avg_s / 1e9 / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": src, "bytes_per_launch": nbytes,
+                         "steps_per_launch": K, "avg_launch_ms": avg_s * 1e3, "bytes_per_env_step": per_step},
+            "parity": parity}
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (nothing in THIS
+    process has touched the GPU), fail loudly when the node has fewer devices, exit with the worst child code."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    if have < args.gpus:
+        raise SystemExit("bench.py --gpus %d: this node exposes %d GPU(s)" % (args.gpus, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -311,9 +460,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=3000)
     ap.add_argument("--replicas", type=int, default=4096, help="replicas per GPU")
     ap.add_argument("--fragment", type=int, default=1500, help="env steps per rollout launch")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f64", "mixed"])
-    ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline / step_api / f64 legs")
+    ap.add_argument("--precision", default="mixed", choices=["f32", "f64", "mixed"],
+                    help="mixed (default): float64 state, float32 controller -- the precision that holds the 1e-4 "
+                         "trajectory bar; f32: the float32 bit-twin; f64: the reference's arithmetic")
+    ap.add_argument("--no-extras", action="store_true", help="skip every leg but the headline and its roofline")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
 
     # stdout carries exactly ONE line (the JSON); native libraries print banners there (RCCL's
     # version block), so file descriptor 1 points at stderr until the result is written
@@ -327,8 +481,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the simulation path is HIP-only (no CPU fallback)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: LOCAL_RANK %d but only %d GPU(s) visible" % (local_rank, torch.cuda.device_count()))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     # every launch of this process (simulator, events, collectives) goes to one explicit stream
@@ -340,8 +498,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+        world = dist.get_world_size()          # what RCCL actually formed
 
     R = args.replicas
     spec = c2_spec(R, seed=1000 + rank)
@@ -378,57 +535,48 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- roofline of the dominant kernel (k_steps), per launch, from HIP events on its stream
-    full = [(e0.elapsed_time(e1) * 1e-3, k) for e0, e1, k in runner.events if k == runner.fragment]
-    if not full:
-        full = [(e0.elapsed_time(e1) * 1e-3, k) for e0, e1, k in runner.events]
-    k_launch = full[0][1]
-    avg_launch_s = float(np.mean([t for t, _ in full]))
     N = spec["num_vehicles"]
-    obs_b = runner.obs_dim * 4 + 4 + 1                    # obs + reward + done, per env-step
-    state_b = N * (4 + 4) * 2 + 4 * 2                     # pos+vel read and written once per launch, time counter
-    if args.precision != "f32":
-        state_b = N * (8 + 8) * 2 + 4 * 2
-    bytes_per_launch = R * (k_launch * obs_b + state_b)
-    achieved = bytes_per_launch / avg_launch_s / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    if os.path.exists(tpath) and args.precision == "f32":
-        try:
-            tj = json.load(open(tpath))
-            if tj.get("replicas") == R and tj.get("steps_per_launch") == k_launch:
-                traffic = tj.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    roofline = {"bound": "hbm",
-                "kernel": "fs::k_rollout_idm<%s, 32, true, %s>" % (("float", "true") if args.precision == "f32"
-                                                                   else ("double", "false")),
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "bytes_per_launch": bytes_per_launch, "steps_per_launch": k_launch,
-                "avg_launch_ms": avg_launch_s * 1e3, "launches_timed": len(full),
-                "bytes_per_env_step": obs_b + state_b / k_launch,
-                "survey_533B_equiv_GBs": 533.0 * R * k_launch / avg_launch_s / 1e9}
-
     out = {"metric": "env-steps/sec", "value": world * R * args.steps / elapsed, "unit": "env-steps/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-           "config": {"workload": "C2: RingNetwork 230 m, 22 IDM vehicles, %d replicas per GPU, AccelEnv obs "
-                                  "[R,44] + reward + done written every step, episodes of 1500 steps" % R,
+           "config": {"workload": "C2: RingNetwork 230 m, 22 IDM vehicles (speed_mode 'aggressive': the rollout "
+                                  "kernels' configuration class), %d replicas per GPU, AccelEnv obs [R,44] + reward + "
+                                  "done written every step, episodes of 1500 steps" % R,
                       "replicas_per_gpu": R, "vehicles": N, "sim_step": 0.1, "horizon": 1500,
-                      "fragment_steps": runner.fragment,
+                      "fragment_steps": runner.fragment, "speed_mode": "aggressive",
+                      "precision": {"mixed": "float64 state, float32 controller (FS_MIXED)", "f32": "float32",
+                                    "f64": "float64"}[args.precision],
                       "parallelism": "replica-sharded x%d, obs all-gather per fragment" % world},
-           "roofline": roofline}
+           "timed_region": {"steps": args.steps, "launches": len(runner.events),
+                            "note": "value = replicas x steps / wall time of exactly --steps env steps (barrier + "
+                                    "synchronize on both sides); a region shorter than one 1500-step fragment is "
+                                    "dominated by launch + synchronize latency -- the kernel's own rate is in "
+                                    "`roofline` / `rollout_1500`, measured over >= 5 full fragments in this process"}}
+
+    # ---- roofline of the dominant kernel: ALWAYS from >= 5 full 1500-step launches of this process (HIP events
+    # on the kernel's stream), whatever --steps was; plus the parity figure of the reported dtype
+    legs = {}
+    if rank == 0:
+        legs[args.precision] = rollout_1500_leg(device, args.precision, R, check_parity=True)
+        out["roofline"] = legs[args.precision]["roofline"]
+        out["parity"] = legs[args.precision]["parity"]
+    runner.sim.close()
 
     if world == 1 and rank == 0 and not args.no_extras:
+        for other in ("mixed", "f32", "f64"):
+            if other not in legs:
+                legs[other] = rollout_1500_leg(device, other, R, check_parity=True)
+        out["rollout_1500"] = {k: {kk: vv for kk, vv in v.items()} for k, v in legs.items()}
         # the Gym-faithful call pattern: one launch per env step (state round-trips through HBM)
+        r1 = Runner(c2_spec(R, seed=1000), args.precision, device, args.fragment)
         n_api = 3000
-        runner.run_step_api(300)
+        r1.run_step_api(300)
         torch.cuda.synchronize(device)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t1 = time.perf_counter()
         e0.record()
-        runner.run_step_api(n_api)
+        r1.run_step_api(n_api)
         e1.record()
         torch.cuda.synchronize(device)
         dt_api = time.perf_counter() - t1
@@ -438,23 +586,16 @@ def main():
                            "us_per_launch_stream": e0.elapsed_time(e1) * 1e3 / n_api,
                            "achieved_GBs": per_step_b * R * n_api / dt_api / 1e9,
                            "note": "fs_step_dev: 1 launch per env step, 533 B/env-step algorithmic (SURVEY 8d)"}
-        # same workload in float64 (the reference's arithmetic type)
-        other = "f64" if args.precision == "f32" else "f32"
-        r2 = Runner(c2_spec(R, seed=1000), other, device, args.fragment)
-        r2.run(1500)
-        torch.cuda.synchronize(device)
-        t2 = time.perf_counter()
-        r2.run(6000)
-        torch.cuda.synchronize(device)
-        out[other] = {"value": R * 6000 / (time.perf_counter() - t2), "unit": "env-steps/s", "steps": 6000}
-        r2.sim.close()
+        r1.sim.close()
+        out["ring_default_speed_mode"] = ring_defaults_leg(device)
         out["c3_figure_eight"] = c3_leg(device)
         out["c3_figure_eight_po"] = c3_leg(device, po=True)
         out["c4_bottleneck"] = c4_leg(device)
         out["c5_merge"] = c5_leg(device)
         out["cpu_baseline"] = cpu_baseline(lambda r: c2_spec(r, seed=1000))
+    elif world == 1 and rank == 0:
+        out["cpu_baseline"] = None
 
-    runner.sim.close()
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:
