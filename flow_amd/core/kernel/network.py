@@ -46,8 +46,6 @@ class NetworkKernel(object):
         self.total_edgestarts = sorted(self.edgestarts + self.internal_edgestarts, key=lambda t: t[1])
         self.total_edgestarts_dict = dict(self.total_edgestarts)
         self.rts = network.routes
-        # several separate rings: ring r is replica r of the simulator, each with its own loop coordinate
-        self.ring_tables = network.specify_ring_tables(junction_length)
         # loop coordinate (what the simulator integrates) when it is not the table coordinate
         order = network.specify_loop_order()
         self.loop_starts = None
@@ -130,20 +128,6 @@ class NetworkKernel(object):
         """(route, x) of a point on ``edge`` (an edge both routes share belongs to route 0)."""
         for r, starts in enumerate(self._open_starts):
             for e, start in starts:
-                if e == edge:
-                    return r, start + position
-        raise KeyError(edge)
-
-    def locate_ring(self, ring, s):
-        """(edge, position on it) of loop coordinate ``s`` of ring ``ring`` (MultiRingNetwork)."""
-        for (edge, start) in reversed(self.ring_tables[ring]):
-            if s >= start:
-                return edge, s - start
-
-    def ring_coordinate(self, edge, position):
-        """(ring, loop coordinate on it) of a point on ``edge`` (MultiRingNetwork)."""
-        for r, table in enumerate(self.ring_tables):
-            for e, start in table:
                 if e == edge:
                     return r, start + position
         raise KeyError(edge)

@@ -41,7 +41,6 @@ class VehicleKernel(object):
         self.type_parameters = vehicles.type_parameters
         self.minGap = vehicles.minGap
         self._open, self._slot_id, self._slot, self.sim = False, {}, {}, None    # until attach()
-        self._ring_n = None
         self.__ids, self.__human_ids, self.__controlled_ids = [], [], []
         self.__controlled_lc_ids, self.__rl_ids = [], []
         self.__vehicles = {}
@@ -84,8 +83,6 @@ class VehicleKernel(object):
     def attach(self, sim, replica=0):
         self.sim, self.replica = sim, replica
         self._cache = {}
-        # MultiRingNetwork: ring r = replica r; vehicle g = r * N + i is slot i of replica r (ids in ring order)
-        self._ring_n = int(sim.spec["num_vehicles"]) if sim.spec.get("rings") else None
         self._open = bool(getattr(sim, "open_net", False))
         if self._open:
             self._init_id_of_slot = {i: v for v, i in sim.spec["init_slot"].items()}
@@ -227,14 +224,12 @@ class VehicleKernel(object):
     def _field(self, field):
         if field not in self._cache:
             a = self.sim.get_state(field)
-            self._cache[field] = a.reshape(-1) if self._ring_n else a[self.replica]
+            self._cache[field] = a[self.replica]
         return self._cache[field]
 
     def _ring_neighbour(self, i, step):
-        """Slot ``step`` places ahead of slot i on i's own ring (closed single-lane loops keep their order)."""
-        n = self._ring_n or self.num_vehicles
-        base = (i // n) * n
-        return base + (i - base + step) % n
+        """Slot ``step`` places ahead of slot i (closed single-lane loops keep their order)."""
+        return (i + step) % self.num_vehicles
 
     def _vec(self, veh_id, fn, error=-1001):
         if isinstance(veh_id, (list, np.ndarray)):
@@ -259,13 +254,11 @@ class VehicleKernel(object):
         """Flow's absolute position: edge start of the network's table + position on the edge
         (vehicle/traci.py:1011-1017)."""
         net = self.master_kernel.network
-        if net.loop_starts is None and not self._open and not self._ring_n:
+        if net.loop_starts is None and not self._open:
             return self._vec(veh_id, lambda i: float(self._field(L.FS_FIELD_POS)[i]), 0.)
         return self._vec(veh_id, lambda i: float(net.get_x(*self._edge_pos(i))), 0.)
 
     def _edge_pos(self, i):
-        if self._ring_n:
-            return self.master_kernel.network.locate_ring(i // self._ring_n, float(self._field(L.FS_FIELD_POS)[i]))
         if self._open:
             return self.master_kernel.network.open_locate(int(self._field(L.FS_FIELD_ROUTE)[i]),
                                                           float(self._field(L.FS_FIELD_POS)[i]))
@@ -466,7 +459,7 @@ class VehicleKernel(object):
     # ---- test back-doors (vehicle/traci.py:411-425)
     def _rs(self, veh_id):
         i = self._slot[veh_id]
-        return (i // self._ring_n, i % self._ring_n) if self._ring_n else (self.replica, i)
+        return self.replica, i
 
     def test_set_speed(self, veh_id, speed):
         v = self.sim.get_state(L.FS_FIELD_VEL)

@@ -275,7 +275,9 @@ struct Sim : SimBase {
     if ((rc = dev_alloc(&d_done, size_t(R)))) return rc;
     if ((rc = dev_alloc(&d_mask, size_t(R)))) return rc;
     if ((rc = dev_alloc(&d_dump, size_t(256)))) return rc;
-    return launch_reset(nullptr);
+    if ((rc = launch_reset(nullptr))) return rc;
+    if (open_net) HIP_TRY(hipMemsetAsync(ov.episode, 0xFF, size_t(R) * sizeof(int32_t), stream));
+    return FS_OK;
   }
 
   // ---- open networks: per-slot bookkeeping arrays, route tables, inflow table ------------------
@@ -295,6 +297,8 @@ struct Sim : SimBase {
     if ((rc = dev_alloc(&ov.arr_hist, size_t(R) * 20))) return rc;
     if ((rc = dev_alloc(&ov.counters, size_t(R) * 8))) return rc;
     if ((rc = dev_alloc(&ov.emitted, size_t(R) * FS_MAX_INFLOWS))) return rc;
+    if ((rc = dev_alloc(&ov.episode, size_t(R)))) return rc;
+    HIP_TRY(hipMemset(ov.episode, 0xFF, size_t(R) * sizeof(int32_t)));     // -1: fs_create's own reset below is not an episode
     if ((rc = upload(&ov.init_alive, init_alive))) return rc;
     std::vector<int32_t> st(N);
     int n_rl_slots = 0;
@@ -1057,6 +1061,19 @@ int create_typed(const fs_config* cfg, fs_handle* out) {
 
 inline SimBase* S(fs_handle h) { return reinterpret_cast<SimBase*>(h); }
 
+// Every entry point runs on the handle's device whatever the caller's current device is, and leaves the caller's
+// current device as it found it (two handles on two GPUs in one process; torch's current device).
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int want) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != want) switched = hipSetDevice(want) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
 }  // namespace
 
 extern "C" {
@@ -1070,13 +1087,17 @@ int fs_create(const fs_config* cfg, fs_handle* out) {
   *out = nullptr;
   int rc = validate(cfg);
   if (rc) return rc;
-  return cfg->precision == FS_F32 ? create_typed<float>(cfg, out) : create_typed<double>(cfg, out);
+  int prev = -1;
+  const bool have_prev = hipGetDevice(&prev) == hipSuccess;
+  rc = cfg->precision == FS_F32 ? create_typed<float>(cfg, out) : create_typed<double>(cfg, out);
+  if (have_prev && prev != cfg->device) (void)hipSetDevice(prev);      // the caller's current device is not ours to change
+  return rc;
 }
 
 void fs_destroy(fs_handle h) {
   if (!h) return;
   SimBase* s = S(h);
-  (void)hipSetDevice(s->cfg.device);
+  DeviceGuard guard(s->cfg.device);
   (void)hipStreamSynchronize(s->stream);
   for (void* p : s->allocs) (void)hipFree(p);
   (void)hipStreamDestroy(s->own_stream);
@@ -1090,6 +1111,7 @@ int fs_action_dim(fs_handle h) { return h ? S(h)->act_dim : fail(FS_ERR_INVALID,
 int fs_set_stream(fs_handle h, void* hip_stream) {
   if (!h) return fail(FS_ERR_INVALID, "fs_set_stream: NULL handle");
   SimBase* s = S(h);
+  DeviceGuard guard(s->cfg.device);
   HIP_TRY(hipStreamSynchronize(s->stream));
   s->stream = static_cast<hipStream_t>(hip_stream);
   return FS_OK;
@@ -1098,6 +1120,7 @@ int fs_set_stream(fs_handle h, void* hip_stream) {
 int fs_use_own_stream(fs_handle h) {
   if (!h) return fail(FS_ERR_INVALID, "fs_use_own_stream: NULL handle");
   SimBase* s = S(h);
+  DeviceGuard guard(s->cfg.device);
   HIP_TRY(hipStreamSynchronize(s->stream));
   s->stream = s->own_stream;
   return FS_OK;
@@ -1105,6 +1128,7 @@ int fs_use_own_stream(fs_handle h) {
 
 int fs_sync(fs_handle h) {
   if (!h) return fail(FS_ERR_INVALID, "fs_sync: NULL handle");
+  DeviceGuard guard(S(h)->cfg.device);
   HIP_TRY(hipStreamSynchronize(S(h)->stream));
   return FS_OK;
 }
@@ -1112,6 +1136,7 @@ int fs_sync(fs_handle h) {
 int fs_reset_dev(fs_handle h, const uint8_t* mask_dev, float* obs_dev) {
   if (!h) return fail(FS_ERR_INVALID, "fs_reset_dev: NULL handle");
   SimBase* s = S(h);
+  DeviceGuard guard(s->cfg.device);
   int rc = s->launch_reset(mask_dev);
   if (rc) return rc;
   float* obs = obs_dev ? obs_dev : s->d_obs;
@@ -1132,6 +1157,7 @@ int fs_reset_dev(fs_handle h, const uint8_t* mask_dev, float* obs_dev) {
 int fs_reset(fs_handle h, const uint8_t* mask, float* obs_out) {
   if (!h) return fail(FS_ERR_INVALID, "fs_reset: NULL handle");
   SimBase* s = S(h);
+  DeviceGuard guard(s->cfg.device);
   const size_t R = size_t(s->cfg.num_replicas);
   const uint8_t* dmask = nullptr;
   if (mask) {
@@ -1149,6 +1175,7 @@ int fs_reset(fs_handle h, const uint8_t* mask, float* obs_out) {
 int fs_step_dev(fs_handle h, const float* actions_dev, float* obs_dev, float* rew_dev, uint8_t* done_dev) {
   if (!h) return fail(FS_ERR_INVALID, "fs_step_dev: NULL handle");
   if (!obs_dev || !rew_dev || !done_dev) return fail(FS_ERR_INVALID, "fs_step_dev: NULL output pointer");
+  DeviceGuard guard(S(h)->cfg.device);
   return S(h)->launch_steps(1, nullptr, actions_dev, 0, obs_dev, rew_dev, done_dev, 0);
 }
 
@@ -1156,6 +1183,7 @@ int fs_step(fs_handle h, const float* actions, float* obs, float* rew, uint8_t* 
   if (!h) return fail(FS_ERR_INVALID, "fs_step: NULL handle");
   if (!obs || !rew || !done) return fail(FS_ERR_INVALID, "fs_step: NULL output pointer");
   SimBase* s = S(h);
+  DeviceGuard guard(s->cfg.device);
   const size_t R = size_t(s->cfg.num_replicas);
   const float* dact = nullptr;
   if (actions && s->act_dim > 0) {
@@ -1176,18 +1204,56 @@ int fs_rollout_dev(fs_handle h, int num_steps, const float* actions_dev, size_t 
   if (!h) return fail(FS_ERR_INVALID, "fs_rollout_dev: NULL handle");
   if (num_steps < 1) return fail(FS_ERR_INVALID, "fs_rollout_dev: num_steps < 1");
   if (!obs_dev || !rew_dev || !done_dev) return fail(FS_ERR_INVALID, "fs_rollout_dev: NULL output pointer");
+  DeviceGuard guard(S(h)->cfg.device);
   return S(h)->launch_steps(num_steps, nullptr, actions_dev, action_stride_steps, obs_dev, rew_dev, done_dev,
                             obs_every_step ? 1 : 0);
 }
 
 int fs_get_state(fs_handle h, int field, void* dst, size_t bytes) {
   if (!h || !dst) return fail(FS_ERR_INVALID, "fs_get_state: NULL argument");
+  DeviceGuard guard(S(h)->cfg.device);
   return S(h)->get_state(field, dst, bytes);
 }
 
 int fs_set_state(fs_handle h, int field, const void* src, size_t bytes) {
   if (!h || !src) return fail(FS_ERR_INVALID, "fs_set_state: NULL argument");
+  DeviceGuard guard(S(h)->cfg.device);
   return S(h)->set_state(field, src, bytes);
+}
+
+int fs_dump_trajectory(fs_handle h, int replica, const char* csv_path) {
+  if (!h || !csv_path) return fail(FS_ERR_INVALID, "fs_dump_trajectory: NULL argument");
+  SimBase* s = S(h);
+  if (replica < 0 || replica >= s->cfg.num_replicas) return fail(FS_ERR_INVALID, "fs_dump_trajectory: replica out of range");
+  DeviceGuard guard(s->cfg.device);
+  const size_t R = size_t(s->cfg.num_replicas), N = size_t(s->cfg.num_vehicles);
+  const bool f32 = s->cfg.precision == FS_F32;
+  const size_t el = f32 ? sizeof(float) : sizeof(double);
+  std::vector<char> pos(R * N * el), vel(R * N * el);
+  std::vector<int32_t> tc(R), lane(R * N, 0);
+  int rc = s->get_state(FS_FIELD_POS, pos.data(), pos.size());
+  if (!rc) rc = s->get_state(FS_FIELD_VEL, vel.data(), vel.size());
+  if (!rc) rc = s->get_state(FS_FIELD_TIME, tc.data(), R * sizeof(int32_t));
+  const bool open_net = s->cfg.network == FS_NET_MERGE || s->cfg.network == FS_NET_BOTTLENECK;
+  if (!rc && (open_net || s->cfg.num_lanes > 1))
+    rc = s->get_state(open_net ? FS_FIELD_ROUTE : FS_FIELD_LANE, lane.data(), R * N * sizeof(int32_t));
+  if (rc) return rc;
+  FILE* probe = std::fopen(csv_path, "r");
+  const bool fresh = probe == nullptr;
+  if (probe) std::fclose(probe);
+  FILE* f = std::fopen(csv_path, "a");
+  if (!f) return fail(FS_ERR_INVALID, std::string("fs_dump_trajectory: cannot open ") + csv_path);
+  if (fresh) std::fprintf(f, "time,id,x,speed,lane_number\n");
+  const double t = double(tc[replica]) * s->cfg.sim_step;
+  for (size_t i = 0; i < N; ++i) {
+    const size_t e = size_t(replica) * N + i;
+    if (open_net && lane[e] < 0) continue;                       // a free slot: no vehicle
+    const double x = f32 ? double(reinterpret_cast<const float*>(pos.data())[e]) : reinterpret_cast<const double*>(pos.data())[e];
+    const double v = f32 ? double(reinterpret_cast<const float*>(vel.data())[e]) : reinterpret_cast<const double*>(vel.data())[e];
+    std::fprintf(f, "%.6f,%zu,%.17g,%.17g,%d\n", t, i, x, v, int(lane[e]));
+  }
+  std::fclose(f);
+  return FS_OK;
 }
 
 }  // extern "C"

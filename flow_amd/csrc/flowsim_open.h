@@ -33,6 +33,7 @@ struct OpenView {
   int32_t* arr_hist;     // [R,20] arrivals of the last 20 sub-steps (ring buffer indexed by sub-step % 20)
   int32_t* counters;     // [R,8]
   int32_t* emitted;      // [R,FS_MAX_INFLOWS]
+  int32_t* episode;      // [R] resets of the replica since fs_create (-1 before the first): keys the entry-lane draws (M9)
   const uint8_t* init_alive;   // [R,N]
   const int32_t* slot_type;    // [N]
   // Launch constants the step loop reads are kept one-per-lane in a few VGPRs and fetched with v_readlane, so the
@@ -375,6 +376,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       tot_dep = cnt[CNT_TOTAL_DEPARTED], tot_drop = cnt[CNT_TOTAL_DROPPED];
   // vehicles emitted so far by inflow f of this replica: held by lane f of the replica's segment (SEG >= 8)
   int emit_l = (i < FS_MAX_INFLOWS) ? o.emitted[size_t(rr) * FS_MAX_INFLOWS + i] : 0;
+  const uint32_t episode = uint32_t(o.episode[rr]);
   double next_due = -1.0e300;                                   // unknown yet: the first sub-step evaluates the schedule
 
   T x = s.pos[idx];
@@ -865,7 +867,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         int route_f = tb.template fi<1>(f);
         const bool random_lane = route_f < 0;
         if (random_lane) {                               // M9: departLane = "random"
-          uint32_t c0 = uint32_t(k), c1 = uint32_t(1000 + f), c2 = s.rep0 + uint32_t(rr), c3 = 1u;
+          uint32_t c0 = uint32_t(k), c1 = uint32_t(1000 + f), c2 = s.rep0 + uint32_t(rr), c3 = 1u + 2u * episode;
           philox4x32_10(c0, c1, c2, c3, s.seed_lo, s.seed_hi);
           route_f = int((uint64_t(c0 >> 8) * uint64_t(P)) >> 24);
         }
@@ -1051,6 +1053,7 @@ __global__ void k_reset_open(DevView<T> s, OpenView<T> o, const uint8_t* __restr
       for (int q = 2; q < 8; ++q) cnt[q] = 0;
       for (int q = 0; q < 20; ++q) o.arr_hist[size_t(r) * 20 + q] = 0;
       s.time[r] = 0;
+      o.episode[r] += 1;                           // a new episode draws new entry lanes (the reference re-seeds SUMO)
     }
   }
   // replicas with fewer than FS_MAX_INFLOWS slots: the remaining inflow counters

@@ -97,6 +97,7 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
   if (tid < 20) L.hist[tid] = o.arr_hist[size_t(rr) * 20 + tid];
 
   const bool live_replica = mask == nullptr || mask[rr] != 0;
+  const uint32_t episode = uint32_t(o.episode[rr]);
   int tcount = s.time[rr];
   uint32_t nctr = s.noise_ctr[rr];
   int32_t* cnt = o.counters + size_t(rr) * 8;
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
         int route_f = tb.template fi<1>(f);
         const bool random_lane = route_f < 0;
         if (random_lane) {                               // M9: departLane = "random"
-          uint32_t c0 = uint32_t(k), c1 = uint32_t(1000 + f), c2 = s.rep0 + uint32_t(rr), c3 = 1u;
+          uint32_t c0 = uint32_t(k), c1 = uint32_t(1000 + f), c2 = s.rep0 + uint32_t(rr), c3 = 1u + 2u * episode;
           philox4x32_10(c0, c1, c2, c3, s.seed_lo, s.seed_hi);
           route_f = int((uint64_t(c0 >> 8) * uint64_t(P)) >> 24);
         }

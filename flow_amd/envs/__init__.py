@@ -8,10 +8,6 @@ from flow_amd.envs.merge import MergePOEnv
 from flow_amd.envs.test import TestEnv
 from flow_amd.envs.vec import VecFlowEnv
 
-# deprecated classes whose names have changed (flow/envs/__init__.py:17-21; the traffic-light ones are out of scope)
-from flow_amd.envs.bottleneck_env import BottleNeckAccelEnv
-from flow_amd.envs.bottleneck_env import DesiredVelocityEnv
-
 __all__ = ['Env', 'AccelEnv', 'LaneChangeAccelEnv', 'LaneChangeAccelPOEnv', 'WaveAttenuationEnv', 'WaveAttenuationPOEnv', 'MergePOEnv',
            'BottleneckEnv', 'BottleneckAccelEnv', 'BottleneckDesiredVelocityEnv',
-           'TestEnv', 'VecFlowEnv', 'BottleNeckAccelEnv', 'DesiredVelocityEnv']
+           'TestEnv', 'VecFlowEnv']

@@ -101,10 +101,7 @@ class Env(_Base):
         open_net = spec.get("network") in ("merge", "bottleneck")
         # closed loops: slot i of the simulator holds k.vehicle._order[i] (id order unless shuffled / re-ordered)
         for i, veh_id in enumerate(self.initial_ids if open_net else self.k.vehicle._order):
-            if spec.get("rings"):                     # MultiRingNetwork: vehicle i is slot i % n of ring i // n
-                r, k = divmod(i, int(spec["num_vehicles"]))
-                edge, pos = self.k.network.locate_ring(r, float(spec["init_pos"][r][k]))
-            elif open_net:
+            if open_net:
                 slot = spec["init_slot"][veh_id]
                 edge, pos = self.k.network.open_locate(int(spec["init_route"][0][slot]), float(x0[slot]))
             else:

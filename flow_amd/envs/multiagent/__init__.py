@@ -1,8 +1,5 @@
 """Multi-agent environments on the GPU hot path (names as in flow/envs/multiagent/__init__.py)."""
 from flow_amd.envs.multiagent.base import MultiEnv
 from flow_amd.envs.multiagent.merge import MultiAgentMergePOEnv
-from flow_amd.envs.multiagent.ring.accel import AdversarialAccelEnv, MultiAgentAccelPOEnv
-from flow_amd.envs.multiagent.ring.wave_attenuation import MultiAgentWaveAttenuationPOEnv, MultiWaveAttenuationPOEnv
 
-__all__ = ["MultiEnv", "MultiAgentMergePOEnv", "AdversarialAccelEnv", "MultiAgentAccelPOEnv",
-           "MultiAgentWaveAttenuationPOEnv", "MultiWaveAttenuationPOEnv"]
+__all__ = ["MultiEnv", "MultiAgentMergePOEnv"]

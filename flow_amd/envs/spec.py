@@ -9,9 +9,21 @@ from flow_amd.networks.ring import RingNetwork
 from flow_amd.utils.exceptions import FatalFlowError
 
 
+def handle_seed(sim_params):
+    """Philox key of the handle.  ``SumoParams(seed=None)`` means "SUMO --random" in the reference
+    (flow/core/kernel/simulation/traci.py:122-127): a seed is drawn here, once per simulator.  Within a handle the
+    random streams never replay: the acceleration-noise counter runs on across resets and the entry-lane draws are
+    keyed by the replica's episode number (k_reset_open), which is what the reference's re-seeding on
+    restart_instance resets (envs/base.py:436-441) amounts to."""
+    if sim_params.seed is None:
+        import random
+        return random.getrandbits(31)
+    return int(sim_params.seed)
+
+
 def vehicle_slots(vehicle_kernel, rl_order, ids=None):
     """One fs_vehicle_spec dict per vehicle, in id (insertion) order (vehicle/traci.py:109-117); ``ids`` restricts
-    the table to some of the vehicles (one ring of a MultiRingNetwork)."""
+    the table to some of the vehicles."""
     slots = []
     for veh_id in ids or getattr(vehicle_kernel, "_order", None) or vehicle_kernel.get_ids():
         ctrl = vehicle_kernel.get_acc_controller(veh_id)
@@ -260,64 +272,11 @@ def build_open_spec(env, num_replicas, rng=None):
         # MultiEnv.clip_actions returns the dict unclipped in this fork (multiagent/base.py:366-391)
         clip_actions=bool(ep.clip_actions) and env.FS_ENV != L.FS_ENV_MERGE_MA, evaluate=bool(ep.evaluate),
         horizon=ep.horizon, warmup_steps=int(ep.warmup_steps), sims_per_step=int(ep.sims_per_step),
-        seed=int(sp.seed or 0), replica_offset=int(getattr(env, "_replica_offset", 0)), track_aux=True,
+        seed=handle_seed(sp), replica_offset=int(getattr(env, "_replica_offset", 0)), track_aux=True,
         ma_apply_actions=not bool(getattr(env, "APPLY_ENUMERATE_QUIRK", True)),
         slot_types=names, slot_base=base, slot_caps=dict(zip(names, caps)), init_slot=init_slot, **tables)
     spec.update(extra)
     return spec
-
-
-def build_multi_ring_spec(env, num_replicas):
-    """MultiRingNetwork: the rings do not interact, so ring r is REPLICA r of the ring kernel.  The device keeps one slot
-    table for all replicas, hence every ring must hold the same vehicles in the same order (what the reference's
-    "lord of the rings" experiment builds); vehicle ids follow VehicleParams order, ring after ring."""
-    network, net_k, veh_k = env.network, env.k.network, env.k.vehicle
-    sp, ep = env.sim_params, env.env_params
-    ap = network.net_params.additional_params
-    K = int(ap["num_rings"])
-    if int(num_replicas) != 1:
-        raise NotImplementedError("a MultiRingNetwork env holds its rings as the replicas of one handle")
-    if int(ap["lanes"]) != 1 or len(network.net_params.inflows.get()) > 0 or network.initial_config.shuffle:
-        raise NotImplementedError("MultiRingNetwork is built for one-lane rings without inflows / shuffle")
-    ids = veh_k.get_ids()
-    if len(ids) % K != 0:
-        raise FatalFlowError("MultiRingNetwork needs the same number of vehicles on every ring")
-    n = len(ids) // K
-    rl_ids = veh_k.get_rl_ids()
-    rings = []
-    for r in range(K):
-        ring_ids = ids[r * n:(r + 1) * n]
-        rings.append(vehicle_slots(veh_k, [v for v in ring_ids if v in rl_ids], ids=ring_ids))
-    if any(ring != rings[0] for ring in rings[1:]):
-        raise NotImplementedError("the rings of a MultiRingNetwork must hold the same vehicle types in the same order")
-    pos, lanes = net_k.generate_starting_positions(network.initial_config, len(ids))
-    X = np.zeros((K, n))
-    for g, (edge, p) in enumerate(pos):
-        r, s = net_k.ring_coordinate(edge, p)
-        if r != g // n:
-            raise NotImplementedError("the start placement puts vehicle %d on ring %d, not on ring %d" % (g, r, g // n))
-        X[r, g % n] = s
-    length = float(ap["length"])
-    loop = length + 4 * float(net_k.junction_length)
-    check_placement(X, np.array([s["length"] for s in rings[0]]), loop, None)
-    dt = sp.sim_step
-    ramp = getattr(sp, "slowdown_ramp", None)
-    space = env.action_space
-    n_rl = len([v for v in ids[:n] if v in rl_ids])
-    return dict(
-        rings=K, num_replicas=K, num_vehicles=n, num_rl=n_rl, vehicles=rings[0], ring_length=np.full(K, length),
-        init_pos=X, segments=None, junction=None, sim_step=dt,
-        slowdown_ramp=dt / (dt + 1e-3) if ramp is None else float(ramp),
-        integrator="ballistic" if getattr(sp, "use_ballistic", False) else "euler",
-        junction_mode=int(getattr(sp, "junction_mode", None) or 0), junction_length=float(net_k.junction_length),
-        crash_gap=float(getattr(sp, "crash_gap", 0.0)), max_speed=float(net_k.max_speed()), env=L.FS_ENV_ACCEL,
-        target_velocity=float(ep.additional_params.get("target_velocity", 0.0)),
-        action_low=float(space.low[0]) if n_rl else 0.0, action_high=float(space.high[0]) if n_rl else 0.0,
-        clip_actions=bool(ep.clip_actions), evaluate=bool(ep.evaluate), po_max_length=float(loop),
-        horizon=ep.horizon, warmup_steps=int(ep.warmup_steps), sims_per_step=int(ep.sims_per_step),
-        seed=int(sp.seed or 0), track_aux=True, replica_offset=0, num_lanes=1,
-        init_lane=np.zeros((K, n), dtype=np.int32), lane_change_duration=0.0, lane_change_mode=512,
-        last_lc_quirk=True, sort_vehicles=False)
 
 
 def build_spec(env, num_replicas, rng=None):
@@ -332,8 +291,6 @@ def build_spec(env, num_replicas, rng=None):
         return build_open_spec(env, num_replicas, rng)
     if env.FS_ENV in (L.FS_ENV_MERGE_PO, L.FS_ENV_MERGE_MA, L.FS_ENV_BOTTLENECK_DV, L.FS_ENV_BOTTLENECK):
         raise NotImplementedError("%s needs its open network (MergeNetwork / BottleneckNetwork)" % type(env).__name__)
-    if network.specify_ring_tables(0.0) is not None:
-        return build_multi_ring_spec(env, num_replicas)
     if not isinstance(network, (RingNetwork, FigureEightNetwork)):
         raise NotImplementedError("network %s is not built in the HIP step loop yet" % type(network).__name__)
     num_lanes = int(network.net_params.additional_params["lanes"])
@@ -389,7 +346,7 @@ def build_spec(env, num_replicas, rng=None):
         action_high=float(space.high[0]) if N and veh_k.num_rl_vehicles else 0.0,
         clip_actions=bool(ep.clip_actions), evaluate=bool(ep.evaluate),
         po_max_length=float(env._po_max_length()), horizon=ep.horizon, warmup_steps=int(ep.warmup_steps),
-        sims_per_step=int(ep.sims_per_step), seed=int(sp.seed or 0), track_aux=True,
+        sims_per_step=int(ep.sims_per_step), seed=handle_seed(sp), track_aux=True,
         replica_offset=int(getattr(env, "_replica_offset", 0)),
         num_lanes=num_lanes, init_lane=lanes,
         lane_change_duration=float(ep.additional_params.get("lane_change_duration", 0)),

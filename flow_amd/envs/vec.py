@@ -60,8 +60,13 @@ class VecFlowEnv(object):
         self.use_current_stream()
 
     def use_current_stream(self):
-        """Enqueue the simulator's launches on torch's current stream (ordering with learner kernels)."""
-        self.sim.set_stream(self.torch.cuda.current_stream(self.device).cuda_stream)
+        """Enqueue the simulator's launches on torch's current stream (ordering with learner kernels).  Called by
+        every reset / step / rollout, so a caller that switches streams (``with torch.cuda.stream(s):``) is followed:
+        the launches, the temporaries they read and the caller's kernels are then all ordered on one stream."""
+        st = self.torch.cuda.current_stream(self.device).cuda_stream
+        if st != getattr(self, "_bound_stream", None):
+            self.sim.set_stream(st)
+            self._bound_stream = st
 
     def _check(self, t, shape, dtype):
         if t is None:
@@ -105,6 +110,7 @@ class VecFlowEnv(object):
 
     def reset(self, mask=None):
         """Reset all replicas (or those where ``mask`` [R] uint8/bool tensor is set); returns obs [R, obs_dim]."""
+        self.use_current_stream()
         if mask is not None:
             mask = self._check(mask.to(self.torch.uint8), (self.num_envs,), self.torch.uint8)
         if self._resample:
@@ -116,6 +122,7 @@ class VecFlowEnv(object):
     def reset_done(self):
         """Reset exactly the replicas whose last ``done`` flag is set.  No host synchronisation, unless the
         environment redraws its network per episode (WaveAttenuationEnv with ``ring_length``)."""
+        self.use_current_stream()
         if self._resample:
             self._resample_ring_lengths(self._done.cpu().numpy() != 0)
         self.sim.reset_dev(self._obs, self._done)
@@ -123,6 +130,7 @@ class VecFlowEnv(object):
 
     def step(self, actions=None):
         """One Env.step of every replica.  ``actions``: float32 [R, action_dim] device tensor or None."""
+        self.use_current_stream()
         a = self._check(actions, (self.num_envs, self.act_dim), self.torch.float32) if self.act_dim else None
         self.sim.step_dev(self._obs, self._rew, self._done, a)
         return self._obs, self._rew, self._done
@@ -132,6 +140,7 @@ class VecFlowEnv(object):
         [K, R, num_rl] (one per step).  Returns (obs, rew, done) with a leading K axis when
         ``obs_every_step``."""
         torch, R, K = self.torch, self.num_envs, int(num_steps)
+        self.use_current_stream()
         if out is None:
             lead = (K,) if obs_every_step else ()
             out = (torch.empty(lead + (R, self.obs_dim), dtype=torch.float32, device=self.device),

@@ -4,6 +4,5 @@ from flow_amd.networks.ring import RingNetwork
 from flow_amd.networks.figure_eight import FigureEightNetwork
 from flow_amd.networks.merge import MergeNetwork
 from flow_amd.networks.bottleneck import BottleneckNetwork
-from flow_amd.networks.multi_ring import MultiRingNetwork
 
-__all__ = ["Network", "RingNetwork", "FigureEightNetwork", "MergeNetwork", "BottleneckNetwork", "MultiRingNetwork"]
+__all__ = ["Network", "RingNetwork", "FigureEightNetwork", "MergeNetwork", "BottleneckNetwork"]

@@ -67,11 +67,6 @@ class Network(object):
     def specify_crossing(self):
         return None
 
-    def specify_ring_tables(self, junction_length):
-        """Networks made of several separate rings (MultiRingNetwork) list, per ring, their edges with the start on the
-        ring's own loop coordinate: ring r then runs as replica r of the ring kernel.  None otherwise."""
-        return None
-
     def specify_lane_joins(self):
         """Lane-drop networks: the edges at whose start the lanes have joined pairwise; None otherwise."""
         return None

@@ -275,6 +275,10 @@ class FlowSim:
         a = np.ascontiguousarray(np.broadcast_to(np.asarray(value, dtype=dt), shape))
         L.check(self.lib.fs_set_state(self._h, int(field), _ptr(a), a.nbytes))
 
+    def dump_trajectory(self, replica, csv_path):
+        """Append the current state of ``replica`` to ``csv_path`` (fs_dump_trajectory)."""
+        L.check(self.lib.fs_dump_trajectory(self._h, int(replica), str(csv_path).encode()))
+
     # convenience
     @property
     def pos(self):

@@ -353,6 +353,12 @@ int fs_rollout_dev(fs_handle h, int num_steps, const float* actions_dev, size_t 
 int fs_get_state(fs_handle h, int field, void* dst, size_t bytes);
 int fs_set_state(fs_handle h, int field, const void* src, size_t bytes);
 
+/* Append the CURRENT state of one replica to a CSV file (header `time,id,x,speed,lane_number` when the file is new;
+ * one row per vehicle, id = slot index, free slots of open networks skipped): the trajectory ("emission") dump of
+ * flow/core/kernel/simulation/traci.py:95-101 (SUMO's --emission-output) for callers without the Python layer;
+ * flow_amd.core.util.TrajectoryRecorder writes the reference's full column set (flow/core/util.py:57-99). */
+int fs_dump_trajectory(fs_handle h, int replica, const char* csv_path);
+
 #ifdef __cplusplus
 }
 #endif

@@ -166,6 +166,7 @@ class MergeOracle:
         self.seq_ctr = np.zeros(R, dtype=np.int64)
         self.ctl_ctr = np.zeros(R, dtype=np.int64)
         self.emitted = np.zeros((R, max(len(self.inflows), 1)), dtype=np.int64)
+        self.episode = np.full(R, -1, dtype=np.int64)      # resets so far (-1 before the first): keys the entry-lane draws
         self.num_arrived = np.zeros(R, dtype=np.int64)             # of the last sub-step (get_num_arrived)
         self.num_departed = np.zeros(R, dtype=np.int64)
         self.total_arrived = np.zeros(R, dtype=np.int64)
@@ -465,6 +466,7 @@ class MergeOracle:
         self.lac_a = np.where(m2, T(0), self.lac_a)
         self.last_accel = np.where(m2, T(0), self.last_accel)
         self.emitted = np.where(m2[:, :1], 0, self.emitted)
+        self.episode = np.where(m, self.episode + 1, self.episode)
         self.vmax = np.where(m2, np.array([v.get("sumo_max_speed", 30.0) for v in self.veh], dtype=self.dt_)[None, :],
                              self.vmax)
         self.arr_hist = np.where(m2[:, :1], 0, self.arr_hist)
@@ -500,7 +502,7 @@ class MergeOracle:
             if int(fl["route"]) < 0:                                      # M9: departLane = "random"
                 r0, _, _, _ = philox4x32_10(k.astype(np.uint32), np.full(R, 1000 + f, dtype=np.uint32),
                                             (np.arange(R) + int(self.spec.get("replica_offset", 0))).astype(np.uint32),
-                                            np.ones(R, dtype=np.uint32),
+                                            (1 + 2 * self.episode).astype(np.uint32),
                                             np.uint32(int(self.spec.get("seed", 0)) & 0xFFFFFFFF),
                                             np.uint32((int(self.spec.get("seed", 0)) >> 32) & 0xFFFFFFFF))
                 route = (((r0 >> np.uint32(8)).astype(np.int64) * self.P) >> 24)

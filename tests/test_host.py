@@ -383,46 +383,3 @@ def test_package_alias_lets_reference_style_imports_resolve(monkeypatch):
     assert ns["AccelEnv"] is flow_amd.envs.AccelEnv and ns["Experiment"].__module__ == "flow_amd.core.experiment"
     for name in [m for m in list(sys.modules) if m == "flow" or m.startswith("flow.")]:
         monkeypatch.delitem(sys.modules, name, raising=False)
-
-
-def test_deprecated_module_paths_still_resolve_and_warn():
-    """flow.scenarios.* / flow.envs.loop.* / flow.envs.bottleneck_env (pending-deprecation files of the reference): the
-    old names are subclasses of the new ones and warn with the reference's message when constructed."""
-    import warnings
-    import flow_amd
-    flow_amd.install_as_flow()
-    from flow.core.params import NetParams, VehicleParams
-    from flow.envs import BottleNeckAccelEnv, BottleneckAccelEnv, BottleneckDesiredVelocityEnv, DesiredVelocityEnv
-    from flow.envs.loop.lane_changing import LaneChangeAccelEnv as OldLC
-    from flow.envs.loop.loop_accel import AccelEnv as OldAccel
-    from flow.envs.loop.wave_attenuation import WaveAttenuationPOEnv as OldWA
-    from flow.envs.ring.accel import AccelEnv
-    from flow.envs.ring.lane_change_accel import LaneChangeAccelEnv
-    from flow.envs.ring.wave_attenuation import WaveAttenuationPOEnv
-    from flow.networks import BottleneckNetwork, FigureEightNetwork, MergeNetwork, RingNetwork
-    from flow.networks.ring import ADDITIONAL_NET_PARAMS
-    from flow.scenarios import (BottleneckScenario, Figure8Scenario, FigureEightScenario, LoopScenario, MergeScenario,
-                                RingScenario, Scenario)
-    for old, new in ((OldAccel, AccelEnv), (OldLC, LaneChangeAccelEnv), (OldWA, WaveAttenuationPOEnv),
-                     (BottleNeckAccelEnv, BottleneckAccelEnv), (DesiredVelocityEnv, BottleneckDesiredVelocityEnv),
-                     (RingScenario, RingNetwork), (LoopScenario, RingNetwork), (FigureEightScenario, FigureEightNetwork),
-                     (Figure8Scenario, FigureEightNetwork), (MergeScenario, MergeNetwork),
-                     (BottleneckScenario, BottleneckNetwork)):
-        assert issubclass(old, new) and old is not new
-    assert issubclass(RingScenario, Scenario.__mro__[1])
-    from flow.envs.multiagent import AdversarialAccelEnv, MultiEnv, MultiWaveAttenuationPOEnv
-    from flow.multiagent_envs import AdversarialAccelEnv as OldAdv, MultiEnv as OldMulti
-    from flow.multiagent_envs.loop.wave_attenuation import MultiWaveAttenuationPOEnv as OldMW
-    from flow.networks import MultiRingNetwork
-    from flow.scenarios import MultiLoopScenario, MultiRingScenario
-    for old, new in ((OldAdv, AdversarialAccelEnv), (OldMulti, MultiEnv), (OldMW, MultiWaveAttenuationPOEnv),
-                     (MultiRingScenario, MultiRingNetwork), (MultiLoopScenario, MultiRingNetwork)):
-        assert issubclass(old, new) and old is not new
-    vehicles = VehicleParams()
-    vehicles.add("human", num_vehicles=3)
-    with warnings.catch_warnings(record=True) as caught:
-        warnings.simplefilter("always")
-        net = LoopScenario("ring", vehicles, NetParams(additional_params=dict(ADDITIONAL_NET_PARAMS)))
-    msgs = [str(w.message) for w in caught if issubclass(w.category, PendingDeprecationWarning)]
-    assert msgs == ["The class flow.scenarios.loop.LoopScenario is deprecated, use flow.networks.ring.RingNetwork instead."]
-    assert isinstance(net, RingNetwork) and len(net.edges) == 4

@@ -808,3 +808,23 @@ def test_multilane_shuffled_ids_with_and_without_sorting():
         run_pair_ml(spec, "f32", K, actions=acts)
     plain = multilane_spec(R=R, N=N, lanes=3, length=180.0, horizon=40, env=S.ENV_ACCEL, obs_perm=perm)
     run_pair_ml(plain, "f32", 40)
+
+
+def test_fs_dump_trajectory_appends_the_current_state(tmp_path):
+    import csv
+    spec = perturbed(ring_spec(R=3, N=6, junction_length=0.1, horizon=50), seed=9)
+    sim = make(spec, "f64")
+    sim.reset()
+    path = tmp_path / "traj.csv"
+    for k in range(3):
+        sim.step(None)
+        sim.dump_trajectory(1, path)
+    rows = list(csv.DictReader(open(path)))
+    assert len(rows) == 3 * 6 and list(rows[0].keys()) == ["time", "id", "x", "speed", "lane_number"]
+    last = rows[-6:]
+    np.testing.assert_array_equal([float(r["x"]) for r in last], sim.pos[1])
+    np.testing.assert_array_equal([float(r["speed"]) for r in last], sim.vel[1])
+    assert [float(r["time"]) for r in last] == [0.3] * 6 and [int(r["id"]) for r in last] == list(range(6))
+    with pytest.raises(ValueError):
+        sim.dump_trajectory(7, path)
+    sim.close()
