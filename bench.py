@@ -430,6 +430,45 @@ def rollout_1500_leg(device, precision, R, launches=6, check_parity=True):
             "parity": parity}
 
 
+def step_graph_leg(device, precision, R, K=100, replays=40):
+    """The closed-loop call pattern without the per-launch host cost: K single-step launches (fs_step_dev, state
+    round-trips through HBM between them, a policy could sit between any two) captured ONCE as a HIP graph and
+    replayed -- what VecFlowEnv.capture does for a learner (examples/train_vec.py)."""
+    import torch
+    from flow_amd.sim import FlowSim
+    spec = c2_spec(R, seed=1000, horizon=10 ** 9)
+    sim = FlowSim(spec, precision=precision, device=device.index)
+    stream = torch.cuda.Stream(device)
+    obs = torch.empty((K, R, sim.obs_dim), dtype=torch.float32, device=device)
+    rew = torch.empty((K, R), dtype=torch.float32, device=device)
+    done = torch.empty((K, R), dtype=torch.uint8, device=device)
+    with torch.cuda.stream(stream):
+        sim.set_stream(stream.cuda_stream)
+        sim.reset_dev(obs[0])
+        sim.step_dev(obs[0], rew[0], done[0])          # warm-up: lazy host work happens outside the capture
+    stream.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream):
+        for k in range(K):
+            sim.step_dev(obs[k], rew[k], done[k])
+    with torch.cuda.stream(stream):                 # CUDAGraph.replay() goes to torch's CURRENT stream
+        graph.replay()
+        stream.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(replays):
+            graph.replay()
+        stream.synchronize()
+    dt = time.perf_counter() - t0
+    sim.use_own_stream()
+    advanced = int(sim.time_counter[0])
+    sim.close()
+    if advanced != 1 + K * (replays + 1):
+        raise RuntimeError("step graph: the simulator advanced %d steps, expected %d" % (advanced, 1 + K * (replays + 1)))
+    return {"value": R * K * replays / dt, "unit": "env-steps/s", "steps_per_graph": K, "replays": replays,
+            "us_per_step": dt / (K * replays) * 1e6, "dtype": precision,
+            "note": "K fs_step_dev launches per HIP-graph replay (one launch per env step, no host in the loop)"}
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (nothing in THIS
     process has touched the GPU), fail loudly when the node has fewer devices, exit with the worst child code."""
@@ -587,6 +626,7 @@ def main():
                            "achieved_GBs": per_step_b * R * n_api / dt_api / 1e9,
                            "note": "fs_step_dev: 1 launch per env step, 533 B/env-step algorithmic (SURVEY 8d)"}
         r1.sim.close()
+        out["step_api_graph"] = step_graph_leg(device, args.precision, R)
         out["ring_default_speed_mode"] = ring_defaults_leg(device)
         out["c3_figure_eight"] = c3_leg(device)
         out["c3_figure_eight_po"] = c3_leg(device, po=True)

@@ -1,0 +1,123 @@
+"""train_vec.py -- a minimal on-device PPO loop over VecFlowEnv (the GPU counterpart of the reference's
+examples/train.py:110-212, where RLlib rollout workers each drive one SUMO process).
+
+    python examples/train_vec.py --replicas 1024 --iterations 20
+
+Environment: the reference's single-agent ring experiment (examples/exp_configs/rl/singleagent/singleagent_ring.py:
+WaveAttenuationPOEnv, 21 IDM humans + 1 RL vehicle on a 230..270 m ring).  A rollout fragment of K steps -- policy
+forward, action sampling, Env.step of every replica, reset of finished episodes -- is ONE replay of a captured HIP
+graph (VecFlowEnv.capture); observations, actions, rewards and the PPO update all stay in HBM.
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch
+import torch.nn as nn
+
+
+def ring_flow_params(horizon):
+    from flow_amd.controllers import ContinuousRouter, IDMController, RLController
+    from flow_amd.core.params import EnvParams, InitialConfig, NetParams, SumoParams, VehicleParams
+    from flow_amd.envs import WaveAttenuationPOEnv
+    from flow_amd.networks import RingNetwork
+    veh = VehicleParams()
+    veh.add(veh_id="human", acceleration_controller=(IDMController, {"noise": 0.2}),
+            routing_controller=(ContinuousRouter, {}), num_vehicles=21)
+    veh.add(veh_id="rl", acceleration_controller=(RLController, {}), routing_controller=(ContinuousRouter, {}),
+            num_vehicles=1)
+    return dict(exp_tag="stabilizing_the_ring", env_name=WaveAttenuationPOEnv, network=RingNetwork, simulator="traci",
+                sim=SumoParams(sim_step=0.1, render=False, seed=3),
+                env=EnvParams(horizon=horizon, warmup_steps=0,
+                              additional_params={"max_accel": 1, "max_decel": 1, "ring_length": None}),
+                net=NetParams(additional_params={"length": 260, "lanes": 1, "speed_limit": 30, "resolution": 40}),
+                veh=veh, initial=InitialConfig(bunching=20))
+
+
+class GaussianPolicy(nn.Module):
+    def __init__(self, obs_dim, act_dim, hidden=32):
+        super().__init__()
+        self.mu = nn.Sequential(nn.Linear(obs_dim, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh(),
+                                nn.Linear(hidden, act_dim))
+        self.value = nn.Sequential(nn.Linear(obs_dim, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh(),
+                                   nn.Linear(hidden, 1))
+        self.log_std = nn.Parameter(torch.full((act_dim,), -0.5))
+
+    def act(self, obs):                       # what the captured graph runs every step
+        with torch.no_grad():
+            mu = self.mu(obs)
+            return mu + torch.randn_like(mu) * self.log_std.exp()
+
+    def logp_value(self, obs, act):
+        mu = self.mu(obs)
+        std = self.log_std.exp()
+        logp = (-0.5 * ((act - mu) / std) ** 2 - self.log_std - 0.9189385).sum(-1)
+        return logp, self.value(obs).squeeze(-1)
+
+
+def gae(rew, val, done, last_val, gamma=0.999, lam=0.97):
+    K = rew.shape[0]
+    adv = torch.zeros_like(rew)
+    run = torch.zeros_like(last_val)
+    nxt = last_val
+    for t in range(K - 1, -1, -1):
+        live = 1.0 - done[t].float()
+        delta = rew[t] + gamma * nxt * live - val[t]
+        run = delta + gamma * lam * live * run
+        adv[t] = run
+        nxt = val[t]
+    return adv, adv + val
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--replicas", type=int, default=1024)
+    ap.add_argument("--fragment", type=int, default=100, help="env steps per captured graph")
+    ap.add_argument("--horizon", type=int, default=500)
+    ap.add_argument("--iterations", type=int, default=20)
+    ap.add_argument("--epochs", type=int, default=4)
+    ap.add_argument("--lr", type=float, default=3e-4)
+    args = ap.parse_args(argv)
+
+    from flow_amd.envs import VecFlowEnv
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    vec = VecFlowEnv(ring_flow_params(args.horizon), num_replicas=args.replicas, device=0)
+    pi = GaussianPolicy(vec.obs_dim, vec.act_dim).to(dev)
+    opt = torch.optim.Adam(pi.parameters(), lr=args.lr)
+    graph = vec.capture(args.fragment, policy=pi.act, reset_done=True)
+    graph.begin(vec.reset())
+    K, R = args.fragment, args.replicas
+    history = []
+    for it in range(args.iterations):
+        t0 = time.perf_counter()
+        obs, act, rew, done = graph.replay()                   # K closed-loop steps of R replicas: one graph launch
+        graph.synchronize()
+        t_roll = time.perf_counter() - t0
+        o, a = obs[:K].reshape(K * R, -1), act.reshape(K * R, -1)
+        with torch.no_grad():
+            logp_old, val = pi.logp_value(o, a)
+            last_val = pi.value(obs[K]).squeeze(-1)
+            adv, ret = gae(rew, val.view(K, R), done, last_val)
+            adv = ((adv - adv.mean()) / (adv.std() + 1e-8)).reshape(-1)
+            ret = ret.reshape(-1)
+        for _ in range(args.epochs):
+            logp, v = pi.logp_value(o, a)
+            ratio = (logp - logp_old).exp()
+            loss = -torch.min(ratio * adv, ratio.clamp(0.8, 1.2) * adv).mean() + 0.5 * (v - ret).pow(2).mean()
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        mean_rew = float(rew.mean())
+        history.append(mean_rew)
+        print("iteration %3d  mean step reward %8.4f  rollout %.1f ms (%.2f M env-steps/s)  episodes ended %d"
+              % (it, mean_rew, t_roll * 1e3, K * R / t_roll / 1e6, int(done.sum())))
+    vec.close()
+    return history
+
+
+if __name__ == "__main__":
+    main()

@@ -158,6 +158,14 @@ class VecFlowEnv(object):
         self.sim.rollout_dev(K, out[0], out[1], out[2], actions, stride, obs_every_step)
         return out
 
+    def capture(self, num_steps, policy=None, reset_done=False):
+        """A closed-loop fragment of ``num_steps`` steps as ONE replayable HIP graph (StepGraph): per step the
+        ``policy`` (a callable on the [R, obs_dim] observation tensor returning [R, action_dim] actions, e.g. a torch
+        module) and one fs_step_dev launch, captured back to back on one stream.  What the reference's rollout workers
+        do with one Python call + socket round trips per step (examples/train.py:110-212) costs one graph launch per
+        fragment here; observations and actions never leave HBM."""
+        return StepGraph(self, num_steps, policy, reset_done)
+
     # ---- host-side inspection
     def get_state(self, field):
         return self.sim.get_state(field)
@@ -179,3 +187,67 @@ class VecFlowEnv(object):
         self.env.terminate()
 
     terminate = close
+
+
+class StepGraph(object):
+    """``vec.capture(K, policy)``: K x (policy -> actions -> Env.step of every replica) recorded once with HIP stream
+    capture (``torch.cuda.CUDAGraph``; libflowsim's launches go to the capturing stream) and replayed per fragment.
+
+    Buffers (device, owned by the graph): ``obs [K+1, R, obs_dim]`` (``obs[0]`` = observation before the first step:
+    what ``begin`` set, then the last observation of the previous replay), ``actions [K, R, action_dim]``, ``rew [K, R]``,
+    ``done [K, R]`` uint8.  With ``reset_done`` every replica whose episode ended is reset inside the graph
+    (masked fs_reset_dev) and ``obs[k+1]`` holds the first observation of its next episode, as a vectorised
+    Gym / RLlib VectorEnv does.  The policy must be capturable (no host synchronisation, static shapes).
+    Building the graph runs up to two eager warm-up steps: call ``vec.reset()`` and ``begin(obs)`` afterwards."""
+
+    def __init__(self, vec, num_steps, policy=None, reset_done=False):
+        torch = vec.torch
+        self.vec, self.K, self.policy, self.reset_done = vec, int(num_steps), policy, bool(reset_done)
+        R, K = vec.num_envs, self.K
+        dev = vec.device
+        self.obs = torch.zeros((K + 1, R, vec.obs_dim), dtype=torch.float32, device=dev)
+        self.rew = torch.zeros((K, R), dtype=torch.float32, device=dev)
+        self.done = torch.zeros((K, R), dtype=torch.uint8, device=dev)
+        self.actions = torch.zeros((K, R, max(vec.act_dim, 1)), dtype=torch.float32, device=dev)
+        self._carry = torch.zeros((R, vec.obs_dim), dtype=torch.float32, device=dev)
+        self.stream = torch.cuda.Stream(dev)
+        with torch.cuda.stream(self.stream):
+            vec.use_current_stream()                 # bind BEFORE the capture: fs_set_stream synchronises
+            self.obs[0].copy_(vec._obs)
+            self._body(2 if K > 1 else 1)            # eager warm-up: lazy host work (divisor proofs, allocator) happens here
+            vec.sim.sync()
+            self.obs[0].copy_(vec._obs)
+        self.stream.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=self.stream):
+            self.obs[0].copy_(self._carry)
+            self._body(K)
+            self._carry.copy_(self.obs[K])
+        # NOTE: the eager warm-up advanced the simulator by up to two steps: vec.reset() + begin(obs) start a rollout
+
+    def _body(self, steps):
+        vec, sim = self.vec, self.vec.sim
+        for k in range(steps):
+            a = None
+            if vec.act_dim:
+                if self.policy is not None:
+                    self.actions[k].copy_(self.policy(self.obs[k]))
+                a = self.actions[k]
+            sim.step_dev(self.obs[k + 1], self.rew[k], self.done[k], a)
+            if self.reset_done:
+                sim.reset_dev(self.obs[k + 1], self.done[k])
+
+    def begin(self, obs0):
+        """Set the observation the first step's policy call sees (after ``vec.reset()``)."""
+        with self.vec.torch.cuda.stream(self.stream):
+            self._carry.copy_(obs0)
+
+    def replay(self):
+        """One fragment: returns (obs [K+1,R,D], actions [K,R,A], rew [K,R], done [K,R]) views, valid until the next
+        replay; enqueued on the graph's stream (``graph.stream``), synchronise or wait on it before reading."""
+        with self.vec.torch.cuda.stream(self.stream):      # CUDAGraph.replay() goes to torch's CURRENT stream
+            self.graph.replay()
+        return self.obs, self.actions, self.rew, self.done
+
+    def synchronize(self):
+        self.stream.synchronize()

@@ -1,0 +1,82 @@
+"""Closed-loop use of the batched simulator: the HIP-graph fragment (VecFlowEnv.capture), the
+RLlib-shaped FlowVectorEnv adapter (flow/utils/rllib.py / examples/train.py:110-212 of the reference give every
+rollout worker its own SUMO; here the workers are replicas) and the on-device training example."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "examples"))
+
+
+def flow_params(horizon=60):
+    import train_vec
+    return train_vec.ring_flow_params(horizon)
+
+
+def test_captured_fragment_bit_exact_without_noise():
+    import torch
+    from flow_amd.controllers import ContinuousRouter, IDMController, RLController
+    from flow_amd.core.params import VehicleParams
+    from flow_amd.envs import VecFlowEnv
+    fp = flow_params(horizon=40)
+    veh = VehicleParams()
+    veh.add(veh_id="human", acceleration_controller=(IDMController, {}), routing_controller=(ContinuousRouter, {}),
+            num_vehicles=21)
+    veh.add(veh_id="rl", acceleration_controller=(RLController, {}), routing_controller=(ContinuousRouter, {}),
+            num_vehicles=1)
+    fp["veh"] = veh
+    R, K = 33, 16
+    lin = torch.nn.Linear(3, 1).to("cuda")
+
+    def policy(obs):
+        with torch.no_grad():
+            return torch.tanh(lin(obs))
+
+    a = VecFlowEnv(fp, num_replicas=R, device=0)
+    g = a.capture(K, policy=policy, reset_done=True)
+    g.begin(a.reset())
+    b = VecFlowEnv(fp, num_replicas=R, device=0)
+    ob = b.reset().clone()
+    for frag in range(4):                             # 64 steps: crosses the 40-step horizon -> in-graph resets
+        obs, act, rew, done = g.replay()
+        g.synchronize()
+        for k in range(K):
+            assert torch.equal(obs[k], ob)
+            act_b = policy(ob)
+            assert torch.equal(act[k], act_b)
+            o2, r2, d2 = b.step(act_b)
+            assert torch.equal(rew[k], r2) and torch.equal(done[k], d2)
+            if bool(d2.any()):
+                b.reset_done()
+            ob = b._obs.clone()
+            assert torch.equal(obs[k + 1], ob)
+        assert int(done.sum()) == (R if frag == 2 else 0)
+    a.close(), b.close()
+
+
+def test_flow_vector_env_has_the_rllib_vector_env_interface():
+    from flow_amd.utils.vector_env import FlowVectorEnv
+    env = FlowVectorEnv(flow_params(horizon=5), num_envs=6, seed=2)
+    obs = env.vector_reset()
+    assert len(obs) == 6 and obs[0].shape == (3,)
+    for t in range(5):
+        obs, rew, done, info = env.vector_step([[0.1]] * 6)
+        assert len(obs) == len(rew) == len(done) == len(info) == 6 and isinstance(rew[0], float)
+    assert all(done)
+    o3 = env.reset_at(3)
+    assert o3.shape == (3,) and len(env.get_sub_environments()) == 1
+    obs, rew, done, info = env.vector_step([[0.0]] * 6)
+    assert not done[3]                                # replica 3 started a new episode, the others are past theirs
+    assert env.action_space.shape == (1,) and env.observation_space.shape == (3,)
+    env.close()
+
+
+def test_train_vec_example_runs_on_the_device():
+    import train_vec
+    hist = train_vec.main(["--replicas", "64", "--fragment", "20", "--horizon", "50", "--iterations", "3",
+                           "--epochs", "1"])
+    assert len(hist) == 3 and all(np.isfinite(hist))
