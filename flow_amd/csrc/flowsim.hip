@@ -220,6 +220,18 @@ struct Sim : SimBase {
     dv.lane_change_mode = cfg.lane_change_mode;
     dv.last_lc_quirk = cfg.last_lc_quirk;
     dv.lc_duration = T(cfg.lane_change_duration);
+    {  // ML7: autonomous lane changing of the non-RL vehicles on a multi-lane ring
+      std::vector<int32_t> lca(N, 0);
+      int any_lc = 0;
+      for (int i = 0; i < N; ++i) {
+        lca[i] = (veh[i].lane_change_mode & 0x55) != 0 && veh[i].controller != FS_CTRL_RL;
+        any_lc |= lca[i];
+      }
+      if ((rc = upload(&dv.lc_auto, lca))) return rc;
+      dv.lc_enabled = (cfg.network == FS_NET_RING && cfg.num_lanes > 1 && any_lc) ? 1 : 0;
+      dv.lc_cooldown = cfg.lane_change_cooldown_steps > 0 ? cfg.lane_change_cooldown_steps : 1;
+      dv.lc_min_gain = T(cfg.lane_change_min_gain);
+    }
     dv.nseg = cfg.num_segments;
     dv.seg_internal = 0u;
     for (int k = 0; k < FS_MAX_SEGMENTS; ++k) {

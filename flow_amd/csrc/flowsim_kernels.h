@@ -78,6 +78,10 @@ struct DevView {
   uint32_t rep0;        // global index of this handle's replica 0: noise streams are keyed by GLOBAL replica ids
   T dt, ramp, jlen, crash_gap, max_speed, target_velocity, max_cost, act_lo, act_hi, po_max_length;
   T lc_duration;
+  // autonomous lane changing on multi-lane rings (ML7; the rule M11 of the lane-drop network)
+  const int32_t* lc_auto;   // [N] 1: the slot's vehicle changes lane on its own
+  int lc_enabled, lc_cooldown;
+  T lc_min_gain;
   // non-ring closed loops (figure eight): edge table in route order + the crossing model (S-J)
   int nseg, junction_on;
   unsigned seg_internal;                 // bit k: segment k is a junction-internal edge
@@ -352,6 +356,64 @@ __device__ __forceinline__ bool seg_any(bool pred, int seg) {
   unsigned long long m = ((1ull << (SEG & 63)) - 1ull) << (seg * (SEG & 63));
   return (b & m) != 0ull;
 }
+
+template <int SEG>
+__device__ __forceinline__ unsigned long long seg_ballot(bool pred, int seg) {
+  unsigned long long b = __ballot(pred);
+  if (SEG == 64) return b;
+  return (b >> (seg * (SEG & 63))) & ((1ull << (SEG & 63)) - 1ull);
+}
+
+// minimum over the SEG-lane segment: the butterfly of seg_sum with min instead of +
+__device__ __forceinline__ float min_swap16(float v) {
+  unsigned a = __float_as_uint(v), b = a;
+  swap_rows16(a, b);
+  const float fa = __uint_as_float(a), fb = __uint_as_float(b);
+  return fb < fa ? fb : fa;
+}
+__device__ __forceinline__ float min_swap32(float v) {
+  unsigned a = __float_as_uint(v), b = a;
+  swap_rows32(a, b);
+  const float fa = __uint_as_float(a), fb = __uint_as_float(b);
+  return fb < fa ? fb : fa;
+}
+__device__ __forceinline__ double min_swap16(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  unsigned lo0 = unsigned(u), lo1 = lo0, hi0 = unsigned(u >> 32), hi1 = hi0;
+  swap_rows16(lo0, lo1);
+  swap_rows16(hi0, hi1);
+  const double a = __builtin_bit_cast(double, ((unsigned long long)hi0 << 32) | lo0);
+  const double b = __builtin_bit_cast(double, ((unsigned long long)hi1 << 32) | lo1);
+  return b < a ? b : a;
+}
+__device__ __forceinline__ double min_swap32(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  unsigned lo0 = unsigned(u), lo1 = lo0, hi0 = unsigned(u >> 32), hi1 = hi0;
+  swap_rows32(lo0, lo1);
+  swap_rows32(hi0, hi1);
+  const double a = __builtin_bit_cast(double, ((unsigned long long)hi0 << 32) | lo0);
+  const double b = __builtin_bit_cast(double, ((unsigned long long)hi1 << 32) | lo1);
+  return b < a ? b : a;
+}
+template <int SEG, typename T>
+__device__ __forceinline__ T seg_min(T v) {
+  T w = dpp<DPP_QUAD_XOR1>(v);
+  v = w < v ? w : v;
+  w = dpp<DPP_QUAD_XOR2>(v);
+  v = w < v ? w : v;
+  w = dpp<DPP_ROW_HALF_MIRROR>(v);
+  v = w < v ? w : v;
+  if (SEG >= 16) {
+    w = dpp<DPP_ROW_MIRROR>(v);
+    v = w < v ? w : v;
+  }
+  if (SEG >= 32) v = min_swap16(v);
+  if (SEG >= 64) v = min_swap32(v);
+  return v;
+}
+
+template <int SEG, typename T>
+__device__ __forceinline__ T seg_max(T v) { return -seg_min<SEG>(-v); }
 
 // ---------------------------------------------------------------------------
 // Philox-4x32-10 + Box-Muller: oracle/refsim.py philox4x32_10 / gaussian_noise
@@ -1286,11 +1348,22 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
   int lead = -1, foll = -1;
   T dlead = T(0), vl = T(0), len_lead = T(0), h = T(1000), vf = T(0);
   bool has = false;
+  // ML7 (autonomous lane changing, the lane-drop network's rule M11 on a ring): vehicles whose type lets SUMO change
+  // lanes (lane_change_mode with a strategic / cooperative / speed-gain / keep-right bit; not the RL vehicles, whose
+  // changes are commanded) want the adjacent lane whose leader gap beats their headway by lc_min_gain, if the gaps to
+  // the new leader and follower are at least the SUMO-IDM desired gaps; wishes are formed on every neighbour
+  // snapshot, ONE change per replica and sub-step (largest gain, lowest slot) is executed with the move.
+  const bool lc_on = s.lc_enabled != 0;
+  const bool my_lc_auto = lc_on && s.lc_auto[ii] != 0 && sl.ctrl != FS_CTRL_RL;
+  int lc_want = -1;
+  T lc_gain = T(0);
   auto scan = [&]() {
     const T big = T(3.0e38);
     T best = big, bestf = big;
     lead = -1;
     foll = -1;
+    T abest[2] = {big, big}, abestf[2] = {big, big};     // [0]: lane - 1, [1]: lane + 1
+    int alead[2] = {-1, -1}, afoll[2] = {-1, -1};
     // slot j is the same for every lane of the wave: x_j / lane_j come by v_readlane (no LDS round trip per
     // candidate), and the tests are bitwise so that they stay selects instead of nested exec-mask branches
     for (int j = 0; j < N; ++j) {
@@ -1309,6 +1382,17 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
       lead = tl ? j : lead;
       bestf = tf ? dji : bestf;
       foll = tf ? j : foll;
+      if (lc_on) {                                      // wave-uniform
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const bool adj = (lj == ln + (2 * q - 1)) & (j != ii);
+          const bool al = adj & (dij < abest[q]), af = adj & (dji < abestf[q]);
+          abest[q] = al ? dij : abest[q];
+          alead[q] = al ? j : alead[q];
+          abestf[q] = af ? dji : abestf[q];
+          afoll[q] = af ? j : afoll[q];
+        }
+      }
     }
     has = lead >= 0;
     const int lsrc = segbase + (has ? lead : ii);
@@ -1316,6 +1400,32 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
     vl = bperm(v, lsrc);
     len_lead = bperm(sl.length, lsrc);
     h = has ? dlead - len_lead : T(1000);
+    if (lc_on) {                                        // ML7 wishes on this snapshot (operation order of M11)
+      const bool ok0 = my_lc_auto && (tcount - last_lc >= s.lc_cooldown);
+      const T two_sqrt = T(2) * tsqrt(sl.max_accel * sl.max_decel);
+      T best_gain = -big;
+      int best_lane = -1;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {                     // right first, so that left wins a tie
+        const int tl = ln + (2 * q - 1);
+        const bool valid_t = ok0 && tl >= 0 && tl < s.num_lanes;
+        const bool has_l = alead[q] >= 0, has_f = afoll[q] >= 0;
+        const int ls = segbase + (has_l ? alead[q] : ii), fs_ = segbase + (has_f ? afoll[q] : ii);
+        const T vl2 = bperm(v, ls), ll2 = bperm(sl.length, ls), vf2 = bperm(v, fs_);
+        const T gap_l = has_l ? abest[q] - ll2 : T(1000.0);
+        const T gap_f = has_f ? abestf[q] - sl.length : T(1000.0);
+        const T v_l = has_l ? vl2 : T(0), v_f = has_f ? vf2 : T(0);
+        const T need_l = sl.sumo_min_gap + tmax(T(0), v * sl.sumo_tau + v * (v - v_l) / two_sqrt);
+        const T need_f = sl.sumo_min_gap + tmax(T(0), v_f * sl.sumo_tau + v_f * (v_f - v) / two_sqrt);
+        const bool safe = (!has_l || gap_l >= need_l) && (!has_f || gap_f >= need_f);
+        const T gain = gap_l - h;
+        const bool take = valid_t && safe && (gain >= s.lc_min_gain) && (gain >= best_gain);
+        best_gain = take ? gain : best_gain;
+        best_lane = take ? tl : best_lane;
+      }
+      lc_want = best_lane;
+      lc_gain = best_lane >= 0 ? best_gain : T(0);
+    }
     if (!has) vl = T(-1001);                            // get_speed(None): the reference's error value
   };
   scan();
@@ -1372,6 +1482,14 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
           }
         }
         if (clash || !live) new_ln = ln;
+      }
+      if (lc_on) {                                       // ML7: the one autonomous change of this sub-step
+        const bool want = lc_want >= 0 && valid && live;
+        const T gsel = want ? lc_gain : T(-3.0e38);
+        const T gmax = seg_max<SEG>(gsel);
+        const unsigned long long wb = seg_ballot<SEG>(want && gsel == gmax, seg);
+        const int win = wb ? __ffsll((long long)wb) - 1 : -1;
+        if (i == win) new_ln = lc_want;
       }
       // ---- apply_acceleration + integration (S4-S9) -----------------------
       T next_vel = tmax(v + acc * dt, T(0));

@@ -81,64 +81,6 @@ enum { CELL_OBS_START = 0, CELL_OBS_LO = 1, CELL_OBS_HI = 2, CELL_ACT_START = 3,
 enum { CNT_SIM_STEPS = 0, CNT_SEQ = 1, CNT_CTL = 2, CNT_ARRIVED = 3, CNT_DEPARTED = 4, CNT_TOTAL_ARRIVED = 5,
        CNT_TOTAL_DEPARTED = 6, CNT_TOTAL_DROPPED = 7 };
 
-template <int SEG>
-__device__ __forceinline__ unsigned long long seg_ballot(bool pred, int seg) {
-  unsigned long long b = __ballot(pred);
-  if (SEG == 64) return b;
-  return (b >> (seg * (SEG & 63))) & ((1ull << (SEG & 63)) - 1ull);
-}
-
-// minimum over the SEG-lane segment: the butterfly of seg_sum with min instead of +
-__device__ __forceinline__ float min_swap16(float v) {
-  unsigned a = __float_as_uint(v), b = a;
-  swap_rows16(a, b);
-  const float fa = __uint_as_float(a), fb = __uint_as_float(b);
-  return fb < fa ? fb : fa;
-}
-__device__ __forceinline__ float min_swap32(float v) {
-  unsigned a = __float_as_uint(v), b = a;
-  swap_rows32(a, b);
-  const float fa = __uint_as_float(a), fb = __uint_as_float(b);
-  return fb < fa ? fb : fa;
-}
-__device__ __forceinline__ double min_swap16(double v) {
-  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-  unsigned lo0 = unsigned(u), lo1 = lo0, hi0 = unsigned(u >> 32), hi1 = hi0;
-  swap_rows16(lo0, lo1);
-  swap_rows16(hi0, hi1);
-  const double a = __builtin_bit_cast(double, ((unsigned long long)hi0 << 32) | lo0);
-  const double b = __builtin_bit_cast(double, ((unsigned long long)hi1 << 32) | lo1);
-  return b < a ? b : a;
-}
-__device__ __forceinline__ double min_swap32(double v) {
-  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-  unsigned lo0 = unsigned(u), lo1 = lo0, hi0 = unsigned(u >> 32), hi1 = hi0;
-  swap_rows32(lo0, lo1);
-  swap_rows32(hi0, hi1);
-  const double a = __builtin_bit_cast(double, ((unsigned long long)hi0 << 32) | lo0);
-  const double b = __builtin_bit_cast(double, ((unsigned long long)hi1 << 32) | lo1);
-  return b < a ? b : a;
-}
-template <int SEG, typename T>
-__device__ __forceinline__ T seg_min(T v) {
-  T w = dpp<DPP_QUAD_XOR1>(v);
-  v = w < v ? w : v;
-  w = dpp<DPP_QUAD_XOR2>(v);
-  v = w < v ? w : v;
-  w = dpp<DPP_ROW_HALF_MIRROR>(v);
-  v = w < v ? w : v;
-  if (SEG >= 16) {
-    w = dpp<DPP_ROW_MIRROR>(v);
-    v = w < v ? w : v;
-  }
-  if (SEG >= 32) v = min_swap16(v);
-  if (SEG >= 64) v = min_swap32(v);
-  return v;
-}
-
-template <int SEG, typename T>
-__device__ __forceinline__ T seg_max(T v) { return -seg_min<SEG>(-v); }
-
 // ---- launch constants of the step loop ---------------------------------------------------------------------
 // Two homes for the tables, chosen by OpenTabs<T, IN_LDS>:
 //   IN_LDS = false  one entry per lane in VGPRs, entry j fetched with v_readlane (no memory access in the loop);

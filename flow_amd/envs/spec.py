@@ -38,6 +38,8 @@ def vehicle_slots(vehicle_kernel, rl_order, ids=None):
                  sumo_min_gap=float(cf.controller_params["minGap"]),
                  sumo_max_speed=float(cf.controller_params["maxSpeed"]),
                  initial_speed=float(vehicle_kernel.get_initial_speed(veh_id)),
+                 lane_change_mode=int(vehicle_kernel.type_parameters[vehicle_kernel.get_type(veh_id)][
+                     "lane_change_params"].lane_change_mode),
                  rl_index=rl_order.index(veh_id) if isinstance(ctrl, RLController) else -1)
         slots.append(d)
     return slots
@@ -351,6 +353,9 @@ def build_spec(env, num_replicas, rng=None):
         num_lanes=num_lanes, init_lane=lanes,
         lane_change_duration=float(ep.additional_params.get("lane_change_duration", 0)),
         lane_change_mode=max(lc_modes) if lc_modes else 512,
+        # ML7: vehicles whose lane_change_mode lets SUMO change lanes do so on their own (simplified model M11)
+        lane_change_cooldown_steps=max(1, int(round(float(getattr(sp, "lane_change_cooldown", 5.0)) / dt))),
+        lane_change_min_gain=float(getattr(sp, "lane_change_min_gain", 10.0)),
         last_lc_quirk=bool(getattr(env, "LAST_LC_QUIRK", True)), sort_vehicles=sort_vehicles)
     if obs_perm is not None:
         spec["obs_perm"] = obs_perm

@@ -526,6 +526,14 @@ class MultiLaneRingOracle(RingOracle):
         self.lc_duration = self.dt_.type(spec.get("lane_change_duration", 0))
         self.lc_mode = int(spec.get("lane_change_mode", 512))
         self.quirk = bool(spec.get("last_lc_quirk", True))
+        # ML7: autonomous lane changing (the simplified model M11 of oracle/opennet.py on a ring) for the non-RL
+        # vehicles whose lane_change_mode has a strategic / cooperative / speed-gain / keep-right bit
+        self.lc_auto = np.array([(int(v.get("lane_change_mode", 0)) & 0x55) != 0 and v["controller"] != CTRL_RL
+                                 for v in self.veh])
+        self.lc_enabled = bool(self.lc_auto.any()) and self.lanes > 1
+        self.lc_cooldown = max(1, int(spec.get("lane_change_cooldown_steps", 10)))
+        self.lc_min_gain = self.dt_.type(spec.get("lane_change_min_gain", 10.0))
+        self.num_lane_changes = np.zeros(self.R, dtype=np.int64)
 
     # ---- ML2
     def neighbours(self, x=None, lane=None):
@@ -608,11 +616,63 @@ class MultiLaneRingOracle(RingOracle):
             new_lane[:, i] = np.where(want, target, self.lane[:, i])
         return new_lane
 
+    def _auto_lane_changes(self, new_lane, active, h):
+        """ML7 on the snapshot: every candidate's wish (adjacent lane whose leader gap beats the own headway by
+        lc_min_gain with SUMO-IDM desired gaps to the new leader / follower, left wins a tie), then ONE change per
+        replica: largest gain, lowest slot."""
+        T = self.dt_.type
+        R, N = self.R, self.N
+        BIG = T(3.0e38)
+        _, _, _, _, d = self.neighbours()
+        jj = np.arange(N)
+        other = jj[None, None, :] != jj[None, :, None]
+        v = self.v
+        p = {k: np.array([vv.get(k, dflt) for vv in self.veh], dtype=self.dt_)
+             for k, dflt in (("sumo_min_gap", 2.5), ("sumo_tau", 1.0), ("max_accel", 2.6), ("max_decel", 4.5))}
+        two_sqrt = T(2) * np.sqrt(p["max_accel"] * p["max_decel"])
+
+        def need(a, b):
+            return p["sumo_min_gap"][None, :] + np.maximum(T(0), a * p["sumo_tau"][None, :] + a * (a - b) / two_sqrt[None, :])
+        ok0 = self.lc_auto[None, :] & ((self.time_counter[:, None] - self.last_lc) >= self.lc_cooldown)
+        best_gain = np.full((R, N), -BIG)
+        best_lane = np.full((R, N), -1, dtype=np.int64)
+        dT = np.transpose(d, (0, 2, 1))                              # dT[r,i,j] = arc from j to i
+        for dl in (-1, 1):                                           # right first, so that left wins a tie
+            tl = self.lane + dl
+            valid = ok0 & (tl >= 0) & (tl < self.lanes)
+            in_t = other & (self.lane[:, None, :] == tl[:, :, None])
+            dl_ = np.where(in_t, d, BIG)
+            li = np.argmin(dl_, axis=2)
+            has_l = np.take_along_axis(dl_, li[:, :, None], 2)[:, :, 0] < BIG
+            gap_l = np.where(has_l, np.take_along_axis(d, li[:, :, None], 2)[:, :, 0] - self.veh_len[li], T(1000.0))
+            v_l = np.where(has_l, np.take_along_axis(v, li, 1), T(0))
+            df_ = np.where(in_t, dT, BIG)
+            fi = np.argmin(df_, axis=2)
+            has_f = np.take_along_axis(df_, fi[:, :, None], 2)[:, :, 0] < BIG
+            gap_f = np.where(has_f, np.take_along_axis(dT, fi[:, :, None], 2)[:, :, 0] - self.veh_len[None, :], T(1000.0))
+            v_f = np.where(has_f, np.take_along_axis(v, fi, 1), T(0))
+            safe = (~has_l | (gap_l >= need(v, v_l))) & (~has_f | (gap_f >= need(v_f, v)))
+            gain = gap_l - h
+            take = valid & safe & (gain >= self.lc_min_gain) & (gain >= best_gain)
+            best_gain = np.where(take, gain, best_gain)
+            best_lane = np.where(take, tl, best_lane)
+        want = (best_lane >= 0) & active[:, None]
+        gsel = np.where(want, best_gain, -BIG)
+        win = np.argmax(gsel, axis=1)                                # first maximum = lowest slot
+        rows = np.arange(R)
+        ok = want[rows, win]
+        out = new_lane.copy()
+        out[rows[ok], win[ok]] = best_lane[rows[ok], win[ok]]
+        self.num_lane_changes = self.num_lane_changes + ok
+        return out
+
     def _substep(self, actions, active):
         T = self.dt_.type
         dt = T(self.dt)
         acc, commanded, h, v_lead, has_lead = self._accelerations(actions, active)
         new_lane = self._lane_changes(actions, active, h)
+        if self.lc_enabled:
+            new_lane = self._auto_lane_changes(new_lane, active, h)
         if self.sort_vehicles:                                       # accel.py:150-169: additional_command
             self.x_sort = np.where(active[:, None], self.obs_position(self.x), self.x_sort)
         v = self.v

@@ -697,3 +697,41 @@ def test_shuffle_on_a_multi_lane_ring():
     again = np.array([veh.get_x_by_id(v) for v in veh.get_ids()])
     assert sorted(np.round(again, 6)) == sorted(np.round(first, 6)) and not np.allclose(again, first)
     env.terminate()
+
+
+def test_sim_lane_change_controller_humans_change_lanes_on_a_multilane_ring():
+    """a19: SimLaneChangeController vehicles (lane_change_controllers.py:7-16: "SUMO decides") whose
+    SumoLaneChangeParams.lane_change_mode allows it ("strategic", core/params.py:20-25) change lanes on their own on a
+    multi-lane ring (simplified model ML7); with the default mode "no_lat_collide" nobody moves."""
+    from flow_amd.controllers import ContinuousRouter, IDMController, SimLaneChangeController
+    from flow_amd.core.params import (EnvParams, InitialConfig, NetParams, SumoCarFollowingParams,
+                                      SumoLaneChangeParams, SumoParams, VehicleParams)
+    from flow_amd.envs import AccelEnv
+    from flow_amd.networks import RingNetwork
+    from flow_amd.utils.registry import make_create_env
+
+    def params(mode):
+        veh = VehicleParams()
+        for name, v0 in (("slow", 6), ("fast", 25)):
+            veh.add(veh_id=name, acceleration_controller=(IDMController, {"v0": v0}),
+                    lane_change_controller=(SimLaneChangeController, {}), routing_controller=(ContinuousRouter, {}),
+                    car_following_params=SumoCarFollowingParams(speed_mode="aggressive"),
+                    lane_change_params=SumoLaneChangeParams(lane_change_mode=mode), num_vehicles=6)
+        return dict(exp_tag="ring2", env_name=AccelEnv, network=RingNetwork, simulator="traci",
+                    sim=SumoParams(sim_step=0.1, render=False),
+                    env=EnvParams(horizon=400, additional_params={"max_accel": 3, "max_decel": 3, "target_velocity": 10,
+                                                                  "sort_vehicles": False}),
+                    net=NetParams(additional_params={"length": 230, "lanes": 2, "speed_limit": 30, "resolution": 40}),
+                    veh=veh, initial=InitialConfig(lanes_distribution=1))          # everybody starts in lane 0
+    moved = {}
+    for mode in ("strategic", "no_lat_collide"):
+        env = make_create_env(params(mode))[0]()
+        env.reset()
+        ids = env.k.vehicle.get_ids()
+        assert all(env.k.vehicle.get_lane(v) == 0 for v in ids)
+        for _ in range(300):
+            _, _, done, _ = env.step(None)
+            assert not done
+        moved[mode] = [v for v in ids if env.k.vehicle.get_lane(v) != 0]
+        env.terminate()
+    assert len(moved["strategic"]) > 0 and moved["no_lat_collide"] == []

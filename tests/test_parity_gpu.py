@@ -828,3 +828,54 @@ def test_fs_dump_trajectory_appends_the_current_state(tmp_path):
     with pytest.raises(ValueError):
         sim.dump_trajectory(7, path)
     sim.close()
+
+
+# ------------------------------------------------------------------ ML7: autonomous lane changing on multi-lane rings
+def strategic_spec(R, N, lanes, seed, length=260.0, horizon=300, n_rl=0, **kw):
+    """Humans whose SumoLaneChangeParams.lane_change_mode is "strategic" (1621, core/params.py:20-25): SUMO would
+    change their lane on its own (SimLaneChangeController, lane_change_controllers.py:7-16)."""
+    spec = multilane_spec(R=R, N=N, lanes=lanes, length=length, horizon=horizon, n_rl=n_rl, seed=seed, **kw)
+    rng = np.random.default_rng(seed)
+    veh = []
+    for i, vs in enumerate(spec["vehicles"]):
+        if vs["controller"] == S.CTRL_RL:
+            veh.append(dict(vs, lane_change_mode=1621))            # RL vehicles: commanded changes only
+        else:                                                      # unequal desired speeds: faster cars want to pass
+            veh.append(idm_vehicle(p=[float(rng.uniform(8, 30)), 1, 1, 1.5, 4, 2, 0, 0], lane_change_mode=1621))
+    spec["vehicles"] = veh
+    # everybody starts in one lane: the others are empty, so changing pays at once
+    lane0 = np.zeros((R, N), dtype=np.int32)
+    lane0[:, ::4] = 1
+    spec["init_lane"] = lane0
+    spec["lane_change_cooldown_steps"] = 20
+    spec["lane_change_min_gain"] = 6.0
+    return spec
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_autonomous_lane_changes_on_multilane_ring_bit_exact(seed):
+    R, N, K = 6, 18, 250
+    spec = strategic_spec(R, N, lanes=2 + seed % 2, seed=seed, env=S.ENV_ACCEL)
+    spec["init_pos"] = np.tile(np.arange(N) * (260.4 / N), (R, 1)) + np.abs(
+        np.random.default_rng(seed).normal(0, 0.3, (R, N)))
+    ora = run_pair_ml(spec, "f32", K)
+    assert ora.num_lane_changes.min() > 0, "every replica must see autonomous lane changes"
+    assert (ora.lane != spec["init_lane"]).any()
+    # cooldown: no vehicle changed twice within 20 sub-steps is implied by the oracle; a vehicle with mode 512 never moves
+    spec2 = dict(spec, vehicles=[dict(v, lane_change_mode=512) for v in spec["vehicles"]])
+    ora2 = run_pair_ml(spec2, "f32", 60)
+    assert ora2.num_lane_changes.max() == 0 and (ora2.lane == spec["init_lane"]).all()
+
+
+def test_autonomous_and_commanded_lane_changes_together_f32_and_f64():
+    R, N, K = 5, 16, 200
+    spec = strategic_spec(R, N, lanes=3, seed=7, n_rl=2, lane_change_duration=2)
+    spec["init_pos"] = np.tile(np.arange(N) * (260.4 / N), (R, 1))
+    rng = np.random.default_rng(3)
+    acts = np.zeros((K, R, 4), dtype=np.float32)
+    acts[:, :, 0::2] = rng.uniform(-1.0, 1.0, (K, R, 2))
+    acts[:, :, 1::2] = rng.integers(-1, 2, (K, R, 2))
+    ora = run_pair_ml(spec, "f32", K, actions=acts)
+    assert ora.num_lane_changes.min() > 0
+    run_pair_ml(dict(spec, num_replicas=2, init_pos=spec["init_pos"][:2], init_lane=spec["init_lane"][:2],
+                     ring_length=spec["ring_length"][:2]), "f64", 120, actions=acts[:120, :2], exact=False, atol=1e-9)
