@@ -21,6 +21,7 @@
 #include "flowsim_kernels.h"
 #include "flowsim_open.h"
 #include "flowsim_pair.h"
+#include "flowsim_fig8.h"
 #include "flowsim_wide.h"
 
 namespace {
@@ -67,6 +68,7 @@ struct SimBase {
   int rollout_block = 512;      // threads per block of k_rollout_idm (FLOWSIM_ROLLOUT_BLOCK overrides; sweep: DESIGN.md)
   bool mixed = false;           // FS_MIXED: float64 state, float32 controller arithmetic (k_rollout_pair<double>)
   bool no_pair = false;         // FLOWSIM_NO_PAIR=1: keep k_rollout_idm (one vehicle per lane) for the float rollout
+  bool no_loop_kernel = false;  // FLOWSIM_NO_LOOP_KERNEL=1: keep the generic k_steps for segment-table loops (tests)
   int pair_block = 256;         // threads per block of k_rollout_pair (FLOWSIM_PAIR_BLOCK overrides)
 
   virtual int launch_steps(int num_steps, const uint8_t* mask, const float* actions, size_t act_stride,
@@ -180,6 +182,10 @@ struct Sim : SimBase {
       if (v.controller != FS_CTRL_IDM) all_idm = false;
       if (v.controller != FS_CTRL_IDM && v.controller != FS_CTRL_RL && v.controller != FS_CTRL_SIM) idm_set = false;
     }
+    loop_div_ok = true;      // premises of div_core in k_rollout_loop: s0 and minGap keep the dividends out of the tiny range
+    for (int i = 0; i < N; ++i)
+      loop_div_ok = loop_div_ok && float(veh[i].sumo_min_gap) >= 1e-3f && float(veh[i].sumo_min_gap) <= 1e6f &&
+                    (veh[i].controller != FS_CTRL_IDM || (float(veh[i].p[5]) >= 1e-3f && float(veh[i].p[5]) <= 1e6f));
     if (all_idm) flags |= fs::FLAG_ALL_IDM;
     if (idm_set) flags |= fs::FLAG_IDM_SET;
     delta4 = all_idm;
@@ -507,6 +513,7 @@ struct Sim : SimBase {
 
   // the specialisations for the headline configuration (see flowsim_kernels.h)
   bool delta4 = false;
+  bool loop_div_ok = false;
   bool fast_ok(const uint8_t* mask, int num_steps) const {
     const int f = dv.flags;
     return (f & fs::FLAG_ALL_IDM) && !(f & (fs::FLAG_HAS_NOISE | fs::FLAG_HAS_FAILSAFE | fs::FLAG_NEED_SUMO)) &&
@@ -568,6 +575,26 @@ struct Sim : SimBase {
     const bool pair_ok = fast_ok(mask, num_steps) && (obs_every_step || num_steps == 1) && dv.N >= 2 &&
                          (dv.N % 2) == 0 && actions == nullptr && !no_pair &&
                          size_t(dv.R) * 2 * dv.N * sizeof(float) * 16 < (size_t(1) << 32);   // 32-bit offsets in a block
+    // closed loops with a segment table (figure eight): the rollout kernel of flowsim_fig8.h
+    if constexpr (SEG == 16 && std::is_same<T, float>::value) {
+      const int f = dv.flags;
+      const bool head_ok = (dv.env == FS_ENV_ACCEL && !dv.evaluate) || dv.env == FS_ENV_WAVE_ATTENUATION_PO;
+      if (dv.nseg > 0 && (f & fs::FLAG_IDM_SET) && !(f & fs::FLAG_HAS_FAILSAFE) && head_ok &&
+          dv.integrator == FS_EULER && dv.sims_per_step == 1 && mask == nullptr &&
+          !dv.sort_vehicles && dv.obs_perm == nullptr && num_steps > 0 && (obs_every_step || num_steps == 1) &&
+          dv.N > 1 && loop_div_ok && !force_generic && !no_loop_kernel) {
+        const int waves = (dv.R + 3) / 4;
+        const dim3 grid((waves + 3) / 4), block(256);
+        if (dv.env == FS_ENV_ACCEL)
+          hipLaunchKernelGGL((fs::k_rollout_loop<0>), grid, block, 0, stream, dv, num_steps, actions, act_stride, obs,
+                             rew, done);
+        else
+          hipLaunchKernelGGL((fs::k_rollout_loop<1>), grid, block, 0, stream, dv, num_steps, actions, act_stride, obs,
+                             rew, done);
+        HIP_TRY(hipGetLastError());
+        return FS_OK;
+      }
+    }
     if (mixed && num_steps == 0) {                       // observation of the current state (Env.reset)
       const int n = dv.R * dv.N;
       hipLaunchKernelGGL((fs::k_obs_mixed), dim3((n + 255) / 256), dim3(256), 0, stream, dv, obs);
@@ -1031,6 +1058,8 @@ int create_typed(const fs_config* cfg, fs_handle* out) {
     s->force_generic = fg && fg[0] == '1';
     const char* nf = std::getenv("FLOWSIM_NO_FASTDIV");
     s->no_fastdiv = nf && nf[0] == '1';
+    const char* nl = std::getenv("FLOWSIM_NO_LOOP_KERNEL");
+    s->no_loop_kernel = nl && nl[0] == '1';
     const char* np = std::getenv("FLOWSIM_NO_PAIR");
     s->no_pair = np && np[0] == '1';
     const char* pb = std::getenv("FLOWSIM_PAIR_BLOCK");

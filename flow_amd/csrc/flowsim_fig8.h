@@ -1,0 +1,359 @@
+// flowsim_fig8.h -- k_rollout_loop: rollout kernel of closed single-lane loops WITH a segment table, a crossing and
+// mixed IDM / RL / SUMO-driven populations (BASELINE configs[2]: FigureEightNetwork, 13 noisy IDM + 1 RL vehicle).
+//
+// Same arithmetic as the generic k_steps<float, SEG, 0, 1> (the helper functions and their operation order are
+// shared; tests/test_parity_gpu.py::test_loop_rollout_kernel_equals_generic_kernel compares the two bit for bit,
+// noise included), restructured for a wave that is ALONE on its SIMD (4096 replicas x 14 vehicles = 1024 waves):
+// every instruction costs an issue slot and nothing hides a wait, so
+//   * the segment a vehicle is on is an index advanced by compares; its table row (start of the next segment,
+//     Flow-table start and slope) is re-read from an LDS copy of the table with plain ds_read -- issued right after
+//     the move, consumed at the end of the step;
+//   * the per-replica facts of a step (stream a busy, stream b in the box, both streams on the crossing point, a
+//     headway below the crash gap, a speed below -100) are bits of ONE word reduced with one OR-butterfly (DPP);
+//   * a vehicle is on at most one approach of the crossing: ONE evaluation of the SUMO car-following speed towards
+//     the stop line serves both yield rules;
+//   * one Philox call yields the noise of four steps (gauss4);
+//   * the reward tail (sqrt, divide) of PERIOD steps is finished at once by PERIOD lanes (transposed_sum), as in
+//     k_rollout_idm; launch constants live in registers, actions are read one step ahead.
+// Chosen by the host when: float, segment table present, every slot IDM / RL / Sim without fail-safe, Euler,
+// sims_per_step 1, no reset mask, no sorting / shuffling, AccelEnv (not evaluate) or
+// WaveAttenuationPOEnv head, observation every step, N <= 16.
+#pragma once
+#include "flowsim_kernels.h"
+
+namespace fs {
+
+// a launch constant kept in a VGPR (the loop has far more uniform values than SGPRs: hipcc spilled 45 of them to
+// VGPR lanes and read them back with v_readlane inside the loop)
+__device__ __forceinline__ float in_vgpr(float x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ double in_vgpr(double x) { asm volatile("" : "+v"(x)); return x; }
+// x / c for a launch constant c: the float64 route of div_via_f64 (exact for every float x)
+struct DivC { double c, rc; };
+__device__ __forceinline__ DivC make_divc(float c) { return DivC{in_vgpr(double(c)), in_vgpr(1.0 / double(c))}; }
+__device__ __forceinline__ float divc(float x, const DivC& d) { return div_via_f64(x, d.c, d.rc); }
+// value of the NEXT slot of the 16-lane row (slot 0's for the last occupied slot and the idle lanes)
+__device__ __forceinline__ float lead16(float v, bool wrap) {
+  const float t = dpp<DPP_ROW_SHL1>(v), w = dpp<0x150>(v);     // row_shl:1, row_newbcast:0
+  return wrap ? w : t;
+}
+
+// ctrl_idm / sumo_idm_speed (flowsim_kernels.h) with their divisions made cheap WITHOUT changing a bit: divisors
+// that are launch constants go through divc, the others (|h| >= 1e-3, gap >= 1e-3; dividends s* >= s0 >= 1e-3 and
+// ss >= minGap >= 1e-3, host-checked) through div_core
+struct IdmC { float p1, p2, p4, p5; DivC v0, two_sqrt; bool delta4; };
+__device__ __forceinline__ float idm_fast(float v, float vl, float h, bool has, const IdmC& c) {
+  const float hh = tabs(h) < 1e-3f ? 1e-3f : h;
+  const float dyn = v * c.p1 + divc(v * (v - vl), c.two_sqrt);
+  const float s_star = has ? c.p5 + tmax(0.0f, dyn) : 0.0f;
+  const float q = div_core(s_star, hh);
+  const float ratio = divc(v, c.v0);
+  float pw;
+  if (c.delta4) { const float r2 = ratio * ratio; pw = r2 * r2; } else pw = pow_delta(ratio, c.p4);
+  return c.p2 * (1.0f - pw - q * q);
+}
+struct SumoC { float min_gap, tau, max_accel; DivC two_sqrt, max_speed; };
+__device__ __forceinline__ float sumo_fast(float v, float vl, float h, bool has, float dt, const SumoC& c) {
+  const float gap = tmax(h, 1e-3f);
+  const float ss = c.min_gap + tmax(0.0f, v * c.tau + divc(v * (v - vl), c.two_sqrt));
+  const float q = has ? div_core(ss, gap) : 0.0f;
+  const float r = divc(v, c.max_speed);
+  const float r2 = r * r;
+  const float acc = c.max_accel * (1.0f - r2 * r2 - q * q);
+  return tmax(0.0f, v + acc * dt);
+}
+
+template <int HEAD /* 0: AccelEnv, 1: WaveAttenuationPOEnv */>
+__global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_steps,
+                                                      const float* __restrict__ actions, size_t act_stride,
+                                                      float* __restrict__ obs, float* __restrict__ rew,
+                                                      uint8_t* __restrict__ done) {
+  typedef float T;
+  constexpr int SEG = 16, RPW = 4, PERIOD = 4;
+  __shared__ T tab_start[FS_MAX_SEGMENTS + 1], tab_fs[FS_MAX_SEGMENTS], tab_sl[FS_MAX_SEGMENTS];
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int seg = lane / SEG;
+  const int i = lane % SEG;
+  const int r = wave * RPW + seg;
+  const int N = s.N;
+  const bool rvalid = r < s.R;
+  const bool valid = rvalid && i < N;
+  const int rr = rvalid ? r : s.R - 1;
+  const int ii = i < N ? i : N - 1;
+  const size_t idx = size_t(rr) * N + ii;
+  const bool wrap_lead = (i + 1 >= N);
+  const bool has = N > 1;
+  const int flags = s.flags;
+
+  if (threadIdx.x <= FS_MAX_SEGMENTS) {
+    const int q = threadIdx.x;
+    tab_start[q] = q < s.nseg ? s.seg_start[q < FS_MAX_SEGMENTS ? q : 0] : T(3.0e38);
+    if (q < FS_MAX_SEGMENTS) {
+      tab_fs[q] = s.seg_flow_start[q];
+      tab_sl[q] = s.seg_flow_slope[q];
+    }
+  }
+  __syncthreads();
+
+  Slot<T> sl;
+  sl.ctrl = s.ctrl[ii];
+  sl.failsafe = 0;
+  sl.speed_mode = s.speed_mode[ii];
+  sl.rl_index = s.rl_index[ii];
+  sl.pis_index = -1;
+#pragma unroll
+  for (int k = 0; k < FS_MAX_CTRL_PARAMS; ++k) sl.p[k] = s.p[k * N + ii];
+  sl.noise = s.noise[ii];
+  sl.delay = T(0);
+  sl.max_accel = s.max_accel[ii];
+  sl.max_decel = s.max_decel[ii];
+  sl.length = s.length[ii];
+  sl.sumo_tau = s.sumo_tau[ii];
+  sl.sumo_min_gap = s.sumo_min_gap[ii];
+  sl.sumo_max_speed = s.sumo_max_speed[ii];
+  const T len_lead = lead16(sl.length, wrap_lead);
+
+  const T base_len = s.ring_len[rr];
+  const T L = base_len + T(4) * s.jlen;
+  int tcount = s.time[rr];
+  const bool any_noise = (flags & FLAG_HAS_NOISE) != 0;
+  uint32_t nctr = any_noise ? s.noise_ctr[rr] : 0u;
+  const bool noisy = any_noise && sl.noise > T(0) && sl.ctrl != FS_CTRL_RL && sl.ctrl != FS_CTRL_SIM;
+
+  T x = s.pos[idx];
+  T v = s.vel[idx];
+  // segment cursor: index + the row values read from LDS
+  int k = 0;
+  for (int q = 1; q < s.nseg; ++q) k = (x >= tab_start[q]) ? q : k;
+  T c_st = tab_start[k], c_next = tab_start[k + 1], c_fs = tab_fs[k], c_sl = tab_sl[k];
+  T xl = lead16(x, wrap_lead);
+  T vl = lead16(v, wrap_lead);
+  T d = xl - x;
+  d = d < T(0) ? d + L : d;
+  T h = has ? d - len_lead : T(1000);
+
+  // launch constants in VGPRs
+  const T dt = in_vgpr(s.dt), ramp = in_vgpr(s.ramp), crash_gap = in_vgpr(s.crash_gap), target_v = in_vgpr(s.target_velocity);
+  const T ja_in = in_vgpr(s.ja_in), ja_out = in_vgpr(s.ja_out), jb_in = in_vgpr(s.jb_in), jb_out = in_vgpr(s.jb_out);
+  const T look = in_vgpr(s.j_lookahead), tgap = in_vgpr(s.j_time_gap);
+  const T za_lo = in_vgpr(s.za_lo), za_hi = in_vgpr(s.za_hi), zb_lo = in_vgpr(s.zb_lo), zb_hi = in_vgpr(s.zb_hi);
+  const T act_lo = in_vgpr(s.act_lo), act_hi = in_vgpr(s.act_hi), max_cost = in_vgpr(s.max_cost);
+  const T Lv = in_vgpr(L);
+  const DivC d_ms = make_divc(s.max_speed), d_L = make_divc(L), d_15 = make_divc(15.0f), d_po = make_divc(s.po_max_length);
+  IdmC ic;
+  ic.p1 = sl.p[1]; ic.p2 = sl.p[2]; ic.p4 = sl.p[4]; ic.p5 = sl.p[5];
+  ic.v0 = make_divc(sl.p[0]);
+  ic.two_sqrt = make_divc(T(2) * tsqrt(sl.p[2] * sl.p[3]));
+  ic.delta4 = sl.p[4] == T(4);
+  SumoC sc;
+  sc.min_gap = sl.sumo_min_gap; sc.tau = sl.sumo_tau; sc.max_accel = sl.max_accel;
+  sc.two_sqrt = make_divc(T(2) * tsqrt(sl.max_accel * sl.max_decel));
+  sc.max_speed = make_divc(sl.sumo_max_speed);
+  const unsigned seg_internal = s.seg_internal;
+  const bool junction_on = s.junction_on != 0, need_sumo = (flags & FLAG_NEED_SUMO) != 0;
+  const bool gated = s.junction_mode && sl.ctrl != FS_CTRL_RL && sl.ctrl != FS_CTRL_SIM;
+  const bool clip = s.clip_actions != 0;
+  const bool rl_lane = sl.ctrl == FS_CTRL_RL, sim_lane = sl.ctrl == FS_CTRL_SIM;
+  const bool use_act = actions != nullptr;
+  const int num_rl = s.num_rl;
+  const int own_col = sl.rl_index < 0 ? 0 : sl.rl_index;
+  const bool red_lane = ii < num_rl && i < N;
+  const int obs_dim = HEAD == 1 ? 3 : 2 * N;
+  const bool obs_lane = HEAD == 1 ? (valid && rl_lane && sl.rl_index == 0) : valid;
+
+  float a_own_next = 0.0f, a_red_next = 0.0f;
+  if (use_act && num_steps > 0) {
+    const float* a0 = actions + size_t(rr) * num_rl;
+    if (rl_lane) a_own_next = a0[own_col];
+    if (red_lane) a_red_next = a0[ii];
+  }
+  T g4[4] = {T(0), T(0), T(0), T(0)};
+  if (any_noise && (nctr & 3u) != 0u && noisy)          // mid-block start: the block of the current counter
+    gauss4<T>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(ii), nctr >> 2, g4);
+
+  float* orow = obs + size_t(rr) * obs_dim;
+  const size_t obs_step = size_t(s.R) * obs_dim;
+  unsigned crash_bits = 0u, bad_bits = 0u;
+  T prev_v = v, last_acc = T(0);                          // track_aux: get_previous_speed / get_accel of the scalar Env
+
+  for (int base = 0; base < num_steps; base += PERIOD) {
+    T red[PERIOD];                // per-step reward ingredients: AccelEnv (v - target)^2, PO: speeds (mean) in red, |a| in red2
+    T red2[PERIOD];
+    const int nsteps = num_steps - base < PERIOD ? num_steps - base : PERIOD;
+#pragma unroll
+    for (int slot = 0; slot < PERIOD; ++slot) {
+      red[slot] = T(0);
+      red2[slot] = T(0);
+      if (slot < nsteps) {                                   // wave-uniform
+        const int step = base + slot;
+        const float a_own = a_own_next, a_red = a_red_next;
+        if (use_act && step + 1 < num_steps) {
+          const float* an = actions + size_t(step + 1) * act_stride + size_t(rr) * num_rl;
+          if (rl_lane) a_own_next = an[own_col];
+          if (red_lane) a_red_next = an[ii];
+        }
+        // ---- controllers on the snapshot (control_accel_on, CSET = 1) ----------------------------------
+        const bool on_edge = gated ? !((seg_internal >> k) & 1u) : true;
+        T acc = T(0);
+        bool commanded = false;
+        if (any_noise) {
+          if (__ballot(noisy && (nctr & 3u) == 0u) != 0ull) {
+            if (noisy && (nctr & 3u) == 0u)
+              gauss4<T>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(ii), nctr >> 2, g4);
+          }
+        }
+        {
+          T a = idm_fast(v, vl, h, has, ic);
+          if (any_noise) {
+            const uint32_t j = nctr & 3u;
+            const T g = j == 0u ? g4[0] : (j == 1u ? g4[1] : (j == 2u ? g4[2] : g4[3]));
+            if (noisy) a = a + sl.noise * g;
+          }
+          T arl = T(a_own);
+          if (clip) arl = tmin(tmax(arl, act_lo), act_hi);
+          acc = rl_lane ? (use_act ? arl : T(0)) : (sim_lane ? T(0) : a);
+          commanded = rl_lane ? use_act : (sim_lane ? false : on_edge);
+        }
+        // ---- apply_acceleration + SUMO integration (S4-S9) ---------------------------------------------
+        T next_vel = tmax(v + acc * dt, T(0));
+        T vc = v + (next_vel - v) * ramp;
+        T v_new = vc;
+        if (need_sumo) {
+          T v_sumo = sumo_fast(v, vl, h, has, dt, sc);
+          if (sl.speed_mode & 1) vc = tmin(vc, v_sumo);
+          if (sl.speed_mode & 2) vc = tmin(vc, v + sl.max_accel * dt);
+          if (sl.speed_mode & 4) vc = tmax(vc, v - sl.max_decel * dt);
+          v_new = commanded ? vc : v_sumo;
+        }
+        if (junction_on) {
+          // per-replica facts of the snapshot, one OR-butterfly: bit 0 stream a busy, bit 1 stream b in the box
+          unsigned f = 0u;
+          f |= (valid && (x >= ja_in - tgap * v) && (x < ja_out + sl.length)) ? 1u : 0u;
+          f |= (valid && (x >= jb_in) && (x < jb_out + sl.length)) ? 2u : 0u;
+          f = seg_or<SEG>(f);
+          const bool on_b = (x >= jb_in - look) && (x < jb_in) && (f & 1u);
+          const bool on_a = (x >= ja_in - look) && (x < ja_in) && (f & 2u);
+          // a vehicle is on at most one approach (the two lines are different places of the loop); should both
+          // hold for a degenerate table, stream b's line is evaluated first and stream a's overrides as min would
+          if (__ballot(on_a || on_b) != 0ull) {
+            const T line = on_b ? jb_in - x : ja_in - x;
+            T cap = sumo_fast(v, T(0), line, true, dt, sc);
+            cap = (on_a || on_b) ? cap : T(3.0e38);
+            if (__ballot(on_a && on_b) != 0ull) {                // degenerate table: both lines ahead of one vehicle
+              const T cap_a = sumo_fast(v, T(0), ja_in - x, true, dt, sc);
+              cap = (on_a && on_b) ? tmin(cap, cap_a) : cap;
+            }
+            if ((sl.speed_mode & 1) || !commanded) v_new = tmin(v_new, cap);
+          }
+        }
+        T x_new = x + v_new * dt;
+        x_new = x_new >= Lv ? x_new - Lv : x_new;
+        prev_v = v;
+        last_acc = acc;
+        x = x_new;
+        v = v_new;
+        tcount += 1;
+        nctr += 1u;
+        // ---- segment cursor: advance by compares, re-read the row from LDS --------------------------------
+        k = (x < c_st) ? 0 : k;                                 // wrapped around the loop
+        k += (x >= c_next && !(x < c_st)) ? 1 : 0;
+        c_st = tab_start[k];
+        c_next = tab_start[k + 1];
+        while (__ballot(x >= c_next) != 0ull) {                 // more than one start passed (or after a wrap): rare
+          k += (x >= c_next) ? 1 : 0;
+          c_st = tab_start[k];
+          c_next = tab_start[k + 1];
+        }
+        c_fs = tab_fs[k];
+        c_sl = tab_sl[k];
+        // ---- new neighbour snapshot (S10) + per-replica facts of the new state -----------------------------
+        xl = lead16(x, wrap_lead);
+        vl = lead16(v, wrap_lead);
+        d = xl - x;
+        d = d < T(0) ? d + Lv : d;
+        h = has ? d - len_lead : T(1000);
+        unsigned f2 = (valid && has && (h < crash_gap)) ? 1u : 0u;
+        if (junction_on) {
+          f2 |= (valid && (x >= za_lo) && (x < za_hi)) ? 2u : 0u;
+          f2 |= (valid && (x >= zb_lo) && (x < zb_hi)) ? 4u : 0u;
+        }
+        f2 |= (valid && (v < T(-100))) ? 8u : 0u;
+        f2 = seg_or<SEG>(f2);
+        const bool crashed = (f2 & 1u) || ((f2 & 6u) == 6u);
+        const bool bad = (f2 & 8u) || crashed;
+        crash_bits |= crashed ? (1u << slot) : 0u;
+        bad_bits |= bad ? (1u << slot) : 0u;
+        // ---- observation ---------------------------------------------------------------------------------
+        if (HEAD == 1) {
+          if (obs_lane) {                                        // wave_attenuation.py:248-269
+            orow[0] = divc(v, d_15);
+            orow[1] = divc(vl - v, d_15);
+            orow[2] = divc(d, d_po);
+          }
+          red[slot] = valid ? v : T(0);
+          T a = T(0);
+          if (red_lane && use_act) {
+            a = T(a_red);
+            if (clip) a = tmin(tmax(a, act_lo), act_hi);
+            a = tabs(a);
+          }
+          red2[slot] = a;
+        } else {
+          const T xo = c_fs + c_sl * (x - c_st);
+          if (obs_lane) {                                        // accel.py:116-123
+            orow[ii] = divc(v, d_ms);
+            orow[N + ii] = divc(xo, d_L);
+          }
+          const T dv = valid ? v - target_v : T(0);
+          red[slot] = dv * dv;
+        }
+        orow += obs_step;
+      }
+    }
+    // ---- rewards + done of the block: lane j finishes step j ------------------------------------------------
+    const T racc = transposed_sum<SEG, PERIOD>(red, lane);
+    T racc2 = T(0);
+    if (HEAD == 1) racc2 = transposed_sum<SEG, PERIOD>(red2, lane);
+    const unsigned crash_any = crash_bits, bad_any = bad_bits;       // already per-replica (seg_or above)
+    crash_bits = 0u;
+    bad_bits = 0u;
+    const int j = i;
+    if (rvalid && j < nsteps) {
+      const bool my_crash = (crash_any >> j) & 1u, my_bad = (bad_any >> j) & 1u;
+      const int t_j = tcount - (nsteps - 1 - j);
+      T reward;
+      if (HEAD == 1) {                                               // wave_attenuation.py:113-139
+        if (!use_act) {
+          reward = T(0);
+        } else {
+          const T mean_v = racc / T(N);
+          const T mean_a = racc2 / T(num_rl);
+          reward = T(4.0) * mean_v / T(20);
+          if (mean_a > T(0)) reward = reward + T(4) * (T(0) - mean_a);
+          reward = my_bad ? T(0) : reward;
+        }
+      } else {                                                       // rewards.py:6-59
+        const T cost = tsqrt(racc);
+        reward = tmax(max_cost - cost, T(0)) / (max_cost + T(1.1920928955078125e-07));
+        reward = my_bad ? T(0) : reward;
+      }
+      const size_t o = size_t(base + j) * s.R + rr;
+      rew[o] = float(reward);
+      done[o] = uint8_t((t_j >= s.step_limit) || my_crash);
+    }
+  }
+  if (valid) {
+    s.pos[idx] = x;
+    s.vel[idx] = v;
+    if (s.track_aux && num_steps > 0) {
+      s.prev_vel[idx] = prev_v;
+      s.accel[idx] = last_acc;
+    }
+    if (ii == 0) {
+      s.time[rr] = tcount;
+      if (any_noise) s.noise_ctr[rr] = nctr;
+    }
+  }
+}
+
+}  // namespace fs

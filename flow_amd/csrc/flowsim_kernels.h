@@ -318,10 +318,18 @@ __device__ __forceinline__ T transposed_sum(T* a, int lane) {
   if (K >= 32) a[0] = tr_combine16(a[0], a[1]);
   T v = a[0];
   // lanes of the segment that hold the same vector index still have to be added up (SEG > K)
+  // (the xor-4 / xor-8 partners are reached by row shifts picked per lane: the mirror forms of seg_sum need the
+  // lanes of a quad / half row to hold the SAME value, which is only true for K = 1 here)
   if (K < 2 && SEG >= 2) v = v + dpp<DPP_QUAD_XOR1>(v);
   if (K < 4 && SEG >= 4) v = v + dpp<DPP_QUAD_XOR2>(v);
-  if (K < 8 && SEG >= 8) v = v + dpp<DPP_ROW_HALF_MIRROR>(v);
-  if (K < 16 && SEG >= 16) v = v + dpp<DPP_ROW_MIRROR>(v);
+  if (K < 8 && SEG >= 8) {
+    if (K == 1) v = v + dpp<DPP_ROW_HALF_MIRROR>(v);
+    else v = tr_combine<DPP_ROW_SHL4, DPP_ROW_SHR4>(v, v, (lane & 4) != 0);
+  }
+  if (K < 16 && SEG >= 16) {
+    if (K == 1) v = v + dpp<DPP_ROW_MIRROR>(v);
+    else v = tr_combine<DPP_ROW_SHL8, DPP_ROW_SHR8>(v, v, (lane & 8) != 0);
+  }
   if (K < 32 && SEG >= 32) v = add_swap16(v);
   if (SEG >= 64) v = add_swap32(v);
   return v;
@@ -430,14 +438,38 @@ __device__ __forceinline__ void philox4x32_10(uint32_t& c0, uint32_t& c1, uint32
   }
 }
 
+// Four N(0,1) draws from ONE Philox call: the counter is (block = step / 4, vehicle, replica, 0); the words (c0, c1)
+// and (c2, c3) feed two Box-Muller transforms whose cosine AND sine branches are both used, so draw j = step % 4 of
+// the block is pair j / 2, cosine for even j, sine for odd j (oracle/refsim.py gaussian_noise, changed in lock-step).
+// The generic kernels evaluate the block of the current step and pick one draw; k_rollout_fig8 keeps the four for
+// four steps.  float: the hardware's log2 / sin / cos (argument in revolutions) / sqrt -- noise is compared with the
+// numpy oracle at libm tolerance anyway (DESIGN "Precision"); double: libm.
+__device__ __forceinline__ void box_muller2(float u1, float u2, float& gc, float& gs) {
+  const float r = __builtin_amdgcn_sqrtf(-2.0f * (__builtin_amdgcn_logf(u1) * 0.6931471805599453f));
+  gc = r * __builtin_amdgcn_cosf(u2);
+  gs = r * __builtin_amdgcn_sinf(u2);
+}
+__device__ __forceinline__ void box_muller2(double u1, double u2, double& gc, double& gs) {
+  const double r = sqrt(-2.0 * log(u1));
+  gc = r * cos(6.283185307179586 * u2);
+  gs = r * sin(6.283185307179586 * u2);
+}
+template <typename T>
+__device__ __forceinline__ void gauss4(uint32_t seed_lo, uint32_t seed_hi, uint32_t replica, uint32_t vehicle,
+                                       uint32_t block, T* g) {
+  uint32_t c0 = block, c1 = vehicle, c2 = replica, c3 = 0u;
+  philox4x32_10(c0, c1, c2, c3, seed_lo, seed_hi);
+  const T k = T(1.0 / 16777216.0);                     // u1 in (0, 1], u2 in [0, 1): 24-bit integers, exact in float
+  box_muller2(T((c0 >> 8) + 1u) * k, T(c1 >> 8) * k, g[0], g[1]);
+  box_muller2(T((c2 >> 8) + 1u) * k, T(c3 >> 8) * k, g[2], g[3]);
+}
 template <typename T>
 __device__ __forceinline__ T gauss(uint32_t seed_lo, uint32_t seed_hi, uint32_t replica, uint32_t vehicle,
                                    uint32_t step) {
-  uint32_t c0 = step, c1 = vehicle, c2 = replica, c3 = 0u;
-  philox4x32_10(c0, c1, c2, c3, seed_lo, seed_hi);
-  T u1 = T(double((c0 >> 8) + 1u) * (1.0 / 16777216.0));
-  T u2 = T(double(c1 >> 8) * (1.0 / 16777216.0));
-  return tsqrt(T(-2.0) * tlog(u1)) * tcos(T(6.283185307179586) * u2);
+  T g[4];
+  gauss4<T>(seed_lo, seed_hi, replica, vehicle, step >> 2, g);
+  const uint32_t j = step & 3u;
+  return j == 0u ? g[0] : (j == 1u ? g[1] : (j == 2u ? g[2] : g[3]));
 }
 
 // ---------------------------------------------------------------------------
@@ -1119,6 +1151,19 @@ __device__ __forceinline__ float div_core(float n, float d) {
   return __builtin_fmaf(r1, y, q1);
 }
 __device__ __forceinline__ double div_core(double n, double d) { return n / d; }
+
+// x / c, correctly rounded to float for every float x (any sign, zero, denormal) and every normal float c:
+// q = RN64(x * RN64(1/c)) is within 2^-52 of the quotient, one fma pair makes it the correctly rounded float64
+// quotient up to 1 ulp64 and EXACT whenever the quotient is representable (the only way to sit on a float32
+// rounding boundary, ties of the denormal range included); otherwise the quotient of two 24-bit numbers stays
+// >= 2^-47 (relative) away from every boundary, so the second rounding cannot differ from a single one.
+__device__ __forceinline__ float div_via_f64(float x, double c, double rc) {
+  const double xd = double(x);
+  double q = xd * rc;
+  const double r = __builtin_fma(-q, c, xd);
+  q = __builtin_fma(r, rc, q);
+  return float(q);
+}
 
 template <typename T, int SEG, bool DELTA4, bool FASTDIV, bool BADCHK>
 __global__ __launch_bounds__(1024) void k_rollout_idm(DevView<T> s, int num_steps, float* __restrict__ obs,

@@ -75,19 +75,6 @@ __device__ __forceinline__ double next_a(double v, bool last, int lane) {
                                         __builtin_bit_cast(unsigned, lo));
 }
 
-// x / c, correctly rounded to float for every float x (any sign, zero, denormal) and every normal float c:
-// q = RN64(x * RN64(1/c)) is within 2^-52 of the quotient, one fma pair makes it the correctly rounded float64
-// quotient up to 1 ulp64 and EXACT whenever the quotient is representable (the only way to sit on a float32
-// rounding boundary, ties of the denormal range included); otherwise the quotient of two 24-bit numbers stays
-// >= 2^-47 (relative) away from every boundary, so the second rounding cannot differ from a single one.
-__device__ __forceinline__ float div_via_f64(float x, double c, double rc) {
-  const double xd = double(x);
-  double q = xd * rc;
-  const double r = __builtin_fma(-q, c, xd);
-  q = __builtin_fma(r, rc, q);
-  return float(q);
-}
-
 template <bool FASTDIV>
 __device__ __forceinline__ f2 div_const2(f2 x, f2 c, f2 rc) {
   if (FASTDIV) {

@@ -52,20 +52,27 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 
 def gaussian_noise(seed, replica, vehicle, step, dtype):
-    """N(0,1) per (replica, vehicle, step): Philox keyed by the 64-bit seed,
-    counter (step, vehicle, replica, 0); Box-Muller on the first two words.
-    Shared definition with the kernels (flowsim.hip: fs_gauss)."""
+    """N(0,1) per (replica, vehicle, step): ONE Philox call, keyed by the 64-bit seed with counter
+    (step // 4, vehicle, replica, 0), serves four steps: words (c0, c1) and (c2, c3) feed two Box-Muller
+    transforms, cosine and sine branch both used -- draw j = step % 4 is pair j // 2, cosine for even j, sine for
+    odd j.  Shared definition with the kernels (flowsim_kernels.h gauss4 / gauss)."""
     seed = int(seed)
     k0 = np.uint32(seed & 0xFFFFFFFF)
     k1 = np.uint32((seed >> 32) & 0xFFFFFFFF)
-    r0, r1, _, _ = philox4x32_10(step, vehicle, replica, np.zeros_like(replica), k0, k1)
+    step = np.asarray(step, dtype=np.uint32)
+    r0, r1, r2, r3 = philox4x32_10(step >> np.uint32(2), vehicle, replica, np.zeros_like(replica), k0, k1)
+    j = step & np.uint32(3)
+    first = j < 2
+    ra = np.where(first, r0, r2)
+    rb = np.where(first, r1, r3)
     # u1 in (0,1], u2 in [0,1)
-    u1 = ((r0 >> np.uint32(8)).astype(np.float64) + 1.0) * (1.0 / 16777216.0)
-    u2 = (r1 >> np.uint32(8)).astype(np.float64) * (1.0 / 16777216.0)
+    u1 = ((ra >> np.uint32(8)).astype(np.float64) + 1.0) * (1.0 / 16777216.0)
+    u2 = (rb >> np.uint32(8)).astype(np.float64) * (1.0 / 16777216.0)
     u1 = u1.astype(dtype)
     u2 = u2.astype(dtype)
     two_pi = np.asarray(6.283185307179586, dtype)
-    return np.sqrt(np.asarray(-2.0, dtype) * np.log(u1)) * np.cos(two_pi * u2)
+    rad = np.sqrt(np.asarray(-2.0, dtype) * np.log(u1))
+    return rad * np.where((j & np.uint32(1)) == 0, np.cos(two_pi * u2), np.sin(two_pi * u2))
 
 
 def pisaturation_step(hist, n, v_cmd, v, v_lead, h, dt, max_accel, do_update, dtype):

@@ -879,3 +879,88 @@ def test_autonomous_and_commanded_lane_changes_together_f32_and_f64():
     assert ora.num_lane_changes.min() > 0
     run_pair_ml(dict(spec, num_replicas=2, init_pos=spec["init_pos"][:2], init_lane=spec["init_lane"][:2],
                      ring_length=spec["ring_length"][:2]), "f64", 120, actions=acts[:120, :2], exact=False, atol=1e-9)
+
+
+# ------------------------------------------------------------------ k_rollout_loop (flowsim_fig8.h) vs the generic kernel
+def _rollout(spec, K, actions, env=None):
+    import os
+    import torch
+    from flow_amd.sim import FlowSim
+    old = {}
+    for k_, v_ in (env or {}).items():
+        old[k_] = os.environ.get(k_)
+        os.environ[k_] = v_
+    try:
+        sim = FlowSim(spec, "f32")
+    finally:
+        for k_, v_ in old.items():
+            if v_ is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v_
+    dev = torch.device("cuda", 0)
+    R = sim.R
+    obs = torch.full((K, R, sim.obs_dim), float("nan"), device=dev)
+    rew = torch.full((K, R), float("nan"), device=dev)
+    done = torch.full((K, R), 7, dtype=torch.uint8, device=dev)
+    act = None if actions is None else torch.as_tensor(actions, device=dev)
+    sim.reset()
+    torch.cuda.synchronize()
+    sim.rollout_dev(K, obs, rew, done, actions=act)
+    sim.sync()
+    return sim, obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+
+
+@pytest.mark.parametrize("head", ["accel", "po"])
+def test_loop_rollout_kernel_equals_generic_kernel(head):
+    """C3's population (13 noisy IDM with obey_safe_speed + 1 RL vehicle, crossing with right of way, junction
+    mode) through the specialised rollout kernel and through the generic k_steps: bit-identical observations,
+    rewards, dones and final state, noise included; plus a run whose hostile RL actions crash at the crossing."""
+    R, N, K = 37, 14, 150
+    spec = figure_eight_spec(R=R, N=N, horizon=120, seed=5, num_rl=1)
+    veh = [idm_vehicle(speed_mode=1, max_decel=1.5, noise=0.2) for _ in range(N - 1)]
+    veh.append(idm_vehicle(controller=S.CTRL_RL, rl_index=0, speed_mode=0 if head == "accel" else 1, max_decel=1.5))
+    spec["vehicles"] = veh
+    spec["seed"] = 77
+    if head == "po":
+        spec["env"] = S.ENV_WAVE_ATTENUATION_PO
+        spec["po_max_length"] = 421.94
+    rng = np.random.default_rng(9)
+    acts = rng.uniform(-3, 3, (K, R, 1)).astype(np.float32)
+    a, oa, ra, da = _rollout(spec, K, acts)
+    b, ob, rb, db = _rollout(spec, K, acts, env={"FLOWSIM_NO_LOOP_KERNEL": "1"})
+    np.testing.assert_array_equal(oa, ob)
+    np.testing.assert_array_equal(ra, rb)
+    np.testing.assert_array_equal(da, db)
+    np.testing.assert_array_equal(a.pos, b.pos)
+    np.testing.assert_array_equal(a.vel, b.vel)
+    np.testing.assert_array_equal(a.time_counter, b.time_counter)
+    assert not np.isnan(oa).any() and not np.isnan(ra).any() and da.max() == 1
+    if head == "accel":                               # full throttle in 'aggressive' mode: the RL vehicle rams someone
+        spec2 = dict(spec, horizon=10 ** 6)
+        hostile = np.full((260, R, 1), 3.0, dtype=np.float32)
+        c, oc, rc, dc = _rollout(spec2, 260, hostile)
+        e, oe, re_, de = _rollout(spec2, 260, hostile, env={"FLOWSIM_NO_LOOP_KERNEL": "1"})
+        np.testing.assert_array_equal(oc, oe)
+        np.testing.assert_array_equal(rc, re_)
+        np.testing.assert_array_equal(dc, de)
+        assert dc.any(), "the hostile run must contain a crash"
+        c.close(), e.close()
+    # a second launch continues the noise stream mid-block (K = 150 is not a multiple of 4)
+    _, oa2, ra2, _ = (lambda s_: (s_, *(_continue(s_, 30, acts[:30]))))(a)
+    _, ob2, rb2, _ = (lambda s_: (s_, *(_continue(s_, 30, acts[:30]))))(b)
+    np.testing.assert_array_equal(oa2, ob2)
+    np.testing.assert_array_equal(ra2, rb2)
+    a.close(), b.close()
+
+
+def _continue(sim, K, actions):
+    import torch
+    dev = torch.device("cuda", 0)
+    obs = torch.empty((K, sim.R, sim.obs_dim), device=dev)
+    rew = torch.empty((K, sim.R), device=dev)
+    done = torch.empty((K, sim.R), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    sim.rollout_dev(K, obs, rew, done, actions=torch.as_tensor(actions, device=dev))
+    sim.sync()
+    return obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
