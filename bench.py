@@ -144,6 +144,8 @@ def c3_leg(device, R=4096, steps=3000, po=False):
     out = (torch.empty((K, R, vec.obs_dim), dtype=torch.float32, device=device),
            torch.empty((K, R), dtype=torch.float32, device=device),
            torch.empty((K, R), dtype=torch.uint8, device=device))
+    if os.environ.get("BENCH_C3_NO_ACTIONS") == "1":     # diagnostic: the RL vehicle stays uncommanded (no action tape reads)
+        tape = None
     vec.reset()
     vec.rollout(K, tape, out=out)
     torch.cuda.synchronize(device)

@@ -186,6 +186,8 @@ struct Sim : SimBase {
     for (int i = 0; i < N; ++i)
       loop_div_ok = loop_div_ok && float(veh[i].sumo_min_gap) >= 1e-3f && float(veh[i].sumo_min_gap) <= 1e6f &&
                     (veh[i].controller != FS_CTRL_IDM || (float(veh[i].p[5]) >= 1e-3f && float(veh[i].p[5]) <= 1e6f));
+    loop_delta4 = true;
+    for (int i = 0; i < N; ++i) loop_delta4 = loop_delta4 && (veh[i].controller != FS_CTRL_IDM || veh[i].p[4] == 4.0);
     if (all_idm) flags |= fs::FLAG_ALL_IDM;
     if (idm_set) flags |= fs::FLAG_IDM_SET;
     delta4 = all_idm;
@@ -513,7 +515,7 @@ struct Sim : SimBase {
 
   // the specialisations for the headline configuration (see flowsim_kernels.h)
   bool delta4 = false;
-  bool loop_div_ok = false;
+  bool loop_div_ok = false, loop_delta4 = false;
   bool fast_ok(const uint8_t* mask, int num_steps) const {
     const int f = dv.flags;
     return (f & fs::FLAG_ALL_IDM) && !(f & (fs::FLAG_HAS_NOISE | fs::FLAG_HAS_FAILSAFE | fs::FLAG_NEED_SUMO)) &&
@@ -585,12 +587,12 @@ struct Sim : SimBase {
           dv.N > 1 && loop_div_ok && !force_generic && !no_loop_kernel) {
         const int waves = (dv.R + 3) / 4;
         const dim3 grid((waves + 3) / 4), block(256);
-        if (dv.env == FS_ENV_ACCEL)
-          hipLaunchKernelGGL((fs::k_rollout_loop<0>), grid, block, 0, stream, dv, num_steps, actions, act_stride, obs,
-                             rew, done);
-        else
-          hipLaunchKernelGGL((fs::k_rollout_loop<1>), grid, block, 0, stream, dv, num_steps, actions, act_stride, obs,
-                             rew, done);
+#define FS_LOOP(H_, D_)                                                                                       \
+  hipLaunchKernelGGL((fs::k_rollout_loop<H_, D_>), grid, block, 0, stream, dv, num_steps, actions, act_stride, obs, \
+                     rew, done)
+        if (dv.env == FS_ENV_ACCEL) { if (loop_delta4) FS_LOOP(0, true); else FS_LOOP(0, false); }
+        else { if (loop_delta4) FS_LOOP(1, true); else FS_LOOP(1, false); }
+#undef FS_LOOP
         HIP_TRY(hipGetLastError());
         return FS_OK;
       }

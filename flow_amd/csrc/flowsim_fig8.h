@@ -40,7 +40,8 @@ __device__ __forceinline__ float lead16(float v, bool wrap) {
 // ctrl_idm / sumo_idm_speed (flowsim_kernels.h) with their divisions made cheap WITHOUT changing a bit: divisors
 // that are launch constants go through divc, the others (|h| >= 1e-3, gap >= 1e-3; dividends s* >= s0 >= 1e-3 and
 // ss >= minGap >= 1e-3, host-checked) through div_core
-struct IdmC { float p1, p2, p4, p5; DivC v0, two_sqrt; bool delta4; };
+struct IdmC { float p1, p2, p4, p5; DivC v0, two_sqrt; };
+template <bool DELTA4>
 __device__ __forceinline__ float idm_fast(float v, float vl, float h, bool has, const IdmC& c) {
   const float hh = tabs(h) < 1e-3f ? 1e-3f : h;
   const float dyn = v * c.p1 + divc(v * (v - vl), c.two_sqrt);
@@ -48,7 +49,7 @@ __device__ __forceinline__ float idm_fast(float v, float vl, float h, bool has, 
   const float q = div_core(s_star, hh);
   const float ratio = divc(v, c.v0);
   float pw;
-  if (c.delta4) { const float r2 = ratio * ratio; pw = r2 * r2; } else pw = pow_delta(ratio, c.p4);
+  if (DELTA4) { const float r2 = ratio * ratio; pw = r2 * r2; } else pw = pow_delta(ratio, c.p4);
   return c.p2 * (1.0f - pw - q * q);
 }
 struct SumoC { float min_gap, tau, max_accel; DivC two_sqrt, max_speed; };
@@ -62,14 +63,14 @@ __device__ __forceinline__ float sumo_fast(float v, float vl, float h, bool has,
   return tmax(0.0f, v + acc * dt);
 }
 
-template <int HEAD /* 0: AccelEnv, 1: WaveAttenuationPOEnv */>
+template <int HEAD /* 0: AccelEnv, 1: WaveAttenuationPOEnv */, bool DELTA4 /* every IDM slot has delta = 4 */>
 __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_steps,
                                                       const float* __restrict__ actions, size_t act_stride,
                                                       float* __restrict__ obs, float* __restrict__ rew,
                                                       uint8_t* __restrict__ done) {
   typedef float T;
   constexpr int SEG = 16, RPW = 4, PERIOD = 4;
-  __shared__ T tab_start[FS_MAX_SEGMENTS + 1], tab_fs[FS_MAX_SEGMENTS], tab_sl[FS_MAX_SEGMENTS];
+  __shared__ T tab_start[FS_MAX_SEGMENTS + 2], tab_fs[FS_MAX_SEGMENTS + 2], tab_sl[FS_MAX_SEGMENTS + 2];
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int seg = lane / SEG;
@@ -82,16 +83,14 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
   const int ii = i < N ? i : N - 1;
   const size_t idx = size_t(rr) * N + ii;
   const bool wrap_lead = (i + 1 >= N);
-  const bool has = N > 1;
+  constexpr bool has = true;                          // N > 1 (host-checked)
   const int flags = s.flags;
 
-  if (threadIdx.x <= FS_MAX_SEGMENTS) {
-    const int q = threadIdx.x;
-    tab_start[q] = q < s.nseg ? s.seg_start[q < FS_MAX_SEGMENTS ? q : 0] : T(3.0e38);
-    if (q < FS_MAX_SEGMENTS) {
-      tab_fs[q] = s.seg_flow_start[q];
-      tab_sl[q] = s.seg_flow_slope[q];
-    }
+  if (threadIdx.x < FS_MAX_SEGMENTS + 2) {
+    const int q = threadIdx.x, qq = q < FS_MAX_SEGMENTS ? q : 0;
+    tab_start[q] = q < s.nseg ? s.seg_start[qq] : T(3.0e38);
+    tab_fs[q] = q < s.nseg ? s.seg_flow_start[qq] : T(0);
+    tab_sl[q] = q < s.nseg ? s.seg_flow_slope[qq] : T(0);
   }
   __syncthreads();
 
@@ -125,7 +124,7 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
   // segment cursor: index + the row values read from LDS
   int k = 0;
   for (int q = 1; q < s.nseg; ++q) k = (x >= tab_start[q]) ? q : k;
-  T c_st = tab_start[k], c_next = tab_start[k + 1], c_fs = tab_fs[k], c_sl = tab_sl[k];
+  T c_st = tab_start[k], c_next = tab_start[k + 1], c_next2 = tab_start[k + 2], c_fs = tab_fs[k], c_sl = tab_sl[k];
   T xl = lead16(x, wrap_lead);
   T vl = lead16(v, wrap_lead);
   T d = xl - x;
@@ -144,7 +143,6 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
   ic.p1 = sl.p[1]; ic.p2 = sl.p[2]; ic.p4 = sl.p[4]; ic.p5 = sl.p[5];
   ic.v0 = make_divc(sl.p[0]);
   ic.two_sqrt = make_divc(T(2) * tsqrt(sl.p[2] * sl.p[3]));
-  ic.delta4 = sl.p[4] == T(4);
   SumoC sc;
   sc.min_gap = sl.sumo_min_gap; sc.tau = sl.sumo_tau; sc.max_accel = sl.max_accel;
   sc.two_sqrt = make_divc(T(2) * tsqrt(sl.max_accel * sl.max_decel));
@@ -162,18 +160,55 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
   const bool obs_lane = HEAD == 1 ? (valid && rl_lane && sl.rl_index == 0) : valid;
 
   float a_own_next = 0.0f, a_red_next = 0.0f;
+  const int red_col = red_lane ? ii : 0;                 // every lane loads (no exec-mask branch); only its role's value is used
   if (use_act && num_steps > 0) {
     const float* a0 = actions + size_t(rr) * num_rl;
-    if (rl_lane) a_own_next = a0[own_col];
-    if (red_lane) a_red_next = a0[ii];
+    a_own_next = a0[own_col];
+    a_red_next = a0[red_col];
   }
+  // the four draws of the current noise block, ROTATED so that g4[0] is always the draw of the next step (no
+  // per-step index select); a launch that starts in the middle of a block evaluates it and rotates up to there
   T g4[4] = {T(0), T(0), T(0), T(0)};
-  if (any_noise && (nctr & 3u) != 0u && noisy)          // mid-block start: the block of the current counter
+  if (any_noise && (nctr & 3u) != 0u && noisy) {
     gauss4<T>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(ii), nctr >> 2, g4);
+    for (uint32_t q = 0; q < (nctr & 3u); ++q) { g4[0] = g4[1]; g4[1] = g4[2]; g4[2] = g4[3]; }
+  }
 
   float* orow = obs + size_t(rr) * obs_dim;
   const size_t obs_step = size_t(s.R) * obs_dim;
   unsigned crash_bits = 0u, bad_bits = 0u;
+  // Stores are issued ONE STEP LATE (the values wait in registers): the action of the next step is a vector load,
+  // vector loads and stores share vmcnt and complete in order, so waiting for that load at the top of a step also
+  // waits for every store issued before the wait -- with the stores at the end of the previous step the wave stood
+  // still until they had landed (38 % of its life in the first version).  Issued right AFTER the wait, they have a
+  // whole step to complete before the next one.
+  float po0 = 0.0f, po1 = 0.0f, po2 = 0.0f;              // pending observation values of the previous step
+  bool pend_obs = false;
+  float prew = 0.0f;                                      // pending reward / done of the previous block
+  uint8_t pdone = 0;
+  size_t prew_at = 0;
+  bool pend_rew = false;
+  auto flush_obs = [&]() {
+    if (pend_obs) {                                       // wave-uniform
+#ifndef FS_DIAG_LOOP_NOSTORE                                // timing experiment only
+      if (obs_lane) {
+        if (HEAD == 1) { orow[0] = po0; orow[1] = po1; orow[2] = po2; }
+        else { orow[ii] = po0; orow[N + ii] = po1; }
+      }
+#else
+      asm volatile("" :: "v"(po0), "v"(po1), "v"(po2));
+#endif
+      orow += obs_step;
+      pend_obs = false;
+    }
+  };
+  auto flush_rew = [&]() {
+    if (pend_rew) {                                       // per lane
+      rew[prew_at] = prew;
+      done[prew_at] = pdone;
+      pend_rew = false;
+    }
+  };
   T prev_v = v, last_acc = T(0);                          // track_aux: get_previous_speed / get_accel of the scalar Env
 
   for (int base = 0; base < num_steps; base += PERIOD) {
@@ -187,10 +222,13 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
       if (slot < nsteps) {                                   // wave-uniform
         const int step = base + slot;
         const float a_own = a_own_next, a_red = a_red_next;
+        asm volatile("" :: "v"(a_own), "v"(a_red));             // the wait for the prefetched action happens HERE
+        flush_obs();
+        if (slot == 0) flush_rew();
         if (use_act && step + 1 < num_steps) {
           const float* an = actions + size_t(step + 1) * act_stride + size_t(rr) * num_rl;
-          if (rl_lane) a_own_next = an[own_col];
-          if (red_lane) a_red_next = an[ii];
+          a_own_next = an[own_col];
+          a_red_next = an[red_col];
         }
         // ---- controllers on the snapshot (control_accel_on, CSET = 1) ----------------------------------
         const bool on_edge = gated ? !((seg_internal >> k) & 1u) : true;
@@ -203,11 +241,11 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
           }
         }
         {
-          T a = idm_fast(v, vl, h, has, ic);
+          T a = idm_fast<DELTA4>(v, vl, h, has, ic);
           if (any_noise) {
-            const uint32_t j = nctr & 3u;
-            const T g = j == 0u ? g4[0] : (j == 1u ? g4[1] : (j == 2u ? g4[2] : g4[3]));
-            if (noisy) a = a + sl.noise * g;
+            const T an = a + sl.noise * g4[0];
+            a = noisy ? an : a;
+            g4[0] = g4[1]; g4[1] = g4[2]; g4[2] = g4[3];
           }
           T arl = T(a_own);
           if (clip) arl = tmin(tmax(arl, act_lo), act_hi);
@@ -228,11 +266,11 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
         if (junction_on) {
           // per-replica facts of the snapshot, one OR-butterfly: bit 0 stream a busy, bit 1 stream b in the box
           unsigned f = 0u;
-          f |= (valid && (x >= ja_in - tgap * v) && (x < ja_out + sl.length)) ? 1u : 0u;
-          f |= (valid && (x >= jb_in) && (x < jb_out + sl.length)) ? 2u : 0u;
+          f |= (valid & (x >= ja_in - tgap * v) & (x < ja_out + sl.length)) ? 1u : 0u;
+          f |= (valid & (x >= jb_in) & (x < jb_out + sl.length)) ? 2u : 0u;
           f = seg_or<SEG>(f);
-          const bool on_b = (x >= jb_in - look) && (x < jb_in) && (f & 1u);
-          const bool on_a = (x >= ja_in - look) && (x < ja_in) && (f & 2u);
+          const bool on_b = (x >= jb_in - look) & (x < jb_in) & ((f & 1u) != 0u);
+          const bool on_a = (x >= ja_in - look) & (x < ja_in) & ((f & 2u) != 0u);
           // a vehicle is on at most one approach (the two lines are different places of the loop); should both
           // hold for a degenerate table, stream b's line is evaluated first and stream a's overrides as min would
           if (__ballot(on_a || on_b) != 0ull) {
@@ -255,41 +293,43 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
         tcount += 1;
         nctr += 1u;
         // ---- segment cursor: advance by compares, re-read the row from LDS --------------------------------
-        k = (x < c_st) ? 0 : k;                                 // wrapped around the loop
-        k += (x >= c_next && !(x < c_st)) ? 1 : 0;
-        c_st = tab_start[k];
-        c_next = tab_start[k + 1];
-        while (__ballot(x >= c_next) != 0ull) {                 // more than one start passed (or after a wrap): rare
-          k += (x >= c_next) ? 1 : 0;
-          c_st = tab_start[k];
-          c_next = tab_start[k + 1];
-        }
-        c_fs = tab_fs[k];
-        c_sl = tab_sl[k];
+        // (up to two starts passed per step without a table access; the row of the new segment is read from LDS
+        // now and consumed at the end of the step, the rare third advance / advance after a wrap is caught there)
+        k = (x < c_st) ? 0 : k + ((x >= c_next) ? 1 : 0) + ((x >= c_next2) ? 1 : 0);
+        const T n_st = tab_start[k], n_next = tab_start[k + 1], n_next2 = tab_start[k + 2];
+        const T n_fs = tab_fs[k], n_sl = tab_sl[k];
         // ---- new neighbour snapshot (S10) + per-replica facts of the new state -----------------------------
         xl = lead16(x, wrap_lead);
         vl = lead16(v, wrap_lead);
         d = xl - x;
         d = d < T(0) ? d + Lv : d;
         h = has ? d - len_lead : T(1000);
-        unsigned f2 = (valid && has && (h < crash_gap)) ? 1u : 0u;
+        unsigned f2 = (valid & (h < crash_gap)) ? 1u : 0u;
         if (junction_on) {
-          f2 |= (valid && (x >= za_lo) && (x < za_hi)) ? 2u : 0u;
-          f2 |= (valid && (x >= zb_lo) && (x < zb_hi)) ? 4u : 0u;
+          f2 |= (valid & (x >= za_lo) & (x < za_hi)) ? 2u : 0u;
+          f2 |= (valid & (x >= zb_lo) & (x < zb_hi)) ? 4u : 0u;
         }
-        f2 |= (valid && (v < T(-100))) ? 8u : 0u;
+        f2 |= (valid & (v < T(-100))) ? 8u : 0u;
         f2 = seg_or<SEG>(f2);
         const bool crashed = (f2 & 1u) || ((f2 & 6u) == 6u);
         const bool bad = (f2 & 8u) || crashed;
         crash_bits |= crashed ? (1u << slot) : 0u;
         bad_bits |= bad ? (1u << slot) : 0u;
+        // ---- the segment row read above
+        c_st = n_st; c_next = n_next; c_next2 = n_next2; c_fs = n_fs; c_sl = n_sl;
+        while (__ballot(x >= c_next) != 0ull) {                  // rare
+          k += (x >= c_next) ? 1 : 0;
+          c_st = tab_start[k];
+          c_next = tab_start[k + 1];
+          c_next2 = tab_start[k + 2];
+          c_fs = tab_fs[k];
+          c_sl = tab_sl[k];
+        }
         // ---- observation ---------------------------------------------------------------------------------
         if (HEAD == 1) {
-          if (obs_lane) {                                        // wave_attenuation.py:248-269
-            orow[0] = divc(v, d_15);
-            orow[1] = divc(vl - v, d_15);
-            orow[2] = divc(d, d_po);
-          }
+          po0 = divc(v, d_15);                                   // wave_attenuation.py:248-269
+          po1 = divc(vl - v, d_15);
+          po2 = divc(d, d_po);
           red[slot] = valid ? v : T(0);
           T a = T(0);
           if (red_lane && use_act) {
@@ -300,14 +340,12 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
           red2[slot] = a;
         } else {
           const T xo = c_fs + c_sl * (x - c_st);
-          if (obs_lane) {                                        // accel.py:116-123
-            orow[ii] = divc(v, d_ms);
-            orow[N + ii] = divc(xo, d_L);
-          }
+          po0 = divc(v, d_ms);                                   // accel.py:116-123
+          po1 = divc(xo, d_L);
           const T dv = valid ? v - target_v : T(0);
           red[slot] = dv * dv;
         }
-        orow += obs_step;
+        pend_obs = true;
       }
     }
     // ---- rewards + done of the block: lane j finishes step j ------------------------------------------------
@@ -338,10 +376,14 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
         reward = my_bad ? T(0) : reward;
       }
       const size_t o = size_t(base + j) * s.R + rr;
-      rew[o] = float(reward);
-      done[o] = uint8_t((t_j >= s.step_limit) || my_crash);
+      prew = float(reward);
+      pdone = uint8_t((t_j >= s.step_limit) || my_crash);
+      prew_at = o;
+      pend_rew = true;
     }
   }
+  flush_obs();
+  flush_rew();
   if (valid) {
     s.pos[idx] = x;
     s.vel[idx] = v;

@@ -31,7 +31,7 @@ waves = bench["replicas"] * (1 if slots <= 64 else (2 if slots <= 128 else 4))
 substeps = bench.get("env_steps", bench.get("steps", 0)) * bench.get("sims_per_step", 1)
 pattern = "k_steps_wide" if slots > 64 else "k_steps_open"
 if leg == "c3":                                # 14 vehicles -> 16 lanes per replica, 4 replicas per wave
-    waves, pattern = bench["replicas"] // 4, "fs::k_steps<"
+    waves, pattern = bench["replicas"] // 4, ("fs::k_rollout_loop" if any("k_rollout_loop" in r["Name"] for r in csv.DictReader(open(newest("trace/*/*_kernel_stats.csv")))) else "fs::k_steps<")
     substeps = bench.get("steps_per_launch", 1500)
 counters = {}
 for d in ("pmc_sq", "pmc_sq2"):
