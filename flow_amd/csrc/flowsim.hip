@@ -567,8 +567,12 @@ struct Sim : SimBase {
       return FS_OK;
     }
     if (dv.num_lanes > 1) {
-      hipLaunchKernelGGL((fs::k_steps_ml<T, SEG>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, mask, actions,
-                         act_stride, obs, rew, done, obs_every_step);
+      if (dv.lc_enabled)
+        hipLaunchKernelGGL((fs::k_steps_ml<T, SEG, true>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, mask,
+                           actions, act_stride, obs, rew, done, obs_every_step);
+      else
+        hipLaunchKernelGGL((fs::k_steps_ml<T, SEG, false>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, mask,
+                           actions, act_stride, obs, rew, done, obs_every_step);
       HIP_TRY(hipGetLastError());
       return FS_OK;
     }

@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
       }
       const size_t o = size_t(base + j) * s.R + rr;
       prew = float(reward);
-      pdone = uint8_t((t_j >= s.step_limit) || my_crash);
+      pdone = done_flag(t_j >= s.step_limit, my_crash);
       prew_at = o;
       pend_rew = true;
     }

@@ -89,6 +89,13 @@ struct DevView {
   T ja_in, ja_out, jb_in, jb_out, j_lookahead, j_time_gap, za_lo, za_hi, zb_lo, zb_hi;
 };
 
+// done flag of a step (envs/base.py:398-400 `done = time_counter >= horizon limit or crash`): non-zero = done, and
+// the two reasons stay readable -- bit 0: the horizon was reached, bit 1: a collision ended the episode (so a crash
+// on the very last step of the horizon still reaches compute_reward(fail=True) in the scalar Env)
+__device__ __forceinline__ uint8_t done_flag(bool horizon, bool crashed) {
+  return uint8_t((horizon ? 1 : 0) | (crashed ? 2 : 0));
+}
+
 // ---------------------------------------------------------------------------
 // small math helpers with a fixed operation order
 // ---------------------------------------------------------------------------
@@ -439,37 +446,41 @@ __device__ __forceinline__ void philox4x32_10(uint32_t& c0, uint32_t& c1, uint32
 }
 
 // Four N(0,1) draws from ONE Philox call: the counter is (block = step / 4, vehicle, replica, 0); the words (c0, c1)
-// and (c2, c3) feed two Box-Muller transforms whose cosine AND sine branches are both used, so draw j = step % 4 of
-// the block is pair j / 2, cosine for even j, sine for odd j (oracle/refsim.py gaussian_noise, changed in lock-step).
-// The generic kernels evaluate the block of the current step and pick one draw; k_rollout_fig8 keeps the four for
-// four steps.  float: the hardware's log2 / sin / cos (argument in revolutions) / sqrt -- noise is compared with the
-// numpy oracle at libm tolerance anyway (DESIGN "Precision"); double: libm.
-__device__ __forceinline__ void box_muller2(float u1, float u2, float& gc, float& gs) {
-  const float r = __builtin_amdgcn_sqrtf(-2.0f * (__builtin_amdgcn_logf(u1) * 0.6931471805599453f));
-  gc = r * __builtin_amdgcn_cosf(u2);
-  gs = r * __builtin_amdgcn_sinf(u2);
+// and (c2, c3) feed two Box-Muller transforms that are each used twice, at the angle 2 pi u2 and a quarter turn back
+// (i.e. the sine branch, written as a cosine so that ONE trigonometric function serves every draw): draw j = step % 4
+// of the block is r_{j/2} * cos(2 pi (u2_{j/2} - (j & 1) / 4))  (oracle/refsim.py gaussian_noise, in lock-step).
+// The generic kernels evaluate the draw of the current step; k_rollout_loop keeps the block's four for four steps.
+// float: the hardware's log2 / cos (argument in revolutions) / sqrt -- noise is compared with the numpy oracle at
+// libm tolerance anyway (DESIGN "Precision"); double: libm.
+__device__ __forceinline__ float bm_radius(float u1) {
+  return __builtin_amdgcn_sqrtf(-2.0f * (__builtin_amdgcn_logf(u1) * 0.6931471805599453f));
 }
-__device__ __forceinline__ void box_muller2(double u1, double u2, double& gc, double& gs) {
-  const double r = sqrt(-2.0 * log(u1));
-  gc = r * cos(6.283185307179586 * u2);
-  gs = r * sin(6.283185307179586 * u2);
-}
+__device__ __forceinline__ double bm_radius(double u1) { return sqrt(-2.0 * log(u1)); }
+__device__ __forceinline__ float bm_cos(float turns) { return __builtin_amdgcn_cosf(turns); }
+__device__ __forceinline__ double bm_cos(double turns) { return cos(6.283185307179586 * turns); }
 template <typename T>
 __device__ __forceinline__ void gauss4(uint32_t seed_lo, uint32_t seed_hi, uint32_t replica, uint32_t vehicle,
                                        uint32_t block, T* g) {
   uint32_t c0 = block, c1 = vehicle, c2 = replica, c3 = 0u;
   philox4x32_10(c0, c1, c2, c3, seed_lo, seed_hi);
   const T k = T(1.0 / 16777216.0);                     // u1 in (0, 1], u2 in [0, 1): 24-bit integers, exact in float
-  box_muller2(T((c0 >> 8) + 1u) * k, T(c1 >> 8) * k, g[0], g[1]);
-  box_muller2(T((c2 >> 8) + 1u) * k, T(c3 >> 8) * k, g[2], g[3]);
+  const T ra = bm_radius(T((c0 >> 8) + 1u) * k), ua = T(c1 >> 8) * k;
+  const T rb = bm_radius(T((c2 >> 8) + 1u) * k), ub = T(c3 >> 8) * k;
+  g[0] = ra * bm_cos(ua);
+  g[1] = ra * bm_cos(ua - T(0.25));
+  g[2] = rb * bm_cos(ub);
+  g[3] = rb * bm_cos(ub - T(0.25));
 }
 template <typename T>
 __device__ __forceinline__ T gauss(uint32_t seed_lo, uint32_t seed_hi, uint32_t replica, uint32_t vehicle,
                                    uint32_t step) {
-  T g[4];
-  gauss4<T>(seed_lo, seed_hi, replica, vehicle, step >> 2, g);
-  const uint32_t j = step & 3u;
-  return j == 0u ? g[0] : (j == 1u ? g[1] : (j == 2u ? g[2] : g[3]));
+  uint32_t c0 = step >> 2, c1 = vehicle, c2 = replica, c3 = 0u;
+  philox4x32_10(c0, c1, c2, c3, seed_lo, seed_hi);
+  const bool second = (step & 2u) != 0u;
+  const uint32_t w1 = second ? c2 : c0, w2 = second ? c3 : c1;
+  const T k = T(1.0 / 16777216.0);
+  const T u2 = T(w2 >> 8) * k;
+  return bm_radius(T((w1 >> 8) + 1u) * k) * bm_cos((step & 1u) ? u2 - T(0.25) : u2);
 }
 
 // ---------------------------------------------------------------------------
@@ -628,32 +639,38 @@ __device__ __forceinline__ T sumo_idm_speed(T v, T vl, T h, bool has, T dt, cons
   return tmax(T(0), v + acc * dt);
 }
 
-// The closed-network segment table (<= FS_MAX_SEGMENTS rows) lives in three VGPRs, lane q holding row
-// q, loaded once per launch: a lookup inside the step loop is then v_readlane compares plus three
-// ds_bpermute gathers, with no trip to the kernarg segment (a lane-varying index into the by-value
-// DevView arrays compiles to global loads, whose latency one wave per SIMD cannot hide).
+// The closed-network segment table (<= FS_MAX_SEGMENTS rows) is copied to LDS once per launch (one wave per block)
+// and read with plain, lane-indexed ds_read: a lookup inside the step loop makes no trip to the kernarg segment (a
+// lane-varying index into the by-value DevView arrays compiles to global loads, whose latency one wave per SIMD
+// cannot hide), and -- unlike the lane-held VGPR table + v_readlane / ds_bpermute form this replaced -- it is valid
+// under ANY exec mask and holds no value the compiler could park in an AGPR and re-materialise under a partial
+// mask in front of a v_readlane (the wide kernel's miscompile; tests/test_codegen.py).
 template <typename T>
-struct SegTab { T start, flow_start, flow_slope; };
+struct SegTab { const T* start; const T* flow_start; const T* flow_slope; };     // LDS rows, [FS_MAX_SEGMENTS + 1]
+
+#define FS_SEGTAB_LDS(T, name)                                                                    \
+  __shared__ T name##_st[FS_MAX_SEGMENTS + 1], name##_fs[FS_MAX_SEGMENTS + 1], name##_sl[FS_MAX_SEGMENTS + 1]
 
 template <typename T>
-__device__ __forceinline__ SegTab<T> load_segtab(const DevView<T>& s, int lane) {
-  const int q = lane & (FS_MAX_SEGMENTS - 1);
-  SegTab<T> t;
-  t.start = s.seg_start[q];
-  t.flow_start = s.seg_flow_start[q];
-  t.flow_slope = s.seg_flow_slope[q];
-  return t;
+__device__ __forceinline__ SegTab<T> load_segtab(const DevView<T>& s, int lane, T* st, T* fs0, T* sl) {
+  if (lane <= FS_MAX_SEGMENTS) {
+    const int q = lane < FS_MAX_SEGMENTS ? lane : 0;
+    st[lane] = lane < s.nseg ? s.seg_start[q] : T(3.0e38);
+    fs0[lane] = lane < s.nseg ? s.seg_flow_start[q] : T(0);
+    sl[lane] = lane < s.nseg ? s.seg_flow_slope[q] : T(0);
+  }
+  __syncthreads();
+  return SegTab<T>{st, fs0, sl};
 }
 
 // segment of loop coordinate x (the last one whose start is <= x): is it internal, and Flow's table
 // coordinate of x (oracle/refsim.py _segment_lookup)
 template <typename T>
-// MUST be called with all 64 lanes active (ds_bpermute reads 0 from a disabled lane).
 __device__ __forceinline__ void segment_lookup(const DevView<T>& s, const SegTab<T>& tab, T x, bool& internal,
                                                T& flow_x) {
   int k = 0;
-  for (int q = 1; q < s.nseg; ++q) k = (x >= read_lane(tab.start, q)) ? q : k;
-  const T st = __shfl(tab.start, k, 64), fs0 = __shfl(tab.flow_start, k, 64), sl = __shfl(tab.flow_slope, k, 64);
+  for (int q = 1; q < s.nseg; ++q) k = (x >= tab.start[q]) ? q : k;
+  const T st = tab.start[k], fs0 = tab.flow_start[k], sl = tab.flow_slope[k];
   internal = (s.seg_internal >> k) & 1u;
   flow_x = fs0 + sl * (x - st);
 }
@@ -685,19 +702,19 @@ struct SegCursor {
   int k;
   T st, fs0, sl, next;
 
-  __device__ __forceinline__ void refresh(const SegTab<T>& tab, int nseg) {        // all 64 lanes active
-    st = __shfl(tab.start, k, 64);
-    fs0 = __shfl(tab.flow_start, k, 64);
-    sl = __shfl(tab.flow_slope, k, 64);
-    const T nx = __shfl(tab.start, k + 1 < nseg ? k + 1 : k, 64);
-    next = (k + 1 < nseg) ? nx : T(3.0e38);
+  __device__ __forceinline__ void refresh(const SegTab<T>& tab, int nseg) {
+    st = tab.start[k];
+    fs0 = tab.flow_start[k];
+    sl = tab.flow_slope[k];
+    next = tab.start[k + 1];                           // row nseg holds 3.0e38
+    (void)nseg;
   }
   __device__ __forceinline__ void init(const DevView<T>& s, const SegTab<T>& tab, T x) {
     k = 0;
-    for (int q = 1; q < s.nseg; ++q) k = (x >= read_lane(tab.start, q)) ? q : k;
+    for (int q = 1; q < s.nseg; ++q) k = (x >= tab.start[q]) ? q : k;
     refresh(tab, s.nseg);
   }
-  __device__ __forceinline__ void follow(const DevView<T>& s, const SegTab<T>& tab, T x) {   // all 64 lanes active
+  __device__ __forceinline__ void follow(const DevView<T>& s, const SegTab<T>& tab, T x) {
     if (__ballot(x < st) != 0ull) {
       k = (x < st) ? 0 : k;
       refresh(tab, s.nseg);
@@ -835,7 +852,8 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
   sl.sumo_min_gap = s.sumo_min_gap[ii];
   sl.sumo_max_speed = s.sumo_max_speed[ii];
   const T len_lead = lead_read<SEG>(sl.length, seg, wrap_lead);
-  const SegTab<T> segtab = (!FAST && s.nseg > 0) ? load_segtab(s, lane) : SegTab<T>{T(0), T(0), T(0)};
+  FS_SEGTAB_LDS(T, segrows);
+  const SegTab<T> segtab = load_segtab(s, lane, segrows_st, segrows_fs, segrows_sl);
   const bool use_seg = !FAST && s.nseg > 0;            // figure eight: Flow's table coordinate / internal edges
   SegCursor<T> cur = {0, T(0), T(0), T(1), T(3.0e38)};
 
@@ -1049,7 +1067,7 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
       }
       if (valid && ii == 0) {
         *rrow = float(reward);
-        *drow = uint8_t((tcount >= s.step_limit) || crashed);              // envs/base.py:398-400
+        *drow = done_flag(tcount >= s.step_limit, crashed);              // envs/base.py:398-400
       }
       orow += step_rows * obs_dim;
       rrow += step_rows;
@@ -1287,7 +1305,7 @@ __global__ __launch_bounds__(1024) void k_rollout_idm(DevView<T> s, int num_step
       reward = my_bad ? T(0) : reward;                                                        // rewards.py:46
       const size_t o = size_t(base + j) * s.R + rr;
       rew[o] = float(reward);
-      done[o] = uint8_t((t_i >= s.step_limit) || my_crash);                                   // envs/base.py:398-400
+      done[o] = done_flag(t_i >= s.step_limit, my_crash);                                   // envs/base.py:398-400
     }
   }
   if (valid) {
@@ -1309,7 +1327,7 @@ __global__ __launch_bounds__(1024) void k_rollout_idm(DevView<T> s, int num_step
 template <typename T>
 __device__ __forceinline__ T bperm(T v, int src_lane) { return __shfl(v, src_lane, 64); }
 
-template <typename T, int SEG>
+template <typename T, int SEG, bool LC /* some vehicle changes lane on its own (ML7) */>
 __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, const uint8_t* __restrict__ mask,
                                                  const float* __restrict__ actions, size_t act_stride,
                                                  float* __restrict__ obs, float* __restrict__ rew,
@@ -1346,7 +1364,8 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
   sl.sumo_tau = s.sumo_tau[ii];
   sl.sumo_min_gap = s.sumo_min_gap[ii];
   sl.sumo_max_speed = s.sumo_max_speed[ii];
-  const SegTab<T> segtab = s.nseg > 0 ? load_segtab(s, threadIdx.x) : SegTab<T>{T(0), T(0), T(0)};
+  FS_SEGTAB_LDS(T, segrows);
+  const SegTab<T> segtab = load_segtab(s, int(threadIdx.x), segrows_st, segrows_fs, segrows_sl);
 
   const T base_len = s.ring_len[rr];
   const T L = base_len + T(4) * s.jlen;
@@ -1398,7 +1417,7 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
   // changes are commanded) want the adjacent lane whose leader gap beats their headway by lc_min_gain, if the gaps to
   // the new leader and follower are at least the SUMO-IDM desired gaps; wishes are formed on every neighbour
   // snapshot, ONE change per replica and sub-step (largest gain, lowest slot) is executed with the move.
-  const bool lc_on = s.lc_enabled != 0;
+  constexpr bool lc_on = LC;
   const bool my_lc_auto = lc_on && s.lc_auto[ii] != 0 && sl.ctrl != FS_CTRL_RL;
   int lc_want = -1;
   T lc_gain = T(0);
@@ -1407,8 +1426,7 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
     T best = big, bestf = big;
     lead = -1;
     foll = -1;
-    T abest[2] = {big, big}, abestf[2] = {big, big};     // [0]: lane - 1, [1]: lane + 1
-    int alead[2] = {-1, -1}, afoll[2] = {-1, -1};
+
     // slot j is the same for every lane of the wave: x_j / lane_j come by v_readlane (no LDS round trip per
     // candidate), and the tests are bitwise so that they stay selects instead of nested exec-mask branches
     for (int j = 0; j < N; ++j) {
@@ -1427,17 +1445,6 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
       lead = tl ? j : lead;
       bestf = tf ? dji : bestf;
       foll = tf ? j : foll;
-      if (lc_on) {                                      // wave-uniform
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const bool adj = (lj == ln + (2 * q - 1)) & (j != ii);
-          const bool al = adj & (dij < abest[q]), af = adj & (dji < abestf[q]);
-          abest[q] = al ? dij : abest[q];
-          alead[q] = al ? j : alead[q];
-          abestf[q] = af ? dji : abestf[q];
-          afoll[q] = af ? j : afoll[q];
-        }
-      }
     }
     has = lead >= 0;
     const int lsrc = segbase + (has ? lead : ii);
@@ -1450,15 +1457,35 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
       const T two_sqrt = T(2) * tsqrt(sl.max_accel * sl.max_decel);
       T best_gain = -big;
       int best_lane = -1;
-#pragma unroll
+      // one more pass of the neighbour scan per side (not fused into the own-lane pass: the float64 instantiation
+      // would need more than 256 VGPRs and re-materialise lane-held values from AGPRs, tests/test_codegen.py)
+#pragma unroll 1
       for (int q = 0; q < 2; ++q) {                     // right first, so that left wins a tie
         const int tl = ln + (2 * q - 1);
         const bool valid_t = ok0 && tl >= 0 && tl < s.num_lanes;
-        const bool has_l = alead[q] >= 0, has_f = afoll[q] >= 0;
-        const int ls = segbase + (has_l ? alead[q] : ii), fs_ = segbase + (has_f ? afoll[q] : ii);
+        T abest = big, abestf = big;
+        int alead = -1, afoll = -1;
+        for (int j = 0; j < N; ++j) {
+          const T xj = seg_read<SEG>(x, j, seg);
+          const int lj = seg_read_i<SEG>(ln, j, seg);
+          T dij = xj - x;
+          const bool wrapf = (dij < T(0)) | ((dij == T(0)) & (j < ii));
+          dij = wrapf ? dij + L : dij;
+          T dji = x - xj;
+          const bool wrapb = (dji < T(0)) | ((dji == T(0)) & (ii < j));
+          dji = wrapb ? dji + L : dji;
+          const bool adj = (lj == tl) & (j != ii);
+          const bool al = adj & (dij < abest), af = adj & (dji < abestf);
+          abest = al ? dij : abest;
+          alead = al ? j : alead;
+          abestf = af ? dji : abestf;
+          afoll = af ? j : afoll;
+        }
+        const bool has_l = alead >= 0, has_f = afoll >= 0;
+        const int ls = segbase + (has_l ? alead : ii), fs_ = segbase + (has_f ? afoll : ii);
         const T vl2 = bperm(v, ls), ll2 = bperm(sl.length, ls), vf2 = bperm(v, fs_);
-        const T gap_l = has_l ? abest[q] - ll2 : T(1000.0);
-        const T gap_f = has_f ? abestf[q] - sl.length : T(1000.0);
+        const T gap_l = has_l ? abest - ll2 : T(1000.0);
+        const T gap_f = has_f ? abestf - sl.length : T(1000.0);
         const T v_l = has_l ? vl2 : T(0), v_f = has_f ? vf2 : T(0);
         const T need_l = sl.sumo_min_gap + tmax(T(0), v * sl.sumo_tau + v * (v - v_l) / two_sqrt);
         const T need_f = sl.sumo_min_gap + tmax(T(0), v_f * sl.sumo_tau + v_f * (v_f - v) / two_sqrt);
@@ -1621,7 +1648,7 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
       }
       if (valid && ii == 0) {
         *rrow = float(reward);
-        *drow = uint8_t((tcount >= s.step_limit) || crashed);
+        *drow = done_flag(tcount >= s.step_limit, crashed);
       }
       orow += step_rows * obs_dim;
       rrow += step_rows;

@@ -913,7 +913,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       }
       if (valid && ii == 0) {
         *rrow = float(reward);
-        *drow = uint8_t((tcount >= s.step_limit) || crashed);
+        *drow = done_flag(tcount >= s.step_limit, crashed);
       }
       orow += step_rows * obs_dim;
       rrow += step_rows;

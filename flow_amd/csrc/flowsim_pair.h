@@ -603,7 +603,7 @@ __global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_step
       reward = my_bad ? 0.0f : reward;                                                     // rewards.py:46
       const size_t o = size_t(base + k) * s.R + rr;
       rew[o] = reward;
-      done[o] = uint8_t((t_k >= s.step_limit) || my_crash);                                // envs/base.py:398-400
+      done[o] = done_flag(t_k >= s.step_limit, my_crash);                                // envs/base.py:398-400
     }
   }
   // the remaining num_steps % PERIOD steps one at a time (same tree: seg_sum is transposed_sum's order)
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_step
       reward = my_bad ? 0.0f : reward;
       const size_t o = size_t(base) * s.R + rr;
       rew[o] = reward;
-      done[o] = uint8_t((tcount >= s.step_limit) || my_crash);
+      done[o] = done_flag(tcount >= s.step_limit, my_crash);
     }
   }
   if (valid) {

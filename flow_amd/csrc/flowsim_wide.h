@@ -637,7 +637,7 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
       const T reward = outflow(o.rew_window) / o.out_norm;       // bottleneck.py:474-478, 971-981
       if (tid == 64 * (W - 1)) {
         *rrow = float(reward);
-        *drow = uint8_t((tcount >= s.step_limit) || crashed);
+        *drow = done_flag(tcount >= s.step_limit, crashed);
       }
       orow += step_rows * obs_dim;
       rrow += step_rows;

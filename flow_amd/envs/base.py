@@ -141,7 +141,7 @@ class Env(_Base):
         self.k.update(reset=False)
         limit = n_sub * (self.env_params.warmup_steps + self.env_params.horizon)
         tc = int(self.sim.time_counter[0])
-        crash = bool(done[0]) and tc < limit
+        crash = bool(int(self.sim.last_done_flags[0]) & 2)      # the kernel reports a collision separately from the horizon
         self.time_counter = tc
         self._crash = crash
         self.k.simulation.crashed = crash

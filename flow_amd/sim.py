@@ -232,6 +232,7 @@ class FlowSim:
         rew = np.empty(self.R, dtype=np.float32)
         done = np.empty(self.R, dtype=np.uint8)
         L.check(self.lib.fs_step(self._h, _ptr(a), _ptr(obs), _ptr(rew), _ptr(done)))
+        self.last_done_flags = done          # bit 0: horizon reached, bit 1: collision (include/flowsim.h)
         return obs, rew, done.astype(bool)
 
     # ------------------------------------------------------------------ device API (torch-ROCm tensors)

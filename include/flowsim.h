@@ -342,6 +342,8 @@ int fs_step_dev(fs_handle h, const float* actions_dev, float* obs_dev, float* re
  *                or one real32[R,num_rl] reused every step (stride 0), or NULL
  *   obs_dev      real32[K,R,obs_dim] if obs_every_step, else real32[R,obs_dim] (last step)
  *   rew_dev      real32[K,R] / real32[R]      done_dev uint8[K,R] / uint8[R]
+ *   done: 0 = the episode goes on; non-zero = done, bit 0: the horizon was reached (time_counter >= sims_per_step *
+ *   (warmup_steps + horizon)), bit 1: a collision ended it (envs/base.py:381-400)
  * A replica that is done keeps stepping (the caller resets it, as
  * Experiment.run / RLlib do after `done`, flow/core/experiment.py:144-161). */
 int fs_rollout_dev(fs_handle h, int num_steps, const float* actions_dev, size_t action_stride_steps,

@@ -54,8 +54,9 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 def gaussian_noise(seed, replica, vehicle, step, dtype):
     """N(0,1) per (replica, vehicle, step): ONE Philox call, keyed by the 64-bit seed with counter
     (step // 4, vehicle, replica, 0), serves four steps: words (c0, c1) and (c2, c3) feed two Box-Muller
-    transforms, cosine and sine branch both used -- draw j = step % 4 is pair j // 2, cosine for even j, sine for
-    odd j.  Shared definition with the kernels (flowsim_kernels.h gauss4 / gauss)."""
+    transforms, each used at the angle 2 pi u2 and a quarter turn back (the sine branch written as a cosine) --
+    draw j = step % 4 is r_{j // 2} * cos(2 pi (u2_{j // 2} - (j & 1) / 4)).  Shared definition with the kernels
+    (flowsim_kernels.h gauss4 / gauss)."""
     seed = int(seed)
     k0 = np.uint32(seed & 0xFFFFFFFF)
     k1 = np.uint32((seed >> 32) & 0xFFFFFFFF)
@@ -70,9 +71,9 @@ def gaussian_noise(seed, replica, vehicle, step, dtype):
     u2 = (rb >> np.uint32(8)).astype(np.float64) * (1.0 / 16777216.0)
     u1 = u1.astype(dtype)
     u2 = u2.astype(dtype)
+    u2 = np.where((j & np.uint32(1)) == 1, u2 - np.asarray(0.25, dtype), u2)
     two_pi = np.asarray(6.283185307179586, dtype)
-    rad = np.sqrt(np.asarray(-2.0, dtype) * np.log(u1))
-    return rad * np.where((j & np.uint32(1)) == 0, np.cos(two_pi * u2), np.sin(two_pi * u2))
+    return np.sqrt(np.asarray(-2.0, dtype) * np.log(u1)) * np.cos(two_pi * u2)
 
 
 def pisaturation_step(hist, n, v_cmd, v, v_lead, h, dt, max_accel, do_update, dtype):
