@@ -116,7 +116,7 @@ def host_cores():
 
 def c3_leg(device, R=4096, steps=3000, po=False):
     """BASELINE configs[2] (informational, not the headline): FigureEightNetwork, 13 noisy IDM + 1 RL vehicle,
-    random RL actions from a pre-generated tape, generic k_steps kernel.  ``po=False``: AccelEnv observation (28),
+    random RL actions from a pre-generated tape, rollout kernel of segment-table loops (flowsim_fig8.h).  ``po=False``: AccelEnv observation (28),
     the pairing the reference itself uses (singleagent_figure_eight.py:44); ``po=True``: the 3-value
     WaveAttenuationPOEnv observation BASELINE.json names."""
     import torch
@@ -162,7 +162,7 @@ def c3_leg(device, R=4096, steps=3000, po=False):
     return {"value": R * done_steps / dt, "unit": "env-steps/s", "steps": done_steps, "steps_per_launch": K, "replicas": R,
             "obs_dim": 3 if po else 28, "replicas_crashed_before_horizon": crashed,
             "workload": "C3: FigureEightNetwork r=30, 13 IDM (noise 0.2, obey_safe_speed) + 1 RL, %s, "
-                        "random actions; generic kernel" % ("WaveAttenuationPOEnv" if po else "AccelEnv")}
+                        "random actions; k_rollout_loop" % ("WaveAttenuationPOEnv" if po else "AccelEnv")}
 
 
 def c5_leg(device, R=1024, env_steps=600):
