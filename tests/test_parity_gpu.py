@@ -964,3 +964,49 @@ def _continue(sim, K, actions):
     sim.rollout_dev(K, obs, rew, done, actions=torch.as_tensor(actions, device=dev))
     sim.sync()
     return obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+
+
+def test_c3_full_size_launch_4096_replicas_1500_steps():
+    """BASELINE configs[2] at the size bench.py runs it (4096 replicas x 14 vehicles x 1500 steps in ONE launch):
+    (a) with noise + random RL actions the rollout kernel equals the generic kernel bit for bit on every replica;
+    (b) size-independent properties: positions stay on the loop, speeds are non-negative, no two vehicles overlap
+        unless the episode is flagged crashed, time counters = 1500;
+    (c) without noise, 8 sampled replicas equal the numpy oracle bit for bit over the whole episode."""
+    R, N, K = 4096, 14, 1500
+    spec = figure_eight_spec(R=R, N=N, horizon=K, seed=11, num_rl=1)
+    veh = [idm_vehicle(speed_mode=1, max_decel=1.5, noise=0.2) for _ in range(N - 1)]
+    veh.append(idm_vehicle(controller=S.CTRL_RL, rl_index=0, speed_mode=1, max_decel=1.5))
+    spec["vehicles"] = veh
+    spec["seed"] = 5
+    rng = np.random.default_rng(2)
+    acts = rng.uniform(-1, 1, (K, R, 1)).astype(np.float32)
+    a, oa, ra, da = _rollout(spec, K, acts)
+    b, ob, rb, db = _rollout(spec, K, acts, env={"FLOWSIM_NO_LOOP_KERNEL": "1"})
+    assert np.array_equal(oa, ob) and np.array_equal(ra, rb) and np.array_equal(da, db)
+    np.testing.assert_array_equal(a.pos, b.pos)
+    np.testing.assert_array_equal(a.vel, b.vel)
+    L = float(spec["ring_length"][0]) + 4 * spec["junction_length"]
+    x, v = a.pos, a.vel
+    assert (x >= 0).all() and (x < L).all() and (v >= 0).all() and (a.time_counter == K).all()
+    crashed = (da[:-1] & 2).any(axis=0)
+    h = a.headway
+    assert (h[~crashed] > 0).all(), "vehicles of an uncrashed replica may not overlap along the loop"
+    assert da[-1].all() and crashed.mean() < 0.2
+    a.close(), b.close()
+    # (c) deterministic variant, sampled replicas against the oracle
+    pick = np.array([0, 1, 511, 1024, 2047, 2048, 4000, 4095])
+    det = dict(spec, vehicles=[dict(v_, noise=0.0) for v_ in veh])
+    c, oc, rc, dc = _rollout(det, K, acts)
+    sub = dict(det, num_replicas=len(pick), init_pos=np.asarray(det["init_pos"])[pick],
+               ring_length=np.asarray(det["ring_length"])[pick])
+    ora = S.RingOracle(sub, np.float32)
+    ora.reset()
+    for k in range(K):
+        o_ref, r_ref, d_ref = ora.step(acts[k, pick])
+        if k % 100 == 0 or k == K - 1:
+            np.testing.assert_array_equal(oc[k][pick], o_ref.astype(np.float32), err_msg="obs step %d" % k)
+            np.testing.assert_array_equal(rc[k][pick], r_ref.astype(np.float32), err_msg="rew step %d" % k)
+            np.testing.assert_array_equal(dc[k][pick] != 0, d_ref, err_msg="done step %d" % k)
+    np.testing.assert_array_equal(c.pos[pick], ora.x)
+    np.testing.assert_array_equal(c.vel[pick], ora.v)
+    c.close()
