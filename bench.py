@@ -369,8 +369,9 @@ def pmc_traffic(precision, R, K):
     path = os.path.join(ROOT, "profiles", "r02_pmc_summary_%s.json" % precision)
     try:
         tj = json.load(open(path))
-        if tj.get("replicas") == R and tj.get("steps_per_launch") == K and tj.get("kernel", "").startswith(
-                KERNEL_NAMES[precision].split("<")[0]):
+        # rocprofv3 prints the kernel as "void fs::k_...<...>(args)": the bench line's name is a substring of it
+        if tj.get("replicas") == R and tj.get("steps_per_launch") == K and KERNEL_NAMES[precision] in tj.get(
+                "kernel", ""):
             return tj.get("hbm_bytes_per_launch"), os.path.basename(path)
     except Exception:
         pass

@@ -488,15 +488,42 @@ __global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_step
   char* ob = reinterpret_cast<char*>(obs);
   unsigned crash_bits = 0u, bad_bits = 0u;
 
+  // Transposed observation store of the hand-written step (ROW = 16): the row image [v_0..v_{N-1} | x_0..x_{N-1}]
+  // of a replica (8 N bytes = N/2 pieces of 16 bytes) is assembled in LDS -- lane k writes its two speeds at byte
+  // 8 k and its two positions at byte 4 N + 8 k -- and read back so that lane k holds piece k: ONE
+  // buffer_store_dwordx4 per lane and step, 704 contiguous bytes per wave, instead of two dwordx2 with 88-byte
+  // runs.  The piece read at the end of step t is stored during step t + 1 (its ds_read has long landed: the only
+  // wait is an already satisfied lgkmcnt(0) in front of the store), the last one of a block after the block.
+  // Measured in one gpurun call (scripts/ubench/pair_bench.hip, 4096 x 22 x 1500): mixed 0.415 -> 0.393 ms, f32
+  // 0.366 -> 0.361 ms.  What the stores still cost against a launch that keeps its results (FS_DIAG_NOSTORE, 0.27
+  // ms) is by the counters (scripts/dbg/pmc_variants.sh) mostly NOT wave time: ~50 cycles per step of LDS /
+  // vector-memory issue for a wave alone on its SIMD, the rest a lower clock while 3 TB/s leave the chip (2.18 GHz
+  // without stores, 1.94-2.02 GHz with).  Handing the stores to a second wave per SIMD through an LDS ring (tried,
+  // removed) gained nothing: two ds_write_b64 per step cost the stepping wave what the stores did.
+  typedef unsigned u4v __attribute__((__vector_size__(16)));
+  constexpr bool XPOSE = ASM;
+  __shared__ float row_img[XPOSE ? 4 : 1][XPOSE ? RPW * 64 : 1];          // [wave of the block][row * 2 N floats], N <= 32
+  float* const my_img = row_img[XPOSE ? (threadIdx.x >> 6) & 3 : 0] + (XPOSE ? row * 2 * N : 0);
+  const unsigned off_16 = unsigned(rr) * rowb + unsigned(kk) * 16u;         // byte offset of piece kk of my replica's row
+  u4v piece = {0u, 0u, 0u, 0u};
+  auto transpose_in = [&](f2 ov, f2 ox) {
+    *reinterpret_cast<f2*>(my_img + 2 * kk) = ov;
+    *reinterpret_cast<f2*>(my_img + N + 2 * kk) = ox;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");               // same wave: LDS operations execute in order
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    piece = *reinterpret_cast<const u4v*>(my_img + 4 * kk);
+  };
+
   auto one_step = [&](int slot, __amdgpu_buffer_rsrc_t rs, float& sq_out) {
     if constexpr (ASM) {
       f2 ov, ox;
       const unsigned so = unsigned(slot) * step_b32;
       if constexpr (MIXED) {
         mixed_step_asm_a(v, xdA, xdB, vdA, vdB, h, dvl, ov, mc);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, ov), rs, off_v, so, 0);
+        if (slot > 0) __builtin_amdgcn_raw_buffer_store_b128(piece, rs, off_16, so - step_b32, 0);
         mixed_step_asm_b(v, xdA, xdB, h, dvl, ox, crash_bits, sq_out, mc);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, ox), rs, off_x, so, 0);
+        transpose_in(ov, ox);
       } else {
 #if defined(FS_DIAG_X4)       // timing experiment: ONE 16-byte store per lane and step (wrong layout)
         pair_step_asm_a(v, x, h, dvl, ox, pc);
@@ -509,11 +536,16 @@ __global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_step
         pair_step_asm_a(v, x, h, dvl, ox, pc);
         pair_step_asm_b(v, x, h, dvl, ov, crash_bits, sq_out, pc);
         asm volatile("" :: "v"(ov), "v"(ox), "s"(so));
-#else
+#elif defined(FS_DIAG_NOXPOSE)   // the two-dwordx2 form this replaced (timing comparisons)
         pair_step_asm_a(v, x, h, dvl, ox, pc);
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, ox), rs, off_x, so, 0);
         pair_step_asm_b(v, x, h, dvl, ov, crash_bits, sq_out, pc);
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, ov), rs, off_v, so, 0);
+#else
+        pair_step_asm_a(v, x, h, dvl, ox, pc);
+        if (slot > 0) __builtin_amdgcn_raw_buffer_store_b128(piece, rs, off_16, so - step_b32, 0);
+        pair_step_asm_b(v, x, h, dvl, ov, crash_bits, sq_out, pc);
+        transpose_in(ov, ox);
 #endif
       }
       return;
@@ -586,6 +618,9 @@ __global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_step
         ob, 0, remain > 0xFFFFFFFFull ? 0xFFFFFFFFu : unsigned(remain), 0x00020000);
 #pragma unroll
     for (int slot = 0; slot < PERIOD; ++slot) one_step(slot, rs, sq[slot]);
+#if !defined(FS_DIAG_X4) && !defined(FS_DIAG_NOSTORE) && !defined(FS_DIAG_NOXPOSE)
+    if (XPOSE) __builtin_amdgcn_raw_buffer_store_b128(piece, rs, off_16, unsigned(PERIOD - 1) * step_b32, 0);
+#endif
     ob += size_t(PERIOD) * step_bytes;
     tcount += PERIOD;
     const float racc = transposed_sum<ROW, PERIOD>(sq, lane);
@@ -612,6 +647,9 @@ __global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_step
     float sq1;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ob, 0, unsigned(step_bytes), 0x00020000);
     one_step(0, rs, sq1);
+#if !defined(FS_DIAG_X4) && !defined(FS_DIAG_NOSTORE) && !defined(FS_DIAG_NOXPOSE)
+    if (XPOSE) __builtin_amdgcn_raw_buffer_store_b128(piece, rs, off_16, 0u, 0);
+#endif
     ob += step_bytes;
     tcount += 1;
     const float racc = seg_sum<ROW>(sq1);

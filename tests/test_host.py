@@ -383,3 +383,16 @@ def test_package_alias_lets_reference_style_imports_resolve(monkeypatch):
     assert ns["AccelEnv"] is flow_amd.envs.AccelEnv and ns["Experiment"].__module__ == "flow_amd.core.experiment"
     for name in [m for m in list(sys.modules) if m == "flow" or m.startswith("flow.")]:
         monkeypatch.delitem(sys.modules, name, raising=False)
+
+
+def test_bench_roofline_traffic_comes_from_the_committed_pmc_summary():
+    """bench.py's `roofline.traffic` is the HBM byte count of the committed PMC summary of the SAME kernel
+    (profiles/r02_pmc_summary_<dtype>.json); a summary of another kernel, size or fragment length gives None."""
+    import bench
+    for prec in ("mixed", "f32"):
+        traffic, src = bench.pmc_traffic(prec, 4096, 1500)
+        nbytes, _ = bench.launch_bytes(4096, 22, 1500, prec)
+        assert src == "r02_pmc_summary_%s.json" % prec
+        assert 0.98 * nbytes < traffic < 1.10 * nbytes          # no wasted traffic: within 10 % of the algorithmic bytes
+    assert bench.pmc_traffic("mixed", 4096, 20) == (None, None)
+    assert bench.pmc_traffic("mixed", 1024, 1500) == (None, None)
