@@ -312,42 +312,46 @@ def cpu_baseline(spec_fn, seconds=12.0):
 def ring_defaults_leg(device, R=4096, K=1500):
     """The reference's own 22-IDM ring experiment AS SHIPPED (examples/exp_configs/non_rl/ring.py:13-61: the
     SumoCarFollowingParams default speed_mode 'right_of_way' = 25, whose bit 0 makes SUMO's safe-speed rule cap
-    every command) through VecFlowEnv: this configuration cannot take the specialised rollout kernels (they are
-    for speed_mode 'aggressive', which the headline states in `config`) and runs the generic k_steps kernel."""
+    every command) through VecFlowEnv, in float32 and in FS_MIXED: k_rollout_pair with the speed-mode clamps
+    compiled in (round 1 and the first half of round 2 ran it on the generic k_steps kernel, 2.5 G env-steps/s)."""
     import torch
     from flow_amd.controllers import ContinuousRouter, IDMController
     from flow_amd.core.params import EnvParams, InitialConfig, NetParams, SumoParams, VehicleParams
     from flow_amd.envs import AccelEnv, VecFlowEnv
     from flow_amd.networks import RingNetwork
     from flow_amd.networks.ring import ADDITIONAL_NET_PARAMS
-    veh = VehicleParams()
-    veh.add(veh_id="idm", acceleration_controller=(IDMController, {}), routing_controller=(ContinuousRouter, {}),
-            num_vehicles=22)
-    fp = dict(exp_tag="ring", env_name=AccelEnv, network=RingNetwork, simulator="traci",
-              sim=SumoParams(render=False, sim_step=0.1),
-              env=EnvParams(horizon=1500, additional_params={"max_accel": 3, "max_decel": 3, "target_velocity": 10,
-                                                             "sort_vehicles": False}),
-              net=NetParams(additional_params=dict(ADDITIONAL_NET_PARAMS)), veh=veh,
-              initial=InitialConfig(bunching=20))
-    vec = VecFlowEnv(fp, num_replicas=R, device=device.index)
-    out = (torch.empty((K, R, vec.obs_dim), dtype=torch.float32, device=device),
-           torch.empty((K, R), dtype=torch.float32, device=device),
-           torch.empty((K, R), dtype=torch.uint8, device=device))
-    vec.reset()
-    vec.rollout(K, None, out=out)
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    n = 0
-    for _ in range(2):
+    out = {"unit": "env-steps/s", "replicas": R,
+           "workload": "examples/exp_configs/non_rl/ring.py through VecFlowEnv: 22 IDM, speed_mode 'right_of_way' "
+                       "(the SumoCarFollowingParams default), %d-step rollout launches" % K}
+    for precision in ("mixed", "f32"):
+        veh = VehicleParams()
+        veh.add(veh_id="idm", acceleration_controller=(IDMController, {}), routing_controller=(ContinuousRouter, {}),
+                num_vehicles=22)
+        fp = dict(exp_tag="ring", env_name=AccelEnv, network=RingNetwork, simulator="traci",
+                  sim=SumoParams(render=False, sim_step=0.1, precision=precision),
+                  env=EnvParams(horizon=1500, additional_params={"max_accel": 3, "max_decel": 3, "target_velocity": 10,
+                                                                 "sort_vehicles": False}),
+                  net=NetParams(additional_params=dict(ADDITIONAL_NET_PARAMS)), veh=veh,
+                  initial=InitialConfig(bunching=20))
+        vec = VecFlowEnv(fp, num_replicas=R, device=device.index)
+        buf = (torch.empty((K, R, vec.obs_dim), dtype=torch.float32, device=device),
+               torch.empty((K, R), dtype=torch.float32, device=device),
+               torch.empty((K, R), dtype=torch.uint8, device=device))
         vec.reset()
-        vec.rollout(K, None, out=out)
-        n += K
-    torch.cuda.synchronize(device)
-    dt = time.perf_counter() - t0
-    vec.close()
-    return {"value": R * n / dt, "unit": "env-steps/s", "steps": n, "replicas": R,
-            "workload": "examples/exp_configs/non_rl/ring.py through VecFlowEnv: 22 IDM, speed_mode 'right_of_way' "
-                        "(the SumoCarFollowingParams default); generic kernel k_steps<float,32,0,1>"}
+        vec.rollout(K, None, out=buf)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        n = 0
+        for _ in range(3):
+            vec.reset()
+            vec.rollout(K, None, out=buf)
+            n += K
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        out[precision] = {"value": R * n / dt, "steps": n, "kernel": vec.sim.last_kernel}
+        vec.close()
+    out["value"] = out["mixed"]["value"]
+    return out
 
 
 KERNEL_NAMES = {"f32": "fs::k_rollout_pair<float, 16, true, true, false>",

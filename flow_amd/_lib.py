@@ -40,7 +40,7 @@ FS_EULER, FS_BALLISTIC = 0, 1
 
 EXPORTS = ["fs_create", "fs_destroy", "fs_last_error", "fs_abi_version", "fs_obs_dim", "fs_action_dim", "fs_set_stream",
            "fs_use_own_stream", "fs_sync", "fs_reset", "fs_reset_dev", "fs_step", "fs_step_dev", "fs_rollout_dev",
-           "fs_get_state", "fs_set_state", "fs_dump_trajectory"]
+           "fs_get_state", "fs_set_state", "fs_dump_trajectory", "fs_last_kernel"]
 
 
 class fs_vehicle_spec(C.Structure):
@@ -157,6 +157,8 @@ def load():
     lib.fs_set_state.restype = C.c_int
     lib.fs_dump_trajectory.argtypes = [h, C.c_int, C.c_char_p]
     lib.fs_dump_trajectory.restype = C.c_int
+    lib.fs_last_kernel.argtypes = [h]
+    lib.fs_last_kernel.restype = C.c_char_p
     if lib.fs_abi_version() != FS_ABI_VERSION:
         raise FatalFlowError("libflowsim.so ABI %d != binding ABI %d" % (lib.fs_abi_version(), FS_ABI_VERSION))
     _lib = lib

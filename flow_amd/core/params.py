@@ -181,7 +181,8 @@ class SumoParams(SimParams):
                     lanes (the simplified model M11, NOT LC2013)
     junction_length length of each internal edge (netconvert output in the reference)
     crash_gap       a replica crashes when a bumper gap falls below this after a move
-    precision       'f32' | 'f64' arithmetic and state type of the kernels
+    precision       'f32' | 'f64' arithmetic and state type of the kernels; 'mixed' (float64 state, float32
+                    controller: all-IDM single-lane rings, holds 1e-4 of the float64 trajectories at f32 cost)
     """
 
     def __init__(self, port=None, sim_step=0.1, emission_path=None, lateral_resolution=None, no_step_log=True,

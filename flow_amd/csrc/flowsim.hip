@@ -70,6 +70,7 @@ struct SimBase {
   bool no_pair = false;         // FLOWSIM_NO_PAIR=1: keep k_rollout_idm (one vehicle per lane) for the float rollout
   bool no_loop_kernel = false;  // FLOWSIM_NO_LOOP_KERNEL=1: keep the generic k_steps for segment-table loops (tests)
   int pair_block = 256;         // threads per block of k_rollout_pair (FLOWSIM_PAIR_BLOCK overrides)
+  const char* last_kernel = "";  // family of the step kernel the last launch_steps call chose (fs_last_kernel)
 
   virtual int launch_steps(int num_steps, const uint8_t* mask, const float* actions, size_t act_stride,
                            float* obs, float* rew, uint8_t* done, int obs_every_step) = 0;
@@ -179,6 +180,8 @@ struct Sim : SimBase {
       if (v.controller == FS_CTRL_SIM || v.controller == FS_CTRL_RL || (v.speed_mode & 1) || cfg.junction_mode)
         flags |= fs::FLAG_NEED_SUMO;
       if (v.speed_mode & 6) flags |= fs::FLAG_NEED_SUMO;
+      if (v.controller == FS_CTRL_SIM || v.controller == FS_CTRL_RL || cfg.junction_mode) sumo_beyond_speed_mode = true;
+      if (v.speed_mode & 7) speed_mode_any = true;
       if (v.controller != FS_CTRL_IDM) all_idm = false;
       if (v.controller != FS_CTRL_IDM && v.controller != FS_CTRL_RL && v.controller != FS_CTRL_SIM) idm_set = false;
     }
@@ -500,6 +503,11 @@ struct Sim : SimBase {
       add(float(veh[i].p[0]));
       add(2.0f * std::sqrt(float(veh[i].p[2]) * float(veh[i].p[3])));
       if (!(float(veh[i].p[5]) >= 1e-3f) || !(float(veh[i].p[5]) <= 1e6f)) return false;
+      if (speed_mode_any) {                     // sumo_acc_pair's divisors and its minGap >= 1e-3 premise
+        add(float(veh[i].sumo_max_speed));
+        add(2.0f * std::sqrt(float(veh[i].max_accel) * float(veh[i].max_decel)));
+        if (!(float(veh[i].sumo_min_gap) >= 1e-3f) || !(float(veh[i].sumo_min_gap) <= 1e6f)) return false;
+      }
     }
     for (T b : h_ring_len) {                    // host copy: no HIP call on the launch path
       const float L = float(b) + 4.0f * float(dv.jlen);
@@ -516,9 +524,13 @@ struct Sim : SimBase {
   // the specialisations for the headline configuration (see flowsim_kernels.h)
   bool delta4 = false;
   bool loop_div_ok = false, loop_delta4 = false;
-  bool fast_ok(const uint8_t* mask, int num_steps) const {
+  bool sumo_beyond_speed_mode = false;   // FLAG_NEED_SUMO for more than speed-mode bits (Sim / RL slots, junction mode)
+  bool speed_mode_any = false;           // some slot carries a speed-mode clamp (bits 0-2)
+  // allow_speed_mode: the caller's kernel evaluates the speed-mode clamps itself (k_rollout_pair<..., SM = true>)
+  bool fast_ok(const uint8_t* mask, int num_steps, bool allow_speed_mode = false) const {
     const int f = dv.flags;
-    return (f & fs::FLAG_ALL_IDM) && !(f & (fs::FLAG_HAS_NOISE | fs::FLAG_HAS_FAILSAFE | fs::FLAG_NEED_SUMO)) &&
+    const bool sumo_free = !(f & fs::FLAG_NEED_SUMO) || (allow_speed_mode && !sumo_beyond_speed_mode);
+    return (f & fs::FLAG_ALL_IDM) && !(f & (fs::FLAG_HAS_NOISE | fs::FLAG_HAS_FAILSAFE)) && sumo_free &&
            dv.env == FS_ENV_ACCEL && !dv.evaluate && dv.sims_per_step == 1 && dv.integrator == FS_EULER &&
            !dv.junction_mode && !dv.track_aux && mask == nullptr && num_steps > 0 && !force_generic &&
            dv.nseg == 0 && !dv.junction_on && !dv.sort_vehicles && dv.obs_perm == nullptr;
@@ -534,6 +546,7 @@ struct Sim : SimBase {
 #define FS_WIDE(P_, C_)                                                                                          \
   hipLaunchKernelGGL((fs::k_steps_wide<T, W, C_, P_>), dim3(dv.R), dim3(64 * W), 0, stream, dv, ov, num_steps, mask, \
                      actions, act_stride, obs, rew, done, obs_every_step, after_reset)
+    last_kernel = "k_steps_wide";
     if (cfg.num_paths == 8) { if (cset) FS_WIDE(8, C1); else FS_WIDE(8, 0); }
     else { if (cset) FS_WIDE(4, C1); else FS_WIDE(4, 0); }
 #undef FS_WIDE
@@ -552,6 +565,7 @@ struct Sim : SimBase {
 #define FS_OPEN(P_, C_)                                                                                          \
   hipLaunchKernelGGL((fs::k_steps_open<T, SEG, P_, C_>), dim3(blocks), dim3(64), 0, stream, dv, ov, num_steps, mask, \
                      actions, act_stride, obs, rew, done, obs_every_step, after_reset)
+      last_kernel = "k_steps_open";
       if (cfg.network == FS_NET_BOTTLENECK) {
         // the lane-drop heads need more than 32 slots (fs_create checks it): only the 64-lane segment is built
         if constexpr (SEG == 64) {
@@ -567,6 +581,7 @@ struct Sim : SimBase {
       return FS_OK;
     }
     if (dv.num_lanes > 1) {
+      last_kernel = "k_steps_ml";
       if (dv.lc_enabled)
         hipLaunchKernelGGL((fs::k_steps_ml<T, SEG, true>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, mask,
                            actions, act_stride, obs, rew, done, obs_every_step);
@@ -578,7 +593,7 @@ struct Sim : SimBase {
     }
     // two vehicles per lane (flowsim_pair.h): even N; the only stepping kernel of a FS_MIXED handle
     constexpr int ROW = SEG >= 16 ? SEG / 2 : 8;
-    const bool pair_ok = fast_ok(mask, num_steps) && (obs_every_step || num_steps == 1) && dv.N >= 2 &&
+    const bool pair_ok = fast_ok(mask, num_steps, true) && (obs_every_step || num_steps == 1) && dv.N >= 2 &&
                          (dv.N % 2) == 0 && actions == nullptr && !no_pair &&
                          size_t(dv.R) * 2 * dv.N * sizeof(float) * 16 < (size_t(1) << 32);   // 32-bit offsets in a block
     // closed loops with a segment table (figure eight): the rollout kernel of flowsim_fig8.h
@@ -591,6 +606,7 @@ struct Sim : SimBase {
           dv.N > 1 && loop_div_ok && !force_generic && !no_loop_kernel) {
         const int waves = (dv.R + 3) / 4;
         const dim3 grid((waves + 3) / 4), block(256);
+        last_kernel = "k_rollout_loop";
 #define FS_LOOP(H_, D_)                                                                                       \
   hipLaunchKernelGGL((fs::k_rollout_loop<H_, D_>), grid, block, 0, stream, dv, num_steps, actions, act_stride, obs, \
                      rew, done)
@@ -603,6 +619,7 @@ struct Sim : SimBase {
     }
     if (mixed && num_steps == 0) {                       // observation of the current state (Env.reset)
       const int n = dv.R * dv.N;
+      last_kernel = "k_obs_mixed";
       hipLaunchKernelGGL((fs::k_obs_mixed), dim3((n + 255) / 256), dim3(256), 0, stream, dv, obs);
       HIP_TRY(hipGetLastError());
       return FS_OK;
@@ -618,7 +635,16 @@ struct Sim : SimBase {
       const bool bc = neg_speed_possible;
 #define FS_PAIR(D4, FD, BC)                                                                                   \
   hipLaunchKernelGGL((fs::k_rollout_pair<T, ROW, D4, FD, BC>), grid, block, 0, stream, dv, num_steps, obs, rew, done)
-      if (delta4 && fd) { if (bc) FS_PAIR(true, true, true); else FS_PAIR(true, true, false); }
+      last_kernel = speed_mode_any ? "k_rollout_pair+speed_mode" : "k_rollout_pair";
+      if (speed_mode_any) {                   // the reference's default speed mode "right_of_way" lands here
+        if (delta4 && fd && !bc)
+          hipLaunchKernelGGL((fs::k_rollout_pair<T, ROW, true, true, false, true>), grid, block, 0, stream, dv,
+                             num_steps, obs, rew, done);
+        else                                  // any exponent, IEEE divisions, v < -100 check: always valid
+          hipLaunchKernelGGL((fs::k_rollout_pair<T, ROW, false, false, true, true>), grid, block, 0, stream, dv,
+                             num_steps, obs, rew, done);
+      }
+      else if (delta4 && fd) { if (bc) FS_PAIR(true, true, true); else FS_PAIR(true, true, false); }
       else if (delta4) { if (bc) FS_PAIR(true, false, true); else FS_PAIR(true, false, false); }
       else { if (bc) FS_PAIR(false, false, true); else FS_PAIR(false, false, false); }
 #undef FS_PAIR
@@ -629,6 +655,7 @@ struct Sim : SimBase {
       const int wpb = rollout_block / 64;                         // waves per block
       const dim3 grid((waves + wpb - 1) / wpb), block(rollout_block);
       const bool bc = neg_speed_possible;
+      last_kernel = "k_rollout_idm";
 #define FS_ROLLOUT(D4, FD, BC)                                                                               \
   hipLaunchKernelGGL((fs::k_rollout_idm<T, SEG, D4, FD, BC>), grid, block, 0, stream, dv, num_steps, obs, rew, \
                      done, d_dump)
@@ -636,15 +663,19 @@ struct Sim : SimBase {
       else if (delta4) { if (bc) FS_ROLLOUT(true, false, true); else FS_ROLLOUT(true, false, false); }
       else { if (bc) FS_ROLLOUT(false, false, true); else FS_ROLLOUT(false, false, false); }
 #undef FS_ROLLOUT
-    } else if (fast_ok(mask, num_steps))
+    } else if (fast_ok(mask, num_steps)) {
+      last_kernel = "k_steps<FAST>";
       hipLaunchKernelGGL((fs::k_steps<T, SEG, 1>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, mask, actions,
                          act_stride, obs, rew, done, obs_every_step);
-    else if ((dv.flags & fs::FLAG_IDM_SET) && !force_generic)
+    } else if ((dv.flags & fs::FLAG_IDM_SET) && !force_generic) {
+      last_kernel = "k_steps<CSET>";
       hipLaunchKernelGGL((fs::k_steps<T, SEG, 0, 1>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, mask, actions,
                          act_stride, obs, rew, done, obs_every_step);
-    else
+    } else {
+      last_kernel = "k_steps";
       hipLaunchKernelGGL((fs::k_steps<T, SEG, 0, 0>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, mask, actions,
                          act_stride, obs, rew, done, obs_every_step);
+    }
     HIP_TRY(hipGetLastError());
     return FS_OK;
   }
@@ -841,11 +872,11 @@ int validate(const fs_config* c) {
               c->num_vehicles <= 64 && (c->num_vehicles % 2) == 0 && c->vehicles;
     for (int i = 0; ok && i < c->num_vehicles; ++i) {
       const fs_vehicle_spec& v = c->vehicles[i];
-      ok = v.controller == FS_CTRL_IDM && !(v.noise > 0) && v.fail_safe == FS_FAILSAFE_NONE && v.speed_mode == 0;
+      ok = v.controller == FS_CTRL_IDM && !(v.noise > 0) && v.fail_safe == FS_FAILSAFE_NONE;
     }
     if (!ok)
       return fail(FS_ERR_UNSUPPORTED, "fs_create: FS_MIXED is built for the rollout path of single-lane rings with an "
-                                      "even number of plain IDM vehicles (speed mode 0, AccelEnv, no warm-up)");
+                                      "even number of plain IDM vehicles (any speed mode, AccelEnv, no warm-up)");
   }
   if (c->network < FS_NET_RING || c->network > FS_NET_BOTTLENECK)
     return fail(FS_ERR_UNSUPPORTED, "fs_create: network not built");
@@ -1267,6 +1298,8 @@ int fs_set_state(fs_handle h, int field, const void* src, size_t bytes) {
   DeviceGuard guard(S(h)->cfg.device);
   return S(h)->set_state(field, src, bytes);
 }
+
+const char* fs_last_kernel(fs_handle h) { return h ? reinterpret_cast<SimBase*>(h)->last_kernel : ""; }
 
 int fs_dump_trajectory(fs_handle h, int replica, const char* csv_path) {
   if (!h || !csv_path) return fail(FS_ERR_INVALID, "fs_dump_trajectory: NULL argument");

@@ -121,6 +121,33 @@ __device__ __forceinline__ f2 idm_pair(f2 v, f2 vl, f2 h, const f2* p, f2 two_sq
   return pk_mul(p[2], pk_sub(pk_sub(one, pw), pk_mul(q, q)));
 }
 
+// Speed-mode clamps (S7/S8: SumoCarFollowingParams.speed_mode bits 0-2, the reference's default "right_of_way" = 25
+// sets bit 0) for the two vehicles of a lane.  sumo_acc_pair = the acceleration inside sumo_idm_speed
+// (flowsim_kernels.h; oracle/controllers.py sumo_idm_speed), same operation order; v * (v - vl) is the product the
+// IDM controller forms too.  Divisions as in idm_pair: by the launch constants through div_const2 (host-verified per
+// constant), ss / gap through div_core2 (gap >= 1e-3, ss >= minGap >= 1e-3: host-checked).
+struct SumoPair {
+  f2 tau, min_gap, maxa, smax, rc_smax, ts, rc_ts;
+  f2 floor0;     // bit 0 set: 0 (v_sumo = max(0, v + acc dt)), clear: 3e38 (the cap never binds)
+  f2 adt, ddt;   // bit 1 / bit 2 set: max_accel dt / max_decel dt, clear: 3e38
+};
+template <bool FASTDIV>
+__device__ __forceinline__ f2 sumo_acc_pair(f2 v, f2 vl, f2 h, const SumoPair& c, f2 one) {
+  f2 gap;
+  gap.x = tmax(h.x, 1e-3f);
+  gap.y = tmax(h.y, 1e-3f);
+  const f2 num = pk_mul(v, pk_sub(v, vl));
+  const f2 dq = div_const2<FASTDIV>(num, c.ts, c.rc_ts);
+  const f2 dyn = pk_add(pk_mul(v, c.tau), dq);
+  f2 ss;
+  ss.x = tmax(0.0f, dyn.x);
+  ss.y = tmax(0.0f, dyn.y);
+  ss = pk_add(c.min_gap, ss);
+  const f2 q = FASTDIV ? div_core2(ss, gap, one) : f2{ss.x / gap.x, ss.y / gap.y};
+  const f2 r = div_const2<FASTDIV>(v, c.smax, c.rc_smax);
+  const f2 r2 = pk_mul(r, r);
+  return pk_mul(c.maxa, pk_sub(pk_sub(one, pk_mul(r2, r2)), pk_mul(q, q)));
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // One step of the float32 twin written out instruction by instruction (ROW = 16, delta = 4, exact reciprocal
@@ -383,11 +410,12 @@ __device__ __forceinline__ void mixed_step_asm_b(f2& V32, double& XA, double& XB
 }
 
 // T = float: the float32 bit-twin.  T = double: MIXED (see the header).  ROW = lanes per replica (N <= 2 ROW).
-template <typename T, int ROW, bool DELTA4, bool FASTDIV, bool BADCHK>
+// SM: some slot carries a speed-mode clamp (bits 0-2): the C++ step with sumo_acc_pair.
+template <typename T, int ROW, bool DELTA4, bool FASTDIV, bool BADCHK, bool SM = false>
 __global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_steps, float* __restrict__ obs,
                                                       float* __restrict__ rew, uint8_t* __restrict__ done) {
   constexpr bool MIXED = sizeof(T) == 8;
-  constexpr bool ASM = ROW == 16 && DELTA4 && FASTDIV && !BADCHK;     // pair_step_asm / mixed_step_asm
+  constexpr bool ASM = ROW == 16 && DELTA4 && FASTDIV && !BADCHK && !SM;     // pair_step_asm / mixed_step_asm
   constexpr int RPW = 64 / ROW;
   constexpr int PERIOD = ROW < 16 ? ROW : 16;       // steps whose reward tail is finished together
   const int lane = threadIdx.x & 63;
@@ -472,6 +500,29 @@ __global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_step
   mc.one = one; mc.gap2 = gap2; mc.vmask = vmask; mc.tvm = tvm; mc.c1e3 = 1e-3f; mc.dt = dt64; mc.ramp = ramp64;
   mc.L = L64; mc.rc_L = rc_L64; mc.rc_ms = rc_ms64; mc.len_b = double(lenB); mc.len_next = double(len_nextA);
   mc.zero = 0.0; mc.last_mask = pc.last_mask;
+  SumoPair sc{};
+  double floor0A = 0, floor0B = 0, adtA = 0, adtB = 0, ddtA = 0, ddtB = 0;      // MIXED: the clamp constants in float64
+  if constexpr (SM) {
+    const int mA = s.speed_mode[iA], mB = s.speed_mode[iB];
+    const float maA = float(s.max_accel[iA]), maB = float(s.max_accel[iB]);
+    const float mdA = float(s.max_decel[iA]), mdB = float(s.max_decel[iB]);
+    sc.tau = f2{float(s.sumo_tau[iA]), float(s.sumo_tau[iB])};
+    sc.min_gap = f2{float(s.sumo_min_gap[iA]), float(s.sumo_min_gap[iB])};
+    sc.maxa = f2{maA, maB};
+    sc.smax = f2{float(s.sumo_max_speed[iA]), float(s.sumo_max_speed[iB])};
+    sc.rc_smax = f2{1.0f / sc.smax.x, 1.0f / sc.smax.y};
+    sc.ts = f2{2.0f * tsqrt(maA * mdA), 2.0f * tsqrt(maB * mdB)};
+    sc.rc_ts = f2{1.0f / sc.ts.x, 1.0f / sc.ts.y};
+    const float BIG = 3.0e38f;
+    sc.floor0 = f2{(mA & 1) ? 0.0f : BIG, (mB & 1) ? 0.0f : BIG};
+    sc.adt = f2{(mA & 2) ? maA * dt : BIG, (mB & 2) ? maB * dt : BIG};
+    sc.ddt = f2{(mA & 4) ? mdA * dt : BIG, (mB & 4) ? mdB * dt : BIG};
+    floor0A = double(sc.floor0.x); floor0B = double(sc.floor0.y);
+    adtA = (mA & 2) ? double(s.max_accel[iA]) * dt64 : double(BIG);
+    adtB = (mB & 2) ? double(s.max_accel[iB]) * dt64 : double(BIG);
+    ddtA = (mA & 4) ? double(s.max_decel[iA]) * dt64 : double(BIG);
+    ddtB = (mB & 4) ? double(s.max_decel[iB]) * dt64 : double(BIG);
+  }
 
   // observation stores: buffer descriptor over the PERIOD-step block being written + per-lane byte offsets; the
   // scalar offset of an unrolled step is a launch constant (slot * bytes per step)
@@ -552,13 +603,22 @@ __global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_step
     }
     // IDMController.get_accel on the snapshot
     const f2 acc = idm_pair<DELTA4, FASTDIV>(v, vl, h, p, two_sqrt_ab, rc_ab, rc_v0, one);
+    f2 acc_s = {0.0f, 0.0f};
+    if constexpr (SM) acc_s = sumo_acc_pair<FASTDIV>(v, vl, h, sc, one);
     f2 ox;
     if (MIXED) {
       // apply_acceleration + integration (S4-S9) in float64 on the float32 acceleration
       const double aA = double(acc.x), aB = double(acc.y);
       const double nA = tmax(vdA + aA * dt64, 0.0), nB = tmax(vdB + aB * dt64, 0.0);
-      vdA = vdA + (nA - vdA) * ramp64;
-      vdB = vdB + (nB - vdB) * ramp64;
+      double cA = vdA + (nA - vdA) * ramp64, cB = vdB + (nB - vdB) * ramp64;
+      if constexpr (SM) {        // S7/S8 in float64 on SUMO's float32 acceleration (floor0 = 3e38 switches the cap off)
+        const double sA = tmax(vdA + double(acc_s.x) * dt64, floor0A), sB = tmax(vdB + double(acc_s.y) * dt64, floor0B);
+        cA = tmin(cA, sA); cB = tmin(cB, sB);
+        cA = tmin(cA, vdA + adtA); cB = tmin(cB, vdB + adtB);
+        cA = tmax(cA, vdA - ddtA); cB = tmax(cB, vdB - ddtB);
+      }
+      vdA = cA;
+      vdB = cB;
       const double xA = xdA + vdA * dt64, xB = xdB + vdB * dt64;
       xdA = xA >= L64 ? xA - L64 : xA;
       xdB = xB >= L64 ? xB - L64 : xB;
@@ -568,7 +628,16 @@ __global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_step
       f2 nv = pk_add(v, pk_mul(acc, dt2));
       nv.x = tmax(nv.x, 0.0f);
       nv.y = tmax(nv.y, 0.0f);
-      v = pk_add(v, pk_mul(pk_sub(nv, v), ramp2));
+      f2 vc = pk_add(v, pk_mul(pk_sub(nv, v), ramp2));
+      if constexpr (SM) {        // S7/S8: min(vc, v_sumo), min(vc, v + max_accel dt), max(vc, v - max_decel dt)
+        const f2 vs = pk_add(v, pk_mul(acc_s, dt2));
+        const f2 cap1 = pk_add(v, sc.adt), flo = pk_sub(v, sc.ddt);
+        vc.x = tmin(vc.x, tmax(sc.floor0.x, vs.x));
+        vc.y = tmin(vc.y, tmax(sc.floor0.y, vs.y));
+        vc.x = tmax(tmin(vc.x, cap1.x), flo.x);
+        vc.y = tmax(tmin(vc.y, cap1.y), flo.y);
+      }
+      v = vc;
       const f2 xn = pk_add(x, pk_mul(v, dt2));
       const f2 xw = pk_sub(xn, L2);                  // x_new >= L ? x_new - L : x_new  (0 <= x_new - L < x_new)
       x.x = nonneg_else(xw.x, xn.x);

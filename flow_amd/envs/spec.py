@@ -274,7 +274,7 @@ def build_open_spec(env, num_replicas, rng=None):
         # MultiEnv.clip_actions returns the dict unclipped in this fork (multiagent/base.py:366-391)
         clip_actions=bool(ep.clip_actions) and env.FS_ENV != L.FS_ENV_MERGE_MA, evaluate=bool(ep.evaluate),
         horizon=ep.horizon, warmup_steps=int(ep.warmup_steps), sims_per_step=int(ep.sims_per_step),
-        seed=handle_seed(sp), replica_offset=int(getattr(env, "_replica_offset", 0)), track_aux=True,
+        seed=handle_seed(sp), replica_offset=int(getattr(env, "_replica_offset", 0)), track_aux=bool(getattr(env, "_track_aux", True)),
         ma_apply_actions=not bool(getattr(env, "APPLY_ENUMERATE_QUIRK", True)),
         slot_types=names, slot_base=base, slot_caps=dict(zip(names, caps)), init_slot=init_slot, **tables)
     spec.update(extra)
@@ -348,7 +348,7 @@ def build_spec(env, num_replicas, rng=None):
         action_high=float(space.high[0]) if N and veh_k.num_rl_vehicles else 0.0,
         clip_actions=bool(ep.clip_actions), evaluate=bool(ep.evaluate),
         po_max_length=float(env._po_max_length()), horizon=ep.horizon, warmup_steps=int(ep.warmup_steps),
-        sims_per_step=int(ep.sims_per_step), seed=handle_seed(sp), track_aux=True,
+        sims_per_step=int(ep.sims_per_step), seed=handle_seed(sp), track_aux=bool(getattr(env, "_track_aux", True)),
         replica_offset=int(getattr(env, "_replica_offset", 0)),
         num_lanes=num_lanes, init_lane=lanes,
         lane_change_duration=float(ep.additional_params.get("lane_change_duration", 0)),

@@ -15,10 +15,12 @@ class VecFlowEnv(object):
     """Parameters: either ``flow_params`` (the reference's dict: env_name, network, env, sim, net,
     veh, initial; flow/utils/registry.py:29-46) or the four objects ``env_class, env_params,
     sim_params, network``.  ``device`` is the HIP ordinal of this process' GPU; ``replica_offset`` the global index
-    of this process' first replica when a job is sharded over GPUs (noise streams follow global replica ids)."""
+    of this process' first replica when a job is sharded over GPUs (noise streams follow global replica ids).
+    ``track_aux=True`` keeps ``k.vehicle.get_previous_speed`` / ``get_accel`` of the wrapped env current (fields the
+    specialised rollout kernels do not write: such a handle steps on the generic kernels)."""
 
     def __init__(self, flow_params=None, num_replicas=4096, device=0, env_class=None, env_params=None,
-                 sim_params=None, network=None, seed=None, replica_offset=0):
+                 sim_params=None, network=None, seed=None, replica_offset=0, track_aux=False):
         import torch
         self.torch = torch
         if flow_params is not None:
@@ -38,6 +40,9 @@ class VecFlowEnv(object):
         env.num_replicas = self.num_envs
         env._device_index = int(device)
         env._replica_offset = int(replica_offset)     # global index of replica 0 (flow_amd.dist.shard_range)
+        # per-vehicle previous speed / realised acceleration (k.vehicle.get_previous_speed / get_accel) are scalar-Env
+        # accessors; keeping them costs the specialised rollout kernels (they do not write those fields)
+        env._track_aux = bool(track_aux)
         env.__init__(env_params, sim_params, network)
         if env.FS_ENV is None or getattr(env, "HOST_HEADS", False):
             env.terminate()

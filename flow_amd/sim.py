@@ -276,6 +276,11 @@ class FlowSim:
         a = np.ascontiguousarray(np.broadcast_to(np.asarray(value, dtype=dt), shape))
         L.check(self.lib.fs_set_state(self._h, int(field), _ptr(a), a.nbytes))
 
+    @property
+    def last_kernel(self):
+        """Family of the step kernel the last step / rollout launch chose (fs_last_kernel)."""
+        return self.lib.fs_last_kernel(self._h).decode()
+
     def dump_trajectory(self, replica, csv_path):
         """Append the current state of ``replica`` to ``csv_path`` (fs_dump_trajectory)."""
         L.check(self.lib.fs_dump_trajectory(self._h, int(replica), str(csv_path).encode()))

@@ -97,9 +97,15 @@ class CRingIDMMixed:
         self.R, self.N = int(spec["num_replicas"]), int(spec["num_vehicles"])
         for v in spec["vehicles"]:
             assert v["controller"] == 2 and v.get("fail_safe", 0) == 0 and v.get("noise", 0) == 0
-            assert v.get("speed_mode", 0) == 0
         assert spec.get("env", 0) == 0 and not spec.get("junction_mode", 0)
         assert spec.get("sims_per_step", 1) == 1 and spec.get("integrator", "euler") == "euler"
+        # speed-mode clamps (bits 0-2; higher bits do nothing on a ring): per-slot SUMO car-following parameters
+        self.sm = None
+        if any(int(v.get("speed_mode", 0)) & 7 for v in spec["vehicles"]):
+            self.sm = np.ascontiguousarray(np.array(
+                [[float(int(v.get("speed_mode", 0)) & 7), v.get("sumo_tau", 1.0), v.get("sumo_min_gap", 2.5),
+                  v.get("sumo_max_speed", 30.0), v.get("max_accel", 2.6), v.get("max_decel", 4.5)]
+                 for v in spec["vehicles"]], np.float64).T)                                            # [6,N]
         self.p = np.ascontiguousarray(np.array([list(v["p"][:6]) for v in spec["vehicles"]], np.float64).T)  # [6,N]
         self.veh_len = np.ascontiguousarray(np.array([v.get("length", 5.0) for v in spec["vehicles"]], np.float64))
         self.dt = float(spec["sim_step"])
@@ -133,11 +139,12 @@ class CRingIDMMixed:
         d = C.c_double
         fn.restype = None
         fn.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, d, d, d, C.c_void_p, C.c_void_p, d, d, d, d, C.c_int,
-                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                       C.c_void_p]
         fn(self.R, self.N, int(steps), self.ring_len.ctypes.data, self.jlen, self.dt, self.ramp, self.p.ctypes.data,
            self.veh_len.ctypes.data, self.max_speed, self.target_v, self.max_cost, self.crash_gap, self.step_limit,
            self.x.ctypes.data, self.v.ctypes.data, self.tc.ctypes.data, obs.ctypes.data, rew.ctypes.data,
-           done.ctypes.data, int(obs_every_step), self.threads)
+           done.ctypes.data, int(obs_every_step), self.threads, None if self.sm is None else self.sm.ctypes.data)
         return obs, rew, done.astype(bool)
 
 

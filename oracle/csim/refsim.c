@@ -37,7 +37,9 @@ void refsim_ring_idm_mixed(int R, int r0, int r1, int N, int steps, const double
                            double ramp, const double* p /* [6][N]: v0,T,a,b,delta,s0 per slot */,
                            const double* veh_len /* [N] */, double max_speed, double target_v, double max_cost,
                            double crash_gap, int step_limit, double* x, double* v, int32_t* time_counter,
-                           float* obs, float* rew, uint8_t* done, int obs_every_step) {
+                           float* obs, float* rew, uint8_t* done, int obs_every_step,
+                           const double* sm /* NULL, or [6][N]: speed_mode bits, sumo tau, minGap, maxSpeed,
+                                               max_accel, max_decel per slot (S7/S8 speed-mode clamps) */) {
   double xn[64], vn[64];
   float hh[64], dd[64];
   const double rc_ms = 1.0 / max_speed;
@@ -77,7 +79,30 @@ void refsim_ring_idm_mixed(int R, int r0, int r1, int N, int steps, const double
         const float acc = a * (1.0f - pw - q * q);
         double nv = vr[i] + (double)acc * dt;
         if (!(nv > 0)) nv = 0;
-        const double v_new = vr[i] + (nv - vr[i]) * ramp;
+        double v_new = vr[i] + (nv - vr[i]) * ramp;
+        if (sm) {
+          /* speed-mode clamps: the acceleration of sumo_idm_speed (oracle/controllers.py) in float32 on the rounded
+           * images, applied in float64: bit 0 min(vc, max(0, v + acc_s dt)), bit 1 min(vc, v + max_accel dt),
+           * bit 2 max(vc, v - max_decel dt) */
+          const int mode = (int)sm[0 * N + i];
+          const float tau = (float)sm[1 * N + i], min_gap = (float)sm[2 * N + i], smax = (float)sm[3 * N + i],
+                      ma = (float)sm[4 * N + i], md = (float)sm[5 * N + i];
+          const float gap = hh[i] > 1e-3f ? hh[i] : 1e-3f;
+          const float ts = 2.0f * sqrtf(ma * md);
+          const float dyn_s = vi * tau + vi * (vi - vl) / ts;
+          const float ss = min_gap + (0.0f > dyn_s ? 0.0f : dyn_s);
+          const float qs = ss / gap;
+          const float rs = vi / smax;
+          const float rs2 = rs * rs;
+          const float acc_s = ma * (1.0f - rs2 * rs2 - qs * qs);
+          if (mode & 1) {
+            double vs = vr[i] + (double)acc_s * dt;
+            if (!(vs > 0)) vs = 0;
+            if (!(v_new < vs)) v_new = vs;
+          }
+          if (mode & 2) { const double cap = vr[i] + sm[4 * N + i] * dt; if (!(v_new < cap)) v_new = cap; }
+          if (mode & 4) { const double flo = vr[i] - sm[5 * N + i] * dt; if (!(v_new > flo)) v_new = flo; }
+        }
         double x_new = xr[i] + v_new * dt;
         if (x_new >= L) x_new = x_new - L;
         xn[i] = x_new;
@@ -120,17 +145,18 @@ void refsim_ring_idm_mixed(int R, int r0, int r1, int N, int steps, const double
 void refsim_ring_idm_mixed_all(int R, int N, int steps, const double* ring_len, double jlen, double dt, double ramp,
                                const double* p, const double* veh_len, double max_speed, double target_v,
                                double max_cost, double crash_gap, int step_limit, double* x, double* v, int32_t* tc,
-                               float* obs, float* rew, uint8_t* done, int obs_every_step, int threads) {
+                               float* obs, float* rew, uint8_t* done, int obs_every_step, int threads,
+                               const double* sm) {
   if (threads <= 1) {
     refsim_ring_idm_mixed(R, 0, R, N, steps, ring_len, jlen, dt, ramp, p, veh_len, max_speed, target_v, max_cost,
-                          crash_gap, step_limit, x, v, tc, obs, rew, done, obs_every_step);
+                          crash_gap, step_limit, x, v, tc, obs, rew, done, obs_every_step, sm);
     return;
   }
 #pragma omp parallel for num_threads(threads) schedule(static)
   for (int t = 0; t < threads; ++t) {
     int r0 = (int)((long long)R * t / threads), r1 = (int)((long long)R * (t + 1) / threads);
     refsim_ring_idm_mixed(R, r0, r1, N, steps, ring_len, jlen, dt, ramp, p, veh_len, max_speed, target_v, max_cost,
-                          crash_gap, step_limit, x, v, tc, obs, rew, done, obs_every_step);
+                          crash_gap, step_limit, x, v, tc, obs, rew, done, obs_every_step, sm);
   }
 }
 

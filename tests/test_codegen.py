@@ -61,4 +61,5 @@ def test_float32_step_kernels_use_no_agprs(device_asm):
     assert set(spilling) <= {"k_steps", "k_steps_open", "k_steps_wide"}, spilling
     # the two-vehicles-per-lane kernels pin v112..v145 by hand: they must stay well inside the VGPR file
     pair = [r for n, r in table.items() if "k_rollout_pair" in n]
-    assert pair and max(r["num_vgpr"] for r in pair) <= 160 and all(r.get("num_agpr", 0) == 0 for r in pair)
+    # (the FS_MIXED instantiation with speed-mode clamps is the largest: float64 state + two controllers' constants)
+    assert pair and max(r["num_vgpr"] for r in pair) <= 192 and all(r.get("num_agpr", 0) == 0 for r in pair)

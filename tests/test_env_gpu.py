@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 def ring_flow_params(n=22, length=230, horizon=1500, precision="f32", bunching=20, env_name=None, add_env=None,
-                     rl=0, warmup=0, **sim_kw):
+                     rl=0, warmup=0, speed_mode="aggressive", **sim_kw):
     from flow_amd.controllers import ContinuousRouter, IDMController, RLController
     from flow_amd.core.params import (EnvParams, InitialConfig, NetParams, SumoCarFollowingParams, SumoParams,
                                       VehicleParams)
@@ -24,7 +24,7 @@ def ring_flow_params(n=22, length=230, horizon=1500, precision="f32", bunching=2
     vehicles = VehicleParams()
     vehicles.add(veh_id="idm", acceleration_controller=(IDMController, {}),
                  routing_controller=(ContinuousRouter, {}),
-                 car_following_params=SumoCarFollowingParams(speed_mode="aggressive"), num_vehicles=n - rl)
+                 car_following_params=SumoCarFollowingParams(speed_mode=speed_mode), num_vehicles=n - rl)
     if rl:
         vehicles.add(veh_id="rl", acceleration_controller=(RLController, {}),
                      routing_controller=(ContinuousRouter, {}),
@@ -185,6 +185,42 @@ def test_vec_env_step_rollout_and_reset_done():
     view = vec.vehicle_view(3)
     assert len(view.get_speed(view.get_ids())) == 22
     vec.close()
+
+
+def test_vec_env_reaches_the_rollout_kernels_for_the_reference_ring_experiment():
+    """The headline kernels must be reachable through the drop-in API, not only through the C ABI: the reference's
+    ring experiment (examples/exp_configs/non_rl/ring.py:13-61) with the speed mode it ships ("right_of_way", the
+    SumoCarFollowingParams default) and with "aggressive", in float32 and FS_MIXED, lands on k_rollout_pair; the same
+    env with track_aux=True (scalar-Env accessors kept current) steps on the generic kernel -- bit-identically."""
+    from flow_amd.envs import VecFlowEnv
+    R, K = 40, 120
+    for mode, want in (("right_of_way", "k_rollout_pair+speed_mode"), ("aggressive", "k_rollout_pair")):
+        outs = {}
+        for precision in ("f32", "mixed"):
+            fp = ring_flow_params(n=22, horizon=100, precision=precision, speed_mode=mode)
+            fp["initial"].perturbation = 0.3
+            np.random.seed(4)
+            vec = VecFlowEnv(fp, num_replicas=R)
+            vec.reset()
+            o, r, d = vec.rollout(K)
+            assert vec.sim.last_kernel == want, (mode, precision, vec.sim.last_kernel)
+            outs[precision] = (o.cpu().numpy(), r.cpu().numpy(), d.cpu().numpy(), vec.positions.copy())
+            assert bool(d[99].all()) and not bool(d[98].any())
+            vec.close()
+        fp = ring_flow_params(n=22, horizon=100, speed_mode=mode)
+        fp["initial"].perturbation = 0.3
+        np.random.seed(4)
+        gen = VecFlowEnv(fp, num_replicas=R, track_aux=True)
+        gen.reset()
+        o, r, d = gen.rollout(K)
+        assert gen.sim.last_kernel.startswith("k_steps")
+        np.testing.assert_array_equal(outs["f32"][0], o.cpu().numpy())
+        np.testing.assert_array_equal(outs["f32"][1], r.cpu().numpy())
+        np.testing.assert_array_equal(outs["f32"][3], gen.positions)
+        assert len(gen.env.k.vehicle.get_previous_speed(gen.env.k.vehicle.get_ids())) == 22
+        gen.close()
+        # FS_MIXED stays within float32 rounding of the float32 run over 120 steps, and is not the same numbers
+        assert np.abs(outs["mixed"][0] - outs["f32"][0]).max() < 1e-4
 
 
 def test_custom_python_env_hooks_still_work():

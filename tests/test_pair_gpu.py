@@ -230,6 +230,98 @@ def test_c1_mixed_within_1e4_of_reference_arithmetic_1500_steps():
     sim.close()
 
 
+# ------------------------------------------------------------------- speed-mode clamps in the pair kernel
+# (the reference's ring experiment as shipped runs SumoCarFollowingParams' default "right_of_way" = 25: bit 0)
+def speed_mode_vehicles(rng, N, modes):
+    veh = []
+    for i in range(N):
+        veh.append(idm_vehicle(speed_mode=int(modes[i % len(modes)]),
+                               max_accel=float(rng.choice([1.0, 2.6, 3.0])), max_decel=float(rng.choice([1.5, 4.5, 7.5])),
+                               sumo_tau=float(rng.choice([0.5, 1.0, 1.3])), sumo_min_gap=float(rng.choice([0.5, 2.5])),
+                               sumo_max_speed=float(rng.choice([8.0, 30.0]))))
+    return veh
+
+
+@pytest.mark.parametrize("N,modes", [(22, [25]), (22, [0, 1, 7, 25, 31, 2, 4, 6]), (8, [1]), (34, [31, 0]), (64, [25, 6])])
+def test_pair_speed_modes_f32_bit_exact_vs_numpy_oracle_and_generic_kernel(N, modes):
+    rng = np.random.default_rng(N + len(modes))
+    R, K = (7, 90) if N <= 32 else (5, 60)
+    L = max(230.0, 9.0 * N)
+    spec = perturbed(ring_spec(R=R, N=N, length=L, bunching=0, junction_length=0.1, horizon=70,
+                               vehicles=speed_mode_vehicles(rng, N, modes)), seed=N, sigma=0.3)
+    spec["init_vel"] = rng.uniform(0, 9, (R, N))
+    sim, obs, rew, done = gpu_rollout(spec, "f32", K)
+    assert sim.last_kernel == "k_rollout_pair+speed_mode"
+    gen, og, rg, dg = gpu_rollout(spec, "f32", K, env={"FLOWSIM_FORCE_GENERIC": "1"})
+    assert gen.last_kernel.startswith("k_steps")
+    ora = S.RingOracle(spec, np.float32)
+    ora.reset()
+    capped = False
+    for k in range(K):
+        v_before = ora.v.copy()
+        o, r, d = ora.step(None)
+        np.testing.assert_array_equal(obs[k].cpu().numpy(), o.astype(np.float32), err_msg="obs step %d" % k)
+        np.testing.assert_array_equal(rew[k].cpu().numpy(), r.astype(np.float32), err_msg="rew step %d" % k)
+        np.testing.assert_array_equal(done[k].cpu().numpy().astype(bool), d, err_msg="done step %d" % k)
+        capped = capped or bool((ora.v < v_before - 0.3).any())
+    assert (obs == og).all() and (rew == rg).all() and (done == dg).all()
+    np.testing.assert_array_equal(sim.pos, ora.x)
+    np.testing.assert_array_equal(sim.vel, ora.v)
+    np.testing.assert_array_equal(sim.pos, gen.pos)
+    sim.close(), gen.close()
+
+
+def test_speed_mode_changes_the_trajectory_and_is_not_the_aggressive_kernel():
+    # the same ring with and without bit 0: the clamp must bind somewhere (otherwise the tests above prove nothing)
+    base = perturbed(ring_spec(R=6, N=22, length=150.0, bunching=0, junction_length=0.1, horizon=400), seed=9, sigma=0.4)
+    base["init_vel"] = np.random.default_rng(1).uniform(0, 14, (6, 22))
+    clamp = dict(base, vehicles=[idm_vehicle(speed_mode=25) for _ in range(22)])
+    a, oa, _, _ = gpu_rollout(base, "f32", 300)
+    b, ob, _, _ = gpu_rollout(clamp, "f32", 300)
+    assert a.last_kernel == "k_rollout_pair" and b.last_kernel == "k_rollout_pair+speed_mode"
+    assert float((oa - ob).abs().max()) > 1e-3
+    a.close(), b.close()
+
+
+@pytest.mark.parametrize("N,modes", [(22, [25]), (22, [0, 1, 7, 25, 31, 2, 4, 6]), (40, [1, 6])])
+def test_mixed_speed_modes_bit_exact_vs_its_c_twin(N, modes):
+    rng = np.random.default_rng(3 * N + len(modes))
+    R, K = 9, 120
+    spec = perturbed(ring_spec(R=R, N=N, length=max(230.0, 9.0 * N), bunching=0, junction_length=0.1, horizon=100,
+                               vehicles=speed_mode_vehicles(rng, N, modes)), seed=N, sigma=0.3)
+    spec["init_vel"] = rng.uniform(0, 9, (R, N))
+    sim, obs, rew, done = gpu_rollout(spec, "mixed", K)
+    assert sim.last_kernel == "k_rollout_pair+speed_mode"
+    twin = cbuild.CRingIDMMixed(spec)
+    o, r, d = twin.rollout(K, obs_every_step=True)
+    np.testing.assert_array_equal(obs.cpu().numpy(), o)
+    np.testing.assert_array_equal(rew.cpu().numpy(), r)
+    np.testing.assert_array_equal(done.cpu().numpy().astype(bool), d)
+    np.testing.assert_array_equal(sim.pos, twin.x)
+    np.testing.assert_array_equal(sim.vel, twin.v)
+    sim.close()
+
+
+def test_reference_ring_default_speed_mode_mixed_within_1e4_of_float64_1500_steps():
+    # examples/exp_configs/non_rl/ring.py as shipped: 22 IDM, speed_mode "right_of_way" (= 25); float64 numpy oracle =
+    # the reference's arithmetic (the C oracle covers speed_mode 0 only)
+    R, K = 24, 1500
+    spec = perturbed(ring_spec(R=R, N=22, junction_length=0.1, horizon=1500,
+                               vehicles=[idm_vehicle(speed_mode=25) for _ in range(22)]), seed=12)
+    sim, obs, rew, done = gpu_rollout(spec, "mixed", K)
+    assert sim.last_kernel == "k_rollout_pair+speed_mode"
+    ref = S.RingOracle(spec, np.float64)
+    ref.reset()
+    for _ in range(K):
+        o, r, d = ref.step(None)
+    dx = ring_distance(sim.pos, ref.x, 230.4).max()
+    dv = np.abs(sim.vel - ref.v).max()
+    assert dx < 1e-4 and dv < 1e-4, (dx, dv)
+    assert np.abs(obs[K - 1].cpu().numpy() - o).max() < 1e-6
+    assert ref.v.max() > 1.0
+    sim.close()
+
+
 # ------------------------------------------------------------------- the launch bench.py times (C2, full size)
 SAMPLED = [0, 1, 15, 16, 17, 31, 100, 500, 777, 1000, 1234, 1498, 1499]
 
