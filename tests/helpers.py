@@ -232,3 +232,40 @@ def bottleneck_spec(R=4, cap_human=40, cap_rl=8, horizon=300, seed=0, q=2300.0, 
                 **{k: v for k, v in tb.items() if k not in ("edge_start", "edge_lanes", "edge_length")})
     spec.update(kw)
     return spec
+
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def fig8_fixture_case():
+    """tests/golden/fig8_emission.csv (the reference's tests/fast_tests/test_files/fig8_emission.csv, a SUMO
+    emission file its visualizer tests read): 14 IDM vehicles on the one-lane figure eight, sim_step 1 s, four
+    timestamps.  Returns (spec starting from the fixture's first timestamp, {time: {slot: (loop x, speed)}}, ids in
+    slot order).  The experiment of that file is examples/exp_configs/non_rl/figure_eight.py:15-27 (IDMController
+    defaults, speed_mode obey_safe_speed, decel 1.5) of a Flow version that still commanded vehicles on
+    junction-internal edges (junction_mode 0: idm_8 gains 0.99 m/s inside ':center_0' at t = 4, Flow's IDM, not SUMO's
+    2.6 m/s^2)."""
+    import csv
+    segs, junction, total, starts, _ = figure_eight_tables(30.0, 1, 0.1, 9.4)
+    data = {}
+    with open(os.path.join(GOLDEN_DIR, "fig8_emission.csv")) as f:
+        for r in csv.DictReader(f):
+            data.setdefault(int(r["id"].split("_")[1]), {})[float(r["time"])] = (
+                starts[r["edge_id"]] + float(r["relative_position"]), float(r["speed"]))
+    N = 14
+    x0 = np.array([data[i][1.0][0] for i in range(N)])
+    assert (np.diff(x0) > 0).all()                       # ids are in driving order already
+    veh = [idm_vehicle(speed_mode=1, max_decel=1.5) for _ in range(N)]
+    spec = dict(num_replicas=1, num_vehicles=N, num_rl=0, sim_step=1.0, junction_length=0.1,
+                ring_length=np.full(1, total - 0.4), max_speed=30.0, env=S.ENV_ACCEL, target_velocity=20.0,
+                action_low=-3.0, action_high=3.0, horizon=100, warmup_steps=0, sims_per_step=1, vehicles=veh,
+                init_pos=x0[None, :], junction_mode=0, segments=segs, junction=junction)
+    expected = {t: {i: data[i][t] for i in range(N)} for t in (2.0, 3.0, 4.0)}
+    return spec, expected
+
+
+# what the crossing model S-J (DESIGN.md section 2) does NOT reproduce of that file: idm_8 starts 0.56 m before the
+# crossing on the minor stream while idm_1's tail still covers the crossing point; SUMO lets it creep in behind the
+# leaving vehicle (0.84 / 1.76 / 2.75 m/s), S-J holds it until the tail has left the box; idm_7 behind it feels that
+# from the third step on
+FIG8_FIXTURE_DEVIATIONS = {(8, 2.0), (8, 3.0), (8, 4.0), (7, 4.0)}

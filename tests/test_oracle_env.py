@@ -160,6 +160,57 @@ def test_emission_fixture_positions_euler():
     assert worst <= 0.0051 + 1e-9    # 2-decimal rounding of the fixture
 
 
+# ----------------------------------------------------------------- the SUMO figure-eight fixture (dt = 1 s)
+def test_fig8_emission_fixture_positions_and_speeds():
+    """13 of the 14 SUMO trajectories of tests/golden/fig8_emission.csv (positions incl. the edge changes top ->
+    upper_ring across the 0.1 m internal edge, speeds) to the fixture's two decimals over three 1-second steps: S4-S9
+    (Euler update with the new speed, slowDown ramp, safe-speed cap not binding) and the netconvert lengths hold at
+    a sim_step ten times the ring fixture's.  The 14th (idm_8, entering the crossing behind a leaving vehicle) is
+    the recorded deviation of the crossing model."""
+    from helpers import FIG8_FIXTURE_DEVIATIONS, fig8_fixture_case
+    spec, expected = fig8_fixture_case()
+    sim = S.RingOracle(spec, np.float64)
+    sim.reset()
+    checked, worst_x, worst_v = 0, 0.0, 0.0
+    for t in (2.0, 3.0, 4.0):
+        sim.step(None)
+        for i, (x, v) in expected[t].items():
+            if (i, t) in FIG8_FIXTURE_DEVIATIONS:
+                continue
+            worst_x = max(worst_x, abs(float(sim.x[0, i]) - x))
+            worst_v = max(worst_v, abs(float(sim.v[0, i]) - v))
+            checked += 1
+    assert checked == 38
+    assert worst_v <= 0.0075 and worst_x <= 0.0105, (worst_x, worst_v)      # two decimals per column (x = edge start + position)
+    # the recorded deviation, so that a change of the crossing model shows up here
+    assert float(sim.v[0, 8]) == 0.0 and abs(expected[4.0][8][1] - 2.75) < 1e-9
+
+
+def test_merge_emission_fixture_uncommanded_vehicles_accelerate_at_the_sumo_models_rate():
+    """tests/golden/merge_emission.csv (reference fixture, SUMO output, sim_step 0.2): five SimCarFollowingController
+    vehicles starting at rest gain accel * dt = 0.2 m/s per step (SumoCarFollowingParams(accel=1.0) of merge.json),
+    minus a random shortfall of at most 0.07 m/s in some steps (SUMO-internal, not modelled).  sumo_idm_speed -- what
+    uncommanded vehicles run here -- gives the 0.2."""
+    from oracle import controllers as Ctl
+    rows = defaultdict(dict)
+    with open(os.path.join(GOLDEN, "merge_emission.csv")) as f:
+        for r in csv.DictReader(f):
+            rows[r["id"]][round(float(r["time"]), 1)] = float(r["speed"])
+    n = 0
+    for vid, tr in rows.items():
+        times = sorted(tr)
+        assert tr[times[0]] == 0.0
+        for a, b in zip(times[:-1], times[1:]):
+            v = np.array([tr[a]])
+            nxt = float(Ctl.sumo_idm_speed(v, np.array([0.0]), np.array([1000.0]), np.array([False]), 0.2,
+                                           accel=1.0, decel=1.5, tau=1.0, min_gap=2.5, max_speed=30.0)[0])
+            gain, ref_gain = tr[b] - tr[a], nxt - tr[a]
+            assert abs(ref_gain - 0.2) < 1e-3
+            assert ref_gain - 0.075 <= gain <= ref_gain + 0.0051, (vid, a, gain)
+            n += 1
+    assert n == 22
+
+
 # ----------------------------------------------------------------- step bookkeeping
 def test_horizon_done_and_obs_layout():
     spec = ring_spec(R=3, N=5, bunching=0, horizon=4)
