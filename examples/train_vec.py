@@ -72,27 +72,19 @@ def gae(rew, val, done, last_val, gamma=0.999, lam=0.97):
     return adv, adv + val
 
 
-def main(argv=None):
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--replicas", type=int, default=1024)
-    ap.add_argument("--fragment", type=int, default=100, help="env steps per captured graph")
-    ap.add_argument("--horizon", type=int, default=500)
-    ap.add_argument("--iterations", type=int, default=20)
-    ap.add_argument("--epochs", type=int, default=4)
-    ap.add_argument("--lr", type=float, default=3e-4)
-    args = ap.parse_args(argv)
-
+def train_on_device(flow_params, replicas=1024, fragment=100, iterations=20, epochs=4, lr=3e-4, seed=0, log=print):
+    """PPO on R replicas of ``flow_params`` with everything in HBM: returns the mean step reward per iteration."""
     from flow_amd.envs import VecFlowEnv
     dev = torch.device("cuda", 0)
-    torch.manual_seed(0)
-    vec = VecFlowEnv(ring_flow_params(args.horizon), num_replicas=args.replicas, device=0)
+    torch.manual_seed(seed)
+    vec = VecFlowEnv(flow_params, num_replicas=replicas, device=0)
     pi = GaussianPolicy(vec.obs_dim, vec.act_dim).to(dev)
-    opt = torch.optim.Adam(pi.parameters(), lr=args.lr)
-    graph = vec.capture(args.fragment, policy=pi.act, reset_done=True)
+    opt = torch.optim.Adam(pi.parameters(), lr=lr)
+    graph = vec.capture(fragment, policy=pi.act, reset_done=True)
     graph.begin(vec.reset())
-    K, R = args.fragment, args.replicas
+    K, R = fragment, replicas
     history = []
-    for it in range(args.iterations):
+    for it in range(iterations):
         t0 = time.perf_counter()
         obs, act, rew, done = graph.replay()                   # K closed-loop steps of R replicas: one graph launch
         graph.synchronize()
@@ -104,7 +96,7 @@ def main(argv=None):
             adv, ret = gae(rew, val.view(K, R), done, last_val)
             adv = ((adv - adv.mean()) / (adv.std() + 1e-8)).reshape(-1)
             ret = ret.reshape(-1)
-        for _ in range(args.epochs):
+        for _ in range(epochs):
             logp, v = pi.logp_value(o, a)
             ratio = (logp - logp_old).exp()
             loss = -torch.min(ratio * adv, ratio.clamp(0.8, 1.2) * adv).mean() + 0.5 * (v - ret).pow(2).mean()
@@ -113,10 +105,23 @@ def main(argv=None):
             opt.step()
         mean_rew = float(rew.mean())
         history.append(mean_rew)
-        print("iteration %3d  mean step reward %8.4f  rollout %.1f ms (%.2f M env-steps/s)  episodes ended %d"
-              % (it, mean_rew, t_roll * 1e3, K * R / t_roll / 1e6, int(done.sum())))
+        log("iteration %3d  mean step reward %8.4f  rollout %.1f ms (%.2f M env-steps/s)  episodes ended %d"
+            % (it, mean_rew, t_roll * 1e3, K * R / t_roll / 1e6, int(done.sum())))
     vec.close()
     return history
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--replicas", type=int, default=1024)
+    ap.add_argument("--fragment", type=int, default=100, help="env steps per captured graph")
+    ap.add_argument("--horizon", type=int, default=500)
+    ap.add_argument("--iterations", type=int, default=20)
+    ap.add_argument("--epochs", type=int, default=4)
+    ap.add_argument("--lr", type=float, default=3e-4)
+    args = ap.parse_args(argv)
+    return train_on_device(ring_flow_params(args.horizon), replicas=args.replicas, fragment=args.fragment,
+                           iterations=args.iterations, epochs=args.epochs, lr=args.lr)
 
 
 if __name__ == "__main__":

@@ -814,7 +814,7 @@ __device__ __forceinline__ T control_accel(const DevView<T>& s, const SegTab<T>&
 // CSET = 1 (generic path only) compiles the controller switch down to IDM / RL / Sim slots, the common
 // "IDM humans + RL vehicles" population of the reference's experiments: every other feature stays.
 template <typename T, int SEG, int FAST, int CSET = 0>
-__global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const uint8_t* __restrict__ mask,
+__global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps_arg, const uint8_t* __restrict__ mask,
                                               const float* __restrict__ actions, size_t act_stride,
                                               float* __restrict__ obs, float* __restrict__ rew,
                                               uint8_t* __restrict__ done, int obs_every_step) {
@@ -863,6 +863,10 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps, const
   const T quarter = base_len / T(4);
   const T qj = quarter + s.jlen;
   const bool live_replica = rvalid && (FAST || mask == nullptr || mask[rr] != 0);
+  // a masked launch (the warm-up steps of a reset) advances nothing in a wave none of whose replicas is selected: it
+  // only has to report the observation of the unchanged state (the zero-step form) -- what makes a reset of the few
+  // finished episodes cheap inside a captured closed-loop fragment (VecFlowEnv.capture with warm-up steps)
+  const int num_steps = (!FAST && mask != nullptr && __ballot(live_replica) == 0ull) ? 0 : num_steps_arg;
   int tcount = s.time[rr];
   uint32_t nctr = (!FAST && (flags & FLAG_HAS_NOISE)) ? s.noise_ctr[rr] : 0u;
 
@@ -1328,7 +1332,7 @@ template <typename T>
 __device__ __forceinline__ T bperm(T v, int src_lane) { return __shfl(v, src_lane, 64); }
 
 template <typename T, int SEG, bool LC /* some vehicle changes lane on its own (ML7) */>
-__global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, const uint8_t* __restrict__ mask,
+__global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps_arg, const uint8_t* __restrict__ mask,
                                                  const float* __restrict__ actions, size_t act_stride,
                                                  float* __restrict__ obs, float* __restrict__ rew,
                                                  uint8_t* __restrict__ done, int obs_every_step) {
@@ -1372,6 +1376,7 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps, co
   const T quarter = base_len / T(4);
   const T qj = quarter + s.jlen;
   const bool live_replica = rvalid && (mask == nullptr || mask[rr] != 0);
+  const int num_steps = (mask != nullptr && __ballot(live_replica) == 0ull) ? 0 : num_steps_arg;   // as in k_steps
   int tcount = s.time[rr];
   uint32_t nctr = (flags & FLAG_HAS_NOISE) ? s.noise_ctr[rr] : 0u;
 

@@ -80,3 +80,24 @@ def test_train_vec_example_runs_on_the_device():
     hist = train_vec.main(["--replicas", "64", "--fragment", "20", "--horizon", "50", "--iterations", "3",
                            "--epochs", "1"])
     assert len(hist) == 3 and all(np.isfinite(hist))
+
+
+def test_train_script_has_the_reference_command_line_and_trains_reference_experiments():
+    """examples/train.py EXP_CONFIG [--rl_trainer --num_steps --rollout_size ...] (the reference's train.py:34-71):
+    the two single-agent experiments written with the reference's own parameter values run on the device (the ring one
+    with its 750 warm-up steps inside the in-graph resets), the rllib route fails loudly without ray."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "train.py")
+    for exp in ("singleagent_figure_eight", "singleagent_ring"):
+        res = subprocess.run([sys.executable, script, exp, "--num_steps", "2", "--rollout_size", "15", "--replicas", "48"],
+                             capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        lines = [ln for ln in res.stdout.splitlines() if ln.startswith("iteration")]
+        assert len(lines) == 2 and all(np.isfinite(float(ln.split()[5])) for ln in lines), res.stdout
+    res = subprocess.run([sys.executable, script, "singleagent_ring", "--rl_trainer", "rllib"], capture_output=True,
+                         text=True, timeout=600)
+    try:
+        import ray  # noqa: F401
+    except ImportError:
+        assert res.returncode != 0 and "ray" in res.stderr
