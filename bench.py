@@ -158,11 +158,12 @@ def c3_leg(device, R=4096, steps=3000, po=False):
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
     crashed = float((out[2][:-1].max(dim=0).values > 0).float().mean().item())
+    kernel = vec.sim.last_kernel
     vec.close()
     return {"value": R * done_steps / dt, "unit": "env-steps/s", "steps": done_steps, "steps_per_launch": K, "replicas": R,
-            "obs_dim": 3 if po else 28, "replicas_crashed_before_horizon": crashed,
+            "obs_dim": 3 if po else 28, "replicas_crashed_before_horizon": crashed, "kernel": kernel,
             "workload": "C3: FigureEightNetwork r=30, 13 IDM (noise 0.2, obey_safe_speed) + 1 RL, %s, "
-                        "random actions; k_rollout_loop" % ("WaveAttenuationPOEnv" if po else "AccelEnv")}
+                        "random actions" % ("WaveAttenuationPOEnv" if po else "AccelEnv")}
 
 
 def c5_leg(device, R=1024, env_steps=600):

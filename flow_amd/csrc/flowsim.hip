@@ -69,6 +69,7 @@ struct SimBase {
   bool mixed = false;           // FS_MIXED: float64 state, float32 controller arithmetic (k_rollout_pair<double>)
   bool no_pair = false;         // FLOWSIM_NO_PAIR=1: keep k_rollout_idm (one vehicle per lane) for the float rollout
   bool no_loop_kernel = false;  // FLOWSIM_NO_LOOP_KERNEL=1: keep the generic k_steps for segment-table loops (tests)
+  bool no_loop_full = false;    // FLOWSIM_NO_LOOP_FULL=1: keep the run-time-flag instantiation of k_rollout_loop (tests)
   int pair_block = 256;         // threads per block of k_rollout_pair (FLOWSIM_PAIR_BLOCK overrides)
   const char* last_kernel = "";  // family of the step kernel the last launch_steps call chose (fs_last_kernel)
 
@@ -610,7 +611,18 @@ struct Sim : SimBase {
 #define FS_LOOP(H_, D_)                                                                                       \
   hipLaunchKernelGGL((fs::k_rollout_loop<H_, D_>), grid, block, 0, stream, dv, num_steps, actions, act_stride, obs, \
                      rew, done)
-        if (dv.env == FS_ENV_ACCEL) { if (loop_delta4) FS_LOOP(0, true); else FS_LOOP(0, false); }
+        const bool full = (f & fs::FLAG_HAS_NOISE) && (f & fs::FLAG_NEED_SUMO) && dv.junction_on && actions != nullptr &&
+                          loop_delta4 && !no_loop_full;
+        if (full) {
+          last_kernel = "k_rollout_loop<FULL>";
+          if (dv.env == FS_ENV_ACCEL)
+            hipLaunchKernelGGL((fs::k_rollout_loop<0, true, true>), grid, block, 0, stream, dv, num_steps, actions,
+                               act_stride, obs, rew, done);
+          else
+            hipLaunchKernelGGL((fs::k_rollout_loop<1, true, true>), grid, block, 0, stream, dv, num_steps, actions,
+                               act_stride, obs, rew, done);
+        }
+        else if (dv.env == FS_ENV_ACCEL) { if (loop_delta4) FS_LOOP(0, true); else FS_LOOP(0, false); }
         else { if (loop_delta4) FS_LOOP(1, true); else FS_LOOP(1, false); }
 #undef FS_LOOP
         HIP_TRY(hipGetLastError());
@@ -1097,6 +1109,8 @@ int create_typed(const fs_config* cfg, fs_handle* out) {
     s->no_fastdiv = nf && nf[0] == '1';
     const char* nl = std::getenv("FLOWSIM_NO_LOOP_KERNEL");
     s->no_loop_kernel = nl && nl[0] == '1';
+    const char* nlf = std::getenv("FLOWSIM_NO_LOOP_FULL");
+    s->no_loop_full = nlf && nlf[0] == '1';
     const char* np = std::getenv("FLOWSIM_NO_PAIR");
     s->no_pair = np && np[0] == '1';
     const char* pb = std::getenv("FLOWSIM_PAIR_BLOCK");

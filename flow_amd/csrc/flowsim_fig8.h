@@ -19,6 +19,7 @@
 // sims_per_step 1, no reset mask, no sorting / shuffling, AccelEnv (not evaluate) or
 // WaveAttenuationPOEnv head, observation every step, N <= 16.
 #pragma once
+#include <type_traits>
 #include "flowsim_kernels.h"
 
 namespace fs {
@@ -63,7 +64,21 @@ __device__ __forceinline__ float sumo_fast(float v, float vl, float h, bool has,
   return tmax(0.0f, v + acc * dt);
 }
 
-template <int HEAD /* 0: AccelEnv, 1: WaveAttenuationPOEnv */, bool DELTA4 /* every IDM slot has delta = 4 */>
+// FULL: the launch is known to have noisy slots, speed-mode clamps / uncommanded slots, the crossing and an action
+// tensor (BASELINE's C3 and the reference's figure-eight experiments): the four launch-constant tests become
+// compile-time facts instead of taken branches (a wave alone on its SIMD pays an instruction-fetch bubble for each).
+// A wave-wide test whose result steers a branch, evaluated HERE: a scalar branch that reads a VALU-written mask in
+// the next instruction stands still for ~35 cycles (scripts/ubench: v_cmp + s_cbranch_vccz 44.6 cycles against 13 for
+// the two alone) -- a wave alone on its SIMD has nothing to fill that with, so every such test of the step is
+// evaluated as early as its inputs exist and consumed later.
+__device__ __forceinline__ unsigned long long ballot_here(bool p) {
+  unsigned long long m = __ballot(p);
+  asm volatile("" : "+s"(m));
+  return m;
+}
+
+template <int HEAD /* 0: AccelEnv, 1: WaveAttenuationPOEnv */, bool DELTA4 /* every IDM slot has delta = 4 */,
+          bool FULL = false>
 __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_steps,
                                                       const float* __restrict__ actions, size_t act_stride,
                                                       float* __restrict__ obs, float* __restrict__ rew,
@@ -115,7 +130,7 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
   const T base_len = s.ring_len[rr];
   const T L = base_len + T(4) * s.jlen;
   int tcount = s.time[rr];
-  const bool any_noise = (flags & FLAG_HAS_NOISE) != 0;
+  const bool any_noise = FULL || (flags & FLAG_HAS_NOISE) != 0;
   uint32_t nctr = any_noise ? s.noise_ctr[rr] : 0u;
   const bool noisy = any_noise && sl.noise > T(0) && sl.ctrl != FS_CTRL_RL && sl.ctrl != FS_CTRL_SIM;
 
@@ -148,23 +163,32 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
   sc.two_sqrt = make_divc(T(2) * tsqrt(sl.max_accel * sl.max_decel));
   sc.max_speed = make_divc(sl.sumo_max_speed);
   const unsigned seg_internal = s.seg_internal;
-  const bool junction_on = s.junction_on != 0, need_sumo = (flags & FLAG_NEED_SUMO) != 0;
+  const bool junction_on = FULL || s.junction_on != 0, need_sumo = FULL || (flags & FLAG_NEED_SUMO) != 0;
   const bool gated = s.junction_mode && sl.ctrl != FS_CTRL_RL && sl.ctrl != FS_CTRL_SIM;
   const bool clip = s.clip_actions != 0;
   const bool rl_lane = sl.ctrl == FS_CTRL_RL, sim_lane = sl.ctrl == FS_CTRL_SIM;
-  const bool use_act = actions != nullptr;
+  const bool use_act = FULL || actions != nullptr;
   const int num_rl = s.num_rl;
   const int own_col = sl.rl_index < 0 ? 0 : sl.rl_index;
   const bool red_lane = ii < num_rl && i < N;
   const int obs_dim = HEAD == 1 ? 3 : 2 * N;
   const bool obs_lane = HEAD == 1 ? (valid && rl_lane && sl.rl_index == 0) : valid;
 
-  float a_own_next = 0.0f, a_red_next = 0.0f;
+  // RL actions are read PERIOD steps ahead, into the register the step PERIOD steps earlier has just consumed (slot s
+  // of a block <-> element s: static after unrolling).  The action tensor is streamed once -- every step's row is a
+  // cold line from HBM, several thousand cycles away under load, more than one step of this kernel: with the load
+  // issued ONE step ahead (the first version) the wave stood waiting for it a third of its life.
+  float a_own_q[PERIOD] = {0.0f, 0.0f, 0.0f, 0.0f}, a_red_q[PERIOD] = {0.0f, 0.0f, 0.0f, 0.0f};
   const int red_col = red_lane ? ii : 0;                 // every lane loads (no exec-mask branch); only its role's value is used
-  if (use_act && num_steps > 0) {
-    const float* a0 = actions + size_t(rr) * num_rl;
-    a_own_next = a0[own_col];
-    a_red_next = a0[red_col];
+  if (use_act) {
+#pragma unroll
+    for (int q = 0; q < PERIOD; ++q) {
+      if (q < num_steps) {
+        const float* a0 = actions + size_t(q) * act_stride + size_t(rr) * num_rl;
+        a_own_q[q] = a0[own_col];
+        a_red_q[q] = a0[red_col];
+      }
+    }
   }
   // the four draws of the current noise block, ROTATED so that g4[0] is always the draw of the next step (no
   // per-step index select); a launch that starts in the middle of a block evaluates it and rotates up to there
@@ -211,31 +235,49 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
   };
   T prev_v = v, last_acc = T(0);                          // track_aux: get_previous_speed / get_accel of the scalar Env
 
-  for (int base = 0; base < num_steps; base += PERIOD) {
+  // one block of PERIOD steps; FB (a full block): the per-step "is this step inside the launch" test is a compile-time
+  // fact -- the tail of a launch (num_steps % PERIOD steps) runs the same body with the test
+  auto run_block = [&](const int base, auto full_block) {
+    constexpr bool FB = decltype(full_block)::value;
     T red[PERIOD];                // per-step reward ingredients: AccelEnv (v - target)^2, PO: speeds (mean) in red, |a| in red2
     T red2[PERIOD];
-    const int nsteps = num_steps - base < PERIOD ? num_steps - base : PERIOD;
+    const int nsteps = FB ? PERIOD : num_steps - base;
 #pragma unroll
     for (int slot = 0; slot < PERIOD; ++slot) {
       red[slot] = T(0);
       red2[slot] = T(0);
-      if (slot < nsteps) {                                   // wave-uniform
+      if (FB || slot < nsteps) {                             // wave-uniform
         const int step = base + slot;
-        const float a_own = a_own_next, a_red = a_red_next;
+        // the step's wave-wide tests whose inputs are the snapshot: evaluated first, consumed where they steer
+        const unsigned long long draw_m = any_noise ? ballot_here(noisy && (nctr & 3u) == 0u) : 0ull;
+        unsigned jf = 0u;
+        bool on_a = false, on_b = false;
+        unsigned long long cap_m = 0ull, cap2_m = 0ull;
+        if (junction_on) {
+          // per-replica facts of the snapshot, one OR-butterfly: bit 0 stream a busy, bit 1 stream b in the box
+          jf |= (valid & (x >= ja_in - tgap * v) & (x < ja_out + sl.length)) ? 1u : 0u;
+          jf |= (valid & (x >= jb_in) & (x < jb_out + sl.length)) ? 2u : 0u;
+          jf = seg_or<SEG>(jf);
+          on_b = (x >= jb_in - look) & (x < jb_in) & ((jf & 1u) != 0u);
+          on_a = (x >= ja_in - look) & (x < ja_in) & ((jf & 2u) != 0u);
+          cap_m = ballot_here(on_a || on_b);
+          cap2_m = ballot_here(on_a && on_b);
+        }
+        const float a_own = a_own_q[slot], a_red = a_red_q[slot];
         asm volatile("" :: "v"(a_own), "v"(a_red));             // the wait for the prefetched action happens HERE
         flush_obs();
         if (slot == 0) flush_rew();
-        if (use_act && step + 1 < num_steps) {
-          const float* an = actions + size_t(step + 1) * act_stride + size_t(rr) * num_rl;
-          a_own_next = an[own_col];
-          a_red_next = an[red_col];
+        if (use_act && step + PERIOD < num_steps) {
+          const float* an = actions + size_t(step + PERIOD) * act_stride + size_t(rr) * num_rl;
+          a_own_q[slot] = an[own_col];
+          a_red_q[slot] = an[red_col];
         }
         // ---- controllers on the snapshot (control_accel_on, CSET = 1) ----------------------------------
         const bool on_edge = gated ? !((seg_internal >> k) & 1u) : true;
         T acc = T(0);
         bool commanded = false;
         if (any_noise) {
-          if (__ballot(noisy && (nctr & 3u) == 0u) != 0ull) {
+          if (draw_m != 0ull) {
             if (noisy && (nctr & 3u) == 0u)
               gauss4<T>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(ii), nctr >> 2, g4);
           }
@@ -264,20 +306,14 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
           v_new = commanded ? vc : v_sumo;
         }
         if (junction_on) {
-          // per-replica facts of the snapshot, one OR-butterfly: bit 0 stream a busy, bit 1 stream b in the box
-          unsigned f = 0u;
-          f |= (valid & (x >= ja_in - tgap * v) & (x < ja_out + sl.length)) ? 1u : 0u;
-          f |= (valid & (x >= jb_in) & (x < jb_out + sl.length)) ? 2u : 0u;
-          f = seg_or<SEG>(f);
-          const bool on_b = (x >= jb_in - look) & (x < jb_in) & ((f & 1u) != 0u);
-          const bool on_a = (x >= ja_in - look) & (x < ja_in) & ((f & 2u) != 0u);
+          // (jf, on_a, on_b and the two tests: top of the step)
           // a vehicle is on at most one approach (the two lines are different places of the loop); should both
           // hold for a degenerate table, stream b's line is evaluated first and stream a's overrides as min would
-          if (__ballot(on_a || on_b) != 0ull) {
+          if (cap_m != 0ull) {
             const T line = on_b ? jb_in - x : ja_in - x;
             T cap = sumo_fast(v, T(0), line, true, dt, sc);
             cap = (on_a || on_b) ? cap : T(3.0e38);
-            if (__ballot(on_a && on_b) != 0ull) {                // degenerate table: both lines ahead of one vehicle
+            if (cap2_m != 0ull) {                                // degenerate table: both lines ahead of one vehicle
               const T cap_a = sumo_fast(v, T(0), ja_in - x, true, dt, sc);
               cap = (on_a && on_b) ? tmin(cap, cap_a) : cap;
             }
@@ -298,6 +334,9 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
         k = (x < c_st) ? 0 : k + ((x >= c_next) ? 1 : 0) + ((x >= c_next2) ? 1 : 0);
         const T n_st = tab_start[k], n_next = tab_start[k + 1], n_next2 = tab_start[k + 2];
         const T n_fs = tab_fs[k], n_sl = tab_sl[k];
+        // the reads must be ISSUED here: without the fence hipcc sinks them into the block of their first use (the
+        // `while` below) and the wave waits out two LDS latencies there, every step
+        asm volatile("" ::: "memory");
         // ---- new neighbour snapshot (S10) + per-replica facts of the new state -----------------------------
         xl = lead16(x, wrap_lead);
         vl = lead16(v, wrap_lead);
@@ -310,6 +349,7 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
           f2 |= (valid & (x >= zb_lo) & (x < zb_hi)) ? 4u : 0u;
         }
         f2 |= (valid & (v < T(-100))) ? 8u : 0u;
+        unsigned long long adv_m = ballot_here(x >= n_next);     // a third start passed / one passed after a wrap (rare)
         f2 = seg_or<SEG>(f2);
         const bool crashed = (f2 & 1u) || ((f2 & 6u) == 6u);
         const bool bad = (f2 & 8u) || crashed;
@@ -317,13 +357,15 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
         bad_bits |= bad ? (1u << slot) : 0u;
         // ---- the segment row read above
         c_st = n_st; c_next = n_next; c_next2 = n_next2; c_fs = n_fs; c_sl = n_sl;
-        while (__ballot(x >= c_next) != 0ull) {                  // rare
+        while (adv_m != 0ull) {                                  // rare
+          asm volatile("" ::: "memory");                         // (keeps the body's reads from being hoisted above the test)
           k += (x >= c_next) ? 1 : 0;
           c_st = tab_start[k];
           c_next = tab_start[k + 1];
           c_next2 = tab_start[k + 2];
           c_fs = tab_fs[k];
           c_sl = tab_sl[k];
+          adv_m = __ballot(x >= c_next);
         }
         // ---- observation ---------------------------------------------------------------------------------
         if (HEAD == 1) {
@@ -381,7 +423,10 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
       prew_at = o;
       pend_rew = true;
     }
-  }
+  };
+  int base0 = 0;
+  for (; base0 + PERIOD <= num_steps; base0 += PERIOD) run_block(base0, std::true_type{});
+  if (base0 < num_steps) run_block(base0, std::false_type{});
   flush_obs();
   flush_rew();
   if (valid) {

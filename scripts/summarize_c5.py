@@ -26,6 +26,8 @@ def newest(pattern):
 shutil.copy(newest("trace/*/*_kernel_stats.csv"), os.path.join(out, "%s_%s_kernel_stats.csv" % (tag, leg)))
 bench = json.loads(open(os.path.join(src, "bench_trace.json")).read().strip().splitlines()[-1])
 json.dump(bench, open(os.path.join(out, "%s_%s_bench.json" % (tag, leg)), "w"), indent=1)
+if leg == "c3" and "c3_figure_eight" in bench:   # scripts/bench_c3.py prints both heads: the counters are the AccelEnv launch's
+    bench = dict(bench["c3_figure_eight"], po_head=bench.get("c3_figure_eight_po"))
 slots = bench.get("slots", 64)                 # 64 slots per replica: one wave each; k_steps_wide: 2 or 4 waves
 waves = bench["replicas"] * (1 if slots <= 64 else (2 if slots <= 128 else 4))
 substeps = bench.get("env_steps", bench.get("steps", 0)) * bench.get("sims_per_step", 1)

@@ -98,10 +98,22 @@ OPS = [
     ("v_min_u32", lambda i: "v_min_u32 %s, %s, %s" % (D32(i), S32(i), D32(i))),
     ("v_cmp_lt_u32", lambda i: "v_cmp_lt_u32 vcc, %s, %s" % (S32(i), D32(i))),
     ("v_permlane32_swap", lambda i: "v_permlane32_swap_b32 %s, %s" % (D32(i), D32((i + 4) % 8))),
+    # control flow as a wave alone on its SIMD sees it (the rollout kernels' steps are branchy straight-line code)
+    ("s_branch taken (over 1 instr)", lambda i: "s_branch 1f\\ns_nop 0\\n1:"),
+    ("s_cbranch_vccnz taken (over 1)", lambda i: "s_cbranch_vccnz 1f\\ns_nop 0\\n1:"),
+    ("s_cbranch_vccz not taken", lambda i: "s_cbranch_vccz 1f\\n1:"),
+    ("v_cmp vcc + s_cbranch_vccz n.t.", lambda i: "v_cmp_lt_f32 vcc, v20, v21\\ns_cbranch_vccz 1f\\n1:"),
+    ("v_cmp vcc + s_cbranch_vccnz taken", lambda i: "v_cmp_lt_f32 vcc, v21, v20\\ns_cbranch_vccnz 1f\\ns_nop 0\\n1:"),
+    ("v_cmp sgpr + s_and_b64 on it", lambda i: "v_cmp_lt_f32 s[20:21], v20, v21\\ns_and_b64 s[22:23], s[20:21], s[28:29]"),
+    ("v_cmp sgpr + s_and_b64 + v_cndmask on that", lambda i: "v_cmp_lt_f32 s[20:21], v20, v21\\ns_and_b64 s[22:23], s[20:21], s[28:29]\\nv_cndmask_b32_e64 v10, v20, v10, s[22:23]"),
+    ("v_cmp x2 + s_and + cndmask (A & B ? .. : ..)", lambda i: "v_cmp_lt_f32 s[20:21], v20, v21\\nv_cmp_lt_f32 s[24:25], v21, v22\\ns_and_b64 s[22:23], s[20:21], s[24:25]\\nv_cndmask_b32_e64 v10, v20, v10, s[22:23]"),
+    ("v_cmp, cndmask, v_cmp, cndmask (no SALU)", lambda i: "v_cmp_lt_f32 s[20:21], v20, v21\\nv_cndmask_b32_e64 v11, 0, 1, s[20:21]\\nv_cmp_lt_f32 s[24:25], v21, v22\\nv_cndmask_b32_e64 v10, 0, v11, s[24:25]"),
+    ("v_readfirstlane + s_add on it", lambda i: "v_readfirstlane_b32 s20, v20\\ns_add_u32 s22, s20, s30"),
+    ("s_branch taken over 16 instrs", lambda i: "s_branch 1f\\n" + "s_nop 0\\n" * 16 + "1:"),
 ]
 
 CLOB = ", ".join('"v%d"' % r for r in list(range(10, 18)) + list(range(30, 46))) + \
-    ', "vcc", ' + ", ".join('"s%d"' % r for r in range(20, 31))
+    ', "vcc", "scc", ' + ", ".join('"s%d"' % r for r in range(20, 31))
 ALLREG = ", ".join('"v%d"' % r for r in list(range(10, 18)) + list(range(20, 28)) + list(range(30, 46)) + list(range(50, 66)))
 
 print("""// GENERATED by gen_valu_issue.py -- do not edit

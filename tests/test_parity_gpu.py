@@ -963,6 +963,14 @@ def test_loop_rollout_kernel_equals_generic_kernel(head):
     acts = rng.uniform(-3, 3, (K, R, 1)).astype(np.float32)
     a, oa, ra, da = _rollout(spec, K, acts)
     b, ob, rb, db = _rollout(spec, K, acts, env={"FLOWSIM_NO_LOOP_KERNEL": "1"})
+    # this population is the FULL configuration class (noise, speed-mode clamps, crossing, action tensor: the launch
+    # constants are compile-time facts); the run-time-flag instantiation must give the same bits
+    f, of, rf, df = _rollout(spec, K, acts, env={"FLOWSIM_NO_LOOP_FULL": "1"})
+    assert a.last_kernel == "k_rollout_loop<FULL>" and f.last_kernel == "k_rollout_loop" and b.last_kernel.startswith("k_steps")
+    np.testing.assert_array_equal(oa, of)
+    np.testing.assert_array_equal(ra, rf)
+    np.testing.assert_array_equal(a.pos, f.pos)
+    f.close()
     np.testing.assert_array_equal(oa, ob)
     np.testing.assert_array_equal(ra, rb)
     np.testing.assert_array_equal(da, db)
