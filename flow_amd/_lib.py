@@ -11,7 +11,7 @@ from .utils.exceptions import FatalFlowError
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libflowsim.so")
 
-FS_ABI_VERSION = 5
+FS_ABI_VERSION = 6
 FS_MAX_CTRL_PARAMS = 8
 
 # error codes
@@ -60,7 +60,7 @@ class fs_segment(C.Structure):
 class fs_inflow(C.Structure):
     _fields_ = [("type", C.c_int32), ("route", C.c_int32), ("number", C.c_int32), ("reserved", C.c_int32),
                 ("period", C.c_double), ("begin", C.c_double), ("end", C.c_double), ("depart_speed", C.c_double),
-                ("depart_pos", C.c_double)]
+                ("depart_pos", C.c_double), ("probability", C.c_double)]
 
 
 class fs_cell(C.Structure):

@@ -321,6 +321,7 @@ struct Sim : SimBase {
     if ((rc = dev_alloc(&ov.arr_hist, size_t(R) * 20))) return rc;
     if ((rc = dev_alloc(&ov.counters, size_t(R) * 8))) return rc;
     if ((rc = dev_alloc(&ov.emitted, size_t(R) * FS_MAX_INFLOWS))) return rc;
+    if ((rc = dev_alloc(&ov.generated, size_t(R) * FS_MAX_INFLOWS))) return rc;
     if ((rc = dev_alloc(&ov.episode, size_t(R)))) return rc;
     HIP_TRY(hipMemset(ov.episode, 0xFF, size_t(R) * sizeof(int32_t)));     // -1: fs_create's own reset below is not an episode
     if ((rc = upload(&ov.init_alive, init_alive))) return rc;
@@ -343,8 +344,17 @@ struct Sim : SimBase {
     ov.n_rl_slots = n_rl_slots;
     std::vector<double> ftd(3 * 64, 0.0);
     std::vector<int32_t> fti(3 * 64, 0);
+    ov.n_prob = 0;
     for (int f = 0; f < cfg.num_inflows; ++f) {
       ftd[f] = inflows[f].period;
+      if (inflows[f].probability >= 0.0) {
+        // a probabilistic inflow keeps, in the place of its period, -(threshold + 1): a vehicle is generated in a
+        // sub-step when the sub-step's 32-bit Philox draw is below threshold = floor(p * sim_step * 2^32)
+        double thr = std::floor(inflows[f].probability * cfg.sim_step * 4294967296.0);
+        if (thr > 4294967295.0) thr = 4294967295.0;
+        ftd[f] = -(thr + 1.0);
+        ov.n_prob += 1;
+      }
       ftd[64 + f] = inflows[f].begin;
       ftd[128 + f] = inflows[f].end;
       fti[f] = inflows[f].type;
@@ -953,7 +963,8 @@ int validate(const fs_config* c) {
       if (c->network == FS_NET_MERGE ? (fl.route < 0 || fl.route > 1)
                                      : (fl.route < -1 || fl.route > (c->num_paths == 8 ? 7 : 3)))
         return fail(FS_ERR_INVALID, "fs_create: inflow route out of range");
-      if (!(fl.period > 0)) return fail(FS_ERR_INVALID, "fs_create: inflow period <= 0");
+      if (fl.probability > 1.0) return fail(FS_ERR_INVALID, "fs_create: inflow probability > 1");
+      if (!(fl.probability >= 0.0) && !(fl.period > 0)) return fail(FS_ERR_INVALID, "fs_create: inflow period <= 0");
       if (!(fl.depart_speed >= 0) || !(fl.depart_pos >= 0)) return fail(FS_ERR_INVALID, "fs_create: bad inflow departure");
       bool type_ok = false;
       for (int i = 0; i < c->num_vehicles; ++i) type_ok = type_ok || c->vehicles[i].type == fl.type;

@@ -33,6 +33,7 @@ struct OpenView {
   int32_t* arr_hist;     // [R,20] arrivals of the last 20 sub-steps (ring buffer indexed by sub-step % 20)
   int32_t* counters;     // [R,8]
   int32_t* emitted;      // [R,FS_MAX_INFLOWS]
+  int32_t* generated;    // [R,FS_MAX_INFLOWS] vehicles a probabilistic inflow has generated so far (M2b)
   int32_t* episode;      // [R] resets of the replica since fs_create (-1 before the first): keys the entry-lane draws (M9)
   const uint8_t* init_alive;   // [R,N]
   const int32_t* slot_type;    // [N]
@@ -42,6 +43,7 @@ struct OpenView {
   const double* flow_tab_d;    // [3][64] lane f: period, begin, end of inflow f (the schedule is evaluated in double)
   const int32_t* flow_tab_i;   // [3][64] lane f: vehicle type, route, number (-1 = unlimited)
   int n_inflows, ma_apply_actions, n_rl_slots;
+  int n_prob;                  // inflows with a probability instead of a period (flow_tab_d row 0 holds -(threshold + 1))
   double dt_d;
   int nseg[2];
   unsigned seg_internal[2];
@@ -318,6 +320,18 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       tot_dep = cnt[CNT_TOTAL_DEPARTED], tot_drop = cnt[CNT_TOTAL_DROPPED];
   // vehicles emitted so far by inflow f of this replica: held by lane f of the replica's segment (SEG >= 8)
   int emit_l = (i < FS_MAX_INFLOWS) ? o.emitted[size_t(rr) * FS_MAX_INFLOWS + i] : 0;
+  // M2b probabilistic inflows (InFlows.add(probability=p), params.py:1103-1105; SUMO: one Bernoulli(p * step length)
+  // trial per flow and step between begin and end): lane f of the segment makes inflow f's trial of the sub-step -- a
+  // Philox word keyed by (sub-step, 2000 + f, global replica, episode) against a 32-bit threshold -- and counts the
+  // vehicles generated; vehicle k of the flow is due once k < generated
+  const bool prob_any = o.n_prob > 0;
+  const bool my_flow = prob_any && i < o.n_inflows;
+  const double my_per = my_flow ? o.flow_tab_d[i] : 0.0;
+  const bool my_prob = my_per < 0.0;
+  const uint32_t my_thr = my_prob ? uint32_t(-my_per - 1.0) : 0u;
+  const double my_begin = my_flow ? o.flow_tab_d[64 + i] : 0.0, my_end = my_flow ? o.flow_tab_d[128 + i] : 0.0;
+  const int my_number = my_flow ? o.flow_tab_i[128 + i] : 0;
+  int gen_l = (prob_any && i < FS_MAX_INFLOWS) ? o.generated[size_t(rr) * FS_MAX_INFLOWS + i] : 0;
   const uint32_t episode = uint32_t(o.episode[rr]);
   double next_due = -1.0e300;                                   // unknown yet: the first sub-step evaluates the schedule
 
@@ -796,14 +810,25 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       const double now = double(sim_steps - 1) * o.dt_d;
       // `next_due` = earliest scheduled time of the replica's next vehicles (their count / end limits aside): while
       // it lies ahead in every replica of the wave the whole loop is skipped -- most sub-steps
+      if (prob_any) {                                    // M2b: this sub-step's trial of every probabilistic inflow
+        uint32_t c0 = uint32_t(sim_steps - 1), c1 = uint32_t(2000 + i), c2 = s.rep0 + uint32_t(rr), c3 = 1u + 2u * episode;
+        philox4x32_10(c0, c1, c2, c3, s.seed_lo, s.seed_hi);
+        const bool gen = my_prob && live && (now >= my_begin) && (now <= my_end) &&
+                         (my_number < 0 || gen_l < my_number) && (c0 < my_thr);
+        gen_l += gen ? 1 : 0;
+        if (seg_any<SEG>(gen, seg)) next_due = -1.0e300;  // a vehicle became due: the schedule is looked at
+      }
       const bool any_due = __ballot(live && (next_due <= now)) != 0ull;
       double nd = 1.0e300;
       for (int f = 0; any_due && f < o.n_inflows; ++f) {
         const int k = seg_read_i<SEG>(emit_l, f, seg);
-        const double due_t = tb.template fd<1>(f) + double(k) * tb.template fd<0>(f);
+        const double per_f = tb.template fd<0>(f);
+        const bool prob_f = per_f < 0.0;
+        const int g = prob_f ? seg_read_i<SEG>(gen_l, f, seg) : 0;
+        const double due_t = prob_f ? (k < g ? -1.0e300 : 1.0e300) : tb.template fd<1>(f) + double(k) * per_f;
         nd = (due_t < nd) ? due_t : nd;
         const int number = tb.template fi<2>(f);
-        const bool due = (due_t <= now) && (due_t <= tb.template fd<2>(f)) && (number < 0 || k < number);
+        const bool due = prob_f ? (k < g) : (due_t <= now) && (due_t <= tb.template fd<2>(f)) && (number < 0 || k < number);
         if (__ballot(due && live) == 0ull) continue;     // wave-uniform: this inflow is due in no replica of the wave
         const int typ = tb.template fi<0>(f);
         int route_f = tb.template fi<1>(f);
@@ -952,6 +977,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
     }
   }
   if (rvalid && live_replica && i < FS_MAX_INFLOWS) o.emitted[size_t(rr) * FS_MAX_INFLOWS + i] = emit_l;
+  if (prob_any && rvalid && live_replica && i < FS_MAX_INFLOWS) o.generated[size_t(rr) * FS_MAX_INFLOWS + i] = gen_l;
   if (bn_env && rvalid && live_replica && i < 20) o.arr_hist[size_t(rr) * 20 + i] = hist_l;
 }
 
@@ -985,7 +1011,10 @@ __global__ void k_reset_open(DevView<T> s, OpenView<T> o, const uint8_t* __restr
     s.last_lc[e] = -(1 << 30);
     o.lead[e] = -1;
     o.headway[e] = T(1000);
-    if (i < FS_MAX_INFLOWS) o.emitted[size_t(r) * FS_MAX_INFLOWS + i] = 0;
+    if (i < FS_MAX_INFLOWS) {
+      o.emitted[size_t(r) * FS_MAX_INFLOWS + i] = 0;
+      o.generated[size_t(r) * FS_MAX_INFLOWS + i] = 0;
+    }
     if (i == 0) {
       int total = 0;
       for (int j = 0; j < N; ++j) total += al[j] ? 1 : 0;
@@ -1003,7 +1032,10 @@ __global__ void k_reset_open(DevView<T> s, OpenView<T> o, const uint8_t* __restr
     for (size_t e = size_t(blockIdx.x) * blockDim.x + threadIdx.x; e < size_t(s.R) * FS_MAX_INFLOWS;
          e += size_t(gridDim.x) * blockDim.x) {
       const int r = int(e / FS_MAX_INFLOWS);
-      if (mask == nullptr || mask[r] != 0) o.emitted[e] = 0;
+      if (mask == nullptr || mask[r] != 0) {
+        o.emitted[e] = 0;
+        o.generated[e] = 0;
+      }
     }
 }
 

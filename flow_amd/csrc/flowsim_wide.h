@@ -39,6 +39,7 @@ struct WideLds {
   // launch constants, read with uniform / gathered addresses -- OpenTabs<T, IN_LDS> of flowsim_open.h, and why
   OpenTabsLds<T> tabs;
   int emitted[FS_MAX_INFLOWS];           // vehicles emitted so far by inflow f
+  int generated[FS_MAX_INFLOWS];         // vehicles generated so far by a probabilistic inflow f (M2b)
   int hist[20];                          // arrivals of sub-step % 20
 };
 
@@ -93,7 +94,18 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
   tb.load(o, l, dv_env, &L.tabs);
   static_assert(TABS_IN_LDS, "RouteCursor reads the tables with per-lane indices under divergent control flow");
   RouteCursor<T, OpenTabs<T, TABS_IN_LDS>> cur;
-  if (tid < FS_MAX_INFLOWS) L.emitted[tid] = o.emitted[size_t(rr) * FS_MAX_INFLOWS + tid];
+  if (tid < FS_MAX_INFLOWS) {
+    L.emitted[tid] = o.emitted[size_t(rr) * FS_MAX_INFLOWS + tid];
+    L.generated[tid] = o.generated[size_t(rr) * FS_MAX_INFLOWS + tid];
+  }
+  // M2b (flowsim_open.h): thread f makes the per-sub-step trial of probabilistic inflow f
+  const bool prob_any = o.n_prob > 0;
+  const bool my_flow = prob_any && tid < o.n_inflows;
+  const double my_per = my_flow ? o.flow_tab_d[tid] : 0.0;
+  const bool my_prob = my_per < 0.0;
+  const uint32_t my_thr = my_prob ? uint32_t(-my_per - 1.0) : 0u;
+  const double my_begin = my_flow ? o.flow_tab_d[64 + tid] : 0.0, my_end = my_flow ? o.flow_tab_d[128 + tid] : 0.0;
+  const int my_number = my_flow ? o.flow_tab_i[128 + tid] : 0;
   if (tid < 20) L.hist[tid] = o.arr_hist[size_t(rr) * 20 + tid];
 
   const bool live_replica = mask == nullptr || mask[rr] != 0;
@@ -539,11 +551,24 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
       }
       // ---- M2 / M3: insertions in InFlows order -------------------------------------------------------
       const double now = double(sim_steps - 1) * o.dt_d;
+      if (prob_any) {                                    // block-uniform
+        if (my_prob && live) {
+          uint32_t c0 = uint32_t(sim_steps - 1), c1 = uint32_t(2000 + tid), c2 = s.rep0 + uint32_t(rr), c3 = 1u + 2u * episode;
+          philox4x32_10(c0, c1, c2, c3, s.seed_lo, s.seed_hi);
+          const int gl = L.generated[tid];
+          if ((now >= my_begin) && (now <= my_end) && (my_number < 0 || gl < my_number) && (c0 < my_thr))
+            L.generated[tid] = gl + 1;
+        }
+        __syncthreads();
+      }
       for (int f = 0; f < o.n_inflows; ++f) {
         const int k = L.emitted[f];
-        const double due_t = tb.template fd<1>(f) + double(k) * tb.template fd<0>(f);
+        const double per_f = tb.template fd<0>(f);
+        const bool prob_f = per_f < 0.0;
+        const double due_t = tb.template fd<1>(f) + double(k) * per_f;
         const int number = tb.template fi<2>(f);
-        const bool due = (due_t <= now) && (due_t <= tb.template fd<2>(f)) && (number < 0 || k < number);
+        const bool due = prob_f ? (k < L.generated[f])
+                                : (due_t <= now) && (due_t <= tb.template fd<2>(f)) && (number < 0 || k < number);
         if (!(due && live)) continue;                    // block-uniform
         const int typ = tb.template fi<0>(f);
         int route_f = tb.template fi<1>(f);
@@ -676,7 +701,10 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
     }
   }
   __syncthreads();
-  if (live_replica && tid < FS_MAX_INFLOWS) o.emitted[size_t(rr) * FS_MAX_INFLOWS + tid] = L.emitted[tid];
+  if (live_replica && tid < FS_MAX_INFLOWS) {
+    o.emitted[size_t(rr) * FS_MAX_INFLOWS + tid] = L.emitted[tid];
+    o.generated[size_t(rr) * FS_MAX_INFLOWS + tid] = L.generated[tid];
+  }
   if (live_replica && tid < 20) o.arr_hist[size_t(rr) * 20 + tid] = L.hist[tid];
 }
 

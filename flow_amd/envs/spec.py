@@ -120,7 +120,8 @@ def slot_capacities(vehicles, inflows, total, given=None):
     else:
         rate = {n: 0.0 for n in names}
         for f in inflows:
-            rate[f["vtype"]] += float(f["vehsPerHour"]) if "vehsPerHour" in f else 3600.0 / float(f["period"])
+            rate[f["vtype"]] += (float(f["vehsPerHour"]) if "vehsPerHour" in f else
+                                 3600.0 * float(f["probability"]) if "probability" in f else 3600.0 / float(f["period"]))
         spare = total - sum(init.values())
         if spare < 0:
             raise FatalFlowError("more initial vehicles than vehicle slots (max_vehicles)")
@@ -211,14 +212,13 @@ def build_open_spec(env, num_replicas, rng=None):
     for f in flows:
         if f["edge"] not in first_edges:
             raise NotImplementedError("inflow on edge %r: only the first edge of a route is built" % f["edge"])
-        if "probability" in f:
-            raise NotImplementedError("probabilistic inflows are not built (vehs_per_hour / period are)")
         ds = f.get("departSpeed", 0)
         if isinstance(ds, str):
             if ds not in ("speedLimit", "max"):
                 raise NotImplementedError("departSpeed=%r is not built" % ds)
             ds = net_k.speed_limit(f["edge"])
-        period = 3600.0 / float(f["vehsPerHour"]) if "vehsPerHour" in f else float(f["period"])
+        prob = float(f["probability"]) if "probability" in f else None   # per second (params.py:1103-1105)
+        period = 0.0 if prob is not None else (3600.0 / float(f["vehsPerHour"]) if "vehsPerHour" in f else float(f["period"]))
         tname = f["vtype"]
         flow_route = first_edges.index(f["edge"])
         if lane_drop:                                      # the "route" of a lane-drop network is the entry lane
@@ -232,7 +232,7 @@ def build_open_spec(env, num_replicas, rng=None):
             else:
                 raise NotImplementedError("departLane=%r on a multi-lane edge is not built ('random', 'first' or a "
                                           "lane index are)" % (dl,))
-        inflows.append(dict(type=names.index(tname), route=flow_route, period=period,
+        inflows.append(dict(type=names.index(tname), route=flow_route, period=period, probability=prob,
                             begin=float(f.get("begin", 1)), end=float(f.get("end", 86400)),
                             number=int(f["number"]) if "number" in f else -1, depart_speed=float(ds),
                             depart_pos=float(veh_k.type_parameters[tname].get("length", 5.0)), name=f["name"]))

@@ -117,8 +117,10 @@ class FlowSim:
                 a.type, a.route = int(f["type"]), int(f["route"])
                 num = f.get("number", -1)
                 a.number = -1 if num is None else int(num)
-                a.period, a.begin, a.end = float(f["period"]), float(f.get("begin", 1.0)), float(f.get("end", 86400.0))
+                a.period, a.begin, a.end = float(f.get("period", 0.0)), float(f.get("begin", 1.0)), float(f.get("end", 86400.0))
                 a.depart_speed, a.depart_pos = float(f["depart_speed"]), float(f["depart_pos"])
+                prob = f.get("probability")
+                a.probability = -1.0 if prob is None else float(prob)
             init_alive = np.ascontiguousarray(np.asarray(spec["init_alive"], dtype=np.uint8).reshape(self.R, self.N))
             if init_vel is None:
                 init_vel = np.zeros((self.R, self.N))

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FS_ABI_VERSION 5
+#define FS_ABI_VERSION 6
 
 /* ---- error codes -------------------------------------------------------- */
 #define FS_OK 0
@@ -159,6 +159,10 @@ typedef struct fs_inflow {
   double begin, end;                  /* first departure time / end of the departure interval [s] */
   double depart_speed;                /* departSpeed [m/s] */
   double depart_pos;                  /* front position on the first edge at insertion (SUMO "base": the vehicle length) */
+  double probability;                 /* < 0: equally spaced vehicles (`period`).  In [0, 1]: InFlows.add(probability=p),
+                                         params.py:1103-1105 -- in every simulation sub-step between begin and end a
+                                         vehicle is generated with probability p * sim_step (at most `number` of them);
+                                         generated vehicles wait their turn like due ones (M2b, Philox-drawn) */
 } fs_inflow;
 
 /* The self-crossing of the figure eight (SUMO's junction logic restated, unpinned).

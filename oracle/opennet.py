@@ -33,6 +33,9 @@ SUMO-side rules (third-party code, absent; stated here, PARITY UNPINNED -- DESIG
   M2  inflow schedule: the k-th vehicle of a flow is due at begin + k * 3600/vehsPerHour; a vehicle is
       inserted at the end of the first integration step whose START time (n * sim_step, n = steps since
       the simulator started) is >= its due time
+  M2b probabilistic inflow (InFlows.add(probability=p), flow/core/params.py:1103-1105): one trial per sub-step with
+      begin <= now <= end, success probability p * sim_step, at most `number` vehicles; vehicle k is due once k
+      successes have been counted.  Trial = Philox word (sub-step, 2000 + flow, replica, episode) < floor(p dt 2^32)
   M3  insertion: front at departPos = vehicle length ("base"), speed departSpeed; refused (retried next
       step) while the gap to the nearest vehicle ahead on the route is below the SUMO-IDM desired gap
       minGap + max(0, v*tau + v*(v - v_lead) / (2*sqrt(accel*decel))); one vehicle per flow and step
@@ -166,6 +169,7 @@ class MergeOracle:
         self.seq_ctr = np.zeros(R, dtype=np.int64)
         self.ctl_ctr = np.zeros(R, dtype=np.int64)
         self.emitted = np.zeros((R, max(len(self.inflows), 1)), dtype=np.int64)
+        self.generated = np.zeros((R, max(len(self.inflows), 1)), dtype=np.int64)
         self.episode = np.full(R, -1, dtype=np.int64)      # resets so far (-1 before the first): keys the entry-lane draws
         self.num_arrived = np.zeros(R, dtype=np.int64)             # of the last sub-step (get_num_arrived)
         self.num_departed = np.zeros(R, dtype=np.int64)
@@ -466,6 +470,7 @@ class MergeOracle:
         self.lac_a = np.where(m2, T(0), self.lac_a)
         self.last_accel = np.where(m2, T(0), self.last_accel)
         self.emitted = np.where(m2[:, :1], 0, self.emitted)
+        self.generated = np.where(m2[:, :1], 0, self.generated)
         self.episode = np.where(m, self.episode + 1, self.episode)
         self.vmax = np.where(m2, np.array([v.get("sumo_max_speed", 30.0) for v in self.veh], dtype=self.dt_)[None, :],
                              self.vmax)
@@ -492,12 +497,30 @@ class MergeOracle:
         rows = np.arange(R)
         self.num_departed = np.where(active, 0, self.num_departed)
         now = (self.sim_steps - 1).astype(np.float64) * self.dt           # start time of the step that just ran
+        seed = int(self.spec.get("seed", 0))
         for f, fl in enumerate(self.inflows):
             k = self.emitted[:, f]
-            due_t = float(fl["begin"]) + k.astype(np.float64) * float(fl["period"])
-            due = (due_t <= now) & (due_t <= float(fl.get("end", 86400.0)))
-            if fl.get("number", -1) is not None and fl.get("number", -1) >= 0:
-                due &= k < int(fl["number"])
+            prob = fl.get("probability")
+            if prob is not None and prob >= 0:
+                # M2b: InFlows.add(probability=p) -- one Bernoulli(p * sim_step) trial per sub-step between begin and
+                # end (SUMO scales the per-second probability by the step length), at most `number` vehicles; a
+                # generated vehicle waits for its turn like a due one.  Trial = Philox word < floor(p dt 2^32).
+                thr = min(np.floor(float(prob) * float(self.dt) * 4294967296.0), 4294967295.0)
+                r0, _, _, _ = philox4x32_10((self.sim_steps - 1).astype(np.uint32), np.full(R, 2000 + f, dtype=np.uint32),
+                                            (np.arange(R) + int(self.spec.get("replica_offset", 0))).astype(np.uint32),
+                                            (1 + 2 * self.episode).astype(np.uint32),
+                                            np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF))
+                gen = active & (now >= float(fl["begin"])) & (now <= float(fl.get("end", 86400.0))) & \
+                    (r0.astype(np.int64) < int(thr))
+                if fl.get("number", -1) is not None and fl.get("number", -1) >= 0:
+                    gen &= self.generated[:, f] < int(fl["number"])
+                self.generated[:, f] = self.generated[:, f] + gen
+                due = k < self.generated[:, f]
+            else:
+                due_t = float(fl["begin"]) + k.astype(np.float64) * float(fl["period"])
+                due = (due_t <= now) & (due_t <= float(fl.get("end", 86400.0)))
+                if fl.get("number", -1) is not None and fl.get("number", -1) >= 0:
+                    due &= k < int(fl["number"])
             typ = int(fl["type"])
             if int(fl["route"]) < 0:                                      # M9: departLane = "random"
                 r0, _, _, _ = philox4x32_10(k.astype(np.uint32), np.full(R, 1000 + f, dtype=np.uint32),

@@ -179,6 +179,27 @@ def test_vec_env_runs_the_c5_merge_configuration():
     assert torch.isfinite(o).all() and (r >= 0).all()
 
 
+def test_probabilistic_inflow_through_the_env_api():
+    """InFlows.add(probability=p) (params.py:1103-1105, 1080-1213) reaches the kernel through flow_params: about
+    p * T vehicles of that flow depart, differently in every replica."""
+    from flow_amd import _lib as L
+    from flow_amd.core.params import InFlows
+    from flow_amd.envs import MergePOEnv, VecFlowEnv
+    fp = merge_flow_params(MergePOEnv, num_rl=3, horizon=500, n_human=0)
+    inflow = InFlows()
+    inflow.add(veh_type="human", edge="inflow_highway", probability=0.3, departLane="free", departSpeed=10)
+    inflow.add(veh_type="rl", edge="inflow_highway", vehs_per_hour=100, departLane="free", departSpeed=10)
+    fp["net"].inflows = inflow
+    vec = VecFlowEnv(fp, num_replicas=32, device=0)
+    vec.reset()
+    vec.rollout(500)                                     # 100 s of 0.2 s steps: ~0.3 * 99 vehicles of the first flow
+    origin = vec.sim.get_state(L.FS_FIELD_ORIGIN)
+    departed = vec.sim.get_state(L.FS_FIELD_COUNTERS)[:, 6]
+    assert 15 <= departed.mean() <= 45 and len(set(departed.tolist())) > 3, departed
+    assert (origin[origin >= 0] >> 20 <= 1).all()
+    vec.close()
+
+
 def test_simulate_script_runs_the_merge_experiment_and_writes_the_emission_file(tmp_path):
     """examples/simulate.py merge (the reference's examples/exp_configs/non_rl/merge.py experiment, 3600 steps of
     5 sub-steps): runs through install_as_flow() + Experiment.run and leaves a trajectory CSV whose vehicle ids and

@@ -590,3 +590,35 @@ def test_inflows_and_vehicle_types_match_the_reference_golden():
         assert tp["initial_speed"] == want["initial_speed"]
     assert [(t["veh_id"], t["num_vehicles"], t["initial_speed"]) for t in v.initial] == \
         [(t["veh_id"], t["num_vehicles"], t["initial_speed"]) for t in gold["initial"]]
+
+
+def test_probabilistic_inflow_statistics_of_the_oracle():
+    """M2b: a flow with probability p per second generates Binomial(n_trials, p * sim_step) vehicles over n_trials
+    sub-steps; deterministic for a seed, different between replicas and episodes, capped by `number`."""
+    from helpers import merge_spec
+    spec = merge_spec(R=64, cap_human=40, cap_rl=4, num_rl=2, horizon=400, seed=3)
+    spec["vehicles"] = [dict(v, noise=0.0) for v in spec["vehicles"]]
+    fl = dict(spec["inflows"][0], probability=0.5)
+    fl.pop("period")
+    spec["inflows"] = [fl] + [dict(f) for f in spec["inflows"][1:]]
+    a, b = O.MergeOracle(spec, np.float32), O.MergeOracle(spec, np.float32)
+    a.reset(), b.reset()
+    for _ in range(400):
+        a.step(None), b.step(None)
+    np.testing.assert_array_equal(a.generated, b.generated)
+    g = a.generated[:, 0].astype(np.float64)
+    n_trials = 400 - 5 + 1                      # trials start at now = begin = 1.0 s = sub-step 5 (now = (n - 1) * 0.2)
+    mean, std = n_trials * 0.5 * 0.2, (n_trials * 0.1 * 0.9) ** 0.5
+    assert abs(g.mean() - mean) < 4 * std / 8 and 0.5 * std < g.std() < 1.6 * std, (g.mean(), g.std(), mean, std)
+    assert (a.emitted[:, 0] <= a.generated[:, 0]).all()
+    first = a.generated[:, 0].copy()
+    a.reset()
+    for _ in range(400):
+        a.step(None)
+    assert (a.generated[:, 0] != first).any()   # the next episode draws anew
+    fl2 = dict(fl, number=7)
+    c = O.MergeOracle(dict(spec, inflows=[fl2] + spec["inflows"][1:]), np.float32)
+    c.reset()
+    for _ in range(400):
+        c.step(None)
+    assert (c.generated[:, 0] == 7).all()

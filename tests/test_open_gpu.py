@@ -208,6 +208,83 @@ def compare_vmax(sim, ora):
     np.testing.assert_array_equal(got[ora.alive], ora.vmax[ora.alive])
 
 
+def with_probabilistic_inflows(spec, probs, number=None, window=None):
+    """The spec with inflow f given a per-second probability probs[f] instead of its period (None keeps it)."""
+    spec = dict(spec)
+    flows = []
+    for f, fl in enumerate(spec["inflows"]):
+        fl = dict(fl)
+        if f < len(probs) and probs[f] is not None:
+            fl["probability"] = float(probs[f])
+            fl.pop("period", None)
+            if number is not None:
+                fl["number"] = int(number)
+            if window is not None:
+                fl["begin"], fl["end"] = window
+        flows.append(fl)
+    spec["inflows"] = flows
+    return spec
+
+
+def test_merge_probabilistic_inflows_f32_bit_exact_incl_reset_and_limits():
+    # InFlows.add(probability=p) (params.py:1103-1105): one Philox trial per flow and sub-step; a mix of a
+    # probabilistic highway flow, a deterministic RL flow and a probabilistic on-ramp flow with a vehicle count limit
+    base = quiet(merge_spec(R=9, cap_human=14, cap_rl=4, num_rl=3, horizon=260, seed=6))
+    spec = with_probabilistic_inflows(base, [0.45, None, 0.2])
+    spec["inflows"][2]["number"] = 4
+    ora = run_pair(spec, "f32", 260, uniform_actions(spec, 4))
+    assert ora.generated[:, 0].min() > 5 and (ora.generated[:, 2] <= 4).all() and ora.generated[:, 2].max() == 4
+    assert len(set(ora.generated[:, 0].tolist())) > 1                   # replicas draw their own sequences
+    # a second episode of the same handle draws a different sequence (episode-keyed), the oracle alike
+    sim = make(spec, "f32")
+    o2 = O.MergeOracle(spec, np.float32)
+    sim.reset(), o2.reset()
+    for _ in range(40):
+        sim.step(None), o2.step(None)
+    first = sim.get_state(__import__("flow_amd")._lib.FS_FIELD_COUNTERS)[:, 6].copy()
+    np.testing.assert_array_equal(sim.reset(), o2.reset().astype(np.float32))
+    for _ in range(40):
+        og, _, _ = sim.step(None)
+        orf, _, _ = o2.step(None)
+    np.testing.assert_array_equal(og, orf.astype(np.float32))
+    second = sim.get_state(__import__("flow_amd")._lib.FS_FIELD_COUNTERS)[:, 6]
+    assert (first != second).any()
+    sim.close()
+
+
+def test_probabilistic_inflow_window_and_rollout_equals_stepping():
+    import torch
+    base = quiet(merge_spec(R=6, cap_human=14, cap_rl=4, num_rl=2, horizon=150, seed=8))
+    spec = with_probabilistic_inflows(base, [1.0, None, None], window=(3.0, 9.0))     # p = 1: a trial succeeds iff in the window
+    ora = run_pair(spec, "f32", 150, uniform_actions(spec, 2))
+    # trials at now = 3.0 .. 9.0 in steps of 0.2 s, each with p * dt = 0.2
+    assert 0 < ora.generated[:, 0].min() and ora.generated[:, 0].max() <= 31
+    a, b = make(spec, "f32"), make(spec, "f32")
+    a.reset(), b.reset()
+    for _ in range(60):
+        a.step(None)
+    dev = torch.device("cuda", 0)
+    o = torch.empty((60, 6, a.obs_dim), device=dev)
+    r = torch.empty((60, 6), device=dev)
+    d = torch.empty((60, 6), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    b.rollout_dev(60, o, r, d)
+    b.sync()
+    np.testing.assert_array_equal(a.pos, b.pos)
+    np.testing.assert_array_equal(a.get_state(__import__("flow_amd")._lib.FS_FIELD_ROUTE), b.get_state(__import__("flow_amd")._lib.FS_FIELD_ROUTE))
+    a.close(), b.close()
+
+
+def test_bottleneck_probabilistic_random_lane_inflows_both_kernels():
+    # the lane-drop network: 64-slot kernel and the wide kernel (one workgroup per replica), random entry lanes
+    from helpers import bottleneck_spec
+    for caps in ((48, 8), (90, 10)):
+        spec = bottleneck_spec(R=3, cap_human=caps[0], cap_rl=caps[1], horizon=220, seed=11, q=2300.0)
+        spec = with_probabilistic_inflows(spec, [0.55, 0.08])
+        ora = run_pair(spec, "f32", 220, bottleneck_actions(spec, 3))
+        assert ora.generated[:, 0].min() > 10 and ora.total_departed.min() > 10
+
+
 def test_bottleneck_desired_velocity_f32_bit_exact():
     from helpers import bottleneck_spec
     spec = bottleneck_spec(R=5, cap_human=48, cap_rl=8, horizon=500, seed=3)
