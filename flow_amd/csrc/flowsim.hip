@@ -324,6 +324,9 @@ struct Sim : SimBase {
     if ((rc = dev_alloc(&ov.generated, size_t(R) * FS_MAX_INFLOWS))) return rc;
     if ((rc = dev_alloc(&ov.episode, size_t(R)))) return rc;
     HIP_TRY(hipMemset(ov.episode, 0xFF, size_t(R) * sizeof(int32_t)));     // -1: fs_create's own reset below is not an episode
+    HIP_TRY(hipMemset(ov.ctl_seq, 0xFF, RN * sizeof(int32_t)));            // rl_veh starts empty (a reset keeps it, O2)
+    HIP_TRY(hipMemset(ov.origin, 0xFF, RN * sizeof(int32_t)));
+    HIP_TRY(hipMemset(ov.counters, 0, size_t(R) * 8 * sizeof(int32_t)));
     if ((rc = upload(&ov.init_alive, init_alive))) return rc;
     std::vector<int32_t> st(N);
     int n_rl_slots = 0;
@@ -1046,6 +1049,8 @@ int validate(const fs_config* c) {
     }
     if (!(v.length > 0)) return fail(FS_ERR_INVALID, "fs_create: vehicle length <= 0");
   }
+  if (c->env == FS_ENV_MERGE_PO && c->num_rl > 32)      // the removal pass of rl_veh keeps the list places in one 32-bit mask
+    return fail(FS_ERR_UNSUPPORTED, "fs_create: MergePOEnv with more than 32 controlled places (num_rl) is not built");
   if (seen_rl != c->num_rl && c->env != FS_ENV_MERGE_PO && !bn_env)
     return fail(FS_ERR_INVALID, "fs_create: num_rl does not match the RL slots");
   if (open_net) {

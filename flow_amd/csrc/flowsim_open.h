@@ -705,8 +705,9 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       // RL command (envs/base.py:355 runs before additional_command: the rl_veh list of the last sub-step)
       bool have_rl = false;
       T a_rl = T(0);
+      const int po_place = po_env ? ctl_rank() : -1;        // my place in rl_veh as the last additional_command left it
       if (po_env) {
-        const int rank = ctl_rank();
+        const int rank = po_place;
         have_rl = (act != nullptr) && is_rl && alive && rank >= 0 && rank < num_rl;
         if (have_rl) a_rl = T(act[rank]);
       } else if (o.ma_apply_actions && act != nullptr && is_rl && alive) {
@@ -730,7 +731,21 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       // ---- MergePOEnv.additional_command (merge.py:189-221) --------------------------------------------
       if (po_env) {
         const bool alive_rl = alive && is_rl;
-        if (live && !alive_rl) ctl_seq = -1;
+        // `for veh_id in self.rl_veh: if veh_id not in rl_ids: self.rl_veh.remove(veh_id)` (merge.py:206-208) removes
+        // from the list it iterates: the entry behind a removed one is skipped, so of a RUN of consecutive entries
+        // that have left only the 1st, 3rd, ... go in this pass; the others stay listed (ghost rows of error values
+        // in get_state, merge.py:128-156) for another sub-step.  D = the departed entries as a mask over list places
+        // (a seg_or of 1 << place), run = the departed entries directly in front of mine.
+        {
+          const int place = po_place;
+          const bool gone = place >= 0 && !alive_rl;
+          const unsigned D = seg_or<SEG>(gone ? (1u << (place & 31)) : 0u);
+          const unsigned below = place > 0 ? ((1u << (place & 31)) - 1u) : 0u;
+          const unsigned holes = ~D & below;                       // places in front of mine that have NOT left
+          const int run = holes != 0u ? (place - 1) - (31 - __clz(int(holes))) : place;
+          if (live && gone && (run & 1) == 0) ctl_seq = -1;
+          if (live && place < 0) ctl_seq = -1;                     // (not listed)
+        }
         const int n_ctl = __popcll(seg_ballot<SEG>(ctl_seq >= 0, seg));
         const int free_places = num_rl - n_ctl > 0 ? num_rl - n_ctl : 0;
         const bool queued = alive_rl && ctl_seq < 0;
@@ -839,7 +854,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
           route_f = int((uint64_t(c0 >> 8) * uint64_t(P)) >> 24);
         }
         const bool alive_now = route >= 0;
-        const bool free_slot = !alive_now && slot_ok && (my_type == typ) && !just_arrived;
+        const bool free_slot = !alive_now && slot_ok && (my_type == typ) && !just_arrived && ctl_seq < 0;   // (a listed ghost keeps its slot)
         const unsigned long long fb = seg_ballot<SEG>(free_slot, seg);
         const int slot = fb ? __ffsll((long long)fb) - 1 : 0;
         const T x_dep = tb.template t<TAB_FL_XDEP>(f);
@@ -1002,10 +1017,20 @@ __global__ void k_reset_open(DevView<T> s, OpenView<T> o, const uint8_t* __restr
     s.ctrl_state[e] = T(0);
     s.lane[e] = a ? s.init_lane[e] : -1;
     o.seq[e] = a ? ids : 0;
+    const int old_origin = o.origin[e];
+    const bool po_keep = s.env == FS_ENV_MERGE_PO;
     o.origin[e] = a ? -1 - i : -1;
     o.foll[e] = -1;
     o.foll_h[e] = T(3.0e38);
-    o.ctl_seq[e] = -1;
+    // MergePOEnv never clears rl_veh (merge.py:223-231 resets only leader / follower): the vehicles it lists at the end
+    // of an episode stay listed into the next one -- an initial vehicle that is placed again keeps its place, every
+    // other entry is a vehicle that no longer exists (a ghost row until additional_command has removed it, subject to
+    // the skipping above).  A slot that an initial vehicle needs cannot also hold such a ghost: that entry is dropped.
+    {
+      const int old_ctl = o.ctl_seq[e];
+      const bool same_vehicle = a && old_origin == -1 - i;
+      o.ctl_seq[e] = (po_keep && old_ctl >= 0 && (same_vehicle || !a)) ? old_ctl : -1;
+    }
     o.arrived_rl[e] = 0;
     o.vmax[e] = s.sumo_max_speed[i];
     s.last_lc[e] = -(1 << 30);
@@ -1021,7 +1046,8 @@ __global__ void k_reset_open(DevView<T> s, OpenView<T> o, const uint8_t* __restr
       int32_t* cnt = o.counters + size_t(r) * 8;
       cnt[CNT_SIM_STEPS] = 1;
       cnt[CNT_SEQ] = total;
-      for (int q = 2; q < 8; ++q) cnt[q] = 0;
+      for (int q = 2; q < 8; ++q)
+        if (!(q == CNT_CTL && s.env == FS_ENV_MERGE_PO)) cnt[q] = 0;      // (the join counter orders rl_veh: it goes on)
       for (int q = 0; q < 20; ++q) o.arr_hist[size_t(r) * 20 + q] = 0;
       s.time[r] = 0;
       o.episode[r] += 1;                           // a new episode draws new entry lanes (the reference re-seeds SUMO)

@@ -31,9 +31,9 @@ class MergePOEnv(Env):
     place in ``rl_veh``.  Reward: desired-velocity term minus a small-time-headway penalty.  A rollout ends
     at the horizon or on a collision.
 
-    Not reproduced (documented in DESIGN.md): rl_veh surviving ``reset`` (the reference never clears it), and
-    the skipped element when two consecutive entries of rl_veh leave in the same sub-step (merge.py:206-208
-    removes from the list it iterates)."""
+    As in the reference, ``rl_veh`` survives ``reset`` (merge.py:223-231 never clears it: the entries of the last
+    episode open the next one as rows of error values) and the loop that drops departed entries skips the entry behind
+    each one it removes (merge.py:208-210 removes from the list it iterates); DESIGN.md O2."""
 
     FS_ENV = L.FS_ENV_MERGE_PO
 

@@ -394,8 +394,19 @@ class MergeOracle:
             return
         alive_rl = self.alive & self.is_rl[None, :]
         a2 = active[:, None]
-        # vehicles that left are dropped from rl_veh (and from the queue, which is implicit here)
-        self.ctl_seq = np.where(a2 & ~alive_rl, -1, self.ctl_seq)
+        # vehicles that left are dropped from rl_veh -- by a loop that removes from the list it iterates
+        # (merge.py:206-208): the entry behind a removed one is skipped, so of a run of consecutive departed entries
+        # only the 1st, 3rd, ... go in this pass (the queue, implicit here, is pruned over a copy: no skipping)
+        rank = self._ctl_rank()
+        gone = (rank >= 0) & ~alive_rl
+        removed_prev = np.zeros(self.R, dtype=bool)
+        removed = np.zeros_like(gone)
+        for t in range(int(rank.max()) + 1 if rank.size else 0):
+            at_t = rank == t
+            rem_t = (gone & at_t).any(axis=1) & ~removed_prev
+            removed |= at_t & rem_t[:, None]
+            removed_prev = rem_t
+        self.ctl_seq = np.where(a2 & removed, -1, self.ctl_seq)
         n_ctl = (self.ctl_seq >= 0).sum(axis=1)
         free = np.maximum(self.num_rl - n_ctl, 0)
         queued = alive_rl & (self.ctl_seq < 0)
@@ -461,12 +472,21 @@ class MergeOracle:
         self.route = np.where(m2, np.where(self.init_alive, self.init_route, -1), self.route)
         ids = np.cumsum(self.init_alive, axis=1) - 1                       # id-list order = slot order at reset
         self.seq = np.where(m2, np.where(self.init_alive, ids, 0), self.seq)
+        old_origin = self.origin.copy()
         self.origin = np.where(m2, np.where(self.init_alive, -1 - np.arange(N)[None, :], -1), self.origin)
         self.seq_ctr = np.where(m, self.init_alive.sum(axis=1), self.seq_ctr)
         self.foll = np.where(m2, -1, self.foll)
         self.foll_h = np.where(m2, T(BIG), self.foll_h)
-        self.ctl_seq = np.where(m2, -1, self.ctl_seq)
-        self.ctl_ctr = np.where(m, 0, self.ctl_ctr)
+        if self.env == ENV_MERGE_PO:
+            # MergePOEnv.reset (merge.py:223-231) clears leader / follower only: rl_veh goes into the next episode.  An
+            # initial vehicle placed again keeps its place; every other entry is now a vehicle that does not exist (a
+            # ghost row until additional_command drops it); a slot an initial vehicle needs cannot hold a ghost too
+            same = self.init_alive & (old_origin == -1 - np.arange(N)[None, :])
+            keep = (self.ctl_seq >= 0) & (same | ~self.init_alive)
+            self.ctl_seq = np.where(m2 & ~keep, -1, self.ctl_seq)
+        else:
+            self.ctl_seq = np.where(m2, -1, self.ctl_seq)
+            self.ctl_ctr = np.where(m, 0, self.ctl_ctr)
         self.lac_a = np.where(m2, T(0), self.lac_a)
         self.last_accel = np.where(m2, T(0), self.last_accel)
         self.emitted = np.where(m2[:, :1], 0, self.emitted)
@@ -531,7 +551,7 @@ class MergeOracle:
                 route = (((r0 >> np.uint32(8)).astype(np.int64) * self.P) >> 24)
             else:
                 route = np.full(R, int(fl["route"]), dtype=np.int64)
-            free = (~self.alive) & (self.slot_type[None, :] == typ) & ~self._just_arrived
+            free = (~self.alive) & (self.slot_type[None, :] == typ) & ~self._just_arrived & (self.ctl_seq < 0)
             slot = np.argmax(free, axis=1)                                 # lowest free slot of the type
             has_slot = free.any(axis=1)
             vs = self.veh[int(np.flatnonzero(self.slot_type == typ)[0])]

@@ -622,3 +622,74 @@ def test_probabilistic_inflow_statistics_of_the_oracle():
     for _ in range(400):
         c.step(None)
     assert (c.generated[:, 0] == 7).all()
+
+
+def test_merge_po_lists_follow_the_reference_list_operations_across_resets():
+    """O2: MergePOEnv.additional_command (merge.py:189-221) restated with its own Python list operations -- including
+    `for veh_id in self.rl_veh: ... self.rl_veh.remove(veh_id)` (removing from the list being iterated skips the next
+    entry) and the fact that reset() (merge.py:223-231) never clears rl_veh -- and driven by the vehicles the oracle
+    has in the network at every call: the oracle's rl_veh (slots ordered by ctl_seq) must be that list, step by step,
+    over three episodes."""
+    import collections
+    from helpers import merge_spec
+    spec = merge_spec(R=3, cap_human=10, cap_rl=8, num_rl=4, horizon=10 ** 6, seed=5, q_rl=1500.0, q_highway=600.0)
+    spec["vehicles"] = [dict(v, noise=0.0) for v in spec["vehicles"]]
+    ora = O.MergeOracle(spec, np.float32)
+    R, num_rl = 3, 4
+    queues = [collections.deque() for _ in range(R)]
+    lists = [[] for _ in range(R)]
+    skipped = [0]
+
+    def vehicle_ids(r):
+        """ids of the RL vehicles of replica r now in the network, in the order they entered"""
+        alive = ora.alive[r] & ora.is_rl
+        slots = sorted(np.flatnonzero(alive), key=lambda i: ora.seq[r, i])
+        return [(int(ora.episode[r]) if ora.origin[r, i] >= 0 else -1, int(ora.origin[r, i])) for i in slots]
+
+    def oracle_list(r):
+        slots = sorted(np.flatnonzero(ora.ctl_seq[r] >= 0), key=lambda i: ora.ctl_seq[r, i])
+        return [i for i in slots]
+
+    original = ora._additional_command
+
+    def hooked(active):
+        for r in range(R):
+            if not active[r]:
+                continue
+            rl_ids = vehicle_ids(r)
+            rl_queue, rl_veh = queues[r], lists[r]
+            for veh_id in rl_ids:                                     # merge.py:201-203
+                if veh_id not in list(rl_queue) + rl_veh:
+                    rl_queue.append(veh_id)
+            for veh_id in list(rl_queue):                             # :205-207
+                if veh_id not in rl_ids:
+                    rl_queue.remove(veh_id)
+            before = len(rl_veh)
+            gone = sum(1 for v in rl_veh if v not in rl_ids)
+            for veh_id in rl_veh:                                     # :208-210 (iterates the list it shrinks)
+                if veh_id not in rl_ids:
+                    rl_veh.remove(veh_id)
+            skipped[0] += gone - (before - len(rl_veh))
+            while len(rl_queue) > 0 and len(rl_veh) < num_rl:         # :213-215
+                rl_veh.append(rl_queue.popleft())
+        original(active)
+        for r in range(R):
+            if not active[r]:
+                continue
+            got = []
+            for i in oracle_list(r):
+                alive = ora.alive[r, i] and ora.is_rl[i]
+                got.append((int(ora.episode[r]) if ora.origin[r, i] >= 0 else -1, int(ora.origin[r, i])) if alive else None)
+            want = [v if v in vehicle_ids(r) else None for v in lists[r]]
+            assert got == want, (r, got, want)
+
+    ora._additional_command = hooked
+    ora.reset()
+    for episode in range(3):
+        for _ in range(220):
+            ora.step(np.zeros((R, num_rl), dtype=np.float32))
+        assert all(len(v) == num_rl for v in lists)                   # the places are taken when the episode ends
+        obs = ora.reset()
+        # the first observation of the next episode shows the stale entries as rows of the accessors' error values
+        np.testing.assert_allclose(obs[:, 0], -1001.0 / 30.0, rtol=1e-6)
+    assert skipped[0] > 0                                             # the skipping did occur (after every reset)

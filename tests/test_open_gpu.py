@@ -208,6 +208,35 @@ def compare_vmax(sim, ora):
     np.testing.assert_array_equal(got[ora.alive], ora.vmax[ora.alive])
 
 
+def test_merge_po_rl_veh_survives_reset_and_skips_while_removing_bit_exact():
+    # O2 (merge.py:189-231): reset() never clears rl_veh -- the next episode starts with the old entries as ghost rows
+    # of error values, removed by a loop that skips the entry behind each one it removes -- kernel and oracle agree bit
+    # for bit over three episodes (tests/test_open_cpu.py holds the oracle to the reference's literal list operations)
+    spec = quiet(merge_spec(R=7, cap_human=10, cap_rl=8, num_rl=4, horizon=10 ** 6, seed=5, q_rl=1500.0, q_highway=600.0))
+    ora = O.MergeOracle(spec, np.float32)
+    sim = make(spec, "f32")
+    act = uniform_actions(spec, 3, lo=-0.5, hi=1.0)
+    np.testing.assert_array_equal(sim.reset(), ora.reset().astype(np.float32))
+    ghost_steps = 0
+    for episode in range(3):
+        for k in range(200):
+            a = act(k)
+            o_ref, r_ref, d_ref = ora.step(a)
+            o_gpu, r_gpu, d_gpu = sim.step(a)
+            np.testing.assert_array_equal(o_gpu, o_ref.astype(np.float32), err_msg="episode %d step %d" % (episode, k))
+            np.testing.assert_array_equal(r_gpu, r_ref.astype(np.float32))
+            if episode > 0 and k < 4:
+                ghost_steps += int((o_ref[:, 0::5] < -30).any())
+        compare_state(sim, ora)
+        assert ((ora.ctl_seq >= 0).sum(axis=1) == 4).all()
+        o_reset = ora.reset().astype(np.float32)
+        np.testing.assert_array_equal(sim.reset(), o_reset)
+        assert (o_reset[:, 0::5] < -30).all()                      # four stale entries: four rows of error values
+        compare_state(sim, ora)
+    assert ghost_steps >= 2                                        # the skipped entries outlive the first pass
+    sim.close()
+
+
 def with_probabilistic_inflows(spec, probs, number=None, window=None):
     """The spec with inflow f given a per-second probability probs[f] instead of its period (None keeps it)."""
     spec = dict(spec)
