@@ -645,6 +645,9 @@ def main():
         out["cpu_baseline"] = None
 
     if use_dist:
+        # rank 0 has just spent seconds on the roofline / parity launches: the others wait for it here, so that no rank
+        # tears its communicator down while a peer is still inside the job
+        barrier()
         dist.destroy_process_group()
     if rank == 0:
         sys.stdout.flush()
