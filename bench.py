@@ -369,18 +369,41 @@ def launch_bytes(R, N, K, precision):
     return R * (K * obs_b + state_b), obs_b + state_b / float(K)
 
 
-def pmc_traffic(precision, R, K):
-    """HBM bytes per launch from the committed PMC summary of THIS kernel (profiles/r02_*), or None."""
+def pmc_summary(precision, R, K):
+    """The committed PMC summary of THIS kernel at THIS launch shape (profiles/r02_*), or None."""
     path = os.path.join(ROOT, "profiles", "r02_pmc_summary_%s.json" % precision)
     try:
         tj = json.load(open(path))
         # rocprofv3 prints the kernel as "void fs::k_...<...>(args)": the bench line's name is a substring of it
         if tj.get("replicas") == R and tj.get("steps_per_launch") == K and KERNEL_NAMES[precision] in tj.get(
                 "kernel", ""):
-            return tj.get("hbm_bytes_per_launch"), os.path.basename(path)
+            return tj, os.path.basename(path)
     except Exception:
         pass
     return None, None
+
+
+def pmc_traffic(precision, R, K):
+    """HBM bytes per launch from that summary, or None."""
+    tj, src = pmc_summary(precision, R, K)
+    return (tj.get("hbm_bytes_per_launch"), src) if tj else (None, None)
+
+
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0     # wave-instructions per ns the chip can issue: 1024 SIMDs, one wave64 VALU
+#                                           instruction per 4 cycles each, 2.4 GHz (MI355X_MICROARCH.md) = 614.4 G/s
+
+
+def valu_issue(precision, R, K, avg_s):
+    """The second roof of this kernel: it is instruction-bound (about 20 VALU instructions per env step, most of them
+    packed float32; scripts/sweep_pair.sh: the same kernel on a FULL chip reaches 0.49 of the HBM roof, not more).
+    Wave-instructions per launch from the PMC summary (SQ_INSTS_VALU) over the launch time measured here."""
+    tj, src = pmc_summary(precision, R, K)
+    try:
+        insts = float(tj["counters_per_launch"]["SQ_INSTS_VALU"]["mean"])
+    except Exception:
+        return None
+    return {"valu_insts_per_launch": insts, "valu_insts_per_env_step": insts / (R * K), "achieved_Ginst_s": insts / avg_s / 1e9,
+            "peak_Ginst_s": VALU_PEAK_GINST, "frac": insts / avg_s / 1e9 / VALU_PEAK_GINST, "source": src}
 
 
 def rollout_1500_leg(device, precision, R, launches=6, check_parity=True):
@@ -434,7 +457,8 @@ def rollout_1500_leg(device, precision, R, launches=6, check_parity=True):
             "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[precision], "achieved": nbytes / avg_s / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / avg_s / 1e9 / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": src, "bytes_per_launch": nbytes,
-                         "steps_per_launch": K, "avg_launch_ms": avg_s * 1e3, "bytes_per_env_step": per_step},
+                         "steps_per_launch": K, "avg_launch_ms": avg_s * 1e3, "bytes_per_env_step": per_step,
+                         "valu_issue": valu_issue(precision, R, K, avg_s)},
             "parity": parity}
 
 
