@@ -576,9 +576,10 @@ struct Sim : SimBase {
     if (open_net) {
       // the float32 instantiations exist twice: CSET = 1 for populations of IDM / RL / Sim slots only
       const bool cset = std::is_same<T, float>::value && (dv.flags & fs::FLAG_IDM_SET) && !force_generic;
-#define FS_OPEN(P_, C_)                                                                                          \
-  hipLaunchKernelGGL((fs::k_steps_open<T, SEG, P_, C_>), dim3(blocks), dim3(64), 0, stream, dv, ov, num_steps, mask, \
-                     actions, act_stride, obs, rew, done, obs_every_step, after_reset)
+#define FS_OPEN_(P_, C_, PR_)                                                                                    \
+  hipLaunchKernelGGL((fs::k_steps_open<T, SEG, P_, C_, PR_>), dim3(blocks), dim3(64), 0, stream, dv, ov, num_steps,  \
+                     mask, actions, act_stride, obs, rew, done, obs_every_step, after_reset)
+#define FS_OPEN(P_, C_) do { if (ov.n_prob > 0) FS_OPEN_(P_, C_, true); else FS_OPEN_(P_, C_, false); } while (0)
       last_kernel = "k_steps_open";
       if (cfg.network == FS_NET_BOTTLENECK) {
         // the lane-drop heads need more than 32 slots (fs_create checks it): only the 64-lane segment is built
@@ -591,6 +592,7 @@ struct Sim : SimBase {
         if (cset) FS_OPEN(2, (std::is_same<T, float>::value ? 1 : 0)); else FS_OPEN(2, 0);
       }
 #undef FS_OPEN
+#undef FS_OPEN_
       HIP_TRY(hipGetLastError());
       return FS_OK;
     }

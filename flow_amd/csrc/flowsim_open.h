@@ -255,7 +255,9 @@ __device__ __forceinline__ int cell_of(const TABS& tb, int span, T x, int seg_k,
 // P = number of paths (entry lanes): 2 = MergeNetwork (each path has its own segment table), 4 = BottleneckNetwork
 // (one table; lanes 2q / 2q+1 join at m1, the two resulting lanes at m2)
 // CSET = 1: every slot is an IDM / RL / Sim-car-following controller (FLAG_IDM_SET), see control_accel_on
-template <typename T, int SEG, int P, int CSET = 0>
+// PROB: some inflow is probabilistic (M2b) -- its own instantiation: the per-sub-step trial and the schedule's second
+// form cost the deterministic configurations 7 % (C5) when they were run-time branches of one kernel
+template <typename T, int SEG, int P, int CSET = 0, bool PROB = false>
 __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, int num_steps,
                                                    const uint8_t* __restrict__ mask,
                                                    const float* __restrict__ actions, size_t act_stride,
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
   // trial per flow and step between begin and end): lane f of the segment makes inflow f's trial of the sub-step -- a
   // Philox word keyed by (sub-step, 2000 + f, global replica, episode) against a 32-bit threshold -- and counts the
   // vehicles generated; vehicle k of the flow is due once k < generated
-  const bool prob_any = o.n_prob > 0;
+  constexpr bool prob_any = PROB;
   const bool my_flow = prob_any && i < o.n_inflows;
   const double my_per = my_flow ? o.flow_tab_d[i] : 0.0;
   const bool my_prob = my_per < 0.0;
@@ -705,8 +707,9 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       // RL command (envs/base.py:355 runs before additional_command: the rl_veh list of the last sub-step)
       bool have_rl = false;
       T a_rl = T(0);
-      const int po_place = po_env ? ctl_rank() : -1;        // my place in rl_veh as the last additional_command left it
+      int po_place = -1;                                    // my place in rl_veh as the last additional_command left it
       if (po_env) {
+        po_place = ctl_rank();
         const int rank = po_place;
         have_rl = (act != nullptr) && is_rl && alive && rank >= 0 && rank < num_rl;
         if (have_rl) a_rl = T(act[rank]);
@@ -838,7 +841,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       for (int f = 0; any_due && f < o.n_inflows; ++f) {
         const int k = seg_read_i<SEG>(emit_l, f, seg);
         const double per_f = tb.template fd<0>(f);
-        const bool prob_f = per_f < 0.0;
+        const bool prob_f = PROB && per_f < 0.0;
         const int g = prob_f ? seg_read_i<SEG>(gen_l, f, seg) : 0;
         const double due_t = prob_f ? (k < g ? -1.0e300 : 1.0e300) : tb.template fd<1>(f) + double(k) * per_f;
         nd = (due_t < nd) ? due_t : nd;
