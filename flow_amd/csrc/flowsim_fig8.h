@@ -67,6 +67,16 @@ __device__ __forceinline__ float sumo_fast(float v, float vl, float h, bool has,
 // FULL: the launch is known to have noisy slots, speed-mode clamps / uncommanded slots, the crossing and an action
 // tensor (BASELINE's C3 and the reference's figure-eight experiments): the four launch-constant tests become
 // compile-time facts instead of taken branches (a wave alone on its SIMD pays an instruction-fetch bubble for each).
+// Predicates as VALU integers.  hipcc turns every `a & b` of two float compares into v_cmp, v_cmp, s_and_b64 -- and a
+// scalar operation on a VALU-written mask waits ~14 cycles for it (scripts/ubench), ~30 times per step of this kernel.
+// A float difference carries the same fact in its sign bit (a - b is never -0 for a != b, +0 for a == b; denormals
+// are kept): sign masks are combined with v_and / v_or / v_bfi and become a bool (one v_cmp) only where a select
+// needs it.  Bit 31 of the result is the predicate, the other bits are junk.
+__device__ __forceinline__ unsigned fbits(float a) { return __builtin_bit_cast(unsigned, a); }
+__device__ __forceinline__ unsigned sm_lt(float a, float b) { return fbits(a - b); }                      // a < b
+__device__ __forceinline__ unsigned sm_in(float x, float lo, float hi) { return ~fbits(x - lo) & fbits(x - hi); }  // lo <= x < hi
+__device__ __forceinline__ bool sm_true(unsigned m) { return int(m) < 0; }
+
 // A wave-wide test whose result steers a branch, evaluated HERE: a scalar branch that reads a VALU-written mask in
 // the next instruction stands still for ~35 cycles (scripts/ubench: v_cmp + s_cbranch_vccz 44.6 cycles against 13 for
 // the two alone) -- a wave alone on its SIMD has nothing to fill that with, so every such test of the step is
@@ -173,6 +183,11 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
   const bool red_lane = ii < num_rl && i < N;
   const int obs_dim = HEAD == 1 ? 3 : 2 * N;
   const bool obs_lane = HEAD == 1 ? (valid && rl_lane && sl.rl_index == 0) : valid;
+  const unsigned valid_bits = valid ? 0xFu : 0u;          // flag words of idle lanes are empty
+  const unsigned gate_u = gated ? 1u : 0u, cmd_rl = (rl_lane && use_act) ? 1u : 0u,
+                 cmd_other = (!rl_lane && !sim_lane) ? 1u : 0u, sm1_u = unsigned(sl.speed_mode) & 1u;
+  const bool sm1_lane = (sl.speed_mode & 1) != 0;
+  const T adt_c = (sl.speed_mode & 2) ? sl.max_accel * dt : T(3.0e38), ddt_c = (sl.speed_mode & 4) ? sl.max_decel * dt : T(3.0e38);
 
   // RL actions are read PERIOD steps ahead, into the register the step PERIOD steps earlier has just consumed (slot s
   // of a block <-> element s: static after unrolling).  The action tensor is streamed once -- every step's row is a
@@ -251,17 +266,22 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
         // the step's wave-wide tests whose inputs are the snapshot: evaluated first, consumed where they steer
         const unsigned long long draw_m = any_noise ? ballot_here(noisy && (nctr & 3u) == 0u) : 0ull;
         unsigned jf = 0u;
-        bool on_a = false, on_b = false;
+        bool on_a = false, on_b = false, on_any = false, on_both = false;
         unsigned long long cap_m = 0ull, cap2_m = 0ull;
         if (junction_on) {
           // per-replica facts of the snapshot, one OR-butterfly: bit 0 stream a busy, bit 1 stream b in the box
-          jf |= (valid & (x >= ja_in - tgap * v) & (x < ja_out + sl.length)) ? 1u : 0u;
-          jf |= (valid & (x >= jb_in) & (x < jb_out + sl.length)) ? 2u : 0u;
+          const unsigned busy_a = sm_in(x, ja_in - tgap * v, ja_out + sl.length);
+          const unsigned in_b = sm_in(x, jb_in, jb_out + sl.length);
+          jf = ((busy_a >> 31) | ((in_b >> 31) << 1)) & valid_bits;
           jf = seg_or<SEG>(jf);
-          on_b = (x >= jb_in - look) & (x < jb_in) & ((jf & 1u) != 0u);
-          on_a = (x >= ja_in - look) & (x < ja_in) & ((jf & 2u) != 0u);
-          cap_m = ballot_here(on_a || on_b);
-          cap2_m = ballot_here(on_a && on_b);
+          const unsigned on_b_m = sm_in(x, jb_in - look, jb_in) & (jf << 31);
+          const unsigned on_a_m = sm_in(x, ja_in - look, ja_in) & (jf << 30);
+          on_b = sm_true(on_b_m);
+          on_a = sm_true(on_a_m);
+          on_any = sm_true(on_a_m | on_b_m);
+          on_both = sm_true(on_a_m & on_b_m);
+          cap_m = ballot_here(on_any);
+          cap2_m = ballot_here(on_both);
         }
         const float a_own = a_own_q[slot], a_red = a_red_q[slot];
         asm volatile("" :: "v"(a_own), "v"(a_red));             // the wait for the prefetched action happens HERE
@@ -273,9 +293,12 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
           a_red_q[slot] = an[red_col];
         }
         // ---- controllers on the snapshot (control_accel_on, CSET = 1) ----------------------------------
-        const bool on_edge = gated ? !((seg_internal >> k) & 1u) : true;
+        // commanded (base_controller.py:93-106): an RL lane when there are actions, never a SimCarFollowing lane, any
+        // other lane unless it is gated off an internal edge -- as an integer (constants: cmd_rl, cmd_other, gate_u)
+        const unsigned on_edge_u = 1u ^ (gate_u & (seg_internal >> k));
+        const unsigned commanded_u = (on_edge_u & cmd_other) | cmd_rl;
+        const bool commanded = commanded_u != 0u;
         T acc = T(0);
-        bool commanded = false;
         if (any_noise) {
           if (draw_m != 0ull) {
             if (noisy && (nctr & 3u) == 0u)
@@ -292,7 +315,6 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
           T arl = T(a_own);
           if (clip) arl = tmin(tmax(arl, act_lo), act_hi);
           acc = rl_lane ? (use_act ? arl : T(0)) : (sim_lane ? T(0) : a);
-          commanded = rl_lane ? use_act : (sim_lane ? false : on_edge);
         }
         // ---- apply_acceleration + SUMO integration (S4-S9) ---------------------------------------------
         T next_vel = tmax(v + acc * dt, T(0));
@@ -300,9 +322,10 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
         T v_new = vc;
         if (need_sumo) {
           T v_sumo = sumo_fast(v, vl, h, has, dt, sc);
-          if (sl.speed_mode & 1) vc = tmin(vc, v_sumo);
-          if (sl.speed_mode & 2) vc = tmin(vc, v + sl.max_accel * dt);
-          if (sl.speed_mode & 4) vc = tmax(vc, v - sl.max_decel * dt);
+          // S7/S8 without a per-slot test: a slot whose bit is clear holds 3e38 in the clamp's place (k_rollout_pair's form)
+          vc = tmin(vc, sm1_lane ? v_sumo : T(3.0e38));
+          vc = tmin(vc, v + adt_c);
+          vc = tmax(vc, v - ddt_c);
           v_new = commanded ? vc : v_sumo;
         }
         if (junction_on) {
@@ -312,12 +335,13 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
           if (cap_m != 0ull) {
             const T line = on_b ? jb_in - x : ja_in - x;
             T cap = sumo_fast(v, T(0), line, true, dt, sc);
-            cap = (on_a || on_b) ? cap : T(3.0e38);
+            cap = on_any ? cap : T(3.0e38);
             if (cap2_m != 0ull) {                                // degenerate table: both lines ahead of one vehicle
               const T cap_a = sumo_fast(v, T(0), ja_in - x, true, dt, sc);
-              cap = (on_a && on_b) ? tmin(cap, cap_a) : cap;
+              cap = on_both ? tmin(cap, cap_a) : cap;
             }
-            if ((sl.speed_mode & 1) || !commanded) v_new = tmin(v_new, cap);
+            const bool cap_applies = (sm1_u | (commanded_u ^ 1u)) != 0u;          // (speed_mode & 1) || !commanded
+            v_new = tmin(v_new, cap_applies ? cap : T(3.0e38));
           }
         }
         T x_new = x + v_new * dt;
@@ -343,18 +367,20 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
         d = xl - x;
         d = d < T(0) ? d + Lv : d;
         h = has ? d - len_lead : T(1000);
-        unsigned f2 = (valid & (h < crash_gap)) ? 1u : 0u;
+        // bit 0 a gap below crash_gap, bits 1 / 2 a body on the crossing point of stream a / b, bit 3 v < -100 (sign masks)
+        unsigned f2 = sm_lt(h, crash_gap) >> 31;
         if (junction_on) {
-          f2 |= (valid & (x >= za_lo) & (x < za_hi)) ? 2u : 0u;
-          f2 |= (valid & (x >= zb_lo) & (x < zb_hi)) ? 4u : 0u;
+          f2 |= (sm_in(x, za_lo, za_hi) >> 31) << 1;
+          f2 |= (sm_in(x, zb_lo, zb_hi) >> 31) << 2;
         }
-        f2 |= (valid & (v < T(-100))) ? 8u : 0u;
+        f2 |= (sm_lt(v, T(-100)) >> 31) << 3;
+        f2 &= valid_bits;
         unsigned long long adv_m = ballot_here(x >= n_next);     // a third start passed / one passed after a wrap (rare)
         f2 = seg_or<SEG>(f2);
-        const bool crashed = (f2 & 1u) || ((f2 & 6u) == 6u);
-        const bool bad = (f2 & 8u) || crashed;
-        crash_bits |= crashed ? (1u << slot) : 0u;
-        bad_bits |= bad ? (1u << slot) : 0u;
+        const unsigned crashed = (f2 | ((f2 >> 1) & (f2 >> 2))) & 1u;       // (f2 & 1) || ((f2 & 6) == 6)
+        const unsigned bad = ((f2 >> 3) | crashed) & 1u;
+        crash_bits |= crashed << slot;
+        bad_bits |= bad << slot;
         // ---- the segment row read above
         c_st = n_st; c_next = n_next; c_next2 = n_next2; c_fs = n_fs; c_sl = n_sl;
         while (adv_m != 0ull) {                                  // rare
