@@ -231,6 +231,111 @@ __device__ __forceinline__ void pair_step_asm_a(f2& V, f2& X, f2& H, f2& DVL, f2
         [L2] "v"(c.L2), [rcL2] "v"(c.rc_L2)
       : "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v130", "v131", "v132", "v133");
 }
+// part A with the speed-mode clamps (SM: sumo_acc_pair's operations interleaved with the controller's, same order per
+// quantity; the clamps as max / min against constants that are 3e38 for a slot whose bit is clear).  Extra registers:
+// G (gap) v[138:139], YS v[140:141], S v[142:143], Q v[144:145], R v[146:147]; E v[134:135] as a second residual.
+__device__ __forceinline__ void pair_step_asm_a_sm(f2& V, f2& X, f2& H, f2& DVL, f2& OX, const PairConsts& c,
+                                                   const SumoPair& m) {
+  unsigned long long sa, sb;
+  asm volatile(
+      "v_cmp_nlt_f32_e64 %[sa], |v116|, %[c1e3]\n"
+      "v_cmp_nlt_f32_e64 %[sb], |v117|, %[c1e3]\n"
+      "v_pk_mul_f32 v[124:125], v[112:113], v[118:119]\n"                                   // num = v (v - vl)
+      "v_pk_mul_f32 v[126:127], v[124:125], %[rcab]\n"
+      "v_pk_mul_f32 v[142:143], v[124:125], %[rcts]\n"                                      // S: num / 2sqrt(accel decel) ...
+      "v_pk_fma_f32 v[130:131], v[126:127], %[tsab], v[124:125] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+      "v_pk_fma_f32 v[144:145], v[142:143], %[ts], v[124:125] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+      "v_pk_fma_f32 v[126:127], v[130:131], %[rcab], v[126:127]\n"                          // B = num / 2sqrt(ab)
+      "v_pk_fma_f32 v[142:143], v[144:145], %[rcts], v[142:143]\n"                          // S = num / ts
+      "v_cndmask_b32_e64 v120, %[c1e3], v116, %[sa]\n"                                      // hh
+      "v_cndmask_b32_e64 v121, %[c1e3], v117, %[sb]\n"
+      "v_max_f32_e32 v138, v116, %[c1e3]\n"                                                 // G = max(h, 1e-3)
+      "v_max_f32_e32 v139, v117, %[c1e3]\n"
+      "v_pk_mul_f32 v[124:125], v[112:113], %[rcv0]\n"
+      "v_rcp_f32_e32 v122, v120\n"
+      "v_rcp_f32_e32 v123, v121\n"
+      "v_rcp_f32_e32 v140, v138\n"
+      "v_rcp_f32_e32 v141, v139\n"
+      "v_pk_fma_f32 v[130:131], v[124:125], %[p0], v[112:113] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+      "v_pk_mul_f32 v[146:147], v[112:113], %[rcsm]\n"                                      // R: v / maxSpeed ...
+      "v_pk_fma_f32 v[124:125], v[130:131], %[rcv0], v[124:125]\n"                          // A = v / v0
+      "v_pk_fma_f32 v[144:145], v[146:147], %[smax], v[112:113] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+      "v_pk_mul_f32 v[130:131], v[112:113], %[p1]\n"
+      "v_pk_fma_f32 v[146:147], v[144:145], %[rcsm], v[146:147]\n"                          // R = v / maxSpeed
+      "v_pk_add_f32 v[130:131], v[130:131], v[126:127]\n"                                   // C = dyn
+      "v_pk_mul_f32 v[144:145], v[112:113], %[tau]\n"
+      "v_pk_fma_f32 v[126:127], v[120:121], v[122:123], %[one] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"   // e
+      "v_pk_add_f32 v[142:143], v[144:145], v[142:143]\n"                                   // S = dyn_s = v tau + dq_s
+      "v_pk_fma_f32 v[144:145], v[138:139], v[140:141], %[one] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"   // e_s
+      "v_max_f32_e32 v130, 0, v130\n"
+      "v_max_f32_e32 v131, 0, v131\n"
+      "v_max_f32_e32 v142, 0, v142\n"
+      "v_max_f32_e32 v143, 0, v143\n"
+      "v_pk_fma_f32 v[122:123], v[126:127], v[122:123], v[122:123]\n"                       // Y = refined 1/hh
+      "v_pk_fma_f32 v[140:141], v[144:145], v[140:141], v[140:141]\n"                       // YS = refined 1/gap
+      "v_pk_add_f32 v[130:131], %[p5], v[130:131]\n"                                        // C = s*
+      "v_pk_add_f32 v[142:143], %[mgap], v[142:143]\n"                                      // S = ss
+      "v_pk_mul_f32 v[124:125], v[124:125], v[124:125]\n"
+      "v_pk_mul_f32 v[146:147], v[146:147], v[146:147]\n"
+      "v_pk_mul_f32 v[126:127], v[130:131], v[122:123]\n"                                   // q0
+      "v_pk_mul_f32 v[144:145], v[142:143], v[140:141]\n"                                   // q0_s
+      "v_pk_mul_f32 v[124:125], v[124:125], v[124:125]\n"                                   // A = (v/v0)^4
+      "v_pk_mul_f32 v[146:147], v[146:147], v[146:147]\n"                                   // R = (v/maxSpeed)^4
+      "v_pk_fma_f32 v[132:133], v[120:121], v[126:127], v[130:131] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+      "v_pk_fma_f32 v[134:135], v[138:139], v[144:145], v[142:143] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+      "v_pk_add_f32 v[124:125], %[one], v[124:125] neg_lo:[0,1] neg_hi:[0,1]\n"             // A = 1 - pw
+      "v_pk_add_f32 v[146:147], %[one], v[146:147] neg_lo:[0,1] neg_hi:[0,1]\n"             // R = 1 - r^4
+      "v_pk_fma_f32 v[126:127], v[132:133], v[122:123], v[126:127]\n"                       // q1
+      "v_pk_fma_f32 v[144:145], v[134:135], v[140:141], v[144:145]\n"                       // q1_s
+      "v_pk_fma_f32 v[132:133], v[120:121], v[126:127], v[130:131] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+      "v_pk_fma_f32 v[134:135], v[138:139], v[144:145], v[142:143] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+      "v_pk_fma_f32 v[126:127], v[132:133], v[122:123], v[126:127]\n"                       // B = s* / hh
+      "v_pk_fma_f32 v[144:145], v[134:135], v[140:141], v[144:145]\n"                       // Q = ss / gap
+      "v_pk_mul_f32 v[126:127], v[126:127], v[126:127]\n"
+      "v_pk_mul_f32 v[144:145], v[144:145], v[144:145]\n"
+      "v_pk_add_f32 v[124:125], v[124:125], v[126:127] neg_lo:[0,1] neg_hi:[0,1]\n"
+      "v_pk_add_f32 v[146:147], v[146:147], v[144:145] neg_lo:[0,1] neg_hi:[0,1]\n"
+      "v_pk_mul_f32 v[124:125], %[p2], v[124:125]\n"                                        // A = acc
+      "v_pk_mul_f32 v[146:147], %[maxa], v[146:147]\n"                                      // R = SUMO's acceleration
+      // ---- apply_acceleration + the clamps (S4-S8)
+      "v_pk_mul_f32 v[124:125], v[124:125], %[dt2]\n"
+      "v_pk_mul_f32 v[146:147], v[146:147], %[dt2]\n"
+      "v_pk_add_f32 v[124:125], v[112:113], v[124:125]\n"
+      "v_pk_add_f32 v[146:147], v[112:113], v[146:147]\n"                                   // v + acc_s dt
+      "v_max_f32_e32 v124, 0, v124\n"
+      "v_max_f32_e32 v125, 0, v125\n"                                                       // next_vel
+      "v_max_f32_e32 v146, %[fl0], v146\n"                                                  // v_sumo (3e38 when bit 0 is clear)
+      "v_max_f32_e32 v147, %[fl1], v147\n"
+      "v_pk_add_f32 v[124:125], v[124:125], v[112:113] neg_lo:[0,1] neg_hi:[0,1]\n"
+      "v_pk_add_f32 v[144:145], v[112:113], %[adt]\n"                                       // v + max_accel dt
+      "v_pk_mul_f32 v[124:125], v[124:125], %[ramp2]\n"
+      "v_pk_add_f32 v[142:143], v[112:113], %[ddt] neg_lo:[0,1] neg_hi:[0,1]\n"             // v - max_decel dt
+      "v_pk_add_f32 v[124:125], v[112:113], v[124:125]\n"                                   // vc
+      "v_min_f32_e32 v124, v124, v146\n"
+      "v_min_f32_e32 v125, v125, v147\n"
+      "v_min_f32_e32 v124, v124, v144\n"
+      "v_min_f32_e32 v125, v125, v145\n"
+      "v_max_f32_e32 v112, v124, v142\n"                                                    // V = v'
+      "v_max_f32_e32 v113, v125, v143\n"
+      "v_pk_mul_f32 v[124:125], v[112:113], %[dt2]\n"
+      "v_pk_add_f32 v[124:125], v[114:115], v[124:125]\n"                                   // x_new
+      "v_pk_add_f32 v[126:127], v[124:125], %[L2] neg_lo:[0,1] neg_hi:[0,1]\n"              // x_new - L
+      "v_min_u32_e32 v114, v126, v124\n"                                                    // X = x'
+      "v_min_u32_e32 v115, v127, v125\n"
+      // ---- observation x'/L
+      "v_pk_mul_f32 v[124:125], v[114:115], %[rcL2]\n"
+      "v_pk_fma_f32 v[126:127], v[124:125], %[L2], v[114:115] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+      "v_pk_fma_f32 %[ox], v[126:127], %[rcL2], v[124:125]\n"
+      : "+{v[112:113]}"(V), "+{v[114:115]}"(X), "+{v[116:117]}"(H), "+{v[118:119]}"(DVL), [ox] "=&v"(OX),
+        [sa] "=&s"(sa), [sb] "=&s"(sb)
+      : [c1e3] "v"(c.c1e3), [rcab] "v"(c.rc_ab), [tsab] "v"(c.tsab), [rcv0] "v"(c.rc_v0), [p0] "v"(c.p0),
+        [p1] "v"(c.p1), [p2] "v"(c.p2), [p5] "v"(c.p5), [one] "v"(c.one), [dt2] "v"(c.dt2), [ramp2] "v"(c.ramp2),
+        [L2] "v"(c.L2), [rcL2] "v"(c.rc_L2), [rcts] "v"(m.rc_ts), [ts] "v"(m.ts), [rcsm] "v"(m.rc_smax),
+        [smax] "v"(m.smax), [tau] "v"(m.tau), [mgap] "v"(m.min_gap), [maxa] "v"(m.maxa), [fl0] "v"(m.floor0.x),
+        [fl1] "v"(m.floor0.y), [adt] "v"(m.adt), [ddt] "v"(m.ddt)
+      : "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v130", "v131", "v132", "v133", "v134", "v135",
+        "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147");
+}
 // part B: new neighbour snapshot, collision bit, reward term, speed observation
 __device__ __forceinline__ void pair_step_asm_b(f2& V, f2& X, f2& H, f2& DVL, f2& OV, unsigned& crash_bits, float& sq,
                                                 const PairConsts& c) {
@@ -361,6 +466,136 @@ __device__ __forceinline__ void mixed_step_asm_a(f2& V32, double& XA, double& XB
       : "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v130", "v131", "v132", "v133", "v134",
         "v135", "v136", "v137");
 }
+// mixed part A with the speed-mode clamps: SUMO's acceleration in float32 next to the controller's (temporaries G
+// v[146:147], YS v[148:149], S v[150:151], Q v[152:153], R v[154:155], second residual v[134:135]), the clamps in
+// float64 (refsim_ring_idm_mixed's order: min(vc, max(v + a_s dt, floor0)), min(.., v + adt), max(.., v - ddt)).
+struct MixedSumoConsts { double fl0a, fl0b, adta, adtb, ddta, ddtb; };
+__device__ __forceinline__ void mixed_step_asm_a_sm(f2& V32, double& XA, double& XB, double& VA, double& VB, f2& H,
+                                                    f2& DVL, f2& OV, const MixedConsts& c, const SumoPair& m,
+                                                    const MixedSumoConsts& d) {
+  unsigned long long sa, sb;
+  asm volatile(
+      "v_cmp_nlt_f32_e64 %[sa], |v140|, %[c1e3]\n"
+      "v_cmp_nlt_f32_e64 %[sb], |v141|, %[c1e3]\n"
+      "v_pk_mul_f32 v[124:125], v[112:113], v[142:143]\n"
+      "v_pk_mul_f32 v[126:127], v[124:125], %[rcab]\n"
+      "v_pk_mul_f32 v[150:151], v[124:125], %[rcts]\n"
+      "v_pk_fma_f32 v[130:131], v[126:127], %[tsab], v[124:125] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+      "v_pk_fma_f32 v[152:153], v[150:151], %[ts], v[124:125] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+      "v_pk_fma_f32 v[126:127], v[130:131], %[rcab], v[126:127]\n"
+      "v_pk_fma_f32 v[150:151], v[152:153], %[rcts], v[150:151]\n"                          // S = num / ts
+      "v_cndmask_b32_e64 v120, %[c1e3], v140, %[sa]\n"
+      "v_cndmask_b32_e64 v121, %[c1e3], v141, %[sb]\n"
+      "v_max_f32_e32 v146, v140, %[c1e3]\n"                                                 // G = max(h, 1e-3)
+      "v_max_f32_e32 v147, v141, %[c1e3]\n"
+      "v_pk_mul_f32 v[124:125], v[112:113], %[rcv0]\n"
+      "v_rcp_f32_e32 v122, v120\n"
+      "v_rcp_f32_e32 v123, v121\n"
+      "v_rcp_f32_e32 v148, v146\n"
+      "v_rcp_f32_e32 v149, v147\n"
+      "v_pk_fma_f32 v[130:131], v[124:125], %[p0], v[112:113] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+      "v_pk_mul_f32 v[154:155], v[112:113], %[rcsm]\n"
+      "v_pk_fma_f32 v[124:125], v[130:131], %[rcv0], v[124:125]\n"
+      "v_pk_fma_f32 v[152:153], v[154:155], %[smax], v[112:113] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+      "v_pk_mul_f32 v[130:131], v[112:113], %[p1]\n"
+      "v_pk_fma_f32 v[154:155], v[152:153], %[rcsm], v[154:155]\n"                          // R = v / maxSpeed
+      "v_pk_add_f32 v[130:131], v[130:131], v[126:127]\n"
+      "v_pk_mul_f32 v[152:153], v[112:113], %[tau]\n"
+      "v_pk_fma_f32 v[126:127], v[120:121], v[122:123], %[one] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+      "v_pk_add_f32 v[150:151], v[152:153], v[150:151]\n"                                   // dyn_s
+      "v_pk_fma_f32 v[152:153], v[146:147], v[148:149], %[one] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+      "v_max_f32_e32 v130, 0, v130\n"
+      "v_max_f32_e32 v131, 0, v131\n"
+      "v_max_f32_e32 v150, 0, v150\n"
+      "v_max_f32_e32 v151, 0, v151\n"
+      "v_pk_fma_f32 v[122:123], v[126:127], v[122:123], v[122:123]\n"
+      "v_pk_fma_f32 v[148:149], v[152:153], v[148:149], v[148:149]\n"
+      "v_pk_add_f32 v[130:131], %[p5], v[130:131]\n"
+      "v_pk_add_f32 v[150:151], %[mgap], v[150:151]\n"                                      // ss
+      "v_pk_mul_f32 v[124:125], v[124:125], v[124:125]\n"
+      "v_pk_mul_f32 v[154:155], v[154:155], v[154:155]\n"
+      "v_pk_mul_f32 v[126:127], v[130:131], v[122:123]\n"
+      "v_pk_mul_f32 v[152:153], v[150:151], v[148:149]\n"                                   // q0_s
+      "v_pk_mul_f32 v[124:125], v[124:125], v[124:125]\n"
+      "v_pk_mul_f32 v[154:155], v[154:155], v[154:155]\n"
+      "v_pk_fma_f32 v[132:133], v[120:121], v[126:127], v[130:131] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+      "v_pk_fma_f32 v[134:135], v[146:147], v[152:153], v[150:151] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+      "v_pk_add_f32 v[124:125], %[one], v[124:125] neg_lo:[0,1] neg_hi:[0,1]\n"
+      "v_pk_add_f32 v[154:155], %[one], v[154:155] neg_lo:[0,1] neg_hi:[0,1]\n"
+      "v_pk_fma_f32 v[126:127], v[132:133], v[122:123], v[126:127]\n"
+      "v_pk_fma_f32 v[152:153], v[134:135], v[148:149], v[152:153]\n"
+      "v_pk_fma_f32 v[132:133], v[120:121], v[126:127], v[130:131] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+      "v_pk_fma_f32 v[134:135], v[146:147], v[152:153], v[150:151] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+      "v_pk_fma_f32 v[126:127], v[132:133], v[122:123], v[126:127]\n"
+      "v_pk_fma_f32 v[152:153], v[134:135], v[148:149], v[152:153]\n"                       // Q = ss / gap
+      "v_pk_mul_f32 v[126:127], v[126:127], v[126:127]\n"
+      "v_pk_mul_f32 v[152:153], v[152:153], v[152:153]\n"
+      "v_pk_add_f32 v[124:125], v[124:125], v[126:127] neg_lo:[0,1] neg_hi:[0,1]\n"
+      "v_pk_add_f32 v[154:155], v[154:155], v[152:153] neg_lo:[0,1] neg_hi:[0,1]\n"
+      "v_pk_mul_f32 v[124:125], %[p2], v[124:125]\n"                                        // A = acc (float32)
+      "v_pk_mul_f32 v[154:155], %[maxa], v[154:155]\n"                                      // R = SUMO's acceleration (float32)
+      // ---- apply_acceleration + clamps + integration in float64
+      "v_cvt_f64_f32_e32 v[130:131], v124\n"
+      "v_cvt_f64_f32_e32 v[132:133], v125\n"
+      "v_cvt_f64_f32_e32 v[134:135], v154\n"
+      "v_cvt_f64_f32_e32 v[136:137], v155\n"
+      "v_mul_f64 v[130:131], v[130:131], %[dt]\n"
+      "v_mul_f64 v[132:133], v[132:133], %[dt]\n"
+      "v_mul_f64 v[134:135], v[134:135], %[dt]\n"
+      "v_mul_f64 v[136:137], v[136:137], %[dt]\n"
+      "v_add_f64 v[130:131], v[118:119], v[130:131]\n"
+      "v_add_f64 v[132:133], v[138:139], v[132:133]\n"
+      "v_add_f64 v[134:135], v[118:119], v[134:135]\n"                                      // v + a_s dt
+      "v_add_f64 v[136:137], v[138:139], v[136:137]\n"
+      "v_max_f64 v[130:131], v[130:131], %[zero]\n"                                        // next_vel
+      "v_max_f64 v[132:133], v[132:133], %[zero]\n"
+      "v_max_f64 v[134:135], v[134:135], %[fl0a]\n"                                        // v_sumo (3e38 when bit 0 is clear)
+      "v_max_f64 v[136:137], v[136:137], %[fl0b]\n"
+      "v_add_f64 v[130:131], v[130:131], -v[118:119]\n"
+      "v_add_f64 v[132:133], v[132:133], -v[138:139]\n"
+      "v_mul_f64 v[130:131], v[130:131], %[ramp]\n"
+      "v_mul_f64 v[132:133], v[132:133], %[ramp]\n"
+      "v_add_f64 v[130:131], v[118:119], v[130:131]\n"                                      // vc
+      "v_add_f64 v[132:133], v[138:139], v[132:133]\n"
+      "v_min_f64 v[130:131], v[130:131], v[134:135]\n"
+      "v_min_f64 v[132:133], v[132:133], v[136:137]\n"
+      "v_add_f64 v[134:135], v[118:119], %[adta]\n"
+      "v_add_f64 v[136:137], v[138:139], %[adtb]\n"
+      "v_min_f64 v[130:131], v[130:131], v[134:135]\n"
+      "v_min_f64 v[132:133], v[132:133], v[136:137]\n"
+      "v_add_f64 v[134:135], v[118:119], -%[ddta]\n"
+      "v_add_f64 v[136:137], v[138:139], -%[ddtb]\n"
+      "v_max_f64 v[118:119], v[130:131], v[134:135]\n"                                      // VA = v'
+      "v_max_f64 v[138:139], v[132:133], v[136:137]\n"                                      // VB
+      "v_mul_f64 v[130:131], v[118:119], %[dt]\n"
+      "v_mul_f64 v[132:133], v[138:139], %[dt]\n"
+      "v_add_f64 v[130:131], v[114:115], v[130:131]\n"                                      // x_new
+      "v_add_f64 v[132:133], v[116:117], v[132:133]\n"
+      "v_add_f64 v[134:135], v[130:131], -%[L]\n"                                           // x_new - L
+      "v_add_f64 v[136:137], v[132:133], -%[L]\n"
+      "v_cvt_f32_f64_e32 v112, v[118:119]\n"                                                // V32 = float images
+      "v_cvt_f32_f64_e32 v113, v[138:139]\n"
+      "v_cmp_gt_i32_e64 %[sa], 0, v135\n"                                                   // x_new - L < 0 (sign)
+      "v_cmp_gt_i32_e64 %[sb], 0, v137\n"
+      "v_mul_f64 v[120:121], v[118:119], %[rcms]\n"                                         // observation v' / max_speed
+      "v_mul_f64 v[122:123], v[138:139], %[rcms]\n"
+      "v_cndmask_b32_e64 v114, v134, v130, %[sa]\n"                                         // XA = x'
+      "v_cndmask_b32_e64 v115, v135, v131, %[sa]\n"
+      "v_cndmask_b32_e64 v116, v136, v132, %[sb]\n"                                         // XB
+      "v_cndmask_b32_e64 v117, v137, v133, %[sb]\n"
+      "v_cvt_f32_f64_e32 v128, v[120:121]\n"
+      "v_cvt_f32_f64_e32 v129, v[122:123]\n"
+      : "+{v[112:113]}"(V32), "+{v[114:115]}"(XA), "+{v[116:117]}"(XB), "+{v[118:119]}"(VA), "+{v[138:139]}"(VB),
+        "+{v[140:141]}"(H), "+{v[142:143]}"(DVL), "={v[128:129]}"(OV), [sa] "=&s"(sa), [sb] "=&s"(sb)
+      : [c1e3] "v"(c.c1e3), [rcab] "v"(c.rc_ab), [tsab] "v"(c.tsab), [rcv0] "v"(c.rc_v0), [p0] "v"(c.p0),
+        [p1] "v"(c.p1), [p2] "v"(c.p2), [p5] "v"(c.p5), [one] "v"(c.one), [dt] "v"(c.dt), [ramp] "v"(c.ramp),
+        [L] "v"(c.L), [rcms] "v"(c.rc_ms), [zero] "v"(c.zero), [rcts] "v"(m.rc_ts), [ts] "v"(m.ts),
+        [rcsm] "v"(m.rc_smax), [smax] "v"(m.smax), [tau] "v"(m.tau), [mgap] "v"(m.min_gap), [maxa] "v"(m.maxa),
+        [fl0a] "v"(d.fl0a), [fl0b] "v"(d.fl0b), [adta] "v"(d.adta), [adtb] "v"(d.adtb), [ddta] "v"(d.ddta),
+        [ddtb] "v"(d.ddtb)
+      : "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v130", "v131", "v132", "v133", "v134",
+        "v135", "v136", "v137", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155");
+}
 __device__ __forceinline__ void mixed_step_asm_b(f2& V32, double& XA, double& XB, f2& H, f2& DVL, f2& OX,
                                                  unsigned& crash_bits, float& sq, const MixedConsts& c) {
   unsigned long long sa, sb;
@@ -415,7 +650,8 @@ template <typename T, int ROW, bool DELTA4, bool FASTDIV, bool BADCHK, bool SM =
 __global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_steps, float* __restrict__ obs,
                                                       float* __restrict__ rew, uint8_t* __restrict__ done) {
   constexpr bool MIXED = sizeof(T) == 8;
-  constexpr bool ASM = ROW == 16 && DELTA4 && FASTDIV && !BADCHK && !SM;     // pair_step_asm / mixed_step_asm
+  // the hand-written steps: pair_step_asm_a / _a_sm + _b (float32, without / with the speed-mode clamps), mixed_step_asm
+  constexpr bool ASM = ROW == 16 && DELTA4 && FASTDIV && !BADCHK;
   constexpr int RPW = 64 / ROW;
   constexpr int PERIOD = ROW < 16 ? ROW : 16;       // steps whose reward tail is finished together
   const int lane = threadIdx.x & 63;
@@ -523,6 +759,7 @@ __global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_step
     ddtA = (mA & 4) ? double(s.max_decel[iA]) * dt64 : double(BIG);
     ddtB = (mB & 4) ? double(s.max_decel[iB]) * dt64 : double(BIG);
   }
+  const MixedSumoConsts msc = {floor0A, floor0B, adtA, adtB, ddtA, ddtB};
 
   // observation stores: buffer descriptor over the PERIOD-step block being written + per-lane byte offsets; the
   // scalar offset of an unrolled step is a launch constant (slot * bytes per step)
@@ -571,7 +808,8 @@ __global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_step
       f2 ov, ox;
       const unsigned so = unsigned(slot) * step_b32;
       if constexpr (MIXED) {
-        mixed_step_asm_a(v, xdA, xdB, vdA, vdB, h, dvl, ov, mc);
+        if constexpr (SM) mixed_step_asm_a_sm(v, xdA, xdB, vdA, vdB, h, dvl, ov, mc, sc, msc);
+        else mixed_step_asm_a(v, xdA, xdB, vdA, vdB, h, dvl, ov, mc);
         if (slot > 0) __builtin_amdgcn_raw_buffer_store_b128(piece, rs, off_16, so - step_b32, 0);
         mixed_step_asm_b(v, xdA, xdB, h, dvl, ox, crash_bits, sq_out, mc);
         transpose_in(ov, ox);
@@ -593,7 +831,8 @@ __global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_step
         pair_step_asm_b(v, x, h, dvl, ov, crash_bits, sq_out, pc);
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, ov), rs, off_v, so, 0);
 #else
-        pair_step_asm_a(v, x, h, dvl, ox, pc);
+        if constexpr (SM) pair_step_asm_a_sm(v, x, h, dvl, ox, pc, sc);
+        else pair_step_asm_a(v, x, h, dvl, ox, pc);
         if (slot > 0) __builtin_amdgcn_raw_buffer_store_b128(piece, rs, off_16, so - step_b32, 0);
         pair_step_asm_b(v, x, h, dvl, ov, crash_bits, sq_out, pc);
         transpose_in(ov, ox);
