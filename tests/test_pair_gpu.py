@@ -271,6 +271,54 @@ def test_pair_speed_modes_f32_bit_exact_vs_numpy_oracle_and_generic_kernel(N, mo
     sim.close(), gen.close()
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
+def test_pair_hand_written_steps_fuzz_f32_and_mixed(seed):
+    """Random per-slot IDM parameters (delta = 4: the hand-written instantiation), lengths, speed modes (none / some),
+    start speeds and ring lengths on 16-lane rows (N = 18..32): float32 against the numpy oracle and the generic kernel,
+    FS_MIXED against its C twin, over a horizon with collisions allowed."""
+    rng = np.random.default_rng(seed)
+    N = int(rng.choice([18, 20, 22, 24, 28, 32]))
+    R, K = 9, 70
+    with_modes = seed % 2 == 0
+    veh = []
+    for i in range(N):
+        veh.append(idm_vehicle(
+            p=[float(rng.uniform(15, 35)), float(rng.uniform(0.6, 1.6)), float(rng.uniform(0.6, 2.5)),
+               float(rng.uniform(0.8, 3.0)), 4, float(rng.uniform(0.5, 3.0)), 0, 0],
+            length=float(rng.choice([3.5, 5.0, 7.0])),
+            speed_mode=int(rng.choice([0, 1, 7, 25, 31, 6])) if with_modes else 0,
+            max_accel=float(rng.uniform(0.8, 3.0)), max_decel=float(rng.uniform(1.0, 7.5)),
+            sumo_tau=float(rng.uniform(0.4, 1.5)), sumo_min_gap=float(rng.uniform(0.2, 3.0)),
+            sumo_max_speed=float(rng.uniform(6.0, 35.0))))
+    L = float(rng.uniform(8.5, 14.0)) * N
+    spec = perturbed(ring_spec(R=R, N=N, length=L, bunching=0, junction_length=0.1, horizon=60, vehicles=veh),
+                     seed=seed, sigma=0.3)
+    spec["init_vel"] = rng.uniform(0, 12, (R, N))
+    sim, obs, rew, done = gpu_rollout(spec, "f32", K)
+    assert sim.last_kernel == ("k_rollout_pair+speed_mode" if with_modes else "k_rollout_pair")
+    gen, og, rg, dg = gpu_rollout(spec, "f32", K, env={"FLOWSIM_FORCE_GENERIC": "1"})
+    ora = S.RingOracle(spec, np.float32)
+    ora.reset()
+    for k in range(K):
+        o, r, d = ora.step(None)
+        np.testing.assert_array_equal(obs[k].cpu().numpy(), o.astype(np.float32), err_msg="obs step %d" % k)
+        np.testing.assert_array_equal(rew[k].cpu().numpy(), r.astype(np.float32), err_msg="rew step %d" % k)
+        np.testing.assert_array_equal(done[k].cpu().numpy().astype(bool), d, err_msg="done step %d" % k)
+    assert (obs == og).all() and (rew == rg).all() and (done == dg).all()
+    np.testing.assert_array_equal(sim.pos, ora.x)
+    np.testing.assert_array_equal(sim.vel, ora.v)
+    sim.close(), gen.close()
+    msim, mo, mr, md = gpu_rollout(spec, "mixed", K)
+    twin = cbuild.CRingIDMMixed(spec)
+    to, tr, td = twin.rollout(K, obs_every_step=True)
+    np.testing.assert_array_equal(mo.cpu().numpy(), to)
+    np.testing.assert_array_equal(mr.cpu().numpy(), tr)
+    np.testing.assert_array_equal(md.cpu().numpy().astype(bool), td)
+    np.testing.assert_array_equal(msim.pos, twin.x)
+    np.testing.assert_array_equal(msim.vel, twin.v)
+    msim.close()
+
+
 def test_speed_mode_changes_the_trajectory_and_is_not_the_aggressive_kernel():
     # the same ring with and without bit 0: the clamp must bind somewhere (otherwise the tests above prove nothing)
     base = perturbed(ring_spec(R=6, N=22, length=150.0, bunching=0, junction_length=0.1, horizon=400), seed=9, sigma=0.4)

@@ -881,6 +881,43 @@ def test_autonomous_and_commanded_lane_changes_together_f32_and_f64():
                      ring_length=spec["ring_length"][:2]), "f64", 120, actions=acts[:120, :2], exact=False, atol=1e-9)
 
 
+@pytest.mark.parametrize("seed", [21, 22, 23, 24, 25])
+def test_loop_rollout_kernel_fuzz_against_generic_kernel(seed):
+    """k_rollout_loop (sign-mask predicates, hoisted wave-wide tests, FULL and run-time-flag instantiations) against the
+    generic k_steps on random figure eights: vehicle count, radius, crossing time gap, per-slot noise / speed modes /
+    IDM parameters, aggressive random actions (collisions at the crossing and rear-end included), both heads."""
+    rng = np.random.default_rng(seed)
+    N = int(rng.choice([9, 10, 12, 14, 16]))          # 16-lane rows: the rollout kernel's shape
+    R, K = 21, 130
+    radius = float(rng.choice([30.0, 36.0, 45.0]))
+    spec = figure_eight_spec(R=R, N=N, radius=radius, horizon=100, seed=seed, num_rl=1)
+    spec["junction"] = dict(spec["junction"], time_gap=float(rng.uniform(0.5, 4.0)))
+    veh = []
+    for i in range(N - 1):
+        veh.append(idm_vehicle(p=[float(rng.uniform(20, 32)), float(rng.uniform(0.8, 1.4)), float(rng.uniform(0.8, 2.0)),
+                                  float(rng.uniform(1.0, 2.5)), 4, float(rng.uniform(1.0, 3.0)), 0, 0],
+                               speed_mode=int(rng.choice([0, 1, 1, 7])), max_decel=float(rng.choice([1.5, 4.5])),
+                               noise=float(rng.choice([0.0, 0.2, 0.5]))))
+    veh.append(idm_vehicle(controller=S.CTRL_RL, rl_index=0, speed_mode=int(rng.choice([0, 1])), max_decel=1.5))
+    spec["vehicles"] = veh
+    spec["seed"] = 1000 + seed
+    if seed % 2:
+        spec["env"] = S.ENV_WAVE_ATTENUATION_PO
+        spec["po_max_length"] = 421.94
+    acts = rng.uniform(-3, 3, (K, R, 1)).astype(np.float32)
+    a, oa, ra, da = _rollout(spec, K, acts)
+    b, ob, rb, db = _rollout(spec, K, acts, env={"FLOWSIM_NO_LOOP_KERNEL": "1"})
+    f, of, rf, df = _rollout(spec, K, acts, env={"FLOWSIM_NO_LOOP_FULL": "1"})
+    assert a.last_kernel.startswith("k_rollout_loop") and b.last_kernel.startswith("k_steps")
+    for o2, r2, d2, s2 in ((ob, rb, db, b), (of, rf, df, f)):
+        np.testing.assert_array_equal(oa, o2)
+        np.testing.assert_array_equal(ra, r2)
+        np.testing.assert_array_equal(da, d2)
+        np.testing.assert_array_equal(a.pos, s2.pos)
+        np.testing.assert_array_equal(a.vel, s2.vel)
+    a.close(), b.close(), f.close()
+
+
 # ------------------------------------------------------------------ the SUMO figure-eight fixture through the HIP path
 @pytest.mark.parametrize("precision", ["f64", "f32"])
 def test_hip_path_reproduces_the_sumo_figure_eight_fixture(precision):
