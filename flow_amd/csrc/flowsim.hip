@@ -576,9 +576,11 @@ struct Sim : SimBase {
     if (open_net) {
       // the float32 instantiations exist twice: CSET = 1 for populations of IDM / RL / Sim slots only
       const bool cset = std::is_same<T, float>::value && (dv.flags & fs::FLAG_IDM_SET) && !force_generic;
-#define FS_OPEN_(P_, C_, PR_)                                                                                    \
-  hipLaunchKernelGGL((fs::k_steps_open<T, SEG, P_, C_, PR_>), dim3(blocks), dim3(64), 0, stream, dv, ov, num_steps,  \
-                     mask, actions, act_stride, obs, rew, done, obs_every_step, after_reset)
+#define FS_OPEN__(P_, C_, PR_, PO_)                                                                              \
+  hipLaunchKernelGGL((fs::k_steps_open<T, SEG, P_, C_, PR_, PO_>), dim3(blocks), dim3(64), 0, stream, dv, ov,        \
+                     num_steps, mask, actions, act_stride, obs, rew, done, obs_every_step, after_reset)
+#define FS_OPEN_(P_, C_, PR_) do { if (P_ == 2 && dv.env == FS_ENV_MERGE_PO) FS_OPEN__(P_, C_, PR_, (P_ == 2));    \
+                                   else FS_OPEN__(P_, C_, PR_, false); } while (0)
 #define FS_OPEN(P_, C_) do { if (ov.n_prob > 0) FS_OPEN_(P_, C_, true); else FS_OPEN_(P_, C_, false); } while (0)
       last_kernel = "k_steps_open";
       if (cfg.network == FS_NET_BOTTLENECK) {
@@ -593,6 +595,7 @@ struct Sim : SimBase {
       }
 #undef FS_OPEN
 #undef FS_OPEN_
+#undef FS_OPEN__
       HIP_TRY(hipGetLastError());
       return FS_OK;
     }

@@ -257,7 +257,9 @@ __device__ __forceinline__ int cell_of(const TABS& tb, int span, T x, int seg_k,
 // CSET = 1: every slot is an IDM / RL / Sim-car-following controller (FLAG_IDM_SET), see control_accel_on
 // PROB: some inflow is probabilistic (M2b) -- its own instantiation: the per-sub-step trial and the schedule's second
 // form cost the deterministic configurations 7 % (C5) when they were run-time branches of one kernel
-template <typename T, int SEG, int P, int CSET = 0, bool PROB = false>
+// PO: the MergePOEnv head (rl_veh / rl_queue bookkeeping, places -> action columns); the other merge head
+// (MultiAgentMergePOEnv, C5) is its own instantiation without any of it
+template <typename T, int SEG, int P, int CSET = 0, bool PROB = false, bool PO = false>
 __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, int num_steps,
                                                    const uint8_t* __restrict__ mask,
                                                    const float* __restrict__ actions, size_t act_stride,
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
   const int env = s.env;
   // the env families are tied to the network (validated by fs_create): P == 2 merge heads, P == 4 bottleneck heads;
   // making that a compile-time fact keeps each instantiation free of the other family's code and registers
-  const bool po_env = (P == 2) && (env == FS_ENV_MERGE_PO);
+  constexpr bool po_env = (P == 2) && PO;                 // (the host launches PO = (env == FS_ENV_MERGE_PO))
   const bool bn_env = (P == 4) && (SEG == 64) && (env == FS_ENV_BOTTLENECK_DV || env == FS_ENV_BOTTLENECK);
   const bool dv_env = (P == 4) && (SEG == 64) && (env == FS_ENV_BOTTLENECK_DV);
   const bool track_foll = (P == 2) ? true : (o.track_followers != 0);
