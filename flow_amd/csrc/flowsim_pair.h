@@ -764,13 +764,8 @@ __global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_step
   // observation stores: buffer descriptor over the PERIOD-step block being written + per-lane byte offsets; the
   // scalar offset of an unrolled step is a launch constant (slot * bytes per step)
   const unsigned rowb = 2u * unsigned(N) * 4u;                              // bytes of one replica's observation
-#ifdef FS_DIAG_OOB
-  const unsigned off_v = valid ? unsigned(rr) * rowb + unsigned(iA) * 4u : 0xFFFFFF00u;
-  const unsigned off_x = valid ? off_v + unsigned(N) * 4u : 0xFFFFFF00u;
-#else
   const unsigned off_v = unsigned(rr) * rowb + unsigned(iA) * 4u;           // BYTE offsets: host guarantees < 2^32
   const unsigned off_x = off_v + unsigned(N) * 4u;
-#endif
   const size_t step_bytes = size_t(s.R) * rowb;
   const unsigned step_b32 = unsigned(step_bytes);                           // PERIOD * step_bytes < 2^32 (host)
   char* ob = reinterpret_cast<char*>(obs);
@@ -814,14 +809,7 @@ __global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_step
         mixed_step_asm_b(v, xdA, xdB, h, dvl, ox, crash_bits, sq_out, mc);
         transpose_in(ov, ox);
       } else {
-#if defined(FS_DIAG_X4)       // timing experiment: ONE 16-byte store per lane and step (wrong layout)
-        pair_step_asm_a(v, x, h, dvl, ox, pc);
-        pair_step_asm_b(v, x, h, dvl, ov, crash_bits, sq_out, pc);
-        typedef unsigned u4v_ __attribute__((__vector_size__(16)));
-        const u4v_ d4 = {__builtin_bit_cast(unsigned, ov.x), __builtin_bit_cast(unsigned, ov.y),
-                         __builtin_bit_cast(unsigned, ox.x), __builtin_bit_cast(unsigned, ox.y)};
-        __builtin_amdgcn_raw_buffer_store_b128(d4, rs, unsigned(wave) * 1024u + unsigned(lane) * 16u, so, 0);
-#elif defined(FS_DIAG_NOSTORE)
+#if defined(FS_DIAG_NOSTORE)   // timing experiment (scripts/dbg/pmc_variants.sh): the results stay in registers
         pair_step_asm_a(v, x, h, dvl, ox, pc);
         pair_step_asm_b(v, x, h, dvl, ov, crash_bits, sq_out, pc);
         asm volatile("" :: "v"(ov), "v"(ox), "s"(so));
@@ -910,13 +898,6 @@ __global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_step
     sq_out = sq.x + sq.y;
   };
 
-#ifdef FS_DIAG_STAGGER
-  // timing experiment: the waves of a workgroup start FS_DIAG_STAGGER x 64 cycles apart
-  for (int w = 0; w < int(threadIdx.x >> 6); ++w) __builtin_amdgcn_s_sleep(FS_DIAG_STAGGER);
-#endif
-#ifdef FS_DIAG_STAGGER_CU
-  for (int w = 0; w < int(blockIdx.x % FS_DIAG_STAGGER_MOD); ++w) __builtin_amdgcn_s_sleep(FS_DIAG_STAGGER_CU);
-#endif
   // full blocks of PERIOD steps: straight-line code, rewards finished PERIOD at a time
   int base = 0;
   for (; base + PERIOD <= num_steps; base += PERIOD) {
@@ -926,7 +907,7 @@ __global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_step
         ob, 0, remain > 0xFFFFFFFFull ? 0xFFFFFFFFu : unsigned(remain), 0x00020000);
 #pragma unroll
     for (int slot = 0; slot < PERIOD; ++slot) one_step(slot, rs, sq[slot]);
-#if !defined(FS_DIAG_X4) && !defined(FS_DIAG_NOSTORE) && !defined(FS_DIAG_NOXPOSE)
+#if !defined(FS_DIAG_NOSTORE) && !defined(FS_DIAG_NOXPOSE)
     if (XPOSE) __builtin_amdgcn_raw_buffer_store_b128(piece, rs, off_16, unsigned(PERIOD - 1) * step_b32, 0);
 #endif
     ob += size_t(PERIOD) * step_bytes;
@@ -955,7 +936,7 @@ __global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_step
     float sq1;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ob, 0, unsigned(step_bytes), 0x00020000);
     one_step(0, rs, sq1);
-#if !defined(FS_DIAG_X4) && !defined(FS_DIAG_NOSTORE) && !defined(FS_DIAG_NOXPOSE)
+#if !defined(FS_DIAG_NOSTORE) && !defined(FS_DIAG_NOXPOSE)
     if (XPOSE) __builtin_amdgcn_raw_buffer_store_b128(piece, rs, off_16, 0u, 0);
 #endif
     ob += step_bytes;
