@@ -535,6 +535,25 @@ struct Sim : SimBase {
     return true;
   }
 
+  // k_rollout_loop<..., FULL>: its controller divisions by launch constants are div_const -- every divisor proven
+  int loop_fastc_state = -1;
+  bool loop_fastc_ok() {
+    if (!std::is_same<T, float>::value || no_fastdiv) return false;
+    if (loop_fastc_state >= 0) return loop_fastc_state == 1;
+    loop_fastc_state = 0;
+    if (!loop_div_ok) return false;               // s0 / minGap in [1e-3, 1e6]: tiny dividends cannot matter
+    for (int i = 0; i < dv.N; ++i) {
+      if (veh[i].controller == FS_CTRL_IDM) {
+        if (!fastdiv_exact_for(float(veh[i].p[0]))) return false;
+        if (!fastdiv_exact_for(2.0f * std::sqrt(float(veh[i].p[2]) * float(veh[i].p[3])))) return false;
+      }
+      if (!fastdiv_exact_for(float(veh[i].sumo_max_speed))) return false;
+      if (!fastdiv_exact_for(2.0f * std::sqrt(float(veh[i].max_accel) * float(veh[i].max_decel)))) return false;
+    }
+    loop_fastc_state = 1;
+    return true;
+  }
+
   // the specialisations for the headline configuration (see flowsim_kernels.h)
   bool delta4 = false;
   bool loop_div_ok = false, loop_delta4 = false;
@@ -630,7 +649,7 @@ struct Sim : SimBase {
   hipLaunchKernelGGL((fs::k_rollout_loop<H_, D_>), grid, block, 0, stream, dv, num_steps, actions, act_stride, obs, \
                      rew, done)
         const bool full = (f & fs::FLAG_HAS_NOISE) && (f & fs::FLAG_NEED_SUMO) && dv.junction_on && actions != nullptr &&
-                          loop_delta4 && !no_loop_full;
+                          loop_delta4 && !no_loop_full && loop_fastc_ok();
         if (full) {
           last_kernel = "k_rollout_loop<FULL>";
           if (dv.env == FS_ENV_ACCEL)

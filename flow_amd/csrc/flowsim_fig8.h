@@ -29,9 +29,19 @@ namespace fs {
 __device__ __forceinline__ float in_vgpr(float x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ double in_vgpr(double x) { asm volatile("" : "+v"(x)); return x; }
 // x / c for a launch constant c: the float64 route of div_via_f64 (exact for every float x)
-struct DivC { double c, rc; };
-__device__ __forceinline__ DivC make_divc(float c) { return DivC{in_vgpr(double(c)), in_vgpr(1.0 / double(c))}; }
+struct DivC { double c, rc; float cf, rcf; };
+__device__ __forceinline__ DivC make_divc(float c) {
+  return DivC{in_vgpr(double(c)), in_vgpr(1.0 / double(c)), in_vgpr(c), in_vgpr(1.0f / c)};
+}
 __device__ __forceinline__ float divc(float x, const DivC& d) { return div_via_f64(x, d.c, d.rc); }
+// FASTC: the controller's constant divisions as div_const (multiply by RN(1/c), one residual correction: 3 float32
+// instructions instead of 5 through float64) -- host-verified per divisor, and for dividends below 2^-70 without effect
+// on the results they feed (the argument of flowsim_kernels.h div_const: pw = (v/v0)^4 underflows either way, a tiny
+// v (v - vl) / c vanishes next to s0 / minGap >= 1e-3).  Observations are OUTPUTS: they keep divc.
+template <bool FASTC>
+__device__ __forceinline__ float divk(float x, const DivC& d) {
+  return FASTC ? div_const<true>(x, d.cf, d.rcf) : div_via_f64(x, d.c, d.rc);
+}
 // value of the NEXT slot of the 16-lane row (slot 0's for the last occupied slot and the idle lanes)
 __device__ __forceinline__ float lead16(float v, bool wrap) {
   const float t = dpp<DPP_ROW_SHL1>(v), w = dpp<0x150>(v);     // row_shl:1, row_newbcast:0
@@ -42,23 +52,24 @@ __device__ __forceinline__ float lead16(float v, bool wrap) {
 // that are launch constants go through divc, the others (|h| >= 1e-3, gap >= 1e-3; dividends s* >= s0 >= 1e-3 and
 // ss >= minGap >= 1e-3, host-checked) through div_core
 struct IdmC { float p1, p2, p4, p5; DivC v0, two_sqrt; };
-template <bool DELTA4>
+template <bool DELTA4, bool FASTC = false>
 __device__ __forceinline__ float idm_fast(float v, float vl, float h, bool has, const IdmC& c) {
   const float hh = tabs(h) < 1e-3f ? 1e-3f : h;
-  const float dyn = v * c.p1 + divc(v * (v - vl), c.two_sqrt);
+  const float dyn = v * c.p1 + divk<FASTC>(v * (v - vl), c.two_sqrt);
   const float s_star = has ? c.p5 + tmax(0.0f, dyn) : 0.0f;
   const float q = div_core(s_star, hh);
-  const float ratio = divc(v, c.v0);
+  const float ratio = divk<FASTC>(v, c.v0);
   float pw;
   if (DELTA4) { const float r2 = ratio * ratio; pw = r2 * r2; } else pw = pow_delta(ratio, c.p4);
   return c.p2 * (1.0f - pw - q * q);
 }
 struct SumoC { float min_gap, tau, max_accel; DivC two_sqrt, max_speed; };
+template <bool FASTC = false>
 __device__ __forceinline__ float sumo_fast(float v, float vl, float h, bool has, float dt, const SumoC& c) {
   const float gap = tmax(h, 1e-3f);
-  const float ss = c.min_gap + tmax(0.0f, v * c.tau + divc(v * (v - vl), c.two_sqrt));
+  const float ss = c.min_gap + tmax(0.0f, v * c.tau + divk<FASTC>(v * (v - vl), c.two_sqrt));
   const float q = has ? div_core(ss, gap) : 0.0f;
-  const float r = divc(v, c.max_speed);
+  const float r = divk<FASTC>(v, c.max_speed);
   const float r2 = r * r;
   const float acc = c.max_accel * (1.0f - r2 * r2 - q * q);
   return tmax(0.0f, v + acc * dt);
@@ -66,7 +77,8 @@ __device__ __forceinline__ float sumo_fast(float v, float vl, float h, bool has,
 
 // FULL: the launch is known to have noisy slots, speed-mode clamps / uncommanded slots, the crossing and an action
 // tensor (BASELINE's C3 and the reference's figure-eight experiments): the four launch-constant tests become
-// compile-time facts instead of taken branches (a wave alone on its SIMD pays an instruction-fetch bubble for each).
+// compile-time facts instead of taken branches (a wave alone on its SIMD pays an instruction-fetch bubble for each);
+// and the host has proven the controller's constant divisors for div_const (FASTC, Sim::loop_fastc_ok).
 // Predicates as VALU integers.  hipcc turns every `a & b` of two float compares into v_cmp, v_cmp, s_and_b64 -- and a
 // scalar operation on a VALU-written mask waits ~14 cycles for it (scripts/ubench), ~30 times per step of this kernel.
 // A float difference carries the same fact in its sign bit (a - b is never -0 for a != b, +0 for a == b; denormals
@@ -306,7 +318,7 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
           }
         }
         {
-          T a = idm_fast<DELTA4>(v, vl, h, has, ic);
+          T a = idm_fast<DELTA4, FULL>(v, vl, h, has, ic);
           if (any_noise) {
             const T an = a + sl.noise * g4[0];
             a = noisy ? an : a;
@@ -321,7 +333,7 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
         T vc = v + (next_vel - v) * ramp;
         T v_new = vc;
         if (need_sumo) {
-          T v_sumo = sumo_fast(v, vl, h, has, dt, sc);
+          T v_sumo = sumo_fast<FULL>(v, vl, h, has, dt, sc);
           // S7/S8 without a per-slot test: a slot whose bit is clear holds 3e38 in the clamp's place (k_rollout_pair's form)
           vc = tmin(vc, sm1_lane ? v_sumo : T(3.0e38));
           vc = tmin(vc, v + adt_c);
@@ -334,10 +346,10 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
           // hold for a degenerate table, stream b's line is evaluated first and stream a's overrides as min would
           if (cap_m != 0ull) {
             const T line = on_b ? jb_in - x : ja_in - x;
-            T cap = sumo_fast(v, T(0), line, true, dt, sc);
+            T cap = sumo_fast<FULL>(v, T(0), line, true, dt, sc);
             cap = on_any ? cap : T(3.0e38);
             if (cap2_m != 0ull) {                                // degenerate table: both lines ahead of one vehicle
-              const T cap_a = sumo_fast(v, T(0), ja_in - x, true, dt, sc);
+              const T cap_a = sumo_fast<FULL>(v, T(0), ja_in - x, true, dt, sc);
               cap = on_both ? tmin(cap, cap_a) : cap;
             }
             const bool cap_applies = (sm1_u | (commanded_u ^ 1u)) != 0u;          // (speed_mode & 1) || !commanded
