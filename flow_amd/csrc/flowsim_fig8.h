@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
   const bool red_lane = ii < num_rl && i < N;
   const int obs_dim = HEAD == 1 ? 3 : 2 * N;
   const bool obs_lane = HEAD == 1 ? (valid && rl_lane && sl.rl_index == 0) : valid;
-  const unsigned valid_bits = valid ? 0xFu : 0u;          // flag words of idle lanes are empty
+  const unsigned valid_bits = valid ? 0x3Fu : 0u;         // flag words of idle lanes are empty
   const unsigned gate_u = gated ? 1u : 0u, cmd_rl = (rl_lane && use_act) ? 1u : 0u,
                  cmd_other = (!rl_lane && !sim_lane) ? 1u : 0u, sm1_u = unsigned(sl.speed_mode) & 1u;
   const bool sm1_lane = (sl.speed_mode & 1) != 0;
@@ -262,6 +262,15 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
   };
   T prev_v = v, last_acc = T(0);                          // track_aux: get_previous_speed / get_accel of the scalar Env
 
+  // stream a busy (bit 0: a vehicle of stream a inside the box, not yet clear of it with its tail, or within time_gap
+  // of it) / stream b in the box (bit 1), of ONE lane for the state (xx, vv)
+  auto junction_flags = [&](T xx, T vv) -> unsigned {
+    const unsigned busy_a = sm_in(xx, ja_in - tgap * vv, ja_out + sl.length);
+    const unsigned in_b = sm_in(xx, jb_in, jb_out + sl.length);
+    return (busy_a >> 31) | ((in_b >> 31) << 1);
+  };
+  unsigned jf = junction_on ? seg_or<SEG>(junction_flags(x, v) & valid_bits) : 0u;    // of the launch's first snapshot
+
   // one block of PERIOD steps; FB (a full block): the per-step "is this step inside the launch" test is a compile-time
   // fact -- the tail of a launch (num_steps % PERIOD steps) runs the same body with the test
   auto run_block = [&](const int base, auto full_block) {
@@ -277,15 +286,11 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
         const int step = base + slot;
         // the step's wave-wide tests whose inputs are the snapshot: evaluated first, consumed where they steer
         const unsigned long long draw_m = any_noise ? ballot_here(noisy && (nctr & 3u) == 0u) : 0ull;
-        unsigned jf = 0u;
         bool on_a = false, on_b = false, on_any = false, on_both = false;
         unsigned long long cap_m = 0ull, cap2_m = 0ull;
         if (junction_on) {
-          // per-replica facts of the snapshot, one OR-butterfly: bit 0 stream a busy, bit 1 stream b in the box
-          const unsigned busy_a = sm_in(x, ja_in - tgap * v, ja_out + sl.length);
-          const unsigned in_b = sm_in(x, jb_in, jb_out + sl.length);
-          jf = ((busy_a >> 31) | ((in_b >> 31) << 1)) & valid_bits;
-          jf = seg_or<SEG>(jf);
+          // per-replica facts of the snapshot (bit 0 stream a busy, bit 1 stream b in the box): `jf`, reduced over the
+          // replica together with the collision flags of the state it describes -- at the end of the previous step
           const unsigned on_b_m = sm_in(x, jb_in - look, jb_in) & (jf << 31);
           const unsigned on_a_m = sm_in(x, ja_in - look, ja_in) & (jf << 30);
           on_b = sm_true(on_b_m);
@@ -386,9 +391,11 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
           f2 |= (sm_in(x, zb_lo, zb_hi) >> 31) << 2;
         }
         f2 |= (sm_lt(v, T(-100)) >> 31) << 3;
+        if (junction_on) f2 |= junction_flags(x, v) << 4;        // the next step's jf rides in bits 4 / 5 of the same butterfly
         f2 &= valid_bits;
         unsigned long long adv_m = ballot_here(x >= n_next);     // a third start passed / one passed after a wrap (rare)
         f2 = seg_or<SEG>(f2);
+        jf = (f2 >> 4) & 3u;
         const unsigned crashed = (f2 | ((f2 >> 1) & (f2 >> 2))) & 1u;       // (f2 & 1) || ((f2 & 6) == 6)
         const unsigned bad = ((f2 >> 3) | crashed) & 1u;
         crash_bits |= crashed << slot;
