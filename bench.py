@@ -314,7 +314,8 @@ def ring_defaults_leg(device, R=4096, K=1500):
     """The reference's own 22-IDM ring experiment AS SHIPPED (examples/exp_configs/non_rl/ring.py:13-61: the
     SumoCarFollowingParams default speed_mode 'right_of_way' = 25, whose bit 0 makes SUMO's safe-speed rule cap
     every command) through VecFlowEnv, in float32 and in FS_MIXED: k_rollout_pair with the speed-mode clamps
-    compiled in (round 1 and the first half of round 2 ran it on the generic k_steps kernel, 2.5 G env-steps/s)."""
+    compiled in (round 1 and the first half of round 2 ran it on the generic k_steps kernel, 2.5 G env-steps/s); and
+    the same experiment with IDMController(noise=0.2), the human model of the reference's RL experiments."""
     import torch
     from flow_amd.controllers import ContinuousRouter, IDMController
     from flow_amd.core.params import EnvParams, InitialConfig, NetParams, SumoParams, VehicleParams
@@ -324,10 +325,10 @@ def ring_defaults_leg(device, R=4096, K=1500):
     out = {"unit": "env-steps/s", "replicas": R,
            "workload": "examples/exp_configs/non_rl/ring.py through VecFlowEnv: 22 IDM, speed_mode 'right_of_way' "
                        "(the SumoCarFollowingParams default), %d-step rollout launches" % K}
-    for precision in ("mixed", "f32"):
+    for precision, noise in (("mixed", 0.0), ("f32", 0.0), ("f32", 0.2)):
         veh = VehicleParams()
-        veh.add(veh_id="idm", acceleration_controller=(IDMController, {}), routing_controller=(ContinuousRouter, {}),
-                num_vehicles=22)
+        veh.add(veh_id="idm", acceleration_controller=(IDMController, {"noise": noise} if noise else {}),
+                routing_controller=(ContinuousRouter, {}), num_vehicles=22)
         fp = dict(exp_tag="ring", env_name=AccelEnv, network=RingNetwork, simulator="traci",
                   sim=SumoParams(render=False, sim_step=0.1, precision=precision),
                   env=EnvParams(horizon=1500, additional_params={"max_accel": 3, "max_decel": 3, "target_velocity": 10,
@@ -349,7 +350,8 @@ def ring_defaults_leg(device, R=4096, K=1500):
             n += K
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - t0
-        out[precision] = {"value": R * n / dt, "steps": n, "kernel": vec.sim.last_kernel}
+        out[precision + ("_noise_%g" % noise if noise else "")] = {"value": R * n / dt, "steps": n,
+                                                                   "kernel": vec.sim.last_kernel}
         vec.close()
     out["value"] = out["mixed"]["value"]
     return out

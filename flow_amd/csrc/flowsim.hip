@@ -560,10 +560,11 @@ struct Sim : SimBase {
   bool sumo_beyond_speed_mode = false;   // FLAG_NEED_SUMO for more than speed-mode bits (Sim / RL slots, junction mode)
   bool speed_mode_any = false;           // some slot carries a speed-mode clamp (bits 0-2)
   // allow_speed_mode: the caller's kernel evaluates the speed-mode clamps itself (k_rollout_pair<..., SM = true>)
-  bool fast_ok(const uint8_t* mask, int num_steps, bool allow_speed_mode = false) const {
+  bool fast_ok(const uint8_t* mask, int num_steps, bool allow_speed_mode = false, bool allow_noise = false) const {
     const int f = dv.flags;
     const bool sumo_free = !(f & fs::FLAG_NEED_SUMO) || (allow_speed_mode && !sumo_beyond_speed_mode);
-    return (f & fs::FLAG_ALL_IDM) && !(f & (fs::FLAG_HAS_NOISE | fs::FLAG_HAS_FAILSAFE)) && sumo_free &&
+    const bool noise_free = !(f & fs::FLAG_HAS_NOISE) || allow_noise;
+    return (f & fs::FLAG_ALL_IDM) && !(f & fs::FLAG_HAS_FAILSAFE) && noise_free && sumo_free &&
            dv.env == FS_ENV_ACCEL && !dv.evaluate && dv.sims_per_step == 1 && dv.integrator == FS_EULER &&
            !dv.junction_mode && !dv.track_aux && mask == nullptr && num_steps > 0 && !force_generic &&
            dv.nseg == 0 && !dv.junction_on && !dv.sort_vehicles && dv.obs_perm == nullptr;
@@ -631,7 +632,8 @@ struct Sim : SimBase {
     }
     // two vehicles per lane (flowsim_pair.h): even N; the only stepping kernel of a FS_MIXED handle
     constexpr int ROW = SEG >= 16 ? SEG / 2 : 8;
-    const bool pair_ok = fast_ok(mask, num_steps, true) && (obs_every_step || num_steps == 1) && dv.N >= 2 &&
+    const bool pair_noise = std::is_same<T, float>::value && !mixed;      // the noisy form exists in float32 only
+    const bool pair_ok = fast_ok(mask, num_steps, true, pair_noise) && (obs_every_step || num_steps == 1) && dv.N >= 2 &&
                          (dv.N % 2) == 0 && actions == nullptr && !no_pair &&
                          size_t(dv.R) * 2 * dv.N * sizeof(float) * 16 < (size_t(1) << 32);   // 32-bit offsets in a block
     // closed loops with a segment table (figure eight): the rollout kernel of flowsim_fig8.h
@@ -685,7 +687,17 @@ struct Sim : SimBase {
 #define FS_PAIR(D4, FD, BC)                                                                                   \
   hipLaunchKernelGGL((fs::k_rollout_pair<T, ROW, D4, FD, BC>), grid, block, 0, stream, dv, num_steps, obs, rew, done)
       last_kernel = speed_mode_any ? "k_rollout_pair+speed_mode" : "k_rollout_pair";
-      if (speed_mode_any) {                   // the reference's default speed mode "right_of_way" lands here
+      if (dv.flags & fs::FLAG_HAS_NOISE) {
+        if constexpr (std::is_same<T, float>::value) {
+          last_kernel = speed_mode_any ? "k_rollout_pair+speed_mode+noise" : "k_rollout_pair+noise";
+#define FS_PAIR_N(D4, FD, BC, SM_)                                                                            \
+  hipLaunchKernelGGL((fs::k_rollout_pair<float, ROW, D4, FD, BC, SM_, true>), grid, block, 0, stream, dv, num_steps,  \
+                     obs, rew, done)
+          if (delta4 && fd && !bc) { if (speed_mode_any) FS_PAIR_N(true, true, false, true); else FS_PAIR_N(true, true, false, false); }
+          else { if (speed_mode_any) FS_PAIR_N(false, false, true, true); else FS_PAIR_N(false, false, true, false); }
+#undef FS_PAIR_N
+        }
+      } else if (speed_mode_any) {                   // the reference's default speed mode "right_of_way" lands here
         if (delta4 && fd && !bc)
           hipLaunchKernelGGL((fs::k_rollout_pair<T, ROW, true, true, false, true>), grid, block, 0, stream, dv,
                              num_steps, obs, rew, done);

@@ -646,12 +646,15 @@ __device__ __forceinline__ void mixed_step_asm_b(f2& V32, double& XA, double& XB
 
 // T = float: the float32 bit-twin.  T = double: MIXED (see the header).  ROW = lanes per replica (N <= 2 ROW).
 // SM: some slot carries a speed-mode clamp (bits 0-2): the C++ step with sumo_acc_pair.
-template <typename T, int ROW, bool DELTA4, bool FASTDIV, bool BADCHK, bool SM = false>
+// NOISE (float32 only): IDMController(noise = sigma) slots -- acc + sigma * g with the generic kernel's draws (gauss4 keyed
+// by seed, global replica, vehicle, draw counter / 4; base_controller.py:109-110), the C++ step.
+template <typename T, int ROW, bool DELTA4, bool FASTDIV, bool BADCHK, bool SM = false, bool NOISE = false>
 __global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_steps, float* __restrict__ obs,
                                                       float* __restrict__ rew, uint8_t* __restrict__ done) {
   constexpr bool MIXED = sizeof(T) == 8;
+  static_assert(!(NOISE && MIXED), "FS_MIXED has no noise form (its C twin cannot reproduce the hardware's log / cos)");
   // the hand-written steps: pair_step_asm_a / _a_sm + _b (float32, without / with the speed-mode clamps), mixed_step_asm
-  constexpr bool ASM = ROW == 16 && DELTA4 && FASTDIV && !BADCHK;
+  constexpr bool ASM = ROW == 16 && DELTA4 && FASTDIV && !BADCHK && !NOISE;
   constexpr int RPW = 64 / ROW;
   constexpr int PERIOD = ROW < 16 ? ROW : 16;       // steps whose reward tail is finished together
   const int lane = threadIdx.x & 63;
@@ -679,6 +682,22 @@ __global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_step
   const T base_len = s.ring_len[rr];
   const T L = base_len + T(4) * s.jlen;
   int tcount = s.time[rr];
+  // acceleration noise: the two vehicles' blocks of four draws, rotated so that [0] is the next step's (k_rollout_loop's
+  // scheme); a launch that starts inside a block evaluates it and rotates up to there
+  uint32_t nctr = NOISE ? s.noise_ctr[rr] : 0u;
+  const f2 sigma = NOISE ? f2{float(s.noise[iA]), float(s.noise[iB])} : f2{0.0f, 0.0f};
+  const bool noisyA = NOISE && sigma.x > 0.0f, noisyB = NOISE && sigma.y > 0.0f;
+  float gA[4] = {0.0f, 0.0f, 0.0f, 0.0f}, gB[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if constexpr (NOISE) {
+    if ((nctr & 3u) != 0u) {
+      gauss4<float>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(iA), nctr >> 2, gA);
+      gauss4<float>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(iB), nctr >> 2, gB);
+      for (uint32_t q = 0; q < (nctr & 3u); ++q) {
+        gA[0] = gA[1]; gA[1] = gA[2]; gA[2] = gA[3];
+        gB[0] = gB[1]; gB[1] = gB[2]; gB[2] = gB[3];
+      }
+    }
+  }
 
   const float dt = float(s.dt), ramp = float(s.ramp);
   const f2 two_sqrt_ab = {2.0f * tsqrt(p[2].x * p[3].x), 2.0f * tsqrt(p[2].y * p[3].y)};
@@ -829,7 +848,22 @@ __global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_step
       return;
     }
     // IDMController.get_accel on the snapshot
-    const f2 acc = idm_pair<DELTA4, FASTDIV>(v, vl, h, p, two_sqrt_ab, rc_ab, rc_v0, one);
+    f2 acc = idm_pair<DELTA4, FASTDIV>(v, vl, h, p, two_sqrt_ab, rc_ab, rc_v0, one);
+    if constexpr (NOISE) {
+      const bool fresh = (nctr & 3u) == 0u;                      // a new block of four draws starts with this step
+      if (__ballot(fresh) != 0ull) {
+        if (fresh) {
+          gauss4<float>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(iA), nctr >> 2, gA);
+          gauss4<float>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(iB), nctr >> 2, gB);
+        }
+      }
+      const float aA = acc.x + sigma.x * gA[0], aB = acc.y + sigma.y * gB[0];
+      acc.x = noisyA ? aA : acc.x;
+      acc.y = noisyB ? aB : acc.y;
+      gA[0] = gA[1]; gA[1] = gA[2]; gA[2] = gA[3];
+      gB[0] = gB[1]; gB[1] = gB[2]; gB[2] = gB[3];
+      nctr += 1u;
+    }
     f2 acc_s = {0.0f, 0.0f};
     if constexpr (SM) acc_s = sumo_acc_pair<FASTDIV>(v, vl, h, sc, one);
     f2 ox;
@@ -965,6 +999,7 @@ __global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_step
       s.vel[idx] = T(v.x); s.vel[idx + 1] = T(v.y);
     }
     if (kk == 0) s.time[rr] = tcount;
+    if (NOISE && kk == 0) s.noise_ctr[rr] = nctr;
   }
 }
 

@@ -319,6 +319,54 @@ def test_pair_hand_written_steps_fuzz_f32_and_mixed(seed):
     msim.close()
 
 
+@pytest.mark.parametrize("N,modes", [(22, [0]), (22, [25]), (30, [0, 1, 7]), (8, [0]), (40, [25, 0])])
+def test_pair_noisy_idm_bit_exact_vs_generic_kernel_and_close_to_the_oracle(N, modes):
+    """IDMController(noise = sigma) on every second slot or all of them: the pair kernel's noisy form draws what the
+    generic kernel draws (same Philox keys, same hardware log / cos): bit-identical outputs and state, also across two
+    launches that split a block of four draws; the numpy oracle (libm log / cos) agrees to float tolerance."""
+    import torch
+    from flow_amd.sim import FlowSim
+    rng = np.random.default_rng(7 * N + len(modes))
+    R, K1, K2 = 9, 37, 45
+    veh = [idm_vehicle(noise=float(rng.choice([0.0, 0.2, 0.6])) if i % 3 else 0.3, speed_mode=int(modes[i % len(modes)]),
+                       max_decel=float(rng.choice([1.5, 4.5]))) for i in range(N)]
+    spec = perturbed(ring_spec(R=R, N=N, length=max(230.0, 9.5 * N), bunching=0, junction_length=0.1, horizon=10 ** 6,
+                               vehicles=veh, seed=123), seed=N, sigma=0.3)
+    dev = torch.device("cuda", 0)
+    outs = []
+    for env in ({}, {"FLOWSIM_FORCE_GENERIC": "1"}):
+        for k_, v_ in env.items():
+            os.environ[k_] = v_
+        try:
+            sim = FlowSim(spec, "f32")
+        finally:
+            for k_ in env:
+                os.environ.pop(k_, None)
+        o = torch.empty((K1 + K2, R, sim.obs_dim), device=dev)
+        r = torch.empty((K1 + K2, R), device=dev)
+        d = torch.empty((K1 + K2, R), dtype=torch.uint8, device=dev)
+        sim.reset()
+        torch.cuda.synchronize()
+        sim.rollout_dev(K1, o[:K1], r[:K1], d[:K1])
+        sim.rollout_dev(K2, o[K1:], r[K1:], d[K1:])
+        sim.sync()
+        outs.append((sim, o.cpu().numpy(), r.cpu().numpy(), d.cpu().numpy()))
+    (a, oa, ra, da), (b, ob, rb, db) = outs
+    want = "k_rollout_pair+speed_mode+noise" if any(m & 7 for m in modes) else "k_rollout_pair+noise"
+    assert a.last_kernel == want and b.last_kernel.startswith("k_steps")
+    np.testing.assert_array_equal(oa, ob)
+    np.testing.assert_array_equal(ra, rb)
+    np.testing.assert_array_equal(da, db)
+    np.testing.assert_array_equal(a.pos, b.pos)
+    np.testing.assert_array_equal(a.vel, b.vel)
+    ora = S.RingOracle(spec, np.float32)
+    ora.reset()
+    for k in range(20):
+        o_ref, _, _ = ora.step(None)
+    np.testing.assert_allclose(oa[19], o_ref, atol=2e-4)
+    a.close(), b.close()
+
+
 def test_speed_mode_changes_the_trajectory_and_is_not_the_aggressive_kernel():
     # the same ring with and without bit 0: the clamp must bind somewhere (otherwise the tests above prove nothing)
     base = perturbed(ring_spec(R=6, N=22, length=150.0, bunching=0, junction_length=0.1, horizon=400), seed=9, sigma=0.4)
