@@ -359,8 +359,8 @@ int fs_rollout_dev(fs_handle h, int num_steps, const float* actions_dev, size_t 
 int fs_get_state(fs_handle h, int field, void* dst, size_t bytes);
 int fs_set_state(fs_handle h, int field, const void* src, size_t bytes);
 
-/* Family of the step kernel the handle's last fs_step / fs_rollout launch chose ("k_rollout_pair",
- * "k_rollout_pair+speed_mode", "k_rollout_idm", "k_rollout_loop", "k_steps<FAST>", "k_steps<CSET>", "k_steps",
+/* Family of the step kernel the handle's last fs_step / fs_rollout launch chose ("k_rollout_pair" with "+speed_mode"
+ * and / or "+noise", "k_rollout_idm", "k_rollout_loop", "k_rollout_loop<FULL>", "k_steps<FAST>", "k_steps<CSET>", "k_steps",
  * "k_steps_ml", "k_steps_open", "k_steps_wide"; "" before the first launch).  Diagnostics for tests and bench.py: which
  * configuration class a workload landed in (no reference counterpart).  The string is static. */
 const char* fs_last_kernel(fs_handle h);
