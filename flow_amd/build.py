@@ -7,7 +7,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 SRC = os.path.join(PKG, "csrc", "flowsim.hip")
 DEPS = [SRC, os.path.join(PKG, "csrc", "flowsim_kernels.h"), os.path.join(PKG, "csrc", "flowsim_open.h"),
-        os.path.join(PKG, "csrc", "flowsim_wide.h"), os.path.join(PKG, "csrc", "flowsim_pair.h"), os.path.join(PKG, "csrc", "flowsim_fig8.h"),
+        os.path.join(PKG, "csrc", "flowsim_wide.h"), os.path.join(PKG, "csrc", "flowsim_pair.h"), os.path.join(PKG, "csrc", "flowsim_pair_step_a.inc"),
+        os.path.join(PKG, "csrc", "flowsim_pair_step_a_sm.inc"), os.path.join(PKG, "csrc", "flowsim_fig8.h"),
         os.path.join(ROOT, "include", "flowsim.h")]
 LIB = os.path.join(PKG, "libflowsim.so")
 

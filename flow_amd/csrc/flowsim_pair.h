@@ -172,170 +172,37 @@ struct PairConsts {
 };
 // part A: controller, integration, position observation (stored by the caller between the two parts: the two
 // stores of a step reach the CU's memory pipeline half a step apart)
-__device__ __forceinline__ void pair_step_asm_a(f2& V, f2& X, f2& H, f2& DVL, f2& OX, const PairConsts& c) {
-  unsigned long long sa, sb;
-  asm volatile(
-      // ---- IDMController.get_accel
-      "v_cmp_nlt_f32_e64 %[sa], |v116|, %[c1e3]\n"
-      "v_cmp_nlt_f32_e64 %[sb], |v117|, %[c1e3]\n"
-      "v_pk_mul_f32 v[124:125], v[112:113], v[118:119]\n"                                   // num = v (v - vl)
-      "v_pk_mul_f32 v[126:127], v[124:125], %[rcab]\n"
-      "v_pk_fma_f32 v[130:131], v[126:127], %[tsab], v[124:125] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
-      "v_pk_fma_f32 v[126:127], v[130:131], %[rcab], v[126:127]\n"                          // B = num / 2sqrt(ab)
-      "v_cndmask_b32_e64 v120, %[c1e3], v116, %[sa]\n"                                      // hh
-      "v_cndmask_b32_e64 v121, %[c1e3], v117, %[sb]\n"
-      "v_pk_mul_f32 v[124:125], v[112:113], %[rcv0]\n"
-      "v_rcp_f32_e32 v122, v120\n"
-      "v_rcp_f32_e32 v123, v121\n"
-      "v_pk_fma_f32 v[130:131], v[124:125], %[p0], v[112:113] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
-      "v_pk_fma_f32 v[124:125], v[130:131], %[rcv0], v[124:125]\n"                          // A = v / v0
-      "v_pk_mul_f32 v[130:131], v[112:113], %[p1]\n"
-      "v_pk_add_f32 v[130:131], v[130:131], v[126:127]\n"                                   // C = dyn
-      "v_pk_fma_f32 v[126:127], v[120:121], v[122:123], %[one] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"   // e
-      "v_max_f32_e32 v130, 0, v130\n"
-      "v_max_f32_e32 v131, 0, v131\n"
-      "v_pk_fma_f32 v[122:123], v[126:127], v[122:123], v[122:123]\n"                       // Y = refined 1/hh
-      "v_pk_add_f32 v[130:131], %[p5], v[130:131]\n"                                        // C = s*
-      "v_pk_mul_f32 v[124:125], v[124:125], v[124:125]\n"
-      "v_pk_mul_f32 v[126:127], v[130:131], v[122:123]\n"                                   // q0
-      "v_pk_mul_f32 v[124:125], v[124:125], v[124:125]\n"                                   // A = (v/v0)^4
-      "v_pk_fma_f32 v[132:133], v[120:121], v[126:127], v[130:131] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
-      "v_pk_add_f32 v[124:125], %[one], v[124:125] neg_lo:[0,1] neg_hi:[0,1]\n"             // A = 1 - pw
-      "v_pk_fma_f32 v[126:127], v[132:133], v[122:123], v[126:127]\n"                       // q1
-      "v_pk_fma_f32 v[132:133], v[120:121], v[126:127], v[130:131] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
-      "v_pk_fma_f32 v[126:127], v[132:133], v[122:123], v[126:127]\n"                       // B = s* / hh
-      "v_pk_mul_f32 v[126:127], v[126:127], v[126:127]\n"
-      "v_pk_add_f32 v[124:125], v[124:125], v[126:127] neg_lo:[0,1] neg_hi:[0,1]\n"
-      "v_pk_mul_f32 v[124:125], %[p2], v[124:125]\n"                                        // A = acc
-      // ---- apply_acceleration + integration (S4-S9)
-      "v_pk_mul_f32 v[124:125], v[124:125], %[dt2]\n"
-      "v_pk_add_f32 v[124:125], v[112:113], v[124:125]\n"
-      "v_max_f32_e32 v124, 0, v124\n"
-      "v_max_f32_e32 v125, 0, v125\n"                                                       // next_vel
-      "v_pk_add_f32 v[124:125], v[124:125], v[112:113] neg_lo:[0,1] neg_hi:[0,1]\n"
-      "v_pk_mul_f32 v[124:125], v[124:125], %[ramp2]\n"
-      "v_pk_add_f32 v[112:113], v[112:113], v[124:125]\n"                                   // V = v'
-      "v_pk_mul_f32 v[124:125], v[112:113], %[dt2]\n"
-      "v_pk_add_f32 v[124:125], v[114:115], v[124:125]\n"                                   // x_new
-      "v_pk_add_f32 v[126:127], v[124:125], %[L2] neg_lo:[0,1] neg_hi:[0,1]\n"              // x_new - L
-      "v_min_u32_e32 v114, v126, v124\n"                                                    // X = x'
-      "v_min_u32_e32 v115, v127, v125\n"
-      // ---- observation x'/L
-      "v_pk_mul_f32 v[124:125], v[114:115], %[rcL2]\n"
-      "v_pk_fma_f32 v[126:127], v[124:125], %[L2], v[114:115] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
-      "v_pk_fma_f32 %[ox], v[126:127], %[rcL2], v[124:125]\n"
-      : "+{v[112:113]}"(V), "+{v[114:115]}"(X), "+{v[116:117]}"(H), "+{v[118:119]}"(DVL), [ox] "=&v"(OX),
-        [sa] "=&s"(sa), [sb] "=&s"(sb)
-      : [c1e3] "v"(c.c1e3), [rcab] "v"(c.rc_ab), [tsab] "v"(c.tsab), [rcv0] "v"(c.rc_v0), [p0] "v"(c.p0),
-        [p1] "v"(c.p1), [p2] "v"(c.p2), [p5] "v"(c.p5), [one] "v"(c.one), [dt2] "v"(c.dt2), [ramp2] "v"(c.ramp2),
-        [L2] "v"(c.L2), [rcL2] "v"(c.rc_L2)
-      : "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v130", "v131", "v132", "v133");
-}
+#define FS_PAIR_A_NAME pair_step_asm_a
+#define FS_PAIR_A_NZ 0
+#define FS_PAIR_A_NZ_PARAM
+#include "flowsim_pair_step_a.inc"
+#undef FS_PAIR_A_NAME
+#undef FS_PAIR_A_NZ
+#undef FS_PAIR_A_NZ_PARAM
+#define FS_PAIR_A_NAME pair_step_asm_a_nz
+#define FS_PAIR_A_NZ 1
+#define FS_PAIR_A_NZ_PARAM , f2 nz
+#include "flowsim_pair_step_a.inc"
+#undef FS_PAIR_A_NAME
+#undef FS_PAIR_A_NZ
+#undef FS_PAIR_A_NZ_PARAM
 // part A with the speed-mode clamps (SM: sumo_acc_pair's operations interleaved with the controller's, same order per
 // quantity; the clamps as max / min against constants that are 3e38 for a slot whose bit is clear).  Extra registers:
 // G (gap) v[138:139], YS v[140:141], S v[142:143], Q v[144:145], R v[146:147]; E v[134:135] as a second residual.
-__device__ __forceinline__ void pair_step_asm_a_sm(f2& V, f2& X, f2& H, f2& DVL, f2& OX, const PairConsts& c,
-                                                   const SumoPair& m) {
-  unsigned long long sa, sb;
-  asm volatile(
-      "v_cmp_nlt_f32_e64 %[sa], |v116|, %[c1e3]\n"
-      "v_cmp_nlt_f32_e64 %[sb], |v117|, %[c1e3]\n"
-      "v_pk_mul_f32 v[124:125], v[112:113], v[118:119]\n"                                   // num = v (v - vl)
-      "v_pk_mul_f32 v[126:127], v[124:125], %[rcab]\n"
-      "v_pk_mul_f32 v[142:143], v[124:125], %[rcts]\n"                                      // S: num / 2sqrt(accel decel) ...
-      "v_pk_fma_f32 v[130:131], v[126:127], %[tsab], v[124:125] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
-      "v_pk_fma_f32 v[144:145], v[142:143], %[ts], v[124:125] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
-      "v_pk_fma_f32 v[126:127], v[130:131], %[rcab], v[126:127]\n"                          // B = num / 2sqrt(ab)
-      "v_pk_fma_f32 v[142:143], v[144:145], %[rcts], v[142:143]\n"                          // S = num / ts
-      "v_cndmask_b32_e64 v120, %[c1e3], v116, %[sa]\n"                                      // hh
-      "v_cndmask_b32_e64 v121, %[c1e3], v117, %[sb]\n"
-      "v_max_f32_e32 v138, v116, %[c1e3]\n"                                                 // G = max(h, 1e-3)
-      "v_max_f32_e32 v139, v117, %[c1e3]\n"
-      "v_pk_mul_f32 v[124:125], v[112:113], %[rcv0]\n"
-      "v_rcp_f32_e32 v122, v120\n"
-      "v_rcp_f32_e32 v123, v121\n"
-      "v_rcp_f32_e32 v140, v138\n"
-      "v_rcp_f32_e32 v141, v139\n"
-      "v_pk_fma_f32 v[130:131], v[124:125], %[p0], v[112:113] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
-      "v_pk_mul_f32 v[146:147], v[112:113], %[rcsm]\n"                                      // R: v / maxSpeed ...
-      "v_pk_fma_f32 v[124:125], v[130:131], %[rcv0], v[124:125]\n"                          // A = v / v0
-      "v_pk_fma_f32 v[144:145], v[146:147], %[smax], v[112:113] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
-      "v_pk_mul_f32 v[130:131], v[112:113], %[p1]\n"
-      "v_pk_fma_f32 v[146:147], v[144:145], %[rcsm], v[146:147]\n"                          // R = v / maxSpeed
-      "v_pk_add_f32 v[130:131], v[130:131], v[126:127]\n"                                   // C = dyn
-      "v_pk_mul_f32 v[144:145], v[112:113], %[tau]\n"
-      "v_pk_fma_f32 v[126:127], v[120:121], v[122:123], %[one] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"   // e
-      "v_pk_add_f32 v[142:143], v[144:145], v[142:143]\n"                                   // S = dyn_s = v tau + dq_s
-      "v_pk_fma_f32 v[144:145], v[138:139], v[140:141], %[one] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"   // e_s
-      "v_max_f32_e32 v130, 0, v130\n"
-      "v_max_f32_e32 v131, 0, v131\n"
-      "v_max_f32_e32 v142, 0, v142\n"
-      "v_max_f32_e32 v143, 0, v143\n"
-      "v_pk_fma_f32 v[122:123], v[126:127], v[122:123], v[122:123]\n"                       // Y = refined 1/hh
-      "v_pk_fma_f32 v[140:141], v[144:145], v[140:141], v[140:141]\n"                       // YS = refined 1/gap
-      "v_pk_add_f32 v[130:131], %[p5], v[130:131]\n"                                        // C = s*
-      "v_pk_add_f32 v[142:143], %[mgap], v[142:143]\n"                                      // S = ss
-      "v_pk_mul_f32 v[124:125], v[124:125], v[124:125]\n"
-      "v_pk_mul_f32 v[146:147], v[146:147], v[146:147]\n"
-      "v_pk_mul_f32 v[126:127], v[130:131], v[122:123]\n"                                   // q0
-      "v_pk_mul_f32 v[144:145], v[142:143], v[140:141]\n"                                   // q0_s
-      "v_pk_mul_f32 v[124:125], v[124:125], v[124:125]\n"                                   // A = (v/v0)^4
-      "v_pk_mul_f32 v[146:147], v[146:147], v[146:147]\n"                                   // R = (v/maxSpeed)^4
-      "v_pk_fma_f32 v[132:133], v[120:121], v[126:127], v[130:131] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
-      "v_pk_fma_f32 v[134:135], v[138:139], v[144:145], v[142:143] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
-      "v_pk_add_f32 v[124:125], %[one], v[124:125] neg_lo:[0,1] neg_hi:[0,1]\n"             // A = 1 - pw
-      "v_pk_add_f32 v[146:147], %[one], v[146:147] neg_lo:[0,1] neg_hi:[0,1]\n"             // R = 1 - r^4
-      "v_pk_fma_f32 v[126:127], v[132:133], v[122:123], v[126:127]\n"                       // q1
-      "v_pk_fma_f32 v[144:145], v[134:135], v[140:141], v[144:145]\n"                       // q1_s
-      "v_pk_fma_f32 v[132:133], v[120:121], v[126:127], v[130:131] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
-      "v_pk_fma_f32 v[134:135], v[138:139], v[144:145], v[142:143] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
-      "v_pk_fma_f32 v[126:127], v[132:133], v[122:123], v[126:127]\n"                       // B = s* / hh
-      "v_pk_fma_f32 v[144:145], v[134:135], v[140:141], v[144:145]\n"                       // Q = ss / gap
-      "v_pk_mul_f32 v[126:127], v[126:127], v[126:127]\n"
-      "v_pk_mul_f32 v[144:145], v[144:145], v[144:145]\n"
-      "v_pk_add_f32 v[124:125], v[124:125], v[126:127] neg_lo:[0,1] neg_hi:[0,1]\n"
-      "v_pk_add_f32 v[146:147], v[146:147], v[144:145] neg_lo:[0,1] neg_hi:[0,1]\n"
-      "v_pk_mul_f32 v[124:125], %[p2], v[124:125]\n"                                        // A = acc
-      "v_pk_mul_f32 v[146:147], %[maxa], v[146:147]\n"                                      // R = SUMO's acceleration
-      // ---- apply_acceleration + the clamps (S4-S8)
-      "v_pk_mul_f32 v[124:125], v[124:125], %[dt2]\n"
-      "v_pk_mul_f32 v[146:147], v[146:147], %[dt2]\n"
-      "v_pk_add_f32 v[124:125], v[112:113], v[124:125]\n"
-      "v_pk_add_f32 v[146:147], v[112:113], v[146:147]\n"                                   // v + acc_s dt
-      "v_max_f32_e32 v124, 0, v124\n"
-      "v_max_f32_e32 v125, 0, v125\n"                                                       // next_vel
-      "v_max_f32_e32 v146, %[fl0], v146\n"                                                  // v_sumo (3e38 when bit 0 is clear)
-      "v_max_f32_e32 v147, %[fl1], v147\n"
-      "v_pk_add_f32 v[124:125], v[124:125], v[112:113] neg_lo:[0,1] neg_hi:[0,1]\n"
-      "v_pk_add_f32 v[144:145], v[112:113], %[adt]\n"                                       // v + max_accel dt
-      "v_pk_mul_f32 v[124:125], v[124:125], %[ramp2]\n"
-      "v_pk_add_f32 v[142:143], v[112:113], %[ddt] neg_lo:[0,1] neg_hi:[0,1]\n"             // v - max_decel dt
-      "v_pk_add_f32 v[124:125], v[112:113], v[124:125]\n"                                   // vc
-      "v_min_f32_e32 v124, v124, v146\n"
-      "v_min_f32_e32 v125, v125, v147\n"
-      "v_min_f32_e32 v124, v124, v144\n"
-      "v_min_f32_e32 v125, v125, v145\n"
-      "v_max_f32_e32 v112, v124, v142\n"                                                    // V = v'
-      "v_max_f32_e32 v113, v125, v143\n"
-      "v_pk_mul_f32 v[124:125], v[112:113], %[dt2]\n"
-      "v_pk_add_f32 v[124:125], v[114:115], v[124:125]\n"                                   // x_new
-      "v_pk_add_f32 v[126:127], v[124:125], %[L2] neg_lo:[0,1] neg_hi:[0,1]\n"              // x_new - L
-      "v_min_u32_e32 v114, v126, v124\n"                                                    // X = x'
-      "v_min_u32_e32 v115, v127, v125\n"
-      // ---- observation x'/L
-      "v_pk_mul_f32 v[124:125], v[114:115], %[rcL2]\n"
-      "v_pk_fma_f32 v[126:127], v[124:125], %[L2], v[114:115] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
-      "v_pk_fma_f32 %[ox], v[126:127], %[rcL2], v[124:125]\n"
-      : "+{v[112:113]}"(V), "+{v[114:115]}"(X), "+{v[116:117]}"(H), "+{v[118:119]}"(DVL), [ox] "=&v"(OX),
-        [sa] "=&s"(sa), [sb] "=&s"(sb)
-      : [c1e3] "v"(c.c1e3), [rcab] "v"(c.rc_ab), [tsab] "v"(c.tsab), [rcv0] "v"(c.rc_v0), [p0] "v"(c.p0),
-        [p1] "v"(c.p1), [p2] "v"(c.p2), [p5] "v"(c.p5), [one] "v"(c.one), [dt2] "v"(c.dt2), [ramp2] "v"(c.ramp2),
-        [L2] "v"(c.L2), [rcL2] "v"(c.rc_L2), [rcts] "v"(m.rc_ts), [ts] "v"(m.ts), [rcsm] "v"(m.rc_smax),
-        [smax] "v"(m.smax), [tau] "v"(m.tau), [mgap] "v"(m.min_gap), [maxa] "v"(m.maxa), [fl0] "v"(m.floor0.x),
-        [fl1] "v"(m.floor0.y), [adt] "v"(m.adt), [ddt] "v"(m.ddt)
-      : "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v130", "v131", "v132", "v133", "v134", "v135",
-        "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147");
-}
+#define FS_PAIR_A_NAME pair_step_asm_a_sm
+#define FS_PAIR_A_NZ 0
+#define FS_PAIR_A_NZ_PARAM
+#include "flowsim_pair_step_a_sm.inc"
+#undef FS_PAIR_A_NAME
+#undef FS_PAIR_A_NZ
+#undef FS_PAIR_A_NZ_PARAM
+#define FS_PAIR_A_NAME pair_step_asm_a_sm_nz
+#define FS_PAIR_A_NZ 1
+#define FS_PAIR_A_NZ_PARAM , f2 nz
+#include "flowsim_pair_step_a_sm.inc"
+#undef FS_PAIR_A_NAME
+#undef FS_PAIR_A_NZ
+#undef FS_PAIR_A_NZ_PARAM
 // part B: new neighbour snapshot, collision bit, reward term, speed observation
 __device__ __forceinline__ void pair_step_asm_b(f2& V, f2& X, f2& H, f2& DVL, f2& OV, unsigned& crash_bits, float& sq,
                                                 const PairConsts& c) {
@@ -654,7 +521,7 @@ __global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_step
   constexpr bool MIXED = sizeof(T) == 8;
   static_assert(!(NOISE && MIXED), "FS_MIXED has no noise form (its C twin cannot reproduce the hardware's log / cos)");
   // the hand-written steps: pair_step_asm_a / _a_sm + _b (float32, without / with the speed-mode clamps), mixed_step_asm
-  constexpr bool ASM = ROW == 16 && DELTA4 && FASTDIV && !BADCHK && !NOISE;
+  constexpr bool ASM = ROW == 16 && DELTA4 && FASTDIV && !BADCHK;
   constexpr int RPW = 64 / ROW;
   constexpr int PERIOD = ROW < 16 ? ROW : 16;       // steps whose reward tail is finished together
   const int lane = threadIdx.x & 63;
@@ -817,6 +684,27 @@ __global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_step
     piece = *reinterpret_cast<const u4v*>(my_img + 4 * kk);
   };
 
+  // sigma * g of this step for the lane's two vehicles (-0.0 for a slot without noise: x + (-0) keeps every bit of x)
+  auto noise_term = [&]() -> f2 {
+    f2 nz = {-0.0f, -0.0f};
+    if constexpr (NOISE) {
+      const bool fresh = (nctr & 3u) == 0u;                      // a new block of four draws starts with this step
+      if (__ballot(fresh) != 0ull) {
+        if (fresh) {
+          gauss4<float>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(iA), nctr >> 2, gA);
+          gauss4<float>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(iB), nctr >> 2, gB);
+        }
+      }
+      const float tA = sigma.x * gA[0], tB = sigma.y * gB[0];
+      nz.x = noisyA ? tA : -0.0f;
+      nz.y = noisyB ? tB : -0.0f;
+      gA[0] = gA[1]; gA[1] = gA[2]; gA[2] = gA[3];
+      gB[0] = gB[1]; gB[1] = gB[2]; gB[2] = gB[3];
+      nctr += 1u;
+    }
+    return nz;
+  };
+
   auto one_step = [&](int slot, __amdgpu_buffer_rsrc_t rs, float& sq_out) {
     if constexpr (ASM) {
       f2 ov, ox;
@@ -838,8 +726,14 @@ __global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_step
         pair_step_asm_b(v, x, h, dvl, ov, crash_bits, sq_out, pc);
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, ov), rs, off_v, so, 0);
 #else
-        if constexpr (SM) pair_step_asm_a_sm(v, x, h, dvl, ox, pc, sc);
-        else pair_step_asm_a(v, x, h, dvl, ox, pc);
+        if constexpr (NOISE) {
+          const f2 nz = noise_term();
+          if constexpr (SM) pair_step_asm_a_sm_nz(v, x, h, dvl, ox, pc, sc, nz);
+          else pair_step_asm_a_nz(v, x, h, dvl, ox, pc, nz);
+        } else {
+          if constexpr (SM) pair_step_asm_a_sm(v, x, h, dvl, ox, pc, sc);
+          else pair_step_asm_a(v, x, h, dvl, ox, pc);
+        }
         if (slot > 0) __builtin_amdgcn_raw_buffer_store_b128(piece, rs, off_16, so - step_b32, 0);
         pair_step_asm_b(v, x, h, dvl, ov, crash_bits, sq_out, pc);
         transpose_in(ov, ox);
@@ -849,21 +743,7 @@ __global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_step
     }
     // IDMController.get_accel on the snapshot
     f2 acc = idm_pair<DELTA4, FASTDIV>(v, vl, h, p, two_sqrt_ab, rc_ab, rc_v0, one);
-    if constexpr (NOISE) {
-      const bool fresh = (nctr & 3u) == 0u;                      // a new block of four draws starts with this step
-      if (__ballot(fresh) != 0ull) {
-        if (fresh) {
-          gauss4<float>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(iA), nctr >> 2, gA);
-          gauss4<float>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(iB), nctr >> 2, gB);
-        }
-      }
-      const float aA = acc.x + sigma.x * gA[0], aB = acc.y + sigma.y * gB[0];
-      acc.x = noisyA ? aA : acc.x;
-      acc.y = noisyB ? aB : acc.y;
-      gA[0] = gA[1]; gA[1] = gA[2]; gA[2] = gA[3];
-      gB[0] = gB[1]; gB[1] = gB[2]; gB[2] = gB[3];
-      nctr += 1u;
-    }
+    if constexpr (NOISE) acc = pk_add(acc, noise_term());
     f2 acc_s = {0.0f, 0.0f};
     if constexpr (SM) acc_s = sumo_acc_pair<FASTDIV>(v, vl, h, sc, one);
     f2 ox;
