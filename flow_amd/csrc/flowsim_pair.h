@@ -18,6 +18,10 @@
 // denormal range (exhaustively checked for the divisors of tests/test_oracle_c.py::test_div_via_f64), which
 // replaces the ten-instruction IEEE sequence.
 //
+// SM: slots with speed-mode clamps (the reference's default "right_of_way"): sumo_acc_pair + three branch-free clamps.
+// NOISE (float32): IDMController(noise = sigma) slots: acc + sigma * g with the generic kernel's draws.  Both keep the
+// hand-written step in the hot instantiation (part A: flowsim_pair_step_a.inc / _a_sm.inc).
+//
 // MIXED (state type double): positions and speeds are kept and integrated in float64, the controller (the IDM
 // acceleration) runs in float32 on their rounded images -- "fp32 physics on f64 accumulators".  This is the
 // precision that meets BASELINE's 1e-4 trajectory bar at fp32 cost: float32 state drifts ~5e-3 m from the
