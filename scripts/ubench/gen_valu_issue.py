@@ -98,6 +98,8 @@ OPS = [
     ("v_min_u32", lambda i: "v_min_u32 %s, %s, %s" % (D32(i), S32(i), D32(i))),
     ("v_cmp_lt_u32", lambda i: "v_cmp_lt_u32 vcc, %s, %s" % (S32(i), D32(i))),
     ("v_permlane32_swap", lambda i: "v_permlane32_swap_b32 %s, %s" % (D32(i), D32((i + 4) % 8))),
+    ("v_mad_u64_u32", lambda i: "v_mad_u64_u32 %s, s[20:21], %s, %s, %s" % (D64(i), S32(i), S32((i + 1) % 8), S64(i))),
+    ("v_mul_hi_u32 + v_mul_lo_u32 pair", lambda i: ("v_mul_hi_u32 %s, %s, %s" % (D32(i), S32(i), S32((i + 1) % 8))) if i % 2 == 0 else ("v_mul_lo_u32 %s, %s, %s" % (D32(i), S32(i - 1), S32(i)))),
     # control flow as a wave alone on its SIMD sees it (the rollout kernels' steps are branchy straight-line code)
     ("s_branch taken (over 1 instr)", lambda i: "s_branch 1f\\ns_nop 0\\n1:"),
     ("s_cbranch_vccnz taken (over 1)", lambda i: "s_cbranch_vccnz 1f\\ns_nop 0\\n1:"),
