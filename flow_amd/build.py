@@ -1,20 +1,45 @@
-"""Build libflowsim.so (HIP, gfx950) in-tree.  hipcc cross-compiles without a GPU."""
+"""Build libflowsim.so (HIP, gfx950) in-tree.  hipcc cross-compiles without a GPU.
+
+The library is several objects: `flowsim.hip` (C ABI, validation, handle) and `flowsim_part.hip` compiled once per
+(precision, lanes per replica) pair -- each pair instantiates its own step kernels, so the objects compile in parallel
+and an edit to one kernel family rebuilds only the objects whose dependencies changed (objects are cached under
+flow_amd/csrc/_obj/, keyed by a hash of the preprocessed inputs' mtimes and the flags)."""
+import concurrent.futures
+import hashlib
 import os
 import shutil
 import subprocess
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
-SRC = os.path.join(PKG, "csrc", "flowsim.hip")
-DEPS = [SRC, os.path.join(PKG, "csrc", "flowsim_kernels.h"), os.path.join(PKG, "csrc", "flowsim_open.h"),
-        os.path.join(PKG, "csrc", "flowsim_wide.h"), os.path.join(PKG, "csrc", "flowsim_pair.h"), os.path.join(PKG, "csrc", "flowsim_pair_step_a.inc"),
-        os.path.join(PKG, "csrc", "flowsim_pair_step_a_sm.inc"), os.path.join(PKG, "csrc", "flowsim_fig8.h"),
-        os.path.join(ROOT, "include", "flowsim.h")]
+CSRC = os.path.join(PKG, "csrc")
+SRC = os.path.join(CSRC, "flowsim.hip")
+PART = os.path.join(CSRC, "flowsim_part.hip")
+OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(PKG, "libflowsim.so")
 
+# the ROCm release the hand-written register assignment of k_rollout_pair (v112..v145, flowsim_pair_step_a*.inc) was
+# validated on; tests/test_codegen.py re-checks the assignment against the disassembly on every build
+VALIDATED_ROCM = "7.2"
+
+HEADERS = ["flowsim_sim.h", "flowsim_launch.h", "flowsim_kernels.h", "flowsim_open.h", "flowsim_wide.h",
+           "flowsim_pair.h", "flowsim_pair_step_a.inc", "flowsim_pair_step_a_sm.inc", "flowsim_fig8.h"]
+DEPS = [SRC, PART] + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, "include", "flowsim.h")]
+
 # -ffp-contract=off: the kernels are the float32 bit-twin of the oracle only if a*b+c is never fused
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-               "-Wall", "-Wno-unused-function"]
+COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-Wall", "-Wno-unused-function"]
+HIPCC_FLAGS = COMMON_FLAGS + ["-fPIC", "-shared"]       # (kept for callers that compile a single file themselves)
+
+
+def parts():
+    """[(object name, source, extra -D flags)] of the library."""
+    out = [("main", SRC, [])]
+    for t, tn in (("float", "f32"), ("double", "f64")):
+        for seg in (8, 16, 32, 64):
+            out.append(("seg%d_%s" % (seg, tn), PART, ["-DFS_PART_T=" + t, "-DFS_PART_SEG=%d" % seg]))
+        for w in (2, 4):
+            out.append(("wide%d_%s" % (w, tn), PART, ["-DFS_PART_T=" + t, "-DFS_PART_WIDE=%d" % w]))
+    return out
 
 
 def find_hipcc():
@@ -24,6 +49,20 @@ def find_hipcc():
     raise RuntimeError("hipcc not found: libflowsim.so cannot be built (no CPU fallback exists)")
 
 
+def include_flags():
+    return ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+
+
+def _stamp(extra):
+    h = hashlib.sha256()
+    for d in DEPS:
+        h.update(d.encode())
+        with open(d, "rb") as f:
+            h.update(hashlib.sha256(f.read()).digest())
+    h.update(" ".join(COMMON_FLAGS + extra).encode())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
@@ -31,20 +70,76 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def build(force=False, verbose=False):
-    """Compile flow_amd/csrc/flowsim.hip -> flow_amd/libflowsim.so; returns the path."""
-    if not force and not needs_build():
-        return LIB
-    cmd = [find_hipcc()] + HIPCC_FLAGS + ["-I" + os.path.join(ROOT, "include"),
-                                          "-I" + os.path.join(PKG, "csrc"), "-o", LIB + ".tmp", SRC]
+def _compile(job):
+    name, src, extra, out, verbose = job
+    cmd = [find_hipcc()] + COMMON_FLAGS + ["-fPIC", "-c"] + extra + include_flags() + ["-o", out + ".tmp", src]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+        raise RuntimeError("hipcc failed (%s):\n%s%s" % (name, res.stdout, res.stderr))
+    os.replace(out + ".tmp", out)
+    return out
+
+
+def _jobs():
+    return max(1, min(len(parts()), int(os.environ.get("FLOWSIM_BUILD_JOBS", os.cpu_count() or 4))))
+
+
+def build(force=False, verbose=False, only=None):
+    """Compile the objects (in parallel) and link flow_amd/libflowsim.so; returns its path.  `only` = names of the
+    parts to recompile whatever their stamps say (development)."""
+    if not force and not only and not needs_build():
+        return LIB
+    os.makedirs(OBJ, exist_ok=True)
+    objs, todo, stamps = [], [], {}
+    for name, src, extra in parts():
+        out = os.path.join(OBJ, name + ".o")
+        stamp, have = _stamp(extra), None
+        if os.path.exists(out) and os.path.exists(out + ".stamp"):
+            with open(out + ".stamp") as f:
+                have = f.read().strip()
+        objs.append(out)
+        # development (`only`): the named parts are recompiled, every other object is linked as it is -- its stale
+        # stamp makes the next plain build() recompile it
+        if force or (only and name in only) or (not only and have != stamp) or not os.path.exists(out):
+            todo.append((name, src, extra, out, verbose))
+            stamps[out] = stamp
+    with concurrent.futures.ThreadPoolExecutor(_jobs()) as pool:
+        for out in pool.map(_compile, todo):
+            with open(out + ".stamp", "w") as f:
+                f.write(stamps[out])
+    cmd = [find_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
     os.replace(LIB + ".tmp", LIB)
     return LIB
 
 
+def device_asm(out_dir, names=None):
+    """Device assembly (gfx950) of the parts, for the code-generation guards: {part name: path of its .s}."""
+    os.makedirs(out_dir, exist_ok=True)
+    jobs = []
+    for name, src, extra in parts():
+        if names and name not in names:
+            continue
+        out = os.path.join(out_dir, name + ".s")
+        jobs.append((name, [find_hipcc()] + COMMON_FLAGS + ["-S", "--cuda-device-only"] + extra + include_flags() +
+                     ["-o", out, src], out))
+
+    def run(job):
+        res = subprocess.run(job[1], capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("hipcc -S failed (%s):\n%s" % (job[0], res.stderr[-2000:]))
+        return job[0], job[2]
+
+    with concurrent.futures.ThreadPoolExecutor(_jobs()) as pool:
+        return dict(pool.map(run, jobs))
+
+
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force="--force" in sys.argv, verbose=True, only=[a for a in sys.argv[1:] if not a.startswith("-")]))

@@ -1,0 +1,181 @@
+// flowsim_launch.h -- Sim<T>::launch_seg<SEG> / launch_wide<W>: which step kernel a launch takes.  Included by
+// flowsim_part.hip only, so that each (precision, SEG) pair and its kernels compile in an object of their own.
+#pragma once
+#include "flowsim_sim.h"
+
+namespace fsim {
+
+  // more than 64 slots per replica (lane-drop network): one workgroup of W waves per replica
+  template <typename T>
+  template <int W>
+  int Sim<T>::launch_wide(int num_steps, const uint8_t* mask, const float* actions, size_t act_stride, float* obs,
+                  float* rew, uint8_t* done, int obs_every_step) {
+    // float32 exists twice (CSET = 1: IDM / RL / Sim slots only); num_paths = 8 is the scaling-2 network
+    constexpr int C1 = std::is_same<T, float>::value ? 1 : 0;
+    const bool cset = C1 == 1 && (dv.flags & fs::FLAG_IDM_SET) && !force_generic;
+#define FS_WIDE(P_, C_)                                                                                          \
+  hipLaunchKernelGGL((fs::k_steps_wide<T, W, C_, P_>), dim3(dv.R), dim3(64 * W), 0, stream, dv, ov, num_steps, mask, \
+                     actions, act_stride, obs, rew, done, obs_every_step, after_reset)
+    last_kernel = "k_steps_wide";
+    if (cfg.num_paths == 8) { if (cset) FS_WIDE(8, C1); else FS_WIDE(8, 0); }
+    else { if (cset) FS_WIDE(4, C1); else FS_WIDE(4, 0); }
+#undef FS_WIDE
+    HIP_TRY(hipGetLastError());
+    return FS_OK;
+  }
+
+  template <typename T>
+  template <int SEG>
+  int Sim<T>::launch_seg(int num_steps, const uint8_t* mask, const float* actions, size_t act_stride, float* obs,
+                 float* rew, uint8_t* done, int obs_every_step) {
+    constexpr int RPW = 64 / SEG;
+    const int blocks = (dv.R + RPW - 1) / RPW;
+    if (open_net) {
+      // the float32 instantiations exist twice: CSET = 1 for populations of IDM / RL / Sim slots only
+      const bool cset = std::is_same<T, float>::value && (dv.flags & fs::FLAG_IDM_SET) && !force_generic;
+#define FS_OPEN__(P_, C_, PR_, PO_)                                                                              \
+  hipLaunchKernelGGL((fs::k_steps_open<T, SEG, P_, C_, PR_, PO_>), dim3(blocks), dim3(64), 0, stream, dv, ov,        \
+                     num_steps, mask, actions, act_stride, obs, rew, done, obs_every_step, after_reset)
+#define FS_OPEN_(P_, C_, PR_) do { if (P_ == 2 && dv.env == FS_ENV_MERGE_PO) FS_OPEN__(P_, C_, PR_, (P_ == 2));    \
+                                   else FS_OPEN__(P_, C_, PR_, false); } while (0)
+#define FS_OPEN(P_, C_) do { if (ov.n_prob > 0) FS_OPEN_(P_, C_, true); else FS_OPEN_(P_, C_, false); } while (0)
+      last_kernel = "k_steps_open";
+      if (cfg.network == FS_NET_BOTTLENECK) {
+        // the lane-drop heads need more than 32 slots (fs_create checks it): only the 64-lane segment is built
+        if constexpr (SEG == 64) {
+          if (cset) FS_OPEN(4, (std::is_same<T, float>::value ? 1 : 0)); else FS_OPEN(4, 0);
+        } else {
+          return fail(FS_ERR_UNSUPPORTED, "fs_step: FS_NET_BOTTLENECK runs on 64-lane segments only");
+        }
+      } else {
+        if (cset) FS_OPEN(2, (std::is_same<T, float>::value ? 1 : 0)); else FS_OPEN(2, 0);
+      }
+#undef FS_OPEN
+#undef FS_OPEN_
+#undef FS_OPEN__
+      HIP_TRY(hipGetLastError());
+      return FS_OK;
+    }
+    if (dv.num_lanes > 1) {
+      last_kernel = "k_steps_ml";
+      if (dv.lc_enabled)
+        hipLaunchKernelGGL((fs::k_steps_ml<T, SEG, true>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, mask,
+                           actions, act_stride, obs, rew, done, obs_every_step);
+      else
+        hipLaunchKernelGGL((fs::k_steps_ml<T, SEG, false>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, mask,
+                           actions, act_stride, obs, rew, done, obs_every_step);
+      HIP_TRY(hipGetLastError());
+      return FS_OK;
+    }
+    // two vehicles per lane (flowsim_pair.h): even N; the only stepping kernel of a FS_MIXED handle
+    constexpr int ROW = SEG >= 16 ? SEG / 2 : 8;
+    const bool pair_noise = std::is_same<T, float>::value && !mixed;      // the noisy form exists in float32 only
+    const bool pair_ok = fast_ok(mask, num_steps, true, pair_noise) && (obs_every_step || num_steps == 1) && dv.N >= 2 &&
+                         (dv.N % 2) == 0 && actions == nullptr && !no_pair &&
+                         size_t(dv.R) * 2 * dv.N * sizeof(float) * 16 < (size_t(1) << 32);   // 32-bit offsets in a block
+    // closed loops with a segment table (figure eight): the rollout kernel of flowsim_fig8.h
+    if constexpr (SEG == 16 && std::is_same<T, float>::value) {
+      const int f = dv.flags;
+      const bool head_ok = (dv.env == FS_ENV_ACCEL && !dv.evaluate) || dv.env == FS_ENV_WAVE_ATTENUATION_PO;
+      if (dv.nseg > 0 && (f & fs::FLAG_IDM_SET) && !(f & fs::FLAG_HAS_FAILSAFE) && head_ok &&
+          dv.integrator == FS_EULER && dv.sims_per_step == 1 && mask == nullptr &&
+          !dv.sort_vehicles && dv.obs_perm == nullptr && num_steps > 0 && (obs_every_step || num_steps == 1) &&
+          dv.N > 1 && loop_div_ok && !force_generic && !no_loop_kernel) {
+        const int waves = (dv.R + 3) / 4;
+        const dim3 grid((waves + 3) / 4), block(256);
+        last_kernel = "k_rollout_loop";
+#define FS_LOOP(H_, D_)                                                                                       \
+  hipLaunchKernelGGL((fs::k_rollout_loop<H_, D_>), grid, block, 0, stream, dv, num_steps, actions, act_stride, obs, \
+                     rew, done)
+        const bool full = (f & fs::FLAG_HAS_NOISE) && (f & fs::FLAG_NEED_SUMO) && dv.junction_on && actions != nullptr &&
+                          loop_delta4 && !no_loop_full && loop_fastc_ok();
+        if (full) {
+          last_kernel = "k_rollout_loop<FULL>";
+          if (dv.env == FS_ENV_ACCEL)
+            hipLaunchKernelGGL((fs::k_rollout_loop<0, true, true>), grid, block, 0, stream, dv, num_steps, actions,
+                               act_stride, obs, rew, done);
+          else
+            hipLaunchKernelGGL((fs::k_rollout_loop<1, true, true>), grid, block, 0, stream, dv, num_steps, actions,
+                               act_stride, obs, rew, done);
+        }
+        else if (dv.env == FS_ENV_ACCEL) { if (loop_delta4) FS_LOOP(0, true); else FS_LOOP(0, false); }
+        else { if (loop_delta4) FS_LOOP(1, true); else FS_LOOP(1, false); }
+#undef FS_LOOP
+        HIP_TRY(hipGetLastError());
+        return FS_OK;
+      }
+    }
+    if (mixed && num_steps == 0) {                       // observation of the current state (Env.reset)
+      const int n = dv.R * dv.N;
+      last_kernel = "k_obs_mixed";
+      hipLaunchKernelGGL((fs::k_obs_mixed<T>), dim3((n + 255) / 256), dim3(256), 0, stream, dv, obs);
+      HIP_TRY(hipGetLastError());
+      return FS_OK;
+    }
+    if (mixed && !pair_ok)
+      return fail(FS_ERR_UNSUPPORTED, "FS_MIXED is built for the all-IDM ring rollout (observation every step or "
+                                      "single steps, no reset mask during stepping)");
+    if (pair_ok && (mixed || std::is_same<T, float>::value)) {
+      const bool fd = fastdiv_ok();
+      const int waves = (dv.R + (64 / ROW) - 1) / (64 / ROW);
+      const int wpb = pair_block / 64;
+      const dim3 grid((waves + wpb - 1) / wpb), block(pair_block);
+      const bool bc = neg_speed_possible;
+#define FS_PAIR(D4, FD, BC)                                                                                   \
+  hipLaunchKernelGGL((fs::k_rollout_pair<T, ROW, D4, FD, BC>), grid, block, 0, stream, dv, num_steps, obs, rew, done)
+      last_kernel = speed_mode_any ? "k_rollout_pair+speed_mode" : "k_rollout_pair";
+      if (dv.flags & fs::FLAG_HAS_NOISE) {
+        if constexpr (std::is_same<T, float>::value) {
+          last_kernel = speed_mode_any ? "k_rollout_pair+speed_mode+noise" : "k_rollout_pair+noise";
+#define FS_PAIR_N(D4, FD, BC, SM_)                                                                            \
+  hipLaunchKernelGGL((fs::k_rollout_pair<float, ROW, D4, FD, BC, SM_, true>), grid, block, 0, stream, dv, num_steps,  \
+                     obs, rew, done)
+          if (delta4 && fd && !bc) { if (speed_mode_any) FS_PAIR_N(true, true, false, true); else FS_PAIR_N(true, true, false, false); }
+          else { if (speed_mode_any) FS_PAIR_N(false, false, true, true); else FS_PAIR_N(false, false, true, false); }
+#undef FS_PAIR_N
+        }
+      } else if (speed_mode_any) {                   // the reference's default speed mode "right_of_way" lands here
+        if (delta4 && fd && !bc)
+          hipLaunchKernelGGL((fs::k_rollout_pair<T, ROW, true, true, false, true>), grid, block, 0, stream, dv,
+                             num_steps, obs, rew, done);
+        else                                  // any exponent, IEEE divisions, v < -100 check: always valid
+          hipLaunchKernelGGL((fs::k_rollout_pair<T, ROW, false, false, true, true>), grid, block, 0, stream, dv,
+                             num_steps, obs, rew, done);
+      }
+      else if (delta4 && fd) { if (bc) FS_PAIR(true, true, true); else FS_PAIR(true, true, false); }
+      else if (delta4) { if (bc) FS_PAIR(true, false, true); else FS_PAIR(true, false, false); }
+      else { if (bc) FS_PAIR(false, false, true); else FS_PAIR(false, false, false); }
+#undef FS_PAIR
+    } else if (fast_ok(mask, num_steps) && obs_every_step && dv.N > 1 && actions == nullptr &&
+        size_t(dv.R) * 2 * dv.N * sizeof(float) < (size_t(1) << 32)) {   // 32-bit byte offsets inside one step's block
+      const bool fd = fastdiv_ok();
+      const int waves = blocks;                                   // one wave per 64/SEG replicas
+      const int wpb = rollout_block / 64;                         // waves per block
+      const dim3 grid((waves + wpb - 1) / wpb), block(rollout_block);
+      const bool bc = neg_speed_possible;
+      last_kernel = "k_rollout_idm";
+#define FS_ROLLOUT(D4, FD, BC)                                                                               \
+  hipLaunchKernelGGL((fs::k_rollout_idm<T, SEG, D4, FD, BC>), grid, block, 0, stream, dv, num_steps, obs, rew, \
+                     done, d_dump)
+      if (delta4 && fd) { if (bc) FS_ROLLOUT(true, true, true); else FS_ROLLOUT(true, true, false); }
+      else if (delta4) { if (bc) FS_ROLLOUT(true, false, true); else FS_ROLLOUT(true, false, false); }
+      else { if (bc) FS_ROLLOUT(false, false, true); else FS_ROLLOUT(false, false, false); }
+#undef FS_ROLLOUT
+    } else if (fast_ok(mask, num_steps)) {
+      last_kernel = "k_steps<FAST>";
+      hipLaunchKernelGGL((fs::k_steps<T, SEG, 1>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, mask, actions,
+                         act_stride, obs, rew, done, obs_every_step);
+    } else if ((dv.flags & fs::FLAG_IDM_SET) && !force_generic) {
+      last_kernel = "k_steps<CSET>";
+      hipLaunchKernelGGL((fs::k_steps<T, SEG, 0, 1>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, mask, actions,
+                         act_stride, obs, rew, done, obs_every_step);
+    } else {
+      last_kernel = "k_steps";
+      hipLaunchKernelGGL((fs::k_steps<T, SEG, 0, 0>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, mask, actions,
+                         act_stride, obs, rew, done, obs_every_step);
+    }
+    HIP_TRY(hipGetLastError());
+    return FS_OK;
+  }
+
+}  // namespace fsim

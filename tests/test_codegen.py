@@ -18,17 +18,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def device_asm(tmp_path_factory):
+    """Device assembly of every object of the library (flow_amd/build.py: parts()), concatenated."""
     from flow_amd import build
-    hipcc = build.find_hipcc()
-    if hipcc is None:
+    try:
+        build.find_hipcc()
+    except RuntimeError:
         pytest.skip("hipcc not found")
-    out = tmp_path_factory.mktemp("asm") / "flowsim.s"
-    flags = [f for f in build.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
-    cmd = [hipcc] + flags + ["-S", "--cuda-device-only", "-I" + os.path.join(ROOT, "include"),
-                             "-I" + os.path.join(ROOT, "flow_amd", "csrc"), "-o", str(out), build.SRC]
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    assert res.returncode == 0, res.stderr[-2000:]
-    return out.read_text()
+    files = build.device_asm(str(tmp_path_factory.mktemp("asm")))
+    return "\n".join(open(f).read() for f in files.values())
 
 
 def kernel_resources(asm):
