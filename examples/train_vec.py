@@ -59,12 +59,14 @@ class GaussianPolicy(nn.Module):
 
 
 def gae(rew, val, done, last_val, gamma=0.999, lam=0.97):
+    """Generalised advantage estimation over a [K, R] fragment.  ``done`` is the simulator's FLAG BYTE (bit 0: horizon
+    reached, bit 1: collision -- include/flowsim.h), so "the episode went on" is ``done == 0``, not ``1 - done``."""
     K = rew.shape[0]
     adv = torch.zeros_like(rew)
     run = torch.zeros_like(last_val)
     nxt = last_val
     for t in range(K - 1, -1, -1):
-        live = 1.0 - done[t].float()
+        live = (done[t] == 0).float()
         delta = rew[t] + gamma * nxt * live - val[t]
         run = delta + gamma * lam * live * run
         adv[t] = run
@@ -106,7 +108,7 @@ def train_on_device(flow_params, replicas=1024, fragment=100, iterations=20, epo
         mean_rew = float(rew.mean())
         history.append(mean_rew)
         log("iteration %3d  mean step reward %8.4f  rollout %.1f ms (%.2f M env-steps/s)  episodes ended %d"
-            % (it, mean_rew, t_roll * 1e3, K * R / t_roll / 1e6, int(done.sum())))
+            % (it, mean_rew, t_roll * 1e3, K * R / t_roll / 1e6, int((done != 0).sum())))
     vec.close()
     return history
 

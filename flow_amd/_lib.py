@@ -9,7 +9,8 @@ import os
 from .utils.exceptions import FatalFlowError
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libflowsim.so")
+# FLOWSIM_LIB: a development build of the same sources (e.g. the phase-timer build of scripts/phase_open.py)
+LIB_PATH = os.environ.get("FLOWSIM_LIB") or os.path.join(PKG, "libflowsim.so")
 
 FS_ABI_VERSION = 6
 FS_MAX_CTRL_PARAMS = 8

@@ -86,6 +86,29 @@ def _jobs():
     return max(1, min(len(parts()), int(os.environ.get("FLOWSIM_BUILD_JOBS", os.cpu_count() or 4))))
 
 
+def build_variant(lib, defines, names=None, verbose=False):
+    """A development build of the library with extra -D flags (phase timers, diagnostics) at path `lib`; objects under
+    _obj/<basename>/.  `names`: the parts to compile with the flags (the others are taken from the plain build)."""
+    build()
+    obj_dir = os.path.join(OBJ, os.path.basename(lib))
+    os.makedirs(obj_dir, exist_ok=True)
+    objs, todo = [], []
+    for name, src, extra in parts():
+        if names and name not in names:
+            objs.append(os.path.join(OBJ, name + ".o"))
+            continue
+        out = os.path.join(obj_dir, name + ".o")
+        objs.append(out)
+        todo.append((name, src, extra + list(defines), out, verbose))
+    with concurrent.futures.ThreadPoolExecutor(_jobs()) as pool:
+        list(pool.map(_compile, todo))
+    res = subprocess.run([find_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs,
+                         capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
+    return lib
+
+
 def build(force=False, verbose=False, only=None):
     """Compile the objects (in parallel) and link flow_amd/libflowsim.so; returns its path.  `only` = names of the
     parts to recompile whatever their stamps say (development)."""

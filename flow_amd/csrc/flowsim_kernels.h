@@ -485,6 +485,28 @@ __device__ __forceinline__ T gauss(uint32_t seed_lo, uint32_t seed_hi, uint32_t 
   return bm_radius(T((w1 >> 8) + 1u) * k) * bm_cos((step & 1u) ? u2 - T(0.25) : u2);
 }
 
+// The four draws of one Philox block, kept over the four steps they serve: draw(ctr) is gauss(.., ctr) bit for bit
+// (gauss4 evaluates the same expressions), at a quarter of the Philox / log / sqrt work.  The block is re-evaluated by
+// the WHOLE wave whenever some lane's counter has left the block it holds (replicas of one wave may be at different
+// counters: a lane that is still inside its block recomputes the values it already has).
+template <typename T>
+struct NoiseBlock {
+  T g[4];
+  uint32_t block;
+  bool loaded;
+  __device__ __forceinline__ void init() { block = 0u; loaded = false; g[0] = g[1] = g[2] = g[3] = T(0); }
+  __device__ __forceinline__ T draw(uint32_t seed_lo, uint32_t seed_hi, uint32_t replica, uint32_t vehicle, uint32_t ctr) {
+    if (__ballot(!loaded || block != (ctr >> 2)) != 0ull) {
+      block = ctr >> 2;
+      loaded = true;
+      gauss4<T>(seed_lo, seed_hi, replica, vehicle, block, g);
+    }
+    const uint32_t ph = ctr & 3u;
+    const T lo = (ph & 1u) ? g[1] : g[0], hi = (ph & 1u) ? g[3] : g[2];
+    return (ph & 2u) ? hi : lo;
+  }
+};
+
 // ---------------------------------------------------------------------------
 // controllers (one lane = one vehicle); see oracle/controllers.py for citations
 // ---------------------------------------------------------------------------
@@ -496,15 +518,17 @@ struct Slot {           // per-lane copy of the vehicle slot tables
 };
 
 template <typename T>
-__device__ __forceinline__ T ctrl_idm(T v, T vl, T h, bool has, const T* p) {
+__device__ __forceinline__ T ctrl_idm(T v, T vl, T h, bool has, const T* p, T delta) {
   // p = {v0, T, a, b, delta, s0}; car_following_models.py:464-482
   T hh = tabs(h) < T(1e-3) ? T(1e-3) : h;
   T two_sqrt_ab = T(2) * tsqrt(p[2] * p[3]);
   T dyn = v * p[1] + v * (v - vl) / two_sqrt_ab;
   T s_star = has ? p[5] + tmax(T(0), dyn) : T(0);
   T q = s_star / hh;
-  return p[2] * (T(1) - pow_delta(v / p[0], p[4]) - q * q);
+  return p[2] * (T(1) - pow_delta(v / p[0], delta) - q * q);
 }
+template <typename T>
+__device__ __forceinline__ T ctrl_idm(T v, T vl, T h, bool has, const T* p) { return ctrl_idm(v, vl, h, has, p, p[4]); }
 
 template <typename T>
 __device__ __forceinline__ T ctrl_cfm(T v, T vl, T h, bool has, T max_accel, const T* p) {
@@ -736,10 +760,30 @@ struct SegCursor {
 // Returns the commanded acceleration; `commanded` = false means "no command this step" (S5).
 // ---------------------------------------------------------------------------
 // CSET = 1: the host guarantees every slot is IDM / RL / Sim (FLAG_IDM_SET), so the controller switch collapses.
-template <typename T, int CSET = 0>
+// EXT_NOISE: the caller hands in this step's N(0,1) draw (`noise_g`: the kernels that keep the four draws of a Philox
+// block over four steps, NoiseBlock below) instead of one Philox evaluation per call.
+template <typename T, int CSET = 0, bool EXT_NOISE = false>
 __device__ __forceinline__ T control_accel_on(const DevView<T>& s, const Slot<T>& sl, int flags, T v, T vl, T h, bool has,
                                               T vf, T hf, T mean_v, bool on_edge, bool have_rl, T a_rl, bool live,
-                                              int rr, int ii, uint32_t nctr, T& cst, bool& commanded) {
+                                              int rr, int ii, uint32_t nctr, T& cst, bool& commanded, T noise_g = T(0)) {
+  if constexpr (CSET == 1 && EXT_NOISE) {
+    // IDM / RL / Sim slots only, written without lane-divergent control flow: every lane evaluates the IDM law (on
+    // whatever its parameter registers hold) and the slot's kind selects afterwards -- the same values as the
+    // branches below, which cost a wave that is alone on its SIMD an exec-mask region each
+    const bool is_rl = sl.ctrl == FS_CTRL_RL, is_sim = sl.ctrl == FS_CTRL_SIM;
+    // (a slot that is not an IDM one holds no exponent: 4 keeps its lanes off pow()'s general path)
+    T a = ctrl_idm(v, vl, h, has, sl.p, (is_rl || is_sim) ? T(4) : sl.p[4]);
+    if (flags & FLAG_HAS_NOISE) a = (sl.noise > T(0)) ? a + sl.noise * noise_g : a;     // base_controller.py:109-110
+    if (flags & FLAG_HAS_FAILSAFE) {                                                     // base_controller.py:113-116
+      const T a1 = failsafe_instantaneous(a, v, h, has, s.dt), a2 = failsafe_safe_velocity(a, v, vl, h, s.dt, sl.delay);
+      const T af = sl.failsafe == FS_FAILSAFE_INSTANTANEOUS ? a1 : (sl.failsafe == FS_FAILSAFE_SAFE_VELOCITY ? a2 : a);
+      a = has ? af : a;
+    }
+    T ar = a_rl;
+    if (s.clip_actions) ar = tmin(tmax(ar, s.act_lo), s.act_hi);
+    commanded = is_rl ? have_rl : (is_sim ? false : on_edge);
+    return is_rl ? (have_rl ? ar : T(0)) : (is_sim ? T(0) : a);
+  }
   T acc = T(0);
   commanded = false;
   const int ct = sl.ctrl;
@@ -773,7 +817,8 @@ __device__ __forceinline__ T control_accel_on(const DevView<T>& s, const Slot<T>
     commanded = on_edge;
     if (CSET == 0 && ct == FS_CTRL_LAC && commanded && live) cst = a;
     if (flags & FLAG_HAS_NOISE) {                // base_controller.py:109-110
-      if (sl.noise > T(0)) a = a + sl.noise * gauss<T>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(ii), nctr);
+      if (sl.noise > T(0))
+        a = a + sl.noise * (EXT_NOISE ? noise_g : gauss<T>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(ii), nctr));
     }
     if (has) {                                   // base_controller.py:113-116, 141-142, 191-193
       if (sl.failsafe == FS_FAILSAFE_INSTANTANEOUS) a = failsafe_instantaneous(a, v, h, has, s.dt);

@@ -393,12 +393,36 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
   int lead = -1;
   T vl = T(-1001), h = T(1000);
   bool has = false, lead_same_lane = false;
-  auto neighbours = [&](bool live, bool follow) {
+  // ---- the neighbour STRUCTURE is kept from sub-step to sub-step ---------------------------------------------------
+  // Who my leader is, who could register as my follower and who stands next to me on the other lanes are functions of
+  // (a) the ORDER of the vehicles by position, (b) each vehicle's key = (path, joins upstream of it) and (c) my
+  // look-ahead region `la`.  Insertions, arrivals and lane changes change (b) (a free slot's key is 0xffff), crossing a
+  // join or coming within zipper_distance of one changes (b) / (c), and the order changes only when some vehicle catches
+  // up with its leader (see `neighbours` below for why nothing else has to be watched).  These are cheap to test after a
+  // move (two integer compares and the sign of the leader gap that is needed anyway); while no lane of the wave reports a
+  // change -- most sub-steps -- the masks and the slot numbers derived from them are those of the last evaluation, and a
+  // step only re-reads the positions and speeds of the neighbours it already knows.  nb_structure() is the full
+  // evaluation and the only writer of the kept values, so the two paths cannot drift apart.
+#ifdef FS_PHASE_TIMERS
+  long long nb_struct_cycles = 0;
+  int nb_struct_calls = 0;
+#endif
+  int nb_key = -1, nb_la = -1;      // my key and look-ahead region at the last nb_structure (-1: none yet)
+  int nb_succ = -1;                 // slot of the vehicle ranked directly above me (-1: I am the front vehicle / free)
+  int nb_pred = -1;                 // ... directly below me (-1: I am the last vehicle / free)
+  int nb_rank = 0;                  // my rank at the last nb_structure
+  T nb_len_lead = T(0);             // length of my leader
+  int nb_cand[P], nb_cseq[P];       // O1: per path, the nearest vehicle behind me (slot, id-list place) ...
+  bool nb_celig[P];                 // ... and whether its leader is me
+#pragma unroll
+  for (int q = 0; q < P; ++q) { nb_cand[q] = -1; nb_cseq[q] = 0; nb_celig[q] = false; }
+  auto nb_structure = [&]() {
     const bool alive = route >= 0;
     const T xr = alive ? x : BIGV;
     const unsigned long long segmask = SEG == 64 ? ~0ull : ((1ull << (SEG & 63)) - 1ull);
     const unsigned long long am = seg_ballot<SEG>(alive, seg);
-    const int dead_rank = __popcll(am) + __popcll(~am & segmask & ((1ull << i) - 1ull));
+    const int n_alive = __popcll(am);
+    const int dead_rank = n_alive + __popcll(~am & segmask & ((1ull << i) - 1ull));
     const int my_key = alive ? (route | (shift_of(x) << 8)) : 0xffff;
     int rank = 0, sorted_slot, skey;
     if (sizeof(T) == 4) {
@@ -412,27 +436,48 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       // images would otherwise differ.)
       const uint32_t xb = __float_as_uint(float(xr) + 0.0f);
       const uint32_t ord = (xb & 0x80000000u) ? ~xb : (xb | 0x80000000u);
-      const unsigned long long occ = occupied_slots();
-      int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-      for (int q = 0; q < SEG; q += 4) {
-        if (((occ >> q) & 0xFull) == 0ull) continue;
-        r0 += (uint32_t(seg_read_i<SEG>(int(ord), q, seg)) < ord) ? 1 : 0;
-        r1 += (uint32_t(seg_read_i<SEG>(int(ord), q + 1, seg)) < ord) ? 1 : 0;
-        r2 += (uint32_t(seg_read_i<SEG>(int(ord), q + 2, seg)) < ord) ? 1 : 0;
-        r3 += (uint32_t(seg_read_i<SEG>(int(ord), q + 3, seg)) < ord) ? 1 : 0;
+      // The order rarely changes by more than vehicles of different paths passing each other (a queue on the minor
+      // route is passed by every vehicle of the major one): unless a vehicle has just been inserted, the ranks of the
+      // last evaluation are tried with every inverted ADJACENT pair exchanged, and the try is PROVEN before it is used
+      // -- the keys pushed to their rank lanes must fill lanes 0 .. n_alive-1 and ascend strictly there (a strictly
+      // ascending arrangement of the keys is unique, so it is the ranking the count would give).  Anything else --
+      // newcomers, ties, a vehicle that passed two others -- fails the proof and is counted in full.
+      bool counted = true;
+      if (__ballot(alive && (nb_key < 0 || nb_key == 0xffff)) == 0ull) {
+        const T x_succ = bperm(x, segbase + (nb_succ >= 0 ? nb_succ : ii));
+        const T x_pred = bperm(x, segbase + (nb_pred >= 0 ? nb_pred : ii));
+        const int up = (alive && nb_succ >= 0 && x_succ < x) ? 1 : 0;
+        const int down = (alive && nb_pred >= 0 && x < x_pred) ? 1 : 0;
+        const int rank_try = alive ? nb_rank + up - down : dead_rank;
+        const uint32_t xs = uint32_t(__builtin_amdgcn_ds_permute((segbase + rank_try) << 2, int(alive ? ord : 0xffffffffu)));
+        const uint32_t nx = uint32_t(dpp_i<DPP_WAVE_SHL1>(int(xs)));
+        const bool bad = (i < n_alive) && ((xs == 0u) || ((i + 1 < n_alive) && !(xs < nx)));
+        counted = __ballot(bad) != 0ull;
+        rank = rank_try;
       }
-      rank = alive ? (r0 + r1) + (r2 + r3) : dead_rank;
-      const int marked = __builtin_amdgcn_ds_permute((segbase + rank) << 2, 1);
-      if (__ballot(marked == 0) != 0ull) {                      // some rank lane got no vehicle: a tie somewhere
-        const unsigned long long key = ((unsigned long long)ord << 32) | (unsigned long long)uint32_t(SEG - 1 - ii);
-        int rk = 0;
-        for (unsigned long long u = occ; u; u &= u - 1ull) {
-          const int j = __ffsll((long long)u) - 1;
-          const unsigned long long kj = ((unsigned long long)uint32_t(seg_read_i<SEG>(int(ord), j, seg)) << 32) |
-                                        (unsigned long long)uint32_t(SEG - 1 - j);
-          rk += (kj < key) ? 1 : 0;
+      if (counted) {
+        const unsigned long long occ = occupied_slots();
+        int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        for (int q = 0; q < SEG; q += 4) {
+          if (((occ >> q) & 0xFull) == 0ull) continue;
+          r0 += (uint32_t(seg_read_i<SEG>(int(ord), q, seg)) < ord) ? 1 : 0;
+          r1 += (uint32_t(seg_read_i<SEG>(int(ord), q + 1, seg)) < ord) ? 1 : 0;
+          r2 += (uint32_t(seg_read_i<SEG>(int(ord), q + 2, seg)) < ord) ? 1 : 0;
+          r3 += (uint32_t(seg_read_i<SEG>(int(ord), q + 3, seg)) < ord) ? 1 : 0;
         }
-        rank = alive ? rk : dead_rank;
+        rank = alive ? (r0 + r1) + (r2 + r3) : dead_rank;
+        const int marked = __builtin_amdgcn_ds_permute((segbase + rank) << 2, 1);
+        if (__ballot(marked == 0) != 0ull) {                      // some rank lane got no vehicle: a tie somewhere
+          const unsigned long long key = ((unsigned long long)ord << 32) | (unsigned long long)uint32_t(SEG - 1 - ii);
+          int rk = 0;
+          for (unsigned long long u = occ; u; u &= u - 1ull) {
+            const int j = __ffsll((long long)u) - 1;
+            const unsigned long long kj = ((unsigned long long)uint32_t(seg_read_i<SEG>(int(ord), j, seg)) << 32) |
+                                          (unsigned long long)uint32_t(SEG - 1 - j);
+            rk += (kj < key) ? 1 : 0;
+          }
+          rank = alive ? rk : dead_rank;
+        }
       }
     } else {
       for (unsigned long long u = occupied_slots(); u; u &= u - 1ull) {
@@ -472,20 +517,30 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
     const int lslot = __shfl(sorted_slot, segbase + lead_pos, 64);
     lead = has ? lslot : -1;
     const int lsrc = segbase + (has ? lslot : ii);
-    const T x_l = bperm(x, lsrc);
-    const T v_l = bperm(v, lsrc);
-    const T len_lead = bperm(sl.length, lsrc);
-    vl = has ? v_l : T(-1001);                          // get_speed(None): the accessor's error value
-    h = has ? (x_l - x) - len_lead : T(1000);           // vehicle/traci.py:237
+    nb_len_lead = bperm(sl.length, lsrc);
+    T x_l = T(0);
     if (P > 2) {                                        // M8: does the leader share my PHYSICAL lane (collision check)
       const int p_l = __shfl(route, lsrc, 64);
+      x_l = bperm(x, lsrc);
       const int sh_l = shift_of(x_l);
       lead_same_lane = has && ((route >> sh_l) == (p_l >> sh_l));
     } else {
       lead_same_lane = has;
     }
+    // the vehicle ranked directly above me: while I stay behind it (and nothing else changes) the order stands
+    {
+      const int sidx = rank + 1 < SEG ? rank + 1 : SEG - 1;
+      const int ss = __shfl(sorted_slot, segbase + sidx, 64);
+      nb_succ = (alive && rank + 1 < n_alive) ? ss : -1;
+      const int pp = __shfl(sorted_slot, segbase + (rank > 0 ? rank - 1 : 0), 64);
+      nb_pred = (alive && rank > 0) ? pp : -1;
+      nb_rank = rank;
+    }
+    nb_key = my_key;
+    nb_la = la;
     if (lc_on) {
       // ---- M11: which adjacent lane (if any) this vehicle would like to continue on after the next move ----------
+      const T h_now = has ? (x_l - x) - nb_len_lead : T(1000);          // (the headway nb_refresh is about to set)
       const bool internal = cur.internal(o, seg_route());
       const int g = shift_of(x);
       const int my_path = route < 0 ? 0 : route;
@@ -523,7 +578,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         const T need_l = sl.sumo_min_gap + tmax(T(0), v * sl.sumo_tau + v * (v - v_l) / two_sqrt);
         const T need_f = sl.sumo_min_gap + tmax(T(0), v_f * sl.sumo_tau + v_f * (v_f - v) / two_sqrt);
         const bool safe = (!has_l || gap_l >= need_l) && (!has_f || gap_f >= need_f);
-        const T gain = gap_l - h;
+        const T gain = gap_l - h_now;
         const bool take = valid_t && safe && (gain >= o.lc_min_gain) && (gain >= best_gain);
         best_gain = take ? gain : best_gain;
         best_path = take ? p2 : best_path;
@@ -531,25 +586,75 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       lc_want = best_path;
       lc_gain = best_path >= 0 ? best_gain : T(0);
     }
+    // ---- O1: who could register as my follower (vehicle/traci.py:243-250): per path the nearest vehicle behind me
+    if (track_foll) {
+      const unsigned long long below = bit - 1ull;
+#pragma unroll
+      for (int r = 0; r < P; ++r) {
+        const unsigned long long mb = B[r] & below;
+        const bool has_c = alive && mb != 0ull;
+        const int q = has_c ? 63 - __clzll((long long)mb) : 0;
+        const int cslot = __shfl(sorted_slot, segbase + q, 64);
+        const int c_lead = __shfl(lead, segbase + cslot, 64);
+        nb_cseq[r] = __shfl(seq, segbase + cslot, 64);
+        nb_cand[r] = has_c ? cslot : -1;
+        nb_celig[r] = has_c && (c_lead == ii);
+      }
+    }
+  };
+  // The snapshot proper: leader speed and headway from the kept leader slot; the sticky follower entry of THIS vehicle
+  // (vehicle/traci.py:232-250) from the kept candidates -- a candidate whose leader I am has the headway
+  // (x_me - x_c) - length_me, the very expression its own lane evaluates, so its x is all that has to be fetched.
+  //
+  // WHEN the kept structure stands.  Which vehicle can be whose leader depends on the classes (path, joins upstream,
+  // look-ahead region) of the two and on which of them is ahead.  Between two vehicles that matter to each other the one
+  // behind has the other among its leader candidates, i.e. AT or BEYOND its leader: their order cannot change before a
+  // vehicle has caught up with its own leader (vehicles only move forward; classes that differ in region or look-ahead
+  // are ordered by position, so they cannot swap without a class change first).  Vehicles that do not matter to each
+  // other -- different paths, both upstream of the zipper zone -- may pass each other freely: a queue on the minor route
+  // is passed by every vehicle of the major one, which changes ranks and mask bits but no leader, no follower and no
+  // slot number.  So the structure is re-evaluated when a class changed somewhere in the wave (insertion, arrival, lane
+  // change, a join or zipper zone reached) or a vehicle is no longer strictly behind its leader; the positions just
+  // fetched for the headway decide that, and the follower state is only touched once it is settled.
+  auto neighbours = [&](bool live, bool follow) {
+    const bool alive = route >= 0;
+    T x_l, v_l, x_c[P];
+    auto fetch = [&]() {
+      const int lsrc = segbase + (has ? lead : ii);
+      x_l = bperm(x, lsrc);
+      v_l = bperm(v, lsrc);
+#pragma unroll
+      for (int r = 0; r < P; ++r) x_c[r] = follow ? bperm(x, segbase + (nb_cand[r] >= 0 ? nb_cand[r] : ii)) : T(0);
+    };
+    fetch();
+    const int key_now = alive ? (route | (shift_of(x) << 8)) : 0xffff;
+    const bool changed = (key_now != nb_key) | (shift_of(x + o.zip_d) != nb_la) | (has & !(x < x_l));
+    // M11 reads gaps on the adjacent lanes every sub-step: with lane changing on, the full evaluation always runs
+    if (lc_on || __ballot(changed) != 0ull) {
+#ifdef FS_PHASE_TIMERS
+      const long long t0_ = clock64();
+      nb_structure();
+      fetch();
+      nb_struct_cycles += clock64() - t0_;
+      nb_struct_calls += 1;
+#else
+      nb_structure();
+      fetch();
+#endif
+    }
+    vl = has ? v_l : T(-1001);                          // get_speed(None): the accessor's error value
+    h = has ? (x_l - x) - nb_len_lead : T(1000);        // vehicle/traci.py:237
     if (!follow) return;
-    // ---- O1: the sticky follower entry of THIS vehicle (vehicle/traci.py:232-250) ----------------------
     const bool no_lead = alive && !has;
     const T start_h = no_lead ? T(1000) : foll_h;
     const int start_f = no_lead ? -1 : foll;
-    const unsigned long long below = bit - 1ull;
     T bestf = BIGV;
     int bseq = 0x7fffffff, bj = -1;
 #pragma unroll
     for (int r = 0; r < P; ++r) {
-      const unsigned long long mb = B[r] & below;
-      const bool has_c = alive && mb != 0ull;
-      const int q = has_c ? 63 - __clzll((long long)mb) : 0;
-      const int cslot = __shfl(sorted_slot, segbase + q, 64);
-      const int c_lead = __shfl(lead, segbase + cslot, 64);
-      const T c_h = bperm(h, segbase + cslot);
-      const int c_seq = __shfl(seq, segbase + cslot, 64);
-      const bool elig = has_c && (c_lead == ii) && (has || c_seq > seq);
-      if (elig && (c_h < bestf || (c_h == bestf && c_seq < bseq))) { bestf = c_h; bseq = c_seq; bj = cslot; }
+      const T c_h = (x - x_c[r]) - sl.length;
+      const bool elig = nb_celig[r] && (has || nb_cseq[r] > seq);
+      if (elig && (c_h < bestf || (c_h == bestf && nb_cseq[r] < bseq))) { bestf = c_h; bseq = nb_cseq[r]; bj = nb_cand[r]; }
     }
     const bool better = (bestf < start_h) && (bestf < BIGV);
     if (alive && live) {
@@ -671,6 +776,18 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
   };
 
   neighbours(false, false);
+  NoiseBlock<T> nzb;
+  nzb.init();
+
+  // -DFS_PHASE_TIMERS (scripts/phase_open.py): cycles per section of the sub-step, summed per wave and left in the
+  // replica's counters (which makes the handle useless for anything else -- a measurement build)
+#ifdef FS_PHASE_TIMERS
+  long long ph_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long ph_last = clock64();
+#define FS_TICK(p_) do { const long long n_ = clock64(); ph_t[p_] += n_ - ph_last; ph_last = n_; } while (0)
+#else
+#define FS_TICK(p_) do {} while (0)
+#endif
 
   if (num_steps == 0) {
     // after_reset: update(reset=True) registers the followers of the initial placement (vehicle/traci.py:219-250)
@@ -721,8 +838,11 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         a_rl = have_rl ? T(a) : T(0);
       }
       bool commanded = false;
-      T acc = control_accel_on<T, CSET>(s, sl, flags, v, vl, h, has, vf, hf, mean_v, on_edge, have_rl, a_rl, live && slot_ok,
-                               rr, ii, nctr, cst, commanded);
+      T g_now = T(0);
+      if (flags & FLAG_HAS_NOISE) g_now = nzb.draw(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(ii), nctr);
+      T acc = control_accel_on<T, CSET, true>(s, sl, flags, v, vl, h, has, vf, hf, mean_v, on_edge, have_rl, a_rl,
+                                              live && slot_ok, rr, ii, nctr, cst, commanded, g_now);
+      FS_TICK(0);
       // ---- O6: BottleneckDesiredVelocityEnv._apply_rl_actions (bottleneck.py:926-969) -------------------
       if (dv_env && act != nullptr) {
         const int my_lane = (route < 0 ? 0 : route) >> shift_of(x);
@@ -799,6 +919,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
           last_lc = tcount + 1;
         }
       }
+      FS_TICK(1);
       T x_new = (s.integrator == FS_BALLISTIC) ? x + (v + v_new) / T(2) * dt : x + v_new * dt;
       const bool mv = live && alive;
       if (mv) {
@@ -824,6 +945,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         tot_arr += na;
         if (bn_env && live && i == (tcount - 1) % 20) hist_l = na;
       }
+      FS_TICK(2);
       // ---- M2 / M3: insertions in InFlows order -------------------------------------------------------
       // (a rolled loop over the inflows; every per-flow constant comes out of a lane table, so the loop keeps no
       // scalar registers alive across the step loop)
@@ -845,11 +967,16 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         const double per_f = tb.template fd<0>(f);
         const bool prob_f = PROB && per_f < 0.0;
         const int g = prob_f ? seg_read_i<SEG>(gen_l, f, seg) : 0;
-        const double due_t = prob_f ? (k < g ? -1.0e300 : 1.0e300) : tb.template fd<1>(f) + double(k) * per_f;
-        nd = (due_t < nd) ? due_t : nd;
+        const double begin_f = tb.template fd<1>(f), end_f = tb.template fd<2>(f);
+        const double due_t = prob_f ? (k < g ? -1.0e300 : 1.0e300) : begin_f + double(k) * per_f;
         const int number = tb.template fi<2>(f);
-        const bool due = prob_f ? (k < g) : (due_t <= now) && (due_t <= tb.template fd<2>(f)) && (number < 0 || k < number);
-        if (__ballot(due && live) == 0ull) continue;     // wave-uniform: this inflow is due in no replica of the wave
+        const bool open_f = prob_f || ((due_t <= end_f) && (number < 0 || k < number));     // not exhausted
+        const bool due = prob_f ? (k < g) : (due_t <= now) && open_f;
+        if (__ballot(due && live) == 0ull) {             // wave-uniform: this inflow is due in no replica of the wave
+          const double mine = open_f ? due_t : 1.0e300;
+          nd = (mine < nd) ? mine : nd;
+          continue;
+        }
         const int typ = tb.template fi<0>(f);
         int route_f = tb.template fi<1>(f);
         const bool random_lane = route_f < 0;
@@ -902,9 +1029,15 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         const bool consumed = ok || (random_lane && live && due);
         if (consumed && i == f) emit_l = k + 1;
         if (consumed && !ok) tot_drop += 1;
-        if (consumed) nd = 0.0;                            // its next vehicle: re-evaluated in the next sub-step
+        {                                                // when this inflow is next worth looking at
+          const double t_next = prob_f ? ((k + 1 < g) ? -1.0e300 : 1.0e300) : begin_f + double(k + 1) * per_f;
+          const bool more = prob_f || ((t_next <= end_f) && (number < 0 || k + 1 < number));
+          const double mine = consumed ? (more ? t_next : 1.0e300) : (open_f ? due_t : 1.0e300);
+          nd = (mine < nd) ? mine : nd;
+        }
       }
       if (any_due) next_due = nd;
+      FS_TICK(3);
       // ---- O1: new neighbour snapshot, sticky followers, collision check --------------------------------
       neighbours(live, track_foll);
       bool c = seg_any<SEG>((route >= 0) && has && lead_same_lane && (h < s.crash_gap), seg);
@@ -914,6 +1047,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       }
       if (env == FS_ENV_MERGE_MA) c = false;             // multiagent/base.py:188-190: crash = 0
       crashed = crashed || (c && live);
+      FS_TICK(4);
     }
 
     // ---- get_state / compute_reward / done ---------------------------------------------------------------
@@ -944,14 +1078,20 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         const T term = tmin((t_headway - T(1)) / T(1), T(0));
         T cost2 = T(0);
         unsigned long long ub = seg_ballot<SEG>(use, seg);
-        const int lim = po_env ? num_rl : o.n_rl_slots;
-        for (int t = 0; t < lim; ++t) {
-          const unsigned long long b = po_env ? seg_ballot<SEG>(use && rank == t, seg) : ub;
-          const bool bit = b != 0ull;
-          const int j = bit ? __ffsll((long long)b) - 1 : 0;
-          ub &= ub - 1ull;
-          const T tj = bperm(term, segbase + j);
-          if (bit) cost2 = cost2 + tj;
+        if (SEG == 64 && !po_env) {
+          // one replica per wave: the mask is wave-uniform, so the terms are walked in slot order with v_readlane
+          // (no LDS round trip per term) and only as many times as there are terms
+          for (unsigned long long u = ub; u; u &= u - 1ull) cost2 = cost2 + read_lane(term, __ffsll((long long)u) - 1);
+        } else {
+          const int lim = po_env ? num_rl : o.n_rl_slots;
+          for (int t = 0; t < lim; ++t) {
+            const unsigned long long b = po_env ? seg_ballot<SEG>(use && rank == t, seg) : ub;
+            const bool bit = b != 0ull;
+            const int j = bit ? __ffsll((long long)b) - 1 : 0;
+            ub &= ub - 1ull;
+            const T tj = bperm(term, segbase + j);
+            if (bit) cost2 = cost2 + tj;
+          }
         }
         reward = tmax(cost1 + T(0.1) * cost2, T(0));
         reward = crashed ? T(0) : reward;
@@ -964,6 +1104,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       rrow += step_rows;
       drow += step_rows;
     }
+    FS_TICK(7);
   }
 
   if (valid && live_replica) {
@@ -994,8 +1135,14 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       cnt[CNT_TOTAL_ARRIVED] = tot_arr;
       cnt[CNT_TOTAL_DEPARTED] = tot_dep;
       cnt[CNT_TOTAL_DROPPED] = tot_drop;
+#ifdef FS_PHASE_TIMERS
+      for (int q = 0; q < 8; ++q) cnt[q] = int(ph_t[q] >> 6);
+      cnt[5] = int(nb_struct_cycles >> 6);          // (part of section 4)
+      cnt[6] = nb_struct_calls;                     // full evaluations of the neighbour structure
+#endif
     }
   }
+#undef FS_TICK
   if (rvalid && live_replica && i < FS_MAX_INFLOWS) o.emitted[size_t(rr) * FS_MAX_INFLOWS + i] = emit_l;
   if (prob_any && rvalid && live_replica && i < FS_MAX_INFLOWS) o.generated[size_t(rr) * FS_MAX_INFLOWS + i] = gen_l;
   if (bn_env && rvalid && live_replica && i < 20) o.arr_hist[size_t(rr) * 20 + i] = hist_l;

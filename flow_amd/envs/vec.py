@@ -168,7 +168,16 @@ class VecFlowEnv(object):
         ``policy`` (a callable on the [R, obs_dim] observation tensor returning [R, action_dim] actions, e.g. a torch
         module) and one fs_step_dev launch, captured back to back on one stream.  What the reference's rollout workers
         do with one Python call + socket round trips per step (examples/train.py:110-212) costs one graph launch per
-        fragment here; observations and actions never leave HBM."""
+        fragment here; observations and actions never leave HBM.
+
+        ``done`` is the simulator's flag byte (bit 0: horizon reached, bit 1: collision), not a 0/1 value."""
+        if reset_done and self._resample:
+            import warnings
+            warnings.warn("VecFlowEnv.capture(reset_done=True): this environment redraws its ring length on reset "
+                          "(WaveAttenuationEnv ring_length, flow/envs/ring/wave_attenuation.py:157-210); a reset inside "
+                          "the captured graph re-places a replica on the length it drew at the last vec.reset() / "
+                          "vec.reset_done() instead.  Call vec.redraw_ring_lengths() between replays to give every "
+                          "replica a fresh pending length for its next in-graph reset.", stacklevel=2)
         return StepGraph(self, num_steps, policy, reset_done)
 
     # ---- host-side inspection
@@ -242,16 +251,26 @@ class StepGraph(object):
             if self.reset_done:
                 sim.reset_dev(self.obs[k + 1], self.done[k])
 
+    def _after_caller(self):
+        # the graph's stream is non-blocking: what the caller enqueued on ITS stream so far (vec.reset()'s kernels, the
+        # optimiser step that rewrote the policy weights) must have finished before anything here reads it
+        self.stream.wait_stream(self.vec.torch.cuda.current_stream(self.vec.device))
+
     def begin(self, obs0):
         """Set the observation the first step's policy call sees (after ``vec.reset()``)."""
+        self._after_caller()
         with self.vec.torch.cuda.stream(self.stream):
             self._carry.copy_(obs0)
 
     def replay(self):
         """One fragment: returns (obs [K+1,R,D], actions [K,R,A], rew [K,R], done [K,R]) views, valid until the next
-        replay; enqueued on the graph's stream (``graph.stream``), synchronise or wait on it before reading."""
+        replay.  Ordered on both sides: the replay starts after the work the caller's current stream holds so far, and
+        the caller's current stream waits for the fragment before it runs anything enqueued after this call (no host
+        synchronisation either way).  ``done`` is a flag byte (bit 0 horizon, bit 1 collision)."""
+        self._after_caller()
         with self.vec.torch.cuda.stream(self.stream):      # CUDAGraph.replay() goes to torch's CURRENT stream
             self.graph.replay()
+        self.vec.torch.cuda.current_stream(self.vec.device).wait_stream(self.stream)
         return self.obs, self.actions, self.rew, self.done
 
     def synchronize(self):
