@@ -87,6 +87,7 @@ def train_on_device(flow_params, replicas=1024, fragment=100, iterations=20, epo
     K, R = fragment, replicas
     history = []
     for it in range(iterations):
+        vec.redraw_ring_lengths()                              # pending ring length per replica for its next in-graph reset
         t0 = time.perf_counter()
         obs, act, rew, done = graph.replay()                   # K closed-loop steps of R replicas: one graph launch
         graph.synchronize()

@@ -12,7 +12,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 # FLOWSIM_LIB: a development build of the same sources (e.g. the phase-timer build of scripts/phase_open.py)
 LIB_PATH = os.environ.get("FLOWSIM_LIB") or os.path.join(PKG, "libflowsim.so")
 
-FS_ABI_VERSION = 6
+FS_ABI_VERSION = 7
 FS_MAX_CTRL_PARAMS = 8
 
 # error codes
@@ -37,7 +37,8 @@ FS_EULER, FS_BALLISTIC = 0, 1
 (FS_FIELD_POS, FS_FIELD_VEL, FS_FIELD_HEADWAY, FS_FIELD_PREV_VEL, FS_FIELD_ACCEL, FS_FIELD_TIME,
  FS_FIELD_RING_LENGTH, FS_FIELD_INIT_POS, FS_FIELD_INIT_VEL, FS_FIELD_CTRL_STATE, FS_FIELD_LANE,
  FS_FIELD_LAST_LC, FS_FIELD_LEADER, FS_FIELD_INIT_LANE, FS_FIELD_ROUTE, FS_FIELD_SEQ, FS_FIELD_ORIGIN,
- FS_FIELD_FOLLOWER, FS_FIELD_CTL_SEQ, FS_FIELD_COUNTERS, FS_FIELD_ARRIVED_RL, FS_FIELD_MAX_SPEED) = range(22)
+ FS_FIELD_FOLLOWER, FS_FIELD_CTL_SEQ, FS_FIELD_COUNTERS, FS_FIELD_ARRIVED_RL, FS_FIELD_MAX_SPEED,
+ FS_FIELD_INIT_RING_LENGTH) = range(23)
 
 EXPORTS = ["fs_create", "fs_destroy", "fs_last_error", "fs_abi_version", "fs_obs_dim", "fs_action_dim", "fs_set_stream",
            "fs_use_own_stream", "fs_sync", "fs_reset", "fs_reset_dev", "fs_step", "fs_step_dev", "fs_rollout_dev",

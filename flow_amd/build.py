@@ -23,8 +23,12 @@ LIB = os.path.join(PKG, "libflowsim.so")
 VALIDATED_ROCM = "7.2"
 
 HEADERS = ["flowsim_sim.h", "flowsim_launch.h", "flowsim_kernels.h", "flowsim_open.h", "flowsim_wide.h",
-           "flowsim_pair.h", "flowsim_pair_step_a.inc", "flowsim_pair_step_a_sm.inc", "flowsim_fig8.h"]
-DEPS = [SRC, PART] + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, "include", "flowsim.h")]
+           "flowsim_pair.h", "flowsim_pair_step_a.inc", "flowsim_pair_step_a_sm.inc", "flowsim_fig8.h", "flowsim_ringrl.h",
+           "flowsim_part.hip"]
+DEPS = [SRC] + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, "include", "flowsim.h")]
+assert all(os.path.exists(d) for d in DEPS)
+_known = set(os.path.basename(d) for d in DEPS)
+assert all(f in _known for f in os.listdir(CSRC) if f.endswith((".h", ".inc", ".hip"))), "flow_amd/build.py: a source under csrc/ is not in DEPS"
 
 # -ffp-contract=off: the kernels are the float32 bit-twin of the oracle only if a*b+c is never fused
 COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-Wall", "-Wno-unused-function"]

@@ -15,17 +15,27 @@ int validate(const fs_config* c) {
   if (c->precision != FS_F32 && c->precision != FS_F64 && c->precision != FS_MIXED)
     return fail(FS_ERR_INVALID, "fs_create: bad precision");
   if (c->precision == FS_MIXED) {
-    bool ok = c->network == FS_NET_RING && c->num_lanes <= 1 && c->env == FS_ENV_ACCEL && !c->evaluate &&
-              c->sims_per_step == 1 && c->integrator == FS_EULER && !c->junction_mode && !c->track_aux &&
-              !c->sort_vehicles && !c->obs_perm && c->warmup_steps == 0 && c->num_vehicles >= 2 &&
-              c->num_vehicles <= 64 && (c->num_vehicles % 2) == 0 && c->vehicles;
-    for (int i = 0; ok && i < c->num_vehicles; ++i) {
+    // float64 state, float32 controllers: k_rollout_pair (all-IDM AccelEnv rollout) and k_ring_pair (IDM + RL vehicles,
+    // AccelEnv / WaveAttenuationPOEnv, warm-up steps and masked resets included).  Name the field that does not fit.
+    const char* why = nullptr;
+    if (c->network != FS_NET_RING || c->num_lanes > 1) why = "network (single-lane ring only)";
+    else if (c->env != FS_ENV_ACCEL && c->env != FS_ENV_WAVE_ATTENUATION_PO) why = "env (AccelEnv or WaveAttenuationPOEnv)";
+    else if (c->evaluate) why = "evaluate";
+    else if (c->sims_per_step != 1) why = "sims_per_step (1)";
+    else if (c->integrator != FS_EULER) why = "integrator (Euler)";
+    else if (c->junction_mode) why = "junction_mode";
+    else if (c->track_aux) why = "track_aux (the scalar Env's previous-speed / acceleration fields: VecFlowEnv(track_aux=False))";
+    else if (c->sort_vehicles || c->obs_perm) why = "sort_vehicles / shuffled ids";
+    else if (c->num_vehicles < 2 || c->num_vehicles > 64 || (c->num_vehicles % 2) != 0) why = "num_vehicles (even, 2..64)";
+    else if (!c->vehicles) why = "vehicles (NULL)";
+    for (int i = 0; !why && i < c->num_vehicles; ++i) {
       const fs_vehicle_spec& v = c->vehicles[i];
-      ok = v.controller == FS_CTRL_IDM && !(v.noise > 0) && v.fail_safe == FS_FAILSAFE_NONE;
+      if (v.controller != FS_CTRL_IDM && v.controller != FS_CTRL_RL) why = "vehicles[].controller (IDMController / RLController)";
+      else if (v.noise > 0 && v.controller == FS_CTRL_IDM) why = "vehicles[].noise (the hardware's log / cos have no bit-twin on the CPU)";
+      else if (v.fail_safe != FS_FAILSAFE_NONE) why = "vehicles[].fail_safe";
     }
-    if (!ok)
-      return fail(FS_ERR_UNSUPPORTED, "fs_create: FS_MIXED is built for the rollout path of single-lane rings with an "
-                                      "even number of plain IDM vehicles (any speed mode, AccelEnv, no warm-up)");
+    if (why)
+      return fail(FS_ERR_UNSUPPORTED, std::string("fs_create: FS_MIXED does not support this configuration: ") + why);
   }
   if (c->network < FS_NET_RING || c->network > FS_NET_BOTTLENECK)
     return fail(FS_ERR_UNSUPPORTED, "fs_create: network not built");
@@ -251,6 +261,8 @@ int create_typed(const fs_config* cfg, fs_handle* out) {
     s->no_loop_kernel = nl && nl[0] == '1';
     const char* nlf = std::getenv("FLOWSIM_NO_LOOP_FULL");
     s->no_loop_full = nlf && nlf[0] == '1';
+    const char* nrr = std::getenv("FLOWSIM_NO_RING_RL");
+    s->no_ring_rl = nrr && nrr[0] == '1';
     const char* np = std::getenv("FLOWSIM_NO_PAIR");
     s->no_pair = np && np[0] == '1';
     const char* pb = std::getenv("FLOWSIM_PAIR_BLOCK");

@@ -32,6 +32,7 @@ enum : int {
   FLAG_HAS_FAILSAFE = 32,
   FLAG_ALL_IDM = 64,        // every slot is an IDM controller (fast path)
   FLAG_IDM_SET = 128,       // every slot is an IDMController, an RLController or a SimCarFollowingController
+  FLAG_NO_FLOW_CTRL = 256,  // every slot is an RLController or a SimCarFollowingController: no Flow acceleration controller
 };
 
 template <typename T>
@@ -55,6 +56,7 @@ struct DevView {
   const T* init_pos;
   const T* init_vel;
   const T* ring_len;    // [R]
+  const T* init_ring_len;   // [R] the length a replica takes at its next reset (FS_FIELD_INIT_RING_LENGTH)
   // per-slot tables, [N]
   const int32_t* ctrl;
   const int32_t* failsafe;
@@ -1233,6 +1235,10 @@ __device__ __forceinline__ float div_via_f64(float x, double c, double rc) {
   q = __builtin_fma(r, rc, q);
   return float(q);
 }
+// x / c for a compile-time-known c (an OUTPUT: must be the correctly rounded quotient): float through div_via_f64
+__device__ __forceinline__ float div_out(float x, double c) { return div_via_f64(x, c, 1.0 / c); }
+__device__ __forceinline__ double div_out(double x, double c) { return x / c; }
+
 
 template <typename T, int SEG, bool DELTA4, bool FASTDIV, bool BADCHK>
 __global__ __launch_bounds__(1024) void k_rollout_idm(DevView<T> s, int num_steps, float* __restrict__ obs,
@@ -1757,6 +1763,7 @@ __global__ void k_reset(DevView<T> s, const uint8_t* __restrict__ mask) {
     s.prev_vel[e] = s.init_vel[e];
     s.accel[e] = T(0);
     s.ctrl_state[e] = T(0);
+    if (e % s.N == 0 && s.init_ring_len != nullptr) const_cast<T*>(s.ring_len)[r] = s.init_ring_len[r];
     if (s.sort_vehicles) {                         // accel.py:171-183: absolute_position = get_x_by_id at reset
       T xa = s.init_pos[e];
       if (s.nseg > 0) {

@@ -105,6 +105,38 @@ namespace fsim {
         return FS_OK;
       }
     }
+    // single-lane rings of IDM and RL vehicles (flowsim_ringrl.h): the RL experiments' populations and heads, masked
+    // and zero-step launches included; the all-IDM AccelEnv rollout keeps its hand-written kernel below
+    {
+      const int f = dv.flags;
+      const bool ring_rl_ok = dv.nseg == 0 && !dv.junction_on && (f & fs::FLAG_IDM_SET) && !any_sim &&
+                              !(f & fs::FLAG_HAS_FAILSAFE) && dv.sims_per_step == 1 && dv.integrator == FS_EULER &&
+                              !dv.junction_mode && !dv.track_aux && !dv.sort_vehicles && dv.obs_perm == nullptr &&
+                              !dv.evaluate && (dv.env == FS_ENV_ACCEL || dv.env == FS_ENV_WAVE_ATTENUATION_PO) &&
+                              dv.N >= 2 && (dv.N % 2) == 0 && !force_generic && !no_ring_rl &&
+                              (!(f & fs::FLAG_HAS_NOISE) || pair_noise);
+      if (ring_rl_ok && !(pair_ok && (mixed || std::is_same<T, float>::value)) && (mixed || std::is_same<T, float>::value)) {
+        const bool fast = ringrl_fast_ok();
+        const int waves = (dv.R + (64 / ROW) - 1) / (64 / ROW);
+        const dim3 grid((waves + 3) / 4), block(256);
+        const bool po = dv.env == FS_ENV_WAVE_ATTENUATION_PO;
+        last_kernel = po ? "k_ring_pair<PO>" : "k_ring_pair<Accel>";
+#define FS_RING(H_, NZ_, FA_)                                                                                    \
+  hipLaunchKernelGGL((fs::k_ring_pair<T, ROW, H_, NZ_, FA_>), grid, block, 0, stream, dv, num_steps, mask, actions,   \
+                     act_stride, obs, rew, done, obs_every_step)
+#define FS_RING_F(H_, NZ_) do { if (fast) FS_RING(H_, NZ_, true); else FS_RING(H_, NZ_, false); } while (0)
+        if constexpr (std::is_same<T, float>::value) {
+          if (f & fs::FLAG_HAS_NOISE) { if (po) FS_RING_F(1, true); else FS_RING_F(0, true); }
+          else { if (po) FS_RING_F(1, false); else FS_RING_F(0, false); }
+        } else {
+          if (po) FS_RING_F(1, false); else FS_RING_F(0, false);
+        }
+#undef FS_RING_F
+#undef FS_RING
+        HIP_TRY(hipGetLastError());
+        return FS_OK;
+      }
+    }
     if (mixed && num_steps == 0) {                       // observation of the current state (Env.reset)
       const int n = dv.R * dv.N;
       last_kernel = "k_obs_mixed";
@@ -113,8 +145,9 @@ namespace fsim {
       return FS_OK;
     }
     if (mixed && !pair_ok)
-      return fail(FS_ERR_UNSUPPORTED, "FS_MIXED is built for the all-IDM ring rollout (observation every step or "
-                                      "single steps, no reset mask during stepping)");
+      return fail(FS_ERR_UNSUPPORTED, "FS_MIXED: this launch fits neither mixed kernel (k_rollout_pair / k_ring_pair: "
+                                      "single-lane ring, even number of IDM / RL vehicles, AccelEnv or "
+                                      "WaveAttenuationPOEnv, track_aux = 0)");
     if (pair_ok && (mixed || std::is_same<T, float>::value)) {
       const bool fd = fastdiv_ok();
       const int waves = (dv.R + (64 / ROW) - 1) / (64 / ROW);

@@ -93,7 +93,11 @@ enum { CNT_SIM_STEPS = 0, CNT_SEQ = 1, CNT_CTL = 2, CNT_ARRIVED = 3, CNT_DEPARTE
 // test of k_steps_wide).  The float64 kernels always spill; the float32 ones sit at 190-256 VGPRs, one edit away
 // from it, and measured no faster with the VGPR home (C5 237 M, C4 15.5 M either way) -- so LDS for all of them.
 template <typename T>
+struct alignas(16) CellRow { T start, lo, hi; int meta; };      // one lane-segment group: a single LDS read in cell_of
+
+template <typename T>
 struct OpenTabsLds {
+  CellRow<T> cpack[2][64];      // [observation | action][group]
   T tab[TAB_ROWS][64];
   T ctab[6][64];
   double ftd[3][64];
@@ -131,6 +135,14 @@ struct OpenTabs<T, false> {
   template <int ROW> __device__ __forceinline__ T t_gather(int j) const { return __shfl(tab[ROW], j, 64); }
   template <int ROW> __device__ __forceinline__ T c_gather(int j) const { return __shfl(ctab[ROW], j, 64); }
   template <int ROW> __device__ __forceinline__ int ci_gather(int j) const { return __shfl(ctab_i[ROW], j, 64); }
+  template <int KIND> __device__ __forceinline__ CellRow<T> cell_row(int g) const {
+    CellRow<T> row;
+    row.start = c_gather<KIND * 3 + 0>(g);
+    row.lo = c_gather<KIND * 3 + 1>(g);
+    row.hi = c_gather<KIND * 3 + 2>(g);
+    row.meta = ci_gather<KIND>(g);
+    return row;
+  }
 };
 
 template <typename T>
@@ -148,9 +160,19 @@ struct OpenTabs<T, true> {
     for (int r = 0; r < 6; ++r) lds->ctab[r][lane] = cells ? o.cell_tab[r * 64 + lane] : T(0);
 #pragma unroll
     for (int r = 0; r < 3; ++r) lds->ctab_i[r][lane] = cells ? o.cell_tab_i[r * 64 + lane] : 0;
+#pragma unroll
+    for (int kind = 0; kind < 2; ++kind) {
+      CellRow<T> row;
+      row.start = cells ? o.cell_tab[(kind * 3 + 0) * 64 + lane] : T(0);
+      row.lo = cells ? o.cell_tab[(kind * 3 + 1) * 64 + lane] : T(0);
+      row.hi = cells ? o.cell_tab[(kind * 3 + 2) * 64 + lane] : T(0);
+      row.meta = cells ? o.cell_tab_i[kind * 64 + lane] : 0;
+      lds->cpack[kind][lane] = row;
+    }
     L = lds;
     __syncthreads();
   }
+  template <int KIND> __device__ __forceinline__ CellRow<T> cell_row(int g) const { return L->cpack[KIND][g]; }
   template <int ROW> __device__ __forceinline__ T t(int j) const { return L->tab[ROW][j]; }
   template <int ROW> __device__ __forceinline__ T c(int j) const { return L->ctab[ROW][j]; }
   template <int ROW> __device__ __forceinline__ int ci(int j) const { return L->ctab_i[ROW][j]; }
@@ -240,9 +262,10 @@ __device__ __forceinline__ int cell_of(const TABS& tb, int span, T x, int seg_k,
   int cell = -1;
   for (int r = 0; r < span; ++r) {
     const int g = g0 + (r < cnt ? r : 0);
-    const T pos = x - tb.template c_gather<KIND * 3 + 0>(g);
-    const T lo = tb.template c_gather<KIND * 3 + 1>(g), hi = tb.template c_gather<KIND * 3 + 2>(g);
-    const int meta = tb.template ci_gather<KIND>(g);
+    const CellRow<T> row = tb.template cell_row<KIND>(g);
+    const T pos = x - row.start;
+    const T lo = row.lo, hi = row.hi;
+    const int meta = row.meta;
     bool inside = (pos > lo) & (pos <= hi);
     if (KIND == 0) inside = inside | (((meta >> 24) != 0) & (pos == T(0)));   // searchsorted(..) - 1 == -1: last segment
     const int rel = my_lane - ((meta >> 16) & 0xff);

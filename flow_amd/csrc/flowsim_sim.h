@@ -23,6 +23,7 @@
 #include "flowsim_open.h"
 #include "flowsim_pair.h"
 #include "flowsim_fig8.h"
+#include "flowsim_ringrl.h"
 #include "flowsim_wide.h"
 
 
@@ -72,6 +73,7 @@ struct SimBase {
   bool no_pair = false;         // FLOWSIM_NO_PAIR=1: keep k_rollout_idm (one vehicle per lane) for the float rollout
   bool no_loop_kernel = false;  // FLOWSIM_NO_LOOP_KERNEL=1: keep the generic k_steps for segment-table loops (tests)
   bool no_loop_full = false;    // FLOWSIM_NO_LOOP_FULL=1: keep the run-time-flag instantiation of k_rollout_loop (tests)
+  bool no_ring_rl = false;      // FLOWSIM_NO_RING_RL=1: keep the generic k_steps for IDM + RL rings (tests)
   int pair_block = 256;         // threads per block of k_rollout_pair (FLOWSIM_PAIR_BLOCK overrides)
   const char* last_kernel = "";  // family of the step kernel the last launch_steps call chose (fs_last_kernel)
 
@@ -148,6 +150,7 @@ struct Sim : SimBase {
     if ((rc = upload(&dv.init_pos, ipos))) return rc;
     if ((rc = upload(&dv.init_vel, ivel))) return rc;
     if ((rc = upload(&dv.ring_len, rlen))) return rc;
+    if ((rc = upload(&dv.init_ring_len, rlen))) return rc;
     h_ring_len = rlen;
 
     std::vector<int32_t> ctrl(N), fsafe(N), smode(N), rli(N), pisi(N, -1);
@@ -185,6 +188,7 @@ struct Sim : SimBase {
       if (v.speed_mode & 6) flags |= fs::FLAG_NEED_SUMO;
       if (v.controller == FS_CTRL_SIM || v.controller == FS_CTRL_RL || cfg.junction_mode) sumo_beyond_speed_mode = true;
       if (v.speed_mode & 7) speed_mode_any = true;
+      if (v.controller == FS_CTRL_SIM) any_sim = true;
       if (v.controller != FS_CTRL_IDM) all_idm = false;
       if (v.controller != FS_CTRL_IDM && v.controller != FS_CTRL_RL && v.controller != FS_CTRL_SIM) idm_set = false;
     }
@@ -194,6 +198,11 @@ struct Sim : SimBase {
                     (veh[i].controller != FS_CTRL_IDM || (float(veh[i].p[5]) >= 1e-3f && float(veh[i].p[5]) <= 1e6f));
     loop_delta4 = true;
     for (int i = 0; i < N; ++i) loop_delta4 = loop_delta4 && (veh[i].controller != FS_CTRL_IDM || veh[i].p[4] == 4.0);
+    {
+      bool no_ctrl = true;
+      for (int i = 0; i < N; ++i) no_ctrl = no_ctrl && (veh[i].controller == FS_CTRL_SIM || veh[i].controller == FS_CTRL_RL);
+      if (no_ctrl) flags |= fs::FLAG_NO_FLOW_CTRL;
+    }
     if (all_idm) flags |= fs::FLAG_ALL_IDM;
     if (idm_set) flags |= fs::FLAG_IDM_SET;
     delta4 = all_idm;
@@ -556,6 +565,46 @@ struct Sim : SimBase {
     return true;
   }
 
+  // k_ring_pair<..., FAST> (flowsim_ringrl.h): exponent 4 and the exact reciprocal divisions -- every divisor proven.
+  // The premises on s0 / minGap are weaker than fastdiv_ok()'s (>= 0 instead of >= 1e-3): s* = s0 + max(0, dyn) below
+  // 2^-60 makes q = s* / h < 2^-50, whose square vanishes against every non-zero 1 - (v/v0)^4 (>= 2^-24) and, where that
+  // term is exactly zero, gives an acceleration too small to move a speed near v0 -- so an inexact quotient there
+  // cannot change a result; from 2^-60 up div_core's operands are inside its proven range (|h| in [1e-3, L]).
+  int ringrl_fast_state = -1;
+  bool any_sim = false;                  // some slot is a SimCarFollowingController
+  bool ringrl_fast_ok() {
+    if (no_fastdiv || force_generic) return false;
+    if (ringrl_fast_state >= 0) return ringrl_fast_state == 1;
+    ringrl_fast_state = 0;
+    std::vector<float> cs;
+    auto add = [&cs](float c) {
+      for (float e : cs)
+        if (e == c) return;
+      cs.push_back(c);
+    };
+    for (int i = 0; i < dv.N; ++i) {
+      if (veh[i].controller == FS_CTRL_IDM) {
+        if (veh[i].p[4] != 4.0) return false;
+        add(float(veh[i].p[0]));
+        add(2.0f * std::sqrt(float(veh[i].p[2]) * float(veh[i].p[3])));
+        if (!(float(veh[i].p[5]) >= 0.0f) || !(float(veh[i].p[5]) <= 1e6f)) return false;
+      }
+      add(float(veh[i].sumo_max_speed));
+      add(2.0f * std::sqrt(float(veh[i].max_accel) * float(veh[i].max_decel)));
+      if (!(float(veh[i].sumo_min_gap) >= 0.0f) || !(float(veh[i].sumo_min_gap) <= 1e6f)) return false;
+    }
+    for (T b : h_ring_len) {
+      const float L = float(b) + 4.0f * float(dv.jlen);
+      if (!(L >= 1.0f)) return false;
+      add(L);
+      if (cs.size() > 96) return false;
+    }
+    for (float c : cs)
+      if (!fastdiv_exact_for(c)) return false;
+    ringrl_fast_state = 1;
+    return true;
+  }
+
   // the specialisations for the headline configuration (see flowsim_kernels.h)
   bool delta4 = false;
   bool loop_div_ok = false, loop_delta4 = false;
@@ -623,6 +672,7 @@ struct Sim : SimBase {
       case FS_FIELD_CTRL_STATE: *count = RN; return dv.ctrl_state;
       case FS_FIELD_MAX_SPEED: *count = open_net ? RN : 0; return open_net ? ov.vmax : nullptr;
       case FS_FIELD_RING_LENGTH: *count = size_t(dv.R); return const_cast<T*>(dv.ring_len);
+      case FS_FIELD_INIT_RING_LENGTH: *count = size_t(dv.R); return const_cast<T*>(dv.init_ring_len);
       case FS_FIELD_INIT_POS: *count = RN; return const_cast<T*>(dv.init_pos);
       case FS_FIELD_INIT_VEL: *count = RN; return const_cast<T*>(dv.init_vel);
       default: *count = 0; return nullptr;
@@ -752,9 +802,23 @@ struct Sim : SimBase {
     }
     if (open_net && (field == FS_FIELD_POS || field == FS_FIELD_VEL))   // refresh the leader / headway snapshot
       return launch_steps(0, nullptr, nullptr, 0, d_obs, d_rew, d_done, 0);
-    if (field == FS_FIELD_RING_LENGTH) {
+    if (field == FS_FIELD_RING_LENGTH) {            // sets the pending lengths too
+      HIP_TRY(hipMemcpy(const_cast<T*>(dv.init_ring_len), src, bytes, hipMemcpyHostToDevice));
       h_ring_len.assign(static_cast<const T*>(src), static_cast<const T*>(src) + count);
       fastdiv_state = -1;
+      ringrl_fast_state = -1;
+    }
+    if (field == FS_FIELD_INIT_RING_LENGTH) {
+      // the host copy the divisor proofs walk holds every length a replica may be running on: the current ones and,
+      // appended, the pending ones (a masked reset on the device swaps them in without the host knowing which)
+      const T* vals = static_cast<const T*>(src);
+      for (size_t e = 0; e < count; ++e) {
+        bool seen = false;
+        for (T b : h_ring_len) seen = seen || (b == vals[e]);
+        if (!seen) h_ring_len.push_back(vals[e]);
+      }
+      fastdiv_state = -1;
+      ringrl_fast_state = -1;
     }
     return FS_OK;
   }

@@ -9,12 +9,15 @@
 //   * a mask over slots / ranks is W 64-bit words, one ballot per wave, published to LDS and read back by everyone;
 //   * a reduction is one per-wave partial (DPP / ballot inside the wave) + a combine over the W partials, in the
 //     order of the xor-butterfly's next levels ((w0 + w1) + (w2 + w3)) so that oracle/rewards.py tree_sum holds.
-// A value is published before a __syncthreads() and consumed after it; scratch words alternate between two
+// A value is published before a lds_barrier() and consumed after it; scratch words alternate between two
 // buffers so that a fast wave's next publication never lands on words a slow wave is still reading.  Control flow
 // around every barrier is block-uniform: a block holds ONE replica, so `live`, `due`, `crashed` are uniform.
 #pragma once
 
 namespace fs {
+
+template <typename T>
+struct alignas(16) CellQuad { T a, b, c, d; };
 
 template <typename T, int W>
 struct WideLds {
@@ -29,19 +32,30 @@ struct WideLds {
   int sorted_slot[NS];          // [rank] -> slot
   int skey[NS];                 // [rank] -> path | joins << 8, 0xffff for a free slot
   unsigned long long okey[sizeof(T) == 4 ? NS : 1];   // float32: the 64-bit ordering keys of the vehicles, compacted
+  unsigned long long okey2[sizeof(T) == 4 ? NS : 1];  // ... and in the order of the updated ranking (its proof)
   T cx[sizeof(T) == 4 ? 1 : NS];                      // float64: their positions ...
   int cslot[sizeof(T) == 4 ? 1 : NS];                 // ... and slots, compacted
   unsigned long long rmask[10][W];       // masks over RANKS: path 0..P-1 (P <= 8), then passed the first / the second join
+  unsigned long long comb[24][W];        // [path * 3 + look-ahead region]: the ranks that hold a leader candidate of that class
   unsigned long long words[2][2][W];
   T red_t[2][4][W];
   int red_i[2][4][W];
   unsigned long long cell[2][128][W];    // observation cells: [human | rl][cell][wave] = members in that wave
+  static constexpr int CELL_CAP = 32;    // speeds a cell's member list holds (a lane-segment of ~100 m: <= ~20 vehicles)
+  alignas(16) T cellv[2][128][CELL_CAP]; // [human | rl][cell][k]: speed of the k-th member in slot order
   // launch constants, read with uniform / gathered addresses -- OpenTabs<T, IN_LDS> of flowsim_open.h, and why
   OpenTabsLds<T> tabs;
   int emitted[FS_MAX_INFLOWS];           // vehicles emitted so far by inflow f
   int generated[FS_MAX_INFLOWS];         // vehicles generated so far by a probabilistic inflow f (M2b)
   int hist[20];                          // arrivals of sub-step % 20
+  float act[2][64];                      // the RL actions of this step / the next one (loaded a step ahead)
 };
+
+// Workgroup barrier for data exchanged through LDS only.  __syncthreads() is a full fence: it also waits for the
+// wave's outstanding GLOBAL stores (s_waitcnt vmcnt(0)) -- the observation rows written a few hundred instructions
+// earlier, an HBM round trip on the critical path of every sub-step.  Nothing in this kernel reads back what it stored
+// to global memory, so the barriers only order the LDS traffic.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ int first_bit(unsigned long long m) { return __ffsll((long long)m) - 1; }
 __device__ __forceinline__ int last_bit(unsigned long long m) { return 63 - __clzll((long long)m); }
@@ -146,15 +160,40 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
   uint8_t* drow = done + rr;
 
   L.len[tid] = sl.length;
+  if (sizeof(T) == 4) { L.okey[tid] = 0ull; L.okey2[tid] = 0ull; }      // (stamp 0: never a ranking update's)
   for (int k = tid; k < 2 * 128 * W; k += NS) (&L.cell[0][0][0])[k] = 0ull;
   int phase = 0;                           // scratch buffer of the next publication (block-uniform)
+  double next_due = -1.0e300;              // see the inflow loop (unknown yet: the first sub-step looks)
 
+  // -DFS_PHASE_TIMERS (scripts/phase_open.py c4): cycles per section of the sub-step, left in the replica's counters
+#ifdef FS_PHASE_TIMERS
+  long long ph_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long ph_last = clock64();
+#if FS_PHASE_TIMERS == 2      // the fine sections of the neighbour update and the observation (phase_open.py c4fine)
+#define FS_TICKF(p_) do { const long long n_ = clock64(); ph_t[p_] += n_ - ph_last; ph_last = n_; } while (0)
+#define FS_TICKW(p_) do {} while (0)
+#else
+#define FS_TICKW(p_) do { const long long n_ = clock64(); ph_t[p_] += n_ - ph_last; ph_last = n_; } while (0)
+#define FS_TICKF(p_) do {} while (0)
+#endif
+#else
+#define FS_TICKW(p_) do {} while (0)
+#define FS_TICKF(p_) do {} while (0)
+#endif
   // ---- M5 + O1: neighbours through the ORDER of the vehicles (see k_steps_open) ----------------------------
   int lead = -1;
   T vl = T(-1001), h = T(1000);
   bool has = false, lead_same_lane = false;
-  // `crash_out`: does any vehicle of the replica sit closer than crash_gap behind its leader on its own lane
-  auto neighbours = [&](bool live, bool follow, bool& crash_out) {
+  // `crash_out`: does any vehicle of the replica sit closer than crash_gap behind its leader on its own lane;
+  // `arrived_now` / `na_out`: the arrivals of this sub-step are counted through the first barrier of the update
+  int nb_rank = -1;                        // my rank at the last update (-1: none yet / the slot was free)
+  unsigned gen = 0u;                       // stamp of the ranking try (block-uniform)
+  int n_new = 0;                           // vehicles inserted in this sub-step (block-uniform) ...
+  int new_slot[FS_MAX_INFLOWS];            // ... and their slots
+#pragma unroll
+  for (int q = 0; q < FS_MAX_INFLOWS; ++q) new_slot[q] = -1;
+  int out_obs = 0, out_rew = 0;            // arrivals inside the observation's / the reward's outflow window (block-uniform)
+  auto neighbours = [&](bool live, bool follow, bool& crash_out, bool arrived_now, bool count_arrivals, int& na_out) {
     const bool alive = route >= 0;
     const T xr = alive ? x : BIGV;
     L.x[tid] = xr;
@@ -163,48 +202,136 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
     // rank: x ascending, equal x: higher slot first; free slots after the vehicles (any fixed order).  Only the
     // vehicles are compared: their keys are first compacted (ballot prefix inside the wave + the wave totals), so the
     // count runs over n_alive entries instead of all NS slots; a free slot ranks n_alive + (free slots below it).
+    FS_TICKF(0);       // everything outside the update and the observation
     const ull am = __ballot(alive);
     const int bA = phase & 1;
     phase += 1;
-    if (l == 0) L.red_i[bA][0][w] = __popcll(am);
-    __syncthreads();
+    {
+      const int na_w = __popcll(__ballot(arrived_now));
+      if (l == 0) {
+        L.red_i[bA][0][w] = __popcll(am);
+        L.red_i[bA][1][w] = na_w;
+      }
+    }
+    lds_barrier();
     int base = 0, n_alive = 0;
+    na_out = 0;
 #pragma unroll
     for (int ww = 0; ww < W; ++ww) {
       const int cw = L.red_i[bA][0][ww];
       base += ww < w ? cw : 0;
       n_alive += cw;
+      na_out += L.red_i[bA][1][ww];
     }
+    if (count_arrivals) {
+      // get_outflow_rate's windows (vehicle/traci.py:500-505) as running sums: this sub-step's arrivals enter, the
+      // entry that has left the window goes (read here, between two barriers; the ring itself is written after the next)
+      const int eo = tcount - 1 - o.obs_window, er = tcount - 1 - o.rew_window;
+      out_obs += na_out - (eo >= 0 ? L.hist[eo % 20] : 0);
+      out_rew += na_out - (er >= 0 ? L.hist[er % 20] : 0);
+    }
+    FS_TICKF(1);       // first barrier (publish + wait)
     const int place = base + __popcll(am & ((1ull << l) - 1ull));    // vehicles in lower slots
     int rank = 0;
+    bool rank_bad = false;                 // float32: this thread saw the updated ranking fail its proof
+    ull rank_key = 0ull;
     if (sizeof(T) == 4) {
       // float32: the order is that of ONE unsigned 64-bit key, (order-preserving image of x) : (NS-1-slot), so a
       // pair costs a v_cmp_lt_u64 and an add-with-carry instead of two float compares and three mask operations
       // (x + 0 turns a -0.0 into +0.0, whose integer images would otherwise differ)
       const uint32_t xb = __float_as_uint(float(xr) + 0.0f);
       const uint32_t ord = (xb & 0x80000000u) ? ~xb : (xb | 0x80000000u);
-      const ull key = (ull(ord) << 32) | ull(uint32_t(NS - 1 - tid));
-      if (alive) L.okey[place] = key;
-      __syncthreads();
-#pragma unroll 8
-      for (int j = 0; j < n_alive; ++j) rank += (L.okey[j] < key) ? 1 : 0;
+      // Between two updates the order changes little (vehicles of neighbouring lanes pass each other, a few places at
+      // most), so the ranking is UPDATED instead of counted: every vehicle writes its new key at the place its OLD rank
+      // gives (the vehicles inserted in this sub-step in front -- they stand at the network's entry --, everyone else
+      // moved up by their number; arrivals were the front vehicles), reads the keys RW places either side and moves by
+      // the number of them that are now on the other side of it.  The result is PROVEN before it is used: the keys
+      // written to their new places must fill places 0 .. n_alive-1 with this update's stamp and ascend strictly there
+      // (a strictly ascending arrangement of the full keys is unique: it is the ranking the count gives).  Anything
+      // else -- a vehicle that moved further than RW places, an insertion behind a standing vehicle -- fails the proof
+      // and the block counts as before (the loop over the n_alive compacted keys was 19 % of C4's step).
+      // The stamp sits between the position image and the slot, so it never decides a comparison of two fresh keys.
+      constexpr int RW = 4;
+      gen += 1u;
+      const unsigned stamp = gen & 0xffffffu;
+      const ull key = (ull(ord) << 32) | (ull(stamp) << 8) | ull(uint32_t(NS - 1 - tid));
+      {
+        int newer = 0;                                    // inserted vehicles that rank below me
+        bool i_am_new = false;
+#pragma unroll
+        for (int q = 0; q < FS_MAX_INFLOWS; ++q) {
+          i_am_new = i_am_new || (q < n_new && new_slot[q] == tid);
+          newer += (q < n_new && new_slot[q] > tid) ? 1 : 0;
+        }
+        const int pos = i_am_new ? newer : nb_rank + n_new;
+        bool lost = alive && (pos < 0 || pos >= n_alive || (!i_am_new && nb_rank < 0));
+        if (alive && !lost) L.okey[pos] = key;
+        lds_barrier();
+        if (count_arrivals && tid == 0) L.hist[(tcount - 1) % 20] = na_out;
+        int delta = 0;
+#pragma unroll
+        for (int d = 1; d <= RW; ++d) {
+          const int ja = pos + d, jb = pos - d;
+          const bool ina = alive && !lost && ja < n_alive, inb = alive && !lost && jb >= 0;
+          const ull ka = L.okey[ina ? ja : 0], kb = L.okey[inb ? jb : 0];
+          lost = lost || (ina && (unsigned(ka >> 8) & 0xffffffu) != stamp) || (inb && (unsigned(kb >> 8) & 0xffffffu) != stamp);
+          delta += (ina && ka < key) ? 1 : 0;
+          delta -= (inb && kb > key) ? 1 : 0;
+        }
+        FS_TICKF(2);   // keys at the old places, barrier, window
+        int rank_try = pos + delta;
+        lost = lost || (alive && (rank_try < 0 || rank_try >= n_alive));
+        if (alive && !lost) L.okey2[rank_try] = key;
+        lds_barrier();
+        const ull k0 = L.okey2[tid], k1 = L.okey2[tid + 1 < NS ? tid + 1 : tid];
+        rank_bad = lost || ((tid < n_alive) && ((unsigned(k0 >> 8) & 0xffffffu) != stamp || ((tid + 1 < n_alive) && !(k0 < k1))));
+        rank = lost ? 0 : rank_try;
+        rank_key = key;
+      }
     } else {
       if (alive) {
         L.cx[place] = xr;
         L.cslot[place] = tid;
       }
-      __syncthreads();
+      lds_barrier();
+      if (count_arrivals && tid == 0) L.hist[(tcount - 1) % 20] = na_out;
 #pragma unroll 8
       for (int j = 0; j < n_alive; ++j) {
         const T xj = L.cx[j];
         rank += ((xj < xr) || (xj == xr && L.cslot[j] > tid)) ? 1 : 0;
       }
     }
-    if (!alive) rank = n_alive + (tid - place);
-    L.sorted_slot[rank] = tid;
     const int my_key = alive ? (route | (shift_of(x) << 8)) : 0xffff;
+    if (!alive) rank = n_alive + (tid - place);
+    L.sorted_slot[rank] = tid;             // (a ranking that fails its proof leaves rubbish here: written again below)
     L.skey[rank] = my_key;
-    __syncthreads();
+    if (sizeof(T) == 4) {
+      const int bP = phase & 1;
+      phase += 1;
+      const ull bw_ = __ballot(rank_bad);
+      if (l == 0) L.words[bP][1][w] = bw_;
+      lds_barrier();
+      ull ball = 0ull;
+#pragma unroll
+      for (int ww = 0; ww < W; ++ww) ball |= L.words[bP][1][ww];
+      if (ball != 0ull) {                                 // block-uniform: count in full
+        if (alive) L.okey[place] = rank_key;
+        lds_barrier();
+        int rk = 0;
+#pragma unroll 8
+        for (int j = 0; j < n_alive; ++j) rk += (L.okey[j] < rank_key) ? 1 : 0;
+        rank = alive ? rk : rank;
+        L.sorted_slot[rank] = tid;
+        L.skey[rank] = my_key;
+        lds_barrier();
+      }
+    } else {
+      lds_barrier();
+    }
+    nb_rank = alive ? rank : -1;
+    n_new = 0;
+    FS_TICKF(3);       // proof, scatter, flag barrier (+ the count when it failed)
+    FS_TICKW(3);
     const int skey = L.skey[tid];          // the key of the vehicle whose rank is my thread index
     const bool s_alive = skey != 0xffff;
     {
@@ -217,8 +344,25 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
 #pragma unroll
         for (int q = 0; q < P + 2; ++q) L.rmask[q][w] = bw[q];
       }
+      // the ranks of this wave's word that hold a leader candidate of class (path p, look-ahead region la): see cand_w
+      if (l < 3 * P) {
+        const int p = l / 3, la_ = l % 3;
+        ull path_w = 0ull, pair_w = 0ull, quad_w = 0ull;
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+          path_w |= (q == p) ? bw[q] : 0ull;
+          pair_w |= ((q & ~1) == (p & ~1)) ? bw[q] : 0ull;
+          quad_w |= ((q & ~3) == (p & ~3)) ? bw[q] : 0ull;
+        }
+        const ull R1 = bw[P], R2 = bw[P + 1];
+        const ull c0 = la_ == 0 ? path_w : (la_ == 1 ? pair_w : quad_w);
+        const ull c1 = la_ <= 1 ? pair_w : quad_w;
+        L.comb[l][w] = (~R1 & c0) | (R1 & ~R2 & c1) | (R2 & quad_w);
+      }
     }
-    __syncthreads();
+    lds_barrier();
+    FS_TICKW(4);
+    FS_TICKF(4);       // masks
     // the masks stay in LDS (written again two barriers into the next call) and are fetched word by word
     auto Bw = [&](int q, int ww) -> ull { return L.rmask[q][ww]; };
     // lanes of path p / of the pair p joins first / of the four paths that share p's lane after both joins
@@ -230,13 +374,9 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
     };
     // vehicles on "my lane" of those ahead, word ww: see k_steps_open (M5 / M8); a vehicle that has passed j joins
     // shares my lane if our paths agree after max(j, la) joins
-    auto cand_w = [&](int p, int la_, int ww) -> ull {
-      const ull R1 = L.rmask[P][ww], R2 = L.rmask[P + 1][ww], G2 = quadw(p, ww);
-      const ull pr = pairw(p, ww);
-      const ull c0 = la_ == 0 ? pathw(p, ww) : (la_ == 1 ? pr : G2);
-      const ull c1 = la_ <= 1 ? pr : G2;
-      return (~R1 & c0) | (R1 & ~R2 & c1) | (R2 & G2);
-    };
+    // (M5 / M8, see k_steps_open: (~R1 & c0) | (R1 & ~R2 & c1) | (R2 & quad) with c0 / c1 by look-ahead region -- combined
+    // once per wave word when the masks were published, so a search reads one word per wave instead of ten)
+    auto cand_w = [&](int p, int la_, int ww) -> ull { return L.comb[(p & (P - 1)) * 3 + la_][ww]; };
     const int rw = rank >> 6, rb = rank & 63;
     auto above_w = [&](int ww) -> ull { return ww < rw ? 0ull : (ww > rw ? ~0ull : (rb == 63 ? 0ull : (~0ull << (rb + 1)))); };
     auto below_w = [&](int ww) -> ull { return ww < rw ? ~0ull : (ww > rw ? 0ull : ((1ull << rb) - 1ull)); };
@@ -304,6 +444,8 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
       lc_want = best_path;
       lc_gain = best_path >= 0 ? best_gain : T(0);
     }
+    FS_TICKW(5);
+    FS_TICKF(5);       // leader search
     // publish what the follower rule and the crash check read of OTHER slots
     L.lead[tid] = lead;
     L.h[tid] = h;
@@ -314,7 +456,7 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
       const ull cw = __ballot(alive && has && lead_same_lane && (h < s.crash_gap));
       if (l == 0) L.words[b1][0][w] = cw;
     }
-    __syncthreads();
+    lds_barrier();
     ull call = 0ull;
 #pragma unroll
     for (int ww = 0; ww < W; ++ww) call |= L.words[b1][0][ww];
@@ -348,8 +490,8 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
       foll_h = better ? bestf : start_h;
     }
   };
-  // get_outflow_rate over the last `window` sub-steps (vehicle/traci.py:500-505): inside each wave, on its copy
-  auto outflow = [&](int window) -> T {
+  // get_outflow_rate over the last `window` sub-steps (vehicle/traci.py:500-505): `total_i` arrivals in the window
+  auto window_sum = [&](int window) -> int {             // the ring walked once (launch start; the sub-steps keep sums)
     const int n = tcount < window ? tcount : window;
     const int newest = (((tcount - 1) % 20) + 20) % 20;  // entry of the last sub-step; entry q is (newest - q) mod 20 old
     int total_i = 0;
@@ -358,6 +500,10 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
       ago += ago < 0 ? 20 : 0;
       total_i += (ago < n) ? L.hist[q] : 0;
     }
+    return total_i;
+  };
+  auto outflow = [&](int window, int total_i) -> T {
+    const int n = tcount < window ? tcount : window;
     const T total = T(total_i);                           // small integers: the float sum of k_steps_open is exact
     const T rate = (T(3600) * total) / (T(n > 0 ? n : 1) * dt);
     return n > 0 ? rate : T(0);
@@ -376,38 +522,71 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
     // ... then every vehicle enters itself in its cell's membership words (one LDS atomic per vehicle instead of two
     // ballots per cell; the words were cleared by their owner after the previous observation)
     const int C = o.n_obs_cells;
-    if (ocell >= 0) atomicOr(&L.cell[is_rl ? 1 : 0][ocell][w], 1ull << l);
-    __syncthreads();
-    // cell c is collected by lane c / W of wave c % W: the sequential gathers of the W waves run side by side
+    FS_TICKF(6);       // tail of the update (crash word, followers) + the cell lookup
+    const int cls = is_rl ? 1 : 0;
+    if (ocell >= 0) atomicOr(&L.cell[cls][ocell][w], 1ull << l);
+    lds_barrier();
+    // ... and writes its speed at its place in the cell's member list: the place is its ordinal among the members of its
+    // class in slot order (members in lower waves' words + lower lanes of its own word), so the list holds the speeds in
+    // the order the reference adds them (its loop over the ids) and the cell's owner reads them back four per LDS read
+    // instead of walking the masks with one dependent LDS read per member (28 % of C4's step)
+    if (ocell >= 0) {
+      int k = 0;
+#pragma unroll
+      for (int ww = 0; ww < W; ++ww) {
+        const ull word = L.cell[cls][ocell][ww];
+        k += ww < w ? __popcll(word) : (ww == w ? __popcll(word & ((1ull << l) - 1ull)) : 0);
+      }
+      if (k < WideLds<T, W>::CELL_CAP) L.cellv[cls][ocell][k] = v;
+    }
+    lds_barrier();
+    // cell c is collected by lane c / W of wave c % W: the W waves' collections run side by side
     const int my_cell = l * W + w;
     if (my_cell < C) {
       int cnt_h = 0, cnt_r = 0;
       T sp_h = T(0), sp_r = T(0);
+      ull mh[W], mr[W];
 #pragma unroll
       for (int ww = 0; ww < W; ++ww) {
-        ull mh = L.cell[0][my_cell][ww], mr = L.cell[1][my_cell][ww];
+        mh[ww] = L.cell[0][my_cell][ww];
+        mr[ww] = L.cell[1][my_cell][ww];
         L.cell[0][my_cell][ww] = 0ull;                  // (the next entries come several barriers later)
         L.cell[1][my_cell][ww] = 0ull;
-        cnt_h += __popcll(mh);
-        cnt_r += __popcll(mr);
-        while (mh != 0ull) {
-          sp_h = sp_h + L.v[ww * 64 + first_bit(mh)];
-          mh &= mh - 1ull;
+        cnt_h += __popcll(mh[ww]);
+        cnt_r += __popcll(mr[ww]);
+      }
+      constexpr int CAP = WideLds<T, W>::CELL_CAP;
+      auto list_sum = [&](int which, int cnt) -> T {
+        T sp = T(0);
+        for (int k0 = 0; k0 < cnt; k0 += 4) {
+          const CellQuad<T> q = *reinterpret_cast<const CellQuad<T>*>(&L.cellv[which][my_cell][k0]);
+          sp = sp + q.a;
+          if (k0 + 1 < cnt) sp = sp + q.b;
+          if (k0 + 2 < cnt) sp = sp + q.c;
+          if (k0 + 3 < cnt) sp = sp + q.d;
         }
-        while (mr != 0ull) {
-          sp_r = sp_r + L.v[ww * 64 + first_bit(mr)];
-          mr &= mr - 1ull;
+        return sp;
+      };
+      if (cnt_h <= CAP && cnt_r <= CAP) {
+        sp_h = list_sum(0, cnt_h);
+        sp_r = list_sum(1, cnt_r);
+      } else {
+        // a cell with more members than a list holds: the walk over the membership masks, in slot order
+#pragma unroll
+        for (int ww = 0; ww < W; ++ww) {
+          for (ull m = mh[ww]; m != 0ull; m &= m - 1ull) sp_h = sp_h + L.v[ww * 64 + first_bit(m)];
+          for (ull m = mr[ww]; m != 0ull; m &= m - 1ull) sp_r = sp_r + L.v[ww * 64 + first_bit(m)];
         }
       }
-      const T nh = T(cnt_h) / T(20), nr = T(cnt_r) / T(20);          // NUM_VEHICLE_NORM
-      const T mean_h = (cnt_h > 0 ? sp_h / (nh * T(20)) : T(0)) / T(50);
-      const T mean_r = (cnt_r > 0 ? sp_r / (nr * T(20)) : T(0)) / T(50);
+      const T nh = div_out(T(cnt_h), 20.0), nr = div_out(T(cnt_r), 20.0);          // NUM_VEHICLE_NORM
+      const T mean_h = div_out(cnt_h > 0 ? sp_h / (nh * T(20)) : T(0), 50.0);
+      const T mean_r = div_out(cnt_r > 0 ? sp_r / (nr * T(20)) : T(0), 50.0);
       orow[my_cell] = float(nh);
       orow[C + my_cell] = float(nr);
       orow[2 * C + my_cell] = float(mean_h);
       orow[3 * C + my_cell] = float(mean_r);
     }
-    const T of = outflow(o.obs_window) / T(2000.0);
+    const T of = div_out(outflow(o.obs_window, out_obs), 2000.0);
     if (tid == 64) orow[4 * C] = float(of);            // (each single-lane store costs its wave ~0.5 us: one per wave)
     // (the next write of the cell words is a whole sub-step, i.e. several barriers, away)
   };
@@ -418,12 +597,19 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
     }
   };
 
+  // the actions of a step are read from global memory one step early (by the threads that own a column) and handed
+  // over through LDS: the barriers of the neighbour update in between make them visible, no thread waits for HBM
+  if (actions != nullptr && num_steps > 0 && tid < s.num_rl) L.act[0][tid] = actions[size_t(rr) * s.num_rl + tid];
   bool crash_now = false;
-  neighbours(false, false, crash_now);
+  int na_unused = 0;
+  neighbours(false, false, crash_now, false, false, na_unused);
+  out_obs = window_sum(o.obs_window);       // (L.hist was loaded before the barriers of the update above)
+  out_rew = window_sum(o.rew_window);
+  FS_TICKW(7);
 
   if (num_steps == 0) {
     if (after_reset) {
-      neighbours(live_replica, track_foll, crash_now);
+      neighbours(live_replica, track_foll, crash_now, false, false, na_unused);
       if (slot_ok && live_replica) {
         o.foll[idx] = foll;
         o.foll_h[idx] = foll_h;
@@ -435,7 +621,10 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
   }
 
   for (int step = 0; step < num_steps; ++step) {
-    const float* act = actions ? actions + size_t(step) * act_stride + size_t(rr) * s.num_rl : nullptr;
+    const bool have_act = actions != nullptr;
+    const int ab = step & 1;                 // (L.act[ab]: this step's actions)
+    if (actions != nullptr && step + 1 < num_steps && tid < s.num_rl)
+      L.act[(step + 1) & 1][tid] = actions[size_t(step + 1) * act_stride + size_t(rr) * s.num_rl + tid];
     bool crashed = false;
     for (int sub = 0; sub < s.sims_per_step; ++sub) {
       const bool live = live_replica && !crashed;
@@ -456,7 +645,7 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
           L.red_i[bm][0][w] = na_w;
           L.red_t[bm][0][w] = sv_w;
         }
-        __syncthreads();
+        lds_barrier();
         int n_alive = 0;
         T part[W];
 #pragma unroll
@@ -472,48 +661,55 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
       const bool internal = cur.internal(o, 0);
       const int seg_k = cur.k;
       const bool on_edge = s.junction_mode ? !internal : true;
+      // (the lane-drop heads hand no acceleration to an RL vehicle: with SUMO-driven humans -- every shipped bottleneck
+      // experiment -- no vehicle is commanded and S4-S8's command path is dead: block-uniform skip)
+      const bool any_cmd = !(flags & FLAG_NO_FLOW_CTRL);
       bool commanded = false;
-      T acc = control_accel_on<T, CSET>(s, sl, flags, v, vl, h, has, vf, hf, mean_v, on_edge, false, T(0), live && slot_ok,
-                               rr, ii, nctr, cst, commanded);
+      T acc = T(0);
+      if (any_cmd)
+        acc = control_accel_on<T, CSET>(s, sl, flags, v, vl, h, has, vf, hf, mean_v, on_edge, false, T(0), live && slot_ok,
+                                        rr, ii, nctr, cst, commanded);
+      FS_TICKW(6);      // (section 6 = tail of neighbours + controllers)
       // ---- O6: BottleneckDesiredVelocityEnv._apply_rl_actions (bottleneck.py:926-969) -------------------
-      if (dv_env && act != nullptr) {
+      if (dv_env && have_act) {
         const int my_lane = (route < 0 ? 0 : route) >> shift_of(x);
         const int acell = cell_of<1>(tb, o.act_span, x, seg_k, my_lane, alive && !internal);
-        T a = acell >= 0 ? T(act[acell]) : T(0);
+        T a = acell >= 0 ? T(L.act[ab][acell & 63]) : T(0);
         if (s.clip_actions) a = tmin(tmax(a, s.act_lo), s.act_hi);
         T nxt = tmin(tmax(vmax + a, T(0.01)), T(23.0));
         nxt = acell >= 0 ? nxt : T(23.0);
         if (live && alive && is_rl) vmax = nxt;
       }
       // ---- M7: apply_acceleration + SUMO integration ---------------------------------------------------
-      T next_vel = tmax(v + acc * dt, T(0));
-      T vc = v + (next_vel - v) * s.ramp;
       Slot<T> sm = sl;
       sm.sumo_max_speed = tmin(vmax, o.speed_limit);     // M10
       T v_sumo = sumo_idm_speed(v, vl, h, has, dt, sm);
-      if (sl.speed_mode & 1) vc = tmin(vc, v_sumo);
-      if (sl.speed_mode & 2) vc = tmin(vc, v + sl.max_accel * dt);
-      if (sl.speed_mode & 4) vc = tmax(vc, v - sl.max_decel * dt);
-      T v_new = commanded ? vc : v_sumo;
+      T v_new = v_sumo;
+      if (any_cmd) {
+        T next_vel = tmax(v + acc * dt, T(0));
+        T vc = v + (next_vel - v) * s.ramp;
+        if (sl.speed_mode & 1) vc = tmin(vc, v_sumo);
+        if (sl.speed_mode & 2) vc = tmin(vc, v + sl.max_accel * dt);
+        if (sl.speed_mode & 4) vc = tmax(vc, v - sl.max_decel * dt);
+        v_new = commanded ? vc : v_sumo;
+      }
       T x_new = (s.integrator == FS_BALLISTIC) ? x + (v + v_new) / T(2) * dt : x + v_new * dt;
       const bool mv = live && alive;
       const bool arrived = mv && (x_new >= o.end_x);
-      // ---- one publication for M11's arbitration (largest gain, lowest slot on a tie) and the arrival count ----
-      {
+      // ---- M11's arbitration (largest gain, lowest slot on a tie): one publication, only with lane changing on ----
+      if (lc_on) {
         const int bq = phase & 1;
         phase += 1;
-        const bool want = lc_on && lc_want >= 0 && alive && live;
+        const bool want = lc_want >= 0 && alive && live;
         const T gsel = want ? lc_gain : -BIGV;
         const T gmax_w = seg_max<64>(gsel);
         const ull wb = __ballot(want && gsel == gmax_w);
-        const int na_w = __popcll(__ballot(arrived));
         if (l == 0) {
           L.red_t[bq][0][w] = gmax_w;
           L.red_i[bq][0][w] = wb ? w * 64 + first_bit(wb) : -1;
-          L.red_i[bq][1][w] = na_w;
         }
-        __syncthreads();
-        int win = -1, na = 0;
+        lds_barrier();
+        int win = -1;
         T gbest = -BIGV;
 #pragma unroll
         for (int ww = 0; ww < W; ++ww) {
@@ -523,32 +719,30 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
             win = cw;
             gbest = gw;
           }
-          na += L.red_i[bq][1][ww];
         }
-        if (lc_on && slot_ok && ii == win) {
+        if (slot_ok && ii == win) {
           route = lc_want;
           last_lc = tcount + 1;
         }
-        if (mv) {
-          prev_v = v;
-          last_acc = acc;
-          x = x_new;
-          v = v_new;
-        }
-        if (mv) cur.follow(o, tb, 0, x);
-        if (live) {
-          tcount += 1;
-          nctr += 1u;
-          sim_steps += 1;
-        }
-        // ---- M4: arrivals -----------------------------------------------------------------------------
-        if (live) arrived_rl = (arrived && is_rl) ? 1 : 0;
-        if (arrived) route = -1;
-        just_arrived = arrived;
-        if (live) { n_arr = na; n_dep = 0; }
-        tot_arr += na;
-        if (live && tid == 0) L.hist[(tcount - 1) % 20] = na;   // read after the next barriers (outflow)
       }
+      if (mv) {
+        prev_v = v;
+        last_acc = acc;
+        x = x_new;
+        v = v_new;
+      }
+      if (mv) cur.follow(o, tb, 0, x);
+      if (live) {
+        tcount += 1;
+        nctr += 1u;
+        sim_steps += 1;
+      }
+      // ---- M4: arrivals (counted through the first barrier of the neighbour update below) ----------------
+      if (live) arrived_rl = (arrived && is_rl) ? 1 : 0;
+      if (arrived) route = -1;
+      just_arrived = arrived;
+      if (live) n_dep = 0;
+      FS_TICKW(1);      // (section 1 = actions + integration + arbitration + move)
       // ---- M2 / M3: insertions in InFlows order -------------------------------------------------------
       const double now = double(sim_steps - 1) * o.dt_d;
       if (prob_any) {                                    // block-uniform
@@ -559,16 +753,26 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
           if ((now >= my_begin) && (now <= my_end) && (my_number < 0 || gl < my_number) && (c0 < my_thr))
             L.generated[tid] = gl + 1;
         }
-        __syncthreads();
+        lds_barrier();
       }
-      for (int f = 0; f < o.n_inflows; ++f) {
+      // `next_due` (block-uniform): the earliest time an inflow has to be looked at again; a schedule that lies ahead
+      // skips the loop and its table reads -- most sub-steps (probabilistic inflows: always looked at)
+      const bool look = live && (prob_any || next_due <= now);
+      double nd = 1.0e300;
+      bool nd_consumed = false;
+      for (int f = 0; look && f < o.n_inflows; ++f) {
         const int k = L.emitted[f];
         const double per_f = tb.template fd<0>(f);
         const bool prob_f = per_f < 0.0;
-        const double due_t = tb.template fd<1>(f) + double(k) * per_f;
+        const double begin_f = tb.template fd<1>(f), end_f = tb.template fd<2>(f);
+        const double due_t = begin_f + double(k) * per_f;
         const int number = tb.template fi<2>(f);
-        const bool due = prob_f ? (k < L.generated[f])
-                                : (due_t <= now) && (due_t <= tb.template fd<2>(f)) && (number < 0 || k < number);
+        const bool open_f = prob_f || ((due_t <= end_f) && (number < 0 || k < number));
+        const bool due = prob_f ? (k < L.generated[f]) : (due_t <= now) && open_f;
+        {
+          const double mine = prob_f ? -1.0e300 : (open_f ? due_t : 1.0e300);
+          nd = mine < nd ? mine : nd;
+        }
         if (!(due && live)) continue;                    // block-uniform
         const int typ = tb.template fi<0>(f);
         int route_f = tb.template fi<1>(f);
@@ -602,7 +806,7 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
             L.red_t[bi][2][w] = vlead_w;
           }
         }
-        __syncthreads();
+        lds_barrier();
         int slot = -1;
         bool has_lead = false;
         T xm = BIGV, back_j = T(0), v_lead = T(0);
@@ -643,15 +847,24 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
           seq_ctr += 1;
           n_dep += 1;
           tot_dep += 1;
+#pragma unroll
+          for (int q = 0; q < FS_MAX_INFLOWS; ++q) new_slot[q] = (q == n_new) ? slot : new_slot[q];
+          n_new += 1;
         }
         // M9: a random-lane vehicle that does not fit when it is due is dropped, not retried
         const bool consumed = ok || random_lane;
         if (consumed && tid == 0) L.emitted[f] = k + 1;    // every thread read k before this iteration's barrier
         if (consumed && !ok) tot_drop += 1;
+        nd_consumed = nd_consumed || consumed;
       }
+      if (look) next_due = nd_consumed ? -1.0e300 : nd;     // (after an insertion the schedule is simply looked at again)
+      FS_TICKW(2);
       // ---- O1: new neighbour snapshot, sticky followers, collision check --------------------------------
       bool c = false;
-      neighbours(live, track_foll, c);
+      int na = 0;
+      neighbours(live, track_foll, c, arrived, live, na);
+      if (live) n_arr = na;
+      tot_arr += na;
       crashed = crashed || (c && live);
     }
 
@@ -659,7 +872,7 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
     const bool emit = obs_every_step || (step == num_steps - 1);
     if (emit) {
       write_obs();
-      const T reward = outflow(o.rew_window) / o.out_norm;       // bottleneck.py:474-478, 971-981
+      const T reward = outflow(o.rew_window, out_rew) / o.out_norm;       // bottleneck.py:474-478, 971-981
       if (tid == 64 * (W - 1)) {
         *rrow = float(reward);
         *drow = done_flag(tcount >= s.step_limit, crashed);
@@ -668,6 +881,8 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
       rrow += step_rows;
       drow += step_rows;
     }
+    FS_TICKW(7);
+    FS_TICKF(7);       // cell collection, divisions, stores, reward
   }
 
   if (slot_ok && live_replica) {
@@ -698,9 +913,14 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
       cnt[CNT_TOTAL_ARRIVED] = tot_arr;
       cnt[CNT_TOTAL_DEPARTED] = tot_dep;
       cnt[CNT_TOTAL_DROPPED] = tot_drop;
+#ifdef FS_PHASE_TIMERS
+      for (int q = 0; q < 8; ++q) cnt[q] = int(ph_t[q] >> 6);
+#endif
     }
   }
-  __syncthreads();
+#undef FS_TICKW
+#undef FS_TICKF
+  lds_barrier();
   if (live_replica && tid < FS_MAX_INFLOWS) {
     o.emitted[size_t(rr) * FS_MAX_INFLOWS + tid] = L.emitted[tid];
     o.generated[size_t(rr) * FS_MAX_INFLOWS + tid] = L.generated[tid];

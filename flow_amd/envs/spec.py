@@ -348,7 +348,10 @@ def build_spec(env, num_replicas, rng=None):
         action_high=float(space.high[0]) if N and veh_k.num_rl_vehicles else 0.0,
         clip_actions=bool(ep.clip_actions), evaluate=bool(ep.evaluate),
         po_max_length=float(env._po_max_length()), horizon=ep.horizon, warmup_steps=int(ep.warmup_steps),
-        sims_per_step=int(ep.sims_per_step), seed=handle_seed(sp), track_aux=bool(getattr(env, "_track_aux", True)),
+        sims_per_step=int(ep.sims_per_step), seed=handle_seed(sp),
+        # (FS_MIXED keeps no previous-speed / acceleration fields: a scalar Env with precision='mixed' steps without
+        # them -- k.vehicle.get_previous_speed / get_accel then report the values of the last reset)
+        track_aux=bool(getattr(env, "_track_aux", True)) and getattr(sp, "precision", "f32") != "mixed",
         replica_offset=int(getattr(env, "_replica_offset", 0)),
         num_lanes=num_lanes, init_lane=lanes,
         lane_change_duration=float(ep.additional_params.get("lane_change_duration", 0)),

@@ -94,7 +94,19 @@ class VecFlowEnv(object):
             return
         lengths = self.sim.get_state(L.FS_FIELD_RING_LENGTH).astype(np.float64)
         init = self.sim.get_state(L.FS_FIELD_INIT_POS).astype(np.float64)
-        draw = self._rng.integers(lo, hi + 1, idx.size)            # random.randint(lo, hi) per replica
+        self._draw_placements(idx, lengths, init)
+        self.sim.set_state(L.FS_FIELD_RING_LENGTH, lengths)
+        self.sim.set_state(L.FS_FIELD_INIT_POS, init)
+
+    def _draw_placements(self, idx, lengths, init):
+        """random.randint(lo, hi) per replica in ``idx``; InitialConfig(bunching=50, min_gap=0) placement for the drawn
+        length (once per distinct length), written into ``lengths`` / ``init``."""
+        import numpy as np
+        from flow_amd.core.kernel.network import NetworkKernel
+        from flow_amd.core.params import InitialConfig, NetParams
+        from flow_amd.envs.spec import check_placement, initial_positions
+        lo, hi = self.env.env_params.additional_params['ring_length']
+        draw = self._rng.integers(lo, hi + 1, idx.size)
         veh_len = np.array([v["length"] for v in self.env._spec["vehicles"]])
         ic = InitialConfig(bunching=50, min_gap=0)
         for length in np.unique(draw):
@@ -110,7 +122,20 @@ class VecFlowEnv(object):
             sel = idx[draw == length]
             lengths[sel] = float(length)
             init[sel] = self._placement_cache[length][None, :]
-        self.sim.set_state(L.FS_FIELD_RING_LENGTH, lengths)
+
+    def redraw_ring_lengths(self):
+        """Give EVERY replica a fresh pending ring length and start placement for its NEXT reset without touching the
+        episode it is in (FS_FIELD_INIT_RING_LENGTH / FS_FIELD_INIT_POS): call between replays of a fragment captured
+        with ``reset_done=True``, so that the resets inside the graph redraw the length per episode as
+        WaveAttenuationEnv.reset does (flow/envs/ring/wave_attenuation.py:157-210).  Host-side draw + two uploads; the
+        uploads synchronise the handle's stream."""
+        import numpy as np
+        if not self._resample:
+            return
+        lengths = self.sim.get_state(L.FS_FIELD_INIT_RING_LENGTH).astype(np.float64)
+        init = self.sim.get_state(L.FS_FIELD_INIT_POS).astype(np.float64)
+        self._draw_placements(np.arange(self.num_envs), lengths, init)
+        self.sim.set_state(L.FS_FIELD_INIT_RING_LENGTH, lengths)
         self.sim.set_state(L.FS_FIELD_INIT_POS, init)
 
     def reset(self, mask=None):

@@ -263,7 +263,7 @@ class FlowSim:
             return (self.R, 8), np.int32
         if field == L.FS_FIELD_MAX_SPEED:
             return (self.R, self.N), self.real
-        if field == L.FS_FIELD_RING_LENGTH:
+        if field in (L.FS_FIELD_RING_LENGTH, L.FS_FIELD_INIT_RING_LENGTH):
             return (self.R,), self.real
         return (self.R, self.N), self.real
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FS_ABI_VERSION 6
+#define FS_ABI_VERSION 7
 
 /* ---- error codes -------------------------------------------------------- */
 #define FS_OK 0
@@ -127,7 +127,12 @@ enum fs_field {
                               departed total, random-lane vehicles dropped at insertion}  (get_num_arrived /
                               get_outflow_rate inputs, vehicle/traci.py:493-533) */
   FS_FIELD_ARRIVED_RL = 20,/* int32[R,N] 1: the RL vehicle of this slot arrived in the last sub-step (get_arrived_rl_ids) */
-  FS_FIELD_MAX_SPEED = 21  /* real[R,N]  get_max_speed / set_max_speed: maxSpeed of the SUMO car-following model */
+  FS_FIELD_MAX_SPEED = 21, /* real[R,N]  get_max_speed / set_max_speed: maxSpeed of the SUMO car-following model */
+  FS_FIELD_INIT_RING_LENGTH = 22 /* real[R] the ring length a replica takes at its NEXT reset (WaveAttenuationEnv.reset
+                              draws a new length per episode, flow/envs/ring/wave_attenuation.py:157-210): fs_reset[_dev]
+                              copies it into FS_FIELD_RING_LENGTH for the replicas it resets, so a reset inside a
+                              captured graph can change the length without touching replicas that are mid-episode.
+                              Writing FS_FIELD_RING_LENGTH sets both. */
 };
 
 #define FS_MAX_CTRL_PARAMS 8

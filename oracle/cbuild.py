@@ -7,16 +7,18 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csim", "refsim.c")
+SRC_RL = os.path.join(HERE, "csim", "refsim_rl.c")
 HDR = os.path.join(HERE, "csim", "refsim_body.h")
 LIB = os.path.join(HERE, "csim", "librefsim.so")
 
 
 def build(force=False):
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(SRC),
+                                                                         os.path.getmtime(SRC_RL),
                                                                          os.path.getmtime(HDR)):
         return LIB
     cmd = ["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-shared", "-fPIC",
-           "-o", LIB + ".tmp", SRC, "-lm"]
+           "-o", LIB + ".tmp", SRC, SRC_RL, "-lm"]
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
     return LIB
@@ -146,6 +148,89 @@ class CRingIDMMixed:
            self.x.ctypes.data, self.v.ctypes.data, self.tc.ctypes.data, obs.ctypes.data, rew.ctypes.data,
            done.ctypes.data, int(obs_every_step), self.threads, None if self.sm is None else self.sm.ctypes.data)
         return obs, rew, done.astype(bool)
+
+
+class CRingRLMixed:
+    """C twin of the FS_MIXED form of k_ring_pair (flow_amd/csrc/flowsim_ringrl.h): rings of IDMControllers and
+    RLControllers, AccelEnv (env 0) or WaveAttenuationPOEnv (env 2) head: refsim_ring_rl_mixed in csim/refsim_rl.c."""
+
+    def __init__(self, spec):
+        self.lib = load()
+        self.R, self.N = int(spec["num_replicas"]), int(spec["num_vehicles"])
+        veh = spec["vehicles"]
+        for v in veh:
+            assert v["controller"] in (1, 2) and v.get("fail_safe", 0) == 0 and not (v.get("noise", 0) > 0 and v["controller"] == 2)
+        assert spec.get("env", 0) in (0, 2) and not spec.get("junction_mode", 0)
+        assert spec.get("sims_per_step", 1) == 1 and spec.get("integrator", "euler") == "euler"
+        self.head = 1 if spec.get("env", 0) == 2 else 0
+        self.ctrl = np.ascontiguousarray(np.array([v["controller"] for v in veh], np.int32))
+        self.rl_index = np.ascontiguousarray(np.array([v.get("rl_index", -1) for v in veh], np.int32))
+        self.num_rl = int(spec.get("num_rl", 0))
+        self.sm = np.ascontiguousarray(np.array(
+            [[float(int(v.get("speed_mode", 0)) & 7), v.get("sumo_tau", 1.0), v.get("sumo_min_gap", 2.5),
+              v.get("sumo_max_speed", 30.0), v.get("max_accel", 2.6), v.get("max_decel", 4.5)] for v in veh], np.float64).T)
+        # FLAG_NEED_SUMO of the handle (flowsim_sim.h): an RL slot, or a speed-mode clamp
+        self.need_sumo = int(any(v["controller"] == 1 or (int(v.get("speed_mode", 0)) & 7) for v in veh))
+        self.p = np.ascontiguousarray(np.array([list(v["p"][:6]) for v in veh], np.float64).T)
+        self.veh_len = np.ascontiguousarray(np.array([v.get("length", 5.0) for v in veh], np.float64))
+        self.dt = float(spec["sim_step"])
+        self.ramp = float(spec.get("slowdown_ramp", self.dt / (self.dt + 1e-3)))
+        self.jlen = float(spec.get("junction_length", 0.1))
+        self.ring_len = np.ascontiguousarray(np.broadcast_to(np.asarray(spec["ring_length"], np.float64), (self.R,)).copy())
+        self.max_speed, self.target_v = float(spec["max_speed"]), float(spec["target_velocity"])
+        self.max_cost = float(np.linalg.norm(np.array([spec["target_velocity"]] * self.N, dtype=np.float64)))
+        self.po_max_length = float(spec.get("po_max_length", 1.0) or 1.0)
+        self.clip = int(bool(spec.get("clip_actions", True)))
+        self.act_lo, self.act_hi = float(spec.get("action_low", -1.0)), float(spec.get("action_high", 1.0))
+        self.crash_gap = float(spec.get("crash_gap", 0.0))
+        hz = spec.get("horizon", float("inf"))
+        self.warmup = int(spec.get("warmup_steps", 0))
+        self.step_limit = 2**31 - 1 if hz == float("inf") else int(self.warmup + hz)
+        self.init_pos = np.asarray(spec["init_pos"], np.float64).reshape(self.R, self.N)
+        iv = spec.get("init_vel")
+        self.init_vel = np.zeros((self.R, self.N)) if iv is None else np.asarray(iv, np.float64).reshape(self.R, self.N)
+        self.obs_dim = 3 if self.head == 1 else 2 * self.N
+        self.x = np.ascontiguousarray(self.init_pos.copy())
+        self.v = np.ascontiguousarray(self.init_vel.copy())
+        self.tc = np.zeros(self.R, dtype=np.int32)
+
+    def _call(self, steps, actions, mask, obs_every_step):
+        K = steps if (obs_every_step and steps > 0) else 1
+        obs = np.zeros((K, self.R, self.obs_dim), np.float32)
+        rew = np.zeros((K, self.R), np.float32)
+        done = np.zeros((K, self.R), np.uint8)
+        stride = 0
+        if actions is not None:
+            actions = np.ascontiguousarray(actions, np.float32)
+            if actions.ndim == 3:
+                stride = self.R * self.num_rl
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, np.uint8)
+        fn = self.lib.refsim_ring_rl_mixed
+        d, vp, ci = C.c_double, C.c_void_p, C.c_int
+        fn.restype = None
+        fn.argtypes = [ci, ci, ci, vp, d, d, d, vp, vp, vp, vp, vp, ci, ci, d, d, ci, d, d, d, d, ci, d, ci, vp, vp, vp,
+                       vp, vp, C.c_size_t, vp, vp, vp, ci]
+        fn(self.R, self.N, int(steps), self.ring_len.ctypes.data, self.jlen, self.dt, self.ramp, self.ctrl.ctypes.data,
+           self.rl_index.ctypes.data, self.p.ctypes.data, self.veh_len.ctypes.data, self.sm.ctypes.data, self.need_sumo,
+           self.clip, self.act_lo, self.act_hi, self.head, self.max_speed, self.target_v, self.max_cost,
+           self.po_max_length, self.num_rl, self.crash_gap, self.step_limit, self.x.ctypes.data, self.v.ctypes.data,
+           self.tc.ctypes.data, None if mask is None else mask.ctypes.data,
+           None if actions is None else actions.ctypes.data, stride, obs.ctypes.data, rew.ctypes.data,
+           done.ctypes.data, int(obs_every_step))
+        return obs, rew, done
+
+    def reset(self, mask=None):
+        """Env.reset of the masked replicas: placement, then the warm-up steps with rl_actions = None."""
+        sel = np.ones(self.R, bool) if mask is None else np.asarray(mask).astype(bool)
+        self.x[sel] = self.init_pos[sel]
+        self.v[sel] = self.init_vel[sel]
+        self.tc[sel] = 0
+        obs, _, _ = self._call(self.warmup, None, None if mask is None else sel.astype(np.uint8), False)
+        return obs[0]
+
+    def rollout(self, steps, actions=None, obs_every_step=True):
+        return self._call(steps, actions, None, obs_every_step)
 
 
 def div_via_f64_mismatches(c, bits_lo, bits_hi, threads=8):

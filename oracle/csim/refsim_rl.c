@@ -1,0 +1,199 @@
+/* refsim_rl.c -- C twin of the FS_MIXED form of k_ring_pair (flow_amd/csrc/flowsim_ringrl.h, T = double): single-lane
+ * rings of IDMControllers and RLControllers, AccelEnv or WaveAttenuationPOEnv head (TEST INFRASTRUCTURE ONLY).
+ *
+ * Positions and speeds are float64 and integrated in float64; the controllers run in float32 on their rounded images;
+ * observations are state * RN64(1/normaliser) rounded to float32; rewards are float32 on the rounded speeds.  Reference
+ * lines restated (as oracle/refsim.py, which is the float64 statement of the same rules):
+ *   IDMController.get_accel            flow/controllers/car_following_models.py:464-482
+ *   RLController / apply_rl_actions    flow/controllers/rlcontroller.py:6-39, flow/envs/base.py:566-615
+ *   apply_acceleration                 flow/core/kernel/vehicle/traci.py:952-963
+ *   speed modes / uncommanded vehicles S5-S8 of DESIGN.md (SUMO side, unpinned)
+ *   AccelEnv.get_state / reward        flow/envs/ring/accel.py:109-123, flow/core/rewards.py:6-59
+ *   WaveAttenuationPOEnv               flow/envs/ring/wave_attenuation.py:113-139, 248-269
+ * Every operation below is one IEEE operation of the kernel, in the kernel's order (-ffp-contract=off). */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+
+static float rl_tree_sum(const float* a, int n) {
+  float buf[64];
+  int seg = 1;
+  while (seg < n) seg *= 2;
+  for (int i = 0; i < seg; ++i) buf[i] = i < n ? a[i] : 0.0f;
+  while (seg > 1) {
+    for (int i = 0; i < seg / 2; ++i) buf[i] = buf[2 * i] + buf[2 * i + 1];
+    seg /= 2;
+  }
+  return buf[0];
+}
+
+static double dmax(double a, double b) { return a > b ? a : b; }     /* the kernel's tmax / tmin */
+static double dmin(double a, double b) { return a < b ? a : b; }
+static float fmax_(float a, float b) { return a > b ? a : b; }
+static float fmin_(float a, float b) { return a < b ? a : b; }
+
+/* ctrl[N]: 2 = IDMController, 1 = RLController;  sm[6][N]: speed_mode bits, sumo tau, minGap, maxSpeed, max_accel,
+ * max_decel;  actions: NULL (rl_actions = None: RL vehicles uncommanded) or float[steps, R, num_rl] (stride in floats
+ * between steps; 0 = the same row every step);  mask: NULL or uint8[R] (only these replicas advance).
+ * obs: [K, R, obs_dim] with K = steps (obs_every_step) or 1; steps == 0 writes the observation of the current state. */
+void refsim_ring_rl_mixed(int R, int N, int steps, const double* ring_len, double jlen, double dt, double ramp,
+                          const int32_t* ctrl, const int32_t* rl_index, const double* p, const double* veh_len,
+                          const double* sm, int need_sumo, int clip_actions, double act_lo, double act_hi, int head,
+                          double max_speed, double target_v, double max_cost, double po_max_length, int num_rl,
+                          double crash_gap, int step_limit, double* x, double* v, int32_t* time_counter,
+                          const uint8_t* mask, const float* actions, size_t act_stride, float* obs, float* rew,
+                          uint8_t* done, int obs_every_step) {
+  const float BIG = 3.0e38f;
+  const double rc_ms = 1.0 / max_speed, rc15 = 1.0 / 15.0, rc_pml = 1.0 / po_max_length;
+  const float gap32 = (float)crash_gap, tv32 = (float)target_v, mc32 = (float)max_cost;
+  const float lo32 = (float)act_lo, hi32 = (float)act_hi;
+  const int obs_dim = head == 1 ? 3 : 2 * N;
+  for (int r = 0; r < R; ++r) {
+    double* xr = x + (size_t)r * N;
+    double* vr = v + (size_t)r * N;
+    const double L = ring_len[r] + 4.0 * jlen, rc_L = 1.0 / L;
+    const int live = mask == NULL || mask[r] != 0;
+    int tc = time_counter[r];
+    float hh[64], term[64];
+    double dg[64], xn[64], vn[64];
+    for (int i = 0; i < N; ++i) {                 /* snapshot of the current state */
+      const int j = (i + 1 >= N) ? 0 : i + 1;
+      double d = xr[j] - xr[i];
+      if (d < 0.0) d = d + L;
+      dg[i] = d;
+      hh[i] = (float)(d - veh_len[j]);
+    }
+    for (int s = 0; s <= steps; ++s) {
+      const int emit_only = (steps == 0);
+      if (s == steps && !emit_only) break;
+      int crashed = 0, bad = 0;
+      const float* act = (actions != NULL && !emit_only) ? actions + (size_t)s * act_stride + (size_t)r * num_rl : NULL;
+      if (!emit_only) {
+        for (int i = 0; i < N; ++i) {
+          const int j = (i + 1 >= N) ? 0 : i + 1;
+          const int is_rl = ctrl[i] == 1;
+          const float vi = (float)vr[i], vl = (float)vr[j];
+          float acc;
+          if (!is_rl) {
+            const float v0 = (float)p[0 * N + i], Tt = (float)p[1 * N + i], a = (float)p[2 * N + i],
+                        b = (float)p[3 * N + i], delta = (float)p[4 * N + i], s0 = (float)p[5 * N + i];
+            const float two_sqrt_ab = 2.0f * sqrtf(a * b);
+            const float h = fabsf(hh[i]) < 1e-3f ? 1e-3f : hh[i];
+            const float dyn = vi * Tt + vi * (vi - vl) / two_sqrt_ab;
+            const float s_star = s0 + fmax_(dyn, 0.0f);
+            const float q = s_star / h;
+            const float ratio = vi / v0;
+            float pw;
+            if (delta == 4.0f) { float r2 = ratio * ratio; pw = r2 * r2; }
+            else if (delta == 2.0f) pw = ratio * ratio;
+            else if (delta == 1.0f) pw = ratio;
+            else if (delta == 3.0f) pw = (ratio * ratio) * ratio;
+            else if (delta == 8.0f) { float r2 = ratio * ratio, r4 = r2 * r2; pw = r4 * r4; }
+            else pw = powf(ratio, delta);
+            acc = a * (1.0f - pw - q * q);
+          } else {
+            float a = act != NULL ? act[rl_index[i]] : 0.0f;
+            if (clip_actions) a = fmin_(fmax_(a, lo32), hi32);
+            acc = a;
+          }
+          const int commanded = !is_rl || act != NULL;
+          const double nv = dmax(vr[i] + (double)acc * dt, 0.0);
+          double c = vr[i] + (nv - vr[i]) * ramp;
+          if (need_sumo) {
+            const int mode = (int)sm[0 * N + i];
+            const float tau = (float)sm[1 * N + i], min_gap = (float)sm[2 * N + i], smax = (float)sm[3 * N + i],
+                        ma = (float)sm[4 * N + i], md = (float)sm[5 * N + i];
+            const float gap = fmax_(hh[i], 1e-3f);
+            const float ts = 2.0f * sqrtf(ma * md);
+            const float dyn_s = vi * tau + vi * (vi - vl) / ts;
+            const float ss = min_gap + fmax_(0.0f, dyn_s);
+            const float qs = ss / gap;
+            const float rs = vi / smax;
+            const float rs2 = rs * rs;
+            const float acc_s = ma * (1.0f - rs2 * rs2 - qs * qs);
+            const double floor0 = (mode & 1) ? 0.0 : (double)BIG;
+            const double adt = (mode & 2) ? sm[4 * N + i] * dt : (double)BIG;
+            const double ddt = (mode & 4) ? sm[5 * N + i] * dt : (double)BIG;
+            const double vs = vr[i] + (double)acc_s * dt;
+            c = dmin(c, dmax(vs, floor0));
+            c = dmin(c, vr[i] + adt);
+            c = dmax(c, vr[i] - ddt);
+            if (!commanded) c = dmax(vs, 0.0);
+          }
+          double x_new = xr[i] + c * dt;
+          if (x_new >= L) x_new = x_new - L;
+          xn[i] = x_new;
+          vn[i] = c;
+        }
+        if (live) {
+          for (int i = 0; i < N; ++i) { xr[i] = xn[i]; vr[i] = vn[i]; }
+          tc += 1;
+        }
+        for (int i = 0; i < N; ++i) {
+          const int j = (i + 1 >= N) ? 0 : i + 1;
+          double d = xr[j] - xr[i];
+          if (d < 0.0) d = d + L;
+          dg[i] = d;
+          hh[i] = (float)(d - veh_len[j]);
+          if (hh[i] < gap32) crashed = 1;
+          if ((float)vr[i] < -100.0f) bad = 1;
+        }
+        crashed = crashed && live;
+        if (crashed) bad = 1;
+      }
+      if (emit_only || obs_every_step || s == steps - 1) {
+        const size_t so = (obs_every_step && !emit_only) ? (size_t)s : 0;
+        float* o = obs + (so * R + r) * (size_t)obs_dim;
+        if (head == 1) {
+          for (int i = 0; i < N; ++i) {
+            if (ctrl[i] == 1 && rl_index[i] == 0) {
+              const int j = (i + 1 >= N) ? 0 : i + 1;
+              o[0] = (float)(vr[i] * rc15);
+              o[1] = (float)((vr[j] - vr[i]) * rc15);
+              o[2] = (float)(dg[i] * rc_pml);
+            }
+          }
+        } else {
+          for (int i = 0; i < N; ++i) {
+            o[i] = (float)(vr[i] * rc_ms);
+            o[N + i] = (float)(xr[i] * rc_L);
+          }
+        }
+        if (!emit_only) {
+          float rw;
+          if (head == 1) {
+            for (int i = 0; i < N; ++i) term[i] = (float)vr[i];
+            const float sv = rl_tree_sum(term, N);
+            for (int i = 0; i < N; ++i) {
+              float a = 0.0f;
+              if (i < num_rl && act != NULL) {
+                a = act[i];
+                if (clip_actions) a = fmin_(fmax_(a, lo32), hi32);
+                a = fabsf(a);
+              }
+              term[i] = a;
+            }
+            const float sa = rl_tree_sum(term, N);
+            const float mean_v = sv / (float)N, mean_a = sa / (float)num_rl;
+            rw = (4.0f * mean_v) / 20.0f;
+            if (mean_a > 0.0f) rw = rw + 4.0f * (0.0f - mean_a);
+            if (bad) rw = 0.0f;
+            if (act == NULL) rw = 0.0f;
+          } else {
+            for (int i = 0; i < N; ++i) {
+              const float dv = (float)vr[i] - tv32;
+              term[i] = dv * dv;
+            }
+            const float cost = sqrtf(rl_tree_sum(term, N));
+            rw = fmax_(mc32 - cost, 0.0f) / (mc32 + 1.1920928955078125e-07f);
+            if (bad) rw = 0.0f;
+          }
+          rew[so * R + r] = rw;
+          done[so * R + r] = (uint8_t)((tc >= step_limit ? 1 : 0) | (crashed ? 2 : 0));
+        }
+      }
+      if (emit_only) break;
+    }
+    time_counter[r] = tc;
+  }
+}

@@ -17,7 +17,40 @@ SECTIONS = ["controllers", "integration + right of way", "move + arrivals", "inf
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "build":
         from flow_amd import build
-        print(build.build_variant(LIB, ["-DFS_PHASE_TIMERS"], names=["seg64_f32"]))
+        print(build.build_variant(LIB, ["-DFS_PHASE_TIMERS"], names=["seg64_f32", "wide4_f32"]))
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "buildfine":
+        from flow_amd import build
+        print(build.build_variant(LIB.replace("timers", "timers2"), ["-DFS_PHASE_TIMERS=2"], names=["wide4_f32"]))
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] in ("c4", "c4fine"):          # the wide kernel (C4): its own sections
+        import numpy as np
+        import torch
+        import bench
+        import flow_amd.sim as simmod
+        from flow_amd import _lib as L
+        keep = {}
+        real_close = simmod.FlowSim.close
+
+        def close(self):
+            keep["cnt"] = self.get_state(L.FS_FIELD_COUNTERS).astype(np.float64)
+            real_close(self)
+        simmod.FlowSim.close = close
+        res = bench.c4_leg(torch.device("cuda", 0), R=int(sys.argv[2]) if len(sys.argv) > 2 else 128)
+        mean = keep["cnt"].mean(axis=0) * 64.0 / res["env_steps"]
+        names = ["-", "actions + integration + arbitration + move", "inflows", "neighbours: publish + rank",
+                 "neighbours: masks", "neighbours: leader (+ lane-change wishes)", "neighbours tail + controllers",
+                 "observation + reward"]
+        first = 1
+        if sys.argv[1] == "c4fine":
+            names = ["outside the update and the observation", "update: first barrier", "update: old places, barrier, window",
+                     "update: proof, scatter, flag barrier (+ count)", "update: masks", "update: leader search",
+                     "update tail + cell lookup", "cell collection, stores, reward"]
+            first = 0
+        out = {"env_steps_per_s": res["value"], "cycles_per_sub_step (wave 0)": mean[first:].sum()}
+        for q in range(first, 8):
+            out[names[q]] = {"cycles_per_sub_step": mean[q], "share": mean[q] / mean[first:].sum()}
+        print(json.dumps(out, indent=1))
         sys.exit(0)
     assert os.environ.get("FLOWSIM_LIB"), "run with FLOWSIM_LIB=flow_amd/libflowsim_timers.so"
     import numpy as np

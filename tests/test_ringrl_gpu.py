@@ -1,0 +1,212 @@
+"""k_ring_pair (flow_amd/csrc/flowsim_ringrl.h): rings of IDMControllers + RLControllers on the two-vehicles-per-lane
+kernel -- the reference's RL ring experiment (examples/exp_configs/rl/singleagent/singleagent_ring.py:17-65:
+21 x IDMController(noise=0.2) + 1 x RLController, WaveAttenuationPOEnv, ring length 220..270, warm-up steps).
+
+float32: bit-exact against the numpy oracle (no noise) and against the generic kernel k_steps (with noise: the two
+kernels share the hardware's log / cos).  FS_MIXED: bit-exact against its C twin (oracle/csim/refsim_rl.c) and within
+1e-4 of the float64 oracle -- the reference's arithmetic -- after 1500 steps of a fixed action tape."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import idm_vehicle, ring_spec
+from oracle import cbuild
+from oracle import refsim as S
+
+pytestmark = pytest.mark.gpu
+
+
+def make(spec, precision, **env):
+    from flow_amd.sim import FlowSim
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return FlowSim(spec, precision=precision)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def rl_ring_spec(R=9, N=22, n_rl=1, po=True, noise=0.0, speed_mode=25, warmup=0, horizon=400, seed=0, clip=False,
+                 lengths=(220, 270), min_gap=0.0):
+    """The reference's RL ring: N - n_rl IDM humans (minGap 0, default speed mode 'right_of_way' = 25) followed by n_rl RL
+    vehicles; one ring length per replica drawn from `lengths`, InitialConfig(bunching=50) placement for that length."""
+    rng = np.random.default_rng(seed)
+    Ls = rng.integers(lengths[0], lengths[1] + 1, R).astype(np.float64)
+    pos = np.stack([ring_spec(R=1, N=N, length=float(L), bunching=50, junction_length=0.1)["init_pos"][0] for L in Ls])
+    pos = pos + np.abs(rng.normal(0, 0.3, pos.shape))
+    spec = ring_spec(R=R, N=N, length=260.0, bunching=50, junction_length=0.1, horizon=horizon,
+                     env=S.ENV_WAVE_ATTENUATION_PO if po else S.ENV_ACCEL, num_rl=n_rl, action_low=-1.0, action_high=1.0,
+                     po_max_length=float(lengths[1]), warmup_steps=warmup, clip_actions=clip, seed=1234)
+    spec["ring_length"] = Ls
+    spec["init_pos"] = pos
+    veh = [idm_vehicle(sumo_min_gap=min_gap, noise=noise, speed_mode=speed_mode) for _ in range(N - n_rl)]
+    # RL vehicles: rl ids sorted lexicographically give the columns (S2); here simply in slot order
+    veh += [idm_vehicle(controller=S.CTRL_RL, rl_index=k, speed_mode=speed_mode) for k in range(n_rl)]
+    spec["vehicles"] = veh
+    return spec
+
+
+def tape(K, R, n_rl, seed=5, scale=1.3):
+    return np.random.default_rng(seed).uniform(-scale, scale, (K, R, n_rl)).astype(np.float32)
+
+
+def rollout(sim, K, actions, obs_every_step=True):
+    import torch
+    dev = torch.device("cuda", 0)
+    o = torch.zeros((K if obs_every_step else 1, sim.R, sim.obs_dim), device=dev)
+    r = torch.zeros((K if obs_every_step else 1, sim.R), device=dev)
+    d = torch.zeros((K if obs_every_step else 1, sim.R), dtype=torch.uint8, device=dev)
+    a = None if actions is None else torch.as_tensor(actions, device=dev).contiguous()
+    sim.rollout_dev(K, o, r, d, actions=a, action_stride_steps=None if a is None else sim.R * sim.num_rl,
+                    obs_every_step=obs_every_step)
+    sim.sync()
+    return o.cpu().numpy(), r.cpu().numpy(), d.cpu().numpy()
+
+
+@pytest.mark.parametrize("po,n_rl,N,clip", [(True, 1, 22, False), (True, 1, 22, True), (False, 1, 22, True),
+                                              (True, 3, 14, True), (False, 2, 8, False), (True, 1, 40, False)])
+def test_f32_rollout_bit_exact_against_the_oracle(po, n_rl, N, clip):
+    K, R = 120, 7
+    spec = rl_ring_spec(R=R, N=N, n_rl=n_rl, po=po, clip=clip, lengths=(220, 270) if N <= 22 else (420, 470), seed=N)
+    acts = tape(K, R, n_rl, seed=N + 1)
+    sim, ora = make(spec, "f32"), S.RingOracle(spec, np.float32)
+    np.testing.assert_array_equal(sim.reset(), ora.reset().astype(np.float32))
+    o, r, d = rollout(sim, K, acts)
+    assert sim.last_kernel.startswith("k_ring_pair"), sim.last_kernel
+    for k in range(K):
+        o_ref, r_ref, d_ref = ora.step(acts[k])
+        np.testing.assert_array_equal(o[k], o_ref.astype(np.float32), err_msg="obs, step %d" % k)
+        np.testing.assert_array_equal(r[k], r_ref.astype(np.float32), err_msg="reward, step %d" % k)
+        np.testing.assert_array_equal(d[k] != 0, d_ref)
+    np.testing.assert_array_equal(sim.pos, ora.x)
+    np.testing.assert_array_equal(sim.vel, ora.v)
+    np.testing.assert_array_equal(sim.time_counter, ora.time_counter)
+    sim.close()
+
+
+def test_f32_reference_experiment_with_noise_equals_the_generic_kernel():
+    """singleagent_ring as shipped (noise 0.2, speed mode 25, warm-up, ring length per replica): rollout on k_ring_pair
+    == the same handle forced onto the generic kernel, bit for bit, across two launches that split a Philox block."""
+    K, R = 150, 11
+    spec = rl_ring_spec(R=R, N=22, noise=0.2, warmup=30, seed=3)
+    acts = tape(K, R, 1, seed=9)
+    fast, slow = make(spec, "f32"), make(spec, "f32", FLOWSIM_NO_RING_RL=1)
+    np.testing.assert_array_equal(fast.reset(), slow.reset())                 # (warm-up steps: RL vehicle uncommanded)
+    assert fast.last_kernel.startswith("k_ring_pair") and slow.last_kernel.startswith("k_steps")
+    for k0, k1 in ((0, 37), (37, 150)):
+        a, b = rollout(fast, k1 - k0, acts[k0:k1]), rollout(slow, k1 - k0, acts[k0:k1])
+        for u, w in zip(a, b):
+            np.testing.assert_array_equal(u, w)
+        np.testing.assert_array_equal(fast.pos, slow.pos)
+        np.testing.assert_array_equal(fast.vel, slow.vel)
+    assert np.abs(a[1]).max() > 0 and fast.vel.max() > 1.0
+    # single steps (fs_step) land on the same kernel and continue the same trajectory
+    for k in range(5):
+        oa, ra, da = fast.step(acts[k])
+        ob, rb, db = slow.step(acts[k])
+        np.testing.assert_array_equal(oa, ob)
+        np.testing.assert_array_equal(ra, rb)
+    assert fast.last_kernel.startswith("k_ring_pair")
+    fast.close(), slow.close()
+
+
+def test_masked_reset_with_warmup_and_last_step_observation():
+    K, R = 40, 10
+    spec = rl_ring_spec(R=R, N=22, warmup=12, seed=4, horizon=25)
+    acts = tape(K, R, 1, seed=2)
+    sim, ora = make(spec, "f32"), S.RingOracle(spec, np.float32)
+    np.testing.assert_array_equal(sim.reset(), ora.reset().astype(np.float32))
+    o, r, d = rollout(sim, 25, acts[:25], obs_every_step=False)                # observation of the last step only
+    for k in range(25):
+        o_ref, r_ref, d_ref = ora.step(acts[k])
+    np.testing.assert_array_equal(o[0], o_ref.astype(np.float32))
+    np.testing.assert_array_equal(r[0], r_ref.astype(np.float32))
+    assert (d[0] != 0).all() and d_ref.all()
+    mask = np.zeros(R, np.uint8)
+    mask[[0, 3, 4, 9]] = 1
+    np.testing.assert_array_equal(sim.reset(mask), ora.reset(mask.astype(bool)).astype(np.float32))
+    assert sim.last_kernel.startswith("k_ring_pair")
+    np.testing.assert_array_equal(sim.pos, ora.x)
+    np.testing.assert_array_equal(sim.time_counter, ora.time_counter)
+    o, r, d = rollout(sim, 10, acts[25:35])
+    for k in range(10):
+        o_ref, r_ref, d_ref = ora.step(acts[25 + k])
+        np.testing.assert_array_equal(o[k], o_ref.astype(np.float32))
+        np.testing.assert_array_equal(r[k], r_ref.astype(np.float32))
+    np.testing.assert_array_equal(sim.vel, ora.v)
+    sim.close()
+
+
+@pytest.mark.parametrize("po", [True, False])
+def test_mixed_bit_exact_against_its_c_twin_and_within_1e_4_of_float64(po):
+    """FS_MIXED with an RL vehicle: reset with warm-up steps, then 1500 steps of a fixed action tape."""
+    K, R = 1500, 6
+    spec = rl_ring_spec(R=R, N=22, po=po, warmup=50, seed=7, horizon=3000)
+    acts = tape(K, R, 1, seed=11, scale=0.8)
+    sim, twin, ref = make(spec, "mixed"), cbuild.CRingRLMixed(spec), S.RingOracle(spec, np.float64)
+    np.testing.assert_array_equal(sim.reset(), twin.reset())
+    assert sim.last_kernel.startswith("k_ring_pair")
+    ref.reset()
+    o, r, d = rollout(sim, K, acts)
+    to, tr, td = twin.rollout(K, acts)
+    np.testing.assert_array_equal(o, to)
+    np.testing.assert_array_equal(r, tr)
+    np.testing.assert_array_equal(d, td)
+    np.testing.assert_array_equal(sim.pos, twin.x)
+    np.testing.assert_array_equal(sim.vel, twin.v)
+    for k in range(K):
+        ref.step(acts[k].astype(np.float64))
+    L = spec["ring_length"][:, None] + 0.4
+    dx = np.abs(sim.pos - ref.x)
+    dx = np.minimum(dx, L - dx)
+    assert dx.max() < 1e-4 and np.abs(sim.vel - ref.v).max() < 1e-4, (dx.max(), np.abs(sim.vel - ref.v).max())
+    assert ref.v.max() > 1.0
+    # the float32 twin of the same run drifts past the bar (why FS_MIXED exists)
+    f32 = make(spec, "f32")
+    f32.reset()
+    rollout(f32, K, acts)
+    d32 = np.abs(f32.pos - ref.x)
+    assert np.minimum(d32, L - d32).max() > dx.max()
+    f32.close()
+    # masked reset on the mixed handle
+    mask = np.array([1, 0, 0, 1, 0, 1], np.uint8)
+    np.testing.assert_array_equal(sim.reset(mask), twin.reset(mask))
+    np.testing.assert_array_equal(sim.pos, twin.x)
+    sim.close()
+
+
+def test_pending_ring_length_is_taken_at_the_next_reset_only():
+    """FS_FIELD_INIT_RING_LENGTH: what VecFlowEnv.redraw_ring_lengths writes between replays of a captured fragment."""
+    from flow_amd import _lib as L
+    R = 6
+    spec = rl_ring_spec(R=R, N=22, warmup=0, seed=12)
+    sim = make(spec, "f32")
+    sim.reset()
+    acts = tape(20, R, 1, seed=1)
+    before = sim.get_state(L.FS_FIELD_RING_LENGTH).copy()
+    new_len = before + 7.0
+    sim.set_state(L.FS_FIELD_INIT_RING_LENGTH, new_len)
+    rollout(sim, 20, acts)
+    np.testing.assert_array_equal(sim.get_state(L.FS_FIELD_RING_LENGTH), before)          # mid-episode: untouched
+    mask = np.array([1, 1, 0, 0, 1, 0], np.uint8)
+    sim.reset(mask)
+    want = np.where(mask != 0, new_len, before)
+    np.testing.assert_array_equal(sim.get_state(L.FS_FIELD_RING_LENGTH), want)
+    # and the trajectory follows the new length: the oracle on the mixed lengths agrees
+    spec2 = dict(spec, ring_length=want)
+    ora = S.RingOracle(spec2, np.float32)
+    ora.reset()
+    ora.x[mask == 0] = sim.pos[mask == 0]
+    ora.v[mask == 0] = sim.vel[mask == 0]
+    ora.time_counter[mask == 0] = sim.time_counter[mask == 0]
+    o, r, d = rollout(sim, 20, acts)
+    for k in range(20):
+        o_ref, r_ref, d_ref = ora.step(acts[k])
+    np.testing.assert_array_equal(sim.pos, ora.x)
+    np.testing.assert_array_equal(o[-1], o_ref.astype(np.float32))
+    sim.close()
