@@ -126,8 +126,6 @@ __global__ __launch_bounds__(256) void k_ring_pair(DevView<T> s, int num_steps_a
     ddtB = (mB & 4) ? double(s.max_decel[iB]) * dt64 : double(BIG);
   }
   const bool have_act = actions != nullptr;
-  // SUMO's model is needed for the speed-mode clamps and for an uncommanded RL vehicle (wave-uniform)
-  const bool need_sumo = (s.flags & FLAG_NEED_SUMO) != 0;
 
   // ---- state -------------------------------------------------------------------------------------------------
   f2 x, v;                       // float32 images (float: THE state)
@@ -187,7 +185,11 @@ __global__ __launch_bounds__(256) void k_ring_pair(DevView<T> s, int num_steps_a
   };
   if (have_act && num_steps > 0) load_actions(0);
   const float act_lo = float(s.act_lo), act_hi = float(s.act_hi);
-  auto clip = [&](float a) -> float { return s.clip_actions ? tmin(tmax(a, act_lo), act_hi) : a; };
+  const bool clip_on = s.clip_actions != 0;
+  auto clip = [&](float a) -> float {               // (both forms evaluated, one select: no branch in the step)
+    const float c = tmin(tmax(a, act_lo), act_hi);
+    return clip_on ? c : a;
+  };
 
   // sigma * g of this step for the lane's two vehicles (-0.0 for a slot without noise: x + (-0) keeps every bit of x);
   // a replica that does not advance keeps its draws
@@ -267,13 +269,14 @@ __global__ __launch_bounds__(256) void k_ring_pair(DevView<T> s, int num_steps_a
     acc.x = rlA ? clip(ownA) : acc.x;
     acc.y = rlB ? clip(ownB) : acc.y;
     const bool cmdA = !rlA || have_act, cmdB = !rlB || have_act;       // rl_actions = None: no command (S5)
-    f2 acc_s = {0.0f, 0.0f};
-    if (need_sumo) acc_s = sumo_acc_pair<FAST>(v, vl, h, sc, one);
+    // SUMO's model is evaluated unconditionally: without a speed-mode bit its caps are 3e38 (the identity), and every
+    // population this kernel is chosen for has an RL slot (FLAG_NEED_SUMO) anyway -- no wave-uniform branch in the step
+    const f2 acc_s = sumo_acc_pair<FAST>(v, vl, h, sc, one);
     if (MIXED) {
       const double aA = double(acc.x), aB = double(acc.y);
       const double nA = tmax(vdA + aA * dt64, 0.0), nB = tmax(vdB + aB * dt64, 0.0);
       double cA = vdA + (nA - vdA) * ramp64, cB = vdB + (nB - vdB) * ramp64;
-      if (need_sumo) {
+      {
         const double vsA = vdA + double(acc_s.x) * dt64, vsB = vdB + double(acc_s.y) * dt64;
         cA = tmin(cA, tmax(vsA, floor0A)); cB = tmin(cB, tmax(vsB, floor0B));
         cA = tmin(cA, vdA + adtA); cB = tmin(cB, vdB + adtB);
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(256) void k_ring_pair(DevView<T> s, int num_steps_a
       nv.x = tmax(nv.x, 0.0f);
       nv.y = tmax(nv.y, 0.0f);
       f2 vc = pk_add(v, pk_mul(pk_sub(nv, v), ramp2));
-      if (need_sumo) {           // S7/S8: min(vc, v_sumo), min(vc, v + max_accel dt), max(vc, v - max_decel dt)
+      {                          // S7/S8: min(vc, v_sumo), min(vc, v + max_accel dt), max(vc, v - max_decel dt)
         const f2 vs = pk_add(v, pk_mul(acc_s, dt2));
         const f2 cap1 = pk_add(v, sc.adt), flo = pk_sub(v, sc.ddt);
         vc.x = tmin(vc.x, tmax(sc.floor0.x, vs.x));

@@ -169,8 +169,8 @@ class CRingRLMixed:
         self.sm = np.ascontiguousarray(np.array(
             [[float(int(v.get("speed_mode", 0)) & 7), v.get("sumo_tau", 1.0), v.get("sumo_min_gap", 2.5),
               v.get("sumo_max_speed", 30.0), v.get("max_accel", 2.6), v.get("max_decel", 4.5)] for v in veh], np.float64).T)
-        # FLAG_NEED_SUMO of the handle (flowsim_sim.h): an RL slot, or a speed-mode clamp
-        self.need_sumo = int(any(v["controller"] == 1 or (int(v.get("speed_mode", 0)) & 7) for v in veh))
+        # the kernel evaluates SUMO's model for every slot (caps of 3e38 where no speed-mode bit is set)
+        self.need_sumo = 1
         self.p = np.ascontiguousarray(np.array([list(v["p"][:6]) for v in veh], np.float64).T)
         self.veh_len = np.ascontiguousarray(np.array([v.get("length", 5.0) for v in veh], np.float64))
         self.dt = float(spec["sim_step"])
