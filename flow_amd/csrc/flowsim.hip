@@ -467,6 +467,21 @@ int fs_set_state(fs_handle h, int field, const void* src, size_t bytes) {
   return S(h)->set_state(field, src, bytes);
 }
 
+int fs_policy_act_dev(fs_handle h, const fs_policy* pol, const float* obs_dev, float* act_dev, float* logp_dev) {
+  if (!h || !pol || !obs_dev || !act_dev || !logp_dev) return fail(FS_ERR_INVALID, "fs_policy_act_dev: NULL argument");
+  DeviceGuard guard(S(h)->cfg.device);
+  return S(h)->launch_policy(pol, 0, 0, obs_dev, nullptr, act_dev, logp_dev, nullptr, nullptr);
+}
+
+int fs_policy_rollout_dev(fs_handle h, const fs_policy* pol, int num_steps, int reset_done, float* obs_dev,
+                          float* act_dev, float* logp_dev, float* rew_dev, uint8_t* done_dev) {
+  if (!h || !pol || !obs_dev || !act_dev || !logp_dev || !rew_dev || !done_dev)
+    return fail(FS_ERR_INVALID, "fs_policy_rollout_dev: NULL argument");
+  if (num_steps < 1) return fail(FS_ERR_INVALID, "fs_policy_rollout_dev: num_steps < 1");
+  DeviceGuard guard(S(h)->cfg.device);
+  return S(h)->launch_policy(pol, num_steps, reset_done ? 1 : 0, nullptr, obs_dev, act_dev, logp_dev, rew_dev, done_dev);
+}
+
 const char* fs_last_kernel(fs_handle h) { return h ? reinterpret_cast<SimBase*>(h)->last_kernel : ""; }
 
 int fs_dump_trajectory(fs_handle h, int replica, const char* csv_path) {

@@ -211,4 +211,44 @@ namespace fsim {
     return FS_OK;
   }
 
+  template <typename T>
+  int Sim<T>::launch_policy_row16(const fs_policy* pol, int num_steps, int reset_done, const float* obs_in, float* obs,
+                                  float* act, float* logp, float* rew, uint8_t* done) {
+    fs::PolicyView pv;
+    pv.w = pol->weights_dev;
+    pv.log_std = pol->log_std_dev;
+    pv.ctr = d_pol_ctr;
+    pv.in_dim = pol->obs_dim;
+    pv.num_hidden = pol->num_hidden;
+    pv.n_out = pol->log_std_dev ? 1 : 2;
+    pv.seed_lo = uint32_t(pol->seed & 0xFFFFFFFFull);
+    pv.seed_hi = uint32_t(pol->seed >> 32);
+    if (obs == nullptr) {                                  // eager: the policy alone
+      const int rows = dv.R, blocks = (rows * 16 + 255) / 256;
+      last_kernel = "k_policy_act";
+      hipLaunchKernelGGL(fs::k_policy_act<16>, dim3(blocks), dim3(256), 0, stream, pv, dv.R, dv.rep0, obs_in, act, logp);
+      HIP_TRY(hipGetLastError());
+      return FS_OK;
+    }
+    if constexpr (std::is_same<T, float>::value || std::is_same<T, double>::value) {
+      const bool fast = ringrl_fast_ok();
+      const int waves = (dv.R + 3) / 4;
+      const dim3 grid((waves + 3) / 4), block(256);
+      const int wu = cfg.warmup_steps;
+      last_kernel = "k_ring_policy";
+#define FS_POL(NZ_, FA_)                                                                                          \
+  hipLaunchKernelGGL((fs::k_ring_policy<T, NZ_, FA_>), grid, block, 0, stream, dv, pv, num_steps, reset_done, wu, obs, \
+                     act, logp, rew, done)
+      if constexpr (std::is_same<T, float>::value) {
+        if (dv.flags & fs::FLAG_HAS_NOISE) { if (fast) FS_POL(true, true); else FS_POL(true, false); }
+        else { if (fast) FS_POL(false, true); else FS_POL(false, false); }
+      } else {
+        if (fast) FS_POL(false, true); else FS_POL(false, false);
+      }
+#undef FS_POL
+      HIP_TRY(hipGetLastError());
+    }
+    return FS_OK;
+  }
+
 }  // namespace fsim

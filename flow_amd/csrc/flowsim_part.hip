@@ -9,6 +9,10 @@ namespace fsim {
 template int Sim<FS_PART_T>::launch_wide<FS_PART_WIDE>(int, const uint8_t*, const float*, size_t, float*, float*, uint8_t*, int);
 #elif defined(FS_PART_SEG)
 template int Sim<FS_PART_T>::launch_seg<FS_PART_SEG>(int, const uint8_t*, const float*, size_t, float*, float*, uint8_t*, int);
+#if FS_PART_SEG == 32
+template int Sim<FS_PART_T>::launch_policy_row16(const fs_policy*, int, int, const float*, float*, float*, float*, float*,
+                                                 uint8_t*);
+#endif
 #else
 #error "flowsim_part.hip: define FS_PART_T and FS_PART_SEG or FS_PART_WIDE"
 #endif

@@ -1,0 +1,472 @@
+// flowsim_policy.h -- the closed loop in ONE kernel: policy -> action -> Env.step, K times, for the reference's RL ring
+// experiment (examples/train.py:110-212 is what it replaces: one Python call + socket round trips per step and
+// environment; examples/exp_configs/rl/singleagent/singleagent_ring.py: 21 IDM + 1 RL vehicle, WaveAttenuationPOEnv).
+//
+// What a learner gets per fragment: obs [K+1, R, 3], actions [K, R, 1], log-probabilities [K, R], rewards, done flags --
+// the rollout batch of a policy-gradient method -- with the state of a replica in registers for the whole fragment and the
+// policy evaluated where the observation is produced.  The policy is the reference's default model class: a fully
+// connected network of up to three hidden layers of 32 tanh units (examples/train.py:152 `fcnet_hiddens [32, 32, 32]`)
+// with a diagonal Gaussian head -- either two outputs (mean, log std: RLlib's default) or one output and a free log std.
+//
+// Mapping: the simulator's (k_ring_pair, flowsim_ringrl.h): a row of 16 lanes = one replica, four replicas per wave.
+// Lane j of a row holds hidden units j and j + 16; a layer's inputs are fetched from the row with DPP row broadcasts
+// (folded into the FMAs), its weights are read from an LDS copy (16 b128 reads per lane and layer), the two outputs are
+// reduced over the row with the xor-tree of seg_sum.  The sampled action uses the replica's own Philox stream (keyed by
+// the policy's seed, the global replica index and a per-replica counter that a fragment continues where the last one
+// stopped).  policy_eval is ONE device function shared with k_policy_act (the eager form: fs_policy_act_dev followed by
+// fs_step_dev), so the fragment is bit-identical to eager stepping by construction (tests/test_policy_gpu.py).
+// Every operation is an explicit fma / hardware exp2 / rcp: the arithmetic is defined by this file (a torch module with
+// the same weights agrees to ~1e-6, not bit for bit).
+#pragma once
+#include "flowsim_ringrl.h"
+
+namespace fs {
+
+struct PolicyView {
+  const float* w;          // device: per layer W [out][in] row-major, then b [out]
+  const float* log_std;    // device [1], or NULL: the network's second output is the log std
+  uint32_t* ctr;           // device [R]: actions sampled so far per replica (the draw counter of the policy's stream)
+  int in_dim, num_hidden, n_out;
+  uint32_t seed_lo, seed_hi;
+};
+
+struct alignas(16) PolicyLds {
+  float w_hid[2][32][32];  // hidden layers 2 and 3: [layer][unit][input]
+  float w_in[32][4];       // layer 1: [unit][input (3, padded)]
+  float b[3][32];
+  float w_out[2][32];
+  float b_out[2];
+  float obs[4][4][4];      // [wave of the block][row][value]: the observation of a replica, handed from its RL lane to the row
+};
+
+__device__ __forceinline__ void policy_load(const PolicyView& pv, PolicyLds* L, int tid, int nthreads) {
+  // weights -> LDS (once per launch); layout of pv.w: [W1 32x3][b1 32][W2 32x32][b2][W3 32x32][b3][Wout n_out x 32][bout]
+  const float* p = pv.w;
+  for (int e = tid; e < 32 * 4; e += nthreads) L->w_in[e / 4][e % 4] = (e % 4) < pv.in_dim ? p[(e / 4) * pv.in_dim + (e % 4)] : 0.0f;
+  p += 32 * pv.in_dim;
+  for (int e = tid; e < 32; e += nthreads) L->b[0][e] = p[e];
+  p += 32;
+  for (int l = 0; l < 2; ++l) {
+    const bool have = l + 1 < pv.num_hidden;
+    for (int e = tid; e < 32 * 32; e += nthreads) L->w_hid[l][e / 32][e % 32] = have ? p[e] : 0.0f;
+    if (have) p += 32 * 32;
+    for (int e = tid; e < 32; e += nthreads) L->b[l + 1][e] = have ? p[e] : 0.0f;
+    if (have) p += 32;
+  }
+  for (int e = tid; e < 2 * 32; e += nthreads) L->w_out[e / 32][e % 32] = (e / 32) < pv.n_out ? p[e] : 0.0f;
+  p += pv.n_out * 32;
+  if (tid < 2) L->b_out[tid] = tid < pv.n_out ? p[tid] : 0.0f;
+  __syncthreads();
+}
+
+__device__ __forceinline__ float policy_tanh(float z) {
+  const float e = __builtin_amdgcn_exp2f(z * 2.885390081777927f);       // exp(2 z)
+  const float r = __builtin_amdgcn_rcpf(e + 1.0f);
+  return __builtin_fmaf(-2.0f, r, 1.0f);                                // 1 - 2 / (exp(2 z) + 1)
+}
+
+// mean and log std of the action distribution for the observation (o0, o1, o2) of THIS row's replica (every lane of the
+// row passes the same three values); j = lane within the row
+template <int ROW>
+__device__ __forceinline__ void policy_eval(const PolicyView& pv, const PolicyLds* L, int j, float o0, float o1, float o2,
+                                            float& mu, float& log_std) {
+  static_assert(ROW == 16, "policy_eval: a row of 16 lanes holds the 32 units of a layer");
+  // layer 1
+  float ha, hb;      // units j and j + 16
+  {
+    const float4 wa = *reinterpret_cast<const float4*>(L->w_in[j]), wb = *reinterpret_cast<const float4*>(L->w_in[j + 16]);
+    float za = L->b[0][j], zb = L->b[0][j + 16];
+    za = __builtin_fmaf(wa.x, o0, za); zb = __builtin_fmaf(wb.x, o0, zb);
+    za = __builtin_fmaf(wa.y, o1, za); zb = __builtin_fmaf(wb.y, o1, zb);
+    za = __builtin_fmaf(wa.z, o2, za); zb = __builtin_fmaf(wb.z, o2, zb);
+    ha = policy_tanh(za);
+    hb = policy_tanh(zb);
+  }
+  // hidden layers 2 .. num_hidden: z[u] = b[u] + sum_i W[u][i] h[i], i ascending; input i < 16 sits in `ha` of lane i,
+  // input i >= 16 in `hb` of lane i - 16 (row broadcasts, folded into the FMAs)
+#pragma unroll 1
+  for (int l = 0; l + 1 < pv.num_hidden; ++l) {
+    float za = L->b[l + 1][j], zb = L->b[l + 1][j + 16];
+    const float4* wa = reinterpret_cast<const float4*>(L->w_hid[l][j]);
+    const float4* wb = reinterpret_cast<const float4*>(L->w_hid[l][j + 16]);
+    static_for<4>([&](auto q_c) {                  // inputs 4q .. 4q+3 (ha) and 16 + 4q .. (hb)
+      constexpr int q = decltype(q_c)::value;
+      const float4 a0 = wa[q], b0 = wb[q];
+      const float i0 = dpp<DPP_ROW_NEWBCAST0 + 4 * q + 0>(ha), i1 = dpp<DPP_ROW_NEWBCAST0 + 4 * q + 1>(ha);
+      const float i2 = dpp<DPP_ROW_NEWBCAST0 + 4 * q + 2>(ha), i3 = dpp<DPP_ROW_NEWBCAST0 + 4 * q + 3>(ha);
+      za = __builtin_fmaf(a0.x, i0, za); zb = __builtin_fmaf(b0.x, i0, zb);
+      za = __builtin_fmaf(a0.y, i1, za); zb = __builtin_fmaf(b0.y, i1, zb);
+      za = __builtin_fmaf(a0.z, i2, za); zb = __builtin_fmaf(b0.z, i2, zb);
+      za = __builtin_fmaf(a0.w, i3, za); zb = __builtin_fmaf(b0.w, i3, zb);
+    });
+    static_for<4>([&](auto q_c) {
+      constexpr int q = decltype(q_c)::value;
+      const float4 a0 = wa[4 + q], b0 = wb[4 + q];
+      const float i0 = dpp<DPP_ROW_NEWBCAST0 + 4 * q + 0>(hb), i1 = dpp<DPP_ROW_NEWBCAST0 + 4 * q + 1>(hb);
+      const float i2 = dpp<DPP_ROW_NEWBCAST0 + 4 * q + 2>(hb), i3 = dpp<DPP_ROW_NEWBCAST0 + 4 * q + 3>(hb);
+      za = __builtin_fmaf(a0.x, i0, za); zb = __builtin_fmaf(b0.x, i0, zb);
+      za = __builtin_fmaf(a0.y, i1, za); zb = __builtin_fmaf(b0.y, i1, zb);
+      za = __builtin_fmaf(a0.z, i2, za); zb = __builtin_fmaf(b0.z, i2, zb);
+      za = __builtin_fmaf(a0.w, i3, za); zb = __builtin_fmaf(b0.w, i3, zb);
+    });
+    ha = policy_tanh(za);
+    hb = policy_tanh(zb);
+  }
+  // head: two outputs, each the row's tree sum of the lanes' two products
+  float p0 = L->w_out[0][j] * ha, p1 = L->w_out[1][j] * ha;
+  p0 = __builtin_fmaf(L->w_out[0][j + 16], hb, p0);
+  p1 = __builtin_fmaf(L->w_out[1][j + 16], hb, p1);
+  mu = seg_sum<ROW>(p0) + L->b_out[0];
+  const float o1_ = seg_sum<ROW>(p1) + L->b_out[1];
+  log_std = pv.log_std != nullptr ? pv.log_std[0] : o1_;
+}
+
+// the action: mean + std * g, g the replica's next standard normal draw (Philox block of four per counter / 4, column
+// 0x40000000 + 0: a stream of its own next to the vehicles' noise); log-probability of a 1-d diagonal Gaussian
+__device__ __forceinline__ void policy_sample(const PolicyView& pv, uint32_t replica, uint32_t ctr, float mu, float log_std,
+                                              float& action, float& logp) {
+  const float g = gauss<float>(pv.seed_lo, pv.seed_hi, replica, 0x40000000u, ctr);
+  const float sd = __builtin_amdgcn_exp2f(log_std * 1.4426950408889634f);
+  action = __builtin_fmaf(sd, g, mu);
+  logp = __builtin_fmaf(-0.5f * g, g, -log_std) - 0.9189385332046727f;
+}
+
+// eager form: actions and log-probabilities for the observations obs [R, 3]; advances the sampling counters
+template <int ROW>     // (a template so that every object of the library may include this header)
+__global__ __launch_bounds__(256) void k_policy_act(PolicyView pv, int R, uint32_t rep0, const float* __restrict__ obs,
+                                                    float* __restrict__ act, float* __restrict__ logp) {
+  __shared__ PolicyLds L;
+  policy_load(pv, &L, threadIdx.x, blockDim.x);
+  const int lane = threadIdx.x & 63, j = lane & 15;
+  const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int rr = r < R ? r : R - 1;
+  const float* o = obs + size_t(rr) * pv.in_dim;
+  float mu, ls;
+  policy_eval<ROW>(pv, &L, j, o[0], pv.in_dim > 1 ? o[1] : 0.0f, pv.in_dim > 2 ? o[2] : 0.0f, mu, ls);
+  const uint32_t c = pv.ctr[rr];
+  float a, lp;
+  policy_sample(pv, rep0 + uint32_t(rr), c, mu, ls, a, lp);
+  if (r < R && j == 0) {
+    act[r] = a;
+    logp[r] = lp;
+    pv.ctr[r] = c + 1u;
+  }
+}
+
+// K x (policy -> action -> Env.step [-> reset of a finished episode]) for rings of IDM vehicles and ONE RL vehicle with
+// the WaveAttenuationPOEnv head.  obs [K+1, R, 3] (obs[0]: the observation of the state the fragment starts from),
+// act [K, R], logp [K, R], rew [K, R], done [K, R].  The simulator part is k_ring_pair's arithmetic statement by statement.
+template <typename T, bool NOISE, bool FAST>
+__global__ __launch_bounds__(256) void k_ring_policy(DevView<T> s, PolicyView pv, int num_steps, int reset_done,
+                                                     int warmup_steps, float* __restrict__ obs, float* __restrict__ act,
+                                                     float* __restrict__ logp, float* __restrict__ rew,
+                                                     uint8_t* __restrict__ done) {
+  constexpr int ROW = 16;
+  constexpr bool MIXED = sizeof(T) == 8;
+  static_assert(!(NOISE && MIXED), "FS_MIXED has no noise form");
+  constexpr int RPW = 64 / ROW;
+  __shared__ PolicyLds PL;
+  policy_load(pv, &PL, threadIdx.x, blockDim.x);
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int wib = (threadIdx.x >> 6) & 3;
+  const int row = lane / ROW;
+  const int k = lane % ROW;
+  const int r = wave * RPW + row;
+  const int N = s.N;
+  const int LP = N >> 1;
+  const bool rvalid = r < s.R;
+  const bool valid = rvalid && k < LP;
+  const int rr = rvalid ? r : s.R - 1;
+  const int kk = k < LP ? k : LP - 1;
+  const bool last = (kk == LP - 1);
+  const int iA = 2 * kk, iB = iA + 1;
+  const size_t idx = size_t(rr) * N + iA;
+
+  const bool rlA = s.ctrl[iA] == FS_CTRL_RL, rlB = s.ctrl[iB] == FS_CTRL_RL;
+  f2 p[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) p[q] = f2{float(s.p[q * N + iA]), float(s.p[q * N + iB])};
+  {
+    const float dflt[6] = {30.0f, 1.0f, 1.0f, 1.5f, 4.0f, 2.0f};
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      p[q].x = rlA ? dflt[q] : p[q].x;
+      p[q].y = rlB ? dflt[q] : p[q].y;
+    }
+  }
+  const T lenB = s.length[iB];
+  const T len_nextA = next_a<ROW>(T(s.length[iA]), last, lane);
+  T L = s.ring_len[rr] + T(4) * s.jlen;
+  int tcount = s.time[rr];
+  uint32_t nctr = NOISE ? s.noise_ctr[rr] : 0u;
+  uint32_t pctr = pv.ctr[rr];
+  const f2 sigma = NOISE ? f2{float(s.noise[iA]), float(s.noise[iB])} : f2{0.0f, 0.0f};
+  const bool noisyA = NOISE && sigma.x > 0.0f && !rlA, noisyB = NOISE && sigma.y > 0.0f && !rlB;
+  float gA[4] = {0.0f, 0.0f, 0.0f, 0.0f}, gB[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if constexpr (NOISE) {
+    if ((nctr & 3u) != 0u) {
+      gauss4<float>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(iA), nctr >> 2, gA);
+      gauss4<float>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(iB), nctr >> 2, gB);
+      for (uint32_t q = 0; q < (nctr & 3u); ++q) {
+        gA[0] = gA[1]; gA[1] = gA[2]; gA[2] = gA[3];
+        gB[0] = gB[1]; gB[1] = gB[2]; gB[2] = gB[3];
+      }
+    }
+  }
+  const float dt = float(s.dt), ramp = float(s.ramp);
+  const f2 two_sqrt_ab = {2.0f * tsqrt(p[2].x * p[3].x), 2.0f * tsqrt(p[2].y * p[3].y)};
+  const f2 rc_v0 = {1.0f / p[0].x, 1.0f / p[0].y}, rc_ab = {1.0f / two_sqrt_ab.x, 1.0f / two_sqrt_ab.y};
+  const f2 one = splat(1.0f), dt2 = splat(dt), ramp2 = splat(ramp);
+  const f2 gap2 = splat(float(s.crash_gap));
+  const double dt64 = double(s.dt), ramp64 = double(s.ramp);
+  const f2 len_lead = {float(lenB), float(len_nextA)};
+  // the loop length and what depends on it: a reset inside the fragment takes the replica's pending length
+  f2 L2 = splat(float(L));
+  double L64 = double(L);
+  SumoPair sc;
+  double floor0A, floor0B, adtA, adtB, ddtA, ddtB;
+  {
+    const int mA = s.speed_mode[iA], mB = s.speed_mode[iB];
+    const float maA = float(s.max_accel[iA]), maB = float(s.max_accel[iB]);
+    const float mdA = float(s.max_decel[iA]), mdB = float(s.max_decel[iB]);
+    sc.tau = f2{float(s.sumo_tau[iA]), float(s.sumo_tau[iB])};
+    sc.min_gap = f2{float(s.sumo_min_gap[iA]), float(s.sumo_min_gap[iB])};
+    sc.maxa = f2{maA, maB};
+    sc.smax = f2{float(s.sumo_max_speed[iA]), float(s.sumo_max_speed[iB])};
+    sc.rc_smax = f2{1.0f / sc.smax.x, 1.0f / sc.smax.y};
+    sc.ts = f2{2.0f * tsqrt(maA * mdA), 2.0f * tsqrt(maB * mdB)};
+    sc.rc_ts = f2{1.0f / sc.ts.x, 1.0f / sc.ts.y};
+    const float BIG = 3.0e38f;
+    sc.floor0 = f2{(mA & 1) ? 0.0f : BIG, (mB & 1) ? 0.0f : BIG};
+    sc.adt = f2{(mA & 2) ? maA * dt : BIG, (mB & 2) ? maB * dt : BIG};
+    sc.ddt = f2{(mA & 4) ? mdA * dt : BIG, (mB & 4) ? mdB * dt : BIG};
+    floor0A = double(sc.floor0.x); floor0B = double(sc.floor0.y);
+    adtA = (mA & 2) ? double(s.max_accel[iA]) * dt64 : double(BIG);
+    adtB = (mB & 2) ? double(s.max_accel[iB]) * dt64 : double(BIG);
+    ddtA = (mA & 4) ? double(s.max_decel[iA]) * dt64 : double(BIG);
+    ddtB = (mB & 4) ? double(s.max_decel[iB]) * dt64 : double(BIG);
+  }
+
+  f2 x, v;
+  double xdA = 0, xdB = 0, vdA = 0, vdB = 0;
+  auto load_state = [&](const T* px, const T* pvv) {
+    if (MIXED) {
+      xdA = double(px[idx]); xdB = double(px[idx + 1]);
+      vdA = double(pvv[idx]); vdB = double(pvv[idx + 1]);
+      v = f2{float(vdA), float(vdB)};
+      x = f2{0.0f, 0.0f};
+    } else {
+      x = f2{float(px[idx]), float(px[idx + 1])};
+      v = f2{float(pvv[idx]), float(pvv[idx + 1])};
+    }
+  };
+  load_state(s.pos, s.vel);
+  f2 dgap = {0.0f, 0.0f};
+  double dgA = 0, dgB = 0;
+  auto headway = [&]() -> f2 {
+    if (MIXED) {
+      const double xn = next_a<ROW>(xdA, last, lane);
+      double dA = xdB - xdA, dB = xn - xdB;
+      dA = dA < 0.0 ? dA + L64 : dA;
+      dB = dB < 0.0 ? dB + L64 : dB;
+      dgA = dA;
+      dgB = dB;
+      return f2{float(dA - double(lenB)), float(dB - double(len_nextA))};
+    } else {
+      const f2 xl = {x.y, next_a<ROW>(x.x, last, lane)};
+      f2 d = pk_sub(xl, x);
+      const f2 dw = pk_add(d, L2);
+      d.x = nonneg_else(d.x, dw.x);
+      d.y = nonneg_else(d.y, dw.y);
+      dgap = d;
+      return pk_sub(d, len_lead);
+    }
+  };
+  f2 h = headway();
+  f2 vl = {v.y, next_a<ROW>(v.x, last, lane)};
+
+  const float act_lo = float(s.act_lo), act_hi = float(s.act_hi);
+  const bool clip_on = s.clip_actions != 0;
+  auto clip = [&](float a) -> float {
+    const float c = tmin(tmax(a, act_lo), act_hi);
+    return clip_on ? c : a;
+  };
+  auto noise_term = [&](bool live) -> f2 {
+    f2 nz = {-0.0f, -0.0f};
+    if constexpr (NOISE) {
+      const bool fresh = live && (nctr & 3u) == 0u;
+      if (__ballot(fresh) != 0ull) {
+        if (fresh) {
+          gauss4<float>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(iA), nctr >> 2, gA);
+          gauss4<float>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(iB), nctr >> 2, gB);
+        }
+      }
+      const float tA = sigma.x * gA[0], tB = sigma.y * gB[0];
+      nz.x = noisyA ? tA : -0.0f;
+      nz.y = noisyB ? tB : -0.0f;
+      if (live) {
+        gA[0] = gA[1]; gA[1] = gA[2]; gA[2] = gA[3];
+        gB[0] = gB[1]; gB[1] = gB[2]; gB[2] = gB[3];
+        nctr += 1u;
+      }
+    }
+    return nz;
+  };
+  // one step (k_ring_pair's `advance`): `have_act` false = rl_actions None (the warm-up steps of a reset)
+  auto advance = [&](bool live, bool have_act, float a_rl) {
+    f2 acc = idm_pair<FAST, FAST>(v, vl, h, p, two_sqrt_ab, rc_ab, rc_v0, one);
+    if constexpr (NOISE) acc = pk_add(acc, noise_term(live));
+    acc.x = rlA ? clip(a_rl) : acc.x;
+    acc.y = rlB ? clip(a_rl) : acc.y;
+    const bool cmdA = !rlA || have_act, cmdB = !rlB || have_act;
+    const f2 acc_s = sumo_acc_pair<FAST>(v, vl, h, sc, one);
+    if (MIXED) {
+      const double aA = double(acc.x), aB = double(acc.y);
+      const double nA = tmax(vdA + aA * dt64, 0.0), nB = tmax(vdB + aB * dt64, 0.0);
+      double cA = vdA + (nA - vdA) * ramp64, cB = vdB + (nB - vdB) * ramp64;
+      const double vsA = vdA + double(acc_s.x) * dt64, vsB = vdB + double(acc_s.y) * dt64;
+      cA = tmin(cA, tmax(vsA, floor0A)); cB = tmin(cB, tmax(vsB, floor0B));
+      cA = tmin(cA, vdA + adtA); cB = tmin(cB, vdB + adtB);
+      cA = tmax(cA, vdA - ddtA); cB = tmax(cB, vdB - ddtB);
+      cA = cmdA ? cA : tmax(vsA, 0.0);
+      cB = cmdB ? cB : tmax(vsB, 0.0);
+      const double xA = xdA + cA * dt64, xB = xdB + cB * dt64;
+      const double wA = xA >= L64 ? xA - L64 : xA, wB = xB >= L64 ? xB - L64 : xB;
+      if (live) {
+        vdA = cA; vdB = cB;
+        xdA = wA; xdB = wB;
+      }
+      v = f2{float(vdA), float(vdB)};
+    } else {
+      f2 nv = pk_add(v, pk_mul(acc, dt2));
+      nv.x = tmax(nv.x, 0.0f);
+      nv.y = tmax(nv.y, 0.0f);
+      f2 vc = pk_add(v, pk_mul(pk_sub(nv, v), ramp2));
+      const f2 vs = pk_add(v, pk_mul(acc_s, dt2));
+      const f2 cap1 = pk_add(v, sc.adt), flo = pk_sub(v, sc.ddt);
+      vc.x = tmin(vc.x, tmax(sc.floor0.x, vs.x));
+      vc.y = tmin(vc.y, tmax(sc.floor0.y, vs.y));
+      vc.x = tmax(tmin(vc.x, cap1.x), flo.x);
+      vc.y = tmax(tmin(vc.y, cap1.y), flo.y);
+      vc.x = cmdA ? vc.x : tmax(0.0f, vs.x);
+      vc.y = cmdB ? vc.y : tmax(0.0f, vs.y);
+      const f2 xn = pk_add(x, pk_mul(vc, dt2));
+      const f2 xw = pk_sub(xn, L2);
+      f2 xq;
+      xq.x = nonneg_else(xw.x, xn.x);
+      xq.y = nonneg_else(xw.y, xn.y);
+      if (live) {
+        v = vc;
+        x = xq;
+      }
+    }
+    if (live) tcount += 1;
+    h = headway();
+    vl = f2{v.y, next_a<ROW>(v.x, last, lane)};
+  };
+
+  // WaveAttenuationPOEnv.get_state of the current snapshot (k_ring_pair's write_obs): computed by the RL vehicle's
+  // lane, handed to the row through LDS (the policy's input), stored by that lane
+  const bool poA = valid && rlA, poB = valid && rlB;
+  const double rc15 = 1.0 / 15.0, pml64 = double(s.po_max_length), rc_pml64 = 1.0 / pml64;
+  float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
+  auto observe = [&](float* orow) {
+    float q0, q1, q2;
+    if (MIXED) {
+      const double vdn = next_a<ROW>(vdA, last, lane);
+      const double v_me = poB ? vdB : vdA, v_ld = poB ? vdn : vdB, d_me = poB ? dgB : dgA;
+      q0 = float(v_me * rc15);
+      q1 = float((v_ld - v_me) * rc15);
+      q2 = float(d_me * rc_pml64);
+    } else {
+      const float v_me = poB ? v.y : v.x, v_ld = poB ? vl.y : vl.x, d_me = poB ? dgap.y : dgap.x;
+      q0 = div_via_f64(v_me, 15.0, rc15);
+      q1 = div_via_f64(v_ld - v_me, 15.0, rc15);
+      q2 = div_via_f64(d_me, pml64, rc_pml64);
+    }
+    if (poA || poB) {
+      orow[0] = q0;
+      orow[1] = q1;
+      orow[2] = q2;
+      PL.obs[wib][row][0] = q0;
+      PL.obs[wib][row][1] = q1;
+      PL.obs[wib][row][2] = q2;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    o0 = PL.obs[wib][row][0];
+    o1 = PL.obs[wib][row][1];
+    o2 = PL.obs[wib][row][2];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // (read before the next step's write of the same words)
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  const size_t R = size_t(s.R);
+  observe(obs + size_t(rr) * 3);
+  for (int step = 0; step < num_steps; ++step) {
+    // ---- policy -> action --------------------------------------------------------------------------------------
+    float mu, ls, a, lp;
+    policy_eval<ROW>(pv, &PL, k, o0, o1, o2, mu, ls);
+    policy_sample(pv, s.rep0 + uint32_t(rr), pctr, mu, ls, a, lp);
+    pctr += 1u;
+    if (rvalid && k == 0) {
+      act[size_t(step) * R + rr] = a;
+      logp[size_t(step) * R + rr] = lp;
+    }
+    // ---- Env.step ------------------------------------------------------------------------------------------------
+    advance(true, true, a);
+    const unsigned fl = (valid && ((h.x < gap2.x) || (h.y < gap2.x)) ? 1u : 0u) |
+                        (valid && ((v.x < -100.0f) || (v.y < -100.0f)) ? 2u : 0u);
+    const unsigned fany = seg_or<ROW>(fl);
+    const bool crashed = (fany & 1u) != 0u;
+    const bool bad = (fany & 2u) != 0u || crashed;
+    const float sv = seg_sum<ROW>(valid ? v.x + v.y : 0.0f);
+    const float mean_v = div_via_f64(sv, double(N), 1.0 / double(N));
+    const float mean_a = tabs(clip(a));                     // (one column: the sum is the value, / 1)
+    float reward = div_via_f64(4.0f * mean_v, 20.0, 1.0 / 20.0);
+    if (mean_a > 0.0f) reward = reward + 4.0f * (0.0f - mean_a);
+    reward = bad ? 0.0f : reward;
+    const uint8_t dflag = done_flag(tcount >= s.step_limit, crashed);
+    if (rvalid && k == 0) {
+      rew[size_t(step) * R + rr] = reward;
+      done[size_t(step) * R + rr] = dflag;
+    }
+    // ---- Env.reset of a finished episode (what VecFlowEnv.capture(reset_done=True) does with a masked fs_reset_dev):
+    // placement, the pending ring length, warm-up steps with rl_actions = None; the other replicas of the wave wait
+    const bool fin = reset_done && dflag != 0;
+    if (__ballot(fin) != 0ull) {
+      if (fin) {
+        load_state(s.init_pos, s.init_vel);
+        L = s.init_ring_len[rr] + T(4) * s.jlen;
+        L2 = splat(float(L));
+        L64 = double(L);
+        tcount = 0;
+      }
+      h = headway();
+      vl = f2{v.y, next_a<ROW>(v.x, last, lane)};
+#pragma unroll 1
+      for (int w = 0; w < warmup_steps; ++w) advance(fin, false, 0.0f);
+      if (fin && valid && kk == 0) const_cast<T*>(s.ring_len)[rr] = s.init_ring_len[rr];
+    }
+    observe(obs + (size_t(step + 1) * R + rr) * 3);
+  }
+
+  if (valid) {
+    if (MIXED) {
+      s.pos[idx] = T(xdA); s.pos[idx + 1] = T(xdB);
+      s.vel[idx] = T(vdA); s.vel[idx + 1] = T(vdB);
+    } else {
+      s.pos[idx] = T(x.x); s.pos[idx + 1] = T(x.y);
+      s.vel[idx] = T(v.x); s.vel[idx + 1] = T(v.y);
+    }
+    if (kk == 0) {
+      s.time[rr] = tcount;
+      pv.ctr[rr] = pctr;
+      if (NOISE) s.noise_ctr[rr] = nctr;
+    }
+  }
+}
+
+}  // namespace fs

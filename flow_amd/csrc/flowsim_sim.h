@@ -24,6 +24,7 @@
 #include "flowsim_pair.h"
 #include "flowsim_fig8.h"
 #include "flowsim_ringrl.h"
+#include "flowsim_policy.h"
 #include "flowsim_wide.h"
 
 
@@ -80,6 +81,10 @@ struct SimBase {
   virtual int launch_steps(int num_steps, const uint8_t* mask, const float* actions, size_t act_stride,
                            float* obs, float* rew, uint8_t* done, int obs_every_step) = 0;
   virtual int launch_reset(const uint8_t* mask) = 0;
+  // policy in the loop (flowsim_policy.h): obs == nullptr selects the eager form (act only)
+  virtual int launch_policy(const fs_policy* pol, int num_steps, int reset_done, const float* obs_in, float* obs,
+                            float* act, float* logp, float* rew, uint8_t* done) = 0;
+  uint32_t* d_pol_ctr = nullptr;   // [R] actions sampled so far per replica (the policy's draw counters)
   virtual int get_state(int field, void* dst, size_t bytes) = 0;
   virtual int set_state(int field, const void* src, size_t bytes) = 0;
 };
@@ -625,6 +630,36 @@ struct Sim : SimBase {
   template <int W>
   int launch_wide(int num_steps, const uint8_t* mask, const float* actions, size_t act_stride, float* obs,
                   float* rew, uint8_t* done, int obs_every_step);
+
+  // the policy kernels exist for rows of 16 lanes (SEG = 32: 18..32 vehicles); defined in flowsim_launch.h, instantiated
+  // by the SEG = 32 objects
+  int launch_policy_row16(const fs_policy* pol, int num_steps, int reset_done, const float* obs_in, float* obs, float* act,
+                          float* logp, float* rew, uint8_t* done);
+  int launch_policy(const fs_policy* pol, int num_steps, int reset_done, const float* obs_in, float* obs, float* act,
+                    float* logp, float* rew, uint8_t* done) override {
+    if (!pol || pol->struct_size != sizeof(fs_policy)) return fail(FS_ERR_INVALID, "fs_policy: struct_size mismatch");
+    const bool f32_or_mixed = mixed || std::is_same<T, float>::value;
+    const char* why = nullptr;
+    if (!f32_or_mixed) why = "precision (f32 or mixed)";
+    else if (seg != 32) why = "num_vehicles (18..32: a row of 16 lanes per replica)";
+    else if (dv.env != FS_ENV_WAVE_ATTENUATION_PO || dv.num_rl != 1) why = "env (WaveAttenuationPOEnv with one RL vehicle)";
+    else if (pol->obs_dim != 3) why = "fs_policy.obs_dim (3)";
+    else if (pol->num_hidden < 1 || pol->num_hidden > 3 || pol->hidden_width != 32 || pol->activation != 0)
+      why = "fs_policy model (1..3 hidden layers of 32 tanh units)";
+    else if (!pol->weights_dev) why = "fs_policy.weights_dev (NULL)";
+    else if (dv.nseg != 0 || dv.junction_on || dv.num_lanes > 1 || !(dv.flags & fs::FLAG_IDM_SET) || any_sim ||
+             (dv.flags & fs::FLAG_HAS_FAILSAFE) || dv.sims_per_step != 1 || dv.integrator != FS_EULER || dv.junction_mode ||
+             dv.track_aux || dv.sort_vehicles || dv.obs_perm != nullptr || dv.evaluate || (dv.N % 2) != 0)
+      why = "configuration (what k_ring_pair steps: single-lane ring of IDM / RL vehicles, Euler, track_aux = 0)";
+    else if ((dv.flags & fs::FLAG_HAS_NOISE) && mixed) why = "noise with FS_MIXED";
+    if (why) return fail(FS_ERR_UNSUPPORTED, std::string("fs_policy: not built for this handle: ") + why);
+    if (!d_pol_ctr) {
+      int rc = dev_alloc(&d_pol_ctr, size_t(dv.R));
+      if (rc) return rc;
+      HIP_TRY(hipMemsetAsync(d_pol_ctr, 0, size_t(dv.R) * sizeof(uint32_t), stream));
+    }
+    return launch_policy_row16(pol, num_steps, reset_done, obs_in, obs, act, logp, rew, done);
+  }
 
   // one wave carries 64 / SEG replicas (flowsim_launch.h)
   template <int SEG>

@@ -370,6 +370,39 @@ int fs_set_state(fs_handle h, int field, const void* src, size_t bytes);
  * configuration class a workload landed in (no reference counterpart).  The string is static. */
 const char* fs_last_kernel(fs_handle h);
 
+/* ---- policy in the loop ------------------------------------------------------
+ * What examples/train.py:110-212 runs per rollout worker -- policy forward pass, Env.step, reset of a finished episode,
+ * one Python call and N socket round trips per step -- as ONE launch per fragment of K steps.  Built for the
+ * reference's RL ring experiments (examples/exp_configs/rl/singleagent/singleagent_ring.py: IDM vehicles + ONE RL
+ * vehicle, WaveAttenuationPOEnv: observation 3, action 1) and its default model class: a fully connected network of 1..3
+ * hidden layers of 32 tanh units (examples/train.py:152 fcnet_hiddens [32, 32, 32]) with a diagonal Gaussian head.
+ *   weights_dev  float32, device: per layer W [out][in] row-major then b [out]; the last layer has 2 outputs (mean,
+ *                log std: RLlib's DiagGaussian) or, with log_std_dev != NULL, 1 output and a free log std [1]
+ *   seed         keys the action sampling streams (Philox, per global replica, continued from fragment to fragment)
+ * The arithmetic (fma order, hardware exp2 / rcp) is defined by flow_amd/csrc/flowsim_policy.h; fs_policy_act_dev is
+ * the SAME evaluation as a call of its own, so fs_policy_rollout_dev equals K x (fs_policy_act_dev, fs_step_dev
+ * [, fs_reset_dev(done)]) bit for bit.  Other environments / models: FS_ERR_UNSUPPORTED (capture K single steps
+ * around any policy instead: flow_amd.envs.VecFlowEnv.capture). */
+typedef struct fs_policy {
+  uint32_t struct_size;               /* sizeof(fs_policy) */
+  int32_t obs_dim;                    /* must equal fs_obs_dim (3) */
+  int32_t num_hidden;                 /* 1..3 hidden layers ... */
+  int32_t hidden_width;               /* ... of 32 units each */
+  int32_t activation;                 /* 0 = tanh */
+  const float* weights_dev;
+  const float* log_std_dev;           /* NULL: the network's second output is the log std */
+  uint64_t seed;
+} fs_policy;
+
+/* actions [R] and log-probabilities [R] for the observations obs_dev [R, obs_dim]; advances the sampling streams */
+int fs_policy_act_dev(fs_handle h, const fs_policy* pol, const float* obs_dev, float* act_dev, float* logp_dev);
+/* K x (policy -> action -> Env.step), with reset_done != 0 followed by Env.reset of the replicas whose episode ended
+ * (placement, FS_FIELD_INIT_RING_LENGTH, warm-up steps).  obs_dev [K+1, R, obs_dim]: obs[0] = observation of the state
+ * the fragment starts from (written by the call), obs[k+1] = observation after step k (after the reset, if one
+ * happened); act_dev [K, R], logp_dev [K, R], rew_dev [K, R], done_dev [K, R] (flags as in fs_rollout_dev). */
+int fs_policy_rollout_dev(fs_handle h, const fs_policy* pol, int num_steps, int reset_done, float* obs_dev,
+                          float* act_dev, float* logp_dev, float* rew_dev, uint8_t* done_dev);
+
 /* Append the CURRENT state of one replica to a CSV file (header `time,id,x,speed,lane_number` when the file is new;
  * one row per vehicle, id = slot index, free slots of open networks skipped): the trajectory ("emission") dump of
  * flow/core/kernel/simulation/traci.py:95-101 (SUMO's --emission-output) for callers without the Python layer;
