@@ -357,6 +357,75 @@ def ring_defaults_leg(device, R=4096, K=1500):
     return out
 
 
+def rl_ring_legs(device, R=4096, K=1500):
+    """The reference's RL ring experiment (examples/exp_configs/rl/singleagent/singleagent_ring.py:17-65: 21 x
+    IDMController(noise=0.2) + 1 x RLController, WaveAttenuationPOEnv, ring length 220..270 per replica) through
+    VecFlowEnv: (a) open loop with an action tape on k_ring_pair (kernel time of 1500-step launches), float32 with the
+    noise and FS_MIXED without; (b) closed loop: policy (fcnet_hiddens [32, 32, 32], diagonal Gaussian) -> action ->
+    step -> reset of finished episodes, K = 500 steps per launch of the fused kernel (fs_policy_rollout_dev)."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import train_vec
+    from flow_amd.envs import VecFlowEnv
+    from flow_amd.utils.device_policy import DevicePolicy
+    out = {"unit": "env-steps/s", "replicas": R,
+           "workload": "singleagent_ring: 21 IDM (noise 0.2) + 1 RL, WaveAttenuationPOEnv, ring length 220..270 per replica"}
+    for label, precision, noise in (("f32_noise_0.2", "f32", 0.2), ("mixed_quiet", "mixed", 0.0)):
+        fp = train_vec.ring_flow_params(3000)
+        fp["sim"].precision = precision
+        fp["env"].additional_params["ring_length"] = [220, 270]
+        if not noise:
+            for t in fp["veh"].type_parameters.values():
+                if "noise" in t["acceleration_controller"][1]:
+                    t["acceleration_controller"][1]["noise"] = 0.0
+        vec = VecFlowEnv(fp, num_replicas=R, device=device.index)
+        gen = torch.Generator(device=device).manual_seed(2)
+        tape = torch.rand((K, R, 1), device=device, generator=gen) * 2 - 1
+        buf = (torch.empty((K, R, vec.obs_dim), device=device), torch.empty((K, R), device=device),
+               torch.empty((K, R), dtype=torch.uint8, device=device))
+        vec.reset()
+        vec.rollout(K, tape, out=buf)
+        torch.cuda.synchronize(device)
+        ms = []
+        for _ in range(4):
+            vec.reset()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            vec.rollout(K, tape, out=buf)
+            e1.record()
+            torch.cuda.synchronize(device)
+            ms.append(e0.elapsed_time(e1))
+        t = float(np.mean(ms)) * 1e-3
+        leg = {"open_loop": {"value": R * K / t, "avg_launch_ms": t * 1e3, "steps_per_launch": K,
+                             "kernel": vec.sim.last_kernel,
+                             # PO head: 3 observations + reward + done per env step, one action read
+                             "algorithmic_GBs": R * K * (3 * 4 + 4 + 1 + 4) / t / 1e9}}
+        hidden = [torch.nn.Linear(3, 32), torch.nn.Linear(32, 32), torch.nn.Linear(32, 32)]
+        head = torch.nn.Linear(32, 2)
+        for l in hidden + [head]:
+            l.to(device)
+        pol = DevicePolicy(hidden, head, seed=1)
+        KP = 500
+        vec.reset()
+        res = vec.policy_rollout(pol, KP, reset_done=True)
+        torch.cuda.synchronize(device)
+        ms = []
+        for _ in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            vec.policy_rollout(pol, KP, reset_done=True, out=res)
+            e1.record()
+            torch.cuda.synchronize(device)
+            ms.append(e0.elapsed_time(e1))
+        t = float(np.mean(ms)) * 1e-3
+        leg["closed_loop_fused_policy"] = {"value": R * KP / t, "avg_launch_ms": t * 1e3, "steps_per_launch": KP,
+                                           "kernel": vec.sim.last_kernel, "model": "fcnet 3-32-32-32-2 tanh, diagonal Gaussian"}
+        out[label] = leg
+        vec.close()
+    out["value"] = out["f32_noise_0.2"]["open_loop"]["value"]
+    return out
+
+
 KERNEL_NAMES = {"f32": "fs::k_rollout_pair<float, 16, true, true, false>",
                 "mixed": "fs::k_rollout_pair<double, 16, true, true, false>",
                 "f64": "fs::k_rollout_idm<double, 32, true, false, false>"}
@@ -371,24 +440,38 @@ def launch_bytes(R, N, K, precision):
     return R * (K * obs_b + state_b), obs_b + state_b / float(K)
 
 
-def pmc_summary(precision, R, K):
-    """The committed PMC summary of THIS kernel at THIS launch shape (profiles/r02_*), or None."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_summary_%s.json" % precision)
+PMC_STALE_TOLERANCE = 0.15
+
+
+def pmc_summary(precision, R, K, avg_s=None):
+    """The committed PMC summary of THIS kernel at THIS launch shape (newest profiles/rNN_pmc_summary_<dtype>.json), or
+    (None, reason).  A summary is only used while it still describes the kernel that was just timed: same kernel name,
+    same launch shape, and a launch duration within 15 % of the one measured in this run -- a counter file of an older
+    kernel would otherwise pass for a measurement."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_summary_%s.json" % precision)))
+    if not paths:
+        return None, "no profiles/rNN_pmc_summary_%s.json" % precision
+    path = paths[-1]
     try:
         tj = json.load(open(path))
-        # rocprofv3 prints the kernel as "void fs::k_...<...>(args)": the bench line's name is a substring of it
-        if tj.get("replicas") == R and tj.get("steps_per_launch") == K and KERNEL_NAMES[precision] in tj.get(
-                "kernel", ""):
-            return tj, os.path.basename(path)
-    except Exception:
-        pass
-    return None, None
+    except Exception as e:
+        return None, "%s unreadable: %s" % (os.path.basename(path), e)
+    # rocprofv3 prints the kernel as "void fs::k_...<...>(args)": the bench line's name is a substring of it
+    if not (tj.get("replicas") == R and tj.get("steps_per_launch") == K and KERNEL_NAMES[precision] in tj.get("kernel", "")):
+        return None, "%s describes another kernel / launch shape" % os.path.basename(path)
+    if avg_s is not None:
+        ref_s = float(tj.get("avg_launch_ns_kernel_trace", 0.0)) * 1e-9
+        if not ref_s > 0 or abs(avg_s - ref_s) / ref_s > PMC_STALE_TOLERANCE:
+            return None, "%s is stale: its launches took %.4f ms, this run's %.4f ms (> %d %% apart)" % (
+                os.path.basename(path), ref_s * 1e3, avg_s * 1e3, int(PMC_STALE_TOLERANCE * 100))
+    return tj, os.path.basename(path)
 
 
-def pmc_traffic(precision, R, K):
-    """HBM bytes per launch from that summary, or None."""
-    tj, src = pmc_summary(precision, R, K)
-    return (tj.get("hbm_bytes_per_launch"), src) if tj else (None, None)
+def pmc_traffic(precision, R, K, avg_s=None):
+    """HBM bytes per launch from that summary, or (None, why not)."""
+    tj, src = pmc_summary(precision, R, K, avg_s)
+    return (tj.get("hbm_bytes_per_launch"), src) if tj else (None, src)
 
 
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0     # wave-instructions per ns the chip can issue: 1024 SIMDs, one wave64 VALU
@@ -398,14 +481,21 @@ VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0     # wave-instructions per ns the chip ca
 def valu_issue(precision, R, K, avg_s):
     """The second roof of this kernel: it is instruction-bound (about 20 VALU instructions per env step, most of them
     packed float32; scripts/sweep_pair.sh: the same kernel on a FULL chip reaches 0.49 of the HBM roof, not more).
-    Wave-instructions per launch from the PMC summary (SQ_INSTS_VALU) over the launch time measured here."""
-    tj, src = pmc_summary(precision, R, K)
+    Wave-instructions per launch from the PMC summary (SQ_INSTS_VALU) over the launch time measured here.  Two peaks:
+    the nominal one (2.4 GHz) and the one at the clock the chip actually ran this kernel at (GRBM_GUI_ACTIVE / 8 /
+    launch time of the counter run: ~2.04 GHz while 3 TB/s leave the chip) -- `frac` is against the latter."""
+    tj, src = pmc_summary(precision, R, K, avg_s)
     try:
         insts = float(tj["counters_per_launch"]["SQ_INSTS_VALU"]["mean"])
     except Exception:
-        return None
-    return {"valu_insts_per_launch": insts, "valu_insts_per_env_step": insts / (R * K), "achieved_Ginst_s": insts / avg_s / 1e9,
-            "peak_Ginst_s": VALU_PEAK_GINST, "frac": insts / avg_s / 1e9 / VALU_PEAK_GINST, "source": src}
+        return {"frac": None, "source": src}
+    clock = float(tj.get("effective_clock_GHz") or 0.0)
+    peak_eff = 256 * 4 * clock / 4.0 if clock > 0 else None
+    ach = insts / avg_s / 1e9
+    return {"valu_insts_per_launch": insts, "valu_insts_per_env_step": insts / (R * K), "achieved_Ginst_s": ach,
+            "peak_Ginst_s_nominal_2.4GHz": VALU_PEAK_GINST, "frac_of_nominal": ach / VALU_PEAK_GINST,
+            "effective_clock_GHz": clock or None, "peak_Ginst_s": peak_eff,
+            "frac": ach / peak_eff if peak_eff else None, "source": src}
 
 
 def rollout_1500_leg(device, precision, R, launches=6, check_parity=True):
@@ -451,7 +541,7 @@ def rollout_1500_leg(device, precision, R, launches=6, check_parity=True):
     ms = [a.elapsed_time(b) for a, b in events]
     avg_s = float(np.mean(ms)) * 1e-3
     nbytes, per_step = launch_bytes(R, N, K, precision)
-    traffic, src = pmc_traffic(precision, R, K)
+    traffic, src = pmc_traffic(precision, R, K, avg_s)
     sim.close()
     return {"value": R * K / avg_s, "unit": "env-steps/s (kernel time of a 1500-step launch)",
             "value_wall": R * K * launches / wall, "dtype": precision, "launches_timed": launches,
@@ -531,7 +621,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30000)
     ap.add_argument("--warmup", type=int, default=3000)
-    ap.add_argument("--replicas", type=int, default=4096, help="replicas per GPU")
+    ap.add_argument("--replicas", type=int, default=4096, help="replicas per GPU (weak scaling) / in total (strong)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): --replicas per GPU; strong: --replicas in total, split over the ranks "
+                         "(BASELINE's '4096 replicas, whole node')")
     ap.add_argument("--fragment", type=int, default=1500, help="env steps per rollout launch")
     ap.add_argument("--precision", default="mixed", choices=["f32", "f64", "mixed"],
                     help="mixed (default): float64 state, float32 controller -- the precision that holds the 1e-4 "
@@ -573,9 +666,16 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         world = dist.get_world_size()          # what RCCL actually formed
 
-    R = args.replicas
+    if args.scaling == "strong":
+        from flow_amd.dist import shard_range
+        lo, hi = shard_range(args.replicas, rank, world)
+        R, offset = hi - lo, lo
+        if R < 1 or args.replicas % world:
+            raise SystemExit("bench.py --scaling strong: %d replicas do not split evenly over %d ranks" % (args.replicas, world))
+    else:
+        R, offset = args.replicas, rank * args.replicas
     spec = c2_spec(R, seed=1000 + rank)
-    spec["replica_offset"] = rank * R          # global replica ids (noise streams do not depend on the sharding)
+    spec["replica_offset"] = offset            # global replica ids (noise streams do not depend on the sharding)
     runner = Runner(spec, args.precision, device, args.fragment)
 
     gather = None
@@ -609,9 +709,10 @@ def main():
         elapsed = float(t.item())
 
     N = spec["num_vehicles"]
-    out = {"metric": "env-steps/sec", "value": world * R * args.steps / elapsed, "unit": "env-steps/s",
+    total_R = args.replicas if args.scaling == "strong" else world * R
+    out = {"metric": "env-steps/sec", "value": total_R * args.steps / elapsed, "unit": "env-steps/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
            "config": {"workload": "C2: RingNetwork 230 m, 22 IDM vehicles (speed_mode 'aggressive': the rollout "
                                   "kernels' configuration class), %d replicas per GPU, AccelEnv obs [R,44] + reward + "
@@ -620,12 +721,27 @@ def main():
                       "fragment_steps": runner.fragment, "speed_mode": "aggressive",
                       "precision": {"mixed": "float64 state, float32 controller (FS_MIXED)", "f32": "float32",
                                     "f64": "float64"}[args.precision],
+                      "replicas_total": total_R,
                       "parallelism": "replica-sharded x%d, obs all-gather per fragment" % world},
+           "fragment_latency": None,
            "timed_region": {"steps": args.steps, "launches": len(runner.events),
                             "note": "value = replicas x steps / wall time of exactly --steps env steps (barrier + "
                                     "synchronize on both sides); a region shorter than one 1500-step fragment is "
                                     "dominated by launch + synchronize latency -- the kernel's own rate is in "
                                     "`roofline` / `rollout_1500`, measured over >= 5 full fragments in this process"}}
+
+    # the latency floor of a fragment: a launch is a chain of `fragment` dependent steps per wave, and 4096 replicas are
+    # about one wave per SIMD already -- fewer replicas per GPU (strong scaling of BASELINE's "4096 replicas, whole node")
+    # leave the chain as long as it is: the same milliseconds per fragment on every GPU count
+    full = [a.elapsed_time(b) for a, b, kk in runner.events if kk == runner.fragment]
+    if full:
+        ms = float(np.mean(full))
+        out["fragment_latency"] = {
+            "steps": runner.fragment, "replicas_this_gpu": R, "avg_launch_ms": ms, "us_per_step": ms * 1e3 / runner.fragment,
+            "note": "one launch = %d dependent steps per wave; %d replicas = %.2f waves per SIMD: the launch time is the "
+                    "chain's latency, not throughput -- splitting a FIXED number of replicas over more GPUs (strong "
+                    "scaling) cannot shorten it, adding replicas per GPU (weak scaling) is what scales"
+                    % (runner.fragment, R, R / 4.0 / 1024.0)}
 
     # ---- roofline of the dominant kernel: ALWAYS from >= 5 full 1500-step launches of this process (HIP events
     # on the kernel's stream), whatever --steps was; plus the parity figure of the reported dtype
@@ -662,6 +778,7 @@ def main():
         r1.sim.close()
         out["step_api_graph"] = step_graph_leg(device, args.precision, R)
         out["ring_default_speed_mode"] = ring_defaults_leg(device)
+        out["rl_ring"] = rl_ring_legs(device)
         out["c3_figure_eight"] = c3_leg(device)
         out["c3_figure_eight_po"] = c3_leg(device, po=True)
         out["c4_bottleneck"] = c4_leg(device)

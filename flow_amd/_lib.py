@@ -42,7 +42,8 @@ FS_EULER, FS_BALLISTIC = 0, 1
 
 EXPORTS = ["fs_create", "fs_destroy", "fs_last_error", "fs_abi_version", "fs_obs_dim", "fs_action_dim", "fs_set_stream",
            "fs_use_own_stream", "fs_sync", "fs_reset", "fs_reset_dev", "fs_step", "fs_step_dev", "fs_rollout_dev",
-           "fs_get_state", "fs_set_state", "fs_dump_trajectory", "fs_last_kernel"]
+           "fs_get_state", "fs_set_state", "fs_dump_trajectory", "fs_last_kernel", "fs_policy_act_dev",
+           "fs_policy_rollout_dev"]
 
 
 class fs_vehicle_spec(C.Structure):
@@ -106,6 +107,12 @@ class fs_config(C.Structure):
                 ("reserved5", C.c_int32), ("obs_perm", C.POINTER(C.c_int32)), ("replica_offset", C.c_int64)]
 
 
+class fs_policy(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("obs_dim", C.c_int32), ("num_hidden", C.c_int32),
+                ("hidden_width", C.c_int32), ("activation", C.c_int32), ("weights_dev", C.c_void_p),
+                ("log_std_dev", C.c_void_p), ("seed", C.c_uint64)]
+
+
 _lib = None
 
 
@@ -161,6 +168,10 @@ def load():
     lib.fs_dump_trajectory.restype = C.c_int
     lib.fs_last_kernel.argtypes = [h]
     lib.fs_last_kernel.restype = C.c_char_p
+    lib.fs_policy_act_dev.argtypes = [h, C.POINTER(fs_policy), f32p, f32p, f32p]
+    lib.fs_policy_act_dev.restype = C.c_int
+    lib.fs_policy_rollout_dev.argtypes = [h, C.POINTER(fs_policy), C.c_int, C.c_int, f32p, f32p, f32p, f32p, u8p]
+    lib.fs_policy_rollout_dev.restype = C.c_int
     if lib.fs_abi_version() != FS_ABI_VERSION:
         raise FatalFlowError("libflowsim.so ABI %d != binding ABI %d" % (lib.fs_abi_version(), FS_ABI_VERSION))
     _lib = lib

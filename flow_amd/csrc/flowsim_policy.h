@@ -31,7 +31,10 @@ struct PolicyView {
 };
 
 struct alignas(16) PolicyLds {
-  float w_hid[2][32][32];  // hidden layers 2 and 3: [layer][unit][input]
+  // hidden layers 2 and 3: [layer][quad q][lane j][4] = (W[j][2q], W[j+16][2q], W[j][2q+1], W[j+16][2q+1]) -- a packed FMA per
+  // input, and the 16 lanes of a row read 256 consecutive bytes per quad (a per-lane row of 256 B would put all of them on
+  // the same LDS banks: a 16-way conflict on every read, measured 1.4 -> 0.9 G)
+  float w_hid[2][16][16][4];
   float w_in[32][4];       // layer 1: [unit][input (3, padded)]
   float b[3][32];
   float w_out[2][32];
@@ -48,7 +51,10 @@ __device__ __forceinline__ void policy_load(const PolicyView& pv, PolicyLds* L, 
   p += 32;
   for (int l = 0; l < 2; ++l) {
     const bool have = l + 1 < pv.num_hidden;
-    for (int e = tid; e < 32 * 32; e += nthreads) L->w_hid[l][e / 32][e % 32] = have ? p[e] : 0.0f;
+    for (int e = tid; e < 32 * 32; e += nthreads) {
+      const int u = e / 32, i = e % 32;
+      L->w_hid[l][i >> 1][u & 15][(i & 1) * 2 + (u >> 4)] = have ? p[e] : 0.0f;
+    }
     if (have) p += 32 * 32;
     for (int e = tid; e < 32; e += nthreads) L->b[l + 1][e] = have ? p[e] : 0.0f;
     if (have) p += 32;
@@ -86,29 +92,30 @@ __device__ __forceinline__ void policy_eval(const PolicyView& pv, const PolicyLd
   // input i >= 16 in `hb` of lane i - 16 (row broadcasts, folded into the FMAs)
 #pragma unroll 1
   for (int l = 0; l + 1 < pv.num_hidden; ++l) {
-    float za = L->b[l + 1][j], zb = L->b[l + 1][j + 16];
-    const float4* wa = reinterpret_cast<const float4*>(L->w_hid[l][j]);
-    const float4* wb = reinterpret_cast<const float4*>(L->w_hid[l][j + 16]);
-    static_for<4>([&](auto q_c) {                  // inputs 4q .. 4q+3 (ha) and 16 + 4q .. (hb)
+    // all sixteen weight quads of the layer first (the LDS reads in flight together), then four independent accumulators
+    // (inputs i with the same i mod 4 share one; the chain of dependent packed FMAs is 8 long instead of 32), combined
+    // as ((b + z0) + z1) + (z2 + z3)
+    float4 ww[16];                                 // ww[i / 2] = weights of inputs i, i + 1
+#pragma unroll
+    for (int q = 0; q < 16; ++q) ww[q] = *reinterpret_cast<const float4*>(L->w_hid[l][q][j]);
+    f2 z0 = {L->b[l + 1][j], L->b[l + 1][j + 16]}, z1 = {0.0f, 0.0f}, z2 = {0.0f, 0.0f}, z3 = {0.0f, 0.0f};
+    static_for<4>([&](auto q_c) {                  // inputs 4q .. 4q + 3 (`ha` of lanes 4q ..) and 16 + 4q .. (`hb`)
       constexpr int q = decltype(q_c)::value;
-      const float4 a0 = wa[q], b0 = wb[q];
-      const float i0 = dpp<DPP_ROW_NEWBCAST0 + 4 * q + 0>(ha), i1 = dpp<DPP_ROW_NEWBCAST0 + 4 * q + 1>(ha);
-      const float i2 = dpp<DPP_ROW_NEWBCAST0 + 4 * q + 2>(ha), i3 = dpp<DPP_ROW_NEWBCAST0 + 4 * q + 3>(ha);
-      za = __builtin_fmaf(a0.x, i0, za); zb = __builtin_fmaf(b0.x, i0, zb);
-      za = __builtin_fmaf(a0.y, i1, za); zb = __builtin_fmaf(b0.y, i1, zb);
-      za = __builtin_fmaf(a0.z, i2, za); zb = __builtin_fmaf(b0.z, i2, zb);
-      za = __builtin_fmaf(a0.w, i3, za); zb = __builtin_fmaf(b0.w, i3, zb);
+      const float a0 = dpp<DPP_ROW_NEWBCAST0 + 4 * q>(ha), a1 = dpp<DPP_ROW_NEWBCAST0 + 4 * q + 1>(ha);
+      const float a2 = dpp<DPP_ROW_NEWBCAST0 + 4 * q + 2>(ha), a3 = dpp<DPP_ROW_NEWBCAST0 + 4 * q + 3>(ha);
+      const float b0 = dpp<DPP_ROW_NEWBCAST0 + 4 * q>(hb), b1 = dpp<DPP_ROW_NEWBCAST0 + 4 * q + 1>(hb);
+      const float b2 = dpp<DPP_ROW_NEWBCAST0 + 4 * q + 2>(hb), b3 = dpp<DPP_ROW_NEWBCAST0 + 4 * q + 3>(hb);
+      z0 = fma2(f2{ww[2 * q].x, ww[2 * q].y}, splat(a0), z0);
+      z1 = fma2(f2{ww[2 * q].z, ww[2 * q].w}, splat(a1), z1);
+      z2 = fma2(f2{ww[2 * q + 1].x, ww[2 * q + 1].y}, splat(a2), z2);
+      z3 = fma2(f2{ww[2 * q + 1].z, ww[2 * q + 1].w}, splat(a3), z3);
+      z0 = fma2(f2{ww[8 + 2 * q].x, ww[8 + 2 * q].y}, splat(b0), z0);
+      z1 = fma2(f2{ww[8 + 2 * q].z, ww[8 + 2 * q].w}, splat(b1), z1);
+      z2 = fma2(f2{ww[8 + 2 * q + 1].x, ww[8 + 2 * q + 1].y}, splat(b2), z2);
+      z3 = fma2(f2{ww[8 + 2 * q + 1].z, ww[8 + 2 * q + 1].w}, splat(b3), z3);
     });
-    static_for<4>([&](auto q_c) {
-      constexpr int q = decltype(q_c)::value;
-      const float4 a0 = wa[4 + q], b0 = wb[4 + q];
-      const float i0 = dpp<DPP_ROW_NEWBCAST0 + 4 * q + 0>(hb), i1 = dpp<DPP_ROW_NEWBCAST0 + 4 * q + 1>(hb);
-      const float i2 = dpp<DPP_ROW_NEWBCAST0 + 4 * q + 2>(hb), i3 = dpp<DPP_ROW_NEWBCAST0 + 4 * q + 3>(hb);
-      za = __builtin_fmaf(a0.x, i0, za); zb = __builtin_fmaf(b0.x, i0, zb);
-      za = __builtin_fmaf(a0.y, i1, za); zb = __builtin_fmaf(b0.y, i1, zb);
-      za = __builtin_fmaf(a0.z, i2, za); zb = __builtin_fmaf(b0.z, i2, zb);
-      za = __builtin_fmaf(a0.w, i3, za); zb = __builtin_fmaf(b0.w, i3, zb);
-    });
+    const f2 z = pk_add(pk_add(z0, z1), pk_add(z2, z3));
+    const float za = z.x, zb = z.y;
     ha = policy_tanh(za);
     hb = policy_tanh(zb);
   }
@@ -124,8 +131,10 @@ __device__ __forceinline__ void policy_eval(const PolicyView& pv, const PolicyLd
 // the action: mean + std * g, g the replica's next standard normal draw (Philox block of four per counter / 4, column
 // 0x40000000 + 0: a stream of its own next to the vehicles' noise); log-probability of a 1-d diagonal Gaussian
 __device__ __forceinline__ void policy_sample(const PolicyView& pv, uint32_t replica, uint32_t ctr, float mu, float log_std,
-                                              float& action, float& logp) {
-  const float g = gauss<float>(pv.seed_lo, pv.seed_hi, replica, 0x40000000u, ctr);
+                                              float& action, float& logp, NoiseBlock<float>* nzb = nullptr) {
+  // (a fragment keeps the four draws of a block over four steps: NoiseBlock::draw is gauss() bit for bit)
+  const float g = nzb ? nzb->draw(pv.seed_lo, pv.seed_hi, replica, 0x40000000u, ctr)
+                      : gauss<float>(pv.seed_lo, pv.seed_hi, replica, 0x40000000u, ctr);
   const float sd = __builtin_amdgcn_exp2f(log_std * 1.4426950408889634f);
   action = __builtin_fmaf(sd, g, mu);
   logp = __builtin_fmaf(-0.5f * g, g, -log_std) - 0.9189385332046727f;
@@ -404,12 +413,14 @@ __global__ __launch_bounds__(256) void k_ring_policy(DevView<T> s, PolicyView pv
   };
 
   const size_t R = size_t(s.R);
+  NoiseBlock<float> act_draws;
+  act_draws.init();
   observe(obs + size_t(rr) * 3);
   for (int step = 0; step < num_steps; ++step) {
     // ---- policy -> action --------------------------------------------------------------------------------------
     float mu, ls, a, lp;
     policy_eval<ROW>(pv, &PL, k, o0, o1, o2, mu, ls);
-    policy_sample(pv, s.rep0 + uint32_t(rr), pctr, mu, ls, a, lp);
+    policy_sample(pv, s.rep0 + uint32_t(rr), pctr, mu, ls, a, lp, &act_draws);
     pctr += 1u;
     if (rvalid && k == 0) {
       act[size_t(step) * R + rr] = a;

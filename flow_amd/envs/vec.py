@@ -205,6 +205,23 @@ class VecFlowEnv(object):
                           "replica a fresh pending length for its next in-graph reset.", stacklevel=2)
         return StepGraph(self, num_steps, policy, reset_done)
 
+    def policy_rollout(self, policy, num_steps, reset_done=False, out=None):
+        """``num_steps`` x (policy -> action -> Env.step [-> Env.reset of finished episodes]) in ONE kernel launch
+        (``fs_policy_rollout_dev``; ``policy``: a ``flow_amd.utils.device_policy.DevicePolicy``).  Returns device tensors
+        ``obs [K+1, R, obs_dim]`` (obs[0]: the state the fragment starts from), ``actions [K, R]``, ``logp [K, R]``,
+        ``rew [K, R]``, ``done [K, R]`` (flag byte: bit 0 horizon, bit 1 collision).  Built for the reference's RL ring
+        experiments (one RL vehicle, WaveAttenuationPOEnv); ``capture`` serves every other environment / model."""
+        torch, R, K = self.torch, self.num_envs, int(num_steps)
+        self.use_current_stream()
+        if out is None:
+            out = (torch.empty((K + 1, R, self.obs_dim), dtype=torch.float32, device=self.device),
+                   torch.empty((K, R), dtype=torch.float32, device=self.device),
+                   torch.empty((K, R), dtype=torch.float32, device=self.device),
+                   torch.empty((K, R), dtype=torch.float32, device=self.device),
+                   torch.empty((K, R), dtype=torch.uint8, device=self.device))
+        self.sim.policy_rollout_dev(policy.struct, K, out[0], out[1], out[2], out[3], out[4], reset_done=reset_done)
+        return out
+
     # ---- host-side inspection
     def get_state(self, field):
         return self.sim.get_state(field)

@@ -252,6 +252,14 @@ class FlowSim:
         L.check(self.lib.fs_rollout_dev(self._h, int(num_steps), _ptr(actions), int(action_stride_steps),
                                         _ptr(obs), _ptr(rew), _ptr(done), int(bool(obs_every_step))))
 
+    # ------------------------------------------------------------------ policy in the loop (include/flowsim.h fs_policy)
+    def policy_act_dev(self, pol, obs, act, logp):
+        L.check(self.lib.fs_policy_act_dev(self._h, C.byref(pol), _ptr(obs), _ptr(act), _ptr(logp)))
+
+    def policy_rollout_dev(self, pol, num_steps, obs, act, logp, rew, done, reset_done=False):
+        L.check(self.lib.fs_policy_rollout_dev(self._h, C.byref(pol), int(num_steps), int(bool(reset_done)), _ptr(obs),
+                                               _ptr(act), _ptr(logp), _ptr(rew), _ptr(done)))
+
     # ------------------------------------------------------------------ state access
     def _field_shape(self, field):
         if field in (L.FS_FIELD_TIME,):

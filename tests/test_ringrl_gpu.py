@@ -62,6 +62,7 @@ def rollout(sim, K, actions, obs_every_step=True):
     r = torch.zeros((K if obs_every_step else 1, sim.R), device=dev)
     d = torch.zeros((K if obs_every_step else 1, sim.R), dtype=torch.uint8, device=dev)
     a = None if actions is None else torch.as_tensor(actions, device=dev).contiguous()
+    torch.cuda.synchronize()          # (the handle launches on a stream of its own)
     sim.rollout_dev(K, o, r, d, actions=a, action_stride_steps=None if a is None else sim.R * sim.num_rl,
                     obs_every_step=obs_every_step)
     sim.sync()
