@@ -683,9 +683,12 @@ def main():
         from flow_amd.dist import ObservationGather
         gather = ObservationGather(R, runner.obs_dim, world, device)
 
+    last_local = {}
+
     def after_fragment(o, r, d):
         if gather is not None:
             gather.launch(o, r, d)       # overlaps the next fragment; the learner reads gather.result() one fragment late
+            last_local["row"] = (o, r, d)
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -703,10 +706,19 @@ def main():
         gather.wait()
     barrier()
     elapsed = time.perf_counter() - t0
+    gather_check = None
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # the learner's view of this rank's block must be what the rank produced (the last fragment's final step)
+        go, gr, gd = gather.result()
+        lo_, ro_, do_ = last_local["row"]
+        blk = slice(rank * R, (rank + 1) * R)
+        ok = bool(torch.equal(go[blk], lo_) and torch.equal(gr[blk], ro_) and torch.equal(gd[blk], do_ != 0))
+        tt = torch.tensor([1.0 if ok else 0.0], device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+        gather_check = {"gathered_rows": int(go.shape[0]), "rank_blocks_equal_local": bool(tt.item() > 0.5)}
 
     N = spec["num_vehicles"]
     total_R = args.replicas if args.scaling == "strong" else world * R
@@ -723,7 +735,7 @@ def main():
                                     "f64": "float64"}[args.precision],
                       "replicas_total": total_R,
                       "parallelism": "replica-sharded x%d, obs all-gather per fragment" % world},
-           "fragment_latency": None,
+           "fragment_latency": None, "gather_check": gather_check,
            "timed_region": {"steps": args.steps, "launches": len(runner.events),
                             "note": "value = replicas x steps / wall time of exactly --steps env steps (barrier + "
                                     "synchronize on both sides); a region shorter than one 1500-step fragment is "

@@ -82,15 +82,34 @@ def train_on_device(flow_params, replicas=1024, fragment=100, iterations=20, epo
     vec = VecFlowEnv(flow_params, num_replicas=replicas, device=0)
     pi = GaussianPolicy(vec.obs_dim, vec.act_dim).to(dev)
     opt = torch.optim.Adam(pi.parameters(), lr=lr)
-    graph = vec.capture(fragment, policy=pi.act, reset_done=True)
-    graph.begin(vec.reset())
+    # the rollout: ONE kernel per fragment where the library has the fused policy + step form for this experiment and
+    # model (fs_policy_rollout_dev: rings with one RL vehicle, WaveAttenuationPOEnv, 1..3 hidden layers of 32 tanh units);
+    # otherwise K single steps around the torch policy captured as one HIP graph
+    fused, graph = None, None
+    try:
+        from flow_amd.utils.device_policy import DevicePolicy
+        fused = DevicePolicy([pi.mu[0], pi.mu[2]], pi.mu[4], log_std=pi.log_std, seed=seed)
+        vec.reset()
+        vec.policy_rollout(fused, 1, reset_done=True)           # (probe: raises NotImplementedError when not built)
+        vec.reset()
+        log("rollout: fused policy + step kernel (%s)" % vec.sim.last_kernel)
+    except NotImplementedError as e:
+        fused = None
+        log("rollout: HIP graph of %d single steps around the torch policy (%s)" % (fragment, e))
+        graph = vec.capture(fragment, policy=pi.act, reset_done=True)
+        graph.begin(vec.reset())
     K, R = fragment, replicas
     history = []
     for it in range(iterations):
         vec.redraw_ring_lengths()                              # pending ring length per replica for its next in-graph reset
         t0 = time.perf_counter()
-        obs, act, rew, done = graph.replay()                   # K closed-loop steps of R replicas: one graph launch
-        graph.synchronize()
+        if fused is not None:
+            fused.sync()                                       # the optimiser moved the weights: repack them for the kernel
+            obs, act, _, rew, done = vec.policy_rollout(fused, K, reset_done=True)
+            torch.cuda.synchronize(dev)
+        else:
+            obs, act, rew, done = graph.replay()               # K closed-loop steps of R replicas: one graph launch
+            graph.synchronize()
         t_roll = time.perf_counter() - t0
         o, a = obs[:K].reshape(K * R, -1), act.reshape(K * R, -1)
         with torch.no_grad():

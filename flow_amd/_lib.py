@@ -38,7 +38,7 @@ FS_EULER, FS_BALLISTIC = 0, 1
  FS_FIELD_RING_LENGTH, FS_FIELD_INIT_POS, FS_FIELD_INIT_VEL, FS_FIELD_CTRL_STATE, FS_FIELD_LANE,
  FS_FIELD_LAST_LC, FS_FIELD_LEADER, FS_FIELD_INIT_LANE, FS_FIELD_ROUTE, FS_FIELD_SEQ, FS_FIELD_ORIGIN,
  FS_FIELD_FOLLOWER, FS_FIELD_CTL_SEQ, FS_FIELD_COUNTERS, FS_FIELD_ARRIVED_RL, FS_FIELD_MAX_SPEED,
- FS_FIELD_INIT_RING_LENGTH) = range(23)
+ FS_FIELD_INIT_RING_LENGTH, FS_FIELD_SORT_KEY) = range(24)
 
 EXPORTS = ["fs_create", "fs_destroy", "fs_last_error", "fs_abi_version", "fs_obs_dim", "fs_action_dim", "fs_set_stream",
            "fs_use_own_stream", "fs_sync", "fs_reset", "fs_reset_dev", "fs_step", "fs_step_dev", "fs_rollout_dev",

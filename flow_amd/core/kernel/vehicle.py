@@ -238,6 +238,19 @@ class VehicleKernel(object):
             return error
         return fn(self._slot[veh_id])
 
+    # ---- array views (no reference counterpart): what the host-side reward helpers reduce over
+    def slots_of(self, veh_ids=None):
+        """Slot indices (into the simulator's [N] state rows of this replica) of ``veh_ids`` (default: get_ids())."""
+        ids = self.get_ids() if veh_ids is None else veh_ids
+        return np.fromiter((self._slot[v] for v in ids if v in self._slot), dtype=np.int64)
+
+    def speeds(self, veh_ids=None):
+        """float64 array of the speeds of ``veh_ids`` (default: every vehicle in the network), one device read per step."""
+        return self._field(L.FS_FIELD_VEL)[self.slots_of(veh_ids)].astype(np.float64)
+
+    def previous_speeds(self, veh_ids=None):
+        return self._field(L.FS_FIELD_PREV_VEL)[self.slots_of(veh_ids)].astype(np.float64)
+
     def get_speed(self, veh_id, error=-1001):
         return self._vec(veh_id, lambda i: float(self._field(L.FS_FIELD_VEL)[i]), error)
 
@@ -401,6 +414,10 @@ class VehicleKernel(object):
                     df, foll, best_t = behind, self._order[j], behind - self.__vehicles[self._order[i]]["length"]
             out.append((lead, best_h, foll, best_t))
         return out
+
+    def lane_neighbour_table(self, veh_id):
+        """[(leader id, headway, follower id, tailway)] per lane for one vehicle ('' / 1000 where a lane is empty)."""
+        return self._lane_neighbours(self._slot[veh_id])
 
     def get_lane_leaders(self, veh_id, error=None):
         return self._vec(veh_id, lambda i: [t[0] for t in self._lane_neighbours(i)], error)

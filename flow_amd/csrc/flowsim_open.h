@@ -639,8 +639,16 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
   // slot number.  So the structure is re-evaluated when a class changed somewhere in the wave (insertion, arrival, lane
   // change, a join or zipper zone reached) or a vehicle is no longer strictly behind its leader; the positions just
   // fetched for the headway decide that, and the follower state is only touched once it is settled.
+  // (lane-drop network, P > 2: the follower candidates are not kept from sub-step to sub-step -- with followers tracked
+  // there every sub-step evaluates in full -- which keeps those instantiations inside the 256 VGPRs the code-generation
+  // guard holds the float32 kernels to, tests/test_codegen.py)
+  constexpr bool KEEP_FOLL = P == 2;
   auto neighbours = [&](bool live, bool follow) {
     const bool alive = route >= 0;
+    if (!KEEP_FOLL) {
+#pragma unroll
+      for (int q = 0; q < P; ++q) { nb_cand[q] = -1; nb_cseq[q] = 0; nb_celig[q] = false; }
+    }
     T x_l, v_l, x_c[P];
     auto fetch = [&]() {
       const int lsrc = segbase + (has ? lead : ii);
@@ -653,7 +661,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
     const int key_now = alive ? (route | (shift_of(x) << 8)) : 0xffff;
     const bool changed = (key_now != nb_key) | (shift_of(x + o.zip_d) != nb_la) | (has & !(x < x_l));
     // M11 reads gaps on the adjacent lanes every sub-step: with lane changing on, the full evaluation always runs
-    if (lc_on || __ballot(changed) != 0ull) {
+    if (lc_on || (!KEEP_FOLL && follow) || __ballot(changed) != 0ull) {
 #ifdef FS_PHASE_TIMERS
       const long long t0_ = clock64();
       nb_structure();

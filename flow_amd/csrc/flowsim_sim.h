@@ -708,6 +708,7 @@ struct Sim : SimBase {
       case FS_FIELD_MAX_SPEED: *count = open_net ? RN : 0; return open_net ? ov.vmax : nullptr;
       case FS_FIELD_RING_LENGTH: *count = size_t(dv.R); return const_cast<T*>(dv.ring_len);
       case FS_FIELD_INIT_RING_LENGTH: *count = size_t(dv.R); return const_cast<T*>(dv.init_ring_len);
+      case FS_FIELD_SORT_KEY: *count = RN; return dv.sort_key;
       case FS_FIELD_INIT_POS: *count = RN; return const_cast<T*>(dv.init_pos);
       case FS_FIELD_INIT_VEL: *count = RN; return const_cast<T*>(dv.init_vel);
       default: *count = 0; return nullptr;

@@ -139,8 +139,7 @@ class BottleneckAccelEnv(BottleneckEnv):
     the network.  The observation is then the per-edge block only (mean speed / max speed and vehicles per metre for
     every edge of ``get_edge_list()``, the rendering-only "fake_edge" included: 12 numbers), the action space is empty,
     and the reward is ``rewards.desired_velocity`` (the forward-progress and lane-change terms are sums over the RL
-    vehicles).  Both are assembled on the host from the device state (``HOST_HEADS``), statement by statement as the
-    reference does.  With RL vehicles the env needs per-vehicle lane-change commands on the lane-drop network and the
+    vehicles).  Both are host heads over the device state (``HOST_HEADS``): masked reductions over the replica's rows.  With RL vehicles the env needs per-vehicle lane-change commands on the lane-drop network and the
     re-insertion of exited RL vehicles (:733-757): not built, raises at construction."""
 
     HOST_HEADS = True
@@ -175,18 +174,19 @@ class BottleneckAccelEnv(BottleneckEnv):
         return Box(np.array(lb, dtype=np.float32), np.array(ub, dtype=np.float32), dtype=np.float32)
 
     def get_state(self):
-        """:539-640 with an empty RL list: rl_obs and relative_obs are empty, the per-edge block remains."""
-        veh = self.k.vehicle
-        edge_obs = []
-        for edge in self.k.network.get_edge_list():
-            veh_ids = veh.get_ids_by_edge(edge)
-            if len(veh_ids) > 0:
-                avg_speed = (sum(veh.get_speed(veh_ids)) / len(veh_ids)) / self.max_speed
-                density = len(veh_ids) / self.k.network.edge_length(edge)
-                edge_obs += [avg_speed, density]
-            else:
-                edge_obs += [0, 0]
-        return np.asarray(edge_obs, dtype=np.float64)
+        """The per-edge block of :539-640 (with no RL vehicle the rl / relative blocks are empty): for every edge of
+        ``get_edge_list()`` the mean speed over ``max_speed`` and the vehicles per metre -- two masked reductions over
+        the replica's speed row per edge."""
+        veh, net = self.k.vehicle, self.k.network
+        ids = veh.get_ids()
+        on_edge = np.asarray(veh.get_edge(ids), dtype=object)
+        speed = veh.speeds(ids)
+        out = []
+        for edge in net.get_edge_list():
+            here = on_edge == edge
+            n = int(here.sum())
+            out += [speed[here].sum() / n / self.max_speed, n / net.edge_length(edge)] if n else [0., 0.]
+        return np.asarray(out, dtype=np.float64)
 
     def compute_reward(self, rl_actions, **kwargs):
         """:642-649; no RL vehicles: the lane-change penalty and the forward-progress term are empty sums."""

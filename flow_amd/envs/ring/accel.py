@@ -28,8 +28,6 @@ class AccelEnv(Env):
             if p not in env_params.additional_params:
                 raise KeyError('Environment parameter \'{}\' not supplied'.format(p))
         self._sorted_actions = None
-        self.prev_pos = dict()
-        self.absolute_position = dict()
         super().__init__(env_params, sim_params, network, simulator)
 
     @property
@@ -65,34 +63,30 @@ class AccelEnv(Env):
         return np.array(self._last_obs, dtype=np.float64)
 
     def additional_command(self):
-        """accel.py:150-169: observed vehicles, and the running absolute position behind ``sorted_ids``."""
+        """accel.py:150-169: the observed vehicles.  The running absolute position behind ``sorted_ids`` is kept by the
+        step kernel (``fs_config.sort_vehicles``: it ranks observation entries and RL action columns by it)."""
         if self.k.vehicle.num_rl_vehicles > 0:
             for veh_id in self.k.vehicle.get_human_ids():
                 self.k.vehicle.set_observed(veh_id)
-        if self.env_params.additional_params['sort_vehicles']:
-            for veh_id in self.k.vehicle.get_ids():
-                this_pos = self.k.vehicle.get_x_by_id(veh_id)
-                if this_pos == -1001:
-                    self.absolute_position[veh_id] = -1001
-                else:
-                    change = this_pos - self.prev_pos.get(veh_id, this_pos)
-                    self.absolute_position[veh_id] = \
-                        (self.absolute_position.get(veh_id, this_pos) + change) % self.k.network.length()
-                    self.prev_pos[veh_id] = this_pos
 
-    def _get_abs_position(self, veh_id):
-        return self.absolute_position.get(veh_id, -1001)
+    @property
+    def absolute_position(self):
+        """{veh_id: absolute position at the last additional_command}: a view of the kernel's sort key
+        (FS_FIELD_SORT_KEY); the vehicles' own positions while sort_vehicles is off."""
+        vk = self.k.vehicle
+        ids = vk.get_ids()
+        if self.env_params.additional_params['sort_vehicles']:
+            key = self.sim.get_state(L.FS_FIELD_SORT_KEY)[vk.replica]
+            return {v: float(key[s]) for v, s in zip(ids, vk.slots_of(ids))}
+        return {v: vk.get_x_by_id(v) for v in ids}
 
     @property
     def sorted_ids(self):
-        """accel.py:134-148."""
-        if self.env_params.additional_params['sort_vehicles']:
-            return sorted(self.k.vehicle.get_ids(), key=self._get_abs_position)
-        return self.k.vehicle.get_ids()
-
-    def reset(self):
-        obs = super().reset()
-        for veh_id in self.k.vehicle.get_ids():
-            self.absolute_position[veh_id] = self.k.vehicle.get_x_by_id(veh_id)
-            self.prev_pos[veh_id] = self.k.vehicle.get_x_by_id(veh_id)
-        return obs
+        """accel.py:134-148: the ids by absolute position, ties in id order -- the order the kernel writes observations
+        and reads action columns in, derived from ITS key."""
+        vk = self.k.vehicle
+        ids = vk.get_ids()
+        if not self.env_params.additional_params['sort_vehicles']:
+            return ids
+        key = self.sim.get_state(L.FS_FIELD_SORT_KEY)[vk.replica][vk.slots_of(ids)]
+        return [ids[i] for i in np.argsort(key, kind="stable")]

@@ -63,13 +63,15 @@ class LaneChangeAccelEnv(AccelEnv):
 
 
 class LaneChangeAccelPOEnv(LaneChangeAccelEnv):
-    """POMDP version (flow/envs/ring/lane_change_accel.py:163-262): for every RL vehicle the headway, tailway, leader
-    speed and follower speed in EVERY lane, then the RL vehicles' own speeds.  The observation is assembled on the
-    host from the device state through ``k.vehicle.get_lane_*`` (the per-lane lists of vehicle/traci.py:699-950),
-    statement by statement as the reference does it -- including that the headways and tailways go into the vector in
-    metres (the reference normalises a list it has already copied from), the trailing ego speed in m/s, and that its
-    ``return`` sits INSIDE the loop over the RL vehicles (:262): only the first RL vehicle's block is filled and one
-    ego speed appended (``RETURN_IN_LOOP_QUIRK``; False = all RL vehicles, the evident intent)."""
+    """POMDP version (flow/envs/ring/lane_change_accel.py:163-262): for every RL vehicle the gap to and the speed of
+    its nearest leader and follower in EVERY lane, then the RL vehicles' own speeds.
+
+    A host head over the multi-lane kernel's state (``HOST_HEADS``: the step runs in ``k_steps_ml``, the observation is
+    a handful of array reductions per RL vehicle on the replica's position / lane / speed rows).  What the reference's
+    vector holds, kept as is: gaps in METRES with 1000 for an empty lane (its normalisation divides a list it has
+    already copied from, :236-247), neighbour speeds over ``max_speed`` with 0 for an empty lane, the ego speed in m/s;
+    and its ``return`` sits inside the loop over the RL vehicles (:262), so only the FIRST RL vehicle's block is filled
+    and one ego speed appended -- ``RETURN_IN_LOOP_QUIRK`` (False: every RL vehicle, the evident intent)."""
 
     HOST_HEADS = True
     RETURN_IN_LOOP_QUIRK = True
@@ -86,39 +88,23 @@ class LaneChangeAccelPOEnv(LaneChangeAccelEnv):
 
     def get_state(self):
         veh = self.k.vehicle
-        obs = [0 for _ in range(4 * veh.num_rl_vehicles * self.num_lanes)]
+        rl_ids = veh.get_rl_ids()
+        lanes, max_speed = self.num_lanes, self.k.network.max_speed()
+        shown = rl_ids[:1] if self.RETURN_IN_LOOP_QUIRK else rl_ids
+        blocks = np.zeros((len(rl_ids), 4, lanes))
         self.visible = []
-        for i, rl_id in enumerate(veh.get_rl_ids()):
-            max_length = self.k.network.length()
-            max_speed = self.k.network.max_speed()
-            headway = [1] * self.num_lanes
-            tailway = [1] * self.num_lanes
-            vel_in_front = [0] * self.num_lanes
-            vel_behind = [0] * self.num_lanes
-            lane_leaders = veh.get_lane_leaders(rl_id)
-            lane_followers = veh.get_lane_followers(rl_id)
-            lane_headways = veh.get_lane_headways(rl_id)
-            lane_tailways = veh.get_lane_tailways(rl_id)
-            headway[0:len(lane_headways)] = lane_headways
-            tailway[0:len(lane_tailways)] = lane_tailways
-            for j, lane_leader in enumerate(lane_leaders):
-                if lane_leader != '':
-                    lane_headways[j] /= max_length
-                    vel_in_front[j] = veh.get_speed(lane_leader) / max_speed
-                    self.visible.extend([lane_leader])
-            for j, lane_follower in enumerate(lane_followers):
-                if lane_follower != '':
-                    lane_headways[j] /= max_length
-                    vel_behind[j] = veh.get_speed(lane_follower) / max_speed
-                    self.visible.extend([lane_follower])
-            obs[4 * self.num_lanes * i:4 * self.num_lanes * (i + 1)] = \
-                np.concatenate((headway, tailway, vel_in_front, vel_behind))
-            obs.append(veh.get_speed(rl_id))
-            if self.RETURN_IN_LOOP_QUIRK:
-                return np.array(obs)
-        return np.array(obs) if not self.RETURN_IN_LOOP_QUIRK else None
+        for row, rl_id in zip(blocks, shown):
+            table = veh.lane_neighbour_table(rl_id)          # [(leader, headway, follower, tailway)] per lane
+            row[0] = [t[1] for t in table] + [1] * (lanes - len(table))
+            row[1] = [t[3] for t in table] + [1] * (lanes - len(table))
+            for col, ids in ((2, [t[0] for t in table]), (3, [t[2] for t in table])):
+                seen = [v for v in ids if v != '']
+                row[col, [j for j, v in enumerate(ids) if v != '']] = np.asarray(veh.get_speed(seen)) / max_speed
+                self.visible.extend(seen)
+        ego = veh.get_speed(list(shown))
+        return np.concatenate((blocks.reshape(-1), np.asarray(ego, dtype=np.float64)))
 
     def additional_command(self):
-        """lane_change_accel.py:257-262."""
+        """lane_change_accel.py:257-262: the neighbours that entered the observation are the observed vehicles."""
         for veh_id in self.visible:
             self.k.vehicle.set_observed(veh_id)

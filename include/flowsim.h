@@ -128,6 +128,8 @@ enum fs_field {
                               get_outflow_rate inputs, vehicle/traci.py:493-533) */
   FS_FIELD_ARRIVED_RL = 20,/* int32[R,N] 1: the RL vehicle of this slot arrived in the last sub-step (get_arrived_rl_ids) */
   FS_FIELD_MAX_SPEED = 21, /* real[R,N]  get_max_speed / set_max_speed: maxSpeed of the SUMO car-following model */
+  FS_FIELD_SORT_KEY = 23,  /* real[R,N] AccelEnv.absolute_position as of the last additional_command (sort_vehicles only,
+                              flow/envs/ring/accel.py:150-169): the key the kernel ranks observations and actions by */
   FS_FIELD_INIT_RING_LENGTH = 22 /* real[R] the ring length a replica takes at its NEXT reset (WaveAttenuationEnv.reset
                               draws a new length per episode, flow/envs/ring/wave_attenuation.py:157-210): fs_reset[_dev]
                               copies it into FS_FIELD_RING_LENGTH for the replicas it resets, so a reset inside a

@@ -60,3 +60,51 @@ def test_float32_step_kernels_use_no_agprs(device_asm):
     pair = [r for n, r in table.items() if "k_rollout_pair" in n]
     # (the FS_MIXED instantiation with speed-mode clamps is the largest: float64 state + two controllers' constants)
     assert pair and max(r["num_vgpr"] for r in pair) <= 192 and all(r.get("num_agpr", 0) == 0 for r in pair)
+
+
+def test_hand_written_pair_step_keeps_its_registers(device_asm):
+    """flowsim_pair.h pins v112..v147 by name inside its asm blocks (flowsim_pair_step_a*.inc): the values that live
+    across the blocks (speeds, positions, headways, v - v_leader: v[112:119]) are operands bound to those registers.
+    The assignment was validated on ROCm VALIDATED_ROCM; a compiler that stopped honouring the pins, or that started to
+    park something of its own in them between the blocks, would corrupt the step silently on the CPU box (the GPU
+    parity tests would catch it a round late).  Checked on the disassembly of the hot float32 instantiation:
+      * the toolchain is the validated release;
+      * between the asm blocks of the unrolled 16-step body the compiler's own instructions never WRITE v112..v119 and
+        never read a temporary both blocks clobber (v124..v127, v130..v133) that it has not written itself since the
+        last block (the blocks' outputs -- v[128:129], the `=&v` operand of part A -- are the compiler's to read);
+      * no vector-memory LOAD appears inside that body (nothing asynchronous can feed a block)."""
+    from flow_amd import build
+    ver = subprocess.run([build.find_hipcc(), "--version"], capture_output=True, text=True).stdout
+    m = re.search(r"HIP version: (\d+\.\d+)", ver)
+    assert m and m.group(1) == build.VALIDATED_ROCM, "the hand-written register assignment was validated on ROCm %s: " \
+        "re-validate (tests/test_pair_gpu.py on a GPU) and bump flow_amd/build.py VALIDATED_ROCM" % build.VALIDATED_ROCM
+    name = re.search(r"^(_ZN2fs14k_rollout_pairIfLi16ELb1ELb1ELb0ELb0ELb0EE\S+?):", device_asm, re.M).group(1)
+    body = device_asm[device_asm.index("\n" + name + ":"):]
+    body = body[:body.index(".set " + name)]
+    first, last = body.index(";;#ASMSTART"), body.rindex(";;#ASMEND")
+    assert body.count(";;#ASMSTART") == body.count(";;#ASMEND") >= 32          # 16 unrolled steps x (part A, part B)
+    outside = re.split(r";;#ASMSTART.*?;;#ASMEND", body[first:last + len(";;#ASMEND")], flags=re.S)
+
+    def regs(tok):
+        out = []
+        for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", tok):
+            out += list(range(int(a), int(b) + 1))
+        out += [int(a) for a in re.findall(r"\bv(\d+)\b", tok)]
+        return out
+
+    for seg in outside:
+        written = set()
+        for line in seg.split("\n"):
+            t = line.strip()
+            if not t or t.startswith(";") or t.startswith(".") or t.endswith(":") or t.startswith("s_"):
+                continue
+            assert not t.startswith(("global_load", "buffer_load", "flat_load", "scratch_load")), t
+            op, _, rest = t.partition(" ")
+            args = rest.split(",")
+            is_store = op.startswith(("buffer_store", "global_store", "ds_write"))
+            dst = [] if is_store else regs(args[0])
+            src = regs(rest) if is_store else regs(",".join(args[1:]))
+            assert not any(112 <= r <= 119 for r in dst), "compiler code writes a pinned state register: " + t
+            stale = [r for r in src if (124 <= r <= 127 or 130 <= r <= 133) and r not in written]
+            assert not stale, "compiler code reads a clobbered temporary of the asm blocks: " + t
+            written.update(dst)
