@@ -166,12 +166,13 @@ def c3_leg(device, R=4096, steps=3000, po=False):
                         "random actions" % ("WaveAttenuationPOEnv" if po else "AccelEnv")}
 
 
-def c5_leg(device, R=1024, env_steps=600):
+def c5_leg(device, R=1024, env_steps=600, precision="f32"):
     """BASELINE configs[4] (informational, not the headline): MergeNetwork pre_merge 500 m, 5 initial humans +
     inflows 1800 / 200 (RL) / 100 veh/h, sim_step 0.2, sims_per_step 5, horizon 600, MultiAgentMergePOEnv head
     (examples/exp_configs/rl/multiagent/multiagent_merge.py); 1024 replicas per GPU = 8192 over 8 GPUs; the
-    open-network kernel k_steps_open, 64 vehicle slots per replica.  fp32 state (BASELINE names fp16 state /
-    fp32 integrator: the state arrays here are fp32, nothing is stored in fp16)."""
+    open-network kernel k_steps_open, 64 vehicle slots per replica.  ``precision="f16s"`` is the configuration as BASELINE
+    names it -- fp16 state, fp32 integrator: positions (two halves) and speeds (one) are kept as IEEE halves in HBM
+    between launches, a launch steps in float32 (include/flowsim.h FS_F16S); "f32" keeps float32 state."""
     import torch
     from flow_amd import _lib as L
     from flow_amd.controllers import IDMController, RLController
@@ -193,7 +194,7 @@ def c5_leg(device, R=1024, env_steps=600):
     inflow.add(veh_type="rl", edge="inflow_highway", vehs_per_hour=200, depart_lane="free", depart_speed=10)
     inflow.add(veh_type="human", edge="inflow_merge", vehs_per_hour=100, depart_lane="free", depart_speed=7.5)
     fp = dict(exp_tag="multiagent_merge", env_name=MultiAgentMergePOEnv, network=MergeNetwork, simulator="traci",
-              sim=SumoParams(sim_step=0.2, render=False, restart_instance=True, seed=11),
+              sim=SumoParams(sim_step=0.2, render=False, restart_instance=True, seed=11, precision=precision),
               env=EnvParams(horizon=600, sims_per_step=5, warmup_steps=0,
                             additional_params={"max_accel": 1.5, "max_decel": 1.5, "target_velocity": 20}),
               net=NetParams(inflows=inflow, additional_params=add), veh=veh)
@@ -213,7 +214,7 @@ def c5_leg(device, R=1024, env_steps=600):
     cnt = vec.sim.get_state(L.FS_FIELD_COUNTERS)
     route = vec.sim.get_state(L.FS_FIELD_ROUTE)
     res = {"value": R * K * 5 / dt, "unit": "env-steps/s (simulation sub-steps)", "env_steps": K, "sims_per_step": 5,
-           "replicas": R, "gym_steps_per_s": R * K / dt, "obs_dim": vec.obs_dim,
+           "replicas": R, "gym_steps_per_s": R * K / dt, "obs_dim": vec.obs_dim, "state": precision,
            "vehicles_in_network_mean": float((route >= 0).sum(axis=1).mean()),
            "departed_mean": float(cnt[:, 6].mean()), "arrived_mean": float(cnt[:, 5].mean()),
            "workload": "C5: MergeNetwork pre_merge 500 m, inflows 1800 + 200 RL + 100 veh/h, 64 slots, "
@@ -795,6 +796,7 @@ def main():
         out["c3_figure_eight_po"] = c3_leg(device, po=True)
         out["c4_bottleneck"] = c4_leg(device)
         out["c5_merge"] = c5_leg(device)
+        out["c5_merge_fp16_state"] = c5_leg(device, precision="f16s")
         out["cpu_baseline"] = cpu_baseline(lambda r: c2_spec(r, seed=1000))
     elif world == 1 and rank == 0:
         out["cpu_baseline"] = None

@@ -18,7 +18,7 @@ FS_MAX_CTRL_PARAMS = 8
 # error codes
 FS_OK, FS_ERR_INVALID, FS_ERR_UNSUPPORTED, FS_ERR_HIP, FS_ERR_NOSPACE = 0, -1, -2, -3, -4
 # enum fs_precision
-FS_F32, FS_F64, FS_MIXED = 0, 1, 2
+FS_F32, FS_F64, FS_MIXED, FS_F16S = 0, 1, 2, 3
 # enum fs_controller
 (FS_CTRL_SIM, FS_CTRL_RL, FS_CTRL_IDM, FS_CTRL_CFM, FS_CTRL_BCM, FS_CTRL_LAC, FS_CTRL_OVM,
  FS_CTRL_LINEAR_OVM, FS_CTRL_GIPPS, FS_CTRL_FOLLOWER_STOPPER, FS_CTRL_NONLOCAL_FOLLOWER_STOPPER,

@@ -181,7 +181,8 @@ class SumoParams(SimParams):
                     lanes (the simplified model M11, NOT LC2013)
     junction_length length of each internal edge (netconvert output in the reference)
     crash_gap       a replica crashes when a bumper gap falls below this after a move
-    precision       'f32' | 'f64' arithmetic and state type of the kernels; 'mixed' (float64 state, float32
+    precision       'f32' | 'f64' arithmetic and state type of the kernels; 'f16s' (merge network: half state in HBM
+                    between launches, float32 integrator -- include/flowsim.h FS_F16S); 'mixed' (float64 state, float32
                     controller: all-IDM single-lane rings, holds 1e-4 of the float64 trajectories at f32 cost)
     """
 

@@ -12,8 +12,11 @@ int validate(const fs_config* c) {
   if (c->struct_size != sizeof(fs_config))
     return fail(FS_ERR_INVALID, "fs_create: struct_size mismatch (header/library out of sync)");
   if (c->abi_version != FS_ABI_VERSION) return fail(FS_ERR_INVALID, "fs_create: abi_version mismatch");
-  if (c->precision != FS_F32 && c->precision != FS_F64 && c->precision != FS_MIXED)
+  if (c->precision != FS_F32 && c->precision != FS_F64 && c->precision != FS_MIXED && c->precision != FS_F16S)
     return fail(FS_ERR_INVALID, "fs_create: bad precision");
+  if (c->precision == FS_F16S && (c->network != FS_NET_MERGE || c->num_vehicles > 64))
+    return fail(FS_ERR_UNSUPPORTED, "fs_create: FS_F16S (half state, float32 integrator) is built for FS_NET_MERGE "
+                                    "(k_steps_open, <= 64 vehicle slots)");
   if (c->precision == FS_MIXED) {
     // float64 state, float32 controllers: k_rollout_pair (all-IDM AccelEnv rollout) and k_ring_pair (IDM + RL vehicles,
     // AccelEnv / WaveAttenuationPOEnv, warm-up steps and masked resets included).  Name the field that does not fit.
@@ -223,6 +226,7 @@ int create_typed(const fs_config* cfg, fs_handle* out) {
   if (!s) return fail(FS_ERR_HIP, "fs_create: out of host memory");
   s->cfg = *cfg;
   s->mixed = cfg->precision == FS_MIXED;
+  s->f16s = cfg->precision == FS_F16S;
   s->veh.assign(cfg->vehicles, cfg->vehicles + cfg->num_vehicles);
   if (cfg->num_segments > 0) s->segs.assign(cfg->segments, cfg->segments + cfg->num_segments);
   if (cfg->obs_perm) s->obs_perm.assign(cfg->obs_perm, cfg->obs_perm + cfg->num_vehicles);
@@ -335,7 +339,8 @@ int fs_create(const fs_config* cfg, fs_handle* out) {
   if (rc) return rc;
   int prev = -1;
   const bool have_prev = hipGetDevice(&prev) == hipSuccess;
-  rc = cfg->precision == FS_F32 ? create_typed<float>(cfg, out) : create_typed<double>(cfg, out);
+  rc = (cfg->precision == FS_F32 || cfg->precision == FS_F16S) ? create_typed<float>(cfg, out)
+                                                                 : create_typed<double>(cfg, out);
   if (have_prev && prev != cfg->device) (void)hipSetDevice(prev);      // the caller's current device is not ours to change
   return rc;
 }
@@ -490,7 +495,7 @@ int fs_dump_trajectory(fs_handle h, int replica, const char* csv_path) {
   if (replica < 0 || replica >= s->cfg.num_replicas) return fail(FS_ERR_INVALID, "fs_dump_trajectory: replica out of range");
   DeviceGuard guard(s->cfg.device);
   const size_t R = size_t(s->cfg.num_replicas), N = size_t(s->cfg.num_vehicles);
-  const bool f32 = s->cfg.precision == FS_F32;
+  const bool f32 = s->cfg.precision == FS_F32 || s->cfg.precision == FS_F16S;
   const size_t el = f32 ? sizeof(float) : sizeof(double);
   std::vector<char> pos(R * N * el), vel(R * N * el);
   std::vector<int32_t> tc(R), lane(R * N, 0);

@@ -57,6 +57,9 @@ struct DevView {
   const T* init_vel;
   const T* ring_len;    // [R]
   const T* init_ring_len;   // [R] the length a replica takes at its next reset (FS_FIELD_INIT_RING_LENGTH)
+  // FS_F16S: the state of record between launches, IEEE halves: [0 .. RN) position hi, [RN .. 2RN) position lo
+  // (x = hi + lo), [2RN .. 3RN) speed; NULL otherwise.  pos / vel (float32) are then staging for reset and host access.
+  uint16_t* st16;
   // per-slot tables, [N]
   const int32_t* ctrl;
   const int32_t* failsafe;
@@ -90,6 +93,37 @@ struct DevView {
   T seg_start[FS_MAX_SEGMENTS], seg_flow_start[FS_MAX_SEGMENTS], seg_flow_slope[FS_MAX_SEGMENTS];
   T ja_in, ja_out, jb_in, jb_out, j_lookahead, j_time_gap, za_lo, za_hi, zb_lo, zb_hi;
 };
+
+// FS_F16S: a position as two halves (hi = RN16(x), lo = RN16(x - hi): 22 significant bits), a speed as one
+__device__ __forceinline__ float half_bits_to_float(uint16_t b) { return float(__builtin_bit_cast(_Float16, b)); }
+__device__ __forceinline__ uint16_t float_to_half_bits(float f) { return __builtin_bit_cast(uint16_t, _Float16(f)); }
+template <typename T>
+__device__ __forceinline__ void state16_load(const DevView<T>& s, size_t e, T& x, T& v) {
+  const size_t RN = size_t(s.R) * s.N;
+  x = T(half_bits_to_float(s.st16[e]) + half_bits_to_float(s.st16[RN + e]));
+  v = T(half_bits_to_float(s.st16[2 * RN + e]));
+}
+template <typename T>
+__device__ __forceinline__ void state16_store(const DevView<T>& s, size_t e, T x, T v) {
+  const size_t RN = size_t(s.R) * s.N;
+  const uint16_t hi = float_to_half_bits(float(x));
+  s.st16[e] = hi;
+  s.st16[RN + e] = float_to_half_bits(float(x) - half_bits_to_float(hi));
+  s.st16[2 * RN + e] = float_to_half_bits(float(v));
+}
+// the float32 staging arrays <-> the half state (reset, fs_set_state / fs_get_state)
+template <typename T>
+__global__ void k_state16_pack(DevView<T> s, const uint8_t* __restrict__ mask) {
+  const size_t n = size_t(s.R) * s.N;
+  for (size_t e = size_t(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += size_t(gridDim.x) * blockDim.x)
+    if (mask == nullptr || mask[e / s.N] != 0) state16_store(s, e, s.pos[e], s.vel[e]);
+}
+template <typename T>
+__global__ void k_state16_unpack(DevView<T> s) {
+  const size_t n = size_t(s.R) * s.N;
+  for (size_t e = size_t(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += size_t(gridDim.x) * blockDim.x)
+    state16_load(s, e, s.pos[e], s.vel[e]);
+}
 
 // done flag of a step (envs/base.py:398-400 `done = time_counter >= horizon limit or crash`): non-zero = done, and
 // the two reasons stay readable -- bit 0: the horizon was reached, bit 1: a collision ended the episode (so a crash

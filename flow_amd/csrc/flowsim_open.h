@@ -364,6 +364,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
 
   T x = s.pos[idx];
   T v = s.vel[idx];
+  if (s.st16 != nullptr) state16_load(s, idx, x, v);       // FS_F16S: the state of record is the half arrays
   int route = slot_ok ? s.lane[idx] : -1;
   int seq = o.seq[idx];
   int origin = o.origin[idx];
@@ -1139,8 +1140,11 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
   }
 
   if (valid && live_replica) {
-    s.pos[idx] = x;
-    s.vel[idx] = v;
+    if (s.st16 != nullptr) state16_store(s, idx, x, v);
+    else {
+      s.pos[idx] = x;
+      s.vel[idx] = v;
+    }
     s.lane[idx] = route;
     s.prev_vel[idx] = prev_v;
     s.accel[idx] = last_acc;

@@ -70,6 +70,7 @@ struct SimBase {
   bool force_generic = false;   // FLOWSIM_FORCE_GENERIC=1: never take the specialised kernels (tests)
   bool no_fastdiv = false;      // FLOWSIM_NO_FASTDIV=1: keep the IEEE division sequence in k_rollout_idm
   int rollout_block = 512;      // threads per block of k_rollout_idm (FLOWSIM_ROLLOUT_BLOCK overrides; sweep: DESIGN.md)
+  bool f16s = false;            // FS_F16S: the state between launches is kept as halves (DevView::st16)
   bool mixed = false;           // FS_MIXED: float64 state, float32 controller arithmetic (k_rollout_pair<double>)
   bool no_pair = false;         // FLOWSIM_NO_PAIR=1: keep k_rollout_idm (one vehicle per lane) for the float rollout
   bool no_loop_kernel = false;  // FLOWSIM_NO_LOOP_KERNEL=1: keep the generic k_steps for segment-table loops (tests)
@@ -156,6 +157,8 @@ struct Sim : SimBase {
     if ((rc = upload(&dv.init_vel, ivel))) return rc;
     if ((rc = upload(&dv.ring_len, rlen))) return rc;
     if ((rc = upload(&dv.init_ring_len, rlen))) return rc;
+    dv.st16 = nullptr;
+    if (f16s && (rc = dev_alloc(&dv.st16, 3 * RN))) return rc;
     h_ring_len = rlen;
 
     std::vector<int32_t> ctrl(N), fsafe(N), smode(N), rli(N), pisi(N, -1);
@@ -685,6 +688,7 @@ struct Sim : SimBase {
       int blocks_open = int((n_open + 255) / 256);
       if (blocks_open > 2048) blocks_open = 2048;
       hipLaunchKernelGGL((fs::k_reset_open<T>), dim3(blocks_open), dim3(256), 0, stream, dv, ov, mask);
+      if (dv.st16) hipLaunchKernelGGL((fs::k_state16_pack<T>), dim3(blocks_open), dim3(256), 0, stream, dv, mask);
       HIP_TRY(hipGetLastError());
       return FS_OK;
     }
@@ -716,6 +720,10 @@ struct Sim : SimBase {
   }
 
   int get_state(int field, void* dst, size_t bytes) override {
+    if (dv.st16 && (field == FS_FIELD_POS || field == FS_FIELD_VEL)) {     // the halves -> the float32 staging arrays
+      hipLaunchKernelGGL((fs::k_state16_unpack<T>), dim3(256), dim3(256), 0, stream, dv);
+      HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipStreamSynchronize(stream));
     if (field == FS_FIELD_TIME) {
       if (bytes != size_t(dv.R) * sizeof(int32_t)) return fail(FS_ERR_INVALID, "FS_FIELD_TIME: wrong byte count");
@@ -835,6 +843,17 @@ struct Sim : SimBase {
       for (size_t e = 0; e < count; ++e) neg = neg || !(vals[e] >= T(-100));
       if (field == FS_FIELD_INIT_VEL) init_vel_negative = neg;
       neg_speed_possible = neg_speed_possible || neg;
+    }
+    if (dv.st16 && (field == FS_FIELD_POS || field == FS_FIELD_VEL)) {
+      // one of the two staging arrays was just overwritten: bring the OTHER one up to date from the halves first, then
+      // pack both (a float32 value that is no half is rounded here, as every launch boundary does)
+      std::vector<T> keep(count);
+      HIP_TRY(hipMemcpy(keep.data(), p, bytes, hipMemcpyDeviceToHost));
+      hipLaunchKernelGGL((fs::k_state16_unpack<T>), dim3(256), dim3(256), 0, stream, dv);
+      HIP_TRY(hipStreamSynchronize(stream));
+      HIP_TRY(hipMemcpy(p, keep.data(), bytes, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL((fs::k_state16_pack<T>), dim3(256), dim3(256), 0, stream, dv, static_cast<const uint8_t*>(nullptr));
+      HIP_TRY(hipGetLastError());
     }
     if (open_net && (field == FS_FIELD_POS || field == FS_FIELD_VEL))   // refresh the leader / headway snapshot
       return launch_steps(0, nullptr, nullptr, 0, d_obs, d_rew, d_done, 0);

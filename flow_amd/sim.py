@@ -12,7 +12,7 @@ import numpy as np
 from . import _lib as L
 
 PRECISIONS = {"f32": L.FS_F32, "float32": L.FS_F32, "f64": L.FS_F64, "float64": L.FS_F64,
-              np.float32: L.FS_F32, np.float64: L.FS_F64, "mixed": L.FS_MIXED}
+              np.float32: L.FS_F32, np.float64: L.FS_F64, "mixed": L.FS_MIXED, "f16s": L.FS_F16S}
 INTEGRATORS = {"euler": L.FS_EULER, "ballistic": L.FS_BALLISTIC}
 
 VEHICLE_DEFAULTS = dict(controller=L.FS_CTRL_SIM, fail_safe=L.FS_FAILSAFE_NONE, speed_mode=0, rl_index=-1,
@@ -49,7 +49,7 @@ class FlowSim:
         self.N = int(spec["num_vehicles"])
         self.num_rl = int(spec.get("num_rl", 0))
         self.precision = PRECISIONS[precision]
-        self.real = np.float32 if self.precision == L.FS_F32 else np.float64      # type of the state fields
+        self.real = np.float32 if self.precision in (L.FS_F32, L.FS_F16S) else np.float64      # type of the state fields
         self.device = int(device)
         self._h = C.c_void_p()
 

@@ -45,7 +45,15 @@ extern "C" {
  * float32 on their rounded images -- within 1e-4 of the float64 trajectories over a 1500-step episode at
  * float32 cost.  Built for the rollout path of all-IDM single-lane rings (AccelEnv head); state fields are
  * float64 as for FS_F64. */
-enum fs_precision { FS_F32 = 0, FS_F64 = 1, FS_MIXED = 2 };
+enum fs_precision { FS_F32 = 0, FS_F64 = 1, FS_MIXED = 2,
+                    FS_F16S = 3    /* "fp16 state, fp32 integrator" (BASELINE configs[4]): the positions and speeds a handle
+                                      keeps in HBM BETWEEN launches are IEEE half values -- a speed is one half, a position
+                                      two (x = hi + lo, 22 significant bits: a single half has a 0.5 m ulp at 700 m) -- and a
+                                      launch loads them into float32 registers, steps in float32 exactly as FS_F32 does, and
+                                      stores halves again.  6 bytes of state per vehicle instead of 8; every launch boundary
+                                      rounds the speeds to 11 bits (<= 0.008 m/s below 32 m/s).  Built for FS_NET_MERGE
+                                      (the configuration BASELINE names); fs_get_state / fs_set_state speak float32. */
+};
 
 /* acceleration controllers, flow/controllers/__init__.py */
 enum fs_controller {
