@@ -458,8 +458,12 @@ def pmc_summary(precision, R, K, avg_s=None):
         tj = json.load(open(path))
     except Exception as e:
         return None, "%s unreadable: %s" % (os.path.basename(path), e)
-    # rocprofv3 prints the kernel as "void fs::k_...<...>(args)": the bench line's name is a substring of it
-    if not (tj.get("replicas") == R and tj.get("steps_per_launch") == K and KERNEL_NAMES[precision] in tj.get("kernel", "")):
+    # rocprofv3 prints the kernel as "void fs::k_...<...>(args)", with or without the defaulted template arguments
+    # (SM = false, NOISE = false): the bench line's name must be that instantiation
+    want = KERNEL_NAMES[precision]
+    printed = tj.get("kernel", "")
+    same_kernel = want in printed or (want[:-1] + ", false, false>") in printed
+    if not (tj.get("replicas") == R and tj.get("steps_per_launch") == K and same_kernel):
         return None, "%s describes another kernel / launch shape" % os.path.basename(path)
     if avg_s is not None:
         ref_s = float(tj.get("avg_launch_ns_kernel_trace", 0.0)) * 1e-9

@@ -125,7 +125,13 @@ int validate(const fs_config* c) {
       if (!(c->segments[k].start > c->segments[k - 1].start))
         return fail(FS_ERR_INVALID, "fs_create: segment starts must increase");
   }
-  if (c->env < FS_ENV_ACCEL || c->env > FS_ENV_BOTTLENECK) return fail(FS_ERR_INVALID, "fs_create: bad env");
+  if (c->env < FS_ENV_ACCEL || c->env > FS_ENV_ACCEL_PO_MA) return fail(FS_ERR_INVALID, "fs_create: bad env");
+  if (c->env == FS_ENV_WAVE_ATTENUATION_PO_MA || c->env == FS_ENV_ACCEL_PO_MA) {
+    if (open_net || c->num_lanes > 1)
+      return fail(FS_ERR_UNSUPPORTED, "fs_create: the multi-agent ring heads are built for single-lane closed loops");
+    if (c->num_rl < 1) return fail(FS_ERR_INVALID, "fs_create: a multi-agent ring env needs an RL vehicle");
+    if (c->sort_vehicles || c->obs_perm) return fail(FS_ERR_INVALID, "fs_create: sort_vehicles / shuffled ids belong to AccelEnv");
+  }
   if (c->num_lanes > 1 && c->env == FS_ENV_WAVE_ATTENUATION_PO)
     return fail(FS_ERR_UNSUPPORTED, "fs_create: WaveAttenuationPOEnv on a multi-lane ring is not built");
   if (c->num_lanes > 64) return fail(FS_ERR_INVALID, "fs_create: num_lanes > 64");
@@ -239,6 +245,8 @@ int create_typed(const fs_config* cfg, fs_handle* out) {
     }
   }
   s->obs_dim = (cfg->env == FS_ENV_WAVE_ATTENUATION_PO) ? 3
+               : (cfg->env == FS_ENV_WAVE_ATTENUATION_PO_MA) ? 3 * cfg->num_rl
+               : (cfg->env == FS_ENV_ACCEL_PO_MA) ? 6 * cfg->num_rl
                : (cfg->env == FS_ENV_BOTTLENECK_DV) ? 4 * cfg->num_obs_cells + 1
                : (cfg->env == FS_ENV_BOTTLENECK) ? 1
                : (cfg->env == FS_ENV_MERGE_PO || cfg->env == FS_ENV_MERGE_MA)

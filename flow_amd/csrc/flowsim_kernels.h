@@ -989,8 +989,37 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps_arg, c
 
   const T dt = s.dt;
   const int env = FAST ? int(FS_ENV_ACCEL) : s.env;
-  const int obs_dim = (env == FS_ENV_WAVE_ATTENUATION_PO) ? 3 : 2 * N;
+  const bool ma_wa = !FAST && env == FS_ENV_WAVE_ATTENUATION_PO_MA, ma_acc = !FAST && env == FS_ENV_ACCEL_PO_MA;
+  const int obs_dim = (env == FS_ENV_WAVE_ATTENUATION_PO) ? 3 : (ma_wa ? 3 * s.num_rl : (ma_acc ? 6 * s.num_rl : 2 * N));
   const int sims_per_step = FAST ? 1 : s.sims_per_step;
+  // the multi-agent ring heads (flow/envs/multiagent/ring/*): one block per RL vehicle at column rl_index; `xo` = Flow's
+  // coordinate of x, `hh` the headway of the snapshot (written by the RL vehicle's lane; every lane makes the follower reads)
+  auto write_ma = [&](float* orow_, T xo, T hh, T dd) {
+    if (ma_wa) {                                             // multiagent/ring/wave_attenuation.py:188-208
+      (void)dd;
+      if (valid && sl.ctrl == FS_CTRL_RL) {
+        float* o = orow_ + 3 * sl.rl_index;
+        o[0] = float(v / T(15));
+        o[1] = float((vl - v) / T(15));
+        o[2] = float(hh / s.po_max_length);                  // get_headway: bumper to bumper
+      }
+    } else {                                                 // multiagent/ring/accel.py:163-208
+      const T vf_ = foll_read<SEG>(v, seg, wrap_foll, N), hf_ = foll_read<SEG>(hh, seg, wrap_foll, N);
+      const T xol = lead_read<SEG>(xo, seg, wrap_lead);
+      if (valid && sl.ctrl == FS_CTRL_RL) {
+        float* o = orow_ + 6 * sl.rl_index;
+        const T lead_speed = has ? vl : s.max_speed, follow_speed = has ? vf_ : T(0);
+        const T lead_head = has ? (xol - xo) - sl.length : L;        // (:186-188: no wrap-around, the ego's length)
+        const T follow_head = has ? hf_ : L;                         // get_headway(follower)
+        o[0] = float(xo / L);
+        o[1] = float(v / s.max_speed);
+        o[2] = float((lead_speed - v) / s.max_speed);
+        o[3] = float(lead_head / L);
+        o[4] = float((v - follow_speed) / s.max_speed);
+        o[5] = float(follow_head / L);
+      }
+    }
+  };
   const size_t step_rows = obs_every_step ? size_t(s.R) : 0;     // rows to advance per step
   float* orow = obs + size_t(rr) * obs_dim;
   float* rrow = rew + rr;
@@ -1104,6 +1133,7 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps_arg, c
       if (!FAST && s.junction_on)                     // S-J: both streams on the crossing point at once
         c = c || (seg_any<SEG>(valid && (x >= s.za_lo) && (x < s.za_hi), seg) &&
                   seg_any<SEG>(valid && (x >= s.zb_lo) && (x < s.zb_hi), seg));
+      if (ma_wa || ma_acc) c = false;                  // multiagent/base.py:188-190: crash = 0
       crashed = crashed || (c && live);
     }
 
@@ -1112,7 +1142,9 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps_arg, c
     if (emit) {
       const int oi = FAST ? ii : (sorted ? order_rank(false) : perm_i);
       const T xo = use_seg ? cur.flow_x(x) : x;
-      if (env == FS_ENV_WAVE_ATTENUATION_PO) {
+      if (ma_wa || ma_acc) {
+        write_ma(orow, xo, h, d);
+      } else if (env == FS_ENV_WAVE_ATTENUATION_PO) {
         // wave_attenuation.py:248-269; written by the RL vehicle's lane
         if (valid && sl.ctrl == FS_CTRL_RL && sl.rl_index == 0) {
           orow[0] = float(v / T(15));
@@ -1126,7 +1158,7 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps_arg, c
       // reward
       T reward;
       const bool bad = seg_any<SEG>(valid && (v < T(-100)), seg) || crashed;
-      if (env == FS_ENV_ACCEL) {
+      if (env == FS_ENV_ACCEL || ma_acc) {
         if (!FAST && s.evaluate) {
           reward = seg_sum<SEG>(valid ? v : T(0)) / T(N);                    // accel.py:111-112
         } else {                                                            // rewards.py:6-59
@@ -1165,7 +1197,9 @@ __global__ __launch_bounds__(64) void k_steps(DevView<T> s, int num_steps_arg, c
   if (num_steps == 0) {   // observation of the current state only (Env.reset, envs/base.py:544-551)
     const int oi = FAST ? ii : (sorted ? order_rank(false) : perm_i);
     const T xo = use_seg ? cur.flow_x(x) : x;
-    if (env == FS_ENV_WAVE_ATTENUATION_PO) {
+    if (ma_wa || ma_acc) {
+      write_ma(orow, xo, h, d);
+    } else if (env == FS_ENV_WAVE_ATTENUATION_PO) {
       if (valid && sl.ctrl == FS_CTRL_RL && sl.rl_index == 0) {
         orow[0] = float(v / T(15));
         orow[1] = float((vl - v) / T(15));

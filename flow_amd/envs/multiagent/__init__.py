@@ -1,5 +1,7 @@
 """Multi-agent environments on the GPU hot path (names as in flow/envs/multiagent/__init__.py)."""
 from flow_amd.envs.multiagent.base import MultiEnv
 from flow_amd.envs.multiagent.merge import MultiAgentMergePOEnv
+from flow_amd.envs.multiagent.ring import AdversarialAccelEnv, MultiAgentAccelPOEnv, MultiAgentWaveAttenuationPOEnv
 
-__all__ = ["MultiEnv", "MultiAgentMergePOEnv"]
+__all__ = ["MultiEnv", "MultiAgentMergePOEnv", "AdversarialAccelEnv", "MultiAgentAccelPOEnv",
+           "MultiAgentWaveAttenuationPOEnv"]

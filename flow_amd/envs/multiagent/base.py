@@ -19,6 +19,8 @@ except Exception:
 class MultiEnv(_MA, Env):
     """See module docstring."""
 
+    UNCLIPPED_ACTIONS = True      # multiagent/base.py:366-391: this fork's clip_actions returns the dict as it is
+
     def step(self, rl_actions):
         if getattr(self, "_action_repeat", False):
             raise NotImplementedError("action repeat is defined by the fork's traffic-light environments only")

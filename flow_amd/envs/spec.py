@@ -346,7 +346,7 @@ def build_spec(env, num_replicas, rng=None):
         env=env.FS_ENV, target_velocity=float(ep.additional_params.get("target_velocity", 0.0)),
         action_low=float(space.low[0]) if N and veh_k.num_rl_vehicles else 0.0,      # acceleration bounds
         action_high=float(space.high[0]) if N and veh_k.num_rl_vehicles else 0.0,
-        clip_actions=bool(ep.clip_actions), evaluate=bool(ep.evaluate),
+        clip_actions=bool(ep.clip_actions) and not getattr(env, "UNCLIPPED_ACTIONS", False), evaluate=bool(ep.evaluate),
         po_max_length=float(env._po_max_length()), horizon=ep.horizon, warmup_steps=int(ep.warmup_steps),
         sims_per_step=int(ep.sims_per_step), seed=handle_seed(sp),
         # (FS_MIXED keeps no previous-speed / acceleration fields: a scalar Env with precision='mixed' steps without

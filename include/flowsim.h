@@ -88,7 +88,14 @@ enum fs_env {
   FS_ENV_BOTTLENECK_DV = 6,         /* BottleneckDesiredVelocityEnv  flow/envs/bottleneck.py:760-1085: 4 values per
                                        observed lane-segment + outflow; one action per controlled lane-segment (num_rl =
                                        num_act_cells) shifting the maxSpeed of the RL vehicles inside it */
-  FS_ENV_BOTTLENECK = 7             /* BottleneckEnv            flow/envs/bottleneck.py:83-483: observation [1], outflow reward */
+  FS_ENV_BOTTLENECK = 7,            /* BottleneckEnv            flow/envs/bottleneck.py:83-483: observation [1], outflow reward */
+  FS_ENV_WAVE_ATTENUATION_PO_MA = 8,/* MultiAgentWaveAttenuationPOEnv  flow/envs/multiagent/ring/wave_attenuation.py:128-252:
+                                       per RL vehicle (column = rl_index) [v / 15, (v_lead - v) / 15, headway / max_length],
+                                       obs 3 * num_rl; WaveAttenuationEnv's reward shared by the agents; crash = 0 */
+  FS_ENV_ACCEL_PO_MA = 9            /* MultiAgentAccelPOEnv     flow/envs/multiagent/ring/accel.py:84-227: per RL vehicle
+                                       [x / L, v / v_max, (v_lead - v) / v_max, (x_lead - x - len_ego) / L,
+                                       (v - v_follow) / v_max, headway(follower) / L], obs 6 * num_rl; desired_velocity
+                                       reward shared by the agents; crash = 0 (multiagent/base.py:188-190) */
 };
 
 enum fs_network {

@@ -30,6 +30,8 @@ CTRL_SIM, CTRL_RL, CTRL_IDM, CTRL_CFM, CTRL_BCM, CTRL_LAC, CTRL_OVM, CTRL_LINEAR
     CTRL_GIPPS, CTRL_FOLLOWER_STOPPER, CTRL_NONLOCAL_FOLLOWER_STOPPER, CTRL_PISATURATION = range(12)
 FAILSAFE_NONE, FAILSAFE_INSTANTANEOUS, FAILSAFE_SAFE_VELOCITY = range(3)
 ENV_ACCEL, ENV_WAVE_ATTENUATION, ENV_WAVE_ATTENUATION_PO, ENV_LANE_CHANGE_ACCEL = range(4)
+# multi-agent ring heads (flow/envs/multiagent/ring/*): one observation block per RL vehicle, column = its rl_index
+ENV_WAVE_ATTENUATION_PO_MA, ENV_ACCEL_PO_MA = 8, 9
 
 
 def philox4x32_10(c0, c1, c2, c3, k0, k1):
@@ -457,6 +459,8 @@ class RingOracle:
         obs = self.get_state()
         horizon = self.spec.get("horizon", float("inf"))
         limit = self.spec.get("sims_per_step", 1) * (self.spec.get("warmup_steps", 0) + horizon)
+        if self.spec.get("env", ENV_ACCEL) in (ENV_WAVE_ATTENUATION_PO_MA, ENV_ACCEL_PO_MA):
+            crashed = np.zeros(self.R, dtype=bool)                   # multiagent/base.py:188-190: crash = 0
         done = (self.time_counter >= limit) | crashed                # :398-400
         reward = self.compute_reward(actions, crashed)
         return obs, reward, done
@@ -487,11 +491,46 @@ class RingOracle:
             return np.stack([self.v[:, i] / max_speed,
                              (self.v[:, j] - self.v[:, i]) / max_speed,
                              d / max_length], axis=1)
+        if env == ENV_WAVE_ATTENUATION_PO_MA:                        # multiagent/ring/wave_attenuation.py:188-208
+            out = np.zeros((self.R, 3 * len(self.rl_slots)), self.dt_)
+            h = self.headways()
+            for i in self.rl_slots:
+                c = int(self.spec["vehicles"][i]["rl_index"])
+                j = (i + 1) % self.N                                 # get_leader(rl_id) or rl_id
+                out[:, 3 * c] = self.v[:, i] / T(15.)
+                out[:, 3 * c + 1] = (self.v[:, j] - self.v[:, i]) / T(15.)
+                out[:, 3 * c + 2] = h[:, i] / T(self.spec["po_max_length"])      # get_headway: bumper to bumper
+            return out
+        if env == ENV_ACCEL_PO_MA:                                   # multiagent/ring/accel.py:163-208
+            out = np.zeros((self.R, 6 * len(self.rl_slots)), self.dt_)
+            h = self.headways()
+            xo = self.obs_position(self.x)
+            ms, Lr = T(self.spec["max_speed"]), self.L
+            lens = self.veh_len
+            for i in self.rl_slots:
+                c = int(self.spec["vehicles"][i]["rl_index"])
+                j, f = (i + 1) % self.N, (i - 1) % self.N
+                if self.N > 1:
+                    lead_speed, follow_speed = self.v[:, j], self.v[:, f]
+                    lead_head = xo[:, j] - xo[:, i] - lens[i]         # (:186-188: no wrap-around, the ego's length)
+                    follow_head = h[:, f]                            # get_headway(follower)
+                else:
+                    lead_speed, follow_speed = np.full(self.R, ms), np.zeros(self.R, self.dt_)
+                    lead_head = follow_head = Lr
+                out[:, 6 * c + 0] = xo[:, i] / Lr
+                out[:, 6 * c + 1] = self.v[:, i] / ms
+                out[:, 6 * c + 2] = (lead_speed - self.v[:, i]) / ms
+                out[:, 6 * c + 3] = lead_head / Lr
+                out[:, 6 * c + 4] = (self.v[:, i] - follow_speed) / ms
+                out[:, 6 * c + 5] = follow_head / Lr
+            return out
         raise ValueError(env)
 
     def compute_reward(self, actions, fail):
         env = self.spec.get("env", ENV_ACCEL)
         T = self.dt_.type
+        if env == ENV_ACCEL_PO_MA:                                   # multiagent/ring/accel.py:157-161 (fail = crash = 0)
+            return Rw.desired_velocity(self.v, self.spec["target_velocity"], np.zeros(self.R, bool))
         if env == ENV_ACCEL:                                         # accel.py:109-114
             if self.spec.get("evaluate", False):
                 return Rw.tree_sum(self.v) / T(self.N)

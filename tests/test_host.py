@@ -386,13 +386,21 @@ def test_package_alias_lets_reference_style_imports_resolve(monkeypatch):
 
 
 def test_bench_roofline_traffic_comes_from_the_committed_pmc_summary():
-    """bench.py's `roofline.traffic` is the HBM byte count of the committed PMC summary of the SAME kernel
-    (profiles/r02_pmc_summary_<dtype>.json); a summary of another kernel, size or fragment length gives None."""
+    """bench.py's `roofline.traffic` is the HBM byte count of the newest committed PMC summary of the SAME kernel
+    (profiles/rNN_pmc_summary_<dtype>.json); a summary of another kernel, size or fragment length -- or one whose launch
+    time is more than 15 % off the launch the bench has just timed -- is refused, with the reason in place of the source."""
+    import json
     import bench
     for prec in ("mixed", "f32"):
         traffic, src = bench.pmc_traffic(prec, 4096, 1500)
         nbytes, _ = bench.launch_bytes(4096, 22, 1500, prec)
-        assert src == "r02_pmc_summary_%s.json" % prec
+        assert src.endswith("_pmc_summary_%s.json" % prec) and src[:1] == "r"
         assert 0.98 * nbytes < traffic < 1.10 * nbytes          # no wasted traffic: within 10 % of the algorithmic bytes
-    assert bench.pmc_traffic("mixed", 4096, 20) == (None, None)
-    assert bench.pmc_traffic("mixed", 1024, 1500) == (None, None)
+        ref_s = json.load(open(os.path.join(os.path.dirname(bench.__file__), "profiles", src)))["avg_launch_ns_kernel_trace"] * 1e-9
+        assert bench.pmc_traffic(prec, 4096, 1500, ref_s * 1.1)[0] == traffic
+        stale, why = bench.pmc_traffic(prec, 4096, 1500, ref_s * 1.3)
+        assert stale is None and "stale" in why
+        vi = bench.valu_issue(prec, 4096, 1500, ref_s)
+        assert 0.5 < vi["frac"] < 1.0 and vi["frac"] > vi["frac_of_nominal"] and 1.8 < vi["effective_clock_GHz"] < 2.4
+    assert bench.pmc_traffic("mixed", 4096, 20)[0] is None
+    assert bench.pmc_traffic("mixed", 1024, 1500)[0] is None
