@@ -166,26 +166,18 @@ def c3_leg(device, R=4096, steps=3000, po=False):
                         "random actions" % ("WaveAttenuationPOEnv" if po else "AccelEnv")}
 
 
-def c5_leg(device, R=1024, env_steps=600, precision="f32"):
-    """BASELINE configs[4] (informational, not the headline): MergeNetwork pre_merge 500 m, 5 initial humans +
-    inflows 1800 / 200 (RL) / 100 veh/h, sim_step 0.2, sims_per_step 5, horizon 600, MultiAgentMergePOEnv head
-    (examples/exp_configs/rl/multiagent/multiagent_merge.py); 1024 replicas per GPU = 8192 over 8 GPUs; the
-    open-network kernel k_steps_open, 64 vehicle slots per replica.  ``precision="f16s"`` is the configuration as BASELINE
-    names it -- fp16 state, fp32 integrator: positions (two halves) and speeds (one) are kept as IEEE halves in HBM
-    between launches, a launch steps in float32 (include/flowsim.h FS_F16S); "f32" keeps float32 state."""
-    import torch
-    from flow_amd import _lib as L
+def c5_flow_params(precision="f32", noise=0.2):
+    """The flow_params of BASELINE configs[4] (see c5_leg)."""
     from flow_amd.controllers import IDMController, RLController
     from flow_amd.core.params import (EnvParams, InFlows, NetParams, SumoCarFollowingParams, SumoParams,
                                       VehicleParams)
-    from flow_amd.envs import VecFlowEnv
     from flow_amd.envs.multiagent import MultiAgentMergePOEnv
     from flow_amd.networks import MergeNetwork
     from flow_amd.networks.merge import ADDITIONAL_NET_PARAMS
     add = dict(ADDITIONAL_NET_PARAMS)
     add["pre_merge_length"] = 500
     veh = VehicleParams()
-    veh.add(veh_id="human", acceleration_controller=(IDMController, {"noise": 0.2}),
+    veh.add(veh_id="human", acceleration_controller=(IDMController, {"noise": noise}),
             car_following_params=SumoCarFollowingParams(speed_mode="obey_safe_speed"), num_vehicles=5)
     veh.add(veh_id="rl", acceleration_controller=(RLController, {}),
             car_following_params=SumoCarFollowingParams(speed_mode="obey_safe_speed"), num_vehicles=0)
@@ -198,6 +190,20 @@ def c5_leg(device, R=1024, env_steps=600, precision="f32"):
               env=EnvParams(horizon=600, sims_per_step=5, warmup_steps=0,
                             additional_params={"max_accel": 1.5, "max_decel": 1.5, "target_velocity": 20}),
               net=NetParams(inflows=inflow, additional_params=add), veh=veh)
+    return fp
+
+
+def c5_leg(device, R=1024, env_steps=600, precision="f32"):
+    """BASELINE configs[4] (informational, not the headline): MergeNetwork pre_merge 500 m, 5 initial humans +
+    inflows 1800 / 200 (RL) / 100 veh/h, sim_step 0.2, sims_per_step 5, horizon 600, MultiAgentMergePOEnv head
+    (examples/exp_configs/rl/multiagent/multiagent_merge.py); 1024 replicas per GPU = 8192 over 8 GPUs; the
+    open-network kernel k_steps_open, 64 vehicle slots per replica.  ``precision="f16s"`` is the configuration as BASELINE
+    names it -- fp16 state, fp32 integrator: positions (two halves) and speeds (one) are kept as IEEE halves in HBM
+    between launches, a launch steps in float32 (include/flowsim.h FS_F16S); "f32" keeps float32 state."""
+    import torch
+    from flow_amd import _lib as L
+    from flow_amd.envs import VecFlowEnv
+    fp = c5_flow_params(precision)
     vec = VecFlowEnv(fp, num_replicas=R, device=device.index)
     K = env_steps
     out = (torch.empty((K, R, vec.obs_dim), dtype=torch.float32, device=device),
@@ -223,17 +229,12 @@ def c5_leg(device, R=1024, env_steps=600, precision="f32"):
     return res
 
 
-def c4_leg(device, R=128, env_steps=1000, slots=256):
-    """BASELINE configs[3] (informational, not the headline): BottleneckNetwork scaling 1 (4 -> 2 -> 1 lanes at two
-    zipper junctions), inflow 2300 veh/h (10 % RL) with random entry lanes, all vehicles on the SUMO car-following
-    model, BottleneckDesiredVelocityEnv head (141 observations, 20 actions), sim_step 0.5, warm-up 40 + horizon 1000
-    (examples/exp_configs/rl/singleagent/singleagent_bottleneck.py); 128 replicas per GPU = 1024 over 8 GPUs."""
-    import torch
-    from flow_amd import _lib as L
+def c4_flow_params(slots=256):
+    """The flow_params of BASELINE configs[3] (see c4_leg)."""
     from flow_amd.controllers import ContinuousRouter, RLController, SimLaneChangeController
     from flow_amd.core.params import (EnvParams, InFlows, InitialConfig, NetParams, SumoCarFollowingParams,
                                       SumoLaneChangeParams, SumoParams, VehicleParams)
-    from flow_amd.envs import BottleneckDesiredVelocityEnv, VecFlowEnv
+    from flow_amd.envs import BottleneckDesiredVelocityEnv
     from flow_amd.networks import BottleneckNetwork
     veh = VehicleParams()
     veh.add(veh_id="human", lane_change_controller=(SimLaneChangeController, {}),
@@ -259,6 +260,18 @@ def c4_leg(device, R=128, env_steps=1000, slots=256):
               net=NetParams(inflows=inflow, additional_params={"scaling": 1, "speed_limit": 23}), veh=veh,
               initial=InitialConfig(spacing="uniform", min_gap=5, lanes_distribution=float("inf"),
                                     edges_distribution=["2", "3", "4", "5"]))
+    return fp
+
+
+def c4_leg(device, R=128, env_steps=1000, slots=256):
+    """BASELINE configs[3] (informational, not the headline): BottleneckNetwork scaling 1 (4 -> 2 -> 1 lanes at two
+    zipper junctions), inflow 2300 veh/h (10 % RL) with random entry lanes, all vehicles on the SUMO car-following
+    model, BottleneckDesiredVelocityEnv head (141 observations, 20 actions), sim_step 0.5, warm-up 40 + horizon 1000
+    (examples/exp_configs/rl/singleagent/singleagent_bottleneck.py); 128 replicas per GPU = 1024 over 8 GPUs."""
+    import torch
+    from flow_amd import _lib as L
+    from flow_amd.envs import VecFlowEnv
+    fp = c4_flow_params(slots)
     vec = VecFlowEnv(fp, num_replicas=R, device=device.index)
     K = env_steps
     gen = torch.Generator(device=device).manual_seed(3)

@@ -82,7 +82,7 @@ import numpy as np
 
 from . import controllers as C
 from . import rewards as Rw
-from .refsim import CTRL_RL, controller_dispatch, philox4x32_10
+from .refsim import CTRL_RL, controller_dispatch, philox4x32_10, replica_ids
 
 ENV_MERGE_PO, ENV_MERGE_MA, ENV_BOTTLENECK_DV, ENV_BOTTLENECK = 4, 5, 6, 7     # include/flowsim.h FS_ENV_*
 NO_LEADER_HEADWAY = 1000.0                 # vehicle/traci.py:237
@@ -527,7 +527,7 @@ class MergeOracle:
                 # generated vehicle waits for its turn like a due one.  Trial = Philox word < floor(p dt 2^32).
                 thr = min(np.floor(float(prob) * float(self.dt) * 4294967296.0), 4294967295.0)
                 r0, _, _, _ = philox4x32_10((self.sim_steps - 1).astype(np.uint32), np.full(R, 2000 + f, dtype=np.uint32),
-                                            (np.arange(R) + int(self.spec.get("replica_offset", 0))).astype(np.uint32),
+                                            replica_ids(self.spec, R),
                                             (1 + 2 * self.episode).astype(np.uint32),
                                             np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF))
                 gen = active & (now >= float(fl["begin"])) & (now <= float(fl.get("end", 86400.0))) & \
@@ -544,7 +544,7 @@ class MergeOracle:
             typ = int(fl["type"])
             if int(fl["route"]) < 0:                                      # M9: departLane = "random"
                 r0, _, _, _ = philox4x32_10(k.astype(np.uint32), np.full(R, 1000 + f, dtype=np.uint32),
-                                            (np.arange(R) + int(self.spec.get("replica_offset", 0))).astype(np.uint32),
+                                            replica_ids(self.spec, R),
                                             (1 + 2 * self.episode).astype(np.uint32),
                                             np.uint32(int(self.spec.get("seed", 0)) & 0xFFFFFFFF),
                                             np.uint32((int(self.spec.get("seed", 0)) >> 32) & 0xFFFFFFFF))

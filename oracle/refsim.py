@@ -175,7 +175,7 @@ def controller_dispatch(o, v, v_lead, h, has_lead, v_follow, h_follow, rl_value,
         if vs.get("noise", 0) > 0:                                # base_controller.py:109-110
             slot = np.full(R, i, dtype=np.uint32) if noise_slot is None else noise_slot[sl].astype(np.uint32)
             g = gaussian_noise(o.spec.get("seed", 0),
-                               (np.arange(R) + int(o.spec.get("replica_offset", 0))).astype(np.uint32), slot,
+                               replica_ids(o.spec, R), slot,
                                o.step_counter.astype(np.uint32), o.dt_)
             a = a + T(vs["noise"]) * g
         fs = vs.get("fail_safe", FAILSAFE_NONE)
@@ -188,6 +188,18 @@ def controller_dispatch(o, v, v_lead, h, has_lead, v_follow, h_follow, rl_value,
         acc[sl] = a
         commanded[sl] = cmd
     return acc, commanded
+
+
+def replica_ids(spec, R):
+    """Global replica indices of the R rows (they key the Philox streams): a contiguous shard starting at
+    `replica_offset` (what fs_config carries), or -- oracle only, to check SAMPLED replicas of a large handle -- the explicit
+    list `replica_ids`."""
+    ids = spec.get("replica_ids")
+    if ids is not None:
+        ids = np.asarray(ids, dtype=np.uint32)
+        assert ids.shape == (R,)
+        return ids
+    return (np.arange(R) + int(spec.get("replica_offset", 0))).astype(np.uint32)
 
 
 class RingOracle:

@@ -1,0 +1,78 @@
+"""BASELINE configs[3] (C4) and configs[4] (C5) exactly as bench.py runs them -- same flow_params, same replica count,
+whole episode in one launch -- with SAMPLED replicas checked bit for bit against the numpy oracle (which is far too slow for
+all of them): observation, reward and done of every step, and the state at the end.  The oracle runs the sampled replicas
+alone; the Philox streams of the inflows (random entry lanes) are keyed by the global replica index, which the oracle takes
+from `replica_ids`."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import opennet as O                                     # noqa: E402
+from test_open_gpu import compare_state                             # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+class Rows:
+    """The sampled rows of a FlowSim handle, presented like a handle of their own to compare_state."""
+
+    def __init__(self, sim, rows):
+        self.sim, self.rows = sim, rows
+
+    def get_state(self, field):
+        return self.sim.get_state(field)[self.rows]
+
+    pos = property(lambda s: s.sim.pos[s.rows])
+    vel = property(lambda s: s.sim.vel[s.rows])
+    headway = property(lambda s: s.sim.headway[s.rows])
+
+
+def sampled_parity(fp, R, K, rows, act_seed):
+    import torch
+    from flow_amd.envs import VecFlowEnv
+    dev = torch.device("cuda:0")
+    vec = VecFlowEnv(fp, num_replicas=R, device=0)
+    spec = vec.env._spec
+    A = vec.act_dim
+    gen = torch.Generator(device=dev).manual_seed(act_seed)
+    tape = ((torch.rand((K, R, max(A, 1)), device=dev, generator=gen) * 2 - 1) * 1.5)[:, :, :A].contiguous()
+    out = (torch.empty((K, R, vec.obs_dim), dtype=torch.float32, device=dev),
+           torch.empty((K, R), dtype=torch.float32, device=dev), torch.empty((K, R), dtype=torch.uint8, device=dev))
+    obs0 = vec.reset()
+    vec.sim.rollout_dev(K, *out, actions=tape if A else None)
+    torch.cuda.synchronize()
+    kernel = vec.sim.last_kernel
+    sub = dict(spec, num_replicas=len(rows), replica_ids=np.asarray(rows) + int(spec.get("replica_offset", 0)))
+    for key in ("init_alive", "init_pos", "init_vel", "init_route"):
+        sub[key] = np.asarray(spec[key])[rows]
+    ora = O.MergeOracle(sub, np.float32)
+    np.testing.assert_array_equal(obs0[rows].cpu().numpy(), ora.reset().astype(np.float32))
+    obs, rew, done = (t[:, rows].cpu().numpy() for t in out)
+    acts = tape[:, rows].cpu().numpy()
+    for k in range(K):
+        o, r, d = ora.step(acts[k] if A else None)
+        np.testing.assert_array_equal(obs[k], o.astype(np.float32), err_msg="obs, step %d" % k)
+        np.testing.assert_array_equal(rew[k], r.astype(np.float32), err_msg="reward, step %d" % k)
+        np.testing.assert_array_equal(done[k], d, err_msg="done, step %d" % k)
+    compare_state(Rows(vec.sim, rows), ora)
+    vec.close()
+    return kernel, ora
+
+
+def test_c4_full_size_sampled_replicas_equal_the_oracle():
+    import bench
+    kernel, ora = sampled_parity(bench.c4_flow_params(256), R=128, K=1000, rows=[0, 37, 90, 127], act_seed=3)
+    assert "k_steps_wide" in kernel
+    assert ora.total_departed.min() > 250 and ora.total_arrived.min() > 150      # the whole episode was traffic
+
+
+def test_c5_full_size_sampled_replicas_equal_the_oracle():
+    """Noise off: the Box-Muller draws go through libm on the host and through the device's log / cos in the kernel
+    (tolerance test: test_merge_po_noise_short_horizon_tolerance); everything else is the bench's configuration."""
+    import bench
+    kernel, ora = sampled_parity(bench.c5_flow_params("f32", noise=0.0), R=1024, K=600, rows=[0, 301, 640, 1023], act_seed=4)
+    assert "k_steps_open" in kernel
+    assert ora.total_departed.min() > 250 and ora.total_arrived.min() > 100
