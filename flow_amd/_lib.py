@@ -28,7 +28,7 @@ FS_FAILSAFE_NONE, FS_FAILSAFE_INSTANTANEOUS, FS_FAILSAFE_SAFE_VELOCITY = range(3
 # enum fs_env
 (FS_ENV_ACCEL, FS_ENV_WAVE_ATTENUATION, FS_ENV_WAVE_ATTENUATION_PO, FS_ENV_LANE_CHANGE_ACCEL, FS_ENV_MERGE_PO,
  FS_ENV_MERGE_MA, FS_ENV_BOTTLENECK_DV, FS_ENV_BOTTLENECK, FS_ENV_WAVE_ATTENUATION_PO_MA,
- FS_ENV_ACCEL_PO_MA) = range(10)
+ FS_ENV_ACCEL_PO_MA, FS_ENV_LANE_CHANGE_ACCEL_PO) = range(11)
 # enum fs_network / fs_integrator
 FS_NET_RING, FS_NET_FIGURE_EIGHT, FS_NET_MERGE, FS_NET_BOTTLENECK = 0, 1, 2, 3
 FS_MAX_SEGMENTS = 16

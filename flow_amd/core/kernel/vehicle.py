@@ -391,28 +391,30 @@ class VehicleKernel(object):
 
     def _lane_neighbours(self, i):
         """Per lane: (leader id, headway, follower id, tailway) as _multi_lane_headways computes them
-        (vehicle/traci.py:776-867): headway = pos_lead - pos - len(lead), tailway = pos - pos_follow -
-        len(self), defaults '' / 1000 when the lane holds no other vehicle."""
+        (vehicle/traci.py:776-867): headway = pos_lead - pos - len(lead), tailway = pos - pos_follow - len(self),
+        '' / 1000 for an empty lane.  The candidates of a lane are ALL its vehicles, this one included: the
+        reference's walk over the edges ahead / behind ends on the vehicle's own edge, so alone in its lane it is its
+        own leader and follower, one lap away.  (Host accessor for user code and rendering; the observation of
+        LaneChangeAccelPOEnv is written by the kernel.)"""
         lanes = int(self.sim.spec.get("num_lanes", 1))
-        x = self._field(L.FS_FIELD_POS)
+        x = self._field(L.FS_FIELD_POS).astype(np.float64)
         ln = self._field(L.FS_FIELD_LANE) if lanes > 1 else np.zeros(self.num_vehicles, dtype=np.int32)
-        Lloop = self.master_kernel.network.length()
+        lap = self.master_kernel.network.length()
+        slots = np.arange(self.num_vehicles)
+        ahead = x - x[i]
+        ahead[(ahead < 0) | (slots == i)] += lap          # bisect_left: a vehicle at the same position is a leader
+        behind = x[i] - x
+        behind[behind <= 0] += lap
         out = []
         for lane in range(lanes):
-            best_h, best_t, lead, foll = 1000, 1000, "", ""
-            dl, df = None, None
-            for j in range(self.num_vehicles):
-                if j == i or int(ln[j]) != lane:
-                    continue
-                ahead = (float(x[j]) - float(x[i])) % Lloop
-                behind = (float(x[i]) - float(x[j])) % Lloop
-                if dl is None or ahead < dl:
-                    dl, lead, best_h = ahead, self._order[j], ahead - self.__vehicles[self._order[j]]["length"]
-                # bisect_left semantics (vehicle/traci.py:826-848): a vehicle at the same position counts
-                # as the leader of that lane, never as the follower
-                if behind > 0 and (df is None or behind < df):
-                    df, foll, best_t = behind, self._order[j], behind - self.__vehicles[self._order[i]]["length"]
-            out.append((lead, best_h, foll, best_t))
+            cand = slots[np.asarray(ln) == lane]
+            if cand.size == 0:
+                out.append(("", 1000, "", 1000))
+                continue
+            lj = cand[np.argmin(ahead[cand])]
+            fj = cand[::-1][np.argmin(behind[cand[::-1]])]
+            out.append((self._order[lj], ahead[lj] - self.__vehicles[self._order[lj]]["length"],
+                        self._order[fj], behind[fj] - self.__vehicles[self._order[i]]["length"]))
         return out
 
     def lane_neighbour_table(self, veh_id):

@@ -125,7 +125,12 @@ int validate(const fs_config* c) {
       if (!(c->segments[k].start > c->segments[k - 1].start))
         return fail(FS_ERR_INVALID, "fs_create: segment starts must increase");
   }
-  if (c->env < FS_ENV_ACCEL || c->env > FS_ENV_ACCEL_PO_MA) return fail(FS_ERR_INVALID, "fs_create: bad env");
+  if (c->env < FS_ENV_ACCEL || c->env > FS_ENV_LANE_CHANGE_ACCEL_PO) return fail(FS_ERR_INVALID, "fs_create: bad env");
+  const bool lc_env = c->env == FS_ENV_LANE_CHANGE_ACCEL || c->env == FS_ENV_LANE_CHANGE_ACCEL_PO;
+  if (lc_env && c->network != FS_NET_RING)
+    return fail(FS_ERR_UNSUPPORTED, "fs_create: the lane-change envs are built for rings (k_steps_ml)");
+  if (c->env == FS_ENV_LANE_CHANGE_ACCEL_PO && (c->num_rl < 1 || c->obs_perm))
+    return fail(FS_ERR_INVALID, "fs_create: LaneChangeAccelPOEnv needs an RL vehicle and takes no observation permutation");
   if (c->env == FS_ENV_WAVE_ATTENUATION_PO_MA || c->env == FS_ENV_ACCEL_PO_MA) {
     if (open_net || c->num_lanes > 1)
       return fail(FS_ERR_UNSUPPORTED, "fs_create: the multi-agent ring heads are built for single-lane closed loops");
@@ -142,10 +147,10 @@ int validate(const fs_config* c) {
   if (c->num_replicas < 1) return fail(FS_ERR_INVALID, "fs_create: num_replicas < 1");
   if (c->replica_offset < 0) return fail(FS_ERR_INVALID, "fs_create: replica_offset < 0");
   if (c->sort_vehicles || c->obs_perm) {
-    if (c->env != FS_ENV_ACCEL && c->env != FS_ENV_LANE_CHANGE_ACCEL && c->sort_vehicles)
+    if (c->env != FS_ENV_ACCEL && !lc_env && c->sort_vehicles)
       return fail(FS_ERR_INVALID, "fs_create: sort_vehicles belongs to AccelEnv / LaneChangeAccelEnv");
     if (c->network == FS_NET_MERGE || c->network == FS_NET_BOTTLENECK ||
-        (c->num_lanes > 1 && c->sort_vehicles && c->env != FS_ENV_LANE_CHANGE_ACCEL))
+        (c->num_lanes > 1 && c->sort_vehicles && !lc_env))
       return fail(FS_ERR_UNSUPPORTED, "fs_create: sort_vehicles / shuffled ids are built for closed loops "
                                       "(sort_vehicles on multi-lane rings: LaneChangeAccelEnv)");
     if (c->obs_perm) {
@@ -251,9 +256,11 @@ int create_typed(const fs_config* cfg, fs_handle* out) {
                : (cfg->env == FS_ENV_BOTTLENECK) ? 1
                : (cfg->env == FS_ENV_MERGE_PO || cfg->env == FS_ENV_MERGE_MA)
                      ? 5 * cfg->num_rl
-                     : (cfg->env == FS_ENV_LANE_CHANGE_ACCEL ? 3 : 2) * cfg->num_vehicles;
+                     : (cfg->env == FS_ENV_LANE_CHANGE_ACCEL_PO)
+                           ? (4 * (cfg->num_lanes < 1 ? 1 : cfg->num_lanes) + 1) * cfg->num_rl
+                           : (cfg->env == FS_ENV_LANE_CHANGE_ACCEL ? 3 : 2) * cfg->num_vehicles;
   if (s->obs_dim < 1) s->obs_dim = 1;      // an env without RL places still gets a (dummy) buffer
-  s->act_dim = cfg->num_rl * (cfg->env == FS_ENV_LANE_CHANGE_ACCEL ? 2 : 1);
+  s->act_dim = cfg->num_rl * ((cfg->env == FS_ENV_LANE_CHANGE_ACCEL || cfg->env == FS_ENV_LANE_CHANGE_ACCEL_PO) ? 2 : 1);
   int seg = 8;
   while (seg < cfg->num_vehicles) seg <<= 1;       // 128 / 256: one workgroup of 2 / 4 waves per replica (k_steps_wide)
   s->seg = seg;

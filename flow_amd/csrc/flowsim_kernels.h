@@ -1470,7 +1470,8 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps_arg
   const int ii = i < N ? i : N - 1;
   const size_t idx = size_t(rr) * N + ii;
   const int flags = s.flags;
-  const bool lc_env = (s.env == FS_ENV_LANE_CHANGE_ACCEL);
+  const bool lcpo_env = (s.env == FS_ENV_LANE_CHANGE_ACCEL_PO);       // LaneChangeAccelEnv's actions and reward, own head
+  const bool lc_env = (s.env == FS_ENV_LANE_CHANGE_ACCEL) || lcpo_env;
   const int act_w = s.num_rl * (lc_env ? 2 : 1);
 
   Slot<T> sl;
@@ -1528,7 +1529,8 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps_arg
   };
 
   const T dt = s.dt;
-  const int obs_dim = lc_env ? 3 * N : ((s.env == FS_ENV_WAVE_ATTENUATION_PO) ? 3 : 2 * N);
+  const int obs_dim = lcpo_env ? (4 * s.num_lanes + 1) * s.num_rl
+                                : (lc_env ? 3 * N : ((s.env == FS_ENV_WAVE_ATTENUATION_PO) ? 3 : 2 * N));
   const size_t step_rows = obs_every_step ? size_t(s.R) : 0;
   float* orow = obs + size_t(rr) * obs_dim;
   float* rrow = rew + rr;
@@ -1628,6 +1630,70 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps_arg
   };
   scan();
 
+  // the observation of the state the lanes hold (orow: the row of this step)
+  auto write_obs = [&]() {
+    if (lcpo_env) {
+      // ML8, LaneChangeAccelPOEnv (lane_change_accel.py:218-262 over vehicle/traci.py:776-867): per RL vehicle and lane q the
+      // nearest leader / follower among ALL vehicles of lane q, the vehicle itself included (the reference's walk round
+      // the loop ends on its own edge: alone in its lane it is its own leader and follower, one lap away).  Arc ahead =
+      // x_j - x (+ L when negative or j is me: a vehicle of another lane at my position is a leader, bisect_left); arc
+      // behind = x - x_j (+ L when <= 0).  Ties: leader the first, follower the last in slot order.  Every lane of
+      // the wave scans (one pass per lane of the road, slot j by v_readlane as in scan()), the RL lanes store.
+      const T big = T(3.0e38);
+      const int lanes = s.num_lanes;
+      const bool rl = valid && sl.ctrl == FS_CTRL_RL;
+      const int col = sl.rl_index < 0 ? 0 : sl.rl_index;
+      float* blk = orow + size_t(4) * lanes * col;
+#pragma unroll 1
+      for (int q = 0; q < lanes; ++q) {
+        T best = big, bestf = big;
+        int lj = -1, fj = -1;
+        for (int j = 0; j < N; ++j) {
+          const T xj = seg_read<SEG>(x, j, seg);
+          const int lane_j = seg_read_i<SEG>(ln, j, seg);
+          T a = xj - x;
+          a = ((a < T(0)) | (j == ii)) ? a + L : a;
+          T b = x - xj;
+          b = (b <= T(0)) ? b + L : b;
+          const bool c = (lane_j == q);
+          const bool tl = c & (a < best), tf = c & (b <= bestf);
+          best = tl ? a : best;
+          lj = tl ? j : lj;
+          bestf = tf ? b : bestf;
+          fj = tf ? j : fj;
+        }
+        const bool hq = lj >= 0;
+        const T v_l = bperm(v, segbase + (hq ? lj : ii)), len_l = bperm(sl.length, segbase + (hq ? lj : ii));
+        const T v_f = bperm(v, segbase + (hq ? fj : ii));
+        if (rl) {
+          blk[q] = float(hq ? best - len_l : T(1000));
+          blk[lanes + q] = float(hq ? bestf - sl.length : T(1000));
+          blk[2 * lanes + q] = float(hq ? v_l / s.max_speed : T(0));
+          blk[3 * lanes + q] = float(hq ? v_f / s.max_speed : T(0));
+        }
+      }
+      if (rl) orow[size_t(4) * lanes * s.num_rl + col] = float(v);
+      return;
+    }
+    const int oi = sorted ? order_rank(false) : perm_i;
+    if (lc_env) {                                                  // lane_change_accel.py:100-117
+      if (valid) {
+        orow[oi] = float(v / s.max_speed);
+        orow[N + oi] = float(x / L);
+        orow[2 * N + oi] = float(T(ln) / T(s.num_lanes));
+      }
+    } else if (s.env == FS_ENV_WAVE_ATTENUATION_PO) {
+      if (valid && sl.ctrl == FS_CTRL_RL && sl.rl_index == 0) {
+        orow[0] = float(v / T(15));
+        orow[1] = float((vl - v) / T(15));
+        orow[2] = float((has ? dlead : T(0)) / s.po_max_length);
+      }
+    } else if (valid) {
+      orow[oi] = float(v / s.max_speed);
+      orow[N + oi] = float(x / L);
+    }
+  };
+
   for (int step = 0; step < num_steps; ++step) {
     const float* act = actions ? actions + size_t(step) * act_stride + size_t(rr) * act_w : nullptr;
     bool crashed = false;
@@ -1719,23 +1785,7 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps_arg
 
     const bool emit = obs_every_step || (step == num_steps - 1);
     if (emit) {
-      const int oi = sorted ? order_rank(false) : perm_i;
-      if (lc_env) {                                                  // lane_change_accel.py:100-117
-        if (valid) {
-          orow[oi] = float(v / s.max_speed);
-          orow[N + oi] = float(x / L);
-          orow[2 * N + oi] = float(T(ln) / T(s.num_lanes));
-        }
-      } else if (s.env == FS_ENV_WAVE_ATTENUATION_PO) {
-        if (valid && sl.ctrl == FS_CTRL_RL && sl.rl_index == 0) {
-          orow[0] = float(v / T(15));
-          orow[1] = float((vl - v) / T(15));
-          orow[2] = float((has ? dlead : T(0)) / s.po_max_length);
-        }
-      } else if (valid) {
-        orow[oi] = float(v / s.max_speed);
-        orow[N + oi] = float(x / L);
-      }
+      write_obs();
       T reward;
       const bool bad = seg_any<SEG>(valid && (v < T(-100)), seg) || crashed;
       if (s.env == FS_ENV_ACCEL || lc_env) {
@@ -1783,23 +1833,7 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps_arg
   }
 
   if (num_steps == 0) {
-    const int oi = sorted ? order_rank(false) : perm_i;
-    if (lc_env) {
-      if (valid) {
-        orow[oi] = float(v / s.max_speed);
-        orow[N + oi] = float(x / L);
-        orow[2 * N + oi] = float(T(ln) / T(s.num_lanes));
-      }
-    } else if (s.env == FS_ENV_WAVE_ATTENUATION_PO) {
-      if (valid && sl.ctrl == FS_CTRL_RL && sl.rl_index == 0) {
-        orow[0] = float(v / T(15));
-        orow[1] = float((vl - v) / T(15));
-        orow[2] = float((has ? dlead : T(0)) / s.po_max_length);
-      }
-    } else if (valid) {
-      orow[oi] = float(v / s.max_speed);
-      orow[N + oi] = float(x / L);
-    }
+    write_obs();
     return;
   }
 
@@ -1840,7 +1874,8 @@ __global__ void k_reset(DevView<T> s, const uint8_t* __restrict__ mask) {
       }
       s.sort_key[e] = xa;
     }
-    if (s.num_lanes > 1) {
+    // (the lane-change envs step on k_steps_ml, which reads the lane fields, on a one-lane ring too)
+    if (s.num_lanes > 1 || s.env == FS_ENV_LANE_CHANGE_ACCEL || s.env == FS_ENV_LANE_CHANGE_ACCEL_PO) {
       s.lane[e] = s.init_lane[e];
       s.last_lc[e] = -(1 << 30);
     }

@@ -56,7 +56,7 @@ namespace fsim {
       HIP_TRY(hipGetLastError());
       return FS_OK;
     }
-    if (dv.num_lanes > 1) {
+    if (dv.num_lanes > 1 || dv.env == FS_ENV_LANE_CHANGE_ACCEL || dv.env == FS_ENV_LANE_CHANGE_ACCEL_PO) {
       last_kernel = "k_steps_ml";
       if (dv.lc_enabled)
         hipLaunchKernelGGL((fs::k_steps_ml<T, SEG, true>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, mask,

@@ -122,7 +122,7 @@ class Env(_Base):
         if not pend:
             return None
         order = self._rl_action_order()
-        if self.FS_ENV == L.FS_ENV_LANE_CHANGE_ACCEL:          # [acc_0, dir_0, acc_1, dir_1, ...]
+        if self.FS_ENV in (L.FS_ENV_LANE_CHANGE_ACCEL, L.FS_ENV_LANE_CHANGE_ACCEL_PO):          # [acc_0, dir_0, acc_1, dir_1, ...]
             lc = self.k.vehicle._pending_lc or {}
             row = []
             for v in order:

@@ -66,20 +66,20 @@ class LaneChangeAccelPOEnv(LaneChangeAccelEnv):
     """POMDP version (flow/envs/ring/lane_change_accel.py:163-262): for every RL vehicle the gap to and the speed of
     its nearest leader and follower in EVERY lane, then the RL vehicles' own speeds.
 
-    A host head over the multi-lane kernel's state (``HOST_HEADS``: the step runs in ``k_steps_ml``, the observation is
-    a handful of array reductions per RL vehicle on the replica's position / lane / speed rows).  What the reference's
-    vector holds, kept as is: gaps in METRES with 1000 for an empty lane (its normalisation divides a list it has
-    already copied from, :236-247), neighbour speeds over ``max_speed`` with 0 for an empty lane, the ego speed in m/s;
-    and its ``return`` sits inside the loop over the RL vehicles (:262), so only the FIRST RL vehicle's block is filled
-    and one ego speed appended -- ``RETURN_IN_LOOP_QUIRK`` (False: every RL vehicle, the evident intent)."""
+    A kernel head (``FS_ENV_LANE_CHANGE_ACCEL_PO``, written by ``k_steps_ml``): the per-lane neighbour search of
+    flow/core/kernel/vehicle/traci.py:776-867 runs on the device for the RL vehicles, the observation row arrives with
+    the step.  What the reference's vector holds, kept as is: gaps in METRES with 1000 for an empty lane (its
+    normalisation divides a list it has already copied from, :236-247), neighbour speeds over ``max_speed`` with 0 for an
+    empty lane, the ego speed in m/s.  The reference's ``return`` sits inside its loop over the RL vehicles (:262), so
+    only the FIRST RL vehicle's block is filled and ONE ego speed appended -- ``RETURN_IN_LOOP_QUIRK``, applied here by
+    slicing the kernel's row (False: every RL vehicle, the evident intent and what ``VecFlowEnv`` hands out)."""
 
-    HOST_HEADS = True
+    FS_ENV = L.FS_ENV_LANE_CHANGE_ACCEL_PO
     RETURN_IN_LOOP_QUIRK = True
 
     def __init__(self, env_params, sim_params, network, simulator='traci'):
         super().__init__(env_params, sim_params, network, simulator)
         self.num_lanes = max(self.k.network.num_lanes(edge) for edge in self.k.network.get_edge_list())
-        self.visible = []
 
     @property
     def observation_space(self):
@@ -87,22 +87,22 @@ class LaneChangeAccelPOEnv(LaneChangeAccelEnv):
         return Box(low=0, high=1, shape=(4 * n_rl * self.num_lanes + n_rl, ), dtype=np.float32)
 
     def get_state(self):
+        row = np.array(self._last_obs, dtype=np.float64)
+        if not self.RETURN_IN_LOOP_QUIRK:
+            return row
+        n_rl, block = self.k.vehicle.num_rl_vehicles, 4 * self.num_lanes
+        out = np.zeros(block * n_rl + 1)
+        out[:block] = row[:block]
+        out[-1] = row[block * n_rl]
+        return out
+
+    @property
+    def visible(self):
+        """The vehicles that entered the observation (lane_change_accel.py:240-254), for rendering: read back from the
+        device state on demand."""
         veh = self.k.vehicle
-        rl_ids = veh.get_rl_ids()
-        lanes, max_speed = self.num_lanes, self.k.network.max_speed()
-        shown = rl_ids[:1] if self.RETURN_IN_LOOP_QUIRK else rl_ids
-        blocks = np.zeros((len(rl_ids), 4, lanes))
-        self.visible = []
-        for row, rl_id in zip(blocks, shown):
-            table = veh.lane_neighbour_table(rl_id)          # [(leader, headway, follower, tailway)] per lane
-            row[0] = [t[1] for t in table] + [1] * (lanes - len(table))
-            row[1] = [t[3] for t in table] + [1] * (lanes - len(table))
-            for col, ids in ((2, [t[0] for t in table]), (3, [t[2] for t in table])):
-                seen = [v for v in ids if v != '']
-                row[col, [j for j, v in enumerate(ids) if v != '']] = np.asarray(veh.get_speed(seen)) / max_speed
-                self.visible.extend(seen)
-        ego = veh.get_speed(list(shown))
-        return np.concatenate((blocks.reshape(-1), np.asarray(ego, dtype=np.float64)))
+        shown = veh.get_rl_ids()[:1] if self.RETURN_IN_LOOP_QUIRK else veh.get_rl_ids()
+        return [v for rl_id in shown for t in veh.lane_neighbour_table(rl_id) for v in (t[0], t[2]) if v != '']
 
     def additional_command(self):
         """lane_change_accel.py:257-262: the neighbours that entered the observation are the observed vehicles."""

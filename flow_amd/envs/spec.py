@@ -309,7 +309,7 @@ def build_spec(env, num_replicas, rng=None):
         obs_perm = np.array([ids.index(v) for v in env.initial_ids], dtype=np.int32)
     sort_vehicles = bool(ep.additional_params.get("sort_vehicles", False))
     if sort_vehicles and not (env.FS_ENV == L.FS_ENV_ACCEL or
-                              (env.FS_ENV == L.FS_ENV_LANE_CHANGE_ACCEL and num_lanes > 1)):
+                              (env.FS_ENV in (L.FS_ENV_LANE_CHANGE_ACCEL, L.FS_ENV_LANE_CHANGE_ACCEL_PO) and num_lanes > 1)):
         raise NotImplementedError("sort_vehicles is built for AccelEnv on single-lane closed loops and for "
                                   "LaneChangeAccelEnv on multi-lane rings")
     X, lanes = initial_positions(net_k, network.initial_config, N, R, rng)

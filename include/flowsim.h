@@ -92,6 +92,13 @@ enum fs_env {
   FS_ENV_WAVE_ATTENUATION_PO_MA = 8,/* MultiAgentWaveAttenuationPOEnv  flow/envs/multiagent/ring/wave_attenuation.py:128-252:
                                        per RL vehicle (column = rl_index) [v / 15, (v_lead - v) / 15, headway / max_length],
                                        obs 3 * num_rl; WaveAttenuationEnv's reward shared by the agents; crash = 0 */
+  FS_ENV_LANE_CHANGE_ACCEL_PO = 10, /* LaneChangeAccelPOEnv     flow/envs/ring/lane_change_accel.py:163-262: LaneChangeAccelEnv's
+                                       actions and reward; per RL vehicle (column c = rl_index) and lane q its nearest
+                                       leader / follower of that lane as flow/core/kernel/vehicle/traci.py:776-867 finds them:
+                                       obs[4 * lanes * c + {0, 1, 2, 3} * lanes + q] = gap to the leader [m], gap to the follower
+                                       [m], leader speed / v_max, follower speed / v_max (1000, 1000, 0, 0 for an empty lane; a
+                                       vehicle alone in its lane is its own leader and follower, one lap away), then
+                                       obs[4 * lanes * num_rl + c] = own speed [m/s]; obs 4 * lanes * num_rl + num_rl */
   FS_ENV_ACCEL_PO_MA = 9            /* MultiAgentAccelPOEnv     flow/envs/multiagent/ring/accel.py:84-227: per RL vehicle
                                        [x / L, v / v_max, (v_lead - v) / v_max, (x_lead - x - len_ego) / L,
                                        (v - v_follow) / v_max, headway(follower) / L], obs 6 * num_rl; desired_velocity

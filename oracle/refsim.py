@@ -32,6 +32,9 @@ FAILSAFE_NONE, FAILSAFE_INSTANTANEOUS, FAILSAFE_SAFE_VELOCITY = range(3)
 ENV_ACCEL, ENV_WAVE_ATTENUATION, ENV_WAVE_ATTENUATION_PO, ENV_LANE_CHANGE_ACCEL = range(4)
 # multi-agent ring heads (flow/envs/multiagent/ring/*): one observation block per RL vehicle, column = its rl_index
 ENV_WAVE_ATTENUATION_PO_MA, ENV_ACCEL_PO_MA = 8, 9
+# LaneChangeAccelPOEnv: LaneChangeAccelEnv's actions and reward, per-lane nearest leader / follower of every RL vehicle
+ENV_LANE_CHANGE_ACCEL_PO = 10
+LC_ENVS = (ENV_LANE_CHANGE_ACCEL, ENV_LANE_CHANGE_ACCEL_PO)
 
 
 def philox4x32_10(c0, c1, c2, c3, k0, k1):
@@ -639,7 +642,7 @@ class MultiLaneRingOracle(RingOracle):
         v_lead = np.where(lead >= 0, np.take_along_axis(v, li, 1), T(-1001))
         v_follow = np.take_along_axis(v, fi, 1)
         h_follow = np.take_along_axis(h, fi, 1)
-        per_rl = 2 if self.spec.get("env") == ENV_LANE_CHANGE_ACCEL else 1
+        per_rl = 2 if self.spec.get("env") in LC_ENVS else 1
         rl_value, rl_cmd = self._rl_inputs(actions, per_rl)
         acc, commanded = controller_dispatch(self, v, v_lead, h, has_lead, v_follow, h_follow, rl_value, rl_cmd,
                                              self._on_edge(), active, lambda: Rw.tree_sum(v) / T(self.N))
@@ -647,7 +650,7 @@ class MultiLaneRingOracle(RingOracle):
 
     # ---- ML3: the lane the RL vehicles are in after this sub-step's commands
     def _lane_changes(self, actions, active, h):
-        if actions is None or self.spec.get("env") != ENV_LANE_CHANGE_ACCEL:
+        if actions is None or self.spec.get("env") not in LC_ENVS:
             return self.lane
         T = self.dt_.type
         acts = np.asarray(actions, dtype=self.dt_)
@@ -769,7 +772,62 @@ class MultiLaneRingOracle(RingOracle):
         crash = np.any(has_new & (h_new < self.crash_gap), axis=1)
         return crash & active
 
+    def lane_neighbours(self):
+        """ML8: for every vehicle i and lane q the nearest leader / follower of that lane as the reference finds them
+        (flow/core/kernel/vehicle/traci.py:776-867: per lane the vehicles sorted by position, bisect_left at the own
+        position, then the edges ahead / behind all the way round the loop).  Stated on ring coordinates: the candidates
+        of lane q are ALL its vehicles, the vehicle itself included (the walk round the loop ends on its own edge: a
+        vehicle alone in its lane is its own leader and follower, one lap away); arc ahead of i to j = x_j - x_i, plus
+        L when negative or j == i (a vehicle of another lane at the SAME position is a leader, gap -length: bisect_left);
+        arc behind = x_i - x_j, plus L when <= 0.  Leader = smallest arc ahead (first in id order on a tie, as the stable
+        sort + bisect_left pick it), follower = smallest arc behind (last in id order on a tie).
+        Returns lead, foll [R, N, lanes] (slot or -1), headway, tailway [R, N, lanes] (1000 for an empty lane)."""
+        T = self.dt_.type
+        N, x = self.N, self.x
+        jj = np.arange(N)
+        Lr = self.L[:, None, None]
+        ahead = x[:, None, :] - x[:, :, None]
+        ahead = np.where((ahead < 0) | (jj[None, None, :] == jj[None, :, None]), ahead + Lr, ahead)
+        behind = x[:, :, None] - x[:, None, :]
+        behind = np.where(behind <= 0, behind + Lr, behind)
+        big = T(3.0e38)
+        lead, foll, hw, tw = [], [], [], []
+        for q in range(self.lanes):
+            cand = np.broadcast_to((self.lane == q)[:, None, :], ahead.shape)
+            al, bl = np.where(cand, ahead, big), np.where(cand, behind, big)
+            lj = np.argmin(al, axis=2)
+            fj = N - 1 - np.argmin(bl[:, :, ::-1], axis=2)
+            has = cand.any(axis=2)
+            a_min = np.take_along_axis(al, lj[:, :, None], 2)[:, :, 0]
+            b_min = np.take_along_axis(bl, fj[:, :, None], 2)[:, :, 0]
+            lead.append(np.where(has, lj, -1))
+            foll.append(np.where(has, fj, -1))
+            hw.append(np.where(has, a_min - self.veh_len[lj], T(1000.0)))
+            tw.append(np.where(has, b_min - self.veh_len[None, :], T(1000.0)))
+        return tuple(np.stack(a, axis=2) for a in (lead, foll, hw, tw))
+
+    def get_state_po(self):
+        """lane_change_accel.py:218-262 with the values it ends up holding: gaps in METRES (its normalisation divides a list
+        it has already copied from, :236-247), neighbour speeds over max_speed, the own speed in m/s.  EVERY RL vehicle's block
+        is filled here (the reference's `return` sits inside its loop over the RL vehicles: the host env applies that)."""
+        T = self.dt_.type
+        lead, foll, hw, tw = self.lane_neighbours()
+        ms = T(self.spec["max_speed"])
+        nrl, lanes = len(self.rl_slots), self.lanes
+        out = np.zeros((self.R, 4 * lanes * nrl + nrl), dtype=self.dt_)
+        for i, vs in enumerate(self.veh):
+            if vs["controller"] != CTRL_RL:
+                continue
+            c = vs["rl_index"]
+            vl = np.where(lead[:, i] >= 0, np.take_along_axis(self.v, np.maximum(lead[:, i], 0), 1) / ms, T(0))
+            vf = np.where(foll[:, i] >= 0, np.take_along_axis(self.v, np.maximum(foll[:, i], 0), 1) / ms, T(0))
+            out[:, 4 * lanes * c:4 * lanes * (c + 1)] = np.concatenate((hw[:, i], tw[:, i], vl, vf), axis=1)
+            out[:, 4 * lanes * nrl + c] = self.v[:, i]
+        return out
+
     def get_state(self):
+        if self.spec.get("env") == ENV_LANE_CHANGE_ACCEL_PO:
+            return self.get_state_po()
         if self.spec.get("env") != ENV_LANE_CHANGE_ACCEL:
             return super().get_state()
         T = self.dt_.type                                            # lane_change_accel.py:100-117
@@ -782,7 +840,7 @@ class MultiLaneRingOracle(RingOracle):
         return np.concatenate(out, axis=1)
 
     def compute_reward(self, actions, fail):
-        if self.spec.get("env") != ENV_LANE_CHANGE_ACCEL:
+        if self.spec.get("env") not in LC_ENVS:
             return super().compute_reward(actions, fail)
         T = self.dt_.type                                            # lane_change_accel.py:86-98
         reward = Rw.desired_velocity(self.v, self.spec["target_velocity"], fail)

@@ -617,10 +617,11 @@ def test_lane_change_accel_po_env_reference_tests_and_observation():
     assert obs.shape == (4 * 2 * 3 + 1,)                 # the reference returns inside its loop over the RL vehicles
     veh = env.k.vehicle
     rl = veh.get_rl_ids()[0]
-    np.testing.assert_allclose(obs[0:3], veh.get_lane_headways(rl))
-    np.testing.assert_allclose(obs[3:6], veh.get_lane_tailways(rl))
-    np.testing.assert_allclose(obs[6:9], [s / 30 for s in veh.get_lane_leaders_speed(rl)])
-    np.testing.assert_allclose(obs[9:12], [s / 30 for s in veh.get_lane_followers_speed(rl)])
+    # the kernel's row (float32 arithmetic on the device) against the host accessors (float64 on the same state)
+    np.testing.assert_allclose(obs[0:3], veh.get_lane_headways(rl), atol=1e-4)
+    np.testing.assert_allclose(obs[3:6], veh.get_lane_tailways(rl), atol=1e-4)
+    np.testing.assert_allclose(obs[6:9], [s / 30 for s in veh.get_lane_leaders_speed(rl)], atol=1e-6)
+    np.testing.assert_allclose(obs[9:12], [s / 30 for s in veh.get_lane_followers_speed(rl)], atol=1e-6)
     assert (obs[12:24] == 0).all() and obs[24] == veh.get_speed(rl)
 
     class AllRl(LaneChangeAccelPOEnv):

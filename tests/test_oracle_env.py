@@ -272,3 +272,34 @@ def test_float32_trajectory_tracks_float64():
     assert b.x.dtype == np.float32
     np.testing.assert_allclose(b.x, a.x, atol=2e-3)
     np.testing.assert_allclose(b.v, a.v, atol=2e-3)
+
+
+def test_per_lane_neighbours_known_answers_of_reference_test_vehicles():
+    """reference tests/fast_tests/test_vehicles.py:205-253 (TestMultiLaneData.test_no_junctions_ring): 21 vehicles side by
+    side in threes on a 3-lane ring of 230 m; lane leaders / headways / followers / tailways of test_0 -- the oracle's
+    restatement of _multi_lane_headways (MultiLaneRingOracle.lane_neighbours) and the LaneChangeAccelPOEnv row built on it.
+    The tailway 28.577143 crosses the ring's four junctions: 230 + 4 * 0.18 - 6 * 230 / 7 - 5."""
+    from helpers import idm_vehicle, multilane_spec
+    spec = multilane_spec(R=1, N=21, lanes=3, length=230.0, junction_length=0.18, env=S.ENV_LANE_CHANGE_ACCEL_PO)
+    spec["init_pos"] = np.repeat(np.arange(7) * 230.0 / 7.0, 3)[None, :]
+    spec["vehicles"] = [idm_vehicle(controller=S.CTRL_RL, rl_index=i) for i in range(21)]
+    spec["num_rl"] = 21
+    ora = S.MultiLaneRingOracle(spec, np.float64)
+    obs = ora.reset()
+    lead, foll, hw, tw = ora.lane_neighbours()
+    assert list(lead[0, 0]) == [3, 1, 2] and list(foll[0, 0]) == [18, 19, 20]
+    np.testing.assert_allclose(hw[0, 0], [27.85714285714286, -5, -5], atol=1e-9)
+    np.testing.assert_allclose(tw[0, 0], [28.577143] * 3, atol=1e-6)
+    np.testing.assert_allclose(obs[0, :12], [27.85714285714286, -5, -5] + [28.577143] * 3 + [0.0] * 6, atol=1e-6)
+    assert obs.shape == (1, 4 * 3 * 21 + 21)
+    # a vehicle alone in its lane is its own leader and follower one lap away (the reference's walk over the next / previous
+    # edges ends on its own edge, vehicle/traci.py:883-905); an empty lane reads 1000 / ''
+    spec = multilane_spec(R=1, N=3, lanes=3, length=100.0, junction_length=0.0, env=S.ENV_LANE_CHANGE_ACCEL_PO, n_rl=1)
+    spec["init_pos"] = np.array([[20.0, 30.0, 10.0]])
+    spec["init_lane"] = np.array([[1, 1, 0]], dtype=np.int32)
+    ora = S.MultiLaneRingOracle(spec, np.float64)
+    ora.reset()
+    lead, foll, hw, tw = ora.lane_neighbours()
+    assert list(lead[0, 2]) == [2, 0, -1] and list(foll[0, 2]) == [2, 1, -1]
+    np.testing.assert_allclose(hw[0, 2], [95.0, 5.0, 1000.0])
+    np.testing.assert_allclose(tw[0, 2], [95.0, 75.0, 1000.0])

@@ -429,6 +429,57 @@ def test_multilane_lane_change_commands_rate_limit_and_overlap_refusal():
     assert (ora2.last_lc > 0).any()
 
 
+def test_lane_change_accel_po_head_bit_exact_incl_empty_lanes_and_lone_vehicles():
+    """FS_ENV_LANE_CHANGE_ACCEL_PO: per RL vehicle and lane the nearest leader / follower of that lane, found by the
+    step kernel (k_steps_ml) as flow/core/kernel/vehicle/traci.py:776-867 finds them; LaneChangeAccelEnv's actions and
+    reward.  Random lane-change commands move the RL vehicles through all lanes; the second configuration has an EMPTY
+    lane (1000 / 1000 / 0 / 0), a lane whose only vehicle is the RL vehicle itself (its own leader and follower, one lap
+    away) once it has moved there, and vehicles side by side at one position (leader with gap -length, never follower)."""
+    R, N, K = 6, 14, 150
+    spec = multilane_spec(R=R, N=N, lanes=3, length=200.0, horizon=K, n_rl=3, seed=3, lane_change_duration=2,
+                          env=S.ENV_LANE_CHANGE_ACCEL_PO, lane_change_mode=0)
+    rng = np.random.default_rng(12)
+    acts = np.zeros((K, R, 6), dtype=np.float32)
+    acts[:, :, 0::2] = rng.uniform(-1.0, 1.5, (K, R, 3))
+    acts[:, :, 1::2] = rng.integers(-1, 2, (K, R, 3))
+    ora = run_pair_ml(spec, "f32", K, actions=acts)
+    assert (ora.last_lc > 0).any() and ora.get_state().shape == (R, 4 * 3 * 3 + 3)
+    run_pair_ml(dict(spec, sort_vehicles=True), "f32", 60, actions=acts)          # actions in sorted RL order, same head
+    run_pair_ml(spec, "f64", 60, actions=acts, exact=False, atol=1e-9)
+    # 4 lanes, 5 vehicles: lanes 0 / 1 hold two humans each (side by side in pairs), lane 2 is empty, the RL vehicle starts
+    # alone in lane 3 and wanders
+    R, N, K = 5, 5, 120
+    spec = multilane_spec(R=R, N=N, lanes=4, length=120.0, horizon=K, n_rl=1, seed=5, lane_change_duration=0,
+                          env=S.ENV_LANE_CHANGE_ACCEL_PO, lane_change_mode=0, last_lc_quirk=False)
+    spec["init_lane"] = np.tile(np.array([0, 1, 0, 1, 3], dtype=np.int32), (R, 1))
+    X = np.tile(np.array([10.0, 10.0, 60.0, 60.0, 10.0]), (R, 1))
+    X[1:, 4] += np.arange(1, R) * 7.0                     # replica 0: the RL vehicle starts side by side with two humans
+    spec["init_pos"] = X
+    acts = np.zeros((K, R, 2), dtype=np.float32)
+    acts[:, :, 0] = rng.uniform(-0.5, 1.0, (K, R))
+    acts[20::15, :, 1] = -1
+    acts[27::30, :, 1] = 1
+    sim, ora = make(spec, "f32"), S.MultiLaneRingOracle(spec, np.float32)
+    o0 = sim.reset()
+    np.testing.assert_array_equal(o0, ora.reset().astype(np.float32))
+    lanes = 4
+    np.testing.assert_array_equal(o0[:, 2], [1000.0] * R)                              # the empty lane
+    np.testing.assert_array_equal(o0[:, lanes + 2], [1000.0] * R)
+    np.testing.assert_array_equal(o0[:, 3], np.float32(120.4 - 5.0))                    # alone in lane 3: itself, one lap away
+    np.testing.assert_array_equal(o0[:, lanes + 3], np.float32(120.4 - 5.0))
+    assert o0[0, 0] == -5.0 and o0[0, 1] == -5.0                                       # side by side: leaders, gap -length
+    np.testing.assert_array_equal(o0[0, lanes:lanes + 2], np.float32([120.4 - 50.0 - 5.0] * 2))   # ... never followers
+    seen_lanes = set()
+    for k in range(K):
+        o, r, d = sim.step(acts[k])
+        o_ref, r_ref, d_ref = ora.step(acts[k])
+        np.testing.assert_array_equal(o, o_ref.astype(np.float32), err_msg="step %d" % k)
+        np.testing.assert_array_equal(r, r_ref.astype(np.float32))
+        seen_lanes |= set(ora.lane[:, 4])
+    assert seen_lanes == {0, 1, 2, 3}
+    sim.close()
+
+
 def test_multilane_mixed_controllers_and_single_vehicle_lanes():
     """A lane holding one vehicle has no leader (headway 1000, get_speed(None) = -1001 for LAC / Gipps)."""
     R, N = 4, 7
@@ -1089,3 +1140,22 @@ def test_c3_full_size_launch_4096_replicas_1500_steps():
     np.testing.assert_array_equal(c.pos[pick], ora.x)
     np.testing.assert_array_equal(c.vel[pick], ora.v)
     c.close()
+
+
+def test_lane_change_envs_on_a_one_lane_ring_step_on_the_multilane_kernel():
+    """The reference's own TestLaneChangeAccelEnv / TestLaneChangeAccelPOEnv run on a ONE-lane ring: lane-change commands are
+    clipped to lane 0, the heads (3 N values / per-lane neighbours) are those of k_steps_ml."""
+    R, N, K = 4, 9, 60
+    rng = np.random.default_rng(2)
+    acts = np.zeros((K, R, 4), dtype=np.float32)
+    acts[:, :, 0::2] = rng.uniform(-1.0, 1.0, (K, R, 2))
+    acts[:, :, 1::2] = rng.integers(-1, 2, (K, R, 2))
+    for env in (S.ENV_LANE_CHANGE_ACCEL, S.ENV_LANE_CHANGE_ACCEL_PO):
+        spec = multilane_spec(R=R, N=N, lanes=1, length=150.0, horizon=K, n_rl=2, seed=1, env=env)
+        sim = make(spec, "f32")
+        sim.reset()
+        sim.step(acts[0])
+        assert sim.last_kernel == "k_steps_ml"
+        sim.close()
+        ora = run_pair_ml(spec, "f32", K, actions=acts)
+        assert (ora.lane == 0).all()
