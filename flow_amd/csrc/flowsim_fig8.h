@@ -48,6 +48,24 @@ __device__ __forceinline__ float lead16(float v, bool wrap) {
   return wrap ? w : t;
 }
 
+// min / max as ONE instruction.  tmin / tmax (a < b ? a : b) compile to v_cmp + s_nop + v_cndmask -- hipcc may not
+// assume the operands are numbers -- and a wave alone on its SIMD pays every one of those issue slots, a dozen times per
+// step.  v_min_f32 / v_max_f32 return the same value for every pair of numbers; for a pair of zeros of opposite sign they
+// may return the other zero, which no consumer in this kernel tells apart (sums with non-zero terms, products, compares
+// -- the sign-mask predicates below take differences a - b, and 0 - 0 is +0 whatever the signs unless a is -0 and b
+// is +0: every b of such a test is a launch constant or a position, never a -0).  k_rollout_pair's hand-written step
+// uses the same instructions.
+__device__ __forceinline__ float hmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float hmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// x >= y ? x - y : x for 0 <= x < 2 y (a position past the end of the loop), and d < 0 ? d + y : d for -y <= d < y (an
+// arc): non-negative floats order like their bit patterns and a negative one is a huge unsigned, so both are one v_min_u32
+__device__ __forceinline__ float wrap_down(float x, float y) {
+  return __builtin_bit_cast(float, min(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x - y)));
+}
+__device__ __forceinline__ float wrap_up(float d, float y) {
+  return __builtin_bit_cast(float, min(__builtin_bit_cast(unsigned, d), __builtin_bit_cast(unsigned, d + y)));
+}
+
 // ctrl_idm / sumo_idm_speed (flowsim_kernels.h) with their divisions made cheap WITHOUT changing a bit: divisors
 // that are launch constants go through divc, the others (|h| >= 1e-3, gap >= 1e-3; dividends s* >= s0 >= 1e-3 and
 // ss >= minGap >= 1e-3, host-checked) through div_core
@@ -56,7 +74,7 @@ template <bool DELTA4, bool FASTC = false>
 __device__ __forceinline__ float idm_fast(float v, float vl, float h, bool has, const IdmC& c) {
   const float hh = tabs(h) < 1e-3f ? 1e-3f : h;
   const float dyn = v * c.p1 + divk<FASTC>(v * (v - vl), c.two_sqrt);
-  const float s_star = has ? c.p5 + tmax(0.0f, dyn) : 0.0f;
+  const float s_star = has ? c.p5 + hmax(0.0f, dyn) : 0.0f;
   const float q = div_core(s_star, hh);
   const float ratio = divk<FASTC>(v, c.v0);
   float pw;
@@ -66,13 +84,13 @@ __device__ __forceinline__ float idm_fast(float v, float vl, float h, bool has, 
 struct SumoC { float min_gap, tau, max_accel; DivC two_sqrt, max_speed; };
 template <bool FASTC = false>
 __device__ __forceinline__ float sumo_fast(float v, float vl, float h, bool has, float dt, const SumoC& c) {
-  const float gap = tmax(h, 1e-3f);
-  const float ss = c.min_gap + tmax(0.0f, v * c.tau + divk<FASTC>(v * (v - vl), c.two_sqrt));
+  const float gap = hmax(h, 1e-3f);
+  const float ss = c.min_gap + hmax(0.0f, v * c.tau + divk<FASTC>(v * (v - vl), c.two_sqrt));
   const float q = has ? div_core(ss, gap) : 0.0f;
   const float r = divk<FASTC>(v, c.max_speed);
   const float r2 = r * r;
   const float acc = c.max_accel * (1.0f - r2 * r2 - q * q);
-  return tmax(0.0f, v + acc * dt);
+  return hmax(0.0f, v + acc * dt);
 }
 
 // FULL: the launch is known to have noisy slots, speed-mode clamps / uncommanded slots, the crossing and an action
@@ -173,7 +191,7 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
   const T ja_in = in_vgpr(s.ja_in), ja_out = in_vgpr(s.ja_out), jb_in = in_vgpr(s.jb_in), jb_out = in_vgpr(s.jb_out);
   const T look = in_vgpr(s.j_lookahead), tgap = in_vgpr(s.j_time_gap);
   const T za_lo = in_vgpr(s.za_lo), za_hi = in_vgpr(s.za_hi), zb_lo = in_vgpr(s.zb_lo), zb_hi = in_vgpr(s.zb_hi);
-  const T act_lo = in_vgpr(s.act_lo), act_hi = in_vgpr(s.act_hi), max_cost = in_vgpr(s.max_cost);
+  const T max_cost = in_vgpr(s.max_cost);
   const T Lv = in_vgpr(L);
   const DivC d_ms = make_divc(s.max_speed), d_L = make_divc(L), d_15 = make_divc(15.0f), d_po = make_divc(s.po_max_length);
   IdmC ic;
@@ -187,7 +205,8 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
   const unsigned seg_internal = s.seg_internal;
   const bool junction_on = FULL || s.junction_on != 0, need_sumo = FULL || (flags & FLAG_NEED_SUMO) != 0;
   const bool gated = s.junction_mode && sl.ctrl != FS_CTRL_RL && sl.ctrl != FS_CTRL_SIM;
-  const bool clip = s.clip_actions != 0;
+  // (clipping as an unconditional clamp: without clip_actions the bounds are +-3e38)
+  const T clip_lo = in_vgpr(s.clip_actions != 0 ? s.act_lo : T(-3.0e38)), clip_hi = in_vgpr(s.clip_actions != 0 ? s.act_hi : T(3.0e38));
   const bool rl_lane = sl.ctrl == FS_CTRL_RL, sim_lane = sl.ctrl == FS_CTRL_SIM;
   const bool use_act = FULL || actions != nullptr;
   const int num_rl = s.num_rl;
@@ -217,6 +236,8 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
       }
     }
   }
+  const float* a_own_p = actions + size_t(PERIOD) * act_stride + size_t(rr) * num_rl + own_col;
+  const float* a_red_p = actions + size_t(PERIOD) * act_stride + size_t(rr) * num_rl + red_col;
   // the four draws of the current noise block, ROTATED so that g4[0] is always the draw of the next step (no
   // per-step index select); a launch that starts in the middle of a block evaluates it and rotates up to there
   T g4[4] = {T(0), T(0), T(0), T(0)};
@@ -305,9 +326,10 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
         flush_obs();
         if (slot == 0) flush_rew();
         if (use_act && step + PERIOD < num_steps) {
-          const float* an = actions + size_t(step + PERIOD) * act_stride + size_t(rr) * num_rl;
-          a_own_q[slot] = an[own_col];
-          a_red_q[slot] = an[red_col];
+          a_own_q[slot] = *a_own_p;                              // the row of step + PERIOD (running pointers: one
+          a_red_q[slot] = *a_red_p;                              // 64-bit add per step instead of the index arithmetic)
+          a_own_p += act_stride;
+          a_red_p += act_stride;
         }
         // ---- controllers on the snapshot (control_accel_on, CSET = 1) ----------------------------------
         // commanded (base_controller.py:93-106): an RL lane when there are actions, never a SimCarFollowing lane, any
@@ -324,25 +346,27 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
         }
         {
           T a = idm_fast<DELTA4, FULL>(v, vl, h, has, ic);
+          // (every lane evaluates it: left to itself hipcc wraps the evaluation into an exec-mask region of the lanes that
+          // use it -- s_and_saveexec, a branch, s_or -- which costs a wave alone on its SIMD more than the masked lanes save)
+          if (FULL) asm volatile("" : "+v"(a));
           if (any_noise) {
             const T an = a + sl.noise * g4[0];
             a = noisy ? an : a;
             g4[0] = g4[1]; g4[1] = g4[2]; g4[2] = g4[3];
           }
-          T arl = T(a_own);
-          if (clip) arl = tmin(tmax(arl, act_lo), act_hi);
+          const T arl = hmin(hmax(T(a_own), clip_lo), clip_hi);
           acc = rl_lane ? (use_act ? arl : T(0)) : (sim_lane ? T(0) : a);
         }
         // ---- apply_acceleration + SUMO integration (S4-S9) ---------------------------------------------
-        T next_vel = tmax(v + acc * dt, T(0));
+        T next_vel = hmax(v + acc * dt, T(0));
         T vc = v + (next_vel - v) * ramp;
         T v_new = vc;
         if (need_sumo) {
           T v_sumo = sumo_fast<FULL>(v, vl, h, has, dt, sc);
           // S7/S8 without a per-slot test: a slot whose bit is clear holds 3e38 in the clamp's place (k_rollout_pair's form)
-          vc = tmin(vc, sm1_lane ? v_sumo : T(3.0e38));
-          vc = tmin(vc, v + adt_c);
-          vc = tmax(vc, v - ddt_c);
+          vc = hmin(vc, sm1_lane ? v_sumo : T(3.0e38));
+          vc = hmin(vc, v + adt_c);
+          vc = hmax(vc, v - ddt_c);
           v_new = commanded ? vc : v_sumo;
         }
         if (junction_on) {
@@ -355,14 +379,14 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
             cap = on_any ? cap : T(3.0e38);
             if (cap2_m != 0ull) {                                // degenerate table: both lines ahead of one vehicle
               const T cap_a = sumo_fast<FULL>(v, T(0), ja_in - x, true, dt, sc);
-              cap = on_both ? tmin(cap, cap_a) : cap;
+              cap = hmin(cap, on_both ? cap_a : T(3.0e38));
             }
             const bool cap_applies = (sm1_u | (commanded_u ^ 1u)) != 0u;          // (speed_mode & 1) || !commanded
-            v_new = tmin(v_new, cap_applies ? cap : T(3.0e38));
+            v_new = hmin(v_new, cap_applies ? cap : T(3.0e38));
           }
         }
         T x_new = x + v_new * dt;
-        x_new = x_new >= Lv ? x_new - Lv : x_new;
+        x_new = wrap_down(x_new, Lv);
         prev_v = v;
         last_acc = acc;
         x = x_new;
@@ -381,8 +405,7 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
         // ---- new neighbour snapshot (S10) + per-replica facts of the new state -----------------------------
         xl = lead16(x, wrap_lead);
         vl = lead16(v, wrap_lead);
-        d = xl - x;
-        d = d < T(0) ? d + Lv : d;
+        d = wrap_up(xl - x, Lv);
         h = has ? d - len_lead : T(1000);
         // bit 0 a gap below crash_gap, bits 1 / 2 a body on the crossing point of stream a / b, bit 3 v < -100 (sign masks)
         unsigned f2 = sm_lt(h, crash_gap) >> 31;
@@ -420,9 +443,7 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
           red[slot] = valid ? v : T(0);
           T a = T(0);
           if (red_lane && use_act) {
-            a = T(a_red);
-            if (clip) a = tmin(tmax(a, act_lo), act_hi);
-            a = tabs(a);
+            a = tabs(hmin(hmax(T(a_red), clip_lo), clip_hi));
           }
           red2[slot] = a;
         } else {

@@ -1,0 +1,9 @@
+"""C3 (figure eight, 13 noisy IDM + 1 RL) rollout rate, both heads: bench.py's own leg, three runs each."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import bench
+dev = torch.device("cuda", 0)
+for po in (False, True):
+    best = max(bench.c3_leg(dev, po=po)["value"] for _ in range(3))
+    print("C3 %s: %.3f G env-steps/s" % ("WaveAttenuationPOEnv" if po else "AccelEnv", best / 1e9))
