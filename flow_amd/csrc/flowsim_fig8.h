@@ -48,15 +48,6 @@ __device__ __forceinline__ float lead16(float v, bool wrap) {
   return wrap ? w : t;
 }
 
-// min / max as ONE instruction.  tmin / tmax (a < b ? a : b) compile to v_cmp + s_nop + v_cndmask -- hipcc may not
-// assume the operands are numbers -- and a wave alone on its SIMD pays every one of those issue slots, a dozen times per
-// step.  v_min_f32 / v_max_f32 return the same value for every pair of numbers; for a pair of zeros of opposite sign they
-// may return the other zero, which no consumer in this kernel tells apart (sums with non-zero terms, products, compares
-// -- the sign-mask predicates below take differences a - b, and 0 - 0 is +0 whatever the signs unless a is -0 and b
-// is +0: every b of such a test is a launch constant or a position, never a -0).  k_rollout_pair's hand-written step
-// uses the same instructions.
-__device__ __forceinline__ float hmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float hmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // x >= y ? x - y : x for 0 <= x < 2 y (a position past the end of the loop), and d < 0 ? d + y : d for -y <= d < y (an
 // arc): non-negative floats order like their bit patterns and a negative one is a huge unsigned, so both are one v_min_u32
 __device__ __forceinline__ float wrap_down(float x, float y) {

@@ -137,6 +137,17 @@ __device__ __forceinline__ uint8_t done_flag(bool horizon, bool crashed) {
 // ---------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ T tmax(T a, T b) { return a > b ? a : b; }   // np.maximum (no NaN)
 template <typename T> __device__ __forceinline__ T tmin(T a, T b) { return a < b ? a : b; }   // np.minimum (no NaN)
+// min / max as ONE instruction.  tmin / tmax (a < b ? a : b) compile to v_cmp + s_nop + v_cndmask -- hipcc may not
+// assume the operands are numbers -- and a wave alone on its SIMD pays every one of those issue slots, a dozen times per
+// step.  v_min_f32 / v_max_f32 return the same value for every pair of numbers; for a pair of zeros of opposite sign they
+// may return the other zero, which no consumer in the rollout kernels that use them tells apart (sums with non-zero terms, products, compares
+// -- the sign-mask predicates of flowsim_fig8.h take differences a - b, and 0 - 0 is +0 whatever the signs unless a is -0 and b
+// is +0: every b of such a test is a launch constant or a position, never a -0).  k_rollout_pair's hand-written step
+// uses the same instructions.
+// (evaluate them BEFORE a select, `const float m = hmax(..); r = c ? m : r;` -- inside the arms of ?: they are conditional
+// code, and hipcc builds an exec-mask region, s_and_saveexec + branch + s_or, around a one-cycle instruction)
+__device__ __forceinline__ float hmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float hmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // __builtin_sqrt* is correctly rounded under hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt;
 // __fsqrt_rn is NOT (it maps to the native 1-ulp v_sqrt_f32 in this toolchain).
 __device__ __forceinline__ float tsqrt(float x) { return __builtin_sqrtf(x); }

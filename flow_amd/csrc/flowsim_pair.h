@@ -50,7 +50,7 @@ __device__ __forceinline__ f2 pk_fnma(f2 a, f2 b, f2 c) { return fma2(-a, b, c);
 // integers, so this is one v_min_u32 on the bit patterns when additionally x <= y whenever x >= 0
 __device__ __forceinline__ float nonneg_else(float x, float y) {
   const unsigned a = __builtin_bit_cast(unsigned, x), b = __builtin_bit_cast(unsigned, y);
-  return __builtin_bit_cast(float, a < b ? a : b);
+  return __builtin_bit_cast(float, min(a, b));             // (a < b ? a : b compiles to v_cmp + s_nop + v_cndmask)
 }
 
 // value of slot A of the NEXT lane of the row (lane 0's for the last occupied lane and its idle clones)

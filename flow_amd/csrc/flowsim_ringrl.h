@@ -184,12 +184,10 @@ __global__ __launch_bounds__(256) void k_ring_pair(DevView<T> s, int num_steps_a
     }
   };
   if (have_act && num_steps > 0) load_actions(0);
-  const float act_lo = float(s.act_lo), act_hi = float(s.act_hi);
+  // clipping as an unconditional clamp (two instructions, no branch, no select): without clip_actions the bounds are +-3e38
   const bool clip_on = s.clip_actions != 0;
-  auto clip = [&](float a) -> float {               // (both forms evaluated, one select: no branch in the step)
-    const float c = tmin(tmax(a, act_lo), act_hi);
-    return clip_on ? c : a;
-  };
+  const float act_lo = clip_on ? float(s.act_lo) : -3.0e38f, act_hi = clip_on ? float(s.act_hi) : 3.0e38f;
+  auto clip = [&](float a) -> float { return hmin(hmax(a, act_lo), act_hi); };
 
   // sigma * g of this step for the lane's two vehicles (-0.0 for a slot without noise: x + (-0) keeps every bit of x);
   // a replica that does not advance keeps its draws
@@ -266,8 +264,9 @@ __global__ __launch_bounds__(256) void k_ring_pair(DevView<T> s, int num_steps_a
     const bool live = LIVE_ALL ? true : live_replica;
     f2 acc = idm_pair<FAST, FAST>(v, vl, h, p, two_sqrt_ab, rc_ab, rc_v0, one);
     if constexpr (NOISE) acc = pk_add(acc, LIVE_ALL ? nz_in : noise_term(live));
-    acc.x = rlA ? clip(ownA) : acc.x;
-    acc.y = rlB ? clip(ownB) : acc.y;
+    const float clA = clip(ownA), clB = clip(ownB);
+    acc.x = rlA ? clA : acc.x;
+    acc.y = rlB ? clB : acc.y;
     const bool cmdA = !rlA || have_act, cmdB = !rlB || have_act;       // rl_actions = None: no command (S5)
     // SUMO's model is evaluated unconditionally: without a speed-mode bit its caps are 3e38 (the identity), and every
     // population this kernel is chosen for has an RL slot (FLAG_NEED_SUMO) anyway -- no wave-uniform branch in the step
@@ -293,18 +292,19 @@ __global__ __launch_bounds__(256) void k_ring_pair(DevView<T> s, int num_steps_a
       v = f2{float(vdA), float(vdB)};
     } else {
       f2 nv = pk_add(v, pk_mul(acc, dt2));
-      nv.x = tmax(nv.x, 0.0f);
-      nv.y = tmax(nv.y, 0.0f);
+      nv.x = hmax(nv.x, 0.0f);
+      nv.y = hmax(nv.y, 0.0f);
       f2 vc = pk_add(v, pk_mul(pk_sub(nv, v), ramp2));
       {                          // S7/S8: min(vc, v_sumo), min(vc, v + max_accel dt), max(vc, v - max_decel dt)
         const f2 vs = pk_add(v, pk_mul(acc_s, dt2));
         const f2 cap1 = pk_add(v, sc.adt), flo = pk_sub(v, sc.ddt);
-        vc.x = tmin(vc.x, tmax(sc.floor0.x, vs.x));
-        vc.y = tmin(vc.y, tmax(sc.floor0.y, vs.y));
-        vc.x = tmax(tmin(vc.x, cap1.x), flo.x);
-        vc.y = tmax(tmin(vc.y, cap1.y), flo.y);
-        vc.x = cmdA ? vc.x : tmax(0.0f, vs.x);
-        vc.y = cmdB ? vc.y : tmax(0.0f, vs.y);
+        vc.x = hmin(vc.x, hmax(sc.floor0.x, vs.x));
+        vc.y = hmin(vc.y, hmax(sc.floor0.y, vs.y));
+        vc.x = hmax(hmin(vc.x, cap1.x), flo.x);
+        vc.y = hmax(hmin(vc.y, cap1.y), flo.y);
+        const float zA = hmax(0.0f, vs.x), zB = hmax(0.0f, vs.y);
+        vc.x = cmdA ? vc.x : zA;
+        vc.y = cmdB ? vc.y : zB;
       }
       const f2 xn = pk_add(x, pk_mul(vc, dt2));
       const f2 xw = pk_sub(xn, L2);                  // x_new >= L ? x_new - L : x_new  (0 <= x_new - L < x_new)
@@ -323,10 +323,15 @@ __global__ __launch_bounds__(256) void k_ring_pair(DevView<T> s, int num_steps_a
   // the lane's terms of the replica's reductions after a step: flags (bit 0 a gap below crash_gap, bit 1 a speed below
   // -100, rewards.py:46), first sum (PO: speeds; Accel: squared deviations), second sum (PO: |actions|)
   auto terms = [&](float aredA, float aredB, unsigned& fl, float& t0, float& t1) {
-    fl = (valid && ((h.x < gap2.x) || (h.y < gap2.x)) ? 1u : 0u) | (valid && ((v.x < -100.0f) || (v.y < -100.0f)) ? 2u : 0u);
+    // h < gap <=> h - gap negative (no -0 from a non-zero difference, denormals are kept), v < -100 likewise; the smaller
+    // of the lane's two differences carries the sign (flowsim_pair.h one_step)
+    const f2 hc = pk_sub(h, gap2), vb = pk_sub(v, f2{-100.0f, -100.0f});
+    fl = ((__builtin_bit_cast(unsigned, hmin(hc.x, hc.y)) >> 31) | ((__builtin_bit_cast(unsigned, hmin(vb.x, vb.y)) >> 31) << 1)) &
+         (valid ? 3u : 0u);
     if (HEAD == 1) {
       t0 = valid ? v.x + v.y : 0.0f;
-      t1 = (redA ? tabs(clip(aredA)) : 0.0f) + (redB ? tabs(clip(aredB)) : 0.0f);
+      const float caA = tabs(clip(aredA)), caB = tabs(clip(aredB));
+      t1 = (redA ? caA : 0.0f) + (redB ? caB : 0.0f);
     } else {
       const float tv = float(s.target_velocity);
       const f2 dv = {valid ? v.x - tv : 0.0f, valid ? v.y - tv : 0.0f};
@@ -408,6 +413,26 @@ __global__ __launch_bounds__(256) void k_ring_pair(DevView<T> s, int num_steps_a
     };
     float a_cur = 0.0f, a_nxt = 0.0f;
     if (deep && step + 16 <= num_steps) a_nxt = group_actions(step);
+    // WaveAttenuationPOEnv rows of a block, finished TOGETHER: the three quotients of a step are exact divisions through
+    // float64 (div_via_f64: five instructions, three of them float64, all of them issued for the ONE lane that holds the
+    // RL vehicle).  Instead the lane pushes its twelve numerators of a block into a row-wide shift register (rotate the
+    // row by one lane, insert at the RL vehicle's lane: two instructions per value) and after the block twelve lanes of
+    // the row divide one value each and store it -- one division sequence per block instead of twelve.
+    // Lane offset o = (k - k_po) mod 16 ends up with numerator 11 - o (step (11 - o) / 3 of the block, value (11 - o) % 3).
+    constexpr bool PO_ROWS = HEAD == 1 && !MIXED;
+    const bool po_lane = poA || poB;
+    const unsigned long long po_m = __ballot(po_lane);
+    const int k_po = po_m ? (__builtin_ctzll(po_m) & 15) : 0;
+    const int po_idx = 11 - ((k - k_po) & 15);                        // < 0: the row's four spare lanes
+    const int po_st = po_idx < 0 ? 0 : po_idx / 3, po_c = po_idx < 0 ? 0 : po_idx % 3;
+    const double po_div = po_c == 2 ? pml64 : 15.0, po_rc = po_c == 2 ? rc_pml64 : rc15;
+    const size_t po_off = size_t(po_st) * step_rows * obs_dim + po_c;
+    const bool po_store = rvalid && po_idx >= 0;
+    float oacc = 0.0f;
+    auto po_push = [&](float n) {
+      oacc = dpp<0x120 + 1>(oacc);                                    // row_ror:1 (lane i <- lane i - 1)
+      oacc = po_lane ? n : oacc;
+    };
 #pragma unroll 1
     for (; step + 16 <= num_steps; step += 16) {
       a_cur = a_nxt;
@@ -431,13 +456,25 @@ __global__ __launch_bounds__(256) void k_ring_pair(DevView<T> s, int num_steps_a
             nz.y = noisyB ? tB : -0.0f;
           }
           advance(std::true_type{}, a, a, nz);
-          write_obs();
-          orow += step_rows * obs_dim;
+          if constexpr (PO_ROWS) {
+            const float v_me = poB ? v.y : v.x, v_ld = poB ? vl.y : vl.x, d_me = poB ? dgap.y : dgap.x;
+            po_push(v_me);
+            po_push(v_ld - v_me);
+            po_push(d_me);
+          } else {
+            write_obs();
+            orow += step_rows * obs_dim;
+          }
           unsigned fl;
           terms(a, 0.0f, fl, t0[slot], t1[slot]);
           crash_bits = (crash_bits << 1) | (fl & 1u);
           bad_bits = (bad_bits << 1) | (fl >> 1);
         });
+        if constexpr (PO_ROWS) {
+          const float q = div_via_f64(oacc, po_div, po_rc);
+          if (po_store) orow[po_off] = q;
+          orow += size_t(4) * step_rows * obs_dim;
+        }
         const float s0 = transposed_sum<ROW, 4>(t0, lane);
         const float s1 = HEAD == 1 ? transposed_sum<ROW, 4>(t1, lane) : 0.0f;
         const unsigned crash_any = seg_or<ROW>(crash_bits), bad_any = seg_or<ROW>(bad_bits);
