@@ -295,12 +295,11 @@ __global__ __launch_bounds__(256) void k_ring_policy(DevView<T> s, PolicyView pv
   f2 h = headway();
   f2 vl = {v.y, next_a<ROW>(v.x, last, lane)};
 
-  const float act_lo = float(s.act_lo), act_hi = float(s.act_hi);
+  // (k_ring_pair's forms: an unconditional clamp with +-3e38 bounds without clip_actions; one-instruction min / max
+  // evaluated before the selects that take them)
   const bool clip_on = s.clip_actions != 0;
-  auto clip = [&](float a) -> float {
-    const float c = tmin(tmax(a, act_lo), act_hi);
-    return clip_on ? c : a;
-  };
+  const float act_lo = clip_on ? float(s.act_lo) : -3.0e38f, act_hi = clip_on ? float(s.act_hi) : 3.0e38f;
+  auto clip = [&](float a) -> float { return hmin(hmax(a, act_lo), act_hi); };
   auto noise_term = [&](bool live) -> f2 {
     f2 nz = {-0.0f, -0.0f};
     if constexpr (NOISE) {
@@ -326,8 +325,9 @@ __global__ __launch_bounds__(256) void k_ring_policy(DevView<T> s, PolicyView pv
   auto advance = [&](bool live, bool have_act, float a_rl) {
     f2 acc = idm_pair<FAST, FAST>(v, vl, h, p, two_sqrt_ab, rc_ab, rc_v0, one);
     if constexpr (NOISE) acc = pk_add(acc, noise_term(live));
-    acc.x = rlA ? clip(a_rl) : acc.x;
-    acc.y = rlB ? clip(a_rl) : acc.y;
+    const float a_cl = clip(a_rl);
+    acc.x = rlA ? a_cl : acc.x;
+    acc.y = rlB ? a_cl : acc.y;
     const bool cmdA = !rlA || have_act, cmdB = !rlB || have_act;
     const f2 acc_s = sumo_acc_pair<FAST>(v, vl, h, sc, one);
     if (MIXED) {
@@ -349,17 +349,18 @@ __global__ __launch_bounds__(256) void k_ring_policy(DevView<T> s, PolicyView pv
       v = f2{float(vdA), float(vdB)};
     } else {
       f2 nv = pk_add(v, pk_mul(acc, dt2));
-      nv.x = tmax(nv.x, 0.0f);
-      nv.y = tmax(nv.y, 0.0f);
+      nv.x = hmax(nv.x, 0.0f);
+      nv.y = hmax(nv.y, 0.0f);
       f2 vc = pk_add(v, pk_mul(pk_sub(nv, v), ramp2));
       const f2 vs = pk_add(v, pk_mul(acc_s, dt2));
       const f2 cap1 = pk_add(v, sc.adt), flo = pk_sub(v, sc.ddt);
-      vc.x = tmin(vc.x, tmax(sc.floor0.x, vs.x));
-      vc.y = tmin(vc.y, tmax(sc.floor0.y, vs.y));
-      vc.x = tmax(tmin(vc.x, cap1.x), flo.x);
-      vc.y = tmax(tmin(vc.y, cap1.y), flo.y);
-      vc.x = cmdA ? vc.x : tmax(0.0f, vs.x);
-      vc.y = cmdB ? vc.y : tmax(0.0f, vs.y);
+      vc.x = hmin(vc.x, hmax(sc.floor0.x, vs.x));
+      vc.y = hmin(vc.y, hmax(sc.floor0.y, vs.y));
+      vc.x = hmax(hmin(vc.x, cap1.x), flo.x);
+      vc.y = hmax(hmin(vc.y, cap1.y), flo.y);
+      const float zA = hmax(0.0f, vs.x), zB = hmax(0.0f, vs.y);
+      vc.x = cmdA ? vc.x : zA;
+      vc.y = cmdB ? vc.y : zB;
       const f2 xn = pk_add(x, pk_mul(vc, dt2));
       const f2 xw = pk_sub(xn, L2);
       f2 xq;
@@ -380,7 +381,24 @@ __global__ __launch_bounds__(256) void k_ring_policy(DevView<T> s, PolicyView pv
   const bool poA = valid && rlA, poB = valid && rlB;
   const double rc15 = 1.0 / 15.0, pml64 = double(s.po_max_length), rc_pml64 = 1.0 / pml64;
   float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
+  // float32: the three quotients are exact divisions through float64 (five instructions each, issued for one lane):
+  // the RL vehicle's lane hands its second and third numerator to its two neighbours (row rotations) and the three lanes
+  // divide one value each -- one division sequence per step instead of three
+  const unsigned long long po_m = __ballot(poA || poB);
+  const int k_po = po_m ? (__builtin_ctzll(po_m) & (ROW - 1)) : 0;
+  const int po_c = (k - k_po) & (ROW - 1);                               // 0: the RL vehicle's lane, 1 / 2: its helpers
+  const double po_div = po_c == 2 ? pml64 : 15.0, po_rc = po_c == 2 ? rc_pml64 : rc15;
   auto observe = [&](float* orow) {
+    if constexpr (!MIXED && ROW == 16) {
+      const float v_me = poB ? v.y : v.x, v_ld = poB ? vl.y : vl.x, d_me = poB ? dgap.y : dgap.x;
+      const float n1 = dpp<0x120 + 1>(v_ld - v_me), n2 = dpp<0x120 + 2>(d_me);      // row_ror: lane i <- lane i - 1 / i - 2
+      const float n = po_c == 0 ? v_me : (po_c == 1 ? n1 : n2);
+      const float q = div_via_f64(n, po_div, po_rc);
+      if (rvalid && po_c < 3) {
+        orow[po_c] = q;
+        PL.obs[wib][row][po_c] = q;
+      }
+    } else {
     float q0, q1, q2;
     if (MIXED) {
       const double vdn = next_a<ROW>(vdA, last, lane);
@@ -401,6 +419,7 @@ __global__ __launch_bounds__(256) void k_ring_policy(DevView<T> s, PolicyView pv
       PL.obs[wib][row][0] = q0;
       PL.obs[wib][row][1] = q1;
       PL.obs[wib][row][2] = q2;
+    }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -428,8 +447,9 @@ __global__ __launch_bounds__(256) void k_ring_policy(DevView<T> s, PolicyView pv
     }
     // ---- Env.step ------------------------------------------------------------------------------------------------
     advance(true, true, a);
-    const unsigned fl = (valid && ((h.x < gap2.x) || (h.y < gap2.x)) ? 1u : 0u) |
-                        (valid && ((v.x < -100.0f) || (v.y < -100.0f)) ? 2u : 0u);
+    const f2 hc = pk_sub(h, gap2), vb = pk_sub(v, f2{-100.0f, -100.0f});        // sign masks (k_ring_pair's terms)
+    const unsigned fl = ((__builtin_bit_cast(unsigned, hmin(hc.x, hc.y)) >> 31) |
+                         ((__builtin_bit_cast(unsigned, hmin(vb.x, vb.y)) >> 31) << 1)) & (valid ? 3u : 0u);
     const unsigned fany = seg_or<ROW>(fl);
     const bool crashed = (fany & 1u) != 0u;
     const bool bad = (fany & 2u) != 0u || crashed;
