@@ -33,6 +33,7 @@ enum : int {
   FLAG_ALL_IDM = 64,        // every slot is an IDM controller (fast path)
   FLAG_IDM_SET = 128,       // every slot is an IDMController, an RLController or a SimCarFollowingController
   FLAG_NO_FLOW_CTRL = 256,  // every slot is an RLController or a SimCarFollowingController: no Flow acceleration controller
+  FLAG_DELTA4 = 512,        // every IDM slot has the exponent delta = 4
 };
 
 template <typename T>
@@ -1301,6 +1302,62 @@ __device__ __forceinline__ float div_core(float n, float d) {
   return __builtin_fmaf(r1, y, q1);
 }
 __device__ __forceinline__ double div_core(double n, double d) { return n / d; }
+
+// ---- the IDM-set controllers of the open-network kernels with their divisions as div_core (CSET = 1, float32) ----------
+// k_steps_open / k_steps_wide evaluate, per vehicle and sub-step, the IDM law and the SUMO car-following speed once or
+// twice: nine IEEE divisions (ten instructions each and two wait states for v_div_fmas' vcc) and three square roots of
+// launch constants.  Here: div_core (eight instructions, bit-identical for operands in its range) and the roots taken
+// once per launch (FdSlot).  Host-checked premises (Sim::open_div_ok): s0 and minGap in [1e-3, 1e6] -- the dividends
+// s* and ss stay in range; v0, maxSpeed (the bottleneck's action-driven one is clamped to [0.01, 23]), the speed limit
+// and both 2 sqrt(a b) in [2^-20, 2^20].  The remaining dividends may be tiny or zero -- v (v - v_lead) and v itself as
+// a vehicle comes to rest -- where div_core's last bits may differ from the IEEE quotient's: the consumers cannot tell
+// (the argument of div_const above: a quotient below 2^-58 vanishes next to v T or next to s0 / minGap >= 1e-3, and
+// (v / v0)^4 underflows to zero either way).
+struct FdSlot { float ts_idm, ts_sumo; };
+__device__ __forceinline__ FdSlot make_fd(const Slot<float>& sl) {
+  return FdSlot{2.0f * tsqrt(sl.p[2] * sl.p[3]), 2.0f * tsqrt(sl.max_accel * sl.max_decel)};
+}
+__device__ __forceinline__ float idm_fd(float v, float vl, float h, bool has, const float* p, float delta, float ts, bool delta4) {
+  const float hh = tabs(h) < 1e-3f ? 1e-3f : h;                       // ctrl_idm, same operation order
+  const float dyn = v * p[1] + div_core(v * (v - vl), ts);
+  const float m = hmax(0.0f, dyn);
+  const float s_star = has ? p[5] + m : 0.0f;
+  const float q = div_core(s_star, hh);
+  const float ratio = div_core(v, p[0]);
+  float pw;
+  if (delta4) { const float r2 = ratio * ratio; pw = r2 * r2; } else pw = pow_delta(ratio, delta);    // (wave-uniform)
+  return p[2] * (1.0f - pw - q * q);
+}
+__device__ __forceinline__ float sumo_speed_fd(float v, float vl, float h, bool has, float dt, const Slot<float>& s,
+                                               float max_speed, float ts) {
+  const float gap = hmax(h, 1e-3f);                                   // sumo_idm_speed, same operation order
+  const float m = hmax(0.0f, v * s.sumo_tau + div_core(v * (v - vl), ts));
+  const float ss = s.sumo_min_gap + m;
+  const float qq = div_core(ss, gap);
+  const float q = has ? qq : 0.0f;
+  const float r = div_core(v, max_speed);
+  const float r2 = r * r;
+  const float acc = s.max_accel * (1.0f - r2 * r2 - q * q);
+  return hmax(0.0f, v + acc * dt);
+}
+// control_accel_on<float, 1, true> (its branch-free form) over idm_fd
+__device__ __forceinline__ float control_accel_fd(const DevView<float>& s, const Slot<float>& sl, const FdSlot& fd, int flags,
+                                                  float v, float vl, float h, bool has, bool on_edge, bool have_rl, float a_rl,
+                                                  bool& commanded, float noise_g) {
+  const bool is_rl = sl.ctrl == FS_CTRL_RL, is_sim = sl.ctrl == FS_CTRL_SIM;
+  const bool delta4 = (flags & FLAG_DELTA4) != 0;
+  float a = idm_fd(v, vl, h, has, sl.p, (is_rl || is_sim) ? 4.0f : sl.p[4], fd.ts_idm, delta4);
+  if (flags & FLAG_HAS_NOISE) a = (sl.noise > 0.0f) ? a + sl.noise * noise_g : a;     // base_controller.py:109-110
+  if (flags & FLAG_HAS_FAILSAFE) {                                                     // base_controller.py:113-116
+    const float a1 = failsafe_instantaneous(a, v, h, has, s.dt), a2 = failsafe_safe_velocity(a, v, vl, h, s.dt, sl.delay);
+    const float af = sl.failsafe == FS_FAILSAFE_INSTANTANEOUS ? a1 : (sl.failsafe == FS_FAILSAFE_SAFE_VELOCITY ? a2 : a);
+    a = has ? af : a;
+  }
+  const float lo = s.clip_actions ? s.act_lo : -3.0e38f, hi = s.clip_actions ? s.act_hi : 3.0e38f;
+  const float ar = hmin(hmax(a_rl, lo), hi);
+  commanded = is_rl ? have_rl : (is_sim ? false : on_edge);
+  return is_rl ? (have_rl ? ar : 0.0f) : (is_sim ? 0.0f : a);
+}
 
 // x / c, correctly rounded to float for every float x (any sign, zero, denormal) and every normal float c:
 // q = RN64(x * RN64(1/c)) is within 2^-52 of the quotient, one fma pair makes it the correctly rounded float64

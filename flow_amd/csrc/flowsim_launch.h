@@ -12,7 +12,7 @@ namespace fsim {
                   float* rew, uint8_t* done, int obs_every_step) {
     // float32 exists twice (CSET = 1: IDM / RL / Sim slots only); num_paths = 8 is the scaling-2 network
     constexpr int C1 = std::is_same<T, float>::value ? 1 : 0;
-    const bool cset = C1 == 1 && (dv.flags & fs::FLAG_IDM_SET) && !force_generic;
+    const bool cset = C1 == 1 && (dv.flags & fs::FLAG_IDM_SET) && !force_generic && open_div_ok;
 #define FS_WIDE(P_, C_)                                                                                          \
   hipLaunchKernelGGL((fs::k_steps_wide<T, W, C_, P_>), dim3(dv.R), dim3(64 * W), 0, stream, dv, ov, num_steps, mask, \
                      actions, act_stride, obs, rew, done, obs_every_step, after_reset)
@@ -32,7 +32,7 @@ namespace fsim {
     const int blocks = (dv.R + RPW - 1) / RPW;
     if (open_net) {
       // the float32 instantiations exist twice: CSET = 1 for populations of IDM / RL / Sim slots only
-      const bool cset = std::is_same<T, float>::value && (dv.flags & fs::FLAG_IDM_SET) && !force_generic;
+      const bool cset = std::is_same<T, float>::value && (dv.flags & fs::FLAG_IDM_SET) && !force_generic && open_div_ok;
 #define FS_OPEN__(P_, C_, PR_, PO_)                                                                              \
   hipLaunchKernelGGL((fs::k_steps_open<T, SEG, P_, C_, PR_, PO_>), dim3(blocks), dim3(64), 0, stream, dv, ov,        \
                      num_steps, mask, actions, act_stride, obs, rew, done, obs_every_step, after_reset)

@@ -329,6 +329,15 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
   sl.sumo_tau = s.sumo_tau[ii];
   sl.sumo_min_gap = s.sumo_min_gap[ii];
   sl.sumo_max_speed = s.sumo_max_speed[ii];
+  // CSET = 1 in float32: the controllers' divisions as div_core, their square roots taken here (flowsim_kernels.h idm_fd)
+  constexpr bool FD = CSET == 1 && std::is_same<T, float>::value;
+  FdSlot fd = FdSlot{0.0f, 0.0f};
+  float fd_adt = 3.0e38f, fd_ddt = 3.0e38f;
+  if constexpr (FD) {
+    fd = make_fd(sl);
+    fd_adt = (sl.speed_mode & 2) ? sl.max_accel * s.dt : 3.0e38f;
+    fd_ddt = (sl.speed_mode & 4) ? sl.max_decel * s.dt : 3.0e38f;
+  }
   const int my_type = o.slot_type[ii];
   const bool is_rl = sl.ctrl == FS_CTRL_RL;
   constexpr bool TABS_IN_LDS = true;               // see OpenTabs above
@@ -872,8 +881,10 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       bool commanded = false;
       T g_now = T(0);
       if (flags & FLAG_HAS_NOISE) g_now = nzb.draw(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(ii), nctr);
-      T acc = control_accel_on<T, CSET, true>(s, sl, flags, v, vl, h, has, vf, hf, mean_v, on_edge, have_rl, a_rl,
-                                              live && slot_ok, rr, ii, nctr, cst, commanded, g_now);
+      T acc;
+      if constexpr (FD) acc = control_accel_fd(s, sl, fd, flags, v, vl, h, has, on_edge, have_rl, a_rl, commanded, g_now);
+      else acc = control_accel_on<T, CSET, true>(s, sl, flags, v, vl, h, has, vf, hf, mean_v, on_edge, have_rl, a_rl,
+                                                 live && slot_ok, rr, ii, nctr, cst, commanded, g_now);
       FS_TICK(0);
       // ---- O6: BottleneckDesiredVelocityEnv._apply_rl_actions (bottleneck.py:926-969) -------------------
       if (dv_env && act != nullptr) {
@@ -921,24 +932,42 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         ctl_ctr += n_take;
       }
       // ---- M7: apply_acceleration + SUMO integration ---------------------------------------------------
-      T next_vel = tmax(v + acc * dt, T(0));
-      T vc = v + (next_vel - v) * s.ramp;
       Slot<T> sm = sl;
       sm.sumo_max_speed = tmin(vmax, o.speed_limit);     // M10
-      T v_sumo = sumo_idm_speed(v, vl, h, has, dt, sm);
-      if (sl.speed_mode & 1) vc = tmin(vc, v_sumo);
-      if (sl.speed_mode & 2) vc = tmin(vc, v + sl.max_accel * dt);
-      if (sl.speed_mode & 4) vc = tmax(vc, v - sl.max_decel * dt);
-      T v_new = commanded ? vc : v_sumo;
+      T v_sumo, v_new;
+      if constexpr (FD) {
+        // (one-instruction clamps, k_rollout_loop's form: a slot whose speed-mode bit is clear holds 3e38 in the clamp's place)
+        const float next_vel = hmax(v + acc * dt, 0.0f);
+        float vc = v + (next_vel - v) * s.ramp;
+        v_sumo = sumo_speed_fd(v, vl, h, has, dt, sl, sm.sumo_max_speed, fd.ts_sumo);
+        vc = hmin(vc, (sl.speed_mode & 1) ? v_sumo : 3.0e38f);
+        vc = hmin(vc, v + fd_adt);
+        vc = hmax(vc, v - fd_ddt);
+        v_new = commanded ? vc : v_sumo;
+      } else {
+        T next_vel = tmax(v + acc * dt, T(0));
+        T vc = v + (next_vel - v) * s.ramp;
+        v_sumo = sumo_idm_speed(v, vl, h, has, dt, sm);
+        if (sl.speed_mode & 1) vc = tmin(vc, v_sumo);
+        if (sl.speed_mode & 2) vc = tmin(vc, v + sl.max_accel * dt);
+        if (sl.speed_mode & 4) vc = tmax(vc, v - sl.max_decel * dt);
+        v_new = commanded ? vc : v_sumo;
+      }
       if (s.junction_on) {                               // M6: right of way at the merge
         const bool in_reach = alive && (x < o.merge_x);
         const bool major_busy = seg_any<SEG>(in_reach && route == 0 && (x >= o.box_in - s.j_time_gap * v), seg);
         const bool minor_in_box = seg_any<SEG>(in_reach && route == 1 && (x >= o.box_in), seg);
         const bool approaching = alive && (x >= o.box_in - s.j_lookahead) && (x < o.box_in);
         const bool yields = approaching && ((route == 1 && major_busy) || (route == 0 && minor_in_box));
-        const T stop = sumo_idm_speed(v, T(0), o.box_in - x, true, dt, sm);
+        T stop;
+        if constexpr (FD) stop = sumo_speed_fd(v, 0.0f, o.box_in - x, true, dt, sl, sm.sumo_max_speed, fd.ts_sumo);
+        else stop = sumo_idm_speed(v, T(0), o.box_in - x, true, dt, sm);
         const T cap = yields ? stop : BIGV;
-        if ((sl.speed_mode & 1) || !commanded) v_new = tmin(v_new, cap);
+        if constexpr (FD) {
+          v_new = hmin(v_new, ((sl.speed_mode & 1) || !commanded) ? cap : BIGV);
+        } else {
+          if ((sl.speed_mode & 1) || !commanded) v_new = tmin(v_new, cap);
+        }
       }
       if (lc_on) {                                       // M11: the one lane change of this step, with the move
         const bool want = lc_want >= 0 && alive && live;

@@ -206,6 +206,17 @@ struct Sim : SimBase {
                     (veh[i].controller != FS_CTRL_IDM || (float(veh[i].p[5]) >= 1e-3f && float(veh[i].p[5]) <= 1e6f));
     loop_delta4 = true;
     for (int i = 0; i < N; ++i) loop_delta4 = loop_delta4 && (veh[i].controller != FS_CTRL_IDM || veh[i].p[4] == 4.0);
+    if (loop_delta4) flags |= fs::FLAG_DELTA4;
+    // premises of the open-network kernels' div_core forms (flowsim_kernels.h idm_fd / sumo_speed_fd)
+    open_div_ok = loop_div_ok && (cfg.speed_limit <= 0 ||        // (0: no limit)
+                                  (float(cfg.speed_limit) >= 9.5367431640625e-07f && float(cfg.speed_limit) <= 1048576.0f));
+    for (int i = 0; i < N; ++i) {
+      auto in_range = [](float c) { return c >= 9.5367431640625e-07f && c <= 1048576.0f; };      // [2^-20, 2^20]
+      open_div_ok = open_div_ok && in_range(float(veh[i].sumo_max_speed)) &&
+                    in_range(2.0f * std::sqrt(float(veh[i].max_accel) * float(veh[i].max_decel))) &&
+                    (veh[i].controller != FS_CTRL_IDM ||
+                     (in_range(float(veh[i].p[0])) && in_range(2.0f * std::sqrt(float(veh[i].p[2]) * float(veh[i].p[3])))));
+    }
     {
       bool no_ctrl = true;
       for (int i = 0; i < N; ++i) no_ctrl = no_ctrl && (veh[i].controller == FS_CTRL_SIM || veh[i].controller == FS_CTRL_RL);
@@ -615,7 +626,7 @@ struct Sim : SimBase {
 
   // the specialisations for the headline configuration (see flowsim_kernels.h)
   bool delta4 = false;
-  bool loop_div_ok = false, loop_delta4 = false;
+  bool loop_div_ok = false, loop_delta4 = false, open_div_ok = false;
   bool sumo_beyond_speed_mode = false;   // FLAG_NEED_SUMO for more than speed-mode bits (Sim / RL slots, junction mode)
   bool speed_mode_any = false;           // some slot carries a speed-mode clamp (bits 0-2)
   // allow_speed_mode: the caller's kernel evaluates the speed-mode clamps itself (k_rollout_pair<..., SM = true>)

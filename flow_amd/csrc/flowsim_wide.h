@@ -101,6 +101,10 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
   sl.sumo_tau = s.sumo_tau[ii];
   sl.sumo_min_gap = s.sumo_min_gap[ii];
   sl.sumo_max_speed = s.sumo_max_speed[ii];
+  // CSET = 1 in float32: the controllers' divisions as div_core, their square roots taken here (flowsim_kernels.h idm_fd)
+  constexpr bool FD = CSET == 1 && std::is_same<T, float>::value;
+  FdSlot fd = FdSlot{0.0f, 0.0f};
+  if constexpr (FD) fd = make_fd(sl);
   const int my_type = o.slot_type[ii];
   const bool is_rl = sl.ctrl == FS_CTRL_RL;
   constexpr bool TABS_IN_LDS = true;
@@ -666,9 +670,15 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
       const bool any_cmd = !(flags & FLAG_NO_FLOW_CTRL);
       bool commanded = false;
       T acc = T(0);
-      if (any_cmd)
-        acc = control_accel_on<T, CSET>(s, sl, flags, v, vl, h, has, vf, hf, mean_v, on_edge, false, T(0), live && slot_ok,
-                                        rr, ii, nctr, cst, commanded);
+      if (any_cmd) {
+        if constexpr (FD) {
+          const T g_now = (flags & FLAG_HAS_NOISE) ? gauss<T>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(ii), nctr) : T(0);
+          acc = control_accel_fd(s, sl, fd, flags, v, vl, h, has, on_edge, false, 0.0f, commanded, g_now);
+        } else {
+          acc = control_accel_on<T, CSET>(s, sl, flags, v, vl, h, has, vf, hf, mean_v, on_edge, false, T(0), live && slot_ok,
+                                          rr, ii, nctr, cst, commanded);
+        }
+      }
       FS_TICKW(6);      // (section 6 = tail of neighbours + controllers)
       // ---- O6: BottleneckDesiredVelocityEnv._apply_rl_actions (bottleneck.py:926-969) -------------------
       if (dv_env && have_act) {
@@ -683,7 +693,9 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
       // ---- M7: apply_acceleration + SUMO integration ---------------------------------------------------
       Slot<T> sm = sl;
       sm.sumo_max_speed = tmin(vmax, o.speed_limit);     // M10
-      T v_sumo = sumo_idm_speed(v, vl, h, has, dt, sm);
+      T v_sumo;
+      if constexpr (FD) v_sumo = sumo_speed_fd(v, vl, h, has, dt, sl, sm.sumo_max_speed, fd.ts_sumo);
+      else v_sumo = sumo_idm_speed(v, vl, h, has, dt, sm);
       T v_new = v_sumo;
       if (any_cmd) {
         T next_vel = tmax(v + acc * dt, T(0));
