@@ -222,6 +222,13 @@ __device__ __forceinline__ void route_lookup(const OpenView<T>& o, const TABS& t
 // by every reader: after a move the cached segment holds unless x has passed the next start; a vehicle inserted into
 // the slot starts again from its route's first segment.  The table row of the current segment is cached in registers
 // and re-read from the LDS tables (plain loads with a per-lane index: fine under any exec mask) only on a change.
+// (o.nseg / o.seg_internal live in the kernel-argument segment: indexed with a lane's route they are a MEMORY load per
+// use -- one per sub-step for `internal` -- so the two entries are read as scalars and selected)
+template <typename T>
+__device__ __forceinline__ int nseg_of(const OpenView<T>& o, int r) { return r == 0 ? o.nseg[0] : o.nseg[1]; }
+template <typename T>
+__device__ __forceinline__ unsigned seg_internal_of(const OpenView<T>& o, int r) { return r == 0 ? o.seg_internal[0] : o.seg_internal[1]; }
+
 template <typename T, typename TABS>
 struct RouteCursor {
   int k;
@@ -230,7 +237,7 @@ struct RouteCursor {
     st = tb.template t_gather<TAB_SEG_START>(r * 16 + k);
     fs0 = tb.template t_gather<TAB_SEG_FLOW>(r * 16 + k);
     sl = tb.template t_gather<TAB_SEG_SLOPE>(r * 16 + k);
-    const bool more = k + 1 < o.nseg[r];
+    const bool more = k + 1 < nseg_of(o, r);
     const T nx = tb.template t_gather<TAB_SEG_START>(r * 16 + (more ? k + 1 : k));
     next = more ? nx : T(3.0e38);
   }
@@ -248,7 +255,7 @@ struct RouteCursor {
       refresh(o, tb, r);
     }
   }
-  __device__ __forceinline__ bool internal(const OpenView<T>& o, int r) const { return (o.seg_internal[r] >> k) & 1u; }
+  __device__ __forceinline__ bool internal(const OpenView<T>& o, int r) const { return (seg_internal_of(o, r) >> k) & 1u; }
   __device__ __forceinline__ T flow_x(T x) const { return fs0 + sl * (x - st); }
 };
 
@@ -844,8 +851,21 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
     return;
   }
 
+  // Everything loaded above is waited for HERE.  Vector loads and stores share one counter (vmcnt) and complete in order:
+  // left to hipcc, the wait for a value whose first use is inside the step loop (vmax, ctrl_state, ...) sits at that use --
+  // s_waitcnt vmcnt(0) -- where from the second step on it waits for the previous step's observation stores to land.
+  asm volatile("" :: "v"(x), "v"(v), "v"(route), "v"(seq), "v"(origin), "v"(foll), "v"(foll_h), "v"(ctl_seq), "v"(arrived_rl),
+               "v"(prev_v), "v"(last_acc), "v"(cst), "v"(vmax), "v"(last_lc));
   for (int step = 0; step < num_steps; ++step) {
     const float* act = actions ? actions + size_t(step) * act_stride + size_t(rr) * num_rl : nullptr;
+    // the step's actions, read ONCE (they are the same for its sims_per_step sub-steps; a load inside the sub-step loop
+    // is a memory round trip on the critical path of every sub-step): the multi-agent head's own column per RL slot,
+    // MergePOEnv's row one column per lane (its places -> columns mapping changes with the sub-steps)
+    float act_own = 0.0f, act_row = 0.0f;
+    if (act != nullptr) {
+      if (po_env || dv_env) { if (i < num_rl) act_row = act[i]; }           // (num_rl <= SEG, fs_create)
+      else if (o.ma_apply_actions && sl.ctrl == FS_CTRL_RL) act_own = act[sl.rl_index < 0 ? 0 : sl.rl_index];
+    }
     bool crashed = false;
     for (int sub = 0; sub < s.sims_per_step; ++sub) {
       const bool live = live_replica && !crashed;
@@ -872,9 +892,10 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         po_place = ctl_rank();
         const int rank = po_place;
         have_rl = (act != nullptr) && is_rl && alive && rank >= 0 && rank < num_rl;
-        if (have_rl) a_rl = T(act[rank]);
+        const float a = bperm(act_row, segbase + (have_rl ? rank : 0));
+        if (have_rl) a_rl = T(a);
       } else if (o.ma_apply_actions && act != nullptr && is_rl && alive) {
-        const float a = act[sl.rl_index];
+        const float a = act_own;
         have_rl = !(a != a);                             // NaN: no action for this vehicle this step
         a_rl = have_rl ? T(a) : T(0);
       }
@@ -890,7 +911,8 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       if (dv_env && act != nullptr) {
         const int my_lane = (route < 0 ? 0 : route) >> shift_of(x);
         const int acell = cell_of<1>(tb, o.act_span, x, seg_k, my_lane, alive && !internal);
-        T a = acell >= 0 ? T(act[acell]) : T(0);
+        const float a_cell = bperm(act_row, segbase + (acell >= 0 ? acell : 0));
+        T a = acell >= 0 ? T(a_cell) : T(0);
         if (s.clip_actions) a = tmin(tmax(a, s.act_lo), s.act_hi);
         T nxt = tmin(tmax(vmax + a, T(0.01)), T(23.0));
         nxt = acell >= 0 ? nxt : T(23.0);

@@ -624,6 +624,11 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
     return;
   }
 
+  // Everything loaded above is waited for HERE.  Vector loads and stores share one counter (vmcnt) and complete in order:
+  // left to hipcc, the wait for a value whose first use is inside the step loop (vmax, ctrl_state, ...) sits at that use --
+  // s_waitcnt vmcnt(0) -- where from the second step on it waits for the previous step's observation stores to land.
+  asm volatile("" :: "v"(x), "v"(v), "v"(route), "v"(seq), "v"(origin), "v"(foll), "v"(foll_h), "v"(arrived_rl), "v"(prev_v),
+               "v"(last_acc), "v"(cst), "v"(vmax));
   for (int step = 0; step < num_steps; ++step) {
     const bool have_act = actions != nullptr;
     const int ab = step & 1;                 // (L.act[ab]: this step's actions)
