@@ -134,3 +134,37 @@ def test_environment_classes_speak_the_reference_dict_interface():
     np.testing.assert_allclose(env.k.vehicle.get_speed("rl_0") - v0, 1.5 * 0.1 * (0.1 / 0.101), atol=1e-6)
     np.testing.assert_allclose(obs["av"][0::2], [env.k.vehicle.get_speed(i) / 30 for i in env.k.vehicle.get_ids()], atol=2e-6)
     env.terminate()
+
+
+@pytest.mark.parametrize("name", ["adversarial_figure_eight", "multiagent_figure_eight"])
+def test_reference_multi_agent_figure_eight_experiments_construct_and_step(name):
+    """examples/exp_configs/rl/multiagent/{adversarial,multiagent}_figure_eight.py: the flow_params build through
+    make_create_env, step with the agents' dicts on the figure eight (segment table + crossing) and, batched, through
+    VecFlowEnv."""
+    import importlib
+    import os
+    import sys
+    import flow_amd
+    flow_amd.install_as_flow()                     # the experiment files import `flow.*` as the reference's do
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from flow_amd.envs import VecFlowEnv
+    from flow_amd.utils.registry import make_create_env
+    fp = importlib.import_module("exp_configs.rl.multiagent." + name).flow_params
+    env = make_create_env(fp)[0]()
+    obs = env.reset()
+    agents = sorted(obs)
+    assert agents == (["adversary", "av"] if name.startswith("adversarial") else ["rl_0_0", "rl_1_0"])
+    total = 0.0
+    for _ in range(20):
+        obs, rew, done, _ = env.step({a: np.array([0.4]) for a in agents})
+        total += sum(rew.values())
+    assert all(np.isfinite(o).all() for o in obs.values()) and done["__all__"] is False
+    if name.startswith("adversarial"):
+        assert abs(total) < 1e-6 and obs["av"].shape == (28,)          # the adversary's reward is the negative of the AV's
+    else:
+        assert all(o.shape == (6,) for o in obs.values()) and rew["rl_0_0"] == rew["rl_1_0"] > 0
+    env.terminate()
+    vec = VecFlowEnv(fp, num_replicas=16, device=0)
+    o = vec.reset()
+    assert tuple(o.shape) == (16, vec.obs_dim) and vec.obs_dim == (28 if name.startswith("adversarial") else 12)
+    vec.close()
