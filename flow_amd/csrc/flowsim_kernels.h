@@ -1520,7 +1520,9 @@ __global__ __launch_bounds__(1024) void k_rollout_idm(DevView<T> s, int num_step
 template <typename T>
 __device__ __forceinline__ T bperm(T v, int src_lane) { return __shfl(v, src_lane, 64); }
 
-template <typename T, int SEG, bool LC /* some vehicle changes lane on its own (ML7) */>
+template <typename T, int SEG, bool LC /* some vehicle changes lane on its own (ML7) */,
+          bool LCPO = false /* the LaneChangeAccelPOEnv head (ML8): an instantiation of its own, its per-lane neighbour search
+                               would push the float64 kernels of the other heads past 256 VGPRs */>
 __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps_arg, const uint8_t* __restrict__ mask,
                                                  const float* __restrict__ actions, size_t act_stride,
                                                  float* __restrict__ obs, float* __restrict__ rew,
@@ -1538,7 +1540,7 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps_arg
   const int ii = i < N ? i : N - 1;
   const size_t idx = size_t(rr) * N + ii;
   const int flags = s.flags;
-  const bool lcpo_env = (s.env == FS_ENV_LANE_CHANGE_ACCEL_PO);       // LaneChangeAccelEnv's actions and reward, own head
+  const bool lcpo_env = LCPO;                                         // LaneChangeAccelEnv's actions and reward, own head
   const bool lc_env = (s.env == FS_ENV_LANE_CHANGE_ACCEL) || lcpo_env;
   const int act_w = s.num_rl * (lc_env ? 2 : 1);
 
@@ -1700,7 +1702,7 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps_arg
 
   // the observation of the state the lanes hold (orow: the row of this step)
   auto write_obs = [&]() {
-    if (lcpo_env) {
+    if constexpr (LCPO) {
       // ML8, LaneChangeAccelPOEnv (lane_change_accel.py:218-262 over vehicle/traci.py:776-867): per RL vehicle and lane q the
       // nearest leader / follower among ALL vehicles of lane q, the vehicle itself included (the reference's walk round
       // the loop ends on its own edge: alone in its lane it is its own leader and follower, one lap away).  Arc ahead =
@@ -1714,19 +1716,27 @@ __global__ __launch_bounds__(64) void k_steps_ml(DevView<T> s, int num_steps_arg
       float* blk = orow + size_t(4) * lanes * col;
 #pragma unroll 1
       for (int q = 0; q < lanes; ++q) {
+        // (two passes, leaders then followers: one pass holds more values than the float64 instantiation has VGPRs for,
+        // and its surplus would go to AGPRs -- tests/test_codegen.py keeps the v_readlane kernels out of them)
         T best = big, bestf = big;
         int lj = -1, fj = -1;
+#pragma unroll 1
         for (int j = 0; j < N; ++j) {
           const T xj = seg_read<SEG>(x, j, seg);
           const int lane_j = seg_read_i<SEG>(ln, j, seg);
           T a = xj - x;
           a = ((a < T(0)) | (j == ii)) ? a + L : a;
-          T b = x - xj;
-          b = (b <= T(0)) ? b + L : b;
-          const bool c = (lane_j == q);
-          const bool tl = c & (a < best), tf = c & (b <= bestf);
+          const bool tl = (lane_j == q) & (a < best);
           best = tl ? a : best;
           lj = tl ? j : lj;
+        }
+#pragma unroll 1
+        for (int j = 0; j < N; ++j) {
+          const T xj = seg_read<SEG>(x, j, seg);
+          const int lane_j = seg_read_i<SEG>(ln, j, seg);
+          T b = x - xj;
+          b = (b <= T(0)) ? b + L : b;
+          const bool tf = (lane_j == q) & (b <= bestf);
           bestf = tf ? b : bestf;
           fj = tf ? j : fj;
         }

@@ -58,12 +58,12 @@ namespace fsim {
     }
     if (dv.num_lanes > 1 || dv.env == FS_ENV_LANE_CHANGE_ACCEL || dv.env == FS_ENV_LANE_CHANGE_ACCEL_PO) {
       last_kernel = "k_steps_ml";
-      if (dv.lc_enabled)
-        hipLaunchKernelGGL((fs::k_steps_ml<T, SEG, true>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, mask,
-                           actions, act_stride, obs, rew, done, obs_every_step);
-      else
-        hipLaunchKernelGGL((fs::k_steps_ml<T, SEG, false>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, mask,
-                           actions, act_stride, obs, rew, done, obs_every_step);
+      const bool lcpo = dv.env == FS_ENV_LANE_CHANGE_ACCEL_PO;
+#define FS_ML(LC_, PO_) hipLaunchKernelGGL((fs::k_steps_ml<T, SEG, LC_, PO_>), dim3(blocks), dim3(64), 0, stream, dv, num_steps, \
+                                           mask, actions, act_stride, obs, rew, done, obs_every_step)
+      if (dv.lc_enabled) { if (lcpo) FS_ML(true, true); else FS_ML(true, false); }
+      else { if (lcpo) FS_ML(false, true); else FS_ML(false, false); }
+#undef FS_ML
       HIP_TRY(hipGetLastError());
       return FS_OK;
     }
