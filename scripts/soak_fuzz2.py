@@ -1,4 +1,4 @@
-"""One-off soak of the rollout-kernel fuzz cases (tests/test_pair_gpu.py, tests/test_parity_gpu.py) with seeds beyond the
+"""One-off soak of the rollout-kernel fuzz cases (tests/test_pair_gpu.py, tests/test_parity_gpu.py, tests/test_ringrl_gpu.py) with seeds beyond the
 pinned ones: python scripts/soak_fuzz2.py [first] [count]"""
 import os
 import sys
@@ -13,10 +13,12 @@ if __name__ == "__main__":
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     import test_pair_gpu as tpair
     import test_parity_gpu as tpar
+    import test_ringrl_gpu as tring
     bad = []
     for seed in range(first, first + count):
         for name, fn in (("pair", tpair.test_pair_hand_written_steps_fuzz_f32_and_mixed),
-                         ("loop", tpar.test_loop_rollout_kernel_fuzz_against_generic_kernel)):
+                         ("loop", tpar.test_loop_rollout_kernel_fuzz_against_generic_kernel),
+                         ("ring_rl", tring.test_fuzz_ring_pair_equals_generic_kernel)):
             try:
                 fn(seed)
             except Exception:

@@ -211,3 +211,48 @@ def test_pending_ring_length_is_taken_at_the_next_reset_only():
     np.testing.assert_array_equal(sim.pos, ora.x)
     np.testing.assert_array_equal(o[-1], o_ref.astype(np.float32))
     sim.close()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_fuzz_ring_pair_equals_generic_kernel(seed):
+    """Random RL rings (vehicle count, RL count and places, noise, speed modes, clipping, lengths, per-slot parameters,
+    launch lengths that split the 16-step groups and the Philox blocks): k_ring_pair == k_steps bit for bit -- observations,
+    rewards, done flags of every step and the state after every launch."""
+    rng = np.random.default_rng(1000 + seed)
+    N = int(rng.choice([8, 14, 22, 22, 30]))
+    n_rl = int(rng.choice([1, 1, 1, 2, 3]))
+    po = bool(rng.integers(0, 2))
+    R = int(rng.integers(3, 14))
+    spec = rl_ring_spec(R=R, N=N, n_rl=n_rl, po=po, noise=float(rng.choice([0.0, 0.2, 0.5])),
+                        speed_mode=int(rng.choice([0, 1, 25, 31])), warmup=int(rng.choice([0, 0, 17])),
+                        clip=bool(rng.integers(0, 2)), lengths=(10 * N, 12 * N + 6), seed=seed,
+                        min_gap=float(rng.choice([0.0, 2.5])))
+    # per-slot IDM parameters and lengths; RL vehicles at random places (columns in slot order)
+    veh = spec["vehicles"]
+    for v in veh:
+        if v["controller"] != S.CTRL_RL:
+            v["p"] = [float(rng.uniform(20, 35)), float(rng.uniform(0.8, 1.5)), float(rng.uniform(0.8, 1.6)),
+                      float(rng.uniform(1.0, 2.5)), 4.0, float(rng.uniform(1.5, 3.0))] + list(v["p"][6:])
+        v["length"] = float(rng.choice([4.0, 5.0, 6.5]))
+    order = rng.permutation(N)
+    veh = [veh[j] for j in order]
+    col = 0
+    for v in veh:
+        if v["controller"] == S.CTRL_RL:
+            v["rl_index"] = col
+            col += 1
+    spec["vehicles"] = veh
+    K = int(rng.integers(40, 130))
+    acts = tape(K, R, n_rl, seed=seed + 50, scale=float(rng.choice([0.8, 1.6])))
+    fast, slow = make(spec, "f32"), make(spec, "f32", FLOWSIM_NO_RING_RL=1)
+    np.testing.assert_array_equal(fast.reset(), slow.reset())
+    cut = int(rng.integers(1, K - 1))
+    for k0, k1 in ((0, cut), (cut, K)):
+        a, b = rollout(fast, k1 - k0, acts[k0:k1]), rollout(slow, k1 - k0, acts[k0:k1])
+        assert fast.last_kernel.startswith("k_ring_pair") and slow.last_kernel.startswith("k_steps"), \
+            (fast.last_kernel, slow.last_kernel)
+        for u, w, what in zip(a, b, ("obs", "reward", "done")):
+            np.testing.assert_array_equal(u, w, err_msg="%s, launch %d..%d" % (what, k0, k1))
+        np.testing.assert_array_equal(fast.pos, slow.pos)
+        np.testing.assert_array_equal(fast.vel, slow.vel)
+    fast.close(), slow.close()
