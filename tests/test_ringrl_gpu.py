@@ -225,7 +225,7 @@ def test_fuzz_ring_pair_equals_generic_kernel(seed):
     R = int(rng.integers(3, 14))
     spec = rl_ring_spec(R=R, N=N, n_rl=n_rl, po=po, noise=float(rng.choice([0.0, 0.2, 0.5])),
                         speed_mode=int(rng.choice([0, 1, 25, 31])), warmup=int(rng.choice([0, 0, 17])),
-                        clip=bool(rng.integers(0, 2)), lengths=(10 * N, 12 * N + 6), seed=seed,
+                        clip=bool(rng.integers(0, 2)), lengths=(8 * N + 60, 10 * N + 66), seed=seed,
                         min_gap=float(rng.choice([0.0, 2.5])))
     # per-slot IDM parameters and lengths; RL vehicles at random places (columns in slot order)
     veh = spec["vehicles"]
