@@ -77,6 +77,15 @@ template <int ROW>
 __device__ __forceinline__ void policy_eval(const PolicyView& pv, const PolicyLds* L, int j, float o0, float o1, float o2,
                                             float& mu, float& log_std) {
   static_assert(ROW == 16, "policy_eval: a row of 16 lanes holds the 32 units of a layer");
+  // The first two weight quads of a hidden layer are read one layer AHEAD (before the previous layer's tanh): the layer's
+  // FMAs start on them while its other fourteen reads are in flight, instead of waiting out an LDS round trip at the top
+  // of every layer.  (All sixteen ahead was measured slower: the 64 registers stay live through tanh and the kernel spills.)
+  float4 wa0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), wa1 = wa0;
+  auto load_ahead = [&](int l) {
+    wa0 = *reinterpret_cast<const float4*>(L->w_hid[l][0][j]);
+    wa1 = *reinterpret_cast<const float4*>(L->w_hid[l][1][j]);
+  };
+  if (pv.num_hidden > 1) load_ahead(0);
   // layer 1
   float ha, hb;      // units j and j + 16
   {
@@ -96,8 +105,10 @@ __device__ __forceinline__ void policy_eval(const PolicyView& pv, const PolicyLd
     // (inputs i with the same i mod 4 share one; the chain of dependent packed FMAs is 8 long instead of 32), combined
     // as ((b + z0) + z1) + (z2 + z3)
     float4 ww[16];                                 // ww[i / 2] = weights of inputs i, i + 1
+    ww[0] = wa0;
+    ww[1] = wa1;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) ww[q] = *reinterpret_cast<const float4*>(L->w_hid[l][q][j]);
+    for (int q = 2; q < 16; ++q) ww[q] = *reinterpret_cast<const float4*>(L->w_hid[l][q][j]);
     f2 z0 = {L->b[l + 1][j], L->b[l + 1][j + 16]}, z1 = {0.0f, 0.0f}, z2 = {0.0f, 0.0f}, z3 = {0.0f, 0.0f};
     static_for<4>([&](auto q_c) {                  // inputs 4q .. 4q + 3 (`ha` of lanes 4q ..) and 16 + 4q .. (`hb`)
       constexpr int q = decltype(q_c)::value;
@@ -114,6 +125,7 @@ __device__ __forceinline__ void policy_eval(const PolicyView& pv, const PolicyLd
       z2 = fma2(f2{ww[8 + 2 * q + 1].x, ww[8 + 2 * q + 1].y}, splat(b2), z2);
       z3 = fma2(f2{ww[8 + 2 * q + 1].z, ww[8 + 2 * q + 1].w}, splat(b3), z3);
     });
+    if (l + 2 < pv.num_hidden) load_ahead(l + 1);  // (wave-uniform)
     const f2 z = pk_add(pk_add(z0, z1), pk_add(z2, z3));
     const float za = z.x, zb = z.y;
     ha = policy_tanh(za);
@@ -388,47 +400,42 @@ __global__ __launch_bounds__(256) void k_ring_policy(DevView<T> s, PolicyView pv
   const int k_po = po_m ? (__builtin_ctzll(po_m) & (ROW - 1)) : 0;
   const int po_c = (k - k_po) & (ROW - 1);                               // 0: the RL vehicle's lane, 1 / 2: its helpers
   const double po_div = po_c == 2 ? pml64 : 15.0, po_rc = po_c == 2 ? rc_pml64 : rc15;
+  // (hand-off to the row through the LDS crossbar, ds_bpermute: one round trip and no memory, where the first version
+  // wrote the three values to LDS and read them back between two wave barriers)
+  const int src0 = (lane - k) + k_po, src1 = (lane - k) + ((k_po + 1) & (ROW - 1)), src2 = (lane - k) + ((k_po + 2) & (ROW - 1));
   auto observe = [&](float* orow) {
     if constexpr (!MIXED && ROW == 16) {
       const float v_me = poB ? v.y : v.x, v_ld = poB ? vl.y : vl.x, d_me = poB ? dgap.y : dgap.x;
       const float n1 = dpp<0x120 + 1>(v_ld - v_me), n2 = dpp<0x120 + 2>(d_me);      // row_ror: lane i <- lane i - 1 / i - 2
       const float n = po_c == 0 ? v_me : (po_c == 1 ? n1 : n2);
       const float q = div_via_f64(n, po_div, po_rc);
-      if (rvalid && po_c < 3) {
-        orow[po_c] = q;
-        PL.obs[wib][row][po_c] = q;
+      if (rvalid && po_c < 3) orow[po_c] = q;
+      o0 = __shfl(q, src0, 64);
+      o1 = __shfl(q, src1, 64);
+      o2 = __shfl(q, src2, 64);
+    } else {
+      float q0, q1, q2;
+      if (MIXED) {
+        const double vdn = next_a<ROW>(vdA, last, lane);
+        const double v_me = poB ? vdB : vdA, v_ld = poB ? vdn : vdB, d_me = poB ? dgB : dgA;
+        q0 = float(v_me * rc15);
+        q1 = float((v_ld - v_me) * rc15);
+        q2 = float(d_me * rc_pml64);
+      } else {
+        const float v_me = poB ? v.y : v.x, v_ld = poB ? vl.y : vl.x, d_me = poB ? dgap.y : dgap.x;
+        q0 = div_via_f64(v_me, 15.0, rc15);
+        q1 = div_via_f64(v_ld - v_me, 15.0, rc15);
+        q2 = div_via_f64(d_me, pml64, rc_pml64);
       }
-    } else {
-    float q0, q1, q2;
-    if (MIXED) {
-      const double vdn = next_a<ROW>(vdA, last, lane);
-      const double v_me = poB ? vdB : vdA, v_ld = poB ? vdn : vdB, d_me = poB ? dgB : dgA;
-      q0 = float(v_me * rc15);
-      q1 = float((v_ld - v_me) * rc15);
-      q2 = float(d_me * rc_pml64);
-    } else {
-      const float v_me = poB ? v.y : v.x, v_ld = poB ? vl.y : vl.x, d_me = poB ? dgap.y : dgap.x;
-      q0 = div_via_f64(v_me, 15.0, rc15);
-      q1 = div_via_f64(v_ld - v_me, 15.0, rc15);
-      q2 = div_via_f64(d_me, pml64, rc_pml64);
+      if (poA || poB) {
+        orow[0] = q0;
+        orow[1] = q1;
+        orow[2] = q2;
+      }
+      o0 = __shfl(q0, src0, 64);
+      o1 = __shfl(q1, src0, 64);
+      o2 = __shfl(q2, src0, 64);
     }
-    if (poA || poB) {
-      orow[0] = q0;
-      orow[1] = q1;
-      orow[2] = q2;
-      PL.obs[wib][row][0] = q0;
-      PL.obs[wib][row][1] = q1;
-      PL.obs[wib][row][2] = q2;
-    }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    o0 = PL.obs[wib][row][0];
-    o1 = PL.obs[wib][row][1];
-    o2 = PL.obs[wib][row][2];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // (read before the next step's write of the same words)
-    __builtin_amdgcn_wave_barrier();
   };
 
   const size_t R = size_t(s.R);
