@@ -368,9 +368,9 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
   // Philox word keyed by (sub-step, 2000 + f, global replica, episode) against a 32-bit threshold -- and counts the
   // vehicles generated; vehicle k of the flow is due once k < generated
   constexpr bool prob_any = PROB;
-  const bool my_flow = prob_any && i < o.n_inflows;
+  const bool my_flow = i < o.n_inflows;            // lane f of a segment keeps inflow f's schedule (and evaluates it, M2)
   const double my_per = my_flow ? o.flow_tab_d[i] : 0.0;
-  const bool my_prob = my_per < 0.0;
+  const bool my_prob = prob_any && my_per < 0.0;
   const uint32_t my_thr = my_prob ? uint32_t(-my_per - 1.0) : 0u;
   const double my_begin = my_flow ? o.flow_tab_d[64 + i] : 0.0, my_end = my_flow ? o.flow_tab_d[128 + i] : 0.0;
   const int my_number = my_flow ? o.flow_tab_i[128 + i] : 0;
@@ -683,8 +683,10 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       const long long t0_ = clock64();
       nb_structure();
       fetch();
+#if FS_PHASE_TIMERS != 3
       nb_struct_cycles += clock64() - t0_;
       nb_struct_calls += 1;
+#endif
 #else
       nb_structure();
       fetch();
@@ -1044,82 +1046,98 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         if (seg_any<SEG>(gen, seg)) next_due = -1.0e300;  // a vehicle became due: the schedule is looked at
       }
       const bool any_due = __ballot(live && (next_due <= now)) != 0ull;
-      double nd = 1.0e300;
-      for (int f = 0; any_due && f < o.n_inflows; ++f) {
-        const int k = seg_read_i<SEG>(emit_l, f, seg);
-        const double per_f = tb.template fd<0>(f);
-        const bool prob_f = PROB && per_f < 0.0;
-        const int g = prob_f ? seg_read_i<SEG>(gen_l, f, seg) : 0;
-        const double begin_f = tb.template fd<1>(f), end_f = tb.template fd<2>(f);
-        const double due_t = prob_f ? (k < g ? -1.0e300 : 1.0e300) : begin_f + double(k) * per_f;
-        const int number = tb.template fi<2>(f);
-        const bool open_f = prob_f || ((due_t <= end_f) && (number < 0 || k < number));     // not exhausted
-        const bool due = prob_f ? (k < g) : (due_t <= now) && open_f;
-        if (__ballot(due && live) == 0ull) {             // wave-uniform: this inflow is due in no replica of the wave
-          const double mine = open_f ? due_t : 1.0e300;
-          nd = (mine < nd) ? mine : nd;
-          continue;
+#if defined(FS_PHASE_TIMERS) && FS_PHASE_TIMERS == 3     // (diagnostic: how often and how long the schedule is looked at)
+      const long long due_t0_ = clock64();
+#endif
+      if (any_due) {
+        // Lane f of a segment evaluates inflow f of its replica -- all inflows at once, from the schedule constants the lane
+        // holds -- and only the inflows that are due in SOME replica of the wave are walked (in InFlows order).  (The first
+        // version walked every inflow and read its schedule from the tables: C5's highway inflow runs at the capacity of
+        // its insertion rule, some vehicle is due in 43 % of the sub-steps, and the walk was 27 % of the sub-step.)
+        // `t_mine`: when the inflow is next worth looking at, given its counters.
+        auto schedule = [&](double& t_mine) -> bool {
+          const int k_me = emit_l;
+          const double due_t = my_prob ? (k_me < gen_l ? -1.0e300 : 1.0e300) : my_begin + double(k_me) * my_per;
+          const bool open_me = my_flow && (my_prob || ((due_t <= my_end) && (my_number < 0 || k_me < my_number)));
+          t_mine = open_me ? due_t : 1.0e300;
+          return open_me && (my_prob ? (k_me < gen_l) : (due_t <= now));
+        };
+        double t_mine;
+        const bool due_me = schedule(t_mine) && live;
+        const unsigned long long due_w = __ballot(due_me);
+        const unsigned long long due_seg = seg_ballot<SEG>(due_me, seg);       // bit f: inflow f is due in MY replica
+        unsigned fm = 0u;
+#pragma unroll
+        for (int sg = 0; sg < RPW; ++sg) fm |= unsigned(due_w >> (sg * (SEG & 63))) & 0xffu;
+        while (fm != 0u) {
+          const int f = __ffs(int(fm)) - 1;
+          fm &= fm - 1u;
+          const int k = seg_read_i<SEG>(emit_l, f, seg);
+          const bool due = ((due_seg >> f) & 1ull) != 0ull;
+          // (all of the inflow's table entries first: seven LDS reads in flight together, one round trip -- read where they
+          // are used, each waits out its own behind the ballots and reductions in between)
+          const int typ = tb.template fi<0>(f);
+          int route_f = tb.template fi<1>(f);
+          const T x_dep = tb.template t<TAB_FL_XDEP>(f), v_dep = tb.template t<TAB_FL_VDEP>(f);
+          const T two_sqrt = tb.template t<TAB_FL_TWOSQRT>(f), min_gap_f = tb.template t<TAB_FL_MINGAP>(f),
+                  tau_f = tb.template t<TAB_FL_TAU>(f);
+          const bool random_lane = route_f < 0;
+          if (random_lane) {                               // M9: departLane = "random"
+            uint32_t c0 = uint32_t(k), c1 = uint32_t(1000 + f), c2 = s.rep0 + uint32_t(rr), c3 = 1u + 2u * episode;
+            philox4x32_10(c0, c1, c2, c3, s.seed_lo, s.seed_hi);
+            route_f = int((uint64_t(c0 >> 8) * uint64_t(P)) >> 24);
+          }
+          const bool alive_now = route >= 0;
+          const bool free_slot = !alive_now && slot_ok && (my_type == typ) && !just_arrived && ctl_seq < 0;   // (a listed ghost keeps its slot)
+          const unsigned long long fb = seg_ballot<SEG>(free_slot, seg);
+          const int slot = fb ? __ffsll((long long)fb) - 1 : 0;
+          const int sj = tmax(shift_of(x), shift_of(x_dep + o.zip_d));
+          const bool cand = alive_now && ((route >> sj) == (route_f >> sj));
+          const T xm = seg_min<SEG>(cand ? x : BIGV);
+          const unsigned long long cb = seg_ballot<SEG>(cand && x == xm, seg);
+          const bool has_lead = cb != 0ull;
+          const int j = has_lead ? __ffsll((long long)cb) - 1 : 0;
+          const T back_j = bperm(x - sl.length, segbase + j);
+          const T v_lead = bperm(v, segbase + j);
+          const T gap = back_j - x_dep;
+          T dq;                                            // (FD: the divisor is a slot type's 2 sqrt(a b), Sim::open_div_ok)
+          if constexpr (FD) dq = div_core(v_dep * (v_dep - v_lead), two_sqrt);
+          else dq = v_dep * (v_dep - v_lead) / two_sqrt;
+          const T need = min_gap_f + tmax(T(0), v_dep * tau_f + dq);
+          const bool ok = live && due && (fb != 0ull) && (!has_lead || gap >= need);
+          if (ok && slot_ok && ii == slot) {
+            x = x_dep;
+            v = v_dep;
+            prev_v = T(0);                                 // previous_speeds.get(veh_id, 0)
+            cst = T(0);
+            last_acc = T(0);
+            route = route_f;
+            last_lc = -(1 << 30);
+            vmax = sl.sumo_max_speed;
+            seq = seq_ctr;
+            origin = f * (1 << 20) + k;
+            foll = -1;
+            foll_h = BIGV;
+            ctl_seq = -1;
+            cur.restart(o, tb, seg_route(), x);
+          }
+          if (ok) {
+            seq_ctr += 1;
+            n_dep += 1;
+            tot_dep += 1;
+          }
+          // M9: a random-lane vehicle that does not fit when it is due is dropped, not retried
+          const bool consumed = ok || (random_lane && live && due);
+          if (consumed && i == f) emit_l = k + 1;
+          if (consumed && !ok) tot_drop += 1;
         }
-        const int typ = tb.template fi<0>(f);
-        int route_f = tb.template fi<1>(f);
-        const bool random_lane = route_f < 0;
-        if (random_lane) {                               // M9: departLane = "random"
-          uint32_t c0 = uint32_t(k), c1 = uint32_t(1000 + f), c2 = s.rep0 + uint32_t(rr), c3 = 1u + 2u * episode;
-          philox4x32_10(c0, c1, c2, c3, s.seed_lo, s.seed_hi);
-          route_f = int((uint64_t(c0 >> 8) * uint64_t(P)) >> 24);
-        }
-        const bool alive_now = route >= 0;
-        const bool free_slot = !alive_now && slot_ok && (my_type == typ) && !just_arrived && ctl_seq < 0;   // (a listed ghost keeps its slot)
-        const unsigned long long fb = seg_ballot<SEG>(free_slot, seg);
-        const int slot = fb ? __ffsll((long long)fb) - 1 : 0;
-        const T x_dep = tb.template t<TAB_FL_XDEP>(f);
-        const T v_dep = tb.template t<TAB_FL_VDEP>(f);
-        const int sj = tmax(shift_of(x), shift_of(x_dep + o.zip_d));
-        const bool cand = alive_now && ((route >> sj) == (route_f >> sj));
-        const T xm = seg_min<SEG>(cand ? x : BIGV);
-        const unsigned long long cb = seg_ballot<SEG>(cand && x == xm, seg);
-        const bool has_lead = cb != 0ull;
-        const int j = has_lead ? __ffsll((long long)cb) - 1 : 0;
-        const T back_j = bperm(x - sl.length, segbase + j);
-        const T v_lead = bperm(v, segbase + j);
-        const T gap = back_j - x_dep;
-        const T two_sqrt = tb.template t<TAB_FL_TWOSQRT>(f);
-        const T need = tb.template t<TAB_FL_MINGAP>(f) +
-                       tmax(T(0), v_dep * tb.template t<TAB_FL_TAU>(f) + v_dep * (v_dep - v_lead) / two_sqrt);
-        const bool ok = live && due && (fb != 0ull) && (!has_lead || gap >= need);
-        if (ok && slot_ok && ii == slot) {
-          x = x_dep;
-          v = v_dep;
-          prev_v = T(0);                                 // previous_speeds.get(veh_id, 0)
-          cst = T(0);
-          last_acc = T(0);
-          route = route_f;
-          last_lc = -(1 << 30);
-          vmax = sl.sumo_max_speed;
-          seq = seq_ctr;
-          origin = f * (1 << 20) + k;
-          foll = -1;
-          foll_h = BIGV;
-          ctl_seq = -1;
-          cur.restart(o, tb, seg_route(), x);
-        }
-        if (ok) {
-          seq_ctr += 1;
-          n_dep += 1;
-          tot_dep += 1;
-        }
-        // M9: a random-lane vehicle that does not fit when it is due is dropped, not retried
-        const bool consumed = ok || (random_lane && live && due);
-        if (consumed && i == f) emit_l = k + 1;
-        if (consumed && !ok) tot_drop += 1;
-        {                                                // when this inflow is next worth looking at
-          const double t_next = prob_f ? ((k + 1 < g) ? -1.0e300 : 1.0e300) : begin_f + double(k + 1) * per_f;
-          const bool more = prob_f || ((t_next <= end_f) && (number < 0 || k + 1 < number));
-          const double mine = consumed ? (more ? t_next : 1.0e300) : (open_f ? due_t : 1.0e300);
-          nd = (mine < nd) ? mine : nd;
-        }
+        double t_after;
+        schedule(t_after);                               // with the counters as the insertions left them
+        next_due = seg_min<SEG>(t_after);
       }
-      if (any_due) next_due = nd;
+#if defined(FS_PHASE_TIMERS) && FS_PHASE_TIMERS == 3
+      if (any_due) { nb_struct_cycles += clock64() - due_t0_; nb_struct_calls += 1; }
+#endif
       FS_TICK(3);
       // ---- O1: new neighbour snapshot, sticky followers, collision check --------------------------------
       neighbours(live, track_foll);
