@@ -776,23 +776,26 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
       // skips the loop and its table reads -- most sub-steps (probabilistic inflows: always looked at)
       const bool look = live && (prob_any || next_due <= now);
       double nd = 1.0e300;
-      bool nd_consumed = false;
       for (int f = 0; look && f < o.n_inflows; ++f) {
+        // (the schedule entries first, read together: one LDS round trip)
         const int k = L.emitted[f];
         const double per_f = tb.template fd<0>(f);
-        const bool prob_f = per_f < 0.0;
         const double begin_f = tb.template fd<1>(f), end_f = tb.template fd<2>(f);
-        const double due_t = begin_f + double(k) * per_f;
         const int number = tb.template fi<2>(f);
+        const bool prob_f = per_f < 0.0;
+        const double due_t = begin_f + double(k) * per_f;
         const bool open_f = prob_f || ((due_t <= end_f) && (number < 0 || k < number));
         const bool due = prob_f ? (k < L.generated[f]) : (due_t <= now) && open_f;
-        {
+        if (!(due && live)) {                            // block-uniform
           const double mine = prob_f ? -1.0e300 : (open_f ? due_t : 1.0e300);
           nd = mine < nd ? mine : nd;
+          continue;
         }
-        if (!(due && live)) continue;                    // block-uniform
         const int typ = tb.template fi<0>(f);
         int route_f = tb.template fi<1>(f);
+        const T x_dep = tb.template t<TAB_FL_XDEP>(f), v_dep = tb.template t<TAB_FL_VDEP>(f);
+        const T two_sqrt = tb.template t<TAB_FL_TWOSQRT>(f), min_gap_f = tb.template t<TAB_FL_MINGAP>(f),
+                tau_f = tb.template t<TAB_FL_TAU>(f);
         const bool random_lane = route_f < 0;
         if (random_lane) {                               // M9: departLane = "random"
           uint32_t c0 = uint32_t(k), c1 = uint32_t(1000 + f), c2 = s.rep0 + uint32_t(rr), c3 = 1u + 2u * episode;
@@ -801,8 +804,6 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
         }
         const bool alive_now = route >= 0;
         const bool free_slot = !alive_now && slot_ok && (my_type == typ) && !just_arrived;
-        const T x_dep = tb.template t<TAB_FL_XDEP>(f);
-        const T v_dep = tb.template t<TAB_FL_VDEP>(f);
         const int sj = tmax(shift_of(x), shift_of(x_dep + o.zip_d));
         const bool cand = alive_now && ((route >> sj) == (route_f >> sj));
         // per wave: its free slots, its rearmost candidate leader (lowest slot on equal x) and that one's back / speed
@@ -841,9 +842,10 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
           }
         }
         const T gap = back_j - x_dep;
-        const T two_sqrt = tb.template t<TAB_FL_TWOSQRT>(f);
-        const T need = tb.template t<TAB_FL_MINGAP>(f) +
-                       tmax(T(0), v_dep * tb.template t<TAB_FL_TAU>(f) + v_dep * (v_dep - v_lead) / two_sqrt);
+        T dq;                                            // (FD: the divisor is a slot type's 2 sqrt(a b), Sim::open_div_ok)
+        if constexpr (FD) dq = div_core(v_dep * (v_dep - v_lead), two_sqrt);
+        else dq = v_dep * (v_dep - v_lead) / two_sqrt;
+        const T need = min_gap_f + tmax(T(0), v_dep * tau_f + dq);
         const bool ok = (slot >= 0) && (!has_lead || gap >= need);
         if (ok && slot_ok && ii == slot) {
           x = x_dep;
@@ -872,9 +874,14 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
         const bool consumed = ok || random_lane;
         if (consumed && tid == 0) L.emitted[f] = k + 1;    // every thread read k before this iteration's barrier
         if (consumed && !ok) tot_drop += 1;
-        nd_consumed = nd_consumed || consumed;
+        {                                                // when this inflow is next worth looking at (k_steps_open's rule)
+          const double t_next = begin_f + double(k + 1) * per_f;
+          const bool more = (t_next <= end_f) && (number < 0 || k + 1 < number);
+          const double mine = prob_f ? -1.0e300 : (consumed ? (more ? t_next : 1.0e300) : due_t);
+          nd = mine < nd ? mine : nd;
+        }
       }
-      if (look) next_due = nd_consumed ? -1.0e300 : nd;     // (after an insertion the schedule is simply looked at again)
+      if (look) next_due = nd;
       FS_TICKW(2);
       // ---- O1: new neighbour snapshot, sticky followers, collision check --------------------------------
       bool c = false;
