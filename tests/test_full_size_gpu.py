@@ -76,3 +76,69 @@ def test_c5_full_size_sampled_replicas_equal_the_oracle():
     kernel, ora = sampled_parity(bench.c5_flow_params("f32", noise=0.0), R=1024, K=600, rows=[0, 301, 640, 1023], act_seed=4)
     assert "k_steps_open" in kernel
     assert ora.total_departed.min() > 250 and ora.total_arrived.min() > 100
+
+
+def test_rl_ring_full_size_rollout_and_fused_policy_fragment():
+    """The reference's RL ring at the bench's size (4096 replicas x 22 vehicles, a ring length per replica):
+    (a) with noise 0.2, the 1500-step k_ring_pair rollout equals the generic kernel bit for bit in EVERY replica;
+    (b) without noise, 6 sampled replicas of the same rollout equal the numpy oracle bit for bit, every step;
+    (c) a 500-step fused policy fragment (k_ring_policy, noise 0.2, in-fragment resets) equals eager stepping
+        (fs_policy_act_dev + fs_step_dev + masked fs_reset_dev) bit for bit in every replica."""
+    import torch
+    from oracle import refsim as S
+    from test_policy_gpu import buffers, eager_obs0, make_policy
+    from test_ringrl_gpu import make, rl_ring_spec, rollout, tape
+    R, K = 4096, 1500
+    dev = torch.device("cuda", 0)
+    acts = tape(K, R, 1, seed=8)
+    # (a)
+    spec = rl_ring_spec(R=R, N=22, noise=0.2, warmup=0, horizon=K, seed=4)
+    fast, slow = make(spec, "f32"), make(spec, "f32", FLOWSIM_NO_RING_RL=1)
+    fast.reset(), slow.reset()
+    a, b = rollout(fast, K, acts), rollout(slow, K, acts)
+    assert fast.last_kernel.startswith("k_ring_pair") and slow.last_kernel.startswith("k_steps")
+    for u, w, what in zip(a, b, ("obs", "reward", "done")):
+        assert np.array_equal(u, w), what
+    np.testing.assert_array_equal(fast.pos, slow.pos)
+    np.testing.assert_array_equal(fast.vel, slow.vel)
+    fast.close(), slow.close()
+    # (b)
+    rows = [0, 1, 777, 2048, 3333, 4095]
+    quiet = rl_ring_spec(R=R, N=22, noise=0.0, warmup=0, horizon=K, seed=4)
+    sim = make(quiet, "f32")
+    sim.reset()
+    o, r, d = rollout(sim, K, acts)
+    sub = dict(quiet, num_replicas=len(rows), ring_length=np.asarray(quiet["ring_length"])[rows],
+               init_pos=np.asarray(quiet["init_pos"])[rows])
+    ora = S.RingOracle(sub, np.float32)
+    ora.reset()
+    for k in range(K):
+        o_ref, r_ref, d_ref = ora.step(acts[k][rows])
+        np.testing.assert_array_equal(o[k][rows], o_ref.astype(np.float32), err_msg="obs, step %d" % k)
+        np.testing.assert_array_equal(r[k][rows], r_ref.astype(np.float32), err_msg="reward, step %d" % k)
+    np.testing.assert_array_equal(sim.pos[rows], ora.x)
+    sim.close()
+    # (c)
+    from flow_amd import _lib as L
+    Kf = 500
+    spec = rl_ring_spec(R=R, N=22, noise=0.2, warmup=5, horizon=300, seed=4)
+    pol_a, pol_b = make_policy(3, False, seed=5), make_policy(3, False, seed=5)
+    fused, eager = make(spec, "f32"), make(spec, "f32")
+    fused.reset(), eager.reset()
+    fo, fa, flp, fr, fd = buffers(Kf, R, dev)
+    fused.policy_rollout_dev(pol_a.struct, Kf, fo, fa, flp, fr, fd, reset_done=True)
+    fused.sync()
+    assert fused.last_kernel == "k_ring_policy"
+    eo, ea, elp, er, ed = buffers(Kf, R, dev)
+    eo[0].copy_(torch.as_tensor(eager_obs0(eager), device=dev))
+    torch.cuda.synchronize()
+    for k in range(Kf):
+        eager.policy_act_dev(pol_b.struct, eo[k], ea[k], elp[k])
+        eager.step_dev(eo[k + 1], er[k], ed[k], ea[k].reshape(R, 1))
+        eager.reset_dev(eo[k + 1], ed[k])
+    eager.sync()
+    for name, x, y in (("obs", fo, eo), ("act", fa, ea), ("logp", flp, elp), ("rew", fr, er), ("done", fd, ed)):
+        assert torch.equal(x, y), name
+    np.testing.assert_array_equal(fused.pos, eager.pos)
+    assert int((fd != 0).sum()) >= R                       # every replica finished an episode inside the fragment
+    fused.close(), eager.close()
