@@ -374,8 +374,8 @@ def ring_defaults_leg(device, R=4096, K=1500):
 def rl_ring_legs(device, R=4096, K=1500):
     """The reference's RL ring experiment (examples/exp_configs/rl/singleagent/singleagent_ring.py:17-65: 21 x
     IDMController(noise=0.2) + 1 x RLController, WaveAttenuationPOEnv, ring length 220..270 per replica) through
-    VecFlowEnv: (a) open loop with an action tape on k_ring_pair (kernel time of 1500-step launches), float32 with the
-    noise and FS_MIXED without; (b) closed loop: policy (fcnet_hiddens [32, 32, 32], diagonal Gaussian) -> action ->
+    VecFlowEnv: (a) open loop with an action tape on k_ring_pair (kernel time of 1500-step launches), float32 and FS_MIXED
+    with the noise (the experiment as shipped) and FS_MIXED without; (b) closed loop: policy (fcnet_hiddens [32, 32, 32], diagonal Gaussian) -> action ->
     step -> reset of finished episodes, K = 500 steps per launch of the fused kernel (fs_policy_rollout_dev)."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, "examples"))
@@ -384,7 +384,7 @@ def rl_ring_legs(device, R=4096, K=1500):
     from flow_amd.utils.device_policy import DevicePolicy
     out = {"unit": "env-steps/s", "replicas": R,
            "workload": "singleagent_ring: 21 IDM (noise 0.2) + 1 RL, WaveAttenuationPOEnv, ring length 220..270 per replica"}
-    for label, precision, noise in (("f32_noise_0.2", "f32", 0.2), ("mixed_quiet", "mixed", 0.0)):
+    for label, precision, noise in (("f32_noise_0.2", "f32", 0.2), ("mixed_noise_0.2", "mixed", 0.2), ("mixed_quiet", "mixed", 0.0)):
         fp = train_vec.ring_flow_params(3000)
         fp["sim"].precision = precision
         fp["env"].additional_params["ring_length"] = [220, 270]

@@ -34,7 +34,6 @@ int validate(const fs_config* c) {
     for (int i = 0; !why && i < c->num_vehicles; ++i) {
       const fs_vehicle_spec& v = c->vehicles[i];
       if (v.controller != FS_CTRL_IDM && v.controller != FS_CTRL_RL) why = "vehicles[].controller (IDMController / RLController)";
-      else if (v.noise > 0 && v.controller == FS_CTRL_IDM) why = "vehicles[].noise (the hardware's log / cos have no bit-twin on the CPU)";
       else if (v.fail_safe != FS_FAILSAFE_NONE) why = "vehicles[].fail_safe";
     }
     if (why)

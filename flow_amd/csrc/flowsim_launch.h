@@ -114,7 +114,7 @@ namespace fsim {
                               !dv.junction_mode && !dv.track_aux && !dv.sort_vehicles && dv.obs_perm == nullptr &&
                               !dv.evaluate && (dv.env == FS_ENV_ACCEL || dv.env == FS_ENV_WAVE_ATTENUATION_PO) &&
                               dv.N >= 2 && (dv.N % 2) == 0 && !force_generic && !no_ring_rl &&
-                              (!(f & fs::FLAG_HAS_NOISE) || pair_noise);
+                              (!(f & fs::FLAG_HAS_NOISE) || pair_noise || mixed);
       if (ring_rl_ok && !(pair_ok && (mixed || std::is_same<T, float>::value)) && (mixed || std::is_same<T, float>::value)) {
         const bool fast = ringrl_fast_ok();
         const int waves = (dv.R + (64 / ROW) - 1) / (64 / ROW);
@@ -129,7 +129,8 @@ namespace fsim {
           if (f & fs::FLAG_HAS_NOISE) { if (po) FS_RING_F(1, true); else FS_RING_F(0, true); }
           else { if (po) FS_RING_F(1, false); else FS_RING_F(0, false); }
         } else {
-          if (po) FS_RING_F(1, false); else FS_RING_F(0, false);
+          if (f & fs::FLAG_HAS_NOISE) { if (po) FS_RING_F(1, true); else FS_RING_F(0, true); }
+          else { if (po) FS_RING_F(1, false); else FS_RING_F(0, false); }
         }
 #undef FS_RING_F
 #undef FS_RING
@@ -243,7 +244,8 @@ namespace fsim {
         if (dv.flags & fs::FLAG_HAS_NOISE) { if (fast) FS_POL(true, true); else FS_POL(true, false); }
         else { if (fast) FS_POL(false, true); else FS_POL(false, false); }
       } else {
-        if (fast) FS_POL(false, true); else FS_POL(false, false);
+        if (dv.flags & fs::FLAG_HAS_NOISE) { if (fast) FS_POL(true, true); else FS_POL(true, false); }
+        else { if (fast) FS_POL(false, true); else FS_POL(false, false); }
       }
 #undef FS_POL
       HIP_TRY(hipGetLastError());

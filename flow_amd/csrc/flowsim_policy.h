@@ -184,7 +184,6 @@ __global__ __launch_bounds__(256) void k_ring_policy(DevView<T> s, PolicyView pv
                                                      uint8_t* __restrict__ done) {
   constexpr int ROW = 16;
   constexpr bool MIXED = sizeof(T) == 8;
-  static_assert(!(NOISE && MIXED), "FS_MIXED has no noise form");
   constexpr int RPW = 64 / ROW;
   __shared__ PolicyLds PL;
   policy_load(pv, &PL, threadIdx.x, blockDim.x);

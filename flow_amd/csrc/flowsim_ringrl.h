@@ -36,7 +36,9 @@ __global__ __launch_bounds__(256) void k_ring_pair(DevView<T> s, int num_steps_a
                                                    float* __restrict__ obs, float* __restrict__ rew,
                                                    uint8_t* __restrict__ done, int obs_every_step) {
   constexpr bool MIXED = sizeof(T) == 8;
-  static_assert(!(NOISE && MIXED), "FS_MIXED has no noise form (its C twin cannot reproduce the hardware's log / cos)");
+  // (FS_MIXED with noise: the float32 controller output + sigma g in float32, as in the float32 kernel; the C twin cannot
+  // reproduce the hardware's log / cos, so this form is held against the float64 kernel with the same Philox streams at
+  // 1e-4 instead of against a bit-twin -- tests/test_ringrl_gpu.py)
   constexpr int RPW = 64 / ROW;
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;

@@ -665,7 +665,6 @@ struct Sim : SimBase {
              (dv.flags & fs::FLAG_HAS_FAILSAFE) || dv.sims_per_step != 1 || dv.integrator != FS_EULER || dv.junction_mode ||
              dv.track_aux || dv.sort_vehicles || dv.obs_perm != nullptr || dv.evaluate || (dv.N % 2) != 0)
       why = "configuration (what k_ring_pair steps: single-lane ring of IDM / RL vehicles, Euler, track_aux = 0)";
-    else if ((dv.flags & fs::FLAG_HAS_NOISE) && mixed) why = "noise with FS_MIXED";
     if (why) return fail(FS_ERR_UNSUPPORTED, std::string("fs_policy: not built for this handle: ") + why);
     if (!d_pol_ctr) {
       int rc = dev_alloc(&d_pol_ctr, size_t(dv.R));

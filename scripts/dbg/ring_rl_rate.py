@@ -9,7 +9,7 @@ from flow_amd.envs import VecFlowEnv
 
 R, K = 4096, 1500
 dev = torch.device("cuda", 0)
-for label, precision, noise in (("f32 noise 0.2", "f32", 0.2), ("f32 quiet", "f32", 0.0), ("mixed quiet", "mixed", 0.0)):
+for label, precision, noise in (("f32 noise 0.2", "f32", 0.2), ("f32 quiet", "f32", 0.0), ("mixed noise 0.2", "mixed", 0.2), ("mixed quiet", "mixed", 0.0)):
     fp = train_vec.ring_flow_params(1500)
     fp["sim"].precision = precision
     fp["env"].additional_params["ring_length"] = [220, 270]        # singleagent_ring.py:58-62: a length per episode

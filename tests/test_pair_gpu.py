@@ -210,9 +210,9 @@ def test_mixed_refuses_what_it_is_not_built_for():
     spec = ring_spec(R=2, N=21, junction_length=0.1)
     with pytest.raises(NotImplementedError):
         FlowSim(spec, "mixed")                                   # odd vehicle count
-    veh = [idm_vehicle(noise=0.1) for _ in range(22)]
-    with pytest.raises(NotImplementedError):
-        FlowSim(ring_spec(R=2, N=22, vehicles=veh), "mixed")     # noise
+    veh = [idm_vehicle(fail_safe=1) for _ in range(22)]
+    with pytest.raises(NotImplementedError, match="fail_safe"):
+        FlowSim(ring_spec(R=2, N=22, vehicles=veh), "mixed")     # fail-safes
 
 
 def test_c1_mixed_within_1e4_of_reference_arithmetic_1500_steps():

@@ -44,7 +44,8 @@ def buffers(K, R, dev):
 
 
 @pytest.mark.parametrize("precision,noise,num_hidden,free", [("f32", 0.2, 3, False), ("f32", 0.0, 2, True),
-                                                               ("mixed", 0.0, 3, False), ("f32", 0.2, 1, True)])
+                                                               ("mixed", 0.0, 3, False), ("f32", 0.2, 1, True),
+                                                               ("mixed", 0.2, 3, False)])
 def test_fused_fragment_equals_eager_stepping(precision, noise, num_hidden, free):
     import torch
     from flow_amd import _lib as L

@@ -256,3 +256,47 @@ def test_fuzz_ring_pair_equals_generic_kernel(seed):
         np.testing.assert_array_equal(fast.pos, slow.pos)
         np.testing.assert_array_equal(fast.vel, slow.vel)
     fast.close(), slow.close()
+
+
+def test_mixed_with_noise_holds_1e_4_against_the_float64_kernel_where_float32_does_not():
+    """The reference's RL ring experiment AS SHIPPED -- IDMController(noise=0.2) -- in FS_MIXED (float64 state, float32
+    controller + float32 noise term).  The hardware's log / cos have no bit-twin on the CPU, so this form is held against
+    the float64 generic kernel (the reference's arithmetic type) running the SAME Philox streams: 1e-4 m / m/s after 1500
+    steps of a fixed action tape, which the float32 run of the same tape and streams misses; and the all-IDM noisy ring
+    (no RL vehicle) takes the same kernel."""
+    K, R = 1500, 16
+    spec = rl_ring_spec(R=R, N=22, noise=0.2, warmup=0, horizon=K, seed=6)
+    acts = tape(K, R, 1, seed=3, scale=1.0)
+    runs = {}
+    for prec in ("mixed", "f64", "f32"):
+        sim = make(spec, prec)
+        sim.reset()
+        o, r, d = rollout(sim, K, acts)
+        runs[prec] = (sim.pos.astype(np.float64), sim.vel.astype(np.float64), o, r, sim.last_kernel)
+        sim.close()
+    assert runs["mixed"][4].startswith("k_ring_pair") and runs["f64"][4].startswith("k_steps")
+    Ls = np.asarray(spec["ring_length"])[:, None] + 0.4
+
+    def ring_dist(a, b):
+        dd = np.abs(a - b)
+        return np.minimum(dd, Ls - dd)
+    dx_m, dv_m = ring_dist(runs["mixed"][0], runs["f64"][0]).max(), np.abs(runs["mixed"][1] - runs["f64"][1]).max()
+    dx_f = ring_dist(runs["f32"][0], runs["f64"][0]).max()
+    assert dx_m < 1e-4 and dv_m < 1e-4, (dx_m, dv_m)
+    assert dx_f > 3 * dx_m, (dx_f, dx_m)                       # float32 state is what loses the bar, not the noise
+    assert np.abs(runs["mixed"][2] - runs["f64"][2]).max() < 1e-5 and np.abs(runs["mixed"][3] - runs["f64"][3]).max() < 1e-5
+    assert runs["mixed"][1].max() > 1.0
+    # all-IDM ring with noise: FS_MIXED steps it on k_ring_pair as well (k_rollout_pair's noisy form is float32 only)
+    spec2 = rl_ring_spec(R=4, N=22, noise=0.2, po=False, seed=2)
+    spec2["vehicles"] = [dict(v, controller=S.CTRL_IDM, rl_index=-1) if v["controller"] == S.CTRL_RL else v
+                         for v in spec2["vehicles"]]
+    spec2["num_rl"] = 0
+    for v in spec2["vehicles"]:
+        if v["controller"] == S.CTRL_IDM and not v.get("p"):
+            v.update(idm_vehicle(noise=0.2, speed_mode=25, sumo_min_gap=0.0))
+    a, b = make(spec2, "mixed"), make(spec2, "f64")
+    a.reset(), b.reset()
+    rollout(a, 300, None), rollout(b, 300, None)
+    assert a.last_kernel.startswith("k_ring_pair"), a.last_kernel
+    assert np.abs(a.pos - b.pos).max() < 1e-4
+    a.close(), b.close()
