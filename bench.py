@@ -114,7 +114,7 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def c3_leg(device, R=4096, steps=3000, po=False):
+def c3_leg(device, R=4096, steps=3000, po=False, precision="f32"):
     """BASELINE configs[2] (informational, not the headline): FigureEightNetwork, 13 noisy IDM + 1 RL vehicle,
     random RL actions from a pre-generated tape, rollout kernel of segment-table loops (flowsim_fig8.h).  ``po=False``: AccelEnv observation (28),
     the pairing the reference itself uses (singleagent_figure_eight.py:44); ``po=True``: the 3-value
@@ -134,7 +134,7 @@ def c3_leg(device, R=4096, steps=3000, po=False):
     add = {"max_accel": 3, "max_decel": 3, "ring_length": None} if po else \
         {"target_velocity": 20, "max_accel": 3, "max_decel": 3, "sort_vehicles": False}
     fp = dict(exp_tag="figure_eight", env_name=WaveAttenuationPOEnv if po else AccelEnv, network=FigureEightNetwork,
-              simulator="traci", sim=SumoParams(sim_step=0.1, render=False, seed=7),
+              simulator="traci", sim=SumoParams(sim_step=0.1, render=False, seed=7, precision=precision),
               env=EnvParams(horizon=1500, additional_params=add),
               net=NetParams(additional_params=dict(ADDITIONAL_NET_PARAMS)), veh=veh)
     vec = VecFlowEnv(fp, num_replicas=R, device=device.index)
@@ -161,7 +161,7 @@ def c3_leg(device, R=4096, steps=3000, po=False):
     kernel = vec.sim.last_kernel
     vec.close()
     return {"value": R * done_steps / dt, "unit": "env-steps/s", "steps": done_steps, "steps_per_launch": K, "replicas": R,
-            "obs_dim": 3 if po else 28, "replicas_crashed_before_horizon": crashed, "kernel": kernel,
+            "obs_dim": 3 if po else 28, "replicas_crashed_before_horizon": crashed, "kernel": kernel, "precision": precision,
             "workload": "C3: FigureEightNetwork r=30, 13 IDM (noise 0.2, obey_safe_speed) + 1 RL, %s, "
                         "random actions" % ("WaveAttenuationPOEnv" if po else "AccelEnv")}
 
@@ -811,6 +811,7 @@ def main():
         out["rl_ring"] = rl_ring_legs(device)
         out["c3_figure_eight"] = c3_leg(device)
         out["c3_figure_eight_po"] = c3_leg(device, po=True)
+        out["c3_figure_eight_mixed"] = c3_leg(device, precision="mixed")      # float64 state, float32 car-following models
         out["c4_bottleneck"] = c4_leg(device)
         out["c5_merge"] = c5_leg(device)
         out["c5_merge_fp16_state"] = c5_leg(device, precision="f16s")

@@ -20,20 +20,24 @@ int validate(const fs_config* c) {
   if (c->precision == FS_MIXED) {
     // float64 state, float32 controllers: k_rollout_pair (all-IDM AccelEnv rollout) and k_ring_pair (IDM + RL vehicles,
     // AccelEnv / WaveAttenuationPOEnv, warm-up steps and masked resets included).  Name the field that does not fit.
+    // The figure eight (k_rollout_loop's float64-state instantiation, flowsim_fig8.h): rollouts step there, everything else
+    // (resets, masks, single steps of more than 16 vehicles) on the generic float64 kernel -- the reference's arithmetic.
+    const bool fig8 = c->network == FS_NET_FIGURE_EIGHT;
     const char* why = nullptr;
-    if (c->network != FS_NET_RING || c->num_lanes > 1) why = "network (single-lane ring only)";
+    if ((c->network != FS_NET_RING && !fig8) || c->num_lanes > 1) why = "network (single-lane ring or figure eight)";
     else if (c->env != FS_ENV_ACCEL && c->env != FS_ENV_WAVE_ATTENUATION_PO) why = "env (AccelEnv or WaveAttenuationPOEnv)";
     else if (c->evaluate) why = "evaluate";
     else if (c->sims_per_step != 1) why = "sims_per_step (1)";
     else if (c->integrator != FS_EULER) why = "integrator (Euler)";
-    else if (c->junction_mode) why = "junction_mode";
-    else if (c->track_aux) why = "track_aux (the scalar Env's previous-speed / acceleration fields: VecFlowEnv(track_aux=False))";
+    else if (c->junction_mode && !fig8) why = "junction_mode";
+    else if (c->track_aux && !fig8) why = "track_aux (the scalar Env's previous-speed / acceleration fields: VecFlowEnv(track_aux=False))";
     else if (c->sort_vehicles || c->obs_perm) why = "sort_vehicles / shuffled ids";
-    else if (c->num_vehicles < 2 || c->num_vehicles > 64 || (c->num_vehicles % 2) != 0) why = "num_vehicles (even, 2..64)";
+    else if (!fig8 && (c->num_vehicles < 2 || c->num_vehicles > 64 || (c->num_vehicles % 2) != 0)) why = "num_vehicles (even, 2..64)";
     else if (!c->vehicles) why = "vehicles (NULL)";
     for (int i = 0; !why && i < c->num_vehicles; ++i) {
       const fs_vehicle_spec& v = c->vehicles[i];
-      if (v.controller != FS_CTRL_IDM && v.controller != FS_CTRL_RL) why = "vehicles[].controller (IDMController / RLController)";
+      if (v.controller != FS_CTRL_IDM && v.controller != FS_CTRL_RL && !(fig8 && v.controller == FS_CTRL_SIM))
+        why = "vehicles[].controller (IDMController / RLController)";
       else if (v.fail_safe != FS_FAILSAFE_NONE) why = "vehicles[].fail_safe";
     }
     if (why)

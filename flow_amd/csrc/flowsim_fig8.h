@@ -57,6 +57,19 @@ __device__ __forceinline__ float wrap_up(float d, float y) {
   return __builtin_bit_cast(float, min(__builtin_bit_cast(unsigned, d), __builtin_bit_cast(unsigned, d + y)));
 }
 
+// ---- FS_MIXED instantiation (MX): positions, speeds, the loop geometry and every decision taken on a position are float64
+// (the reference's arithmetic type), the car-following models are evaluated in float32 on the rounded speeds and gaps
+__device__ __forceinline__ double lead16(double v, bool wrap) {
+  const double t = dpp<DPP_ROW_SHL1>(v), w = dpp<0x150>(v);
+  return wrap ? w : t;
+}
+__device__ __forceinline__ double wrap_down(double x, double y) { return x >= y ? x - y : x; }
+__device__ __forceinline__ double wrap_up(double d, double y) { return d < 0.0 ? d + y : d; }
+__device__ __forceinline__ float xmax(float a, float b) { return hmax(a, b); }
+__device__ __forceinline__ float xmin(float a, float b) { return hmin(a, b); }
+__device__ __forceinline__ double xmax(double a, double b) { return a > b ? a : b; }
+__device__ __forceinline__ double xmin(double a, double b) { return a < b ? a : b; }
+
 // ctrl_idm / sumo_idm_speed (flowsim_kernels.h) with their divisions made cheap WITHOUT changing a bit: divisors
 // that are launch constants go through divc, the others (|h| >= 1e-3, gap >= 1e-3; dividends s* >= s0 >= 1e-3 and
 // ss >= minGap >= 1e-3, host-checked) through div_core
@@ -74,14 +87,22 @@ __device__ __forceinline__ float idm_fast(float v, float vl, float h, bool has, 
 }
 struct SumoC { float min_gap, tau, max_accel; DivC two_sqrt, max_speed; };
 template <bool FASTC = false>
-__device__ __forceinline__ float sumo_fast(float v, float vl, float h, bool has, float dt, const SumoC& c) {
+__device__ __forceinline__ float sumo_acc_fast(float v, float vl, float h, bool has, const SumoC& c) {
   const float gap = hmax(h, 1e-3f);
   const float ss = c.min_gap + hmax(0.0f, v * c.tau + divk<FASTC>(v * (v - vl), c.two_sqrt));
   const float q = has ? div_core(ss, gap) : 0.0f;
   const float r = divk<FASTC>(v, c.max_speed);
   const float r2 = r * r;
-  const float acc = c.max_accel * (1.0f - r2 * r2 - q * q);
-  return hmax(0.0f, v + acc * dt);
+  return c.max_accel * (1.0f - r2 * r2 - q * q);
+}
+template <bool FASTC = false>
+__device__ __forceinline__ float sumo_fast(float v, float vl, float h, bool has, float dt, const SumoC& c) {
+  return hmax(0.0f, v + sumo_acc_fast<FASTC>(v, vl, h, has, c) * dt);
+}
+// (MX: the model's acceleration in float32 on the rounded state, its speed in float64)
+template <bool FASTC = false>
+__device__ __forceinline__ double sumo_fast(double v, double vl, float h, bool has, double dt, const SumoC& c) {
+  return xmax(0.0, v + double(sumo_acc_fast<FASTC>(float(v), float(vl), h, has, c)) * dt);
 }
 
 // FULL: the launch is known to have noisy slots, speed-mode clamps / uncommanded slots, the crossing and an action
@@ -96,6 +117,9 @@ __device__ __forceinline__ float sumo_fast(float v, float vl, float h, bool has,
 __device__ __forceinline__ unsigned fbits(float a) { return __builtin_bit_cast(unsigned, a); }
 __device__ __forceinline__ unsigned sm_lt(float a, float b) { return fbits(a - b); }                      // a < b
 __device__ __forceinline__ unsigned sm_in(float x, float lo, float hi) { return ~fbits(x - lo) & fbits(x - hi); }  // lo <= x < hi
+__device__ __forceinline__ unsigned fbits(double a) { return unsigned(__builtin_bit_cast(unsigned long long, a) >> 32); }
+__device__ __forceinline__ unsigned sm_lt(double a, double b) { return fbits(a - b); }
+__device__ __forceinline__ unsigned sm_in(double x, double lo, double hi) { return ~fbits(x - lo) & fbits(x - hi); }
 __device__ __forceinline__ bool sm_true(unsigned m) { return int(m) < 0; }
 
 // A wave-wide test whose result steers a branch, evaluated HERE: a scalar branch that reads a VALU-written mask in
@@ -109,14 +133,15 @@ __device__ __forceinline__ unsigned long long ballot_here(bool p) {
 }
 
 template <int HEAD /* 0: AccelEnv, 1: WaveAttenuationPOEnv */, bool DELTA4 /* every IDM slot has delta = 4 */,
-          bool FULL = false>
-__global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_steps,
-                                                      const float* __restrict__ actions, size_t act_stride,
+          bool FULL = false, bool MX = false /* FS_MIXED: float64 state and geometry (X), float32 car-following models (T) */>
+__global__ __launch_bounds__(256) void k_rollout_loop(DevView<typename std::conditional<MX, double, float>::type> s,
+                                                      int num_steps, const float* __restrict__ actions, size_t act_stride,
                                                       float* __restrict__ obs, float* __restrict__ rew,
                                                       uint8_t* __restrict__ done) {
   typedef float T;
+  typedef typename std::conditional<MX, double, float>::type X;
   constexpr int SEG = 16, RPW = 4, PERIOD = 4;
-  __shared__ T tab_start[FS_MAX_SEGMENTS + 2], tab_fs[FS_MAX_SEGMENTS + 2], tab_sl[FS_MAX_SEGMENTS + 2];
+  __shared__ X tab_start[FS_MAX_SEGMENTS + 2], tab_fs[FS_MAX_SEGMENTS + 2], tab_sl[FS_MAX_SEGMENTS + 2];
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int seg = lane / SEG;
@@ -134,9 +159,9 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
 
   if (threadIdx.x < FS_MAX_SEGMENTS + 2) {
     const int q = threadIdx.x, qq = q < FS_MAX_SEGMENTS ? q : 0;
-    tab_start[q] = q < s.nseg ? s.seg_start[qq] : T(3.0e38);
-    tab_fs[q] = q < s.nseg ? s.seg_flow_start[qq] : T(0);
-    tab_sl[q] = q < s.nseg ? s.seg_flow_slope[qq] : T(0);
+    tab_start[q] = q < s.nseg ? s.seg_start[qq] : X(3.0e38);
+    tab_fs[q] = q < s.nseg ? s.seg_flow_start[qq] : X(0);
+    tab_sl[q] = q < s.nseg ? s.seg_flow_slope[qq] : X(0);
   }
   __syncthreads();
 
@@ -147,44 +172,48 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
   sl.rl_index = s.rl_index[ii];
   sl.pis_index = -1;
 #pragma unroll
-  for (int k = 0; k < FS_MAX_CTRL_PARAMS; ++k) sl.p[k] = s.p[k * N + ii];
-  sl.noise = s.noise[ii];
+  for (int k = 0; k < FS_MAX_CTRL_PARAMS; ++k) sl.p[k] = T(s.p[k * N + ii]);
+  sl.noise = T(s.noise[ii]);
   sl.delay = T(0);
-  sl.max_accel = s.max_accel[ii];
-  sl.max_decel = s.max_decel[ii];
-  sl.length = s.length[ii];
-  sl.sumo_tau = s.sumo_tau[ii];
-  sl.sumo_min_gap = s.sumo_min_gap[ii];
-  sl.sumo_max_speed = s.sumo_max_speed[ii];
-  const T len_lead = lead16(sl.length, wrap_lead);
+  sl.max_accel = T(s.max_accel[ii]);
+  sl.max_decel = T(s.max_decel[ii]);
+  sl.length = T(s.length[ii]);
+  sl.sumo_tau = T(s.sumo_tau[ii]);
+  sl.sumo_min_gap = T(s.sumo_min_gap[ii]);
+  sl.sumo_max_speed = T(s.sumo_max_speed[ii]);
+  const X len_me = s.length[ii];
+  const X len_lead = lead16(len_me, wrap_lead);
 
-  const T base_len = s.ring_len[rr];
-  const T L = base_len + T(4) * s.jlen;
+  const X base_len = s.ring_len[rr];
+  const X L = base_len + X(4) * s.jlen;
   int tcount = s.time[rr];
   const bool any_noise = FULL || (flags & FLAG_HAS_NOISE) != 0;
   uint32_t nctr = any_noise ? s.noise_ctr[rr] : 0u;
   const bool noisy = any_noise && sl.noise > T(0) && sl.ctrl != FS_CTRL_RL && sl.ctrl != FS_CTRL_SIM;
 
-  T x = s.pos[idx];
-  T v = s.vel[idx];
+  X x = s.pos[idx];
+  X v = s.vel[idx];
   // segment cursor: index + the row values read from LDS
   int k = 0;
   for (int q = 1; q < s.nseg; ++q) k = (x >= tab_start[q]) ? q : k;
-  T c_st = tab_start[k], c_next = tab_start[k + 1], c_next2 = tab_start[k + 2], c_fs = tab_fs[k], c_sl = tab_sl[k];
-  T xl = lead16(x, wrap_lead);
-  T vl = lead16(v, wrap_lead);
-  T d = xl - x;
-  d = d < T(0) ? d + L : d;
-  T h = has ? d - len_lead : T(1000);
+  X c_st = tab_start[k], c_next = tab_start[k + 1], c_next2 = tab_start[k + 2], c_fs = tab_fs[k], c_sl = tab_sl[k];
+  X xl = lead16(x, wrap_lead);
+  X vl = lead16(v, wrap_lead);
+  X d = xl - x;
+  d = d < X(0) ? d + L : d;
+  T h = has ? T(d - len_lead) : T(1000);
 
   // launch constants in VGPRs
-  const T dt = in_vgpr(s.dt), ramp = in_vgpr(s.ramp), crash_gap = in_vgpr(s.crash_gap), target_v = in_vgpr(s.target_velocity);
-  const T ja_in = in_vgpr(s.ja_in), ja_out = in_vgpr(s.ja_out), jb_in = in_vgpr(s.jb_in), jb_out = in_vgpr(s.jb_out);
-  const T look = in_vgpr(s.j_lookahead), tgap = in_vgpr(s.j_time_gap);
-  const T za_lo = in_vgpr(s.za_lo), za_hi = in_vgpr(s.za_hi), zb_lo = in_vgpr(s.zb_lo), zb_hi = in_vgpr(s.zb_hi);
-  const T max_cost = in_vgpr(s.max_cost);
-  const T Lv = in_vgpr(L);
-  const DivC d_ms = make_divc(s.max_speed), d_L = make_divc(L), d_15 = make_divc(15.0f), d_po = make_divc(s.po_max_length);
+  const X dt = in_vgpr(X(s.dt)), ramp = in_vgpr(X(s.ramp));
+  const T crash_gap = in_vgpr(T(s.crash_gap)), target_v = in_vgpr(T(s.target_velocity));
+  const X ja_in = in_vgpr(X(s.ja_in)), ja_out = in_vgpr(X(s.ja_out)), jb_in = in_vgpr(X(s.jb_in)), jb_out = in_vgpr(X(s.jb_out));
+  const X look = in_vgpr(X(s.j_lookahead)), tgap = in_vgpr(X(s.j_time_gap));
+  const X za_lo = in_vgpr(X(s.za_lo)), za_hi = in_vgpr(X(s.za_hi)), zb_lo = in_vgpr(X(s.zb_lo)), zb_hi = in_vgpr(X(s.zb_hi));
+  const T max_cost = in_vgpr(T(s.max_cost));
+  const X Lv = in_vgpr(L);
+  const DivC d_ms = make_divc(T(s.max_speed)), d_L = make_divc(T(L)), d_15 = make_divc(15.0f), d_po = make_divc(T(s.po_max_length));
+  // (MX: observations as ring FS_MIXED writes them: float(value * RN64(1 / c)))
+  const double rc_ms64 = 1.0 / double(s.max_speed), rc_L64 = 1.0 / double(L), rc_15_64 = 1.0 / 15.0, rc_po64 = 1.0 / double(s.po_max_length);
   IdmC ic;
   ic.p1 = sl.p[1]; ic.p2 = sl.p[2]; ic.p4 = sl.p[4]; ic.p5 = sl.p[5];
   ic.v0 = make_divc(sl.p[0]);
@@ -197,7 +226,7 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
   const bool junction_on = FULL || s.junction_on != 0, need_sumo = FULL || (flags & FLAG_NEED_SUMO) != 0;
   const bool gated = s.junction_mode && sl.ctrl != FS_CTRL_RL && sl.ctrl != FS_CTRL_SIM;
   // (clipping as an unconditional clamp: without clip_actions the bounds are +-3e38)
-  const T clip_lo = in_vgpr(s.clip_actions != 0 ? s.act_lo : T(-3.0e38)), clip_hi = in_vgpr(s.clip_actions != 0 ? s.act_hi : T(3.0e38));
+  const T clip_lo = in_vgpr(s.clip_actions != 0 ? T(s.act_lo) : T(-3.0e38)), clip_hi = in_vgpr(s.clip_actions != 0 ? T(s.act_hi) : T(3.0e38));
   const bool rl_lane = sl.ctrl == FS_CTRL_RL, sim_lane = sl.ctrl == FS_CTRL_SIM;
   const bool use_act = FULL || actions != nullptr;
   const int num_rl = s.num_rl;
@@ -209,7 +238,7 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
   const unsigned gate_u = gated ? 1u : 0u, cmd_rl = (rl_lane && use_act) ? 1u : 0u,
                  cmd_other = (!rl_lane && !sim_lane) ? 1u : 0u, sm1_u = unsigned(sl.speed_mode) & 1u;
   const bool sm1_lane = (sl.speed_mode & 1) != 0;
-  const T adt_c = (sl.speed_mode & 2) ? sl.max_accel * dt : T(3.0e38), ddt_c = (sl.speed_mode & 4) ? sl.max_decel * dt : T(3.0e38);
+  const X adt_c = (sl.speed_mode & 2) ? X(s.max_accel[ii]) * dt : X(3.0e38), ddt_c = (sl.speed_mode & 4) ? X(s.max_decel[ii]) * dt : X(3.0e38);
 
   // RL actions are read PERIOD steps ahead, into the register the step PERIOD steps earlier has just consumed (slot s
   // of a block <-> element s: static after unrolling).  The action tensor is streamed once -- every step's row is a
@@ -272,13 +301,14 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
       pend_rew = false;
     }
   };
-  T prev_v = v, last_acc = T(0);                          // track_aux: get_previous_speed / get_accel of the scalar Env
+  X prev_v = v;                                           // track_aux: get_previous_speed / get_accel of the scalar Env
+  T last_acc = T(0);
 
   // stream a busy (bit 0: a vehicle of stream a inside the box, not yet clear of it with its tail, or within time_gap
   // of it) / stream b in the box (bit 1), of ONE lane for the state (xx, vv)
-  auto junction_flags = [&](T xx, T vv) -> unsigned {
-    const unsigned busy_a = sm_in(xx, ja_in - tgap * vv, ja_out + sl.length);
-    const unsigned in_b = sm_in(xx, jb_in, jb_out + sl.length);
+  auto junction_flags = [&](X xx, X vv) -> unsigned {
+    const unsigned busy_a = sm_in(xx, ja_in - tgap * vv, ja_out + len_me);
+    const unsigned in_b = sm_in(xx, jb_in, jb_out + len_me);
     return (busy_a >> 31) | ((in_b >> 31) << 1);
   };
   unsigned jf = junction_on ? seg_or<SEG>(junction_flags(x, v) & valid_bits) : 0u;    // of the launch's first snapshot
@@ -336,7 +366,7 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
           }
         }
         {
-          T a = idm_fast<DELTA4, FULL>(v, vl, h, has, ic);
+          T a = idm_fast<DELTA4, FULL>(T(v), T(vl), h, has, ic);
           // (every lane evaluates it: left to itself hipcc wraps the evaluation into an exec-mask region of the lanes that
           // use it -- s_and_saveexec, a branch, s_or -- which costs a wave alone on its SIMD more than the masked lanes save)
           if (FULL) asm volatile("" : "+v"(a));
@@ -349,15 +379,15 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
           acc = rl_lane ? (use_act ? arl : T(0)) : (sim_lane ? T(0) : a);
         }
         // ---- apply_acceleration + SUMO integration (S4-S9) ---------------------------------------------
-        T next_vel = hmax(v + acc * dt, T(0));
-        T vc = v + (next_vel - v) * ramp;
-        T v_new = vc;
+        X next_vel = xmax(v + X(acc) * dt, X(0));
+        X vc = v + (next_vel - v) * ramp;
+        X v_new = vc;
         if (need_sumo) {
-          T v_sumo = sumo_fast<FULL>(v, vl, h, has, dt, sc);
+          X v_sumo = sumo_fast<FULL>(v, vl, h, has, dt, sc);
           // S7/S8 without a per-slot test: a slot whose bit is clear holds 3e38 in the clamp's place (k_rollout_pair's form)
-          vc = hmin(vc, sm1_lane ? v_sumo : T(3.0e38));
-          vc = hmin(vc, v + adt_c);
-          vc = hmax(vc, v - ddt_c);
+          vc = xmin(vc, sm1_lane ? v_sumo : X(3.0e38));
+          vc = xmin(vc, v + adt_c);
+          vc = xmax(vc, v - ddt_c);
           v_new = commanded ? vc : v_sumo;
         }
         if (junction_on) {
@@ -365,18 +395,18 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
           // a vehicle is on at most one approach (the two lines are different places of the loop); should both
           // hold for a degenerate table, stream b's line is evaluated first and stream a's overrides as min would
           if (cap_m != 0ull) {
-            const T line = on_b ? jb_in - x : ja_in - x;
-            T cap = sumo_fast<FULL>(v, T(0), line, true, dt, sc);
-            cap = on_any ? cap : T(3.0e38);
+            const X line = on_b ? jb_in - x : ja_in - x;
+            X cap = sumo_fast<FULL>(v, X(0), T(line), true, dt, sc);
+            cap = on_any ? cap : X(3.0e38);
             if (cap2_m != 0ull) {                                // degenerate table: both lines ahead of one vehicle
-              const T cap_a = sumo_fast<FULL>(v, T(0), ja_in - x, true, dt, sc);
-              cap = hmin(cap, on_both ? cap_a : T(3.0e38));
+              const X cap_a = sumo_fast<FULL>(v, X(0), T(ja_in - x), true, dt, sc);
+              cap = xmin(cap, on_both ? cap_a : X(3.0e38));
             }
             const bool cap_applies = (sm1_u | (commanded_u ^ 1u)) != 0u;          // (speed_mode & 1) || !commanded
-            v_new = hmin(v_new, cap_applies ? cap : T(3.0e38));
+            v_new = xmin(v_new, cap_applies ? cap : X(3.0e38));
           }
         }
-        T x_new = x + v_new * dt;
+        X x_new = x + v_new * dt;
         x_new = wrap_down(x_new, Lv);
         prev_v = v;
         last_acc = acc;
@@ -388,8 +418,8 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
         // (up to two starts passed per step without a table access; the row of the new segment is read from LDS
         // now and consumed at the end of the step, the rare third advance / advance after a wrap is caught there)
         k = (x < c_st) ? 0 : k + ((x >= c_next) ? 1 : 0) + ((x >= c_next2) ? 1 : 0);
-        const T n_st = tab_start[k], n_next = tab_start[k + 1], n_next2 = tab_start[k + 2];
-        const T n_fs = tab_fs[k], n_sl = tab_sl[k];
+        const X n_st = tab_start[k], n_next = tab_start[k + 1], n_next2 = tab_start[k + 2];
+        const X n_fs = tab_fs[k], n_sl = tab_sl[k];
         // the reads must be ISSUED here: without the fence hipcc sinks them into the block of their first use (the
         // `while` below) and the wave waits out two LDS latencies there, every step
         asm volatile("" ::: "memory");
@@ -397,14 +427,14 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
         xl = lead16(x, wrap_lead);
         vl = lead16(v, wrap_lead);
         d = wrap_up(xl - x, Lv);
-        h = has ? d - len_lead : T(1000);
+        h = has ? T(d - len_lead) : T(1000);
         // bit 0 a gap below crash_gap, bits 1 / 2 a body on the crossing point of stream a / b, bit 3 v < -100 (sign masks)
         unsigned f2 = sm_lt(h, crash_gap) >> 31;
         if (junction_on) {
           f2 |= (sm_in(x, za_lo, za_hi) >> 31) << 1;
           f2 |= (sm_in(x, zb_lo, zb_hi) >> 31) << 2;
         }
-        f2 |= (sm_lt(v, T(-100)) >> 31) << 3;
+        f2 |= (sm_lt(v, X(-100)) >> 31) << 3;
         if (junction_on) f2 |= junction_flags(x, v) << 4;        // the next step's jf rides in bits 4 / 5 of the same butterfly
         f2 &= valid_bits;
         unsigned long long adv_m = ballot_here(x >= n_next);     // a third start passed / one passed after a wrap (rare)
@@ -428,20 +458,31 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<float> s, int num_
         }
         // ---- observation ---------------------------------------------------------------------------------
         if (HEAD == 1) {
-          po0 = divc(v, d_15);                                   // wave_attenuation.py:248-269
-          po1 = divc(vl - v, d_15);
-          po2 = divc(d, d_po);
-          red[slot] = valid ? v : T(0);
+          if constexpr (MX) {
+            po0 = float(double(v) * rc_15_64);
+            po1 = float(double(vl - v) * rc_15_64);
+            po2 = float(double(d) * rc_po64);
+          } else {
+            po0 = divc(v, d_15);                                 // wave_attenuation.py:248-269
+            po1 = divc(vl - v, d_15);
+            po2 = divc(d, d_po);
+          }
+          red[slot] = valid ? T(v) : T(0);
           T a = T(0);
           if (red_lane && use_act) {
             a = tabs(hmin(hmax(T(a_red), clip_lo), clip_hi));
           }
           red2[slot] = a;
         } else {
-          const T xo = c_fs + c_sl * (x - c_st);
-          po0 = divc(v, d_ms);                                   // accel.py:116-123
-          po1 = divc(xo, d_L);
-          const T dv = valid ? v - target_v : T(0);
+          const X xo = c_fs + c_sl * (x - c_st);
+          if constexpr (MX) {
+            po0 = float(double(v) * rc_ms64);
+            po1 = float(double(xo) * rc_L64);
+          } else {
+            po0 = divc(v, d_ms);                                 // accel.py:116-123
+            po1 = divc(xo, d_L);
+          }
+          const T dv = valid ? T(v) - target_v : T(0);
           red[slot] = dv * dv;
         }
         pend_obs = true;

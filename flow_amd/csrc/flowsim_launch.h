@@ -74,8 +74,12 @@ namespace fsim {
                          (dv.N % 2) == 0 && actions == nullptr && !no_pair &&
                          size_t(dv.R) * 2 * dv.N * sizeof(float) * 16 < (size_t(1) << 32);   // 32-bit offsets in a block
     // closed loops with a segment table (figure eight): the rollout kernel of flowsim_fig8.h
-    if constexpr (SEG == 16 && std::is_same<T, float>::value) {
+    // (FS_MIXED handles: its float64-state instantiation; whatever that does not cover -- resets, masks, warm-up, single
+    // vehicles -- steps on the generic float64 kernel, which is the reference's arithmetic)
+    if constexpr (SEG == 16) {
+      constexpr bool MX = !std::is_same<T, float>::value;
       const int f = dv.flags;
+      if (!MX || mixed) {
       const bool head_ok = (dv.env == FS_ENV_ACCEL && !dv.evaluate) || dv.env == FS_ENV_WAVE_ATTENUATION_PO;
       if (dv.nseg > 0 && (f & fs::FLAG_IDM_SET) && !(f & fs::FLAG_HAS_FAILSAFE) && head_ok &&
           dv.integrator == FS_EULER && dv.sims_per_step == 1 && mask == nullptr &&
@@ -85,17 +89,17 @@ namespace fsim {
         const dim3 grid((waves + 3) / 4), block(256);
         last_kernel = "k_rollout_loop";
 #define FS_LOOP(H_, D_)                                                                                       \
-  hipLaunchKernelGGL((fs::k_rollout_loop<H_, D_>), grid, block, 0, stream, dv, num_steps, actions, act_stride, obs, \
-                     rew, done)
+  hipLaunchKernelGGL((fs::k_rollout_loop<H_, D_, false, MX>), grid, block, 0, stream, dv, num_steps, actions, act_stride, \
+                     obs, rew, done)
         const bool full = (f & fs::FLAG_HAS_NOISE) && (f & fs::FLAG_NEED_SUMO) && dv.junction_on && actions != nullptr &&
                           loop_delta4 && !no_loop_full && loop_fastc_ok();
         if (full) {
           last_kernel = "k_rollout_loop<FULL>";
           if (dv.env == FS_ENV_ACCEL)
-            hipLaunchKernelGGL((fs::k_rollout_loop<0, true, true>), grid, block, 0, stream, dv, num_steps, actions,
+            hipLaunchKernelGGL((fs::k_rollout_loop<0, true, true, MX>), grid, block, 0, stream, dv, num_steps, actions,
                                act_stride, obs, rew, done);
           else
-            hipLaunchKernelGGL((fs::k_rollout_loop<1, true, true>), grid, block, 0, stream, dv, num_steps, actions,
+            hipLaunchKernelGGL((fs::k_rollout_loop<1, true, true, MX>), grid, block, 0, stream, dv, num_steps, actions,
                                act_stride, obs, rew, done);
         }
         else if (dv.env == FS_ENV_ACCEL) { if (loop_delta4) FS_LOOP(0, true); else FS_LOOP(0, false); }
@@ -103,6 +107,7 @@ namespace fsim {
 #undef FS_LOOP
         HIP_TRY(hipGetLastError());
         return FS_OK;
+      }
       }
     }
     // single-lane rings of IDM and RL vehicles (flowsim_ringrl.h): the RL experiments' populations and heads, masked
@@ -138,14 +143,14 @@ namespace fsim {
         return FS_OK;
       }
     }
-    if (mixed && num_steps == 0) {                       // observation of the current state (Env.reset)
+    if (mixed && num_steps == 0 && dv.nseg == 0) {       // observation of the current state (Env.reset)
       const int n = dv.R * dv.N;
       last_kernel = "k_obs_mixed";
       hipLaunchKernelGGL((fs::k_obs_mixed<T>), dim3((n + 255) / 256), dim3(256), 0, stream, dv, obs);
       HIP_TRY(hipGetLastError());
       return FS_OK;
     }
-    if (mixed && !pair_ok)
+    if (mixed && !pair_ok && dv.nseg == 0)
       return fail(FS_ERR_UNSUPPORTED, "FS_MIXED: this launch fits neither mixed kernel (k_rollout_pair / k_ring_pair: "
                                       "single-lane ring, even number of IDM / RL vehicles, AccelEnv or "
                                       "WaveAttenuationPOEnv, track_aux = 0)");

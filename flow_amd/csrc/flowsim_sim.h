@@ -568,7 +568,7 @@ struct Sim : SimBase {
   // k_rollout_loop<..., FULL>: its controller divisions by launch constants are div_const -- every divisor proven
   int loop_fastc_state = -1;
   bool loop_fastc_ok() {
-    if (!std::is_same<T, float>::value || no_fastdiv) return false;
+    if (!(std::is_same<T, float>::value || mixed) || no_fastdiv) return false;
     if (loop_fastc_state >= 0) return loop_fastc_state == 1;
     loop_fastc_state = 0;
     if (!loop_div_ok) return false;               // s0 / minGap in [1e-3, 1e6]: tiny dividends cannot matter

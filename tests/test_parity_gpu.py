@@ -1159,3 +1159,57 @@ def test_lane_change_envs_on_a_one_lane_ring_step_on_the_multilane_kernel():
         sim.close()
         ora = run_pair_ml(spec, "f32", K, actions=acts)
         assert (ora.lane == 0).all()
+
+
+def test_figure_eight_mixed_holds_1e_4_against_the_float64_reference_where_float32_does_not():
+    """FS_MIXED on the figure eight (k_rollout_loop's float64-state instantiation: positions, speeds, geometry and every
+    position-based decision in float64, the car-following models in float32 on the rounded speeds and gaps), BASELINE's C3
+    population.  No bit-twin: held (a) without noise against the float64 ORACLE -- the reference's arithmetic -- at 1e-4
+    m / m/s after 1500 steps of a fixed action tape, which float32 misses (the random walk of 1500 position roundings);
+    (b) with the experiment's noise 0.2 against the float64 kernel running the same Philox streams."""
+    import torch
+    from flow_amd.sim import FlowSim
+    R, N, K = 24, 14, 1500
+    dev = torch.device("cuda", 0)
+    acts = np.random.default_rng(1).uniform(-1, 1, (K, R, 1)).astype(np.float32)
+
+    def spec_for(noise):
+        spec = figure_eight_spec(R=R, N=N, horizon=K, seed=5, num_rl=1)
+        veh = [idm_vehicle(speed_mode=1, max_decel=1.5, noise=noise) for _ in range(N - 1)]
+        veh.append(idm_vehicle(controller=S.CTRL_RL, rl_index=0, speed_mode=1))
+        spec["vehicles"] = veh
+        spec["seed"] = 41
+        return spec
+
+    def gpu_run(spec, prec):
+        sim = FlowSim(spec, prec)
+        sim.reset()
+        o = torch.zeros((K, R, sim.obs_dim), device=dev)
+        r = torch.zeros((K, R), device=dev)
+        d = torch.zeros((K, R), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        sim.rollout_dev(K, o, r, d, actions=torch.as_tensor(acts, device=dev))
+        sim.sync()
+        out = (sim.pos.astype(np.float64), sim.vel.astype(np.float64), o.cpu().numpy(), r.cpu().numpy(), sim.last_kernel)
+        sim.close()
+        return out
+    # (a)
+    quiet = spec_for(0.0)
+    ora = S.RingOracle(quiet, np.float64)
+    ora.reset()
+    for k in range(K):
+        o_ref, r_ref, d_ref = ora.step(acts[k])
+    mixed, f32 = gpu_run(quiet, "mixed"), gpu_run(quiet, "f32")
+    assert mixed[4].startswith("k_rollout_loop") and f32[4].startswith("k_rollout_loop"), (mixed[4], f32[4])
+    dx_m, dv_m = np.abs(mixed[0] - ora.x).max(), np.abs(mixed[1] - ora.v).max()
+    dx_f = np.abs(f32[0] - ora.x).max()
+    assert dx_m < 1e-4 and dv_m < 1e-4, (dx_m, dv_m)
+    assert dx_f > 1e-4 and dx_f > 3 * dx_m, (dx_f, dx_m)
+    assert np.abs(mixed[2][-1] - o_ref).max() < 1e-6 and np.abs(mixed[3][-1] - r_ref).max() < 1e-5
+    assert ora.v.max() > 3.0
+    # (b)
+    noisy = spec_for(0.2)
+    mixed, f64 = gpu_run(noisy, "mixed"), gpu_run(noisy, "f64")
+    assert mixed[4] == "k_rollout_loop<FULL>" and f64[4].startswith("k_steps"), (mixed[4], f64[4])
+    assert np.abs(mixed[0] - f64[0]).max() < 1e-4 and np.abs(mixed[1] - f64[1]).max() < 1e-4
+    assert np.abs(mixed[2] - f64[2]).max() < 1e-5 and np.abs(mixed[3] - f64[3]).max() < 1e-5
