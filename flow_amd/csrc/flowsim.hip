@@ -17,7 +17,10 @@ int validate(const fs_config* c) {
   if (c->precision == FS_F16S && (c->network != FS_NET_MERGE || c->num_vehicles > 64))
     return fail(FS_ERR_UNSUPPORTED, "fs_create: FS_F16S (half state, float32 integrator) is built for FS_NET_MERGE "
                                     "(k_steps_open, <= 64 vehicle slots)");
-  if (c->precision == FS_MIXED) {
+  if (c->precision == FS_MIXED && (c->network == FS_NET_MERGE || c->network == FS_NET_BOTTLENECK)) {
+    // open networks: the float64 kernels with float32 car-following models (k_steps_open<double, ., ., 2>); whatever FS_F64
+    // accepts (the lane-drop network beyond 64 slots, k_steps_wide, steps in plain float64)
+  } else if (c->precision == FS_MIXED) {
     // float64 state, float32 controllers: k_rollout_pair (all-IDM AccelEnv rollout) and k_ring_pair (IDM + RL vehicles,
     // AccelEnv / WaveAttenuationPOEnv, warm-up steps and masked resets included).  Name the field that does not fit.
     // The figure eight (k_rollout_loop's float64-state instantiation, flowsim_fig8.h): rollouts step there, everything else

@@ -1328,8 +1328,8 @@ __device__ __forceinline__ float idm_fd(float v, float vl, float h, bool has, co
   if (delta4) { const float r2 = ratio * ratio; pw = r2 * r2; } else pw = pow_delta(ratio, delta);    // (wave-uniform)
   return p[2] * (1.0f - pw - q * q);
 }
-__device__ __forceinline__ float sumo_speed_fd(float v, float vl, float h, bool has, float dt, const Slot<float>& s,
-                                               float max_speed, float ts) {
+__device__ __forceinline__ float sumo_acc_fd(float v, float vl, float h, bool has, const Slot<float>& s, float max_speed,
+                                             float ts) {
   const float gap = hmax(h, 1e-3f);                                   // sumo_idm_speed, same operation order
   const float m = hmax(0.0f, v * s.sumo_tau + div_core(v * (v - vl), ts));
   const float ss = s.sumo_min_gap + m;
@@ -1337,13 +1337,19 @@ __device__ __forceinline__ float sumo_speed_fd(float v, float vl, float h, bool 
   const float q = has ? qq : 0.0f;
   const float r = div_core(v, max_speed);
   const float r2 = r * r;
-  const float acc = s.max_accel * (1.0f - r2 * r2 - q * q);
-  return hmax(0.0f, v + acc * dt);
+  return s.max_accel * (1.0f - r2 * r2 - q * q);
 }
-// control_accel_on<float, 1, true> (its branch-free form) over idm_fd
-__device__ __forceinline__ float control_accel_fd(const DevView<float>& s, const Slot<float>& sl, const FdSlot& fd, int flags,
+__device__ __forceinline__ float sumo_speed_fd(float v, float vl, float h, bool has, float dt, const Slot<float>& s,
+                                               float max_speed, float ts) {
+  return hmax(0.0f, v + sumo_acc_fd(v, vl, h, has, s, max_speed, ts) * dt);
+}
+// control_accel_on<float, 1, true> (its branch-free form) over idm_fd.  (VIEW: DevView<float>, or DevView<double> for the
+// FS_MIXED instantiation of the open-network kernel, CSET = 2: float32 models inside the float64 kernel)
+template <typename VIEW>
+__device__ __forceinline__ float control_accel_fd(const VIEW& sv, const Slot<float>& sl, const FdSlot& fd, int flags,
                                                   float v, float vl, float h, bool has, bool on_edge, bool have_rl, float a_rl,
                                                   bool& commanded, float noise_g) {
+  struct { float dt, act_lo, act_hi; int clip_actions; } s = {float(sv.dt), float(sv.act_lo), float(sv.act_hi), sv.clip_actions};
   const bool is_rl = sl.ctrl == FS_CTRL_RL, is_sim = sl.ctrl == FS_CTRL_SIM;
   const bool delta4 = (flags & FLAG_DELTA4) != 0;
   float a = idm_fd(v, vl, h, has, sl.p, (is_rl || is_sim) ? 4.0f : sl.p[4], fd.ts_idm, delta4);

@@ -33,6 +33,10 @@ namespace fsim {
     if (open_net) {
       // the float32 instantiations exist twice: CSET = 1 for populations of IDM / RL / Sim slots only
       const bool cset = std::is_same<T, float>::value && (dv.flags & fs::FLAG_IDM_SET) && !force_generic && open_div_ok;
+      // FS_MIXED: the float64 kernel with the float32 car-following models (CSET = 2); a population outside their
+      // premises steps in plain float64
+      const bool mset = std::is_same<T, double>::value && mixed && (dv.flags & fs::FLAG_IDM_SET) && !force_generic && open_div_ok;
+      constexpr int C2 = std::is_same<T, double>::value ? 2 : 0;
 #define FS_OPEN__(P_, C_, PR_, PO_)                                                                              \
   hipLaunchKernelGGL((fs::k_steps_open<T, SEG, P_, C_, PR_, PO_>), dim3(blocks), dim3(64), 0, stream, dv, ov,        \
                      num_steps, mask, actions, act_stride, obs, rew, done, obs_every_step, after_reset)
@@ -43,12 +47,13 @@ namespace fsim {
       if (cfg.network == FS_NET_BOTTLENECK) {
         // the lane-drop heads need more than 32 slots (fs_create checks it): only the 64-lane segment is built
         if constexpr (SEG == 64) {
-          if (cset) FS_OPEN(4, (std::is_same<T, float>::value ? 1 : 0)); else FS_OPEN(4, 0);
+          if (cset) FS_OPEN(4, (std::is_same<T, float>::value ? 1 : 0)); else if (mset) FS_OPEN(4, C2); else FS_OPEN(4, 0);
         } else {
           return fail(FS_ERR_UNSUPPORTED, "fs_step: FS_NET_BOTTLENECK runs on 64-lane segments only");
         }
       } else {
-        if (cset) FS_OPEN(2, (std::is_same<T, float>::value ? 1 : 0)); else FS_OPEN(2, 0);
+        if (cset) FS_OPEN(2, (std::is_same<T, float>::value ? 1 : 0)); else if (mset) FS_OPEN(2, C2); else FS_OPEN(2, 0);
+        if (mset) last_kernel = "k_steps_open<mixed>";
       }
 #undef FS_OPEN
 #undef FS_OPEN_

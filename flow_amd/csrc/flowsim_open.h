@@ -338,10 +338,22 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
   sl.sumo_max_speed = s.sumo_max_speed[ii];
   // CSET = 1 in float32: the controllers' divisions as div_core, their square roots taken here (flowsim_kernels.h idm_fd)
   constexpr bool FD = CSET == 1 && std::is_same<T, float>::value;
+  // CSET = 2 (FS_MIXED, T = double): the same float32 car-following models, evaluated on the rounded speeds and gaps; their
+  // accelerations enter the float64 integration.  Everything else -- positions, geometry, every decision -- is this
+  // kernel's float64 arithmetic.
+  constexpr bool MXC = CSET == 2;
+  static_assert(!MXC || std::is_same<T, double>::value, "CSET = 2 is the float64 kernel's FS_MIXED form");
   FdSlot fd = FdSlot{0.0f, 0.0f};
   float fd_adt = 3.0e38f, fd_ddt = 3.0e38f;
+  Slot<float> slf;
+  slf.ctrl = sl.ctrl; slf.failsafe = sl.failsafe; slf.speed_mode = sl.speed_mode; slf.rl_index = sl.rl_index; slf.pis_index = sl.pis_index;
+#pragma unroll
+  for (int k = 0; k < FS_MAX_CTRL_PARAMS; ++k) slf.p[k] = float(sl.p[k]);
+  slf.noise = float(sl.noise); slf.delay = float(sl.delay); slf.max_accel = float(sl.max_accel); slf.max_decel = float(sl.max_decel);
+  slf.length = float(sl.length); slf.sumo_tau = float(sl.sumo_tau); slf.sumo_min_gap = float(sl.sumo_min_gap);
+  slf.sumo_max_speed = float(sl.sumo_max_speed);
+  if constexpr (FD || MXC) fd = make_fd(slf);
   if constexpr (FD) {
-    fd = make_fd(sl);
     fd_adt = (sl.speed_mode & 2) ? sl.max_accel * s.dt : 3.0e38f;
     fd_ddt = (sl.speed_mode & 4) ? sl.max_decel * s.dt : 3.0e38f;
   }
@@ -906,6 +918,8 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       if (flags & FLAG_HAS_NOISE) g_now = nzb.draw(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(ii), nctr);
       T acc;
       if constexpr (FD) acc = control_accel_fd(s, sl, fd, flags, v, vl, h, has, on_edge, have_rl, a_rl, commanded, g_now);
+      else if constexpr (MXC) acc = T(control_accel_fd(s, slf, fd, flags, float(v), float(vl), float(h), has, on_edge, have_rl,
+                                                       float(a_rl), commanded, float(g_now)));
       else acc = control_accel_on<T, CSET, true>(s, sl, flags, v, vl, h, has, vf, hf, mean_v, on_edge, have_rl, a_rl,
                                                  live && slot_ok, rr, ii, nctr, cst, commanded, g_now);
       FS_TICK(0);
@@ -971,7 +985,9 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       } else {
         T next_vel = tmax(v + acc * dt, T(0));
         T vc = v + (next_vel - v) * s.ramp;
-        v_sumo = sumo_idm_speed(v, vl, h, has, dt, sm);
+        if constexpr (MXC)
+          v_sumo = tmax(T(0), v + T(sumo_acc_fd(float(v), float(vl), float(h), has, slf, float(sm.sumo_max_speed), fd.ts_sumo)) * dt);
+        else v_sumo = sumo_idm_speed(v, vl, h, has, dt, sm);
         if (sl.speed_mode & 1) vc = tmin(vc, v_sumo);
         if (sl.speed_mode & 2) vc = tmin(vc, v + sl.max_accel * dt);
         if (sl.speed_mode & 4) vc = tmax(vc, v - sl.max_decel * dt);
@@ -985,6 +1001,8 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         const bool yields = approaching && ((route == 1 && major_busy) || (route == 0 && minor_in_box));
         T stop;
         if constexpr (FD) stop = sumo_speed_fd(v, 0.0f, o.box_in - x, true, dt, sl, sm.sumo_max_speed, fd.ts_sumo);
+        else if constexpr (MXC)
+          stop = tmax(T(0), v + T(sumo_acc_fd(float(v), 0.0f, float(o.box_in - x), true, slf, float(sm.sumo_max_speed), fd.ts_sumo)) * dt);
         else stop = sumo_idm_speed(v, T(0), o.box_in - x, true, dt, sm);
         const T cap = yields ? stop : BIGV;
         if constexpr (FD) {

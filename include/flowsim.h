@@ -44,9 +44,10 @@ extern "C" {
  * FS_MIXED: positions and speeds kept and integrated in float64, the acceleration controller evaluated in
  * float32 on their rounded images -- within 1e-4 of the float64 trajectories over a 1500-step episode at
  * float32 cost.  Built for single-lane rings of IDM and RL vehicles (AccelEnv and WaveAttenuationPOEnv heads, warm-up
- * steps, masked resets, acceleration noise) and for the figure eight (rollouts of up to 16 vehicles; what that kernel
- * does not cover steps in float64); fs_create names the field of a configuration that does not fit.  State fields are
- * float64 as for FS_F64. */
+ * steps, masked resets, acceleration noise), for the figure eight (rollouts of up to 16 vehicles; what that kernel
+ * does not cover steps in float64) and for the open networks up to 64 vehicle slots (the float64 kernel with float32
+ * car-following models; beyond 64 slots: plain float64); fs_create names the field of a configuration that does not
+ * fit.  State fields are float64 as for FS_F64. */
 enum fs_precision { FS_F32 = 0, FS_F64 = 1, FS_MIXED = 2,
                     FS_F16S = 3    /* "fp16 state, fp32 integrator" (BASELINE configs[4]): the positions and speeds a handle
                                       keeps in HBM BETWEEN launches are IEEE half values -- a speed is one half, a position

@@ -514,3 +514,41 @@ def test_equal_positions_take_the_exact_ranking_path():
         run_pair(mspec, "f32", 120, uniform_actions(mspec, 2, 0.0, 1.0), check_every=5)
     except ValueError as e:                                 # the placement check may refuse overlapping same-route starts
         assert "init" in str(e)
+
+
+def test_merge_mixed_precision_holds_1e_4_against_float64_where_float32_does_not():
+    """FS_MIXED on the open networks (k_steps_open<double, ., ., CSET = 2>): the float64 kernel -- positions, geometry, the
+    inflow clocks, every decision in float64 -- with the float32 car-following models (idm_fd / sumo_acc_fd on the rounded
+    speeds and gaps).  No bit-twin: held against the float64 kernel, (a) without noise over a whole 600-step episode of 5
+    sub-steps: every discrete event identical (routes / arrivals / departures), positions and speeds within 1e-4 (measured: 3e-6 m), the
+    float32 run an order of magnitude further off; (b) with noise 0.2 and the same Philox streams."""
+    from flow_amd import _lib as L
+    K = 600
+    for noise in (0.0, 0.2):
+        spec = merge_spec(R=24, cap_human=56, cap_rl=8, num_rl=8, pre=500.0, horizon=K, seed=33, env=O.ENV_MERGE_MA,
+                          sims_per_step=5)
+        spec["vehicles"] = [dict(v, noise=noise if v["controller"] != S.CTRL_RL else 0.0) for v in spec["vehicles"]]
+        sims = {p: make(spec, p) for p in ("mixed", "f64", "f32")}
+        for sim in sims.values():
+            sim.reset()
+        rng = np.random.default_rng(3)
+        for k in range(K):
+            a = rng.uniform(-1.0, 1.0, (24, 8)).astype(np.float32)
+            outs = {p: sim.step(a) for p, sim in sims.items()}
+            if k % 100 == 99 or k == K - 1:
+                np.testing.assert_array_equal(sims["mixed"].get_state(L.FS_FIELD_ROUTE), sims["f64"].get_state(L.FS_FIELD_ROUTE))
+                np.testing.assert_array_equal(sims["mixed"].get_state(L.FS_FIELD_COUNTERS), sims["f64"].get_state(L.FS_FIELD_COUNTERS))
+                np.testing.assert_allclose(outs["mixed"][0], outs["f64"][0], rtol=0, atol=2e-6)     # normalised observations
+                np.testing.assert_allclose(outs["mixed"][1], outs["f64"][1], rtol=0, atol=1e-5)
+        assert sims["mixed"].last_kernel == "k_steps_open<mixed>", sims["mixed"].last_kernel
+        alive = sims["f64"].get_state(L.FS_FIELD_ROUTE) >= 0
+        dx_m = np.abs(sims["mixed"].pos - sims["f64"].pos)[alive].max()
+        dv_m = np.abs(sims["mixed"].vel - sims["f64"].vel)[alive].max()
+        assert dx_m < 1e-4 and dv_m < 1e-4, (noise, dx_m, dv_m)
+        if noise == 0.0:
+            same = (sims["f32"].get_state(L.FS_FIELD_ROUTE) == sims["f64"].get_state(L.FS_FIELD_ROUTE)).all(axis=1)
+            dx_f = np.abs(sims["f32"].pos.astype(np.float64) - sims["f64"].pos)[alive & same[:, None]].max()
+            assert dx_f > 10 * dx_m, (dx_f, dx_m)               # (float32: 1e-4 .. 7e-4 m on this network)
+        assert sims["f64"].get_state(L.FS_FIELD_COUNTERS)[:, 5].min() > 100          # a whole episode of traffic
+        for sim in sims.values():
+            sim.close()
