@@ -552,3 +552,27 @@ def test_merge_mixed_precision_holds_1e_4_against_float64_where_float32_does_not
         assert sims["f64"].get_state(L.FS_FIELD_COUNTERS)[:, 5].min() > 100          # a whole episode of traffic
         for sim in sims.values():
             sim.close()
+
+
+def test_lane_drop_mixed_precision_matches_float64():
+    """The same form on the lane-drop network (k_steps_open<double, 64, 4, 2>, up to 64 vehicle slots): discrete events as in
+    float64, positions within 1e-4 over 300 steps with random desired-velocity actions."""
+    from flow_amd import _lib as L
+    from helpers import bottleneck_spec
+    spec = bottleneck_spec(R=6, cap_human=52, cap_rl=10, horizon=300, seed=9, q=2000.0)
+    spec["vehicles"] = [dict(v, noise=0.0) for v in spec["vehicles"]]
+    a, b = make(spec, "mixed"), make(spec, "f64")
+    a.reset(), b.reset()
+    rng = np.random.default_rng(4)
+    for k in range(300):
+        act = rng.uniform(-1.0, 1.0, (6, spec["num_rl"])).astype(np.float32)
+        oa, ra, da = a.step(act)
+        ob, rb, db = b.step(act)
+        np.testing.assert_array_equal(da, db)
+    np.testing.assert_array_equal(a.get_state(L.FS_FIELD_ROUTE), b.get_state(L.FS_FIELD_ROUTE))
+    np.testing.assert_array_equal(a.get_state(L.FS_FIELD_COUNTERS), b.get_state(L.FS_FIELD_COUNTERS))
+    alive = b.get_state(L.FS_FIELD_ROUTE) >= 0
+    assert np.abs(a.pos - b.pos)[alive].max() < 1e-4 and np.abs(a.vel - b.vel)[alive].max() < 1e-4
+    np.testing.assert_allclose(oa, ob, rtol=0, atol=2e-5)
+    assert b.get_state(L.FS_FIELD_COUNTERS)[:, 6].min() > 20
+    a.close(), b.close()
