@@ -229,7 +229,7 @@ def c5_leg(device, R=1024, env_steps=600, precision="f32"):
     return res
 
 
-def c4_flow_params(slots=256):
+def c4_flow_params(slots=256, precision="f32"):
     """The flow_params of BASELINE configs[3] (see c4_leg)."""
     from flow_amd.controllers import ContinuousRouter, RLController, SimLaneChangeController
     from flow_amd.core.params import (EnvParams, InFlows, InitialConfig, NetParams, SumoCarFollowingParams,
@@ -255,7 +255,7 @@ def c4_flow_params(slots=256):
     inflow.add(veh_type="followerstopper", edge="1", vehs_per_hour=2300 * 0.1, depart_lane="random", depart_speed=10)
     fp = dict(exp_tag="DesiredVelocity", env_name=BottleneckDesiredVelocityEnv, network=BottleneckNetwork,
               simulator="traci", sim=SumoParams(sim_step=0.5, render=False, restart_instance=True, seed=5,
-                                                max_vehicles=slots),
+                                                max_vehicles=slots, precision=precision),
               env=EnvParams(warmup_steps=40, sims_per_step=1, horizon=1000, additional_params=add),
               net=NetParams(inflows=inflow, additional_params={"scaling": 1, "speed_limit": 23}), veh=veh,
               initial=InitialConfig(spacing="uniform", min_gap=5, lanes_distribution=float("inf"),
@@ -263,7 +263,7 @@ def c4_flow_params(slots=256):
     return fp
 
 
-def c4_leg(device, R=128, env_steps=1000, slots=256):
+def c4_leg(device, R=128, env_steps=1000, slots=256, precision="f32"):
     """BASELINE configs[3] (informational, not the headline): BottleneckNetwork scaling 1 (4 -> 2 -> 1 lanes at two
     zipper junctions), inflow 2300 veh/h (10 % RL) with random entry lanes, all vehicles on the SUMO car-following
     model, BottleneckDesiredVelocityEnv head (141 observations, 20 actions), sim_step 0.5, warm-up 40 + horizon 1000
@@ -271,7 +271,7 @@ def c4_leg(device, R=128, env_steps=1000, slots=256):
     import torch
     from flow_amd import _lib as L
     from flow_amd.envs import VecFlowEnv
-    fp = c4_flow_params(slots)
+    fp = c4_flow_params(slots, precision)
     vec = VecFlowEnv(fp, num_replicas=R, device=device.index)
     K = env_steps
     gen = torch.Generator(device=device).manual_seed(3)
