@@ -72,7 +72,7 @@ namespace fsim {
       HIP_TRY(hipGetLastError());
       return FS_OK;
     }
-    // two vehicles per lane (flowsim_pair.h): even N; the only stepping kernel of a FS_MIXED handle
+    // two vehicles per lane (flowsim_pair.h): even N; with k_ring_pair the stepping kernels of a FS_MIXED ring handle
     constexpr int ROW = SEG >= 16 ? SEG / 2 : 8;
     const bool pair_noise = std::is_same<T, float>::value && !mixed;      // the noisy form exists in float32 only
     const bool pair_ok = fast_ok(mask, num_steps, true, pair_noise) && (obs_every_step || num_steps == 1) && dv.N >= 2 &&
