@@ -289,7 +289,7 @@ def c4_leg(device, R=128, env_steps=1000, slots=256, precision="f32"):
     dt = time.perf_counter() - t0
     cnt = vec.sim.get_state(L.FS_FIELD_COUNTERS)
     route = vec.sim.get_state(L.FS_FIELD_ROUTE)
-    res = {"value": R * K / dt, "unit": "env-steps/s", "env_steps": K, "replicas": R, "obs_dim": vec.obs_dim,
+    res = {"value": R * K / dt, "unit": "env-steps/s", "env_steps": K, "replicas": R, "obs_dim": vec.obs_dim, "precision": precision,
            "act_dim": vec.act_dim, "vehicles_in_network_mean": float((route >= 0).sum(axis=1).mean()),
            "departed_mean": float(cnt[:, 6].mean()), "arrived_mean": float(cnt[:, 5].mean()),
            "dropped_at_insertion_mean": float(cnt[:, 7].mean()),
@@ -813,6 +813,7 @@ def main():
         out["c3_figure_eight_po"] = c3_leg(device, po=True)
         out["c3_figure_eight_mixed"] = c3_leg(device, precision="mixed")      # float64 state, float32 car-following models
         out["c4_bottleneck"] = c4_leg(device)
+        out["c4_bottleneck_f64"] = c4_leg(device, precision="f64")            # the reference's arithmetic type
         out["c5_merge"] = c5_leg(device)
         out["c5_merge_fp16_state"] = c5_leg(device, precision="f16s")
         out["c5_merge_mixed"] = c5_leg(device, precision="mixed")             # float64 kernel, float32 car-following models

@@ -31,10 +31,10 @@ struct WideLds {
   int seq[NS];
   int sorted_slot[NS];          // [rank] -> slot
   int skey[NS];                 // [rank] -> path | joins << 8, 0xffff for a free slot
-  unsigned long long okey[sizeof(T) == 4 ? NS : 1];   // float32: the 64-bit ordering keys of the vehicles, compacted
-  unsigned long long okey2[sizeof(T) == 4 ? NS : 1];  // ... and in the order of the updated ranking (its proof)
-  T cx[sizeof(T) == 4 ? 1 : NS];                      // float64: their positions ...
-  int cslot[sizeof(T) == 4 ? 1 : NS];                 // ... and slots, compacted
+  unsigned long long okey[NS];                        // the 64-bit ordering keys of the vehicles, compacted
+  unsigned long long okey2[NS];                       // ... and in the order of the updated ranking (its proof)
+  T cx[sizeof(T) == 4 ? 1 : NS];                      // float64, when the proof fails: their positions ...
+  int cslot[sizeof(T) == 4 ? 1 : NS];                 // ... and slots, compacted (the exact count)
   unsigned long long rmask[10][W];       // masks over RANKS: path 0..P-1 (P <= 8), then passed the first / the second join
   unsigned long long comb[24][W];        // [path * 3 + look-ahead region]: the ranks that hold a leader candidate of that class
   unsigned long long words[2][2][W];
@@ -239,7 +239,10 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
     int rank = 0;
     bool rank_bad = false;                 // float32: this thread saw the updated ranking fail its proof
     ull rank_key = 0ull;
-    if (sizeof(T) == 4) {
+    {
+      // The order is that of ONE unsigned 64-bit key -- float64 (round 3): the key holds the FLOAT32 image of the position,
+      // which orders two vehicles correctly whenever their images differ (rounding is monotone); two neighbours of the
+      // updated ranking with EQUAL images fail the proof below and the block counts exactly, on the float64 positions --
       // float32: the order is that of ONE unsigned 64-bit key, (order-preserving image of x) : (NS-1-slot), so a
       // pair costs a v_cmp_lt_u64 and an add-with-carry instead of two float compares and three mask operations
       // (x + 0 turns a -0.0 into +0.0, whose integer images would otherwise differ)
@@ -289,27 +292,16 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
         lds_barrier();
         const ull k0 = L.okey2[tid], k1 = L.okey2[tid + 1 < NS ? tid + 1 : tid];
         rank_bad = lost || ((tid < n_alive) && ((unsigned(k0 >> 8) & 0xffffffu) != stamp || ((tid + 1 < n_alive) && !(k0 < k1))));
+        if (sizeof(T) == 8) rank_bad = rank_bad || ((tid + 1 < n_alive) && unsigned(k0 >> 32) == unsigned(k1 >> 32));
         rank = lost ? 0 : rank_try;
         rank_key = key;
-      }
-    } else {
-      if (alive) {
-        L.cx[place] = xr;
-        L.cslot[place] = tid;
-      }
-      lds_barrier();
-      if (count_arrivals && tid == 0) L.hist[(tcount - 1) % 20] = na_out;
-#pragma unroll 8
-      for (int j = 0; j < n_alive; ++j) {
-        const T xj = L.cx[j];
-        rank += ((xj < xr) || (xj == xr && L.cslot[j] > tid)) ? 1 : 0;
       }
     }
     const int my_key = alive ? (route | (shift_of(x) << 8)) : 0xffff;
     if (!alive) rank = n_alive + (tid - place);
     L.sorted_slot[rank] = tid;             // (a ranking that fails its proof leaves rubbish here: written again below)
     L.skey[rank] = my_key;
-    if (sizeof(T) == 4) {
+    {
       const int bP = phase & 1;
       phase += 1;
       const ull bw_ = __ballot(rank_bad);
@@ -319,18 +311,29 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
 #pragma unroll
       for (int ww = 0; ww < W; ++ww) ball |= L.words[bP][1][ww];
       if (ball != 0ull) {                                 // block-uniform: count in full
-        if (alive) L.okey[place] = rank_key;
-        lds_barrier();
         int rk = 0;
+        if constexpr (sizeof(T) == 4) {
+          if (alive) L.okey[place] = rank_key;
+          lds_barrier();
 #pragma unroll 8
-        for (int j = 0; j < n_alive; ++j) rk += (L.okey[j] < rank_key) ? 1 : 0;
+          for (int j = 0; j < n_alive; ++j) rk += (L.okey[j] < rank_key) ? 1 : 0;
+        } else {                                          // float64: x ascending, equal x: higher slot first
+          if (alive) {
+            L.cx[place] = xr;
+            L.cslot[place] = tid;
+          }
+          lds_barrier();
+#pragma unroll 8
+          for (int j = 0; j < n_alive; ++j) {
+            const T xj = L.cx[j];
+            rk += ((xj < xr) || (xj == xr && L.cslot[j] > tid)) ? 1 : 0;
+          }
+        }
         rank = alive ? rk : rank;
         L.sorted_slot[rank] = tid;
         L.skey[rank] = my_key;
         lds_barrier();
       }
-    } else {
-      lds_barrier();
     }
     nb_rank = alive ? rank : -1;
     n_new = 0;

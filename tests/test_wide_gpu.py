@@ -296,3 +296,25 @@ def test_wide_equal_positions_take_the_exact_ranking_path():
         tie_steps += sum(len(np.unique(probe.x[r][probe.alive[r]])) < probe.alive[r].sum() for r in range(2))
     assert tie_steps > 30 and (probe.alive.sum(axis=1) > 64).any()
     run_pair(spec, "f32", 220, bottleneck_actions(spec, 3), check_every=10)
+
+
+def test_wide_float64_ranks_on_float32_images_and_counts_exactly_when_they_collide():
+    """The float64 kernel ranks by updating 64-bit keys that hold the FLOAT32 image of a position; two neighbours of the
+    ranking with equal images -- here: vehicles released side by side (equal positions) and vehicles a nanometre apart
+    (equal images, different float64 positions, the HIGHER slot ahead where the key's slot field says behind) -- fail the proof and the block counts on
+    the float64 positions.  Leaders, headways and everything downstream must be the float64 oracle's."""
+    from helpers import bottleneck_spec
+    spec = bottleneck_spec(R=2, cap_human=110, cap_rl=18, horizon=200, seed=4, q=3600.0)
+    X = np.asarray(spec["init_pos"], dtype=np.float64).copy()
+    A, R_ = np.asarray(spec["init_alive"]).copy(), np.asarray(spec["init_route"]).copy()
+    # slots 1 / 2: same float32 image, float64 says the HIGHER slot is ahead (the key's slot field says the opposite)
+    A[:, 1], X[:, 1], R_[:, 1] = True, 150.0, 0
+    A[:, 2], X[:, 2], R_[:, 2] = True, 150.0 + 1e-9, 3
+    assert np.float32(X[0, 1]) == np.float32(X[0, 2]) and X[0, 1] < X[0, 2]
+    A[:, 3], X[:, 3], R_[:, 3] = True, X[:, 0], 3       # and a vehicle at exactly the position of another one
+    spec["init_alive"], spec["init_route"] = A, R_
+    spec["init_pos"] = X
+    for f in spec["inflows"]:
+        f["period"], f["begin"] = 1.0, 1.0
+    ora = run_pair(spec, "f64", 200, bottleneck_actions(spec, 3), check_every=10, exact=False, atol=1e-9)
+    assert (ora.alive.sum(axis=1) > 64).any()
