@@ -477,7 +477,10 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
     const int dead_rank = n_alive + __popcll(~am & segmask & ((1ull << i) - 1ull));
     const int my_key = alive ? (route | (shift_of(x) << 8)) : 0xffff;
     int rank = 0, sorted_slot, skey;
-    if (sizeof(T) == 4) {
+    {
+      // float64 (round 3): the same machinery on the FLOAT32 image of the position -- rounding is monotone, so images that
+      // ascend strictly order the float64 positions too; equal images (equal positions, or positions less than a float32 ulp
+      // apart) are the "tie" below and are then counted exactly on the float64 positions.
       // float32: the order "x ascending, equal x: higher slot first" is that of the unsigned 64-bit key
       // (order-preserving image of x) : (SEG-1-slot).  Two vehicles with the SAME x are rare (two inflows releasing
       // at one coordinate in one sub-step), so the count runs on the 32-bit images alone -- v_readlane, v_cmp_lt_u32,
@@ -520,24 +523,25 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
         rank = alive ? (r0 + r1) + (r2 + r3) : dead_rank;
         const int marked = __builtin_amdgcn_ds_permute((segbase + rank) << 2, 1);
         if (__ballot(marked == 0) != 0ull) {                      // some rank lane got no vehicle: a tie somewhere
-          const unsigned long long key = ((unsigned long long)ord << 32) | (unsigned long long)uint32_t(SEG - 1 - ii);
           int rk = 0;
-          for (unsigned long long u = occ; u; u &= u - 1ull) {
-            const int j = __ffsll((long long)u) - 1;
-            const unsigned long long kj = ((unsigned long long)uint32_t(seg_read_i<SEG>(int(ord), j, seg)) << 32) |
-                                          (unsigned long long)uint32_t(SEG - 1 - j);
-            rk += (kj < key) ? 1 : 0;
+          if constexpr (sizeof(T) == 4) {
+            const unsigned long long key = ((unsigned long long)ord << 32) | (unsigned long long)uint32_t(SEG - 1 - ii);
+            for (unsigned long long u = occ; u; u &= u - 1ull) {
+              const int j = __ffsll((long long)u) - 1;
+              const unsigned long long kj = ((unsigned long long)uint32_t(seg_read_i<SEG>(int(ord), j, seg)) << 32) |
+                                            (unsigned long long)uint32_t(SEG - 1 - j);
+              rk += (kj < key) ? 1 : 0;
+            }
+          } else {                                                // float64: the exact count on the positions themselves
+            for (unsigned long long u = occ; u; u &= u - 1ull) {
+              const int j = __ffsll((long long)u) - 1;
+              const T xj = seg_read<SEG>(xr, j, seg);
+              rk += (int(xj < xr) | (int(xj == xr) & int(j > ii)));     // bitwise: no short-circuit branches
+            }
           }
           rank = alive ? rk : dead_rank;
         }
       }
-    } else {
-      for (unsigned long long u = occupied_slots(); u; u &= u - 1ull) {
-        const int j = __ffsll((long long)u) - 1;
-        const T xj = seg_read<SEG>(xr, j, seg);
-        rank += (int(xj < xr) | (int(xj == xr) & int(j > ii)));     // bitwise: no short-circuit branches
-      }
-      rank = alive ? rank : dead_rank;
     }
     sorted_slot = __builtin_amdgcn_ds_permute((segbase + rank) << 2, i);
     // the same push for (path, joins upstream of the vehicle): once the lanes hold these in rank order the

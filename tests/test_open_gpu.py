@@ -576,3 +576,22 @@ def test_lane_drop_mixed_precision_matches_float64():
     np.testing.assert_allclose(oa, ob, rtol=0, atol=2e-5)
     assert b.get_state(L.FS_FIELD_COUNTERS)[:, 6].min() > 20
     a.close(), b.close()
+
+
+def test_float64_open_kernel_ranks_on_float32_images_and_counts_exactly_when_they_collide():
+    """k_steps_open<double>: the ranking runs on the float32 IMAGES of the float64 positions (try-and-prove, count on 32-bit
+    words) and hands over to the exact float64 count when images tie -- vehicles at one coordinate (released together), and
+    vehicles a nanometre apart whose slot order contradicts their position order."""
+    from helpers import bottleneck_spec
+    spec = bottleneck_spec(R=3, cap_human=40, cap_rl=8, horizon=160, seed=2)
+    X = np.asarray(spec["init_pos"], dtype=np.float64).copy()
+    A, R_ = np.asarray(spec["init_alive"]).copy(), np.asarray(spec["init_route"]).copy()
+    X[:, 40] = X[:, 0]                                      # the RL vehicle starts level with the human, other lane
+    A[:, 1], X[:, 1], R_[:, 1] = True, 150.0, 0             # slots 1 / 2: same float32 image, the HIGHER slot is ahead
+    A[:, 2], X[:, 2], R_[:, 2] = True, 150.0 + 1e-9, 3
+    assert np.float32(X[0, 1]) == np.float32(X[0, 2]) and X[0, 1] < X[0, 2]
+    spec["init_pos"], spec["init_alive"], spec["init_route"] = X, A, R_
+    for f in spec["inflows"]:                               # same clock for both inflows: they release together
+        f["period"], f["begin"] = 1.5, 1.0
+    ora = run_pair(spec, "f64", 160, bottleneck_actions(spec, 3), check_every=5, exact=False, atol=1e-9)
+    assert ora.total_departed.min() > 40
