@@ -817,6 +817,7 @@ def main():
         out["c5_merge"] = c5_leg(device)
         out["c5_merge_fp16_state"] = c5_leg(device, precision="f16s")
         out["c5_merge_mixed"] = c5_leg(device, precision="mixed")             # float64 kernel, float32 car-following models
+        out["c5_merge_f64"] = c5_leg(device, precision="f64")                 # the reference's arithmetic type
         out["cpu_baseline"] = cpu_baseline(lambda r: c2_spec(r, seed=1000))
     elif world == 1 and rank == 0:
         out["cpu_baseline"] = None

@@ -37,6 +37,9 @@ namespace fsim {
       // premises steps in plain float64
       const bool mset = std::is_same<T, double>::value && mixed && (dv.flags & fs::FLAG_IDM_SET) && !force_generic && open_div_ok;
       constexpr int C2 = std::is_same<T, double>::value ? 2 : 0;
+      // plain float64 with an IDM / RL / Sim population: the branch-free controller selection (CSET = 1) in float64
+      // arithmetic -- the same operations as the generic instantiation, without its per-controller exec-mask branches
+      const bool dset = std::is_same<T, double>::value && !mixed && (dv.flags & fs::FLAG_IDM_SET) && !force_generic;
 #define FS_OPEN__(P_, C_, PR_, PO_)                                                                              \
   hipLaunchKernelGGL((fs::k_steps_open<T, SEG, P_, C_, PR_, PO_>), dim3(blocks), dim3(64), 0, stream, dv, ov,        \
                      num_steps, mask, actions, act_stride, obs, rew, done, obs_every_step, after_reset)
@@ -47,12 +50,12 @@ namespace fsim {
       if (cfg.network == FS_NET_BOTTLENECK) {
         // the lane-drop heads need more than 32 slots (fs_create checks it): only the 64-lane segment is built
         if constexpr (SEG == 64) {
-          if (cset) FS_OPEN(4, (std::is_same<T, float>::value ? 1 : 0)); else if (mset) FS_OPEN(4, C2); else FS_OPEN(4, 0);
+          if (cset || dset) FS_OPEN(4, 1); else if (mset) FS_OPEN(4, C2); else FS_OPEN(4, 0);
         } else {
           return fail(FS_ERR_UNSUPPORTED, "fs_step: FS_NET_BOTTLENECK runs on 64-lane segments only");
         }
       } else {
-        if (cset) FS_OPEN(2, (std::is_same<T, float>::value ? 1 : 0)); else if (mset) FS_OPEN(2, C2); else FS_OPEN(2, 0);
+        if (cset || dset) FS_OPEN(2, 1); else if (mset) FS_OPEN(2, C2); else FS_OPEN(2, 0);
         if (mset) last_kernel = "k_steps_open<mixed>";
       }
 #undef FS_OPEN
