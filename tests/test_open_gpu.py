@@ -595,3 +595,13 @@ def test_float64_open_kernel_ranks_on_float32_images_and_counts_exactly_when_the
         f["period"], f["begin"] = 1.5, 1.0
     ora = run_pair(spec, "f64", 160, bottleneck_actions(spec, 3), check_every=5, exact=False, atol=1e-9)
     assert ora.total_departed.min() > 40
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 4, 5, 7, 11, 14])
+def test_fuzz_random_open_network_configs_float64(seed):
+    """The float64 kernels (ranking on float32 images with the exact count on ties; branch-free controller selection for
+    IDM / RL / Sim populations) on the random configurations of the float32 fuzz, without noise, against the float64 oracle."""
+    spec, acts = random_open_spec(seed)
+    spec = quiet(spec)
+    steps = int(spec["horizon"])
+    run_pair(spec, "f64", steps, acts if seed % 5 else None, check_every=max(1, steps // 4), exact=False, atol=1e-9)

@@ -318,3 +318,26 @@ def test_wide_float64_ranks_on_float32_images_and_counts_exactly_when_they_colli
         f["period"], f["begin"] = 1.0, 1.0
     ora = run_pair(spec, "f64", 200, bottleneck_actions(spec, 3), check_every=10, exact=False, atol=1e-9)
     assert (ora.alive.sum(axis=1) > 64).any()
+
+
+@pytest.mark.parametrize("seed", [0, 3, 5])
+def test_wide_fuzz_random_lane_drop_configs_float64(seed):
+    """k_steps_wide<double> (ranking on float32 images, exact count on ties) on random lane-drop configurations against the
+    float64 oracle."""
+    from helpers import bottleneck_spec
+    rng = np.random.default_rng(7000 + seed)
+    R = int(rng.integers(1, 4))
+    cap_rl = int(rng.integers(2, 30))
+    N = int(rng.integers(65, 257))
+    spec = bottleneck_spec(R=R, cap_human=N - cap_rl, cap_rl=cap_rl, horizon=int(rng.integers(150, 300)), seed=seed,
+                           q=float(rng.choice([2300, 3600, 5000])), av_frac=float(rng.choice([0.1, 0.3])),
+                           zipper_distance=float(rng.choice([0.0, 20.0, 50.0, 120.0])),
+                           lane_change_cooldown_steps=int(rng.choice([2, 8, 20])),
+                           lane_change_min_gain=float(rng.choice([3.0, 10.0])), crash_gap=float(rng.choice([0.0, 1.0])),
+                           track_followers=bool(rng.integers(0, 2)))
+    if rng.integers(0, 2):
+        for v in spec["vehicles"][:N - cap_rl]:
+            v["lane_change_mode"] = 1621
+    A = spec["num_rl"]
+    acts = (lambda k, r=np.random.default_rng(seed): r.uniform(-1.5, 1.5, (R, A)).astype(np.float32))
+    run_pair(spec, "f64", int(spec["horizon"]), acts, check_every=30, exact=False, atol=1e-9)
