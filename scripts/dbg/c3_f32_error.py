@@ -1,5 +1,6 @@
 import sys, os
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, 'tests'))
 import numpy as np, torch
 from helpers import figure_eight_spec, idm_vehicle
 from oracle import refsim as S
