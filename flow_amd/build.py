@@ -1,9 +1,10 @@
 """Build libflowsim.so (HIP, gfx950) in-tree.  hipcc cross-compiles without a GPU.
 
 The library is several objects: `flowsim.hip` (C ABI, validation, handle) and `flowsim_part.hip` compiled once per
-(precision, lanes per replica) pair -- each pair instantiates its own step kernels, so the objects compile in parallel
-and an edit to one kernel family rebuilds only the objects whose dependencies changed (objects are cached under
-flow_amd/csrc/_obj/, keyed by a hash of the preprocessed inputs' mtimes and the flags)."""
+(precision, lanes per replica) pair -- each pair instantiates its own step kernels, so the objects compile in parallel.
+Objects are cached under flow_amd/csrc/_obj/ with a stamp = hash of the CONTENTS of every source and header plus the
+flags: an edit to any of them recompiles every object (they share the headers' struct layouts), a change of flags only
+the objects it concerns.  The library is current only if every object's stamp is (needs_build)."""
 import concurrent.futures
 import hashlib
 import os
@@ -23,7 +24,7 @@ LIB = os.path.join(PKG, "libflowsim.so")
 VALIDATED_ROCM = "7.2"
 
 HEADERS = ["flowsim_sim.h", "flowsim_launch.h", "flowsim_kernels.h", "flowsim_open.h", "flowsim_wide.h",
-           "flowsim_pair.h", "flowsim_pair_step_a.inc", "flowsim_pair_step_a_sm.inc", "flowsim_fig8.h", "flowsim_ringrl.h", "flowsim_policy.h",
+           "flowsim_pair.h", "flowsim_pair_step_a.inc", "flowsim_pair_step_a_sm.inc", "flowsim_fig8.h", "flowsim_ringrl.h", "flowsim_policy.h", "flowsim_queue.h",
            "flowsim_part.hip"]
 DEPS = [SRC] + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, "include", "flowsim.h")]
 assert all(os.path.exists(d) for d in DEPS)
@@ -43,6 +44,7 @@ def parts():
             out.append(("seg%d_%s" % (seg, tn), PART, ["-DFS_PART_T=" + t, "-DFS_PART_SEG=%d" % seg]))
         for w in (2, 4):
             out.append(("wide%d_%s" % (w, tn), PART, ["-DFS_PART_T=" + t, "-DFS_PART_WIDE=%d" % w]))
+    out.append(("queue_f32", PART, ["-DFS_PART_T=float", "-DFS_PART_QUEUE=1"]))
     return out
 
 
@@ -67,11 +69,22 @@ def _stamp(extra):
     return h.hexdigest()[:16]
 
 
+def _have_stamp(out):
+    if not (os.path.exists(out) and os.path.exists(out + ".stamp")):
+        return None
+    with open(out + ".stamp") as f:
+        return f.read().strip()
+
+
 def needs_build():
+    """The library is missing, older than a source, or some object was built from other sources / flags than the current
+    ones (build(only=...) links stale objects: their stamps say so and the next plain build() recompiles them)."""
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    if any(os.path.getmtime(d) > t for d in DEPS):
+        return True
+    return any(_have_stamp(os.path.join(OBJ, name + ".o")) != _stamp(extra) for name, _, extra in parts())
 
 
 def _compile(job):
@@ -122,13 +135,10 @@ def build(force=False, verbose=False, only=None):
     objs, todo, stamps = [], [], {}
     for name, src, extra in parts():
         out = os.path.join(OBJ, name + ".o")
-        stamp, have = _stamp(extra), None
-        if os.path.exists(out) and os.path.exists(out + ".stamp"):
-            with open(out + ".stamp") as f:
-                have = f.read().strip()
+        stamp, have = _stamp(extra), _have_stamp(out)
         objs.append(out)
         # development (`only`): the named parts are recompiled, every other object is linked as it is -- its stale
-        # stamp makes the next plain build() recompile it
+        # stamp makes needs_build() true, so the next plain build() recompiles it
         if force or (only and name in only) or (not only and have != stamp) or not os.path.exists(out):
             todo.append((name, src, extra, out, verbose))
             stamps[out] = stamp

@@ -288,6 +288,8 @@ int create_typed(const fs_config* cfg, fs_handle* out) {
     s->no_loop_full = nlf && nlf[0] == '1';
     const char* nrr = std::getenv("FLOWSIM_NO_RING_RL");
     s->no_ring_rl = nrr && nrr[0] == '1';
+    const char* nq = std::getenv("FLOWSIM_NO_QUEUE");
+    s->no_queue = nq && nq[0] == '1';
     const char* np = std::getenv("FLOWSIM_NO_PAIR");
     s->no_pair = np && np[0] == '1';
     const char* pb = std::getenv("FLOWSIM_PAIR_BLOCK");

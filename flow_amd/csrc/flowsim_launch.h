@@ -2,8 +2,27 @@
 // flowsim_part.hip only, so that each (precision, SEG) pair and its kernels compile in an object of their own.
 #pragma once
 #include "flowsim_sim.h"
+#ifdef FS_PART_QUEUE
+#include "flowsim_queue.h"
+#endif
 
 namespace fsim {
+
+#ifdef FS_PART_QUEUE
+  template <typename T>
+  int Sim<T>::launch_queue(int num_steps, const float* actions, size_t act_stride, float* obs, float* rew, uint8_t* done,
+                           int obs_every_step) {
+    if constexpr (std::is_same<T, float>::value) {
+      last_kernel = "k_merge_queue";
+      hipLaunchKernelGGL((fs::k_merge_queue<true>), dim3(dv.R), dim3(64), 0, stream, dv, ov, num_steps, actions, act_stride,
+                         obs, rew, done, obs_every_step);
+      HIP_TRY(hipGetLastError());
+      return FS_OK;
+    } else {
+      return fail(FS_ERR_UNSUPPORTED, "k_merge_queue is a float32 kernel");
+    }
+  }
+#endif
 
   // more than 64 slots per replica (lane-drop network): one workgroup of W waves per replica
   template <typename T>
@@ -31,6 +50,9 @@ namespace fsim {
     constexpr int RPW = 64 / SEG;
     const int blocks = (dv.R + RPW - 1) / RPW;
     if (open_net) {
+      if constexpr (std::is_same<T, float>::value) {
+        if (queue_ok(mask, num_steps)) return launch_queue(num_steps, actions, act_stride, obs, rew, done, obs_every_step);
+      }
       // the float32 instantiations exist twice: CSET = 1 for populations of IDM / RL / Sim slots only
       const bool cset = std::is_same<T, float>::value && (dv.flags & fs::FLAG_IDM_SET) && !force_generic && open_div_ok;
       // FS_MIXED: the float64 kernel with the float32 car-following models (CSET = 2); a population outside their

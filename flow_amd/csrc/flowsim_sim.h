@@ -76,6 +76,7 @@ struct SimBase {
   bool no_loop_kernel = false;  // FLOWSIM_NO_LOOP_KERNEL=1: keep the generic k_steps for segment-table loops (tests)
   bool no_loop_full = false;    // FLOWSIM_NO_LOOP_FULL=1: keep the run-time-flag instantiation of k_rollout_loop (tests)
   bool no_ring_rl = false;      // FLOWSIM_NO_RING_RL=1: keep the generic k_steps for IDM + RL rings (tests)
+  bool no_queue = false;        // FLOWSIM_NO_QUEUE=1: keep k_steps_open / k_steps_wide for the open networks (tests)
   int pair_block = 256;         // threads per block of k_rollout_pair (FLOWSIM_PAIR_BLOCK overrides)
   const char* last_kernel = "";  // family of the step kernel the last launch_steps call chose (fs_last_kernel)
 
@@ -639,6 +640,19 @@ struct Sim : SimBase {
            !dv.junction_mode && !dv.track_aux && mask == nullptr && num_steps > 0 && !force_generic &&
            dv.nseg == 0 && !dv.junction_on && !dv.sort_vehicles && dv.obs_perm == nullptr;
   }
+
+  // the merge network in queue order (flowsim_queue.h): float32, IDM / RL / Sim slots, the multi-agent head, scheduled
+  // inflows, every replica stepping.  Defined in flowsim_launch.h for the one part that holds the kernel (FS_PART_QUEUE).
+  bool queue_ok(const uint8_t* mask, int num_steps) const {
+    if (!std::is_same<T, float>::value || !open_net || cfg.network != FS_NET_MERGE || no_queue || force_generic) return false;
+    if (dv.env != FS_ENV_MERGE_MA || !(dv.flags & fs::FLAG_IDM_SET) || !open_div_ok || ov.n_prob > 0) return false;
+    if (mask != nullptr || num_steps < 1 || dv.N > 64) return false;
+    for (const fs_inflow& f : inflows)
+      if (f.route < 0 || f.route > 1) return false;
+    return true;
+  }
+  int launch_queue(int num_steps, const float* actions, size_t act_stride, float* obs, float* rew, uint8_t* done,
+                   int obs_every_step);
 
   // more than 64 slots per replica (lane-drop network): one workgroup of W waves per replica (flowsim_launch.h)
   template <int W>

@@ -32,6 +32,10 @@ slots = bench.get("slots", 64)                 # 64 slots per replica: one wave 
 waves = bench["replicas"] * (1 if slots <= 64 else (2 if slots <= 128 else 4))
 substeps = bench.get("env_steps", bench.get("steps", 0)) * bench.get("sims_per_step", 1)
 pattern = "k_steps_wide" if slots > 64 else "k_steps_open"
+_names = [r["Name"] for r in csv.DictReader(open(newest("trace/*/*_kernel_stats.csv")))]
+for _q in ("k_merge_queue", "k_drop_queue"):          # the queue-order kernels (flowsim_queue.h), when the leg ran on them
+    if any(_q in n for n in _names):
+        pattern = _q
 if leg == "c3":                                # 14 vehicles -> 16 lanes per replica, 4 replicas per wave
     waves, pattern = bench["replicas"] // 4, ("fs::k_rollout_loop" if any("k_rollout_loop" in r["Name"] for r in csv.DictReader(open(newest("trace/*/*_kernel_stats.csv")))) else "fs::k_steps<")
     substeps = bench.get("steps_per_launch", 1500)
