@@ -14,8 +14,13 @@ namespace fsim {
                            int obs_every_step) {
     if constexpr (std::is_same<T, float>::value) {
       last_kernel = "k_merge_queue";
-      hipLaunchKernelGGL((fs::k_merge_queue<true>), dim3(dv.R), dim3(64), 0, stream, dv, ov, num_steps, actions, act_stride,
-                         obs, rew, done, obs_every_step);
+      const bool noise = (dv.flags & fs::FLAG_HAS_NOISE) != 0, act = actions != nullptr && ov.ma_apply_actions != 0;
+#define FS_QUEUE(NZ_, ACT_)                                                                                        \
+  hipLaunchKernelGGL((fs::k_merge_queue<NZ_, ACT_>), dim3(dv.R), dim3(64), 0, stream, dv, ov, qc, num_steps, actions, \
+                     act_stride, obs, rew, done, obs_every_step)
+      if (noise) { if (act) FS_QUEUE(true, true); else FS_QUEUE(true, false); }
+      else { if (act) FS_QUEUE(false, true); else FS_QUEUE(false, false); }
+#undef FS_QUEUE
       HIP_TRY(hipGetLastError());
       return FS_OK;
     } else {

@@ -26,6 +26,7 @@
 #include "flowsim_ringrl.h"
 #include "flowsim_policy.h"
 #include "flowsim_wide.h"
+#include "flowsim_queue_consts.h"
 
 
 namespace fsim {
@@ -95,6 +96,7 @@ template <typename T>
 struct Sim : SimBase {
   fs::DevView<T> dv{};
   fs::OpenView<T> ov{};        // open networks (FS_NET_MERGE) only
+  fs::QueueConsts qc{};        // the queue-order kernels' view of the network (flowsim_queue.h)
   bool open_net = false;
   std::vector<T> h_len;        // vehicle lengths (host copy, for FS_FIELD_HEADWAY)
   std::vector<T> h_ring_len;   // ring lengths (host copy, for the divisor verification)
@@ -487,6 +489,28 @@ struct Sim : SimBase {
       if ((rc = upload(&ov.cell_tab, ct))) return rc;
       if ((rc = upload(&ov.cell_tab_i, cti))) return rc;
     }
+    {   // flowsim_queue.h: the junction-internal stretches of each route as intervals, the one vehicle length
+      qc.ok = (cfg.network == FS_NET_MERGE) ? 1 : 0;
+      for (int r = 0; r < 2; ++r)
+        for (int j = 0; j < 2; ++j) qc.in_lo[r][j] = qc.in_hi[r][j] = 3.0e38f;
+      int n_int[2] = {0, 0}, k_of[2] = {0, 0};
+      for (size_t i = 0; i < segs.size() && qc.ok; ++i) {
+        const int r = segs[i].route;
+        if (r < 0 || r > 1) { qc.ok = 0; break; }
+        const int k = k_of[r]++;
+        if (!segs[i].internal) continue;
+        if (n_int[r] >= 2) { qc.ok = 0; break; }
+        float hi = 3.0e38f;                              // the next segment of the same route starts where this one ends
+        for (size_t j = i + 1; j < segs.size(); ++j)
+          if (segs[j].route == r) { hi = float(segs[j].start); break; }
+        qc.in_lo[r][n_int[r]] = k == 0 ? -3.0e38f : float(segs[i].start);
+        qc.in_hi[r][n_int[r]] = hi;
+        n_int[r] += 1;
+      }
+      qc.veh_len = N > 0 ? float(veh[0].length) : 5.0f;
+      for (int i = 0; i < N; ++i)
+        if (float(veh[i].length) != qc.veh_len) qc.ok = 0;
+    }
     ov.merge_x = T(cfg.merge_x);
     ov.box_in = T(cfg.box_in);
     ov.end_x = T(cfg.end_x);
@@ -646,6 +670,7 @@ struct Sim : SimBase {
   bool queue_ok(const uint8_t* mask, int num_steps) const {
     if (!std::is_same<T, float>::value || !open_net || cfg.network != FS_NET_MERGE || no_queue || force_generic) return false;
     if (dv.env != FS_ENV_MERGE_MA || !(dv.flags & fs::FLAG_IDM_SET) || !open_div_ok || ov.n_prob > 0) return false;
+    if (!(dv.flags & fs::FLAG_DELTA4) || (dv.flags & fs::FLAG_HAS_FAILSAFE) || dv.integrator != FS_EULER || !qc.ok) return false;
     if (mask != nullptr || num_steps < 1 || dv.N > 64) return false;
     for (const fs_inflow& f : inflows)
       if (f.route < 0 || f.route > 1) return false;
