@@ -219,7 +219,7 @@ def c5_leg(device, R=1024, env_steps=600, precision="f32"):
     dt = time.perf_counter() - t0
     cnt = vec.sim.get_state(L.FS_FIELD_COUNTERS)
     route = vec.sim.get_state(L.FS_FIELD_ROUTE)
-    res = {"value": R * K * 5 / dt, "unit": "env-steps/s (simulation sub-steps)", "env_steps": K, "sims_per_step": 5,
+    res = {"kernel": vec.sim.last_kernel, "value": R * K * 5 / dt, "unit": "env-steps/s (simulation sub-steps)", "env_steps": K, "sims_per_step": 5,
            "replicas": R, "gym_steps_per_s": R * K / dt, "obs_dim": vec.obs_dim, "state": precision,
            "vehicles_in_network_mean": float((route >= 0).sum(axis=1).mean()),
            "departed_mean": float(cnt[:, 6].mean()), "arrived_mean": float(cnt[:, 5].mean()),
@@ -289,7 +289,7 @@ def c4_leg(device, R=128, env_steps=1000, slots=256, precision="f32"):
     dt = time.perf_counter() - t0
     cnt = vec.sim.get_state(L.FS_FIELD_COUNTERS)
     route = vec.sim.get_state(L.FS_FIELD_ROUTE)
-    res = {"value": R * K / dt, "unit": "env-steps/s", "env_steps": K, "replicas": R, "obs_dim": vec.obs_dim, "precision": precision,
+    res = {"kernel": vec.sim.last_kernel, "value": R * K / dt, "unit": "env-steps/s", "env_steps": K, "replicas": R, "obs_dim": vec.obs_dim, "precision": precision,
            "act_dim": vec.act_dim, "vehicles_in_network_mean": float((route >= 0).sum(axis=1).mean()),
            "departed_mean": float(cnt[:, 6].mean()), "arrived_mean": float(cnt[:, 5].mean()),
            "dropped_at_insertion_mean": float(cnt[:, 7].mean()),

@@ -24,7 +24,7 @@ LIB = os.path.join(PKG, "libflowsim.so")
 VALIDATED_ROCM = "7.2"
 
 HEADERS = ["flowsim_sim.h", "flowsim_launch.h", "flowsim_kernels.h", "flowsim_open.h", "flowsim_wide.h",
-           "flowsim_pair.h", "flowsim_pair_step_a.inc", "flowsim_pair_step_a_sm.inc", "flowsim_fig8.h", "flowsim_ringrl.h", "flowsim_policy.h", "flowsim_queue.h", "flowsim_queue_consts.h",
+           "flowsim_pair.h", "flowsim_pair_step_a.inc", "flowsim_pair_step_a_sm.inc", "flowsim_fig8.h", "flowsim_ringrl.h", "flowsim_policy.h", "flowsim_queue.h", "flowsim_queue_consts.h", "flowsim_dropq.h",
            "flowsim_part.hip"]
 DEPS = [SRC] + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, "include", "flowsim.h")]
 assert all(os.path.exists(d) for d in DEPS)

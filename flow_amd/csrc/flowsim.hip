@@ -404,7 +404,7 @@ int fs_sync(fs_handle h) {
   if (!h) return fail(FS_ERR_INVALID, "fs_sync: NULL handle");
   DeviceGuard guard(S(h)->cfg.device);
   HIP_TRY(hipStreamSynchronize(S(h)->stream));
-  return FS_OK;
+  return S(h)->check_qflag();
 }
 
 int fs_reset_dev(fs_handle h, const uint8_t* mask_dev, float* obs_dev) {

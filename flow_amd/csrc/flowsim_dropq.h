@@ -1,0 +1,600 @@
+// flowsim_dropq.h -- gfx950 rollout kernel of the lane-drop network (FS_NET_BOTTLENECK, 4 -> 2 -> 1 lanes) in QUEUE order.
+//
+// k_steps_wide (flowsim_wide.h) keeps vehicle SLOT t in thread t of a workgroup and, every sub-step, ranks all slots by
+// position, scatters them into rank order and searches masks over ranks for leaders (~9 barriers, ~1400 instructions per
+// wave and sub-step).  With lane changing off (lane_change_mode = 0: every shipped bottleneck RL experiment,
+// examples/exp_configs/rl/singleagent/singleagent_bottleneck.py:33-53) a vehicle keeps the entry lane ("path") it was
+// inserted on, and a path is a queue: vehicles enter upstream, leave downstream, nobody overtakes.  So here
+//   * one replica = one workgroup of 4 waves, WAVE p HOLDS PATH p in driving order, head in lane 0: the nearest vehicle
+//     ahead on the own path (M5, flow/core/kernel/vehicle/traci.py:219-242) is the previous lane -- one DPP move;
+//   * the other candidates of the zipper rule M8 (a vehicle within zipper_distance of a join, or past it, follows the
+//     nearest vehicle ahead on every lane that joins its own there) come out of the other waves' queues, mirrored in LDS
+//     after the move: a vehicle upstream of the zone needs only the REARMOST vehicle of the partner path beyond the
+//     first join and of the other two paths beyond the second (two prefix lengths per path, one ballot each); a vehicle
+//     inside a zone or beyond a join does a 6-step binary search for its place in the sorted partner queue(s);
+//   * the slot a vehicle occupies in the state arrays (M1: lowest free slot of its type) is a LABEL it carries;
+//   * the observation of BottleneckDesiredVelocityEnv (flow/envs/bottleneck.py:868-924: vehicles and mean speeds per
+//     lane-segment) is one LDS integer atomic per vehicle and quantity -- speeds in units of 2^-16 m/s, so the sum is
+//     exact and its order does not matter (oracle/opennet.py, spec['cell_sum'] = 'fixed', states the same sum);
+//   * a sub-step has TWO barriers: after the move (mirrors, arrivals) and before the observation is read back.
+// Events inside a wave -- an arrival moves the queue down one lane, a vehicle that is no longer strictly behind the
+// previous lane (a collision) re-sorts the path by (x descending, lower slot first) -- are wave-uniform branches; the
+// insertion bookkeeping (schedule, random entry lanes M9, slot pools M1, id counters) is computed redundantly by all
+// four waves from the same published values, so it needs no barrier of its own.
+//
+// Scope (Sim::dropq_ok): float32, every vehicle driven by SUMO's car-following model (SimCarFollowingController or an
+// RLController whose actions are maxSpeed shifts: FLAG_NO_FLOW_CTRL), one vehicle length, Euler, four entry lanes,
+// lane changing and follower tracking off, scheduled inflows, no replica mask, >= 1 step per launch.  A path holds at
+// most 64 vehicles: an insertion into a full path is refused and the handle is flagged (fs_* calls then fail) -- with
+// the bench's 256 slots a path holds ~40.  Everything else steps on k_steps_wide / k_steps_open<., 64, 4>.
+#pragma once
+
+namespace fs {
+
+struct DropRow { float tau, min_gap, max_accel, ts_sumo, sumo_max; int is_rl, type, pad; };   // per label (slot)
+struct DropXL { float x; int lab; };
+
+struct DropQLds {
+  OpenTabsLds<float> tabs;
+  DropRow row[256];
+  DropXL xl[4][64];            // path p's queue, head first: (position, label) after the move
+  float vm[4][64];             // ... speeds
+  int n[4], ng1[4], ng2[4];    // vehicles on path p; of them beyond the first / the second join (prefixes of the queue)
+  int arr_n[4], arr_lab[4][8]; // arrivals of this sub-step: count and labels per path
+  int crash[2][4];
+  int acc[4][64];              // observation cells: human count, RL count, human speed sum, RL speed sum (2^-16 m/s)
+  float act[2][64];
+  unsigned long long alive_w[4], tmask[8][4];   // slots in use at launch start; slots of vehicle type t
+  // staging for the (re)build of the queues from the slot arrays
+  float st_x[256], st_v[256], st_vmax[256], st_prev[256];
+  int st_path[256], st_seq[256], st_origin[256], st_lab[256];
+};
+
+template <bool DV>
+__global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<float> o, QueueConsts qc, int* __restrict__ qflag,
+                                                    int num_steps, const float* __restrict__ actions, size_t act_stride,
+                                                    float* __restrict__ obs, float* __restrict__ rew,
+                                                    uint8_t* __restrict__ done, int obs_every_step) {
+  using T = float;
+  using ull = unsigned long long;
+  constexpr int P = 4;
+  const T BIGV = 3.0e38f;
+  __shared__ DropQLds L;
+  const int tid = threadIdx.x;
+  const int w = tid >> 6;                         // wave = path (entry lane)
+  const int l = tid & 63;
+  const int rr = blockIdx.x;                      // one replica per workgroup
+  const int N = s.N;
+  const bool slot_ok = tid < N;                   // SLOT view: thread t speaks for slot t of the state arrays
+  const int ti = slot_ok ? tid : N - 1;
+  const size_t base = size_t(rr) * N;
+
+  OpenTabs<T, true> tb;
+  tb.load(o, l, DV, &L.tabs);
+  {
+    DropRow q;
+    q.tau = s.sumo_tau[ti]; q.min_gap = s.sumo_min_gap[ti]; q.max_accel = s.max_accel[ti];
+    q.ts_sumo = 2.0f * tsqrt(s.max_accel[ti] * s.max_decel[ti]);
+    q.sumo_max = s.sumo_max_speed[ti];
+    q.is_rl = s.ctrl[ti] == FS_CTRL_RL ? 1 : 0;
+    q.type = o.slot_type[ti];
+    q.pad = 0;
+    L.row[tid] = q;
+  }
+  const int slot_type = o.slot_type[ti];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const ull m = __ballot(slot_ok && slot_type == t);
+    if (l == 0) L.tmask[t][w] = m;
+  }
+  if (tid < 4) { L.n[tid] = 0; L.arr_n[tid] = 0; L.crash[0][tid] = 0; L.crash[1][tid] = 0; }
+  if (tid < 64) { L.acc[0][tid] = 0; L.acc[1][tid] = 0; L.acc[2][tid] = 0; L.acc[3][tid] = 0; }
+
+  // ---- replica scalars: every wave keeps its own copy and updates it the same way ----------------------------
+  int tcount = s.time[rr];
+  int32_t* cnt = o.counters + size_t(rr) * 8;
+  int sim_steps = cnt[CNT_SIM_STEPS], seq_ctr = cnt[CNT_SEQ];
+  int n_arr = cnt[CNT_ARRIVED], n_dep = cnt[CNT_DEPARTED], tot_arr = cnt[CNT_TOTAL_ARRIVED],
+      tot_dep = cnt[CNT_TOTAL_DEPARTED], tot_drop = cnt[CNT_TOTAL_DROPPED];
+  const uint32_t episode = uint32_t(o.episode[rr]);
+  int emit_l = (l < FS_MAX_INFLOWS) ? o.emitted[size_t(rr) * FS_MAX_INFLOWS + l] : 0;
+  int hist_l = (l < 20) ? o.arr_hist[size_t(rr) * 20 + l] : 0;           // arrivals of sub-step % 20 == lane
+  const bool my_flow = l < o.n_inflows;                                    // lane f of every wave keeps inflow f (M2)
+  const int fl = my_flow ? l : 0;
+  const double my_per = o.flow_tab_d[fl], my_begin = o.flow_tab_d[64 + fl], my_end = o.flow_tab_d[128 + fl];
+  const int my_number = o.flow_tab_i[128 + fl];
+  const float f_xdep = o.lane_tab[TAB_FL_XDEP * 64 + fl], f_vdep = o.lane_tab[TAB_FL_VDEP * 64 + fl];
+  const float f_ts = o.lane_tab[TAB_FL_TWOSQRT * 64 + fl], f_gap = o.lane_tab[TAB_FL_MINGAP * 64 + fl],
+              f_tau = o.lane_tab[TAB_FL_TAU * 64 + fl];
+  const int f_typ = o.flow_tab_i[fl], f_route = o.flow_tab_i[64 + fl];
+  // the first sub-step index n (now = n * sim_step, n = sim_steps - 1) at which my inflow's next vehicle is due: the
+  // schedule is float64 (M2), the sub-steps compare integers
+  auto due_index = [&](int k) -> int {
+    const double t = my_begin + double(k) * my_per;
+    if (!my_flow || !(t <= my_end) || !(my_number < 0 || k < my_number)) return 0x7fffffff;
+    if (!(t > 0.0)) return 0;
+    const double q = t / o.dt_d;
+    if (!(q < 2.0e9)) return 0x7fffffff;
+    int n = int(q);
+    while (double(n) * o.dt_d < t) n += 1;
+    while (n > 0 && double(n - 1) * o.dt_d >= t) n -= 1;
+    return n;
+  };
+  int my_due_n = due_index(emit_l);
+
+  const T dt = s.dt;
+  const T m1 = o.m1, m2 = o.m2, zip = o.zip_d, end_x = o.end_x, LEN = qc.veh_len, vlim = o.speed_limit;
+  auto shift_of = [&](T xx) -> int { return (xx >= m1 ? 1 : 0) + (xx >= m2 ? 1 : 0); };
+  // the route segments (one table: edges and junction-internal stretches alternate): segment of a coordinate
+  const int nseg = o.nseg[0];
+  auto seg_of = [&](T xx) -> int {
+    int k = 0;
+    for (int q = 1; q < nseg; ++q) k += (xx >= tb.template t<TAB_SEG_START>(q)) ? 1 : 0;
+    return k;
+  };
+  const unsigned seg_internal = o.seg_internal[0];
+
+  // ---- build the queues from the slot arrays: rank of every vehicle within its path ---------------------------
+  T x = 0.0f, v = 0.0f, vmax = 1.0f, prev_v = 0.0f;
+  int lab = 0, seq = 0, origin = -1;
+  int n = 0;                                      // vehicles in MY wave's queue (wave-uniform)
+  {
+    T sx = s.pos[base + ti], sv = s.vel[base + ti];
+    if (s.st16 != nullptr) state16_load(s, base + ti, sx, sv);
+    const int sp = slot_ok ? s.lane[base + ti] : -1;
+    L.st_x[tid] = sx;
+    L.st_path[tid] = sp;
+    const ull am = __ballot(sp >= 0);
+    if (l == 0) L.alive_w[w] = am;
+    __syncthreads();
+    int rank = 0;
+    for (int j = 0; j < N; ++j) {
+      const T xj = L.st_x[j];
+      const int pj = L.st_path[j];
+      rank += (pj == sp) & ((xj > sx) | ((xj == sx) & (j < tid))) ? 1 : 0;
+    }
+    __syncthreads();
+    if (sp >= 0 && sp < P && rank < 64) {
+      const int d = sp * 64 + rank;
+      L.st_x[d] = sx; L.st_v[d] = sv; L.st_vmax[d] = o.vmax[base + ti]; L.st_prev[d] = s.prev_vel[base + ti];
+      L.st_lab[d] = tid; L.st_seq[d] = o.seq[base + ti]; L.st_origin[d] = o.origin[base + ti];
+      atomicAdd(&L.n[sp], 1);
+    } else if (sp >= 0) {
+      atomicOr(qflag, 1);                         // more than 64 vehicles on one path (or a path this kernel does not know)
+    }
+    __syncthreads();
+    n = L.n[w];
+    n = __builtin_amdgcn_readfirstlane(n);
+    const int d = w * 64 + l;
+    if (l < n) {
+      x = L.st_x[d]; v = L.st_v[d]; vmax = L.st_vmax[d]; prev_v = L.st_prev[d];
+      lab = L.st_lab[d]; seq = L.st_seq[d]; origin = L.st_origin[d];
+    }
+  }
+  ull aw0 = L.alive_w[0], aw1 = L.alive_w[1], aw2 = L.alive_w[2], aw3 = L.alive_w[3];      // slots in use (all waves: same)
+  ull ar0 = 0ull, ar1 = 0ull, ar2 = 0ull, ar3 = 0ull;                                       // RL slots that arrived in the last sub-step
+
+  // my vehicle's parameters (by label)
+  T u_tau = 1.0f, u_gap = 1.0f, u_acc = 1.0f, u_ts = 1.0f;
+  bool is_rl = false;
+  auto load_params = [&]() {
+    const DropRow q = L.row[lab & 255];
+    u_tau = q.tau; u_gap = q.min_gap; u_acc = q.max_accel; u_ts = q.ts_sumo;
+    is_rl = q.is_rl != 0;
+  };
+  load_params();
+  auto gather_all = [&](int src, bool take) {
+#define FS_D_G(reg_) do { const auto t_ = bperm(reg_, src); reg_ = take ? t_ : reg_; } while (0)
+    FS_D_G(x); FS_D_G(v); FS_D_G(lab); FS_D_G(seq); FS_D_G(origin); FS_D_G(vmax); FS_D_G(prev_v);
+#undef FS_D_G
+  };
+  // my path re-sorted by (x descending, lower slot first) -- after a collision
+  auto resort = [&]() {
+    const bool al = l < n;
+    int c = 0;
+    for (int j = 0; j < n; ++j) {
+      const T xj = read_lane(x, j);
+      const int lj = read_lane_i(lab, j);
+      c += (int(xj > x) | (int(xj == x) & int(lj < lab)));
+    }
+    const int target = al ? c : l;
+    const int src = __builtin_amdgcn_ds_permute(target << 2, l);
+    gather_all(src, true);
+    load_params();
+  };
+
+  // ---- M5 / M8: leader, headway, collision --------------------------------------------------------------------
+  T h = 1000.0f, vl = -1001.0f;
+  bool has = false;
+  int lead_lab = -1;
+  // the number of vehicles of path q AHEAD of (xi, labi): binary search in its sorted mirror
+  auto count_ahead = [&](int q, int nq, T xi, int labi) -> int {
+    int lo = 0;
+#pragma unroll
+    for (int step = 32; step >= 1; step >>= 1) {
+      const int idx = lo + step - 1;
+      const DropXL e = L.xl[q][idx & 63];
+      const int ahead = int(idx < nq) & (int(e.x > xi) | (int(e.x == xi) & int(e.lab < labi)));   // (bitwise: no branches)
+      lo += ahead ? step : 0;
+    }
+    return lo;
+  };
+  auto neighbours = [&](int n0, int n1_, int n2, int n3, int g10, int g11, int g12, int g13, int g20, int g21, int g22, int g23,
+                        bool& crash) {
+    const bool alive = l < n;
+    const int la = shift_of(x + zip);
+    const T x_up = dpp<DPP_WAVE_SHR1>(x), v_up = dpp<DPP_WAVE_SHR1>(v);
+    const int lab_up = dpp_i<DPP_WAVE_SHR1>(lab);
+    T bx = BIGV, bv = 0.0f;
+    int bl = -1, bp = w;
+    bool any = false;
+    if (alive && l > 0) { bx = x_up; bv = v_up; bl = lab_up; any = true; }
+#pragma unroll
+    for (int t = 1; t < P; ++t) {
+      const int q = w ^ t;
+      const int nq = q == 0 ? n0 : (q == 1 ? n1_ : (q == 2 ? n2 : n3));
+      const int g1q = q == 0 ? g10 : (q == 1 ? g11 : (q == 2 ? g12 : g13));
+      const int g2q = q == 0 ? g20 : (q == 1 ? g21 : (q == 2 ? g22 : g23));
+      const int cnt_q = count_ahead(q, nq, x, lab);
+      // the partner path (t = 1): every vehicle ahead once I look across the first join (la >= 1), else its rearmost
+      // vehicle beyond that join; the other pair: every vehicle ahead once I look across the second join, else its
+      // rearmost vehicle beyond it
+      const bool search = t == 1 ? la >= 1 : la == 2;
+      const int ci = search ? cnt_q - 1 : (t == 1 ? g1q : g2q) - 1;
+      const DropXL e = L.xl[q][ci < 0 ? 0 : ci];
+      const T ev = L.vm[q][ci < 0 ? 0 : ci];
+      const bool take = (int(alive) & int(ci >= 0) & (int(e.x < bx) | (int(e.x == bx) & int(e.lab > bl)))) != 0;   // the nearest; equal x: the higher slot
+      bx = take ? e.x : bx;
+      bv = take ? ev : bv;
+      bl = take ? e.lab : bl;
+      bp = take ? q : bp;
+      any = any || take;
+    }
+    has = any;
+    h = any ? (bx - x) - LEN : 1000.0f;                 // vehicle/traci.py:237
+    vl = any ? bv : -1001.0f;
+    lead_lab = any ? bl : -1;
+    const int sh_l = shift_of(bx);
+    const bool same_lane = any && ((w >> sh_l) == (bp >> sh_l));            // M8: a collision needs one physical lane
+    crash = __ballot(alive && same_lane && (h < s.crash_gap)) != 0ull;
+  };
+
+  // the queue lengths and join prefixes of all paths, as the owners published them
+  int n0, n1_, n2, n3, g10, g11, g12, g13, g20, g21, g22, g23;
+  auto read_counts = [&]() {
+    n0 = __builtin_amdgcn_readfirstlane(L.n[0]); n1_ = __builtin_amdgcn_readfirstlane(L.n[1]);
+    n2 = __builtin_amdgcn_readfirstlane(L.n[2]); n3 = __builtin_amdgcn_readfirstlane(L.n[3]);
+    g10 = __builtin_amdgcn_readfirstlane(L.ng1[0]); g11 = __builtin_amdgcn_readfirstlane(L.ng1[1]);
+    g12 = __builtin_amdgcn_readfirstlane(L.ng1[2]); g13 = __builtin_amdgcn_readfirstlane(L.ng1[3]);
+    g20 = __builtin_amdgcn_readfirstlane(L.ng2[0]); g21 = __builtin_amdgcn_readfirstlane(L.ng2[1]);
+    g22 = __builtin_amdgcn_readfirstlane(L.ng2[2]); g23 = __builtin_amdgcn_readfirstlane(L.ng2[3]);
+  };
+  auto publish = [&]() {
+    const bool alive = l < n;
+    DropXL e;
+    e.x = x; e.lab = lab;
+    L.xl[w][l] = e;
+    L.vm[w][l] = v;
+    const int c1 = __popcll(__ballot(alive && x >= m1)), c2 = __popcll(__ballot(alive && x >= m2));
+    if (l == 0) { L.n[w] = n; L.ng1[w] = c1; L.ng2[w] = c2; }
+  };
+
+  // get_outflow_rate over the last `window` sub-steps (vehicle/traci.py:500-505); the history is one count per lane
+  auto outflow = [&](int window) -> T {
+    const int nn = tcount < window ? tcount : window;
+    const int ago = (((tcount - 1 - l) % 20) + 20) % 20;
+    const T mine = (l < 20 && ago < nn) ? T(hist_l) : 0.0f;
+    const T total = seg_sum<64>(mine);                     // small integers: exact in any order
+    const T rate = (3600.0f * total) / (T(nn > 0 ? nn : 1) * dt);
+    return nn > 0 ? rate : 0.0f;
+  };
+
+  const int obs_dim = o.obs_dim;
+  const size_t step_rows = obs_every_step ? size_t(s.R) : 0;
+  float* orow = obs + size_t(rr) * obs_dim;
+  float* rrow = rew + rr;
+  uint8_t* drow = done + rr;
+
+  // the vehicle in this lane leaves the network: its final state goes to its slot now
+  auto retire = [&](bool mine) {
+    if (mine) {
+      const size_t e = base + size_t(lab & 255);
+      if (s.st16 != nullptr) state16_store(s, e, x, v);
+      else { s.pos[e] = x; s.vel[e] = v; }
+      s.lane[e] = -1;
+      s.prev_vel[e] = prev_v;
+      s.accel[e] = 0.0f;
+      o.seq[e] = seq;
+      o.origin[e] = origin;
+      o.vmax[e] = vmax;
+      o.lead[e] = -1;
+      o.headway[e] = 1000.0f;
+    }
+  };
+
+  // ---- the snapshot of the launch's first sub-step ------------------------------------------------------------------
+  if (actions != nullptr && tid < s.num_rl) L.act[0][tid] = actions[size_t(rr) * s.num_rl + tid];
+  publish();
+  __syncthreads();
+  read_counts();
+  {
+    bool c_;
+    neighbours(n0, n1_, n2, n3, g10, g11, g12, g13, g20, g21, g22, g23, c_);
+  }
+  __syncthreads();
+
+  for (int step = 0; step < num_steps; ++step) {
+    const int ab = step & 1;
+    if (actions != nullptr && step + 1 < num_steps && tid < s.num_rl)
+      L.act[(step + 1) & 1][tid] = actions[size_t(step + 1) * act_stride + size_t(rr) * s.num_rl + tid];
+    bool crashed = false;
+    const bool emit = obs_every_step || (step == num_steps - 1);
+    for (int sub = 0; sub < s.sims_per_step; ++sub) {
+      const bool live = !crashed;
+      bool alive = l < n;
+      // ---- O6: BottleneckDesiredVelocityEnv._apply_rl_actions (bottleneck.py:926-969) -----------------------------
+      if (DV && actions != nullptr) {
+        const int seg_k = seg_of(x);
+        const bool internal = (seg_internal >> seg_k) & 1u;
+        const int my_lane = w >> shift_of(x);
+        const int acell = cell_of<1>(tb, o.act_span, x, seg_k, my_lane, alive && !internal);
+        const float a_cell = L.act[ab][acell >= 0 ? acell : 0];
+        T a = acell >= 0 ? a_cell : 0.0f;
+        if (s.clip_actions) a = tmin(tmax(a, s.act_lo), s.act_hi);
+        T nxt = tmin(tmax(vmax + a, 0.01f), 23.0f);
+        nxt = acell >= 0 ? nxt : 23.0f;
+        if (live && alive && is_rl) vmax = nxt;
+      }
+      // ---- M7: every vehicle follows SUMO's model (sumo_speed_fd) ---------------------------------------------------
+      {
+        const T u_vmax = tmin(vmax, vlim);                 // M10
+        const float gap = hmax(h, 1e-3f);
+        const float m = hmax(0.0f, v * u_tau + div_core(v * (v - vl), u_ts));
+        const float ss = u_gap + m;
+        const float qq = div_core(ss, gap);
+        const float q = has ? qq : 0.0f;
+        const float r_ = div_core(v, u_vmax);
+        const float r2 = r_ * r_;
+        const float a_s = u_acc * (1.0f - r2 * r2 - q * q);
+        const T v_new = hmax(0.0f, v + a_s * dt);
+        const bool mv = live && alive;
+        prev_v = mv ? v : prev_v;
+        x = mv ? x + v_new * dt : x;
+        v = mv ? v_new : v;
+      }
+      if (live) { tcount += 1; sim_steps += 1; }
+      // ---- the order of my path: a collision re-sorts it; arrivals (M4) leave from the head -----------------------
+      int na = 0;
+      if (live) {
+        const T x_up = dpp<DPP_WAVE_SHR1>(x);
+        if (__ballot(alive && l > 0 && !(x < x_up)) != 0ull) resort();
+        const bool arrived = alive && (x >= end_x);
+        na = __popcll(__ballot(arrived));
+        if (na > 0) {
+          retire(arrived);
+          if (arrived && l < 8) L.arr_lab[w][l] = lab;
+          if (na > 8) atomicOr(qflag, 2);
+          n -= na;
+          gather_all(l + na, l < n);
+          load_params();
+          alive = l < n;
+        }
+      }
+      if (l == 0) L.arr_n[w] = na;
+      publish();
+      lds_barrier();
+      // ---- every wave: the arrivals of all paths, then the insertions (M2 / M3 / M9 / M1) in InFlows order ---------
+      read_counts();
+      ull ja0 = 0ull, ja1 = 0ull, ja2 = 0ull, ja3 = 0ull;      // slots freed in this sub-step: free from the next one on
+      if (live) {
+        int na_all = 0;
+        ar0 = ar1 = ar2 = ar3 = 0ull;
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+          const int nq = __builtin_amdgcn_readfirstlane(L.arr_n[q]);
+          na_all += nq;
+          for (int j = 0; j < nq && j < 8; ++j) {
+            const int lj = __builtin_amdgcn_readfirstlane(L.arr_lab[q][j]) & 255;
+            const ull bit = 1ull << (lj & 63);
+            const bool rl_j = L.row[lj].is_rl != 0;
+            if ((lj >> 6) == 0) { ja0 |= bit; if (rl_j) ar0 |= bit; }
+            else if ((lj >> 6) == 1) { ja1 |= bit; if (rl_j) ar1 |= bit; }
+            else if ((lj >> 6) == 2) { ja2 |= bit; if (rl_j) ar2 |= bit; }
+            else { ja3 |= bit; if (rl_j) ar3 |= bit; }
+          }
+        }
+        n_arr = na_all;
+        n_dep = 0;
+        tot_arr += na_all;
+        if (l == (tcount - 1) % 20) hist_l = na_all;
+        // inflows whose next vehicle is due (lane f of every wave evaluates inflow f)
+        unsigned fm = unsigned(__ballot(sim_steps - 1 >= my_due_n)) & 0xffu;
+        // (x, v, label) of the vehicles inserted so far in this sub-step, per path: the tail an insertion is checked against
+        T ix0 = 0, ix1 = 0, ix2 = 0, ix3 = 0, iv0 = 0, iv1 = 0, iv2 = 0, iv3 = 0;
+        int ic0 = 0, ic1 = 0, ic2 = 0, ic3 = 0;
+        while (fm != 0u) {
+          const int f = __ffs(int(fm)) - 1;
+          fm &= fm - 1u;
+          const int k = read_lane_i(emit_l, f);
+          const int typ = read_lane_i(f_typ, f);
+          int route_f = read_lane_i(f_route, f);
+          const T x_dep = read_lane(f_xdep, f), v_dep = read_lane(f_vdep, f);
+          const T two_sqrt = read_lane(f_ts, f), min_gap_f = read_lane(f_gap, f), tau_f = read_lane(f_tau, f);
+          const bool random_lane = route_f < 0;
+          if (random_lane) {                                 // M9: departLane = "random"
+            uint32_t c0 = uint32_t(k), c1 = uint32_t(1000 + f), c2 = s.rep0 + uint32_t(rr), c3 = 1u + 2u * episode;
+            philox4x32_10(c0, c1, c2, c3, s.seed_lo, s.seed_hi);
+            route_f = __builtin_amdgcn_readfirstlane(int((uint64_t(c0 >> 8) * uint64_t(P)) >> 24));
+          }
+          // M1: the lowest free slot of the type (a slot freed in this sub-step is not free yet)
+          const ull f0 = L.tmask[typ & 7][0] & ~aw0 & ~ja0, f1 = L.tmask[typ & 7][1] & ~aw1 & ~ja1,
+                    f2 = L.tmask[typ & 7][2] & ~aw2 & ~ja2, f3 = L.tmask[typ & 7][3] & ~aw3 & ~ja3;
+          int slot = -1;
+          if (f0) slot = first_bit(f0);
+          else if (f1) slot = 64 + first_bit(f1);
+          else if (f2) slot = 128 + first_bit(f2);
+          else if (f3) slot = 192 + first_bit(f3);
+          slot = __builtin_amdgcn_readfirstlane(slot);
+          // M3: the nearest vehicle ahead on the route: the tail of the own path, the rearmost vehicle of the partner
+          // path beyond the first join, of the other two beyond the second; equal positions: the lowest slot
+          T xm = BIGV, vm_ = 0.0f;
+          int lm = 256;
+          bool has_lead = false;
+#pragma unroll
+          for (int q = 0; q < P; ++q) {
+            const int t = q ^ route_f;
+            const int nq = q == 0 ? n0 : (q == 1 ? n1_ : (q == 2 ? n2 : n3));
+            const int icq = q == 0 ? ic0 : (q == 1 ? ic1 : (q == 2 ? ic2 : ic3));
+            int ci;
+            if (t == 0) ci = nq + icq - 1;
+            else if (t == 1) ci = (q == 0 ? g10 : (q == 1 ? g11 : (q == 2 ? g12 : g13))) - 1;
+            else ci = (q == 0 ? g20 : (q == 1 ? g21 : (q == 2 ? g22 : g23))) - 1;
+            T cx, cv;
+            int cl;
+            if (t == 0 && icq > 0) {                       // the vehicle inserted a moment ago on this path
+              cx = q == 0 ? ix0 : (q == 1 ? ix1 : (q == 2 ? ix2 : ix3));
+              cv = q == 0 ? iv0 : (q == 1 ? iv1 : (q == 2 ? iv2 : iv3));
+              cl = 255;                                     // (its position is the insertion point: no tie with a vehicle ahead)
+            } else {
+              const DropXL e = L.xl[q][ci < 0 ? 0 : ci];
+              cx = e.x; cl = e.lab; cv = L.vm[q][ci < 0 ? 0 : ci];
+            }
+            const bool take = ci >= 0 && (cx < xm || (cx == xm && cl < lm));
+            xm = take ? cx : xm; vm_ = take ? cv : vm_; lm = take ? cl : lm;
+            has_lead = has_lead || take;
+          }
+          const T gap = (xm - LEN) - x_dep;
+          const T dq = div_core(v_dep * (v_dep - vm_), two_sqrt);
+          const T need = min_gap_f + tmax(0.0f, v_dep * tau_f + dq);
+          const int n_own = (route_f == 0 ? n0 + ic0 : (route_f == 1 ? n1_ + ic1 : (route_f == 2 ? n2 + ic2 : n3 + ic3)));
+          if (slot >= 0 && n_own >= 64 && (!has_lead || gap >= need)) atomicOr(qflag, 1);   // the path is full: refused, flagged
+          const bool ok = __builtin_amdgcn_readfirstlane(int((slot >= 0) && n_own < 64 && (!has_lead || gap >= need))) != 0;
+          if (ok) {
+            if (w == route_f) {
+              if (l == n) {
+                x = x_dep;
+                v = v_dep;
+                prev_v = 0.0f;                             // previous_speeds.get(veh_id, 0)
+                lab = slot;
+                seq = seq_ctr;
+                origin = f * (1 << 20) + k;
+                vmax = L.row[slot & 255].sumo_max;
+              }
+              n += 1;
+              load_params();
+            }
+            if (route_f == 0) { ix0 = x_dep; iv0 = v_dep; ic0 += 1; }
+            else if (route_f == 1) { ix1 = x_dep; iv1 = v_dep; ic1 += 1; }
+            else if (route_f == 2) { ix2 = x_dep; iv2 = v_dep; ic2 += 1; }
+            else { ix3 = x_dep; iv3 = v_dep; ic3 += 1; }
+            const ull bit = 1ull << (slot & 63);
+            if ((slot >> 6) == 0) aw0 |= bit; else if ((slot >> 6) == 1) aw1 |= bit; else if ((slot >> 6) == 2) aw2 |= bit; else aw3 |= bit;
+            seq_ctr += 1;
+            n_dep += 1;
+            tot_dep += 1;
+          }
+          // M9: a random-lane vehicle that does not fit when it is due is dropped, not retried
+          const bool consumed = ok || random_lane;
+          if (consumed && l == f) { emit_l = k + 1; my_due_n = due_index(k + 1); }
+          if (consumed && !ok) tot_drop += 1;
+        }
+        aw0 &= ~ja0; aw1 &= ~ja1; aw2 &= ~ja2; aw3 &= ~ja3;
+      }
+      // ---- O1: the new snapshot, the collision check ---------------------------------------------------------------
+      bool c = false;
+      neighbours(n0, n1_, n2, n3, g10, g11, g12, g13, g20, g21, g22, g23, c);
+      const int cb = (step * s.sims_per_step + sub) & 1;
+      if (c && l == 0) L.crash[cb][w] = 1;
+      // ---- O6 get_state (bottleneck.py:868-924): every vehicle enters itself into its cell ---------------------------
+      const bool last_sub = sub == s.sims_per_step - 1;
+      if (DV && emit && last_sub) {
+        alive = l < n;
+        const int seg_k = seg_of(x);
+        const bool internal = (seg_internal >> seg_k) & 1u;
+        const int my_lane = w >> shift_of(x);
+        const int ocell = cell_of<0>(tb, o.obs_span, x, seg_k, my_lane, alive && !internal);
+        if (ocell >= 0) {
+          const int vi = int(rintf(v * 65536.0f));
+          atomicAdd(&L.acc[is_rl ? 1 : 0][ocell], 1);
+          atomicAdd(&L.acc[is_rl ? 3 : 2][ocell], vi);
+        }
+      }
+      lds_barrier();
+      {
+        const bool cc = (L.crash[cb][0] | L.crash[cb][1] | L.crash[cb][2] | L.crash[cb][3]) != 0;
+        crashed = crashed || (cc && live);
+        if (tid < 4) L.crash[cb ^ 1][tid] = 0;             // (the other buffer is written in the next sub-step, two barriers away)
+      }
+    }
+
+    // ---- get_state / compute_reward / done ------------------------------------------------------------------------
+    if (emit) {
+      if (DV) {
+        const int C = o.n_obs_cells;
+        if (tid < C) {
+          const int cnt_h = L.acc[0][tid], cnt_r = L.acc[1][tid];
+          const T sp_h = T(L.acc[2][tid]) * (1.0f / 65536.0f), sp_r = T(L.acc[3][tid]) * (1.0f / 65536.0f);
+          L.acc[0][tid] = 0; L.acc[1][tid] = 0; L.acc[2][tid] = 0; L.acc[3][tid] = 0;
+          const T nh = div_out(T(cnt_h), 20.0), nr = div_out(T(cnt_r), 20.0);          // NUM_VEHICLE_NORM
+          const T mean_h = div_out(cnt_h > 0 ? sp_h / (nh * 20.0f) : 0.0f, 50.0);
+          const T mean_r = div_out(cnt_r > 0 ? sp_r / (nr * 20.0f) : 0.0f, 50.0);
+          orow[tid] = nh;
+          orow[C + tid] = nr;
+          orow[2 * C + tid] = mean_h;
+          orow[3 * C + tid] = mean_r;
+        }
+        const T of = div_out(outflow(o.obs_window), 2000.0);
+        if (tid == 64) orow[4 * C] = of;
+      } else if (tid == 0) {
+        orow[0] = 1.0f;                                    // bottleneck.py:481-483
+      }
+      const T reward = outflow(o.rew_window) / o.out_norm;     // bottleneck.py:474-478, 971-981
+      if (tid == 128) {
+        *rrow = reward;
+        *drow = done_flag(tcount >= s.step_limit, crashed);
+      }
+      orow += step_rows * obs_dim;
+      rrow += step_rows;
+      drow += step_rows;
+    }
+  }
+
+  // ---- the state back to its slots ---------------------------------------------------------------------------------
+  __threadfence();
+  if (slot_ok) o.arrived_rl[base + tid] = 0;
+  __syncthreads();
+  {
+    const bool alive = l < n;
+    if (alive) {
+      const size_t e = base + size_t(lab & 255);
+      if (s.st16 != nullptr) state16_store(s, e, x, v);
+      else { s.pos[e] = x; s.vel[e] = v; }
+      s.lane[e] = w;
+      s.prev_vel[e] = prev_v;
+      s.accel[e] = 0.0f;
+      o.seq[e] = seq;
+      o.origin[e] = origin;
+      o.vmax[e] = vmax;
+      o.lead[e] = lead_lab;
+      o.headway[e] = h;
+    }
+    if (slot_ok) {
+      const ull arw = w == 0 ? ar0 : (w == 1 ? ar1 : (w == 2 ? ar2 : ar3));
+      if ((arw >> l) & 1ull) o.arrived_rl[base + tid] = 1;
+    }
+    if (tid == 0) {
+      s.time[rr] = tcount;
+      cnt[CNT_SIM_STEPS] = sim_steps;
+      cnt[CNT_SEQ] = seq_ctr;
+      cnt[CNT_ARRIVED] = n_arr;
+      cnt[CNT_DEPARTED] = n_dep;
+      cnt[CNT_TOTAL_ARRIVED] = tot_arr;
+      cnt[CNT_TOTAL_DEPARTED] = tot_dep;
+      cnt[CNT_TOTAL_DROPPED] = tot_drop;
+    }
+    if (w == 0 && l < FS_MAX_INFLOWS) o.emitted[size_t(rr) * FS_MAX_INFLOWS + l] = emit_l;
+    if (w == 0 && l < 20) o.arr_hist[size_t(rr) * 20 + l] = hist_l;
+  }
+}
+
+}  // namespace fs

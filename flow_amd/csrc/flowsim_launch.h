@@ -4,6 +4,7 @@
 #include "flowsim_sim.h"
 #ifdef FS_PART_QUEUE
 #include "flowsim_queue.h"
+#include "flowsim_dropq.h"
 #endif
 
 namespace fsim {
@@ -27,6 +28,24 @@ namespace fsim {
       return fail(FS_ERR_UNSUPPORTED, "k_merge_queue is a float32 kernel");
     }
   }
+  template <typename T>
+  int Sim<T>::launch_dropq(int num_steps, const float* actions, size_t act_stride, float* obs, float* rew, uint8_t* done,
+                           int obs_every_step) {
+    if constexpr (std::is_same<T, float>::value) {
+      last_kernel = "k_drop_queue";
+      qflag_armed = true;
+      if (dv.env == FS_ENV_BOTTLENECK_DV)
+        hipLaunchKernelGGL((fs::k_drop_queue<true>), dim3(dv.R), dim3(256), 0, stream, dv, ov, qc, d_qflag, num_steps, actions,
+                           act_stride, obs, rew, done, obs_every_step);
+      else
+        hipLaunchKernelGGL((fs::k_drop_queue<false>), dim3(dv.R), dim3(256), 0, stream, dv, ov, qc, d_qflag, num_steps, actions,
+                           act_stride, obs, rew, done, obs_every_step);
+      HIP_TRY(hipGetLastError());
+      return FS_OK;
+    } else {
+      return fail(FS_ERR_UNSUPPORTED, "k_drop_queue is a float32 kernel");
+    }
+  }
 #endif
 
   // more than 64 slots per replica (lane-drop network): one workgroup of W waves per replica
@@ -36,6 +55,9 @@ namespace fsim {
                   float* rew, uint8_t* done, int obs_every_step) {
     // float32 exists twice (CSET = 1: IDM / RL / Sim slots only); num_paths = 8 is the scaling-2 network
     constexpr int C1 = std::is_same<T, float>::value ? 1 : 0;
+    if constexpr (std::is_same<T, float>::value) {
+      if (dropq_ok(mask, num_steps)) return launch_dropq(num_steps, actions, act_stride, obs, rew, done, obs_every_step);
+    }
     const bool cset = C1 == 1 && (dv.flags & fs::FLAG_IDM_SET) && !force_generic && open_div_ok;
 #define FS_WIDE(P_, C_)                                                                                          \
   hipLaunchKernelGGL((fs::k_steps_wide<T, W, C_, P_>), dim3(dv.R), dim3(64 * W), 0, stream, dv, ov, num_steps, mask, \
@@ -57,6 +79,7 @@ namespace fsim {
     if (open_net) {
       if constexpr (std::is_same<T, float>::value) {
         if (queue_ok(mask, num_steps)) return launch_queue(num_steps, actions, act_stride, obs, rew, done, obs_every_step);
+        if (dropq_ok(mask, num_steps)) return launch_dropq(num_steps, actions, act_stride, obs, rew, done, obs_every_step);
       }
       // the float32 instantiations exist twice: CSET = 1 for populations of IDM / RL / Sim slots only
       const bool cset = std::is_same<T, float>::value && (dv.flags & fs::FLAG_IDM_SET) && !force_generic && open_div_ok;

@@ -8,6 +8,7 @@
 namespace fsim {
 #if defined(FS_PART_QUEUE)
 template int Sim<FS_PART_T>::launch_queue(int, const float*, size_t, float*, float*, uint8_t*, int);
+template int Sim<FS_PART_T>::launch_dropq(int, const float*, size_t, float*, float*, uint8_t*, int);
 #elif defined(FS_PART_WIDE)
 template int Sim<FS_PART_T>::launch_wide<FS_PART_WIDE>(int, const uint8_t*, const float*, size_t, float*, float*, uint8_t*, int);
 #elif defined(FS_PART_SEG)

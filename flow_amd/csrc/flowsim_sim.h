@@ -78,6 +78,20 @@ struct SimBase {
   bool no_loop_full = false;    // FLOWSIM_NO_LOOP_FULL=1: keep the run-time-flag instantiation of k_rollout_loop (tests)
   bool no_ring_rl = false;      // FLOWSIM_NO_RING_RL=1: keep the generic k_steps for IDM + RL rings (tests)
   bool no_queue = false;        // FLOWSIM_NO_QUEUE=1: keep k_steps_open / k_steps_wide for the open networks (tests)
+  int* d_qflag = nullptr;       // k_drop_queue: bit 0 = a path held more than its 64 lanes (the launch's results are invalid)
+  bool qflag_armed = false;     // a queue-order launch ran since the flag was last read
+  // after a stream synchronisation: did a queue-order launch overflow a path?  (sticky: the handle is unusable then)
+  int check_qflag() {
+    if (!qflag_armed || !d_qflag) return FS_OK;
+    int f = 0;
+    HIP_TRY(hipMemcpy(&f, d_qflag, sizeof(int), hipMemcpyDeviceToHost));
+    if (f != 0)
+      return fail(FS_ERR_UNSUPPORTED, "k_drop_queue: a path of the lane-drop network held more than 64 vehicles (or more than 8 "
+                                      "arrived in one sub-step): the results of this handle are invalid -- create it "
+                                      "with FLOWSIM_NO_QUEUE=1 (slot-order kernels)");
+    qflag_armed = false;
+    return FS_OK;
+  }
   int pair_block = 256;         // threads per block of k_rollout_pair (FLOWSIM_PAIR_BLOCK overrides)
   const char* last_kernel = "";  // family of the step kernel the last launch_steps call chose (fs_last_kernel)
 
@@ -356,6 +370,8 @@ struct Sim : SimBase {
     if ((rc = dev_alloc(&ov.emitted, size_t(R) * FS_MAX_INFLOWS))) return rc;
     if ((rc = dev_alloc(&ov.generated, size_t(R) * FS_MAX_INFLOWS))) return rc;
     if ((rc = dev_alloc(&ov.episode, size_t(R)))) return rc;
+    if ((rc = dev_alloc(&d_qflag, size_t(1)))) return rc;
+    HIP_TRY(hipMemset(d_qflag, 0, sizeof(int)));
     HIP_TRY(hipMemset(ov.episode, 0xFF, size_t(R) * sizeof(int32_t)));     // -1: fs_create's own reset below is not an episode
     HIP_TRY(hipMemset(ov.ctl_seq, 0xFF, RN * sizeof(int32_t)));            // rl_veh starts empty (a reset keeps it, O2)
     HIP_TRY(hipMemset(ov.origin, 0xFF, RN * sizeof(int32_t)));
@@ -400,7 +416,9 @@ struct Sim : SimBase {
       for (int i = N - 1; i >= 0; --i)
         if (veh[i].type == inflows[f].type) first = i;
       // same operations, in T, as oracle/opennet.py _insert
-      tab[size_t(fs::TAB_FL_XDEP) * 64 + f] = T(cfg.route_start[inflows[f].route]) + T(inflows[f].depart_pos);
+      // (the lane-drop network has ONE route table: its "routes" are entry lanes, -1 = a random one)
+      const int rs = (cfg.network == FS_NET_MERGE && inflows[f].route == 1) ? 1 : 0;
+      tab[size_t(fs::TAB_FL_XDEP) * 64 + f] = T(cfg.route_start[rs]) + T(inflows[f].depart_pos);
       tab[size_t(fs::TAB_FL_VDEP) * 64 + f] = T(inflows[f].depart_speed);
       tab[size_t(fs::TAB_FL_MINGAP) * 64 + f] = T(veh[first].sumo_min_gap);
       tab[size_t(fs::TAB_FL_TAU) * 64 + f] = T(veh[first].sumo_tau);
@@ -507,7 +525,7 @@ struct Sim : SimBase {
         qc.in_hi[r][n_int[r]] = hi;
         n_int[r] += 1;
       }
-      qc.veh_len = N > 0 ? float(veh[0].length) : 5.0f;
+      qc.veh_len = N > 0 ? float(veh[0].length) : 5.0f;          // (k_drop_queue checks the lengths itself: dropq_ok)
       for (int i = 0; i < N; ++i)
         if (float(veh[i].length) != qc.veh_len) qc.ok = 0;
     }
@@ -678,6 +696,21 @@ struct Sim : SimBase {
   }
   int launch_queue(int num_steps, const float* actions, size_t act_stride, float* obs, float* rew, uint8_t* done,
                    int obs_every_step);
+  // the lane-drop network in queue order (flowsim_dropq.h): one wave per entry lane, every vehicle on SUMO's model
+  bool dropq_ok(const uint8_t* mask, int num_steps) const {
+    if (!std::is_same<T, float>::value || !open_net || cfg.network != FS_NET_BOTTLENECK || no_queue || force_generic) return false;
+    if (cfg.num_paths != 4 || ov.lc_enabled || ov.track_followers || ov.n_prob > 0 || !open_div_ok) return false;
+    if (!(dv.flags & fs::FLAG_NO_FLOW_CTRL) || dv.integrator != FS_EULER) return false;
+    if (dv.env != FS_ENV_BOTTLENECK_DV && dv.env != FS_ENV_BOTTLENECK) return false;
+    if (mask != nullptr || num_steps < 1 || dv.N > 256 || ov.nseg[0] > 16) return false;
+    for (int i = 0; i < dv.N; ++i)
+      if (float(veh[i].length) != float(veh[0].length) || veh[i].type < 0 || veh[i].type > 7) return false;
+    for (const fs_inflow& f : inflows)
+      if (f.route > 3) return false;
+    return true;
+  }
+  int launch_dropq(int num_steps, const float* actions, size_t act_stride, float* obs, float* rew, uint8_t* done,
+                   int obs_every_step);
 
   // more than 64 slots per replica (lane-drop network): one workgroup of W waves per replica (flowsim_launch.h)
   template <int W>
@@ -774,6 +807,7 @@ struct Sim : SimBase {
       HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(stream));
+    if (int qrc = check_qflag()) return qrc;
     if (field == FS_FIELD_TIME) {
       if (bytes != size_t(dv.R) * sizeof(int32_t)) return fail(FS_ERR_INVALID, "FS_FIELD_TIME: wrong byte count");
       HIP_TRY(hipMemcpy(dst, dv.time, bytes, hipMemcpyDeviceToHost));

@@ -711,10 +711,19 @@ class MergeOracle:
             C = len(self.cells)
             cnt_h, cnt_r = np.zeros((R, C), self.dt_), np.zeros((R, C), self.dt_)
             sp_h, sp_r = np.zeros((R, C), self.dt_), np.zeros((R, C), self.dt_)
+            # spec['cell_sum'] = 'fixed' (float32 twin of k_drop_queue, flow_amd/csrc/flowsim_dropq.h): the speeds of a
+            # cell are added as integers in units of 2^-16 m/s -- exact, so in any order -- and the sum goes back to float
+            # once (a float32 sum of 20 speeds is ~2e-5 m/s off the reference's float64 sum, this ~8e-6 per vehicle)
+            fixed = self.spec.get("cell_sum", "slot") == "fixed" and self.dt_ == np.dtype(np.float32)
+            vi = np.rint(self.v.astype(np.float64) * 65536.0).astype(np.int64) if fixed else None
             for c in range(C):
                 mh = (cell == c) & ~self.is_rl[None, :]
                 mr = (cell == c) & self.is_rl[None, :]
                 cnt_h[:, c], cnt_r[:, c] = mh.sum(axis=1), mr.sum(axis=1)
+                if fixed:
+                    sp_h[:, c] = np.where(mh, vi, 0).sum(axis=1).astype(np.float32) * T(1.0 / 65536.0)
+                    sp_r[:, c] = np.where(mr, vi, 0).sum(axis=1).astype(np.float32) * T(1.0 / 65536.0)
+                    continue
                 for i in range(N):                                         # speeds added up in slot order
                     sp_h[:, c] = np.where(mh[:, i], sp_h[:, c] + self.v[:, i], sp_h[:, c])
                     sp_r[:, c] = np.where(mr[:, i], sp_r[:, c] + self.v[:, i], sp_r[:, c])

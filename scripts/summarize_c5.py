@@ -30,6 +30,8 @@ if leg == "c3" and "c3_figure_eight" in bench:   # scripts/bench_c3.py prints bo
     bench = dict(bench["c3_figure_eight"], po_head=bench.get("c3_figure_eight_po"))
 slots = bench.get("slots", 64)                 # 64 slots per replica: one wave each; k_steps_wide: 2 or 4 waves
 waves = bench["replicas"] * (1 if slots <= 64 else (2 if slots <= 128 else 4))
+if "k_drop_queue" in str(bench.get("kernel", "")):
+    waves = bench["replicas"] * 4                 # one wave per entry lane, whatever the slot count
 substeps = bench.get("env_steps", bench.get("steps", 0)) * bench.get("sims_per_step", 1)
 pattern = "k_steps_wide" if slots > 64 else "k_steps_open"
 _names = [r["Name"] for r in csv.DictReader(open(newest("trace/*/*_kernel_stats.csv")))]
