@@ -32,13 +32,12 @@
 namespace fs {
 
 struct DropRow { float tau, min_gap, max_accel, ts_sumo, sumo_max; int is_rl, type, pad; };   // per label (slot)
-struct DropXL { float x; int lab; };
+struct alignas(16) DropXL { float x; int lab; float v; int pad; };     // a queue entry as the other waves see it
 
 struct DropQLds {
   OpenTabsLds<float> tabs;
   DropRow row[256];
-  DropXL xl[4][64];            // path p's queue, head first: (position, label) after the move
-  float vm[4][64];             // ... speeds
+  DropXL xl[4][64];            // path p's queue, head first: (position, label, speed) after the move
   int n[4], ng1[4], ng2[4];    // vehicles on path p; of them beyond the first / the second join (prefixes of the queue)
   int arr_n[4], arr_lab[4][8]; // arrivals of this sub-step: count and labels per path
   int crash[2][4];
@@ -127,9 +126,13 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
   auto shift_of = [&](T xx) -> int { return (xx >= m1 ? 1 : 0) + (xx >= m2 ? 1 : 0); };
   // the route segments (one table: edges and junction-internal stretches alternate): segment of a coordinate
   const int nseg = o.nseg[0];
+  T sst[15];                                     // the starts of segments 1 .. 15 (3e38 beyond the table): registers
+#pragma unroll
+  for (int q = 1; q < 16; ++q) sst[q - 1] = q < nseg ? o.lane_tab[TAB_SEG_START * 64 + q] : 3.0e38f;
   auto seg_of = [&](T xx) -> int {
     int k = 0;
-    for (int q = 1; q < nseg; ++q) k += (xx >= tb.template t<TAB_SEG_START>(q)) ? 1 : 0;
+#pragma unroll
+    for (int q = 0; q < 15; ++q) k += (xx >= sst[q]) ? 1 : 0;
     return k;
   };
   const unsigned seg_internal = o.seg_internal[0];
@@ -207,20 +210,48 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
   T h = 1000.0f, vl = -1001.0f;
   bool has = false;
   int lead_lab = -1;
-  // the number of vehicles of path q AHEAD of (xi, labi): binary search in its sorted mirror
-  auto count_ahead = [&](int q, int nq, T xi, int labi) -> int {
-    int lo = 0;
+  // the number of vehicles of the three other paths AHEAD of mine: binary searches in their sorted mirrors, the three
+  // side by side (every round is one LDS round trip for all of them).  The searches compare positions only; vehicles AT
+  // my position (rare: ahead iff their slot is lower) are counted afterwards, by the whole wave, when some lane met one
+  auto count_ahead3 = [&](int na_, int nb_, int nc_, int& ca, int& cb_, int& cc) {
+    const int qa = w ^ 1, qb = w ^ 2, qc_ = w ^ 3;
+    int la_ = 0, lb_ = 0, lc_ = 0;
 #pragma unroll
     for (int step = 32; step >= 1; step >>= 1) {
-      const int idx = lo + step - 1;
-      const DropXL e = L.xl[q][idx & 63];
-      const int ahead = int(idx < nq) & (int(e.x > xi) | (int(e.x == xi) & int(e.lab < labi)));   // (bitwise: no branches)
-      lo += ahead ? step : 0;
+      const int ia = la_ + step - 1, ib = lb_ + step - 1, ic = lc_ + step - 1;
+      const T xa = L.xl[qa][ia & 63].x, xb = L.xl[qb][ib & 63].x, xc = L.xl[qc_][ic & 63].x;
+      la_ += (int(ia < na_) & int(xa > x)) ? step : 0;                 // (bitwise: no branches)
+      lb_ += (int(ib < nb_) & int(xb > x)) ? step : 0;
+      lc_ += (int(ic < nc_) & int(xc > x)) ? step : 0;
     }
-    return lo;
+    const DropXL ea = L.xl[qa][la_ & 63], eb = L.xl[qb][lb_ & 63], ec = L.xl[qc_][lc_ & 63];   // the first NOT strictly ahead
+    const bool ta = la_ < na_ && ea.x == x, tb_ = lb_ < nb_ && eb.x == x, tc = lc_ < nc_ && ec.x == x;
+    if (__ballot(ta || tb_ || tc) != 0ull) {
+      auto ties = [&](int q, int nq, int& lo, bool tie) {
+        int k = lo;
+        for (int it = 0; it < 64 && __ballot(tie) != 0ull; ++it) {
+          const DropXL ek = L.xl[q][k & 63];
+          tie = tie && k < nq && ek.x == x;
+          if (tie && ek.lab < lab) lo = k + 1;                         // (equal positions are sorted by slot)
+          k += 1;
+        }
+      };
+      ties(qa, na_, la_, ta);
+      ties(qb, nb_, lb_, tb_);
+      ties(qc_, nc_, lc_, tc);
+    }
+    ca = la_; cb_ = lb_; cc = lc_;
   };
-  auto neighbours = [&](int n0, int n1_, int n2, int n3, int g10, int g11, int g12, int g13, int g20, int g21, int g22, int g23,
-                        bool& crash) {
+  // the queue lengths and join prefixes of the three OTHER paths (t = 1: my partner at the first join, t = 2, 3: the other
+  // pair), as their owners published them
+  int nT1 = 0, nT2 = 0, nT3 = 0, g1T1 = 0, g2T2 = 0, g2T3 = 0;
+  auto read_counts = [&]() {
+    nT1 = __builtin_amdgcn_readfirstlane(L.n[w ^ 1]); nT2 = __builtin_amdgcn_readfirstlane(L.n[w ^ 2]);
+    nT3 = __builtin_amdgcn_readfirstlane(L.n[w ^ 3]);
+    g1T1 = __builtin_amdgcn_readfirstlane(L.ng1[w ^ 1]);
+    g2T2 = __builtin_amdgcn_readfirstlane(L.ng2[w ^ 2]); g2T3 = __builtin_amdgcn_readfirstlane(L.ng2[w ^ 3]);
+  };
+  auto neighbours = [&](bool& crash) {
     const bool alive = l < n;
     const int la = shift_of(x + zip);
     const T x_up = dpp<DPP_WAVE_SHR1>(x), v_up = dpp<DPP_WAVE_SHR1>(v);
@@ -229,23 +260,22 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
     int bl = -1, bp = w;
     bool any = false;
     if (alive && l > 0) { bx = x_up; bv = v_up; bl = lab_up; any = true; }
+    int cnt1, cnt2, cnt3;
+    count_ahead3(nT1, nT2, nT3, cnt1, cnt2, cnt3);
 #pragma unroll
     for (int t = 1; t < P; ++t) {
       const int q = w ^ t;
-      const int nq = q == 0 ? n0 : (q == 1 ? n1_ : (q == 2 ? n2 : n3));
-      const int g1q = q == 0 ? g10 : (q == 1 ? g11 : (q == 2 ? g12 : g13));
-      const int g2q = q == 0 ? g20 : (q == 1 ? g21 : (q == 2 ? g22 : g23));
-      const int cnt_q = count_ahead(q, nq, x, lab);
+      const int gq = t == 1 ? g1T1 : (t == 2 ? g2T2 : g2T3);
+      const int cnt_q = t == 1 ? cnt1 : (t == 2 ? cnt2 : cnt3);
       // the partner path (t = 1): every vehicle ahead once I look across the first join (la >= 1), else its rearmost
       // vehicle beyond that join; the other pair: every vehicle ahead once I look across the second join, else its
       // rearmost vehicle beyond it
       const bool search = t == 1 ? la >= 1 : la == 2;
-      const int ci = search ? cnt_q - 1 : (t == 1 ? g1q : g2q) - 1;
+      const int ci = (search ? cnt_q : gq) - 1;
       const DropXL e = L.xl[q][ci < 0 ? 0 : ci];
-      const T ev = L.vm[q][ci < 0 ? 0 : ci];
       const bool take = (int(alive) & int(ci >= 0) & (int(e.x < bx) | (int(e.x == bx) & int(e.lab > bl)))) != 0;   // the nearest; equal x: the higher slot
       bx = take ? e.x : bx;
-      bv = take ? ev : bv;
+      bv = take ? e.v : bv;
       bl = take ? e.lab : bl;
       bp = take ? q : bp;
       any = any || take;
@@ -258,34 +288,62 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
     const bool same_lane = any && ((w >> sh_l) == (bp >> sh_l));            // M8: a collision needs one physical lane
     crash = __ballot(alive && same_lane && (h < s.crash_gap)) != 0ull;
   };
-
-  // the queue lengths and join prefixes of all paths, as the owners published them
-  int n0, n1_, n2, n3, g10, g11, g12, g13, g20, g21, g22, g23;
-  auto read_counts = [&]() {
-    n0 = __builtin_amdgcn_readfirstlane(L.n[0]); n1_ = __builtin_amdgcn_readfirstlane(L.n[1]);
-    n2 = __builtin_amdgcn_readfirstlane(L.n[2]); n3 = __builtin_amdgcn_readfirstlane(L.n[3]);
-    g10 = __builtin_amdgcn_readfirstlane(L.ng1[0]); g11 = __builtin_amdgcn_readfirstlane(L.ng1[1]);
-    g12 = __builtin_amdgcn_readfirstlane(L.ng1[2]); g13 = __builtin_amdgcn_readfirstlane(L.ng1[3]);
-    g20 = __builtin_amdgcn_readfirstlane(L.ng2[0]); g21 = __builtin_amdgcn_readfirstlane(L.ng2[1]);
-    g22 = __builtin_amdgcn_readfirstlane(L.ng2[2]); g23 = __builtin_amdgcn_readfirstlane(L.ng2[3]);
-  };
   auto publish = [&]() {
     const bool alive = l < n;
     DropXL e;
-    e.x = x; e.lab = lab;
+    e.x = x; e.lab = lab; e.v = v; e.pad = 0;
     L.xl[w][l] = e;
-    L.vm[w][l] = v;
     const int c1 = __popcll(__ballot(alive && x >= m1)), c2 = __popcll(__ballot(alive && x >= m2));
     if (l == 0) { L.n[w] = n; L.ng1[w] = c1; L.ng2[w] = c2; }
   };
+  // O6: the lane-segments of my vehicle at its position: the one it is observed in (bottleneck.py:868-924) and the one
+  // whose action shifts its maxSpeed in the next sub-step (:926-969) -- one lookup serves both
+  int acell = -1;
+  auto cells = [&](bool want_obs, int& ocell) {
+    const bool alive = l < n;
+    const int seg_k = seg_of(x);
+    const bool eligible = alive && !((seg_internal >> seg_k) & 1u);
+    const int my_lane = w >> shift_of(x);
+    // cell_of<0> / cell_of<1> (flowsim_open.h) with their table rows read together: the groups of my edge (at most three
+    // observation groups, two action groups: Sim::dropq_ok), each (start, lo, hi, first cell | lanes | first lane | last)
+    const int range = L.tabs.ctab_i[2][seg_k & 63];
+    const int og0 = range & 0xff, ocnt = (range >> 8) & 0xff, ag0 = (range >> 16) & 0xff, acnt = (range >> 24) & 0xff;
+    const CellRow<T> o0 = L.tabs.cpack[0][(og0) & 63], o1 = L.tabs.cpack[0][(og0 + (1 < ocnt ? 1 : 0)) & 63],
+                     o2 = L.tabs.cpack[0][(og0 + (2 < ocnt ? 2 : 0)) & 63];
+    const CellRow<T> a0 = L.tabs.cpack[1][(ag0) & 63], a1 = L.tabs.cpack[1][(ag0 + (1 < acnt ? 1 : 0)) & 63];
+    auto hit = [&](const CellRow<T>& row, bool valid, bool last_rule, int cur) -> int {
+      const T pos = x - row.start;
+      int inside = int(pos > row.lo) & int(pos <= row.hi);
+      if (last_rule) inside |= int((row.meta >> 24) != 0) & int(pos == 0.0f);    // searchsorted(..) - 1 == -1: last segment
+      const int rel = my_lane - ((row.meta >> 16) & 0xff);
+      const int ok = int(eligible) & int(valid) & inside & int(rel >= 0) & int(rel < ((row.meta >> 8) & 0xff)) & int(cur < 0);
+      return ok ? (row.meta & 0xff) + rel : cur;
+    };
+    int ac = -1;
+    ac = hit(a0, 0 < acnt, false, ac);
+    ac = hit(a1, 1 < acnt, false, ac);
+    acell = ac;
+    int oc = -1;
+    if (want_obs) {
+      oc = hit(o0, 0 < ocnt, true, oc);
+      oc = hit(o1, 1 < ocnt, true, oc);
+      oc = hit(o2, 2 < ocnt, true, oc);
+    }
+    ocell = oc;
+  };
 
-  // get_outflow_rate over the last `window` sub-steps (vehicle/traci.py:500-505); the history is one count per lane
-  auto outflow = [&](int window) -> T {
+  // get_outflow_rate over the last `window` sub-steps (vehicle/traci.py:500-505): the arrivals inside the observation's /
+  // the reward's window are kept as running sums (this sub-step's arrivals enter, the sub-step that leaves the window goes)
+  auto window_sum = [&](int window) -> int {
     const int nn = tcount < window ? tcount : window;
     const int ago = (((tcount - 1 - l) % 20) + 20) % 20;
     const T mine = (l < 20 && ago < nn) ? T(hist_l) : 0.0f;
-    const T total = seg_sum<64>(mine);                     // small integers: exact in any order
-    const T rate = (3600.0f * total) / (T(nn > 0 ? nn : 1) * dt);
+    return __builtin_amdgcn_readfirstlane(int(seg_sum<64>(mine)));   // small integers: exact in any order
+  };
+  int out_obs = window_sum(o.obs_window), out_rew = window_sum(o.rew_window);
+  auto outflow = [&](int window, int total_i) -> T {
+    const int nn = tcount < window ? tcount : window;
+    const T rate = (3600.0f * T(total_i)) / (T(nn > 0 ? nn : 1) * dt);
     return nn > 0 ? rate : 0.0f;
   };
 
@@ -319,7 +377,9 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
   read_counts();
   {
     bool c_;
-    neighbours(n0, n1_, n2, n3, g10, g11, g12, g13, g20, g21, g22, g23, c_);
+    neighbours(c_);
+    int oc_;
+    if (DV) cells(false, oc_);
   }
   __syncthreads();
 
@@ -334,10 +394,6 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
       bool alive = l < n;
       // ---- O6: BottleneckDesiredVelocityEnv._apply_rl_actions (bottleneck.py:926-969) -----------------------------
       if (DV && actions != nullptr) {
-        const int seg_k = seg_of(x);
-        const bool internal = (seg_internal >> seg_k) & 1u;
-        const int my_lane = w >> shift_of(x);
-        const int acell = cell_of<1>(tb, o.act_span, x, seg_k, my_lane, alive && !internal);
         const float a_cell = L.act[ab][acell >= 0 ? acell : 0];
         T a = acell >= 0 ? a_cell : 0.0f;
         if (s.clip_actions) a = tmin(tmax(a, s.act_lo), s.act_hi);
@@ -406,6 +462,11 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
         n_arr = na_all;
         n_dep = 0;
         tot_arr += na_all;
+        {
+          const int eo = tcount - 1 - o.obs_window, er = tcount - 1 - o.rew_window;      // the sub-steps that leave the windows
+          out_obs += na_all - (eo >= 0 ? read_lane_i(hist_l, eo % 20) : 0);
+          out_rew += na_all - (er >= 0 ? read_lane_i(hist_l, er % 20) : 0);
+        }
         if (l == (tcount - 1) % 20) hist_l = na_all;
         // inflows whose next vehicle is due (lane f of every wave evaluates inflow f)
         unsigned fm = unsigned(__ballot(sim_steps - 1 >= my_due_n)) & 0xffu;
@@ -443,12 +504,12 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
 #pragma unroll
           for (int q = 0; q < P; ++q) {
             const int t = q ^ route_f;
-            const int nq = q == 0 ? n0 : (q == 1 ? n1_ : (q == 2 ? n2 : n3));
             const int icq = q == 0 ? ic0 : (q == 1 ? ic1 : (q == 2 ? ic2 : ic3));
             int ci;
-            if (t == 0) ci = nq + icq - 1;
-            else if (t == 1) ci = (q == 0 ? g10 : (q == 1 ? g11 : (q == 2 ? g12 : g13))) - 1;
-            else ci = (q == 0 ? g20 : (q == 1 ? g21 : (q == 2 ? g22 : g23))) - 1;
+            if (t == 0) ci = L.n[q] + icq - 1;
+            else if (t == 1) ci = L.ng1[q] - 1;
+            else ci = L.ng2[q] - 1;
+            ci = __builtin_amdgcn_readfirstlane(ci);
             T cx, cv;
             int cl;
             if (t == 0 && icq > 0) {                       // the vehicle inserted a moment ago on this path
@@ -457,7 +518,7 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
               cl = 255;                                     // (its position is the insertion point: no tie with a vehicle ahead)
             } else {
               const DropXL e = L.xl[q][ci < 0 ? 0 : ci];
-              cx = e.x; cl = e.lab; cv = L.vm[q][ci < 0 ? 0 : ci];
+              cx = e.x; cl = e.lab; cv = e.v;
             }
             const bool take = ci >= 0 && (cx < xm || (cx == xm && cl < lm));
             xm = take ? cx : xm; vm_ = take ? cv : vm_; lm = take ? cl : lm;
@@ -466,7 +527,8 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
           const T gap = (xm - LEN) - x_dep;
           const T dq = div_core(v_dep * (v_dep - vm_), two_sqrt);
           const T need = min_gap_f + tmax(0.0f, v_dep * tau_f + dq);
-          const int n_own = (route_f == 0 ? n0 + ic0 : (route_f == 1 ? n1_ + ic1 : (route_f == 2 ? n2 + ic2 : n3 + ic3)));
+          const int n_own = __builtin_amdgcn_readfirstlane(L.n[route_f & 3]) +
+                            (route_f == 0 ? ic0 : (route_f == 1 ? ic1 : (route_f == 2 ? ic2 : ic3)));
           if (slot >= 0 && n_own >= 64 && (!has_lead || gap >= need)) atomicOr(qflag, 1);   // the path is full: refused, flagged
           const bool ok = __builtin_amdgcn_readfirstlane(int((slot >= 0) && n_own < 64 && (!has_lead || gap >= need))) != 0;
           if (ok) {
@@ -502,17 +564,14 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
       }
       // ---- O1: the new snapshot, the collision check ---------------------------------------------------------------
       bool c = false;
-      neighbours(n0, n1_, n2, n3, g10, g11, g12, g13, g20, g21, g22, g23, c);
+      neighbours(c);
       const int cb = (step * s.sims_per_step + sub) & 1;
       if (c && l == 0) L.crash[cb][w] = 1;
       // ---- O6 get_state (bottleneck.py:868-924): every vehicle enters itself into its cell ---------------------------
       const bool last_sub = sub == s.sims_per_step - 1;
-      if (DV && emit && last_sub) {
-        alive = l < n;
-        const int seg_k = seg_of(x);
-        const bool internal = (seg_internal >> seg_k) & 1u;
-        const int my_lane = w >> shift_of(x);
-        const int ocell = cell_of<0>(tb, o.obs_span, x, seg_k, my_lane, alive && !internal);
+      if (DV && (actions != nullptr || (emit && last_sub))) {
+        int ocell;
+        cells(emit && last_sub, ocell);
         if (ocell >= 0) {
           const int vi = int(rintf(v * 65536.0f));
           atomicAdd(&L.acc[is_rl ? 1 : 0][ocell], 1);
@@ -543,12 +602,12 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
           orow[2 * C + tid] = mean_h;
           orow[3 * C + tid] = mean_r;
         }
-        const T of = div_out(outflow(o.obs_window), 2000.0);
+        const T of = div_out(outflow(o.obs_window, out_obs), 2000.0);
         if (tid == 64) orow[4 * C] = of;
       } else if (tid == 0) {
         orow[0] = 1.0f;                                    // bottleneck.py:481-483
       }
-      const T reward = outflow(o.rew_window) / o.out_norm;     // bottleneck.py:474-478, 971-981
+      const T reward = outflow(o.rew_window, out_rew) / o.out_norm;     // bottleneck.py:474-478, 971-981
       if (tid == 128) {
         *rrow = reward;
         *drow = done_flag(tcount >= s.step_limit, crashed);

@@ -702,7 +702,7 @@ struct Sim : SimBase {
     if (cfg.num_paths != 4 || ov.lc_enabled || ov.track_followers || ov.n_prob > 0 || !open_div_ok) return false;
     if (!(dv.flags & fs::FLAG_NO_FLOW_CTRL) || dv.integrator != FS_EULER) return false;
     if (dv.env != FS_ENV_BOTTLENECK_DV && dv.env != FS_ENV_BOTTLENECK) return false;
-    if (mask != nullptr || num_steps < 1 || dv.N > 256 || ov.nseg[0] > 16) return false;
+    if (mask != nullptr || num_steps < 1 || dv.N > 256 || ov.nseg[0] > 16 || ov.obs_span > 3 || ov.act_span > 2) return false;
     for (int i = 0; i < dv.N; ++i)
       if (float(veh[i].length) != float(veh[0].length) || veh[i].type < 0 || veh[i].type > 7) return false;
     for (const fs_inflow& f : inflows)
