@@ -219,18 +219,27 @@ def c5_leg(device, R=1024, env_steps=600, precision="f32"):
     dt = time.perf_counter() - t0
     cnt = vec.sim.get_state(L.FS_FIELD_COUNTERS)
     route = vec.sim.get_state(L.FS_FIELD_ROUTE)
+    sp, al = vec.sim.vel, route >= 0
     res = {"kernel": vec.sim.last_kernel, "value": R * K * 5 / dt, "unit": "env-steps/s (simulation sub-steps)", "env_steps": K, "sims_per_step": 5,
            "replicas": R, "gym_steps_per_s": R * K / dt, "obs_dim": vec.obs_dim, "state": precision,
            "vehicles_in_network_mean": float((route >= 0).sum(axis=1).mean()),
            "departed_mean": float(cnt[:, 6].mean()), "arrived_mean": float(cnt[:, 5].mean()),
+           # the replicas differ by their acceleration-noise streams only (the inflow schedule is deterministic)
+           "spread_over_replicas": {
+               "vehicles_in_network": [int((route >= 0).sum(axis=1).min()), int((route >= 0).sum(axis=1).max())],
+               "departed": [int(cnt[:, 6].min()), int(cnt[:, 6].max())], "arrived": [int(cnt[:, 5].min()), int(cnt[:, 5].max())],
+               "mean_speed_std_mps": float(np.std([sp[r][al[r]].mean() for r in range(min(R, 256))])),
+               "episode_return_std": float(out[1].sum(dim=0).std().item())},
            "workload": "C5: MergeNetwork pre_merge 500 m, inflows 1800 + 200 RL + 100 veh/h, 64 slots, "
-                       "MultiAgentMergePOEnv head, sim_step 0.2 x 5 sub-steps, one 600-step episode; k_steps_open"}
+                       "MultiAgentMergePOEnv head, sim_step 0.2 x 5 sub-steps, one 600-step episode"}
     vec.close()
     return res
 
 
-def c4_flow_params(slots=256, precision="f32"):
-    """The flow_params of BASELINE configs[3] (see c4_leg)."""
+def c4_flow_params(slots=256, precision="f32", lane_change_mode=0):
+    """The flow_params of BASELINE configs[3] (see c4_leg).  ``lane_change_mode``: 0 as the reference's experiment ships
+    (examples/exp_configs/rl/singleagent/singleagent_bottleneck.py:36-50: nobody changes lane), 1621 as flow/benchmarks/
+    bottleneck1.py (SUMO changes lanes: the simplified model M11 here)."""
     from flow_amd.controllers import ContinuousRouter, RLController, SimLaneChangeController
     from flow_amd.core.params import (EnvParams, InFlows, InitialConfig, NetParams, SumoCarFollowingParams,
                                       SumoLaneChangeParams, SumoParams, VehicleParams)
@@ -240,7 +249,7 @@ def c4_flow_params(slots=256, precision="f32"):
     veh.add(veh_id="human", lane_change_controller=(SimLaneChangeController, {}),
             routing_controller=(ContinuousRouter, {}),
             car_following_params=SumoCarFollowingParams(speed_mode="all_checks"),
-            lane_change_params=SumoLaneChangeParams(lane_change_mode=0), num_vehicles=1)
+            lane_change_params=SumoLaneChangeParams(lane_change_mode=lane_change_mode), num_vehicles=1)
     veh.add(veh_id="followerstopper", acceleration_controller=(RLController, {}),
             lane_change_controller=(SimLaneChangeController, {}), routing_controller=(ContinuousRouter, {}),
             car_following_params=SumoCarFollowingParams(speed_mode=9),
@@ -263,7 +272,7 @@ def c4_flow_params(slots=256, precision="f32"):
     return fp
 
 
-def c4_leg(device, R=128, env_steps=1000, slots=256, precision="f32"):
+def c4_leg(device, R=128, env_steps=1000, slots=256, precision="f32", lane_change_mode=0):
     """BASELINE configs[3] (informational, not the headline): BottleneckNetwork scaling 1 (4 -> 2 -> 1 lanes at two
     zipper junctions), inflow 2300 veh/h (10 % RL) with random entry lanes, all vehicles on the SUMO car-following
     model, BottleneckDesiredVelocityEnv head (141 observations, 20 actions), sim_step 0.5, warm-up 40 + horizon 1000
@@ -271,7 +280,7 @@ def c4_leg(device, R=128, env_steps=1000, slots=256, precision="f32"):
     import torch
     from flow_amd import _lib as L
     from flow_amd.envs import VecFlowEnv
-    fp = c4_flow_params(slots, precision)
+    fp = c4_flow_params(slots, precision, lane_change_mode)
     vec = VecFlowEnv(fp, num_replicas=R, device=device.index)
     K = env_steps
     gen = torch.Generator(device=device).manual_seed(3)
@@ -294,34 +303,75 @@ def c4_leg(device, R=128, env_steps=1000, slots=256, precision="f32"):
            "departed_mean": float(cnt[:, 6].mean()), "arrived_mean": float(cnt[:, 5].mean()),
            "dropped_at_insertion_mean": float(cnt[:, 7].mean()),
            "outflow_veh_per_hour_mean": float(out[1][-200:].mean().item() * 2000.0),
-           "slots": slots,
+           "slots": slots, "lane_change_mode": lane_change_mode,
            "workload": "C4: BottleneckNetwork 4->2->1 lanes, inflow 2300 veh/h (10 %% RL, random lanes), %d slots, "
                        "BottleneckDesiredVelocityEnv head (141 obs / 20 actions), sim_step 0.5, one 1000-step episode "
-                       "after 40 warm-up steps, random actions; %s" %
-                       (slots, "k_steps_wide<., %d> (one workgroup per replica)" % ((slots + 63) // 64 if slots > 128 else 2)
-                        if slots > 64 else "k_steps_open<.,64,4>")}
+                       "after 40 warm-up steps, random actions, lane_change_mode %d" % (slots, lane_change_mode)}
     vec.close()
     return res
 
 
-def cpu_baseline(spec_fn, seconds=12.0):
-    """Oracle C port (oracle/csim) on the host cores, bounded sample of the same workload."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def sumo_probe():
+    """is the reference's own CPU path (SUMO + TraCI) runnable on this box?"""
+    import importlib.util
+    import shutil
+    have = {"sumo": shutil.which("sumo"), "netconvert": shutil.which("netconvert"),
+            "traci": importlib.util.find_spec("traci") is not None}
+    if have["sumo"] and have["netconvert"] and have["traci"]:
+        return "SUMO present (%s) -- the reference path is not driven by this bench (no harness ships with the build)" % have["sumo"]
+    missing = [k for k, v in have.items() if not v]
+    return "SUMO unavailable -- reference CPU path not timed (missing: %s)" % ", ".join(missing)
+
+
+def _time_c_port(spec_fn, threads, seconds):
     from oracle import cbuild
-    cores = host_cores()
     R = 4096
-    spec = spec_fn(R)
-    sim = cbuild.CRingIDM(spec, np.float32, threads=cores)
+    sim = cbuild.CRingIDM(spec_fn(R), np.float32, threads=threads)
     sim.rollout(20, obs_every_step=True)               # warm-up
     chunk, done_steps, t0 = 100, 0, time.perf_counter()
-    while time.perf_counter() - t0 < seconds:          # ~10-30 s of CPU work; episodes of 1500 steps
+    while time.perf_counter() - t0 < seconds:          # episodes of 1500 steps
         if done_steps % 1500 == 0:
             sim.reset()
         sim.rollout(chunk, obs_every_step=True)
         done_steps += chunk
     dt = time.perf_counter() - t0
-    return {"value": R * done_steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+    return R * done_steps / dt, done_steps, dt
+
+
+def cpu_baseline(spec_fn, seconds=7.0):
+    """BASELINE.md section 3 on the host cores, bounded samples of the same workload: (1) the SUMO probe; (2) the oracle's
+    C port (oracle/csim: the build's CPU restatement, NOT SUMO) on all cores -- `value` -- and on one thread; (3) the
+    float64 numpy oracle on C1 (1 env x 1500 steps: the reference's arithmetic type and its per-env rate definition,
+    core/experiment.py:136-149, 178-179)."""
+    from oracle import refsim as S
+    cores = host_cores()
+    v_all, steps_all, dt_all = _time_c_port(spec_fn, cores, seconds)
+    v_one, steps_one, dt_one = _time_c_port(spec_fn, 1, min(seconds, 5.0))
+    spec1 = spec_fn(1)
+    ora = S.RingOracle(spec1, np.float64)
+    ora.reset()
+    t0 = time.perf_counter()
+    for _ in range(1500):
+        ora.step(None)
+    dt_np = time.perf_counter() - t0
+    return {"value": v_all, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": "oracle/csim C port (float32, OpenMP over replicas, obs written every step), "
-                      "%d replicas x 22 vehicles x %d steps in %.1f s" % (R, done_steps, dt)}
+                      "4096 replicas x 22 vehicles x %d steps in %.1f s" % (steps_all, dt_all),
+            "single_thread": {"value": v_one, "cores": 1,
+                              "sample": "the same port on one thread, 4096 x 22 x %d steps in %.1f s" % (steps_one, dt_one)},
+            "numpy_float64_c1": {"value": 1500.0 / dt_np, "cores": 1,
+                                 "sample": "oracle/refsim.py RingOracle float64, C1 (1 env x 22 vehicles x 1500 steps) in %.2f s" % dt_np},
+            "sumo": sumo_probe(), "nproc": os.cpu_count(), "cpu_model": cpu_model()}
 
 
 def ring_defaults_leg(device, R=4096, K=1500):
@@ -516,8 +566,8 @@ def valu_issue(precision, R, K, avg_s):
             "frac": ach / peak_eff if peak_eff else None, "source": src}
 
 
-def rollout_1500_leg(device, precision, R, launches=6, check_parity=True):
-    """>= 5 full 1500-step fragments of C2 in one process, per-launch HIP events on the kernel's
+def rollout_1500_leg(device, precision, R, launches=50, check_parity=True):
+    """50 full 1500-step fragments of C2 in one process (launch times: mean, median, p10 / p90), per-launch HIP events on the kernel's
     stream, roofline of that kernel, and the deviation of the final state from the float64 oracle (oracle/csim,
     the reference's arithmetic) after one 1500-step episode: the parity figure of this dtype."""
     import torch
@@ -564,6 +614,8 @@ def rollout_1500_leg(device, precision, R, launches=6, check_parity=True):
     return {"value": R * K / avg_s, "unit": "env-steps/s (kernel time of a 1500-step launch)",
             "value_wall": R * K * launches / wall, "dtype": precision, "launches_timed": launches,
             "avg_launch_ms": avg_s * 1e3, "min_launch_ms": float(min(ms)), "max_launch_ms": float(max(ms)),
+            "median_launch_ms": float(np.median(ms)), "p10_launch_ms": float(np.percentile(ms, 10)),
+            "p90_launch_ms": float(np.percentile(ms, 90)), "value_median": R * K / (float(np.median(ms)) * 1e-3),
             "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[precision], "achieved": nbytes / avg_s / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / avg_s / 1e9 / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": src, "bytes_per_launch": nbytes,
@@ -609,6 +661,40 @@ def step_graph_leg(device, precision, R, K=100, replays=40):
     return {"value": R * K * replays / dt, "unit": "env-steps/s", "steps_per_graph": K, "replays": replays,
             "us_per_step": dt / (K * replays) * 1e6, "dtype": precision,
             "note": "K fs_step_dev launches per HIP-graph replay (one launch per env step, no host in the loop)"}
+
+
+def generic_kernel_leg(device, R=4096, K=1500):
+    """The cliff's height: C2 forced onto the generic k_steps (what a ring with a fail-safe, an odd vehicle count,
+    sort_vehicles, track_aux or a non-IDM controller steps on: FLOWSIM_FORCE_GENERIC=1), kernel time of a 1500-step launch."""
+    import torch
+    from flow_amd.sim import FlowSim
+    os.environ["FLOWSIM_FORCE_GENERIC"] = "1"
+    try:
+        sim = FlowSim(c2_spec(R, seed=1000), precision="f32", device=device.index)
+    finally:
+        os.environ.pop("FLOWSIM_FORCE_GENERIC")
+    sim.set_stream(torch.cuda.current_stream(device).cuda_stream)
+    obs = torch.empty((K, R, 44), dtype=torch.float32, device=device)
+    rew = torch.empty((K, R), dtype=torch.float32, device=device)
+    done = torch.empty((K, R), dtype=torch.uint8, device=device)
+    obs0 = torch.empty((R, 44), dtype=torch.float32, device=device)
+    sim.reset_dev(obs0)
+    sim.rollout_dev(K, obs, rew, done)
+    torch.cuda.synchronize(device)
+    ms = []
+    for _ in range(3):
+        sim.reset_dev(obs0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        sim.rollout_dev(K, obs, rew, done)
+        e1.record()
+        torch.cuda.synchronize(device)
+        ms.append(e0.elapsed_time(e1))
+    kernel = sim.last_kernel
+    sim.close()
+    t = float(np.median(ms)) * 1e-3
+    return {"value": R * K / t, "unit": "env-steps/s (kernel time of a 1500-step launch)", "kernel": kernel, "dtype": "f32",
+            "median_launch_ms": t * 1e3, "note": "C2 on the generic step kernel (FLOWSIM_FORCE_GENERIC=1)"}
 
 
 def spawn_ranks(args):
@@ -812,9 +898,13 @@ def main():
         out["c3_figure_eight"] = c3_leg(device)
         out["c3_figure_eight_po"] = c3_leg(device, po=True)
         out["c3_figure_eight_mixed"] = c3_leg(device, precision="mixed")      # float64 state, float32 car-following models
+        out["generic_kernel"] = generic_kernel_leg(device)
         out["c4_bottleneck"] = c4_leg(device)
         out["c4_bottleneck_f64"] = c4_leg(device, precision="f64")            # the reference's arithmetic type
+        out["c4_bottleneck_lane_change"] = c4_leg(device, lane_change_mode=1621)   # flow/benchmarks/bottleneck1: M11 on
+        out["c4_fullchip"] = c4_leg(device, R=1024)                           # throughput next to the latency of 128 replicas
         out["c5_merge"] = c5_leg(device)
+        out["c5_fullchip"] = c5_leg(device, R=4096)
         out["c5_merge_fp16_state"] = c5_leg(device, precision="f16s")
         out["c5_merge_mixed"] = c5_leg(device, precision="mixed")             # float64 kernel, float32 car-following models
         out["c5_merge_f64"] = c5_leg(device, precision="f64")                 # the reference's arithmetic type

@@ -11,6 +11,13 @@ from oracle import refsim as S
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def slot_order_kernels(monkeypatch):
+    """This module holds the SLOT-order open-network kernels (k_steps_open / k_steps_wide) to the oracle; the queue-order
+    kernels that take the same configurations by default have tests of their own (test_queue_gpu.py, test_dropq_gpu.py)."""
+    monkeypatch.setenv("FLOWSIM_NO_QUEUE", "1")
+
+
 def make_env(flow_params):
     from flow_amd.utils.registry import make_create_env
     return make_create_env(flow_params)[0]()

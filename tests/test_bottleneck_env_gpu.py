@@ -9,6 +9,13 @@ from oracle import opennet as O
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def slot_order_kernels(monkeypatch):
+    """This module holds the SLOT-order open-network kernels (k_steps_open / k_steps_wide) to the oracle; the queue-order
+    kernels that take the same configurations by default have tests of their own (test_queue_gpu.py, test_dropq_gpu.py)."""
+    monkeypatch.setenv("FLOWSIM_NO_QUEUE", "1")
+
+
 def c4_flow_params(horizon=1000, warmup_steps=40, reset_inflow=False, flow_rate=2300, **sim_kw):
     """examples/exp_configs/rl/singleagent/singleagent_bottleneck.py:28-151."""
     from flow_amd.controllers import ContinuousRouter, RLController, SimLaneChangeController

@@ -1,5 +1,5 @@
 """BASELINE configs[3] (C4) and configs[4] (C5) exactly as bench.py runs them -- same flow_params, same replica count,
-whole episode in one launch -- with SAMPLED replicas checked bit for bit against the numpy oracle (which is far too slow for
+whole episode in one launch (on the queue-order kernels k_drop_queue / k_merge_queue) -- with SAMPLED replicas checked bit for bit against the numpy oracle (which is far too slow for
 all of them): observation, reward and done of every step, and the state at the end.  The oracle runs the sampled replicas
 alone; the Philox streams of the inflows (random entry lanes) are keyed by the global replica index, which the oracle takes
 from `replica_ids`."""
@@ -30,7 +30,7 @@ class Rows:
     headway = property(lambda s: s.sim.headway[s.rows])
 
 
-def sampled_parity(fp, R, K, rows, act_seed):
+def sampled_parity(fp, R, K, rows, act_seed, **oracle_kw):
     import torch
     from flow_amd.envs import VecFlowEnv
     dev = torch.device("cuda:0")
@@ -45,7 +45,7 @@ def sampled_parity(fp, R, K, rows, act_seed):
     vec.sim.rollout_dev(K, *out, actions=tape if A else None)
     torch.cuda.synchronize()
     kernel = vec.sim.last_kernel
-    sub = dict(spec, num_replicas=len(rows), replica_ids=np.asarray(rows) + int(spec.get("replica_offset", 0)))
+    sub = dict(spec, num_replicas=len(rows), replica_ids=np.asarray(rows) + int(spec.get("replica_offset", 0)), **oracle_kw)
     for key in ("init_alive", "init_pos", "init_vel", "init_route"):
         sub[key] = np.asarray(spec[key])[rows]
     ora = O.MergeOracle(sub, np.float32)
@@ -64,8 +64,9 @@ def sampled_parity(fp, R, K, rows, act_seed):
 
 def test_c4_full_size_sampled_replicas_equal_the_oracle():
     import bench
-    kernel, ora = sampled_parity(bench.c4_flow_params(256), R=128, K=1000, rows=[0, 37, 90, 127], act_seed=3)
-    assert "k_steps_wide" in kernel
+    # (k_drop_queue adds the speeds of a lane-segment as exact integers of 2^-16 m/s: the oracle's cell_sum = 'fixed')
+    kernel, ora = sampled_parity(bench.c4_flow_params(256), R=128, K=1000, rows=[0, 37, 90, 127], act_seed=3, cell_sum="fixed")
+    assert kernel == "k_drop_queue"
     assert ora.total_departed.min() > 250 and ora.total_arrived.min() > 150      # the whole episode was traffic
 
 
@@ -74,7 +75,7 @@ def test_c5_full_size_sampled_replicas_equal_the_oracle():
     (tolerance test: test_merge_po_noise_short_horizon_tolerance); everything else is the bench's configuration."""
     import bench
     kernel, ora = sampled_parity(bench.c5_flow_params("f32", noise=0.0), R=1024, K=600, rows=[0, 301, 640, 1023], act_seed=4)
-    assert "k_steps_open" in kernel
+    assert kernel == "k_merge_queue"
     assert ora.total_departed.min() > 250 and ora.total_arrived.min() > 100
 
 

@@ -13,6 +13,13 @@ from test_open_gpu import bottleneck_actions, compare_state, compare_vmax, make,
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def slot_order_kernels(monkeypatch):
+    """This module holds the SLOT-order open-network kernels (k_steps_open / k_steps_wide) to the oracle; the queue-order
+    kernels that take the same configurations by default have tests of their own (test_queue_gpu.py, test_dropq_gpu.py)."""
+    monkeypatch.setenv("FLOWSIM_NO_QUEUE", "1")
+
+
 def test_wide_desired_velocity_f32_bit_exact_192_slots():
     """C4's demand: the queue upstream of the lane drops outgrows one wave (more than 64 vehicles in the network)."""
     from helpers import bottleneck_spec
