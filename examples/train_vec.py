@@ -2,11 +2,19 @@
 examples/train.py:110-212, where RLlib rollout workers each drive one SUMO process).
 
     python examples/train_vec.py --replicas 1024 --iterations 20
+    python examples/train_vec.py --replicas 4096 --gpus 8        # data-parallel: one process per GPU (RCCL)
 
 Environment: the reference's single-agent ring experiment (examples/exp_configs/rl/singleagent/singleagent_ring.py:
 WaveAttenuationPOEnv, 21 IDM humans + 1 RL vehicle on a 230..270 m ring).  A rollout fragment of K steps -- policy
 forward, action sampling, Env.step of every replica, reset of finished episodes -- is ONE replay of a captured HIP
 graph (VecFlowEnv.capture); observations, actions, rewards and the PPO update all stay in HBM.
+
+--gpus N (the reference's num_workers / ray.init(num_cpus), examples/train.py:149,195): N child processes, one per GPU,
+started BEFORE anything touches a GPU; rank r steps the replica block shard_range(R, r, N) (VecFlowEnv(replica_offset=):
+the Philox streams are keyed by the global replica id, so the trajectories do not depend on N); the policy is replicated
+and every PPO step all-reduces the flat gradient and the advantage statistics over RCCL (flow_amd/dist.py).  The update
+is written over SHARDS (ppo_update): a rank holds one, and a single process holding all of them -- gradients accumulated
+shard by shard -- makes the same update, which is what tests/test_train_dist_gloo.py checks bit for bit.
 """
 import argparse
 import os
@@ -74,12 +82,56 @@ def gae(rew, val, done, last_val, gamma=0.999, lam=0.97):
     return adv, adv + val
 
 
-def train_on_device(flow_params, replicas=1024, fragment=100, iterations=20, epochs=4, lr=3e-4, seed=0, log=print):
-    """PPO on R replicas of ``flow_params`` with everything in HBM: returns the mean step reward per iteration."""
+def ppo_update(pi, opt, shards, epochs=4, clip=0.2, group=None):
+    """One PPO update over `shards` = [(obs [K+1, R, D], act [K, R, A], rew [K, R], done [K, R])]: the shards this
+    process holds (one per rank in data-parallel runs, all of them in a single process).  Every quantity that couples the
+    shards is a SUM: the advantage statistics and the gradient -- summed over the local shards here, over the ranks by
+    allreduce_sum / allreduce_gradients -- so N ranks with one shard each and one process with N shards agree."""
+    from flow_amd.dist import allreduce_gradients, allreduce_sum
+    prepared, stats = [], None
+    for obs, act, rew, done in shards:
+        K, R = rew.shape
+        o, a = obs[:K].reshape(K * R, -1), act.reshape(K * R, -1)
+        with torch.no_grad():
+            logp_old, val = pi.logp_value(o, a)
+            last_val = pi.value(obs[K]).squeeze(-1)
+            adv, ret = gae(rew, val.view(K, R), done, last_val)
+            adv = adv.reshape(-1).double()
+            st = torch.stack([adv.sum(), (adv * adv).sum(), torch.tensor(float(adv.numel()), dtype=torch.float64, device=adv.device)])
+            stats = st if stats is None else stats + st
+        prepared.append((o, a, logp_old, adv, ret.reshape(-1)))
+    stats = allreduce_sum(stats, group)
+    n = stats[2]
+    mean = stats[0] / n
+    std = ((stats[1] - n * mean * mean) / (n - 1)).clamp_min(0).sqrt()
+    params = list(pi.parameters())
+    for _ in range(epochs):
+        opt.zero_grad()
+        for o, a, logp_old, adv, ret in prepared:
+            adv_n = ((adv - mean) / (std + 1e-8)).float()
+            logp, v = pi.logp_value(o, a)
+            ratio = (logp - logp_old).exp()
+            # the GLOBAL mean as a sum of per-shard sums
+            loss = (-torch.min(ratio * adv_n, ratio.clamp(1 - clip, 1 + clip) * adv_n).sum()
+                    + 0.5 * (v - ret).pow(2).sum()) / float(n)
+            loss.backward()                                  # (accumulates over the local shards)
+        allreduce_gradients(params, group)
+        opt.step()
+
+
+def train_on_device(flow_params, replicas=1024, fragment=100, iterations=20, epochs=4, lr=3e-4, seed=0, log=print,
+                    rank=0, world=1):
+    """PPO on R replicas of ``flow_params`` with everything in HBM: returns the mean step reward per iteration.
+    ``world`` > 1: this process is rank ``rank`` of a data-parallel run (torch.distributed is initialised): it steps its
+    block of the R replicas on its own GPU."""
+    from flow_amd.dist import allreduce_sum, shard_range
     from flow_amd.envs import VecFlowEnv
-    dev = torch.device("cuda", 0)
-    torch.manual_seed(seed)
-    vec = VecFlowEnv(flow_params, num_replicas=replicas, device=0)
+    local = int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(seed)                                   # the same initial policy on every rank
+    lo, hi = shard_range(replicas, rank, world)
+    vec = VecFlowEnv(flow_params, num_replicas=hi - lo, device=local, replica_offset=lo)
     pi = GaussianPolicy(vec.obs_dim, vec.act_dim).to(dev)
     opt = torch.optim.Adam(pi.parameters(), lr=lr)
     # the rollout: ONE kernel per fragment where the library has the fused policy + step form for this experiment and
@@ -96,9 +148,11 @@ def train_on_device(flow_params, replicas=1024, fragment=100, iterations=20, epo
     except NotImplementedError as e:
         fused = None
         log("rollout: HIP graph of %d single steps around the torch policy (%s)" % (fragment, e))
+        if world > 1:
+            torch.manual_seed(seed + 1000 * (rank + 1))       # the graph's torch.randn: another stream per rank
         graph = vec.capture(fragment, policy=pi.act, reset_done=True)
         graph.begin(vec.reset())
-    K, R = fragment, replicas
+    K, R = fragment, hi - lo
     history = []
     for it in range(iterations):
         vec.redraw_ring_lengths()                              # pending ring length per replica for its next in-graph reset
@@ -111,26 +165,38 @@ def train_on_device(flow_params, replicas=1024, fragment=100, iterations=20, epo
             obs, act, rew, done = graph.replay()               # K closed-loop steps of R replicas: one graph launch
             graph.synchronize()
         t_roll = time.perf_counter() - t0
-        o, a = obs[:K].reshape(K * R, -1), act.reshape(K * R, -1)
-        with torch.no_grad():
-            logp_old, val = pi.logp_value(o, a)
-            last_val = pi.value(obs[K]).squeeze(-1)
-            adv, ret = gae(rew, val.view(K, R), done, last_val)
-            adv = ((adv - adv.mean()) / (adv.std() + 1e-8)).reshape(-1)
-            ret = ret.reshape(-1)
-        for _ in range(epochs):
-            logp, v = pi.logp_value(o, a)
-            ratio = (logp - logp_old).exp()
-            loss = -torch.min(ratio * adv, ratio.clamp(0.8, 1.2) * adv).mean() + 0.5 * (v - ret).pow(2).mean()
-            opt.zero_grad()
-            loss.backward()
-            opt.step()
-        mean_rew = float(rew.mean())
+        ppo_update(pi, opt, [(obs, act, rew, done)], epochs=epochs)
+        tot = allreduce_sum(torch.stack([rew.double().sum(), torch.tensor(float(rew.numel()), dtype=torch.float64, device=dev),
+                                         (done != 0).sum().double()]))
+        mean_rew = float(tot[0] / tot[1])
         history.append(mean_rew)
-        log("iteration %3d  mean step reward %8.4f  rollout %.1f ms (%.2f M env-steps/s)  episodes ended %d"
-            % (it, mean_rew, t_roll * 1e3, K * R / t_roll / 1e6, int((done != 0).sum())))
+        if rank == 0:
+            log("iteration %3d  mean step reward %8.4f  rollout %.1f ms (%.2f M env-steps/s per GPU, %d GPU%s)  episodes ended %d"
+                % (it, mean_rew, t_roll * 1e3, K * R / t_roll / 1e6, world, "s" if world > 1 else "", int(tot[2])))
     vec.close()
     return history
+
+
+def spawn_ranks(gpus, argv):
+    """--gpus N without a launcher: start the N ranks as child processes.  Nothing in THIS process has touched a GPU
+    (torch.cuda.device_count() does not initialise it); never an exec of a process that has."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < gpus:
+        raise SystemExit("train_vec.py --gpus %d: this node exposes %d GPU(s)" % (gpus, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    raise SystemExit(rc)
 
 
 def main(argv=None):
@@ -141,9 +207,28 @@ def main(argv=None):
     ap.add_argument("--iterations", type=int, default=20)
     ap.add_argument("--epochs", type=int, default=4)
     ap.add_argument("--lr", type=float, default=3e-4)
+    ap.add_argument("--gpus", type=int, default=1, help="data-parallel over this many GPUs of the node (one process each)")
     args = ap.parse_args(argv)
-    return train_on_device(ring_flow_params(args.horizon), replicas=args.replicas, fragment=args.fragment,
-                           iterations=args.iterations, epochs=args.epochs, lr=args.lr)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    force = os.environ.get("TRAIN_FORCE_DIST") == "1"            # the N > 1 code path (RCCL init, all-reduces) with one rank
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus, sys.argv[1:] if argv is None else argv)
+    if args.gpus != world and not (args.gpus == 1 and world == 1):
+        raise SystemExit("train_vec.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1 or force:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29544")
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    try:
+        return train_on_device(ring_flow_params(args.horizon), replicas=args.replicas, fragment=args.fragment,
+                               iterations=args.iterations, epochs=args.epochs, lr=args.lr, rank=rank, world=world)
+    finally:
+        if world > 1 or force:
+            import torch.distributed as dist
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":
