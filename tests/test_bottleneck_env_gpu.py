@@ -177,7 +177,7 @@ def test_desired_velocity_env_with_200_vehicle_slots_holds_the_whole_queue():
     obs = env.reset()
     np.testing.assert_array_equal(obs, ora.reset()[0].astype(np.float32))
     rng = np.random.default_rng(1)
-    for k in range(700):
+    for k in range(480):
         a = rng.uniform(-1.5, 1.5, 20).astype(np.float32)
         obs, rew, done, _ = env.step(a)
         o_ref, r_ref, d_ref = ora.step(a[None, :])

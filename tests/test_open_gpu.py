@@ -8,6 +8,8 @@ float64 kernel vs the float64 oracle (the reference's arithmetic type) -- 1e-9.
 import numpy as np
 import pytest
 
+from conftest import seeds
+
 from helpers import idm_vehicle, merge_spec
 from oracle import opennet as O
 from oracle import refsim as S
@@ -482,7 +484,7 @@ def random_open_spec(seed):
     return spec, acts
 
 
-@pytest.mark.parametrize("seed", list(range(18)))
+@pytest.mark.parametrize("seed", seeds(range(9), range(9, 18)))
 def test_fuzz_random_open_network_configs_bit_exact(seed):
     spec, acts = random_open_spec(seed)
     steps = int(spec["horizon"])
@@ -604,7 +606,7 @@ def test_float64_open_kernel_ranks_on_float32_images_and_counts_exactly_when_the
     assert ora.total_departed.min() > 40
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2, 4, 5, 7, 11, 14])
+@pytest.mark.parametrize("seed", seeds([0, 2, 5, 11], [1, 4, 7, 14]))
 def test_fuzz_random_open_network_configs_float64(seed):
     """The float64 kernels (ranking on float32 images with the exact count on ties; branch-free controller selection for
     IDM / RL / Sim populations) on the random configurations of the float32 fuzz, without noise, against the float64 oracle."""

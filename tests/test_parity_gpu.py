@@ -12,6 +12,8 @@ Bars (DESIGN.md "Parity"):
 import numpy as np
 import pytest
 
+from conftest import seeds
+
 from helpers import figure_eight_spec, idm_vehicle, multilane_spec, ring_spec
 from oracle import refsim as S
 
@@ -545,7 +547,7 @@ EXACT_CONTROLLERS = [
 ]
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", seeds(range(12), range(12, 24)))
 def test_fuzz_random_single_lane_configs_bit_exact(seed):
     """Seeded random configurations: vehicle count, replica count, per-replica ring lengths, controller mix,
     fail-safes, speed modes, junction mode, integrator, sims_per_step, warm-up, RL actions, masked resets --

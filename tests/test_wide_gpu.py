@@ -7,6 +7,8 @@ observation, reward and done flag; float64 kernel vs the float64 oracle within 1
 import numpy as np
 import pytest
 
+from conftest import seeds
+
 from oracle import opennet as O
 from test_open_gpu import bottleneck_actions, compare_state, compare_vmax, make, run_pair
 
@@ -23,10 +25,10 @@ def slot_order_kernels(monkeypatch):
 def test_wide_desired_velocity_f32_bit_exact_192_slots():
     """C4's demand: the queue upstream of the lane drops outgrows one wave (more than 64 vehicles in the network)."""
     from helpers import bottleneck_spec
-    spec = bottleneck_spec(R=3, cap_human=170, cap_rl=22, horizon=700, seed=3)
-    ora = run_pair(spec, "f32", 700, bottleneck_actions(spec, 5), check_every=50)
+    spec = bottleneck_spec(R=2, cap_human=170, cap_rl=22, horizon=700, seed=3)
+    ora = run_pair(spec, "f32", 450, bottleneck_actions(spec, 5), check_every=50)
     assert (ora.alive.sum(axis=1) > 64).all()                          # really beyond the 64-slot kernel
-    assert ora.total_arrived.min() > 100
+    assert ora.total_arrived.min() > 60
 
 
 def test_wide_two_waves_and_a_full_block():
@@ -140,7 +142,7 @@ def test_wide_masked_reset_and_rollout_equal_stepping():
     b.close()
 
 
-@pytest.mark.parametrize("seed", list(range(8)))
+@pytest.mark.parametrize("seed", seeds([0, 5, 7], [1, 2, 3, 4, 6]))
 def test_wide_fuzz_random_lane_drop_configs_bit_exact(seed):
     from helpers import bottleneck_spec
     rng = np.random.default_rng(7000 + seed)
@@ -200,7 +202,7 @@ def test_wide_scaling_two_eight_entry_lanes():
     from helpers import bottleneck_spec
     spec = bottleneck_spec(R=1, cap_human=200, cap_rl=40, horizon=400, seed=6, q=4000.0, scaling=2)
     assert spec["num_paths"] == 8 and len(spec["obs_cells"]) == 70 and spec["num_rl"] == 40
-    ora = run_pair(spec, "f32", 400, bottleneck_actions(spec, 3), check_every=50)
+    ora = run_pair(spec, "f32", 300, bottleneck_actions(spec, 3), check_every=50)
     alive = ora.alive[0]
     assert set(ora.route[0][alive]) == set(range(8))                       # every entry lane is in use
     assert set((ora.route[0][alive & (ora.x[0] > spec["merge2_x"])] >> 2)) == {0, 1}    # two lanes leave the network
@@ -210,9 +212,9 @@ def test_wide_scaling_two_eight_entry_lanes():
                            lane_change_cooldown_steps=8, lane_change_min_gain=8.0)
     for v in spec["vehicles"][:100]:
         v["lane_change_mode"] = 1621
-    ora = run_pair(spec, "f32", 250, bottleneck_actions(spec, 5), check_every=50)
-    assert (ora.num_lane_changes > 20).all()
-    run_pair(spec, "f64", 120, bottleneck_actions(spec, 5), check_every=40, exact=False, atol=1e-9)
+    ora = run_pair(spec, "f32", 160, bottleneck_actions(spec, 5), check_every=40)
+    assert (ora.num_lane_changes > 10).all()
+    run_pair(spec, "f64", 60, bottleneck_actions(spec, 5), check_every=30, exact=False, atol=1e-9)
     with pytest.raises(NotImplementedError, match="more than 64 vehicle slots"):
         make(bottleneck_spec(R=1, cap_human=50, cap_rl=10, scaling=2), "f32")
 
@@ -327,7 +329,7 @@ def test_wide_float64_ranks_on_float32_images_and_counts_exactly_when_they_colli
     assert (ora.alive.sum(axis=1) > 64).any()
 
 
-@pytest.mark.parametrize("seed", [0, 3, 5])
+@pytest.mark.parametrize("seed", seeds([0], [3, 5]))
 def test_wide_fuzz_random_lane_drop_configs_float64(seed):
     """k_steps_wide<double> (ranking on float32 images, exact count on ties) on random lane-drop configurations against the
     float64 oracle."""
