@@ -114,6 +114,63 @@ def host_cores():
     return max(1, min(n, 16))
 
 
+def c3_closed_loop_leg(device, R=4096, K=500):
+    """C3 closed loop: policy (fcnet obs-32-32-32-2 tanh, diagonal Gaussian: examples/train.py:152) -> action -> Env.step ->
+    reset of finished episodes, K steps per launch of the fused kernel k_loop_policy (fs_policy_rollout_dev), both heads."""
+    import torch
+    from flow_amd.envs import VecFlowEnv
+    from flow_amd.utils.device_policy import DevicePolicy
+    out = {"unit": "env-steps/s", "replicas": R, "steps_per_launch": K,
+           "workload": "C3 closed loop: FigureEightNetwork, 13 IDM (noise 0.2) + 1 RL, policy in the loop (one launch per "
+                       "%d-step fragment, in-fragment resets)" % K}
+    for label, po in (("po_head", True), ("accel_head", False)):
+        fp = c3_flow_params(po)
+        vec = VecFlowEnv(fp, num_replicas=R, device=device.index)
+        hidden = [torch.nn.Linear(vec.obs_dim, 32), torch.nn.Linear(32, 32), torch.nn.Linear(32, 32)]
+        head = torch.nn.Linear(32, 2)
+        for l in hidden + [head]:
+            l.to(device)
+        pol = DevicePolicy(hidden, head, seed=1)
+        vec.reset()
+        res = vec.policy_rollout(pol, K, reset_done=True)
+        torch.cuda.synchronize(device)
+        ms = []
+        for _ in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            vec.policy_rollout(pol, K, reset_done=True, out=res)
+            e1.record()
+            torch.cuda.synchronize(device)
+            ms.append(e0.elapsed_time(e1))
+        t = float(np.median(ms)) * 1e-3
+        out[label] = {"value": R * K / t, "median_launch_ms": t * 1e3, "kernel": vec.sim.last_kernel, "obs_dim": vec.obs_dim,
+                      "model": "fcnet %d-32-32-32-2 tanh, diagonal Gaussian" % vec.obs_dim}
+        vec.close()
+    out["value"] = out["po_head"]["value"]
+    return out
+
+
+def c3_flow_params(po=False, precision="f32"):
+    """The flow_params of BASELINE configs[2] (see c3_leg)."""
+    from flow_amd.controllers import ContinuousRouter, IDMController, RLController
+    from flow_amd.core.params import EnvParams, NetParams, SumoCarFollowingParams, SumoParams, VehicleParams
+    from flow_amd.envs import AccelEnv, WaveAttenuationPOEnv
+    from flow_amd.networks import FigureEightNetwork
+    from flow_amd.networks.figure_eight import ADDITIONAL_NET_PARAMS
+    veh = VehicleParams()
+    veh.add(veh_id="human", acceleration_controller=(IDMController, {"noise": 0.2}),
+            routing_controller=(ContinuousRouter, {}),
+            car_following_params=SumoCarFollowingParams(speed_mode="obey_safe_speed", decel=1.5), num_vehicles=13)
+    veh.add(veh_id="rl", acceleration_controller=(RLController, {}), routing_controller=(ContinuousRouter, {}),
+            car_following_params=SumoCarFollowingParams(speed_mode="obey_safe_speed", decel=1.5), num_vehicles=1)
+    add = {"max_accel": 3, "max_decel": 3, "ring_length": None} if po else \
+        {"target_velocity": 20, "max_accel": 3, "max_decel": 3, "sort_vehicles": False}
+    return dict(exp_tag="figure_eight", env_name=WaveAttenuationPOEnv if po else AccelEnv, network=FigureEightNetwork,
+                simulator="traci", sim=SumoParams(sim_step=0.1, render=False, seed=7, precision=precision),
+                env=EnvParams(horizon=1500, additional_params=add),
+                net=NetParams(additional_params=dict(ADDITIONAL_NET_PARAMS)), veh=veh)
+
+
 def c3_leg(device, R=4096, steps=3000, po=False, precision="f32"):
     """BASELINE configs[2] (informational, not the headline): FigureEightNetwork, 13 noisy IDM + 1 RL vehicle,
     random RL actions from a pre-generated tape, rollout kernel of segment-table loops (flowsim_fig8.h).  ``po=False``: AccelEnv observation (28),
@@ -898,6 +955,7 @@ def main():
         out["c3_figure_eight"] = c3_leg(device)
         out["c3_figure_eight_po"] = c3_leg(device, po=True)
         out["c3_figure_eight_mixed"] = c3_leg(device, precision="mixed")      # float64 state, float32 car-following models
+        out["c3_closed_loop"] = c3_closed_loop_leg(device)                    # the policy in the loop (k_loop_policy)
         out["generic_kernel"] = generic_kernel_leg(device)
         out["c4_bottleneck"] = c4_leg(device)
         out["c4_bottleneck_f64"] = c4_leg(device, precision="f64")            # the reference's arithmetic type

@@ -143,8 +143,9 @@ def train_on_device(flow_params, replicas=1024, fragment=100, iterations=20, epo
         fused = DevicePolicy([pi.mu[0], pi.mu[2]], pi.mu[4], log_std=pi.log_std, seed=seed)
         vec.reset()
         vec.policy_rollout(fused, 1, reset_done=True)           # (probe: raises NotImplementedError when not built)
+        kernel = vec.sim.last_kernel
         vec.reset()
-        log("rollout: fused policy + step kernel (%s)" % vec.sim.last_kernel)
+        log("rollout: fused policy + step kernel (%s)" % kernel)
     except NotImplementedError as e:
         fused = None
         log("rollout: HIP graph of %d single steps around the torch policy (%s)" % (fragment, e))

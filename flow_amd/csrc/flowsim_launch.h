@@ -316,4 +316,42 @@ namespace fsim {
     return FS_OK;
   }
 
+  template <typename T>
+  int Sim<T>::launch_policy_loop16(const fs_policy* pol, int num_steps, int reset_done, const float* obs_in, float* obs,
+                                   float* act, float* logp, float* rew, uint8_t* done) {
+    fs::PolicyView pv;
+    pv.w = pol->weights_dev;
+    pv.log_std = pol->log_std_dev;
+    pv.ctr = d_pol_ctr;
+    pv.in_dim = pol->obs_dim;
+    pv.num_hidden = pol->num_hidden;
+    pv.n_out = pol->log_std_dev ? 1 : 2;
+    pv.seed_lo = uint32_t(pol->seed & 0xFFFFFFFFull);
+    pv.seed_hi = uint32_t(pol->seed >> 32);
+    if (obs == nullptr) {                                  // eager: the policy alone
+      const int blocks = (dv.R * 16 + 255) / 256;
+      last_kernel = "k_policy_act";
+      hipLaunchKernelGGL(fs::k_policy_act<16>, dim3(blocks), dim3(256), 0, stream, pv, dv.R, dv.rep0, obs_in, act, logp);
+      HIP_TRY(hipGetLastError());
+      return FS_OK;
+    }
+    if constexpr (std::is_same<T, float>::value) {
+      const int waves = (dv.R + 3) / 4;
+      const dim3 grid((waves + 3) / 4), block(256);
+      const bool fastc = loop_delta4 && loop_fastc_ok();
+      last_kernel = "k_loop_policy";
+#define FS_LPOL(H_, D4_, FC_)                                                                                     \
+  hipLaunchKernelGGL((fs::k_loop_policy<H_, D4_, FC_>), grid, block, 0, stream, dv, pv, num_steps, reset_done, obs, act, \
+                     logp, rew, done)
+      const bool po = dv.env == FS_ENV_WAVE_ATTENUATION_PO;
+      if (po) { if (fastc) FS_LPOL(1, true, true); else if (loop_delta4) FS_LPOL(1, true, false); else FS_LPOL(1, false, false); }
+      else { if (fastc) FS_LPOL(0, true, true); else if (loop_delta4) FS_LPOL(0, true, false); else FS_LPOL(0, false, false); }
+#undef FS_LPOL
+      HIP_TRY(hipGetLastError());
+      return FS_OK;
+    } else {
+      return fail(FS_ERR_UNSUPPORTED, "k_loop_policy is a float32 kernel");
+    }
+  }
+
 }  // namespace fsim

@@ -13,6 +13,10 @@ template int Sim<FS_PART_T>::launch_dropq(int, const float*, size_t, float*, flo
 template int Sim<FS_PART_T>::launch_wide<FS_PART_WIDE>(int, const uint8_t*, const float*, size_t, float*, float*, uint8_t*, int);
 #elif defined(FS_PART_SEG)
 template int Sim<FS_PART_T>::launch_seg<FS_PART_SEG>(int, const uint8_t*, const float*, size_t, float*, float*, uint8_t*, int);
+#if FS_PART_SEG == 16
+template int Sim<FS_PART_T>::launch_policy_loop16(const fs_policy*, int, int, const float*, float*, float*, float*, float*,
+                                                  uint8_t*);
+#endif
 #if FS_PART_SEG == 32
 template int Sim<FS_PART_T>::launch_policy_row16(const fs_policy*, int, int, const float*, float*, float*, float*, float*,
                                                  uint8_t*);

@@ -36,6 +36,9 @@ struct alignas(16) PolicyLds {
   // the same LDS banks: a 16-way conflict on every read, measured 1.4 -> 0.9 G)
   float w_hid[2][16][16][4];
   float w_in[32][4];       // layer 1: [unit][input (3, padded)]
+  // layer 1 of a WIDE observation (in_dim = 2 * half <= 32, e.g. AccelEnv's speeds and positions): input i < half is the
+  // first value of lane i, input half + i its second value -- the layout and the summation order of a hidden layer
+  float w_wide[16][16][4];
   float b[3][32];
   float w_out[2][32];
   float b_out[2];
@@ -45,7 +48,17 @@ struct alignas(16) PolicyLds {
 __device__ __forceinline__ void policy_load(const PolicyView& pv, PolicyLds* L, int tid, int nthreads) {
   // weights -> LDS (once per launch); layout of pv.w: [W1 32x3][b1 32][W2 32x32][b2][W3 32x32][b3][Wout n_out x 32][bout]
   const float* p = pv.w;
-  for (int e = tid; e < 32 * 4; e += nthreads) L->w_in[e / 4][e % 4] = (e % 4) < pv.in_dim ? p[(e / 4) * pv.in_dim + (e % 4)] : 0.0f;
+  const bool wide = pv.in_dim > 4;
+  for (int e = tid; e < 32 * 4; e += nthreads) L->w_in[e / 4][e % 4] = (!wide && (e % 4) < pv.in_dim) ? p[(e / 4) * pv.in_dim + (e % 4)] : 0.0f;
+  {
+    const int half = pv.in_dim >> 1;
+    for (int e = tid; e < 32 * 32; e += nthreads) {
+      const int u = e / 32, ip = e % 32;                       // ip: place of the input in the hidden-layer order
+      const int i = ip < 16 ? ip : half + (ip - 16);           // ... and its index in the observation
+      const bool used = wide && (ip & 15) < half;
+      L->w_wide[ip >> 1][u & 15][(ip & 1) * 2 + (u >> 4)] = used ? p[u * pv.in_dim + i] : 0.0f;
+    }
+  }
   p += 32 * pv.in_dim;
   for (int e = tid; e < 32; e += nthreads) L->b[0][e] = p[e];
   p += 32;
@@ -73,7 +86,8 @@ __device__ __forceinline__ float policy_tanh(float z) {
 
 // mean and log std of the action distribution for the observation (o0, o1, o2) of THIS row's replica (every lane of the
 // row passes the same three values); j = lane within the row
-template <int ROW>
+// WIDE: the observation is two values per lane (o0: input j, o1: input half + j of THIS lane; o2 unused)
+template <int ROW, bool WIDE = false>
 __device__ __forceinline__ void policy_eval(const PolicyView& pv, const PolicyLds* L, int j, float o0, float o1, float o2,
                                             float& mu, float& log_std) {
   static_assert(ROW == 16, "policy_eval: a row of 16 lanes holds the 32 units of a layer");
@@ -88,7 +102,31 @@ __device__ __forceinline__ void policy_eval(const PolicyView& pv, const PolicyLd
   if (pv.num_hidden > 1) load_ahead(0);
   // layer 1
   float ha, hb;      // units j and j + 16
-  {
+  if constexpr (WIDE) {
+    // the hidden layers' form (below): four independent accumulators, inputs by row broadcasts folded into packed FMAs
+    float4 ww[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) ww[q] = *reinterpret_cast<const float4*>(L->w_wide[q][j]);
+    f2 z0 = {L->b[0][j], L->b[0][j + 16]}, z1 = {0.0f, 0.0f}, z2 = {0.0f, 0.0f}, z3 = {0.0f, 0.0f};
+    static_for<4>([&](auto q_c) {
+      constexpr int q = decltype(q_c)::value;
+      const float a0 = dpp<DPP_ROW_NEWBCAST0 + 4 * q>(o0), a1 = dpp<DPP_ROW_NEWBCAST0 + 4 * q + 1>(o0);
+      const float a2 = dpp<DPP_ROW_NEWBCAST0 + 4 * q + 2>(o0), a3 = dpp<DPP_ROW_NEWBCAST0 + 4 * q + 3>(o0);
+      const float b0 = dpp<DPP_ROW_NEWBCAST0 + 4 * q>(o1), b1 = dpp<DPP_ROW_NEWBCAST0 + 4 * q + 1>(o1);
+      const float b2 = dpp<DPP_ROW_NEWBCAST0 + 4 * q + 2>(o1), b3 = dpp<DPP_ROW_NEWBCAST0 + 4 * q + 3>(o1);
+      z0 = fma2(f2{ww[2 * q].x, ww[2 * q].y}, splat(a0), z0);
+      z1 = fma2(f2{ww[2 * q].z, ww[2 * q].w}, splat(a1), z1);
+      z2 = fma2(f2{ww[2 * q + 1].x, ww[2 * q + 1].y}, splat(a2), z2);
+      z3 = fma2(f2{ww[2 * q + 1].z, ww[2 * q + 1].w}, splat(a3), z3);
+      z0 = fma2(f2{ww[8 + 2 * q].x, ww[8 + 2 * q].y}, splat(b0), z0);
+      z1 = fma2(f2{ww[8 + 2 * q].z, ww[8 + 2 * q].w}, splat(b1), z1);
+      z2 = fma2(f2{ww[8 + 2 * q + 1].x, ww[8 + 2 * q + 1].y}, splat(b2), z2);
+      z3 = fma2(f2{ww[8 + 2 * q + 1].z, ww[8 + 2 * q + 1].w}, splat(b3), z3);
+    });
+    const f2 z = pk_add(pk_add(z0, z1), pk_add(z2, z3));
+    ha = policy_tanh(z.x);
+    hb = policy_tanh(z.y);
+  } else {
     const float4 wa = *reinterpret_cast<const float4*>(L->w_in[j]), wb = *reinterpret_cast<const float4*>(L->w_in[j + 16]);
     float za = L->b[0][j], zb = L->b[0][j + 16];
     za = __builtin_fmaf(wa.x, o0, za); zb = __builtin_fmaf(wb.x, o0, zb);
@@ -163,7 +201,13 @@ __global__ __launch_bounds__(256) void k_policy_act(PolicyView pv, int R, uint32
   const int rr = r < R ? r : R - 1;
   const float* o = obs + size_t(rr) * pv.in_dim;
   float mu, ls;
-  policy_eval<ROW>(pv, &L, j, o[0], pv.in_dim > 1 ? o[1] : 0.0f, pv.in_dim > 2 ? o[2] : 0.0f, mu, ls);
+  if (pv.in_dim > 4) {                                   // (wave-uniform) two values per lane: inputs j and half + j
+    const int half = pv.in_dim >> 1;
+    const float ia = j < half ? o[j] : 0.0f, ib = j < half ? o[half + j] : 0.0f;
+    policy_eval<ROW, true>(pv, &L, j, ia, ib, 0.0f, mu, ls);
+  } else {
+    policy_eval<ROW>(pv, &L, j, o[0], pv.in_dim > 1 ? o[1] : 0.0f, pv.in_dim > 2 ? o[2] : 0.0f, mu, ls);
+  }
   const uint32_t c = pv.ctr[rr];
   float a, lp;
   policy_sample(pv, rep0 + uint32_t(rr), c, mu, ls, a, lp);
@@ -502,6 +546,303 @@ __global__ __launch_bounds__(256) void k_ring_policy(DevView<T> s, PolicyView pv
       s.time[rr] = tcount;
       pv.ctr[rr] = pctr;
       if (NOISE) s.noise_ctr[rr] = nctr;
+    }
+  }
+}
+
+
+// K x (policy -> action -> Env.step [-> reset of a finished episode]) on a segment-table loop (the figure eight: BASELINE's
+// C3, examples/exp_configs/rl/singleagent/singleagent_figure_eight.py) with ONE RL vehicle.  HEAD 1: WaveAttenuationPOEnv
+// (observation 3: BASELINE's pairing), HEAD 0: AccelEnv (observation 2 N: the reference's own pairing -- every lane feeds its
+// vehicle's speed and position into the first layer, policy_eval<., WIDE>).  The simulator part is k_rollout_loop's step
+// (flowsim_fig8.h), statement by statement: the same model functions, crossing rule, segment cursor, flag word, observation
+// quotients and reward expressions, so a fragment equals eager stepping (fs_policy_act_dev, fs_step_dev -- which runs
+// k_rollout_loop --, masked fs_reset_dev) bit for bit (tests/test_policy_gpu.py).  Resets inside the fragment: placement only
+// (warmup_steps = 0: Sim::launch_policy refuses anything else).
+template <int HEAD, bool DELTA4, bool FASTC>
+__global__ __launch_bounds__(256) void k_loop_policy(DevView<float> s, PolicyView pv, int num_steps, int reset_done,
+                                                     float* __restrict__ obs, float* __restrict__ act,
+                                                     float* __restrict__ logp, float* __restrict__ rew,
+                                                     uint8_t* __restrict__ done) {
+  typedef float T;
+  typedef float X;
+  constexpr int SEG = 16, RPW = 4;
+  __shared__ X tab_start[FS_MAX_SEGMENTS + 2], tab_fs[FS_MAX_SEGMENTS + 2], tab_sl[FS_MAX_SEGMENTS + 2];
+  __shared__ PolicyLds PL;
+  policy_load(pv, &PL, threadIdx.x, blockDim.x);
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int seg = lane / SEG;
+  const int i = lane % SEG;
+  const int r = wave * RPW + seg;
+  const int N = s.N;
+  const bool rvalid = r < s.R;
+  const bool valid = rvalid && i < N;
+  const int rr = rvalid ? r : s.R - 1;
+  const int ii = i < N ? i : N - 1;
+  const size_t idx = size_t(rr) * N + ii;
+  const bool wrap_lead = (i + 1 >= N);
+  constexpr bool has = true;                          // N > 1 (host-checked)
+  const int flags = s.flags;
+
+  if (threadIdx.x < FS_MAX_SEGMENTS + 2) {
+    const int q = threadIdx.x, qq = q < FS_MAX_SEGMENTS ? q : 0;
+    tab_start[q] = q < s.nseg ? s.seg_start[qq] : X(3.0e38);
+    tab_fs[q] = q < s.nseg ? s.seg_flow_start[qq] : X(0);
+    tab_sl[q] = q < s.nseg ? s.seg_flow_slope[qq] : X(0);
+  }
+  __syncthreads();
+
+  Slot<T> sl;
+  sl.ctrl = s.ctrl[ii];
+  sl.failsafe = 0;
+  sl.speed_mode = s.speed_mode[ii];
+  sl.rl_index = s.rl_index[ii];
+  sl.pis_index = -1;
+#pragma unroll
+  for (int k = 0; k < FS_MAX_CTRL_PARAMS; ++k) sl.p[k] = T(s.p[k * N + ii]);
+  sl.noise = T(s.noise[ii]);
+  sl.delay = T(0);
+  sl.max_accel = T(s.max_accel[ii]);
+  sl.max_decel = T(s.max_decel[ii]);
+  sl.length = T(s.length[ii]);
+  sl.sumo_tau = T(s.sumo_tau[ii]);
+  sl.sumo_min_gap = T(s.sumo_min_gap[ii]);
+  sl.sumo_max_speed = T(s.sumo_max_speed[ii]);
+  const X len_me = s.length[ii];
+  const X len_lead = lead16(len_me, wrap_lead);
+
+  const X L = s.ring_len[rr] + X(4) * s.jlen;
+  int tcount = s.time[rr];
+  const bool any_noise = (flags & FLAG_HAS_NOISE) != 0;
+  uint32_t nctr = any_noise ? s.noise_ctr[rr] : 0u;
+  uint32_t pctr = pv.ctr[rr];
+  const bool noisy = any_noise && sl.noise > T(0) && sl.ctrl != FS_CTRL_RL && sl.ctrl != FS_CTRL_SIM;
+
+  X x = s.pos[idx];
+  X v = s.vel[idx];
+  int k = 0;
+  X c_st, c_next, c_fs, c_sl;
+  auto cursor = [&]() {                                    // the segment of x and its table row
+    k = 0;
+    for (int q = 1; q < s.nseg; ++q) k = (x >= tab_start[q]) ? q : k;
+    c_st = tab_start[k]; c_next = tab_start[k + 1]; c_fs = tab_fs[k]; c_sl = tab_sl[k];
+  };
+  cursor();
+  X xl, vl, d;
+  T h;
+  const X Lv = in_vgpr(L);
+  auto snapshot = [&]() {
+    xl = lead16(x, wrap_lead);
+    vl = lead16(v, wrap_lead);
+    d = wrap_up(xl - x, Lv);
+    h = has ? T(d - len_lead) : T(1000);
+  };
+  snapshot();
+
+  const X dt = in_vgpr(X(s.dt)), ramp = in_vgpr(X(s.ramp));
+  const T crash_gap = in_vgpr(T(s.crash_gap)), target_v = in_vgpr(T(s.target_velocity));
+  const X ja_in = in_vgpr(X(s.ja_in)), ja_out = in_vgpr(X(s.ja_out)), jb_in = in_vgpr(X(s.jb_in)), jb_out = in_vgpr(X(s.jb_out));
+  const X look = in_vgpr(X(s.j_lookahead)), tgap = in_vgpr(X(s.j_time_gap));
+  const X za_lo = in_vgpr(X(s.za_lo)), za_hi = in_vgpr(X(s.za_hi)), zb_lo = in_vgpr(X(s.zb_lo)), zb_hi = in_vgpr(X(s.zb_hi));
+  const T max_cost = in_vgpr(T(s.max_cost));
+  const DivC d_ms = make_divc(T(s.max_speed)), d_L = make_divc(T(L)), d_15 = make_divc(15.0f), d_po = make_divc(T(s.po_max_length));
+  IdmC ic;
+  ic.p1 = sl.p[1]; ic.p2 = sl.p[2]; ic.p4 = sl.p[4]; ic.p5 = sl.p[5];
+  ic.v0 = make_divc(sl.p[0]);
+  ic.two_sqrt = make_divc(T(2) * tsqrt(sl.p[2] * sl.p[3]));
+  SumoC sc;
+  sc.min_gap = sl.sumo_min_gap; sc.tau = sl.sumo_tau; sc.max_accel = sl.max_accel;
+  sc.two_sqrt = make_divc(T(2) * tsqrt(sl.max_accel * sl.max_decel));
+  sc.max_speed = make_divc(sl.sumo_max_speed);
+  const unsigned seg_internal = s.seg_internal;
+  const bool junction_on = s.junction_on != 0, need_sumo = (flags & FLAG_NEED_SUMO) != 0;
+  const bool gated = s.junction_mode && sl.ctrl != FS_CTRL_RL && sl.ctrl != FS_CTRL_SIM;
+  const T clip_lo = in_vgpr(s.clip_actions != 0 ? T(s.act_lo) : T(-3.0e38)), clip_hi = in_vgpr(s.clip_actions != 0 ? T(s.act_hi) : T(3.0e38));
+  const bool rl_lane = sl.ctrl == FS_CTRL_RL, sim_lane = sl.ctrl == FS_CTRL_SIM;
+  const int num_rl = s.num_rl;
+  const bool obs_lane = HEAD == 1 ? (valid && rl_lane && sl.rl_index == 0) : valid;
+  const unsigned valid_bits = valid ? 0x3Fu : 0u;
+  const unsigned gate_u = gated ? 1u : 0u, cmd_rl = rl_lane ? 1u : 0u, cmd_other = (!rl_lane && !sim_lane) ? 1u : 0u,
+                 sm1_u = unsigned(sl.speed_mode) & 1u;
+  const bool sm1_lane = (sl.speed_mode & 1) != 0;
+  const X adt_c = (sl.speed_mode & 2) ? X(s.max_accel[ii]) * dt : X(3.0e38), ddt_c = (sl.speed_mode & 4) ? X(s.max_decel[ii]) * dt : X(3.0e38);
+  T g4[4] = {T(0), T(0), T(0), T(0)};
+  if (any_noise && (nctr & 3u) != 0u && noisy) {
+    gauss4<T>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(ii), nctr >> 2, g4);
+    for (uint32_t q = 0; q < (nctr & 3u); ++q) { g4[0] = g4[1]; g4[1] = g4[2]; g4[2] = g4[3]; }
+  }
+  X prev_v = v;
+  T last_acc = T(0);
+  auto junction_flags = [&](X xx, X vv) -> unsigned {
+    const unsigned busy_a = sm_in(xx, ja_in - tgap * vv, ja_out + len_me);
+    const unsigned in_b = sm_in(xx, jb_in, jb_out + len_me);
+    return (busy_a >> 31) | ((in_b >> 31) << 1);
+  };
+  unsigned jf = junction_on ? seg_or<SEG>(junction_flags(x, v) & valid_bits) : 0u;
+
+  // the observation of the current state: stored, and handed to the row as the policy's input.  PO head: the RL vehicle's
+  // three values reach every lane of its row; AccelEnv head: every lane keeps its own two (inputs ii and N + ii)
+  const int obs_dim = HEAD == 1 ? 3 : 2 * N;
+  const unsigned long long rl_m = __ballot(valid && rl_lane);
+  const int k_rl = rl_m ? (__builtin_ctzll(rl_m) & (SEG - 1)) : 0;
+  const int src_rl = (lane - i) + k_rl;
+  float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
+  auto observe = [&](float* orow) {
+    if (HEAD == 1) {
+      const float po0 = divc(v, d_15), po1 = divc(vl - v, d_15), po2 = divc(d, d_po);      // wave_attenuation.py:248-269
+      if (obs_lane) { orow[0] = po0; orow[1] = po1; orow[2] = po2; }
+      o0 = __shfl(po0, src_rl, 64);
+      o1 = __shfl(po1, src_rl, 64);
+      o2 = __shfl(po2, src_rl, 64);
+    } else {
+      const X xo = c_fs + c_sl * (x - c_st);
+      const float po0 = divc(v, d_ms), po1 = divc(xo, d_L);                                   // accel.py:116-123
+      if (obs_lane) { orow[ii] = po0; orow[N + ii] = po1; }
+      o0 = valid ? po0 : 0.0f;
+      o1 = valid ? po1 : 0.0f;
+    }
+  };
+
+  const size_t R = size_t(s.R);
+  NoiseBlock<float> act_draws;
+  act_draws.init();
+  observe(obs + size_t(rr) * obs_dim);
+  for (int step = 0; step < num_steps; ++step) {
+    // ---- policy -> action --------------------------------------------------------------------------------------
+    float mu, ls, a, lp;
+    if (HEAD == 1) policy_eval<SEG>(pv, &PL, i, o0, o1, o2, mu, ls);
+    else policy_eval<SEG, true>(pv, &PL, i, o0, o1, 0.0f, mu, ls);
+    policy_sample(pv, s.rep0 + uint32_t(rr), pctr, mu, ls, a, lp, &act_draws);
+    pctr += 1u;
+    if (rvalid && i == 0) {
+      act[size_t(step) * R + rr] = a;
+      logp[size_t(step) * R + rr] = lp;
+    }
+    // ---- Env.step: k_rollout_loop's step ---------------------------------------------------------------------------
+    bool on_a = false, on_b = false, on_any = false, on_both = false;
+    if (junction_on) {
+      const unsigned on_b_m = sm_in(x, jb_in - look, jb_in) & (jf << 31);
+      const unsigned on_a_m = sm_in(x, ja_in - look, ja_in) & (jf << 30);
+      on_b = sm_true(on_b_m);
+      on_a = sm_true(on_a_m);
+      on_any = sm_true(on_a_m | on_b_m);
+      on_both = sm_true(on_a_m & on_b_m);
+    }
+    const unsigned on_edge_u = 1u ^ (gate_u & (seg_internal >> k));
+    const unsigned commanded_u = (on_edge_u & cmd_other) | cmd_rl;
+    const bool commanded = commanded_u != 0u;
+    T acc;
+    {
+      if (any_noise) {
+        if (__ballot(noisy && (nctr & 3u) == 0u) != 0ull) {
+          if (noisy && (nctr & 3u) == 0u)
+            gauss4<T>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(ii), nctr >> 2, g4);
+        }
+      }
+      T ai = idm_fast<DELTA4, FASTC>(T(v), T(vl), h, has, ic);
+      if (any_noise) {
+        const T an = ai + sl.noise * g4[0];
+        ai = noisy ? an : ai;
+        g4[0] = g4[1]; g4[1] = g4[2]; g4[2] = g4[3];
+      }
+      const T arl = hmin(hmax(T(a), clip_lo), clip_hi);
+      acc = rl_lane ? arl : (sim_lane ? T(0) : ai);
+    }
+    X next_vel = xmax(v + X(acc) * dt, X(0));
+    X vc = v + (next_vel - v) * ramp;
+    X v_new = vc;
+    if (need_sumo) {
+      X v_sumo = sumo_fast<FASTC>(v, vl, h, has, dt, sc);
+      vc = xmin(vc, sm1_lane ? v_sumo : X(3.0e38));
+      vc = xmin(vc, v + adt_c);
+      vc = xmax(vc, v - ddt_c);
+      v_new = commanded ? vc : v_sumo;
+    }
+    if (junction_on) {
+      if (__ballot(on_any) != 0ull) {
+        const X line = on_b ? jb_in - x : ja_in - x;
+        X cap = sumo_fast<FASTC>(v, X(0), T(line), true, dt, sc);
+        cap = on_any ? cap : X(3.0e38);
+        if (__ballot(on_both) != 0ull) {
+          const X cap_a = sumo_fast<FASTC>(v, X(0), T(ja_in - x), true, dt, sc);
+          cap = xmin(cap, on_both ? cap_a : X(3.0e38));
+        }
+        const bool cap_applies = (sm1_u | (commanded_u ^ 1u)) != 0u;
+        v_new = xmin(v_new, cap_applies ? cap : X(3.0e38));
+      }
+    }
+    X x_new = x + v_new * dt;
+    x_new = wrap_down(x_new, Lv);
+    prev_v = v;
+    last_acc = acc;
+    x = x_new;
+    v = v_new;
+    tcount += 1;
+    nctr += 1u;
+    // the segment cursor (k_rollout_loop advances it by compares; the position decides the segment either way)
+    if (__ballot((x < c_st) || (x >= c_next)) != 0ull) cursor();
+    snapshot();
+    unsigned f2_ = sm_lt(h, crash_gap) >> 31;
+    if (junction_on) {
+      f2_ |= (sm_in(x, za_lo, za_hi) >> 31) << 1;
+      f2_ |= (sm_in(x, zb_lo, zb_hi) >> 31) << 2;
+    }
+    f2_ |= (sm_lt(v, X(-100)) >> 31) << 3;
+    if (junction_on) f2_ |= junction_flags(x, v) << 4;
+    f2_ &= valid_bits;
+    f2_ = seg_or<SEG>(f2_);
+    jf = (f2_ >> 4) & 3u;
+    const bool crashed = ((f2_ | ((f2_ >> 1) & (f2_ >> 2))) & 1u) != 0u;
+    const bool bad = (((f2_ >> 3) & 1u) != 0u) || crashed;
+    // ---- reward (the block form's transposed_sum is seg_sum's tree) --------------------------------------------------
+    T reward;
+    if (HEAD == 1) {                                               // wave_attenuation.py:113-139
+      const T racc = seg_sum<SEG>(valid ? T(v) : T(0));
+      // (k_rollout_loop sums |clip(a)| over the lanes of the RL columns: one column, one non-zero term -- the term itself)
+      const T racc2 = tabs(hmin(hmax(T(a), clip_lo), clip_hi));
+      const T mean_v = racc / T(N);
+      const T mean_a = racc2 / T(num_rl);
+      reward = T(4.0) * mean_v / T(20);
+      if (mean_a > T(0)) reward = reward + T(4) * (T(0) - mean_a);
+      reward = bad ? T(0) : reward;
+    } else {                                                       // rewards.py:6-59
+      const T dv = valid ? T(v) - target_v : T(0);
+      const T cost = tsqrt(seg_sum<SEG>(dv * dv));
+      reward = tmax(max_cost - cost, T(0)) / (max_cost + T(1.1920928955078125e-07));
+      reward = bad ? T(0) : reward;
+    }
+    const uint8_t dflag = done_flag(tcount >= s.step_limit, crashed);
+    if (rvalid && i == 0) {
+      rew[size_t(step) * R + rr] = reward;
+      done[size_t(step) * R + rr] = dflag;
+    }
+    // ---- Env.reset of a finished episode (masked fs_reset_dev: the placement; the noise stream runs on) ---------------
+    const bool fin = reset_done && dflag != 0;
+    if (__ballot(fin) != 0ull) {
+      if (fin) {
+        x = s.init_pos[idx];
+        v = s.init_vel[idx];
+        tcount = 0;
+      }
+      cursor();
+      snapshot();
+      jf = junction_on ? seg_or<SEG>(junction_flags(x, v) & valid_bits) : 0u;
+    }
+    observe(obs + (size_t(step + 1) * R + rr) * obs_dim);
+  }
+
+  if (valid) {
+    s.pos[idx] = x;
+    s.vel[idx] = v;
+    if (s.track_aux && num_steps > 0) {
+      s.prev_vel[idx] = prev_v;
+      s.accel[idx] = last_acc;
+    }
+    if (ii == 0) {
+      s.time[rr] = tcount;
+      pv.ctr[rr] = pctr;
+      if (any_noise) s.noise_ctr[rr] = nctr;
     }
   }
 }

@@ -721,18 +721,42 @@ struct Sim : SimBase {
   // by the SEG = 32 objects
   int launch_policy_row16(const fs_policy* pol, int num_steps, int reset_done, const float* obs_in, float* obs, float* act,
                           float* logp, float* rew, uint8_t* done);
+  // the fused policy + step kernel of segment-table loops (the figure eight, flowsim_policy.h k_loop_policy): rows of 16
+  // lanes (up to 16 vehicles); defined in flowsim_launch.h, instantiated by the SEG = 16 objects
+  int launch_policy_loop16(const fs_policy* pol, int num_steps, int reset_done, const float* obs_in, float* obs, float* act,
+                           float* logp, float* rew, uint8_t* done);
   int launch_policy(const fs_policy* pol, int num_steps, int reset_done, const float* obs_in, float* obs, float* act,
                     float* logp, float* rew, uint8_t* done) override {
     if (!pol || pol->struct_size != sizeof(fs_policy)) return fail(FS_ERR_INVALID, "fs_policy: struct_size mismatch");
     const bool f32_or_mixed = mixed || std::is_same<T, float>::value;
+    const bool loop = dv.nseg > 0;                       // a segment-table loop (figure eight) or a ring
     const char* why = nullptr;
-    if (!f32_or_mixed) why = "precision (f32 or mixed)";
+    if (pol->num_hidden < 1 || pol->num_hidden > 3 || pol->hidden_width != 32 || pol->activation != 0)
+      why = "fs_policy model (1..3 hidden layers of 32 tanh units)";
+    else if (!pol->weights_dev) why = "fs_policy.weights_dev (NULL)";
+    else if (loop) {
+      const bool po = dv.env == FS_ENV_WAVE_ATTENUATION_PO, accel = dv.env == FS_ENV_ACCEL && !dv.evaluate;
+      if (!std::is_same<T, float>::value || mixed) why = "precision (f32 on segment-table loops)";
+      else if (seg != 16 || dv.N < 2) why = "num_vehicles (2..16: a row of 16 lanes per replica)";
+      else if (!(po || accel) || dv.num_rl != 1) why = "env (WaveAttenuationPOEnv or AccelEnv with one RL vehicle)";
+      else if (pol->obs_dim != (po ? 3 : 2 * dv.N)) why = "fs_policy.obs_dim (the environment's observation)";
+      else if (!(dv.flags & fs::FLAG_IDM_SET) || (dv.flags & fs::FLAG_HAS_FAILSAFE) || dv.sims_per_step != 1 ||
+               dv.integrator != FS_EULER || dv.track_aux || dv.sort_vehicles || dv.obs_perm != nullptr || !loop_div_ok ||
+               (obs != nullptr && reset_done && cfg.warmup_steps != 0))
+        why = "configuration (what k_rollout_loop steps: IDM / RL / Sim vehicles, Euler, track_aux = 0; resets inside a "
+              "fragment: warmup_steps = 0)";
+      if (why) return fail(FS_ERR_UNSUPPORTED, std::string("fs_policy: not built for this handle: ") + why);
+      if (!d_pol_ctr) {
+        int rc = dev_alloc(&d_pol_ctr, size_t(dv.R));
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(d_pol_ctr, 0, size_t(dv.R) * sizeof(uint32_t), stream));
+      }
+      return launch_policy_loop16(pol, num_steps, reset_done, obs_in, obs, act, logp, rew, done);
+    }
+    else if (!f32_or_mixed) why = "precision (f32 or mixed)";
     else if (seg != 32) why = "num_vehicles (18..32: a row of 16 lanes per replica)";
     else if (dv.env != FS_ENV_WAVE_ATTENUATION_PO || dv.num_rl != 1) why = "env (WaveAttenuationPOEnv with one RL vehicle)";
     else if (pol->obs_dim != 3) why = "fs_policy.obs_dim (3)";
-    else if (pol->num_hidden < 1 || pol->num_hidden > 3 || pol->hidden_width != 32 || pol->activation != 0)
-      why = "fs_policy model (1..3 hidden layers of 32 tanh units)";
-    else if (!pol->weights_dev) why = "fs_policy.weights_dev (NULL)";
     else if (dv.nseg != 0 || dv.junction_on || dv.num_lanes > 1 || !(dv.flags & fs::FLAG_IDM_SET) || any_sim ||
              (dv.flags & fs::FLAG_HAS_FAILSAFE) || dv.sims_per_step != 1 || dv.integrator != FS_EULER || dv.junction_mode ||
              dv.track_aux || dv.sort_vehicles || dv.obs_perm != nullptr || dv.evaluate || (dv.N % 2) != 0)

@@ -172,3 +172,97 @@ def test_unsupported_configurations_are_refused_by_name():
     with pytest.raises(NotImplementedError, match="WaveAttenuationPOEnv"):
         sim.policy_rollout_dev(pol.struct, 3, o, a, lp, r, d)
     sim.close()
+
+
+# ------------------------------------------------------------------ the figure eight (k_loop_policy)
+def fig8_rl_spec(R, head, noise, horizon, seed):
+    """BASELINE's C3 population (examples/exp_configs/rl/singleagent/singleagent_figure_eight.py): 13 IDM + 1 RL vehicle on
+    the figure eight, obey_safe_speed; head 'po' = WaveAttenuationPOEnv (BASELINE's pairing), 'accel' = AccelEnv (the
+    reference's own)."""
+    from helpers import figure_eight_spec, idm_vehicle
+    spec = figure_eight_spec(R=R, N=14, horizon=horizon, seed=seed, num_rl=1, action_low=-3.0, action_high=3.0,
+                             env=S.ENV_WAVE_ATTENUATION_PO if head == "po" else S.ENV_ACCEL, po_max_length=421.94,
+                             track_aux=False)
+    spec["seed"] = 40 + seed
+    spec["vehicles"] = [idm_vehicle(speed_mode=1, max_decel=1.5, noise=noise) for _ in range(13)] + \
+                       [idm_vehicle(controller=S.CTRL_RL, rl_index=0, speed_mode=1, max_decel=1.5)]
+    return spec
+
+
+def make_policy_in(in_dim, num_hidden=3, free_log_std=False, seed=0, dev="cuda:0"):
+    import torch
+    from flow_amd.utils.device_policy import DevicePolicy
+    g = torch.Generator().manual_seed(seed)
+    dims = [in_dim] + [32] * num_hidden
+    hidden = [torch.nn.Linear(dims[i], dims[i + 1]) for i in range(num_hidden)]
+    head = torch.nn.Linear(32, 1 if free_log_std else 2)
+    for l in hidden + [head]:
+        with torch.no_grad():
+            l.weight.copy_(torch.randn(l.weight.shape, generator=g) * (0.4 if l.in_features <= 4 or l is head else 0.25))
+            l.bias.copy_(torch.randn(l.bias.shape, generator=g) * 0.2)
+    with torch.no_grad():
+        head.weight.mul_(0.3)
+    for l in hidden + [head]:
+        l.to(dev)
+    ls = torch.nn.Parameter(torch.tensor([-0.7], device=dev)) if free_log_std else None
+    return DevicePolicy(hidden, head, log_std=ls, seed=77 + seed)
+
+
+@pytest.mark.parametrize("head,noise,num_hidden,free", [("po", 0.2, 3, False), ("accel", 0.2, 3, False), ("po", 0.0, 1, True),
+                                                          ("accel", 0.0, 2, True)])
+def test_figure_eight_fused_fragment_equals_eager_stepping(head, noise, num_hidden, free):
+    import torch
+    K, R = 90, 7
+    dev = torch.device("cuda", 0)
+    spec = fig8_rl_spec(R, head, noise, horizon=35, seed=4)       # every replica finishes episodes inside the fragment
+    D = 3 if head == "po" else 28
+    pol_a, pol_b = make_policy_in(D, num_hidden, free, seed=3), make_policy_in(D, num_hidden, free, seed=3)
+    fused, eager = make(spec, "f32"), make(spec, "f32")
+    fused.reset(), eager.reset()
+
+    def bufs():
+        out = (torch.zeros((K + 1, R, D), device=dev), torch.zeros((K, R), device=dev), torch.zeros((K, R), device=dev),
+               torch.zeros((K, R), device=dev), torch.zeros((K, R), dtype=torch.uint8, device=dev))
+        torch.cuda.synchronize()
+        return out
+    o, a, lp, r, d = bufs()
+    fused.policy_rollout_dev(pol_a.struct, K, o, a, lp, r, d, reset_done=True)
+    fused.sync()
+    assert fused.last_kernel == "k_loop_policy"
+    eo, ea, elp, er, ed = bufs()
+    eo[0].copy_(torch.as_tensor(eager_obs0(eager), device=dev))
+    torch.cuda.synchronize()
+    for k in range(K):
+        eager.policy_act_dev(pol_b.struct, eo[k], ea[k], elp[k])
+        eager.step_dev(eo[k + 1], er[k], ed[k], ea[k].reshape(R, 1))
+        eager.reset_dev(eo[k + 1], ed[k])
+    eager.sync()
+    for name, x, y in (("obs", o, eo), ("act", a, ea), ("logp", lp, elp), ("rew", r, er), ("done", d, ed)):
+        np.testing.assert_array_equal(x.cpu().numpy(), y.cpu().numpy(), err_msg=name)
+    np.testing.assert_array_equal(fused.pos, eager.pos)
+    np.testing.assert_array_equal(fused.vel, eager.vel)
+    np.testing.assert_array_equal(fused.time_counter, eager.time_counter)
+    assert (d.cpu().numpy() != 0).sum() >= 2 * R
+    fused.close(), eager.close()
+
+
+def test_wide_first_layer_matches_torch():
+    """AccelEnv's 28 observations through policy_eval<., WIDE>: the mean of a (nearly) zero-std policy is torch's."""
+    import torch
+    R = 512
+    dev = torch.device("cuda", 0)
+    sim = make(fig8_rl_spec(R, "accel", 0.0, horizon=100, seed=1), "f32")
+    sim.reset()
+    pol = make_policy_in(28, 3, True, seed=9)
+    with torch.no_grad():
+        pol.log_std_param.fill_(-30.0)
+    pol.sync()
+    obs = torch.rand((R, 28), device=dev)
+    act, logp = torch.zeros(R, device=dev), torch.zeros(R, device=dev)
+    torch.cuda.synchronize()
+    sim.policy_act_dev(pol.struct, obs, act, logp)
+    sim.sync()
+    with torch.no_grad():
+        mu, _ = pol.reference(obs)
+    np.testing.assert_allclose(act.cpu().numpy(), mu.cpu().numpy(), atol=3e-5, rtol=0)
+    sim.close()

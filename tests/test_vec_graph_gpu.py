@@ -95,6 +95,9 @@ def test_train_script_has_the_reference_command_line_and_trains_reference_experi
         assert res.returncode == 0, res.stderr[-2000:]
         lines = [ln for ln in res.stdout.splitlines() if ln.startswith("iteration")]
         assert len(lines) == 2 and all(np.isfinite(float(ln.split()[5])) for ln in lines), res.stdout
+        # both roll out on a fused policy + step kernel: the figure eight (AccelEnv, 28 observations) on k_loop_policy
+        fused = "k_loop_policy" if exp == "singleagent_figure_eight" else "k_ring_policy"
+        assert "fused policy + step kernel (%s)" % fused in res.stdout, res.stdout
     res = subprocess.run([sys.executable, script, "singleagent_ring", "--rl_trainer", "rllib"], capture_output=True,
                          text=True, timeout=600)
     try:
