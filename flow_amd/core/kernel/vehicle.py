@@ -248,7 +248,19 @@ class VehicleKernel(object):
         """float64 array of the speeds of ``veh_ids`` (default: every vehicle in the network), one device read per step."""
         return self._field(L.FS_FIELD_VEL)[self.slots_of(veh_ids)].astype(np.float64)
 
+    def _need_aux(self, what):
+        """The previous-speed / acceleration fields are only kept current by handles created with track_aux (the scalar
+        Env's default; off under SumoParams(precision='mixed') and VecFlowEnv's default): say so instead of returning the
+        values of the last reset."""
+        if not getattr(self.sim, "spec", {}).get("track_aux", False) and not getattr(self, "_warned_aux", False):
+            import warnings
+            self._warned_aux = True
+            warnings.warn("k.vehicle.%s: this handle steps without the previous-speed / acceleration fields "
+                          "(track_aux = 0: precision='mixed', or VecFlowEnv(track_aux=False)); the values returned are "
+                          "those of the last reset" % what, stacklevel=3)
+
     def previous_speeds(self, veh_ids=None):
+        self._need_aux("previous_speeds")
         return self._field(L.FS_FIELD_PREV_VEL)[self.slots_of(veh_ids)].astype(np.float64)
 
     def get_speed(self, veh_id, error=-1001):
@@ -258,9 +270,11 @@ class VehicleKernel(object):
         return self.get_speed(veh_id, error)
 
     def get_previous_speed(self, veh_id, error=-1001):
+        self._need_aux("get_previous_speed")
         return self._vec(veh_id, lambda i: float(self._field(L.FS_FIELD_PREV_VEL)[i]), error)
 
     def get_accel(self, veh_id, error=None):
+        self._need_aux("get_accel")
         return self._vec(veh_id, lambda i: float(self._field(L.FS_FIELD_ACCEL)[i]), error)
 
     def get_x_by_id(self, veh_id):

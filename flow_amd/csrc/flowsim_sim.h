@@ -6,6 +6,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -974,11 +975,9 @@ struct Sim : SimBase {
       // the host copy the divisor proofs walk holds every length a replica may be running on: the current ones and,
       // appended, the pending ones (a masked reset on the device swaps them in without the host knowing which)
       const T* vals = static_cast<const T*>(src);
-      for (size_t e = 0; e < count; ++e) {
-        bool seen = false;
-        for (T b : h_ring_len) seen = seen || (b == vals[e]);
-        if (!seen) h_ring_len.push_back(vals[e]);
-      }
+      h_ring_len.insert(h_ring_len.end(), vals, vals + count);
+      std::sort(h_ring_len.begin(), h_ring_len.end());             // the distinct lengths only: the proofs walk this list
+      h_ring_len.erase(std::unique(h_ring_len.begin(), h_ring_len.end()), h_ring_len.end());
       fastdiv_state = -1;
       ringrl_fast_state = -1;
     }

@@ -93,9 +93,12 @@ class VecFlowEnv(object):
         if idx.size == 0:
             return
         lengths = self.sim.get_state(L.FS_FIELD_RING_LENGTH).astype(np.float64)
+        pending = self.sim.get_state(L.FS_FIELD_INIT_RING_LENGTH).astype(np.float64)
         init = self.sim.get_state(L.FS_FIELD_INIT_POS).astype(np.float64)
         self._draw_placements(idx, lengths, init)
-        self.sim.set_state(L.FS_FIELD_RING_LENGTH, lengths)
+        pending[idx] = lengths[idx]
+        self.sim.set_state(L.FS_FIELD_RING_LENGTH, lengths)         # (sets the pending lengths of ALL replicas too ...)
+        self.sim.set_state(L.FS_FIELD_INIT_RING_LENGTH, pending)    # ... so those of the replicas not reset go back
         self.sim.set_state(L.FS_FIELD_INIT_POS, init)
 
     def _draw_placements(self, idx, lengths, init):
@@ -158,11 +161,62 @@ class VecFlowEnv(object):
         self.sim.reset_dev(self._obs, self._done)
         return self._obs
 
+    # ---- performance cliffs: say so, once -----------------------------------------------------------------------
+    GENERIC_KERNELS = ("k_steps", "k_steps<CSET>", "k_steps_ml")
+
+    def why_generic(self):
+        """What sends this handle's rollouts to the generic step kernel (4-7x slower than the specialised rollout
+        kernels of closed loops: flow_amd/csrc/flowsim_launch.h), as a list of the configuration fields responsible;
+        empty for open networks (they have kernels of their own)."""
+        sp = self.env._spec
+        if sp.get("network") in ("merge", "bottleneck"):
+            return []
+        veh, why = sp["vehicles"], []
+        CTRL_SIM, CTRL_RL, CTRL_IDM = 0, 1, 2                # (include/flowsim.h FS_CTRL_*)
+        if any(v["controller"] not in (CTRL_IDM, CTRL_RL, CTRL_SIM) for v in veh):
+            why.append("an acceleration controller other than IDMController / RLController / SimCarFollowingController")
+        if any(v.get("fail_safe", 0) for v in veh):
+            why.append("fail_safe")
+        if len(veh) % 2 and not sp.get("segments"):
+            why.append("an odd number of vehicles (the ring kernels hold two per lane)")
+        if sp.get("sort_vehicles"):
+            why.append("sort_vehicles=True")
+        if sp.get("evaluate"):
+            why.append("EnvParams(evaluate=True)")
+        if sp.get("track_aux"):
+            why.append("track_aux=True")
+        if int(sp.get("num_lanes", 1)) > 1:
+            why.append("a multi-lane ring (k_steps_ml)")
+        if int(sp.get("sims_per_step", 1)) != 1:
+            why.append("sims_per_step > 1")
+        if sp.get("integrator", "euler") != "euler":
+            why.append("use_ballistic=True")
+        if sp.get("obs_perm") is not None:
+            why.append("InitialConfig(shuffle=True) / a placement that is not in driving order")
+        if self.env.FS_ENV in (L.FS_ENV_WAVE_ATTENUATION_PO_MA, L.FS_ENV_ACCEL_PO_MA):
+            why.append("a multi-agent ring head (%s)" % type(self.env).__name__)
+        elif self.env.FS_ENV not in (L.FS_ENV_ACCEL, L.FS_ENV_WAVE_ATTENUATION_PO):
+            why.append("the environment head of %s" % type(self.env).__name__)
+        return why
+
+    def _warn_if_generic(self):
+        if getattr(self, "_warned_generic", False) or self.num_envs < 1024:
+            return
+        if self.sim.last_kernel in self.GENERIC_KERNELS:
+            import warnings
+            self._warned_generic = True
+            why = self.why_generic()
+            warnings.warn("VecFlowEnv: %d replicas step on the generic kernel %s (several times slower than the rollout "
+                          "kernels of this network) because of: %s" %
+                          (self.num_envs, self.sim.last_kernel, "; ".join(why) if why else "this configuration"),
+                          stacklevel=3)
+
     def step(self, actions=None):
         """One Env.step of every replica.  ``actions``: float32 [R, action_dim] device tensor or None."""
         self.use_current_stream()
         a = self._check(actions, (self.num_envs, self.act_dim), self.torch.float32) if self.act_dim else None
         self.sim.step_dev(self._obs, self._rew, self._done, a)
+        self._warn_if_generic()
         return self._obs, self._rew, self._done
 
     def rollout(self, num_steps, actions=None, obs_every_step=True, out=None):
@@ -186,6 +240,7 @@ class VecFlowEnv(object):
         else:
             actions = None
         self.sim.rollout_dev(K, out[0], out[1], out[2], actions, stride, obs_every_step)
+        self._warn_if_generic()
         return out
 
     def capture(self, num_steps, policy=None, reset_done=False):
@@ -213,6 +268,13 @@ class VecFlowEnv(object):
         experiments (one RL vehicle, WaveAttenuationPOEnv); ``capture`` serves every other environment / model."""
         torch, R, K = self.torch, self.num_envs, int(num_steps)
         self.use_current_stream()
+        if reset_done and self._resample and not getattr(self, "_warned_pending_length", False):
+            import warnings
+            self._warned_pending_length = True
+            warnings.warn("VecFlowEnv.policy_rollout(reset_done=True): this environment redraws its ring length on reset "
+                          "(flow/envs/ring/wave_attenuation.py:157-210); every reset inside ONE fragment takes the replica's "
+                          "pending length (FS_FIELD_INIT_RING_LENGTH) -- call vec.redraw_ring_lengths() between fragments, "
+                          "and keep fragments shorter than an episode if each episode must draw its own.", stacklevel=2)
         if out is None:
             out = (torch.empty((K + 1, R, self.obs_dim), dtype=torch.float32, device=self.device),
                    torch.empty((K, R), dtype=torch.float32, device=self.device),

@@ -104,3 +104,58 @@ def test_train_script_has_the_reference_command_line_and_trains_reference_experi
         import ray  # noqa: F401
     except ImportError:
         assert res.returncode != 0 and "ray" in res.stderr
+
+
+def test_a_large_handle_on_the_generic_kernel_warns_once_and_names_the_field():
+    """the 4-7x cliff from the rollout kernels of a closed loop to the generic k_steps is not silent
+    at the replica counts where it matters; a handle on a rollout kernel says nothing."""
+    import warnings
+    import torch
+    from flow_amd.controllers import ContinuousRouter, IDMController, RLController
+    from flow_amd.core.params import VehicleParams
+    from flow_amd.envs import VecFlowEnv
+    fp = flow_params(horizon=20)
+    veh = VehicleParams()
+    veh.add(veh_id="human", acceleration_controller=(IDMController, {"fail_safe": "safe_velocity"}),
+            routing_controller=(ContinuousRouter, {}), num_vehicles=21)
+    veh.add(veh_id="rl", acceleration_controller=(RLController, {}), routing_controller=(ContinuousRouter, {}),
+            num_vehicles=1)
+    slow = VecFlowEnv(dict(fp, veh=veh), num_replicas=1024, device=0)
+    slow.reset()
+    act = torch.zeros((1024, 1), dtype=torch.float32, device="cuda")
+    with pytest.warns(UserWarning, match=r"generic kernel k_steps.*fail_safe"):
+        slow.rollout(4, actions=act)
+    assert slow.sim.last_kernel in VecFlowEnv.GENERIC_KERNELS and "fail_safe" in slow.why_generic()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                # once per handle
+        slow.rollout(4, actions=act)
+    slow.close()
+    fast = VecFlowEnv(fp, num_replicas=1024, device=0)
+    fast.reset()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        fast.rollout(4, actions=act)
+    assert fast.sim.last_kernel not in VecFlowEnv.GENERIC_KERNELS and fast.why_generic() == []
+    fast.close()
+
+
+def test_train_vec_through_rccl_with_one_rank_equals_the_plain_run():
+    """The N > 1 code path of examples/train_vec.py (process group over nccl = RCCL, flat gradient all-reduce, the global
+    advantage sums) with ONE rank -- what a one-GPU box can run of it -- prints the history of the plain run, digit for
+    digit (tests/test_train_dist_gloo.py holds the two-rank bit-for-bit statement on gloo)."""
+    import subprocess
+    script = os.path.join(ROOT, "examples", "train_vec.py")
+    argv = [sys.executable, script, "--replicas", "64", "--fragment", "20", "--horizon", "50", "--iterations", "3",
+            "--epochs", "2"]
+
+    def rewards(env):
+        res = subprocess.run(argv, capture_output=True, text=True, timeout=600, env=env)
+        assert res.returncode == 0, res.stderr[-2000:]
+        rows = [ln.split("rollout")[0] for ln in res.stdout.splitlines() if ln.startswith("iteration")]
+        assert len(rows) == 3, res.stdout
+        return rows
+
+    plain = rewards(dict(os.environ))
+    forced = rewards(dict(os.environ, TRAIN_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29561",
+                          HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert plain == forced
