@@ -132,7 +132,7 @@ __device__ __forceinline__ unsigned long long ballot_here(bool p) {
   return m;
 }
 
-template <int HEAD /* 0: AccelEnv, 1: WaveAttenuationPOEnv */, bool DELTA4 /* every IDM slot has delta = 4 */,
+template <int HEAD /* 0: AccelEnv, 1: WaveAttenuationPOEnv, 2: MultiAgentAccelPOEnv (float32 only) */, bool DELTA4 /* every IDM slot has delta = 4 */,
           bool FULL = false, bool MX = false /* FS_MIXED: float64 state and geometry (X), float32 car-following models (T) */>
 __global__ __launch_bounds__(256) void k_rollout_loop(DevView<typename std::conditional<MX, double, float>::type> s,
                                                       int num_steps, const float* __restrict__ actions, size_t act_stride,
@@ -232,8 +232,13 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<typename std::cond
   const int num_rl = s.num_rl;
   const int own_col = sl.rl_index < 0 ? 0 : sl.rl_index;
   const bool red_lane = ii < num_rl && i < N;
-  const int obs_dim = HEAD == 1 ? 3 : 2 * N;
-  const bool obs_lane = HEAD == 1 ? (valid && rl_lane && sl.rl_index == 0) : valid;
+  static_assert(!(HEAD == 2 && MX), "the multi-agent head exists in float32 only");
+  const int obs_dim = HEAD == 1 ? 3 : (HEAD == 2 ? 6 * num_rl : 2 * N);
+  const bool obs_lane = HEAD == 1 ? (valid && rl_lane && sl.rl_index == 0) : (HEAD == 2 ? (valid && rl_lane) : valid);
+  // MultiAgentAccelPOEnv (multiagent/ring/accel.py:163-208; the reference's multiagent_figure_eight.py): an RL vehicle's
+  // block holds two terms of its FOLLOWER -- written by the follower's lane, which holds them (no lane reads backwards)
+  const int lead_col = HEAD == 2 ? __builtin_bit_cast(int, lead16(__builtin_bit_cast(float, rl_lane ? own_col : -1), wrap_lead)) : -1;
+  const bool fw_lane = HEAD == 2 && valid && lead_col >= 0;
   const unsigned valid_bits = valid ? 0x3Fu : 0u;         // flag words of idle lanes are empty
   const unsigned gate_u = gated ? 1u : 0u, cmd_rl = (rl_lane && use_act) ? 1u : 0u,
                  cmd_other = (!rl_lane && !sim_lane) ? 1u : 0u, sm1_u = unsigned(sl.speed_mode) & 1u;
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<typename std::cond
   // waits for every store issued before the wait -- with the stores at the end of the previous step the wave stood
   // still until they had landed (38 % of its life in the first version).  Issued right AFTER the wait, they have a
   // whole step to complete before the next one.
-  float po0 = 0.0f, po1 = 0.0f, po2 = 0.0f;              // pending observation values of the previous step
+  float po0 = 0.0f, po1 = 0.0f, po2 = 0.0f, po3 = 0.0f, po5 = 0.0f;   // pending observation values of the previous step
   bool pend_obs = false;
   float prew = 0.0f;                                      // pending reward / done of the previous block
   uint8_t pdone = 0;
@@ -285,10 +290,16 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<typename std::cond
 #ifndef FS_DIAG_LOOP_NOSTORE                                // timing experiment only
       if (obs_lane) {
         if (HEAD == 1) { orow[0] = po0; orow[1] = po1; orow[2] = po2; }
+        else if (HEAD == 2) { float* o = orow + 6 * own_col; o[0] = po0; o[1] = po1; o[2] = po2; o[3] = po3; }
         else { orow[ii] = po0; orow[N + ii] = po1; }
       }
+      if (HEAD == 2 && fw_lane) {                          // (v_rl - v_me) / v_max is this lane's own third value
+        float* o = orow + 6 * lead_col;
+        o[4] = po2;
+        o[5] = po5;
+      }
 #else
-      asm volatile("" :: "v"(po0), "v"(po1), "v"(po2));
+      asm volatile("" :: "v"(po0), "v"(po1), "v"(po2), "v"(po3), "v"(po5));
 #endif
       orow += obs_step;
       pend_obs = false;
@@ -440,7 +451,8 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<typename std::cond
         unsigned long long adv_m = ballot_here(x >= n_next);     // a third start passed / one passed after a wrap (rare)
         f2 = seg_or<SEG>(f2);
         jf = (f2 >> 4) & 3u;
-        const unsigned crashed = (f2 | ((f2 >> 1) & (f2 >> 2))) & 1u;       // (f2 & 1) || ((f2 & 6) == 6)
+        // (f2 & 1) || ((f2 & 6) == 6); the multi-agent head sees no crash (multiagent/base.py:188-190)
+        const unsigned crashed = HEAD == 2 ? 0u : (f2 | ((f2 >> 1) & (f2 >> 2))) & 1u;
         const unsigned bad = ((f2 >> 3) | crashed) & 1u;
         crash_bits |= crashed << slot;
         bad_bits |= bad << slot;
@@ -473,6 +485,16 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<typename std::cond
             a = tabs(hmin(hmax(T(a_red), clip_lo), clip_hi));
           }
           red2[slot] = a;
+        } else if constexpr (HEAD == 2) {
+          const T xo = c_fs + c_sl * (x - c_st);
+          const T xol = lead16(xo, wrap_lead);
+          po0 = divc(xo, d_L);
+          po1 = divc(v, d_ms);
+          po2 = divc(vl - v, d_ms);
+          po3 = divc((xol - xo) - len_me, d_L);                  // (:186-188: no wrap-around, the ego's length)
+          po5 = divc(h, d_L);                                    // get_headway(follower): for the leader's block
+          const T dv = valid ? T(v) - target_v : T(0);
+          red[slot] = dv * dv;
         } else {
           const X xo = c_fs + c_sl * (x - c_st);
           if constexpr (MX) {

@@ -138,7 +138,8 @@ namespace fsim {
       constexpr bool MX = !std::is_same<T, float>::value;
       const int f = dv.flags;
       if (!MX || mixed) {
-      const bool head_ok = (dv.env == FS_ENV_ACCEL && !dv.evaluate) || dv.env == FS_ENV_WAVE_ATTENUATION_PO;
+      const bool ma_loop = !MX && dv.env == FS_ENV_ACCEL_PO_MA;        // MultiAgentAccelPOEnv (multiagent_figure_eight.py)
+      const bool head_ok = (dv.env == FS_ENV_ACCEL && !dv.evaluate) || dv.env == FS_ENV_WAVE_ATTENUATION_PO || ma_loop;
       if (dv.nseg > 0 && (f & fs::FLAG_IDM_SET) && !(f & fs::FLAG_HAS_FAILSAFE) && head_ok &&
           dv.integrator == FS_EULER && dv.sims_per_step == 1 && mask == nullptr &&
           !dv.sort_vehicles && dv.obs_perm == nullptr && num_steps > 0 && (obs_every_step || num_steps == 1) &&
@@ -151,7 +152,15 @@ namespace fsim {
                      obs, rew, done)
         const bool full = (f & fs::FLAG_HAS_NOISE) && (f & fs::FLAG_NEED_SUMO) && dv.junction_on && actions != nullptr &&
                           loop_delta4 && !no_loop_full && loop_fastc_ok();
-        if (full) {
+        if (ma_loop) {
+          if constexpr (!MX) {
+            last_kernel = full ? "k_rollout_loop<FULL,AccelMA>" : "k_rollout_loop<AccelMA>";
+            if (full) hipLaunchKernelGGL((fs::k_rollout_loop<2, true, true, false>), grid, block, 0, stream, dv, num_steps,
+                                         actions, act_stride, obs, rew, done);
+            else if (loop_delta4) FS_LOOP(2, true);
+            else FS_LOOP(2, false);
+          }
+        } else if (full) {
           last_kernel = "k_rollout_loop<FULL>";
           if (dv.env == FS_ENV_ACCEL)
             hipLaunchKernelGGL((fs::k_rollout_loop<0, true, true, MX>), grid, block, 0, stream, dv, num_steps, actions,
@@ -172,10 +181,12 @@ namespace fsim {
     // and zero-step launches included; the all-IDM AccelEnv rollout keeps its hand-written kernel below
     {
       const int f = dv.flags;
+      const bool ma_head = dv.env == FS_ENV_WAVE_ATTENUATION_PO_MA || dv.env == FS_ENV_ACCEL_PO_MA;   // float32 only
       const bool ring_rl_ok = dv.nseg == 0 && !dv.junction_on && (f & fs::FLAG_IDM_SET) && !any_sim &&
                               !(f & fs::FLAG_HAS_FAILSAFE) && dv.sims_per_step == 1 && dv.integrator == FS_EULER &&
                               !dv.junction_mode && !dv.track_aux && !dv.sort_vehicles && dv.obs_perm == nullptr &&
-                              !dv.evaluate && (dv.env == FS_ENV_ACCEL || dv.env == FS_ENV_WAVE_ATTENUATION_PO) &&
+                              !dv.evaluate &&
+                              (dv.env == FS_ENV_ACCEL || dv.env == FS_ENV_WAVE_ATTENUATION_PO || (ma_head && !mixed)) &&
                               dv.N >= 2 && (dv.N % 2) == 0 && !force_generic && !no_ring_rl &&
                               (!(f & fs::FLAG_HAS_NOISE) || pair_noise || mixed);
       if (ring_rl_ok && !(pair_ok && (mixed || std::is_same<T, float>::value)) && (mixed || std::is_same<T, float>::value)) {
@@ -183,18 +194,29 @@ namespace fsim {
         const int waves = (dv.R + (64 / ROW) - 1) / (64 / ROW);
         const dim3 grid((waves + 3) / 4), block(256);
         const bool po = dv.env == FS_ENV_WAVE_ATTENUATION_PO;
-        last_kernel = po ? "k_ring_pair<PO>" : "k_ring_pair<Accel>";
-#define FS_RING(H_, NZ_, FA_)                                                                                    \
-  hipLaunchKernelGGL((fs::k_ring_pair<T, ROW, H_, NZ_, FA_>), grid, block, 0, stream, dv, num_steps, mask, actions,   \
+        // MC: the 16-step group form with several action columns (rows of 16 lanes only: 17..32 vehicles); the multi-agent
+        // heads of that size always take it (it also steps without actions: the warm-up steps of a reset)
+        const bool mc = ROW == 16 && std::is_same<T, float>::value && (ma_head || (actions != nullptr && dv.num_rl > 1));
+        last_kernel = ma_head ? (dv.env == FS_ENV_ACCEL_PO_MA ? "k_ring_pair<AccelMA>" : "k_ring_pair<POMA>")
+                              : (po ? "k_ring_pair<PO>" : "k_ring_pair<Accel>");
+#define FS_RING(H_, NZ_, FA_, MC_)                                                                               \
+  hipLaunchKernelGGL((fs::k_ring_pair<T, ROW, H_, NZ_, FA_, MC_>), grid, block, 0, stream, dv, num_steps, mask, actions, \
                      act_stride, obs, rew, done, obs_every_step)
-#define FS_RING_F(H_, NZ_) do { if (fast) FS_RING(H_, NZ_, true); else FS_RING(H_, NZ_, false); } while (0)
+#define FS_RING_F(H_, NZ_, MC_) do { if (fast) FS_RING(H_, NZ_, true, MC_); else FS_RING(H_, NZ_, false, MC_); } while (0)
+#define FS_RING_N(H_, MC_) do { if (f & fs::FLAG_HAS_NOISE) FS_RING_F(H_, true, MC_); else FS_RING_F(H_, false, MC_); } while (0)
         if constexpr (std::is_same<T, float>::value) {
-          if (f & fs::FLAG_HAS_NOISE) { if (po) FS_RING_F(1, true); else FS_RING_F(0, true); }
-          else { if (po) FS_RING_F(1, false); else FS_RING_F(0, false); }
+          if constexpr (ROW == 16) {
+            if (ma_head) { if (dv.env == FS_ENV_ACCEL_PO_MA) FS_RING_N(3, true); else FS_RING_N(2, true); }
+            else if (mc) { if (po) FS_RING_N(1, true); else FS_RING_N(0, true); }
+            else { if (po) FS_RING_N(1, false); else FS_RING_N(0, false); }
+          } else {
+            if (ma_head) { if (dv.env == FS_ENV_ACCEL_PO_MA) FS_RING_N(3, false); else FS_RING_N(2, false); }
+            else { if (po) FS_RING_N(1, false); else FS_RING_N(0, false); }
+          }
         } else {
-          if (f & fs::FLAG_HAS_NOISE) { if (po) FS_RING_F(1, true); else FS_RING_F(0, true); }
-          else { if (po) FS_RING_F(1, false); else FS_RING_F(0, false); }
+          if (po) FS_RING_N(1, false); else FS_RING_N(0, false);
         }
+#undef FS_RING_N
 #undef FS_RING_F
 #undef FS_RING
         HIP_TRY(hipGetLastError());

@@ -9,7 +9,12 @@
 //   * RL slots: the acceleration is the (clipped) action of the slot's column, read from an action tape [K, R, num_rl]
 //     one step ahead; without actions (warm-up steps, envs/base.py:554-555) an RL vehicle is uncommanded and follows
 //     SUMO's car-following model (S5/S7), like in k_steps;
-//   * the heads: HEAD 0 AccelEnv (accel.py:109-123), HEAD 1 WaveAttenuationPOEnv (wave_attenuation.py:113-139, 248-269);
+//   * the heads: HEAD 0 AccelEnv (accel.py:109-123), HEAD 1 WaveAttenuationPOEnv (wave_attenuation.py:113-139, 248-269),
+//     HEAD 2 MultiAgentWaveAttenuationPOEnv (multiagent/ring/wave_attenuation.py:128-252: the reference's
+//     examples/exp_configs/rl/multiagent/multiagent_ring.py), HEAD 3 MultiAgentAccelPOEnv (multiagent/ring/accel.py:84-227);
+//     the multi-agent heads (float32 only) see no crash (multiagent/base.py:188-190);
+//   * MC: several action columns in the 16-step group form (every lane reads the columns of its own slots and of its
+//     places in the reward's reduction four steps ahead, into the register the step four steps earlier has consumed);
 //   * everything a reset needs: a replica mask (masked replicas alone advance), zero-step launches (observation of the
 //     current state), observation at the last step only -- so a FS_MIXED handle can run the warm-up steps of
 //     Env.reset in ITS arithmetic and the whole closed-loop path holds the 1e-4 trajectory bar.
@@ -30,12 +35,15 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <typename T, int ROW, int HEAD, bool NOISE, bool FAST>
+template <typename T, int ROW, int HEAD, bool NOISE, bool FAST, bool MC = false>
 __global__ __launch_bounds__(256) void k_ring_pair(DevView<T> s, int num_steps_arg, const uint8_t* __restrict__ mask,
                                                    const float* __restrict__ actions, size_t act_stride,
                                                    float* __restrict__ obs, float* __restrict__ rew,
                                                    uint8_t* __restrict__ done, int obs_every_step) {
   constexpr bool MIXED = sizeof(T) == 8;
+  constexpr bool WA = HEAD == 1 || HEAD == 2;       // WaveAttenuationEnv's reward (the single- and the multi-agent head)
+  constexpr bool MA = HEAD >= 2;                    // per-agent observation blocks, crash = 0
+  static_assert(!(MA && MIXED), "the multi-agent heads exist in float32 only");
   // (FS_MIXED with noise: the float32 controller output + sigma g in float32, as in the float32 kernel; the C twin cannot
   // reproduce the hardware's log / cos, so this form is held against the float64 kernel with the same Philox streams at
   // 1e-4 instead of against a bit-twin -- tests/test_ringrl_gpu.py)
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(256) void k_ring_pair(DevView<T> s, int num_steps_a
   // replica's single action is one broadcast load per lane and step.
   const int num_rl = s.num_rl;
   const bool single_rl = num_rl == 1;                                            // wave-uniform
-  const bool redA = HEAD == 1 && valid && iA < num_rl, redB = HEAD == 1 && valid && iB < num_rl;
+  const bool redA = WA && valid && iA < num_rl, redB = WA && valid && iB < num_rl;
   float ownA_n = 0.0f, ownB_n = 0.0f, redA_n = 0.0f, redB_n = 0.0f;
   auto load_actions = [&](int step) {
     const float* a0 = actions + size_t(step) * act_stride + size_t(rr) * num_rl;
@@ -216,15 +224,65 @@ __global__ __launch_bounds__(256) void k_ring_pair(DevView<T> s, int num_steps_a
   };
 
   // ---- heads -------------------------------------------------------------------------------------------------
-  const int obs_dim = HEAD == 1 ? 3 : 2 * N;
+  const int obs_dim = HEAD == 1 ? 3 : (HEAD == 2 ? 3 * num_rl : (HEAD == 3 ? 6 * num_rl : 2 * N));
   const size_t step_rows = obs_every_step ? size_t(s.R) : 0;
   float* orow = obs + size_t(rr) * obs_dim;
   float* rrow = rew + rr;
   uint8_t* drow = done + rr;
   const bool poA = HEAD == 1 && valid && rlA && colA == 0, poB = HEAD == 1 && valid && rlB && colB == 0;
   const double rc15 = 1.0 / 15.0, pml64 = double(s.po_max_length), rc_pml64 = 1.0 / pml64;
+  // multi-agent heads: the slots of this lane that are RL vehicles, and -- MultiAgentAccelPOEnv's follower terms are
+  // written by the FOLLOWER's lane, which holds them -- the RL vehicles this lane's slots follow (A follows B, B follows
+  // the next lane's A): no lane reads backwards
+  const bool maA = MA && valid && rlA, maB = MA && valid && rlB;
+  const int col_nextA = MA ? __builtin_bit_cast(int, next_a<ROW>(__builtin_bit_cast(float, rlA ? colA : -1), last, lane)) : -1;      // column of B's leader, -1: not an RL vehicle
+  const bool fwB = HEAD == 3 && valid && col_nextA >= 0;
+  const double Lq64 = double(Lf), rc_Lq64 = 1.0 / Lq64;
+  const float len_meA = float(s.length[iA]), len_meB = float(lenB);
   auto write_obs = [&]() {
-    if (HEAD == 1) {
+    if constexpr (HEAD == 2) {
+      // MultiAgentWaveAttenuationPOEnv.get_state (multiagent/ring/wave_attenuation.py:188-208): per RL vehicle, at column
+      // rl_index, [v / 15, (v_lead - v) / 15, headway / max_length] (get_headway: bumper to bumper).  The lane's RL
+      // half is selected first; a lane with two RL vehicles writes A's block in a second region
+      if (maA || maB) {
+        const float v_me = maB ? v.y : v.x, v_ld = maB ? vl.y : vl.x, h_me = maB ? h.y : h.x;
+        float* o = orow + 3 * (maB ? colB : colA);
+        o[0] = div_via_f64(v_me, 15.0, rc15);
+        o[1] = div_via_f64(v_ld - v_me, 15.0, rc15);
+        o[2] = div_via_f64(h_me, pml64, rc_pml64);
+      }
+      if (maA && maB) {
+        float* o = orow + 3 * colA;
+        o[0] = div_via_f64(v.x, 15.0, rc15);
+        o[1] = div_via_f64(vl.x - v.x, 15.0, rc15);
+        o[2] = div_via_f64(h.x, pml64, rc_pml64);
+      }
+    } else if constexpr (HEAD == 3) {
+      // MultiAgentAccelPOEnv.get_state (multiagent/ring/accel.py:163-208): per RL vehicle [x / L, v / v_max,
+      // (v_lead - v) / v_max, (x_lead - x - len_ego) / L (no wrap-around), (v - v_follow) / v_max, headway(follower) / L]
+      const float xn = next_a<ROW>(x.x, last, lane);                  // position of B's leader
+      if (maA) {
+        float* o = orow + 6 * colA;
+        o[0] = div_via_f64(x.x, Lq64, rc_Lq64);
+        o[1] = div_via_f64(v.x, ms64, rc_ms64);
+        o[2] = div_via_f64(vl.x - v.x, ms64, rc_ms64);
+        o[3] = div_via_f64((x.y - x.x) - len_meA, Lq64, rc_Lq64);
+      }
+      if (maB) {
+        float* o = orow + 6 * colB;
+        o[0] = div_via_f64(x.y, Lq64, rc_Lq64);
+        o[1] = div_via_f64(v.y, ms64, rc_ms64);
+        o[2] = div_via_f64(vl.y - v.y, ms64, rc_ms64);
+        o[3] = div_via_f64((xn - x.y) - len_meB, Lq64, rc_Lq64);
+        o[4] = div_via_f64(v.y - v.x, ms64, rc_ms64);                 // B's follower is A
+        o[5] = div_via_f64(h.x, Lq64, rc_Lq64);
+      }
+      if (fwB) {                                                      // B follows the RL vehicle in the next lane's slot A
+        float* o = orow + 6 * col_nextA;
+        o[4] = div_via_f64(vl.y - v.y, ms64, rc_ms64);
+        o[5] = div_via_f64(h.y, Lq64, rc_Lq64);
+      }
+    } else if (HEAD == 1) {
       // WaveAttenuationPOEnv.get_state (wave_attenuation.py:248-269), written by the lane of the RL vehicle of column 0
       // (its half selected first: one exec-mask region, three quotients)
       if (MIXED) {
@@ -330,7 +388,7 @@ __global__ __launch_bounds__(256) void k_ring_pair(DevView<T> s, int num_steps_a
     const f2 hc = pk_sub(h, gap2), vb = pk_sub(v, f2{-100.0f, -100.0f});
     fl = ((__builtin_bit_cast(unsigned, hmin(hc.x, hc.y)) >> 31) | ((__builtin_bit_cast(unsigned, hmin(vb.x, vb.y)) >> 31) << 1)) &
          (valid ? 3u : 0u);
-    if (HEAD == 1) {
+    if (WA) {
       t0 = valid ? v.x + v.y : 0.0f;
       const float caA = tabs(clip(aredA)), caB = tabs(clip(aredB));
       t1 = (redA ? caA : 0.0f) + (redB ? caB : 0.0f);
@@ -343,9 +401,9 @@ __global__ __launch_bounds__(256) void k_ring_pair(DevView<T> s, int num_steps_a
   };
   // reward and done flag of one step from its reduced terms
   auto finish = [&](unsigned fany, float s0, float s1, bool live, int t_after, float& reward, uint8_t& dflag) {
-    const bool crashed = live && (fany & 1u) != 0u;
+    const bool crashed = !MA && live && (fany & 1u) != 0u;          // (multiagent/base.py:188-190: crash = 0)
     const bool bad = (fany & 2u) != 0u || crashed;
-    if (HEAD == 1) {                                           // wave_attenuation.py:113-139
+    if (WA) {                                           // wave_attenuation.py:113-139
       const float mean_v = div_via_f64(s0, double(N), 1.0 / double(N));
       const float mean_a = div_via_f64(s1, double(num_rl), 1.0 / double(num_rl));
       reward = div_via_f64(4.0f * mean_v, 20.0, 1.0 / 20.0);
@@ -374,7 +432,7 @@ __global__ __launch_bounds__(256) void k_ring_pair(DevView<T> s, int num_steps_a
       terms(aredA, aredB, fl, t0, t1);
       const unsigned fany = seg_or<ROW>(fl);
       write_obs();
-      const float s0 = seg_sum<ROW>(t0), s1 = HEAD == 1 ? seg_sum<ROW>(t1) : 0.0f;
+      const float s0 = seg_sum<ROW>(t0), s1 = WA ? seg_sum<ROW>(t1) : 0.0f;
       float reward;
       uint8_t dflag;
       finish(fany, s0, s1, live_replica, tcount, reward, dflag);
@@ -400,7 +458,7 @@ __global__ __launch_bounds__(256) void k_ring_pair(DevView<T> s, int num_steps_a
   // Kept small on purpose: sixteen unrolled steps with their Philox evaluations were 11 000 instructions, past the
   // instruction cache, and ran at the speed of the single-step loop.
   constexpr bool GROUPS = ROW == 16;
-  if (GROUPS && obs_every_step && mask == nullptr && (single_rl || !have_act)) {
+  if (GROUPS && obs_every_step && mask == nullptr && (single_rl || !have_act || MC)) {
     if constexpr (NOISE) {
 #pragma unroll 1
       while (step < num_steps && (nctr & 3u) != 0u) {
@@ -408,7 +466,27 @@ __global__ __launch_bounds__(256) void k_ring_pair(DevView<T> s, int num_steps_a
         step += 1;
       }
     }
-    const bool deep = single_rl && have_act;
+    const bool deep = !MC && single_rl && have_act;
+    // MC: the action columns of the lane's roles (its slots' commands, its places in the reward's sum), four steps ahead:
+    // slot q of a block holds step (block start + q), refilled with step + 4 as soon as the step has taken its values.
+    // Every lane loads (a role it does not hold reads column 0: no exec-mask region); only the roles' values are used.
+    float qA[4] = {0.0f, 0.0f, 0.0f, 0.0f}, qB[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float qrA[4] = {0.0f, 0.0f, 0.0f, 0.0f}, qrB[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int rcA = redA ? iA : 0, rcB = redB ? iB : 0;
+    const bool mc_act = MC && have_act;
+    const float* mc_p = actions + size_t(rr) * num_rl;
+    if (mc_act) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (step + q < num_steps) {
+          const float* a0 = mc_p + size_t(step + q) * act_stride;
+          qA[q] = a0[colA];
+          qB[q] = a0[colB];
+          if (WA) { qrA[q] = a0[rcA]; qrB[q] = a0[rcB]; }
+        }
+      }
+      mc_p += size_t(step + 4) * act_stride;
+    }
     auto group_actions = [&](int first) -> float {
       const int st = first + k < num_steps ? first + k : num_steps - 1;
       return actions[size_t(st) * act_stride + size_t(rr)];
@@ -457,7 +535,17 @@ __global__ __launch_bounds__(256) void k_ring_pair(DevView<T> s, int num_steps_a
             nz.x = noisyA ? tA : -0.0f;
             nz.y = noisyB ? tB : -0.0f;
           }
-          advance(std::true_type{}, a, a, nz);
+          const float oA = MC ? qA[slot] : a, oB = MC ? qB[slot] : a;
+          const float rA = MC ? qrA[slot] : a, rB = MC ? qrB[slot] : 0.0f;
+          if constexpr (MC) {
+            if (mc_act && step + 4 * blk + slot + 4 < num_steps) {     // wave-uniform
+              qA[slot] = mc_p[colA];
+              qB[slot] = mc_p[colB];
+              if (WA) { qrA[slot] = mc_p[rcA]; qrB[slot] = mc_p[rcB]; }
+            }
+            mc_p += act_stride;
+          }
+          advance(std::true_type{}, oA, oB, nz);
           if constexpr (PO_ROWS) {
             const float v_me = poB ? v.y : v.x, v_ld = poB ? vl.y : vl.x, d_me = poB ? dgap.y : dgap.x;
             po_push(v_me);
@@ -468,7 +556,7 @@ __global__ __launch_bounds__(256) void k_ring_pair(DevView<T> s, int num_steps_a
             orow += step_rows * obs_dim;
           }
           unsigned fl;
-          terms(a, 0.0f, fl, t0[slot], t1[slot]);
+          terms(rA, rB, fl, t0[slot], t1[slot]);
           crash_bits = (crash_bits << 1) | (fl & 1u);
           bad_bits = (bad_bits << 1) | (fl >> 1);
         });
@@ -478,7 +566,7 @@ __global__ __launch_bounds__(256) void k_ring_pair(DevView<T> s, int num_steps_a
           orow += size_t(4) * step_rows * obs_dim;
         }
         const float s0 = transposed_sum<ROW, 4>(t0, lane);
-        const float s1 = HEAD == 1 ? transposed_sum<ROW, 4>(t1, lane) : 0.0f;
+        const float s1 = WA ? transposed_sum<ROW, 4>(t1, lane) : 0.0f;
         const unsigned crash_any = seg_or<ROW>(crash_bits), bad_any = seg_or<ROW>(bad_bits);
         if (k < 4) {                                           // lane k finishes step k of the block
           const unsigned fany = ((crash_any >> (3 - k)) & 1u) | (((bad_any >> (3 - k)) & 1u) << 1);

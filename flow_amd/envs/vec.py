@@ -6,6 +6,7 @@ Here the R replicas are rows of [R, N] arrays in HBM advanced by one launch;
 observations, rewards and done flags stay on the device as torch tensors so a
 learner on the same GPU consumes them without a host copy.
 """
+import os
 from copy import deepcopy
 
 from flow_amd import _lib as L
@@ -59,7 +60,7 @@ class VecFlowEnv(object):
         self._done = torch.zeros((R,), dtype=torch.uint8, device=self.device)
         import numpy as np
         self._resample = env.env_params.additional_params.get('ring_length', None) is not None \
-            and env.FS_ENV in (L.FS_ENV_WAVE_ATTENUATION, L.FS_ENV_WAVE_ATTENUATION_PO)
+            and env.FS_ENV in (L.FS_ENV_WAVE_ATTENUATION, L.FS_ENV_WAVE_ATTENUATION_PO, L.FS_ENV_WAVE_ATTENUATION_PO_MA)
         self._rng = np.random.default_rng(sim_params.seed)
         self._placement_cache = {}
         self.use_current_stream()
@@ -193,10 +194,13 @@ class VecFlowEnv(object):
             why.append("use_ballistic=True")
         if sp.get("obs_perm") is not None:
             why.append("InitialConfig(shuffle=True) / a placement that is not in driving order")
-        if self.env.FS_ENV in (L.FS_ENV_WAVE_ATTENUATION_PO_MA, L.FS_ENV_ACCEL_PO_MA):
-            why.append("a multi-agent ring head (%s)" % type(self.env).__name__)
-        elif self.env.FS_ENV not in (L.FS_ENV_ACCEL, L.FS_ENV_WAVE_ATTENUATION_PO):
+        heads = [L.FS_ENV_ACCEL, L.FS_ENV_WAVE_ATTENUATION_PO, L.FS_ENV_ACCEL_PO_MA]
+        if not sp.get("segments"):
+            heads.append(L.FS_ENV_WAVE_ATTENUATION_PO_MA)
+        if self.env.FS_ENV not in heads:
             why.append("the environment head of %s" % type(self.env).__name__)
+        if os.environ.get("FLOWSIM_FORCE_GENERIC") == "1":
+            why.append("FLOWSIM_FORCE_GENERIC=1")
         return why
 
     def _warn_if_generic(self):

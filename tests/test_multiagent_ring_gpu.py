@@ -168,3 +168,118 @@ def test_reference_multi_agent_figure_eight_experiments_construct_and_step(name)
     o = vec.reset()
     assert tuple(o.shape) == (16, vec.obs_dim) and vec.obs_dim == (28 if name.startswith("adversarial") else 12)
     vec.close()
+
+
+# ---- the multi-agent experiments on the rollout kernels -----------------------------------------
+def _ma_rollout(spec, K, acts, env=None):
+    from test_parity_gpu import _rollout
+    return _rollout(spec, K, acts, env=env)
+
+
+def ma_ring_experiment_spec(env, R, rl_slots, noise, seed=0, N=22):
+    """multiagent_ring.py's population: 22 vehicles, IDM(noise = 0.2, min_gap = 0) humans, RL vehicles spread over the
+    ring, clip_actions = False, a ring length per replica."""
+    spec = ma_spec(env, R=R, N=N, rl_slots=rl_slots, seed=seed, warmup_steps=0)
+    rng = np.random.default_rng(seed + 1)
+    spec["ring_length"] = rng.uniform(220.0, 270.0, R)
+    spec["init_pos"] = np.sort(rng.uniform(0, 1, (R, N)), axis=1) * 30.0 + np.arange(N) * (spec["ring_length"][:, None] - 31.0) / N
+    spec["horizon"] = 60
+    for i, v in enumerate(spec["vehicles"]):
+        if v["controller"] != S.CTRL_RL:
+            v["noise"] = noise
+            v["sumo_min_gap"] = 0.0
+    spec["seed"] = 11
+    return spec
+
+
+@pytest.mark.parametrize("env,name", [(S.ENV_WAVE_ATTENUATION_PO_MA, "k_ring_pair<POMA>"), (S.ENV_ACCEL_PO_MA, "k_ring_pair<AccelMA>")])
+@pytest.mark.parametrize("rl_slots", [(0, 11), (4, 5, 13, 21), (3,)])
+def test_multi_agent_ring_rollouts_run_on_the_pair_kernel_bit_exact(env, name, rl_slots):
+    """The multi-agent ring heads in k_ring_pair's 16-step group form with one action column per agent: equal to the
+    generic k_steps bit for bit (noise included), equal to the oracle without noise; RL vehicles in both halves of a
+    lane, next to each other ((4, 5): one lane; (13, ...): B of lane 6; (21, 0)-style wrap through slot 21), columns not
+    in slot order; 70 steps = four groups + a remainder, across the horizon; then a second launch mid-block."""
+    K, R = 70, 9
+    acts = np.random.default_rng(5).uniform(-1.5, 1.5, (K, R, len(rl_slots))).astype(np.float32)
+    noisy = ma_ring_experiment_spec(env, R, rl_slots, noise=0.2)
+    a, oa, ra, da = _ma_rollout(noisy, K, acts)
+    b, ob, rb, db = _ma_rollout(noisy, K, acts, env={"FLOWSIM_FORCE_GENERIC": "1"})
+    assert a.last_kernel == name and b.last_kernel.startswith("k_steps")
+    np.testing.assert_array_equal(oa, ob)
+    np.testing.assert_array_equal(ra, rb)
+    np.testing.assert_array_equal(da, db)
+    assert not np.isnan(oa).any() and da[59].all() and not da[:59].any()
+    from test_parity_gpu import _continue
+    o2, r2, _ = _continue(a, 23, acts[:23])
+    o3, r3, _ = _continue(b, 23, acts[:23])
+    np.testing.assert_array_equal(o2, o3)
+    np.testing.assert_array_equal(r2, r3)
+    np.testing.assert_array_equal(a.pos, b.pos)
+    np.testing.assert_array_equal(a.vel, b.vel)
+    a.close(), b.close()
+    quiet = ma_ring_experiment_spec(env, R, rl_slots, noise=0.0)
+    c, oc, rc, dc = _ma_rollout(quiet, K, acts)
+    assert c.last_kernel == name
+    ora = S.RingOracle(quiet, np.float32)
+    ora.reset()
+    for k in range(K):
+        o_ref, r_ref, d_ref = ora.step(acts[k])
+        np.testing.assert_array_equal(oc[k], o_ref.astype(np.float32), err_msg="obs, step %d" % k)
+        np.testing.assert_array_equal(rc[k], r_ref.astype(np.float32), err_msg="reward, step %d" % k)
+        np.testing.assert_array_equal(dc[k].astype(bool), d_ref)
+    np.testing.assert_array_equal(c.pos, ora.x)
+    c.close()
+
+
+@pytest.mark.parametrize("head", [S.ENV_ACCEL, S.ENV_WAVE_ATTENUATION_PO])
+def test_several_action_columns_stay_in_the_group_form_of_the_single_agent_heads(head):
+    """AccelEnv / WaveAttenuationPOEnv with three RL vehicles: the rollout keeps k_ring_pair's group form (MC) and its bits."""
+    K, R, rl_slots = 50, 6, (2, 9, 16)
+    spec = ma_ring_experiment_spec(S.ENV_ACCEL_PO_MA, R, rl_slots, noise=0.2)
+    spec["env"] = head
+    acts = np.random.default_rng(6).uniform(-1.5, 1.5, (K, R, 3)).astype(np.float32)
+    a, oa, ra, da = _ma_rollout(spec, K, acts)
+    b, ob, rb, db = _ma_rollout(spec, K, acts, env={"FLOWSIM_FORCE_GENERIC": "1"})
+    assert a.last_kernel.startswith("k_ring_pair") and b.last_kernel.startswith("k_steps")
+    np.testing.assert_array_equal(oa, ob)
+    np.testing.assert_array_equal(ra, rb)
+    np.testing.assert_array_equal(da, db)
+    np.testing.assert_array_equal(a.pos, b.pos)
+    a.close(), b.close()
+
+
+def test_multi_agent_figure_eight_runs_on_the_loop_rollout_kernel_bit_exact():
+    """multiagent_figure_eight.py's population (2 x (6 noisy IDM + 1 RL), obey_safe_speed, MultiAgentAccelPOEnv) on
+    k_rollout_loop: observations (12), the shared reward and the state equal the generic k_steps bit for bit; a crash at
+    the crossing ends nothing (multiagent/base.py:188-190)."""
+    from helpers import figure_eight_spec
+    R, N, K = 21, 14, 150
+    spec = figure_eight_spec(R=R, N=N, horizon=120, seed=5, num_rl=2, env=S.ENV_ACCEL_PO_MA)
+    veh = []
+    for g in range(2):
+        veh += [idm_vehicle(speed_mode=1, max_decel=1.5, noise=0.2) for _ in range(6)]
+        veh.append(idm_vehicle(controller=S.CTRL_RL, rl_index=1 - g, speed_mode=1, max_accel=3.0, max_decel=3.0))
+    spec["vehicles"] = veh
+    spec["seed"] = 31
+    acts = np.random.default_rng(9).uniform(-3, 3, (K, R, 2)).astype(np.float32)
+    a, oa, ra, da = _ma_rollout(spec, K, acts)
+    b, ob, rb, db = _ma_rollout(spec, K, acts, env={"FLOWSIM_NO_LOOP_KERNEL": "1"})
+    f, of, rf, df = _ma_rollout(spec, K, acts, env={"FLOWSIM_NO_LOOP_FULL": "1"})
+    assert a.last_kernel == "k_rollout_loop<FULL,AccelMA>" and f.last_kernel == "k_rollout_loop<AccelMA>"
+    assert b.last_kernel.startswith("k_steps")
+    for o, r, d, sim in ((ob, rb, db, b), (of, rf, df, f)):
+        np.testing.assert_array_equal(oa, o)
+        np.testing.assert_array_equal(ra, r)
+        np.testing.assert_array_equal(da, d)
+        np.testing.assert_array_equal(a.pos, sim.pos)
+        np.testing.assert_array_equal(a.vel, sim.vel)
+    assert oa.shape[2] == 12 and not np.isnan(oa).any() and da.max() == 1
+    a.close(), b.close(), f.close()
+    hostile_spec = dict(spec, horizon=10 ** 6, vehicles=[dict(v, speed_mode=0) for v in veh])
+    hostile = np.full((260, R, 2), 3.0, dtype=np.float32)
+    c, oc, rc, dc = _ma_rollout(hostile_spec, 260, hostile)
+    e, oe, re_, de = _ma_rollout(hostile_spec, 260, hostile, env={"FLOWSIM_NO_LOOP_KERNEL": "1"})
+    np.testing.assert_array_equal(oc, oe)
+    np.testing.assert_array_equal(rc, re_)
+    assert not dc.any() and not de.any()
+    c.close(), e.close()
