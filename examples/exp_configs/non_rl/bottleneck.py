@@ -1,7 +1,7 @@
 """Congestion forming at a lane drop (the experiment of the reference's examples/exp_configs/non_rl/bottleneck.py):
 2300 veh/h enter four lanes that narrow to two and then to one; toll booth and ramp meter are off.  The vehicles'
 lane_change_mode (1621) lets the simulator change lanes: flow_amd runs its simplified lane-change model for them
-(DESIGN.md M11 -- not SUMO's LC2013).  Written against the `flow` names; examples/simulate.py maps them."""
+(docs/HISTORY.md M11 -- not SUMO's LC2013).  Written against the `flow` names; examples/simulate.py maps them."""
 from flow.controllers import ContinuousRouter, SimLaneChangeController
 from flow.core.params import (EnvParams, InFlows, InitialConfig, NetParams, SumoCarFollowingParams,
                               SumoLaneChangeParams, SumoParams, TrafficLightParams, VehicleParams)

@@ -158,7 +158,7 @@ class NetworkKernel(object):
         return segs
 
     def crossing_model(self, vehicle_length=5.0, half_width=0.9, time_gap=3.0):
-        """fs_config.junction of a self-crossing loop, None otherwise."""
+        """fs_config.junction of a self-crossing loop (docs/HISTORY.md S-J), None otherwise."""
         cr = self.network.specify_crossing()
         if cr is None or self.loop_starts is None:
             return None

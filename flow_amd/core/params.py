@@ -164,18 +164,18 @@ class SimParams(object):
 class SumoParams(SimParams):
     """flow/core/params.py:510-617.  Extra, GPU-simulator-only keywords (all optional):
 
-    slowdown_ramp   None -> dt/(dt+1e-3): the ramp of TraCI slowDown(v, 1e-3); 1.0 = exact
+    slowdown_ramp   None -> dt/(dt+1e-3): the ramp of TraCI slowDown(v, 1e-3) (docs/HISTORY.md S6); 1.0 = exact
     junction_mode   1 -> vehicles on internal edges get no Flow command (base_controller.py:98-99);
                     None -> 0 on a ring (0.1 m junctions, treated as seamless), 1 on a figure eight
     center_length   length of the ':center_*' internal edges of a figure eight (None -> 9.4, the
                     netconvert value in the reference's fixture)
-    crossing_time_gap  right-of-way model of the figure-eight crossing / the merge junction:
+    crossing_time_gap  right-of-way model of the figure-eight crossing / the merge junction (docs/HISTORY.md S-J, M6):
                     None -> 3.0 s on a figure eight, 1.0 s on a merge
     max_vehicles    open networks: vehicle slots per replica (<= 64; <= 256 on BottleneckNetwork), shared out over the vehicle types
     slot_capacity   open networks: {vehicle type: slots}, overrides the default share-out
     merge_right_of_way  open networks: False switches the junction priority model off
     zipper_distance lane-drop networks: distance before a zipper junction from which a vehicle follows the nearest
-                    vehicle of either joining lane
+                    vehicle of either joining lane (docs/HISTORY.md M8)
     lane_change_cooldown / lane_change_min_gain  lane-drop networks: seconds a vehicle keeps its lane after a change /
                     leader-gap gain [m] a change must bring, for vehicle types whose lane_change_mode lets SUMO change
                     lanes (the simplified model M11, NOT LC2013)

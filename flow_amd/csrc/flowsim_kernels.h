@@ -1,7 +1,7 @@
 // flowsim_kernels.h -- device code of libflowsim: the fused batched step kernel
 // for closed single-lane routes (RingNetwork), written for gfx950 (CDNA4).
 //
-// Mapping (DESIGN.md "k_steps"): one 64-lane wavefront carries 64/SEG replicas,
+// Mapping (docs/HISTORY.md "k_steps"): one 64-lane wavefront carries 64/SEG replicas,
 // SEG = smallest power of two >= N (vehicles per replica); lane = seg*SEG + i
 // holds vehicle i of its replica in registers for the whole launch.  The leader
 // of slot i on a closed single-lane loop is slot i+1 (cyclic), so the

@@ -71,7 +71,7 @@ struct SimBase {
   int after_reset = 0;          // open networks: the next zero-step launch follows a reset (update(reset=True))
   bool force_generic = false;   // FLOWSIM_FORCE_GENERIC=1: never take the specialised kernels (tests)
   bool no_fastdiv = false;      // FLOWSIM_NO_FASTDIV=1: keep the IEEE division sequence in k_rollout_idm
-  int rollout_block = 512;      // threads per block of k_rollout_idm (FLOWSIM_ROLLOUT_BLOCK overrides; sweep: DESIGN.md)
+  int rollout_block = 512;      // threads per block of k_rollout_idm (FLOWSIM_ROLLOUT_BLOCK overrides; sweep: docs/HISTORY.md)
   bool f16s = false;            // FS_F16S: the state between launches is kept as halves (DevView::st16)
   bool mixed = false;           // FS_MIXED: float64 state, float32 controller arithmetic (k_rollout_pair<double>)
   bool no_pair = false;         // FLOWSIM_NO_PAIR=1: keep k_rollout_idm (one vehicle per lane) for the float rollout

@@ -33,7 +33,7 @@ class MergePOEnv(Env):
 
     As in the reference, ``rl_veh`` survives ``reset`` (merge.py:223-231 never clears it: the entries of the last
     episode open the next one as rows of error values) and the loop that drops departed entries skips the entry behind
-    each one it removes (merge.py:208-210 removes from the list it iterates); DESIGN.md O2."""
+    each one it removes (merge.py:208-210 removes from the list it iterates); docs/HISTORY.md O2."""
 
     FS_ENV = L.FS_ENV_MERGE_PO
 

@@ -197,7 +197,7 @@ typedef struct fs_inflow {
                                          generated vehicles wait their turn like due ones (M2b, Philox-drawn) */
 } fs_inflow;
 
-/* The self-crossing of the figure eight (SUMO's junction logic restated, unpinned).
+/* The self-crossing of the figure eight (docs/HISTORY.md S-J; SUMO's junction logic restated, unpinned).
  * Stream a (bottom->top, priority 78) crosses stream b (right->left, priority 46),
  * flow/networks/figure_eight.py:126-154. */
 typedef struct fs_junction {
@@ -229,7 +229,7 @@ typedef struct fs_vehicle_spec {
   int32_t type;                       /* open networks: index of the vehicle type (VehicleParams.add order) */
   int32_t lane_change_mode;           /* SumoLaneChangeParams.lane_change_mode of the type; FS_NET_BOTTLENECK: a strategic /
                                          cooperative / speed-gain / keep-right bit (mode & 0x55) switches the simplified
-                                         lane-change model on for this vehicle */
+                                         lane-change model on for this vehicle (docs/HISTORY.md M11) */
   double p[FS_MAX_CTRL_PARAMS];       /* controller parameters, see enum fs_controller */
   double noise;                       /* sigma of the Gaussian acceleration noise */
   double delay;                       /* delay used by the safe_velocity fail-safe */
@@ -310,7 +310,7 @@ typedef struct fs_config {
                                          merge observations and BCM); 0 = skip them (the bottleneck envs never read them) */
   int32_t num_paths;                  /* FS_NET_BOTTLENECK: entry lanes = 4 * scaling: 4 (0 = 4) or 8 (8 -> 4 -> 2 lanes;
                                          needs num_vehicles > 64, i.e. the workgroup-per-replica kernel) */
-  /* ---- simplified lane changing on FS_NET_BOTTLENECK ---- */
+  /* ---- simplified lane changing on FS_NET_BOTTLENECK (docs/HISTORY.md M11) ---- */
   int32_t lane_change_cooldown_steps; /* sub-steps a vehicle keeps its lane after a change */
   int32_t reserved6;
   double lane_change_min_gain;        /* leader-gap gain [m] a lane change must bring */
@@ -391,17 +391,25 @@ int fs_rollout_dev(fs_handle h, int num_steps, const float* actions_dev, size_t 
 int fs_get_state(fs_handle h, int field, void* dst, size_t bytes);
 int fs_set_state(fs_handle h, int field, const void* src, size_t bytes);
 
-/* Family of the step kernel the handle's last fs_step / fs_rollout launch chose ("k_rollout_pair" with "+speed_mode"
- * and / or "+noise", "k_rollout_idm", "k_rollout_loop", "k_rollout_loop<FULL>", "k_steps<FAST>", "k_steps<CSET>", "k_steps",
- * "k_steps_ml", "k_steps_open", "k_steps_wide"; "" before the first launch).  Diagnostics for tests and bench.py: which
- * configuration class a workload landed in (no reference counterpart).  The string is static. */
+/* Family of the step kernel the handle's last fs_step / fs_rollout / fs_policy_rollout launch chose ("k_rollout_pair" with
+ * "+speed_mode" and / or "+noise", "k_rollout_idm", "k_ring_pair<Accel | PO | POMA | AccelMA>", "k_rollout_loop",
+ * "k_rollout_loop<FULL>", "k_rollout_loop<AccelMA>", "k_rollout_loop<FULL,AccelMA>", "k_ring_policy", "k_loop_policy",
+ * "k_steps<FAST>", "k_steps<CSET>", "k_steps", "k_steps_ml", "k_steps_open" (also "<mixed>"), "k_steps_wide",
+ * "k_merge_queue", "k_drop_queue", "k_obs_mixed"; "" before the first launch).  Diagnostics for tests and bench.py: which
+ * configuration class a workload landed in (no reference counterpart).  The string is static.
+ * The queue-order kernel of the lane-drop network (k_drop_queue) reports a replica that outgrew its layout (more than
+ * 64 vehicles on one entry path, more than 8 arrivals in one sub-step) through fs_sync /
+ * fs_get_state: FS_ERR_UNSUPPORTED with fs_last_error naming it; FLOWSIM_NO_QUEUE=1 in the environment of fs_create
+ * keeps a handle on the slot-order kernels. */
 const char* fs_last_kernel(fs_handle h);
 
 /* ---- policy in the loop ------------------------------------------------------
  * What examples/train.py:110-212 runs per rollout worker -- policy forward pass, Env.step, reset of a finished episode,
  * one Python call and N socket round trips per step -- as ONE launch per fragment of K steps.  Built for the
  * reference's RL ring experiments (examples/exp_configs/rl/singleagent/singleagent_ring.py: IDM vehicles + ONE RL
- * vehicle, WaveAttenuationPOEnv: observation 3, action 1) and its default model class: a fully connected network of 1..3
+ * vehicle, WaveAttenuationPOEnv: observation 3, action 1), for its figure-eight experiment
+ * (singleagent_figure_eight.py: FS_NET_FIGURE_EIGHT, 13 IDM + ONE RL vehicle, AccelEnv: observation 2 N = 28, or the
+ * WaveAttenuationPOEnv head: observation 3) and its default model class: a fully connected network of 1..3
  * hidden layers of 32 tanh units (examples/train.py:152 fcnet_hiddens [32, 32, 32]) with a diagonal Gaussian head.
  *   weights_dev  float32, device: per layer W [out][in] row-major then b [out]; the last layer has 2 outputs (mean,
  *                log std: RLlib's DiagGaussian) or, with log_std_dev != NULL, 1 output and a free log std [1]

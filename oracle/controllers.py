@@ -241,7 +241,7 @@ def sumo_idm_speed(v, v_lead, h, has_lead, dt, accel=2.6, decel=4.5, tau=1.0,
     MSCFModel_IDM applies it for one iteration per step (sim_step <= 0.25 s):
     gap is bumper-to-bumper, desired gap s* = minGap + max(0, v*tau +
     v*dv/(2*sqrt(accel*decel))), v' = max(0, v + a_idm*dt).  PARITY UNPINNED
-    (SUMO not available); see DESIGN.md S7.
+    (SUMO not available); see docs/HISTORY.md S7.
     """
     v = np.asarray(v)
     gap = np.maximum(h, _c(1e-3, v))

@@ -26,7 +26,7 @@ tests/fast_tests/test_environments.py:616-700, 1140-1225, which tests/test_host.
   O5  get_x_by_id = edge-start table + position, internal edges resolve to their table entry without
       the position (network/traci.py:273-289)
 
-SUMO-side rules (third-party code, absent; stated here, PARITY UNPINNED -- DESIGN.md M-list):
+SUMO-side rules (third-party code, absent; stated here, PARITY UNPINNED -- docs/HISTORY.md M-list):
 
   M1  slots: capacity N, partitioned by vehicle type; an inflow takes the lowest free slot of its type
       (a slot freed by an arrival is free from the next step on; with no free slot the vehicle waits)

@@ -5,7 +5,7 @@ TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 Restates, batched over R independent replicas of N vehicles, the sequence the
 reference executes in ``flow/envs/base.py:294-412`` (step) and ``:414-560``
 (reset) for RingNetwork experiments, with the SUMO side of the step written
-out explicitly (S-list in DESIGN.md):
+out explicitly (S-list in docs/HISTORY.md section 2):
 
   S1  all controllers read the time-t snapshot        envs/base.py:324-371
   S4  next_vel = max(v + acc*dt, 0)                   vehicle/traci.py:962
@@ -236,7 +236,7 @@ class RingOracle:
         self.veh = spec["vehicles"]
         self.veh_len = np.array([v.get("length", 5.0) for v in self.veh], dtype=self.dt_)
         # closed loops other than the plain ring (figure eight): an ordered segment table
-        # [(phys_start, internal, flow_start, flow_slope)] + the crossing model
+        # [(phys_start, internal, flow_start, flow_slope)] + the crossing model (docs/HISTORY.md S-J)
         self.segments = spec.get("segments")
         self.junction = spec.get("junction")
         self.rl_slots = [None] * int(spec.get("num_rl", 0))

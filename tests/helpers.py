@@ -264,7 +264,7 @@ def fig8_fixture_case():
     return spec, expected
 
 
-# what the crossing model S-J does NOT reproduce of that file: idm_8 starts 0.56 m before the
+# what the crossing model S-J (docs/HISTORY.md section 2) does NOT reproduce of that file: idm_8 starts 0.56 m before the
 # crossing on the minor stream while idm_1's tail still covers the crossing point; SUMO lets it creep in behind the
 # leaving vehicle (0.84 / 1.76 / 2.75 m/s), S-J holds it until the tail has left the box; idm_7 behind it feels that
 # from the third step on

@@ -3,7 +3,7 @@
 The step kernels read per-replica values other lanes hold with v_readlane (segment tables of the closed loops,
 ordering keys, inflow counters).  That idiom is only sound while those VGPRs are never parked in AGPRs: hipcc
 re-materialises an AGPR-held value with v_accvgpr_read under the CURRENT exec mask right before the v_readlane, so
-rows held by lanes that are inactive at that point would read stale data (found in the float64 wide kernel, DESIGN.md
+rows held by lanes that are inactive at that point would read stale data (found in the float64 wide kernel, docs/HISTORY.md
 section 4; the open-network kernels read their launch tables from LDS for that reason).  This test pins the premise:
 every float32 instantiation of the step kernels uses zero AGPRs and spills nothing to scratch memory -- it caught
 k_steps_open<float, 32, .> growing past 256 VGPRs once."""

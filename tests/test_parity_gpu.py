@@ -1,7 +1,7 @@
 """GPU parity: the HIP path (through the C ABI, via flow_amd.sim.FlowSim) against
 the CPU oracle on the same seeded inputs.
 
-Bars (DESIGN.md "Parity"):
+Bars (docs/HISTORY.md "Parity"):
   * float32 kernels vs the float32 oracle twin: bit-exact for controllers built
     from + - * / sqrt (IDM, CFM, BCM, LAC, LinearOVM, Gipps, FollowerStopper,
     fail-safes, integrator, observation, reward); 1e-5 where a libm function
