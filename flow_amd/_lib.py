@@ -43,7 +43,7 @@ FS_EULER, FS_BALLISTIC = 0, 1
 
 EXPORTS = ["fs_create", "fs_destroy", "fs_last_error", "fs_abi_version", "fs_obs_dim", "fs_action_dim", "fs_set_stream",
            "fs_use_own_stream", "fs_sync", "fs_reset", "fs_reset_dev", "fs_step", "fs_step_dev", "fs_rollout_dev",
-           "fs_get_state", "fs_set_state", "fs_dump_trajectory", "fs_last_kernel", "fs_policy_act_dev",
+           "fs_get_state", "fs_set_state", "fs_add_vehicle", "fs_dump_trajectory", "fs_last_kernel", "fs_policy_act_dev",
            "fs_policy_rollout_dev"]
 
 
@@ -165,6 +165,8 @@ def load():
     lib.fs_get_state.restype = C.c_int
     lib.fs_set_state.argtypes = [h, C.c_int, C.c_void_p, C.c_size_t]
     lib.fs_set_state.restype = C.c_int
+    lib.fs_add_vehicle.argtypes = [h, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
+    lib.fs_add_vehicle.restype = C.c_int
     lib.fs_dump_trajectory.argtypes = [h, C.c_int, C.c_char_p]
     lib.fs_dump_trajectory.restype = C.c_int
     lib.fs_last_kernel.argtypes = [h]

@@ -33,6 +33,14 @@ class NetworkKernel(object):
         first = next(iter(self._edges.values()))
         for eid, length in network.specify_internal_edges(junction_length, center_length):
             self._edges[eid] = {"length": float(length), "lanes": first["lanes"], "speed": first["speed"]}
+        # lane-drop networks: an internal edge has one lane per connection through it = the lanes of the edge before it
+        # (netconvert's internal lanes ":4_0_0 .. :4_0_3" of the connections 3_i -> 4_floor(i/2), bottleneck.py:179-201)
+        paths = network.specify_open_routes()
+        self._drop_path = paths[0] if paths is not None and network.specify_lane_joins() is not None else None
+        if self._drop_path is not None:
+            for k, eid in enumerate(self._drop_path):
+                if eid[0] == ':' and k > 0:
+                    self._edges[eid]["lanes"] = self._edges[self._drop_path[k - 1]]["lanes"]
         self._edge_list = [e for e in self._edges if e[0] != ':']
         self._junction_list = [e for e in self._edges if e[0] == ':']
         self.edgestarts = list(network.edge_starts) if network.edge_starts is not None else None
@@ -224,13 +232,41 @@ class NetworkKernel(object):
     def get_junction_list(self):
         return self._junction_list
 
+    def _drop_lane_map(self, edge_to):
+        """{fromLane: toLane} of the connections into ``edge_to`` (specify_connections), None: lane i -> lane i."""
+        conn = (self.network.connections or {}).get(edge_to) if isinstance(self.network.connections, dict) else None
+        if not conn:
+            return None
+        return {int(c["fromLane"]): int(c["toLane"]) for c in conn}
+
     def next_edge(self, edge, lane):
+        """network/traci.py:347-352 over the connection data netconvert would write (:946-975): an edge leads to the
+        internal lane of its connection ("via"), an internal lane to the connection's target lane."""
+        if self._drop_path is not None:
+            p = self._drop_path
+            if edge not in p or p.index(edge) + 1 >= len(p) or not 0 <= lane < self._edges[edge]["lanes"]:
+                return []
+            nxt = p[p.index(edge) + 1]
+            if edge[0] == ':':
+                m = self._drop_lane_map(nxt)
+                return [(nxt, lane if m is None else m[lane])]
+            return [(nxt, lane)]
         order = [t[0] for t in self.total_edgestarts if t[0] in self._edges]
         if edge not in order:
             return []
         return [(order[(order.index(edge) + 1) % len(order)], lane)]
 
     def prev_edge(self, edge, lane):
+        if self._drop_path is not None:
+            p = self._drop_path
+            if edge not in p or p.index(edge) == 0 or not 0 <= lane < self._edges[edge]["lanes"]:
+                return []
+            prv = p[p.index(edge) - 1]
+            if edge[0] != ':':
+                m = self._drop_lane_map(edge)
+                if m is not None:                                  # the internal lanes that end on this lane
+                    return [(prv, i) for i in sorted(m) if m[i] == lane]
+            return [(prv, lane)]
         order = [t[0] for t in self.total_edgestarts if t[0] in self._edges]
         if edge not in order:
             return []

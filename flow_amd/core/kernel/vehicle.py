@@ -410,6 +410,8 @@ class VehicleKernel(object):
         reference's walk over the edges ahead / behind ends on the vehicle's own edge, so alone in its lane it is its
         own leader and follower, one lap away.  (Host accessor for user code and rendering; the observation of
         LaneChangeAccelPOEnv is written by the kernel.)"""
+        if self._open and self.sim.spec.get("network") == "bottleneck":
+            return self._lane_neighbours_drop(i)
         lanes = int(self.sim.spec.get("num_lanes", 1))
         x = self._field(L.FS_FIELD_POS).astype(np.float64)
         ln = self._field(L.FS_FIELD_LANE) if lanes > 1 else np.zeros(self.num_vehicles, dtype=np.int32)
@@ -429,6 +431,72 @@ class VehicleKernel(object):
             fj = cand[::-1][np.argmin(behind[cand[::-1]])]
             out.append((self._order[lj], ahead[lj] - self.__vehicles[self._order[lj]]["length"],
                         self._order[fj], behind[fj] - self.__vehicles[self._order[i]]["length"]))
+        return out
+
+    def _drop_geometry(self):
+        """Static tables of the lane-drop network for the per-lane neighbour walk: edge starts on the route coordinate,
+        joins passed at each edge, and the lengths the reference's walk accumulates (``add_length`` of
+        vehicle/traci.py:898-906 / :940-943: summed edge by edge in walking order, so the same floating-point sums)."""
+        g = getattr(self, "_drop_geo", None)
+        if g is None:
+            net = self.master_kernel.network
+            path = net._drop_path
+            starts = np.array([s for _, s in net._open_starts[0]], dtype=np.float64)
+            sd = dict(net._open_starts[0])
+            joins = [sd[e] for e in net.network.specify_lane_joins()]
+            g_edge = np.array([sum(1 for m in joins if s >= m) for s in starts], dtype=np.int64)
+            n = len(path)
+            fwd, bwd = np.zeros((n, n)), np.zeros((n, n))
+            for a in range(n):
+                acc = 0.0
+                for b in range(a + 1, n):                      # leader on edge b: lengths of edges a .. b-1
+                    acc += net.edge_length(path[b - 1])
+                    fwd[a, b] = acc
+                acc = 0.0
+                for b in range(a - 1, -1, -1):                 # follower on edge b: lengths of edges a-1 .. b
+                    acc += net.edge_length(path[b])
+                    bwd[a, b] = acc
+            g = self._drop_geo = (path, starts, g_edge, fwd, bwd)
+        return g
+
+    def _lane_neighbours_drop(self, i):
+        """_multi_lane_headways_util on the lane-drop network (vehicle/traci.py:776-950), in route coordinates.  For lane
+        q of the vehicle's edge: the leader is the first vehicle at or ahead of it (bisect_left: a vehicle at the same
+        position counts as ahead; ties in id-list order) in lane q of this edge, else the first vehicle of the lane the
+        connections lead to on the edges ahead; the follower is the last vehicle strictly behind in lane q of this edge,
+        else the last one on the edges behind, walking prev_edge(...)[0] -- the lowest of the lanes that join."""
+        path, starts, g_edge, fwd, bwd = self._drop_geometry()
+        x = self._field(L.FS_FIELD_POS).astype(np.float64)
+        route = np.asarray(self._field(L.FS_FIELD_ROUTE)).astype(np.int64)
+        seq = np.asarray(self._field(L.FS_FIELD_SEQ)).astype(np.int64)
+        alive = route >= 0
+        e = np.clip(np.searchsorted(starts, x, side="right") - 1, 0, len(path) - 1)
+        pos = x - starts[e]
+        lane = np.where(alive, route, 0) >> g_edge[e]
+        length = np.array([self.__vehicles[self._slot_id[k]]["length"] if alive[k] else 0.0 for k in range(len(x))])
+        others = alive.copy()
+        others[i] = False
+        ei, gi = int(e[i]), int(g_edge[e[i]])
+        n_lanes = self.master_kernel.network.num_lanes(path[ei])
+        out = []
+        for q in range(n_lanes):
+            up = g_edge[e] - gi                                          # joins between my edge and theirs (>= 0 ahead)
+            ahead = others & (((e == ei) & (lane == q) & (pos >= pos[i])) |
+                              ((e > ei) & (lane == (q >> np.maximum(up, 0)))))
+            behind = others & (((e == ei) & (lane == q) & (pos < pos[i])) |
+                               ((e < ei) & (lane == (q << np.maximum(-up, 0)))))
+            lead, head, foll, tail = "", 1000, "", 1000
+            if ahead.any():
+                c = np.flatnonzero(ahead)
+                k = c[np.lexsort((seq[c], pos[c], e[c]))[0]]            # nearest edge, then position, then id-list order
+                lead = self._slot_id[k]
+                head = pos[k] - pos[i] - length[k] if e[k] == ei else pos[k] - pos[i] + fwd[ei, e[k]] - length[k]
+            if behind.any():
+                c = np.flatnonzero(behind)
+                k = c[np.lexsort((-seq[c], -pos[c], -e[c]))[0]]
+                foll = self._slot_id[k]
+                tail = pos[i] - pos[k] - length[i] if e[k] == ei else pos[i] - pos[k] + bwd[ei, e[k]] - length[i]
+            out.append((lead, head, foll, tail))
         return out
 
     def lane_neighbour_table(self, veh_id):

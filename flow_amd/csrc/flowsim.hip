@@ -495,6 +495,12 @@ int fs_set_state(fs_handle h, int field, const void* src, size_t bytes) {
   return S(h)->set_state(field, src, bytes);
 }
 
+int fs_add_vehicle(fs_handle h, int replica, int slot, int route, double x, double speed) {
+  if (!h) return fail(FS_ERR_INVALID, "fs_add_vehicle: NULL handle");
+  DeviceGuard guard(S(h)->cfg.device);
+  return S(h)->add_vehicle(replica, slot, route, x, speed);
+}
+
 int fs_policy_act_dev(fs_handle h, const fs_policy* pol, const float* obs_dev, float* act_dev, float* logp_dev) {
   if (!h || !pol || !obs_dev || !act_dev || !logp_dev) return fail(FS_ERR_INVALID, "fs_policy_act_dev: NULL argument");
   DeviceGuard guard(S(h)->cfg.device);

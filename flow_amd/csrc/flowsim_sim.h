@@ -105,6 +105,7 @@ struct SimBase {
   uint32_t* d_pol_ctr = nullptr;   // [R] actions sampled so far per replica (the policy's draw counters)
   virtual int get_state(int field, void* dst, size_t bytes) = 0;
   virtual int set_state(int field, const void* src, size_t bytes) = 0;
+  virtual int add_vehicle(int replica, int slot, int route, double x, double speed) = 0;
 };
 
 template <typename T>
@@ -703,6 +704,7 @@ struct Sim : SimBase {
     if (cfg.num_paths != 4 || ov.lc_enabled || ov.track_followers || ov.n_prob > 0 || !open_div_ok) return false;
     if (!(dv.flags & fs::FLAG_NO_FLOW_CTRL) || dv.integrator != FS_EULER) return false;
     if (dv.env != FS_ENV_BOTTLENECK_DV && dv.env != FS_ENV_BOTTLENECK) return false;
+    if (dv.env == FS_ENV_BOTTLENECK && dv.num_rl > 0) return false;      // per-vehicle RL accelerations (BottleneckAccelEnv)
     if (mask != nullptr || num_steps < 1 || dv.N > 256 || ov.nseg[0] > 16 || ov.obs_span > 3 || ov.act_span > 2) return false;
     for (int i = 0; i < dv.N; ++i)
       if (float(veh[i].length) != float(veh[0].length) || veh[i].type < 0 || veh[i].type > 7) return false;
@@ -915,6 +917,41 @@ struct Sim : SimBase {
     if (bytes != count * sizeof(T)) return fail(FS_ERR_INVALID, "fs_get_state: wrong byte count");
     HIP_TRY(hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost));
     return FS_OK;
+  }
+
+  // k.vehicle.add (vehicle/traci.py:1089-1122) for a vehicle that has a slot of its own and is not in the network (an
+  // initial vehicle that arrived: BottleneckAccelEnv.additional_command re-inserts its RL vehicles, bottleneck.py:733-757):
+  // the slot's vehicle is back at coordinate x of entry lane / route `route` with the given speed, last in the id list
+  int add_vehicle(int replica, int slot, int route, double x, double speed) override {
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (!open_net) return fail(FS_ERR_UNSUPPORTED, "fs_add_vehicle: open networks only (a closed loop keeps its vehicles)");
+    const int paths = cfg.network == FS_NET_MERGE ? 2 : (cfg.num_paths ? cfg.num_paths : 4);
+    if (replica < 0 || replica >= dv.R || slot < 0 || slot >= dv.N || route < 0 || route >= paths)
+      return fail(FS_ERR_INVALID, "fs_add_vehicle: replica / slot / route out of range");
+    if (!(speed >= 0.0) || !(x >= 0.0) || !(x < double(ov.end_x)))
+      return fail(FS_ERR_INVALID, "fs_add_vehicle: need speed >= 0 and 0 <= x < the end of the route");
+    const size_t e = size_t(replica) * dv.N + slot;
+    int32_t cur = 0, cnt[8];
+    HIP_TRY(hipMemcpy(&cur, dv.lane + e, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (cur >= 0) return fail(FS_ERR_INVALID, "fs_add_vehicle: the slot's vehicle is in the network");
+    HIP_TRY(hipMemcpy(cnt, ov.counters + size_t(replica) * 8, sizeof(cnt), hipMemcpyDeviceToHost));
+    const T xv = T(x), vv = T(speed), zero = T(0), big = T(3.0e38), vm = T(veh[slot].sumo_max_speed);
+    const int32_t rt = route, sq = cnt[fs::CNT_SEQ], minus1 = -1, org = -1 - slot, never = -(1 << 30);
+    cnt[fs::CNT_SEQ] += 1;
+    HIP_TRY(hipMemcpy(dv.pos + e, &xv, sizeof(T), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dv.vel + e, &vv, sizeof(T), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dv.prev_vel + e, &zero, sizeof(T), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dv.accel + e, &zero, sizeof(T), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(const_cast<int32_t*>(dv.lane) + e, &rt, sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(const_cast<int32_t*>(dv.last_lc) + e, &never, sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ov.seq + e, &sq, sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ov.origin + e, &org, sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ov.foll + e, &minus1, sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ov.ctl_seq + e, &minus1, sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ov.foll_h + e, &big, sizeof(T), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ov.vmax + e, &vm, sizeof(T), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ov.counters + size_t(replica) * 8, cnt, sizeof(cnt), hipMemcpyHostToDevice));
+    return launch_steps(0, nullptr, nullptr, 0, d_obs, d_rew, d_done, 0);      // the neighbour fields of the new arrangement
   }
 
   int set_state(int field, const void* src, size_t bytes) override {

@@ -675,15 +675,24 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
       const bool on_edge = s.junction_mode ? !internal : true;
       // (the lane-drop heads hand no acceleration to an RL vehicle: with SUMO-driven humans -- every shipped bottleneck
       // experiment -- no vehicle is commanded and S4-S8's command path is dead: block-uniform skip)
-      const bool any_cmd = !(flags & FLAG_NO_FLOW_CTRL);
+      // (BottleneckAccelEnv: one acceleration column per RL slot, NaN = no command for that vehicle this step)
+      const bool ma_cmd = o.ma_apply_actions != 0 && !dv_env && have_act;       // block-uniform
+      const bool any_cmd = !(flags & FLAG_NO_FLOW_CTRL) || ma_cmd;
+      bool have_rl = false;
+      T a_rl = T(0);
+      if (ma_cmd && is_rl && alive) {
+        const float a = L.act[ab][(sl.rl_index < 0 ? 0 : sl.rl_index) & 63];
+        have_rl = !(a != a);
+        a_rl = have_rl ? T(a) : T(0);
+      }
       bool commanded = false;
       T acc = T(0);
       if (any_cmd) {
         if constexpr (FD) {
           const T g_now = (flags & FLAG_HAS_NOISE) ? gauss<T>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(ii), nctr) : T(0);
-          acc = control_accel_fd(s, sl, fd, flags, v, vl, h, has, on_edge, false, 0.0f, commanded, g_now);
+          acc = control_accel_fd(s, sl, fd, flags, v, vl, h, has, on_edge, have_rl, float(a_rl), commanded, g_now);
         } else {
-          acc = control_accel_on<T, CSET>(s, sl, flags, v, vl, h, has, vf, hf, mean_v, on_edge, false, T(0), live && slot_ok,
+          acc = control_accel_on<T, CSET>(s, sl, flags, v, vl, h, has, vf, hf, mean_v, on_edge, have_rl, a_rl, live && slot_ok,
                                           rr, ii, nctr, cst, commanded);
         }
       }

@@ -138,6 +138,7 @@ class Env(_Base):
         self.apply_rl_actions(rl_actions)
         self.additional_command()
         obs, rew, done = self.sim.step(self._action_vector())
+        self._after_sim_step()
         self.k.update(reset=False)
         limit = n_sub * (self.env_params.warmup_steps + self.env_params.horizon)
         tc = int(self.sim.time_counter[0])
@@ -180,6 +181,11 @@ class Env(_Base):
         return np.copy(states)
 
     def additional_command(self):
+        pass
+
+    def _after_sim_step(self):
+        """What the reference's TraCI commands of this step do once the simulator has moved the vehicles (lane changes,
+        insertions): nothing for most environments."""
         pass
 
     def clip_actions(self, rl_actions=None):

@@ -4,9 +4,10 @@ Built: ``BottleneckEnv`` (the base: observation [1], outflow reward) and ``Bottl
 speed limits per lane-segment for the RL vehicles) with the toll booth and the ramp meter switched OFF, as every
 shipped bottleneck experiment runs them (examples/exp_configs/rl/singleagent/singleagent_bottleneck.py:24-25).
 Observation, maxSpeed updates and reward are computed in the HIP step kernel (heads FS_ENV_BOTTLENECK /
-FS_ENV_BOTTLENECK_DV).  ``BottleneckAccelEnv`` is built for networks without RL vehicles (what the reference's own
-test exercises).  Not built: the toll-booth / ALINEA ramp-meter logic (traffic lights), ``BottleneckAccelEnv`` with RL
-vehicles (per-vehicle lane changes) and the ``evaluate`` reward; they raise NotImplementedError at construction."""
+FS_ENV_BOTTLENECK_DV).  ``BottleneckAccelEnv`` steps on the device too (per-vehicle RL accelerations); its
+observation, lane-change commands and the re-insertion of RL vehicles are host code over the device state, as they are
+Python around the simulator in the reference.  Not built: the toll-booth / ALINEA ramp-meter logic (traffic lights)
+and the ``evaluate`` reward; they raise NotImplementedError at construction."""
 from copy import deepcopy
 
 import numpy as np
@@ -133,26 +134,41 @@ class BottleneckEnv(Env):
 
 
 class BottleneckAccelEnv(BottleneckEnv):
-    """flow/envs/bottleneck.py:486-757.
+    """flow/envs/bottleneck.py:486-757: RL vehicles that accelerate and change lanes on the lane-drop network.
 
-    Built for the case the reference itself tests (tests/fast_tests/test_environments.py:813-878): NO RL vehicles in
-    the network.  The observation is then the per-edge block only (mean speed / max speed and vehicles per metre for
-    every edge of ``get_edge_list()``, the rendering-only "fake_edge" included: 12 numbers), the action space is empty,
-    and the reward is ``rewards.desired_velocity`` (the forward-progress and lane-change terms are sums over the RL
-    vehicles).  Both are host heads over the device state (``HOST_HEADS``): masked reductions over the replica's rows.  With RL vehicles the env needs per-vehicle lane-change commands on the lane-drop network and the
-    re-insertion of exited RL vehicles (:733-757): not built, raises at construction."""
+    The step loop runs on the device (head FS_ENV_BOTTLENECK with one acceleration column per RL slot, NaN = no command);
+    what the reference does in Python around the simulator step is host code here too, over the device state:
+
+    * ``_apply_rl_actions`` (:662-690): actions pair up with the RL vehicles sorted by position; directions are rounded,
+      blocked while ``time_counter <= lane_change_duration + get_last_lc`` (this fork's ``get_last_lc`` returns the
+      headway, vehicle/traci.py:604-614), clipped to the lanes of the vehicle's edge (vehicle/traci.py:965-997);
+    * the lane change itself is SUMO's: restated as in the multi-lane ring (ML3) -- executed with the step's move, refused
+      when ``lane_change_mode != 0`` and the vehicle would overlap one on the target lane; the vehicle continues on the
+      lowest entry lane of its new lane (M11).  Applied through ``fs_set_state(FS_FIELD_ROUTE)`` after the launch;
+    * ``additional_command`` (:733-757): an RL vehicle that left is handed back to the simulator (``fs_add_vehicle``:
+      edge "1", position 0, lane ``index % MAX_LANES * scaling``, speed "max"); as with TraCI's ``vehicle.add`` it enters
+      when there is room (the insertion test M3 of the inflows), at the end of a simulation step;
+    * ``get_state`` (:539-640) and ``compute_reward`` (:642-649) literally, over ``k.vehicle.get_lane_leaders`` /
+      ``followers`` / ``headways`` / ``tailways`` (vehicle/traci.py:776-950; the lane connections across the drops are
+      flow/networks/bottleneck.py:179-201, the internal lanes netconvert adds are one per connection -- stated in
+      ``NetworkKernel.next_edge`` / ``prev_edge``, unpinned).
+    SUMO-side statements (lane-change execution, insertion) are unpinned like every M-rule.
+    The reference's own test of the class has no RL vehicles (tests/fast_tests/test_environments.py:813-878): then the
+    observation is the per-edge block only and the action space is empty."""
 
     HOST_HEADS = True
+    APPLY_ENUMERATE_QUIRK = False            # the kernel's action columns are the RL slots (spec: ma_apply_actions)
+    PER_VEHICLE_ACTIONS = True
 
     def __init__(self, env_params, sim_params, network=None, simulator='traci', scenario=None):
         for p in ADDITIONAL_RL_ENV_PARAMS.keys():
             if p not in env_params.additional_params:
                 raise KeyError('Environment parameter "{}" not supplied'.format(p))
         net = network if network is not None else scenario
-        if net.vehicles.num_rl_vehicles > 0:
-            raise NotImplementedError("BottleneckAccelEnv with RL vehicles needs per-vehicle lane-change commands and "
-                                      "re-insertion on the lane-drop network: not built")
-        self.num_rl = 0                              # the spaces are read while the simulator is being set up
+        self.num_rl = int(net.vehicles.num_rl_vehicles)     # the spaces are read while the simulator is being set up
+        if self.num_rl > 0 and env_params.sims_per_step != 1:
+            raise NotImplementedError("BottleneckAccelEnv with RL vehicles is built for sims_per_step = 1")
+        self._readd, self._lc_targets = [], {}
         super().__init__(env_params, sim_params, network, simulator, scenario)
         self.add_rl_if_exit = env_params.get_additional_param("add_rl_if_exit")
         self.num_rl = deepcopy(self.initial_vehicles.num_rl_vehicles)
@@ -174,28 +190,187 @@ class BottleneckAccelEnv(BottleneckEnv):
         return Box(np.array(lb, dtype=np.float32), np.array(ub, dtype=np.float32), dtype=np.float32)
 
     def get_state(self):
-        """The per-edge block of :539-640 (with no RL vehicle the rl / relative blocks are empty): for every edge of
-        ``get_edge_list()`` the mean speed over ``max_speed`` and the vehicles per metre -- two masked reductions over
-        the replica's speed row per edge."""
+        """:539-640, statement by statement."""
         veh, net = self.k.vehicle, self.k.network
+        headway_scale = 1000
+        rl_ids = veh.get_rl_ids()
+        rl_obs = np.empty(0)
+        id_counter = 0
+        for veh_id in rl_ids:
+            rl_id_num = self.rl_id_list.index(veh_id)
+            if rl_id_num != id_counter:                      # a vehicle before this one is missing: pad its place
+                rl_obs = np.concatenate((rl_obs, np.zeros(4 * (rl_id_num - id_counter))))
+                id_counter = rl_id_num + 1
+            else:
+                id_counter += 1
+            edge_num = veh.get_edge(veh_id)
+            if edge_num is None or edge_num == '' or edge_num[0] == ':':
+                edge_num = -1
+            else:
+                edge_num = int(edge_num) / 6
+            rl_obs = np.concatenate((rl_obs, [veh.get_x_by_id(veh_id) / 1000, veh.get_speed(veh_id) / self.max_speed,
+                                              veh.get_lane(veh_id) / MAX_LANES, edge_num]))
+        diff = self.num_rl - int(rl_obs.shape[0] / 4)
+        if diff > 0:
+            rl_obs = np.concatenate((rl_obs, np.zeros(4 * diff)))
+
+        relative_obs = np.empty(0)
+        id_counter = 0
+        for veh_id in rl_ids:
+            rl_id_num = self.rl_id_list.index(veh_id)
+            if rl_id_num != id_counter:
+                relative_obs = np.concatenate((relative_obs,
+                                               np.zeros(4 * MAX_LANES * self.scaling * (rl_id_num - id_counter))))
+                id_counter = rl_id_num + 1
+            else:
+                id_counter += 1
+            num_lanes = MAX_LANES * self.scaling
+            headway = np.asarray([1000] * num_lanes) / headway_scale
+            tailway = np.asarray([1000] * num_lanes) / headway_scale
+            vel_in_front = np.asarray([0] * num_lanes) / self.max_speed
+            vel_behind = np.asarray([0] * num_lanes) / self.max_speed
+            table = veh.lane_neighbour_table(veh_id)         # [(leader, headway, follower, tailway)] per lane
+            headway[0:len(table)] = np.asarray([t[1] for t in table]) / headway_scale
+            tailway[0:len(table)] = np.asarray([t[3] for t in table]) / headway_scale
+            for i, t in enumerate(table):
+                if t[0] != '':
+                    vel_in_front[i] = veh.get_speed(t[0]) / self.max_speed
+            for i, t in enumerate(table):                    # (:608: the test is on the LIST, so it always holds -- an
+                vel_behind[i] = veh.get_speed(t[2]) / self.max_speed     # empty lane reads get_speed('') = -1001)
+            relative_obs = np.concatenate((relative_obs, headway, tailway, vel_in_front, vel_behind))
+        diff = self.num_rl - int(relative_obs.shape[0] / (4 * MAX_LANES))         # (:616-619: without the scaling)
+        if diff > 0:
+            relative_obs = np.concatenate((relative_obs, np.zeros(4 * MAX_LANES * diff)))
+
         ids = veh.get_ids()
         on_edge = np.asarray(veh.get_edge(ids), dtype=object)
         speed = veh.speeds(ids)
-        out = []
+        edge_obs = []
         for edge in net.get_edge_list():
             here = on_edge == edge
             n = int(here.sum())
-            out += [speed[here].sum() / n / self.max_speed, n / net.edge_length(edge)] if n else [0., 0.]
-        return np.asarray(out, dtype=np.float64)
+            edge_obs += [(sum(speed[here].tolist()) / n) / self.max_speed, n / net.edge_length(edge)] if n else [0, 0]
+        return np.concatenate((rl_obs, relative_obs, edge_obs))
 
     def compute_reward(self, rl_actions, **kwargs):
-        """:642-649; no RL vehicles: the lane-change penalty and the forward-progress term are empty sums."""
+        """:642-649."""
         from flow_amd.core import rewards
+        num_rl = self.k.vehicle.num_rl_vehicles
+        acts = np.zeros(0) if rl_actions is None else np.asarray(rl_actions, dtype=np.float64).reshape(-1)
+        lane_change_acts = np.abs(np.round(acts[1::2])[:num_rl])
         return rewards.desired_velocity(self) + rewards.rl_forward_progress(self, gain=0.1) - \
-            rewards.boolean_action_penalty(np.zeros(0), gain=1.0)
+            rewards.boolean_action_penalty(lane_change_acts, gain=1.0)
 
     def _apply_rl_actions(self, actions):
-        return None
+        """:662-690."""
+        veh = self.k.vehicle
+        num_rl = veh.num_rl_vehicles
+        if num_rl == 0:
+            return
+        actions = np.asarray(actions, dtype=np.float64).reshape(-1)
+        acceleration = actions[::2][:num_rl]
+        direction = np.round(actions[1::2])[:num_rl]
+        sorted_rl_ids = sorted(veh.get_rl_ids(), key=veh.get_x_by_id)
+        non_lane_changing_veh = [
+            self.time_counter <= self.env_params.additional_params['lane_change_duration'] + veh.get_last_lc(veh_id)
+            for veh_id in sorted_rl_ids]
+        direction[non_lane_changing_veh] = np.array([0] * sum(non_lane_changing_veh))
+        veh.apply_acceleration(sorted_rl_ids, acc=acceleration)
+        veh.apply_lane_change(sorted_rl_ids, direction=[int(d) for d in direction])
+        # vehicle/traci.py:978-990: the target lane of a commanded change, from the lane and edge of NOW
+        net = self.k.network
+        for veh_id, d in zip(sorted_rl_ids, direction):
+            lane = veh.get_lane(veh_id)
+            target = min(max(lane + int(d), 0), net.num_lanes(veh.get_edge(veh_id)) - 1)
+            if target != lane:
+                self._lc_targets[veh_id] = int(target)
+
+    def _action_vector(self):
+        """[1, RL slots] accelerations by slot column (NaN: the slot's vehicle got no command this step)."""
+        pend = self.k.vehicle._pending
+        if not pend or self.sim.act_dim == 0:
+            return None
+        row = np.full((1, self.sim.act_dim), np.nan, dtype=np.float32)
+        for veh_id, a in pend.items():
+            slot = self.k.vehicle._slot.get(veh_id)
+            if slot is not None:
+                row[0, self._spec["vehicles"][slot]["rl_index"]] = a
+        return row
+
+    def additional_command(self):
+        """:733-757."""
+        super().additional_command()
+        num_rl = self.k.vehicle.num_rl_vehicles
+        if num_rl != len(self.rl_id_list) and self.add_rl_if_exit:
+            here = set(self.k.vehicle.get_rl_ids())
+            for rl_id in self.rl_id_list:                    # (the reference walks a set difference: any order)
+                if rl_id not in here and rl_id not in self._readd:
+                    self._readd.append(rl_id)                # k.vehicle.add: SUMO inserts it when there is room
+
+    def _after_sim_step(self):
+        if not self._lc_targets and not self._readd:
+            return
+        sim, spec = self.sim, self._spec
+        x = sim.get_state(L.FS_FIELD_POS).astype(np.float64)
+        v = sim.get_state(L.FS_FIELD_VEL).astype(np.float64)
+        route = sim.get_state(L.FS_FIELD_ROUTE).copy()
+        m1, m2, zip_d = float(spec["merge1_x"]), float(spec["merge2_x"]), float(spec.get("zipper_distance", 50.0))
+        length = np.array([s_["length"] for s_ in spec["vehicles"]], dtype=np.float64)
+
+        def shift(xx):
+            return (np.asarray(xx) >= m1).astype(np.int64) + (np.asarray(xx) >= m2).astype(np.int64)
+
+        # ---- commanded lane changes (ML3's statement on the lane-drop network), with this step's move
+        changed = False
+        for veh_id, target in self._lc_targets.items():
+            i = self.k.vehicle._slot.get(veh_id)
+            if i is None or route[0, i] < 0:                 # left the network in this step
+                continue
+            g = int(shift(x[0, i]))
+            if (int(route[0, i]) >> g) == target or target >= (int(spec["num_paths"]) >> g):
+                continue                                     # (a join passed in between has changed the lanes)
+            if int(spec["vehicles"][i].get("lane_change_mode", 0)) != 0:
+                alive = route[0] >= 0
+                alive[i] = False
+                on_target = alive & ((np.maximum(route[0], 0) >> g) == target)
+                d = x[0] - x[0, i]
+                if (on_target & (((d >= 0) & (d < length)) | ((d < 0) & (-d < length[i])))).any():
+                    continue
+            route[0, i] = target << g
+            changed = True
+        self._lc_targets = {}
+        if changed:
+            sim.set_state(L.FS_FIELD_ROUTE, route)
+        # ---- re-insertion of the RL vehicles that left (M3's test at position 0 of edge "1", departSpeed "max")
+        waiting = []
+        for rl_id in self._readd:
+            slot = self._spec["init_slot"][rl_id]
+            if route[0, slot] >= 0:
+                continue
+            lane = self.rl_id_list.index(rl_id) % MAX_LANES * self.scaling
+            vs = spec["vehicles"][slot]
+            v_dep = min(float(vs.get("sumo_max_speed", 30.0)), float(spec["speed_limit"]))
+            alive = route[0] >= 0
+            sh = shift(np.maximum(x[0], 0.0 + zip_d))
+            cand = alive & ((np.maximum(route[0], 0) >> sh) == (lane >> sh))
+            ok = True
+            if cand.any():
+                j = int(np.flatnonzero(cand)[np.argmin(x[0][cand])])
+                gap = (x[0, j] - length[j]) - 0.0
+                need = float(vs.get("sumo_min_gap", 2.5)) + max(
+                    0.0, v_dep * float(vs.get("sumo_tau", 1.0)) + v_dep * (v_dep - v[0, j]) /
+                    (2.0 * np.sqrt(float(vs["max_accel"]) * float(vs["max_decel"]))))
+                ok = gap >= need
+            if ok:
+                sim.add_vehicle(slot, lane, 0.0, v_dep)
+                route[0, slot], x[0, slot], v[0, slot] = lane, 0.0, v_dep
+            else:
+                waiting.append(rl_id)
+        self._readd = waiting
+
+    def reset(self):
+        self._readd, self._lc_targets = [], {}
+        return super().reset()
 
 
 class BottleneckDesiredVelocityEnv(BottleneckEnv):

@@ -246,6 +246,10 @@ def build_open_spec(env, num_replicas, rng=None):
     if lane_drop:
         obs_cells, act_cells = env._fs_cells(tables)
         num_rl = len(act_cells)
+        if getattr(env, "PER_VEHICLE_ACTIONS", False):     # BottleneckAccelEnv: one acceleration column per RL slot
+            num_rl = n_rl_slots
+            if num_rl > 64:
+                raise NotImplementedError("at most 64 RL vehicle slots per replica")
         extra = dict(obs_cells=obs_cells, action_cells=act_cells, scaling=int(ap.get("scaling", 1)),
                      track_followers=False,                          # no bottleneck env reads get_follower
                      # M11 (simplified lane changing for types whose lane_change_mode lets SUMO change lanes)

@@ -291,6 +291,10 @@ class FlowSim:
         """Family of the step kernel the last step / rollout launch chose (fs_last_kernel)."""
         return self.lib.fs_last_kernel(self._h).decode()
 
+    def add_vehicle(self, slot, route, x, speed, replica=0):
+        """Put the (absent) vehicle of ``slot`` back into the network (fs_add_vehicle: k.vehicle.add of the reference)."""
+        L.check(self.lib.fs_add_vehicle(self._h, int(replica), int(slot), int(route), float(x), float(speed)))
+
     def dump_trajectory(self, replica, csv_path):
         """Append the current state of ``replica`` to ``csv_path`` (fs_dump_trajectory)."""
         L.check(self.lib.fs_dump_trajectory(self._h, int(replica), str(csv_path).encode()))

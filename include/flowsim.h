@@ -391,6 +391,15 @@ int fs_rollout_dev(fs_handle h, int num_steps, const float* actions_dev, size_t 
 int fs_get_state(fs_handle h, int field, void* dst, size_t bytes);
 int fs_set_state(fs_handle h, int field, const void* src, size_t bytes);
 
+/* k.vehicle.add(veh_id, type_id, edge, pos, lane, speed) (flow/core/kernel/vehicle/traci.py:1089-1122 -> TraCI vehicle.add)
+ * for a vehicle that HAS a slot and is not in the network: BottleneckAccelEnv.additional_command re-inserts an RL vehicle
+ * that left (flow/envs/bottleneck.py:733-757, add_rl_if_exit).  Open networks only.  The vehicle of `slot` (which must be
+ * empty: FS_ERR_INVALID otherwise) is placed at route coordinate `x` [m] on entry lane / route `route` with `speed`
+ * [m/s], joins the END of the id list (FS_FIELD_SEQ), with its type's maxSpeed and no lane-change history; the
+ * neighbour fields (FS_FIELD_LEADER / HEADWAY) are refreshed.  Whether the vehicle fits is the caller's test (the
+ * reference lets TraCI raise and ignores it).  Host call between launches: synchronises the handle's stream. */
+int fs_add_vehicle(fs_handle h, int replica, int slot, int route, double x, double speed);
+
 /* Family of the step kernel the handle's last fs_step / fs_rollout / fs_policy_rollout launch chose ("k_rollout_pair" with
  * "+speed_mode" and / or "+noise", "k_rollout_idm", "k_ring_pair<Accel | PO | POMA | AccelMA>", "k_rollout_loop",
  * "k_rollout_loop<FULL>", "k_rollout_loop<AccelMA>", "k_rollout_loop<FULL,AccelMA>", "k_ring_policy", "k_loop_policy",

@@ -128,8 +128,81 @@ def test_reference_bottleneck_accel_env_tests():
     rl.add(veh_id="rl", acceleration_controller=(RLController, {}), num_vehicles=2)
     net_rl = BottleneckNetwork(name="bay_bridge_toll", vehicles=rl,
                                net_params=NetParams(additional_params={"scaling": 1, "speed_limit": 23}))
-    with pytest.raises(NotImplementedError, match="RL vehicles"):
-        BottleneckAccelEnv(EnvParams(additional_params=full), sim_params, net_rl)
+    env = BottleneckAccelEnv(EnvParams(additional_params=full), sim_params, net_rl)      # (with RL vehicles: below)
+    assert env.observation_space.shape == (2 * 6 + 4 * 4 * 2 + 4 * 2,) and env.action_space.shape == (4,)
+    env.terminate()
+
+
+def accel_oracle(env):
+    """oracle/bottleneck_accel.py on the env's own spec + the network description its walks need."""
+    from oracle.bottleneck_accel import BottleneckAccelOracle
+    net, spec = env.k.network, dict(env._spec)
+    rl_names = {env._spec["init_slot"][v]: v for v in env.rl_id_list}
+    add = env.env_params.additional_params
+    spec["accel_env"] = dict(
+        path=[(e, net.edge_length(e), net.num_lanes(e)) for e in net._drop_path],
+        connections={k: {c["fromLane"]: c["toLane"] for c in v} for k, v in env.network.connections.items()},
+        edge_list=list(net.get_edge_list()), edge_length={e: net.edge_length(e) for e in net.get_edge_list()},
+        rl_names=rl_names, lane_change_duration=add["lane_change_duration"], scaling=env.scaling,
+        add_rl_if_exit=add["add_rl_if_exit"], max_speed=net.max_speed(), max_accel=add["max_accel"],
+        max_decel=add["max_decel"],
+        lane_change_mode={i: int(v.get("lane_change_mode", 0)) for i, v in enumerate(spec["vehicles"])})
+    return BottleneckAccelOracle(spec, np.float32 if env.sim.precision == "f32" else np.float64)
+
+
+@pytest.mark.parametrize("lc_mode", ["no_lc_safe", 0])
+def test_bottleneck_accel_env_with_rl_vehicles_equals_the_oracle(lc_mode):
+    """BottleneckAccelEnv with RL vehicles (flow/envs/bottleneck.py:486-757): accelerations and lane-change commands of
+    three RL vehicles among inflow traffic, 500 steps of 0.5 s -- every RL vehicle leaves the network and is put back
+    (add_rl_if_exit).  Observation (rl block, per-lane leaders / followers across the lane drops, per-edge block) and
+    reward against oracle/bottleneck_accel.py, which walks the reference's per-edge lists; state bit for bit."""
+    from flow_amd import _lib as L
+    from flow_amd.controllers import RLController
+    from flow_amd.core.params import (EnvParams, InFlows, InitialConfig, NetParams, SumoLaneChangeParams, SumoParams,
+                                      VehicleParams)
+    from flow_amd.envs import BottleneckAccelEnv
+    from flow_amd.networks import BottleneckNetwork
+    vehicles = VehicleParams()
+    vehicles.add(veh_id="human", num_vehicles=6)
+    vehicles.add(veh_id="rl", acceleration_controller=(RLController, {}),
+                 lane_change_params=SumoLaneChangeParams(lane_change_mode=lc_mode), num_vehicles=3)
+    inflow = InFlows()
+    inflow.add(veh_type="human", edge="1", vehs_per_hour=1800, departLane="random", departSpeed=10)
+    add = {"max_accel": 3, "max_decel": 3, "lane_change_duration": 5, "disable_tb": True, "disable_ramp_metering": True,
+           "target_velocity": 30, "add_rl_if_exit": True}
+    net = BottleneckNetwork(name="bottleneck", vehicles=vehicles, initial_config=InitialConfig(spacing="uniform", edges_distribution=["2", "3"]),
+                            net_params=NetParams(inflows=inflow, additional_params={"scaling": 1, "speed_limit": 23}))
+    env = BottleneckAccelEnv(EnvParams(horizon=600, additional_params=add), SumoParams(sim_step=0.5, seed=7), net)
+    ora = accel_oracle(env)
+    obs = env.reset()
+    ora.reset()
+    np.testing.assert_allclose(obs, ora.accel_state(0), rtol=0, atol=1e-12)
+    assert obs.shape == env.observation_space.shape == (12 + 48 + 12,)
+    rng = np.random.default_rng(3)
+    readded, changes, seen_internal = 0, 0, False
+    for k in range(500):
+        a = rng.uniform(-1, 1, 6) * np.tile([3.0, 1.4], 3)          # (clipped to the Box: |direction| <= 1 rounds to -1 / 0 / 1)
+        if k % 3:
+            a[1::2] = 0.0                                            # a lane-change command every third step
+        before = set(env.k.vehicle.get_rl_ids())
+        lanes0 = {v: env.k.vehicle.get_lane(v) for v in before}
+        obs, rew, done, _ = env.step(a)
+        o_ref, r_ref, d_ref = ora.step(a[None, :])
+        np.testing.assert_allclose(obs, o_ref[0], rtol=0, atol=1e-12, err_msg="observation, step %d" % k)
+        np.testing.assert_allclose(rew, r_ref[0], rtol=1e-12, atol=1e-12, err_msg="reward, step %d" % k)
+        assert bool(done) == bool(d_ref[0])
+        for f, ref in ((L.FS_FIELD_POS, ora.x), (L.FS_FIELD_VEL, ora.v), (L.FS_FIELD_ROUTE, ora.route)):
+            got = env.sim.get_state(f)[0]
+            alive = ora.route[0] >= 0
+            np.testing.assert_array_equal(got[alive], ref[0][alive], err_msg="field %d, step %d" % (f, k))
+        now = set(env.k.vehicle.get_rl_ids())
+        readded += len(now - before)
+        changes += sum(1 for v in now & before if env.k.vehicle.get_lane(v) != lanes0[v] and
+                       env.k.vehicle.get_edge(v) in ("1", "2", "3"))
+        seen_internal = seen_internal or any(env.k.vehicle.get_edge(v)[0] == ":" for v in now)
+    assert readded >= 3 and changes >= 5 and seen_internal
+    assert env.sim.last_kernel.startswith("k_steps_open")
+    env.terminate()
 
 
 def test_desired_velocity_env_equals_oracle_on_the_c4_configuration():
