@@ -73,8 +73,6 @@ class BottleneckEnv(Env):
         add = env_params.additional_params
         if not add["disable_tb"] or not add["disable_ramp_metering"]:
             raise NotImplementedError("the toll booth / ramp meter (traffic lights, ALINEA) are not built")
-        if env_params.evaluate:
-            raise NotImplementedError("the evaluate reward of the bottleneck envs (outflow over 500 s) is not built")
         net = scenario if scenario is not None else network
         self.scaling = net.net_params.additional_params.get("scaling", 1)
         self.edge_dict = dict()
@@ -391,8 +389,6 @@ class BottleneckDesiredVelocityEnv(BottleneckEnv):
         default = [(str(i), 1, True) for i in range(1, 6)]
         self.segments = add.get("controlled_segments", default)
         self.symmetric = add.get("symmetric")
-        if self.symmetric:
-            raise NotImplementedError("symmetric=True (one action per segment for all lanes) is not built")
         self.obs_segments = add.get("observed_segments", [])
         self.num_obs_segments = [segment[1] for segment in self.obs_segments]
         self.is_controlled = [segment[2] for segment in self.segments]
@@ -405,12 +401,18 @@ class BottleneckDesiredVelocityEnv(BottleneckEnv):
         self.slices = {edge: np.linspace(0, self.k.network.edge_length(edge), n + 1) for edge, n, _ in self.segments}
         self.obs_slices = {edge: np.linspace(0, self.k.network.edge_length(edge), n + 1)
                            for edge, n in self.obs_segments}
-        # offset of every controlled edge in the action vector (bottleneck.py:826-844)
-        self.action_index, offset = {}, 0
+        # offset of every controlled edge in the action vector (bottleneck.py:826-844); symmetric: the offsets advance by
+        # ONE per controlled edge whatever its number of segments (:829-831 adds `controlled`), kept as written
+        self.action_index, offset, per_lane = {}, 0, 0
+        self._sym_map = []                                   # kernel column (edge, segment, lane) -> symmetric action index
         for edge, n, controlled in self.segments:
             if controlled:
-                self.action_index[edge] = [offset]
-                offset += n * self.k.network.num_lanes(edge)
+                lanes = self.k.network.num_lanes(edge)
+                self.action_index[edge] = [offset if self.symmetric else per_lane]
+                self._sym_map += [bucket + offset for bucket in range(n) for _ in range(lanes)]
+                offset += 1
+                per_lane += n * lanes
+        self._sym_map = np.asarray(self._sym_map, dtype=np.int64) if self.symmetric else None
 
     def _fs_cells(self, tables):
         """Lane-segments in the order get_state / the action vector walk them: edge, segment, lane."""
@@ -448,13 +450,26 @@ class BottleneckDesiredVelocityEnv(BottleneckEnv):
         for segment in self.segments:
             if segment[2]:
                 action_size += self.k.network.num_lanes(segment[0]) * segment[1]
+        if self.symmetric:                                   # :850-851: one action per segment for all its lanes
+            action_size = self.total_controlled_segments
         add_params = self.env_params.additional_params
         return Box(low=-add_params.get("max_decel") * self.sim_step, high=add_params.get("max_accel") * self.sim_step,
                    shape=(int(action_size),), dtype=np.float32)
 
     def _apply_rl_actions(self, rl_actions):
-        """bottleneck.py:926-969: handed to the kernel, which finds each RL vehicle's lane-segment itself."""
-        self._dv_actions = np.asarray(rl_actions, dtype=np.float32).reshape(1, -1)
+        """bottleneck.py:926-969: handed to the kernel, which finds each RL vehicle's lane-segment itself.  symmetric
+        (:946-949): the action of a lane-segment is ``rl_actions[bucket + action_index[edge]]`` -- gathered here into the
+        kernel's one-column-per-lane-segment row."""
+        a = np.asarray(rl_actions, dtype=np.float32).reshape(-1)
+        self._dv_actions = (a[self._sym_map] if self.symmetric else a).reshape(1, -1)
+
+    def compute_reward(self, rl_actions, **kwargs):
+        """:971-981; evaluate: the outflow over the last 500 s at the horizon, 0 before."""
+        if self.env_params.evaluate:
+            if self.time_counter == self.env_params.horizon:
+                return self.k.vehicle.get_outflow_rate(500)
+            return 0
+        return self._last_reward
 
     def _action_vector(self):
         a, self._dv_actions = self._dv_actions, None

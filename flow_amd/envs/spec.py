@@ -276,7 +276,8 @@ def build_open_spec(env, num_replicas, rng=None):
         action_low=float(np.min(space.low)) if space.low.size else 0.0,          # an env without RL vehicles has an
         action_high=float(np.max(space.high)) if space.high.size else 0.0,      # empty action space
         # MultiEnv.clip_actions returns the dict unclipped in this fork (multiagent/base.py:366-391)
-        clip_actions=bool(ep.clip_actions) and env.FS_ENV != L.FS_ENV_MERGE_MA, evaluate=bool(ep.evaluate),
+        clip_actions=bool(ep.clip_actions) and env.FS_ENV != L.FS_ENV_MERGE_MA,
+        evaluate=bool(ep.evaluate) and not lane_drop,      # (BottleneckDesiredVelocityEnv's evaluate reward is the host's)
         horizon=ep.horizon, warmup_steps=int(ep.warmup_steps), sims_per_step=int(ep.sims_per_step),
         seed=handle_seed(sp), replica_offset=int(getattr(env, "_replica_offset", 0)), track_aux=bool(getattr(env, "_track_aux", True)),
         ma_apply_actions=not bool(getattr(env, "APPLY_ENUMERATE_QUIRK", True)),

@@ -48,6 +48,11 @@ class VecFlowEnv(object):
         if env.FS_ENV is None or getattr(env, "HOST_HEADS", False):
             env.terminate()
             raise NotImplementedError("VecFlowEnv needs an env with an in-kernel observation/reward head")
+        if getattr(env, "symmetric", False) or (env.FS_ENV in (L.FS_ENV_BOTTLENECK_DV, L.FS_ENV_BOTTLENECK)
+                                                and env_params.evaluate):
+            env.terminate()
+            raise NotImplementedError("BottleneckDesiredVelocityEnv(symmetric=True) / evaluate=True gather their actions / "
+                                      "reward on the host: scalar Env only")
         self.env = env
         self.sim = env.sim
         self.k = env.k

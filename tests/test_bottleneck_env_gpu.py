@@ -322,3 +322,40 @@ def test_simulate_script_runs_the_bottleneck_experiment(tmp_path):
     assert "steps/second" in out.stdout and "Round 0, return" in out.stdout
     m = re.search(r"Average, std outflows: ([0-9.]+)", out.stdout)
     assert m and 800 < float(m.group(1)) < 2400, out.stdout[-800:]
+
+
+def test_symmetric_actions_and_the_evaluate_reward_of_the_desired_velocity_env():
+    """bottleneck.py:802-851, 946-949: symmetric=True -- one action per segment for all its lanes (6 instead of 20), found
+    at ``bucket + action_index[edge]`` where the offsets advance by ONE per controlled edge (the reference's own
+    arithmetic: segments of neighbouring edges share an entry) -- steps exactly like the per-lane environment fed the
+    gathered row.  :971-978: evaluate=True pays nothing until the horizon, then get_outflow_rate(500)."""
+    from flow_amd.envs import VecFlowEnv
+    fp_sym, fp_ref = c4_flow_params(horizon=200, warmup_steps=0), c4_flow_params(horizon=200, warmup_steps=0)
+    fp_sym["env"].additional_params["symmetric"] = True
+    sym, ref = make_env(fp_sym), make_env(fp_ref)
+    assert sym.action_space.shape == (6,) and ref.action_space.shape == (20,)
+    assert sym.action_index == {"2": [0], "3": [1], "4": [2]} and ref.action_index == {"2": [0], "3": [8], "4": [16]}
+    np.testing.assert_array_equal(sym.reset(), ref.reset())
+    rng = np.random.default_rng(4)
+    for k in range(150):
+        a = rng.uniform(-1.5, 1.5, 6).astype(np.float32)
+        wide = np.concatenate([np.repeat(a[0:2], 4), np.repeat(a[1:3], 4), np.repeat(a[2:4], 2)])   # edges 2, 3, 4
+        o1, r1, d1, _ = sym.step(a)
+        o2, r2, d2, _ = ref.step(wide)
+        np.testing.assert_array_equal(o1, o2)
+        assert r1 == r2 and d1 == d2
+    assert len(sym.k.vehicle.get_rl_ids()) >= 2
+    sym.terminate(), ref.terminate()
+    with pytest.raises(NotImplementedError, match="scalar Env only"):
+        VecFlowEnv(fp_sym, num_replicas=4, device=0)
+    fp_ev = c4_flow_params(horizon=120, warmup_steps=0)
+    fp_ev["env"].evaluate = True
+    ev = make_env(fp_ev)
+    ev.reset()
+    for k in range(120):
+        obs, rew, done, _ = ev.step(np.zeros(20, dtype=np.float32))
+        if k < 119:
+            assert rew == 0 and not done
+    arrived = sum(ev.k.vehicle._num_arrived)
+    assert done and arrived > 5 and rew == pytest.approx(3600 * arrived / (120 * 0.5))
+    ev.terminate()
