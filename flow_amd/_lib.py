@@ -12,7 +12,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 # FLOWSIM_LIB: a development build of the same sources (e.g. the phase-timer build of scripts/phase_open.py)
 LIB_PATH = os.environ.get("FLOWSIM_LIB") or os.path.join(PKG, "libflowsim.so")
 
-FS_ABI_VERSION = 7
+FS_ABI_VERSION = 8
 FS_MAX_CTRL_PARAMS = 8
 
 # error codes

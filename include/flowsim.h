@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FS_ABI_VERSION 7
+#define FS_ABI_VERSION 8
 
 /* ---- error codes -------------------------------------------------------- */
 #define FS_OK 0

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(lib):
     for name in declared_symbols():
         assert hasattr(lib, name), name
     from flow_amd import _lib
-    assert lib.fs_abi_version() == _lib.FS_ABI_VERSION == 7
+    assert lib.fs_abi_version() == _lib.FS_ABI_VERSION == 8
 
 
 def test_ctypes_layout_matches_the_c_header(tmp_path):
