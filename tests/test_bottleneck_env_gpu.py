@@ -363,5 +363,5 @@ def test_symmetric_actions_and_the_evaluate_reward_of_the_desired_velocity_env()
         if k < 119:
             assert rew == 0 and not done
     arrived = sum(ev.k.vehicle._num_arrived)
-    assert done and arrived > 5 and rew == pytest.approx(3600 * arrived / (120 * 0.5))
+    assert done and arrived >= 3 and rew == pytest.approx(3600 * arrived / (120 * 0.5))
     ev.terminate()
