@@ -78,6 +78,29 @@ __device__ __forceinline__ void policy_load(const PolicyView& pv, PolicyLds* L, 
   __syncthreads();
 }
 
+// (a, b, c) of lanes (k, k + 1, k + 2) mod 16 of every 16-lane row -> all lanes of the row (k wave-uniform): three DPP row
+// broadcasts behind one jump on k, where three ds_bpermute would be an LDS round trip the wave waits out (nothing else
+// to issue: the policy's first layer needs the three values)
+__device__ __forceinline__ void row_bcast3(int k, float a, float b, float c, float& oa, float& ob, float& oc) {
+#define FS_RB3(K_) case K_: oa = dpp<DPP_ROW_NEWBCAST0 + K_>(a); ob = dpp<DPP_ROW_NEWBCAST0 + ((K_ + 1) & 15)>(b); \
+                           oc = dpp<DPP_ROW_NEWBCAST0 + ((K_ + 2) & 15)>(c); break;
+  switch (k & 15) {
+    FS_RB3(0) FS_RB3(1) FS_RB3(2) FS_RB3(3) FS_RB3(4) FS_RB3(5) FS_RB3(6) FS_RB3(7)
+    FS_RB3(8) FS_RB3(9) FS_RB3(10) FS_RB3(11) FS_RB3(12) FS_RB3(13) FS_RB3(14) FS_RB3(15)
+  }
+#undef FS_RB3
+}
+// the same lane k three times
+__device__ __forceinline__ void row_bcast1x3(int k, float a, float b, float c, float& oa, float& ob, float& oc) {
+#define FS_RB1(K_) case K_: oa = dpp<DPP_ROW_NEWBCAST0 + K_>(a); ob = dpp<DPP_ROW_NEWBCAST0 + K_>(b); \
+                           oc = dpp<DPP_ROW_NEWBCAST0 + K_>(c); break;
+  switch (k & 15) {
+    FS_RB1(0) FS_RB1(1) FS_RB1(2) FS_RB1(3) FS_RB1(4) FS_RB1(5) FS_RB1(6) FS_RB1(7)
+    FS_RB1(8) FS_RB1(9) FS_RB1(10) FS_RB1(11) FS_RB1(12) FS_RB1(13) FS_RB1(14) FS_RB1(15)
+  }
+#undef FS_RB1
+}
+
 __device__ __forceinline__ float policy_tanh(float z) {
   const float e = __builtin_amdgcn_exp2f(z * 2.885390081777927f);       // exp(2 z)
   const float r = __builtin_amdgcn_rcpf(e + 1.0f);
@@ -453,9 +476,7 @@ __global__ __launch_bounds__(256) void k_ring_policy(DevView<T> s, PolicyView pv
       const float n = po_c == 0 ? v_me : (po_c == 1 ? n1 : n2);
       const float q = div_via_f64(n, po_div, po_rc);
       if (rvalid && po_c < 3) orow[po_c] = q;
-      o0 = __shfl(q, src0, 64);
-      o1 = __shfl(q, src1, 64);
-      o2 = __shfl(q, src2, 64);
+      row_bcast3(k_po, q, q, q, o0, o1, o2);
     } else {
       float q0, q1, q2;
       if (MIXED) {
@@ -647,6 +668,10 @@ __global__ __launch_bounds__(256) void k_loop_policy(DevView<float> s, PolicyVie
   const X za_lo = in_vgpr(X(s.za_lo)), za_hi = in_vgpr(X(s.za_hi)), zb_lo = in_vgpr(X(s.zb_lo)), zb_hi = in_vgpr(X(s.zb_hi));
   const T max_cost = in_vgpr(T(s.max_cost));
   const DivC d_ms = make_divc(T(s.max_speed)), d_L = make_divc(T(L)), d_15 = make_divc(15.0f), d_po = make_divc(T(s.po_max_length));
+  // the reward's quotients (k_rollout_loop divides in float32 once per block of four steps; here every step does, so the
+  // constant divisors take the float64 route: the correctly rounded quotient either way, half the instructions)
+  const DivC d_N = make_divc(T(s.N)), d_nrl = make_divc(T(s.num_rl > 0 ? s.num_rl : 1)), d_20 = make_divc(20.0f),
+             d_mc = make_divc(T(s.max_cost) + T(1.1920928955078125e-07));
   IdmC ic;
   ic.p1 = sl.p[1]; ic.p2 = sl.p[2]; ic.p4 = sl.p[4]; ic.p5 = sl.p[5];
   ic.v0 = make_divc(sl.p[0]);
@@ -692,9 +717,7 @@ __global__ __launch_bounds__(256) void k_loop_policy(DevView<float> s, PolicyVie
     if (HEAD == 1) {
       const float po0 = divc(v, d_15), po1 = divc(vl - v, d_15), po2 = divc(d, d_po);      // wave_attenuation.py:248-269
       if (obs_lane) { orow[0] = po0; orow[1] = po1; orow[2] = po2; }
-      o0 = __shfl(po0, src_rl, 64);
-      o1 = __shfl(po1, src_rl, 64);
-      o2 = __shfl(po2, src_rl, 64);
+      row_bcast1x3(k_rl, po0, po1, po2, o0, o1, o2);
     } else {
       const X xo = c_fs + c_sl * (x - c_st);
       const float po0 = divc(v, d_ms), po1 = divc(xo, d_L);                                   // accel.py:116-123
@@ -801,15 +824,15 @@ __global__ __launch_bounds__(256) void k_loop_policy(DevView<float> s, PolicyVie
       const T racc = seg_sum<SEG>(valid ? T(v) : T(0));
       // (k_rollout_loop sums |clip(a)| over the lanes of the RL columns: one column, one non-zero term -- the term itself)
       const T racc2 = tabs(hmin(hmax(T(a), clip_lo), clip_hi));
-      const T mean_v = racc / T(N);
-      const T mean_a = racc2 / T(num_rl);
-      reward = T(4.0) * mean_v / T(20);
+      const T mean_v = divc(racc, d_N);
+      const T mean_a = divc(racc2, d_nrl);
+      reward = divc(T(4.0) * mean_v, d_20);
       if (mean_a > T(0)) reward = reward + T(4) * (T(0) - mean_a);
       reward = bad ? T(0) : reward;
     } else {                                                       // rewards.py:6-59
       const T dv = valid ? T(v) - target_v : T(0);
       const T cost = tsqrt(seg_sum<SEG>(dv * dv));
-      reward = tmax(max_cost - cost, T(0)) / (max_cost + T(1.1920928955078125e-07));
+      reward = divc(tmax(max_cost - cost, T(0)), d_mc);
       reward = bad ? T(0) : reward;
     }
     const uint8_t dflag = done_flag(tcount >= s.step_limit, crashed);
