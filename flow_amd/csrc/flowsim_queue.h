@@ -80,8 +80,8 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
 
   __shared__ OpenTabsLds<T> tabs_mem;
   __shared__ QueueRow rows[64];
-  __shared__ float scr_f[64];
-  __shared__ int scr_i[64];
+  __shared__ float scr_f[64], scr_g[64], act_row[64];
+  __shared__ int scr_i[64], scr_j[64];
   OpenTabs<T, true> tb;
   tb.load(o, lane, false, &tabs_mem);
 
@@ -333,6 +333,7 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
   };
 
   const int obs_dim = o.obs_dim;
+  const double ms64 = double(s.max_speed), rc_ms64 = 1.0 / ms64, nl64 = double(o.net_length), rc_nl64 = 1.0 / nl64;
   const size_t step_rows = obs_every_step ? size_t(s.R) : 0;
   float* orow = obs + size_t(r) * obs_dim;
   float* rrow = rew + r;
@@ -499,9 +500,9 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
     // the end of D moves when the head of U0 passes the merge point: no vehicle changes lane, the lanes' facts do
     if (structural || inserted) classes(reload);
     if (ACT) {
-      if (moved) {                                     // my vehicle may be another one now: its action column
-        const float* act = actions + size_t(step) * act_stride + size_t(r) * s.num_rl;
-        a_me = act[rl_col < s.num_rl ? rl_col : 0];
+      if (moved) {                                     // my vehicle may be another one now: its action column (the
+        a_me = act_row[rl_col & 63];                   // step's row waits in LDS: a global load here was an L2 round trip)
+        q_fence();
       }
       mHaveRl = mKrl & __ballot(!(a_me != a_me));      // NaN: no action for this vehicle this step
     }
@@ -511,9 +512,9 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
   for (int step = 0; step < num_steps; ++step) {
     if (ACT) {                                         // the step's action row, by RL column, in LDS
       const float* act = actions + size_t(step) * act_stride + size_t(r) * s.num_rl;
-      scr_f[lane] = lane < s.num_rl ? act[lane] : 0.0f;
+      act_row[lane] = lane < s.num_rl ? act[lane] : 0.0f;
       q_fence();
-      a_me = scr_f[rl_col & 63];
+      a_me = act_row[rl_col & 63];
       q_fence();
     }
     if (ACT) mHaveRl = mKrl & __ballot(!(a_me != a_me));          // NaN: no action for this vehicle this step
@@ -644,11 +645,29 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
       const T fx_t = read_lane(fx, td);
       T fx_l = isA ? fx_up : fx_dn;
       fx_l = uh ? fx_t : fx_l;
-      // the follower is a SLOT: which lane holds it now
-      to_slots_i(lane, alive, -1);                                    // (scr_i: lane of slot i, -1 if free)
-      const int fo = alive ? foll : -1;
-      const int fl = fo >= 0 ? scr_i[fo & 63] : -1;
+      // ONE exchange hands everything the head needs by SLOT to the slots' lanes (the follower is a slot: which lane
+      // holds it now; the reward's sums run in slot order): four scatters, one wait, the reads, one wait -- a free slot's
+      // entry is stale and masked by `alive_lab` (the first version cleared and waited per value: fourteen LDS round trips)
+      const T dvt = v - s.target_velocity;
+      const bool use = alive && k_rl && has && (v > 0.0f);
+      const T t_headway = tmax(h / (use ? v : 1.0f), 0.0f);
+      const T term = tmin((t_headway - 1.0f) / 1.0f, 0.0f);
+      if (alive) {
+        scr_i[lab & 63] = lane;
+        scr_f[lab & 63] = s.evaluate ? v : dvt * dvt;
+        scr_g[lab & 63] = term;
+        scr_j[lab & 63] = use ? 1 : 0;
+      }
       q_fence();
+      const bool slot_alive = ((alive_lab >> lane) & 1ull) != 0ull;
+      const int fo = alive ? foll : -1;
+      const int fl_ = scr_i[fo & 63];
+      const T sum_s_ = scr_f[lane], term_s_ = scr_g[lane];
+      const int use_s_ = scr_j[lane];
+      q_fence();
+      const int fl = (fo >= 0 && ((alive_lab >> (fo & 63)) & 1ull) != 0ull) ? fl_ : -1;
+      const T sum_s = slot_alive ? sum_s_ : 0.0f, term_s = slot_alive ? term_s_ : 0.0f;
+      const int use_s = slot_alive ? use_s_ : 0;
       T v_f = bperm(v, fl >= 0 ? fl : lane), h_f = bperm(h, fl >= 0 ? fl : lane);
       if (fo >= 0 && fl < 0) {                          // a recorded follower that has left: its slot's values of record
         v_f = s.vel[base + size_t(fo)];
@@ -660,12 +679,12 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
       const T lead_head = hl ? fx_l - fx - LEN : o.net_length;
       const T follow_speed = fo >= 0 ? v_f : 0.0f;
       const T follow_head = fo >= 0 ? h_f : o.net_length;
-      T f5[5];
-      f5[0] = this_speed / s.max_speed;
-      f5[1] = (lead_speed - this_speed) / s.max_speed;
-      f5[2] = lead_head / o.net_length;
-      f5[3] = (this_speed - follow_speed) / s.max_speed;
-      f5[4] = follow_head / o.net_length;
+      T f5[5];                                                        // (launch-constant divisors: the exact float64 route)
+      f5[0] = div_via_f64(this_speed, ms64, rc_ms64);
+      f5[1] = div_via_f64(lead_speed - this_speed, ms64, rc_ms64);
+      f5[2] = div_via_f64(lead_head, nl64, rc_nl64);
+      f5[3] = div_via_f64(this_speed - follow_speed, ms64, rc_ms64);
+      f5[4] = div_via_f64(follow_head, nl64, rc_nl64);
       if (alive && k_rl) {
         const int col = rows[lab & 63].rl_index;
 #pragma unroll
@@ -679,21 +698,15 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
       const int n_alive = nA + n1;
       T reward;
       if (s.evaluate) {
-        const T sum_v = seg_sum<64>(to_slots_f(v, alive, 0.0f));
+        const T sum_v = seg_sum<64>(sum_s);
         reward = n_alive > 0 ? sum_v / T(n_alive) : 0.0f;
       } else {
         const T mc_lane = tb.template t_gather<TAB_MAX_COST>(n_alive & 63);
         const T max_cost = n_alive < 64 ? mc_lane : o.max_cost_full;
-        const T dv = v - s.target_velocity;
-        const T cost = tsqrt(seg_sum<64>(to_slots_f(dv * dv, alive, 0.0f)));
+        const T cost = tsqrt(seg_sum<64>(sum_s));
         T cost1 = tmax(max_cost - cost, 0.0f) / (max_cost + 1.1920928955078125e-07f);
         const bool bad = (__ballot(alive && (v < -100.0f)) != 0ull) || n_alive == 0;
         cost1 = bad ? 0.0f : cost1;
-        const bool use = alive && k_rl && has && (v > 0.0f);
-        const T t_headway = tmax(h / (use ? v : 1.0f), 0.0f);
-        const T term = tmin((t_headway - 1.0f) / 1.0f, 0.0f);
-        const T term_s = to_slots_f(term, use, 0.0f);
-        const int use_s = to_slots_i(1, use, 0);
         T cost2 = 0.0f;
         for (unsigned long long u = __ballot(use_s != 0); u; u &= u - 1ull) cost2 = cost2 + read_lane(term_s, __ffsll((long long)u) - 1);
         reward = tmax(cost1 + 0.1f * cost2, 0.0f);
