@@ -44,7 +44,8 @@ def parts():
             out.append(("seg%d_%s" % (seg, tn), PART, ["-DFS_PART_T=" + t, "-DFS_PART_SEG=%d" % seg]))
         for w in (2, 4):
             out.append(("wide%d_%s" % (w, tn), PART, ["-DFS_PART_T=" + t, "-DFS_PART_WIDE=%d" % w]))
-    out.append(("queue_f32", PART, ["-DFS_PART_T=float", "-DFS_PART_QUEUE=1"]))
+    out.append(("queue_f32", PART, ["-DFS_PART_T=float", "-DFS_PART_QUEUE=1"] +
+                (["-DFS_QDIAG=1"] if os.environ.get("FLOWSIM_QDIAG") else [])))     # cycle counters of k_merge_queue's sections
     return out
 
 

@@ -359,8 +359,18 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
     }
   };
 
+#ifdef FS_QDIAG
+  unsigned long long dg_t[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};    // cycles: 0 events, 1 resort + join, 2 arrivals, 3 insertions, 4 classes, 5 noise, 6 head, 7 total
+  int dg_n[4] = {0, 0, 0, 0};                               // calls: events, arrivals, insertions, noise blocks
+#define FS_QT(var_) const unsigned long long var_ = __builtin_readcyclecounter()
+#define FS_QA(slot_, t0_) dg_t[slot_] += __builtin_readcyclecounter() - (t0_)
+#else
+#define FS_QT(var_)
+#define FS_QA(slot_, t0_)
+#endif
   // ---- the events of a sub-step (cold: a wave-uniform branch of the loop below) -----------------------------------
   auto events = [&](int step, bool structural, bool try_insert) {
+    FS_QT(q_ev0);
     bool moved = false, reload = false;
     bool isA = lane < nA, isU = lane >= 64 - n1;
     arr_rl = 0ull;
@@ -390,6 +400,8 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
         isA = lane < nA; isU = lane >= 64 - n1;
         moved = reload = true;
       }
+      FS_QA(1, q_ev0);
+      FS_QT(q_ar0);
       // M4: arrivals are the head of A
       const bool arrived = isA && (x >= end_x);
       const int na = __popcll(__ballot(arrived));
@@ -403,14 +415,30 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
           if (rows[lj].ctrl == FS_CTRL_RL) arr_rl |= 1ull << lj;
         }
         alive_lab &= ~just_arrived;
-        nA -= na;
-        gather_all(lane + na, lane < nA);
+        // queue A moves up by the vehicles that left: lane i takes lane i + 1 (DPP: no LDS round trip per register)
+        for (int j = 0; j < na; ++j) {
+          nA -= 1;
+          const bool take = lane < nA;
+#define FS_Q_S(reg_) do { const auto t_ = dpp<DPP_WAVE_SHL1>(reg_); reg_ = take ? t_ : reg_; } while (0)
+#define FS_Q_SI(reg_) do { const int t_ = dpp_i<DPP_WAVE_SHL1>(reg_); reg_ = take ? t_ : reg_; } while (0)
+          FS_Q_S(x); FS_Q_S(v); FS_Q_SI(lab); FS_Q_SI(route); FS_Q_SI(seq); FS_Q_SI(origin); FS_Q_SI(foll); FS_Q_S(foll_h);
+          FS_Q_S(prev_v); FS_Q_S(last_acc); FS_Q_S(vmax);
+          if (ACT) FS_Q_S(a_me);
+          if (NOISE) { FS_Q_S(g0); FS_Q_S(g1); FS_Q_S(g2); FS_Q_S(g3); }
+#undef FS_Q_SI
+#undef FS_Q_S
+        }
         isA = lane < nA;
         moved = reload = true;
+#ifdef FS_QDIAG
+        dg_n[1] += 1;
+#endif
       }
+      FS_QA(2, q_ar0);
     }
     // ---- M2 / M3: insertions in InFlows order ---------------------------------------------------------------
     bool inserted = false;
+    FS_QT(q_in0);
     if (try_insert) {
       const double now = double(sim_steps - 1) * o.dt_d;
       auto schedule = [&](double& t_mine) -> bool {
@@ -423,6 +451,8 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
       double t_mine;
       const bool due_me = schedule(t_mine);
       unsigned fm = unsigned(__ballot(due_me)) & 0xffu;
+      FS_QA(8, q_in0);
+      FS_QT(q_i2);
       while (fm != 0u) {
         const int f = __ffs(int(fm)) - 1;
         fm &= fm - 1u;
@@ -486,6 +516,8 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
           if (lane == f) emit_l = k + 1;
         }
       }
+      FS_QA(9, q_i2);
+      FS_QT(q_i3);
       if (inserted) {
         moved = reload = true;
         nz_reload = 1;                                 // the newcomers' draws: the block is evaluated again
@@ -495,10 +527,23 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
       double t_after;
       const bool still_due = schedule(t_after);
       pend_m = __ballot(still_due) & 0xffull;
-      due_n = __builtin_amdgcn_readfirstlane(due_index(seg_min<64>(still_due ? 1.0e300 : t_after)));   // (uniform: LLVM takes a DPP result for divergent)
+      // (the inflows sit in lanes 0 .. 7: the minimum of their indices -- due_index is monotone -- by three DPP steps)
+      int dn_ = due_index(still_due ? 1.0e300 : t_after);
+      { const int w_ = dpp_i<DPP_QUAD_XOR1>(dn_); dn_ = w_ < dn_ ? w_ : dn_; }
+      { const int w_ = dpp_i<DPP_QUAD_XOR2>(dn_); dn_ = w_ < dn_ ? w_ : dn_; }
+      { const int w_ = dpp_i<DPP_ROW_HALF_MIRROR>(dn_); dn_ = w_ < dn_ ? w_ : dn_; }
+      due_n = __builtin_amdgcn_readfirstlane(dn_);
+      FS_QA(10, q_i3);
     }
+    FS_QA(3, q_in0);
+#ifdef FS_QDIAG
+    dg_n[2] += inserted ? 1 : 0;
+    dg_n[0] += 1;
+#endif
+    FS_QT(q_cl0);
     // the end of D moves when the head of U0 passes the merge point: no vehicle changes lane, the lanes' facts do
     if (structural || inserted) classes(reload);
+    FS_QA(4, q_cl0);
     if (ACT) {
       if (moved) {                                     // my vehicle may be another one now: its action column (the
         a_me = act_row[rl_col & 63];                   // step's row waits in LDS: a global load here was an L2 round trip)
@@ -506,9 +551,13 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
       }
       mHaveRl = mKrl & __ballot(!(a_me != a_me));      // NaN: no action for this vehicle this step
     }
+    FS_QA(0, q_ev0);
   };
 
   asm volatile("" :: "v"(x), "v"(v), "v"(route), "v"(seq), "v"(origin), "v"(foll), "v"(foll_h), "v"(prev_v), "v"(last_acc), "v"(vmax));
+#ifdef FS_QDIAG
+  const unsigned long long dg_start = __builtin_readcyclecounter();
+#endif
   for (int step = 0; step < num_steps; ++step) {
     if (ACT) {                                         // the step's action row, by RL column, in LDS
       const float* act = actions + size_t(step) * act_stride + size_t(r) * s.num_rl;
@@ -523,10 +572,15 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
       T g_now = 0.0f;
       if (NOISE) {
         if ((nctr & 3u) == 0u || nz_reload != 0) {       // (wave-uniform: the counter is the replica's)
+          FS_QT(q_nz0);
+#ifdef FS_QDIAG
+          dg_n[3] += 1;
+#endif
           T g[4];
           gauss4<T>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(r), uint32_t(lab & 63), nctr >> 2, g);
           g0 = g[0]; g1 = g[1]; g2 = g[2]; g3 = g[3];
           nz_reload = 0;
+          FS_QA(5, q_nz0);
         }
         const uint32_t ph = nctr & 3u;
         const T lo_ = (ph & 1u) ? g1 : g0, hi_ = (ph & 1u) ? g3 : g2;
@@ -634,13 +688,30 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
 
     // ---- get_state / compute_reward / done ------------------------------------------------------------------
     const bool emit = obs_every_step || (step == num_steps - 1);
+    FS_QT(q_hd0);
     if (emit) {
       const bool isA = lane < nA, isU = lane >= 64 - n1, alive = isA | isU, uh = isU && lane == 63;
       const bool has = ((mHas >> lane) & 1ull) != 0ull, k_rl = ((mKrl >> lane) & 1ull) != 0ull;
       // the five features of my vehicle (flow/envs/multiagent/merge.py:108-140)
-      bool internal_;
+      // Flow's coordinate of x (O5, route_lookup's arithmetic): both routes' tables are launch constants in scalar
+      // registers -- five compares and selects each, no table walk through LDS (that walk was half of the head's time)
       T fx;
-      route_lookup<2>(o, tb, x, route < 0 ? 0 : route, internal_, fx);
+      {
+        T fxr[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          T st = qc.seg_start[rt][0], fs0 = qc.seg_flow[rt][0], sl = qc.seg_slope[rt][0];
+#pragma unroll
+          for (int q = 1; q < 6; ++q) {
+            const bool hit = x >= qc.seg_start[rt][q];
+            st = hit ? qc.seg_start[rt][q] : st;
+            fs0 = hit ? qc.seg_flow[rt][q] : fs0;
+            sl = hit ? qc.seg_slope[rt][q] : sl;
+          }
+          fxr[rt] = fs0 + sl * (x - st);
+        }
+        fx = route == 1 ? fxr[1] : fxr[0];
+      }
       const T fx_up = dpp<DPP_WAVE_SHR1>(fx), fx_dn = dpp<DPP_WAVE_SHL1>(fx);
       const T fx_t = read_lane(fx, td);
       T fx_l = isA ? fx_up : fx_dn;
@@ -665,6 +736,8 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
       const T sum_s_ = scr_f[lane], term_s_ = scr_g[lane];
       const int use_s_ = scr_j[lane];
       q_fence();
+      FS_QA(11, q_hd0);
+      FS_QT(q_h2);
       const int fl = (fo >= 0 && ((alive_lab >> (fo & 63)) & 1ull) != 0ull) ? fl_ : -1;
       const T sum_s = slot_alive ? sum_s_ : 0.0f, term_s = slot_alive ? term_s_ : 0.0f;
       const int use_s = slot_alive ? use_s_ : 0;
@@ -694,6 +767,8 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
 #pragma unroll
         for (int q = 0; q < 5; ++q) orow[5 * slot_rl_index + q] = 0.0f;
       }
+      FS_QA(12, q_h2);
+      FS_QT(q_h3);
       // reward (flow/envs/multiagent/merge.py:142-171 over rewards.desired_velocity), sums in SLOT order
       const int n_alive = nA + n1;
       T reward;
@@ -711,6 +786,7 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
         for (unsigned long long u = __ballot(use_s != 0); u; u &= u - 1ull) cost2 = cost2 + read_lane(term_s, __ffsll((long long)u) - 1);
         reward = tmax(cost1 + 0.1f * cost2, 0.0f);
       }
+      FS_QA(13, q_h3);
       if (lane == 0) {
         *rrow = reward;
         *drow = done_flag(tcount >= s.step_limit, false);          // multiagent/base.py:188-190: crash = 0
@@ -719,7 +795,17 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
       rrow += step_rows;
       drow += step_rows;
     }
+    FS_QA(6, q_hd0);
   }
+#ifdef FS_QDIAG
+  dg_t[7] = __builtin_readcyclecounter() - dg_start;
+  if (blockIdx.x == 7 && lane == 0)
+    printf("QDIAG total %llu events %llu (n %d) resort+join %llu arrivals %llu (n %d) insert %llu (n %d) classes %llu noise %llu (n %d) head %llu\n",
+           dg_t[7], dg_t[0], dg_n[0], dg_t[1], dg_t[2], dg_n[1], dg_t[3], dg_n[2], dg_t[4], dg_t[5], dg_n[3], dg_t[6]);
+  if (blockIdx.x == 7 && lane == 0)
+    printf("QDIAG2 insert: schedule %llu loop %llu after %llu | head: exchange %llu features %llu reward %llu\n",
+           dg_t[8], dg_t[9], dg_t[10], dg_t[11], dg_t[12], dg_t[13]);
+#endif
 
   // ---- the state back to its slots -----------------------------------------------------------------------------
   __threadfence();

@@ -514,10 +514,16 @@ struct Sim : SimBase {
       for (int r = 0; r < 2; ++r)
         for (int j = 0; j < 2; ++j) qc.in_lo[r][j] = qc.in_hi[r][j] = 3.0e38f;
       int n_int[2] = {0, 0}, k_of[2] = {0, 0};
+      for (int r = 0; r < 2; ++r)
+        for (int q = 0; q < 6; ++q) { qc.seg_start[r][q] = 3.0e38f; qc.seg_flow[r][q] = 0.0f; qc.seg_slope[r][q] = 0.0f; }
       for (size_t i = 0; i < segs.size() && qc.ok; ++i) {
         const int r = segs[i].route;
         if (r < 0 || r > 1) { qc.ok = 0; break; }
         const int k = k_of[r]++;
+        if (k >= 6) { qc.ok = 0; break; }
+        qc.seg_start[r][k] = float(segs[i].start);
+        qc.seg_flow[r][k] = float(segs[i].flow_start);
+        qc.seg_slope[r][k] = float(segs[i].flow_slope);
         if (!segs[i].internal) continue;
         if (n_int[r] >= 2) { qc.ok = 0; break; }
         float hi = 3.0e38f;                              // the next segment of the same route starts where this one ends
