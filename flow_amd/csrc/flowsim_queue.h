@@ -332,6 +332,18 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
     return out;
   };
 
+  // both routes' segment tables (launch constants) in VGPRs: read from the kernel-argument segment inside the head they came
+  // back as vector memory loads, one L2 round trip per observation
+  T sg_st[2][6], sg_fs[2][6], sg_sl[2][6];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      sg_st[rt][q] = in_vgpr(qc.seg_start[rt][q]);
+      sg_fs[rt][q] = in_vgpr(qc.seg_flow[rt][q]);
+      sg_sl[rt][q] = in_vgpr(qc.seg_slope[rt][q]);
+    }
+  }
   const int obs_dim = o.obs_dim;
   const double ms64 = double(s.max_speed), rc_ms64 = 1.0 / ms64, nl64 = double(o.net_length), rc_nl64 = 1.0 / nl64;
   const size_t step_rows = obs_every_step ? size_t(s.R) : 0;
@@ -693,20 +705,20 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
       const bool isA = lane < nA, isU = lane >= 64 - n1, alive = isA | isU, uh = isU && lane == 63;
       const bool has = ((mHas >> lane) & 1ull) != 0ull, k_rl = ((mKrl >> lane) & 1ull) != 0ull;
       // the five features of my vehicle (flow/envs/multiagent/merge.py:108-140)
-      // Flow's coordinate of x (O5, route_lookup's arithmetic): both routes' tables are launch constants in scalar
-      // registers -- five compares and selects each, no table walk through LDS (that walk was half of the head's time)
+      // Flow's coordinate of x (O5, route_lookup's arithmetic): both routes' tables are launch constants in registers
+      // -- five compares and selects each, no table walk through LDS (that walk was half of the head's time)
       T fx;
       {
         T fxr[2];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
-          T st = qc.seg_start[rt][0], fs0 = qc.seg_flow[rt][0], sl = qc.seg_slope[rt][0];
+          T st = sg_st[rt][0], fs0 = sg_fs[rt][0], sl = sg_sl[rt][0];
 #pragma unroll
           for (int q = 1; q < 6; ++q) {
-            const bool hit = x >= qc.seg_start[rt][q];
-            st = hit ? qc.seg_start[rt][q] : st;
-            fs0 = hit ? qc.seg_flow[rt][q] : fs0;
-            sl = hit ? qc.seg_slope[rt][q] : sl;
+            const bool hit = x >= sg_st[rt][q];
+            st = hit ? sg_st[rt][q] : st;
+            fs0 = hit ? sg_fs[rt][q] : fs0;
+            sl = hit ? sg_sl[rt][q] : sl;
           }
           fxr[rt] = fs0 + sl * (x - st);
         }
