@@ -105,7 +105,7 @@ class fs_config(C.Structure):
                 ("track_followers", C.c_int32), ("num_paths", C.c_int32),
                 ("lane_change_cooldown_steps", C.c_int32), ("reserved6", C.c_int32), ("lane_change_min_gain", C.c_double),
                 ("sort_vehicles", C.c_int32),
-                ("reserved5", C.c_int32), ("obs_perm", C.POINTER(C.c_int32)), ("replica_offset", C.c_int64)]
+                ("noise_exact", C.c_int32), ("obs_perm", C.POINTER(C.c_int32)), ("replica_offset", C.c_int64)]
 
 
 class fs_policy(C.Structure):

@@ -181,6 +181,9 @@ class SumoParams(SimParams):
                     lanes (the simplified model M11, NOT LC2013)
     junction_length length of each internal edge (netconvert output in the reference)
     crash_gap       a replica crashes when a bumper gap falls below this after a move
+    noise_math      'hw': the acceleration noise's Box-Muller transform uses the GPU's log2 / cos instructions (default);
+                    'exact': fixed float32 operation sequences instead, so that noisy float32 runs equal the numpy oracle
+                    bit for bit (a few VALU instructions more per draw)
     precision       'f32' | 'f64' arithmetic and state type of the kernels; 'f16s' (merge network: half state in HBM
                     between launches, float32 integrator -- include/flowsim.h FS_F16S); 'mixed' (float64 state, float32
                     controller: all-IDM single-lane rings, holds 1e-4 of the float64 trajectories at f32 cost)
@@ -192,7 +195,8 @@ class SumoParams(SimParams):
                  print_warnings=True, start_at_load=True, teleport_time=-1, num_clients=1, color_by_speed=False,
                  use_ballistic=False, slowdown_ramp=None, junction_mode=None, junction_length=0.1, crash_gap=0.0,
                  precision="f32", center_length=None, crossing_time_gap=None, max_vehicles=64, slot_capacity=None,
-                 merge_right_of_way=True, zipper_distance=50.0, lane_change_cooldown=5.0, lane_change_min_gain=10.0):
+                 merge_right_of_way=True, zipper_distance=50.0, lane_change_cooldown=5.0, lane_change_min_gain=10.0,
+                 noise_math="hw"):
         super(SumoParams, self).__init__(sim_step, render, restart_instance, emission_path, save_render,
                                          sight_radius, show_radius, pxpm, force_color_update)
         self.port = port
@@ -211,6 +215,9 @@ class SumoParams(SimParams):
         self.junction_length = junction_length
         self.crash_gap = crash_gap
         self.precision = precision
+        if noise_math not in ("hw", "exact"):
+            raise ValueError("noise_math must be 'hw' or 'exact'")
+        self.noise_math = noise_math
         self.center_length = center_length
         self.crossing_time_gap = crossing_time_gap
         self.max_vehicles = max_vehicles

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<typename std::cond
   // per-step index select); a launch that starts in the middle of a block evaluates it and rotates up to there
   T g4[4] = {T(0), T(0), T(0), T(0)};
   if (any_noise && (nctr & 3u) != 0u && noisy) {
-    gauss4<T>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(ii), nctr >> 2, g4);
+    gauss4<T>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(ii), nctr >> 2, g4, s.noise_exact != 0);
     for (uint32_t q = 0; q < (nctr & 3u); ++q) { g4[0] = g4[1]; g4[1] = g4[2]; g4[2] = g4[3]; }
   }
 
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void k_rollout_loop(DevView<typename std::cond
         if (any_noise) {
           if (draw_m != 0ull) {
             if (noisy && (nctr & 3u) == 0u)
-              gauss4<T>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(ii), nctr >> 2, g4);
+              gauss4<T>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(ii), nctr >> 2, g4, s.noise_exact != 0);
           }
         }
         {

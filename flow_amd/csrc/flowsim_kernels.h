@@ -78,6 +78,7 @@ struct DevView {
   // scalars
   int R, N, num_rl, env, integrator, sims_per_step, junction_mode, clip_actions, evaluate, track_aux;
   int num_lanes, lane_change_mode, last_lc_quirk, n_pis, pis_H, sort_vehicles;
+  int noise_exact;      // Box-Muller through bm_ln_exact / bm_cos_exact (fs_config.noise_exact)
   int step_limit;       // sims_per_step*(warmup+horizon), INT_MAX for horizon=inf
   int flags;
   uint32_t seed_lo, seed_hi;
@@ -508,29 +509,75 @@ __device__ __forceinline__ float bm_radius(float u1) {
 __device__ __forceinline__ double bm_radius(double u1) { return sqrt(-2.0 * log(u1)); }
 __device__ __forceinline__ float bm_cos(float turns) { return __builtin_amdgcn_cosf(turns); }
 __device__ __forceinline__ double bm_cos(double turns) { return cos(6.283185307179586 * turns); }
+// EXACT forms (fs_config.noise_exact): ln and cos as fixed sequences of float32 operations -- every +, -, * is one IEEE
+// rounding (the library is built with -ffp-contract=off), the one division and the square root are correctly rounded --
+// so that oracle/refsim.py (exact_ln_f32 / exact_cos_turns_f32: the same sequences in numpy float32) reproduces a noisy
+// float32 run bit for bit.  ln u = e ln 2 + 2 atanh((m - 1) / (m + 1)) for u = m 2^e, m in [sqrt(1/2), sqrt(2)), the odd
+// series up to s^9 (|s| < 0.172: 3e-7 absolute); cos(2 pi t) from the quarter turn q = floor(4 t + 1/2) and the even / odd
+// polynomials of the angle (4 t - q) pi / 2 in [-pi/4, pi/4] (9e-8).
+__device__ __forceinline__ float bm_ln_exact(float u) {
+  const unsigned bits = __builtin_bit_cast(unsigned, u);
+  int e = int(bits >> 23) - 127;
+  float m = __builtin_bit_cast(float, (bits & 0x7FFFFFu) | 0x3F800000u);
+  const bool big = m > 1.4142135f;
+  m = big ? m * 0.5f : m;
+  e += big ? 1 : 0;
+  const float t = m - 1.0f;
+  const float s = t / (2.0f + t);
+  const float z = s * s;
+  float p = z * 0.11111111f + 0.14285715f;
+  p = p * z + 0.2f;
+  p = p * z + 0.33333334f;
+  p = p * z + 1.0f;
+  return float(e) * 0.6931472f + (2.0f * s) * p;
+}
+__device__ __forceinline__ float bm_cos_exact(float t) {
+  const float a = t * 4.0f;
+  const float q = __builtin_floorf(a + 0.5f);
+  const float th = (a - q) * 1.5707964f;
+  const float z = th * th;
+  float c = z * 2.4801587e-05f + -1.3888889e-03f;
+  c = c * z + 4.1666668e-02f;
+  c = c * z + -0.5f;
+  c = c * z + 1.0f;
+  float sn = z * 2.7557319e-06f + -1.9841270e-04f;
+  sn = sn * z + 8.3333338e-03f;
+  sn = sn * z + -1.6666667e-01f;
+  sn = sn * z + 1.0f;
+  sn = sn * th;
+  const int qi = int(q) & 3;
+  const float even = (qi & 2) ? -c : c, odd = (qi & 2) ? sn : -sn;
+  return (qi & 1) ? odd : even;
+}
+__device__ __forceinline__ float bm_radius_x(float u1, bool exact) {
+  return exact ? tsqrt(-2.0f * bm_ln_exact(u1)) : bm_radius(u1);
+}
+__device__ __forceinline__ double bm_radius_x(double u1, bool) { return bm_radius(u1); }     // (float64: libm either way)
+__device__ __forceinline__ float bm_cos_x(float turns, bool exact) { return exact ? bm_cos_exact(turns) : bm_cos(turns); }
+__device__ __forceinline__ double bm_cos_x(double turns, bool) { return bm_cos(turns); }
 template <typename T>
 __device__ __forceinline__ void gauss4(uint32_t seed_lo, uint32_t seed_hi, uint32_t replica, uint32_t vehicle,
-                                       uint32_t block, T* g) {
+                                       uint32_t block, T* g, bool exact = false) {
   uint32_t c0 = block, c1 = vehicle, c2 = replica, c3 = 0u;
   philox4x32_10(c0, c1, c2, c3, seed_lo, seed_hi);
   const T k = T(1.0 / 16777216.0);                     // u1 in (0, 1], u2 in [0, 1): 24-bit integers, exact in float
-  const T ra = bm_radius(T((c0 >> 8) + 1u) * k), ua = T(c1 >> 8) * k;
-  const T rb = bm_radius(T((c2 >> 8) + 1u) * k), ub = T(c3 >> 8) * k;
-  g[0] = ra * bm_cos(ua);
-  g[1] = ra * bm_cos(ua - T(0.25));
-  g[2] = rb * bm_cos(ub);
-  g[3] = rb * bm_cos(ub - T(0.25));
+  const T ra = bm_radius_x(T((c0 >> 8) + 1u) * k, exact), ua = T(c1 >> 8) * k;
+  const T rb = bm_radius_x(T((c2 >> 8) + 1u) * k, exact), ub = T(c3 >> 8) * k;
+  g[0] = ra * bm_cos_x(ua, exact);
+  g[1] = ra * bm_cos_x(ua - T(0.25), exact);
+  g[2] = rb * bm_cos_x(ub, exact);
+  g[3] = rb * bm_cos_x(ub - T(0.25), exact);
 }
 template <typename T>
 __device__ __forceinline__ T gauss(uint32_t seed_lo, uint32_t seed_hi, uint32_t replica, uint32_t vehicle,
-                                   uint32_t step) {
+                                   uint32_t step, bool exact = false) {
   uint32_t c0 = step >> 2, c1 = vehicle, c2 = replica, c3 = 0u;
   philox4x32_10(c0, c1, c2, c3, seed_lo, seed_hi);
   const bool second = (step & 2u) != 0u;
   const uint32_t w1 = second ? c2 : c0, w2 = second ? c3 : c1;
   const T k = T(1.0 / 16777216.0);
   const T u2 = T(w2 >> 8) * k;
-  return bm_radius(T((w1 >> 8) + 1u) * k) * bm_cos((step & 1u) ? u2 - T(0.25) : u2);
+  return bm_radius_x(T((w1 >> 8) + 1u) * k, exact) * bm_cos_x((step & 1u) ? u2 - T(0.25) : u2, exact);
 }
 
 // The four draws of one Philox block, kept over the four steps they serve: draw(ctr) is gauss(.., ctr) bit for bit
@@ -543,11 +590,12 @@ struct NoiseBlock {
   uint32_t block;
   bool loaded;
   __device__ __forceinline__ void init() { block = 0u; loaded = false; g[0] = g[1] = g[2] = g[3] = T(0); }
-  __device__ __forceinline__ T draw(uint32_t seed_lo, uint32_t seed_hi, uint32_t replica, uint32_t vehicle, uint32_t ctr) {
+  __device__ __forceinline__ T draw(uint32_t seed_lo, uint32_t seed_hi, uint32_t replica, uint32_t vehicle, uint32_t ctr,
+                                    bool exact = false) {
     if (__ballot(!loaded || block != (ctr >> 2)) != 0ull) {
       block = ctr >> 2;
       loaded = true;
-      gauss4<T>(seed_lo, seed_hi, replica, vehicle, block, g);
+      gauss4<T>(seed_lo, seed_hi, replica, vehicle, block, g, exact);
     }
     const uint32_t ph = ctr & 3u;
     const T lo = (ph & 1u) ? g[1] : g[0], hi = (ph & 1u) ? g[3] : g[2];
@@ -866,7 +914,7 @@ __device__ __forceinline__ T control_accel_on(const DevView<T>& s, const Slot<T>
     if (CSET == 0 && ct == FS_CTRL_LAC && commanded && live) cst = a;
     if (flags & FLAG_HAS_NOISE) {                // base_controller.py:109-110
       if (sl.noise > T(0))
-        a = a + sl.noise * (EXT_NOISE ? noise_g : gauss<T>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(ii), nctr));
+        a = a + sl.noise * (EXT_NOISE ? noise_g : gauss<T>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(ii), nctr, s.noise_exact != 0));
     }
     if (has) {                                   // base_controller.py:113-116, 141-142, 191-193
       if (sl.failsafe == FS_FAILSAFE_INSTANTANEOUS) a = failsafe_instantaneous(a, v, h, has, s.dt);

@@ -919,7 +919,7 @@ __global__ __launch_bounds__(64) void k_steps_open(DevView<T> s, OpenView<T> o, 
       }
       bool commanded = false;
       T g_now = T(0);
-      if (flags & FLAG_HAS_NOISE) g_now = nzb.draw(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(ii), nctr);
+      if (flags & FLAG_HAS_NOISE) g_now = nzb.draw(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(ii), nctr, s.noise_exact != 0);
       T acc;
       if constexpr (FD) acc = control_accel_fd(s, sl, fd, flags, v, vl, h, has, on_edge, have_rl, a_rl, commanded, g_now);
       else if constexpr (MXC) acc = T(control_accel_fd(s, slf, fd, flags, float(v), float(vl), float(h), has, on_edge, have_rl,

@@ -561,8 +561,8 @@ __global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_step
   float gA[4] = {0.0f, 0.0f, 0.0f, 0.0f}, gB[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   if constexpr (NOISE) {
     if ((nctr & 3u) != 0u) {
-      gauss4<float>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(iA), nctr >> 2, gA);
-      gauss4<float>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(iB), nctr >> 2, gB);
+      gauss4<float>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(iA), nctr >> 2, gA, s.noise_exact != 0);
+      gauss4<float>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(iB), nctr >> 2, gB, s.noise_exact != 0);
       for (uint32_t q = 0; q < (nctr & 3u); ++q) {
         gA[0] = gA[1]; gA[1] = gA[2]; gA[2] = gA[3];
         gB[0] = gB[1]; gB[1] = gB[2]; gB[2] = gB[3];
@@ -695,8 +695,8 @@ __global__ __launch_bounds__(256) void k_rollout_pair(DevView<T> s, int num_step
       const bool fresh = (nctr & 3u) == 0u;                      // a new block of four draws starts with this step
       if (__ballot(fresh) != 0ull) {
         if (fresh) {
-          gauss4<float>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(iA), nctr >> 2, gA);
-          gauss4<float>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(iB), nctr >> 2, gB);
+          gauss4<float>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(iA), nctr >> 2, gA, s.noise_exact != 0);
+          gauss4<float>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(iB), nctr >> 2, gB, s.noise_exact != 0);
         }
       }
       const float tA = sigma.x * gA[0], tB = sigma.y * gB[0];

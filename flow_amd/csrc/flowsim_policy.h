@@ -293,8 +293,8 @@ __global__ __launch_bounds__(256) void k_ring_policy(DevView<T> s, PolicyView pv
   float gA[4] = {0.0f, 0.0f, 0.0f, 0.0f}, gB[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   if constexpr (NOISE) {
     if ((nctr & 3u) != 0u) {
-      gauss4<float>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(iA), nctr >> 2, gA);
-      gauss4<float>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(iB), nctr >> 2, gB);
+      gauss4<float>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(iA), nctr >> 2, gA, s.noise_exact != 0);
+      gauss4<float>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(iB), nctr >> 2, gB, s.noise_exact != 0);
       for (uint32_t q = 0; q < (nctr & 3u); ++q) {
         gA[0] = gA[1]; gA[1] = gA[2]; gA[2] = gA[3];
         gB[0] = gB[1]; gB[1] = gB[2]; gB[2] = gB[3];
@@ -384,8 +384,8 @@ __global__ __launch_bounds__(256) void k_ring_policy(DevView<T> s, PolicyView pv
       const bool fresh = live && (nctr & 3u) == 0u;
       if (__ballot(fresh) != 0ull) {
         if (fresh) {
-          gauss4<float>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(iA), nctr >> 2, gA);
-          gauss4<float>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(iB), nctr >> 2, gB);
+          gauss4<float>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(iA), nctr >> 2, gA, s.noise_exact != 0);
+          gauss4<float>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(iB), nctr >> 2, gB, s.noise_exact != 0);
         }
       }
       const float tA = sigma.x * gA[0], tB = sigma.y * gB[0];
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(256) void k_loop_policy(DevView<float> s, PolicyVie
   const X adt_c = (sl.speed_mode & 2) ? X(s.max_accel[ii]) * dt : X(3.0e38), ddt_c = (sl.speed_mode & 4) ? X(s.max_decel[ii]) * dt : X(3.0e38);
   T g4[4] = {T(0), T(0), T(0), T(0)};
   if (any_noise && (nctr & 3u) != 0u && noisy) {
-    gauss4<T>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(ii), nctr >> 2, g4);
+    gauss4<T>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(ii), nctr >> 2, g4, s.noise_exact != 0);
     for (uint32_t q = 0; q < (nctr & 3u); ++q) { g4[0] = g4[1]; g4[1] = g4[2]; g4[2] = g4[3]; }
   }
   X prev_v = v;
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(256) void k_loop_policy(DevView<float> s, PolicyVie
       if (any_noise) {
         if (__ballot(noisy && (nctr & 3u) == 0u) != 0ull) {
           if (noisy && (nctr & 3u) == 0u)
-            gauss4<T>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(ii), nctr >> 2, g4);
+            gauss4<T>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(ii), nctr >> 2, g4, s.noise_exact != 0);
         }
       }
       T ai = idm_fast<DELTA4, FASTC>(T(v), T(vl), h, has, ic);

@@ -589,7 +589,7 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
           dg_n[3] += 1;
 #endif
           T g[4];
-          gauss4<T>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(r), uint32_t(lab & 63), nctr >> 2, g);
+          gauss4<T>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(r), uint32_t(lab & 63), nctr >> 2, g, s.noise_exact != 0);
           g0 = g[0]; g1 = g[1]; g2 = g[2]; g3 = g[3];
           nz_reload = 0;
           FS_QA(5, q_nz0);

@@ -280,6 +280,7 @@ struct Sim : SimBase {
     dv.num_lanes = cfg.num_lanes < 1 ? 1 : cfg.num_lanes;
     dv.lane_change_mode = cfg.lane_change_mode;
     dv.last_lc_quirk = cfg.last_lc_quirk;
+    dv.noise_exact = cfg.noise_exact != 0 ? 1 : 0;
     dv.lc_duration = T(cfg.lane_change_duration);
     {  // ML7: autonomous lane changing of the non-RL vehicles on a multi-lane ring
       std::vector<int32_t> lca(N, 0);
@@ -710,7 +711,7 @@ struct Sim : SimBase {
     if (cfg.num_paths != 4 || ov.lc_enabled || ov.track_followers || ov.n_prob > 0 || !open_div_ok) return false;
     if (!(dv.flags & fs::FLAG_NO_FLOW_CTRL) || dv.integrator != FS_EULER) return false;
     if (dv.env != FS_ENV_BOTTLENECK_DV && dv.env != FS_ENV_BOTTLENECK) return false;
-    if (dv.env == FS_ENV_BOTTLENECK && dv.num_rl > 0) return false;      // per-vehicle RL accelerations (BottleneckAccelEnv)
+    if (dv.env == FS_ENV_BOTTLENECK && dv.num_rl > 0 && ov.ma_apply_actions) return false;   // per-vehicle RL accelerations (BottleneckAccelEnv)
     if (mask != nullptr || num_steps < 1 || dv.N > 256 || ov.nseg[0] > 16 || ov.obs_span > 3 || ov.act_span > 2) return false;
     for (int i = 0; i < dv.N; ++i)
       if (float(veh[i].length) != float(veh[0].length) || veh[i].type < 0 || veh[i].type > 7) return false;

@@ -689,7 +689,7 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
       T acc = T(0);
       if (any_cmd) {
         if constexpr (FD) {
-          const T g_now = (flags & FLAG_HAS_NOISE) ? gauss<T>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(ii), nctr) : T(0);
+          const T g_now = (flags & FLAG_HAS_NOISE) ? gauss<T>(s.seed_lo, s.seed_hi, s.rep0 + uint32_t(rr), uint32_t(ii), nctr, s.noise_exact != 0) : T(0);
           acc = control_accel_fd(s, sl, fd, flags, v, vl, h, has, on_edge, have_rl, float(a_rl), commanded, g_now);
         } else {
           acc = control_accel_on<T, CSET>(s, sl, flags, v, vl, h, has, vf, hf, mean_v, on_edge, have_rl, a_rl, live && slot_ok,

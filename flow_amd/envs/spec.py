@@ -279,7 +279,7 @@ def build_open_spec(env, num_replicas, rng=None):
         clip_actions=bool(ep.clip_actions) and env.FS_ENV != L.FS_ENV_MERGE_MA,
         evaluate=bool(ep.evaluate) and not lane_drop,      # (BottleneckDesiredVelocityEnv's evaluate reward is the host's)
         horizon=ep.horizon, warmup_steps=int(ep.warmup_steps), sims_per_step=int(ep.sims_per_step),
-        seed=handle_seed(sp), replica_offset=int(getattr(env, "_replica_offset", 0)), track_aux=bool(getattr(env, "_track_aux", True)),
+        seed=handle_seed(sp), noise_math=getattr(sp, "noise_math", "hw"), replica_offset=int(getattr(env, "_replica_offset", 0)), track_aux=bool(getattr(env, "_track_aux", True)),
         ma_apply_actions=not bool(getattr(env, "APPLY_ENUMERATE_QUIRK", True)),
         slot_types=names, slot_base=base, slot_caps=dict(zip(names, caps)), init_slot=init_slot, **tables)
     spec.update(extra)
@@ -353,7 +353,7 @@ def build_spec(env, num_replicas, rng=None):
         action_high=float(space.high[0]) if N and veh_k.num_rl_vehicles else 0.0,
         clip_actions=bool(ep.clip_actions) and not getattr(env, "UNCLIPPED_ACTIONS", False), evaluate=bool(ep.evaluate),
         po_max_length=float(env._po_max_length()), horizon=ep.horizon, warmup_steps=int(ep.warmup_steps),
-        sims_per_step=int(ep.sims_per_step), seed=handle_seed(sp),
+        sims_per_step=int(ep.sims_per_step), seed=handle_seed(sp), noise_math=getattr(sp, "noise_math", "hw"),
         # (FS_MIXED keeps no previous-speed / acceleration fields: a scalar Env with precision='mixed' steps without
         # them -- k.vehicle.get_previous_speed / get_accel then report the values of the last reset)
         track_aux=bool(getattr(env, "_track_aux", True)) and getattr(sp, "precision", "f32") != "mixed",

@@ -181,7 +181,7 @@ class FlowSim:
             num_paths=int(spec.get("num_paths", 0)) if spec.get("network") == "bottleneck" else 0,
             lane_change_cooldown_steps=int(spec.get("lane_change_cooldown_steps", 10)), reserved6=0,
             lane_change_min_gain=float(spec.get("lane_change_min_gain", 10.0)),
-            sort_vehicles=int(bool(spec.get("sort_vehicles", False))), reserved5=0,
+            sort_vehicles=int(bool(spec.get("sort_vehicles", False))), noise_exact=int(spec.get("noise_math", "hw") == "exact"),
             obs_perm=obs_perm.ctypes.data_as(C.POINTER(C.c_int32)) if obs_perm is not None else None,
             replica_offset=int(spec.get("replica_offset", 0)))
         if self.open_net:

@@ -317,7 +317,12 @@ typedef struct fs_config {
   /* ---- observation order of AccelEnv-style heads on single-lane closed loops ---- */
   int32_t sort_vehicles;              /* env_params 'sort_vehicles' (accel.py:101-169): observation entries and RL action
                                          columns follow the absolute position recorded at the last additional_command */
-  int32_t reserved5;
+  int32_t noise_exact;                /* 0: the acceleration noise's Box-Muller uses the hardware's log2 / cos (fast; agrees with
+                                         numpy to a few ulp of the draw); 1: log and cos are fixed sequences of float32
+                                         multiplications, additions and one division (flowsim_kernels.h bm_ln_exact /
+                                         bm_cos_exact; oracle/refsim.py exact_ln_f32 / exact_cos_turns_f32) -- the float32
+                                         kernels then reproduce the numpy oracle's noisy runs bit for bit
+                                         (SumoParams(noise_math='exact'); base_controller.py:109-110) */
   const int32_t* obs_perm;            /* [N] place of slot i's vehicle in get_ids() when InitialConfig.shuffle assigned the
                                          start positions in shuffled id order (envs/base.py:268-292); NULL = identity */
   /* ---- sharding ---- */

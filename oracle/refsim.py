@@ -56,7 +56,51 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
     return c0, c1, c2, c3
 
 
-def gaussian_noise(seed, replica, vehicle, step, dtype):
+def exact_ln_f32(u):
+    """ln(u) for float32 u in (0, 1] as a FIXED sequence of float32 operations (every +, -, *, / is one IEEE rounding; the
+    kernels run the same sequence under -ffp-contract=off: flowsim_kernels.h bm_ln_exact).  u = m 2^e with m in
+    [sqrt(1/2), sqrt(2)): ln u = e ln 2 + 2 atanh(s), s = (m - 1) / (m + 1), atanh by its odd series up to s^9."""
+    f = np.float32
+    u = np.asarray(u, dtype=np.float32)
+    bits = u.view(np.uint32)
+    e = (bits >> np.uint32(23)).astype(np.int32) - np.int32(127)
+    m = ((bits & np.uint32(0x7FFFFF)) | np.uint32(0x3F800000)).view(np.float32)
+    big = m > f(1.4142135)
+    m = np.where(big, m * f(0.5), m)
+    e = e + big.astype(np.int32)
+    t = m - f(1.0)
+    s = t / (f(2.0) + t)
+    z = s * s
+    p = z * f(0.11111111) + f(0.14285715)
+    p = p * z + f(0.2)
+    p = p * z + f(0.33333334)
+    p = p * z + f(1.0)
+    return e.astype(np.float32) * f(0.6931472) + (f(2.0) * s) * p
+
+
+def exact_cos_turns_f32(t):
+    """cos(2 pi t) for float32 t in (-0.25, 1) as a fixed sequence of float32 operations (bm_cos_exact): quarter turns
+    a = 4 t, q = floor(a + 1/2), angle (a - q) pi / 2 in [-pi/4, pi/4], even / odd polynomials, selected by q mod 4."""
+    f = np.float32
+    t = np.asarray(t, dtype=np.float32)
+    a = t * f(4.0)
+    q = np.floor(a + f(0.5))
+    th = (a - q) * f(1.5707964)
+    z = th * th
+    c = z * f(2.4801587e-05) + f(-1.3888889e-03)
+    c = c * z + f(4.1666668e-02)
+    c = c * z + f(-0.5)
+    c = c * z + f(1.0)
+    sn = z * f(2.7557319e-06) + f(-1.9841270e-04)
+    sn = sn * z + f(8.3333338e-03)
+    sn = sn * z + f(-1.6666667e-01)
+    sn = sn * z + f(1.0)
+    sn = sn * th
+    qi = q.astype(np.int32) & np.int32(3)
+    return np.where(qi == 0, c, np.where(qi == 1, -sn, np.where(qi == 2, -c, sn)))
+
+
+def gaussian_noise(seed, replica, vehicle, step, dtype, exact=False):
     """N(0,1) per (replica, vehicle, step): ONE Philox call, keyed by the 64-bit seed with counter
     (step // 4, vehicle, replica, 0), serves four steps: words (c0, c1) and (c2, c3) feed two Box-Muller
     transforms, each used at the angle 2 pi u2 and a quarter turn back (the sine branch written as a cosine) --
@@ -77,6 +121,8 @@ def gaussian_noise(seed, replica, vehicle, step, dtype):
     u1 = u1.astype(dtype)
     u2 = u2.astype(dtype)
     u2 = np.where((j & np.uint32(1)) == 1, u2 - np.asarray(0.25, dtype), u2)
+    if exact and np.dtype(dtype) == np.float32:               # spec['noise_math'] = 'exact': bit-reproducible on the GPU
+        return np.sqrt(np.float32(-2.0) * exact_ln_f32(u1)) * exact_cos_turns_f32(u2)
     two_pi = np.asarray(6.283185307179586, dtype)
     return np.sqrt(np.asarray(-2.0, dtype) * np.log(u1)) * np.cos(two_pi * u2)
 
@@ -179,7 +225,7 @@ def controller_dispatch(o, v, v_lead, h, has_lead, v_follow, h_follow, rl_value,
             slot = np.full(R, i, dtype=np.uint32) if noise_slot is None else noise_slot[sl].astype(np.uint32)
             g = gaussian_noise(o.spec.get("seed", 0),
                                replica_ids(o.spec, R), slot,
-                               o.step_counter.astype(np.uint32), o.dt_)
+                               o.step_counter.astype(np.uint32), o.dt_, exact=o.spec.get("noise_math", "hw") == "exact")
             a = a + T(vs["noise"]) * g
         fs = vs.get("fail_safe", FAILSAFE_NONE)
         hl = has_lead[sl]

@@ -9,9 +9,14 @@ from flow_amd.envs import VecFlowEnv
 
 R, K = 4096, 1500
 dev = torch.device("cuda", 0)
-for label, precision, noise in (("f32 noise 0.2", "f32", 0.2), ("f32 quiet", "f32", 0.0), ("mixed noise 0.2", "mixed", 0.2), ("mixed quiet", "mixed", 0.0)):
+CASES = (("f32 noise 0.2", "f32", 0.2, "hw"), ("f32 noise 0.2 exact", "f32", 0.2, "exact"), ("f32 quiet", "f32", 0.0, "hw"),
+         ("mixed noise 0.2", "mixed", 0.2, "hw"), ("mixed quiet", "mixed", 0.0, "hw"))
+if len(sys.argv) > 1:                                  # e.g. "exact": only the cases whose label holds the word
+    CASES = tuple(c for c in CASES if sys.argv[1] in c[0])
+for label, precision, noise, math in CASES:
     fp = train_vec.ring_flow_params(1500)
     fp["sim"].precision = precision
+    fp["sim"].noise_math = math
     fp["env"].additional_params["ring_length"] = [220, 270]        # singleagent_ring.py:58-62: a length per episode
     if not noise:
         for t in fp["veh"].type_parameters.values():
@@ -31,5 +36,5 @@ for label, precision, noise in (("f32 noise 0.2", "f32", 0.2), ("f32 quiet", "f3
         torch.cuda.synchronize()
         ms.append(e0.elapsed_time(e1))
     t = sum(ms) / len(ms) * 1e-3
-    print("%-14s %.2f G env-steps/s  (%.3f ms per %d-step launch), kernel %s" % (label, R * K / t / 1e9, t * 1e3, K, vec.sim.last_kernel))
+    print("%-20s %.2f G env-steps/s  (%.3f ms per %d-step launch), kernel %s" % (label, R * K / t / 1e9, t * 1e3, K, vec.sim.last_kernel))
     vec.close()

@@ -115,3 +115,24 @@ def test_float32_twin_close_to_float64():
     a32 = C.idm(v.astype(np.float32), vl.astype(np.float32), h.astype(np.float32), has)
     assert a32.dtype == np.float32
     np.testing.assert_allclose(a32, a64, rtol=5e-5, atol=5e-5)
+
+
+def test_exact_box_muller_functions_are_accurate_and_pure_float32():
+    """oracle/refsim.py exact_ln_f32 / exact_cos_turns_f32 (the fixed float32 sequences the kernels run with
+    noise_math='exact'): float32 in, float32 out, within 1e-6 (on values up to 16.6) / 1.2e-7 of the float64 functions over the whole input grid
+    (u = m / 2^24), and the Gaussian draws they give keep mean 0 and variance 1."""
+    from oracle import refsim as S
+    u = (np.arange(1, 1 << 24, 251, dtype=np.float64) / 16777216.0).astype(np.float32)
+    ln = S.exact_ln_f32(u)
+    assert ln.dtype == np.float32 and np.abs(ln - np.log(u.astype(np.float64))).max() < 1e-6
+    assert S.exact_ln_f32(np.float32(1.0)) == 0.0
+    t = np.concatenate([np.arange(0, 1 << 24, 257) / 16777216.0, np.arange(0, 1 << 24, 263) / 16777216.0 - 0.25]).astype(np.float32)
+    c = S.exact_cos_turns_f32(t)
+    assert c.dtype == np.float32 and np.abs(c - np.cos(2 * np.pi * t.astype(np.float64))).max() < 1.2e-7
+    n = 200000
+    g = S.gaussian_noise(7, np.arange(n, dtype=np.uint32) % 1000, np.arange(n, dtype=np.uint32) // 1000,
+                         np.arange(n, dtype=np.uint32) % 37, np.float32, exact=True)
+    ref = S.gaussian_noise(7, np.arange(n, dtype=np.uint32) % 1000, np.arange(n, dtype=np.uint32) // 1000,
+                           np.arange(n, dtype=np.uint32) % 37, np.float64)
+    assert g.dtype == np.float32 and np.abs(g - ref).max() < 2e-6
+    assert abs(g.mean()) < 0.01 and abs(g.std() - 1.0) < 0.01
