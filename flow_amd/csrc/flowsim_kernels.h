@@ -531,7 +531,10 @@ __device__ __forceinline__ float bm_ln_exact(float u) {
   p = p * z + 1.0f;
   return float(e) * 0.6931472f + (2.0f * s) * p;
 }
-__device__ __forceinline__ float bm_cos_exact(float t) {
+// cos(2 pi t) and, for a block's second draw of the same angle, cos(2 pi (t - 1/4)): the quarter turn of t - 1/4 is q - 1
+// and its angle the SAME float (4 t, 4 t - 1 and the differences are exact), so ONE evaluation of the two polynomials
+// serves both -- bit for bit what exact_cos_turns_f32 returns for t and for t - 0.25
+__device__ __forceinline__ void bm_cos_exact2(float t, float& cos_t, float& cos_back) {
   const float a = t * 4.0f;
   const float q = __builtin_floorf(a + 0.5f);
   const float th = (a - q) * 1.5707964f;
@@ -545,9 +548,16 @@ __device__ __forceinline__ float bm_cos_exact(float t) {
   sn = sn * z + -1.6666667e-01f;
   sn = sn * z + 1.0f;
   sn = sn * th;
-  const int qi = int(q) & 3;
+  const int qi = int(q) & 3, qb = (qi + 3) & 3;
   const float even = (qi & 2) ? -c : c, odd = (qi & 2) ? sn : -sn;
-  return (qi & 1) ? odd : even;
+  cos_t = (qi & 1) ? odd : even;
+  const float even_b = (qb & 2) ? -c : c, odd_b = (qb & 2) ? sn : -sn;
+  cos_back = (qb & 1) ? odd_b : even_b;
+}
+__device__ __forceinline__ float bm_cos_exact(float t) {
+  float c0, c1;
+  bm_cos_exact2(t, c0, c1);
+  return c0;
 }
 __device__ __forceinline__ float bm_radius_x(float u1, bool exact) {
   return exact ? tsqrt(-2.0f * bm_ln_exact(u1)) : bm_radius(u1);
@@ -563,6 +573,15 @@ __device__ __forceinline__ void gauss4(uint32_t seed_lo, uint32_t seed_hi, uint3
   const T k = T(1.0 / 16777216.0);                     // u1 in (0, 1], u2 in [0, 1): 24-bit integers, exact in float
   const T ra = bm_radius_x(T((c0 >> 8) + 1u) * k, exact), ua = T(c1 >> 8) * k;
   const T rb = bm_radius_x(T((c2 >> 8) + 1u) * k, exact), ub = T(c3 >> 8) * k;
+  if constexpr (sizeof(T) == 4) {
+    if (exact) {                                        // (wave-uniform)
+      float ca, cab, cb, cbb;
+      bm_cos_exact2(float(ua), ca, cab);
+      bm_cos_exact2(float(ub), cb, cbb);
+      g[0] = ra * ca; g[1] = ra * cab; g[2] = rb * cb; g[3] = rb * cbb;
+      return;
+    }
+  }
   g[0] = ra * bm_cos_x(ua, exact);
   g[1] = ra * bm_cos_x(ua - T(0.25), exact);
   g[2] = rb * bm_cos_x(ub, exact);

@@ -4,7 +4,7 @@ set -e
 OUT=gpurun_out/prof_exact
 mkdir -p $OUT
 cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
-for m in "noise 0.2 exact" "f32 noise 0.2"; do
+for m in "exact" "f32 noise 0.2 "; do
   tag=$(echo $m | tr ' .' '__')
   rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $OUT/$tag -- python3 scripts/dbg/ring_rl_rate.py "$m" > $OUT/$tag.txt 2> $OUT/$tag.err
   cat $OUT/$tag.txt

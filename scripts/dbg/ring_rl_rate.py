@@ -12,7 +12,7 @@ dev = torch.device("cuda", 0)
 CASES = (("f32 noise 0.2", "f32", 0.2, "hw"), ("f32 noise 0.2 exact", "f32", 0.2, "exact"), ("f32 quiet", "f32", 0.0, "hw"),
          ("mixed noise 0.2", "mixed", 0.2, "hw"), ("mixed quiet", "mixed", 0.0, "hw"))
 if len(sys.argv) > 1:                                  # e.g. "exact": only the cases whose label holds the word
-    CASES = tuple(c for c in CASES if sys.argv[1] in c[0])
+    CASES = tuple(c for c in CASES if sys.argv[1] in c[0] + " ")
 for label, precision, noise, math in CASES:
     fp = train_vec.ring_flow_params(1500)
     fp["sim"].precision = precision
@@ -36,5 +36,5 @@ for label, precision, noise, math in CASES:
         torch.cuda.synchronize()
         ms.append(e0.elapsed_time(e1))
     t = sum(ms) / len(ms) * 1e-3
-    print("%-20s %.2f G env-steps/s  (%.3f ms per %d-step launch), kernel %s" % (label, R * K / t / 1e9, t * 1e3, K, vec.sim.last_kernel))
+    print("%-20s| %.2f G env-steps/s  (%.3f ms per %d-step launch), kernel %s" % (label, R * K / t / 1e9, t * 1e3, K, vec.sim.last_kernel))
     vec.close()
