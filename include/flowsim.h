@@ -55,7 +55,10 @@ enum fs_precision { FS_F32 = 0, FS_F64 = 1, FS_MIXED = 2,
                                       launch loads them into float32 registers, steps in float32 exactly as FS_F32 does, and
                                       stores halves again.  6 bytes of state per vehicle instead of 8; every launch boundary
                                       rounds the speeds to 11 bits (<= 0.008 m/s below 32 m/s).  Built for FS_NET_MERGE
-                                      (the configuration BASELINE names); fs_get_state / fs_set_state speak float32. */
+                                      (the configuration BASELINE names); fs_get_state / fs_set_state speak float32.
+                                      NOTE: a trajectory therefore depends on where the launches are cut -- K fs_step calls
+                                      round K times, one fs_rollout_dev of K steps once; runs are reproducible for a fixed
+                                      launch pattern only (tests/test_f16s_gpu.py measures the drift between the two). */
 };
 
 /* acceleration controllers, flow/controllers/__init__.py */

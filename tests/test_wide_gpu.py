@@ -22,6 +22,7 @@ def slot_order_kernels(monkeypatch):
     monkeypatch.setenv("FLOWSIM_NO_QUEUE", "1")
 
 
+@pytest.mark.slow                  # (the 100 / 128 / 200-slot cases below and in test_bottleneck_env_gpu.py stay in the fast set)
 def test_wide_desired_velocity_f32_bit_exact_192_slots():
     """C4's demand: the queue upstream of the lane drops outgrows one wave (more than 64 vehicles in the network)."""
     from helpers import bottleneck_spec
@@ -82,7 +83,7 @@ def test_wide_simplified_lane_changing_and_followers():
                            lane_change_min_gain=8.0, track_followers=True)
     for v in spec["vehicles"][:150]:
         v["lane_change_mode"] = 1621
-    ora = run_pair(spec, "f32", 500, bottleneck_actions(spec, 4), check_every=50)
+    ora = run_pair(spec, "f32", 300, bottleneck_actions(spec, 4), check_every=50)
     assert (ora.num_lane_changes > 40).all()
 
 
@@ -202,11 +203,11 @@ def test_wide_scaling_two_eight_entry_lanes():
     from helpers import bottleneck_spec
     spec = bottleneck_spec(R=1, cap_human=200, cap_rl=40, horizon=400, seed=6, q=4000.0, scaling=2)
     assert spec["num_paths"] == 8 and len(spec["obs_cells"]) == 70 and spec["num_rl"] == 40
-    ora = run_pair(spec, "f32", 300, bottleneck_actions(spec, 3), check_every=50)
+    ora = run_pair(spec, "f32", 230, bottleneck_actions(spec, 3), check_every=50)
     alive = ora.alive[0]
     assert set(ora.route[0][alive]) == set(range(8))                       # every entry lane is in use
     assert set((ora.route[0][alive & (ora.x[0] > spec["merge2_x"])] >> 2)) == {0, 1}    # two lanes leave the network
-    assert ora.total_arrived.min() > 60
+    assert ora.total_arrived.min() > 40
     # with the simplified lane changing, in float64 and on two waves
     spec = bottleneck_spec(R=2, cap_human=100, cap_rl=20, horizon=300, seed=8, q=4000.0, scaling=2,
                            lane_change_cooldown_steps=8, lane_change_min_gain=8.0)
