@@ -245,11 +245,15 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
   // the queue lengths and join prefixes of the three OTHER paths (t = 1: my partner at the first join, t = 2, 3: the other
   // pair), as their owners published them
   int nT1 = 0, nT2 = 0, nT3 = 0, g1T1 = 0, g2T2 = 0, g2T3 = 0;
+  int pn_l = 0, pg1_l = 0, pg2_l = 0, parr_l = 0;     // lane q (mod 4): n / ng1 / ng2 / arrivals of path q
+  const int wu = __builtin_amdgcn_readfirstlane(w);
   auto read_counts = [&]() {
-    nT1 = __builtin_amdgcn_readfirstlane(L.n[w ^ 1]); nT2 = __builtin_amdgcn_readfirstlane(L.n[w ^ 2]);
-    nT3 = __builtin_amdgcn_readfirstlane(L.n[w ^ 3]);
-    g1T1 = __builtin_amdgcn_readfirstlane(L.ng1[w ^ 1]);
-    g2T2 = __builtin_amdgcn_readfirstlane(L.ng2[w ^ 2]); g2T3 = __builtin_amdgcn_readfirstlane(L.ng2[w ^ 3]);
+    // (ONE round trip: every lane reads the four words of its path l & 3; the scalars are lane reads -- six uniform LDS
+    // reads, each waited for, were a tenth of the sub-step)
+    pn_l = L.n[l & 3]; pg1_l = L.ng1[l & 3]; pg2_l = L.ng2[l & 3]; parr_l = L.arr_n[l & 3];
+    nT1 = read_lane_i(pn_l, wu ^ 1); nT2 = read_lane_i(pn_l, wu ^ 2); nT3 = read_lane_i(pn_l, wu ^ 3);
+    g1T1 = read_lane_i(pg1_l, wu ^ 1);
+    g2T2 = read_lane_i(pg2_l, wu ^ 2); g2T3 = read_lane_i(pg2_l, wu ^ 3);
   };
   auto neighbours = [&](bool& crash) {
     const bool alive = l < n;
@@ -383,6 +387,16 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
   }
   __syncthreads();
 
+#ifdef FS_QDIAG
+  unsigned long long dq_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // 0 move, 1 order/arrivals, 2 publish+barrier, 3 counts+bookkeeping, 4 insertions, 5 neighbours, 6 cells, 7 barrier 2, 8 head
+  int dq_n[2] = {0, 0};
+  const unsigned long long dq_start = __builtin_readcyclecounter();
+#define FS_DT(var_) const unsigned long long var_ = __builtin_readcyclecounter()
+#define FS_DA(slot_, t0_) dq_t[slot_] += __builtin_readcyclecounter() - (t0_)
+#else
+#define FS_DT(var_)
+#define FS_DA(slot_, t0_)
+#endif
   for (int step = 0; step < num_steps; ++step) {
     const int ab = step & 1;
     if (actions != nullptr && step + 1 < num_steps && tid < s.num_rl)
@@ -392,6 +406,7 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
     for (int sub = 0; sub < s.sims_per_step; ++sub) {
       const bool live = !crashed;
       bool alive = l < n;
+      FS_DT(d0);
       // ---- O6: BottleneckDesiredVelocityEnv._apply_rl_actions (bottleneck.py:926-969) -----------------------------
       if (DV && actions != nullptr) {
         const float a_cell = L.act[ab][acell >= 0 ? acell : 0];
@@ -419,6 +434,8 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
         v = mv ? v_new : v;
       }
       if (live) { tcount += 1; sim_steps += 1; }
+      FS_DA(0, d0);
+      FS_DT(d1);
       // ---- the order of my path: a collision re-sorts it; arrivals (M4) leave from the head -----------------------
       int na = 0;
       if (live) {
@@ -437,8 +454,12 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
         }
       }
       if (l == 0) L.arr_n[w] = na;
+      FS_DA(1, d1);
+      FS_DT(d2);
       publish();
       lds_barrier();
+      FS_DA(2, d2);
+      FS_DT(d3);
       // ---- every wave: the arrivals of all paths, then the insertions (M2 / M3 / M9 / M1) in InFlows order ---------
       read_counts();
       ull ja0 = 0ull, ja1 = 0ull, ja2 = 0ull, ja3 = 0ull;      // slots freed in this sub-step: free from the next one on
@@ -447,7 +468,7 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
         ar0 = ar1 = ar2 = ar3 = 0ull;
 #pragma unroll
         for (int q = 0; q < P; ++q) {
-          const int nq = __builtin_amdgcn_readfirstlane(L.arr_n[q]);
+          const int nq = read_lane_i(parr_l, q);
           na_all += nq;
           for (int j = 0; j < nq && j < 8; ++j) {
             const int lj = __builtin_amdgcn_readfirstlane(L.arr_lab[q][j]) & 255;
@@ -468,8 +489,13 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
           out_rew += na_all - (er >= 0 ? read_lane_i(hist_l, er % 20) : 0);
         }
         if (l == (tcount - 1) % 20) hist_l = na_all;
+        FS_DA(3, d3);
+        FS_DT(d4);
         // inflows whose next vehicle is due (lane f of every wave evaluates inflow f)
         unsigned fm = unsigned(__ballot(sim_steps - 1 >= my_due_n)) & 0xffu;
+#ifdef FS_QDIAG
+        dq_n[0] += fm != 0u ? 1 : 0;
+#endif
         // (x, v, label) of the vehicles inserted so far in this sub-step, per path: the tail an insertion is checked against
         T ix0 = 0, ix1 = 0, ix2 = 0, ix3 = 0, iv0 = 0, iv1 = 0, iv2 = 0, iv3 = 0;
         int ic0 = 0, ic1 = 0, ic2 = 0, ic3 = 0;
@@ -498,36 +524,42 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
           slot = __builtin_amdgcn_readfirstlane(slot);
           // M3: the nearest vehicle ahead on the route: the tail of the own path, the rearmost vehicle of the partner
           // path beyond the first join, of the other two beyond the second; equal positions: the lowest slot
-          T xm = BIGV, vm_ = 0.0f;
-          int lm = 256;
-          bool has_lead = false;
-#pragma unroll
-          for (int q = 0; q < P; ++q) {
+          // (lane q of every quad looks at path q -- one LDS round trip for the four candidates -- and the quad reduces to
+          // the smallest (position, slot); the first version walked the paths one after the other: eight round trips)
+          T xm, vm_;
+          bool has_lead;
+          {
+            const int q = l & 3;
             const int t = q ^ route_f;
             const int icq = q == 0 ? ic0 : (q == 1 ? ic1 : (q == 2 ? ic2 : ic3));
-            int ci;
-            if (t == 0) ci = L.n[q] + icq - 1;
-            else if (t == 1) ci = L.ng1[q] - 1;
-            else ci = L.ng2[q] - 1;
-            ci = __builtin_amdgcn_readfirstlane(ci);
-            T cx, cv;
-            int cl;
-            if (t == 0 && icq > 0) {                       // the vehicle inserted a moment ago on this path
-              cx = q == 0 ? ix0 : (q == 1 ? ix1 : (q == 2 ? ix2 : ix3));
-              cv = q == 0 ? iv0 : (q == 1 ? iv1 : (q == 2 ? iv2 : iv3));
-              cl = 255;                                     // (its position is the insertion point: no tie with a vehicle ahead)
-            } else {
-              const DropXL e = L.xl[q][ci < 0 ? 0 : ci];
-              cx = e.x; cl = e.lab; cv = e.v;
+            const int ci = t == 0 ? pn_l + icq - 1 : (t == 1 ? pg1_l - 1 : pg2_l - 1);
+            const DropXL e = L.xl[q][ci < 0 ? 0 : (ci & 63)];
+            const bool fresh = t == 0 && icq > 0;          // the vehicle inserted a moment ago on this path
+            T cx = fresh ? (q == 0 ? ix0 : (q == 1 ? ix1 : (q == 2 ? ix2 : ix3))) : e.x;
+            T cv = fresh ? (q == 0 ? iv0 : (q == 1 ? iv1 : (q == 2 ? iv2 : iv3))) : e.v;
+            int cl = fresh ? 255 : e.lab;                  // (its position is the insertion point: no tie with a vehicle ahead)
+            cx = ci >= 0 ? cx : BIGV;
+            cl = ci >= 0 ? cl : 256;
+            {
+              const T ox = dpp<DPP_QUAD_XOR1>(cx), ov = dpp<DPP_QUAD_XOR1>(cv);
+              const int ol = dpp_i<DPP_QUAD_XOR1>(cl);
+              const bool b = (ox < cx) || (ox == cx && ol < cl);
+              cx = b ? ox : cx; cv = b ? ov : cv; cl = b ? ol : cl;
             }
-            const bool take = ci >= 0 && (cx < xm || (cx == xm && cl < lm));
-            xm = take ? cx : xm; vm_ = take ? cv : vm_; lm = take ? cl : lm;
-            has_lead = has_lead || take;
+            {
+              const T ox = dpp<DPP_QUAD_XOR2>(cx), ov = dpp<DPP_QUAD_XOR2>(cv);
+              const int ol = dpp_i<DPP_QUAD_XOR2>(cl);
+              const bool b = (ox < cx) || (ox == cx && ol < cl);
+              cx = b ? ox : cx; cv = b ? ov : cv; cl = b ? ol : cl;
+            }
+            xm = read_lane(cx, 0);
+            vm_ = read_lane(cv, 0);
+            has_lead = xm < BIGV;
           }
           const T gap = (xm - LEN) - x_dep;
           const T dq = div_core(v_dep * (v_dep - vm_), two_sqrt);
           const T need = min_gap_f + tmax(0.0f, v_dep * tau_f + dq);
-          const int n_own = __builtin_amdgcn_readfirstlane(L.n[route_f & 3]) +
+          const int n_own = read_lane_i(pn_l, route_f & 3) +
                             (route_f == 0 ? ic0 : (route_f == 1 ? ic1 : (route_f == 2 ? ic2 : ic3)));
           if (slot >= 0 && n_own >= 64 && (!has_lead || gap >= need)) atomicOr(qflag, 1);   // the path is full: refused, flagged
           const bool ok = __builtin_amdgcn_readfirstlane(int((slot >= 0) && n_own < 64 && (!has_lead || gap >= need))) != 0;
@@ -561,10 +593,14 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
           if (consumed && !ok) tot_drop += 1;
         }
         aw0 &= ~ja0; aw1 &= ~ja1; aw2 &= ~ja2; aw3 &= ~ja3;
+        FS_DA(4, d4);
       }
+      FS_DT(d5);
       // ---- O1: the new snapshot, the collision check ---------------------------------------------------------------
       bool c = false;
       neighbours(c);
+      FS_DA(5, d5);
+      FS_DT(d6);
       const int cb = (step * s.sims_per_step + sub) & 1;
       if (c && l == 0) L.crash[cb][w] = 1;
       // ---- O6 get_state (bottleneck.py:868-924): every vehicle enters itself into its cell ---------------------------
@@ -578,7 +614,10 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
           atomicAdd(&L.acc[is_rl ? 3 : 2][ocell], vi);
         }
       }
+      FS_DA(6, d6);
+      FS_DT(d7);
       lds_barrier();
+      FS_DA(7, d7);
       {
         const bool cc = (L.crash[cb][0] | L.crash[cb][1] | L.crash[cb][2] | L.crash[cb][3]) != 0;
         crashed = crashed || (cc && live);
@@ -587,6 +626,7 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
     }
 
     // ---- get_state / compute_reward / done ------------------------------------------------------------------------
+    FS_DT(d8);
     if (emit) {
       if (DV) {
         const int C = o.n_obs_cells;
@@ -616,7 +656,13 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
       rrow += step_rows;
       drow += step_rows;
     }
+    FS_DA(8, d8);
   }
+#ifdef FS_QDIAG
+  if (blockIdx.x == 5 && l == 0)
+    printf("DQDIAG wave %d total %llu move %llu order %llu publish+barrier %llu counts %llu insert %llu (n %d) neighbours %llu cells %llu barrier2 %llu head %llu\n",
+           w, __builtin_readcyclecounter() - dq_start, dq_t[0], dq_t[1], dq_t[2], dq_t[3], dq_t[4], dq_n[0], dq_t[5], dq_t[6], dq_t[7], dq_t[8]);
+#endif
 
   // ---- the state back to its slots ---------------------------------------------------------------------------------
   __threadfence();
