@@ -159,7 +159,15 @@ class CRingRLMixed:
         self.R, self.N = int(spec["num_replicas"]), int(spec["num_vehicles"])
         veh = spec["vehicles"]
         for v in veh:
-            assert v["controller"] in (1, 2) and v.get("fail_safe", 0) == 0 and not (v.get("noise", 0) > 0 and v["controller"] == 2)
+            assert v["controller"] in (1, 2) and v.get("fail_safe", 0) == 0
+        # acceleration noise: the twin draws with the EXACT Box-Muller only (spec['noise_math'] = 'exact')
+        self.sigma = np.ascontiguousarray(np.array([float(v.get("noise", 0.0)) if v["controller"] == 2 else 0.0
+                                                    for v in veh], np.float64))
+        self.noisy = bool((self.sigma > 0).any())
+        assert not self.noisy or spec.get("noise_math", "hw") == "exact", "the C twin has the exact noise math only"
+        self.seed = int(spec.get("seed", 0)) & 0xFFFFFFFFFFFFFFFF
+        self.rep0 = int(spec.get("replica_offset", 0)) & 0xFFFFFFFF
+        self.nctr = np.zeros(self.R, dtype=np.uint32)
         assert spec.get("env", 0) in (0, 2) and not spec.get("junction_mode", 0)
         assert spec.get("sims_per_step", 1) == 1 and spec.get("integrator", "euler") == "euler"
         self.head = 1 if spec.get("env", 0) == 2 else 0
@@ -210,14 +218,15 @@ class CRingRLMixed:
         d, vp, ci = C.c_double, C.c_void_p, C.c_int
         fn.restype = None
         fn.argtypes = [ci, ci, ci, vp, d, d, d, vp, vp, vp, vp, vp, ci, ci, d, d, ci, d, d, d, d, ci, d, ci, vp, vp, vp,
-                       vp, vp, C.c_size_t, vp, vp, vp, ci]
+                       vp, vp, C.c_size_t, vp, vp, vp, ci, vp, C.c_uint64, C.c_uint32, vp]
         fn(self.R, self.N, int(steps), self.ring_len.ctypes.data, self.jlen, self.dt, self.ramp, self.ctrl.ctypes.data,
            self.rl_index.ctypes.data, self.p.ctypes.data, self.veh_len.ctypes.data, self.sm.ctypes.data, self.need_sumo,
            self.clip, self.act_lo, self.act_hi, self.head, self.max_speed, self.target_v, self.max_cost,
            self.po_max_length, self.num_rl, self.crash_gap, self.step_limit, self.x.ctypes.data, self.v.ctypes.data,
            self.tc.ctypes.data, None if mask is None else mask.ctypes.data,
            None if actions is None else actions.ctypes.data, stride, obs.ctypes.data, rew.ctypes.data,
-           done.ctypes.data, int(obs_every_step))
+           done.ctypes.data, int(obs_every_step), self.sigma.ctypes.data if self.noisy else None, self.seed, self.rep0,
+           self.nctr.ctypes.data)
         return obs, rew, done
 
     def reset(self, mask=None):
@@ -225,7 +234,7 @@ class CRingRLMixed:
         sel = np.ones(self.R, bool) if mask is None else np.asarray(mask).astype(bool)
         self.x[sel] = self.init_pos[sel]
         self.v[sel] = self.init_vel[sel]
-        self.tc[sel] = 0
+        self.tc[sel] = 0                         # (the noise counter runs on: base_controller's stream is not reset)
         obs, _, _ = self._call(self.warmup, None, None if mask is None else sel.astype(np.uint8), False)
         return obs[0]
 

@@ -27,6 +27,63 @@ static float rl_tree_sum(const float* a, int n) {
   return buf[0];
 }
 
+/* ---- acceleration noise (base_controller.py:109-110): Philox-4x32-10 + the EXACT Box-Muller of fs_config.noise_exact
+ * (flow_amd/csrc/flowsim_kernels.h gauss / bm_ln_exact / bm_cos_exact2; oracle/refsim.py exact_ln_f32 / exact_cos_turns_f32):
+ * fixed float32 operation sequences, so this twin reproduces the FS_MIXED kernel's noisy runs bit for bit */
+static void rl_philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c[0], p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c[2];
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+static float rl_ln_exact(float u) {
+  union { float f; uint32_t u; } b;
+  b.f = u;
+  int e = (int)(b.u >> 23) - 127;
+  b.u = (b.u & 0x7FFFFFu) | 0x3F800000u;
+  float m = b.f;
+  const int big = m > 1.4142135f;
+  m = big ? m * 0.5f : m;
+  e += big ? 1 : 0;
+  const float t = m - 1.0f;
+  const float s = t / (2.0f + t);
+  const float z = s * s;
+  float p = z * 0.11111111f + 0.14285715f;
+  p = p * z + 0.2f;
+  p = p * z + 0.33333334f;
+  p = p * z + 1.0f;
+  return (float)e * 0.6931472f + (2.0f * s) * p;
+}
+static float rl_cos_exact(float t) {
+  const float a = t * 4.0f;
+  const float q = floorf(a + 0.5f);
+  const float th = (a - q) * 1.5707964f;
+  const float z = th * th;
+  float c = z * 2.4801587e-05f + -1.3888889e-03f;
+  c = c * z + 4.1666668e-02f;
+  c = c * z + -0.5f;
+  c = c * z + 1.0f;
+  float sn = z * 2.7557319e-06f + -1.9841270e-04f;
+  sn = sn * z + 8.3333338e-03f;
+  sn = sn * z + -1.6666667e-01f;
+  sn = sn * z + 1.0f;
+  sn = sn * th;
+  const int qi = (int)q & 3;
+  return qi == 0 ? c : (qi == 1 ? -sn : (qi == 2 ? -c : sn));
+}
+static float rl_gauss_exact(uint64_t seed, uint32_t replica, uint32_t vehicle, uint32_t step) {
+  uint32_t c[4] = {step >> 2, vehicle, replica, 0u};
+  rl_philox4x32_10(c, (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32));
+  const int second = (step & 2u) != 0u;
+  const uint32_t w1 = second ? c[2] : c[0], w2 = second ? c[3] : c[1];
+  const float k = 1.0f / 16777216.0f;
+  const float u1 = (float)((w1 >> 8) + 1u) * k, u2 = (float)(w2 >> 8) * k;
+  return sqrtf(-2.0f * rl_ln_exact(u1)) * rl_cos_exact((step & 1u) ? u2 - 0.25f : u2);
+}
+
 static double dmax(double a, double b) { return a > b ? a : b; }     /* the kernel's tmax / tmin */
 static double dmin(double a, double b) { return a < b ? a : b; }
 static float fmax_(float a, float b) { return a > b ? a : b; }
@@ -42,7 +99,10 @@ void refsim_ring_rl_mixed(int R, int N, int steps, const double* ring_len, doubl
                           double max_speed, double target_v, double max_cost, double po_max_length, int num_rl,
                           double crash_gap, int step_limit, double* x, double* v, int32_t* time_counter,
                           const uint8_t* mask, const float* actions, size_t act_stride, float* obs, float* rew,
-                          uint8_t* done, int obs_every_step) {
+                          uint8_t* done, int obs_every_step,
+                          /* acceleration noise (noise_sigma == NULL: none): standard deviation per vehicle, the 64-bit seed,
+                           * the global index of replica 0, the draw counter per replica (advances with every live step) */
+                          const double* noise_sigma, uint64_t seed, uint32_t rep0, uint32_t* noise_ctr) {
   const float BIG = 3.0e38f;
   const double rc_ms = 1.0 / max_speed, rc15 = 1.0 / 15.0, rc_pml = 1.0 / po_max_length;
   const float gap32 = (float)crash_gap, tv32 = (float)target_v, mc32 = (float)max_cost;
@@ -54,6 +114,7 @@ void refsim_ring_rl_mixed(int R, int N, int steps, const double* ring_len, doubl
     const double L = ring_len[r] + 4.0 * jlen, rc_L = 1.0 / L;
     const int live = mask == NULL || mask[r] != 0;
     int tc = time_counter[r];
+    uint32_t nctr = noise_sigma != NULL ? noise_ctr[r] : 0u;
     float hh[64], term[64];
     double dg[64], xn[64], vn[64];
     for (int i = 0; i < N; ++i) {                 /* snapshot of the current state */
@@ -91,6 +152,8 @@ void refsim_ring_rl_mixed(int R, int N, int steps, const double* ring_len, doubl
             else if (delta == 8.0f) { float r2 = ratio * ratio, r4 = r2 * r2; pw = r4 * r4; }
             else pw = powf(ratio, delta);
             acc = a * (1.0f - pw - q * q);
+            if (noise_sigma != NULL && noise_sigma[i] > 0.0)           /* float32 term, float32 sum (the kernel's nz) */
+              acc = acc + (float)noise_sigma[i] * rl_gauss_exact(seed, rep0 + (uint32_t)r, (uint32_t)i, nctr);
           } else {
             float a = act != NULL ? act[rl_index[i]] : 0.0f;
             if (clip_actions) a = fmin_(fmax_(a, lo32), hi32);
@@ -128,6 +191,7 @@ void refsim_ring_rl_mixed(int R, int N, int steps, const double* ring_len, doubl
         if (live) {
           for (int i = 0; i < N; ++i) { xr[i] = xn[i]; vr[i] = vn[i]; }
           tc += 1;
+          nctr += 1u;
         }
         for (int i = 0; i < N; ++i) {
           const int j = (i + 1 >= N) ? 0 : i + 1;
@@ -195,5 +259,6 @@ void refsim_ring_rl_mixed(int R, int N, int steps, const double* ring_len, doubl
       if (emit_only) break;
     }
     time_counter[r] = tc;
+    if (noise_sigma != NULL) noise_ctr[r] = nctr;
   }
 }

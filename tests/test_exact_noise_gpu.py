@@ -96,3 +96,31 @@ def test_noisy_merge_equals_the_numpy_oracle_bit_for_bit(env, kernel, monkeypatc
     compare_state(sim, ora)
     assert ora.total_arrived.min() > 5
     sim.close()
+
+
+@pytest.mark.parametrize("po", [True, False])
+def test_mixed_with_the_experiments_noise_equals_its_c_twin_bit_for_bit(po):
+    """FS_MIXED (float64 state, float32 controllers) with IDMController(noise=0.2) -- the headline precision on the
+    reference's RL ring experiment AS SHIPPED -- against oracle/csim/refsim_rl.c, which draws the same Philox words through the
+    same exact Box-Muller sequences: reset with warm-up steps, 1500 steps of an action tape, a second fragment (the draw
+    counter runs on) -- observations, rewards, done flags, positions and speeds bit for bit; and within 1e-4 of the float64
+    oracle running the same noise (the draws are float32 there too: float64 has no exact form)."""
+    from oracle import cbuild
+    from test_ringrl_gpu import make, rl_ring_spec, rollout, tape
+    K, R = 1500, 6
+    spec = rl_ring_spec(R=R, N=22, po=po, noise=0.2, warmup=30, seed=7, horizon=4000)
+    spec["noise_math"] = "exact"
+    acts = tape(K, R, 1, seed=11, scale=0.8)
+    sim, twin = make(spec, "mixed"), cbuild.CRingRLMixed(spec)
+    np.testing.assert_array_equal(sim.reset(), twin.reset())
+    assert sim.last_kernel.startswith("k_ring_pair")
+    for frag in range(2):
+        o, r, d = rollout(sim, K, acts)
+        to, tr, td = twin.rollout(K, acts)
+        np.testing.assert_array_equal(o, to, err_msg="fragment %d" % frag)
+        np.testing.assert_array_equal(r, tr)
+        np.testing.assert_array_equal(d, td)
+        np.testing.assert_array_equal(sim.pos, twin.x)
+        np.testing.assert_array_equal(sim.vel, twin.v)
+    assert twin.nctr.min() == 30 + 2 * K and sim.vel.max() > 1.0
+    sim.close()
