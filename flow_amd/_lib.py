@@ -23,6 +23,7 @@ FS_F32, FS_F64, FS_MIXED, FS_F16S = 0, 1, 2, 3
 (FS_CTRL_SIM, FS_CTRL_RL, FS_CTRL_IDM, FS_CTRL_CFM, FS_CTRL_BCM, FS_CTRL_LAC, FS_CTRL_OVM,
  FS_CTRL_LINEAR_OVM, FS_CTRL_GIPPS, FS_CTRL_FOLLOWER_STOPPER, FS_CTRL_NONLOCAL_FOLLOWER_STOPPER,
  FS_CTRL_PISATURATION) = range(12)
+FS_CTRL_USER = 12
 # enum fs_failsafe
 FS_FAILSAFE_NONE, FS_FAILSAFE_INSTANTANEOUS, FS_FAILSAFE_SAFE_VELOCITY = range(3)
 # enum fs_env
@@ -114,23 +115,24 @@ class fs_policy(C.Structure):
                 ("log_std_dev", C.c_void_p), ("seed", C.c_uint64)]
 
 
-_lib = None
+_libs = {}
 
 
-def load():
-    """Load libflowsim.so once; raise if it is absent (the HIP path is the only path)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(path=None):
+    """Load libflowsim.so (or a copy of it built with a user controller: flow_amd.build.build_user) once; raise if it is
+    absent (the HIP path is the only path)."""
+    path = LIB_PATH if path is None else os.path.abspath(path)
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise FatalFlowError(
             "libflowsim.so not found at %s: build it with `python -m flow_amd.build` "
-            "(hipcc, gfx950).  flow_amd has no CPU fallback." % LIB_PATH)
+            "(hipcc, gfx950).  flow_amd has no CPU fallback." % path)
     try:                       # share torch's HIP runtime (same SONAME) when torch is in the process
         import torch  # noqa: F401
     except Exception:          # pragma: no cover - torch is optional for the C ABI itself
         pass
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     h = C.c_void_p
     f32p, u8p = C.c_void_p, C.c_void_p       # raw addresses: host numpy or device pointers
     lib.fs_create.argtypes = [C.POINTER(fs_config), C.POINTER(h)]
@@ -177,15 +179,16 @@ def load():
     lib.fs_policy_rollout_dev.restype = C.c_int
     if lib.fs_abi_version() != FS_ABI_VERSION:
         raise FatalFlowError("libflowsim.so ABI %d != binding ABI %d" % (lib.fs_abi_version(), FS_ABI_VERSION))
-    _lib = lib
+    _libs[path] = lib
     return lib
 
 
-def check(rc):
-    """Map a C return code to the exception type the reference raises at that call point."""
+def check(rc, lib=None):
+    """Map a C return code to the exception type the reference raises at that call point (``lib``: the library the call
+    went to, when it is not the stock one)."""
     if rc == FS_OK:
         return
-    msg = load().fs_last_error().decode("utf-8", "replace")
+    msg = (lib or load()).fs_last_error().decode("utf-8", "replace")
     if rc == FS_ERR_INVALID:
         raise ValueError(msg)
     if rc == FS_ERR_UNSUPPORTED:

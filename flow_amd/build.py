@@ -157,6 +157,59 @@ def build(force=False, verbose=False, only=None):
     return LIB
 
 
+USER_DIR = os.path.join(PKG, "_user")
+USER_SIGNATURE = ("template <typename T>\n__device__ __forceinline__ T fs_user_accel(T v, T v_lead, T h, bool has_lead, "
+                  "T v_follow, T h_follow, T dt, T max_accel, const T* p)")
+
+
+def user_header(body):
+    """The header a user controller is compiled from: ``body`` = the statements of its get_accel (C++, ending in a
+    return), with the vehicle's speed ``v``, the leader's ``v_lead``, the bumper-to-bumper headway ``h``, ``has_lead``,
+    the follower's speed and headway, the step ``dt``, the vehicle type's ``max_accel`` and its parameters ``p[0..7]`` in
+    scope; T is float or double (the handle's precision).  flowsim_kernels.h includes it inside namespace fs, after the
+    helper functions (tmin / tmax / tabs / tsqrt)."""
+    body = "\n".join("  " + ln.strip() for ln in str(body).strip().splitlines())    # (the text is the cache key: normalised)
+    return ("// generated by flow_amd.build.build_user -- the get_accel of a flow_amd.controllers.CompiledController\n"
+            "%s {\n%s\n}\n" % (USER_SIGNATURE, body))
+
+
+def build_user(body, verbose=False):
+    """A copy of the library whose FS_CTRL_USER slots run the user's controller: flow_amd/_user/<hash>/libflowsim.so.
+    Every part that holds generic step kernels is recompiled with -DFS_USER_CONTROLLER_HEADER (in parallel; the stock
+    objects of the C ABI and the queue kernels are reused); cached by the hash of the body and of the sources."""
+    text = user_header(body)
+    tag = hashlib.sha256((text + _stamp([])).encode()).hexdigest()[:16]
+    out_dir = os.path.join(USER_DIR, tag)
+    lib = os.path.join(out_dir, "libflowsim.so")
+    if os.path.exists(lib):
+        return lib
+    build()
+    if not all(os.path.exists(os.path.join(OBJ, name + ".o")) for name, _, _ in parts()):
+        build(force=True)                              # (a tree that holds the library but not its objects)
+    os.makedirs(out_dir, exist_ok=True)
+    hdr = os.path.join(out_dir, "user_controller.h")
+    with open(hdr, "w") as f:
+        f.write(text)
+    objs, todo = [], []
+    for name, src, extra in parts():
+        if name == "main" or name.startswith("queue"):
+            objs.append(os.path.join(OBJ, name + ".o"))
+            continue
+        out = os.path.join(out_dir, name + ".o")
+        objs.append(out)
+        todo.append((name, src, extra + ['-DFS_USER_CONTROLLER_HEADER="%s"' % hdr], out, verbose))
+    with concurrent.futures.ThreadPoolExecutor(_jobs()) as pool:
+        list(pool.map(_compile, todo))
+    res = subprocess.run([find_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib + ".tmp"] + objs,
+                         capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
+    os.replace(lib + ".tmp", lib)
+    for job in todo:                                   # (the objects are not needed again: the library is the cache)
+        os.remove(job[3])
+    return lib
+
+
 def device_asm(out_dir, names=None):
     """Device assembly (gfx950) of the parts, for the code-generation guards: {part name: path of its .s}."""
     os.makedirs(out_dir, exist_ok=True)

@@ -7,10 +7,11 @@ from flow_amd.controllers.velocity_controllers import FollowerStopper, PISaturat
 from flow_amd.controllers.lane_change_controllers import BaseLaneChangeController, StaticLaneChanger, \
     SimLaneChangeController
 from flow_amd.controllers.routing_controllers import BaseRouter, ContinuousRouter
+from flow_amd.controllers.compiled import CompiledController
 
 __all__ = [
     "RLController", "BaseController", "BaseLaneChangeController", "BaseRouter", "CFMController",
     "BCMController", "OVMController", "LinearOVM", "IDMController", "SimCarFollowingController",
     "FollowerStopper", "PISaturation", "StaticLaneChanger", "SimLaneChangeController", "ContinuousRouter",
-    "LACController", "GippsController", "NonLocalFollowerStopper"
+    "LACController", "GippsController", "NonLocalFollowerStopper", "CompiledController"
 ]

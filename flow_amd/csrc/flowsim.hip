@@ -187,7 +187,7 @@ int validate(const fs_config* c) {
   unsigned long long rl_mask = 0ull;       // num_vehicles <= 64
   for (int i = 0; i < c->num_vehicles; ++i) {
     const fs_vehicle_spec& v = c->vehicles[i];
-    if (v.controller < FS_CTRL_SIM || v.controller > FS_CTRL_PISATURATION)
+    if (v.controller < FS_CTRL_SIM || v.controller > FS_CTRL_USER)
       return fail(FS_ERR_INVALID, "fs_create: unknown controller id");
     if (v.fail_safe < FS_FAILSAFE_NONE || v.fail_safe > FS_FAILSAFE_SAFE_VELOCITY)
       return fail(FS_ERR_INVALID, "fs_create: unknown fail_safe id");

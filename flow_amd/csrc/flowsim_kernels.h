@@ -870,6 +870,23 @@ struct SegCursor {
 };
 
 // ---------------------------------------------------------------------------
+// FS_CTRL_USER: the get_accel of a user-defined controller (the reference's extension point: a BaseController subclass,
+// base_controller.py:42-118), compiled into a copy of the library.  flow_amd.build.build_user writes the header
+//   template <typename T> __device__ __forceinline__ T fs_user_accel(T v, T v_lead, T h, bool has_lead, T v_follow,
+//                                                                    T h_follow, T dt, T max_accel, const T* p) { <body> }
+// from the body flow_amd.controllers.CompiledController carries and compiles the parts with -DFS_USER_CONTROLLER_HEADER.
+// Noise, fail-safes, the "on an edge" rule and the speed-mode clamps apply to it as to every other controller.
+// ---------------------------------------------------------------------------
+#ifdef FS_USER_CONTROLLER_HEADER
+#include FS_USER_CONTROLLER_HEADER
+constexpr bool kHasUserController = true;
+#else
+template <typename T>
+__device__ __forceinline__ T fs_user_accel(T, T, T, bool, T, T, T, T, const T*) { return T(0); }
+constexpr bool kHasUserController = false;
+#endif
+
+// ---------------------------------------------------------------------------
 // BaseController.get_action for one vehicle (base_controller.py:70-118) + the RL command
 // (envs/base.py:599-615): shared by the single-lane and the multi-lane step kernels.
 // Returns the commanded acceleration; `commanded` = false means "no command this step" (S5).
@@ -927,6 +944,7 @@ __device__ __forceinline__ T control_accel_on(const DevView<T>& s, const Slot<T>
       case FS_CTRL_LINEAR_OVM: a = ctrl_linear_ovm(v, h, sl.p); break;
       case FS_CTRL_GIPPS: a = ctrl_gipps(v, vl, h, s.dt, sl.p); break;
       case FS_CTRL_FOLLOWER_STOPPER: a = ctrl_follower_stopper(v, vl, h, has, s.dt, sl.p[0]); break;
+      case FS_CTRL_USER: a = fs_user_accel<T>(v, vl, h, has, vf, hf, s.dt, sl.max_accel, sl.p); break;
       default: a = ctrl_follower_stopper(v, vl, h, has, s.dt, mean_v); break;
     }
     commanded = on_edge;

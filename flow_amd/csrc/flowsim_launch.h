@@ -76,6 +76,9 @@ namespace fsim {
                  float* rew, uint8_t* done, int obs_every_step) {
     constexpr int RPW = 64 / SEG;
     const int blocks = (dv.R + RPW - 1) / RPW;
+    if (has_user_ctrl && !fs::kHasUserController)
+      return fail(FS_ERR_UNSUPPORTED, "FS_CTRL_USER: this library was built without a user controller "
+                                      "(flow_amd.build.build_user / flow_amd.controllers.CompiledController)");
     if (open_net) {
       if constexpr (std::is_same<T, float>::value) {
         if (queue_ok(mask, num_steps)) return launch_queue(num_steps, actions, act_stride, obs, rew, done, obs_every_step);

@@ -93,6 +93,7 @@ struct SimBase {
     qflag_armed = false;
     return FS_OK;
   }
+  bool has_user_ctrl = false;   // a FS_CTRL_USER slot: only a library built with the user's controller may launch it
   int pair_block = 256;         // threads per block of k_rollout_pair (FLOWSIM_PAIR_BLOCK overrides)
   const char* last_kernel = "";  // family of the step kernel the last launch_steps call chose (fs_last_kernel)
 
@@ -201,7 +202,8 @@ struct Sim : SimBase {
       stau[i] = T(v.sumo_tau);
       sgap[i] = T(v.sumo_min_gap);
       smax[i] = T(v.sumo_max_speed);
-      if (v.controller == FS_CTRL_BCM) flags |= fs::FLAG_NEED_FOLLOWER;
+      if (v.controller == FS_CTRL_BCM || v.controller == FS_CTRL_USER) flags |= fs::FLAG_NEED_FOLLOWER;
+      if (v.controller == FS_CTRL_USER) has_user_ctrl = true;
       if (v.controller == FS_CTRL_NONLOCAL_FOLLOWER_STOPPER) flags |= fs::FLAG_NEED_MEAN;
       if (v.controller == FS_CTRL_LAC) flags |= fs::FLAG_HAS_LAC;
       if (v.controller == FS_CTRL_PISATURATION) {

@@ -40,9 +40,19 @@ def vehicle_slots(vehicle_kernel, rl_order, ids=None):
                  initial_speed=float(vehicle_kernel.get_initial_speed(veh_id)),
                  lane_change_mode=int(vehicle_kernel.type_parameters[vehicle_kernel.get_type(veh_id)][
                      "lane_change_params"].lane_change_mode),
-                 rl_index=rl_order.index(veh_id) if isinstance(ctrl, RLController) else -1)
+                 rl_index=rl_order.index(veh_id) if isinstance(ctrl, RLController) else -1,
+                 user_source=getattr(ctrl, "source", None))
         slots.append(d)
     return slots
+
+
+def user_controller_source(slots):
+    """The one get_accel body of the population's CompiledControllers (None without any): a handle steps on ONE library."""
+    bodies = {str(d["user_source"]).strip() for d in slots if d["controller"] == L.FS_CTRL_USER}
+    if len(bodies) > 1:
+        raise NotImplementedError("all CompiledControllers of an environment must share one SOURCE (their parameters may "
+                                  "differ): a handle steps on one library")
+    return bodies.pop() if bodies else None
 
 
 def initial_positions(network_kernel, initial_config, num_vehicles, num_replicas, rng=None):
@@ -107,7 +117,7 @@ def type_slot(veh_k, type_name, type_index, rl_index):
                 sumo_max_speed=float(cf.controller_params["maxSpeed"]),
                 initial_speed=float(tp.get("initial_speed", 0.0)), type=type_index,
                 lane_change_mode=int(tp["lane_change_params"].lane_change_mode),
-                rl_index=rl_index if is_rl else -1), is_rl
+                rl_index=rl_index if is_rl else -1, user_source=getattr(ctrl, "source", None)), is_rl
 
 
 def slot_capacities(vehicles, inflows, total, given=None):
@@ -281,7 +291,8 @@ def build_open_spec(env, num_replicas, rng=None):
         horizon=ep.horizon, warmup_steps=int(ep.warmup_steps), sims_per_step=int(ep.sims_per_step),
         seed=handle_seed(sp), noise_math=getattr(sp, "noise_math", "hw"), replica_offset=int(getattr(env, "_replica_offset", 0)), track_aux=bool(getattr(env, "_track_aux", True)),
         ma_apply_actions=not bool(getattr(env, "APPLY_ENUMERATE_QUIRK", True)),
-        slot_types=names, slot_base=base, slot_caps=dict(zip(names, caps)), init_slot=init_slot, **tables)
+        slot_types=names, slot_base=base, slot_caps=dict(zip(names, caps)), init_slot=init_slot,
+        user_controller_source=user_controller_source(slots), **tables)
     spec.update(extra)
     return spec
 
@@ -339,6 +350,7 @@ def build_spec(env, num_replicas, rng=None):
     space = env.action_space
     spec = dict(
         num_replicas=R, num_vehicles=N, num_rl=veh_k.num_rl_vehicles, vehicles=slots,
+        user_controller_source=user_controller_source(slots),
         ring_length=np.full(R, float(network.net_params.additional_params["length"]) if not fig8
                             else net_k.length() - 4 * float(net_k.junction_length)), init_pos=X,
         segments=net_k.loop_segments(),

@@ -43,7 +43,13 @@ class FlowSim:
     """
 
     def __init__(self, spec, precision="f32", device=0):
-        self.lib = L.load()
+        # a population with a CompiledController steps on a copy of the library that holds its get_accel (FS_CTRL_USER)
+        src = spec.get("user_controller_source")
+        if src is not None:
+            from flow_amd import build as _build
+            self.lib = L.load(_build.build_user(src))
+        else:
+            self.lib = L.load()
         self.spec = spec
         self.R = int(spec["num_replicas"])
         self.N = int(spec["num_vehicles"])
@@ -187,7 +193,7 @@ class FlowSim:
         if self.open_net:
             cfg.route_start[0] = float(spec["routes"][0]["start"])
             cfg.route_start[1] = float(spec["routes"][min(1, len(spec["routes"]) - 1)]["start"])
-        L.check(self.lib.fs_create(C.byref(cfg), C.byref(self._h)))
+        L.check(self.lib.fs_create(C.byref(cfg), C.byref(self._h)), self.lib)
         self.obs_dim = self.lib.fs_obs_dim(self._h)
         self.act_dim = self.lib.fs_action_dim(self._h)
 
@@ -206,14 +212,14 @@ class FlowSim:
     def set_stream(self, hip_stream):
         """Enqueue later launches on ``hip_stream`` (int address of a hipStream_t, e.g.
         ``torch.cuda.current_stream().cuda_stream``; 0 is HIP's default stream)."""
-        L.check(self.lib.fs_set_stream(self._h, C.c_void_p(int(hip_stream) if hip_stream else None)))
+        L.check(self.lib.fs_set_stream(self._h, C.c_void_p(int(hip_stream) if hip_stream else None)), self.lib)
 
     def use_own_stream(self):
         """Go back to the non-blocking stream the handle created for itself."""
-        L.check(self.lib.fs_use_own_stream(self._h))
+        L.check(self.lib.fs_use_own_stream(self._h), self.lib)
 
     def sync(self):
-        L.check(self.lib.fs_sync(self._h))
+        L.check(self.lib.fs_sync(self._h), self.lib)
 
     # ------------------------------------------------------------------ host API (numpy in / out)
     def reset(self, mask=None):
@@ -222,7 +228,7 @@ class FlowSim:
         m = None if mask is None else np.ascontiguousarray(np.asarray(mask, dtype=np.uint8))
         if m is not None and m.shape != (self.R,):
             raise ValueError("mask must have shape [R]")
-        L.check(self.lib.fs_reset(self._h, _ptr(m), _ptr(obs)))
+        L.check(self.lib.fs_reset(self._h, _ptr(m), _ptr(obs)), self.lib)
         return obs
 
     def step(self, actions=None):
@@ -233,16 +239,16 @@ class FlowSim:
         obs = np.empty((self.R, self.obs_dim), dtype=np.float32)
         rew = np.empty(self.R, dtype=np.float32)
         done = np.empty(self.R, dtype=np.uint8)
-        L.check(self.lib.fs_step(self._h, _ptr(a), _ptr(obs), _ptr(rew), _ptr(done)))
+        L.check(self.lib.fs_step(self._h, _ptr(a), _ptr(obs), _ptr(rew), _ptr(done)), self.lib)
         self.last_done_flags = done          # bit 0: horizon reached, bit 1: collision (include/flowsim.h)
         return obs, rew, done.astype(bool)
 
     # ------------------------------------------------------------------ device API (torch-ROCm tensors)
     def reset_dev(self, obs, mask=None):
-        L.check(self.lib.fs_reset_dev(self._h, _ptr(mask), _ptr(obs)))
+        L.check(self.lib.fs_reset_dev(self._h, _ptr(mask), _ptr(obs)), self.lib)
 
     def step_dev(self, obs, rew, done, actions=None):
-        L.check(self.lib.fs_step_dev(self._h, _ptr(actions), _ptr(obs), _ptr(rew), _ptr(done)))
+        L.check(self.lib.fs_step_dev(self._h, _ptr(actions), _ptr(obs), _ptr(rew), _ptr(done)), self.lib)
 
     def rollout_dev(self, num_steps, obs, rew, done, actions=None, action_stride_steps=None,
                     obs_every_step=True):
@@ -250,15 +256,15 @@ class FlowSim:
         if action_stride_steps is None:
             action_stride_steps = self.R * self.act_dim if actions is not None and actions.dim() == 3 else 0
         L.check(self.lib.fs_rollout_dev(self._h, int(num_steps), _ptr(actions), int(action_stride_steps),
-                                        _ptr(obs), _ptr(rew), _ptr(done), int(bool(obs_every_step))))
+                                        _ptr(obs), _ptr(rew), _ptr(done), int(bool(obs_every_step))), self.lib)
 
     # ------------------------------------------------------------------ policy in the loop (include/flowsim.h fs_policy)
     def policy_act_dev(self, pol, obs, act, logp):
-        L.check(self.lib.fs_policy_act_dev(self._h, C.byref(pol), _ptr(obs), _ptr(act), _ptr(logp)))
+        L.check(self.lib.fs_policy_act_dev(self._h, C.byref(pol), _ptr(obs), _ptr(act), _ptr(logp)), self.lib)
 
     def policy_rollout_dev(self, pol, num_steps, obs, act, logp, rew, done, reset_done=False):
         L.check(self.lib.fs_policy_rollout_dev(self._h, C.byref(pol), int(num_steps), int(bool(reset_done)), _ptr(obs),
-                                               _ptr(act), _ptr(logp), _ptr(rew), _ptr(done)))
+                                               _ptr(act), _ptr(logp), _ptr(rew), _ptr(done)), self.lib)
 
     # ------------------------------------------------------------------ state access
     def _field_shape(self, field):
@@ -278,13 +284,13 @@ class FlowSim:
     def get_state(self, field):
         shape, dt = self._field_shape(field)
         out = np.empty(shape, dtype=dt)
-        L.check(self.lib.fs_get_state(self._h, int(field), _ptr(out), out.nbytes))
+        L.check(self.lib.fs_get_state(self._h, int(field), _ptr(out), out.nbytes), self.lib)
         return out
 
     def set_state(self, field, value):
         shape, dt = self._field_shape(field)
         a = np.ascontiguousarray(np.broadcast_to(np.asarray(value, dtype=dt), shape))
-        L.check(self.lib.fs_set_state(self._h, int(field), _ptr(a), a.nbytes))
+        L.check(self.lib.fs_set_state(self._h, int(field), _ptr(a), a.nbytes), self.lib)
 
     @property
     def last_kernel(self):
@@ -293,11 +299,11 @@ class FlowSim:
 
     def add_vehicle(self, slot, route, x, speed, replica=0):
         """Put the (absent) vehicle of ``slot`` back into the network (fs_add_vehicle: k.vehicle.add of the reference)."""
-        L.check(self.lib.fs_add_vehicle(self._h, int(replica), int(slot), int(route), float(x), float(speed)))
+        L.check(self.lib.fs_add_vehicle(self._h, int(replica), int(slot), int(route), float(x), float(speed)), self.lib)
 
     def dump_trajectory(self, replica, csv_path):
         """Append the current state of ``replica`` to ``csv_path`` (fs_dump_trajectory)."""
-        L.check(self.lib.fs_dump_trajectory(self._h, int(replica), str(csv_path).encode()))
+        L.check(self.lib.fs_dump_trajectory(self._h, int(replica), str(csv_path).encode()), self.lib)
 
     # convenience
     @property

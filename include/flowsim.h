@@ -74,7 +74,13 @@ enum fs_controller {
   FS_CTRL_GIPPS = 8,            /* p = {v0, acc, b, b_l, s0, tau}                       :500-582 */
   FS_CTRL_FOLLOWER_STOPPER = 9, /* p = {v_des}                                          velocity_controllers.py:7-116 */
   FS_CTRL_NONLOCAL_FOLLOWER_STOPPER = 10, /* v_des = replica mean speed                 velocity_controllers.py:119-164 */
-  FS_CTRL_PISATURATION = 11     /* no parameters; keeps int(38/sim_step)-1 past speeds  velocity_controllers.py:167-240 */
+  FS_CTRL_PISATURATION = 11,    /* no parameters; keeps int(38/sim_step)-1 past speeds  velocity_controllers.py:167-240 */
+  FS_CTRL_USER = 12             /* a controller of the USER's (the reference lets user code subclass BaseController and write
+                                   get_accel in Python, base_controller.py:42-118): its get_accel is a device function compiled
+                                   INTO a copy of this library -- `python -m flow_amd.build` with
+                                   -DFS_USER_CONTROLLER_HEADER, see flow_amd.controllers.CompiledController and
+                                   flow_amd.build.build_user; p = its (up to 8) parameters.  The stock library refuses a
+                                   launch with such a slot (FS_ERR_UNSUPPORTED) */
 };
 
 /* BaseController fail-safes, flow/controllers/base_controller.py:113-116 */

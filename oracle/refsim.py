@@ -28,6 +28,7 @@ from . import rewards as Rw
 # controller ids -- must equal include/flowsim.h FS_CTRL_*
 CTRL_SIM, CTRL_RL, CTRL_IDM, CTRL_CFM, CTRL_BCM, CTRL_LAC, CTRL_OVM, CTRL_LINEAR_OVM, \
     CTRL_GIPPS, CTRL_FOLLOWER_STOPPER, CTRL_NONLOCAL_FOLLOWER_STOPPER, CTRL_PISATURATION = range(12)
+CTRL_USER = 12        # a user-compiled controller (flow_amd.controllers.CompiledController): spec['user_controller_numpy']
 FAILSAFE_NONE, FAILSAFE_INSTANTANEOUS, FAILSAFE_SAFE_VELOCITY = range(3)
 ENV_ACCEL, ENV_WAVE_ATTENUATION, ENV_WAVE_ATTENUATION_PO, ENV_LANE_CHANGE_ACCEL = range(4)
 # multi-agent ring heads (flow/envs/multiagent/ring/*): one observation block per RL vehicle, column = its rl_index
@@ -214,6 +215,11 @@ def controller_dispatch(o, v, v_lead, h, has_lead, v_follow, h_follow, rl_value,
             if ms is None:
                 ms = mean_speed()
             a = C.follower_stopper(*args, o.dt, v_des=ms)
+        elif ct == CTRL_USER:
+            # the user's get_accel restated by the user: a callable (v, v_lead, h, has_lead, v_follow, h_follow, dt,
+            # max_accel, p, dtype) -> acceleration [R], every operation in ``dtype`` in the order of the C++ body
+            a = o.spec["user_controller_numpy"](v[sl], v_lead[sl], h[sl], has_lead[sl], v_follow[sl], h_follow[sl],
+                                                T(o.dt), T(vs["max_accel"]), [T(q) for q in p], o.dt_)
         elif ct == CTRL_PISATURATION:
             a, o.lac_a[sl] = pisaturation_step(o.pis_hist[:, i, :], o.pis_n[:, i], o.lac_a[sl], v[sl],
                                                v_lead[sl], h[sl], o.dt, vs["max_accel"], cmd & active, o.dt_)

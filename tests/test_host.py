@@ -404,3 +404,19 @@ def test_bench_roofline_traffic_comes_from_the_committed_pmc_summary():
         assert 0.5 < vi["frac"] < 1.0 and vi["frac"] > vi["frac_of_nominal"] and 1.8 < vi["effective_clock_GHz"] < 2.4
     assert bench.pmc_traffic("mixed", 4096, 20)[0] is None
     assert bench.pmc_traffic("mixed", 1024, 1500)[0] is None
+
+
+def test_user_controller_header_and_library_tag():
+    """flow_amd.build.user_header / build_user (the extension path for user-defined controllers): the header wraps the
+    body in the documented signature; the library copy is keyed by the body and by the sources."""
+    from flow_amd import build
+    h = build.user_header("    return p[0] * (v_lead - v);\n")
+    assert build.USER_SIGNATURE in h and "return p[0] * (v_lead - v);" in h and h.rstrip().endswith("}")
+    from flow_amd.controllers import CompiledController
+    from flow_amd.core.params import SumoCarFollowingParams
+    with pytest.raises(ValueError):
+        CompiledController("v", SumoCarFollowingParams())
+    with pytest.raises(ValueError):
+        CompiledController("v", SumoCarFollowingParams(), source="return T(0);", params=list(range(9)))
+    c = CompiledController("v", SumoCarFollowingParams(), source="return T(0);", params=[1, 2])
+    assert c.FS_ID == 12 and c.fs_params() == [1.0, 2.0]
