@@ -63,7 +63,7 @@ def include_flags():
 def _stamp(extra):
     h = hashlib.sha256()
     for d in DEPS:
-        h.update(d.encode())
+        h.update(os.path.relpath(d, ROOT).encode())     # (relative: the same tree at another path has the same stamps)
         with open(d, "rb") as f:
             h.update(hashlib.sha256(f.read()).digest())
     h.update(" ".join(COMMON_FLAGS + extra).encode())
