@@ -11,20 +11,13 @@ from oracle import refsim as S
 
 pytestmark = pytest.mark.gpu
 
-BODY = """
-    const T gap_err = h - p[0] * v - p[1];
-    const T a = p[2] * gap_err + p[3] * (v_lead - v) + p[4] * (v - v_follow);
-    const T lim = tmin(tmax(a, T(0) - max_accel), max_accel);
-    return has_lead ? lim : max_accel;
-"""
+import os
+import sys
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+from compiled_controller import TimeGap, time_gap_numpy  # noqa: E402
 
-def time_gap_numpy(v, v_lead, h, has_lead, v_follow, h_follow, dt, max_accel, p, dtype):
-    T = np.dtype(dtype).type
-    gap_err = h - p[0] * v - p[1]
-    a = p[2] * gap_err + p[3] * (v_lead - v) + p[4] * (v - v_follow)
-    lim = np.minimum(np.maximum(a, T(0) - max_accel), max_accel)
-    return np.where(has_lead, lim, max_accel).astype(dtype)
+BODY = TimeGap.SOURCE
 
 
 def user_spec(R=7, N=22, noise=0.0, fail_safe=0):
@@ -63,7 +56,7 @@ def test_user_controller_in_the_generic_kernel_equals_the_oracle(noise, fail_saf
 
 def test_the_stock_library_refuses_a_user_controller_and_the_class_builds_through_vehicle_params():
     from flow_amd import _lib as L
-    from flow_amd.controllers import CompiledController, ContinuousRouter
+    from flow_amd.controllers import ContinuousRouter
     from flow_amd.core.params import EnvParams, InitialConfig, NetParams, SumoParams, VehicleParams
     from flow_amd.envs import AccelEnv
     from flow_amd.networks import RingNetwork
@@ -74,11 +67,6 @@ def test_the_stock_library_refuses_a_user_controller_and_the_class_builds_throug
         stock.reset()
     stock.close()
 
-    class TimeGap(CompiledController):
-        SOURCE = BODY
-
-        def __init__(self, veh_id, car_following_params, t_gap=1.2, **kw):
-            CompiledController.__init__(self, veh_id, car_following_params, params=[t_gap, 2.0, 0.3, 0.6, 0.05], **kw)
     veh = VehicleParams()
     veh.add("gap", acceleration_controller=(TimeGap, {"t_gap": 1.0}), routing_controller=(ContinuousRouter, {}),
             num_vehicles=14)
