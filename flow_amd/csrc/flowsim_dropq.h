@@ -210,21 +210,34 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
   T h = 1000.0f, vl = -1001.0f;
   bool has = false;
   int lead_lab = -1;
-  // the number of vehicles of the three other paths AHEAD of mine: binary searches in their sorted mirrors, the three
-  // side by side (every round is one LDS round trip for all of them).  The searches compare positions only; vehicles AT
-  // my position (rare: ahead iff their slot is lower) are counted afterwards, by the whole wave, when some lane met one
+  // the number of vehicles of the three other paths AHEAD of mine: searches in their sorted mirrors, the three side by
+  // side.  Three pivots per round (steps 16, 4, 1: three dependent LDS round trips for 64 entries, where a binary search
+  // takes six); a mirror is sorted, so the pivots that are ahead form a prefix and their number is the advance.  The
+  // searches compare positions only; vehicles AT my position (rare: ahead iff their slot is lower) are counted afterwards,
+  // by the whole wave, when some lane met one
   auto count_ahead3 = [&](int na_, int nb_, int nc_, int& ca, int& cb_, int& cc) {
     const int qa = w ^ 1, qb = w ^ 2, qc_ = w ^ 3;
     int la_ = 0, lb_ = 0, lc_ = 0;
 #pragma unroll
-    for (int step = 32; step >= 1; step >>= 1) {
-      const int ia = la_ + step - 1, ib = lb_ + step - 1, ic = lc_ + step - 1;
-      const T xa = L.xl[qa][ia & 63].x, xb = L.xl[qb][ib & 63].x, xc = L.xl[qc_][ic & 63].x;
-      la_ += (int(ia < na_) & int(xa > x)) ? step : 0;                 // (bitwise: no branches)
-      lb_ += (int(ib < nb_) & int(xb > x)) ? step : 0;
-      lc_ += (int(ic < nc_) & int(xc > x)) ? step : 0;
+    for (int step = 16; step >= 1; step >>= 2) {
+      int ta = 0, tb2 = 0, tc2 = 0;
+#pragma unroll
+      for (int m = 1; m <= 3; ++m) {
+        const int ia = la_ + m * step - 1, ib = lb_ + m * step - 1, ic = lc_ + m * step - 1;
+        const T xa = L.xl[qa][ia & 63].x, xb = L.xl[qb][ib & 63].x, xc = L.xl[qc_][ic & 63].x;
+        ta += int(ia < na_) & int(xa > x);                             // (bitwise: no branches)
+        tb2 += int(ib < nb_) & int(xb > x);
+        tc2 += int(ic < nc_) & int(xc > x);
+      }
+      la_ += ta * step;
+      lb_ += tb2 * step;
+      lc_ += tc2 * step;
     }
     const DropXL ea = L.xl[qa][la_ & 63], eb = L.xl[qb][lb_ & 63], ec = L.xl[qc_][lc_ & 63];   // the first NOT strictly ahead
+    // (the searches end at 63 at most: a full path whose 64 vehicles are all ahead is one more)
+    la_ += int(la_ < na_) & int(ea.x > x);
+    lb_ += int(lb_ < nb_) & int(eb.x > x);
+    lc_ += int(lc_ < nc_) & int(ec.x > x);
     const bool ta = la_ < na_ && ea.x == x, tb_ = lb_ < nb_ && eb.x == x, tc = lc_ < nc_ && ec.x == x;
     if (__ballot(ta || tb_ || tc) != 0ull) {
       auto ties = [&](int q, int nq, int& lo, bool tie) {
