@@ -187,6 +187,12 @@ def build_user(body, verbose=False):
     if not all(os.path.exists(os.path.join(OBJ, name + ".o")) for name, _, _ in parts()):
         build(force=True)                              # (a tree that holds the library but not its objects)
     os.makedirs(out_dir, exist_ok=True)
+    for stale in os.listdir(USER_DIR):                 # copies built from other sources than the current ones
+        tagfile = os.path.join(USER_DIR, stale, "sources.stamp")
+        if stale != tag and os.path.exists(tagfile) and open(tagfile).read().strip() != _stamp([]):
+            shutil.rmtree(os.path.join(USER_DIR, stale), ignore_errors=True)
+    with open(os.path.join(out_dir, "sources.stamp"), "w") as f:
+        f.write(_stamp([]))
     hdr = os.path.join(out_dir, "user_controller.h")
     with open(hdr, "w") as f:
         f.write(text)
