@@ -141,6 +141,13 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
     return n;
   };
 
+  auto my_due_of = [&](int k_me) -> int {
+    const double due_t = my_begin + double(k_me) * my_per;
+    const bool open_me = my_flow && (due_t <= my_end) && (my_number < 0 || k_me < my_number);
+    return open_me ? due_index(due_t) : 0x7fffffff;
+  };
+  int my_due = my_due_of(emit_l);
+
   // ---- the vehicle this lane holds (slot view first: lane i = slot i) ---------------------------------------
   T x = s.pos[base + li];
   T v = s.vel[base + li];
@@ -452,17 +459,10 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
     bool inserted = false;
     FS_QT(q_in0);
     if (try_insert) {
-      const double now = double(sim_steps - 1) * o.dt_d;
-      auto schedule = [&](double& t_mine) -> bool {
-        const int k_me = emit_l;
-        const double due_t = my_begin + double(k_me) * my_per;
-        const bool open_me = my_flow && (due_t <= my_end) && (my_number < 0 || k_me < my_number);
-        t_mine = open_me ? due_t : 1.0e300;
-        return open_me && (due_t <= now);
-      };
-      double t_mine;
-      const bool due_me = schedule(t_mine);
-      unsigned fm = unsigned(__ballot(due_me)) & 0xffu;
+      // (M2: the float64 schedule begin + k period <= now = n dt as the integer statement my_due <= n; my_due = the first
+      // sub-step index at which my inflow's next vehicle is due, recomputed only when the inflow emits)
+      const int n_now = sim_steps - 1;
+      unsigned fm = unsigned(__ballot(my_due <= n_now)) & 0xffu;
       FS_QA(8, q_in0);
       FS_QT(q_i2);
       while (fm != 0u) {
@@ -533,14 +533,14 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
       if (inserted) {
         moved = reload = true;
         nz_reload = 1;                                 // the newcomers' draws: the block is evaluated again
+        my_due = my_due_of(emit_l);
       }
       // with the counters as the insertions left them: who is still due (watched by the sub-step from now on), and
       // when the next vehicle of the others is
-      double t_after;
-      const bool still_due = schedule(t_after);
+      const bool still_due = my_due <= n_now;
       pend_m = __ballot(still_due) & 0xffull;
-      // (the inflows sit in lanes 0 .. 7: the minimum of their indices -- due_index is monotone -- by three DPP steps)
-      int dn_ = due_index(still_due ? 1.0e300 : t_after);
+      // (the inflows sit in lanes 0 .. 7: the minimum of their indices by three DPP steps)
+      int dn_ = still_due ? 0x7fffffff : my_due;
       { const int w_ = dpp_i<DPP_QUAD_XOR1>(dn_); dn_ = w_ < dn_ ? w_ : dn_; }
       { const int w_ = dpp_i<DPP_QUAD_XOR2>(dn_); dn_ = w_ < dn_ ? w_ : dn_; }
       { const int w_ = dpp_i<DPP_ROW_HALF_MIRROR>(dn_); dn_ = w_ < dn_ ? w_ : dn_; }
