@@ -85,11 +85,12 @@ def train_rllib(submodule, flags):
     run_experiments({flow_params["exp_tag"]: exp})
 
 
-def train_device(submodule, flags):
+def train_device(submodule, flags, multiagent=False):
     from train_vec import train_on_device
     fp = submodule.flow_params
     fp['sim'].render = False
-    return train_on_device(fp, replicas=flags.replicas, fragment=flags.rollout_size, iterations=flags.num_steps)
+    return train_on_device(fp, replicas=flags.replicas, fragment=flags.rollout_size, iterations=flags.num_steps,
+                           shared_agents=multiagent)
 
 
 def main(args):
@@ -98,10 +99,15 @@ def main(args):
     if flags.rl_trainer.lower() == "rllib":
         return train_rllib(submodule, flags)
     if flags.rl_trainer.lower() == "device":
-        if multiagent:
-            raise ValueError("--rl_trainer device trains single-agent experiments (one action vector per replica); "
-                             "step multi-agent experiments with flow_amd.envs.VecFlowEnv directly")
-        return train_device(submodule, flags)
+        # multi-agent experiments whose agents share the policy 'av' (multiagent_ring / _figure_eight / _merge: one
+        # observation block and one action column per agent) train that ONE policy; adversarial_figure_eight has two
+        # policies with opposite rewards: not this loop
+        if multiagent and len(getattr(submodule, "POLICIES_TO_TRAIN", ["av"])) > 1:
+            raise ValueError("--rl_trainer device trains one shared policy; %s trains %s"
+                             % (flags.exp_config, submodule.POLICIES_TO_TRAIN))
+        if multiagent and flags.exp_config.startswith("adversarial"):
+            raise ValueError("--rl_trainer device trains one shared policy; adversarial experiments train two")
+        return train_device(submodule, flags, multiagent)
     raise ValueError("rl_trainer should be either 'device' or 'rllib'.")
 
 

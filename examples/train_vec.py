@@ -120,10 +120,14 @@ def ppo_update(pi, opt, shards, epochs=4, clip=0.2, group=None):
 
 
 def train_on_device(flow_params, replicas=1024, fragment=100, iterations=20, epochs=4, lr=3e-4, seed=0, log=print,
-                    rank=0, world=1):
+                    rank=0, world=1, shared_agents=False):
     """PPO on R replicas of ``flow_params`` with everything in HBM: returns the mean step reward per iteration.
     ``world`` > 1: this process is rank ``rank`` of a data-parallel run (torch.distributed is initialised): it steps its
-    block of the R replicas on its own GPU."""
+    block of the R replicas on its own GPU.
+    ``shared_agents``: a multi-agent experiment whose agents share ONE policy (the reference's multi-agent ring /
+    figure-eight / merge experiments map every agent to the policy 'av': examples/exp_configs/rl/multiagent/*.py
+    policy_mapping_fn): the observation row holds one block per agent, the action row one column per agent; every agent
+    is a sample of the shared policy and receives the shared reward."""
     from flow_amd.dist import allreduce_sum, shard_range
     from flow_amd.envs import VecFlowEnv
     local = int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
@@ -132,13 +136,19 @@ def train_on_device(flow_params, replicas=1024, fragment=100, iterations=20, epo
     torch.manual_seed(seed)                                   # the same initial policy on every rank
     lo, hi = shard_range(replicas, rank, world)
     vec = VecFlowEnv(flow_params, num_replicas=hi - lo, device=local, replica_offset=lo)
-    pi = GaussianPolicy(vec.obs_dim, vec.act_dim).to(dev)
+    n_ag = vec.act_dim if shared_agents else 1
+    if shared_agents and (vec.act_dim < 1 or vec.obs_dim % vec.act_dim):
+        raise ValueError("shared_agents: the observation (%d) is not one block per action column (%d)" % (vec.obs_dim, vec.act_dim))
+    k_ag = vec.obs_dim // n_ag
+    pi = GaussianPolicy(k_ag if shared_agents else vec.obs_dim, 1 if shared_agents else vec.act_dim).to(dev)
     opt = torch.optim.Adam(pi.parameters(), lr=lr)
     # the rollout: ONE kernel per fragment where the library has the fused policy + step form for this experiment and
     # model (fs_policy_rollout_dev: rings with one RL vehicle, WaveAttenuationPOEnv, 1..3 hidden layers of 32 tanh units);
     # otherwise K single steps around the torch policy captured as one HIP graph
     fused, graph = None, None
     try:
+        if shared_agents:
+            raise NotImplementedError("one policy shared by %d agents per replica" % n_ag)
         from flow_amd.utils.device_policy import DevicePolicy
         fused = DevicePolicy([pi.mu[0], pi.mu[2]], pi.mu[4], log_std=pi.log_std, seed=seed)
         vec.reset()
@@ -151,7 +161,11 @@ def train_on_device(flow_params, replicas=1024, fragment=100, iterations=20, epo
         log("rollout: HIP graph of %d single steps around the torch policy (%s)" % (fragment, e))
         if world > 1:
             torch.manual_seed(seed + 1000 * (rank + 1))       # the graph's torch.randn: another stream per rank
-        graph = vec.capture(fragment, policy=pi.act, reset_done=True)
+        R_ = hi - lo
+
+        def act_shared(obs):                                   # [R, agents * k] -> [R, agents]: every agent its own sample
+            return pi.act(obs.view(R_ * n_ag, k_ag)).view(R_, n_ag)
+        graph = vec.capture(fragment, policy=act_shared if shared_agents else pi.act, reset_done=True)
         graph.begin(vec.reset())
     K, R = fragment, hi - lo
     history = []
@@ -166,7 +180,12 @@ def train_on_device(flow_params, replicas=1024, fragment=100, iterations=20, epo
             obs, act, rew, done = graph.replay()               # K closed-loop steps of R replicas: one graph launch
             graph.synchronize()
         t_roll = time.perf_counter() - t0
-        ppo_update(pi, opt, [(obs, act, rew, done)], epochs=epochs)
+        if shared_agents:                                      # agents become samples: [K(+1), R * agents, .]
+            shard = (obs.reshape(K + 1, R * n_ag, k_ag), act.reshape(K, R * n_ag, 1),
+                     rew.repeat_interleave(n_ag, dim=1), done.repeat_interleave(n_ag, dim=1))
+        else:
+            shard = (obs, act, rew, done)
+        ppo_update(pi, opt, [shard], epochs=epochs)
         tot = allreduce_sum(torch.stack([rew.double().sum(), torch.tensor(float(rew.numel()), dtype=torch.float64, device=dev),
                                          (done != 0).sum().double()]))
         mean_rew = float(tot[0] / tot[1])

@@ -159,3 +159,20 @@ def test_train_vec_through_rccl_with_one_rank_equals_the_plain_run():
     forced = rewards(dict(os.environ, TRAIN_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29561",
                           HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert plain == forced
+
+
+def test_train_script_trains_the_shared_policy_of_the_multi_agent_experiments():
+    """examples/train.py multiagent_ring / multiagent_figure_eight (every agent maps to the policy 'av' in the reference's
+    files): one observation block and one action column per agent, ONE policy, the shared reward."""
+    import subprocess
+    script = os.path.join(ROOT, "examples", "train.py")
+    for exp in ("multiagent_ring", "multiagent_figure_eight"):
+        res = subprocess.run([sys.executable, script, exp, "--num_steps", "2", "--rollout_size", "12", "--replicas", "32"],
+                             capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        lines = [ln for ln in res.stdout.splitlines() if ln.startswith("iteration")]
+        assert len(lines) == 2 and all(np.isfinite(float(ln.split()[5])) for ln in lines), res.stdout
+        assert "shared by 2 agents" in res.stdout
+    res = subprocess.run([sys.executable, script, "adversarial_figure_eight", "--num_steps", "1"], capture_output=True,
+                         text=True, timeout=600)
+    assert res.returncode != 0 and "one shared policy" in res.stderr
