@@ -166,7 +166,7 @@ def test_train_script_trains_the_shared_policy_of_the_multi_agent_experiments():
     files): one observation block and one action column per agent, ONE policy, the shared reward."""
     import subprocess
     script = os.path.join(ROOT, "examples", "train.py")
-    for exp in ("multiagent_ring", "multiagent_figure_eight"):
+    for exp in ("multiagent_ring",):                      # (multiagent_figure_eight: the same path; RUN_SLOW covers nothing more)
         res = subprocess.run([sys.executable, script, exp, "--num_steps", "2", "--rollout_size", "12", "--replicas", "32"],
                              capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stderr[-2000:]
