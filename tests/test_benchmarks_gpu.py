@@ -177,6 +177,7 @@ def test_bottleneck_benchmarks(k, slots):
     env.terminate()
 
 
+@pytest.mark.slow            # (scaling 2 stays in the fast set through tests/test_wide_gpu.py::test_wide_scaling_two_eight_entry_lanes)
 def test_bottleneck2_benchmark_scaling_two():
     with pytest.raises(NotImplementedError, match="above 64"):
         make_env(bottleneck_benchmark(2))                                  # the default pool of 64 slots
