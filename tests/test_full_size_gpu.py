@@ -71,12 +71,24 @@ def test_c4_full_size_sampled_replicas_equal_the_oracle():
 
 
 def test_c5_full_size_sampled_replicas_equal_the_oracle():
-    """Noise off: the Box-Muller draws go through libm on the host and through the device's log / cos in the kernel
-    (tolerance test: test_merge_po_noise_short_horizon_tolerance); everything else is the bench's configuration."""
+    """The bench's configuration WITH its acceleration noise (IDMController(noise=0.2), as the reference ships the
+    experiment): SumoParams(noise_math='exact') makes the Box-Muller draws fixed float32 sequences, the same in the numpy
+    oracle (with the hardware's log2 / cos the comparison is a tolerance test: test_merge_po_noise_short_horizon_tolerance)."""
     import bench
-    kernel, ora = sampled_parity(bench.c5_flow_params("f32", noise=0.0), R=1024, K=600, rows=[0, 301, 640, 1023], act_seed=4)
+    fp = bench.c5_flow_params("f32", noise=0.2)
+    fp["sim"].noise_math = "exact"
+    kernel, ora = sampled_parity(fp, R=1024, K=600, rows=[0, 301, 640, 1023], act_seed=4)
     assert kernel == "k_merge_queue"
     assert ora.total_departed.min() > 250 and ora.total_arrived.min() > 100
+
+
+def test_c4_lane_change_leg_full_size_sampled_replicas_equal_the_oracle():
+    """bench.py's c4_bottleneck_lane_change leg (flow/benchmarks/bottleneck1: lane_change_mode 1621 -> the simplified lane
+    changing M11, on k_steps_wide: the ranked slot-order path) at the bench's replica count, two sampled replicas."""
+    import bench
+    kernel, ora = sampled_parity(bench.c4_flow_params(256, lane_change_mode=1621), R=128, K=400, rows=[5, 120], act_seed=6)
+    assert kernel == "k_steps_wide"
+    assert ora.num_lane_changes.min() > 20 and ora.total_arrived.min() > 40
 
 
 def test_rl_ring_full_size_rollout_and_fused_policy_fragment():
