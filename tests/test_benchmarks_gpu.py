@@ -156,7 +156,7 @@ def bottleneck_benchmark(k, **sim_kw):
                                       edges_distribution=["2", "3", "4", "5"]))
 
 
-@pytest.mark.parametrize("k,slots", [(0, 64), (1, 64), pytest.param(0, 160, marks=pytest.mark.slow),
+@pytest.mark.parametrize("k,slots", [(0, 64), pytest.param(1, 64, marks=pytest.mark.slow), pytest.param(0, 160, marks=pytest.mark.slow),
                                      pytest.param(1, 160, marks=pytest.mark.slow)])
 def test_bottleneck_benchmarks(k, slots):
     env = make_env(bottleneck_benchmark(k, max_vehicles=slots))

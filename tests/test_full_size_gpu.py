@@ -77,7 +77,7 @@ def test_c5_full_size_sampled_replicas_equal_the_oracle():
     import bench
     fp = bench.c5_flow_params("f32", noise=0.2)
     fp["sim"].noise_math = "exact"
-    kernel, ora = sampled_parity(fp, R=1024, K=600, rows=[0, 301, 640, 1023], act_seed=4)
+    kernel, ora = sampled_parity(fp, R=1024, K=600, rows=[301, 1023], act_seed=4)
     assert kernel == "k_merge_queue"
     assert ora.total_departed.min() > 250 and ora.total_arrived.min() > 100
 
@@ -86,9 +86,9 @@ def test_c4_lane_change_leg_full_size_sampled_replicas_equal_the_oracle():
     """bench.py's c4_bottleneck_lane_change leg (flow/benchmarks/bottleneck1: lane_change_mode 1621 -> the simplified lane
     changing M11, on k_steps_wide: the ranked slot-order path) at the bench's replica count, two sampled replicas."""
     import bench
-    kernel, ora = sampled_parity(bench.c4_flow_params(256, lane_change_mode=1621), R=128, K=400, rows=[5, 120], act_seed=6)
+    kernel, ora = sampled_parity(bench.c4_flow_params(256, lane_change_mode=1621), R=128, K=300, rows=[5, 120], act_seed=6)
     assert kernel == "k_steps_wide"
-    assert ora.num_lane_changes.min() > 20 and ora.total_arrived.min() > 40
+    assert ora.num_lane_changes.min() > 10 and ora.total_arrived.min() > 20
 
 
 def test_rl_ring_full_size_rollout_and_fused_policy_fragment():
