@@ -77,9 +77,9 @@ def test_c5_full_size_sampled_replicas_equal_the_oracle():
     import bench
     fp = bench.c5_flow_params("f32", noise=0.2)
     fp["sim"].noise_math = "exact"
-    kernel, ora = sampled_parity(fp, R=1024, K=600, rows=[301, 1023], act_seed=4)
+    kernel, ora = sampled_parity(fp, R=1024, K=350, rows=[301, 1023], act_seed=4)     # (the numpy Philox is the slow part)
     assert kernel == "k_merge_queue"
-    assert ora.total_departed.min() > 250 and ora.total_arrived.min() > 100
+    assert ora.total_departed.min() > 150 and ora.total_arrived.min() > 60
 
 
 def test_c4_lane_change_leg_full_size_sampled_replicas_equal_the_oracle():
