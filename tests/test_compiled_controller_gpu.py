@@ -54,6 +54,21 @@ def test_user_controller_in_the_generic_kernel_equals_the_oracle(noise, fail_saf
     sim.close()
 
 
+def test_user_controller_in_float64():
+    """T = double: the same body in the float64 kernels (the reference's arithmetic type), against the float64 oracle."""
+    from flow_amd.sim import FlowSim
+    spec = user_spec(R=3)
+    sim, ora = FlowSim(spec, "f64"), S.RingOracle(spec, np.float64)
+    sim.reset(), ora.reset()
+    for k in range(120):
+        o, r, d = sim.step(None)
+        o_ref, r_ref, d_ref = ora.step(None)
+        np.testing.assert_allclose(o, o_ref.astype(np.float32), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(sim.pos, ora.x, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(sim.vel, ora.v, rtol=0, atol=1e-9)
+    sim.close()
+
+
 def test_the_stock_library_refuses_a_user_controller_and_the_class_builds_through_vehicle_params():
     from flow_amd import _lib as L
     from flow_amd.controllers import ContinuousRouter
