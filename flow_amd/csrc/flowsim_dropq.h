@@ -32,7 +32,11 @@
 namespace fs {
 
 struct DropRow { float tau, min_gap, max_accel, ts_sumo, sumo_max; int is_rl, type, pad; };   // per label (slot)
-struct alignas(16) DropXL { float x; int lab; float v; int pad; };     // a queue entry as the other waves see it
+// a queue entry as the other waves see it.  (key, x) read as ONE 64-bit unsigned integer orders the candidates of the
+// leader choice -- the nearest first, and of two at the same position the higher slot (positions are >= 0: the bits of
+// a float order like the float) -- with a single v_cmp_lt_u64 where (x <, x ==, slot >) took three compares and two
+// scalar operations on their masks
+struct alignas(16) DropXL { unsigned key; float x; float v; int pad; };            // key = 0xffff - slot
 
 struct DropQLds {
   OpenTabsLds<float> tabs;
@@ -41,8 +45,8 @@ struct DropQLds {
   int n[4], ng1[4], ng2[4];    // vehicles on path p; of them beyond the first / the second join (prefixes of the queue)
   int arr_n[4], arr_lab[4][8]; // arrivals of this sub-step: count and labels per path
   int crash[2][4];
-  int acc[4][64];              // observation cells: human count, RL count, human speed sum, RL speed sum (2^-16 m/s)
-  float act[2][64];
+  int acc[2][4][64];           // observation cells [gym step & 1]: human count, RL count, human speed sum, RL speed sum (2^-16 m/s)
+  float act[4][64];            // the step's action row, a copy per wave (written and read by that wave only: no barrier)
   unsigned long long alive_w[4], tmask[8][4];   // slots in use at launch start; slots of vehicle type t
   // staging for the (re)build of the queues from the slot arrays
   float st_x[256], st_v[256], st_vmax[256], st_prev[256];
@@ -87,7 +91,8 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
     if (l == 0) L.tmask[t][w] = m;
   }
   if (tid < 4) { L.n[tid] = 0; L.arr_n[tid] = 0; L.crash[0][tid] = 0; L.crash[1][tid] = 0; }
-  if (tid < 64) { L.acc[0][tid] = 0; L.acc[1][tid] = 0; L.acc[2][tid] = 0; L.acc[3][tid] = 0; }
+  L.acc[0][w][l] = 0;
+  L.acc[1][w][l] = 0;
 
   // ---- replica scalars: every wave keeps its own copy and updates it the same way ----------------------------
   int tcount = s.time[rr];
@@ -121,14 +126,19 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
   };
   int my_due_n = due_index(emit_l);
 
-  const T dt = s.dt;
-  const T m1 = o.m1, m2 = o.m2, zip = o.zip_d, end_x = o.end_x, LEN = qc.veh_len, vlim = o.speed_limit;
+  // (launch constants of the hot path in VECTOR registers: the loop's scalar state does not fit the SGPR file, and what
+  // the compiler spills it reloads with a v_readlane each time)
+  const T dt = in_vgpr(s.dt);
+  const T m1 = in_vgpr(o.m1), m2 = in_vgpr(o.m2), zip = in_vgpr(o.zip_d), end_x = in_vgpr(o.end_x), LEN = in_vgpr(qc.veh_len),
+          vlim = in_vgpr(o.speed_limit);
+  const T crash_gap = in_vgpr(s.crash_gap);
+  const T act_lo = in_vgpr(s.clip_actions ? s.act_lo : -3.0e38f), act_hi = in_vgpr(s.clip_actions ? s.act_hi : 3.0e38f);
   auto shift_of = [&](T xx) -> int { return (xx >= m1 ? 1 : 0) + (xx >= m2 ? 1 : 0); };
   // the route segments (one table: edges and junction-internal stretches alternate): segment of a coordinate
   const int nseg = o.nseg[0];
   T sst[15];                                     // the starts of segments 1 .. 15 (3e38 beyond the table): registers
 #pragma unroll
-  for (int q = 1; q < 16; ++q) sst[q - 1] = q < nseg ? o.lane_tab[TAB_SEG_START * 64 + q] : 3.0e38f;
+  for (int q = 1; q < 16; ++q) sst[q - 1] = in_vgpr(q < nseg ? o.lane_tab[TAB_SEG_START * 64 + q] : 3.0e38f);
   auto seg_of = [&](T xx) -> int {
     int k = 0;
 #pragma unroll
@@ -180,6 +190,10 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
   // my vehicle's parameters (by label)
   T u_tau = 1.0f, u_gap = 1.0f, u_acc = 1.0f, u_ts = 1.0f;
   bool is_rl = false;
+#ifdef FS_QDIAG
+  int dq_n[2] = {0, 0};            // sub-steps with a due inflow; full searches
+#endif
+  int c1 = 0, c2 = 0, c3 = 0;      // vehicles of paths w ^ 1, w ^ 2, w ^ 3 ahead of mine at the last snapshot (count_near3)
   auto load_params = [&]() {
     const DropRow q = L.row[lab & 255];
     u_tau = q.tau; u_gap = q.min_gap; u_acc = q.max_accel; u_ts = q.ts_sumo;
@@ -189,6 +203,7 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
   auto gather_all = [&](int src, bool take) {
 #define FS_D_G(reg_) do { const auto t_ = bperm(reg_, src); reg_ = take ? t_ : reg_; } while (0)
     FS_D_G(x); FS_D_G(v); FS_D_G(lab); FS_D_G(seq); FS_D_G(origin); FS_D_G(vmax); FS_D_G(prev_v);
+    FS_D_G(c1); FS_D_G(c2); FS_D_G(c3);
 #undef FS_D_G
   };
   // my path re-sorted by (x descending, lower slot first) -- after a collision
@@ -215,6 +230,15 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
   // takes six); a mirror is sorted, so the pivots that are ahead form a prefix and their number is the advance.  The
   // searches compare positions only; vehicles AT my position (rare: ahead iff their slot is lower) are counted afterwards,
   // by the whole wave, when some lane met one
+  auto ties = [&](int q, int nq, int& lo, bool tie) {
+    int k = lo;
+    for (int it = 0; it < 64 && __ballot(tie) != 0ull; ++it) {
+      const DropXL ek = L.xl[q][k & 63];
+      tie = tie && k < nq && ek.x == x;
+      if (tie && int(0xffffu - ek.key) < lab) lo = k + 1;              // (equal positions are sorted by slot)
+      k += 1;
+    }
+  };
   auto count_ahead3 = [&](int na_, int nb_, int nc_, int& ca, int& cb_, int& cc) {
     const int qa = w ^ 1, qb = w ^ 2, qc_ = w ^ 3;
     int la_ = 0, lb_ = 0, lc_ = 0;
@@ -240,18 +264,54 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
     lc_ += int(lc_ < nc_) & int(ec.x > x);
     const bool ta = la_ < na_ && ea.x == x, tb_ = lb_ < nb_ && eb.x == x, tc = lc_ < nc_ && ec.x == x;
     if (__ballot(ta || tb_ || tc) != 0ull) {
-      auto ties = [&](int q, int nq, int& lo, bool tie) {
-        int k = lo;
-        for (int it = 0; it < 64 && __ballot(tie) != 0ull; ++it) {
-          const DropXL ek = L.xl[q][k & 63];
-          tie = tie && k < nq && ek.x == x;
-          if (tie && ek.lab < lab) lo = k + 1;                         // (equal positions are sorted by slot)
-          k += 1;
-        }
-      };
       ties(qa, na_, la_, ta);
       ties(qb, nb_, lb_, tb_);
       ties(qc_, nc_, lc_, tc);
+    }
+    ca = la_; cb_ = lb_; cc = lc_;
+  };
+  // The same three counts from the counts of the last snapshot: between two sub-steps a count moves by the arrivals of
+  // that path and by the few vehicles that passed or were passed on another lane, so the FOUR mirror entries around the
+  // old count decide it in one LDS round trip -- the entries strictly ahead form a prefix of a sorted mirror: the window
+  // holds the boundary if it shows an entry that is ahead (or starts at the head) and one that is not (or reaches the
+  // tail).  Any lane whose window does not hold it sends the wave through the full search (the count is a property of the
+  // mirrors, not of how it is found: both ways give the same number).
+  auto count_near3 = [&](bool alive, int na_, int nb_, int nc_, int& ca, int& cb_, int& cc) {
+    const int qa = w ^ 1, qb = w ^ 2, qc_ = w ^ 3;
+    // (entries beyond a queue hold -3e38: never ahead, never equal -- no index tests; the window stays inside the array.
+    // Everything below is a compare into VCC consumed by the next instruction: a predicate combined on the scalar unit
+    // costs this wave, alone on its SIMD, a round trip through the SGPR file each time)
+    const int sa = min(max(min(ca, na_) - 2, 0), 60), sb = min(max(min(cb_, nb_) - 2, 0), 60), sc = min(max(min(cc, nc_) - 2, 0), 60);
+    const DropXL* pa = &L.xl[qa][sa];
+    const DropXL* pb = &L.xl[qb][sb];
+    const DropXL* pc = &L.xl[qc_][sc];
+    int ka = 0, kb = 0, kc = 0, ga = 0, gb = 0, gc = 0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const T xa = pa[m].x, xb = pb[m].x, xc = pc[m].x;
+      ka += xa > x ? 1 : 0; ga += xa >= x ? 1 : 0;
+      kb += xb > x ? 1 : 0; gb += xb >= x ? 1 : 0;
+      kc += xc > x ? 1 : 0; gc += xc >= x ? 1 : 0;
+    }
+    // the window does not hold the boundary: nothing ahead in it and it does not start at the head, or all four ahead and
+    // it does not end at the array's end
+    int bad = (ka == 0 ? sa : 0) | (ka == 4 ? sa - 60 : 0) | (kb == 0 ? sb : 0) | (kb == 4 ? sb - 60 : 0) |
+              (kc == 0 ? sc : 0) | (kc == 4 ? sc - 60 : 0);
+    bad = alive ? bad : 0;
+    if (__ballot(bad != 0) != 0ull) {
+#ifdef FS_QDIAG
+      dq_n[1] += 1;
+#endif
+      count_ahead3(na_, nb_, nc_, ca, cb_, cc);
+      return;
+    }
+    int la_ = sa + ka, lb_ = sb + kb, lc_ = sc + kc;
+    int eq = (ga - ka) | (gb - kb) | (gc - kc);            // vehicles AT my position in a window
+    eq = alive ? eq : 0;
+    if (__ballot(eq != 0) != 0ull) {
+      ties(qa, na_, la_, ga != ka);
+      ties(qb, nb_, lb_, gb != kb);
+      ties(qc_, nc_, lc_, gc != kc);
     }
     ca = la_; cb_ = lb_; cc = lc_;
   };
@@ -270,45 +330,49 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
   };
   auto neighbours = [&](bool& crash) {
     const bool alive = l < n;
-    const int la = shift_of(x + zip);
+    const int la = (x + zip >= m1 ? 1 : 0) + (x + zip >= m2 ? 1 : 0);
     const T x_up = dpp<DPP_WAVE_SHR1>(x), v_up = dpp<DPP_WAVE_SHR1>(v);
     const int lab_up = dpp_i<DPP_WAVE_SHR1>(lab);
-    T bx = BIGV, bv = 0.0f;
-    int bl = -1, bp = w;
-    bool any = false;
-    if (alive && l > 0) { bx = x_up; bv = v_up; bl = lab_up; any = true; }
-    int cnt1, cnt2, cnt3;
-    count_ahead3(nT1, nT2, nT3, cnt1, cnt2, cnt3);
-#pragma unroll
-    for (int t = 1; t < P; ++t) {
-      const int q = w ^ t;
-      const int gq = t == 1 ? g1T1 : (t == 2 ? g2T2 : g2T3);
-      const int cnt_q = t == 1 ? cnt1 : (t == 2 ? cnt2 : cnt3);
-      // the partner path (t = 1): every vehicle ahead once I look across the first join (la >= 1), else its rearmost
-      // vehicle beyond that join; the other pair: every vehicle ahead once I look across the second join, else its
-      // rearmost vehicle beyond it
-      const bool search = t == 1 ? la >= 1 : la == 2;
-      const int ci = (search ? cnt_q : gq) - 1;
-      const DropXL e = L.xl[q][ci < 0 ? 0 : ci];
-      const bool take = (int(alive) & int(ci >= 0) & (int(e.x < bx) | (int(e.x == bx) & int(e.lab > bl)))) != 0;   // the nearest; equal x: the higher slot
-      bx = take ? e.x : bx;
-      bv = take ? e.v : bv;
-      bl = take ? e.lab : bl;
-      bp = take ? q : bp;
-      any = any || take;
-    }
+    // the best candidate so far as (key, x): the vehicle ahead on my own path, if any (lanes beyond the queue compute
+    // along; what they find is never used)
+    const bool up = l > 0;
+    unsigned bk = up ? 0xffffu - unsigned(lab_up) : 0u;
+    T bx = up ? x_up : BIGV, bv = up ? v_up : 0.0f;
+    int bp = w;
+    // (the counts of the last snapshot, less the vehicles that left those paths since)
+    int cnt1 = c1 - read_lane_i(parr_l, wu ^ 1), cnt2 = c2 - read_lane_i(parr_l, wu ^ 2), cnt3 = c3 - read_lane_i(parr_l, wu ^ 3);
+    count_near3(alive, nT1, nT2, nT3, cnt1, cnt2, cnt3);
+    c1 = cnt1; c2 = cnt2; c3 = cnt3;
+    // the partner path (t = 1): every vehicle ahead once I look across the first join (la >= 1), else its rearmost
+    // vehicle beyond that join; the other pair: every vehicle ahead once I look across the second join, else its
+    // rearmost vehicle beyond it
+    const int ci1 = (la >= 1 ? cnt1 : g1T1) - 1, ci2 = (la == 2 ? cnt2 : g2T2) - 1, ci3 = (la == 2 ? cnt3 : g2T3) - 1;
+    const DropXL e1 = L.xl[w ^ 1][ci1 < 0 ? 0 : ci1], e2 = L.xl[w ^ 2][ci2 < 0 ? 0 : ci2], e3 = L.xl[w ^ 3][ci3 < 0 ? 0 : ci3];
+#define FS_D_CAND(e_, ci_, q_) do {                                                                                   \
+      const T ex_ = ci_ >= 0 ? e_.x : BIGV;                                                                           \
+      const ull ke_ = (ull(__float_as_uint(ex_)) << 32) | ull(e_.key), kb_ = (ull(__float_as_uint(bx)) << 32) | ull(bk); \
+      const bool take_ = ke_ < kb_;                       /* the nearest; equal x: the higher slot */                  \
+      bx = take_ ? ex_ : bx; bk = take_ ? e_.key : bk; bv = take_ ? e_.v : bv; bp = take_ ? (q_) : bp;                 \
+    } while (0)
+    FS_D_CAND(e1, ci1, w ^ 1);
+    FS_D_CAND(e2, ci2, w ^ 2);
+    FS_D_CAND(e3, ci3, w ^ 3);
+#undef FS_D_CAND
+    const bool any = bx < BIGV;
     has = any;
     h = any ? (bx - x) - LEN : 1000.0f;                 // vehicle/traci.py:237
     vl = any ? bv : -1001.0f;
-    lead_lab = any ? bl : -1;
-    const int sh_l = shift_of(bx);
-    const bool same_lane = any && ((w >> sh_l) == (bp >> sh_l));            // M8: a collision needs one physical lane
-    crash = __ballot(alive && same_lane && (h < s.crash_gap)) != 0ull;
+    lead_lab = any ? int(0xffffu - bk) : -1;
+    const int sh_l = (bx >= m1 ? 1 : 0) + (bx >= m2 ? 1 : 0);
+    const int other_lane = (w ^ bp) >> sh_l;                                // M8: a collision needs one physical lane
+    const T h_same = other_lane == 0 ? h : 1000.0f;
+    crash = __ballot(alive && (h_same < crash_gap)) != 0ull;
   };
   auto publish = [&]() {
     const bool alive = l < n;
     DropXL e;
-    e.x = x; e.lab = lab; e.v = v; e.pad = 0;
+    e.x = alive ? x : -BIGV;                            // (beyond the queue: behind everybody, whoever compares)
+    e.key = 0xffffu - unsigned(lab); e.v = v; e.pad = 0;
     L.xl[w][l] = e;
     const int c1 = __popcll(__ballot(alive && x >= m1)), c2 = __popcll(__ballot(alive && x >= m2));
     if (l == 0) { L.n[w] = n; L.ng1[w] = c1; L.ng2[w] = c2; }
@@ -388,7 +452,7 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
   };
 
   // ---- the snapshot of the launch's first sub-step ------------------------------------------------------------------
-  if (actions != nullptr && tid < s.num_rl) L.act[0][tid] = actions[size_t(rr) * s.num_rl + tid];
+  if (actions != nullptr && l < s.num_rl) L.act[w][l] = actions[size_t(rr) * s.num_rl + l];
   publish();
   __syncthreads();
   read_counts();
@@ -402,7 +466,6 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
 
 #ifdef FS_QDIAG
   unsigned long long dq_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // 0 move, 1 order/arrivals, 2 publish+barrier, 3 counts+bookkeeping, 4 insertions, 5 neighbours, 6 cells, 7 barrier 2, 8 head
-  int dq_n[2] = {0, 0};
   const unsigned long long dq_start = __builtin_readcyclecounter();
 #define FS_DT(var_) const unsigned long long var_ = __builtin_readcyclecounter()
 #define FS_DA(slot_, t0_) dq_t[slot_] += __builtin_readcyclecounter() - (t0_)
@@ -412,8 +475,12 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
 #endif
   for (int step = 0; step < num_steps; ++step) {
     const int ab = step & 1;
-    if (actions != nullptr && step + 1 < num_steps && tid < s.num_rl)
-      L.act[(step + 1) & 1][tid] = actions[size_t(step + 1) * act_stride + size_t(rr) * s.num_rl + tid];
+    // the next step's action row: the load is issued here and its value goes to the wave's LDS copy after the sub-steps
+    // (stored at once, it was an L2 / HBM round trip at the top of every step; used inside the sub-step loop, the compiler
+    // waits for it in the loop's preheader)
+    const bool act_next = actions != nullptr && step + 1 < num_steps && l < s.num_rl;
+    float a_pref = 0.0f;
+    if (act_next) a_pref = actions[size_t(step + 1) * act_stride + size_t(rr) * s.num_rl + l];
     bool crashed = false;
     const bool emit = obs_every_step || (step == num_steps - 1);
     for (int sub = 0; sub < s.sims_per_step; ++sub) {
@@ -422,9 +489,9 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
       FS_DT(d0);
       // ---- O6: BottleneckDesiredVelocityEnv._apply_rl_actions (bottleneck.py:926-969) -----------------------------
       if (DV && actions != nullptr) {
-        const float a_cell = L.act[ab][acell >= 0 ? acell : 0];
+        const float a_cell = L.act[w][acell >= 0 ? acell : 0];
         T a = acell >= 0 ? a_cell : 0.0f;
-        if (s.clip_actions) a = tmin(tmax(a, s.act_lo), s.act_hi);
+        a = tmin(tmax(a, act_lo), act_hi);
         T nxt = tmin(tmax(vmax + a, 0.01f), 23.0f);
         nxt = acell >= 0 ? nxt : 23.0f;
         if (live && alive && is_rl) vmax = nxt;
@@ -550,7 +617,7 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
             const bool fresh = t == 0 && icq > 0;          // the vehicle inserted a moment ago on this path
             T cx = fresh ? (q == 0 ? ix0 : (q == 1 ? ix1 : (q == 2 ? ix2 : ix3))) : e.x;
             T cv = fresh ? (q == 0 ? iv0 : (q == 1 ? iv1 : (q == 2 ? iv2 : iv3))) : e.v;
-            int cl = fresh ? 255 : e.lab;                  // (its position is the insertion point: no tie with a vehicle ahead)
+            int cl = fresh ? 255 : int(0xffffu - e.key);   // (its position is the insertion point: no tie with a vehicle ahead)
             cx = ci >= 0 ? cx : BIGV;
             cl = ci >= 0 ? cl : 256;
             {
@@ -586,6 +653,7 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
                 seq = seq_ctr;
                 origin = f * (1 << 20) + k;
                 vmax = L.row[slot & 255].sumo_max;
+                c1 = nT1; c2 = nT2; c3 = nT3;              // (all of them ahead of the entry point, as a rule)
               }
               n += 1;
               load_params();
@@ -623,8 +691,8 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
         cells(emit && last_sub, ocell);
         if (ocell >= 0) {
           const int vi = int(rintf(v * 65536.0f));
-          atomicAdd(&L.acc[is_rl ? 1 : 0][ocell], 1);
-          atomicAdd(&L.acc[is_rl ? 3 : 2][ocell], vi);
+          atomicAdd(&L.acc[ab][is_rl ? 1 : 0][ocell], 1);
+          atomicAdd(&L.acc[ab][is_rl ? 3 : 2][ocell], vi);
         }
       }
       FS_DA(6, d6);
@@ -640,23 +708,25 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
 
     // ---- get_state / compute_reward / done ------------------------------------------------------------------------
     FS_DT(d8);
+    if (act_next) L.act[w][l] = a_pref;
     if (emit) {
       if (DV) {
+        // (wave q writes block q of the row -- counts of humans, of RL vehicles, mean speeds of humans, of RL vehicles: the
+        // four waves share the quotients; the sums of the NEXT gym step go to the other buffer, cleared here: its last
+        // readers were the previous step's head, two barriers ago)
         const int C = o.n_obs_cells;
-        if (tid < C) {
-          const int cnt_h = L.acc[0][tid], cnt_r = L.acc[1][tid];
-          const T sp_h = T(L.acc[2][tid]) * (1.0f / 65536.0f), sp_r = T(L.acc[3][tid]) * (1.0f / 65536.0f);
-          L.acc[0][tid] = 0; L.acc[1][tid] = 0; L.acc[2][tid] = 0; L.acc[3][tid] = 0;
-          const T nh = div_out(T(cnt_h), 20.0), nr = div_out(T(cnt_r), 20.0);          // NUM_VEHICLE_NORM
-          const T mean_h = div_out(cnt_h > 0 ? sp_h / (nh * 20.0f) : 0.0f, 50.0);
-          const T mean_r = div_out(cnt_r > 0 ? sp_r / (nr * 20.0f) : 0.0f, 50.0);
-          orow[tid] = nh;
-          orow[C + tid] = nr;
-          orow[2 * C + tid] = mean_h;
-          orow[3 * C + tid] = mean_r;
+        const int kind = w & 1;                                // 0: humans, 1: RL vehicles
+        const int cnt_k = L.acc[ab][kind][l];
+        const T sp_k = T(L.acc[ab][2 + kind][l]) * (1.0f / 65536.0f);
+        L.acc[ab ^ 1][w][l] = 0;
+        const T nk = div_out(T(cnt_k), 20.0);                                           // NUM_VEHICLE_NORM
+        T out_k = nk;
+        if (w >= 2) out_k = div_out(cnt_k > 0 ? sp_k / (nk * 20.0f) : 0.0f, 50.0);     // (wave-uniform)
+        if (l < C) orow[w * C + l] = out_k;
+        if (w == 1) {
+          const T of = div_out(outflow(o.obs_window, out_obs), 2000.0);
+          if (l == 0) orow[4 * C] = of;
         }
-        const T of = div_out(outflow(o.obs_window, out_obs), 2000.0);
-        if (tid == 64) orow[4 * C] = of;
       } else if (tid == 0) {
         orow[0] = 1.0f;                                    // bottleneck.py:481-483
       }
@@ -673,8 +743,8 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
   }
 #ifdef FS_QDIAG
   if (blockIdx.x == 5 && l == 0)
-    printf("DQDIAG wave %d total %llu move %llu order %llu publish+barrier %llu counts %llu insert %llu (n %d) neighbours %llu cells %llu barrier2 %llu head %llu\n",
-           w, __builtin_readcyclecounter() - dq_start, dq_t[0], dq_t[1], dq_t[2], dq_t[3], dq_t[4], dq_n[0], dq_t[5], dq_t[6], dq_t[7], dq_t[8]);
+    printf("DQDIAG wave %d total %llu move %llu order %llu publish+barrier %llu counts %llu insert %llu (n %d) full searches %d neighbours %llu cells %llu barrier2 %llu head %llu\n",
+           w, __builtin_readcyclecounter() - dq_start, dq_t[0], dq_t[1], dq_t[2], dq_t[3], dq_t[4], dq_n[0], dq_n[1], dq_t[5], dq_t[6], dq_t[7], dq_t[8]);
 #endif
 
   // ---- the state back to its slots ---------------------------------------------------------------------------------

@@ -570,13 +570,19 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
 #ifdef FS_QDIAG
   const unsigned long long dg_start = __builtin_readcyclecounter();
 #endif
+  // (the action row of a step is loaded one step ahead: read where it is used, it was an L2 / HBM round trip at the top of
+  // every step; the load itself is unconditional -- a select on its value would wait for it at once)
+  const int act_lane = lane < s.num_rl ? lane : 0;
+  float a_pref = 0.0f;
+  if (ACT && num_steps > 0) a_pref = actions[size_t(r) * s.num_rl + act_lane];
   for (int step = 0; step < num_steps; ++step) {
     if (ACT) {                                         // the step's action row, by RL column, in LDS
-      const float* act = actions + size_t(step) * act_stride + size_t(r) * s.num_rl;
-      act_row[lane] = lane < s.num_rl ? act[lane] : 0.0f;
+      act_row[lane] = lane < s.num_rl ? a_pref : 0.0f;
       q_fence();
       a_me = act_row[rl_col & 63];
       q_fence();
+      const int nxt = step + 1 < num_steps ? step + 1 : step;
+      a_pref = actions[size_t(nxt) * act_stride + size_t(r) * s.num_rl + act_lane];
     }
     if (ACT) mHaveRl = mKrl & __ballot(!(a_me != a_me));          // NaN: no action for this vehicle this step
     for (int sub = 0; sub < s.sims_per_step; ++sub) {

@@ -48,7 +48,7 @@ struct WideLds {
   int emitted[FS_MAX_INFLOWS];           // vehicles emitted so far by inflow f
   int generated[FS_MAX_INFLOWS];         // vehicles generated so far by a probabilistic inflow f (M2b)
   int hist[20];                          // arrivals of sub-step % 20
-  float act[2][64];                      // the RL actions of this step / the next one (loaded a step ahead)
+  float act[4][64];                      // the RL actions of this step, a copy per wave (written and read by that wave only)
 };
 
 // Workgroup barrier for data exchanged through LDS only.  __syncthreads() is a full fence: it also waits for the
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
 
   // the actions of a step are read from global memory one step early (by the threads that own a column) and handed
   // over through LDS: the barriers of the neighbour update in between make them visible, no thread waits for HBM
-  if (actions != nullptr && num_steps > 0 && tid < s.num_rl) L.act[0][tid] = actions[size_t(rr) * s.num_rl + tid];
+  if (actions != nullptr && num_steps > 0 && l < s.num_rl) L.act[w][l] = actions[size_t(rr) * s.num_rl + l];
   bool crash_now = false;
   int na_unused = 0;
   neighbours(false, false, crash_now, false, false, na_unused);
@@ -634,9 +634,12 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
                "v"(last_acc), "v"(cst), "v"(vmax));
   for (int step = 0; step < num_steps; ++step) {
     const bool have_act = actions != nullptr;
-    const int ab = step & 1;                 // (L.act[ab]: this step's actions)
-    if (actions != nullptr && step + 1 < num_steps && tid < s.num_rl)
-      L.act[(step + 1) & 1][tid] = actions[size_t(step + 1) * act_stride + size_t(rr) * s.num_rl + tid];
+    // the next step's action row: loaded here, stored to the wave's LDS copy after the sub-steps (stored at once, the
+    // row's wave sat out an L2 / HBM round trip -- and the previous step's observation stores, same counter -- at the top
+    // of every step while the others waited at the first barrier)
+    const bool act_next = actions != nullptr && step + 1 < num_steps && l < s.num_rl;
+    float a_pref = 0.0f;
+    if (act_next) a_pref = actions[size_t(step + 1) * act_stride + size_t(rr) * s.num_rl + l];
     bool crashed = false;
     for (int sub = 0; sub < s.sims_per_step; ++sub) {
       const bool live = live_replica && !crashed;
@@ -681,7 +684,7 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
       bool have_rl = false;
       T a_rl = T(0);
       if (ma_cmd && is_rl && alive) {
-        const float a = L.act[ab][(sl.rl_index < 0 ? 0 : sl.rl_index) & 63];
+        const float a = L.act[w][(sl.rl_index < 0 ? 0 : sl.rl_index) & 63];
         have_rl = !(a != a);
         a_rl = have_rl ? T(a) : T(0);
       }
@@ -701,7 +704,7 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
       if (dv_env && have_act) {
         const int my_lane = (route < 0 ? 0 : route) >> shift_of(x);
         const int acell = cell_of<1>(tb, o.act_span, x, seg_k, my_lane, alive && !internal);
-        T a = acell >= 0 ? T(L.act[ab][acell & 63]) : T(0);
+        T a = acell >= 0 ? T(L.act[w][acell & 63]) : T(0);
         if (s.clip_actions) a = tmin(tmax(a, s.act_lo), s.act_hi);
         T nxt = tmin(tmax(vmax + a, T(0.01)), T(23.0));
         nxt = acell >= 0 ? nxt : T(23.0);
@@ -904,6 +907,7 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
       crashed = crashed || (c && live);
     }
 
+    if (act_next) L.act[w][l] = a_pref;
     // ---- get_state / compute_reward / done ---------------------------------------------------------------
     const bool emit = obs_every_step || (step == num_steps - 1);
     if (emit) {

@@ -36,8 +36,9 @@ def test_wide_two_waves_and_a_full_block():
     from helpers import bottleneck_spec
     for cap_h, cap_rl in ((90, 10), (116, 12)):                        # 100 slots (two waves, 28 idle lanes) / 128
         spec = bottleneck_spec(R=2, cap_human=cap_h, cap_rl=cap_rl, horizon=400, seed=cap_h)
-        ora = run_pair(spec, "f32", 400, bottleneck_actions(spec, 1), check_every=40)
-        assert (ora.alive.sum(axis=1) > 64).any()
+        steps = 400 if cap_h == 90 else 260              # (the first case fills past one wave)
+        ora = run_pair(spec, "f32", steps, bottleneck_actions(spec, 1), check_every=40)
+        assert (ora.alive.sum(axis=1) > (64 if cap_h == 90 else 45)).any()
 
 
 def test_wide_state_fields_warmup_and_max_speed():
@@ -203,7 +204,7 @@ def test_wide_scaling_two_eight_entry_lanes():
     from helpers import bottleneck_spec
     spec = bottleneck_spec(R=1, cap_human=200, cap_rl=40, horizon=400, seed=6, q=4000.0, scaling=2)
     assert spec["num_paths"] == 8 and len(spec["obs_cells"]) == 70 and spec["num_rl"] == 40
-    ora = run_pair(spec, "f32", 230, bottleneck_actions(spec, 3), check_every=50)
+    ora = run_pair(spec, "f32", 200, bottleneck_actions(spec, 3), check_every=50)
     alive = ora.alive[0]
     assert set(ora.route[0][alive]) == set(range(8))                       # every entry lane is in use
     assert set((ora.route[0][alive & (ora.x[0] > spec["merge2_x"])] >> 2)) == {0, 1}    # two lanes leave the network
@@ -330,7 +331,7 @@ def test_wide_float64_ranks_on_float32_images_and_counts_exactly_when_they_colli
     assert (ora.alive.sum(axis=1) > 64).any()
 
 
-@pytest.mark.parametrize("seed", seeds([0], [3, 5]))
+@pytest.mark.parametrize("seed", seeds([], [0, 3, 5]))     # (float64 on this kernel: test_wide_f64_matches_reference_arithmetic)
 def test_wide_fuzz_random_lane_drop_configs_float64(seed):
     """k_steps_wide<double> (ranking on float32 images, exact count on ties) on random lane-drop configurations against the
     float64 oracle."""
