@@ -392,23 +392,32 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
     const CellRow<T> o0 = L.tabs.cpack[0][(og0) & 63], o1 = L.tabs.cpack[0][(og0 + (1 < ocnt ? 1 : 0)) & 63],
                      o2 = L.tabs.cpack[0][(og0 + (2 < ocnt ? 2 : 0)) & 63];
     const CellRow<T> a0 = L.tabs.cpack[1][(ag0) & 63], a1 = L.tabs.cpack[1][(ag0 + (1 < acnt ? 1 : 0)) & 63];
-    auto hit = [&](const CellRow<T>& row, bool valid, bool last_rule, int cur) -> int {
+    // (a group's tests each turn the candidate into -1 through VCC; the groups of an edge are its segments -- disjoint
+    // stretches (lo, hi], and the position-0 rule picks the last one only when no stretch holds the position -- so the
+    // first hit of the table walk is the only hit: a maximum.  A row index beyond the edge's groups repeats an earlier row)
+    auto hit = [&](const CellRow<T>& row, bool last_rule) -> int {
       const T pos = x - row.start;
-      int inside = int(pos > row.lo) & int(pos <= row.hi);
-      if (last_rule) inside |= int((row.meta >> 24) != 0) & int(pos == 0.0f);    // searchsorted(..) - 1 == -1: last segment
-      const int rel = my_lane - ((row.meta >> 16) & 0xff);
-      const int ok = int(eligible) & int(valid) & inside & int(rel >= 0) & int(rel < ((row.meta >> 8) & 0xff)) & int(cur < 0);
-      return ok ? (row.meta & 0xff) + rel : cur;
+      const unsigned meta = unsigned(row.meta);
+      const int rel = my_lane - int((meta >> 16) & 0xffu);
+      int c = int(meta & 0xffu) + rel;
+      c = unsigned(rel) < ((meta >> 8) & 0xffu) ? c : -1;
+      int c_in = pos > row.lo ? c : -1;
+      c_in = pos <= row.hi ? c_in : -1;
+      if (last_rule) {                                   // searchsorted(..) - 1 == -1: the last segment
+        int c_last = (meta >> 24) != 0u ? c : -1;
+        c_last = pos == 0.0f ? c_last : -1;
+        c_in = max(c_in, c_last);
+      }
+      return c_in;
     };
-    int ac = -1;
-    ac = hit(a0, 0 < acnt, false, ac);
-    ac = hit(a1, 1 < acnt, false, ac);
-    acell = ac;
+    int ac = max(hit(a0, false), hit(a1, false));
+    ac = acnt > 0 ? ac : -1;
+    acell = eligible ? ac : -1;
     int oc = -1;
     if (want_obs) {
-      oc = hit(o0, 0 < ocnt, true, oc);
-      oc = hit(o1, 1 < ocnt, true, oc);
-      oc = hit(o2, 2 < ocnt, true, oc);
+      oc = max(max(hit(o0, true), hit(o1, true)), hit(o2, true));
+      oc = ocnt > 0 ? oc : -1;
+      oc = eligible ? oc : -1;
     }
     ocell = oc;
   };
