@@ -739,10 +739,12 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
       } else if (tid == 0) {
         orow[0] = 1.0f;                                    // bottleneck.py:481-483
       }
-      const T reward = outflow(o.rew_window, out_rew) / o.out_norm;     // bottleneck.py:474-478, 971-981
-      if (tid == 128) {
-        *rrow = reward;
-        *drow = done_flag(tcount >= s.step_limit, crashed);
+      if (w == 0) {                                        // (the wave with the shortest block of the row above)
+        const T reward = outflow(o.rew_window, out_rew) / o.out_norm;     // bottleneck.py:474-478, 971-981
+        if (l == 0) {
+          *rrow = reward;
+          *drow = done_flag(tcount >= s.step_limit, crashed);
+        }
       }
       orow += step_rows * obs_dim;
       rrow += step_rows;
