@@ -42,7 +42,8 @@ struct WideLds {
   int red_i[2][4][W];
   unsigned long long cell[2][128][W];    // observation cells: [human | rl][cell][wave] = members in that wave
   static constexpr int CELL_CAP = 32;    // speeds a cell's member list holds (a lane-segment of ~100 m: <= ~20 vehicles)
-  alignas(16) T cellv[2][128][CELL_CAP]; // [human | rl][cell][k]: speed of the k-th member in slot order
+  alignas(16) T cellv[2][128][sizeof(T) == 4 ? 1 : CELL_CAP]; // float64: [human | rl][cell][k]: speed of the k-th member in slot order
+  int acc[4][128];                       // float32: per cell, vehicles (human, RL) and speed sums in 2^-16 m/s (human, RL)
   // launch constants, read with uniform / gathered addresses -- OpenTabs<T, IN_LDS> of flowsim_open.h, and why
   OpenTabsLds<T> tabs;
   int emitted[FS_MAX_INFLOWS];           // vehicles emitted so far by inflow f
@@ -166,6 +167,7 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
   L.len[tid] = sl.length;
   if (sizeof(T) == 4) { L.okey[tid] = 0ull; L.okey2[tid] = 0ull; }      // (stamp 0: never a ranking update's)
   for (int k = tid; k < 2 * 128 * W; k += NS) (&L.cell[0][0][0])[k] = 0ull;
+  for (int k = tid; k < 4 * 128; k += NS) (&L.acc[0][0])[k] = 0;
   int phase = 0;                           // scratch buffer of the next publication (block-uniform)
   double next_due = -1.0e300;              // see the inflow loop (unknown yet: the first sub-step looks)
 
@@ -531,6 +533,33 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
     const int C = o.n_obs_cells;
     FS_TICKF(6);       // tail of the update (crash word, followers) + the cell lookup
     const int cls = is_rl ? 1 : 0;
+    if constexpr (sizeof(T) == 4) {
+      // float32: the vehicles of a cell are counted and their speeds added by LDS integer atomics, the speeds in units of
+      // 2^-16 m/s -- exact, so in any order (k_drop_queue's sum; oracle/opennet.py cell_sum = 'fixed', its float32 default
+      // beyond 64 slots).  One barrier; the member lists below (two barriers, a list walk per cell) keep the reference's
+      // order of additions for float64
+      if (ocell >= 0) {
+        atomicAdd(&L.acc[cls][ocell], 1);
+        atomicAdd(&L.acc[2 + cls][ocell], int(rintf(float(v) * 65536.0f)));
+      }
+      lds_barrier();
+      const int c = l * W + w;                           // (the W waves' cells side by side)
+      if (c < C) {
+        const int cnt_h = L.acc[0][c], cnt_r = L.acc[1][c];
+        const T sp_h = T(L.acc[2][c]) * T(1.0f / 65536.0f), sp_r = T(L.acc[3][c]) * T(1.0f / 65536.0f);
+        L.acc[0][c] = 0; L.acc[1][c] = 0; L.acc[2][c] = 0; L.acc[3][c] = 0;   // (the next entries come several barriers later)
+        const T nh = div_out(T(cnt_h), 20.0), nr = div_out(T(cnt_r), 20.0);          // NUM_VEHICLE_NORM
+        const T mean_h = div_out(cnt_h > 0 ? sp_h / (nh * T(20)) : T(0), 50.0);
+        const T mean_r = div_out(cnt_r > 0 ? sp_r / (nr * T(20)) : T(0), 50.0);
+        orow[c] = float(nh);
+        orow[C + c] = float(nr);
+        orow[2 * C + c] = float(mean_h);
+        orow[3 * C + c] = float(mean_r);
+      }
+      const T of = div_out(outflow(o.obs_window, out_obs), 2000.0);
+      if (tid == 64) orow[4 * C] = float(of);
+      return;
+    }
     if (ocell >= 0) atomicOr(&L.cell[cls][ocell][w], 1ull << l);
     lds_barrier();
     // ... and writes its speed at its place in the cell's member list: the place is its ordinal among the members of its

@@ -714,7 +714,10 @@ class MergeOracle:
             # spec['cell_sum'] = 'fixed' (float32 twin of k_drop_queue, flow_amd/csrc/flowsim_dropq.h): the speeds of a
             # cell are added as integers in units of 2^-16 m/s -- exact, so in any order -- and the sum goes back to float
             # once (a float32 sum of 20 speeds is ~2e-5 m/s off the reference's float64 sum, this ~8e-6 per vehicle)
-            fixed = self.spec.get("cell_sum", "slot") == "fixed" and self.dt_ == np.dtype(np.float32)
+            # (default: 'fixed' for replicas with more than 64 vehicle slots -- k_steps_wide, flow_amd/csrc/flowsim_wide.h,
+            # adds them the same way in float32 -- and the slot-order float sum of k_steps_open otherwise)
+            fixed = (self.spec.get("cell_sum", "fixed" if N > 64 else "slot") == "fixed"
+                     and self.dt_ == np.dtype(np.float32))
             vi = np.rint(self.v.astype(np.float64) * 65536.0).astype(np.int64) if fixed else None
             for c in range(C):
                 mh = (cell == c) & ~self.is_rl[None, :]

@@ -36,7 +36,9 @@ if __name__ == "__main__":
             keep["cnt"] = self.get_state(L.FS_FIELD_COUNTERS).astype(np.float64)
             real_close(self)
         simmod.FlowSim.close = close
-        res = bench.c4_leg(torch.device("cuda", 0), R=int(sys.argv[2]) if len(sys.argv) > 2 else 128)
+        # (lane changing on -- flow/benchmarks/bottleneck1 -- keeps the leg on k_steps_wide; off, it runs on k_drop_queue)
+        res = bench.c4_leg(torch.device("cuda", 0), R=int(sys.argv[2]) if len(sys.argv) > 2 else 128,
+                           lane_change_mode=int(os.environ.get("FLOWSIM_C4_LC", "1621")))
         mean = keep["cnt"].mean(axis=0) * 64.0 / res["env_steps"]
         names = ["-", "actions + integration + arbitration + move", "inflows", "neighbours: publish + rank",
                  "neighbours: masks", "neighbours: leader (+ lane-change wishes)", "neighbours tail + controllers",
