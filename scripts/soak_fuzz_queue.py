@@ -50,12 +50,21 @@ def drop_case(seed):
                                                int(max((ora.route[r] == p).sum() for r in range(ora.R) for p in range(4))))
 
 
+def wide_case(seed):
+    """k_steps_wide (more than 64 slots; lane changing on in half of the cases): tests/test_wide_gpu.py's fuzz case at other seeds."""
+    import test_wide_gpu as tw
+    tw.test_wide_fuzz_random_lane_drop_configs_bit_exact(100 + seed)
+    return "wide seed %d" % (100 + seed)
+
+
 if __name__ == "__main__":
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     bad = []
     for seed in range(first, first + count):
-        for name, fn in (("merge", merge_case), ("drop", drop_case)):
+        cases = (("merge", merge_case), ("drop", drop_case), ("wide", wide_case))
+        which = os.environ.get("SOAK_CASES")
+        for name, fn in (c for c in cases if not which or c[0] in which.split(",")):
             try:
                 print("seed", seed, fn(seed), flush=True)
             except Exception:
