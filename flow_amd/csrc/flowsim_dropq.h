@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
   ull ar0 = 0ull, ar1 = 0ull, ar2 = 0ull, ar3 = 0ull;                                       // RL slots that arrived in the last sub-step
 
   // my vehicle's parameters (by label)
-  T u_tau = 1.0f, u_gap = 1.0f, u_acc = 1.0f, u_ts = 1.0f;
+  T u_tau = 1.0f, u_gap = 1.0f, u_acc = 1.0f, u_ts = 1.0f, y_uts = 1.0f;      // (y_uts = div_core_recip(u_ts))
   bool is_rl = false;
 #ifdef FS_QDIAG
   int dq_n[2] = {0, 0};            // sub-steps with a due inflow; full searches
@@ -197,6 +197,7 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
   auto load_params = [&]() {
     const DropRow q = L.row[lab & 255];
     u_tau = q.tau; u_gap = q.min_gap; u_acc = q.max_accel; u_ts = q.ts_sumo;
+    y_uts = div_core_recip(u_ts);
     is_rl = q.is_rl != 0;
   };
   load_params();
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
       {
         const T u_vmax = tmin(vmax, vlim);                 // M10
         const float gap = hmax(h, 1e-3f);
-        const float m = hmax(0.0f, v * u_tau + div_core(v * (v - vl), u_ts));
+        const float m = hmax(0.0f, v * u_tau + div_core_by(v * (v - vl), u_ts, y_uts));
         const float ss = u_gap + m;
         const float qq = div_core(ss, gap);
         const float q = has ? qq : 0.0f;

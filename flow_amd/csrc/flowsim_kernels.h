@@ -1387,6 +1387,21 @@ __device__ __forceinline__ float div_core(float n, float d) {
   return __builtin_fmaf(r1, y, q1);
 }
 __device__ __forceinline__ double div_core(double n, double d) { return n / d; }
+// div_core in two halves, for a divisor that stays while the dividends change (a vehicle's 2 sqrt(a b), v0, maxSpeed): the
+// refined reciprocal is a function of the divisor alone -- kept, it saves v_rcp_f32 and two FMAs per quotient; the same
+// operations in the same order, so div_core_by(n, d, div_core_recip(d)) == div_core(n, d) bit for bit
+__device__ __forceinline__ float div_core_recip(float d) {
+  const float y0 = __builtin_amdgcn_rcpf(d);
+  const float e = __builtin_fmaf(-d, y0, 1.0f);
+  return __builtin_fmaf(e, y0, y0);
+}
+__device__ __forceinline__ float div_core_by(float n, float d, float y) {
+  const float q0 = n * y;
+  const float r0 = __builtin_fmaf(-d, q0, n);
+  const float q1 = __builtin_fmaf(r0, y, q0);
+  const float r1 = __builtin_fmaf(-d, q1, n);
+  return __builtin_fmaf(r1, y, q1);
+}
 
 // ---- the IDM-set controllers of the open-network kernels with their divisions as div_core (CSET = 1, float32) ----------
 // k_steps_open / k_steps_wide evaluate, per vehicle and sub-step, the IDM law and the SUMO car-following speed once or

@@ -185,6 +185,7 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
   // ---- my vehicle's parameters (by label) and the facts of my lane: recomputed by the events only --------------
   T p_v0 = 1.0f, p_T = 0.0f, p_a = 0.0f, p_s0 = 0.0f, p_ts = 1.0f, p_sig = 0.0f;          // IDM
   T u_acc = 0.0f, u_tau = 0.0f, u_gap = 1.0f, u_ts = 1.0f, u_adt = BIGV, u_ddt = BIGV, u_vmax = 1.0f;   // SUMO's model
+  T y_pts = 1.0f, y_v0 = 1.0f, y_uts = 1.0f, y_vmax = 1.0f;     // div_core_recip of p_ts, p_v0, u_ts, u_vmax (set with them)
   T ia_lo = BIGV, ia_hi = BIGV, ib_lo = BIGV, ib_hi = BIGV;      // the internal stretches of my route
   int rl_col = 0;
   // (wave-uniform masks, bit = lane)
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
     const QueueRow q = rows[lab & 63];
     p_v0 = q.p0; p_T = q.p1; p_a = q.p2; p_s0 = q.p5; p_ts = q.ts_idm; p_sig = q.noise;
     u_acc = q.max_accel; u_tau = q.tau; u_gap = q.min_gap; u_ts = q.ts_sumo; u_adt = q.adt; u_ddt = q.ddt;
+    y_pts = div_core_recip(p_ts); y_v0 = div_core_recip(p_v0); y_uts = div_core_recip(u_ts);
     const bool k_idm = q.ctrl == FS_CTRL_IDM;
     mKidm = __ballot(k_idm);
     mKrl = __ballot(q.ctrl == FS_CTRL_RL);
@@ -224,6 +226,7 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
     if (!alive) { route = -1; lab = lane; x = 0.0f; v = 0.0f; vmax = 1.0f; }     // (values nobody reads, kept finite)
     if (reload) load_params();
     u_vmax = tmin(vmax, o.speed_limit);               // M10
+    y_vmax = div_core_recip(u_vmax);
     nD = __popcll(__ballot(isA && x >= merge_x));
     td = nD > 0 ? nD - 1 : 0;
     const bool uh = isU && lane == 63;                 // U1's head: its leader is the last vehicle of D
@@ -621,11 +624,11 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
       T acc;
       {
         const float hh = tabs(h) < 1e-3f ? 1e-3f : h;
-        const float dyn = v * p_T + div_core(v * (v - vl), p_ts);
+        const float dyn = v * p_T + div_core_by(v * (v - vl), p_ts, y_pts);
         const float m = hmax(0.0f, dyn);
         const float s_star = selm(mHas, p_s0 + m, c0);
         const float q = div_core(s_star, hh);
-        const float ratio = div_core(v, p_v0);
+        const float ratio = div_core_by(v, p_v0, y_v0);
         const float r2 = ratio * ratio;
         float a = p_a * (1.0f - r2 * r2 - q * q);
         if (NOISE) a = selm(mNoisy, a + p_sig * g_now, a);           // base_controller.py:109-110
@@ -635,13 +638,13 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
       }
       // ---- M7: apply_acceleration + SUMO integration (sumo_speed_fd, k_steps_open's FD form) ---------------------
       // (common to SUMO's speed behind the leader and towards the stop line)
-      const float u_rr = div_core(v, u_vmax);
+      const float u_rr = div_core_by(v, u_vmax, y_vmax);
       const float u_r2 = u_rr * u_rr;
       const float u_free = 1.0f - u_r2 * u_r2;
       const float v_tau = v * u_tau;
       auto sumo_speed = [&](T dvv, T h_, bool has_, unsigned long long has_m) -> T {
         const float gap = hmax(h_, 1e-3f);
-        const float m = hmax(0.0f, v_tau + div_core(dvv, u_ts));
+        const float m = hmax(0.0f, v_tau + div_core_by(dvv, u_ts, y_uts));
         const float ss = u_gap + m;
         const float qq = div_core(ss, gap);
         const float q = has_ ? qq : selm(has_m, qq, c0);
