@@ -231,6 +231,11 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
   // takes six); a mirror is sorted, so the pivots that are ahead form a prefix and their number is the advance.  The
   // searches compare positions only; vehicles AT my position (rare: ahead iff their slot is lower) are counted afterwards,
   // by the whole wave, when some lane met one
+  // the queue lengths and join prefixes of the three OTHER paths (t = 1: my partner at the first join, t = 2, 3: the other
+  // pair), as their owners published them
+  int g1T1 = 0, g2T2 = 0, g2T3 = 0, aT1 = 0, aT2 = 0, aT3 = 0;      // (wave-uniform values in VECTOR registers)
+  int pn_l = 0, pg1_l = 0, pg2_l = 0, parr_l = 0;     // lane q (mod 4): n / ng1 / ng2 / arrivals of path q
+  const int wu = __builtin_amdgcn_readfirstlane(w);
   auto ties = [&](int q, int nq, int& lo, bool tie) {
     int k = lo;
     for (int it = 0; it < 64 && __ballot(tie) != 0ull; ++it) {
@@ -277,12 +282,13 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
   // holds the boundary if it shows an entry that is ahead (or starts at the head) and one that is not (or reaches the
   // tail).  Any lane whose window does not hold it sends the wave through the full search (the count is a property of the
   // mirrors, not of how it is found: both ways give the same number).
-  auto count_near3 = [&](bool alive, int na_, int nb_, int nc_, int& ca, int& cb_, int& cc) {
+  auto count_near3 = [&](bool alive, int& ca, int& cb_, int& cc) {
     const int qa = w ^ 1, qb = w ^ 2, qc_ = w ^ 3;
     // (entries beyond a queue hold -3e38: never ahead, never equal -- no index tests; the window stays inside the array.
     // Everything below is a compare into VCC consumed by the next instruction: a predicate combined on the scalar unit
     // costs this wave, alone on its SIMD, a round trip through the SGPR file each time)
-    const int sa = min(max(min(ca, na_) - 2, 0), 60), sb = min(max(min(cb_, nb_) - 2, 0), 60), sc = min(max(min(cc, nc_) - 2, 0), 60);
+    // (a count never exceeds its queue: it was one a sub-step ago, and what left since is taken off)
+    const int sa = min(max(ca - 2, 0), 60), sb = min(max(cb_ - 2, 0), 60), sc = min(max(cc - 2, 0), 60);
     const DropXL* pa = &L.xl[qa][sa];
     const DropXL* pb = &L.xl[qb][sb];
     const DropXL* pc = &L.xl[qc_][sc];
@@ -303,31 +309,27 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
 #ifdef FS_QDIAG
       dq_n[1] += 1;
 #endif
-      count_ahead3(na_, nb_, nc_, ca, cb_, cc);
+      count_ahead3(read_lane_i(pn_l, wu ^ 1), read_lane_i(pn_l, wu ^ 2), read_lane_i(pn_l, wu ^ 3), ca, cb_, cc);
       return;
     }
     int la_ = sa + ka, lb_ = sb + kb, lc_ = sc + kc;
     int eq = (ga - ka) | (gb - kb) | (gc - kc);            // vehicles AT my position in a window
     eq = alive ? eq : 0;
     if (__ballot(eq != 0) != 0ull) {
-      ties(qa, na_, la_, ga != ka);
-      ties(qb, nb_, lb_, gb != kb);
-      ties(qc_, nc_, lc_, gc != kc);
+      ties(qa, read_lane_i(pn_l, wu ^ 1), la_, ga != ka);
+      ties(qb, read_lane_i(pn_l, wu ^ 2), lb_, gb != kb);
+      ties(qc_, read_lane_i(pn_l, wu ^ 3), lc_, gc != kc);
     }
     ca = la_; cb_ = lb_; cc = lc_;
   };
-  // the queue lengths and join prefixes of the three OTHER paths (t = 1: my partner at the first join, t = 2, 3: the other
-  // pair), as their owners published them
-  int nT1 = 0, nT2 = 0, nT3 = 0, g1T1 = 0, g2T2 = 0, g2T3 = 0;
-  int pn_l = 0, pg1_l = 0, pg2_l = 0, parr_l = 0;     // lane q (mod 4): n / ng1 / ng2 / arrivals of path q
-  const int wu = __builtin_amdgcn_readfirstlane(w);
   auto read_counts = [&]() {
     // (ONE round trip: every lane reads the four words of its path l & 3; the scalars are lane reads -- six uniform LDS
     // reads, each waited for, were a tenth of the sub-step)
     pn_l = L.n[l & 3]; pg1_l = L.ng1[l & 3]; pg2_l = L.ng2[l & 3]; parr_l = L.arr_n[l & 3];
-    nT1 = read_lane_i(pn_l, wu ^ 1); nT2 = read_lane_i(pn_l, wu ^ 2); nT3 = read_lane_i(pn_l, wu ^ 3);
-    g1T1 = read_lane_i(pg1_l, wu ^ 1);
-    g2T2 = read_lane_i(pg2_l, wu ^ 2); g2T3 = read_lane_i(pg2_l, wu ^ 3);
+    // what every sub-step's neighbour update uses of them, read to vector registers directly (uniform addresses: the same
+    // round trip) -- a lane read would take each through the scalar file and back
+    g1T1 = L.ng1[wu ^ 1]; g2T2 = L.ng2[wu ^ 2]; g2T3 = L.ng2[wu ^ 3];
+    aT1 = L.arr_n[wu ^ 1]; aT2 = L.arr_n[wu ^ 2]; aT3 = L.arr_n[wu ^ 3];
   };
   auto neighbours = [&](bool& crash) {
     const bool alive = l < n;
@@ -341,8 +343,8 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
     T bx = up ? x_up : BIGV, bv = up ? v_up : 0.0f;
     int bp = w;
     // (the counts of the last snapshot, less the vehicles that left those paths since)
-    int cnt1 = c1 - read_lane_i(parr_l, wu ^ 1), cnt2 = c2 - read_lane_i(parr_l, wu ^ 2), cnt3 = c3 - read_lane_i(parr_l, wu ^ 3);
-    count_near3(alive, nT1, nT2, nT3, cnt1, cnt2, cnt3);
+    int cnt1 = c1 - aT1, cnt2 = c2 - aT2, cnt3 = c3 - aT3;
+    count_near3(alive, cnt1, cnt2, cnt3);
     c1 = cnt1; c2 = cnt2; c3 = cnt3;
     // the partner path (t = 1): every vehicle ahead once I look across the first join (la >= 1), else its rearmost
     // vehicle beyond that join; the other pair: every vehicle ahead once I look across the second join, else its
@@ -663,7 +665,7 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
                 seq = seq_ctr;
                 origin = f * (1 << 20) + k;
                 vmax = L.row[slot & 255].sumo_max;
-                c1 = nT1; c2 = nT2; c3 = nT3;              // (all of them ahead of the entry point, as a rule)
+                c1 = read_lane_i(pn_l, wu ^ 1); c2 = read_lane_i(pn_l, wu ^ 2); c3 = read_lane_i(pn_l, wu ^ 3);   // (all of them ahead of the entry point, as a rule)
               }
               n += 1;
               load_params();
