@@ -238,6 +238,7 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
   const int wu = __builtin_amdgcn_readfirstlane(w);
   auto ties = [&](int q, int nq, int& lo, bool tie) {
     int k = lo;
+#pragma unroll 1
     for (int it = 0; it < 64 && __ballot(tie) != 0ull; ++it) {
       const DropXL ek = L.xl[q][k & 63];
       tie = tie && k < nq && ek.x == x;
