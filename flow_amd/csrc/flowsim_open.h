@@ -266,19 +266,31 @@ template <int KIND, typename T, typename TABS>
 __device__ __forceinline__ int cell_of(const TABS& tb, int span, T x, int seg_k, int my_lane, bool eligible) {
   const int range = tb.template ci_gather<2>(seg_k);
   const int g0 = (range >> (KIND * 16)) & 0xff, cnt = (range >> (KIND * 16 + 8)) & 0xff;
+  // (every test turns the candidate into -1 through VCC, and the groups of an edge are its segments -- disjoint stretches
+  // (lo, hi], the position-0 rule picking the last one only where no stretch holds the position -- so the first hit of
+  // the walk is the only hit: a maximum.  Written as `eligible & inside & ...` the eight tests were seven scalar
+  // combinations of fresh masks per group, ~14 cycles each for a wave alone on its SIMD.  A row index beyond the edge's
+  // groups repeats its first row)
   int cell = -1;
   for (int r = 0; r < span; ++r) {
     const int g = g0 + (r < cnt ? r : 0);
     const CellRow<T> row = tb.template cell_row<KIND>(g);
     const T pos = x - row.start;
-    const T lo = row.lo, hi = row.hi;
-    const int meta = row.meta;
-    bool inside = (pos > lo) & (pos <= hi);
-    if (KIND == 0) inside = inside | (((meta >> 24) != 0) & (pos == T(0)));   // searchsorted(..) - 1 == -1: last segment
-    const int rel = my_lane - ((meta >> 16) & 0xff);
-    const bool hit = eligible & (r < cnt) & inside & (rel >= 0) & (rel < ((meta >> 8) & 0xff)) & (cell < 0);
-    cell = hit ? (meta & 0xff) + rel : cell;
+    const unsigned meta = unsigned(row.meta);
+    const int rel = my_lane - int((meta >> 16) & 0xffu);
+    int c = int(meta & 0xffu) + rel;
+    c = unsigned(rel) < ((meta >> 8) & 0xffu) ? c : -1;
+    int c_in = pos > row.lo ? c : -1;
+    c_in = pos <= row.hi ? c_in : -1;
+    if (KIND == 0) {                                       // searchsorted(..) - 1 == -1: the last segment
+      int c_last = (meta >> 24) != 0u ? c : -1;
+      c_last = pos == T(0) ? c_last : -1;
+      c_in = max(c_in, c_last);
+    }
+    cell = max(cell, c_in);
   }
+  cell = cnt > 0 ? cell : -1;
+  cell = eligible ? cell : -1;
   return cell;
 }
 

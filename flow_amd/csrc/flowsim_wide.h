@@ -192,6 +192,7 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
   bool has = false, lead_same_lane = false;
   // `crash_out`: does any vehicle of the replica sit closer than crash_gap behind its leader on its own lane;
   // `arrived_now` / `na_out`: the arrivals of this sub-step are counted through the first barrier of the update
+  int lc_winner = -1;                      // the slot that changes lane with the next move (block-uniform; M11's arbitration)
   int nb_rank = -1;                        // my rank at the last update (-1: none yet / the slot was free)
   unsigned gen = 0u;                       // stamp of the ranking try (block-uniform)
   int n_new = 0;                           // vehicles inserted in this sub-step (block-uniform) ...
@@ -465,11 +466,37 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
       const ull cw = __ballot(alive && has && lead_same_lane && (h < s.crash_gap));
       if (l == 0) L.words[b1][0][w] = cw;
     }
+    // M11's arbitration (largest gain, lowest slot on a tie) rides on this barrier: the wishes were made just above; the
+    // winner changes lane with the NEXT move if that sub-step is live (it had a publication and a barrier of its own there)
+    if (lc_on) {
+      const bool want = lc_want >= 0 && alive;
+      const T gsel = want ? lc_gain : -BIGV;
+      const T gmax_w = seg_max<64>(gsel);
+      const ull wb = __ballot(want && gsel == gmax_w);
+      if (l == 0) {
+        L.red_t[b1][3][w] = gmax_w;
+        L.red_i[b1][3][w] = wb ? w * 64 + first_bit(wb) : -1;
+      }
+    }
     lds_barrier();
     ull call = 0ull;
 #pragma unroll
     for (int ww = 0; ww < W; ++ww) call |= L.words[b1][0][ww];
     crash_out = call != 0ull;
+    if (lc_on) {
+      int win = -1;
+      T gbest = -BIGV;
+#pragma unroll
+      for (int ww = 0; ww < W; ++ww) {
+        const int cw = L.red_i[b1][3][ww];
+        const T gw = L.red_t[b1][3][ww];
+        if (cw >= 0 && (win < 0 || gw > gbest)) {        // waves ascend: the first one wins a tie
+          win = cw;
+          gbest = gw;
+        }
+      }
+      lc_winner = win;
+    }
     if (!follow) return;
     // ---- O1: the sticky follower entry of THIS vehicle (vehicle/traci.py:232-250) ----------------------
     const bool no_lead = alive && !has;
@@ -757,34 +784,10 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
       T x_new = (s.integrator == FS_BALLISTIC) ? x + (v + v_new) / T(2) * dt : x + v_new * dt;
       const bool mv = live && alive;
       const bool arrived = mv && (x_new >= o.end_x);
-      // ---- M11's arbitration (largest gain, lowest slot on a tie): one publication, only with lane changing on ----
-      if (lc_on) {
-        const int bq = phase & 1;
-        phase += 1;
-        const bool want = lc_want >= 0 && alive && live;
-        const T gsel = want ? lc_gain : -BIGV;
-        const T gmax_w = seg_max<64>(gsel);
-        const ull wb = __ballot(want && gsel == gmax_w);
-        if (l == 0) {
-          L.red_t[bq][0][w] = gmax_w;
-          L.red_i[bq][0][w] = wb ? w * 64 + first_bit(wb) : -1;
-        }
-        lds_barrier();
-        int win = -1;
-        T gbest = -BIGV;
-#pragma unroll
-        for (int ww = 0; ww < W; ++ww) {
-          const int cw = L.red_i[bq][0][ww];
-          const T gw = L.red_t[bq][0][ww];
-          if (cw >= 0 && (win < 0 || gw > gbest)) {        // waves ascend: the first one wins a tie
-            win = cw;
-            gbest = gw;
-          }
-        }
-        if (slot_ok && ii == win) {
-          route = lc_want;
-          last_lc = tcount + 1;
-        }
+      // ---- M11: the winner of the last update's arbitration changes lane with this move ---------------------------
+      if (lc_on && live && slot_ok && ii == lc_winner) {
+        route = lc_want;
+        last_lc = tcount + 1;
       }
       if (mv) {
         prev_v = v;
