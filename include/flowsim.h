@@ -99,7 +99,11 @@ enum fs_env {
                                        one action column per RL slot (column = rl_index), shared reward, no crash */
   FS_ENV_BOTTLENECK_DV = 6,         /* BottleneckDesiredVelocityEnv  flow/envs/bottleneck.py:760-1085: 4 values per
                                        observed lane-segment + outflow; one action per controlled lane-segment (num_rl =
-                                       num_act_cells) shifting the maxSpeed of the RL vehicles inside it */
+                                       num_act_cells) shifting the maxSpeed of the RL vehicles inside it.  The mean
+                                       speed of a lane-segment: FS_F32 handles with more than 64 vehicle slots, and the
+                                       queue-order kernel k_drop_queue, add the speeds as integers of 2^-16 m/s (exact,
+                                       order-free; oracle/opennet.py cell_sum = 'fixed'); FS_F64 and <= 64 slots add
+                                       them as floats in slot order */
   FS_ENV_BOTTLENECK = 7,            /* BottleneckEnv            flow/envs/bottleneck.py:83-483: observation [1], outflow reward */
   FS_ENV_WAVE_ATTENUATION_PO_MA = 8,/* MultiAgentWaveAttenuationPOEnv  flow/envs/multiagent/ring/wave_attenuation.py:128-252:
                                        per RL vehicle (column = rl_index) [v / 15, (v_lead - v) / 15, headway / max_length],
