@@ -113,11 +113,12 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
   const int f_typ = o.flow_tab_i[fl], f_route = o.flow_tab_i[64 + fl];
   // the first sub-step index n (now = n * sim_step, n = sim_steps - 1) at which my inflow's next vehicle is due: the
   // schedule is float64 (M2), the sub-steps compare integers
+  const double inv_dt_d = 1.0 / o.dt_d;
   auto due_index = [&](int k) -> int {
     const double t = my_begin + double(k) * my_per;
     if (!my_flow || !(t <= my_end) || !(my_number < 0 || k < my_number)) return 0x7fffffff;
     if (!(t > 0.0)) return 0;
-    const double q = t / o.dt_d;
+    const double q = t * inv_dt_d;                 // (a first guess: the two loops below make n exact whatever it is)
     if (!(q < 2.0e9)) return 0x7fffffff;
     int n = int(q);
     while (double(n) * o.dt_d < t) n += 1;
@@ -194,11 +195,13 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
   int dq_n[2] = {0, 0};            // sub-steps with a due inflow; full searches
 #endif
   int c1 = 0, c2 = 0, c3 = 0;      // vehicles of paths w ^ 1, w ^ 2, w ^ 3 ahead of mine at the last snapshot (count_near3)
+  T row_smax = 1.0f;                 // the vType maxSpeed of my vehicle's slot (what a new vehicle starts with)
   auto load_params = [&]() {
     const DropRow q = L.row[lab & 255];
     u_tau = q.tau; u_gap = q.min_gap; u_acc = q.max_accel; u_ts = q.ts_sumo;
     y_uts = div_core_recip(u_ts);
     is_rl = q.is_rl != 0;
+    row_smax = q.sumo_max;
   };
   load_params();
   auto gather_all = [&](int src, bool take) {
@@ -658,18 +661,19 @@ __global__ __launch_bounds__(256) void k_drop_queue(DevView<float> s, OpenView<f
           const bool ok = __builtin_amdgcn_readfirstlane(int((slot >= 0) && n_own < 64 && (!has_lead || gap >= need))) != 0;
           if (ok) {
             if (w == route_f) {
-              if (l == n) {
+              const bool fresh_lane = l == n;
+              if (fresh_lane) {
                 x = x_dep;
                 v = v_dep;
                 prev_v = 0.0f;                             // previous_speeds.get(veh_id, 0)
                 lab = slot;
                 seq = seq_ctr;
                 origin = f * (1 << 20) + k;
-                vmax = L.row[slot & 255].sumo_max;
                 c1 = read_lane_i(pn_l, wu ^ 1); c2 = read_lane_i(pn_l, wu ^ 2); c3 = read_lane_i(pn_l, wu ^ 3);   // (all of them ahead of the entry point, as a rule)
               }
               n += 1;
-              load_params();
+              load_params();                               // (one LDS round trip for the parameters and the newcomer's maxSpeed)
+              vmax = fresh_lane ? row_smax : vmax;
             }
             if (route_f == 0) { ix0 = x_dep; iv0 = v_dep; ic0 += 1; }
             else if (route_f == 1) { ix1 = x_dep; iv1 = v_dep; ic1 += 1; }

@@ -131,9 +131,10 @@ __global__ __launch_bounds__(64) void k_merge_queue(DevView<float> s, OpenView<f
   // the first sub-step index n (n = sim_steps - 1 of the sub-step's `now = n * sim_step`) at which some inflow is due:
   // the schedule is float64 (M2); the hot loop compares integers
   int due_n = 0;
+  const double inv_dt_d = 1.0 / o.dt_d;
   auto due_index = [&](double t) -> int {
     if (!(t > 0.0)) return 0;
-    const double q = t / o.dt_d;
+    const double q = t * inv_dt_d;                   // (a first guess: the two loops below make n exact whatever it is)
     if (!(q < 2.0e9)) return 0x7fffffff;
     int n = int(q);
     while (double(n) * o.dt_d < t) n += 1;
