@@ -106,6 +106,8 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
   constexpr bool FD = CSET == 1 && std::is_same<T, float>::value;
   FdSlot fd = FdSlot{0.0f, 0.0f};
   if constexpr (FD) fd = make_fd(sl);
+  float y_ts_sumo = 1.0f;                 // div_core_recip of the slot's 2 sqrt(accel decel): M11's four quotients
+  if constexpr (FD) y_ts_sumo = div_core_recip(fd.ts_sumo);
   const int my_type = o.slot_type[ii];
   const bool is_rl = sl.ctrl == FS_CTRL_RL;
   constexpr bool TABS_IN_LDS = true;
@@ -392,11 +394,76 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
     auto below_w = [&](int ww) -> ull { return ww < rw ? ~0ull : (ww > rw ? 0ull : ((1ull << rb) - 1ull)); };
     const int la = shift_of(x + o.zip_d);
     const int my_path = route < 0 ? 0 : route;
-    int lead_pos = -1;
+    // The nearest candidate ahead (lowest set bit above my rank) / the nearest feeder behind (highest set bit below it) of
+    // a mask over ranks: looked for in the word of my rank and the next one (the previous one) first -- two LDS reads
+    // instead of W, half the 64-bit logic -- and over all W words only when some lane of the wave found nothing there
+    // although words beyond hold vehicles (a vehicle whose lane class has nobody within 64 .. 127 ranks: rare).  The
+    // position is a property of the masks: both walks give the same one.
+    const int last_w = n_alive > 0 ? (n_alive - 1) >> 6 : 0;              // the last word that holds a vehicle
+    const int w_up = rw + 1 < W ? rw + 1 : rw, w_dn = rw > 0 ? rw - 1 : 0;
+    bool walk_all = false;
+    auto near_above = [&](int p, int la_, bool on) -> int {
+      const int row = (p & (P - 1)) * 3 + la_;
+      const ull a0 = rb == 63 ? 0ull : (L.comb[row][rw] & (~0ull << (rb + 1)));
+      const ull a1 = rw + 1 < W ? L.comb[row][w_up] : 0ull;
+      const int pos = a0 != 0ull ? rw * 64 + first_bit(a0) : (a1 != 0ull ? w_up * 64 + first_bit(a1) : -1);
+      walk_all = walk_all || (on && pos < 0 && rw + 2 <= last_w);
+      return on ? pos : -1;
+    };
+    auto full_above = [&](int p, int la_, bool on) -> int {
+      int pos = -1;
 #pragma unroll
-    for (int ww = 0; ww < W; ++ww) {
-      const ull m = alive ? (cand_w(my_path, la, ww) & above_w(ww)) : 0ull;
-      if (lead_pos < 0 && m != 0ull) lead_pos = ww * 64 + first_bit(m);
+      for (int ww = 0; ww < W; ++ww) {
+        const ull m = on ? (cand_w(p, la_, ww) & above_w(ww)) : 0ull;
+        if (pos < 0 && m != 0ull) pos = ww * 64 + first_bit(m);
+      }
+      return pos;
+    };
+    int lead_pos = near_above(my_path, la, alive);
+    // ---- M11's places (lane changing on): the nearest vehicle ahead and the nearest feeder behind on either adjacent lane
+    const bool internal_lc = lc_on ? cur.internal(o, 0) : false;
+    const int g = shift_of(x);
+    const int lane = my_path >> g, n_lanes = P >> g;
+    const bool ok0 = lc_on && alive && my_lc_auto && !internal_lc && g < 2 && la == g && n_lanes > 1 &&
+                     (tcount - last_lc >= o.lc_cooldown);
+    auto feed_w = [&](int p2, int ww) -> ull { return g == 0 ? pathw(p2, ww) : pairw(p2, ww); };   // the lanes that feed the target lane at my position
+    auto near_below = [&](int p2, bool on) -> int {
+      const ull b0 = feed_w(p2, rw) & ((1ull << rb) - 1ull);
+      const ull b1 = rw > 0 ? feed_w(p2, w_dn) : 0ull;
+      const int pos = b0 != 0ull ? rw * 64 + last_bit(b0) : (b1 != 0ull ? w_dn * 64 + last_bit(b1) : -1);
+      walk_all = walk_all || (on && pos < 0 && rw >= 2);
+      return on ? pos : -1;
+    };
+    auto full_below = [&](int p2, bool on) -> int {
+      int pos = -1;
+#pragma unroll
+      for (int ww = 0; ww < W; ++ww) {
+        const ull mf = on ? (feed_w(p2, ww) & below_w(ww)) : 0ull;
+        if (mf != 0ull) pos = ww * 64 + last_bit(mf);      // words ascend: the last hit is the highest rank
+      }
+      return pos;
+    };
+    int lpos_d[2] = {-1, -1}, fpos_d[2] = {-1, -1}, p2_d[2] = {0, 0};
+    bool valid_d[2] = {false, false};
+    if (lc_on) {
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const int tl = lane + (d == 0 ? -1 : 1);
+        valid_d[d] = ok0 && tl >= 0 && tl < n_lanes;
+        p2_d[d] = valid_d[d] ? (tl << g) : 0;
+        lpos_d[d] = near_above(p2_d[d], la, valid_d[d]);
+        fpos_d[d] = near_below(p2_d[d], valid_d[d]);
+      }
+    }
+    if (__ballot(walk_all) != 0ull) {                      // (wave-uniform, rare) the walks over all W words
+      lead_pos = full_above(my_path, la, alive);
+      if (lc_on) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          lpos_d[d] = full_above(p2_d[d], la, valid_d[d]);
+          fpos_d[d] = full_below(p2_d[d], valid_d[d]);
+        }
+      }
     }
     has = lead_pos >= 0;
     const int lslot = L.sorted_slot[has ? lead_pos : 0];
@@ -414,28 +481,20 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
     }
     if (lc_on) {
       // ---- M11: which adjacent lane (if any) this vehicle would like to continue on after the next move ----------
-      const bool internal = cur.internal(o, 0);
-      const int g = shift_of(x);
-      const int lane = my_path >> g, n_lanes = P >> g;
-      const bool ok0 = alive && my_lc_auto && !internal && g < 2 && la == g && n_lanes > 1 &&
-                       (tcount - last_lc >= o.lc_cooldown);
-      const T two_sqrt = T(2) * tsqrt(sl.max_accel * sl.max_decel);
+      T two_sqrt;                                          // (FD: the slot's constant, its quotients as div_core -- the
+      if constexpr (FD) two_sqrt = fd.ts_sumo;             // insertion test's form of the same expression, Sim::open_div_ok)
+      else two_sqrt = T(2) * tsqrt(sl.max_accel * sl.max_decel);
+      auto by_ts = [&](T n) -> T {
+        if constexpr (FD) return div_core_by(n, two_sqrt, y_ts_sumo);
+        else return n / two_sqrt;
+      };
       T best_gain = -BIGV;
       int best_path = -1;
 #pragma unroll
-      for (int dl = -1; dl <= 1; dl += 2) {               // right first, so that left wins a tie
-        const int tl = lane + dl;
-        const bool valid_t = ok0 && tl >= 0 && tl < n_lanes;
-        const int p2 = valid_t ? (tl << g) : 0;
-        int lpos = -1, fpos = -1;
-#pragma unroll
-        for (int ww = 0; ww < W; ++ww) {
-          const ull ml = valid_t ? (cand_w(p2, la, ww) & above_w(ww)) : 0ull;
-          const ull feed = g == 0 ? pathw(p2, ww) : pairw(p2, ww);   // the lanes that feed the target lane at my position
-          const ull mf = valid_t ? (feed & below_w(ww)) : 0ull;
-          if (lpos < 0 && ml != 0ull) lpos = ww * 64 + first_bit(ml);
-          if (mf != 0ull) fpos = ww * 64 + last_bit(mf);  // words ascend: the last hit is the highest rank
-        }
+      for (int d = 0; d < 2; ++d) {                        // right first, so that left wins a tie
+        const bool valid_t = valid_d[d];
+        const int p2 = p2_d[d];
+        const int lpos = lpos_d[d], fpos = fpos_d[d];
         const bool has_l = lpos >= 0, has_f = fpos >= 0;
         const int ls = L.sorted_slot[has_l ? lpos : 0], fs_ = L.sorted_slot[has_f ? fpos : 0];
         const T xl2 = L.x[ls], vl2 = L.v[ls], ll2 = L.len[ls];
@@ -443,8 +502,8 @@ __global__ __launch_bounds__(64 * W) void k_steps_wide(DevView<T> s, OpenView<T>
         const T gap_l = has_l ? (xl2 - x) - ll2 : T(1000.0);
         const T gap_f = has_f ? (x - xf2) - sl.length : T(1000.0);
         const T v_l2 = has_l ? vl2 : T(0), v_f = has_f ? vf2 : T(0);
-        const T need_l = sl.sumo_min_gap + tmax(T(0), v * sl.sumo_tau + v * (v - v_l2) / two_sqrt);
-        const T need_f = sl.sumo_min_gap + tmax(T(0), v_f * sl.sumo_tau + v_f * (v_f - v) / two_sqrt);
+        const T need_l = sl.sumo_min_gap + tmax(T(0), v * sl.sumo_tau + by_ts(v * (v - v_l2)));
+        const T need_f = sl.sumo_min_gap + tmax(T(0), v_f * sl.sumo_tau + by_ts(v_f * (v_f - v)));
         const bool safe = (!has_l || gap_l >= need_l) && (!has_f || gap_f >= need_f);
         const T gain = gap_l - h;
         const bool take = valid_t && safe && (gain >= o.lc_min_gain) && (gain >= best_gain);
