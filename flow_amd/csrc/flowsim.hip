@@ -470,7 +470,7 @@ int fs_step(fs_handle h, const float* actions, float* obs, float* rew, uint8_t* 
   HIP_TRY(hipMemcpyAsync(rew, s->d_rew, R * sizeof(float), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipMemcpyAsync(done, s->d_done, R, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
-  return FS_OK;
+  return s->check_qflag();        // (a queue-order launch that overflowed a path: the rows just copied are not results)
 }
 
 int fs_rollout_dev(fs_handle h, int num_steps, const float* actions_dev, size_t action_stride_steps,

@@ -53,7 +53,11 @@ def drop_case(seed):
 def wide_case(seed):
     """k_steps_wide (more than 64 slots; lane changing on in half of the cases): tests/test_wide_gpu.py's fuzz case at other seeds."""
     import test_wide_gpu as tw
-    tw.test_wide_fuzz_random_lane_drop_configs_bit_exact(100 + seed)
+    os.environ["FLOWSIM_NO_QUEUE"] = "1"        # (without lane changing the case would run on k_drop_queue: drop_case's job)
+    try:
+        tw.test_wide_fuzz_random_lane_drop_configs_bit_exact(100 + seed)
+    finally:
+        del os.environ["FLOWSIM_NO_QUEUE"]
     return "wide seed %d" % (100 + seed)
 
 

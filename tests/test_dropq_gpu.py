@@ -122,3 +122,39 @@ def test_drop_queue_rollout_equals_stepping_and_the_slot_order_kernel(monkeypatc
         else:
             np.testing.assert_array_equal(fa[alive], fc[alive], err_msg="queue vs slot order, field %d" % f)
     a.close(), b.close(), c.close()
+
+
+def test_drop_queue_path_overflow_is_reported_by_the_step_itself():
+    """A path that outgrows its wave's 64 lanes (243 slots, saturated network: the soak's seed 520) invalidates the handle:
+    the step that overflowed raises (fs_step checks the kernel's flag after its own synchronisation), every step before it
+    equals the oracle, and the same configuration runs through on the slot-order kernel (FLOWSIM_NO_QUEUE=1)."""
+    rng = np.random.default_rng(7000 + 520)
+    R = int(rng.integers(1, 5)); cap_rl = int(rng.integers(2, 30)); N = int(rng.integers(65, 257))
+    spec = bottleneck_spec(R=R, cap_human=N - cap_rl, cap_rl=cap_rl, horizon=int(rng.integers(150, 420)), seed=520,
+                           q=float(rng.choice([2300, 3600, 5000])), av_frac=float(rng.choice([0.1, 0.3])),
+                           zipper_distance=float(rng.choice([0.0, 20.0, 50.0, 120.0])),
+                           warmup_steps=int(rng.choice([0, 0, 20])), lane_change_cooldown_steps=int(rng.choice([2, 8, 20])),
+                           lane_change_min_gain=float(rng.choice([3.0, 10.0])), crash_gap=float(rng.choice([0.0, 1.0])),
+                           track_followers=bool(rng.integers(0, 2)), sims_per_step=int(rng.choice([1, 1, 2])))
+    assert (R, N) == (3, 243)
+    ora = O.MergeOracle(dict(spec, cell_sum="fixed"), np.float32)
+    sim = make(spec, "f32")
+    np.testing.assert_array_equal(sim.reset(), ora.reset().astype(np.float32))
+    act = actions(spec, 520, -1.5, 1.5)
+    raised_at = -1
+    for k in range(int(spec["horizon"])):
+        a = act(k)
+        o_ref, r_ref, d_ref = ora.step(a)
+        try:
+            o_gpu, r_gpu, d_gpu = sim.step(a)
+        except NotImplementedError as e:
+            assert "k_drop_queue" in str(e) and "FLOWSIM_NO_QUEUE" in str(e)
+            raised_at = k
+            break
+        assert sim.last_kernel == "k_drop_queue"
+        np.testing.assert_array_equal(o_gpu, o_ref.astype(np.float32), err_msg="obs, step %d" % k)
+    assert raised_at > 0
+    assert max(int((ora.route[r][ora.alive[r]] == p).sum()) for r in range(R) for p in range(4)) > 64
+    with pytest.raises(NotImplementedError, match="k_drop_queue"):
+        sim.pos                                          # (sticky: the handle stays unusable)
+    sim.close()
