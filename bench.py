@@ -71,19 +71,28 @@ class Runner:
         self.t_in_episode = 0
         self.sim.reset_dev(self.obs0)
         self.events = []
+        self.launches = 0
+        # (HIP events for the per-launch times, made here: creating them inside the timed region cost a short run --
+        # the driver's --steps 20 is ONE launch -- tens of microseconds of host time per launch)
+        self._event_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
 
     def run(self, steps, record=False, after_fragment=None):
+        """`record`: bracket the whole call with ONE pair of HIP events when it holds a full fragment (their elapsed time per
+        fragment feeds `fragment_latency`).  Not one pair per launch: on this stack an event record is a packet of its own
+        with ~40 us of latency -- two per launch were 80 us of a 410 us fragment and three quarters of a 20-step run."""
         torch = self.torch
         left = steps
+        pair = None
+        if record and steps >= self.fragment:
+            pair = self._event_pool.pop()
+            pair[0].record()
+        n_full = 0
         while left > 0:
             k = min(self.fragment, left, self.horizon - self.t_in_episode)
-            if record:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
             self.sim.rollout_dev(k, self.obs, self.rew, self.done, obs_every_step=True)
+            n_full += 1 if k == self.fragment else 0
             if record:
-                e1.record()
-                self.events.append((e0, e1, k))
+                self.launches += 1
             if after_fragment is not None:
                 after_fragment(self.obs[k - 1], self.rew[k - 1], self.done[k - 1])
             self.t_in_episode += k
@@ -91,6 +100,9 @@ class Runner:
             if self.t_in_episode >= self.horizon:          # every replica is done: Env.reset
                 self.sim.reset_dev(self.obs0)
                 self.t_in_episode = 0
+        if pair is not None:
+            pair[1].record()
+            self.events.append((pair[0], pair[1], steps, n_full))
 
     def run_step_api(self, steps):
         for _ in range(steps):
@@ -897,7 +909,7 @@ def main():
                       "replicas_total": total_R,
                       "parallelism": "replica-sharded x%d, obs all-gather per fragment" % world},
            "fragment_latency": None, "gather_check": gather_check,
-           "timed_region": {"steps": args.steps, "launches": len(runner.events),
+           "timed_region": {"steps": args.steps, "launches": runner.launches,
                             "note": "value = replicas x steps / wall time of exactly --steps env steps (barrier + "
                                     "synchronize on both sides); a region shorter than one 1500-step fragment is "
                                     "dominated by launch + synchronize latency -- the kernel's own rate is in "
@@ -906,14 +918,16 @@ def main():
     # the latency floor of a fragment: a launch is a chain of `fragment` dependent steps per wave, and 4096 replicas are
     # about one wave per SIMD already -- fewer replicas per GPU (strong scaling of BASELINE's "4096 replicas, whole node")
     # leave the chain as long as it is: the same milliseconds per fragment on every GPU count
-    full = [a.elapsed_time(b) for a, b, kk in runner.events if kk == runner.fragment]
-    if full:
-        ms = float(np.mean(full))
+    if runner.events:
+        e0, e1, n_steps, n_full = runner.events[-1]
+        ms = float(e0.elapsed_time(e1)) * runner.fragment / n_steps
         out["fragment_latency"] = {
             "steps": runner.fragment, "replicas_this_gpu": R, "avg_launch_ms": ms, "us_per_step": ms * 1e3 / runner.fragment,
-            "note": "one launch = %d dependent steps per wave; %d replicas = %.2f waves per SIMD: the launch time is the "
-                    "chain's latency, not throughput -- splitting a FIXED number of replicas over more GPUs (strong "
-                    "scaling) cannot shorten it, adding replicas per GPU (weak scaling) is what scales"
+            "full_fragments": n_full,
+            "note": "HIP events around the timed region / its fragments (incl. the episode resets between them); one launch "
+                    "= %d dependent steps per wave; %d replicas = %.2f waves per SIMD: the launch time is the chain's "
+                    "latency, not throughput -- splitting a FIXED number of replicas over more GPUs (strong scaling) cannot "
+                    "shorten it, adding replicas per GPU (weak scaling) is what scales"
                     % (runner.fragment, R, R / 4.0 / 1024.0)}
 
     # ---- roofline of the dominant kernel: ALWAYS from >= 5 full 1500-step launches of this process (HIP events
